@@ -1,0 +1,139 @@
+"""First-principle definitions used to pin the oracle (NOT derived from the
+reference's code and not from oracle/): python-xxhash for XXH64, plain Python
+for 2-bit codes, reverse complements, window minima and set intersections.
+
+SURVEY.md 8(c) "Independent checks that replace a runnable oracle" (1)-(5).
+"""
+import struct
+
+import numpy as np
+import xxhash
+
+CODE = {"A": 0, "C": 1, "T": 2, "G": 3}   # (c/2)%4, reference utils.cpp:13-16
+NUC = "ACTG"
+COMP = {"A": "T", "C": "G", "G": "C", "T": "A"}
+
+
+def val(s):
+    v = 0
+    for c in s:
+        v = (v << 2) | CODE[c]
+    return v
+
+
+def to_str(v, n):
+    return "".join(NUC[(v >> (2 * (n - 1 - i))) & 3] for i in range(n))
+
+
+def rc_str(s):
+    return "".join(COMP[c] for c in reversed(s))
+
+
+def canon_val(s):
+    return min(val(s), val(rc_str(s)))
+
+
+def h64(x, seed=1312):
+    return xxhash.xxh64_intdigest(struct.pack("<Q", x), seed=seed)
+
+
+def random_dna(rng, n):
+    return "".join(np.array(list("ACGT"))[rng.integers(0, 4, size=n)])
+
+
+def mutate(rng, s, mu):
+    a = np.array(list(s))
+    hit = np.nonzero(rng.random(len(a)) < mu)[0]
+    for p in hit:
+        a[p] = "ACGT"[("ACGT".index(a[p]) + int(rng.integers(1, 4))) % 4]
+    return "".join(a)
+
+
+def fasta(records, width=70, names=None):
+    out = []
+    for i, r in enumerate(records):
+        out.append(">" + (names[i] if names else "rec%d" % i))
+        for p in range(0, len(r), width):
+            out.append(r[p:p + width])
+    return ("\n".join(out) + "\n").encode()
+
+
+def mmer_hashes(seq, m):
+    """canonical value and hash of every m-mer of seq."""
+    cv = [canon_val(seq[p:p + m]) for p in range(len(seq) - m + 1)]
+    return cv, [h64(x) for x in cv]
+
+
+def selected_kmers(seq, k, m, T):
+    """list of (j, bucket) for every k-mer whose window minimum hash <= T."""
+    if len(seq) < k:
+        return []
+    cv, hs = mmer_hashes(seq, m)
+    w = k - m + 1
+    out = []
+    for j in range(len(seq) - k + 1):
+        best = min(range(j, j + w), key=lambda p: hs[p])
+        if hs[best] <= T:
+            out.append((j, cv[best]))
+    return out
+
+
+def sketch_set(records, k, m, T):
+    """{(bucket minimizer value, canonical k-mer value)} over all records."""
+    s = set()
+    for seq in records:
+        for j, b in selected_kmers(seq, k, m, T):
+            s.add((b, canon_val(seq[j:j + k])))
+    return s
+
+
+def parse_payload(payload):
+    """Uncompressed sketch payload -> (header fields, {minimizer_str: [super-k-mer strings]}, order).
+
+    Format per SURVEY.md 8(b): header line "<2k-m> <m> <n> <rate>\\n", then per
+    bucket [m ASCII][u32 LE nbytes][blob][(prefix\\nsuffix\\n)*]["\\n\\n"].
+    Blob: byte0 = len%4, then 4 bases/byte MSB first (A=0 C=1 T=2 G=3).
+    """
+    nl = payload.index(b"\n")
+    f = payload[:nl].split(b" ")
+    skm, m = int(f[0]), int(f[1])
+    k = (skm + m) // 2
+    hdr = {"skmer": skm, "m": m, "k": k, "n": int(f[2]), "rate": f[3].decode()}
+    pos = nl + 1
+    buckets = {}
+    order = []
+    while pos < len(payload):
+        mini = payload[pos:pos + m].decode(); pos += m
+        nb = struct.unpack_from("<I", payload, pos)[0]; pos += 4
+        blob = payload[pos:pos + nb]; pos += nb
+        seqs = []
+        if nb:
+            mod = blob[0]
+            assert mod == 0, "sketch blobs always hold a multiple of 4 bases"
+            bases = "".join(NUC[(b >> sh) & 3] for b in blob[1:] for sh in (6, 4, 2, 0))
+            half = k - m
+            assert len(bases) % (2 * half) == 0
+            for i in range(0, len(bases), 2 * half):
+                seqs.append(bases[i:i + half] + mini + bases[i + half:i + 2 * half])
+        while True:
+            e1 = payload.index(b"\n", pos); l1 = payload[pos:e1]; pos = e1 + 1
+            e2 = payload.index(b"\n", pos); l2 = payload[pos:e2]; pos = e2 + 1
+            if not l1 and not l2:
+                break
+            seqs.append(l1.decode() + mini + l2.decode())
+        buckets[mini] = seqs
+        order.append(mini)
+    return hdr, buckets, order
+
+
+def payload_set(payload):
+    """{(bucket value, canonical k-mer value)} stored in a sketch payload."""
+    hdr, buckets, _ = parse_payload(payload)
+    k = hdr["k"]
+    s = set()
+    for mini, seqs in buckets.items():
+        b = val(mini)
+        for q in seqs:
+            for j in range(len(q) - k + 1):
+                s.add((b, canon_val(q[j:j + k])))
+    return s
