@@ -1,0 +1,173 @@
+/* spsp.h -- C-ABI of libspsp: the MI355X-native drop-in for SuperSampler's
+ * data-parallel hot path (sketch scan + all-vs-all sketch comparison).
+ *
+ * The reference (TimRouze/supersampler) has no FFI seam of its own: its public
+ * surface is two CLIs and three file formats.  This header is
+ * the seam a maintainer would bind instead of calling the member functions
+ * cited next to each entry point (paths relative to the reference tree).
+ *
+ * Conventions: plain pointers and sizes, no exceptions cross the boundary,
+ * 0 = ok / negative = error (text from spsp_last_error(), thread-local).
+ * Buffers returned through `**out` are owned by the library and released with
+ * spsp_free() (host) or spsp_device_free() (device).  A context is bound to
+ * one HIP device + one stream and is not shared between threads: the CLIs use
+ * one context (= one stream) per in-flight genome.
+ *
+ * Every entry point whose name does not end in _host runs on the GPU and
+ * FAILS (SPSP_ERR_NO_DEVICE) when no gfx950 device is usable -- there is no
+ * CPU fallback in this library.
+ */
+#ifndef SPSP_H
+#define SPSP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPSP_OK 0
+#define SPSP_ERR_ARG (-1)
+#define SPSP_ERR_NO_DEVICE (-2)
+#define SPSP_ERR_HIP (-3)
+#define SPSP_ERR_NOMEM (-4)
+#define SPSP_ERR_IO (-5)
+#define SPSP_ERR_FORMAT (-6)
+#define SPSP_ERR_OVERFLOW (-7)
+
+typedef struct spsp_ctx spsp_ctx;
+
+/* Scan parameters: the state `Subsampler::Subsampler` derives from the command
+ * line (SubSampler.h:63-88). k, m odd, m <= 15, m <= k <= 63. */
+typedef struct spsp_params {
+    uint32_t k;
+    uint32_t m;
+    uint64_t threshold; /* selection_threshold, from spsp_threshold_host() */
+    uint32_t abundance; /* -a, used by the sketch builder only */
+    uint32_t flags;     /* SPSP_SCAN_* */
+} spsp_params;
+
+#define SPSP_SCAN_DEFAULT 0u
+#define SPSP_SCAN_DIRECT_HASH 1u /* force XXH64 at every position (no LDS pre-filter) */
+#define SPSP_SCAN_LDS_FILTER 2u  /* force the memoised LDS pre-filter path */
+
+/* One selected super-k-mer == one call of Subsampler::handle_superkmer
+ * (SubSampler.cpp:426,448): ref.substr(start,len) of record `rec`, its
+ * minimizer (canonical 2-bit value) and whether that minimizer reads
+ * reverse-complemented in the genome. Emitted in genome order. */
+typedef struct spsp_superkmer {
+    uint32_t rec;
+    uint32_t minimizer;
+    uint64_t start; /* offset inside the record */
+    uint32_t len;
+    uint32_t rev;
+} spsp_superkmer;
+
+/* One sketch as the comparator sees it after Comparator.cpp:186-260: the
+ * DISTINCT canonical k-mers of every bucket, sorted by (minimizer, kmer_hi,
+ * kmer_lo). kmer_hi may be NULL when k <= 32. */
+typedef struct spsp_sketch_view {
+    const uint32_t* minimizer;
+    const uint64_t* kmer_lo;
+    const uint64_t* kmer_hi;
+    uint64_t n;
+} spsp_sketch_view;
+
+/* ------------------------------------------------------------ lifecycle -- */
+int spsp_create(int device, void* hip_stream /* hipStream_t or NULL = own stream */, spsp_ctx** out);
+void spsp_destroy(spsp_ctx* ctx);
+const char* spsp_last_error(void);
+const char* spsp_version(void);
+void spsp_free(void* host_ptr);
+void spsp_device_free(spsp_ctx* ctx, void* device_ptr);
+
+/* ------------------------------------------------------------- path A ---- */
+/* Subsampler::compute_threshold + ctor selection (SubSampler.cpp:622-631,
+ * SubSampler.h:79-83). Host long double, as the reference. */
+uint64_t spsp_threshold_host(uint32_t k, uint32_t m, double sampling_rate);
+
+/* Replaces the scan loop SubSampler.cpp:357-455 with regular_minimizer_pos
+ * :81-169 and unrevhash :64-67. `bases` = cleaned upper-case ASCII records
+ * back to back (what getLineFasta returns, utils.cpp:706-718); rec_off has
+ * n_rec+1 entries. Output: the handle_superkmer argument stream. */
+int spsp_scan(spsp_ctx* ctx, const spsp_params* p, const uint8_t* bases, const uint64_t* rec_off,
+              uint32_t n_rec, spsp_superkmer** out, uint64_t* n_out);
+
+/* Same with everything resident in HBM (16-byte aligned d_bases). The result
+ * stays on the device (*d_out, spsp_device_free) and the call returns once
+ * the launches are queued and the two small sizing reads have completed. */
+int spsp_scan_device(spsp_ctx* ctx, const spsp_params* p, const void* d_bases, uint64_t n_bases,
+                     const void* d_rec_off, uint32_t n_rec, void** d_out, uint64_t* n_out);
+
+/* Dense stage only (hash + threshold + hit bitmap), for the roofline
+ * measurement: returns the number of m-mers with hash <= threshold. */
+int spsp_scan_hits_device(spsp_ctx* ctx, const spsp_params* p, const void* d_bases, uint64_t n_bases,
+                          uint64_t* n_hits);
+
+/* ------------------------------------------------------------- path B ---- */
+/* Replaces Comparator::count_intersection / skip_bucket / compute_scores
+ * (Comparator.cpp:97-287): inter is n*n, entry [a*n+b] for a<b =
+ * sum over buckets |A_a,b ∩ A_b,b| (zero elsewhere); card[i] = nb_kmer_seen_infile[i]. */
+int spsp_compare(spsp_ctx* ctx, const spsp_sketch_view* sk, uint32_t n, uint32_t n_query,
+                 uint32_t* inter, uint64_t* card);
+
+/* Device-resident form over concatenated key arrays (sketch i owns entries
+ * [d_sk_off[i], d_sk_off[i+1]) ). Only rows i with i % row_stride == row_first
+ * are computed (the multi-GPU split of SURVEY.md 8e: every rank holds all
+ * sketches after the all-gather and owns a strided set of rows). d_inter is a
+ * dense n*n uint32 matrix; rows not owned are left untouched. */
+int spsp_compare_device(spsp_ctx* ctx, uint32_t k, const void* d_minimizer, const void* d_kmer_lo,
+                        const void* d_kmer_hi /* NULL if k<=32 */, const uint64_t* h_sk_off,
+                        uint32_t n, uint32_t row_first, uint32_t row_stride, void* d_inter);
+
+/* --------------------------------------------- host side of the two CLIs -- */
+/* getLineFasta + clean_dna (utils.cpp:675-718) over an already gunzipped
+ * buffer: records back to back + n_rec+1 offsets. */
+int spsp_fasta_clean_host(const char* text, uint64_t n, uint8_t** bases, uint64_t** rec_off,
+                          uint32_t* n_rec);
+
+typedef struct spsp_sketch_stats {
+    uint64_t read_kmer, selected_kmer_number, selected_superkmer_number, count_maximal_skmer;
+    uint64_t seen_kmers_at_reconstruction, seen_superkmers_at_reconstruction;
+    uint64_t seen_max_superkmers_at_reconstruction, actual_minimizer_number, nb_mmer_selected;
+} spsp_sketch_stats;
+
+/* handle_superkmer + the emission half of parse_fasta_test
+ * (SubSampler.cpp:243-302, 458-504, 512-620; strCompressor utils.cpp:48-68):
+ * super-k-mer stream -> uncompressed sketch payload. `rate` is the -s value
+ * after stof (SubSampler.cpp:699), printed into the header. */
+int spsp_sketch_build_host(const spsp_params* p, double rate, const uint8_t* bases,
+                           const uint64_t* rec_off, uint32_t n_rec, const spsp_superkmer* sk,
+                           uint64_t n_sk, uint8_t** payload, uint64_t* payload_len,
+                           spsp_sketch_stats* stats);
+
+/* Header + bucket reader of the comparator (Comparator.cpp:23-37, 78-92,
+ * 186-260; strDecompressor utils.cpp:71-111): payload -> sorted distinct
+ * (minimizer, canonical k-mer) keys. Arrays are spsp_free()d one by one. */
+int spsp_sketch_parse_host(const uint8_t* payload, uint64_t len, uint32_t* k, uint32_t* m,
+                           uint32_t** minimizer, uint64_t** kmer_lo, uint64_t** kmer_hi, uint64_t* n);
+
+/* print_jaccard / print_containment (Comparator.cpp:362-460), IEEE division.
+ * names: n NUL-terminated strings. */
+int spsp_csv_host(int jaccard, const char* const* names, uint32_t n, uint32_t n_query,
+                  const uint32_t* inter, const uint64_t* card, int precision, double min_threshold,
+                  char** text, uint64_t* len);
+
+/* zstr-compatible I/O (include/zstr.hpp:136-209 autodetect, :392-407 gzip
+ * writer): whole-file read with gzip/zlib/plain autodetection; gzip write. */
+int spsp_read_file_host(const char* path, uint8_t** data, uint64_t* len);
+int spsp_write_gz_host(const char* path, const uint8_t* data, uint64_t len, int level);
+
+/* Whole-file drivers used by the CLIs (Subsampler::parse_fasta_test
+ * SubSampler.cpp:306-510; Comparator::compare_sketches + printers
+ * Comparator.cpp:39-74, 362-460). */
+int spsp_sketch_file(spsp_ctx* ctx, const spsp_params* p, double rate, const char* fasta_path,
+                     const char* out_path, spsp_sketch_stats* stats);
+int spsp_compare_files(spsp_ctx* ctx, const char* const* paths, uint32_t n, uint32_t n_query,
+                       int precision, double min_threshold, const char* out_prefix);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPSP_H */

@@ -1,0 +1,285 @@
+"""supersampler_amd -- Python host mirror of libspsp (include/spsp.h).
+
+A thin ctypes layer over the C-ABI: every GPU entry point goes straight to the
+HIP kernels in libspsp.so; there is no Python or CPU fallback.  Loading fails
+loudly if the shared library has not been built
+(`python -c "import __graft_entry__ as g; g.build()"` or `make -C supersampler_amd/csrc`).
+
+If the process also uses PyTorch, import torch BEFORE this package: torch
+ships its own libamdhip64.so.7 and the first HIP runtime loaded is the one both
+share.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libspsp.so")
+
+SPSP_SCAN_DEFAULT = 0
+SPSP_SCAN_DIRECT_HASH = 1
+SPSP_SCAN_LDS_FILTER = 2
+
+
+class SpspError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    _fields_ = [("k", C.c_uint32), ("m", C.c_uint32), ("threshold", C.c_uint64),
+                ("abundance", C.c_uint32), ("flags", C.c_uint32)]
+
+
+class SketchView(C.Structure):
+    _fields_ = [("minimizer", C.c_void_p), ("kmer_lo", C.c_void_p), ("kmer_hi", C.c_void_p), ("n", C.c_uint64)]
+
+
+class SketchStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in
+                ("read_kmer", "selected_kmer_number", "selected_superkmer_number", "count_maximal_skmer",
+                 "seen_kmers_at_reconstruction", "seen_superkmers_at_reconstruction",
+                 "seen_max_superkmers_at_reconstruction", "actual_minimizer_number", "nb_mmer_selected")]
+
+
+SUPERKMER_DTYPE = np.dtype([("rec", "<u4"), ("minimizer", "<u4"), ("start", "<u8"), ("len", "<u4"), ("rev", "<u4")])
+
+# every symbol include/spsp.h declares (tests check the .so exports them all)
+ABI_SYMBOLS = [
+    "spsp_create", "spsp_destroy", "spsp_last_error", "spsp_version", "spsp_free", "spsp_device_free",
+    "spsp_threshold_host", "spsp_scan", "spsp_scan_device", "spsp_scan_hits_device", "spsp_compare",
+    "spsp_compare_device", "spsp_fasta_clean_host", "spsp_sketch_build_host", "spsp_sketch_parse_host",
+    "spsp_csv_host", "spsp_read_file_host", "spsp_write_gz_host", "spsp_sketch_file", "spsp_compare_files",
+]
+
+_lib = None
+
+
+def lib():
+    """Load libspsp.so (once).  Raises SpspError if it is missing -- never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SpspError("%s not found: build the HIP extension first (make -C supersampler_amd/csrc)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    u64, u32, vp, cp, dbl, i32 = C.c_uint64, C.c_uint32, C.c_void_p, C.c_char_p, C.c_double, C.c_int
+    P = C.POINTER
+    L.spsp_create.restype = i32; L.spsp_create.argtypes = [i32, vp, P(vp)]
+    L.spsp_destroy.restype = None; L.spsp_destroy.argtypes = [vp]
+    L.spsp_last_error.restype = cp; L.spsp_last_error.argtypes = []
+    L.spsp_version.restype = cp; L.spsp_version.argtypes = []
+    L.spsp_free.restype = None; L.spsp_free.argtypes = [vp]
+    L.spsp_device_free.restype = None; L.spsp_device_free.argtypes = [vp, vp]
+    L.spsp_threshold_host.restype = u64; L.spsp_threshold_host.argtypes = [u32, u32, dbl]
+    L.spsp_scan.restype = i32; L.spsp_scan.argtypes = [vp, P(Params), vp, vp, u32, P(vp), P(u64)]
+    L.spsp_scan_device.restype = i32
+    L.spsp_scan_device.argtypes = [vp, P(Params), vp, u64, vp, u32, P(vp), P(u64)]
+    L.spsp_scan_hits_device.restype = i32
+    L.spsp_scan_hits_device.argtypes = [vp, P(Params), vp, u64, P(u64)]
+    L.spsp_compare.restype = i32; L.spsp_compare.argtypes = [vp, P(SketchView), u32, u32, vp, vp]
+    L.spsp_compare_device.restype = i32
+    L.spsp_compare_device.argtypes = [vp, u32, vp, vp, vp, vp, u32, u32, u32, vp]
+    L.spsp_fasta_clean_host.restype = i32
+    L.spsp_fasta_clean_host.argtypes = [cp, u64, P(vp), P(vp), P(u32)]
+    L.spsp_sketch_build_host.restype = i32
+    L.spsp_sketch_build_host.argtypes = [P(Params), dbl, vp, vp, u32, vp, u64, P(vp), P(u64), P(SketchStats)]
+    L.spsp_sketch_parse_host.restype = i32
+    L.spsp_sketch_parse_host.argtypes = [cp, u64, P(u32), P(u32), P(vp), P(vp), P(vp), P(u64)]
+    L.spsp_csv_host.restype = i32
+    L.spsp_csv_host.argtypes = [i32, P(cp), u32, u32, vp, vp, i32, dbl, P(vp), P(u64)]
+    L.spsp_read_file_host.restype = i32; L.spsp_read_file_host.argtypes = [cp, P(vp), P(u64)]
+    L.spsp_write_gz_host.restype = i32; L.spsp_write_gz_host.argtypes = [cp, cp, u64, i32]
+    L.spsp_sketch_file.restype = i32
+    L.spsp_sketch_file.argtypes = [vp, P(Params), dbl, cp, cp, P(SketchStats)]
+    L.spsp_compare_files.restype = i32
+    L.spsp_compare_files.argtypes = [vp, P(cp), u32, u32, i32, dbl, cp]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise SpspError("libspsp error %d: %s" % (rc, lib().spsp_last_error().decode(errors="replace")))
+
+
+def _take(ptr, nbytes):
+    data = C.string_at(ptr, nbytes) if nbytes else b""
+    lib().spsp_free(ptr)
+    return data
+
+
+def threshold(k, m, s):
+    """selection threshold for -s (Subsampler::compute_threshold)."""
+    return lib().spsp_threshold_host(k, m, float(s))
+
+
+def make_params(k=31, m=11, s=1000.0, abundance=1, flags=SPSP_SCAN_DEFAULT, threshold_value=None):
+    p = Params()
+    p.k, p.m, p.abundance, p.flags = k, m, abundance, flags
+    p.threshold = threshold(k, m, s) if threshold_value is None else threshold_value
+    return p
+
+
+def clean_fasta(text):
+    """FASTA bytes (already gunzipped) -> (bases uint8[n], rec_off uint64[n_rec+1])."""
+    bases, offs, n_rec = C.c_void_p(), C.c_void_p(), C.c_uint32()
+    _check(lib().spsp_fasta_clean_host(text, len(text), C.byref(bases), C.byref(offs), C.byref(n_rec)))
+    off = np.frombuffer(_take(offs, 8 * (n_rec.value + 1)), dtype=np.uint64).copy()
+    b = np.frombuffer(_take(bases, int(off[-1])), dtype=np.uint8).copy()
+    return b, off
+
+
+def sketch_build(params, rate, bases, rec_off, superkmers):
+    """super-k-mer stream -> (uncompressed sketch payload, stats dict)."""
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    rec_off = np.ascontiguousarray(rec_off, dtype=np.uint64)
+    sk = np.ascontiguousarray(superkmers, dtype=SUPERKMER_DTYPE)
+    out, n, st = C.c_void_p(), C.c_uint64(), SketchStats()
+    _check(lib().spsp_sketch_build_host(C.byref(params), float(rate), bases.ctypes.data, rec_off.ctypes.data,
+                                        len(rec_off) - 1, sk.ctypes.data, len(sk), C.byref(out), C.byref(n),
+                                        C.byref(st)))
+    return _take(out, n.value), {f: getattr(st, f) for f, _ in SketchStats._fields_}
+
+
+class Sketch:
+    """Parsed sketch: sorted distinct (minimizer, canonical k-mer) keys."""
+
+    def __init__(self, k, m, minimizer, kmer_lo, kmer_hi):
+        self.k, self.m = k, m
+        self.minimizer, self.kmer_lo, self.kmer_hi = minimizer, kmer_lo, kmer_hi
+
+    def __len__(self):
+        return len(self.minimizer)
+
+    def key_set(self):
+        return {(int(a), (int(h) << 64) | int(l)) for a, l, h in zip(self.minimizer, self.kmer_lo, self.kmer_hi)}
+
+
+def sketch_parse(payload):
+    k, m, n = C.c_uint32(), C.c_uint32(), C.c_uint64()
+    mn, lo, hi = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    _check(lib().spsp_sketch_parse_host(payload, len(payload), C.byref(k), C.byref(m), C.byref(mn), C.byref(lo),
+                                        C.byref(hi), C.byref(n)))
+    c = n.value
+    a = np.frombuffer(_take(mn, 4 * c), dtype=np.uint32).copy()
+    b = np.frombuffer(_take(lo, 8 * c), dtype=np.uint64).copy()
+    d = np.frombuffer(_take(hi, 8 * c), dtype=np.uint64).copy()
+    return Sketch(k.value, m.value, a, b, d)
+
+
+def csv(jaccard, names, inter, card, n_query=None, precision=6, min_threshold=0.0):
+    n = len(names)
+    nq = n if n_query is None else n_query
+    inter = np.ascontiguousarray(inter, dtype=np.uint32)
+    card = np.ascontiguousarray(card, dtype=np.uint64)
+    arr = (C.c_char_p * n)(*[s.encode() for s in names])
+    out, ln = C.c_void_p(), C.c_uint64()
+    _check(lib().spsp_csv_host(1 if jaccard else 0, arr, n, nq, inter.ctypes.data, card.ctypes.data, precision,
+                               float(min_threshold), C.byref(out), C.byref(ln)))
+    return _take(out, ln.value)
+
+
+def read_file(path):
+    out, ln = C.c_void_p(), C.c_uint64()
+    _check(lib().spsp_read_file_host(path.encode(), C.byref(out), C.byref(ln)))
+    return _take(out, ln.value)
+
+
+def write_gz(path, data, level=9):
+    _check(lib().spsp_write_gz_host(path.encode(), data, len(data), level))
+
+
+class Context:
+    """One HIP device + one stream (spsp_create).  Raises SpspError without a gfx950 GPU."""
+
+    def __init__(self, device=0, stream=None):
+        self._h = C.c_void_p()
+        _check(lib().spsp_create(device, C.c_void_p(stream) if stream else None, C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().spsp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- path A
+    def scan(self, params, bases, rec_off):
+        """cleaned ASCII records -> structured array of selected super-k-mers (genome order)."""
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        rec_off = np.ascontiguousarray(rec_off, dtype=np.uint64)
+        out, n = C.c_void_p(), C.c_uint64()
+        _check(lib().spsp_scan(self._h, C.byref(params), bases.ctypes.data, rec_off.ctypes.data, len(rec_off) - 1,
+                               C.byref(out), C.byref(n)))
+        if n.value == 0:
+            return np.zeros(0, dtype=SUPERKMER_DTYPE)
+        return np.frombuffer(_take(out, n.value * SUPERKMER_DTYPE.itemsize), dtype=SUPERKMER_DTYPE).copy()
+
+    def scan_device(self, params, d_bases, n_bases, d_rec_off, n_rec):
+        """device pointers in, device pointer out: returns (d_out, n_out); free with device_free."""
+        out, n = C.c_void_p(), C.c_uint64()
+        _check(lib().spsp_scan_device(self._h, C.byref(params), d_bases, n_bases, d_rec_off, n_rec, C.byref(out),
+                                      C.byref(n)))
+        return out.value, n.value
+
+    def scan_hits_device(self, params, d_bases, n_bases):
+        n = C.c_uint64()
+        _check(lib().spsp_scan_hits_device(self._h, C.byref(params), d_bases, n_bases, C.byref(n)))
+        return n.value
+
+    def device_free(self, ptr):
+        if ptr:
+            lib().spsp_device_free(self._h, C.c_void_p(ptr))
+
+    def sketch_fasta(self, text, k=31, m=11, s=1000.0, abundance=1, flags=SPSP_SCAN_DEFAULT):
+        """FASTA bytes -> (payload, stats): clean -> GPU scan -> sketch builder."""
+        p = make_params(k, m, s, abundance, flags)
+        bases, off = clean_fasta(text)
+        sk = self.scan(p, bases, off)
+        return sketch_build(p, s, bases, off, sk)
+
+    def sketch_file(self, fasta_path, out_path, k=31, m=11, s=1000.0, abundance=1):
+        p = make_params(k, m, s, abundance)
+        st = SketchStats()
+        _check(lib().spsp_sketch_file(self._h, C.byref(p), float(s), fasta_path.encode(), out_path.encode(),
+                                      C.byref(st)))
+        return {f: getattr(st, f) for f, _ in SketchStats._fields_}
+
+    # ---- path B
+    def compare(self, sketches, n_query=None):
+        """list of Sketch -> (inter uint32[n,n] upper triangle, card uint64[n])."""
+        n = len(sketches)
+        nq = n if n_query is None else n_query
+        views = (SketchView * max(n, 1))()
+        use_hi = any(s.k > 32 for s in sketches)
+        for i, s in enumerate(sketches):
+            views[i].minimizer = s.minimizer.ctypes.data
+            views[i].kmer_lo = s.kmer_lo.ctypes.data
+            views[i].kmer_hi = s.kmer_hi.ctypes.data if use_hi else None
+            views[i].n = len(s)
+        inter = np.zeros((n, n), dtype=np.uint32)
+        card = np.zeros(n, dtype=np.uint64)
+        _check(lib().spsp_compare(self._h, views, n, nq, inter.ctypes.data, card.ctypes.data))
+        return inter, card
+
+    def compare_device(self, k, d_min, d_lo, d_hi, sk_off, n, row_first, row_stride, d_inter):
+        sk_off = np.ascontiguousarray(sk_off, dtype=np.uint64)
+        _check(lib().spsp_compare_device(self._h, k, d_min, d_lo, d_hi, sk_off.ctypes.data, n, row_first, row_stride,
+                                         d_inter))
+
+    def compare_files(self, paths, out_prefix, n_query=None, precision=6, min_threshold=0.0):
+        n = len(paths)
+        nq = n if n_query is None else n_query
+        arr = (C.c_char_p * n)(*[p.encode() for p in paths])
+        _check(lib().spsp_compare_files(self._h, arr, n, nq, precision, float(min_threshold), out_prefix.encode()))

@@ -1,0 +1,158 @@
+// spsp_abi.hip -- context lifecycle, error reporting and the host-buffer forms
+// of the GPU entry points declared in include/spsp.h.
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "spsp_internal.h"
+
+namespace spsp {
+
+static thread_local std::string g_err;
+
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+    set_error("HIP error %d (%s) at %s:%d in %s", (int)e, hipGetErrorString(e), file, line, what);
+    return (e == hipErrorOutOfMemory) ? SPSP_ERR_NOMEM : SPSP_ERR_HIP;
+}
+
+int DevBuf::reserve(size_t bytes) {
+    if (bytes <= cap && p) return SPSP_OK;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    size_t want = bytes + bytes / 4 + 256;  // headroom so batch loops settle quickly
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+        p = nullptr;
+        set_error("hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+        return SPSP_ERR_NOMEM;
+    }
+    cap = want;
+    return SPSP_OK;
+}
+void DevBuf::release() {
+    if (p) (void)hipFree(p);
+    p = nullptr; cap = 0;
+}
+
+}  // namespace spsp
+
+using namespace spsp;
+
+extern "C" {
+
+const char* spsp_last_error(void) { return g_err.c_str(); }
+const char* spsp_version(void) { return "spsp-mi355x 0.1 (gfx950)"; }
+
+int spsp_create(int device, void* hip_stream, spsp_ctx** out) {
+    if (!out) { set_error("out is NULL"); return SPSP_ERR_ARG; }
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        set_error("no HIP device available (%s); libspsp has no CPU fallback",
+                  e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+        return SPSP_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= count) { set_error("device %d out of range (0..%d)", device, count - 1); return SPSP_ERR_ARG; }
+    SPSP_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    SPSP_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; libspsp carries gfx950 code objects only", device, prop.gcnArchName);
+        return SPSP_ERR_NO_DEVICE;
+    }
+    spsp_ctx* c = new spsp_ctx();
+    c->device = device;
+    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
+    else {
+        e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); }
+        c->own_stream = true;
+    }
+    e = hipHostMalloc((void**)&c->h_scalar, 8 * sizeof(uint64_t), hipHostMallocDefault);
+    if (e != hipSuccess) { if (c->own_stream) (void)hipStreamDestroy(c->stream); delete c; return hip_fail(e, "hipHostMalloc", __FILE__, __LINE__); }
+    memset(c->h_scalar, 0, 8 * sizeof(uint64_t));
+    *out = c;
+    return SPSP_OK;
+}
+
+void spsp_destroy(spsp_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    DevBuf* bufs[] = {&c->bases, &c->rec_off, &c->bitmap, &c->tile_count, &c->tile_off, &c->hits, &c->emit_count,
+                      &c->emit_off, &c->scan_tmp, &c->filter, &c->c_min, &c->c_lo, &c->c_hi, &c->c_table,
+                      &c->c_owner, &c->c_rowid, &c->c_slot, &c->c_row, &c->c_matrix, &c->c_inter, &c->c_flags,
+                      &c->c_skoff};
+    for (DevBuf* b : bufs) b->release();
+    if (c->h_scalar) (void)hipHostFree(c->h_scalar);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+void spsp_free(void* p) { free(p); }
+void spsp_device_free(spsp_ctx* ctx, void* p) {
+    if (!p) return;
+    if (ctx) (void)hipSetDevice(ctx->device);
+    (void)hipFree(p);
+}
+
+int spsp_scan(spsp_ctx* ctx, const spsp_params* p, const uint8_t* bases, const uint64_t* rec_off, uint32_t n_rec,
+              spsp_superkmer** out, uint64_t* n_out) {
+    if (!ctx || !out || !n_out) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    *out = nullptr; *n_out = 0;
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (n_rec == 0) return SPSP_OK;
+    if (!bases || !rec_off) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    if (rec_off[0] != 0) { set_error("rec_off[0] must be 0"); return SPSP_ERR_ARG; }
+    for (uint32_t r = 0; r < n_rec; ++r)
+        if (rec_off[r + 1] < rec_off[r]) { set_error("rec_off must be non-decreasing"); return SPSP_ERR_ARG; }
+    const uint64_t n = rec_off[n_rec];
+    if (n < p->k) return SPSP_OK;
+    SPSP_HIP(hipSetDevice(ctx->device));
+    if ((rc = ctx->bases.reserve((size_t)n + 64))) return rc;
+    if ((rc = ctx->rec_off.reserve((size_t)(n_rec + 1) * 8))) return rc;
+    SPSP_HIP(hipMemcpyAsync(ctx->bases.p, bases, n, hipMemcpyHostToDevice, ctx->stream));
+    SPSP_HIP(hipMemcpyAsync(ctx->rec_off.p, rec_off, (size_t)(n_rec + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    spsp_superkmer* d_out = nullptr;
+    uint64_t cnt = 0;
+    rc = scan_device_impl(ctx, p, ctx->bases.as<uint8_t>(), n, ctx->rec_off.as<uint64_t>(), n_rec, &d_out, &cnt, false);
+    if (rc) return rc;
+    if (cnt == 0) { SPSP_HIP(hipStreamSynchronize(ctx->stream)); return SPSP_OK; }
+    spsp_superkmer* h = (spsp_superkmer*)malloc((size_t)cnt * sizeof(spsp_superkmer));
+    if (!h) { set_error("out of host memory"); return SPSP_ERR_NOMEM; }
+    hipError_t e = hipMemcpyAsync(h, d_out, (size_t)cnt * sizeof(spsp_superkmer), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { free(h); return hip_fail(e, "copy back super-k-mers", __FILE__, __LINE__); }
+    *out = h; *n_out = cnt;
+    return SPSP_OK;
+}
+
+int spsp_scan_device(spsp_ctx* ctx, const spsp_params* p, const void* d_bases, uint64_t n_bases,
+                     const void* d_rec_off, uint32_t n_rec, void** d_out, uint64_t* n_out) {
+    if (!ctx || !d_out || !n_out) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    SPSP_HIP(hipSetDevice(ctx->device));
+    spsp_superkmer* o = nullptr;
+    int rc = scan_device_impl(ctx, p, (const uint8_t*)d_bases, n_bases, (const uint64_t*)d_rec_off, n_rec, &o, n_out, true);
+    *d_out = o;
+    return rc;
+}
+
+int spsp_scan_hits_device(spsp_ctx* ctx, const spsp_params* p, const void* d_bases, uint64_t n_bases,
+                          uint64_t* n_hits) {
+    if (!ctx || !n_hits) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    SPSP_HIP(hipSetDevice(ctx->device));
+    return scan_hits_impl(ctx, p, (const uint8_t*)d_bases, n_bases, n_hits);
+}
+
+}  // extern "C"

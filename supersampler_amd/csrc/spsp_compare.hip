@@ -1,0 +1,299 @@
+// spsp_compare.hip -- path B on gfx950: all-vs-all bucketed k-mer intersection.
+//
+// The reference walks the minimizer buckets in an N-way merge and, per bucket,
+// colours every canonical k-mer with the set of files holding it
+// (Comparator.cpp:177-264), then adds 1 to score_A[i,j] for every pair of
+// files sharing a k-mer (compute_scores :269-287).  Summed over buckets that is
+//     inter[i][j] = | { (minimizer, canonical k-mer) of i } ∩ { ... of j } |
+// because a k-mer only ever meets k-mers of its own bucket.
+//
+// GPU formulation (integer only, no MFMA):
+//   1. dictionary: every distinct (minimizer, k-mer) key of the rows this rank
+//      owns gets a row id (open-addressing table of 64-bit fingerprints,
+//      claimed with one CAS; full keys are verified afterwards, so a
+//      fingerprint collision is detected and the build retried with a new
+//      seed -- results never depend on the fingerprint).
+//   2. colour matrix A[row][N bits]: bit j set iff sketch j holds the key --
+//      the reference's vector<bool>(N+1) colour sets, stored densely.
+//   3. accumulate: for an owned sketch i, inter[i][j] = sum over i's keys of
+//      bit j of the key's row.  A wave owns 64 columns (one lane per column) and
+//      adds the row word's bit for its lane: one wave instruction advances 64
+//      pair counters, so the work is sum_i n_i * N/64 wave-ops instead of the
+//      N^2 * n of pairwise merging.
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "spsp_internal.h"
+#include "spsp_device.h"
+
+namespace spsp {
+
+struct Keys {
+    const uint32_t* mn;
+    const uint64_t* lo;
+    const uint64_t* hi;  // may be null (k <= 32)
+};
+
+__device__ __forceinline__ bool key_eq(const Keys& K, uint64_t a, uint64_t b) {
+    if (K.lo[a] != K.lo[b] || K.mn[a] != K.mn[b]) return false;
+    return K.hi ? K.hi[a] == K.hi[b] : true;
+}
+__device__ __forceinline__ bool key_less(const Keys& K, uint64_t a, uint64_t b) {
+    if (K.mn[a] != K.mn[b]) return K.mn[a] < K.mn[b];
+    if (K.hi && K.hi[a] != K.hi[b]) return K.hi[a] < K.hi[b];
+    return K.lo[a] < K.lo[b];
+}
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ULL;
+    x ^= x >> 27; x *= 0x94d049bb133111ebULL;
+    x ^= x >> 31;
+    return x;
+}
+__device__ __forceinline__ uint64_t fingerprint(const Keys& K, uint64_t e, uint64_t seed) {
+    uint64_t f = mix64(K.lo[e] + seed);
+    f = mix64(f ^ ((uint64_t)K.mn[e] * 0x9E3779B97F4A7C15ULL));
+    if (K.hi) f = mix64(f + K.hi[e]);
+    return f ? f : 1;
+}
+__device__ __forceinline__ uint64_t home_slot(uint64_t fp, uint32_t log2cap) {
+    return (fp * 0x9E3779B97F4A7C15ULL) >> (64 - log2cap);
+}
+// sketch that owns entry e: last j with sk_off[j] <= e
+__device__ __forceinline__ uint32_t sketch_of(const uint64_t* __restrict__ sk_off, uint32_t n, uint64_t e) {
+    uint32_t lo = 0, hi = n;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (sk_off[mid] <= e) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// flags[0]: input not strictly sorted inside a sketch; flags[1]: fingerprint collision
+__global__ void k_insert(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n, uint64_t S, uint32_t row_first,
+                         uint32_t row_stride, uint64_t seed, uint64_t* __restrict__ table, uint32_t log2cap,
+                         uint32_t* __restrict__ owner, uint32_t* __restrict__ slot, uint32_t* __restrict__ flags) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= S) return;
+    const uint32_t j = sketch_of(sk_off, n, e);
+    if (e > sk_off[j] && !key_less(K, e - 1, e)) atomicOr(&flags[0], 1u);
+    if (j % row_stride != row_first) return;
+    const uint64_t fp = fingerprint(K, e, seed);
+    const uint64_t mask = (1ull << log2cap) - 1;
+    uint64_t pos = home_slot(fp, log2cap);
+    for (;;) {
+        const unsigned long long old = atomicCAS((unsigned long long*)&table[pos], 0ull, (unsigned long long)fp);
+        if (old == 0ull || old == fp) break;
+        pos = (pos + 1) & mask;
+    }
+    slot[e] = (uint32_t)pos;
+    atomicMin(&owner[pos], (uint32_t)e);
+}
+
+__global__ void k_assign_rows(const uint64_t* __restrict__ table, uint64_t cap, uint32_t* __restrict__ rowid,
+                              uint32_t* __restrict__ n_rows) {
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= cap) return;
+    if (table[s] != 0) rowid[s] = atomicAdd(n_rows, 1u);
+}
+
+__global__ void k_verify(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n, uint64_t S, uint32_t row_first,
+                         uint32_t row_stride, const uint32_t* __restrict__ owner, const uint32_t* __restrict__ slot,
+                         uint32_t* __restrict__ flags) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= S) return;
+    const uint32_t j = sketch_of(sk_off, n, e);
+    if (j % row_stride != row_first) return;
+    if (!key_eq(K, owner[slot[e]], e)) atomicOr(&flags[1], 1u);
+}
+
+// Colours: every entry of every sketch looks its key up; found => set bit j of
+// the key's row, and (for owned sketches) remember the row for the accumulation.
+__global__ void k_fill(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n, uint64_t S, uint32_t row_first,
+                       uint32_t row_stride, uint64_t seed, const uint64_t* __restrict__ table, uint32_t log2cap,
+                       const uint32_t* __restrict__ owner, const uint32_t* __restrict__ rowid, uint32_t W,
+                       unsigned long long* __restrict__ A, uint32_t* __restrict__ row_of_entry) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= S) return;
+    const uint32_t j = sketch_of(sk_off, n, e);
+    const uint64_t fp = fingerprint(K, e, seed);
+    const uint64_t mask = (1ull << log2cap) - 1;
+    uint64_t pos = home_slot(fp, log2cap);
+    for (;;) {
+        const uint64_t v = table[pos];
+        if (v == 0) return;  // key not held by any owned sketch: contributes to no owned row
+        if (v == fp) {
+            if (key_eq(K, owner[pos], e)) {
+                const uint32_t r = rowid[pos];
+                atomicOr(&A[(uint64_t)r * W + (j >> 6)], 1ull << (j & 63));
+                if (j % row_stride == row_first) row_of_entry[e] = r;
+            }
+            return;  // equal keys share the first slot with this fingerprint; nothing further down matches
+        }
+        pos = (pos + 1) & mask;
+    }
+}
+
+// inter[i][64*wd + lane] for one owned row i and four 64-column words per
+// workgroup.  Row ids are staged through LDS; the row word is wave-uniform.
+constexpr int kAccThreads = 256;
+__global__ __launch_bounds__(kAccThreads) void k_accumulate(const uint32_t* __restrict__ row_of_entry,
+                                                           const uint64_t* __restrict__ A, uint32_t W,
+                                                           const uint64_t* __restrict__ sk_off, uint32_t n,
+                                                           uint32_t row_first, uint32_t row_stride,
+                                                           uint32_t* __restrict__ inter) {
+    const uint32_t i = row_first + blockIdx.y * row_stride;
+    if (i >= n) return;
+    const uint32_t first_wd = (i + 1) >> 6;  // first word holding a column > i
+    if (blockIdx.x * 4 + 3 < first_wd) return;
+    __shared__ uint32_t s_rows[kAccThreads];
+    const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t wd = blockIdx.x * 4 + wave;
+    const bool active = wd < W && wd >= first_wd;
+    const uint64_t e0 = sk_off[i], e1 = sk_off[i + 1];
+    uint32_t cnt = 0;
+    for (uint64_t base = e0; base < e1; base += kAccThreads) {
+        __syncthreads();
+        if (base + t < e1) s_rows[t] = row_of_entry[base + t];
+        __syncthreads();
+        const uint32_t lim = (uint32_t)((e1 - base) < (uint64_t)kAccThreads ? (e1 - base) : (uint64_t)kAccThreads);
+        if (active) {
+            uint32_t q = 0;
+            for (; q + 8 <= lim; q += 8) {
+                uint64_t mk[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) mk[u] = A[(uint64_t)s_rows[q + u] * W + wd];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) cnt += (uint32_t)(mk[u] >> lane) & 1u;
+            }
+            for (; q < lim; ++q) cnt += (uint32_t)(A[(uint64_t)s_rows[q] * W + wd] >> lane) & 1u;
+        }
+    }
+    const uint32_t col = wd * 64 + lane;
+    if (active && col > i && col < n) inter[(uint64_t)i * n + col] = cnt;
+}
+
+int compare_device_impl(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min, const uint64_t* d_lo,
+                        const uint64_t* d_hi, const uint64_t* h_sk_off, uint32_t n, uint32_t row_first,
+                        uint32_t row_stride, uint32_t* d_inter) {
+    if (n == 0) return SPSP_OK;
+    if (n > 65535) { set_error("at most 65535 sketches (the reference's uint32 pair key, Comparator.h:26)"); return SPSP_ERR_ARG; }
+    if (row_stride == 0 || row_first >= row_stride) { set_error("bad row partition %u/%u", row_first, row_stride); return SPSP_ERR_ARG; }
+    if (k > 32 && !d_hi) { set_error("k=%u needs kmer_hi", k); return SPSP_ERR_ARG; }
+    const uint64_t S = h_sk_off[n];
+    if (S == 0) return SPSP_OK;
+    if (S > 0xfffffff0ull) { set_error("too many sketch k-mers for one call"); return SPSP_ERR_OVERFLOW; }
+    uint64_t S_own = 0;
+    uint32_t n_own = 0;
+    for (uint32_t i = row_first; i < n; i += row_stride) { S_own += h_sk_off[i + 1] - h_sk_off[i]; ++n_own; }
+    if (S_own == 0 || n_own == 0) return SPSP_OK;
+    int rc;
+    uint32_t log2cap = 10;
+    while ((1ull << log2cap) < 2 * S_own) ++log2cap;
+    const uint64_t cap = 1ull << log2cap;
+    if ((rc = ctx->c_skoff.reserve((size_t)(n + 1) * 8))) return rc;
+    if ((rc = ctx->c_table.reserve((size_t)cap * 8))) return rc;
+    if ((rc = ctx->c_owner.reserve((size_t)cap * 4))) return rc;
+    if ((rc = ctx->c_rowid.reserve((size_t)cap * 4))) return rc;
+    if ((rc = ctx->c_slot.reserve((size_t)S * 4))) return rc;
+    if ((rc = ctx->c_row.reserve((size_t)S * 4))) return rc;
+    if ((rc = ctx->c_flags.reserve(64))) return rc;
+    SPSP_HIP(hipMemcpyAsync(ctx->c_skoff.p, h_sk_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    Keys K{d_min, d_lo, (k > 32) ? d_hi : nullptr};
+    const uint64_t* sk = ctx->c_skoff.as<uint64_t>();
+    uint32_t* flags = ctx->c_flags.as<uint32_t>();  // [0] unsorted, [1] collision, [2] n_rows
+    const uint32_t eblocks = (uint32_t)((S + 255) / 256);
+    const uint32_t sblocks = (uint32_t)((cap + 255) / 256);
+    uint32_t n_rows = 0;
+    uint64_t seed = 0x5350535053505350ULL;
+    for (int attempt = 0;; ++attempt) {
+        SPSP_HIP(hipMemsetAsync(ctx->c_table.p, 0, (size_t)cap * 8, ctx->stream));
+        SPSP_HIP(hipMemsetAsync(ctx->c_owner.p, 0xff, (size_t)cap * 4, ctx->stream));
+        SPSP_HIP(hipMemsetAsync(flags, 0, 64, ctx->stream));
+        hipLaunchKernelGGL(k_insert, dim3(eblocks), dim3(256), 0, ctx->stream, K, sk, n, S, row_first, row_stride, seed,
+                           ctx->c_table.as<uint64_t>(), log2cap, ctx->c_owner.as<uint32_t>(),
+                           ctx->c_slot.as<uint32_t>(), flags);
+        SPSP_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_assign_rows, dim3(sblocks), dim3(256), 0, ctx->stream, ctx->c_table.as<uint64_t>(), cap,
+                           ctx->c_rowid.as<uint32_t>(), flags + 2);
+        SPSP_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_verify, dim3(eblocks), dim3(256), 0, ctx->stream, K, sk, n, S, row_first, row_stride,
+                           ctx->c_owner.as<uint32_t>(), ctx->c_slot.as<uint32_t>(), flags);
+        SPSP_HIP(hipGetLastError());
+        uint32_t h_flags[3];
+        SPSP_HIP(hipMemcpyAsync(h_flags, flags, sizeof h_flags, hipMemcpyDeviceToHost, ctx->stream));
+        SPSP_HIP(hipStreamSynchronize(ctx->stream));
+        if (h_flags[0]) { set_error("sketch keys must be strictly increasing by (minimizer, kmer_hi, kmer_lo)"); return SPSP_ERR_ARG; }
+        if (!h_flags[1]) { n_rows = h_flags[2]; break; }
+        if (attempt >= 4) { set_error("fingerprint collisions persisted over 5 seeds"); return SPSP_ERR_HIP; }
+        seed = seed * 6364136223846793005ULL + 1442695040888963407ULL;  // new fingerprints, try again
+    }
+    const uint32_t W = (n + 63) / 64;
+    if ((rc = ctx->c_matrix.reserve((size_t)n_rows * W * 8))) return rc;
+    SPSP_HIP(hipMemsetAsync(ctx->c_matrix.p, 0, (size_t)n_rows * W * 8, ctx->stream));
+    hipLaunchKernelGGL(k_fill, dim3(eblocks), dim3(256), 0, ctx->stream, K, sk, n, S, row_first, row_stride, seed,
+                       ctx->c_table.as<uint64_t>(), log2cap, ctx->c_owner.as<uint32_t>(), ctx->c_rowid.as<uint32_t>(),
+                       W, ctx->c_matrix.as<unsigned long long>(), ctx->c_row.as<uint32_t>());
+    SPSP_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_accumulate, dim3((W + 3) / 4, n_own), dim3(kAccThreads), 0, ctx->stream,
+                       ctx->c_row.as<uint32_t>(), ctx->c_matrix.as<uint64_t>(), W, sk, n, row_first, row_stride,
+                       d_inter);
+    SPSP_HIP(hipGetLastError());
+    return SPSP_OK;
+}
+
+}  // namespace spsp
+
+using namespace spsp;
+
+extern "C" {
+
+int spsp_compare_device(spsp_ctx* ctx, uint32_t k, const void* d_minimizer, const void* d_kmer_lo,
+                        const void* d_kmer_hi, const uint64_t* h_sk_off, uint32_t n, uint32_t row_first,
+                        uint32_t row_stride, void* d_inter) {
+    if (!ctx || !h_sk_off || !d_inter) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    SPSP_HIP(hipSetDevice(ctx->device));
+    return compare_device_impl(ctx, k, (const uint32_t*)d_minimizer, (const uint64_t*)d_kmer_lo,
+                               (const uint64_t*)d_kmer_hi, h_sk_off, n, row_first, row_stride, (uint32_t*)d_inter);
+}
+
+int spsp_compare(spsp_ctx* ctx, const spsp_sketch_view* sk, uint32_t n, uint32_t n_query, uint32_t* inter,
+                 uint64_t* card) {
+    if (!ctx || (n && (!sk || !inter || !card))) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    (void)n_query;  // rows of non-query sketches are simply never printed; counts are identical
+    if (n == 0) return SPSP_OK;
+    SPSP_HIP(hipSetDevice(ctx->device));
+    std::vector<uint64_t> off(n + 1, 0);
+    bool need_hi = false;
+    for (uint32_t i = 0; i < n; ++i) {
+        off[i + 1] = off[i] + sk[i].n;
+        card[i] = sk[i].n;
+        if (sk[i].n && (!sk[i].minimizer || !sk[i].kmer_lo)) { set_error("sketch %u has NULL key arrays", i); return SPSP_ERR_ARG; }
+        if (sk[i].kmer_hi) need_hi = true;
+    }
+    for (uint32_t i = 0; i < n; ++i)
+        if (need_hi && sk[i].n && !sk[i].kmer_hi) { set_error("kmer_hi must be given for all sketches or none"); return SPSP_ERR_ARG; }
+    memset(inter, 0, sizeof(uint32_t) * (size_t)n * n);
+    const uint64_t S = off[n];
+    if (S == 0) return SPSP_OK;
+    int rc;
+    if ((rc = ctx->c_min.reserve((size_t)S * 4))) return rc;
+    if ((rc = ctx->c_lo.reserve((size_t)S * 8))) return rc;
+    if (need_hi && (rc = ctx->c_hi.reserve((size_t)S * 8))) return rc;
+    if ((rc = ctx->c_inter.reserve((size_t)n * n * 4))) return rc;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (!sk[i].n) continue;
+        SPSP_HIP(hipMemcpyAsync(ctx->c_min.as<uint32_t>() + off[i], sk[i].minimizer, sk[i].n * 4, hipMemcpyHostToDevice, ctx->stream));
+        SPSP_HIP(hipMemcpyAsync(ctx->c_lo.as<uint64_t>() + off[i], sk[i].kmer_lo, sk[i].n * 8, hipMemcpyHostToDevice, ctx->stream));
+        if (need_hi) SPSP_HIP(hipMemcpyAsync(ctx->c_hi.as<uint64_t>() + off[i], sk[i].kmer_hi, sk[i].n * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    SPSP_HIP(hipMemsetAsync(ctx->c_inter.p, 0, (size_t)n * n * 4, ctx->stream));
+    rc = compare_device_impl(ctx, need_hi ? 63 : 31, ctx->c_min.as<uint32_t>(), ctx->c_lo.as<uint64_t>(),
+                             need_hi ? ctx->c_hi.as<uint64_t>() : nullptr, off.data(), n, 0, 1, ctx->c_inter.as<uint32_t>());
+    if (rc) return rc;
+    SPSP_HIP(hipMemcpyAsync(inter, ctx->c_inter.p, (size_t)n * n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SPSP_HIP(hipStreamSynchronize(ctx->stream));
+    return SPSP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,634 @@
+// spsp_host.cpp -- the host side of the two CLIs behind the C-ABI: FASTA
+// ingest, sketch (de)serialisation, CSV printing and zstr-compatible file I/O.
+// These are the stages SURVEY.md 8(a) keeps on the host (A4, A7-A11, A16);
+// they work on 2-bit integers throughout instead of the reference's
+// std::string substr/find chains, but produce the same bytes.
+#include <zlib.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "spsp_internal.h"
+
+typedef unsigned __int128 u128;
+
+namespace {
+
+using spsp::set_error;
+
+inline uint32_t code_of(uint8_t c) { return (c >> 1) & 3u; }  // A=0 C=1 T=2 G=3 (utils.cpp:13-16)
+const char kNuc[4] = {'A', 'C', 'T', 'G'};                     // int2nuc (utils.cpp:26-45)
+
+template <class T> T* dup_vec(const std::vector<T>& v) {
+    T* p = (T*)malloc(std::max<size_t>(1, v.size()) * sizeof(T));
+    if (p && !v.empty()) memcpy(p, v.data(), v.size() * sizeof(T));
+    return p;
+}
+
+inline uint64_t rev_groups64(uint64_t x) {  // reverse the 32 two-bit groups
+    x = __builtin_bswap64(x);
+    x = ((x & 0x0f0f0f0f0f0f0f0fULL) << 4) | ((x >> 4) & 0x0f0f0f0f0f0f0f0fULL);
+    x = ((x & 0x3333333333333333ULL) << 2) | ((x >> 2) & 0x3333333333333333ULL);
+    return x;
+}
+inline u128 revcomp_kmer(u128 v, uint32_t k) {  // rcb, utils.cpp:397-438
+    const uint64_t lo = (uint64_t)v, hi = (uint64_t)(v >> 64);
+    const u128 r = ((u128)(rev_groups64(lo) ^ 0xaaaaaaaaaaaaaaaaULL) << 64) | (rev_groups64(hi) ^ 0xaaaaaaaaaaaaaaaaULL);
+    return r >> (128 - 2 * k);
+}
+
+// ---------------------------------------------------------------- sketching --
+struct Entry {
+    u128 kmer;
+    uint32_t minimizer;
+    uint8_t count;    // wraps at 256 like the reference's uint8_t (SubSampler.h:24)
+    uint8_t pos_min;
+    uint8_t seen;
+};
+
+// (minimizer, k-mer) -> entry index; linear probing, grows by doubling.
+struct KmerIndex {
+    std::vector<uint32_t> slot;  // entry index + 1, 0 = empty
+    uint64_t mask = 0;
+    size_t used = 0;
+    static uint64_t hash(uint32_t mn, u128 km) {
+        uint64_t x = (uint64_t)km * 0x9E3779B97F4A7C15ULL ^ ((uint64_t)(km >> 64) + mn) * 0xC2B2AE3D27D4EB4FULL;
+        x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ULL; x ^= x >> 32;
+        return x;
+    }
+    void init(size_t cap_pow2) { slot.assign(cap_pow2, 0); mask = cap_pow2 - 1; used = 0; }
+    void grow(const std::vector<Entry>& es) {
+        std::vector<uint32_t> old;
+        old.swap(slot);
+        init(old.size() * 2);
+        for (uint32_t v : old)
+            if (v) place(es, v - 1);
+    }
+    void place(const std::vector<Entry>& es, uint32_t idx) {
+        uint64_t p = hash(es[idx].minimizer, es[idx].kmer) & mask;
+        while (slot[p]) p = (p + 1) & mask;
+        slot[p] = idx + 1; ++used;
+    }
+    int64_t find(const std::vector<Entry>& es, uint32_t mn, u128 km) const {
+        uint64_t p = hash(mn, km) & mask;
+        while (slot[p]) {
+            const Entry& e = es[slot[p] - 1];
+            if (e.kmer == km && e.minimizer == mn) return slot[p] - 1;
+            p = (p + 1) & mask;
+        }
+        return -1;
+    }
+};
+
+struct Builder {
+    uint32_t k, m, abundance;
+    u128 kmask;
+    uint32_t mmask;
+    std::vector<Entry> entries;
+    KmerIndex index;
+    std::vector<std::pair<uint32_t, uint32_t>> order;  // (minimizer, entry index) in insertion order
+    spsp_sketch_stats st;
+
+    // Subsampler::handle_superkmer (SubSampler.cpp:243-302) on 2-bit codes.
+    void add_superkmer(const uint8_t* s, uint32_t len, uint32_t minimizer, bool rev) {
+        st.selected_superkmer_number++;
+        st.selected_kmer_number += len - k + 1;
+        if (len == 2 * k - m) st.count_maximal_skmer++;
+        static thread_local std::vector<uint8_t> o;
+        o.resize(len);
+        if (rev) for (uint32_t t = 0; t < len; ++t) o[t] = (uint8_t)(code_of(s[len - 1 - t]) ^ 2u);
+        else for (uint32_t t = 0; t < len; ++t) o[t] = (uint8_t)code_of(s[t]);
+        // start positions (oriented) where the m-mer equals the minimizer, ascending
+        static thread_local std::vector<uint32_t> occ;
+        occ.clear();
+        uint32_t mv = 0;
+        for (uint32_t t = 0; t < len; ++t) {
+            mv = ((mv << 2) | o[t]) & mmask;
+            if (t + 1 >= m && mv == minimizer) occ.push_back(t + 1 - m);
+        }
+        size_t oc = 0;
+        u128 kv = 0;
+        for (uint32_t t = 0; t < len; ++t) {
+            kv = ((kv << 2) | o[t]) & kmask;
+            if (t + 1 < k) continue;
+            const uint32_t i = t + 1 - k;  // k-mer start
+            while (oc < occ.size() && occ[oc] < i) ++oc;
+            // kmerstr.find(minimizer) : first occurrence inside the k-mer, else npos -> (uint8_t)
+            const uint8_t pos_min = (oc < occ.size() && occ[oc] + m <= i + k) ? (uint8_t)(occ[oc] - i) : (uint8_t)0xff;
+            const int64_t at = index.find(entries, minimizer, kv);
+            if (at >= 0) { entries[at].count++; continue; }
+            Entry e; e.kmer = kv; e.minimizer = minimizer; e.count = 1; e.pos_min = pos_min; e.seen = 0;
+            entries.push_back(e);
+            order.emplace_back(minimizer, (uint32_t)entries.size() - 1);
+            if ((index.used + 1) * 2 > index.slot.size()) index.grow(entries);
+            index.place(entries, (uint32_t)entries.size() - 1);
+        }
+    }
+
+    bool usable(const Entry& e) const { return !e.seen && e.count >= abundance; }
+
+    // Subsampler::find_next (SubSampler.cpp:566-602): neighbours tried in A,T,C,G order.
+    int64_t step(uint32_t mn, u128 from, bool left) {
+        static const uint32_t kTry[4] = {0, 2, 1, 3};
+        for (uint32_t c : kTry) {
+            const u128 nx = left ? ((from >> 2) | ((u128)c << (2 * k - 2))) : (((from << 2) | c) & kmask);
+            const int64_t at = index.find(entries, mn, nx);
+            if (at >= 0 && usable(entries[at])) { entries[at].seen = 1; return at; }
+        }
+        return -1;
+    }
+
+    // emission half of parse_fasta_test (SubSampler.cpp:458-504)
+    void emit(double rate, std::string& out) {
+        char hdr[128];
+        const int hl = snprintf(hdr, sizeof hdr, "%llu %llu %llu %f\n", (unsigned long long)(k - 1 + (k - m + 1)),
+                                (unsigned long long)m, (unsigned long long)st.selected_kmer_number, rate);
+        out.append(hdr, hl);
+        // std::map<uint32_t,...> order over buckets, insertion order inside one (ankerl dense map)
+        std::stable_sort(order.begin(), order.end(),
+                         [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) { return a.first < b.first; });
+        const uint32_t full = 2 * k - m, half = k - m;
+        std::vector<uint8_t> buf(3 * k + 8), maxcodes;
+        std::string text;
+        size_t b0 = 0;
+        while (b0 < order.size()) {
+            size_t b1 = b0;
+            const uint32_t mn = order[b0].first;
+            while (b1 < order.size() && order[b1].first == mn) ++b1;
+            st.actual_minimizer_number++;
+            st.seen_kmers_at_reconstruction += b1 - b0;
+            for (uint32_t j = 0; j < m; ++j) out.push_back(kNuc[(mn >> (2 * (m - 1 - j))) & 3]);
+            maxcodes.clear(); text.clear();
+            size_t cursor = b0;  // find_first_kmer: `seen` only ever turns on, so a cursor visits the same k-mers
+            for (;;) {
+                while (cursor < b1 && !usable(entries[order[cursor].second])) ++cursor;
+                if (cursor >= b1) break;
+                Entry& start = entries[order[cursor].second];
+                start.seen = 1;
+                // reconstruct_superkmer (SubSampler.cpp:512-564)
+                uint64_t n_left = (uint64_t)half - start.pos_min, n_right = start.pos_min;
+                uint32_t L = k + 4, R = L + k;  // [L,R) holds the growing super-k-mer, room for half on each side
+                for (uint32_t j = 0; j < k; ++j) buf[L + j] = (uint8_t)((start.kmer >> (2 * (k - 1 - j))) & 3);
+                u128 cur = start.kmer;
+                while (R - L != full) {
+                    if (n_left != 0) {
+                        const int64_t at = step(mn, cur, true);
+                        n_left -= 1;
+                        if (at >= 0) { buf[--L] = (uint8_t)((entries[at].kmer >> (2 * (k - 1))) & 3); }
+                        else n_left = 0;
+                        if (n_left == 0) cur = start.kmer; else if (at >= 0) cur = entries[at].kmer;
+                    } else if (n_right != 0) {
+                        const int64_t at = step(mn, cur, false);
+                        n_right -= 1;
+                        if (at < 0) break;
+                        buf[R++] = (uint8_t)(entries[at].kmer & 3);
+                        cur = entries[at].kmer;
+                    } else break;
+                }
+                const uint32_t slen = R - L;
+                if (slen == full) {
+                    st.seen_max_superkmers_at_reconstruction++;
+                    maxcodes.insert(maxcodes.end(), buf.begin() + L, buf.begin() + L + half);
+                    maxcodes.insert(maxcodes.end(), buf.begin() + L + k, buf.begin() + L + k + half);
+                } else {
+                    // skmer_str.find(minstr): first m-mer equal to the minimizer
+                    uint32_t mv = 0, p = slen;
+                    for (uint32_t t = 0; t < slen; ++t) {
+                        mv = ((mv << 2) | buf[L + t]) & mmask;
+                        if (t + 1 >= m && mv == mn) { p = t + 1 - m; break; }
+                    }
+                    for (uint32_t t = 0; t < p && t < slen; ++t) text.push_back(kNuc[buf[L + t]]);
+                    text.push_back('\n');
+                    for (uint32_t t = p + m; t < slen; ++t) text.push_back(kNuc[buf[L + t]]);
+                    text.push_back('\n');
+                }
+                st.seen_superkmers_at_reconstruction++;
+            }
+            // strCompressor (utils.cpp:48-68), accumulator starting at 0
+            std::string blob;
+            if (!maxcodes.empty()) {
+                const uint8_t mod = (uint8_t)(maxcodes.size() % 4);
+                blob.push_back((char)mod);
+                uint8_t c = 0;
+                for (size_t i = 0; i < maxcodes.size(); ++i) {
+                    c = (uint8_t)(c + maxcodes[i]);
+                    if ((i + 1) % 4 == 0) { blob.push_back((char)c); c = 0; }
+                    c = (uint8_t)(c << 2);
+                }
+                if (mod != 0) blob.push_back((char)c);
+            }
+            const uint32_t sz = (uint32_t)blob.size();
+            out.append((const char*)&sz, 4);
+            out += blob;
+            out += text;
+            out += "\n\n";
+            b0 = b1;
+        }
+    }
+};
+
+// ------------------------------------------------------------- gzip reading --
+int inflate_all(const uint8_t* in, size_t n, std::vector<uint8_t>& out) {
+    // zstr autodetect (include/zstr.hpp:154-167): gzip or zlib header, else plain
+    const bool packed = n >= 2 && ((in[0] == 0x1F && in[1] == 0x8B) ||
+                                   (in[0] == 0x78 && (in[1] == 0x01 || in[1] == 0x9C || in[1] == 0xDA)));
+    if (!packed) { out.assign(in, in + n); return SPSP_OK; }
+    out.clear();
+    out.reserve(n * 4);
+    std::vector<uint8_t> chunk(1 << 20);
+    size_t at = 0;
+    while (at < n) {  // concatenated members: a fresh inflator per member, as zstr does (:198-203)
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (inflateInit2(&zs, 15 + 32) != Z_OK) { set_error("inflateInit2 failed"); return SPSP_ERR_IO; }
+        int ret = Z_OK;
+        bool truncated = false;
+        while (ret != Z_STREAM_END) {
+            if (zs.avail_in == 0) {
+                if (at >= n) { truncated = true; break; }
+                const size_t take = std::min<size_t>(n - at, (size_t)1 << 30);
+                zs.next_in = const_cast<Bytef*>(in + at);
+                zs.avail_in = (uInt)take;
+                at += take;
+            }
+            zs.next_out = chunk.data();
+            zs.avail_out = (uInt)chunk.size();
+            ret = inflate(&zs, Z_NO_FLUSH);
+            if (ret != Z_OK && ret != Z_STREAM_END && ret != Z_BUF_ERROR) {
+                inflateEnd(&zs);
+                set_error("inflate failed (%d)", ret);
+                return SPSP_ERR_IO;
+            }
+            out.insert(out.end(), chunk.data(), chunk.data() + (chunk.size() - zs.avail_out));
+        }
+        at -= zs.avail_in;  // bytes not consumed belong to the next member
+        inflateEnd(&zs);
+        if (truncated) break;
+    }
+    return SPSP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Subsampler::compute_threshold (SubSampler.cpp:622-631) + SubSampler.h:79-83
+uint64_t spsp_threshold_host(uint32_t k, uint32_t m, double sampling_rate) {
+    if (!(sampling_rate > 1)) return ~0ULL;
+    const uint64_t w = (uint64_t)k - m + 1;
+    const long double frac = (long double)1 / sampling_rate;
+    const long double root = powl((long double)1 - frac, (long double)1 / w);
+    const long double scaled = ((long double)1 - root) * ((uint64_t)1 << 63);
+    return (uint64_t)scaled * 2;
+}
+
+int spsp_fasta_clean_host(const char* text, uint64_t n, uint8_t** bases, uint64_t** rec_off, uint32_t* n_rec) {
+    if (!bases || !rec_off || !n_rec || (n && !text)) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    // keep[c] = upper-cased base for acgtACGT, 0 for everything else (clean_dna, utils.cpp:675-702)
+    struct Keep {
+        uint8_t t[256];
+        Keep() {
+            memset(t, 0, sizeof t);
+            for (const char* q = "ACGT"; *q; ++q) { t[(uint8_t)*q] = (uint8_t)*q; t[(uint8_t)(*q + 32)] = (uint8_t)*q; }
+        }
+    };
+    static const Keep keep_tab;
+    const uint8_t* keep = keep_tab.t;
+    std::vector<uint64_t> off;
+    uint8_t* out = (uint8_t*)malloc((size_t)n + 64);
+    if (!out) { set_error("out of host memory"); return SPSP_ERR_NOMEM; }
+    uint64_t w = 0, pos = 0;
+    bool at_end = false;
+    // SubSampler.cpp:334-348 + getLineFasta utils.cpp:706-718: every turn drops
+    // one line, then swallows lines up to the next one starting with '>'.
+    while (!at_end) {
+        off.push_back(w);
+        const char* nl = pos < n ? (const char*)memchr(text + pos, '\n', n - pos) : nullptr;
+        if (!nl) { pos = n; at_end = true; } else pos = (uint64_t)(nl - text) + 1;
+        while (!at_end) {
+            if (pos >= n) { at_end = true; break; }
+            const uint8_t c0 = (uint8_t)text[pos];
+            if (c0 == '>' || c0 == 0xFF) break;  // (char)peek() == EOF aliasing for 0xFF
+            const char* e = (const char*)memchr(text + pos, '\n', n - pos);
+            const uint64_t stop = e ? (uint64_t)(e - text) : n;
+            for (uint64_t i = pos; i < stop; ++i) {
+                const uint8_t b = keep[(uint8_t)text[i]];
+                out[w] = b;
+                w += (b != 0);
+            }
+            if (!e) { pos = n; at_end = true; } else pos = stop + 1;
+        }
+    }
+    off.push_back(w);
+    *bases = out;
+    *rec_off = dup_vec(off);
+    *n_rec = (uint32_t)(off.size() - 1);
+    if (!*rec_off) { free(out); set_error("out of host memory"); return SPSP_ERR_NOMEM; }
+    return SPSP_OK;
+}
+
+int spsp_sketch_build_host(const spsp_params* p, double rate, const uint8_t* bases, const uint64_t* rec_off,
+                           uint32_t n_rec, const spsp_superkmer* sk, uint64_t n_sk, uint8_t** payload,
+                           uint64_t* payload_len, spsp_sketch_stats* stats) {
+    int rc = spsp::check_params(p);
+    if (rc) return rc;
+    if (!payload || !payload_len || (n_sk && (!sk || !bases || !rec_off))) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    Builder b;
+    b.k = p->k; b.m = p->m; b.abundance = p->abundance;
+    b.kmask = (((u128)1) << (2 * p->k)) - 1;
+    b.mmask = (1u << (2 * p->m)) - 1;
+    memset(&b.st, 0, sizeof b.st);
+    b.index.init(1024);
+    uint64_t nb = 0, pos_end = 0;
+    uint32_t cur_rec = 0xffffffffu;
+    for (uint32_t r = 0; r < n_rec; ++r) {
+        const uint64_t len = rec_off[r + 1] - rec_off[r];
+        if (len >= p->k) b.st.read_kmer += len - p->k + 1;
+    }
+    for (uint64_t i = 0; i < n_sk; ++i) {
+        const spsp_superkmer& e = sk[i];
+        if (e.rec >= n_rec || e.len < p->k || e.start + e.len > rec_off[e.rec + 1] - rec_off[e.rec]) {
+            set_error("super-k-mer %llu is outside its record", (unsigned long long)i);
+            return SPSP_ERR_ARG;
+        }
+        // nb_mmer_selected bookkeeping (SubSampler.cpp:410-424, 445): a pure function of the stream
+        if (e.rec != cur_rec) { cur_rec = e.rec; pos_end = 0; }
+        const uint64_t rlen = rec_off[e.rec + 1] - rec_off[e.rec];
+        if (e.start + e.len == rlen) nb -= p->m - 1;  // the tail call :441-450
+        else {
+            if (e.start + p->m - 2 > pos_end) {
+                if (pos_end > 0) nb -= p->m - 1;
+                nb += e.len;
+                nb -= p->k - p->m;
+            } else nb += e.start + e.len - (pos_end + 1);
+            pos_end = e.start + e.len - 1;
+        }
+        b.add_superkmer(bases + rec_off[e.rec] + e.start, e.len, e.minimizer, e.rev != 0);
+    }
+    nb -= p->m - 1;  // SubSampler.cpp:458
+    b.st.nb_mmer_selected = nb;
+    std::string out;
+    b.emit(rate, out);
+    *payload = (uint8_t*)malloc(out.size() + 1);
+    if (!*payload) { set_error("out of host memory"); return SPSP_ERR_NOMEM; }
+    memcpy(*payload, out.data(), out.size());
+    *payload_len = out.size();
+    if (stats) *stats = b.st;
+    return SPSP_OK;
+}
+
+int spsp_sketch_parse_host(const uint8_t* payload, uint64_t len, uint32_t* k_out, uint32_t* m_out,
+                           uint32_t** minimizer, uint64_t** kmer_lo, uint64_t** kmer_hi, uint64_t* n_out) {
+    if (!payload || !k_out || !m_out || !minimizer || !kmer_lo || !kmer_hi || !n_out) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    // header "<2k-m> <m> <n> <rate>\n" (Comparator.cpp:23-37)
+    const uint8_t* nl = (const uint8_t*)memchr(payload, '\n', len);
+    if (!nl) { set_error("sketch has no header line"); return SPSP_ERR_FORMAT; }
+    char* endp = nullptr;
+    const std::string header((const char*)payload, nl - payload);
+    const long skm = strtol(header.c_str(), &endp, 10);
+    const long mm = strtol(endp, &endp, 10);
+    if (skm <= 0 || mm <= 0 || mm > 15 || (skm + mm) / 2 > 63 || (skm + mm) / 2 < mm) { set_error("bad sketch header '%s'", header.c_str()); return SPSP_ERR_FORMAT; }
+    const uint32_t m = (uint32_t)mm, k = (uint32_t)((skm + mm) / 2), half = (uint32_t)((skm - mm) / 2);
+    const u128 kmask = (((u128)1) << (2 * k)) - 1;
+    struct Key { uint32_t mn; uint64_t hi, lo; };
+    std::vector<Key> keys;
+    std::vector<uint8_t> seq;
+    auto push_kmers = [&](const std::vector<uint8_t>& s, size_t from, size_t count_limit, uint32_t mn) {
+        // canonical k-mers of s[from..], at most count_limit of them
+        u128 kv = 0;
+        size_t made = 0;
+        for (size_t t = from; t < s.size() && made < count_limit; ++t) {
+            kv = ((kv << 2) | s[t]) & kmask;
+            if (t + 1 - from < k) continue;
+            const u128 rc = revcomp_kmer(kv, k);
+            const u128 c = kv < rc ? kv : rc;
+            keys.push_back(Key{mn, (uint64_t)(c >> 64), (uint64_t)c});
+            ++made;
+        }
+    };
+    uint64_t pos = (uint64_t)(nl - payload) + 1;
+    while (pos + m <= len) {
+        uint32_t mn = 0;
+        for (uint32_t j = 0; j < m; ++j) mn = (mn << 2) | code_of(payload[pos + j]);
+        pos += m;
+        uint32_t nbytes = 0;
+        if (pos + 4 > len) break;
+        memcpy(&nbytes, payload + pos, 4);
+        pos += 4;
+        if (pos + nbytes > len) { set_error("bucket blob runs past the end of the sketch"); return SPSP_ERR_FORMAT; }
+        // strDecompressor (utils.cpp:71-111)
+        seq.clear();
+        if (nbytes) {
+            const uint8_t mod = payload[pos];
+            const uint64_t last = (mod == 0) ? nbytes : nbytes - 1;
+            for (uint64_t i = 1; i < last; ++i) {
+                const uint8_t b = payload[pos + i];
+                seq.push_back((b >> 6) & 3); seq.push_back((b >> 4) & 3); seq.push_back((b >> 2) & 3); seq.push_back(b & 3);
+            }
+            if (mod != 0 && last >= 1) {
+                uint8_t b = payload[pos + last];
+                uint8_t f[4] = {0, 0, 0, 0};
+                for (int i = 0; i < (int)(mod & 3) + 1; ++i) { f[(mod & 3) - i] = b & 3; b >>= 2; }
+                for (int i = 0; i < (int)(mod & 3); ++i) seq.push_back(f[i]);
+            }
+        }
+        pos += nbytes;
+        // inject_minimizer (Comparator.cpp:78-92) + maximal walk (:196-225): every
+        // 2(k-m) stored bases are one maximal super-k-mer = k-m+1 k-mers
+        if (half > 0) {
+            std::vector<uint8_t> sk(2 * half + m);
+            for (size_t i = 0; i + 2 * half <= seq.size(); i += 2 * half) {
+                for (uint32_t j = 0; j < half; ++j) sk[j] = seq[i + j];
+                for (uint32_t j = 0; j < m; ++j) sk[half + j] = (mn >> (2 * (m - 1 - j))) & 3;
+                for (uint32_t j = 0; j < half; ++j) sk[half + m + j] = seq[i + half + j];
+                push_kmers(sk, 0, k - m + 1, mn);
+            }
+        } else if (seq.empty()) {
+            // k == m: inject_minimizer returns the bare minimizer for an empty blob and, being k long,
+            // it is walked as one k-mer (Comparator.cpp:88-90,193-198)
+            std::vector<uint8_t> sk(m);
+            for (uint32_t j = 0; j < m; ++j) sk[j] = (mn >> (2 * (m - 1 - j))) & 3;
+            push_kmers(sk, 0, 1, mn);
+        }
+        // non-maximal super-k-mers: "prefix\nsuffix\n" until an empty pair (:226-260)
+        for (;;) {
+            if (pos >= len) break;
+            const uint8_t* e1 = (const uint8_t*)memchr(payload + pos, '\n', len - pos);
+            const uint64_t s1 = pos, l1 = e1 ? (uint64_t)(e1 - payload) - pos : len - pos;
+            pos = e1 ? s1 + l1 + 1 : len;
+            const uint8_t* e2 = pos < len ? (const uint8_t*)memchr(payload + pos, '\n', len - pos) : nullptr;
+            const uint64_t s2 = pos, l2 = pos < len ? (e2 ? (uint64_t)(e2 - payload) - pos : len - pos) : 0;
+            pos = e2 ? s2 + l2 + 1 : len;
+            if (l1 == 0 && l2 == 0) break;
+            std::vector<uint8_t> sk;
+            sk.reserve(l1 + m + l2);
+            for (uint64_t j = 0; j < l1; ++j) sk.push_back((uint8_t)code_of(payload[s1 + j]));
+            for (uint32_t j = 0; j < m; ++j) sk.push_back((mn >> (2 * (m - 1 - j))) & 3);
+            for (uint64_t j = 0; j < l2; ++j) sk.push_back((uint8_t)code_of(payload[s2 + j]));
+            push_kmers(sk, 0, (size_t)-1, mn);
+        }
+    }
+    // distinct canonical k-mers per bucket == distinct (minimizer, k-mer) keys
+    std::sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) {
+        if (a.mn != b.mn) return a.mn < b.mn;
+        if (a.hi != b.hi) return a.hi < b.hi;
+        return a.lo < b.lo;
+    });
+    keys.erase(std::unique(keys.begin(), keys.end(), [](const Key& a, const Key& b) { return a.mn == b.mn && a.hi == b.hi && a.lo == b.lo; }), keys.end());
+    const size_t n = keys.size();
+    uint32_t* mn = (uint32_t*)malloc(std::max<size_t>(1, n) * 4);
+    uint64_t* lo = (uint64_t*)malloc(std::max<size_t>(1, n) * 8);
+    uint64_t* hi = (uint64_t*)malloc(std::max<size_t>(1, n) * 8);
+    if (!mn || !lo || !hi) { free(mn); free(lo); free(hi); set_error("out of host memory"); return SPSP_ERR_NOMEM; }
+    for (size_t i = 0; i < n; ++i) { mn[i] = keys[i].mn; lo[i] = keys[i].lo; hi[i] = keys[i].hi; }
+    *minimizer = mn; *kmer_lo = lo; *kmer_hi = hi; *n_out = n; *k_out = k; *m_out = m;
+    return SPSP_OK;
+}
+
+// print_containment / print_jaccard (Comparator.cpp:362-460); operator<<(double)
+// with setprecision(p) in the default float format is printf's %.*g.
+int spsp_csv_host(int jaccard, const char* const* names, uint32_t n, uint32_t n_query, const uint32_t* inter,
+                  const uint64_t* card, int precision, double min_threshold, char** text, uint64_t* len) {
+    if (!text || !len || (n && (!names || !inter || !card))) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    std::string out;
+    for (uint32_t i = 0; i < n; ++i) { out += names[i]; out += (i + 1 != n) ? ',' : '\n'; }
+    if (!jaccard) out += '\n';
+    char num[64];
+    for (uint32_t i = 0; i < n && i < n_query; ++i) {
+        for (uint32_t j = 0; j < n; ++j) {
+            if (i == j) out += '1';
+            else {
+                const uint32_t a = i < j ? i : j, b = i < j ? j : i;
+                const uint32_t sc = inter[(uint64_t)a * n + b];
+                if (sc == 0) out += '0';
+                else {
+                    const double score = jaccard ? (double)sc / (double)(card[i] + card[j] - sc) : (double)sc / (double)card[i];
+                    if (score < min_threshold) out += '0';
+                    else { const int l = snprintf(num, sizeof num, "%.*g", precision, score); out.append(num, l); }
+                }
+            }
+            out += (j + 1 != n) ? ',' : '\n';
+        }
+    }
+    *text = (char*)malloc(out.size() + 1);
+    if (!*text) { set_error("out of host memory"); return SPSP_ERR_NOMEM; }
+    memcpy(*text, out.data(), out.size());
+    (*text)[out.size()] = 0;
+    *len = out.size();
+    return SPSP_OK;
+}
+
+int spsp_read_file_host(const char* path, uint8_t** data, uint64_t* len) {
+    if (!path || !data || !len) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    FILE* f = fopen(path, "rb");
+    if (!f) { set_error("cannot open '%s'", path); return SPSP_ERR_IO; }
+    std::vector<uint8_t> raw;
+    std::vector<uint8_t> chunk(1 << 20);
+    size_t got;
+    while ((got = fread(chunk.data(), 1, chunk.size(), f)) > 0) raw.insert(raw.end(), chunk.data(), chunk.data() + got);
+    fclose(f);
+    std::vector<uint8_t> plain;
+    int rc = inflate_all(raw.data(), raw.size(), plain);
+    if (rc) return rc;
+    *data = (uint8_t*)malloc(plain.size() + 1);
+    if (!*data) { set_error("out of host memory"); return SPSP_ERR_NOMEM; }
+    if (!plain.empty()) memcpy(*data, plain.data(), plain.size());
+    *len = plain.size();
+    return SPSP_OK;
+}
+
+// zstr::ofstream(filename, expbuffer, level) -> gzip container (zstr.hpp:78-82)
+int spsp_write_gz_host(const char* path, const uint8_t* data, uint64_t len, int level) {
+    if (!path || (len && !data)) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    FILE* f = fopen(path, "wb");
+    if (!f) { set_error("cannot create '%s'", path); return SPSP_ERR_IO; }
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (deflateInit2(&zs, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) { fclose(f); set_error("deflateInit2 failed"); return SPSP_ERR_IO; }
+    std::vector<uint8_t> chunk(1 << 20);
+    uint64_t at = 0;
+    int ret = Z_OK;
+    do {
+        const uint64_t take = std::min<uint64_t>(len - at, 1u << 30);
+        zs.next_in = const_cast<Bytef*>(data + at);
+        zs.avail_in = (uInt)take;
+        at += take;
+        const int flush = at >= len ? Z_FINISH : Z_NO_FLUSH;
+        do {
+            zs.next_out = chunk.data();
+            zs.avail_out = (uInt)chunk.size();
+            ret = deflate(&zs, flush);
+            const size_t have = chunk.size() - zs.avail_out;
+            if (have && fwrite(chunk.data(), 1, have, f) != have) { deflateEnd(&zs); fclose(f); set_error("short write to '%s'", path); return SPSP_ERR_IO; }
+        } while (zs.avail_out == 0);
+    } while (ret != Z_STREAM_END);
+    deflateEnd(&zs);
+    if (fclose(f) != 0) { set_error("close failed for '%s'", path); return SPSP_ERR_IO; }
+    return SPSP_OK;
+}
+
+int spsp_sketch_file(spsp_ctx* ctx, const spsp_params* p, double rate, const char* fasta_path, const char* out_path,
+                     spsp_sketch_stats* stats) {
+    uint8_t* text = nullptr; uint64_t tlen = 0;
+    int rc = spsp_read_file_host(fasta_path, &text, &tlen);
+    if (rc) return rc;
+    uint8_t* bases = nullptr; uint64_t* off = nullptr; uint32_t n_rec = 0;
+    rc = spsp_fasta_clean_host((const char*)text, tlen, &bases, &off, &n_rec);
+    free(text);
+    if (rc) return rc;
+    spsp_superkmer* sk = nullptr; uint64_t n_sk = 0;
+    rc = spsp_scan(ctx, p, bases, off, n_rec, &sk, &n_sk);
+    uint8_t* payload = nullptr; uint64_t plen = 0;
+    if (!rc) rc = spsp_sketch_build_host(p, rate, bases, off, n_rec, sk, n_sk, &payload, &plen, stats);
+    free(bases); free(off); free(sk);
+    if (rc) { free(payload); return rc; }
+    rc = spsp_write_gz_host(out_path, payload, plen, 9);  // level 9: SubSampler.cpp:326
+    free(payload);
+    return rc;
+}
+
+int spsp_compare_files(spsp_ctx* ctx, const char* const* paths, uint32_t n, uint32_t n_query, int precision,
+                       double min_threshold, const char* out_prefix) {
+    if (!paths || !out_prefix) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    std::vector<spsp_sketch_view> views(n);
+    std::vector<void*> owned;
+    int rc = SPSP_OK;
+    uint32_t k0 = 0, m0 = 0;
+    for (uint32_t i = 0; i < n && !rc; ++i) {  // one sketch at a time: no N open streams (Comparator.cpp:45-50)
+        uint8_t* data = nullptr; uint64_t len = 0;
+        rc = spsp_read_file_host(paths[i], &data, &len);
+        if (rc) break;
+        uint32_t k = 0, m = 0; uint32_t* mn = nullptr; uint64_t *lo = nullptr, *hi = nullptr; uint64_t cnt = 0;
+        rc = spsp_sketch_parse_host(data, len, &k, &m, &mn, &lo, &hi, &cnt);
+        free(data);
+        if (rc) break;
+        owned.push_back(mn); owned.push_back(lo); owned.push_back(hi);
+        if (i == 0) { k0 = k; m0 = m; }
+        else if (k != k0 || m != m0) { set_error("'%s' was sketched with k=%u m=%u, expected k=%u m=%u", paths[i], k, m, k0, m0); rc = SPSP_ERR_FORMAT; break; }
+        views[i].minimizer = mn; views[i].kmer_lo = lo; views[i].kmer_hi = (k > 32) ? hi : nullptr; views[i].n = cnt;
+    }
+    std::vector<uint32_t> inter;
+    std::vector<uint64_t> card(n, 0);
+    if (!rc) {
+        inter.assign((size_t)n * n, 0);
+        rc = spsp_compare(ctx, views.data(), n, n_query, inter.data(), card.data());
+    }
+    for (void* p : owned) free(p);
+    if (rc) return rc;
+    for (int jac = 0; jac < 2 && !rc; ++jac) {
+        char* text = nullptr; uint64_t len = 0;
+        rc = spsp_csv_host(jac, paths, n, n_query, inter.data(), card.data(), precision, min_threshold, &text, &len);
+        if (rc) break;
+        const std::string out = std::string(out_prefix) + (jac ? "_jaccard.csv.gz" : "_containment.csv.gz");
+        rc = spsp_write_gz_host(out.c_str(), (const uint8_t*)text, len, 1);  // level 1: Comparator.cpp:363,413
+        free(text);
+    }
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,75 @@
+// Internal declarations shared by the libspsp translation units (not installed).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "../../include/spsp.h"
+
+namespace spsp {
+
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define SPSP_HIP(call)                                                      \
+    do {                                                                    \
+        hipError_t _e = (call);                                             \
+        if (_e != hipSuccess) return spsp::hip_fail(_e, #call, __FILE__, __LINE__); \
+    } while (0)
+
+// Grow-only device buffer owned by a context (re-used across calls so the
+// steady state of a batch loop performs no hipMalloc).
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes);
+    void release();
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// One candidate m-mer: hash <= threshold.  32 bytes.
+struct Hit {
+    uint64_t pos;    // absolute position of the m-mer in the concatenated bases
+    uint64_t hash;   // XXH64(canonical m-mer, seed 1312)
+    uint32_t canon;  // canonical 2-bit value
+    uint32_t rec;    // record index
+    uint32_t flags;  // bit0: occurrence is reverse strand; bit1: usable (inside a record of length >= k)
+    uint32_t pad;
+};
+
+}  // namespace spsp
+
+struct spsp_ctx {
+    int device = 0;
+    int n_cu = 256;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    uint64_t* h_scalar = nullptr;  // pinned, 8 slots
+    // scan workspace
+    spsp::DevBuf bases, rec_off, bitmap, tile_count, tile_off, hits, emit_count, emit_off, scan_tmp;
+    // LDS pre-filter table cache (keyed by m, threshold)
+    spsp::DevBuf filter;
+    uint32_t filter_m = 0;
+    uint64_t filter_thr = 0;
+    uint32_t filter_shift = 0;
+    bool filter_valid = false;
+    // compare workspace
+    spsp::DevBuf c_min, c_lo, c_hi, c_table, c_owner, c_rowid, c_slot, c_row, c_matrix, c_inter, c_flags, c_skoff;
+};
+
+namespace spsp {
+// scan pipeline (spsp_scan.hip)
+int scan_device_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, uint64_t n_bases,
+                     const uint64_t* d_rec_off, uint32_t n_rec, spsp_superkmer** d_out, uint64_t* n_out,
+                     bool own_output);
+int scan_hits_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, uint64_t n_bases,
+                   uint64_t* n_hits);
+// compare pipeline (spsp_compare.hip)
+int compare_device_impl(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min, const uint64_t* d_lo,
+                        const uint64_t* d_hi, const uint64_t* h_sk_off, uint32_t n, uint32_t row_first,
+                        uint32_t row_stride, uint32_t* d_inter);
+int check_params(const spsp_params* p);
+}  // namespace spsp

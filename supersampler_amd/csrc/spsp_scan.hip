@@ -1,0 +1,527 @@
+// spsp_scan.hip -- path A on gfx950: the minimizer / FracMinHash scan.
+//
+// What the reference does serially per base (SubSampler.cpp:357-455: rolling
+// m-mers, XXH64 of the canonical m-mer, running minimum with a full rescan of
+// the k-mer whenever the minimizer leaves the window, super-k-mer emission) is
+// re-formulated for the GPU as a dense pass plus a sparse pass:
+//
+//   dense  (k_dense_*)   every m-mer position: 2-bit pack -> canonical m-mer
+//                        -> XXH64 -> `hash <= T` -> one bit in a hit bitmap.
+//                        1 byte read and 1/8 byte written per position.
+//   sparse (k_expand,    a k-mer is selected iff ANY m-mer of its window has
+//           k_resolve)   hash <= T (min <= T  <=>  exists <= T), so only the
+//                        hits matter.  Hits closer than w = k-m+1 form a
+//                        cluster; a cluster always starts with the reference's
+//                        "new m-mer beats the minimum" event (SubSampler.cpp:374)
+//                        which resets its whole state, so clusters are
+//                        independent and one lane replays the reference's state
+//                        machine literally over the cluster's hits -- including
+//                        its position/strand quirks (SubSampler.cpp:89-93,
+//                        132-166) that split super-k-mers.
+//
+// Output = exactly the argument stream of Subsampler::handle_superkmer.
+#include "spsp_internal.h"
+#include "spsp_device.h"
+
+namespace spsp {
+
+// ---------------------------------------------------------------- geometry --
+constexpr int kThreads = 256;                // 4 waves
+constexpr int kChunk = 16;                   // bases per lane per row (one dwordx4 load)
+constexpr int kRows = 4;                     // rows per tile
+constexpr int kRowPos = kThreads * kChunk;   // 4096 positions per row
+constexpr int kTilePos = kRows * kRowPos;    // 16384 positions per workgroup
+constexpr int kTileWords = kTilePos / 32;    // 512 bitmap words per tile
+
+// 16 ASCII bases -> 32 bits, first base in the two most significant bits.
+// code = (c >> 1) & 3 (reference utils.cpp:13-16: A=0 C=1 T=2 G=3).
+__device__ __forceinline__ uint32_t pack4(uint32_t d) {
+    // bytes b0..b3 (b0 = first base) -> b0<<6 | b1<<4 | b2<<2 | b3 via one multiply:
+    // the four 2-bit fields land in bits 30,28,26,24 without carries.
+    return (((d >> 1) & 0x03030303u) * 0x40100401u) >> 24;
+}
+__device__ __forceinline__ uint32_t pack16(uint4 v) {
+    return (pack4(v.x) << 24) | (pack4(v.y) << 16) | (pack4(v.z) << 8) | pack4(v.w);
+}
+__device__ __forceinline__ uint32_t load_pack(const uint8_t* __restrict__ bases, uint64_t n, uint64_t pos) {
+    if (pos + kChunk <= n) {
+        return pack16(*reinterpret_cast<const uint4*>(bases + pos));
+    }
+    uint32_t w = 0;
+    for (int j = 0; j < kChunk; ++j) {
+        uint32_t c = (pos + j < n) ? bases[pos + j] : 0u;
+        w = (w << 2) | ((c >> 1) & 3u);
+    }
+    return w;
+}
+
+// ------------------------------------------------------------- dense pass ---
+// MODE 0: XXH64 at every position.  MODE 1: LDS-resident memoised pre-filter
+// (a bitmap over canonical m-mer prefixes that says "some m-mer with this
+// prefix has hash <= T"), XXH64 only for the survivors.  Same results.
+//
+// A workgroup is G independent groups of 256 lanes; each group owns one tile of
+// kTilePos positions per iteration and the grid strides over the tiles (MODE 1
+// amortises the 128 KiB table load over many tiles: one workgroup per CU).
+template <int MODE, int G>
+__global__ __launch_bounds__(kThreads* G) void k_dense(const uint8_t* __restrict__ bases, uint64_t n, uint32_t m,
+                                                      uint64_t thr, const uint32_t* __restrict__ filter,
+                                                      uint32_t filter_words, uint32_t filter_shift,
+                                                      uint64_t n_tiles, uint32_t* __restrict__ bitmap,
+                                                      uint32_t* __restrict__ tile_count) {
+    __shared__ uint32_t packed[G][kRows * kThreads + 1];
+    __shared__ uint32_t s_cnt[G];
+    extern __shared__ uint32_t s_filter[];
+    const uint32_t grp = threadIdx.x / kThreads;
+    const uint32_t t = threadIdx.x % kThreads;
+    if (MODE == 1) {
+        for (uint32_t i = threadIdx.x; i < filter_words; i += kThreads * G) s_filter[i] = filter[i];
+    }
+    const uint64_t n_mmers = n >= m ? n - m + 1 : 0;
+    const uint32_t mm = (1u << (2 * m)) - 1u;  // m <= 15
+    const uint32_t sh0 = 64 - 2 * m;
+    for (uint64_t tile0 = (uint64_t)blockIdx.x * G; tile0 < n_tiles; tile0 += (uint64_t)gridDim.x * G) {
+        const uint64_t tile = tile0 + grp;
+        const bool live = tile < n_tiles;
+        const uint64_t tile_base = tile * kTilePos;
+        __syncthreads();  // previous iteration's readers of packed[] / s_cnt[] are done
+        if (t == 0) s_cnt[grp] = 0;
+        if (live) {
+#pragma unroll
+            for (int r = 0; r < kRows; ++r) {
+                const uint32_t c = r * kThreads + t;
+                packed[grp][c] = load_pack(bases, n, tile_base + (uint64_t)c * kChunk);
+            }
+            if (t == 0) packed[grp][kRows * kThreads] = load_pack(bases, n, tile_base + (uint64_t)kTilePos);
+        }
+        __syncthreads();
+        uint32_t local = 0;
+        if (live) {
+#pragma unroll
+            for (int r = 0; r < kRows; ++r) {
+                const uint32_t c = r * kThreads + t;
+                const uint64_t p0 = tile_base + (uint64_t)c * kChunk;
+                const uint64_t W = ((uint64_t)packed[grp][c] << 32) | packed[grp][c + 1];
+                const uint64_t R = rc_window64(W);
+                uint32_t mask16 = 0;
+#pragma unroll
+                for (int j = 0; j < kChunk; ++j) {
+                    const uint32_t f = (uint32_t)(W >> (sh0 - 2 * j)) & mm;
+                    const uint32_t rc = (uint32_t)(R >> (2 * j)) & mm;
+                    const uint32_t x = f < rc ? f : rc;
+                    bool hit;
+                    if (MODE == 1) {
+                        const uint32_t q = x >> filter_shift;
+                        hit = (s_filter[q >> 5] >> (q & 31)) & 1u;
+                        if (hit) hit = xxh64_u64(x) <= thr;
+                    } else {
+                        hit = xxh64_u64(x) <= thr;
+                    }
+                    mask16 |= (hit ? 1u : 0u) << j;
+                }
+                // positions past the last m-mer of the buffer never count
+                if (p0 + kChunk > n_mmers) {
+                    const uint32_t keep = p0 >= n_mmers ? 0u : (uint32_t)(n_mmers - p0);
+                    mask16 &= (keep >= 16) ? 0xffffu : ((1u << keep) - 1u);
+                }
+                const uint32_t other = __shfl_down(mask16, 1);
+                if ((t & 1u) == 0) bitmap[p0 >> 5] = mask16 | (other << 16);
+                local += __popc(mask16);
+            }
+            if (local) atomicAdd(&s_cnt[grp], local);
+        }
+        __syncthreads();
+        if (live && t == 0) tile_count[tile] = s_cnt[grp];
+    }
+}
+
+// Builds the pre-filter table: bit q set iff some canonical m-mer x with
+// x >> shift == q has XXH64(x) <= thr.  One thread per m-mer value.
+__global__ void k_build_filter(uint32_t m, uint64_t thr, uint32_t shift, uint32_t* __restrict__ table) {
+    const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= (1ull << (2 * m))) return;
+    const uint32_t v = (uint32_t)x;
+    if (rc_mmer32(v, m) < v) return;  // not canonical: its reverse complement covers it
+    if (xxh64_u64(v) <= thr) atomicOr(&table[(v >> shift) >> 5], 1u << ((v >> shift) & 31));
+}
+
+// ------------------------------------------------- exclusive scan (1 block) --
+// out[i] = sum(in[0..i)), out[n] = total.  u32, single workgroup of 1024 lanes;
+// the arrays it runs over (tiles, hits) are tiny next to the dense pass.
+__global__ __launch_bounds__(1024) void k_exclusive_scan(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                        uint64_t n, uint64_t* __restrict__ total_out) {
+    __shared__ uint32_t wave_sum[16];
+    __shared__ uint32_t carry_s;
+    const uint32_t t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    if (t == 0) carry_s = 0;
+    __syncthreads();
+    uint64_t total = 0;
+    for (uint64_t base = 0; base < n; base += 1024) {
+        const uint64_t i = base + t;
+        const uint32_t v = i < n ? in[i] : 0u;
+        uint32_t x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d);
+            if (lane >= (uint32_t)d) x += y;
+        }
+        if (lane == 63) wave_sum[wid] = x;
+        __syncthreads();
+        uint32_t pre = 0;
+        for (uint32_t w = 0; w < wid; ++w) pre += wave_sum[w];
+        const uint32_t carry = carry_s;
+        if (i < n) out[i] = carry + pre + x - v;
+        __syncthreads();
+        if (t == 1023) { carry_s = carry + pre + x; }
+        __syncthreads();
+    }
+    if (t == 0) {
+        total = carry_s;
+        out[n] = (uint32_t)total;
+        if (total_out) *total_out = total;
+    }
+}
+
+// ------------------------------------------------------------- expand pass --
+// One workgroup per dense tile: bitmap bits -> Hit records in position order.
+__global__ __launch_bounds__(kThreads) void k_expand(const uint8_t* __restrict__ bases, uint64_t n, uint32_t k,
+                                                    uint32_t m, const uint32_t* __restrict__ bitmap,
+                                                    const uint32_t* __restrict__ tile_count,
+                                                    const uint32_t* __restrict__ tile_off,
+                                                    const uint64_t* __restrict__ rec_off, uint32_t n_rec,
+                                                    Hit* __restrict__ hits) {
+    const uint32_t b = blockIdx.x;
+    if (tile_count[b] == 0) return;
+    __shared__ uint32_t wave_sum[kThreads / 64];
+    const uint32_t t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    constexpr int WPT = kTileWords / kThreads;  // 2 words per lane, consecutive
+    uint32_t words[WPT];
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+        words[i] = bitmap[(uint64_t)b * kTileWords + t * WPT + i];
+        cnt += __popc(words[i]);
+    }
+    uint32_t x = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d);
+        if (lane >= (uint32_t)d) x += y;
+    }
+    if (lane == 63) wave_sum[wid] = x;
+    __syncthreads();
+    uint32_t pre = 0;
+    for (uint32_t w = 0; w < wid; ++w) pre += wave_sum[w];
+    uint32_t rank = tile_off[b] + pre + x - cnt;
+    const uint32_t mm = (1u << (2 * m)) - 1u;
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+        uint32_t bits = words[i];
+        while (bits) {
+            const int bit = __ffs(bits) - 1;
+            bits &= bits - 1;
+            const uint64_t pos = (uint64_t)b * kTilePos + (uint64_t)(t * WPT + i) * 32 + bit;
+            uint32_t f = 0;
+            for (uint32_t j = 0; j < m; ++j) f = (f << 2) | ((bases[pos + j] >> 1) & 3u);
+            f &= mm;
+            const uint32_t rc = rc_mmer32(f, m);
+            Hit h;
+            h.pos = pos;
+            h.canon = f < rc ? f : rc;
+            h.hash = xxh64_u64(h.canon);
+            // record = last r with rec_off[r] <= pos
+            uint32_t lo = 0, hi = n_rec;  // invariant: rec_off[lo] <= pos < rec_off[hi]
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (rec_off[mid] <= pos) lo = mid; else hi = mid;
+            }
+            h.rec = lo;
+            const uint64_t r0 = rec_off[lo], r1 = rec_off[lo + 1];
+            const bool usable = (pos + m <= r1) && (r1 - r0 >= k);
+            h.flags = (h.canon != f ? 1u : 0u) | (usable ? 2u : 0u);
+            h.pad = 0;
+            hits[rank++] = h;
+        }
+    }
+}
+
+// ------------------------------------------------------------ resolve pass --
+// Literal replay of the reference state machine over one cluster of hits.
+struct Rescan { uint32_t mini; uint32_t rev; uint64_t position; uint64_t hash; };
+
+// regular_minimizer_pos (SubSampler.cpp:81-169) restricted to the hits
+// H[lo..hi] of the window starting at m-mer position ws.  Non-hit m-mers can
+// never win (their hash is > T >= any hit's) and can never tie (XXH64 on 8
+// bytes is a bijection), so skipping them leaves every assignment identical.
+__device__ __forceinline__ Rescan rescan_hits(const Hit* __restrict__ H, uint64_t r0, uint32_t lo, uint32_t hi,
+                                              uint64_t ws, uint64_t km) {
+    Rescan r;
+    {
+        const Hit h = H[hi];
+        const uint64_t off = (h.pos - r0) - ws;
+        r.mini = h.canon; r.hash = h.hash; r.rev = h.flags & 1u;
+        if (off == km) r.position = r.rev ? 0 : km;  // rightmost m-mer: :88-93 (reverse => position 0, sic)
+        else r.position = off;                       // first hit met strictly beats the non-hits right of it
+    }
+    for (uint32_t idx = hi; idx-- > lo;) {
+        const Hit h = H[idx];
+        const uint64_t off = (h.pos - r0) - ws;
+        const uint64_t ii = km - off;  // the reference's loop index i
+        const uint32_t lrev = h.flags & 1u;
+        if (r.hash > h.hash) {                                       // :117-129
+            r.position = off; r.mini = h.canon; r.rev = lrev; r.hash = h.hash;
+        } else if (h.canon == r.mini) {                              // :132-166
+            if (lrev == r.rev) {
+                if (r.rev && r.position > ii) r.position = ii;       // :151-157 (sic)
+                if (!r.rev && r.position > off) r.position = off;    // :158-164
+            }
+        }
+    }
+    return r;
+}
+
+template <bool WRITE>
+__device__ uint32_t run_cluster(const Hit* __restrict__ H, uint32_t cnt, uint64_t r0, uint64_t n, uint32_t k,
+                                uint32_t m, uint32_t rec, spsp_superkmer* __restrict__ out) {
+    const uint64_t km = k - m, w = km + 1;
+    auto q = [&](uint32_t i) -> uint64_t { return H[i].pos - r0; };
+    uint32_t nem = 0;
+    auto emit = [&](uint64_t start, uint64_t len, uint32_t mini, uint32_t rev) {
+        if (WRITE) {
+            spsp_superkmer e;
+            e.rec = rec; e.minimizer = mini; e.start = start; e.len = (uint32_t)len; e.rev = rev;
+            out[nem] = e;
+        }
+        ++nem;
+    };
+    const uint64_t q0 = q(0);
+    uint32_t minimizer, rev;
+    uint64_t hash_min, position_min, last_position, i;
+    uint32_t lo = 0;  // first hit with position >= current window start
+    if (q0 > km) {
+        // iteration i = q0-w: the hit enters as the rightmost m-mer and beats an
+        // unselected minimum (SubSampler.cpp:374-388); the old super-k-mer is not selected.
+        const Hit h = H[0];
+        minimizer = h.canon; hash_min = h.hash; position_min = q0; rev = h.flags & 1u;
+        last_position = q0 - km; i = q0 - km;
+    } else {
+        // record start (SubSampler.cpp:359-365): rescan of k-mer 0
+        uint32_t hi = 0;
+        while (hi + 1 < cnt && q(hi + 1) <= km) ++hi;
+        const Rescan r = rescan_hits(H, r0, 0, hi, 0, km);
+        minimizer = r.mini; hash_min = r.hash; position_min = r.position; rev = r.rev;
+        last_position = 0; i = 0;
+    }
+    uint32_t old_min = minimizer, old_rev = rev;
+    uint32_t nh = 0;  // first hit with position >= i + w
+    bool closed = false;
+    while (i + k < n) {                                           // :367
+        const uint64_t pn = i + w;                                // position of the entering m-mer
+        while (nh < cnt && q(nh) < pn) ++nh;
+        const bool enters = nh < cnt && q(nh) == pn;
+        bool dump = false;
+        if (enters && H[nh].hash < hash_min) {                    // :374-388
+            const Hit h = H[nh];
+            minimizer = h.canon; hash_min = h.hash; position_min = pn; rev = h.flags & 1u;
+        } else if (i >= position_min) {                           // :391-398
+            while (lo < cnt && q(lo) < i + 1) ++lo;
+            if (lo >= cnt || q(lo) > pn) {
+                // no hit left in the window: the new minimizer is unselected, the
+                // cluster's last super-k-mer is emitted and the cluster is over.
+                emit(last_position, i + k - last_position, old_min, old_rev);
+                closed = true;
+                break;
+            }
+            const uint32_t hi = enters ? nh : nh - 1;
+            const Rescan r = rescan_hits(H, r0, lo, hi, i + 1, km);
+            minimizer = r.mini; rev = r.rev; hash_min = r.hash;
+            position_min = r.position + i + 1;
+            dump = true;
+        }
+        if (old_min != minimizer || dump) {                       // :401-435 (old one is selected)
+            emit(last_position, i + k - last_position, old_min, old_rev);
+            last_position = i + 1; old_min = minimizer; old_rev = rev;
+        }
+        // skip iterations in which nothing can happen: the next event is the
+        // next hit entering or the tracked minimizer leaving the window.
+        uint64_t ni = position_min;
+        const uint32_t nx = enters ? nh + 1 : nh;
+        if (nx < cnt) { const uint64_t e = q(nx) - w; if (e < ni) ni = e; }
+        i = ni > i + 1 ? ni : i + 1;
+    }
+    if (!closed) emit(last_position, n - last_position, old_min, old_rev);  // :441-454 tail
+    return nem;
+}
+
+template <bool WRITE>
+__global__ void k_resolve(const Hit* __restrict__ hits, uint32_t n_hits, const uint64_t* __restrict__ rec_off,
+                          uint32_t k, uint32_t m, uint32_t* __restrict__ emit_count,
+                          const uint32_t* __restrict__ emit_off, spsp_superkmer* __restrict__ out) {
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= n_hits) return;
+    const uint64_t w = k - m + 1;
+    const Hit me = hits[h];
+    bool head = (me.flags & 2u) != 0;
+    if (head) {
+        for (uint32_t g = h; g-- > 0;) {
+            const Hit o = hits[g];
+            if (me.pos - o.pos > w) break;
+            if ((o.flags & 2u) && o.rec == me.rec) { head = false; break; }
+        }
+    }
+    if (!head) {
+        if (!WRITE) emit_count[h] = 0;
+        return;
+    }
+    uint32_t cnt = 1;
+    while (h + cnt < n_hits) {
+        const Hit a = hits[h + cnt - 1], b = hits[h + cnt];
+        if (!(b.flags & 2u) || b.rec != me.rec || b.pos - a.pos > w) break;
+        ++cnt;
+    }
+    const uint64_t r0 = rec_off[me.rec], r1 = rec_off[me.rec + 1];
+    if (WRITE) {
+        run_cluster<true>(hits + h, cnt, r0, r1 - r0, k, m, me.rec, out + emit_off[h]);
+    } else {
+        emit_count[h] = run_cluster<false>(hits + h, cnt, r0, r1 - r0, k, m, me.rec, nullptr);
+    }
+}
+
+// ----------------------------------------------------------------- helpers --
+int check_params(const spsp_params* p) {
+    if (!p) { set_error("params is NULL"); return SPSP_ERR_ARG; }
+    if (p->m < 1 || p->m > 15) { set_error("m=%u out of range 1..15", p->m); return SPSP_ERR_ARG; }
+    if (p->k < p->m || p->k > 63) { set_error("k=%u out of range m..63", p->k); return SPSP_ERR_ARG; }
+    return SPSP_OK;
+}
+
+static int ensure_filter(spsp_ctx* ctx, const spsp_params* p, uint32_t* words, uint32_t* shift) {
+    // 2^20 bits = 128 KiB of LDS; the table indexes the top 20 bits of the 2m-bit value
+    const uint32_t bits = 2 * p->m;
+    const uint32_t sh = bits > 20 ? bits - 20 : 0;
+    const uint32_t nbits = 1u << (bits - sh);
+    const uint32_t nwords = (nbits + 31) / 32;
+    *words = nwords; *shift = sh;
+    if (ctx->filter_valid && ctx->filter_m == p->m && ctx->filter_thr == p->threshold) return SPSP_OK;
+    int rc = ctx->filter.reserve((size_t)nwords * 4);
+    if (rc) return rc;
+    SPSP_HIP(hipMemsetAsync(ctx->filter.p, 0, (size_t)nwords * 4, ctx->stream));
+    const uint64_t total = 1ull << bits;
+    const uint32_t blocks = (uint32_t)((total + 255) / 256);
+    hipLaunchKernelGGL(k_build_filter, dim3(blocks), dim3(256), 0, ctx->stream, p->m, p->threshold, sh,
+                       ctx->filter.as<uint32_t>());
+    SPSP_HIP(hipGetLastError());
+    ctx->filter_m = p->m; ctx->filter_thr = p->threshold; ctx->filter_shift = sh; ctx->filter_valid = true;
+    return SPSP_OK;
+}
+
+// Picks the dense-pass variant.  The pre-filter pays when few table bits are
+// set (sparse selection); with dense selection nearly every lane hashes anyway.
+static bool want_filter(const spsp_params* p) {
+    if (p->flags & SPSP_SCAN_DIRECT_HASH) return false;
+    if (p->flags & SPSP_SCAN_LDS_FILTER) return true;
+    const double frac = (double)p->threshold / 18446744073709551616.0;  // P(hash <= T)
+    const uint32_t bits = 2 * p->m;
+    const double per_bit = bits > 20 ? (double)(1u << (bits - 20)) : 1.0;
+    return frac * per_bit < 0.02;  // expected fraction of positions that still hash
+}
+
+static int launch_dense(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, uint64_t n_bases,
+                        uint64_t n_tiles) {
+    int rc;
+    if ((rc = ctx->bitmap.reserve((size_t)n_tiles * kTileWords * 4))) return rc;
+    if ((rc = ctx->tile_count.reserve((size_t)n_tiles * 4))) return rc;
+    if ((rc = ctx->tile_off.reserve((size_t)(n_tiles + 1) * 4))) return rc;
+    if (want_filter(p)) {
+        uint32_t words = 0, shift = 0;
+        if ((rc = ensure_filter(ctx, p, &words, &shift))) return rc;
+        static bool attr_set = false;
+        if (!attr_set) {
+            SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense<1, 4>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+            attr_set = true;
+        }
+        const uint64_t want = (n_tiles + 3) / 4;
+        const uint32_t grid = (uint32_t)(want < (uint64_t)ctx->n_cu ? want : (uint64_t)ctx->n_cu);
+        hipLaunchKernelGGL((k_dense<1, 4>), dim3(grid), dim3(kThreads * 4), (size_t)words * 4, ctx->stream, d_bases,
+                           n_bases, p->m, p->threshold, ctx->filter.as<uint32_t>(), words, shift, n_tiles,
+                           ctx->bitmap.as<uint32_t>(), ctx->tile_count.as<uint32_t>());
+    } else {
+        const uint64_t cap = (uint64_t)ctx->n_cu * 16;
+        const uint32_t grid = (uint32_t)(n_tiles < cap ? n_tiles : cap);
+        hipLaunchKernelGGL((k_dense<0, 1>), dim3(grid), dim3(kThreads), 0, ctx->stream, d_bases, n_bases, p->m,
+                           p->threshold, (const uint32_t*)nullptr, 0u, 0u, n_tiles, ctx->bitmap.as<uint32_t>(),
+                           ctx->tile_count.as<uint32_t>());
+    }
+    SPSP_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->tile_count.as<uint32_t>(),
+                       ctx->tile_off.as<uint32_t>(), n_tiles, ctx->h_scalar + 0);
+    SPSP_HIP(hipGetLastError());
+    return SPSP_OK;
+}
+
+int scan_hits_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, uint64_t n_bases,
+                   uint64_t* n_hits) {
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (((uintptr_t)d_bases & 15u) != 0) { set_error("d_bases must be 16-byte aligned"); return SPSP_ERR_ARG; }
+    *n_hits = 0;
+    if (n_bases < p->m) return SPSP_OK;
+    const uint64_t n_tiles = (n_bases + kTilePos - 1) / kTilePos;
+    if (n_tiles > 0x7fffffffull) { set_error("input too large for one call"); return SPSP_ERR_OVERFLOW; }
+    if ((rc = launch_dense(ctx, p, d_bases, n_bases, n_tiles))) return rc;
+    SPSP_HIP(hipStreamSynchronize(ctx->stream));
+    *n_hits = ctx->h_scalar[0];
+    return SPSP_OK;
+}
+
+int scan_device_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, uint64_t n_bases,
+                     const uint64_t* d_rec_off, uint32_t n_rec, spsp_superkmer** d_out, uint64_t* n_out,
+                     bool own_output) {
+    int rc = check_params(p);
+    if (rc) return rc;
+    *d_out = nullptr; *n_out = 0;
+    if (((uintptr_t)d_bases & 15u) != 0) { set_error("d_bases must be 16-byte aligned"); return SPSP_ERR_ARG; }
+    if (n_rec == 0 || n_bases < p->k) return SPSP_OK;
+    const uint64_t n_tiles = (n_bases + kTilePos - 1) / kTilePos;
+    if (n_tiles > 0x7fffffffull) { set_error("input too large for one call"); return SPSP_ERR_OVERFLOW; }
+    if ((rc = launch_dense(ctx, p, d_bases, n_bases, n_tiles))) return rc;
+    SPSP_HIP(hipStreamSynchronize(ctx->stream));
+    const uint64_t n_hits = ctx->h_scalar[0];
+    if (n_hits == 0) return SPSP_OK;
+    if (n_hits > 0xfffffff0ull) { set_error("too many candidate m-mers for one call; split the input"); return SPSP_ERR_OVERFLOW; }
+    if ((rc = ctx->hits.reserve((size_t)n_hits * sizeof(Hit)))) return rc;
+    if ((rc = ctx->emit_count.reserve((size_t)n_hits * 4))) return rc;
+    if ((rc = ctx->emit_off.reserve((size_t)(n_hits + 1) * 4))) return rc;
+    hipLaunchKernelGGL(k_expand, dim3((uint32_t)n_tiles), dim3(kThreads), 0, ctx->stream, d_bases, n_bases, p->k,
+                       p->m, ctx->bitmap.as<uint32_t>(), ctx->tile_count.as<uint32_t>(),
+                       ctx->tile_off.as<uint32_t>(), d_rec_off, n_rec, ctx->hits.as<Hit>());
+    SPSP_HIP(hipGetLastError());
+    const uint32_t rblocks = (uint32_t)((n_hits + 127) / 128);
+    hipLaunchKernelGGL(k_resolve<false>, dim3(rblocks), dim3(128), 0, ctx->stream, ctx->hits.as<Hit>(),
+                       (uint32_t)n_hits, d_rec_off, p->k, p->m, ctx->emit_count.as<uint32_t>(),
+                       (const uint32_t*)nullptr, (spsp_superkmer*)nullptr);
+    SPSP_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->emit_count.as<uint32_t>(),
+                       ctx->emit_off.as<uint32_t>(), n_hits, ctx->h_scalar + 1);
+    SPSP_HIP(hipGetLastError());
+    SPSP_HIP(hipStreamSynchronize(ctx->stream));
+    const uint64_t n_em = ctx->h_scalar[1];
+    if (n_em == 0) return SPSP_OK;
+    if (n_em > 0xfffffff0ull) { set_error("too many super-k-mers for one call; split the input"); return SPSP_ERR_OVERFLOW; }
+    spsp_superkmer* out = nullptr;
+    if (own_output) {
+        SPSP_HIP(hipMalloc((void**)&out, (size_t)n_em * sizeof(spsp_superkmer)));
+    } else {
+        if ((rc = ctx->scan_tmp.reserve((size_t)n_em * sizeof(spsp_superkmer)))) return rc;
+        out = ctx->scan_tmp.as<spsp_superkmer>();
+    }
+    hipLaunchKernelGGL(k_resolve<true>, dim3(rblocks), dim3(128), 0, ctx->stream, ctx->hits.as<Hit>(),
+                       (uint32_t)n_hits, d_rec_off, p->k, p->m, (uint32_t*)nullptr,
+                       ctx->emit_off.as<uint32_t>(), out);
+    SPSP_HIP(hipGetLastError());
+    *d_out = out; *n_out = n_em;
+    return SPSP_OK;
+}
+
+}  // namespace spsp

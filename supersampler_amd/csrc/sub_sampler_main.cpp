@@ -1,0 +1,180 @@
+// sub_sampler -- drop-in command line of the reference's sketcher
+// (SubSampler.cpp:667-803) over libspsp.  Same flags, defaults, output names
+// and stdout chatter; the scan itself runs on the GPU through the C-ABI.
+#include <getopt.h>
+#include <sys/stat.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <mutex>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/spsp.h"
+
+using namespace std;
+
+// get_out_name (SubSampler.cpp:196-221): prefix + basename up to the first '.'
+static string out_name(const string& path, const string& prefix) {
+    size_t begin = 0;
+    for (size_t i = 0; i < path.size(); ++i)
+        if (path[i] == '/') begin = i + 1;
+    string stem;
+    for (size_t i = begin; i < path.size() && path[i] != '.'; ++i) stem.push_back(path[i]);
+    return prefix + stem;
+}
+
+// intToString (utils.cpp:115-127)
+static string with_commas(uint64_t n) {
+    string s = to_string(n), out;
+    for (size_t i = 0; i < s.size(); ++i) {
+        out.push_back(s[i]);
+        const size_t left = s.size() - 1 - i;
+        if (left && left % 3 == 0) out.push_back(',');
+    }
+    return out;
+}
+
+static uint64_t file_size(const string& p) {
+    struct stat st;
+    return stat(p.c_str(), &st) == 0 ? (uint64_t)st.st_size : 0;
+}
+
+// print_stat (SubSampler.cpp:633-665).  Lines that need the count of
+// UNSELECTED super-k-mers are not reproduced: the GPU scan never materialises
+// them (see DESIGN.md "known deviations").
+static void print_stat(const spsp_sketch_stats& s, uint32_t k, uint32_t m, const string& file) {
+    if (s.selected_kmer_number == 0) { cout << "No kmer selected ***Crickets noise***" << endl; return; }
+    cout << "I have seen " << with_commas(s.read_kmer) << " kmers and I selected " << with_commas(s.selected_kmer_number) << " kmers" << endl;
+    cout << "After removing duplicate kmers, I selected " << with_commas(s.seen_kmers_at_reconstruction) << " kmers" << endl;
+    cout << "This means a practical subsampling rate of " << (double)s.read_kmer / s.selected_kmer_number << " with duplicates" << endl;
+    cout << "This means a practical subsampling rate of " << (double)s.read_kmer / s.seen_kmers_at_reconstruction << " without duplicates" << endl;
+    cout << "I selected " << with_commas(s.selected_superkmer_number) << " superkmers" << endl;
+    cout << "After reconstruction and filtering with abundance, I have selected " << with_commas(s.seen_superkmers_at_reconstruction) << " superkmers" << endl;
+    cout << "This means a mean superkmer size of " << (double)s.selected_kmer_number / s.selected_superkmer_number << " kmer per superkmer with duplicates" << endl;
+    cout << "This means a mean superkmer size of " << (double)s.seen_kmers_at_reconstruction / s.seen_superkmers_at_reconstruction << " kmer per superkmer in the output" << endl;
+    cout << "Actual output file size is " << with_commas(file_size(file) / 1000) << "KB" << endl;
+    cout << "This mean " << ((double)file_size(file) * 8 / s.seen_kmers_at_reconstruction) << " bits per kmer" << endl;
+    cout << "Minimizer number: " << with_commas(s.actual_minimizer_number) << " Skmer/minimizer:                    " << s.selected_superkmer_number / s.actual_minimizer_number << endl;
+    cout << "Minimizer number: " << with_commas(s.actual_minimizer_number) << " Skmer/minimizer without duplicates: " << s.seen_superkmers_at_reconstruction / s.actual_minimizer_number << endl;
+    cout << "Density is: " << (((double)s.selected_superkmer_number / s.nb_mmer_selected) * (k - m + 2)) << endl;
+    cout << "Number of maximal skmer was:       " << with_commas(s.count_maximal_skmer) << endl;
+    cout << "Actual number of maximal skmer is: " << with_commas(s.seen_max_superkmers_at_reconstruction) << endl;
+    cout << "Proportion of max skmers:        " << ((double)s.count_maximal_skmer / s.selected_superkmer_number) * 100 << "% with duplicate kmers" << endl;
+    cout << "Actual proportion of max skmers: " << ((double)s.seen_max_superkmers_at_reconstruction / s.seen_superkmers_at_reconstruction) * 100 << "%" << endl;
+    cout << "\n" << endl;
+}
+
+int main(int argc, char** argv) {
+    int ch;
+    string input, inputfof, output("subsampled_");
+    unsigned k = 31, m1 = 11, c = 8, abundance = 1;
+    double s = 1000;
+    bool verbose = true;
+    while ((ch = getopt(argc, argv, "hdg:q:k:m:n:s:t:b:e:f:i:p:v:x:a:")) != -1) {
+        switch (ch) {
+            case 'i': input = optarg; break;
+            case 'f': inputfof = optarg; break;
+            case 'k': k = stoi(optarg); break;
+            case 'm': m1 = stoi(optarg); break;
+            case 't': c = stoi(optarg); break;
+            case 's': s = stof(optarg); break;  // float, as the reference (SubSampler.cpp:699)
+            case 'p': output = optarg; break;
+            case 'v': verbose = stoi(optarg); break;
+            case 'x': break;  // stored but unused by the reference's live code
+            case 'a': abundance = stoi(optarg); break;
+        }
+    }
+    if (input == "" && inputfof == "") {
+        cout << "Core arguments:" << endl
+             << "	-i Input file" << endl
+             << "	-f Input file of file" << endl
+             << "	-p Output prefix (subsampled)" << endl
+             << "	-k Kmer size used  (31) " << endl
+             << "	-s Subsampling used  (1000) " << endl
+             << "	-t Threads used  (8) " << endl
+             << "	-m Minimizer size used  (11, max value is 15) " << endl
+             << "	-v Verbose level (1) " << endl
+             << "	-a Abundance min (2) " << endl
+             << "	-3/2/1 respectively Max skmers + any sized skmers + cursed skmers OR Max skmers and any sized skmers OR max skmers only. (default 3) " << endl;
+        return 0;
+    }
+    if (m1 % 2 == 0) { cout << "Minimizer size must be odd" << endl; m1++; }
+    if (k % 2 == 0) { cout << "Kmer size must be odd" << endl; k++; }
+    if (m1 > 15) { cout << "Minimizer size can't be greater than 15." << endl; m1 = 15; }
+    cout << " I use k=" << k << " m=" << m1 << " s=" << s << endl;
+    cout << "Maximal super kmer are of length " << 2 * k - m1 << " or " << k - m1 + 1 << " kmers" << endl;
+    if (k > 63 || m1 > k) { cout << "k must satisfy m <= k <= 63" << endl; return 0; }
+
+    spsp_params P;
+    P.k = k; P.m = m1; P.abundance = abundance; P.flags = SPSP_SCAN_DEFAULT;
+    P.threshold = spsp_threshold_host(k, m1, s);
+
+    mutex io;
+    auto run_one = [&](spsp_ctx* ctx, const string& file) {
+        const string out = out_name(file, output) + ".gz";  // written to the CWD, like the reference
+        spsp_sketch_stats st;
+        memset(&st, 0, sizeof st);
+        const int rc = spsp_sketch_file(ctx, &P, s, file.c_str(), out.c_str(), &st);
+        lock_guard<mutex> g(io);
+        if (rc != SPSP_OK) { cout << "Can't process file: " << file << " (" << spsp_last_error() << ")" << endl; return; }
+        if (verbose) print_stat(st, k, m1, out);
+    };
+
+    if (input != "") {
+        spsp_ctx* ctx = nullptr;
+        if (spsp_create(0, nullptr, &ctx) != SPSP_OK) { cout << "GPU unavailable: " << spsp_last_error() << endl; return 1; }
+        run_one(ctx, input);
+        spsp_destroy(ctx);
+        return 0;
+    }
+    // file of files: one worker (= one context = one HIP stream) per in-flight genome
+    uint8_t* fof_data = nullptr; uint64_t fof_len = 0;
+    if (spsp_read_file_host(inputfof.c_str(), &fof_data, &fof_len) != SPSP_OK) { cout << "Can't open file of file " << inputfof << endl; return 0; }
+    vector<string> files;
+    {
+        istringstream is(string((const char*)fof_data, fof_len));
+        string line;
+        while (getline(is, line))
+            if (line.size() > 3) files.push_back(line);
+        spsp_free(fof_data);
+    }
+    ofstream out_fof(out_name(inputfof, output) + ".txt");
+    size_t next = 0;
+    mutex qm;
+    if (c == 0) c = 1;
+    vector<thread> pool;
+    bool gpu_ok = true;
+    for (unsigned t = 0; t < c; ++t) {
+        pool.emplace_back([&]() {
+            spsp_ctx* ctx = nullptr;
+            if (spsp_create(0, nullptr, &ctx) != SPSP_OK) {
+                lock_guard<mutex> g(io);
+                if (gpu_ok) cout << "GPU unavailable: " << spsp_last_error() << endl;
+                gpu_ok = false;
+                return;
+            }
+            for (;;) {
+                string file;
+                {
+                    lock_guard<mutex> g(qm);
+                    if (next >= files.size()) break;
+                    file = files[next++];
+                    lock_guard<mutex> g2(io);
+                    cout << file << endl;
+                    out_fof << out_name(file, output) + ".gz\n";
+                }
+                run_one(ctx, file);
+            }
+            spsp_destroy(ctx);
+        });
+    }
+    for (auto& th : pool) th.join();
+    out_fof.close();
+    return gpu_ok ? 0 : 1;
+}

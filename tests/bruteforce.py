@@ -115,6 +115,8 @@ def parse_payload(payload):
             assert len(bases) % (2 * half) == 0
             for i in range(0, len(bases), 2 * half):
                 seqs.append(bases[i:i + half] + mini + bases[i + half:i + 2 * half])
+        elif m >= k:
+            seqs.append(mini)  # k == m: the bare minimizer is walked as one k-mer (Comparator.cpp:88-90)
         while True:
             e1 = payload.index(b"\n", pos); l1 = payload[pos:e1]; pos = e1 + 1
             e2 = payload.index(b"\n", pos); l2 = payload[pos:e2]; pos = e2 + 1

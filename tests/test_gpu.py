@@ -1,0 +1,265 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every call goes through the
+C-ABI of libspsp.so and is compared with the CPU oracle on the same seeded
+inputs; full-size inputs are checked through size-independent properties."""
+import gzip
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import bruteforce as bf
+import supersampler_amd as sp
+from oracle import oracle_py as orc
+from supersampler_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = sp.Context(0)
+    yield c
+    c.close()
+
+
+def _oracle_stream(k, m, thr, bases, offs):
+    em, _ = orc.scan(k, m, thr, bases, offs)
+    return em
+
+
+def _assert_stream_equal(got, want):
+    assert len(got) == len(want), (len(got), len(want))
+    for f in ("rec", "minimizer", "start", "len", "rev"):
+        bad = np.nonzero(got[f] != want[f])[0]
+        assert bad.size == 0, (f, int(bad[0]), got[bad[0]], want[bad[0]])
+
+
+MODES = [sp.SPSP_SCAN_DIRECT_HASH, sp.SPSP_SCAN_LDS_FILTER]
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("k,m,s", [(31, 11, 1000), (31, 11, 20), (21, 11, 5), (63, 15, 10), (63, 15, 100),
+                                   (15, 11, 3), (15, 15, 4), (33, 13, 50), (31, 11, 1.5)])
+def test_scan_stream_equals_oracle(ctx, k, m, s, mode):
+    rng = np.random.default_rng(1000 + k + m)
+    gen = [synth.random_genome(rng, n) for n in (300_000, 17, k, 50_001, k - 1, 0, 120_000)]
+    bases, offs = synth.concat_records(gen)
+    p = sp.make_params(k, m, s, flags=mode)
+    assert p.threshold == orc.threshold(k, m, s)
+    got = ctx.scan(p, bases, offs)
+    want = _oracle_stream(k, m, p.threshold, bases, offs)
+    assert len(want) > 0
+    _assert_stream_equal(got, want)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_scan_select_all_and_low_complexity(ctx, mode):
+    """s <= 1 selects every k-mer; homopolymers / tandem repeats drive the
+    duplicate-minimizer tie rules (SubSampler.cpp:89-93, 132-166)."""
+    rng = np.random.default_rng(5)
+    unit = synth.random_genome(rng, 13)
+    recs = [np.frombuffer(b"A" * 500, np.uint8), np.frombuffer(b"ACGT" * 200, np.uint8), np.tile(unit, 60),
+            np.concatenate([synth.random_genome(rng, 300), np.frombuffer(b"T" * 200, np.uint8),
+                            synth.random_genome(rng, 300)]),
+            synth.random_genome(rng, 20_000)]
+    bases, offs = synth.concat_records(recs)
+    for (k, m, s) in [(31, 11, 1.0), (31, 11, 3), (21, 11, 1.0), (63, 15, 2)]:
+        p = sp.make_params(k, m, s, flags=mode)
+        _assert_stream_equal(ctx.scan(p, bases, offs), _oracle_stream(k, m, p.threshold, bases, offs))
+
+
+def test_scan_repeat_rich_genome(ctx):
+    """genome built from a small repeat library: many windows hold the same
+    m-mer twice, on both strands."""
+    rng = np.random.default_rng(77)
+    lib = [synth.random_genome(rng, int(n)) for n in rng.integers(15, 60, size=12)]
+    comp = {65: 84, 67: 71, 71: 67, 84: 65}
+    parts = []
+    for _ in range(4000):
+        u = lib[int(rng.integers(0, len(lib)))]
+        if rng.random() < 0.5:
+            u = np.array([comp[int(c)] for c in u[::-1]], dtype=np.uint8)
+        parts.append(u)
+    g = np.concatenate(parts)
+    bases, offs = synth.concat_records([g])
+    for (k, m, s) in [(31, 11, 4), (21, 11, 1.0), (63, 15, 3)]:
+        for mode in MODES:
+            p = sp.make_params(k, m, s, flags=mode)
+            _assert_stream_equal(ctx.scan(p, bases, offs), _oracle_stream(k, m, p.threshold, bases, offs))
+
+
+def test_scan_edge_inputs(ctx):
+    p = sp.make_params(31, 11, 10)
+    assert len(ctx.scan(p, np.zeros(0, np.uint8), np.zeros(1, np.uint64))) == 0
+    short = np.frombuffer(b"ACGTACGTAC", np.uint8)
+    assert len(ctx.scan(p, short, np.array([0, 10], np.uint64))) == 0
+    rng = np.random.default_rng(3)
+    g = synth.random_genome(rng, 16384 * 3)  # exact tile multiple: halo of the last tile is past the end
+    bases, offs = synth.concat_records([g])
+    _assert_stream_equal(ctx.scan(p, bases, offs), _oracle_stream(31, 11, p.threshold, bases, offs))
+    with pytest.raises(sp.SpspError):
+        ctx.scan(sp.make_params(31, 17, 10), bases, offs)
+    with pytest.raises(sp.SpspError):
+        ctx.scan(p, bases, np.array([5, 10], np.uint64))
+
+
+@pytest.mark.parametrize("k,m,s,ab", [(31, 11, 200, 1), (63, 15, 40, 1), (21, 11, 6, 2)])
+def test_sketch_payload_bytes_equal_oracle(ctx, k, m, s, ab):
+    gs = synth.family_genomes(11, 3, 150_000, 1, [0.0, 0.01, 0.05])
+    for i, g in enumerate(gs):
+        text = synth.to_fasta(g, "g%d" % i, n_records=1 + i)
+        got, gst = ctx.sketch_fasta(text, k, m, s, ab)
+        want, wst = orc.sketch_fasta(text, k, m, s, ab)
+        assert got == want
+        assert gst["selected_kmer_number"] == wst["selected_kmer_number"]
+        assert gst["nb_mmer_selected"] == wst["nb_mmer_selected"]
+
+
+@pytest.mark.parametrize("k,m,s", [(31, 11, 100), (63, 15, 30), (21, 11, 10)])
+def test_compare_equals_oracle(ctx, k, m, s):
+    gs = synth.family_genomes(21, 9, 60_000, 3, [0.0, 0.005, 0.03])
+    gs.append(gs[0].copy())                       # duplicate: J = C = 1
+    gs.append(np.frombuffer(b"ACGT", np.uint8))   # empty sketch
+    payloads = [orc.sketch_fasta(synth.to_fasta(g, "g%d" % i), k, m, s)[0] for i, g in enumerate(gs)]
+    want_inter, want_card, _, _ = orc.compare(payloads)
+    sketches = [sp.sketch_parse(p) for p in payloads]
+    inter, card = ctx.compare(sketches)
+    assert (card == want_card).all()
+    assert (inter == want_inter).all()
+    n = len(gs)
+    assert inter[0, n - 2] == card[0] == card[n - 2] > 0
+    assert want_inter.sum() > 0 and card[n - 1] == 0
+
+
+def test_compare_many_sketches_multiword_columns(ctx):
+    """N > 64 so the colour matrix has several words per row and the triangle
+    skips leading words."""
+    k, m, s = 31, 11, 20
+    gs = synth.family_genomes(5, 150, 6_000, 15, [0.0, 0.01, 0.03, 0.08])
+    payloads = [orc.sketch_fasta(synth.to_fasta(g, "g%d" % i), k, m, s)[0] for i, g in enumerate(gs)]
+    want_inter, want_card, _, _ = orc.compare(payloads)
+    inter, card = ctx.compare([sp.sketch_parse(p) for p in payloads])
+    assert (card == want_card).all() and (inter == want_inter).all()
+    assert np.count_nonzero(want_inter) > 500
+
+
+def test_compare_rejects_unsorted_keys(ctx):
+    sk = sp.sketch_parse(orc.sketch_fasta(synth.to_fasta(synth.random_genome(np.random.default_rng(1), 20000)),
+                                          31, 11, 10)[0])
+    assert len(sk) > 10
+    sk.kmer_lo[[2, 3]] = sk.kmer_lo[[3, 2]]
+    sk.minimizer[[2, 3]] = sk.minimizer[[3, 2]]
+    with pytest.raises(sp.SpspError):
+        ctx.compare([sk, sk])
+
+
+def test_cli_end_to_end_matches_oracle(tmp_path):
+    """bin/sub_sampler + bin/comparator: the drop-in CLIs produce the sketch
+    payloads and CSVs of the reference algorithm."""
+    k, m, s = 31, 11, 50
+    gs = synth.family_genomes(42, 6, 80_000, 2, [0.0, 0.01, 0.04])
+    names = []
+    for i, g in enumerate(gs):
+        path = tmp_path / ("genome%d.fa" % i)
+        data = synth.to_fasta(g, "g%d" % i, n_records=1 + i % 3)
+        if i % 2:
+            path = tmp_path / ("genome%d.fa.gz" % i)
+            path.write_bytes(gzip.compress(data))
+        else:
+            path.write_bytes(data)
+        names.append(str(path))
+    fof = tmp_path / "genomes.txt"
+    fof.write_text("\n".join(names) + "\n")
+    env = dict(os.environ)
+    r = subprocess.run([os.path.join(ROOT, "bin", "sub_sampler"), "-f", str(fof), "-k", str(k), "-m", str(m), "-s",
+                        str(s), "-t", "1", "-p", "sk_"], cwd=tmp_path, env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    listed = (tmp_path / "sk_genomes.txt").read_text().split()
+    assert listed == ["sk_genome%d.gz" % i for i in range(len(gs))]
+    payloads = []
+    for i, nm in enumerate(listed):
+        got = gzip.open(tmp_path / nm, "rb").read()
+        text = sp.read_file(names[i])
+        want, _ = orc.sketch_fasta(text, k, m, float(np.float32(s)))
+        assert got == want, nm
+        payloads.append(want)
+    r = subprocess.run([os.path.join(ROOT, "bin", "comparator"), "-f", "sk_genomes.txt", "-o", "res", "-p", "5"],
+                       cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    inter, card, _, _ = orc.compare(payloads)
+    for jac, fn in ((True, "res_jaccard.csv.gz"), (False, "res_containment.csv.gz")):
+        assert gzip.open(tmp_path / fn, "rb").read() == orc.csv(jac, listed, inter, card, None, 5, 0.0)
+
+
+# ----------------------------------------------------------------- full size --
+def _np_xxh64(x):
+    """vectorised XXH64 of uint64 words, seed 1312 (first principles, not the oracle)."""
+    P1, P2, P3, P4, P5 = (np.uint64(v) for v in (11400714785074694791, 14029467366897019727, 1609587929392839161,
+                                                  9650029242287828579, 2870177450012600261))
+
+    def rotl(v, b):
+        return (v << np.uint64(b)) | (v >> np.uint64(64 - b))
+    with np.errstate(over="ignore"):
+        h = np.uint64(1312) + P5 + np.uint64(8)
+        h = h ^ (rotl(x * P2, 31) * P1)
+        h = rotl(h, 27) * P1 + P4
+        h ^= h >> np.uint64(33); h *= P2
+        h ^= h >> np.uint64(29); h *= P3
+        h ^= h >> np.uint64(32)
+    return h
+
+
+def _np_hit_count(genome, m, thr):
+    codes = ((genome >> 1) & 3).astype(np.uint64)
+    n = len(codes) - m + 1
+    f = np.zeros(n, np.uint64)
+    r = np.zeros(n, np.uint64)
+    for j in range(m):
+        f = (f << np.uint64(2)) | codes[j:j + n]
+        r |= (codes[j:j + n] ^ np.uint64(2)) << np.uint64(2 * j)
+    return int(np.count_nonzero(_np_xxh64(np.minimum(f, r)) <= np.uint64(thr)))
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_full_size_genome_properties(ctx, mode):
+    """one BASELINE-size 5 Mbp genome, k31 m11 s1000: hit count equals a
+    first-principles numpy count; super-k-mers are disjoint, in order, inside
+    their record, each holds its minimizer with hash <= T; revcomp of the
+    genome selects the mirrored k-mers; a duplicate record repeats the stream."""
+    import torch  # device memory only
+    k, m, s = 31, 11, 1000
+    rng = np.random.default_rng(2)
+    g = synth.random_genome(rng, 5_000_000)
+    p = sp.make_params(k, m, s, flags=mode)
+    d = torch.from_numpy(g.copy()).cuda()
+    hits = ctx.scan_hits_device(p, d.data_ptr(), d.numel())
+    assert hits == _np_hit_count(g, m, p.threshold)
+    bases, offs = synth.concat_records([g, g])
+    em = ctx.scan(p, bases, offs)
+    a, b = em[em["rec"] == 0], em[em["rec"] == 1]
+    assert len(a) == len(b) > 100
+    for f in ("minimizer", "start", "len", "rev"):
+        assert (a[f] == b[f]).all()
+    ends = a["start"] + a["len"]
+    assert (a["len"] >= k).all() and (a["len"] <= 2 * k - m).all() and (ends <= len(g)).all()
+    # disjoint k-mer ranges in genome order
+    assert (a["start"][1:] >= a["start"][:-1] + a["len"][:-1] - k + 1).all()
+    for e in a[:: max(1, len(a) // 200)]:
+        seg = g[int(e["start"]):int(e["start"]) + int(e["len"])].tobytes().decode()
+        ms = bf.to_str(int(e["minimizer"]), m)
+        assert (ms in bf.rc_str(seg)) if e["rev"] else (ms in seg)
+        assert orc.xxh64(int(e["minimizer"])) <= p.threshold
+    comp = np.zeros(256, np.uint8)
+    comp[[65, 67, 71, 84]] = [84, 71, 67, 65]
+    rc = comp[g[::-1]]
+    em_rc = ctx.scan(p, *synth.concat_records([rc]))
+    sel = lambda e: int((e["len"] - k + 1).sum())
+    assert sel(em_rc) == sel(a)
+    sk_f = sp.sketch_parse(sp.sketch_build(p, s, bases[:len(g)], offs[:2], a)[0])
+    sk_r = sp.sketch_parse(sp.sketch_build(p, s, rc, np.array([0, len(rc)], np.uint64), em_rc)[0])
+    assert sk_f.key_set() == sk_r.key_set()  # canonical k-mers do not depend on the strand read
+    inter, card = ctx.compare([sk_f, sk_r])
+    assert inter[0, 1] == card[0] == card[1]

@@ -1,0 +1,190 @@
+"""CPU tests: the C-ABI library loads and exports what include/spsp.h declares,
+the GPU entry points fail loudly without a device, and the host side of the
+CLIs (ingest, sketch builder/reader, CSV, gz I/O) matches the oracle byte for
+byte.  No GPU compute is called here."""
+import ctypes as C
+import gzip
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import bruteforce as bf
+import supersampler_amd as sp
+from oracle import oracle_py as orc
+from supersampler_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _has_gpu():
+    try:
+        out = subprocess.run(["/opt/rocm/bin/rocminfo"], capture_output=True, text=True, timeout=60).stdout
+        return "gfx950" in out
+    except Exception:
+        return False
+
+
+def test_header_symbols_all_exported():
+    hdr = open(os.path.join(ROOT, "include", "spsp.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(spsp_[a-z_0-9]+)\s*\(", hdr)))
+    assert declared == sorted(sp.ABI_SYMBOLS)
+    L = sp.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert b"gfx950" in L.spsp_version()
+
+
+def test_library_carries_gfx950_code_object():
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--list", "--type=o",
+                          "--input=" + sp.LIB_PATH], capture_output=True, text=True)
+    blob = open(sp.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob and (b"k_dense" in blob), out.stderr
+
+
+@pytest.mark.skipif(_has_gpu(), reason="a GPU is present; the loud-failure path is for GPU-less hosts")
+def test_gpu_entry_points_fail_loudly_without_device():
+    with pytest.raises(sp.SpspError) as e:
+        sp.Context(0)
+    assert "no CPU fallback" in str(e.value) or "no HIP device" in str(e.value)
+
+
+def test_threshold_matches_oracle():
+    for (k, m, s) in [(31, 11, 1000), (63, 15, 100), (31, 11, 2), (21, 11, 50), (31, 15, 10000), (15, 15, 3),
+                      (31, 11, 1.0), (31, 11, 0.3), (31, 11, float(np.float32(0.1) * 0 + 1.5))]:
+        assert sp.threshold(k, m, s) == orc.threshold(k, m, s)
+
+
+FASTA_CASES = [
+    b">r1 desc\nACGTNNacgt\r\nGG\n>r2\n\nTTTT\n>empty\n>r4\nAC",
+    b"ACGT\nGGGG\n",
+    b"",
+    b">only header",
+    b">h\n",
+    b"\n\n>x\nAC\n\n\nGT\n>y\nNNNN\n>z\nacgtn",
+    b">a\nAC\xffGT\n\xff\nTT\n",
+    b">a\nACGT",
+]
+
+
+@pytest.mark.parametrize("text", FASTA_CASES)
+def test_fasta_clean_matches_oracle(text):
+    b1, o1 = sp.clean_fasta(text)
+    b2, o2 = orc.clean_fasta(text)
+    assert o1.tolist() == o2.tolist()
+    assert b1.tobytes() == b2.tobytes()
+
+
+def _stream_and_payload(text, k, m, s, abundance=1):
+    bases, offs = orc.clean_fasta(text)
+    T = orc.threshold(k, m, s)
+    em, _ = orc.scan(k, m, T, bases, offs)
+    payload, st = orc.sketch_fasta(text, k, m, s, abundance)
+    return bases, offs, em, payload, st
+
+
+@pytest.mark.parametrize("k,m,s,ab", [(31, 11, 30, 1), (21, 11, 4, 1), (63, 15, 12, 1), (31, 11, 6, 2),
+                                      (15, 15, 3, 1), (31, 11, 1, 1), (33, 13, 9, 3)])
+def test_sketch_builder_matches_oracle_bytes(k, m, s, ab):
+    rng = np.random.default_rng(k * 100 + m + ab)
+    anc = bf.random_dna(rng, 3000)
+    recs = [anc, bf.mutate(rng, anc, 0.01), anc[500:1500], bf.random_dna(rng, 40), "A" * 120, "ACGTTGCA" * 30]
+    text = bf.fasta(recs)
+    bases, offs, em, payload, st = _stream_and_payload(text, k, m, s, ab)
+    p = sp.make_params(k, m, s, ab)
+    got, gst = sp.sketch_build(p, s, bases, offs, em)
+    assert got == payload
+    for f in ("selected_kmer_number", "selected_superkmer_number", "count_maximal_skmer",
+              "seen_kmers_at_reconstruction", "seen_superkmers_at_reconstruction",
+              "seen_max_superkmers_at_reconstruction", "actual_minimizer_number", "read_kmer", "nb_mmer_selected"):
+        assert gst[f] == st[f], f
+
+
+def test_sketch_builder_count_wraps_at_256():
+    """H4: a k-mer seen 256 times has count 0 and fails `count >= abundance`."""
+    k, m, s = 21, 11, 1.0
+    unit = bf.random_dna(np.random.default_rng(4), 60)
+    text = bf.fasta([unit] * 256 + [unit[:40]])
+    bases, offs, em, payload, st = _stream_and_payload(text, k, m, s)
+    got, _ = sp.sketch_build(sp.make_params(k, m, s), s, bases, offs, em)
+    assert got == payload
+    full = bf.sketch_set([unit], k, m, 2**64 - 1)
+    kept = bf.payload_set(payload)
+    assert kept < full and len(kept) > 0  # the k-mers past position 40 were seen exactly 256 times and vanish
+
+
+@pytest.mark.parametrize("k,m,s", [(31, 11, 25), (63, 15, 8), (21, 11, 3), (15, 15, 2)])
+def test_sketch_reader_matches_bruteforce_and_oracle(k, m, s):
+    rng = np.random.default_rng(k + m)
+    anc = bf.random_dna(rng, 4000)
+    gs = [[anc], [bf.mutate(rng, anc, 0.02), bf.random_dna(rng, 300)], [bf.random_dna(rng, 2500)]]
+    payloads = [orc.sketch_fasta(bf.fasta(g), k, m, s)[0] for g in gs]
+    inter, card, kk, mm = orc.compare(payloads)
+    for i, pl in enumerate(payloads):
+        sk = sp.sketch_parse(pl)
+        assert (sk.k, sk.m) == (k, m)
+        assert sk.key_set() == bf.payload_set(pl)
+        assert len(sk) == card[i]
+        keys = list(zip(sk.minimizer.tolist(), sk.kmer_hi.tolist(), sk.kmer_lo.tolist()))
+        assert keys == sorted(set(keys))
+
+
+def test_sketch_reader_empty_and_bad_input():
+    payload, _ = orc.sketch_fasta(b">x\nACGT\n", 31, 11, 1000)
+    sk = sp.sketch_parse(payload)
+    assert len(sk) == 0 and (sk.k, sk.m) == (31, 11)
+    with pytest.raises(sp.SpspError):
+        sp.sketch_parse(b"no newline here")
+    with pytest.raises(sp.SpspError):
+        sp.sketch_parse(b"51 11 3 1000.000000\nACGTACGTACG\xff\xff\xff\x7f")
+
+
+@pytest.mark.parametrize("prec,thr", [(6, 0.0), (3, 0.0), (12, 0.0), (6, 0.4), (1, 0.0), (0, 0.0)])
+def test_csv_matches_oracle(prec, thr):
+    rng = np.random.default_rng(prec + 17)
+    n = 7
+    card = rng.integers(50, 5000, size=n).astype(np.uint64)
+    inter = np.zeros((n, n), dtype=np.uint32)
+    for i in range(n):
+        for j in range(i + 1, n):
+            if rng.random() < 0.7:
+                inter[i, j] = rng.integers(1, int(min(card[i], card[j])) + 1)
+    inter[0, 1] = card[0] = card[1]  # J = C = 1
+    names = ["dir/sk_%d.gz" % i for i in range(n)]
+    for jac in (True, False):
+        for nq in (n, 3):
+            assert sp.csv(jac, names, inter, card, nq, prec, thr) == orc.csv(jac, names, inter, card, nq, prec, thr)
+
+
+def test_gz_io_roundtrip(tmp_path):
+    data = os.urandom(1000) + b"ACGT" * 100000
+    p = str(tmp_path / "x.gz")
+    sp.write_gz(p, data, 9)
+    assert gzip.open(p, "rb").read() == data       # a real gzip container
+    assert sp.read_file(p) == data
+    q = str(tmp_path / "plain.txt")
+    open(q, "wb").write(data)
+    assert sp.read_file(q) == data                  # zstr autodetect: plain passes through
+    r = str(tmp_path / "multi.gz")
+    with open(r, "wb") as f:                        # concatenated members
+        f.write(gzip.compress(b"hello "))
+        f.write(gzip.compress(b"world"))
+    assert sp.read_file(r) == b"hello world"
+    e = str(tmp_path / "empty")
+    open(e, "wb").close()
+    assert sp.read_file(e) == b""
+    with pytest.raises(sp.SpspError):
+        sp.read_file(str(tmp_path / "missing"))
+
+
+def test_synth_generators_are_seeded():
+    a = synth.family_genomes(7, 6, 2000, 2, [0.0, 0.01, 0.05])
+    b = synth.family_genomes(7, 6, 2000, 2, [0.0, 0.01, 0.05])
+    assert all((x == y).all() for x, y in zip(a, b))
+    assert (a[0] != a[1]).sum() > 0 and (a[0] != a[3]).mean() > 0.5
+    fa = synth.to_fasta(a[0], "g0", n_records=3)
+    bases, off = sp.clean_fasta(fa)
+    assert bases.tobytes() == a[0].tobytes() and len(off) == 4
