@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path of BASELINE.json on N MI355X (one process per GPU).
+
+A "step" is one pass of the hot path over one batch of synthetic input that is
+already resident in HBM: the minimizer scan of this rank's genomes
+(spsp_scan_device) followed by this rank's share of the all-vs-all sketch
+comparison (spsp_compare_device).  Workload = BASELINE.json configs[1]:
+100 synthetic 5 Mbp genomes per GPU, k=31 m=11 s=1000.
+
+N > 1: genomes are sharded by rank (no data-path collective for the scan); the
+comparison all-gathers the packed sketch keys over RCCL and every rank owns the
+rows i % N == rank of the (100 N) x (100 N) pair matrix.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch  # device memory, streams, torch.distributed -- plumbing (imported before libspsp, see package docstring)
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import supersampler_amd as sp  # noqa: E402
+from supersampler_amd import synth  # noqa: E402
+
+K, M, S = 31, 11, 1000.0
+N_GENOMES, GENOME_LEN, N_FAMILIES, MUS = 100, 5_000_000, 10, [0.001, 0.01]
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def log(msg):
+    print("[bench] " + msg, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--genomes", type=int, default=N_GENOMES, help="genomes per GPU (default = BASELINE config)")
+    ap.add_argument("--length", type=int, default=GENOME_LEN)
+    ap.add_argument("--mode", choices=["default", "direct", "filter"], default="default")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
+                             % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    flags = {"default": sp.SPSP_SCAN_DEFAULT, "direct": sp.SPSP_SCAN_DIRECT_HASH, "filter": sp.SPSP_SCAN_LDS_FILTER}[args.mode]
+    p = sp.make_params(K, M, S, flags=flags)
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = sp.Context(local_rank, stream if stream else None)
+
+    # ------------------------------------------------------------------ setup (untimed)
+    t_setup = time.time()
+    genomes = synth.family_genomes(2 + 1000 * rank, args.genomes, args.length, N_FAMILIES, MUS)
+    recs = []
+    for i, g in enumerate(genomes):  # 1-3 records per genome
+        nr = 1 + i % 3
+        cuts = [len(g) * j // nr for j in range(nr + 1)]
+        recs += [g[cuts[j]:cuts[j + 1]] for j in range(nr)]
+    bases, rec_off = synth.concat_records(recs)
+    kmers_per_step = int(sum(max(0, len(r) - K + 1) for r in recs))
+    d_bases = torch.from_numpy(bases).to(dev)
+    d_off = torch.from_numpy(rec_off.view(np.int64)).to(dev)
+    # sketches of this rank's genomes -> packed keys (host side of the CLIs, outside the timed region)
+    sketches = []
+    r0 = 0
+    for i, g in enumerate(genomes):
+        nr = 1 + i % 3
+        gb, go = synth.concat_records(recs[r0:r0 + nr])
+        r0 += nr
+        em = ctx.scan(p, gb, go)
+        payload, _ = sp.sketch_build(p, S, gb, go, em)
+        sketches.append(sp.sketch_parse(payload))
+    my_n = np.array([len(s) for s in sketches], dtype=np.int64)
+    my_min = np.concatenate([s.minimizer for s in sketches]).astype(np.uint32)
+    my_lo = np.concatenate([s.kmer_lo for s in sketches]).astype(np.uint64)
+    d_my_min = torch.from_numpy(my_min.view(np.int32)).to(dev)
+    d_my_lo = torch.from_numpy(my_lo.view(np.int64)).to(dev)
+    n_total = args.genomes * world
+    if world > 1:
+        sizes = [torch.zeros(args.genomes, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(sizes, torch.from_numpy(my_n).to(dev))
+        all_n = torch.stack(sizes).cpu().numpy()           # [world, genomes]
+        per_rank = all_n.sum(axis=1)
+        pad = int(per_rank.max())
+        # global sketch index of (rank r, local g) = r * genomes + g; keys stored rank-major with padding removed below
+        sk_off = np.zeros(n_total + 1, dtype=np.uint64)
+        sk_off[1:] = np.cumsum(all_n.reshape(-1))
+        d_pad_min = torch.zeros(pad, dtype=torch.int32, device=dev)
+        d_pad_lo = torch.zeros(pad, dtype=torch.int64, device=dev)
+        d_pad_min[:len(my_min)] = d_my_min
+        d_pad_lo[:len(my_lo)] = d_my_lo
+        d_gather_min = torch.empty(world * pad, dtype=torch.int32, device=dev)
+        d_gather_lo = torch.empty(world * pad, dtype=torch.int64, device=dev)
+        d_all_min = torch.empty(int(per_rank.sum()), dtype=torch.int32, device=dev)
+        d_all_lo = torch.empty(int(per_rank.sum()), dtype=torch.int64, device=dev)
+        starts = np.concatenate([[0], np.cumsum(per_rank)]).astype(np.int64)
+    else:
+        sk_off = np.zeros(n_total + 1, dtype=np.uint64)
+        sk_off[1:] = np.cumsum(my_n)
+        d_all_min, d_all_lo = d_my_min, d_my_lo
+    d_inter = torch.zeros((n_total, n_total), dtype=torch.int32, device=dev)
+    pairs_per_step = n_total * (n_total - 1) // 2
+    torch.cuda.synchronize()
+    if rank == 0:
+        log("setup %.1fs: %d genomes x %d bp per GPU, %d records, %d k-mers/step/GPU, %d sketch keys, %d pairs"
+            % (time.time() - t_setup, args.genomes, args.length, len(recs), kmers_per_step, int(sk_off[-1]), pairs_per_step))
+
+    def step():
+        d_out, n_out = ctx.scan_device(p, d_bases.data_ptr(), d_bases.numel(), d_off.data_ptr(), len(recs))
+        ctx.device_free(d_out)
+        if world > 1:  # the one data-path collective: packed sketch keys over RCCL/xGMI
+            dist.all_gather_into_tensor(d_gather_min, d_pad_min)
+            dist.all_gather_into_tensor(d_gather_lo, d_pad_lo)
+            for r in range(world):
+                d_all_min[starts[r]:starts[r + 1]] = d_gather_min[r * pad:r * pad + int(per_rank[r])]
+                d_all_lo[starts[r]:starts[r + 1]] = d_gather_lo[r * pad:r * pad + int(per_rank[r])]
+        ctx.compare_device(K, d_all_min.data_ptr(), d_all_lo.data_ptr(), None, sk_off, n_total, rank, world,
+                           d_inter.data_ptr())
+        return n_out
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.timing_enable(True)
+    ctx.timing_read()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        n_out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    tm = ctx.timing_read()
+    ctx.timing_enable(False)
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    agg = torch.tensor([float(kmers_per_step), tm["dense_ms"], tm["compare_ms"], tm["scan_ms"], tm["accumulate_ms"]],
+                       dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        mx = agg.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        total_kmers_per_step = float(agg[0].item())
+        dense_ms, compare_ms, scan_ms, acc_ms = (float(mx[i].item()) for i in (1, 2, 3, 4))
+    else:
+        total_kmers_per_step = float(kmers_per_step)
+        dense_ms, compare_ms, scan_ms, acc_ms = tm["dense_ms"], tm["compare_ms"], tm["scan_ms"], tm["accumulate_ms"]
+    elapsed = float(el.item())
+
+    # sanity: the comparison produced something (family structure => shared k-mers)
+    inter_nonzero = int(torch.count_nonzero(d_inter).item())
+
+    if rank == 0:
+        value = total_kmers_per_step * args.steps / elapsed
+        dense_avg_ms = dense_ms / max(1, tm["dense_launches"])
+        achieved = (d_bases.numel() / 1e9) / (dense_avg_ms / 1e3) if dense_avg_ms > 0 else 0.0  # 1 B per position (ASCII)
+        compare_avg_ms = compare_ms / max(1, tm["compare_calls"])
+        out = {
+            "metric": "k-mers hashed/s (sketch) + sketch-pairs/s (all-vs-all)",
+            "value": value,
+            "unit": "k-mers hashed/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed * 1e3 / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: %d synthetic %d bp genomes per GPU (10 families, mu 0.001/0.01), "
+                                   "k=31 m=11 s=1000, scan + all-vs-all; inputs resident in HBM" % (args.genomes, args.length),
+                       "k": K, "m": M, "s": S, "genomes_per_gpu": args.genomes, "genome_len": args.length,
+                       "sketches_total": n_total, "scan_mode": args.mode,
+                       "parallelism": "genomes sharded by rank; pair-matrix rows i%N==rank after RCCL all-gather of sketch keys"},
+            "sketch_pairs_per_s": pairs_per_step / (compare_avg_ms / 1e3) if compare_avg_ms > 0 else None,
+            "stage_ms": {"scan_pipeline": scan_ms / max(1, tm["scan_calls"]), "dense_kernel": dense_avg_ms,
+                         "compare_pipeline": compare_avg_ms, "accumulate_kernel": acc_ms / max(1, tm["accumulate_launches"])},
+            "superkmers_per_step": int(n_out), "inter_nonzero": inter_nonzero,
+            "roofline": {"kernel": "k_dense (hash + threshold at every m-mer position)", "bound": "hbm",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None,
+                         "algorithmic_bytes_per_launch": int(d_bases.numel())},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(recs, sketches, p)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(recs, sketches, p):
+    """The reference-algorithm CPU restatement (oracle/) timed on this host, rank 0, N=1 only.
+    Checker code used as a reported baseline -- never on the product path."""
+    from oracle import oracle_py as orc
+    budget, spent, kmers, used = 12.0, 0.0, 0, 0
+    for r in recs:  # bounded sample: whole records until ~12 s of single-thread CPU work
+        if spent >= budget:
+            break
+        b, o = synth.concat_records([r])
+        sec, km, _ = orc.scan_timed(K, M, p.threshold, b, o)
+        spent += sec; kmers += km; used += 1
+    return {"value": kmers / spent if spent > 0 else None, "unit": "k-mers hashed/s", "cores": 1, "kind": "port",
+            "sample": "oracle scan loop (SubSampler.cpp:357-455 restated), single thread, first %d of %d records "
+                      "of the same workload, %.1f s" % (used, len(recs), spent)}
+
+
+if __name__ == "__main__":
+    main()

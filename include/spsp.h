@@ -82,6 +82,23 @@ const char* spsp_version(void);
 void spsp_free(void* host_ptr);
 void spsp_device_free(spsp_ctx* ctx, void* device_ptr);
 
+/* ------------------------------------------------------------ measurement -- */
+/* HIP-event timing of the two dominant kernels and of the whole pipelines, on
+ * the context's stream (bench.py's `roofline` numbers come from here). */
+typedef struct spsp_timing {
+    double dense_ms;       /* k_dense: hash + threshold over every m-mer position */
+    uint64_t dense_launches;
+    double scan_ms;        /* whole spsp_scan_device pipeline */
+    uint64_t scan_calls;
+    double accumulate_ms;  /* k_accumulate: colour-matrix row sums */
+    uint64_t accumulate_launches;
+    double compare_ms;     /* whole spsp_compare_device pipeline */
+    uint64_t compare_calls;
+} spsp_timing;
+int spsp_timing_enable(spsp_ctx* ctx, int on);
+/* synchronises the stream, returns the totals since the previous read and resets them */
+int spsp_timing_read(spsp_ctx* ctx, spsp_timing* out);
+
 /* ------------------------------------------------------------- path A ---- */
 /* Subsampler::compute_threshold + ctor selection (SubSampler.cpp:622-631,
  * SubSampler.h:79-83). Host long double, as the reference. */

@@ -42,12 +42,18 @@ class SketchStats(C.Structure):
                  "seen_max_superkmers_at_reconstruction", "actual_minimizer_number", "nb_mmer_selected")]
 
 
+class Timing(C.Structure):
+    _fields_ = [("dense_ms", C.c_double), ("dense_launches", C.c_uint64), ("scan_ms", C.c_double),
+                ("scan_calls", C.c_uint64), ("accumulate_ms", C.c_double), ("accumulate_launches", C.c_uint64),
+                ("compare_ms", C.c_double), ("compare_calls", C.c_uint64)]
+
+
 SUPERKMER_DTYPE = np.dtype([("rec", "<u4"), ("minimizer", "<u4"), ("start", "<u8"), ("len", "<u4"), ("rev", "<u4")])
 
 # every symbol include/spsp.h declares (tests check the .so exports them all)
 ABI_SYMBOLS = [
     "spsp_create", "spsp_destroy", "spsp_last_error", "spsp_version", "spsp_free", "spsp_device_free",
-    "spsp_threshold_host", "spsp_scan", "spsp_scan_device", "spsp_scan_hits_device", "spsp_compare",
+    "spsp_timing_enable", "spsp_timing_read", "spsp_threshold_host", "spsp_scan", "spsp_scan_device", "spsp_scan_hits_device", "spsp_compare",
     "spsp_compare_device", "spsp_fasta_clean_host", "spsp_sketch_build_host", "spsp_sketch_parse_host",
     "spsp_csv_host", "spsp_read_file_host", "spsp_write_gz_host", "spsp_sketch_file", "spsp_compare_files",
 ]
@@ -71,6 +77,8 @@ def lib():
     L.spsp_version.restype = cp; L.spsp_version.argtypes = []
     L.spsp_free.restype = None; L.spsp_free.argtypes = [vp]
     L.spsp_device_free.restype = None; L.spsp_device_free.argtypes = [vp, vp]
+    L.spsp_timing_enable.restype = i32; L.spsp_timing_enable.argtypes = [vp, i32]
+    L.spsp_timing_read.restype = i32; L.spsp_timing_read.argtypes = [vp, P(Timing)]
     L.spsp_threshold_host.restype = u64; L.spsp_threshold_host.argtypes = [u32, u32, dbl]
     L.spsp_scan.restype = i32; L.spsp_scan.argtypes = [vp, P(Params), vp, vp, u32, P(vp), P(u64)]
     L.spsp_scan_device.restype = i32
@@ -213,6 +221,16 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    # ---- measurement
+    def timing_enable(self, on=True):
+        _check(lib().spsp_timing_enable(self._h, 1 if on else 0))
+
+    def timing_read(self):
+        """HIP-event totals since the last read (synchronises the stream) as a dict."""
+        t = Timing()
+        _check(lib().spsp_timing_read(self._h, C.byref(t)))
+        return {f: getattr(t, f) for f, _ in Timing._fields_}
 
     # ---- path A
     def scan(self, params, bases, rec_off):

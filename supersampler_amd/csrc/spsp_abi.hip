@@ -46,7 +46,52 @@ void DevBuf::release() {
 
 using namespace spsp;
 
+int spsp_ctx::ev_begin(int kind) {
+    if (!timing) return SPSP_OK;
+    EventLog& L = evlog[kind];
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (!L.spare.empty()) { ev = L.spare.back(); L.spare.pop_back(); }
+    else { SPSP_HIP(hipEventCreate(&ev.first)); SPSP_HIP(hipEventCreate(&ev.second)); }
+    L.used.push_back(ev);
+    SPSP_HIP(hipEventRecord(ev.first, stream));
+    return SPSP_OK;
+}
+int spsp_ctx::ev_end(int kind) {
+    if (!timing) return SPSP_OK;
+    SPSP_HIP(hipEventRecord(evlog[kind].used.back().second, stream));
+    return SPSP_OK;
+}
+
 extern "C" {
+
+int spsp_timing_enable(spsp_ctx* ctx, int on) {
+    if (!ctx) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    ctx->timing = on != 0;
+    return SPSP_OK;
+}
+
+int spsp_timing_read(spsp_ctx* ctx, spsp_timing* out) {
+    if (!ctx || !out) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    SPSP_HIP(hipSetDevice(ctx->device));
+    SPSP_HIP(hipStreamSynchronize(ctx->stream));
+    double ms[kEvKinds]; uint64_t cnt[kEvKinds];
+    for (int kind = 0; kind < kEvKinds; ++kind) {
+        ms[kind] = 0; cnt[kind] = 0;
+        EventLog& L = ctx->evlog[kind];
+        for (auto& ev : L.used) {
+            float t = 0;
+            SPSP_HIP(hipEventElapsedTime(&t, ev.first, ev.second));
+            ms[kind] += t; ++cnt[kind];
+            L.spare.push_back(ev);
+        }
+        L.used.clear();
+    }
+    out->dense_ms = ms[kEvDense]; out->dense_launches = cnt[kEvDense];
+    out->scan_ms = ms[kEvScan]; out->scan_calls = cnt[kEvScan];
+    out->accumulate_ms = ms[kEvAccumulate]; out->accumulate_launches = cnt[kEvAccumulate];
+    out->compare_ms = ms[kEvCompare]; out->compare_calls = cnt[kEvCompare];
+    return SPSP_OK;
+}
 
 const char* spsp_last_error(void) { return g_err.c_str(); }
 const char* spsp_version(void) { return "spsp-mi355x 0.1 (gfx950)"; }
@@ -94,6 +139,10 @@ void spsp_destroy(spsp_ctx* c) {
                       &c->c_owner, &c->c_rowid, &c->c_slot, &c->c_row, &c->c_matrix, &c->c_inter, &c->c_flags,
                       &c->c_skoff};
     for (DevBuf* b : bufs) b->release();
+    for (int kind = 0; kind < kEvKinds; ++kind) {
+        for (auto* v : {&c->evlog[kind].used, &c->evlog[kind].spare})
+            for (auto& ev : *v) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    }
     if (c->h_scalar) (void)hipHostFree(c->h_scalar);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;

@@ -173,9 +173,9 @@ __global__ __launch_bounds__(kAccThreads) void k_accumulate(const uint32_t* __re
     if (active && col > i && col < n) inter[(uint64_t)i * n + col] = cnt;
 }
 
-int compare_device_impl(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min, const uint64_t* d_lo,
-                        const uint64_t* d_hi, const uint64_t* h_sk_off, uint32_t n, uint32_t row_first,
-                        uint32_t row_stride, uint32_t* d_inter) {
+static int compare_device_inner(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min, const uint64_t* d_lo,
+                                const uint64_t* d_hi, const uint64_t* h_sk_off, uint32_t n, uint32_t row_first,
+                                uint32_t row_stride, uint32_t* d_inter) {
     if (n == 0) return SPSP_OK;
     if (n > 65535) { set_error("at most 65535 sketches (the reference's uint32 pair key, Comparator.h:26)"); return SPSP_ERR_ARG; }
     if (row_stride == 0 || row_first >= row_stride) { set_error("bad row partition %u/%u", row_first, row_stride); return SPSP_ERR_ARG; }
@@ -235,11 +235,23 @@ int compare_device_impl(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min, const 
                        ctx->c_table.as<uint64_t>(), log2cap, ctx->c_owner.as<uint32_t>(), ctx->c_rowid.as<uint32_t>(),
                        W, ctx->c_matrix.as<unsigned long long>(), ctx->c_row.as<uint32_t>());
     SPSP_HIP(hipGetLastError());
+    if ((rc = ctx->ev_begin(kEvAccumulate))) return rc;
     hipLaunchKernelGGL(k_accumulate, dim3((W + 3) / 4, n_own), dim3(kAccThreads), 0, ctx->stream,
                        ctx->c_row.as<uint32_t>(), ctx->c_matrix.as<uint64_t>(), W, sk, n, row_first, row_stride,
                        d_inter);
     SPSP_HIP(hipGetLastError());
+    if ((rc = ctx->ev_end(kEvAccumulate))) return rc;
     return SPSP_OK;
+}
+
+int compare_device_impl(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min, const uint64_t* d_lo,
+                        const uint64_t* d_hi, const uint64_t* h_sk_off, uint32_t n, uint32_t row_first,
+                        uint32_t row_stride, uint32_t* d_inter) {
+    int rc = ctx->ev_begin(kEvCompare);
+    if (rc) return rc;
+    rc = compare_device_inner(ctx, k, d_min, d_lo, d_hi, h_sk_off, n, row_first, row_stride, d_inter);
+    const int rc2 = ctx->ev_end(kEvCompare);
+    return rc ? rc : rc2;
 }
 
 }  // namespace spsp

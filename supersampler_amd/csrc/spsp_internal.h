@@ -6,6 +6,8 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "../../include/spsp.h"
 
@@ -42,7 +44,20 @@ struct Hit {
 
 }  // namespace spsp
 
+namespace spsp {
+// HIP-event pairs recorded around one kind of launch
+struct EventLog {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> used, spare;
+};
+enum { kEvDense = 0, kEvScan = 1, kEvAccumulate = 2, kEvCompare = 3, kEvKinds = 4 };
+}  // namespace spsp
+
 struct spsp_ctx {
+    bool timing = false;
+    spsp::EventLog evlog[spsp::kEvKinds];
+    // begin/end bracket for one timed region; no-ops unless timing is on
+    int ev_begin(int kind);
+    int ev_end(int kind);
     int device = 0;
     int n_cu = 256;
     hipStream_t stream = nullptr;

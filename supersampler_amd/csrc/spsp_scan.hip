@@ -432,9 +432,11 @@ static int launch_dense(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_ba
     if ((rc = ctx->bitmap.reserve((size_t)n_tiles * kTileWords * 4))) return rc;
     if ((rc = ctx->tile_count.reserve((size_t)n_tiles * 4))) return rc;
     if ((rc = ctx->tile_off.reserve((size_t)(n_tiles + 1) * 4))) return rc;
-    if (want_filter(p)) {
-        uint32_t words = 0, shift = 0;
-        if ((rc = ensure_filter(ctx, p, &words, &shift))) return rc;
+    const bool filtered = want_filter(p);
+    uint32_t words = 0, shift = 0;
+    if (filtered && (rc = ensure_filter(ctx, p, &words, &shift))) return rc;
+    if ((rc = ctx->ev_begin(kEvDense))) return rc;
+    if (filtered) {
         static bool attr_set = false;
         if (!attr_set) {
             SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense<1, 4>),
@@ -454,6 +456,7 @@ static int launch_dense(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_ba
                            ctx->tile_count.as<uint32_t>());
     }
     SPSP_HIP(hipGetLastError());
+    if ((rc = ctx->ev_end(kEvDense))) return rc;
     hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->tile_count.as<uint32_t>(),
                        ctx->tile_off.as<uint32_t>(), n_tiles, ctx->h_scalar + 0);
     SPSP_HIP(hipGetLastError());
@@ -475,9 +478,9 @@ int scan_hits_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, 
     return SPSP_OK;
 }
 
-int scan_device_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, uint64_t n_bases,
-                     const uint64_t* d_rec_off, uint32_t n_rec, spsp_superkmer** d_out, uint64_t* n_out,
-                     bool own_output) {
+static int scan_device_inner(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, uint64_t n_bases,
+                             const uint64_t* d_rec_off, uint32_t n_rec, spsp_superkmer** d_out, uint64_t* n_out,
+                             bool own_output) {
     int rc = check_params(p);
     if (rc) return rc;
     *d_out = nullptr; *n_out = 0;
@@ -522,6 +525,16 @@ int scan_device_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases
     SPSP_HIP(hipGetLastError());
     *d_out = out; *n_out = n_em;
     return SPSP_OK;
+}
+
+int scan_device_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, uint64_t n_bases,
+                     const uint64_t* d_rec_off, uint32_t n_rec, spsp_superkmer** d_out, uint64_t* n_out,
+                     bool own_output) {
+    int rc = ctx->ev_begin(kEvScan);
+    if (rc) return rc;
+    rc = scan_device_inner(ctx, p, d_bases, n_bases, d_rec_off, n_rec, d_out, n_out, own_output);
+    const int rc2 = ctx->ev_end(kEvScan);
+    return rc ? rc : rc2;
 }
 
 }  // namespace spsp

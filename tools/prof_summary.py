@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 --kernel-trace CSV for bench.py runs.
+
+bench.py's setup phase launches the same kernels on single genomes; the timed
+steps are the launches with the largest grid of each kernel, so the summary is
+restricted to those ("steady" columns) next to the all-launch totals.
+
+usage: tools/prof_summary.py <kernel_trace.csv> [out.md]
+"""
+import csv
+import re
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    name = re.sub(r"\(.*", "", name)
+    name = name.replace("void ", "").replace("spsp::", "")
+    return name[:60]
+
+
+def main():
+    rows = list(csv.DictReader(open(sys.argv[1])))
+    per = defaultdict(list)
+    for r in rows:
+        if r["Kind"] != "KERNEL_DISPATCH":
+            continue
+        dur = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        grid = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"])
+        per[short(r["Kernel_Name"])].append((dur, grid, r["VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"],
+                                            r["Workgroup_Size_X"]))
+    lines = ["| kernel | launches | total us | steady launches | steady avg us | steady min us | grid | wg | VGPR | SGPR | static LDS |",
+             "|---|---|---|---|---|---|---|---|---|---|---|"]
+    order = sorted(per.items(), key=lambda kv: -sum(d[0] for d in kv[1]))
+    for name, ds in order:
+        gmax = max(d[1] for d in ds)
+        steady = [d for d in ds if d[1] == gmax]
+        tot = sum(d[0] for d in ds) / 1e3
+        avg = sum(d[0] for d in steady) / len(steady) / 1e3
+        mn = min(d[0] for d in steady) / 1e3
+        lines.append("| %s | %d | %.1f | %d | %.2f | %.2f | %d | %s | %s | %s | %s |" % (
+            name, len(ds), tot, len(steady), avg, mn, gmax, steady[0][5], steady[0][2], steady[0][3], steady[0][4]))
+    out = "\n".join(lines) + "\n"
+    if len(sys.argv) > 2:
+        open(sys.argv[2], "w").write(out)
+    print(out)
+
+
+if __name__ == "__main__":
+    main()
