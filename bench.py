@@ -26,6 +26,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import supersampler_amd as sp  # noqa: E402
+from supersampler_amd import dist as spd  # noqa: E402
 from supersampler_amd import synth  # noqa: E402
 
 K, M, S = 31, 11, 1000.0
@@ -44,7 +45,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--genomes", type=int, default=N_GENOMES, help="genomes per GPU (default = BASELINE config)")
     ap.add_argument("--length", type=int, default=GENOME_LEN)
-    ap.add_argument("--mode", choices=["default", "direct", "filter"], default="default")
+    ap.add_argument("--mode", choices=["default", "direct", "filter", "pair"], default="default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -61,7 +62,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    flags = {"default": sp.SPSP_SCAN_DEFAULT, "direct": sp.SPSP_SCAN_DIRECT_HASH, "filter": sp.SPSP_SCAN_LDS_FILTER}[args.mode]
+    flags = {"default": sp.SPSP_SCAN_DEFAULT, "direct": sp.SPSP_SCAN_DIRECT_HASH, "filter": sp.SPSP_SCAN_LDS_FILTER,
+             "pair": sp.SPSP_SCAN_PAIR_FILTER}[args.mode]
     p = sp.make_params(K, M, S, flags=flags)
     stream = torch.cuda.current_stream().cuda_stream
     ctx = sp.Context(local_rank, stream if stream else None)
@@ -79,7 +81,7 @@ def main():
     d_bases = torch.from_numpy(bases).to(dev)
     d_off = torch.from_numpy(rec_off.view(np.int64)).to(dev)
     # sketches of this rank's genomes -> packed keys (host side of the CLIs, outside the timed region)
-    sketches = []
+    sketches, payloads = [], []
     r0 = 0
     for i, g in enumerate(genomes):
         nr = 1 + i % 3
@@ -87,6 +89,7 @@ def main():
         r0 += nr
         em = ctx.scan(p, gb, go)
         payload, _ = sp.sketch_build(p, S, gb, go, em)
+        payloads.append(payload)
         sketches.append(sp.sketch_parse(payload))
     my_n = np.array([len(s) for s in sketches], dtype=np.int64)
     my_min = np.concatenate([s.minimizer for s in sketches]).astype(np.uint32)
@@ -95,23 +98,8 @@ def main():
     d_my_lo = torch.from_numpy(my_lo.view(np.int64)).to(dev)
     n_total = args.genomes * world
     if world > 1:
-        sizes = [torch.zeros(args.genomes, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(sizes, torch.from_numpy(my_n).to(dev))
-        all_n = torch.stack(sizes).cpu().numpy()           # [world, genomes]
-        per_rank = all_n.sum(axis=1)
-        pad = int(per_rank.max())
-        # global sketch index of (rank r, local g) = r * genomes + g; keys stored rank-major with padding removed below
-        sk_off = np.zeros(n_total + 1, dtype=np.uint64)
-        sk_off[1:] = np.cumsum(all_n.reshape(-1))
-        d_pad_min = torch.zeros(pad, dtype=torch.int32, device=dev)
-        d_pad_lo = torch.zeros(pad, dtype=torch.int64, device=dev)
-        d_pad_min[:len(my_min)] = d_my_min
-        d_pad_lo[:len(my_lo)] = d_my_lo
-        d_gather_min = torch.empty(world * pad, dtype=torch.int32, device=dev)
-        d_gather_lo = torch.empty(world * pad, dtype=torch.int64, device=dev)
-        d_all_min = torch.empty(int(per_rank.sum()), dtype=torch.int32, device=dev)
-        d_all_lo = torch.empty(int(per_rank.sum()), dtype=torch.int64, device=dev)
-        starts = np.concatenate([[0], np.cumsum(per_rank)]).astype(np.int64)
+        exchange = spd.KeyExchange(my_n, dev)
+        sk_off = exchange.sk_off
     else:
         sk_off = np.zeros(n_total + 1, dtype=np.uint64)
         sk_off[1:] = np.cumsum(my_n)
@@ -127,13 +115,11 @@ def main():
         d_out, n_out = ctx.scan_device(p, d_bases.data_ptr(), d_bases.numel(), d_off.data_ptr(), len(recs))
         ctx.device_free(d_out)
         if world > 1:  # the one data-path collective: packed sketch keys over RCCL/xGMI
-            dist.all_gather_into_tensor(d_gather_min, d_pad_min)
-            dist.all_gather_into_tensor(d_gather_lo, d_pad_lo)
-            for r in range(world):
-                d_all_min[starts[r]:starts[r + 1]] = d_gather_min[r * pad:r * pad + int(per_rank[r])]
-                d_all_lo[starts[r]:starts[r + 1]] = d_gather_lo[r * pad:r * pad + int(per_rank[r])]
-        ctx.compare_device(K, d_all_min.data_ptr(), d_all_lo.data_ptr(), None, sk_off, n_total, rank, world,
-                           d_inter.data_ptr())
+            g = exchange.exchange(d_my_min, d_my_lo)
+            mn_ptr, lo_ptr = g.minimizer.data_ptr(), g.kmer_lo.data_ptr()
+        else:
+            mn_ptr, lo_ptr = d_all_min.data_ptr(), d_all_lo.data_ptr()
+        ctx.compare_device(K, mn_ptr, lo_ptr, None, sk_off, n_total, rank, world, d_inter.data_ptr())
         return n_out
 
     def fence():
@@ -206,14 +192,14 @@ def main():
                          "algorithmic_bytes_per_launch": int(d_bases.numel())},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(recs, sketches, p)
+            out["cpu_baseline"] = cpu_baseline(recs, payloads, p)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(recs, sketches, p):
+def cpu_baseline(recs, payloads, p):
     """The reference-algorithm CPU restatement (oracle/) timed on this host, rank 0, N=1 only.
     Checker code used as a reported baseline -- never on the product path."""
     from oracle import oracle_py as orc
@@ -224,9 +210,14 @@ def cpu_baseline(recs, sketches, p):
         b, o = synth.concat_records([r])
         sec, km, _ = orc.scan_timed(K, M, p.threshold, b, o)
         spent += sec; kmers += km; used += 1
+    n = len(payloads)
+    _, _, csec = orc.compare(payloads, timed=True)  # the reference comparator is single-threaded too
     return {"value": kmers / spent if spent > 0 else None, "unit": "k-mers hashed/s", "cores": 1, "kind": "port",
             "sample": "oracle scan loop (SubSampler.cpp:357-455 restated), single thread, first %d of %d records "
-                      "of the same workload, %.1f s" % (used, len(recs), spent)}
+                      "of the same workload, %.1f s" % (used, len(recs), spent),
+            "sketch_pairs_per_s": (n * (n - 1) // 2) / csec if csec > 0 else None,
+            "pairs_sample": "oracle compare_sketches (Comparator.cpp:39-287 restated) over the same %d sketches, "
+                            "single thread, %.2f s" % (n, csec)}
 
 
 if __name__ == "__main__":

@@ -50,7 +50,8 @@ typedef struct spsp_params {
 
 #define SPSP_SCAN_DEFAULT 0u
 #define SPSP_SCAN_DIRECT_HASH 1u /* force XXH64 at every position (no LDS pre-filter) */
-#define SPSP_SCAN_LDS_FILTER 2u  /* force the memoised LDS pre-filter path */
+#define SPSP_SCAN_LDS_FILTER 2u  /* force the 2^20-bit memoised LDS pre-filter (one lookup per position) */
+#define SPSP_SCAN_PAIR_FILTER 4u /* force the 64 KiB pair table (one lookup per two positions, m >= 9) */
 
 /* One selected super-k-mer == one call of Subsampler::handle_superkmer
  * (SubSampler.cpp:426,448): ref.substr(start,len) of record `rec`, its

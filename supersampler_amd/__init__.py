@@ -20,6 +20,7 @@ LIB_PATH = os.path.join(_HERE, "libspsp.so")
 SPSP_SCAN_DEFAULT = 0
 SPSP_SCAN_DIRECT_HASH = 1
 SPSP_SCAN_LDS_FILTER = 2
+SPSP_SCAN_PAIR_FILTER = 4
 
 
 class SpspError(RuntimeError):

@@ -135,7 +135,7 @@ void spsp_destroy(spsp_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->bases, &c->rec_off, &c->bitmap, &c->tile_count, &c->tile_off, &c->hits, &c->emit_count,
-                      &c->emit_off, &c->scan_tmp, &c->filter, &c->c_min, &c->c_lo, &c->c_hi, &c->c_table,
+                      &c->emit_off, &c->scan_tmp, &c->filter, &c->pairtab, &c->c_min, &c->c_lo, &c->c_hi, &c->c_table,
                       &c->c_owner, &c->c_rowid, &c->c_slot, &c->c_row, &c->c_matrix, &c->c_inter, &c->c_flags,
                       &c->c_skoff};
     for (DevBuf* b : bufs) b->release();

@@ -65,12 +65,19 @@ struct spsp_ctx {
     uint64_t* h_scalar = nullptr;  // pinned, 8 slots
     // scan workspace
     spsp::DevBuf bases, rec_off, bitmap, tile_count, tile_off, hits, emit_count, emit_off, scan_tmp;
+    uint64_t zeroed_tiles = 0;  // bitmap/tile_count tiles [0, zeroed_tiles) are zero unless dirty
+    uint64_t dirty_tiles = 0;   // tiles [0, dirty_tiles) may hold hits of a call that never reached k_expand
     // LDS pre-filter table cache (keyed by m, threshold)
     spsp::DevBuf filter;
     uint32_t filter_m = 0;
     uint64_t filter_thr = 0;
     uint32_t filter_shift = 0;
     bool filter_valid = false;
+    // pair-lookup table cache (64 KiB table + 8 KiB key bitmap)
+    spsp::DevBuf pairtab;
+    uint32_t pair_m = 0;
+    uint64_t pair_thr = 0;
+    bool pair_valid = false;
     // compare workspace
     spsp::DevBuf c_min, c_lo, c_hi, c_table, c_owner, c_rowid, c_slot, c_row, c_matrix, c_inter, c_flags, c_skoff;
 };

@@ -20,6 +20,8 @@
 //                        132-166) that split super-k-mers.
 //
 // Output = exactly the argument stream of Subsampler::handle_superkmer.
+#include <cstdlib>
+
 #include "spsp_internal.h"
 #include "spsp_device.h"
 
@@ -145,6 +147,199 @@ __global__ void k_build_filter(uint32_t m, uint64_t thr, uint32_t shift, uint32_
     if (xxh64_u64(v) <= thr) atomicOr(&table[(v >> shift) >> 5], 1u << ((v >> shift) & 31));
 }
 
+// --------------------------------------------- dense pass, pair-table form ---
+// The selected set is tiny next to the m-mer universe (default k31/m11/s1000:
+// ~100 canonical 11-mers out of 2^21), so the question "can the m-mer starting
+// here be selected at all?" is memoised in LDS and XXH64 only runs on the rare
+// survivors.  One lookup answers it for TWO adjacent positions:
+//
+//   key table  K8[q]   q = first 8 bases (16 bits) of an m-mer, either strand:
+//                      set iff some m-mer x with that prefix has XXH64(canon(x)) <= T
+//   pair table P[e]    e = 9 consecutive bases (18 bits) -> 2 bits
+//                      bit0 = K8[first 8 bases of e], bit1 = K8[last 8 bases of e]
+//                      (64 KiB in LDS, 4 entries per byte)
+//
+// A lane owns 16 consecutive positions; its 32-base register window gives the
+// eight 9-base pair keys with one bit-field extract each, so the hot loop is
+// ~5 VALU + 1 ds_read_u8 per TWO positions, with no branch and no hash.
+// Survivors (<1 % of positions when this variant is chosen) go to a per-wave
+// queue in LDS and are hashed 64 at a time with every lane busy.  Waves never
+// synchronise with each other: the 16-base halo comes from the neighbouring
+// lane by a wave shuffle (lane 63 loads its own), hits are rare enough to be
+// published with global atomics into a pre-zeroed bitmap.
+constexpr int kPairWaves = 16;              // waves per workgroup (1024 lanes)
+constexpr int kPairTabBytes = 65536;        // 2^18 entries x 2 bits
+constexpr int kQueueCap = 256;              // survivor slots per wave (12 bytes each)
+
+__global__ void k_build_key8(uint32_t m, uint64_t thr, uint32_t* __restrict__ key8) {
+    const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= (1ull << (2 * m))) return;
+    const uint32_t v = (uint32_t)x;
+    const uint32_t rc = rc_mmer32(v, m);
+    if (rc < v) return;                       // visit each canonical m-mer once
+    if (xxh64_u64(v) > thr) return;
+    const uint32_t sh = 2 * m - 16;           // m >= 8: first 8 bases
+    const uint32_t a = v >> sh, b = rc >> sh; // either strand may appear in the genome
+    atomicOr(&key8[a >> 5], 1u << (a & 31));
+    atomicOr(&key8[b >> 5], 1u << (b & 31));
+}
+
+__global__ void k_build_pairtab(const uint32_t* __restrict__ key8, uint8_t* __restrict__ tab) {
+    const uint32_t byte = blockIdx.x * blockDim.x + threadIdx.x;
+    if (byte >= (uint32_t)kPairTabBytes) return;
+    uint32_t v = 0;
+    for (uint32_t s2 = 0; s2 < 4; ++s2) {
+        const uint32_t e = byte * 4 + s2;     // 9-base window, first base most significant
+        const uint32_t q0 = e >> 2, q1 = e & 0xffffu;
+        const uint32_t r0 = (key8[q0 >> 5] >> (q0 & 31)) & 1u, r1 = (key8[q1 >> 5] >> (q1 & 31)) & 1u;
+        v |= (r0 << s2) | (r1 << (s2 + 4));   // sub-entry s2: bit s2 = first position, bit s2+4 = second
+    }
+    tab[byte] = (uint8_t)v;
+}
+
+// hash one surviving m-mer (forward value f at position pos) and publish it if it really is a hit
+__device__ __forceinline__ void verify_candidate(uint64_t n_mmers, uint32_t m, uint64_t thr, uint64_t pos, uint32_t f,
+                                                 uint32_t* __restrict__ bitmap, uint32_t* __restrict__ tile_count) {
+    if (pos >= n_mmers) return;
+    const uint32_t rc = rc_mmer32(f, m);
+    const uint32_t x = f < rc ? f : rc;
+    if (xxh64_u64(x) <= thr) {
+        atomicOr(&bitmap[pos >> 5], 1u << (pos & 31));
+        atomicAdd(&tile_count[pos / kTilePos], 1u);
+    }
+}
+
+// A wave-row is 63 chunks of 16 positions: lane 63 only supplies the halo of lane
+// 62 (its chunk is lane 0 of the next row), so every lane runs the same code and
+// no lane needs a second load.
+constexpr int kRowChunks = 63;
+constexpr int kRowPosPair63 = kRowChunks * kChunk;   // 1008 positions per wave-row
+
+// survivors of one lane's 16 positions from its packed window (hi = own 16 bases, nxt = next 16)
+__device__ __forceinline__ uint32_t pair_lookup16(const uint8_t* __restrict__ tab, uint32_t hi, uint32_t nxt) {
+    const uint32_t mid = (hi << 16) | (nxt >> 16);   // bases 8..23
+    uint32_t accA = 0, accB = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                    // pairs 0..3 from hi, 4..7 from mid
+        const uint32_t a0 = (hi >> (16 - 4 * q)) & 0xffffu, a1 = (mid >> (16 - 4 * q)) & 0xffffu;
+        const uint32_t s0 = (hi >> (14 - 4 * q)) & 3u, s1 = (mid >> (14 - 4 * q)) & 3u;
+        const uint32_t t0 = (uint32_t)tab[a0] >> s0, t1 = (uint32_t)tab[a1] >> s1;
+        accA = (accA << 1) | (t0 & 0x11u);
+        accB = (accB << 1) | (t1 & 0x11u);
+    }
+    // accX bit (3-q) = first position of pair q, bit (7-q) = second position
+    return accA | (accB << 8);
+}
+// position offset (0..15) of survivor bit b of pair_lookup16's result
+__device__ __forceinline__ uint32_t pair_bit_to_offset(uint32_t b) {
+    const uint32_t grp = b >> 3, w = b & 7, second = w >> 2, q = 3 - (w & 3);
+    return 2 * (4 * grp + q) + second;
+}
+
+__global__ __launch_bounds__(64 * kPairWaves) void k_dense_pair(const uint8_t* __restrict__ bases, uint64_t n, uint32_t m,
+                                                               uint64_t thr, const uint8_t* __restrict__ pairtab,
+                                                               uint64_t n_rows, uint32_t* __restrict__ bitmap,
+                                                               uint32_t* __restrict__ tile_count) {
+    __shared__ __attribute__((aligned(16))) uint8_t tab[kPairTabBytes];
+    extern __shared__ __attribute__((aligned(16))) uint32_t qbase[];   // per wave: kQueueCap x {pos lo, pos hi, m-mer}
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: row bookkeeping stays on the SALU
+    uint32_t* queue = qbase + wave * kQueueCap * 3;
+    {   // table -> LDS, 64 bytes per lane
+        const uint4* src = reinterpret_cast<const uint4*>(pairtab);
+        uint4* dst = reinterpret_cast<uint4*>(tab);
+        for (uint32_t i = threadIdx.x; i < kPairTabBytes / 16; i += 64 * kPairWaves) dst[i] = src[i];
+    }
+    __syncthreads();
+    const uint64_t n_mmers = n >= m ? n - m + 1 : 0;
+    const uint32_t mm = (1u << (2 * m)) - 1u;
+    const uint64_t gw = (uint64_t)blockIdx.x * kPairWaves + wave, n_waves = (uint64_t)gridDim.x * kPairWaves;
+    uint32_t qn = 0;          // survivors waiting in this wave's queue (wave-uniform, lives in an SGPR)
+
+    auto drain = [&](uint32_t keep_below) {   // verify queued survivors, 64 per round, until fewer than keep_below remain
+        while (qn >= keep_below && qn > 0) {
+            const uint32_t take = qn < 64 ? qn : 64;
+            if (lane < take) {
+                const uint32_t* e = queue + (qn - take + lane) * 3;
+                verify_candidate(n_mmers, m, thr, ((uint64_t)e[1] << 32) | e[0], e[2], bitmap, tile_count);
+            }
+            qn -= take;
+        }
+    };
+    // queue (or hash in place) the survivors of one row; (hi,nxt) = the lane's 32-base window
+    auto handle = [&](uint32_t cand, uint64_t p0, uint32_t hi, uint32_t nxt) {
+        if (lane >= kRowChunks) cand = 0;             // lane 63 is halo only
+        if (!__ballot(cand != 0)) return;
+        // exclusive prefix and total of the per-lane survivor counts, bit-sliced over ballots:
+        // no atomics, no LDS counter, and usually only the two low bit-planes are populated
+        const uint32_t cnt = __popc(cand);
+        uint32_t prefix = 0, total = 0;
+#pragma unroll
+        for (int b = 0; b < 5; ++b) {
+            const unsigned long long plane = __ballot((cnt >> b) & 1u);
+            if (plane) {
+                prefix += __builtin_amdgcn_mbcnt_hi((uint32_t)(plane >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)plane, 0u)) << b;
+                total += (uint32_t)__popcll(plane) << b;
+            }
+        }
+        if (qn + total > (uint32_t)kQueueCap) drain(1);
+        const uint64_t W = ((uint64_t)hi << 32) | nxt;
+        if (total > (uint32_t)kQueueCap) {
+            // more than an empty queue holds (adversarial input): hash in place
+            while (cand) {
+                const uint32_t off = pair_bit_to_offset(__ffs(cand) - 1);
+                cand &= cand - 1;
+                verify_candidate(n_mmers, m, thr, p0 + off, (uint32_t)(W >> (64 - 2 * m - 2 * off)) & mm, bitmap, tile_count);
+            }
+            return;
+        }
+        uint32_t* e = queue + (qn + prefix) * 3;
+        while (cand) {
+            const uint32_t off = pair_bit_to_offset(__ffs(cand) - 1);
+            cand &= cand - 1;
+            const uint64_t pos = p0 + off;
+            e[0] = (uint32_t)pos; e[1] = (uint32_t)(pos >> 32);
+            e[2] = (uint32_t)(W >> (64 - 2 * m - 2 * off)) & mm;
+            e += 3;
+        }
+        qn += total;
+        if (qn >= 64) drain(64);
+    };
+
+    // rows whose 64 chunks lie completely inside the buffer take the vector path
+    const uint64_t full_rows = n >= 64 * kChunk ? (n - 64 * kChunk) / kRowPosPair63 + 1 : 0;
+    const uint64_t fast_rows = full_rows < n_rows ? full_rows : n_rows;
+    const uint64_t stride = n_waves * kRowPosPair63;           // bytes between two rows of this wave
+    uint64_t row = gw;
+    const uint8_t* ptr = bases + row * kRowPosPair63 + (uint64_t)lane * kChunk;
+    // Two rows in flight per wave, in two named register sets: each set is refilled
+    // right after it has been packed, so its wait sits a whole loop trip later.
+    uint4 raw0 = make_uint4(0, 0, 0, 0), raw1 = raw0;
+    if (row < fast_rows) raw0 = *reinterpret_cast<const uint4*>(ptr);
+    if (row + n_waves < fast_rows) raw1 = *reinterpret_cast<const uint4*>(ptr + stride);
+    auto body = [&](uint4& raw, uint64_t r, const uint8_t* at) {
+        const uint32_t hi = pack16(raw);
+        // unconditional refill (a branch around the load would force a full vmcnt(0) wait right here):
+        // past the last row the wave re-reads its current row, whose value is never used
+        raw = *reinterpret_cast<const uint4*>(r + 2 * n_waves < fast_rows ? at + 2 * stride : at);
+        const uint32_t nxt = __shfl_down(hi, 1);
+        handle(pair_lookup16(tab, hi, nxt), r * kRowPosPair63 + (uint64_t)lane * kChunk, hi, nxt);
+    };
+    for (; row + n_waves < fast_rows; row += 2 * n_waves, ptr += 2 * stride) {
+        body(raw0, row, ptr);
+        body(raw1, row + n_waves, ptr + stride);
+    }
+    if (row < fast_rows) body(raw0, row, ptr);
+    // the last (at most two) rows touch the end of the buffer: byte-wise loads
+    for (row = fast_rows + ((gw + n_waves - fast_rows % n_waves) % n_waves); row < n_rows; row += n_waves) {
+        const uint64_t p0 = row * kRowPosPair63 + (uint64_t)lane * kChunk;
+        const uint32_t hi = load_pack(bases, n, p0);
+        const uint32_t nxt = __shfl_down(hi, 1);
+        handle(pair_lookup16(tab, hi, nxt), p0, hi, nxt);
+    }
+    drain(1);
+}
+
 // ------------------------------------------------- exclusive scan (1 block) --
 // out[i] = sum(in[0..i)), out[n] = total.  u32, single workgroup of 1024 lanes;
 // the arrays it runs over (tiles, hits) are tiny next to the dense pass.
@@ -185,8 +380,8 @@ __global__ __launch_bounds__(1024) void k_exclusive_scan(const uint32_t* __restr
 // ------------------------------------------------------------- expand pass --
 // One workgroup per dense tile: bitmap bits -> Hit records in position order.
 __global__ __launch_bounds__(kThreads) void k_expand(const uint8_t* __restrict__ bases, uint64_t n, uint32_t k,
-                                                    uint32_t m, const uint32_t* __restrict__ bitmap,
-                                                    const uint32_t* __restrict__ tile_count,
+                                                    uint32_t m, uint32_t* __restrict__ bitmap,
+                                                    uint32_t* __restrict__ tile_count,
                                                     const uint32_t* __restrict__ tile_off,
                                                     const uint64_t* __restrict__ rec_off, uint32_t n_rec,
                                                     Hit* __restrict__ hits) {
@@ -201,6 +396,9 @@ __global__ __launch_bounds__(kThreads) void k_expand(const uint8_t* __restrict__
     for (int i = 0; i < WPT; ++i) {
         words[i] = bitmap[(uint64_t)b * kTileWords + t * WPT + i];
         cnt += __popc(words[i]);
+        // leave the bitmap all-zero behind us: the pair-table dense pass publishes hits
+        // with atomicOr into a zeroed bitmap, and this saves it a 1/8 B-per-position memset
+        if (words[i]) bitmap[(uint64_t)b * kTileWords + t * WPT + i] = 0;
     }
     uint32_t x = cnt;
 #pragma unroll
@@ -209,7 +407,8 @@ __global__ __launch_bounds__(kThreads) void k_expand(const uint8_t* __restrict__
         if (lane >= (uint32_t)d) x += y;
     }
     if (lane == 63) wave_sum[wid] = x;
-    __syncthreads();
+    __syncthreads();                       // every lane has read tile_count[b] by now
+    if (t == 0) tile_count[b] = 0;
     uint32_t pre = 0;
     for (uint32_t w = 0; w < wid; ++w) pre += wave_sum[w];
     uint32_t rank = tile_off[b] + pre + x - cnt;
@@ -415,28 +614,81 @@ static int ensure_filter(spsp_ctx* ctx, const spsp_params* p, uint32_t* words, u
     return SPSP_OK;
 }
 
-// Picks the dense-pass variant.  The pre-filter pays when few table bits are
-// set (sparse selection); with dense selection nearly every lane hashes anyway.
-static bool want_filter(const spsp_params* p) {
-    if (p->flags & SPSP_SCAN_DIRECT_HASH) return false;
-    if (p->flags & SPSP_SCAN_LDS_FILTER) return true;
+// Picks the dense-pass variant from the expected survivor rate of each memoised
+// filter (P(hash <= T) times the m-mers that share one table bit, both strands).
+enum { kDenseDirect = 0, kDenseFilter20 = 1, kDensePair = 2 };
+static int pick_dense(const spsp_params* p) {
+    if (p->flags & SPSP_SCAN_DIRECT_HASH) return kDenseDirect;
+    if (p->flags & SPSP_SCAN_LDS_FILTER) return kDenseFilter20;
+    if ((p->flags & SPSP_SCAN_PAIR_FILTER) && p->m >= 9) return kDensePair;
     const double frac = (double)p->threshold / 18446744073709551616.0;  // P(hash <= T)
     const uint32_t bits = 2 * p->m;
+    if (p->m >= 9 && frac * (double)(1u << (bits - 16)) < 0.01) return kDensePair;
     const double per_bit = bits > 20 ? (double)(1u << (bits - 20)) : 1.0;
-    return frac * per_bit < 0.02;  // expected fraction of positions that still hash
+    if (frac * per_bit < 0.02) return kDenseFilter20;
+    return kDenseDirect;
+}
+
+static int ensure_pairtab(spsp_ctx* ctx, const spsp_params* p) {
+    if (ctx->pair_valid && ctx->pair_m == p->m && ctx->pair_thr == p->threshold) return SPSP_OK;
+    int rc = ctx->pairtab.reserve((size_t)kPairTabBytes + 8192);
+    if (rc) return rc;
+    uint32_t* key8 = reinterpret_cast<uint32_t*>(ctx->pairtab.as<uint8_t>() + kPairTabBytes);  // 2^16 bits
+    SPSP_HIP(hipMemsetAsync(key8, 0, 8192, ctx->stream));
+    const uint64_t total = 1ull << (2 * p->m);
+    hipLaunchKernelGGL(k_build_key8, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, ctx->stream, p->m,
+                       p->threshold, key8);
+    SPSP_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_build_pairtab, dim3(kPairTabBytes / 256), dim3(256), 0, ctx->stream, key8,
+                       ctx->pairtab.as<uint8_t>());
+    SPSP_HIP(hipGetLastError());
+    ctx->pair_m = p->m; ctx->pair_thr = p->threshold; ctx->pair_valid = true;
+    return SPSP_OK;
 }
 
 static int launch_dense(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, uint64_t n_bases,
                         uint64_t n_tiles) {
     int rc;
+    const void *old_bm = ctx->bitmap.p, *old_tc = ctx->tile_count.p;
     if ((rc = ctx->bitmap.reserve((size_t)n_tiles * kTileWords * 4))) return rc;
     if ((rc = ctx->tile_count.reserve((size_t)n_tiles * 4))) return rc;
     if ((rc = ctx->tile_off.reserve((size_t)(n_tiles + 1) * 4))) return rc;
-    const bool filtered = want_filter(p);
+    if (ctx->bitmap.p != old_bm || ctx->tile_count.p != old_tc) { ctx->zeroed_tiles = 0; ctx->dirty_tiles = 0; }
+    const int variant = pick_dense(p);
     uint32_t words = 0, shift = 0;
-    if (filtered && (rc = ensure_filter(ctx, p, &words, &shift))) return rc;
+    if (variant == kDenseFilter20 && (rc = ensure_filter(ctx, p, &words, &shift))) return rc;
+    if (variant == kDensePair && (rc = ensure_pairtab(ctx, p))) return rc;
     if ((rc = ctx->ev_begin(kEvDense))) return rc;
-    if (filtered) {
+    if (variant == kDensePair) {
+        // hits are published with atomics into a zeroed bitmap.  k_expand zeroes what it
+        // consumes, so in a batch loop nothing has to be cleared here: only tiles never used
+        // before, or left dirty by a call that did not reach k_expand, are memset.
+        if (ctx->dirty_tiles) {
+            SPSP_HIP(hipMemsetAsync(ctx->bitmap.p, 0, (size_t)ctx->dirty_tiles * kTileWords * 4, ctx->stream));
+            SPSP_HIP(hipMemsetAsync(ctx->tile_count.p, 0, (size_t)ctx->dirty_tiles * 4, ctx->stream));
+            ctx->dirty_tiles = 0;
+        }
+        if (ctx->zeroed_tiles < n_tiles) {
+            const uint64_t from = ctx->zeroed_tiles;
+            SPSP_HIP(hipMemsetAsync(ctx->bitmap.as<uint32_t>() + from * kTileWords, 0, (size_t)(n_tiles - from) * kTileWords * 4, ctx->stream));
+            SPSP_HIP(hipMemsetAsync(ctx->tile_count.as<uint32_t>() + from, 0, (size_t)(n_tiles - from) * 4, ctx->stream));
+            ctx->zeroed_tiles = n_tiles;
+        }
+        const size_t lds = (size_t)kPairWaves * kQueueCap * 12;
+        static bool attr_set = false;
+        if (!attr_set) {
+            SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_pair),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        const uint64_t n_rows = (n_bases + kRowPosPair63 - 1) / kRowPosPair63;
+        const uint64_t want = (n_rows + kPairWaves - 1) / kPairWaves;
+        static const int per_cu = getenv("SPSP_PAIR_BLOCKS_PER_CU") ? atoi(getenv("SPSP_PAIR_BLOCKS_PER_CU")) : 1;  // tuning knob
+        const uint64_t cap = (uint64_t)ctx->n_cu * (per_cu > 0 ? per_cu : 1);   // one 1024-lane workgroup per CU (112 KiB of LDS)
+        hipLaunchKernelGGL(k_dense_pair, dim3((uint32_t)(want < cap ? want : cap)), dim3(64 * kPairWaves), lds,
+                           ctx->stream, d_bases, n_bases, p->m, p->threshold, ctx->pairtab.as<uint8_t>(), n_rows,
+                           ctx->bitmap.as<uint32_t>(), ctx->tile_count.as<uint32_t>());
+    } else if (variant == kDenseFilter20) {
         static bool attr_set = false;
         if (!attr_set) {
             SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense<1, 4>),
@@ -456,6 +708,8 @@ static int launch_dense(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_ba
                            ctx->tile_count.as<uint32_t>());
     }
     SPSP_HIP(hipGetLastError());
+    if (n_tiles > ctx->dirty_tiles) ctx->dirty_tiles = n_tiles;   // until k_expand has consumed (and zeroed) them
+    if (n_tiles > ctx->zeroed_tiles) ctx->zeroed_tiles = n_tiles; // ... after which this whole range is zero
     if ((rc = ctx->ev_end(kEvDense))) return rc;
     hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->tile_count.as<uint32_t>(),
                        ctx->tile_off.as<uint32_t>(), n_tiles, ctx->h_scalar + 0);
@@ -500,6 +754,7 @@ static int scan_device_inner(spsp_ctx* ctx, const spsp_params* p, const uint8_t*
                        p->m, ctx->bitmap.as<uint32_t>(), ctx->tile_count.as<uint32_t>(),
                        ctx->tile_off.as<uint32_t>(), d_rec_off, n_rec, ctx->hits.as<Hit>());
     SPSP_HIP(hipGetLastError());
+    ctx->dirty_tiles = 0;   // k_expand leaves bitmap and tile counts zeroed
     const uint32_t rblocks = (uint32_t)((n_hits + 127) / 128);
     hipLaunchKernelGGL(k_resolve<false>, dim3(rblocks), dim3(128), 0, ctx->stream, ctx->hits.as<Hit>(),
                        (uint32_t)n_hits, d_rec_off, p->k, p->m, ctx->emit_count.as<uint32_t>(),

@@ -1,0 +1,32 @@
+"""world_size-2 tests of the multi-GPU comparison path: key
+all-gather + strided row ownership.  CPU variant runs here with gloo; the GPU
+variant runs the real spsp_compare_device in both ranks."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _launch(mode, port):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = []
+    for r in range(2):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), mode], env=e,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+
+
+def test_key_exchange_and_row_partition_gloo_cpu():
+    _launch("cpu", 29611)
+
+
+@pytest.mark.gpu
+def test_two_ranks_compare_device_rows():
+    _launch("gpu", 29612)

@@ -36,7 +36,7 @@ def _assert_stream_equal(got, want):
         assert bad.size == 0, (f, int(bad[0]), got[bad[0]], want[bad[0]])
 
 
-MODES = [sp.SPSP_SCAN_DIRECT_HASH, sp.SPSP_SCAN_LDS_FILTER]
+MODES = [sp.SPSP_SCAN_DIRECT_HASH, sp.SPSP_SCAN_LDS_FILTER, sp.SPSP_SCAN_PAIR_FILTER, sp.SPSP_SCAN_DEFAULT]
 
 
 @pytest.mark.parametrize("mode", MODES)

@@ -1,0 +1,99 @@
+// Scratch ablation harness for the pair-table dense kernel (not part of the product).
+// build: hipcc -O3 --offload-arch=gfx950 exp_dense.hip -o exp_dense
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+__global__ void k_fill(uint8_t* b, uint64_t n, uint64_t seed) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t x = (i + seed) * 0x9E3779B97F4A7C15ULL; x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ULL; x ^= x >> 32;
+        b[i] = "ACGT"[x & 3];
+    }
+}
+__device__ __forceinline__ uint32_t pack4(uint32_t d) { return (((d >> 1) & 0x03030303u) * 0x40100401u) >> 24; }
+__device__ __forceinline__ uint32_t pack16(uint4 v) { return (pack4(v.x) << 24) | (pack4(v.y) << 16) | (pack4(v.z) << 8) | pack4(v.w); }
+
+constexpr int kWaves = 16, kTab = 65536;
+// VAR 0: load + pack only; 1: + bpermute halo; 2: + 8 lookups at real addresses; 3: lookups at a fixed address (no conflicts)
+// 4: lookups via global memory (L1/L2) instead of LDS; 5: full with ballot
+template <int VAR>
+__global__ __launch_bounds__(1024) void k_var(const uint8_t* __restrict__ bases, uint64_t n, const uint8_t* __restrict__ gtab,
+                                             uint64_t n_rows, uint32_t* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) uint8_t tab[kTab];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    { const uint4* src = (const uint4*)gtab; uint4* dst = (uint4*)tab;
+      for (uint32_t i = threadIdx.x; i < kTab / 16; i += 1024) dst[i] = src[i]; }
+    __syncthreads();
+    const uint64_t gw = (uint64_t)blockIdx.x * kWaves + wave, n_waves = (uint64_t)gridDim.x * kWaves;
+    const uint64_t stride = n_waves * 1008;
+    uint64_t row = gw;
+    const uint8_t* ptr = bases + row * 1008 + (uint64_t)lane * 16;
+    uint4 raw0 = make_uint4(0,0,0,0), raw1 = raw0;
+    if (row < n_rows) raw0 = *(const uint4*)ptr;
+    if (row + n_waves < n_rows) raw1 = *(const uint4*)(ptr + stride);
+    uint32_t sink = 0;
+    auto body = [&](uint4& raw, uint64_t r, const uint8_t* at) {
+        const uint32_t hi = pack16(raw);
+        raw = *(const uint4*)(r + 2 * n_waves < n_rows ? at + 2 * stride : at);
+        if (VAR == 0) { sink ^= hi; return; }
+        const uint32_t nxt = __shfl_down(hi, 1);
+        if (VAR == 1) { sink ^= hi ^ nxt; return; }
+        const uint32_t mid = (hi << 16) | (nxt >> 16);
+        uint32_t accA = 0, accB = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t a0 = (hi >> (16 - 4 * q)) & 0xffffu, a1 = (mid >> (16 - 4 * q)) & 0xffffu;
+            const uint32_t s0 = (hi >> (14 - 4 * q)) & 3u, s1 = (mid >> (14 - 4 * q)) & 3u;
+            if (VAR == 3) { a0 = lane * 4; a1 = lane * 4 + 256; }
+            uint32_t t0, t1;
+            if (VAR == 4) { t0 = gtab[a0]; t1 = gtab[a1]; } else { t0 = tab[a0]; t1 = tab[a1]; }
+            t0 >>= s0; t1 >>= s1;
+            accA = (accA << 1) | (t0 & 0x11u);
+            accB = (accB << 1) | (t1 & 0x11u);
+        }
+        uint32_t cand = accA | (accB << 8);
+        if (VAR == 5) { const unsigned long long bl = __ballot(cand != 0); if (bl) { if (lane == 0) sink += __popcll(bl); } }
+        else sink ^= cand;
+    };
+    for (; row + n_waves < n_rows; row += 2 * n_waves, ptr += 2 * stride) { body(raw0, row, ptr); body(raw1, row + n_waves, ptr + stride); }
+    if (row < n_rows) body(raw0, row, ptr);
+    if (sink == 0x12345678) out[0] = sink;
+}
+
+template <int VAR> void run(const char* name, const uint8_t* bases, uint64_t n, const uint8_t* tab, uint32_t* out, int blocks) {
+    const uint64_t n_rows = (n - 1024) / 1008;
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    float best = 1e9, tot = 0;
+    for (int it = 0; it < 6; ++it) {
+        CK(hipEventRecord(a));
+        hipLaunchKernelGGL(k_var<VAR>, dim3(blocks), dim3(1024), 0, 0, bases, n, tab, n_rows, out);
+        CK(hipGetLastError()); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b)); if (it) { tot += ms; if (ms < best) best = ms; }
+    }
+    printf("%-28s blocks=%4d  avg %.4f ms  best %.4f ms  -> %.0f GB/s\n", name, blocks, tot / 5, best, n / best / 1e6);
+}
+
+int main(int argc, char** argv) {
+    const uint64_t n = 500000000ull;
+    uint8_t *bases, *tab; uint32_t* out;
+    CK(hipMalloc(&bases, n + 64)); CK(hipMalloc(&tab, kTab)); CK(hipMalloc(&out, 64));
+    hipLaunchKernelGGL(k_fill, dim3(4096), dim3(256), 0, 0, bases, n, 7ull);
+    std::vector<uint8_t> h(kTab, 0);
+    for (int i = 0; i < kTab; ++i) if ((i * 2654435761u >> 20) % 331 == 0) h[i] = 1u << (i & 7);   // ~0.3% of entries
+    CK(hipMemcpy(tab, h.data(), kTab, hipMemcpyHostToDevice));
+    CK(hipMemset(out, 0, 64));
+    for (int blocks : {256, 512}) {
+        run<0>("0 load+pack", bases, n, tab, out, blocks);
+        run<1>("1 +halo bpermute", bases, n, tab, out, blocks);
+        run<2>("2 +8 LDS lookups", bases, n, tab, out, blocks);
+        run<3>("3 lookups, conflict-free", bases, n, tab, out, blocks);
+        run<4>("4 lookups via global/L1", bases, n, tab, out, blocks);
+        run<5>("5 lookups + ballot", bases, n, tab, out, blocks);
+    }
+    return 0;
+}
