@@ -90,11 +90,39 @@ __global__ void k_insert(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n
     atomicMin(&owner[pos], (uint32_t)e);
 }
 
-__global__ void k_assign_rows(const uint64_t* __restrict__ table, uint64_t cap, uint32_t* __restrict__ rowid,
-                              uint32_t* __restrict__ n_rows) {
-    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= cap) return;
-    if (table[s] != 0) rowid[s] = atomicAdd(n_rows, 1u);
+// Occupied slot -> dense row id.  Same-address atomics retire at ~90 per microsecond on this
+// part, so a workgroup first counts its 16 Ki slots, reserves one run of ids with a single
+// atomic, then hands them out from a workgroup-wide prefix sum.
+constexpr int kRowThreads = 1024, kRowSlots = 16;
+__global__ __launch_bounds__(kRowThreads) void k_assign_rows(const uint64_t* __restrict__ table, uint64_t cap,
+                                                            uint32_t* __restrict__ rowid, uint32_t* __restrict__ n_rows) {
+    __shared__ uint32_t wave_sum[kRowThreads / 64];
+    __shared__ uint32_t s_base;
+    const uint32_t t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const uint64_t base_slot = (uint64_t)blockIdx.x * kRowThreads * kRowSlots;
+    uint32_t occ = 0;   // bit u: slot base_slot + u * kRowThreads + t is occupied
+#pragma unroll
+    for (int u = 0; u < kRowSlots; ++u) {
+        const uint64_t sl = base_slot + (uint64_t)u * kRowThreads + t;
+        if (sl < cap && table[sl] != 0) occ |= 1u << u;
+    }
+    const uint32_t cnt = __popc(occ);
+    uint32_t x = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d);
+        if (lane >= (uint32_t)d) x += y;
+    }
+    if (lane == 63) wave_sum[wid] = x;
+    __syncthreads();
+    uint32_t pre = 0, total = 0;
+    for (uint32_t w = 0; w < kRowThreads / 64; ++w) { if (w < wid) pre += wave_sum[w]; total += wave_sum[w]; }
+    if (t == 0) s_base = total ? atomicAdd(n_rows, total) : 0u;
+    __syncthreads();
+    uint32_t id = s_base + pre + x - cnt;
+#pragma unroll
+    for (int u = 0; u < kRowSlots; ++u)
+        if (occ & (1u << u)) rowid[base_slot + (uint64_t)u * kRowThreads + t] = id++;
 }
 
 __global__ void k_verify(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n, uint64_t S, uint32_t row_first,
@@ -134,9 +162,11 @@ __global__ void k_fill(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n, 
     }
 }
 
-// inter[i][64*wd + lane] for one owned row i and four 64-column words per
-// workgroup.  Row ids are staged through LDS; the row word is wave-uniform.
+// inter[i][64*wd + lane] += number of keys of sketch i (within one chunk of its keys) whose
+// colour row has bit `lane` of word wd set.  One workgroup = one owned sketch x one 64-column word x
+// one chunk of keys; its four waves split the chunk, every lane of a wave is one column.
 constexpr int kAccThreads = 256;
+constexpr int kAccChunk = 1024;   // keys per workgroup
 __global__ __launch_bounds__(kAccThreads) void k_accumulate(const uint32_t* __restrict__ row_of_entry,
                                                            const uint64_t* __restrict__ A, uint32_t W,
                                                            const uint64_t* __restrict__ sk_off, uint32_t n,
@@ -144,33 +174,38 @@ __global__ __launch_bounds__(kAccThreads) void k_accumulate(const uint32_t* __re
                                                            uint32_t* __restrict__ inter) {
     const uint32_t i = row_first + blockIdx.y * row_stride;
     if (i >= n) return;
-    const uint32_t first_wd = (i + 1) >> 6;  // first word holding a column > i
-    if (blockIdx.x * 4 + 3 < first_wd) return;
-    __shared__ uint32_t s_rows[kAccThreads];
+    const uint32_t wd = blockIdx.x;
+    if (wd < ((i + 1) >> 6)) return;           // no column > i in this word
+    const uint64_t e0 = sk_off[i] + (uint64_t)blockIdx.z * kAccChunk, e_end = sk_off[i + 1];
+    if (e0 >= e_end) return;
+    const uint64_t e1 = e0 + kAccChunk < e_end ? e0 + kAccChunk : e_end;
+    __shared__ uint32_t s_part[kAccThreads];
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const uint32_t wd = blockIdx.x * 4 + wave;
-    const bool active = wd < W && wd >= first_wd;
-    const uint64_t e0 = sk_off[i], e1 = sk_off[i + 1];
     uint32_t cnt = 0;
-    for (uint64_t base = e0; base < e1; base += kAccThreads) {
-        __syncthreads();
-        if (base + t < e1) s_rows[t] = row_of_entry[base + t];
-        __syncthreads();
-        const uint32_t lim = (uint32_t)((e1 - base) < (uint64_t)kAccThreads ? (e1 - base) : (uint64_t)kAccThreads);
-        if (active) {
-            uint32_t q = 0;
-            for (; q + 8 <= lim; q += 8) {
-                uint64_t mk[8];
+    // wave w takes keys e0 + w, e0 + w + 4, ...; 8 row words in flight per wave
+    uint64_t e = e0 + wave;
+    for (; e + 28 < e1; e += 32) {
+        uint64_t mk[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) mk[u] = A[(uint64_t)s_rows[q + u] * W + wd];
+        for (int u = 0; u < 8; ++u) mk[u] = A[(uint64_t)row_of_entry[e + 4 * u] * W + wd];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) cnt += (uint32_t)(mk[u] >> lane) & 1u;
-            }
-            for (; q < lim; ++q) cnt += (uint32_t)(A[(uint64_t)s_rows[q] * W + wd] >> lane) & 1u;
-        }
+        for (int u = 0; u < 8; ++u) cnt += (uint32_t)(mk[u] >> lane) & 1u;
     }
-    const uint32_t col = wd * 64 + lane;
-    if (active && col > i && col < n) inter[(uint64_t)i * n + col] = cnt;
+    for (; e < e1; e += 4) cnt += (uint32_t)(A[(uint64_t)row_of_entry[e] * W + wd] >> lane) & 1u;
+    s_part[t] = cnt;
+    __syncthreads();
+    if (wave == 0) {
+        cnt = s_part[lane] + s_part[lane + 64] + s_part[lane + 128] + s_part[lane + 192];
+        const uint32_t col = wd * 64 + lane;
+        if (cnt && col > i && col < n) atomicAdd(&inter[(uint64_t)i * n + col], cnt);
+    }
+}
+
+// cells (i, j > i) of the owned rows start from zero (k_accumulate adds into them)
+__global__ void k_zero_owned(uint32_t n, uint32_t row_first, uint32_t row_stride, uint32_t* __restrict__ inter) {
+    const uint32_t i = row_first + blockIdx.y * row_stride;
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && j < n && j > i) inter[(uint64_t)i * n + j] = 0;
 }
 
 static int compare_device_inner(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min, const uint64_t* d_lo,
@@ -203,7 +238,7 @@ static int compare_device_inner(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min
     const uint64_t* sk = ctx->c_skoff.as<uint64_t>();
     uint32_t* flags = ctx->c_flags.as<uint32_t>();  // [0] unsorted, [1] collision, [2] n_rows
     const uint32_t eblocks = (uint32_t)((S + 255) / 256);
-    const uint32_t sblocks = (uint32_t)((cap + 255) / 256);
+    const uint32_t sblocks = (uint32_t)((cap + (uint64_t)kRowThreads * kRowSlots - 1) / ((uint64_t)kRowThreads * kRowSlots));
     uint32_t n_rows = 0;
     uint64_t seed = 0x5350535053505350ULL;
     for (int attempt = 0;; ++attempt) {
@@ -214,7 +249,7 @@ static int compare_device_inner(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min
                            ctx->c_table.as<uint64_t>(), log2cap, ctx->c_owner.as<uint32_t>(),
                            ctx->c_slot.as<uint32_t>(), flags);
         SPSP_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k_assign_rows, dim3(sblocks), dim3(256), 0, ctx->stream, ctx->c_table.as<uint64_t>(), cap,
+        hipLaunchKernelGGL(k_assign_rows, dim3(sblocks), dim3(kRowThreads), 0, ctx->stream, ctx->c_table.as<uint64_t>(), cap,
                            ctx->c_rowid.as<uint32_t>(), flags + 2);
         SPSP_HIP(hipGetLastError());
         hipLaunchKernelGGL(k_verify, dim3(eblocks), dim3(256), 0, ctx->stream, K, sk, n, S, row_first, row_stride,
@@ -235,8 +270,15 @@ static int compare_device_inner(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min
                        ctx->c_table.as<uint64_t>(), log2cap, ctx->c_owner.as<uint32_t>(), ctx->c_rowid.as<uint32_t>(),
                        W, ctx->c_matrix.as<unsigned long long>(), ctx->c_row.as<uint32_t>());
     SPSP_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_zero_owned, dim3((n + 255) / 256, n_own), dim3(256), 0, ctx->stream, n, row_first, row_stride,
+                       d_inter);
+    SPSP_HIP(hipGetLastError());
     if ((rc = ctx->ev_begin(kEvAccumulate))) return rc;
-    hipLaunchKernelGGL(k_accumulate, dim3((W + 3) / 4, n_own), dim3(kAccThreads), 0, ctx->stream,
+    uint64_t max_keys = 0;
+    for (uint32_t i = row_first; i < n; i += row_stride) max_keys = std::max<uint64_t>(max_keys, h_sk_off[i + 1] - h_sk_off[i]);
+    const uint32_t chunks = (uint32_t)((max_keys + kAccChunk - 1) / kAccChunk);
+    if (chunks > 65535) { set_error("sketch with %llu k-mers is too large for one call", (unsigned long long)max_keys); return SPSP_ERR_OVERFLOW; }
+    hipLaunchKernelGGL(k_accumulate, dim3(W, n_own, chunks ? chunks : 1), dim3(kAccThreads), 0, ctx->stream,
                        ctx->c_row.as<uint32_t>(), ctx->c_matrix.as<uint64_t>(), W, sk, n, row_first, row_stride,
                        d_inter);
     SPSP_HIP(hipGetLastError());

@@ -169,7 +169,7 @@ __global__ void k_build_filter(uint32_t m, uint64_t thr, uint32_t shift, uint32_
 // published with global atomics into a pre-zeroed bitmap.
 constexpr int kPairWaves = 16;              // waves per workgroup (1024 lanes)
 constexpr int kPairTabBytes = 65536;        // 2^18 entries x 2 bits
-constexpr int kQueueCap = 256;              // survivor slots per wave (12 bytes each)
+constexpr int kQueueCap = 256;              // survivor slots per wave (8 bytes each)
 
 __global__ void k_build_key8(uint32_t m, uint64_t thr, uint32_t* __restrict__ key8) {
     const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -241,10 +241,10 @@ __global__ __launch_bounds__(64 * kPairWaves) void k_dense_pair(const uint8_t* _
                                                                uint64_t n_rows, uint32_t* __restrict__ bitmap,
                                                                uint32_t* __restrict__ tile_count) {
     __shared__ __attribute__((aligned(16))) uint8_t tab[kPairTabBytes];
-    extern __shared__ __attribute__((aligned(16))) uint32_t qbase[];   // per wave: kQueueCap x {pos lo, pos hi, m-mer}
+    extern __shared__ __attribute__((aligned(16))) uint32_t qbase[];   // per wave: kQueueCap x {pos low 32 bits, m-mer}
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: row bookkeeping stays on the SALU
-    uint32_t* queue = qbase + wave * kQueueCap * 3;
+    uint32_t* queue = qbase + wave * kQueueCap * 2;
     {   // table -> LDS, 64 bytes per lane
         const uint4* src = reinterpret_cast<const uint4*>(pairtab);
         uint4* dst = reinterpret_cast<uint4*>(tab);
@@ -255,55 +255,61 @@ __global__ __launch_bounds__(64 * kPairWaves) void k_dense_pair(const uint8_t* _
     const uint32_t mm = (1u << (2 * m)) - 1u;
     const uint64_t gw = (uint64_t)blockIdx.x * kPairWaves + wave, n_waves = (uint64_t)gridDim.x * kPairWaves;
     uint32_t qn = 0;          // survivors waiting in this wave's queue (wave-uniform, lives in an SGPR)
+    uint32_t qhigh = 0;       // bits 32.. of every queued position (the queue is drained before they change)
 
     auto drain = [&](uint32_t keep_below) {   // verify queued survivors, 64 per round, until fewer than keep_below remain
         while (qn >= keep_below && qn > 0) {
             const uint32_t take = qn < 64 ? qn : 64;
             if (lane < take) {
-                const uint32_t* e = queue + (qn - take + lane) * 3;
-                verify_candidate(n_mmers, m, thr, ((uint64_t)e[1] << 32) | e[0], e[2], bitmap, tile_count);
+                const uint2 e = reinterpret_cast<const uint2*>(queue)[qn - take + lane];
+                verify_candidate(n_mmers, m, thr, ((uint64_t)qhigh << 32) | e.x, e.y, bitmap, tile_count);
             }
             qn -= take;
         }
     };
-    // queue (or hash in place) the survivors of one row; (hi,nxt) = the lane's 32-base window
-    auto handle = [&](uint32_t cand, uint64_t p0, uint32_t hi, uint32_t nxt) {
-        if (lane >= kRowChunks) cand = 0;             // lane 63 is halo only
-        if (!__ballot(cand != 0)) return;
-        // exclusive prefix and total of the per-lane survivor counts, bit-sliced over ballots:
-        // no atomics, no LDS counter, and usually only the two low bit-planes are populated
-        const uint32_t cnt = __popc(cand);
-        uint32_t prefix = 0, total = 0;
+    // Queue (or hash in place) the survivors of TWO rows of this wave at once: cand bits 0..15 belong to
+    // the row at p0a with window (hia,nxa), bits 16..31 to the row at p0b with (hib,nxb).
+    auto handle = [&](uint32_t cand, uint64_t p0a, uint32_t hia, uint32_t nxa, uint64_t p0b, uint32_t hib, uint32_t nxb) {
+        const unsigned long long holders = __ballot(cand != 0);
+        if (!holders) return;
+        // exclusive prefix and total of the per-lane survivor counts.  Usually no lane holds more
+        // than one survivor and one ballot does it; otherwise the counts are bit-sliced over ballots.
+        uint32_t prefix, total;
+        if (!__ballot((cand & (cand - 1)) != 0)) {
+            prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(holders >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)holders, 0u));
+            total = (uint32_t)__popcll(holders);
+        } else {
+            const uint32_t cnt = __popc(cand);
+            prefix = 0; total = 0;
 #pragma unroll
-        for (int b = 0; b < 5; ++b) {
-            const unsigned long long plane = __ballot((cnt >> b) & 1u);
-            if (plane) {
-                prefix += __builtin_amdgcn_mbcnt_hi((uint32_t)(plane >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)plane, 0u)) << b;
-                total += (uint32_t)__popcll(plane) << b;
+            for (int b = 0; b < 6; ++b) {
+                const unsigned long long plane = __ballot((cnt >> b) & 1u);
+                if (plane) {
+                    prefix += __builtin_amdgcn_mbcnt_hi((uint32_t)(plane >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)plane, 0u)) << b;
+                    total += (uint32_t)__popcll(plane) << b;
+                }
             }
         }
-        if (qn + total > (uint32_t)kQueueCap) drain(1);
-        const uint64_t W = ((uint64_t)hi << 32) | nxt;
-        if (total > (uint32_t)kQueueCap) {
-            // more than an empty queue holds (adversarial input): hash in place
-            while (cand) {
-                const uint32_t off = pair_bit_to_offset(__ffs(cand) - 1);
-                cand &= cand - 1;
-                verify_candidate(n_mmers, m, thr, p0 + off, (uint32_t)(W >> (64 - 2 * m - 2 * off)) & mm, bitmap, tile_count);
-            }
-            return;
-        }
-        uint32_t* e = queue + (qn + prefix) * 3;
+        const uint32_t high = (uint32_t)((p0b > p0a ? p0b : p0a) >> 32);   // rows of one call never straddle 2^32 by more than one step
+        if ((qn && high != qhigh) || qn + total > (uint32_t)kQueueCap) drain(1);
+        const bool in_place = total > (uint32_t)kQueueCap || (uint32_t)(p0a >> 32) != (uint32_t)(p0b >> 32);
+        qhigh = high;
+        uint2* e = reinterpret_cast<uint2*>(queue) + qn + prefix;
         while (cand) {
-            const uint32_t off = pair_bit_to_offset(__ffs(cand) - 1);
+            const uint32_t bit = __ffs(cand) - 1;
             cand &= cand - 1;
-            const uint64_t pos = p0 + off;
-            e[0] = (uint32_t)pos; e[1] = (uint32_t)(pos >> 32);
-            e[2] = (uint32_t)(W >> (64 - 2 * m - 2 * off)) & mm;
-            e += 3;
+            const bool second = bit >= 16;
+            const uint32_t off = pair_bit_to_offset(bit & 15);
+            const uint64_t pos = (second ? p0b : p0a) + off;
+            const uint64_t W = second ? (((uint64_t)hib << 32) | nxb) : (((uint64_t)hia << 32) | nxa);
+            const uint32_t f = (uint32_t)(W >> (64 - 2 * m - 2 * off)) & mm;
+            if (in_place) verify_candidate(n_mmers, m, thr, pos, f, bitmap, tile_count);   // adversarial input / 4 GiB seam
+            else *e++ = make_uint2((uint32_t)pos, f);
         }
-        qn += total;
-        if (qn >= 64) drain(64);
+        if (!in_place) {
+            qn += total;
+            if (qn >= 64) drain(64);
+        }
     };
 
     // rows whose 64 chunks lie completely inside the buffer take the vector path
@@ -317,25 +323,35 @@ __global__ __launch_bounds__(64 * kPairWaves) void k_dense_pair(const uint8_t* _
     uint4 raw0 = make_uint4(0, 0, 0, 0), raw1 = raw0;
     if (row < fast_rows) raw0 = *reinterpret_cast<const uint4*>(ptr);
     if (row + n_waves < fast_rows) raw1 = *reinterpret_cast<const uint4*>(ptr + stride);
-    auto body = [&](uint4& raw, uint64_t r, const uint8_t* at) {
-        const uint32_t hi = pack16(raw);
+    const bool halo_lane = lane >= kRowChunks;                 // lane 63 only feeds lane 62
+    auto body = [&](uint4& raw, uint64_t r, const uint8_t* at, uint32_t& hi, uint32_t& nxt) -> uint32_t {
+        hi = pack16(raw);
         // unconditional refill (a branch around the load would force a full vmcnt(0) wait right here):
         // past the last row the wave re-reads its current row, whose value is never used
         raw = *reinterpret_cast<const uint4*>(r + 2 * n_waves < fast_rows ? at + 2 * stride : at);
-        const uint32_t nxt = __shfl_down(hi, 1);
-        handle(pair_lookup16(tab, hi, nxt), r * kRowPosPair63 + (uint64_t)lane * kChunk, hi, nxt);
+        nxt = __shfl_down(hi, 1);
+        const uint32_t c = pair_lookup16(tab, hi, nxt);
+        return halo_lane ? 0u : c;
     };
+    const uint64_t lane_off = (uint64_t)lane * kChunk;
     for (; row + n_waves < fast_rows; row += 2 * n_waves, ptr += 2 * stride) {
-        body(raw0, row, ptr);
-        body(raw1, row + n_waves, ptr + stride);
+        uint32_t hia, nxa, hib, nxb;
+        const uint32_t ca = body(raw0, row, ptr, hia, nxa);
+        const uint32_t cb = body(raw1, row + n_waves, ptr + stride, hib, nxb);
+        handle(ca | (cb << 16), row * kRowPosPair63 + lane_off, hia, nxa, (row + n_waves) * kRowPosPair63 + lane_off, hib, nxb);
     }
-    if (row < fast_rows) body(raw0, row, ptr);
+    if (row < fast_rows) {
+        uint32_t hia, nxa;
+        const uint32_t ca = body(raw0, row, ptr, hia, nxa);
+        handle(ca, row * kRowPosPair63 + lane_off, hia, nxa, row * kRowPosPair63 + lane_off, hia, nxa);
+    }
     // the last (at most two) rows touch the end of the buffer: byte-wise loads
     for (row = fast_rows + ((gw + n_waves - fast_rows % n_waves) % n_waves); row < n_rows; row += n_waves) {
-        const uint64_t p0 = row * kRowPosPair63 + (uint64_t)lane * kChunk;
+        const uint64_t p0 = row * kRowPosPair63 + lane_off;
         const uint32_t hi = load_pack(bases, n, p0);
         const uint32_t nxt = __shfl_down(hi, 1);
-        handle(pair_lookup16(tab, hi, nxt), p0, hi, nxt);
+        const uint32_t c = pair_lookup16(tab, hi, nxt);
+        handle(halo_lane ? 0u : c, p0, hi, nxt, p0, hi, nxt);
     }
     drain(1);
 }
@@ -378,27 +394,29 @@ __global__ __launch_bounds__(1024) void k_exclusive_scan(const uint32_t* __restr
 }
 
 // ------------------------------------------------------------- expand pass --
-// One workgroup per dense tile: bitmap bits -> Hit records in position order.
+// One WAVE per dense tile (four tiles per workgroup, no workgroup barrier): bitmap
+// bits -> Hit records in position order, and the tile's words/count are left zero.
+constexpr int kExpandTilesPerWg = kThreads / 64;
 __global__ __launch_bounds__(kThreads) void k_expand(const uint8_t* __restrict__ bases, uint64_t n, uint32_t k,
                                                     uint32_t m, uint32_t* __restrict__ bitmap,
                                                     uint32_t* __restrict__ tile_count,
-                                                    const uint32_t* __restrict__ tile_off,
+                                                    const uint32_t* __restrict__ tile_off, uint64_t n_tiles,
                                                     const uint64_t* __restrict__ rec_off, uint32_t n_rec,
                                                     Hit* __restrict__ hits) {
-    const uint32_t b = blockIdx.x;
-    if (tile_count[b] == 0) return;
-    __shared__ uint32_t wave_sum[kThreads / 64];
-    const uint32_t t = threadIdx.x, lane = t & 63, wid = t >> 6;
-    constexpr int WPT = kTileWords / kThreads;  // 2 words per lane, consecutive
-    uint32_t words[WPT];
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t b = (uint64_t)blockIdx.x * kExpandTilesPerWg + (threadIdx.x >> 6);
+    if (b >= n_tiles) return;
+    if (tile_count[b] == 0) return;            // wave-uniform
+    constexpr int WPL = kTileWords / 64;        // 8 consecutive words per lane
+    uint32_t words[WPL];
     uint32_t cnt = 0;
 #pragma unroll
-    for (int i = 0; i < WPT; ++i) {
-        words[i] = bitmap[(uint64_t)b * kTileWords + t * WPT + i];
+    for (int i = 0; i < WPL; ++i) {
+        words[i] = bitmap[b * kTileWords + lane * WPL + i];
         cnt += __popc(words[i]);
         // leave the bitmap all-zero behind us: the pair-table dense pass publishes hits
         // with atomicOr into a zeroed bitmap, and this saves it a 1/8 B-per-position memset
-        if (words[i]) bitmap[(uint64_t)b * kTileWords + t * WPT + i] = 0;
+        if (words[i]) bitmap[b * kTileWords + lane * WPL + i] = 0;
     }
     uint32_t x = cnt;
 #pragma unroll
@@ -406,20 +424,16 @@ __global__ __launch_bounds__(kThreads) void k_expand(const uint8_t* __restrict__
         const uint32_t y = __shfl_up(x, d);
         if (lane >= (uint32_t)d) x += y;
     }
-    if (lane == 63) wave_sum[wid] = x;
-    __syncthreads();                       // every lane has read tile_count[b] by now
-    if (t == 0) tile_count[b] = 0;
-    uint32_t pre = 0;
-    for (uint32_t w = 0; w < wid; ++w) pre += wave_sum[w];
-    uint32_t rank = tile_off[b] + pre + x - cnt;
+    uint32_t rank = tile_off[b] + x - cnt;
+    if (lane == 0) tile_count[b] = 0;          // every lane has read it (same wave, program order)
     const uint32_t mm = (1u << (2 * m)) - 1u;
 #pragma unroll
-    for (int i = 0; i < WPT; ++i) {
+    for (int i = 0; i < WPL; ++i) {
         uint32_t bits = words[i];
         while (bits) {
             const int bit = __ffs(bits) - 1;
             bits &= bits - 1;
-            const uint64_t pos = (uint64_t)b * kTilePos + (uint64_t)(t * WPT + i) * 32 + bit;
+            const uint64_t pos = b * kTilePos + (uint64_t)(lane * WPL + i) * 32 + bit;
             uint32_t f = 0;
             for (uint32_t j = 0; j < m; ++j) f = (f << 2) | ((bases[pos + j] >> 1) & 3u);
             f &= mm;
@@ -674,7 +688,7 @@ static int launch_dense(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_ba
             SPSP_HIP(hipMemsetAsync(ctx->tile_count.as<uint32_t>() + from, 0, (size_t)(n_tiles - from) * 4, ctx->stream));
             ctx->zeroed_tiles = n_tiles;
         }
-        const size_t lds = (size_t)kPairWaves * kQueueCap * 12;
+        const size_t lds = (size_t)kPairWaves * kQueueCap * 8;
         static bool attr_set = false;
         if (!attr_set) {
             SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_pair),
@@ -750,9 +764,10 @@ static int scan_device_inner(spsp_ctx* ctx, const spsp_params* p, const uint8_t*
     if ((rc = ctx->hits.reserve((size_t)n_hits * sizeof(Hit)))) return rc;
     if ((rc = ctx->emit_count.reserve((size_t)n_hits * 4))) return rc;
     if ((rc = ctx->emit_off.reserve((size_t)(n_hits + 1) * 4))) return rc;
-    hipLaunchKernelGGL(k_expand, dim3((uint32_t)n_tiles), dim3(kThreads), 0, ctx->stream, d_bases, n_bases, p->k,
-                       p->m, ctx->bitmap.as<uint32_t>(), ctx->tile_count.as<uint32_t>(),
-                       ctx->tile_off.as<uint32_t>(), d_rec_off, n_rec, ctx->hits.as<Hit>());
+    hipLaunchKernelGGL(k_expand, dim3((uint32_t)((n_tiles + kExpandTilesPerWg - 1) / kExpandTilesPerWg)), dim3(kThreads), 0,
+                       ctx->stream, d_bases, n_bases, p->k, p->m, ctx->bitmap.as<uint32_t>(),
+                       ctx->tile_count.as<uint32_t>(), ctx->tile_off.as<uint32_t>(), n_tiles, d_rec_off, n_rec,
+                       ctx->hits.as<Hit>());
     SPSP_HIP(hipGetLastError());
     ctx->dirty_tiles = 0;   // k_expand leaves bitmap and tile counts zeroed
     const uint32_t rblocks = (uint32_t)((n_hits + 127) / 128);
