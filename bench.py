@@ -113,7 +113,6 @@ def main():
 
     def step():
         d_out, n_out = ctx.scan_device(p, d_bases.data_ptr(), d_bases.numel(), d_off.data_ptr(), len(recs))
-        ctx.device_free(d_out)
         if world > 1:  # the one data-path collective: packed sketch keys over RCCL/xGMI
             g = exchange.exchange(d_my_min, d_my_lo)
             mn_ptr, lo_ptr = g.minimizer.data_ptr(), g.kmer_lo.data_ptr()

@@ -9,7 +9,7 @@
  * Conventions: plain pointers and sizes, no exceptions cross the boundary,
  * 0 = ok / negative = error (text from spsp_last_error(), thread-local).
  * Buffers returned through `**out` are owned by the library and released with
- * spsp_free() (host) or spsp_device_free() (device).  A context is bound to
+ * spsp_free().  A context is bound to
  * one HIP device + one stream and is not shared between threads: the CLIs use
  * one context (= one stream) per in-flight genome.
  *
@@ -81,7 +81,6 @@ void spsp_destroy(spsp_ctx* ctx);
 const char* spsp_last_error(void);
 const char* spsp_version(void);
 void spsp_free(void* host_ptr);
-void spsp_device_free(spsp_ctx* ctx, void* device_ptr);
 
 /* ------------------------------------------------------------ measurement -- */
 /* HIP-event timing of the two dominant kernels and of the whole pipelines, on
@@ -113,8 +112,10 @@ int spsp_scan(spsp_ctx* ctx, const spsp_params* p, const uint8_t* bases, const u
               uint32_t n_rec, spsp_superkmer** out, uint64_t* n_out);
 
 /* Same with everything resident in HBM (16-byte aligned d_bases). The result
- * stays on the device (*d_out, spsp_device_free) and the call returns once
- * the launches are queued and the two small sizing reads have completed. */
+ * stays on the device in a buffer OWNED BY THE CONTEXT (*d_out: n_out records,
+ * valid until the next scan call on this context; do not free). The whole
+ * pipeline is queued on the context's stream and the call returns after the one
+ * host synchronisation that reads back *n_out. */
 int spsp_scan_device(spsp_ctx* ctx, const spsp_params* p, const void* d_bases, uint64_t n_bases,
                      const void* d_rec_off, uint32_t n_rec, void** d_out, uint64_t* n_out);
 

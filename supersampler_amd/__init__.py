@@ -53,7 +53,7 @@ SUPERKMER_DTYPE = np.dtype([("rec", "<u4"), ("minimizer", "<u4"), ("start", "<u8
 
 # every symbol include/spsp.h declares (tests check the .so exports them all)
 ABI_SYMBOLS = [
-    "spsp_create", "spsp_destroy", "spsp_last_error", "spsp_version", "spsp_free", "spsp_device_free",
+    "spsp_create", "spsp_destroy", "spsp_last_error", "spsp_version", "spsp_free",
     "spsp_timing_enable", "spsp_timing_read", "spsp_threshold_host", "spsp_scan", "spsp_scan_device", "spsp_scan_hits_device", "spsp_compare",
     "spsp_compare_device", "spsp_fasta_clean_host", "spsp_sketch_build_host", "spsp_sketch_parse_host",
     "spsp_csv_host", "spsp_read_file_host", "spsp_write_gz_host", "spsp_sketch_file", "spsp_compare_files",
@@ -77,7 +77,6 @@ def lib():
     L.spsp_last_error.restype = cp; L.spsp_last_error.argtypes = []
     L.spsp_version.restype = cp; L.spsp_version.argtypes = []
     L.spsp_free.restype = None; L.spsp_free.argtypes = [vp]
-    L.spsp_device_free.restype = None; L.spsp_device_free.argtypes = [vp, vp]
     L.spsp_timing_enable.restype = i32; L.spsp_timing_enable.argtypes = [vp, i32]
     L.spsp_timing_read.restype = i32; L.spsp_timing_read.argtypes = [vp, P(Timing)]
     L.spsp_threshold_host.restype = u64; L.spsp_threshold_host.argtypes = [u32, u32, dbl]
@@ -246,7 +245,8 @@ class Context:
         return np.frombuffer(_take(out, n.value * SUPERKMER_DTYPE.itemsize), dtype=SUPERKMER_DTYPE).copy()
 
     def scan_device(self, params, d_bases, n_bases, d_rec_off, n_rec):
-        """device pointers in, device pointer out: returns (d_out, n_out); free with device_free."""
+        """device pointers in, device pointer out: returns (d_out, n_out); d_out is owned by the
+        context and valid until its next scan call."""
         out, n = C.c_void_p(), C.c_uint64()
         _check(lib().spsp_scan_device(self._h, C.byref(params), d_bases, n_bases, d_rec_off, n_rec, C.byref(out),
                                       C.byref(n)))
@@ -256,10 +256,6 @@ class Context:
         n = C.c_uint64()
         _check(lib().spsp_scan_hits_device(self._h, C.byref(params), d_bases, n_bases, C.byref(n)))
         return n.value
-
-    def device_free(self, ptr):
-        if ptr:
-            lib().spsp_device_free(self._h, C.c_void_p(ptr))
 
     def sketch_fasta(self, text, k=31, m=11, s=1000.0, abundance=1, flags=SPSP_SCAN_DEFAULT):
         """FASTA bytes -> (payload, stats): clean -> GPU scan -> sketch builder."""

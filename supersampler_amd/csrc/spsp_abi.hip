@@ -135,7 +135,7 @@ void spsp_destroy(spsp_ctx* c) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->bases, &c->rec_off, &c->bitmap, &c->tile_count, &c->tile_off, &c->hits, &c->emit_count,
-                      &c->emit_off, &c->scan_tmp, &c->filter, &c->pairtab, &c->c_min, &c->c_lo, &c->c_hi, &c->c_table,
+                      &c->emit_off, &c->scan_tmp, &c->d_scalar, &c->filter, &c->pairtab, &c->c_min, &c->c_lo, &c->c_hi, &c->c_table,
                       &c->c_owner, &c->c_rowid, &c->c_slot, &c->c_row, &c->c_matrix, &c->c_inter, &c->c_flags,
                       &c->c_skoff};
     for (DevBuf* b : bufs) b->release();
@@ -149,12 +149,6 @@ void spsp_destroy(spsp_ctx* c) {
 }
 
 void spsp_free(void* p) { free(p); }
-void spsp_device_free(spsp_ctx* ctx, void* p) {
-    if (!p) return;
-    if (ctx) (void)hipSetDevice(ctx->device);
-    (void)hipFree(p);
-}
-
 int spsp_scan(spsp_ctx* ctx, const spsp_params* p, const uint8_t* bases, const uint64_t* rec_off, uint32_t n_rec,
               spsp_superkmer** out, uint64_t* n_out) {
     if (!ctx || !out || !n_out) { set_error("NULL argument"); return SPSP_ERR_ARG; }
@@ -175,7 +169,7 @@ int spsp_scan(spsp_ctx* ctx, const spsp_params* p, const uint8_t* bases, const u
     SPSP_HIP(hipMemcpyAsync(ctx->rec_off.p, rec_off, (size_t)(n_rec + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     spsp_superkmer* d_out = nullptr;
     uint64_t cnt = 0;
-    rc = scan_device_impl(ctx, p, ctx->bases.as<uint8_t>(), n, ctx->rec_off.as<uint64_t>(), n_rec, &d_out, &cnt, false);
+    rc = scan_device_impl(ctx, p, ctx->bases.as<uint8_t>(), n, ctx->rec_off.as<uint64_t>(), n_rec, &d_out, &cnt);
     if (rc) return rc;
     if (cnt == 0) { SPSP_HIP(hipStreamSynchronize(ctx->stream)); return SPSP_OK; }
     spsp_superkmer* h = (spsp_superkmer*)malloc((size_t)cnt * sizeof(spsp_superkmer));
@@ -192,7 +186,7 @@ int spsp_scan_device(spsp_ctx* ctx, const spsp_params* p, const void* d_bases, u
     if (!ctx || !d_out || !n_out) { set_error("NULL argument"); return SPSP_ERR_ARG; }
     SPSP_HIP(hipSetDevice(ctx->device));
     spsp_superkmer* o = nullptr;
-    int rc = scan_device_impl(ctx, p, (const uint8_t*)d_bases, n_bases, (const uint64_t*)d_rec_off, n_rec, &o, n_out, true);
+    int rc = scan_device_impl(ctx, p, (const uint8_t*)d_bases, n_bases, (const uint64_t*)d_rec_off, n_rec, &o, n_out);
     *d_out = o;
     return rc;
 }

@@ -10,7 +10,8 @@
 // GPU formulation (integer only, no MFMA):
 //   1. dictionary: every distinct (minimizer, k-mer) key of the rows this rank
 //      owns gets a row id (open-addressing table of 64-bit fingerprints,
-//      claimed with one CAS; full keys are verified afterwards, so a
+//      claimed with one CAS (the winner records itself as the slot's owner);
+//      full keys are verified against the owner afterwards, so a
 //      fingerprint collision is detected and the build retried with a new
 //      seed -- results never depend on the fingerprint).
 //   2. colour matrix A[row][N bits]: bit j set iff sketch j holds the key --
@@ -73,9 +74,10 @@ __device__ __forceinline__ uint32_t sketch_of(const uint64_t* __restrict__ sk_of
 __global__ void k_insert(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n, uint64_t S, uint32_t row_first,
                          uint32_t row_stride, uint64_t seed, uint64_t* __restrict__ table, uint32_t log2cap,
                          uint32_t* __restrict__ owner, uint32_t* __restrict__ slot, uint32_t* __restrict__ flags) {
-    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= S) return;
-    const uint32_t j = sketch_of(sk_off, n, e);
+    // grid.y = sketch, grid.x = 256-key chunk of it (no per-entry search for the owning sketch)
+    const uint32_t j = blockIdx.y;
+    const uint64_t e = sk_off[j] + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= sk_off[j + 1]) return;
     if (e > sk_off[j] && !key_less(K, e - 1, e)) atomicOr(&flags[0], 1u);
     if (j % row_stride != row_first) return;
     const uint64_t fp = fingerprint(K, e, seed);
@@ -83,11 +85,11 @@ __global__ void k_insert(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n
     uint64_t pos = home_slot(fp, log2cap);
     for (;;) {
         const unsigned long long old = atomicCAS((unsigned long long*)&table[pos], 0ull, (unsigned long long)fp);
-        if (old == 0ull || old == fp) break;
+        if (old == 0ull) { owner[pos] = (uint32_t)e; break; }   // the claiming entry is the slot's owner: one plain store
+        if (old == fp) break;
         pos = (pos + 1) & mask;
     }
     slot[e] = (uint32_t)pos;
-    atomicMin(&owner[pos], (uint32_t)e);
 }
 
 // Occupied slot -> dense row id.  Same-address atomics retire at ~90 per microsecond on this
@@ -128,10 +130,10 @@ __global__ __launch_bounds__(kRowThreads) void k_assign_rows(const uint64_t* __r
 __global__ void k_verify(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n, uint64_t S, uint32_t row_first,
                          uint32_t row_stride, const uint32_t* __restrict__ owner, const uint32_t* __restrict__ slot,
                          uint32_t* __restrict__ flags) {
-    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= S) return;
-    const uint32_t j = sketch_of(sk_off, n, e);
-    if (j % row_stride != row_first) return;
+    const uint32_t j = row_first + blockIdx.y * row_stride;   // owned sketches only
+    if (j >= n) return;
+    const uint64_t e = sk_off[j] + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= sk_off[j + 1]) return;
     if (!key_eq(K, owner[slot[e]], e)) atomicOr(&flags[1], 1u);
 }
 
@@ -141,9 +143,9 @@ __global__ void k_fill(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n, 
                        uint32_t row_stride, uint64_t seed, const uint64_t* __restrict__ table, uint32_t log2cap,
                        const uint32_t* __restrict__ owner, const uint32_t* __restrict__ rowid, uint32_t W,
                        unsigned long long* __restrict__ A, uint32_t* __restrict__ row_of_entry) {
-    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= S) return;
-    const uint32_t j = sketch_of(sk_off, n, e);
+    const uint32_t j = blockIdx.y;
+    const uint64_t e = sk_off[j] + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= sk_off[j + 1]) return;
     const uint64_t fp = fingerprint(K, e, seed);
     const uint64_t mask = (1ull << log2cap) - 1;
     uint64_t pos = home_slot(fp, log2cap);
@@ -237,22 +239,27 @@ static int compare_device_inner(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min
     Keys K{d_min, d_lo, (k > 32) ? d_hi : nullptr};
     const uint64_t* sk = ctx->c_skoff.as<uint64_t>();
     uint32_t* flags = ctx->c_flags.as<uint32_t>();  // [0] unsorted, [1] collision, [2] n_rows
-    const uint32_t eblocks = (uint32_t)((S + 255) / 256);
+    uint64_t max_all = 0, max_own = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint64_t c = h_sk_off[i + 1] - h_sk_off[i];
+        max_all = std::max(max_all, c);
+        if (i % row_stride == row_first) max_own = std::max(max_own, c);
+    }
+    const dim3 grid_all((uint32_t)((max_all + 255) / 256), n), grid_own((uint32_t)((max_own + 255) / 256), n_own);
     const uint32_t sblocks = (uint32_t)((cap + (uint64_t)kRowThreads * kRowSlots - 1) / ((uint64_t)kRowThreads * kRowSlots));
     uint32_t n_rows = 0;
     uint64_t seed = 0x5350535053505350ULL;
     for (int attempt = 0;; ++attempt) {
         SPSP_HIP(hipMemsetAsync(ctx->c_table.p, 0, (size_t)cap * 8, ctx->stream));
-        SPSP_HIP(hipMemsetAsync(ctx->c_owner.p, 0xff, (size_t)cap * 4, ctx->stream));
         SPSP_HIP(hipMemsetAsync(flags, 0, 64, ctx->stream));
-        hipLaunchKernelGGL(k_insert, dim3(eblocks), dim3(256), 0, ctx->stream, K, sk, n, S, row_first, row_stride, seed,
+        hipLaunchKernelGGL(k_insert, grid_all, dim3(256), 0, ctx->stream, K, sk, n, S, row_first, row_stride, seed,
                            ctx->c_table.as<uint64_t>(), log2cap, ctx->c_owner.as<uint32_t>(),
                            ctx->c_slot.as<uint32_t>(), flags);
         SPSP_HIP(hipGetLastError());
         hipLaunchKernelGGL(k_assign_rows, dim3(sblocks), dim3(kRowThreads), 0, ctx->stream, ctx->c_table.as<uint64_t>(), cap,
                            ctx->c_rowid.as<uint32_t>(), flags + 2);
         SPSP_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k_verify, dim3(eblocks), dim3(256), 0, ctx->stream, K, sk, n, S, row_first, row_stride,
+        hipLaunchKernelGGL(k_verify, grid_own, dim3(256), 0, ctx->stream, K, sk, n, S, row_first, row_stride,
                            ctx->c_owner.as<uint32_t>(), ctx->c_slot.as<uint32_t>(), flags);
         SPSP_HIP(hipGetLastError());
         uint32_t h_flags[3];
@@ -266,7 +273,7 @@ static int compare_device_inner(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min
     const uint32_t W = (n + 63) / 64;
     if ((rc = ctx->c_matrix.reserve((size_t)n_rows * W * 8))) return rc;
     SPSP_HIP(hipMemsetAsync(ctx->c_matrix.p, 0, (size_t)n_rows * W * 8, ctx->stream));
-    hipLaunchKernelGGL(k_fill, dim3(eblocks), dim3(256), 0, ctx->stream, K, sk, n, S, row_first, row_stride, seed,
+    hipLaunchKernelGGL(k_fill, grid_all, dim3(256), 0, ctx->stream, K, sk, n, S, row_first, row_stride, seed,
                        ctx->c_table.as<uint64_t>(), log2cap, ctx->c_owner.as<uint32_t>(), ctx->c_rowid.as<uint32_t>(),
                        W, ctx->c_matrix.as<unsigned long long>(), ctx->c_row.as<uint32_t>());
     SPSP_HIP(hipGetLastError());

@@ -64,7 +64,8 @@ struct spsp_ctx {
     bool own_stream = false;
     uint64_t* h_scalar = nullptr;  // pinned, 8 slots
     // scan workspace
-    spsp::DevBuf bases, rec_off, bitmap, tile_count, tile_off, hits, emit_count, emit_off, scan_tmp;
+    spsp::DevBuf bases, rec_off, bitmap, tile_count, tile_off, hits, emit_count, emit_off, scan_tmp, d_scalar;
+    uint64_t hits_cap = 0, out_cap = 0;  // entries the sparse-stage buffers are sized for (grow on overflow)
     uint64_t zeroed_tiles = 0;  // bitmap/tile_count tiles [0, zeroed_tiles) are zero unless dirty
     uint64_t dirty_tiles = 0;   // tiles [0, dirty_tiles) may hold hits of a call that never reached k_expand
     // LDS pre-filter table cache (keyed by m, threshold)
@@ -85,8 +86,7 @@ struct spsp_ctx {
 namespace spsp {
 // scan pipeline (spsp_scan.hip)
 int scan_device_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, uint64_t n_bases,
-                     const uint64_t* d_rec_off, uint32_t n_rec, spsp_superkmer** d_out, uint64_t* n_out,
-                     bool own_output);
+                     const uint64_t* d_rec_off, uint32_t n_rec, spsp_superkmer** d_out, uint64_t* n_out);
 int scan_hits_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, uint64_t n_bases,
                    uint64_t* n_hits);
 // compare pipeline (spsp_compare.hip)

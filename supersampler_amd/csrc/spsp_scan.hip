@@ -360,17 +360,24 @@ __global__ __launch_bounds__(64 * kPairWaves) void k_dense_pair(const uint8_t* _
 // out[i] = sum(in[0..i)), out[n] = total.  u32, single workgroup of 1024 lanes;
 // the arrays it runs over (tiles, hits) are tiny next to the dense pass.
 __global__ __launch_bounds__(1024) void k_exclusive_scan(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-                                                        uint64_t n, uint64_t* __restrict__ total_out) {
+                                                        uint64_t n_max, const uint32_t* __restrict__ n_dev,
+                                                        uint64_t* __restrict__ total_host, uint32_t* __restrict__ total_dev) {
+    constexpr int E = 8;                       // consecutive elements per lane per round
     __shared__ uint32_t wave_sum[16];
     __shared__ uint32_t carry_s;
     const uint32_t t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    // n may only be known on the device (a count produced earlier on this stream)
+    uint64_t n = n_max;
+    if (n_dev) { const uint64_t v = *n_dev; n = v < n_max ? v : n_max; }
     if (t == 0) carry_s = 0;
     __syncthreads();
-    uint64_t total = 0;
-    for (uint64_t base = 0; base < n; base += 1024) {
-        const uint64_t i = base + t;
-        const uint32_t v = i < n ? in[i] : 0u;
-        uint32_t x = v;
+    for (uint64_t base = 0; base < n; base += 1024 * E) {
+        const uint64_t i0 = base + (uint64_t)t * E;
+        uint32_t v[E];
+        uint32_t sum = 0;
+#pragma unroll
+        for (int u = 0; u < E; ++u) { v[u] = i0 + u < n ? in[i0 + u] : 0u; sum += v[u]; }
+        uint32_t x = sum;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t y = __shfl_up(x, d);
@@ -378,18 +385,21 @@ __global__ __launch_bounds__(1024) void k_exclusive_scan(const uint32_t* __restr
         }
         if (lane == 63) wave_sum[wid] = x;
         __syncthreads();
-        uint32_t pre = 0;
-        for (uint32_t w = 0; w < wid; ++w) pre += wave_sum[w];
+        uint32_t pre = 0, all = 0;
+        for (uint32_t w = 0; w < 16; ++w) { if (w < wid) pre += wave_sum[w]; all += wave_sum[w]; }
         const uint32_t carry = carry_s;
-        if (i < n) out[i] = carry + pre + x - v;
+        uint32_t run = carry + pre + x - sum;
+#pragma unroll
+        for (int u = 0; u < E; ++u) { if (i0 + u < n) out[i0 + u] = run; run += v[u]; }
         __syncthreads();
-        if (t == 1023) { carry_s = carry + pre + x; }
+        if (t == 0) carry_s = carry + all;
         __syncthreads();
     }
     if (t == 0) {
-        total = carry_s;
-        out[n] = (uint32_t)total;
-        if (total_out) *total_out = total;
+        const uint32_t total = carry_s;
+        out[n] = total;
+        if (total_host) *total_host = total;
+        if (total_dev) *total_dev = total;
     }
 }
 
@@ -397,63 +407,100 @@ __global__ __launch_bounds__(1024) void k_exclusive_scan(const uint32_t* __restr
 // One WAVE per dense tile (four tiles per workgroup, no workgroup barrier): bitmap
 // bits -> Hit records in position order, and the tile's words/count are left zero.
 constexpr int kExpandTilesPerWg = kThreads / 64;
+
+// m bases starting at pos as a 2-bit value: five aligned dwords cover any 15-byte span
+__device__ __forceinline__ uint32_t mmer_at(const uint8_t* __restrict__ bases, uint64_t n, uint64_t pos, uint32_t m) {
+    const uint64_t a0 = pos & ~3ull;
+    const uint32_t sh = (uint32_t)(pos & 3) * 8;
+    uint32_t d[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const uint64_t a = a0 + 4 * i;
+        d[i] = a + 4 <= n ? *reinterpret_cast<const uint32_t*>(bases + a) : 0u;
+        if (a + 4 > n && a < n) {            // ragged end of the buffer
+            for (uint32_t b = 0; a + b < n; ++b) d[i] |= (uint32_t)bases[a + b] << (8 * b);
+        }
+    }
+    uint32_t f = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t w = sh ? (d[i] >> sh) | (d[i + 1] << (32 - sh)) : d[i];   // bytes pos+4i .. pos+4i+3
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            if ((uint32_t)(4 * i + b) < m) f = (f << 2) | ((w >> (8 * b + 1)) & 3u);
+    }
+    return f;
+}
+
 __global__ __launch_bounds__(kThreads) void k_expand(const uint8_t* __restrict__ bases, uint64_t n, uint32_t k,
                                                     uint32_t m, uint32_t* __restrict__ bitmap,
                                                     uint32_t* __restrict__ tile_count,
                                                     const uint32_t* __restrict__ tile_off, uint64_t n_tiles,
                                                     const uint64_t* __restrict__ rec_off, uint32_t n_rec,
-                                                    Hit* __restrict__ hits) {
+                                                    Hit* __restrict__ hits, uint32_t hits_cap) {
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t b = (uint64_t)blockIdx.x * kExpandTilesPerWg + (threadIdx.x >> 6);
     if (b >= n_tiles) return;
     if (tile_count[b] == 0) return;            // wave-uniform
-    constexpr int WPL = kTileWords / 64;        // 8 consecutive words per lane
-    uint32_t words[WPL];
-    uint32_t cnt = 0;
-#pragma unroll
-    for (int i = 0; i < WPL; ++i) {
-        words[i] = bitmap[b * kTileWords + lane * WPL + i];
-        cnt += __popc(words[i]);
-        // leave the bitmap all-zero behind us: the pair-table dense pass publishes hits
-        // with atomicOr into a zeroed bitmap, and this saves it a 1/8 B-per-position memset
-        if (words[i]) bitmap[b * kTileWords + lane * WPL + i] = 0;
+    // the tile's 512 words as two coalesced 16-byte loads per lane: lane holds words
+    // [4*lane, 4*lane+4) of each 256-word half, so position order = (half, lane, word)
+    uint4* tile = reinterpret_cast<uint4*>(bitmap + b * kTileWords);
+    uint4 q[2];
+    q[0] = tile[lane]; q[1] = tile[64 + lane];
+    // record holding the tile's first position: one wave-uniform binary search, the hits then
+    // only step forward from it
+    const uint64_t tile_pos = b * kTilePos;
+    uint32_t rlo = 0, rhi = n_rec;              // invariant: rec_off[rlo] <= tile_pos < rec_off[rhi]
+    while (rhi - rlo > 1) {
+        const uint32_t mid = (rlo + rhi) >> 1;
+        if (rec_off[mid] <= tile_pos) rlo = mid; else rhi = mid;
     }
-    uint32_t x = cnt;
+    uint32_t cnt[2];
+    uint32_t rank[2];
+    uint32_t run = tile_off[b];
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t y = __shfl_up(x, d);
-        if (lane >= (uint32_t)d) x += y;
+    for (int h = 0; h < 2; ++h) {
+        cnt[h] = __popc(q[h].x) + __popc(q[h].y) + __popc(q[h].z) + __popc(q[h].w);
+        uint32_t x = cnt[h];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d);
+            if (lane >= (uint32_t)d) x += y;
+        }
+        rank[h] = run + x - cnt[h];
+        run += __shfl(x, 63);
+        // leave the bitmap all-zero behind us: the pair-table dense pass publishes hits with
+        // atomicOr into a zeroed bitmap, and this saves it a 1/8 B-per-position memset
+        if (cnt[h]) tile[64 * h + lane] = make_uint4(0, 0, 0, 0);
     }
-    uint32_t rank = tile_off[b] + x - cnt;
     if (lane == 0) tile_count[b] = 0;          // every lane has read it (same wave, program order)
-    const uint32_t mm = (1u << (2 * m)) - 1u;
 #pragma unroll
-    for (int i = 0; i < WPL; ++i) {
-        uint32_t bits = words[i];
-        while (bits) {
-            const int bit = __ffs(bits) - 1;
-            bits &= bits - 1;
-            const uint64_t pos = b * kTilePos + (uint64_t)(lane * WPL + i) * 32 + bit;
-            uint32_t f = 0;
-            for (uint32_t j = 0; j < m; ++j) f = (f << 2) | ((bases[pos + j] >> 1) & 3u);
-            f &= mm;
-            const uint32_t rc = rc_mmer32(f, m);
-            Hit h;
-            h.pos = pos;
-            h.canon = f < rc ? f : rc;
-            h.hash = xxh64_u64(h.canon);
-            // record = last r with rec_off[r] <= pos
-            uint32_t lo = 0, hi = n_rec;  // invariant: rec_off[lo] <= pos < rec_off[hi]
-            while (hi - lo > 1) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (rec_off[mid] <= pos) lo = mid; else hi = mid;
+    for (int h = 0; h < 2; ++h) {
+        const uint32_t w4[4] = {q[h].x, q[h].y, q[h].z, q[h].w};
+        uint32_t rk = rank[h];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint32_t bits = w4[i];
+            while (bits) {
+                const int bit = __ffs(bits) - 1;
+                bits &= bits - 1;
+                const uint64_t pos = tile_pos + (uint64_t)(256 * h + 4 * lane + i) * 32 + bit;
+                const uint32_t f = mmer_at(bases, n, pos, m);
+                const uint32_t rc = rc_mmer32(f, m);
+                Hit hrec;
+                hrec.pos = pos;
+                hrec.canon = f < rc ? f : rc;
+                hrec.hash = xxh64_u64(hrec.canon);
+                uint32_t r = rlo;
+                while (r + 1 < n_rec && rec_off[r + 1] <= pos) ++r;   // records shorter than a tile are rare
+                hrec.rec = r;
+                const uint64_t r0 = rec_off[r], r1 = rec_off[r + 1];
+                const bool usable = (pos + m <= r1) && (r1 - r0 >= k);
+                hrec.flags = (hrec.canon != f ? 1u : 0u) | (usable ? 2u : 0u);
+                hrec.pad = 0;
+                if (rk < hits_cap) hits[rk] = hrec;   // the host sees n_hits > hits_cap and retries with room
+                ++rk;
             }
-            h.rec = lo;
-            const uint64_t r0 = rec_off[lo], r1 = rec_off[lo + 1];
-            const bool usable = (pos + m <= r1) && (r1 - r0 >= k);
-            h.flags = (h.canon != f ? 1u : 0u) | (usable ? 2u : 0u);
-            h.pad = 0;
-            hits[rank++] = h;
         }
     }
 }
@@ -495,12 +542,12 @@ __device__ __forceinline__ Rescan rescan_hits(const Hit* __restrict__ H, uint64_
 
 template <bool WRITE>
 __device__ uint32_t run_cluster(const Hit* __restrict__ H, uint32_t cnt, uint64_t r0, uint64_t n, uint32_t k,
-                                uint32_t m, uint32_t rec, spsp_superkmer* __restrict__ out) {
+                                uint32_t m, uint32_t rec, spsp_superkmer* __restrict__ out, uint32_t room) {
     const uint64_t km = k - m, w = km + 1;
     auto q = [&](uint32_t i) -> uint64_t { return H[i].pos - r0; };
     uint32_t nem = 0;
     auto emit = [&](uint64_t start, uint64_t len, uint32_t mini, uint32_t rev) {
-        if (WRITE) {
+        if (WRITE && nem < room) {
             spsp_superkmer e;
             e.rec = rec; e.minimizer = mini; e.start = start; e.len = (uint32_t)len; e.rev = rev;
             out[nem] = e;
@@ -567,10 +614,13 @@ __device__ uint32_t run_cluster(const Hit* __restrict__ H, uint32_t cnt, uint64_
 }
 
 template <bool WRITE>
-__global__ void k_resolve(const Hit* __restrict__ hits, uint32_t n_hits, const uint64_t* __restrict__ rec_off,
-                          uint32_t k, uint32_t m, uint32_t* __restrict__ emit_count,
-                          const uint32_t* __restrict__ emit_off, spsp_superkmer* __restrict__ out) {
+__global__ void k_resolve(const Hit* __restrict__ hits, const uint32_t* __restrict__ n_hits_dev, uint32_t hits_cap,
+                          const uint64_t* __restrict__ rec_off, uint32_t k, uint32_t m,
+                          uint32_t* __restrict__ emit_count, const uint32_t* __restrict__ emit_off,
+                          spsp_superkmer* __restrict__ out, uint32_t out_cap) {
     const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t n_hits = *n_hits_dev;
+    if (n_hits > hits_cap) n_hits = hits_cap;   // overflowed: this pass is discarded by the host
     if (h >= n_hits) return;
     const uint64_t w = k - m + 1;
     const Hit me = hits[h];
@@ -594,9 +644,10 @@ __global__ void k_resolve(const Hit* __restrict__ hits, uint32_t n_hits, const u
     }
     const uint64_t r0 = rec_off[me.rec], r1 = rec_off[me.rec + 1];
     if (WRITE) {
-        run_cluster<true>(hits + h, cnt, r0, r1 - r0, k, m, me.rec, out + emit_off[h]);
+        const uint32_t at = emit_off[h];
+        run_cluster<true>(hits + h, cnt, r0, r1 - r0, k, m, me.rec, out + at, at < out_cap ? out_cap - at : 0u);
     } else {
-        emit_count[h] = run_cluster<false>(hits + h, cnt, r0, r1 - r0, k, m, me.rec, nullptr);
+        emit_count[h] = run_cluster<false>(hits + h, cnt, r0, r1 - r0, k, m, me.rec, nullptr, 0u);
     }
 }
 
@@ -667,6 +718,7 @@ static int launch_dense(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_ba
     if ((rc = ctx->bitmap.reserve((size_t)n_tiles * kTileWords * 4))) return rc;
     if ((rc = ctx->tile_count.reserve((size_t)n_tiles * 4))) return rc;
     if ((rc = ctx->tile_off.reserve((size_t)(n_tiles + 1) * 4))) return rc;
+    if ((rc = ctx->d_scalar.reserve(64))) return rc;
     if (ctx->bitmap.p != old_bm || ctx->tile_count.p != old_tc) { ctx->zeroed_tiles = 0; ctx->dirty_tiles = 0; }
     const int variant = pick_dense(p);
     uint32_t words = 0, shift = 0;
@@ -726,7 +778,8 @@ static int launch_dense(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_ba
     if (n_tiles > ctx->zeroed_tiles) ctx->zeroed_tiles = n_tiles; // ... after which this whole range is zero
     if ((rc = ctx->ev_end(kEvDense))) return rc;
     hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->tile_count.as<uint32_t>(),
-                       ctx->tile_off.as<uint32_t>(), n_tiles, ctx->h_scalar + 0);
+                       ctx->tile_off.as<uint32_t>(), n_tiles, (const uint32_t*)nullptr, ctx->h_scalar + 0,
+                       ctx->d_scalar.as<uint32_t>() + 0);
     SPSP_HIP(hipGetLastError());
     return SPSP_OK;
 }
@@ -746,9 +799,12 @@ int scan_hits_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, 
     return SPSP_OK;
 }
 
+// Whole scan on the stream with ONE host synchronisation at the end: the sparse
+// stages are launched with grids sized by buffer capacity and read the live counts
+// from device memory.  Capacities start from the expected hit density and grow (and
+// the affected stages re-run) in the rare call that overflows them.
 static int scan_device_inner(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, uint64_t n_bases,
-                             const uint64_t* d_rec_off, uint32_t n_rec, spsp_superkmer** d_out, uint64_t* n_out,
-                             bool own_output) {
+                             const uint64_t* d_rec_off, uint32_t n_rec, spsp_superkmer** d_out, uint64_t* n_out) {
     int rc = check_params(p);
     if (rc) return rc;
     *d_out = nullptr; *n_out = 0;
@@ -756,53 +812,78 @@ static int scan_device_inner(spsp_ctx* ctx, const spsp_params* p, const uint8_t*
     if (n_rec == 0 || n_bases < p->k) return SPSP_OK;
     const uint64_t n_tiles = (n_bases + kTilePos - 1) / kTilePos;
     if (n_tiles > 0x7fffffffull) { set_error("input too large for one call"); return SPSP_ERR_OVERFLOW; }
-    if ((rc = launch_dense(ctx, p, d_bases, n_bases, n_tiles))) return rc;
-    SPSP_HIP(hipStreamSynchronize(ctx->stream));
-    const uint64_t n_hits = ctx->h_scalar[0];
-    if (n_hits == 0) return SPSP_OK;
-    if (n_hits > 0xfffffff0ull) { set_error("too many candidate m-mers for one call; split the input"); return SPSP_ERR_OVERFLOW; }
-    if ((rc = ctx->hits.reserve((size_t)n_hits * sizeof(Hit)))) return rc;
-    if ((rc = ctx->emit_count.reserve((size_t)n_hits * 4))) return rc;
-    if ((rc = ctx->emit_off.reserve((size_t)(n_hits + 1) * 4))) return rc;
-    hipLaunchKernelGGL(k_expand, dim3((uint32_t)((n_tiles + kExpandTilesPerWg - 1) / kExpandTilesPerWg)), dim3(kThreads), 0,
-                       ctx->stream, d_bases, n_bases, p->k, p->m, ctx->bitmap.as<uint32_t>(),
-                       ctx->tile_count.as<uint32_t>(), ctx->tile_off.as<uint32_t>(), n_tiles, d_rec_off, n_rec,
-                       ctx->hits.as<Hit>());
-    SPSP_HIP(hipGetLastError());
-    ctx->dirty_tiles = 0;   // k_expand leaves bitmap and tile counts zeroed
-    const uint32_t rblocks = (uint32_t)((n_hits + 127) / 128);
-    hipLaunchKernelGGL(k_resolve<false>, dim3(rblocks), dim3(128), 0, ctx->stream, ctx->hits.as<Hit>(),
-                       (uint32_t)n_hits, d_rec_off, p->k, p->m, ctx->emit_count.as<uint32_t>(),
-                       (const uint32_t*)nullptr, (spsp_superkmer*)nullptr);
-    SPSP_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->emit_count.as<uint32_t>(),
-                       ctx->emit_off.as<uint32_t>(), n_hits, ctx->h_scalar + 1);
-    SPSP_HIP(hipGetLastError());
-    SPSP_HIP(hipStreamSynchronize(ctx->stream));
-    const uint64_t n_em = ctx->h_scalar[1];
-    if (n_em == 0) return SPSP_OK;
-    if (n_em > 0xfffffff0ull) { set_error("too many super-k-mers for one call; split the input"); return SPSP_ERR_OVERFLOW; }
-    spsp_superkmer* out = nullptr;
-    if (own_output) {
-        SPSP_HIP(hipMalloc((void**)&out, (size_t)n_em * sizeof(spsp_superkmer)));
-    } else {
-        if ((rc = ctx->scan_tmp.reserve((size_t)n_em * sizeof(spsp_superkmer)))) return rc;
-        out = ctx->scan_tmp.as<spsp_superkmer>();
+    const double frac = (double)p->threshold / 18446744073709551616.0;
+    uint64_t want_hits = (uint64_t)((double)n_bases * frac * 1.25) + 4096;
+    if (want_hits > n_bases) want_hits = n_bases;
+    if (ctx->hits_cap < want_hits) ctx->hits_cap = want_hits;
+    if (ctx->out_cap < ctx->hits_cap) ctx->out_cap = ctx->hits_cap;
+    // test hooks: start from deliberately small buffers so the overflow/retry paths run
+    static const char* dbg_hits = getenv("SPSP_DEBUG_HITS_CAP");
+    static const char* dbg_out = getenv("SPSP_DEBUG_OUT_CAP");
+    if (dbg_hits) ctx->hits_cap = (uint64_t)atoll(dbg_hits);
+    if (dbg_out) ctx->out_cap = (uint64_t)atoll(dbg_out);
+    bool redo_dense = true;
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        if (ctx->hits_cap > 0xfffffff0ull || ctx->out_cap > 0xfffffff0ull) {
+            set_error("too many selected m-mers / super-k-mers for one call; split the input");
+            return SPSP_ERR_OVERFLOW;
+        }
+        const uint32_t hits_cap = (uint32_t)ctx->hits_cap, out_cap = (uint32_t)ctx->out_cap;
+        if ((rc = ctx->hits.reserve((size_t)hits_cap * sizeof(Hit)))) return rc;
+        if ((rc = ctx->emit_count.reserve((size_t)hits_cap * 4))) return rc;
+        if ((rc = ctx->emit_off.reserve((size_t)(hits_cap + 1) * 4))) return rc;
+        if ((rc = ctx->scan_tmp.reserve((size_t)out_cap * sizeof(spsp_superkmer)))) return rc;
+        const uint32_t rblocks = (hits_cap + 127) / 128;
+        uint32_t* d_sc = nullptr;
+        if (redo_dense) {
+            if ((rc = launch_dense(ctx, p, d_bases, n_bases, n_tiles))) return rc;
+            d_sc = ctx->d_scalar.as<uint32_t>();
+            hipLaunchKernelGGL(k_expand, dim3((uint32_t)((n_tiles + kExpandTilesPerWg - 1) / kExpandTilesPerWg)),
+                               dim3(kThreads), 0, ctx->stream, d_bases, n_bases, p->k, p->m, ctx->bitmap.as<uint32_t>(),
+                               ctx->tile_count.as<uint32_t>(), ctx->tile_off.as<uint32_t>(), n_tiles, d_rec_off, n_rec,
+                               ctx->hits.as<Hit>(), hits_cap);
+            SPSP_HIP(hipGetLastError());
+            ctx->dirty_tiles = 0;   // k_expand leaves bitmap and tile counts zeroed
+            hipLaunchKernelGGL(k_resolve<false>, dim3(rblocks), dim3(128), 0, ctx->stream, ctx->hits.as<Hit>(), d_sc + 0,
+                               hits_cap, d_rec_off, p->k, p->m, ctx->emit_count.as<uint32_t>(),
+                               (const uint32_t*)nullptr, (spsp_superkmer*)nullptr, 0u);
+            SPSP_HIP(hipGetLastError());
+            hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->emit_count.as<uint32_t>(),
+                               ctx->emit_off.as<uint32_t>(), (uint64_t)hits_cap, (const uint32_t*)(d_sc + 0),
+                               ctx->h_scalar + 1, d_sc + 1);
+            SPSP_HIP(hipGetLastError());
+        }
+        d_sc = ctx->d_scalar.as<uint32_t>();
+        hipLaunchKernelGGL(k_resolve<true>, dim3(rblocks), dim3(128), 0, ctx->stream, ctx->hits.as<Hit>(), d_sc + 0, hits_cap,
+                           d_rec_off, p->k, p->m, (uint32_t*)nullptr, ctx->emit_off.as<uint32_t>(),
+                           ctx->scan_tmp.as<spsp_superkmer>(), out_cap);
+        SPSP_HIP(hipGetLastError());
+        SPSP_HIP(hipStreamSynchronize(ctx->stream));
+        const uint64_t n_hits = ctx->h_scalar[0], n_em = ctx->h_scalar[1];
+        if (n_hits > hits_cap) {           // the bitmap has been consumed: start over with room for every hit
+            ctx->hits_cap = n_hits + n_hits / 8 + 1024;
+            if (ctx->out_cap < ctx->hits_cap && !dbg_out) ctx->out_cap = ctx->hits_cap;
+            redo_dense = true;
+            continue;
+        }
+        if (n_em > out_cap) {              // hits and offsets are intact: only the write pass repeats
+            ctx->out_cap = n_em + n_em / 8 + 1024;
+            redo_dense = false;
+            continue;
+        }
+        *d_out = n_em ? ctx->scan_tmp.as<spsp_superkmer>() : nullptr;
+        *n_out = n_em;
+        return SPSP_OK;
     }
-    hipLaunchKernelGGL(k_resolve<true>, dim3(rblocks), dim3(128), 0, ctx->stream, ctx->hits.as<Hit>(),
-                       (uint32_t)n_hits, d_rec_off, p->k, p->m, (uint32_t*)nullptr,
-                       ctx->emit_off.as<uint32_t>(), out);
-    SPSP_HIP(hipGetLastError());
-    *d_out = out; *n_out = n_em;
-    return SPSP_OK;
+    set_error("scan buffers kept overflowing");
+    return SPSP_ERR_OVERFLOW;
 }
 
 int scan_device_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, uint64_t n_bases,
-                     const uint64_t* d_rec_off, uint32_t n_rec, spsp_superkmer** d_out, uint64_t* n_out,
-                     bool own_output) {
+                     const uint64_t* d_rec_off, uint32_t n_rec, spsp_superkmer** d_out, uint64_t* n_out) {
     int rc = ctx->ev_begin(kEvScan);
     if (rc) return rc;
-    rc = scan_device_inner(ctx, p, d_bases, n_bases, d_rec_off, n_rec, d_out, n_out, own_output);
+    rc = scan_device_inner(ctx, p, d_bases, n_bases, d_rec_off, n_rec, d_out, n_out);
     const int rc2 = ctx->ev_end(kEvScan);
     return rc ? rc : rc2;
 }

@@ -4,6 +4,7 @@ inputs; full-size inputs are checked through size-independent properties."""
 import gzip
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -192,6 +193,31 @@ def test_cli_end_to_end_matches_oracle(tmp_path):
     inter, card, _, _ = orc.compare(payloads)
     for jac, fn in ((True, "res_jaccard.csv.gz"), (False, "res_containment.csv.gz")):
         assert gzip.open(tmp_path / fn, "rb").read() == orc.csv(jac, listed, inter, card, None, 5, 0.0)
+
+
+def test_scan_buffer_overflow_retries():
+    """the sparse stages are launched with capacity-sized buffers; a call that overflows them
+    re-runs with room (hits: from the dense pass, super-k-mers: the write pass only)."""
+    code = (
+        "import numpy as np, sys\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import supersampler_amd as sp\n"
+        "from supersampler_amd import synth\n"
+        "from oracle import oracle_py as orc\n"
+        "g = synth.random_genome(np.random.default_rng(8), 400_000)\n"
+        "b, o = synth.concat_records([g[:250_000], g[250_000:]])\n"
+        "ctx = sp.Context(0)\n"
+        "for (k, m, s) in [(31, 11, 50), (21, 11, 1.0)]:\n"
+        "    p = sp.make_params(k, m, s)\n"
+        "    got = ctx.scan(p, b, o)\n"
+        "    want, _ = orc.scan(k, m, p.threshold, b, o)\n"
+        "    assert len(got) == len(want) > 50 and all((got[f] == want[f]).all() for f in got.dtype.names)\n"
+        "print('ok')\n") % (ROOT, os.path.join(ROOT, "tests"))
+    for env_extra in ({"SPSP_DEBUG_HITS_CAP": "16"}, {"SPSP_DEBUG_OUT_CAP": "8"},
+                      {"SPSP_DEBUG_HITS_CAP": "100", "SPSP_DEBUG_OUT_CAP": "3"}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env_extra), capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0 and "ok" in r.stdout, (env_extra, r.stdout[-2000:], r.stderr[-2000:])
 
 
 # ----------------------------------------------------------------- full size --
