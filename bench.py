@@ -187,7 +187,7 @@ def main():
             "superkmers_per_step": int(n_out), "inter_nonzero": inter_nonzero,
             "roofline": {"kernel": "k_dense (hash + threshold at every m-mer position)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None,
+                         "traffic": pmc_traffic(args),
                          "algorithmic_bytes_per_launch": int(d_bases.numel())},
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -196,6 +196,20 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(args):
+    """HBM bytes per launch of the dense kernel from the PMC counters (FETCH_SIZE/WRITE_SIZE, separate
+    rocprofv3 --pmc passes of this same command, gfx950 correction applied: profiles/r01_b_pmc_hbm_traffic.json).
+    Counters cannot be read from inside this process, so the figure is looked up for the matching workload."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_b_pmc_hbm_traffic.json")))
+        w = d["workload"]
+        if (w["genomes"], w["genome_len"], w["k"], w["m"], w["s"], w["scan_mode"]) != (args.genomes, args.length, K, M, S, args.mode):
+            return None
+        return d["kernels"]["k_dense_pair"]["hbm_bytes_per_launch_corrected"]
+    except Exception:
+        return None
 
 
 def cpu_baseline(recs, payloads, p):

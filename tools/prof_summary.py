@@ -3,7 +3,8 @@
 
 bench.py's setup phase launches the same kernels on single genomes; the timed
 steps are the launches with the largest grid of each kernel, so the summary is
-restricted to those ("steady" columns) next to the all-launch totals.
+restricted to those ("steady" columns: largest grid and >= half the longest
+duration) next to the all-launch totals.
 
 usage: tools/prof_summary.py <kernel_trace.csv> [out.md]
 """
@@ -34,7 +35,10 @@ def main():
     order = sorted(per.items(), key=lambda kv: -sum(d[0] for d in kv[1]))
     for name, ds in order:
         gmax = max(d[1] for d in ds)
-        steady = [d for d in ds if d[1] == gmax]
+        dmax = max(d[0] for d in ds)
+        # timed steps = launches with the largest grid; a persistent kernel launches the same grid for
+        # every input size, so also require at least half of the longest duration
+        steady = [d for d in ds if d[1] == gmax and d[0] * 2 >= dmax]
         tot = sum(d[0] for d in ds) / 1e3
         avg = sum(d[0] for d in steady) / len(steady) / 1e3
         mn = min(d[0] for d in steady) / 1e3
