@@ -17,10 +17,10 @@
 //   2. colour matrix A[row][N bits]: bit j set iff sketch j holds the key --
 //      the reference's vector<bool>(N+1) colour sets, stored densely.
 //   3. accumulate: for an owned sketch i, inter[i][j] = sum over i's keys of
-//      bit j of the key's row.  A wave owns 64 columns (one lane per column) and
-//      adds the row word's bit for its lane: one wave instruction advances 64
-//      pair counters, so the work is sum_i n_i * N/64 wave-ops instead of the
-//      N^2 * n of pairwise merging.
+//      bit j of the key's row: a sparse-row sum over the colour matrix.  A lane
+//      owns one 64-bit word and counts its 64 columns bit-sliced (eight 64-bit
+//      adds per word), so the work is ~sum_i n_i * N/64 word-adds instead of
+//      the N^2 * n comparisons of pairwise merging.
 #include <algorithm>
 #include <cstring>
 #include <vector>
@@ -164,50 +164,79 @@ __global__ void k_fill(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n, 
     }
 }
 
-// inter[i][64*wd + lane] += number of keys of sketch i (within one chunk of its keys) whose
-// colour row has bit `lane` of word wd set.  One workgroup = one owned sketch x one 64-column word x
-// one chunk of keys; its four waves split the chunk, every lane of a wave is one column.
+// inter[i][*] for one owned sketch i and one block of 64 colour words (4096 columns).
+// A lane owns ONE 64-bit word of the colour rows (64 columns): a key's row is read
+// with one coalesced wave load and every lane adds its word's 64 bits into 64 private
+// counters.  The adds are bit-sliced: (w >> b) & 0x0101..01 extracts bits b, b+8, ...
+// as eight byte lanes, so eight 64-bit adds cover the whole word; the byte counters
+// are spilled into 32-bit counters before they can wrap.  When a row is narrower than
+// 64 words several keys share one wave load (lane group g handles key g).
+// The four waves of the workgroup split the sketch's keys and meet in LDS; results
+// are written with plain coalesced stores (every column > i, zeros included).
 constexpr int kAccThreads = 256;
-constexpr int kAccChunk = 1024;   // keys per workgroup
 __global__ __launch_bounds__(kAccThreads) void k_accumulate(const uint32_t* __restrict__ row_of_entry,
                                                            const uint64_t* __restrict__ A, uint32_t W,
+                                                           uint32_t lanes_per_key,
                                                            const uint64_t* __restrict__ sk_off, uint32_t n,
                                                            uint32_t row_first, uint32_t row_stride,
                                                            uint32_t* __restrict__ inter) {
     const uint32_t i = row_first + blockIdx.y * row_stride;
     if (i >= n) return;
-    const uint32_t wd = blockIdx.x;
-    if (wd < ((i + 1) >> 6)) return;           // no column > i in this word
-    const uint64_t e0 = sk_off[i] + (uint64_t)blockIdx.z * kAccChunk, e_end = sk_off[i + 1];
-    if (e0 >= e_end) return;
-    const uint64_t e1 = e0 + kAccChunk < e_end ? e0 + kAccChunk : e_end;
-    __shared__ uint32_t s_part[kAccThreads];
+    const uint32_t wb = blockIdx.x;                         // block of 64 words
+    const uint32_t first_wd = (i + 1) >> 6;                 // first word holding a column > i
+    if (wb * 64 + 63 < first_wd) return;
+    __shared__ uint32_t s_cnt[64 * 64];
     const uint32_t t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    uint32_t cnt = 0;
-    // wave w takes keys e0 + w, e0 + w + 4, ...; 8 row words in flight per wave
-    uint64_t e = e0 + wave;
-    for (; e + 28 < e1; e += 32) {
-        uint64_t mk[8];
+    for (uint32_t x = t; x < 64 * 64; x += kAccThreads) s_cnt[x] = 0;
+    const uint32_t groups = 64 / lanes_per_key;             // keys per wave load
+    const uint32_t grp = lane / lanes_per_key, wl = lane % lanes_per_key;
+    const uint32_t word = wb * 64 + wl;
+    const bool active = word < W && word >= first_wd;
+    const uint64_t e0 = sk_off[i], e1 = sk_off[i + 1];
+    const uint64_t M8 = 0x0101010101010101ULL;
+    uint32_t cnt[64];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) mk[u] = A[(uint64_t)row_of_entry[e + 4 * u] * W + wd];
+    for (int b = 0; b < 64; ++b) cnt[b] = 0;
+    uint64_t acc[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) cnt += (uint32_t)(mk[u] >> lane) & 1u;
+    for (int b = 0; b < 8; ++b) acc[b] = 0;
+    uint32_t pending = 0;                                    // keys folded into acc[] since the last spill
+    auto spill = [&]() {
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cnt[8 * j + b] += (uint32_t)(acc[b] >> (8 * j)) & 0xffu;
+            acc[b] = 0;
+        }
+        pending = 0;
+    };
+    const uint64_t step = (uint64_t)(kAccThreads / 64) * groups;
+    for (uint64_t e = e0 + (uint64_t)wave * groups + grp; e < e1 + 3 * step; e += 4 * step) {
+        uint64_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint64_t eu = e + u * step;
+            v[u] = (active && eu < e1) ? A[(uint64_t)row_of_entry[eu] * W + word] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int b = 0; b < 8; ++b) acc[b] += (v[u] >> b) & M8;
+        }
+        pending += 4;
+        if (pending >= 252) spill();
     }
-    for (; e < e1; e += 4) cnt += (uint32_t)(A[(uint64_t)row_of_entry[e] * W + wd] >> lane) & 1u;
-    s_part[t] = cnt;
+    spill();
     __syncthreads();
-    if (wave == 0) {
-        cnt = s_part[lane] + s_part[lane + 64] + s_part[lane + 128] + s_part[lane + 192];
-        const uint32_t col = wd * 64 + lane;
-        if (cnt && col > i && col < n) atomicAdd(&inter[(uint64_t)i * n + col], cnt);
+#pragma unroll
+    for (int b = 0; b < 64; ++b)
+        if (cnt[b]) atomicAdd(&s_cnt[wl * 64 + b], cnt[b]);
+    __syncthreads();
+    const uint32_t cols = lanes_per_key * 64;
+    for (uint32_t x = t; x < cols; x += kAccThreads) {
+        const uint32_t col = wb * 4096 + x;
+        if (col > i && col < n) inter[(uint64_t)i * n + col] = s_cnt[x];
     }
-}
-
-// cells (i, j > i) of the owned rows start from zero (k_accumulate adds into them)
-__global__ void k_zero_owned(uint32_t n, uint32_t row_first, uint32_t row_stride, uint32_t* __restrict__ inter) {
-    const uint32_t i = row_first + blockIdx.y * row_stride;
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && j < n && j > i) inter[(uint64_t)i * n + j] = 0;
 }
 
 static int compare_device_inner(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min, const uint64_t* d_lo,
@@ -277,17 +306,12 @@ static int compare_device_inner(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min
                        ctx->c_table.as<uint64_t>(), log2cap, ctx->c_owner.as<uint32_t>(), ctx->c_rowid.as<uint32_t>(),
                        W, ctx->c_matrix.as<unsigned long long>(), ctx->c_row.as<uint32_t>());
     SPSP_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_zero_owned, dim3((n + 255) / 256, n_own), dim3(256), 0, ctx->stream, n, row_first, row_stride,
-                       d_inter);
-    SPSP_HIP(hipGetLastError());
     if ((rc = ctx->ev_begin(kEvAccumulate))) return rc;
-    uint64_t max_keys = 0;
-    for (uint32_t i = row_first; i < n; i += row_stride) max_keys = std::max<uint64_t>(max_keys, h_sk_off[i + 1] - h_sk_off[i]);
-    const uint32_t chunks = (uint32_t)((max_keys + kAccChunk - 1) / kAccChunk);
-    if (chunks > 65535) { set_error("sketch with %llu k-mers is too large for one call", (unsigned long long)max_keys); return SPSP_ERR_OVERFLOW; }
-    hipLaunchKernelGGL(k_accumulate, dim3(W, n_own, chunks ? chunks : 1), dim3(kAccThreads), 0, ctx->stream,
-                       ctx->c_row.as<uint32_t>(), ctx->c_matrix.as<uint64_t>(), W, sk, n, row_first, row_stride,
-                       d_inter);
+    uint32_t lanes_per_key = 64;
+    if (W < 64) { lanes_per_key = 1; while (lanes_per_key < W) lanes_per_key <<= 1; }
+    hipLaunchKernelGGL(k_accumulate, dim3((W + 63) / 64, n_own), dim3(kAccThreads), 0, ctx->stream,
+                       ctx->c_row.as<uint32_t>(), ctx->c_matrix.as<uint64_t>(), W, lanes_per_key, sk, n, row_first,
+                       row_stride, d_inter);
     SPSP_HIP(hipGetLastError());
     if ((rc = ctx->ev_end(kEvAccumulate))) return rc;
     return SPSP_OK;
