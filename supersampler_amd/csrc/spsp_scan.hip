@@ -57,94 +57,60 @@ __device__ __forceinline__ uint32_t load_pack(const uint8_t* __restrict__ bases,
     return w;
 }
 
-// ------------------------------------------------------------- dense pass ---
-// MODE 0: XXH64 at every position.  MODE 1: LDS-resident memoised pre-filter
-// (a bitmap over canonical m-mer prefixes that says "some m-mer with this
-// prefix has hash <= T"), XXH64 only for the survivors.  Same results.
-//
-// A workgroup is G independent groups of 256 lanes; each group owns one tile of
-// kTilePos positions per iteration and the grid strides over the tiles (MODE 1
-// amortises the 128 KiB table load over many tiles: one workgroup per CU).
-template <int MODE, int G>
-__global__ __launch_bounds__(kThreads* G) void k_dense(const uint8_t* __restrict__ bases, uint64_t n, uint32_t m,
-                                                      uint64_t thr, const uint32_t* __restrict__ filter,
-                                                      uint32_t filter_words, uint32_t filter_shift,
-                                                      uint64_t n_tiles, uint32_t* __restrict__ bitmap,
-                                                      uint32_t* __restrict__ tile_count) {
-    __shared__ uint32_t packed[G][kRows * kThreads + 1];
-    __shared__ uint32_t s_cnt[G];
-    extern __shared__ uint32_t s_filter[];
-    const uint32_t grp = threadIdx.x / kThreads;
-    const uint32_t t = threadIdx.x % kThreads;
-    if (MODE == 1) {
-        for (uint32_t i = threadIdx.x; i < filter_words; i += kThreads * G) s_filter[i] = filter[i];
-    }
+// ------------------------------------------------- dense pass, direct form ---
+// XXH64 at every position: the variant for dense selections (small -s), where
+// nearly every lane has to hash anyway.  A workgroup stages one tile of kTilePos
+// positions as 2-bit words in LDS (16-base halo from the next tile) and the grid
+// strides over the tiles.
+__global__ __launch_bounds__(kThreads) void k_dense_direct(const uint8_t* __restrict__ bases, uint64_t n, uint32_t m,
+                                                          uint64_t thr, uint64_t n_tiles,
+                                                          uint32_t* __restrict__ bitmap,
+                                                          uint32_t* __restrict__ tile_count) {
+    __shared__ uint32_t packed[kRows * kThreads + 1];
+    __shared__ uint32_t s_cnt;
+    const uint32_t t = threadIdx.x;
     const uint64_t n_mmers = n >= m ? n - m + 1 : 0;
     const uint32_t mm = (1u << (2 * m)) - 1u;  // m <= 15
     const uint32_t sh0 = 64 - 2 * m;
-    for (uint64_t tile0 = (uint64_t)blockIdx.x * G; tile0 < n_tiles; tile0 += (uint64_t)gridDim.x * G) {
-        const uint64_t tile = tile0 + grp;
-        const bool live = tile < n_tiles;
+    for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t tile_base = tile * kTilePos;
-        __syncthreads();  // previous iteration's readers of packed[] / s_cnt[] are done
-        if (t == 0) s_cnt[grp] = 0;
-        if (live) {
+        __syncthreads();  // previous iteration's readers of packed[] / s_cnt are done
+        if (t == 0) s_cnt = 0;
 #pragma unroll
-            for (int r = 0; r < kRows; ++r) {
-                const uint32_t c = r * kThreads + t;
-                packed[grp][c] = load_pack(bases, n, tile_base + (uint64_t)c * kChunk);
-            }
-            if (t == 0) packed[grp][kRows * kThreads] = load_pack(bases, n, tile_base + (uint64_t)kTilePos);
+        for (int r = 0; r < kRows; ++r) {
+            const uint32_t c = r * kThreads + t;
+            packed[c] = load_pack(bases, n, tile_base + (uint64_t)c * kChunk);
         }
+        if (t == 0) packed[kRows * kThreads] = load_pack(bases, n, tile_base + (uint64_t)kTilePos);
         __syncthreads();
         uint32_t local = 0;
-        if (live) {
 #pragma unroll
-            for (int r = 0; r < kRows; ++r) {
-                const uint32_t c = r * kThreads + t;
-                const uint64_t p0 = tile_base + (uint64_t)c * kChunk;
-                const uint64_t W = ((uint64_t)packed[grp][c] << 32) | packed[grp][c + 1];
-                const uint64_t R = rc_window64(W);
-                uint32_t mask16 = 0;
+        for (int r = 0; r < kRows; ++r) {
+            const uint32_t c = r * kThreads + t;
+            const uint64_t p0 = tile_base + (uint64_t)c * kChunk;
+            const uint64_t W = ((uint64_t)packed[c] << 32) | packed[c + 1];
+            const uint64_t R = rc_window64(W);
+            uint32_t mask16 = 0;
 #pragma unroll
-                for (int j = 0; j < kChunk; ++j) {
-                    const uint32_t f = (uint32_t)(W >> (sh0 - 2 * j)) & mm;
-                    const uint32_t rc = (uint32_t)(R >> (2 * j)) & mm;
-                    const uint32_t x = f < rc ? f : rc;
-                    bool hit;
-                    if (MODE == 1) {
-                        const uint32_t q = x >> filter_shift;
-                        hit = (s_filter[q >> 5] >> (q & 31)) & 1u;
-                        if (hit) hit = xxh64_u64(x) <= thr;
-                    } else {
-                        hit = xxh64_u64(x) <= thr;
-                    }
-                    mask16 |= (hit ? 1u : 0u) << j;
-                }
-                // positions past the last m-mer of the buffer never count
-                if (p0 + kChunk > n_mmers) {
-                    const uint32_t keep = p0 >= n_mmers ? 0u : (uint32_t)(n_mmers - p0);
-                    mask16 &= (keep >= 16) ? 0xffffu : ((1u << keep) - 1u);
-                }
-                const uint32_t other = __shfl_down(mask16, 1);
-                if ((t & 1u) == 0) bitmap[p0 >> 5] = mask16 | (other << 16);
-                local += __popc(mask16);
+            for (int j = 0; j < kChunk; ++j) {
+                const uint32_t f = (uint32_t)(W >> (sh0 - 2 * j)) & mm;
+                const uint32_t rc = (uint32_t)(R >> (2 * j)) & mm;
+                const uint32_t x = f < rc ? f : rc;
+                mask16 |= (xxh64_u64(x) <= thr ? 1u : 0u) << j;
             }
-            if (local) atomicAdd(&s_cnt[grp], local);
+            // positions past the last m-mer of the buffer never count
+            if (p0 + kChunk > n_mmers) {
+                const uint32_t keep = p0 >= n_mmers ? 0u : (uint32_t)(n_mmers - p0);
+                mask16 &= (keep >= 16) ? 0xffffu : ((1u << keep) - 1u);
+            }
+            const uint32_t other = __shfl_down(mask16, 1);
+            if ((t & 1u) == 0) bitmap[p0 >> 5] = mask16 | (other << 16);
+            local += __popc(mask16);
         }
+        if (local) atomicAdd(&s_cnt, local);
         __syncthreads();
-        if (live && t == 0) tile_count[tile] = s_cnt[grp];
+        if (t == 0) tile_count[tile] = s_cnt;
     }
-}
-
-// Builds the pre-filter table: bit q set iff some canonical m-mer x with
-// x >> shift == q has XXH64(x) <= thr.  One thread per m-mer value.
-__global__ void k_build_filter(uint32_t m, uint64_t thr, uint32_t shift, uint32_t* __restrict__ table) {
-    const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (x >= (1ull << (2 * m))) return;
-    const uint32_t v = (uint32_t)x;
-    if (rc_mmer32(v, m) < v) return;  // not canonical: its reverse complement covers it
-    if (xxh64_u64(v) <= thr) atomicOr(&table[(v >> shift) >> 5], 1u << ((v >> shift) & 31));
 }
 
 // --------------------------------------------- dense pass, pair-table form ---
@@ -209,6 +175,25 @@ __device__ __forceinline__ void verify_candidate(uint64_t n_mmers, uint32_t m, u
     }
 }
 
+// Verify queued survivors {pos low 32 bits, m-mer}, 64 per round with every lane busy, until fewer than
+// keep_below remain; returns the new queue length.  Deliberately NOT inlined: the hash is ~150
+// instructions and the scan kernels reach this from several places -- inlined copies blow the
+// instruction cache of the hot loop.
+__device__ __attribute__((noinline)) uint32_t drain_queue(const uint2* __restrict__ queue, uint32_t qn, uint32_t keep_below,
+                                                          uint32_t qhigh, uint64_t n_mmers, uint32_t m, uint64_t thr,
+                                                          uint32_t* __restrict__ bitmap, uint32_t* __restrict__ tile_count) {
+    const uint32_t lane = threadIdx.x & 63;
+    while (qn >= keep_below && qn > 0) {
+        const uint32_t take = qn < 64 ? qn : 64;
+        if (lane < take) {
+            const uint2 e = queue[qn - take + lane];
+            verify_candidate(n_mmers, m, thr, ((uint64_t)qhigh << 32) | e.x, e.y, bitmap, tile_count);
+        }
+        qn -= take;
+    }
+    return qn;
+}
+
 // A wave-row is 63 chunks of 16 positions: lane 63 only supplies the halo of lane
 // 62 (its chunk is lane 0 of the next row), so every lane runs the same code and
 // no lane needs a second load.
@@ -257,15 +242,8 @@ __global__ __launch_bounds__(64 * kPairWaves) void k_dense_pair(const uint8_t* _
     uint32_t qn = 0;          // survivors waiting in this wave's queue (wave-uniform, lives in an SGPR)
     uint32_t qhigh = 0;       // bits 32.. of every queued position (the queue is drained before they change)
 
-    auto drain = [&](uint32_t keep_below) {   // verify queued survivors, 64 per round, until fewer than keep_below remain
-        while (qn >= keep_below && qn > 0) {
-            const uint32_t take = qn < 64 ? qn : 64;
-            if (lane < take) {
-                const uint2 e = reinterpret_cast<const uint2*>(queue)[qn - take + lane];
-                verify_candidate(n_mmers, m, thr, ((uint64_t)qhigh << 32) | e.x, e.y, bitmap, tile_count);
-            }
-            qn -= take;
-        }
+    auto drain = [&](uint32_t keep_below) {
+        qn = drain_queue(reinterpret_cast<const uint2*>(queue), qn, keep_below, qhigh, n_mmers, m, thr, bitmap, tile_count);
     };
     // Queue (or hash in place) the survivors of TWO rows of this wave at once: cand bits 0..15 belong to
     // the row at p0a with window (hia,nxa), bits 16..31 to the row at p0b with (hib,nxb).
@@ -352,6 +330,117 @@ __global__ __launch_bounds__(64 * kPairWaves) void k_dense_pair(const uint8_t* _
         const uint32_t nxt = __shfl_down(hi, 1);
         const uint32_t c = pair_lookup16(tab, hi, nxt);
         handle(halo_lane ? 0u : c, p0, hi, nxt, p0, hi, nxt);
+    }
+    drain(1);
+}
+
+// ------------------------------------- dense pass, single-position table form ---
+// Same structure as k_dense_pair with a sharper, one-position table for the
+// configurations whose 8-base pair keys are too crowded (m = 13, 15, or dense
+// sampling): K10[q] = some m-mer (either strand) whose first 10 bases are q has
+// XXH64(canonical) <= T; 2^20 bits = 128 KiB of LDS, one ds_read_u8 per position.
+// Survivor rates up to ~30 % are queued bit-plane by bit-plane, so the queue never
+// overflows and every hash round runs with 64 busy lanes.
+constexpr int kKey10Bytes = 131072;
+constexpr int kQueueCap1 = 192;              // 16 waves x 192 x 8 B + table = 152 KiB
+
+__global__ void k_build_key10(uint32_t m, uint64_t thr, uint32_t* __restrict__ key10) {
+    const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= (1ull << (2 * m))) return;
+    const uint32_t v = (uint32_t)x;
+    const uint32_t rc = rc_mmer32(v, m);
+    if (rc < v) return;
+    if (xxh64_u64(v) > thr) return;
+    const uint32_t sh = 2 * m - 20;           // m >= 10: first 10 bases
+    const uint32_t a = v >> sh, b = rc >> sh;
+    atomicOr(&key10[a >> 5], 1u << (a & 31));
+    atomicOr(&key10[b >> 5], 1u << (b & 31));
+}
+
+__device__ __forceinline__ uint32_t single_lookup16(const uint8_t* __restrict__ tab, uint32_t hi, uint32_t nxt) {
+    const uint32_t w1 = (hi << 12) | (nxt >> 20);   // bases 6..21
+    const uint32_t w2 = (hi << 24) | (nxt >> 8);    // bases 12..27
+    uint32_t acc = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const uint32_t src = j < 6 ? hi : (j < 12 ? w1 : w2);
+        const int jj = j < 6 ? j : (j < 12 ? j - 6 : j - 12);
+        const uint32_t addr = (src >> (15 - 2 * jj)) & 0x1ffffu;   // 10-base key >> 3
+        const uint32_t bit = (src >> (12 - 2 * jj)) & 7u;
+        acc = __builtin_amdgcn_alignbit((uint32_t)tab[addr] >> bit, acc, 1);
+    }
+    return acc >> 16;   // bit j = position j survives
+}
+
+__global__ __launch_bounds__(64 * kPairWaves) void k_dense_single(const uint8_t* __restrict__ bases, uint64_t n, uint32_t m,
+                                                                 uint64_t thr, const uint8_t* __restrict__ key10,
+                                                                 uint64_t n_rows, uint32_t* __restrict__ bitmap,
+                                                                 uint32_t* __restrict__ tile_count) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds1[];
+    uint8_t* tab = lds1;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint2* queue = reinterpret_cast<uint2*>(lds1 + kKey10Bytes) + wave * kQueueCap1;
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(key10);
+        uint4* dst = reinterpret_cast<uint4*>(tab);
+        for (uint32_t i = threadIdx.x; i < kKey10Bytes / 16; i += 64 * kPairWaves) dst[i] = src[i];
+    }
+    __syncthreads();
+    const uint64_t n_mmers = n >= m ? n - m + 1 : 0;
+    const uint32_t mm = (1u << (2 * m)) - 1u;
+    const uint64_t gw = (uint64_t)blockIdx.x * kPairWaves + wave, n_waves = (uint64_t)gridDim.x * kPairWaves;
+    uint32_t qn = 0, qhigh = 0;
+    auto drain = [&](uint32_t keep_below) {
+        qn = drain_queue(queue, qn, keep_below, qhigh, n_mmers, m, thr, bitmap, tile_count);
+    };
+    // queue one row's survivors, one bit-plane (= one position offset) at a time
+    auto handle = [&](uint32_t cand, uint64_t p0, uint32_t hi, uint32_t nxt) {
+        if (!__ballot(cand != 0)) return;
+        const uint32_t high = (uint32_t)(p0 >> 32);
+        if (qn && high != qhigh) drain(1);
+        qhigh = high;
+        const uint64_t W = ((uint64_t)hi << 32) | nxt;
+#pragma unroll 1
+        for (int j = 0; j < 16; ++j) {
+            const unsigned long long plane = __ballot((cand >> j) & 1u);
+            if (!plane) continue;
+            if ((cand >> j) & 1u) {
+                const uint32_t at = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(plane >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)plane, 0u));
+                queue[at] = make_uint2((uint32_t)(p0 + j), (uint32_t)(W >> (64 - 2 * m - 2 * j)) & mm);
+            }
+            qn += (uint32_t)__popcll(plane);      // < 64 + 64 <= kQueueCap1
+            if (qn >= 64) drain(64);
+        }
+    };
+    const uint64_t full_rows = n >= 64 * kChunk ? (n - 64 * kChunk) / kRowPosPair63 + 1 : 0;
+    const uint64_t fast_rows = full_rows < n_rows ? full_rows : n_rows;
+    const uint64_t stride = n_waves * kRowPosPair63;
+    uint64_t row = gw;
+    const uint8_t* ptr = bases + row * kRowPosPair63 + (uint64_t)lane * kChunk;
+    uint4 raw0 = make_uint4(0, 0, 0, 0), raw1 = raw0;
+    if (row < fast_rows) raw0 = *reinterpret_cast<const uint4*>(ptr);
+    if (row + n_waves < fast_rows) raw1 = *reinterpret_cast<const uint4*>(ptr + stride);
+    const bool halo_lane = lane >= kRowChunks;
+    const uint64_t lane_off = (uint64_t)lane * kChunk;
+    auto body = [&](uint4& raw, uint64_t r, const uint8_t* at) {
+        const uint32_t hi = pack16(raw);
+        raw = *reinterpret_cast<const uint4*>(r + 2 * n_waves < fast_rows ? at + 2 * stride : at);
+        const uint32_t nxt = __shfl_down(hi, 1);
+        const uint32_t c = single_lookup16(tab, hi, nxt);
+        handle(halo_lane ? 0u : c, r * kRowPosPair63 + lane_off, hi, nxt);
+    };
+    for (; row + n_waves < fast_rows; row += 2 * n_waves, ptr += 2 * stride) {
+        body(raw0, row, ptr);
+        body(raw1, row + n_waves, ptr + stride);
+    }
+    if (row < fast_rows) body(raw0, row, ptr);
+    for (row = fast_rows + ((gw + n_waves - fast_rows % n_waves) % n_waves); row < n_rows; row += n_waves) {
+        const uint64_t p0 = row * kRowPosPair63 + lane_off;
+        const uint32_t hi = load_pack(bases, n, p0);
+        const uint32_t nxt = __shfl_down(hi, 1);
+        const uint32_t c = single_lookup16(tab, hi, nxt);
+        handle(halo_lane ? 0u : c, p0, hi, nxt);
     }
     drain(1);
 }
@@ -659,39 +748,31 @@ int check_params(const spsp_params* p) {
     return SPSP_OK;
 }
 
-static int ensure_filter(spsp_ctx* ctx, const spsp_params* p, uint32_t* words, uint32_t* shift) {
-    // 2^20 bits = 128 KiB of LDS; the table indexes the top 20 bits of the 2m-bit value
-    const uint32_t bits = 2 * p->m;
-    const uint32_t sh = bits > 20 ? bits - 20 : 0;
-    const uint32_t nbits = 1u << (bits - sh);
-    const uint32_t nwords = (nbits + 31) / 32;
-    *words = nwords; *shift = sh;
-    if (ctx->filter_valid && ctx->filter_m == p->m && ctx->filter_thr == p->threshold) return SPSP_OK;
-    int rc = ctx->filter.reserve((size_t)nwords * 4);
-    if (rc) return rc;
-    SPSP_HIP(hipMemsetAsync(ctx->filter.p, 0, (size_t)nwords * 4, ctx->stream));
-    const uint64_t total = 1ull << bits;
-    const uint32_t blocks = (uint32_t)((total + 255) / 256);
-    hipLaunchKernelGGL(k_build_filter, dim3(blocks), dim3(256), 0, ctx->stream, p->m, p->threshold, sh,
-                       ctx->filter.as<uint32_t>());
-    SPSP_HIP(hipGetLastError());
-    ctx->filter_m = p->m; ctx->filter_thr = p->threshold; ctx->filter_shift = sh; ctx->filter_valid = true;
-    return SPSP_OK;
-}
-
-// Picks the dense-pass variant from the expected survivor rate of each memoised
-// filter (P(hash <= T) times the m-mers that share one table bit, both strands).
-enum { kDenseDirect = 0, kDenseFilter20 = 1, kDensePair = 2 };
+// Picks the dense-pass variant from the expected survivor rate of each memoised table:
+// P(hash <= T) times the m-mers (both strands) that share one table bit.
+enum { kDenseDirect = 0, kDenseSingle = 1, kDensePair = 2 };
 static int pick_dense(const spsp_params* p) {
     if (p->flags & SPSP_SCAN_DIRECT_HASH) return kDenseDirect;
-    if (p->flags & SPSP_SCAN_LDS_FILTER) return kDenseFilter20;
+    if ((p->flags & SPSP_SCAN_LDS_FILTER) && p->m >= 10) return kDenseSingle;
     if ((p->flags & SPSP_SCAN_PAIR_FILTER) && p->m >= 9) return kDensePair;
     const double frac = (double)p->threshold / 18446744073709551616.0;  // P(hash <= T)
     const uint32_t bits = 2 * p->m;
     if (p->m >= 9 && frac * (double)(1u << (bits - 16)) < 0.01) return kDensePair;
-    const double per_bit = bits > 20 ? (double)(1u << (bits - 20)) : 1.0;
-    if (frac * per_bit < 0.02) return kDenseFilter20;
+    if (p->m >= 10 && frac * (double)(1u << (bits - 20)) < 0.30) return kDenseSingle;
     return kDenseDirect;
+}
+
+static int ensure_key10(spsp_ctx* ctx, const spsp_params* p) {
+    if (ctx->filter_valid && ctx->filter_m == p->m && ctx->filter_thr == p->threshold) return SPSP_OK;
+    int rc = ctx->filter.reserve((size_t)kKey10Bytes);
+    if (rc) return rc;
+    SPSP_HIP(hipMemsetAsync(ctx->filter.p, 0, (size_t)kKey10Bytes, ctx->stream));
+    const uint64_t total = 1ull << (2 * p->m);
+    hipLaunchKernelGGL(k_build_key10, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, ctx->stream, p->m,
+                       p->threshold, ctx->filter.as<uint32_t>());
+    SPSP_HIP(hipGetLastError());
+    ctx->filter_m = p->m; ctx->filter_thr = p->threshold; ctx->filter_valid = true;
+    return SPSP_OK;
 }
 
 static int ensure_pairtab(spsp_ctx* ctx, const spsp_params* p) {
@@ -721,11 +802,10 @@ static int launch_dense(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_ba
     if ((rc = ctx->d_scalar.reserve(64))) return rc;
     if (ctx->bitmap.p != old_bm || ctx->tile_count.p != old_tc) { ctx->zeroed_tiles = 0; ctx->dirty_tiles = 0; }
     const int variant = pick_dense(p);
-    uint32_t words = 0, shift = 0;
-    if (variant == kDenseFilter20 && (rc = ensure_filter(ctx, p, &words, &shift))) return rc;
+    if (variant == kDenseSingle && (rc = ensure_key10(ctx, p))) return rc;
     if (variant == kDensePair && (rc = ensure_pairtab(ctx, p))) return rc;
     if ((rc = ctx->ev_begin(kEvDense))) return rc;
-    if (variant == kDensePair) {
+    if (variant == kDensePair || variant == kDenseSingle) {
         // hits are published with atomics into a zeroed bitmap.  k_expand zeroes what it
         // consumes, so in a batch loop nothing has to be cleared here: only tiles never used
         // before, or left dirty by a call that did not reach k_expand, are memset.
@@ -740,38 +820,39 @@ static int launch_dense(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_ba
             SPSP_HIP(hipMemsetAsync(ctx->tile_count.as<uint32_t>() + from, 0, (size_t)(n_tiles - from) * 4, ctx->stream));
             ctx->zeroed_tiles = n_tiles;
         }
-        const size_t lds = (size_t)kPairWaves * kQueueCap * 8;
-        static bool attr_set = false;
-        if (!attr_set) {
-            SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_pair),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
-        }
         const uint64_t n_rows = (n_bases + kRowPosPair63 - 1) / kRowPosPair63;
         const uint64_t want = (n_rows + kPairWaves - 1) / kPairWaves;
         static const int per_cu = getenv("SPSP_PAIR_BLOCKS_PER_CU") ? atoi(getenv("SPSP_PAIR_BLOCKS_PER_CU")) : 1;  // tuning knob
-        const uint64_t cap = (uint64_t)ctx->n_cu * (per_cu > 0 ? per_cu : 1);   // one 1024-lane workgroup per CU (112 KiB of LDS)
-        hipLaunchKernelGGL(k_dense_pair, dim3((uint32_t)(want < cap ? want : cap)), dim3(64 * kPairWaves), lds,
-                           ctx->stream, d_bases, n_bases, p->m, p->threshold, ctx->pairtab.as<uint8_t>(), n_rows,
-                           ctx->bitmap.as<uint32_t>(), ctx->tile_count.as<uint32_t>());
-    } else if (variant == kDenseFilter20) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense<1, 4>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-            attr_set = true;
+        const uint64_t cap = (uint64_t)ctx->n_cu * (per_cu > 0 ? per_cu : 1);   // one 1024-lane workgroup per CU
+        const dim3 grid((uint32_t)(want < cap ? want : cap));
+        if (variant == kDensePair) {
+            const size_t lds = (size_t)kPairWaves * kQueueCap * 8;                 // + 64 KiB static table
+            static bool attr_set = false;
+            if (!attr_set) {
+                SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_pair),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(k_dense_pair, grid, dim3(64 * kPairWaves), lds, ctx->stream, d_bases, n_bases, p->m,
+                               p->threshold, ctx->pairtab.as<uint8_t>(), n_rows, ctx->bitmap.as<uint32_t>(),
+                               ctx->tile_count.as<uint32_t>());
+        } else {
+            const size_t lds = (size_t)kKey10Bytes + (size_t)kPairWaves * kQueueCap1 * 8;
+            static bool attr_set = false;
+            if (!attr_set) {
+                SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_single),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(k_dense_single, grid, dim3(64 * kPairWaves), lds, ctx->stream, d_bases, n_bases, p->m,
+                               p->threshold, ctx->filter.as<uint8_t>(), n_rows, ctx->bitmap.as<uint32_t>(),
+                               ctx->tile_count.as<uint32_t>());
         }
-        const uint64_t want = (n_tiles + 3) / 4;
-        const uint32_t grid = (uint32_t)(want < (uint64_t)ctx->n_cu ? want : (uint64_t)ctx->n_cu);
-        hipLaunchKernelGGL((k_dense<1, 4>), dim3(grid), dim3(kThreads * 4), (size_t)words * 4, ctx->stream, d_bases,
-                           n_bases, p->m, p->threshold, ctx->filter.as<uint32_t>(), words, shift, n_tiles,
-                           ctx->bitmap.as<uint32_t>(), ctx->tile_count.as<uint32_t>());
     } else {
         const uint64_t cap = (uint64_t)ctx->n_cu * 16;
         const uint32_t grid = (uint32_t)(n_tiles < cap ? n_tiles : cap);
-        hipLaunchKernelGGL((k_dense<0, 1>), dim3(grid), dim3(kThreads), 0, ctx->stream, d_bases, n_bases, p->m,
-                           p->threshold, (const uint32_t*)nullptr, 0u, 0u, n_tiles, ctx->bitmap.as<uint32_t>(),
-                           ctx->tile_count.as<uint32_t>());
+        hipLaunchKernelGGL(k_dense_direct, dim3(grid), dim3(kThreads), 0, ctx->stream, d_bases, n_bases, p->m,
+                           p->threshold, n_tiles, ctx->bitmap.as<uint32_t>(), ctx->tile_count.as<uint32_t>());
     }
     SPSP_HIP(hipGetLastError());
     if (n_tiles > ctx->dirty_tiles) ctx->dirty_tiles = n_tiles;   // until k_expand has consumed (and zeroed) them
