@@ -194,7 +194,7 @@ def main():
             "stage_ms": {"scan_pipeline": scan_ms / max(1, tm["scan_calls"]), "dense_kernel": dense_avg_ms,
                          "compare_pipeline": compare_avg_ms, "accumulate_kernel": acc_ms / max(1, tm["accumulate_launches"])},
             "superkmers_per_step": int(n_out), "inter_nonzero": inter_nonzero,
-            "roofline": {"kernel": "k_dense (hash + threshold at every m-mer position)", "bound": "hbm",
+            "roofline": {"kernel": "k_dense_pair (2-bit pack + LDS pair-table test of every m-mer position; XXH64 on survivors)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(args),
                          "algorithmic_bytes_per_launch": int(d_bases.numel())},
