@@ -135,7 +135,7 @@ __global__ __launch_bounds__(kThreads) void k_dense_direct(const uint8_t* __rest
 // published with global atomics into a pre-zeroed bitmap.
 constexpr int kPairWaves = 16;              // waves per workgroup (1024 lanes)
 constexpr int kPairTabBytes = 65536;        // 2^18 entries x 2 bits
-constexpr int kQueueCap = 256;              // survivor slots per wave (8 bytes each)
+constexpr int kQueueCap = 256;              // survivor slots per wave (16 bytes each)
 
 __global__ void k_build_key8(uint32_t m, uint64_t thr, uint32_t* __restrict__ key8) {
     const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -194,6 +194,28 @@ __device__ __attribute__((noinline)) uint32_t drain_queue(const uint2* __restric
     return qn;
 }
 
+// Pair-kernel flavour: entries are {row position low 32 bits, survivor bit index, window hi, window nxt};
+// offset and m-mer are decoded here, with all 64 lanes busy, instead of in the divergent push loop.
+__device__ __forceinline__ uint32_t pair_bit_to_offset(uint32_t b);
+__device__ __attribute__((noinline)) uint32_t drain_queue_raw(const uint4* __restrict__ queue, uint32_t qn, uint32_t keep_below,
+                                                              uint32_t qhigh, uint64_t n_mmers, uint32_t m, uint64_t thr,
+                                                              uint32_t* __restrict__ bitmap, uint32_t* __restrict__ tile_count) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t mm = (1u << (2 * m)) - 1u;
+    while (qn >= keep_below && qn > 0) {
+        const uint32_t take = qn < 64 ? qn : 64;
+        if (lane < take) {
+            const uint4 e = queue[qn - take + lane];
+            const uint32_t off = pair_bit_to_offset(e.y);
+            const uint64_t W = ((uint64_t)e.z << 32) | e.w;
+            verify_candidate(n_mmers, m, thr, (((uint64_t)qhigh << 32) | e.x) + off,
+                             (uint32_t)(W >> (64 - 2 * m - 2 * off)) & mm, bitmap, tile_count);
+        }
+        qn -= take;
+    }
+    return qn;
+}
+
 // A wave-row is 63 chunks of 16 positions: lane 63 only supplies the halo of lane
 // 62 (its chunk is lane 0 of the next row), so every lane runs the same code and
 // no lane needs a second load.
@@ -226,10 +248,10 @@ __global__ __launch_bounds__(64 * kPairWaves) void k_dense_pair(const uint8_t* _
                                                                uint64_t n_rows, uint32_t* __restrict__ bitmap,
                                                                uint32_t* __restrict__ tile_count) {
     __shared__ __attribute__((aligned(16))) uint8_t tab[kPairTabBytes];
-    extern __shared__ __attribute__((aligned(16))) uint32_t qbase[];   // per wave: kQueueCap x {pos low 32 bits, m-mer}
+    extern __shared__ __attribute__((aligned(16))) uint32_t qbase[];   // per wave: kQueueCap x {row pos low 32, bit, hi, nxt}
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: row bookkeeping stays on the SALU
-    uint32_t* queue = qbase + wave * kQueueCap * 2;
+    uint4* queue = reinterpret_cast<uint4*>(qbase) + wave * kQueueCap;
     {   // table -> LDS, 64 bytes per lane
         const uint4* src = reinterpret_cast<const uint4*>(pairtab);
         uint4* dst = reinterpret_cast<uint4*>(tab);
@@ -237,13 +259,12 @@ __global__ __launch_bounds__(64 * kPairWaves) void k_dense_pair(const uint8_t* _
     }
     __syncthreads();
     const uint64_t n_mmers = n >= m ? n - m + 1 : 0;
-    const uint32_t mm = (1u << (2 * m)) - 1u;
     const uint64_t gw = (uint64_t)blockIdx.x * kPairWaves + wave, n_waves = (uint64_t)gridDim.x * kPairWaves;
     uint32_t qn = 0;          // survivors waiting in this wave's queue (wave-uniform, lives in an SGPR)
     uint32_t qhigh = 0;       // bits 32.. of every queued position (the queue is drained before they change)
 
     auto drain = [&](uint32_t keep_below) {
-        qn = drain_queue(reinterpret_cast<const uint2*>(queue), qn, keep_below, qhigh, n_mmers, m, thr, bitmap, tile_count);
+        qn = drain_queue_raw(queue, qn, keep_below, qhigh, n_mmers, m, thr, bitmap, tile_count);
     };
     // Queue (or hash in place) the survivors of TWO rows of this wave at once: cand bits 0..15 belong to
     // the row at p0a with window (hia,nxa), bits 16..31 to the row at p0b with (hib,nxb).
@@ -268,26 +289,32 @@ __global__ __launch_bounds__(64 * kPairWaves) void k_dense_pair(const uint8_t* _
                 }
             }
         }
-        const uint32_t high = (uint32_t)((p0b > p0a ? p0b : p0a) >> 32);   // rows of one call never straddle 2^32 by more than one step
-        if ((qn && high != qhigh) || qn + total > (uint32_t)kQueueCap) drain(1);
-        const bool in_place = total > (uint32_t)kQueueCap || (uint32_t)(p0a >> 32) != (uint32_t)(p0b >> 32);
-        qhigh = high;
-        uint2* e = reinterpret_cast<uint2*>(queue) + qn + prefix;
-        while (cand) {
+        // every queued position shares its bits 32.. (qhigh): drain before they change (4 GiB seams)
+        const uint32_t high_a = (uint32_t)(p0a >> 32), high_b = (uint32_t)(p0b >> 32);
+        if ((qn && high_a != qhigh) || qn + total > (uint32_t)kQueueCap) drain(1);
+        const bool in_place = total > (uint32_t)kQueueCap || high_a != high_b;
+        qhigh = high_a;
+        if (in_place) {                                   // adversarial input / a 4 GiB seam between the two rows
+            const uint32_t mm = (1u << (2 * m)) - 1u;
+            while (cand) {
+                const uint32_t bit = __ffs(cand) - 1;
+                cand &= cand - 1;
+                const bool second = bit >= 16;
+                const uint32_t off = pair_bit_to_offset(bit & 15);
+                const uint64_t W = second ? (((uint64_t)hib << 32) | nxb) : (((uint64_t)hia << 32) | nxa);
+                verify_candidate(n_mmers, m, thr, (second ? p0b : p0a) + off, (uint32_t)(W >> (64 - 2 * m - 2 * off)) & mm,
+                                 bitmap, tile_count);
+            }
+            return;
+        }
+        uint4* e = queue + qn + prefix;
+        while (cand) {                                    // divergent, but only an ffs and one 16-byte LDS store per survivor
             const uint32_t bit = __ffs(cand) - 1;
             cand &= cand - 1;
-            const bool second = bit >= 16;
-            const uint32_t off = pair_bit_to_offset(bit & 15);
-            const uint64_t pos = (second ? p0b : p0a) + off;
-            const uint64_t W = second ? (((uint64_t)hib << 32) | nxb) : (((uint64_t)hia << 32) | nxa);
-            const uint32_t f = (uint32_t)(W >> (64 - 2 * m - 2 * off)) & mm;
-            if (in_place) verify_candidate(n_mmers, m, thr, pos, f, bitmap, tile_count);   // adversarial input / 4 GiB seam
-            else *e++ = make_uint2((uint32_t)pos, f);
+            *e++ = bit >= 16 ? make_uint4((uint32_t)p0b, bit & 15, hib, nxb) : make_uint4((uint32_t)p0a, bit, hia, nxa);
         }
-        if (!in_place) {
-            qn += total;
-            if (qn >= 64) drain(64);
-        }
+        qn += total;
+        if (qn >= 64) drain(64);
     };
 
     // rows whose 64 chunks lie completely inside the buffer take the vector path
@@ -826,7 +853,7 @@ static int launch_dense(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_ba
         const uint64_t cap = (uint64_t)ctx->n_cu * (per_cu > 0 ? per_cu : 1);   // one 1024-lane workgroup per CU
         const dim3 grid((uint32_t)(want < cap ? want : cap));
         if (variant == kDensePair) {
-            const size_t lds = (size_t)kPairWaves * kQueueCap * 8;                 // + 64 KiB static table
+            const size_t lds = (size_t)kPairWaves * kQueueCap * 16;                // + 64 KiB static table
             static bool attr_set = false;
             if (!attr_set) {
                 SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_pair),

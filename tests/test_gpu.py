@@ -195,6 +195,50 @@ def test_cli_end_to_end_matches_oracle(tmp_path):
         assert gzip.open(tmp_path / fn, "rb").read() == orc.csv(jac, listed, inter, card, None, 5, 0.0)
 
 
+def test_cli_query_mode_abundance_and_flag_rules(tmp_path):
+    """-q query fof (rows = queries, columns = queries then index), -a abundance, -m/-p of the comparator, and the
+    sketcher's flag rules: even k and m are bumped to odd, m is clamped to 15 (SubSampler.cpp:732-746)."""
+    gs = synth.family_genomes(77, 5, 60_000, 1, [0.0, 0.01, 0.03])
+    # every genome twice in the FASTA so that abundance 2 keeps (almost) everything
+    idx, qry = [], []
+    for i, g in enumerate(gs):
+        path = tmp_path / ("s%d.fasta" % i)
+        path.write_bytes(synth.to_fasta(g, "a%d" % i) + synth.to_fasta(g, "b%d" % i))
+        (qry if i < 2 else idx).append(str(path))
+    (tmp_path / "q.txt").write_text("\n".join(qry) + "\n")
+    (tmp_path / "i.txt").write_text("\n".join(idx) + "\n")
+    exe = os.path.join(ROOT, "bin", "sub_sampler")
+    for fof in ("q.txt", "i.txt"):
+        r = subprocess.run([exe, "-f", fof, "-k", "30", "-m", "16", "-s", "40", "-a", "2", "-t", "2", "-v", "0"],
+                           cwd=tmp_path, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "Kmer size must be odd" in r.stdout and "Minimizer size must be odd" in r.stdout
+        assert "Minimizer size can't be greater than 15." in r.stdout and " I use k=31 m=15 s=40" in r.stdout
+    k, m, s = 31, 15, float(np.float32(40))
+    payloads, names = [], []
+    for fof in ("subsampled_q.txt", "subsampled_i.txt"):
+        for nm in sorted((tmp_path / fof).read_text().split()):
+            names.append(nm)
+    # the .txt lists are written in processing order (2 threads); sort both sides the same way
+    q_names = sorted((tmp_path / "subsampled_q.txt").read_text().split())
+    i_names = sorted((tmp_path / "subsampled_i.txt").read_text().split())
+    (tmp_path / "sq.txt").write_text("\n".join(q_names) + "\n")
+    (tmp_path / "si.txt").write_text("\n".join(i_names) + "\n")
+    order = q_names + i_names
+    for nm in order:
+        src = tmp_path / (nm[len("subsampled_"):-3] + ".fasta")
+        want, _ = orc.sketch_fasta(src.read_bytes(), k, m, s, 2)
+        assert gzip.open(tmp_path / nm, "rb").read() == want, nm
+        payloads.append(want)
+    r = subprocess.run([os.path.join(ROOT, "bin", "comparator"), "-q", "sq.txt", "-f", "si.txt", "-o", "qres", "-p", "4",
+                        "-m", "0.2"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "I query 2 file(s) against the bank" in r.stdout
+    inter, card, _, _ = orc.compare(payloads, n_query=2)
+    for jac, fn in ((True, "qres_jaccard.csv.gz"), (False, "qres_containment.csv.gz")):
+        assert gzip.open(tmp_path / fn, "rb").read() == orc.csv(jac, order, inter, card, 2, 4, 0.2)
+
+
 def test_scan_buffer_overflow_retries():
     """the sparse stages are launched with capacity-sized buffers; a call that overflows them
     re-runs with room (hits: from the dense pass, super-k-mers: the write pass only)."""
