@@ -74,8 +74,11 @@ def main():
     flags = {"default": sp.SPSP_SCAN_DEFAULT, "direct": sp.SPSP_SCAN_DIRECT_HASH, "filter": sp.SPSP_SCAN_LDS_FILTER,
              "pair": sp.SPSP_SCAN_PAIR_FILTER}[args.mode]
     p = sp.make_params(K, M, S, flags=flags)
-    stream = torch.cuda.current_stream().cuda_stream
-    ctx = sp.Context(local_rank, stream if stream else None)
+    # ONE explicit HIP stream for everything in a step: torch copies/collectives (RCCL orders itself against the
+    # current stream) and libspsp's kernels (the context is created on the same stream handle)
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    ctx = sp.Context(local_rank, stream.cuda_stream)
 
     # ------------------------------------------------------------------ setup (untimed)
     t_setup = time.time()

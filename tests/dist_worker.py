@@ -40,6 +40,7 @@ def main():
         ctx = sp.Context(0)
         d_min, d_lo = g.minimizer.to(dev), g.kmer_lo.to(dev)
         d_inter = torch.zeros((n_total, n_total), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()   # torch fills on its own stream; the context has its own
         ctx.compare_device(k, d_min.data_ptr(), d_lo.data_ptr(), None, g.sk_off, n_total, rank, world, d_inter.data_ptr())
         torch.cuda.synchronize()
         local = d_inter.cpu()

@@ -44,6 +44,7 @@ d_min = torch.from_numpy(np.concatenate([x.minimizer for x in sketches]).view(np
 d_lo = torch.from_numpy(np.concatenate([x.kmer_lo for x in sketches]).view(np.int64)).to(dev)
 sk_off = np.zeros(N + 1, np.uint64); sk_off[1:] = np.cumsum(cnt)
 d_inter = torch.zeros((N, N), dtype=torch.int32, device=dev)
+torch.cuda.synchronize()   # torch fills on its own stream; the context has its own
 for _ in range(2):
     ctx.compare_device(k, d_min.data_ptr(), d_lo.data_ptr(), None, sk_off, N, 0, 1, d_inter.data_ptr())
 ctx.timing_enable(True); ctx.timing_read()

@@ -20,6 +20,7 @@ dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev); g.manual_seed(1)
 acgt = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=dev)
 bases = acgt[torch.randint(0, 4, (n,), device=dev, generator=g)]
+torch.cuda.synchronize()
 ctx = sp.Context(0, torch.cuda.current_stream().cuda_stream or None)
 for name, flag in (("pair", sp.SPSP_SCAN_PAIR_FILTER), ("single", sp.SPSP_SCAN_LDS_FILTER), ("direct", sp.SPSP_SCAN_DIRECT_HASH),
                    ("default", sp.SPSP_SCAN_DEFAULT)):
