@@ -135,7 +135,9 @@ int spsp_compare(spsp_ctx* ctx, const spsp_sketch_view* sk, uint32_t n, uint32_t
  * [d_sk_off[i], d_sk_off[i+1]) ). Only rows i with i % row_stride == row_first
  * are computed (the multi-GPU split of SURVEY.md 8e: every rank holds all
  * sketches after the all-gather and owns a strided set of rows). d_inter is a
- * dense n*n uint32 matrix; rows not owned are left untouched. */
+ * dense n*n uint32 matrix; cells (i, j > i) of owned rows are overwritten, everything else is left
+ * untouched. The work is queued on the context's stream: results are complete once that stream has
+ * drained. */
 int spsp_compare_device(spsp_ctx* ctx, uint32_t k, const void* d_minimizer, const void* d_kmer_lo,
                         const void* d_kmer_hi /* NULL if k<=32 */, const uint64_t* h_sk_off,
                         uint32_t n, uint32_t row_first, uint32_t row_stride, void* d_inter);
@@ -145,6 +147,11 @@ int spsp_compare_device(spsp_ctx* ctx, uint32_t k, const void* d_minimizer, cons
  * buffer: records back to back + n_rec+1 offsets. */
 int spsp_fasta_clean_host(const char* text, uint64_t n, uint8_t** bases, uint64_t** rec_off,
                           uint32_t* n_rec);
+
+/* The same two functions on the GPU ("next" row N1): raw gunzipped FASTA text resident in HBM (16-byte
+ * aligned) -> cleaned records + offsets in context-owned device buffers, ready for spsp_scan_device. */
+int spsp_fasta_clean_device(spsp_ctx* ctx, const void* d_text, uint64_t n_text, void** d_bases, uint64_t* n_bases,
+                            void** d_rec_off, uint32_t* n_rec);
 
 typedef struct spsp_sketch_stats {
     uint64_t read_kmer, selected_kmer_number, selected_superkmer_number, count_maximal_skmer;
@@ -160,6 +167,11 @@ int spsp_sketch_build_host(const spsp_params* p, double rate, const uint8_t* bas
                            const uint64_t* rec_off, uint32_t n_rec, const spsp_superkmer* sk,
                            uint64_t n_sk, uint8_t** payload, uint64_t* payload_len,
                            spsp_sketch_stats* stats);
+
+/* FASTA text (host) -> sketch payload with ingest, scan and super-k-mer gather on the GPU: what
+ * parse_fasta_test does between openFile and the gzip writer (SubSampler.cpp:306-504). */
+int spsp_sketch_text(spsp_ctx* ctx, const spsp_params* p, double rate, const char* text, uint64_t n_text,
+                     uint8_t** payload, uint64_t* payload_len, spsp_sketch_stats* stats);
 
 /* Header + bucket reader of the comparator (Comparator.cpp:23-37, 78-92,
  * 186-260; strDecompressor utils.cpp:71-111): payload -> sorted distinct

@@ -55,7 +55,7 @@ SUPERKMER_DTYPE = np.dtype([("rec", "<u4"), ("minimizer", "<u4"), ("start", "<u8
 ABI_SYMBOLS = [
     "spsp_create", "spsp_destroy", "spsp_last_error", "spsp_version", "spsp_free",
     "spsp_timing_enable", "spsp_timing_read", "spsp_threshold_host", "spsp_scan", "spsp_scan_device", "spsp_scan_hits_device", "spsp_compare",
-    "spsp_compare_device", "spsp_fasta_clean_host", "spsp_sketch_build_host", "spsp_sketch_parse_host",
+    "spsp_compare_device", "spsp_fasta_clean_host", "spsp_fasta_clean_device", "spsp_sketch_text", "spsp_sketch_build_host", "spsp_sketch_parse_host",
     "spsp_csv_host", "spsp_read_file_host", "spsp_write_gz_host", "spsp_sketch_file", "spsp_compare_files",
 ]
 
@@ -90,6 +90,10 @@ def lib():
     L.spsp_compare_device.argtypes = [vp, u32, vp, vp, vp, vp, u32, u32, u32, vp]
     L.spsp_fasta_clean_host.restype = i32
     L.spsp_fasta_clean_host.argtypes = [cp, u64, P(vp), P(vp), P(u32)]
+    L.spsp_fasta_clean_device.restype = i32
+    L.spsp_fasta_clean_device.argtypes = [vp, vp, u64, P(vp), P(u64), P(vp), P(u32)]
+    L.spsp_sketch_text.restype = i32
+    L.spsp_sketch_text.argtypes = [vp, P(Params), dbl, cp, u64, P(vp), P(u64), P(SketchStats)]
     L.spsp_sketch_build_host.restype = i32
     L.spsp_sketch_build_host.argtypes = [P(Params), dbl, vp, vp, u32, vp, u64, P(vp), P(u64), P(SketchStats)]
     L.spsp_sketch_parse_host.restype = i32
@@ -256,6 +260,19 @@ class Context:
         n = C.c_uint64()
         _check(lib().spsp_scan_hits_device(self._h, C.byref(params), d_bases, n_bases, C.byref(n)))
         return n.value
+
+    def clean_fasta_device(self, d_text, n_text):
+        """raw FASTA text in HBM -> (d_bases, n_bases, d_rec_off, n_rec), context-owned device buffers."""
+        b, o, nb, nr = C.c_void_p(), C.c_void_p(), C.c_uint64(), C.c_uint32()
+        _check(lib().spsp_fasta_clean_device(self._h, d_text, n_text, C.byref(b), C.byref(nb), C.byref(o), C.byref(nr)))
+        return b.value, nb.value, o.value, nr.value
+
+    def sketch_text(self, text, k=31, m=11, s=1000.0, abundance=1, flags=SPSP_SCAN_DEFAULT):
+        """FASTA bytes -> (payload, stats) with ingest, scan and gather on the GPU."""
+        p = make_params(k, m, s, abundance, flags)
+        out, n, st = C.c_void_p(), C.c_uint64(), SketchStats()
+        _check(lib().spsp_sketch_text(self._h, C.byref(p), float(s), text, len(text), C.byref(out), C.byref(n), C.byref(st)))
+        return _take(out, n.value), {f: getattr(st, f) for f, _ in SketchStats._fields_}
 
     def sketch_fasta(self, text, k=31, m=11, s=1000.0, abundance=1, flags=SPSP_SCAN_DEFAULT):
         """FASTA bytes -> (payload, stats): clean -> GPU scan -> sketch builder."""

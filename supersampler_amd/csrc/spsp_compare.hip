@@ -276,9 +276,11 @@ static int compare_device_inner(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min
     }
     const dim3 grid_all((uint32_t)((max_all + 255) / 256), n), grid_own((uint32_t)((max_own + 255) / 256), n_own);
     const uint32_t sblocks = (uint32_t)((cap + (uint64_t)kRowThreads * kRowSlots - 1) / ((uint64_t)kRowThreads * kRowSlots));
-    uint32_t n_rows = 0;
-    uint64_t seed = 0x5350535053505350ULL;
-    for (int attempt = 0;; ++attempt) {
+    const uint32_t W = (n + 63) / 64;
+    uint32_t lanes_per_key = 64;
+    if (W < 64) { lanes_per_key = 1; while (lanes_per_key < W) lanes_per_key <<= 1; }
+    // dictionary build: table, row ids, full-key verification
+    auto front = [&](uint64_t seed) -> int {
         SPSP_HIP(hipMemsetAsync(ctx->c_table.p, 0, (size_t)cap * 8, ctx->stream));
         SPSP_HIP(hipMemsetAsync(flags, 0, 64, ctx->stream));
         hipLaunchKernelGGL(k_insert, grid_all, dim3(256), 0, ctx->stream, K, sk, n, S, row_first, row_stride, seed,
@@ -291,30 +293,48 @@ static int compare_device_inner(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min
         hipLaunchKernelGGL(k_verify, grid_own, dim3(256), 0, ctx->stream, K, sk, n, S, row_first, row_stride,
                            ctx->c_owner.as<uint32_t>(), ctx->c_slot.as<uint32_t>(), flags);
         SPSP_HIP(hipGetLastError());
-        uint32_t h_flags[3];
-        SPSP_HIP(hipMemcpyAsync(h_flags, flags, sizeof h_flags, hipMemcpyDeviceToHost, ctx->stream));
+        return SPSP_OK;
+    };
+    // colour matrix (room for `rows` rows) and the row sums
+    auto back = [&](uint64_t seed, uint64_t rows) -> int {
+        int r2;
+        if ((r2 = ctx->c_matrix.reserve((size_t)rows * W * 8))) return r2;
+        SPSP_HIP(hipMemsetAsync(ctx->c_matrix.p, 0, (size_t)rows * W * 8, ctx->stream));
+        hipLaunchKernelGGL(k_fill, grid_all, dim3(256), 0, ctx->stream, K, sk, n, S, row_first, row_stride, seed,
+                           ctx->c_table.as<uint64_t>(), log2cap, ctx->c_owner.as<uint32_t>(), ctx->c_rowid.as<uint32_t>(),
+                           W, ctx->c_matrix.as<unsigned long long>(), ctx->c_row.as<uint32_t>());
+        SPSP_HIP(hipGetLastError());
+        if ((r2 = ctx->ev_begin(kEvAccumulate))) return r2;
+        hipLaunchKernelGGL(k_accumulate, dim3((W + 63) / 64, n_own), dim3(kAccThreads), 0, ctx->stream,
+                           ctx->c_row.as<uint32_t>(), ctx->c_matrix.as<uint64_t>(), W, lanes_per_key, sk, n, row_first,
+                           row_stride, d_inter);
+        SPSP_HIP(hipGetLastError());
+        return ctx->ev_end(kEvAccumulate);
+    };
+    auto read_flags = [&](uint32_t* h_flags) -> int {
+        SPSP_HIP(hipMemcpyAsync(h_flags, flags, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         SPSP_HIP(hipStreamSynchronize(ctx->stream));
         if (h_flags[0]) { set_error("sketch keys must be strictly increasing by (minimizer, kmer_hi, kmer_lo)"); return SPSP_ERR_ARG; }
-        if (!h_flags[1]) { n_rows = h_flags[2]; break; }
+        return SPSP_OK;
+    };
+    // A matrix with one row per OWNED KEY (an upper bound on the distinct keys) is cheap for small inputs:
+    // then the whole pipeline is queued without waiting for the row count and checked once at the end.
+    const bool speculative = (uint64_t)S_own * W * 8 <= (256ull << 20);
+    uint64_t seed = 0x5350535053505350ULL;
+    for (int attempt = 0;; ++attempt) {
+        uint32_t h_flags[3];
+        if ((rc = front(seed))) return rc;
+        if (speculative) {
+            if ((rc = back(seed, S_own))) return rc;
+            if ((rc = read_flags(h_flags))) return rc;
+            if (!h_flags[1]) return SPSP_OK;
+        } else {
+            if ((rc = read_flags(h_flags))) return rc;
+            if (!h_flags[1]) return back(seed, h_flags[2]);
+        }
         if (attempt >= 4) { set_error("fingerprint collisions persisted over 5 seeds"); return SPSP_ERR_HIP; }
         seed = seed * 6364136223846793005ULL + 1442695040888963407ULL;  // new fingerprints, try again
     }
-    const uint32_t W = (n + 63) / 64;
-    if ((rc = ctx->c_matrix.reserve((size_t)n_rows * W * 8))) return rc;
-    SPSP_HIP(hipMemsetAsync(ctx->c_matrix.p, 0, (size_t)n_rows * W * 8, ctx->stream));
-    hipLaunchKernelGGL(k_fill, grid_all, dim3(256), 0, ctx->stream, K, sk, n, S, row_first, row_stride, seed,
-                       ctx->c_table.as<uint64_t>(), log2cap, ctx->c_owner.as<uint32_t>(), ctx->c_rowid.as<uint32_t>(),
-                       W, ctx->c_matrix.as<unsigned long long>(), ctx->c_row.as<uint32_t>());
-    SPSP_HIP(hipGetLastError());
-    if ((rc = ctx->ev_begin(kEvAccumulate))) return rc;
-    uint32_t lanes_per_key = 64;
-    if (W < 64) { lanes_per_key = 1; while (lanes_per_key < W) lanes_per_key <<= 1; }
-    hipLaunchKernelGGL(k_accumulate, dim3((W + 63) / 64, n_own), dim3(kAccThreads), 0, ctx->stream,
-                       ctx->c_row.as<uint32_t>(), ctx->c_matrix.as<uint64_t>(), W, lanes_per_key, sk, n, row_first,
-                       row_stride, d_inter);
-    SPSP_HIP(hipGetLastError());
-    if ((rc = ctx->ev_end(kEvAccumulate))) return rc;
-    return SPSP_OK;
 }
 
 int compare_device_impl(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min, const uint64_t* d_lo,

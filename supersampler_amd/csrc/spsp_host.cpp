@@ -275,6 +275,66 @@ int inflate_all(const uint8_t* in, size_t n, std::vector<uint8_t>& out) {
 
 }  // namespace
 
+namespace spsp {
+
+// Super-k-mer i's bases come either from the full cleaned sequence (bases + rec_off[rec] + start) or, when the
+// ingest ran on the GPU, from a compact buffer holding only the selected super-k-mers (compact + compact_off[i]).
+int sketch_build_core(const spsp_params* p, double rate, const uint64_t* rec_off, uint32_t n_rec, const spsp_superkmer* sk,
+                      uint64_t n_sk, const uint8_t* bases, const uint8_t* compact, const uint32_t* compact_off,
+                      uint8_t** payload, uint64_t* payload_len, spsp_sketch_stats* stats) {
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (!payload || !payload_len || (n_rec && !rec_off) || (n_sk && (!sk || (!bases && !(compact && compact_off))))) {
+        set_error("NULL argument");
+        return SPSP_ERR_ARG;
+    }
+    Builder b;
+    b.k = p->k; b.m = p->m; b.abundance = p->abundance;
+    b.kmask = (((u128)1) << (2 * p->k)) - 1;
+    b.mmask = (1u << (2 * p->m)) - 1;
+    memset(&b.st, 0, sizeof b.st);
+    b.index.init(1024);
+    uint64_t nb = 0, pos_end = 0;
+    uint32_t cur_rec = 0xffffffffu;
+    for (uint32_t r = 0; r < n_rec; ++r) {
+        const uint64_t len = rec_off[r + 1] - rec_off[r];
+        if (len >= p->k) b.st.read_kmer += len - p->k + 1;
+    }
+    for (uint64_t i = 0; i < n_sk; ++i) {
+        const spsp_superkmer& e = sk[i];
+        if (e.rec >= n_rec || e.len < p->k || e.start + e.len > rec_off[e.rec + 1] - rec_off[e.rec]) {
+            set_error("super-k-mer %llu is outside its record", (unsigned long long)i);
+            return SPSP_ERR_ARG;
+        }
+        // nb_mmer_selected bookkeeping (SubSampler.cpp:410-424, 445): a pure function of the stream
+        if (e.rec != cur_rec) { cur_rec = e.rec; pos_end = 0; }
+        const uint64_t rlen = rec_off[e.rec + 1] - rec_off[e.rec];
+        if (e.start + e.len == rlen) nb -= p->m - 1;  // the tail call :441-450
+        else {
+            if (e.start + p->m - 2 > pos_end) {
+                if (pos_end > 0) nb -= p->m - 1;
+                nb += e.len;
+                nb -= p->k - p->m;
+            } else nb += e.start + e.len - (pos_end + 1);
+            pos_end = e.start + e.len - 1;
+        }
+        const uint8_t* src = compact ? compact + compact_off[i] : bases + rec_off[e.rec] + e.start;
+        b.add_superkmer(src, e.len, e.minimizer, e.rev != 0);
+    }
+    nb -= p->m - 1;  // SubSampler.cpp:458
+    b.st.nb_mmer_selected = nb;
+    std::string out;
+    b.emit(rate, out);
+    *payload = (uint8_t*)malloc(out.size() + 1);
+    if (!*payload) { set_error("out of host memory"); return SPSP_ERR_NOMEM; }
+    memcpy(*payload, out.data(), out.size());
+    *payload_len = out.size();
+    if (stats) *stats = b.st;
+    return SPSP_OK;
+}
+
+}  // namespace spsp
+
 extern "C" {
 
 // Subsampler::compute_threshold (SubSampler.cpp:622-631) + SubSampler.h:79-83
@@ -335,51 +395,8 @@ int spsp_fasta_clean_host(const char* text, uint64_t n, uint8_t** bases, uint64_
 int spsp_sketch_build_host(const spsp_params* p, double rate, const uint8_t* bases, const uint64_t* rec_off,
                            uint32_t n_rec, const spsp_superkmer* sk, uint64_t n_sk, uint8_t** payload,
                            uint64_t* payload_len, spsp_sketch_stats* stats) {
-    int rc = spsp::check_params(p);
-    if (rc) return rc;
-    if (!payload || !payload_len || (n_sk && (!sk || !bases || !rec_off))) { set_error("NULL argument"); return SPSP_ERR_ARG; }
-    Builder b;
-    b.k = p->k; b.m = p->m; b.abundance = p->abundance;
-    b.kmask = (((u128)1) << (2 * p->k)) - 1;
-    b.mmask = (1u << (2 * p->m)) - 1;
-    memset(&b.st, 0, sizeof b.st);
-    b.index.init(1024);
-    uint64_t nb = 0, pos_end = 0;
-    uint32_t cur_rec = 0xffffffffu;
-    for (uint32_t r = 0; r < n_rec; ++r) {
-        const uint64_t len = rec_off[r + 1] - rec_off[r];
-        if (len >= p->k) b.st.read_kmer += len - p->k + 1;
-    }
-    for (uint64_t i = 0; i < n_sk; ++i) {
-        const spsp_superkmer& e = sk[i];
-        if (e.rec >= n_rec || e.len < p->k || e.start + e.len > rec_off[e.rec + 1] - rec_off[e.rec]) {
-            set_error("super-k-mer %llu is outside its record", (unsigned long long)i);
-            return SPSP_ERR_ARG;
-        }
-        // nb_mmer_selected bookkeeping (SubSampler.cpp:410-424, 445): a pure function of the stream
-        if (e.rec != cur_rec) { cur_rec = e.rec; pos_end = 0; }
-        const uint64_t rlen = rec_off[e.rec + 1] - rec_off[e.rec];
-        if (e.start + e.len == rlen) nb -= p->m - 1;  // the tail call :441-450
-        else {
-            if (e.start + p->m - 2 > pos_end) {
-                if (pos_end > 0) nb -= p->m - 1;
-                nb += e.len;
-                nb -= p->k - p->m;
-            } else nb += e.start + e.len - (pos_end + 1);
-            pos_end = e.start + e.len - 1;
-        }
-        b.add_superkmer(bases + rec_off[e.rec] + e.start, e.len, e.minimizer, e.rev != 0);
-    }
-    nb -= p->m - 1;  // SubSampler.cpp:458
-    b.st.nb_mmer_selected = nb;
-    std::string out;
-    b.emit(rate, out);
-    *payload = (uint8_t*)malloc(out.size() + 1);
-    if (!*payload) { set_error("out of host memory"); return SPSP_ERR_NOMEM; }
-    memcpy(*payload, out.data(), out.size());
-    *payload_len = out.size();
-    if (stats) *stats = b.st;
-    return SPSP_OK;
+    if (n_sk && !bases) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    return spsp::sketch_build_core(p, rate, rec_off, n_rec, sk, n_sk, bases, nullptr, nullptr, payload, payload_len, stats);
 }
 
 int spsp_sketch_parse_host(const uint8_t* payload, uint64_t len, uint32_t* k_out, uint32_t* m_out,
@@ -577,15 +594,10 @@ int spsp_sketch_file(spsp_ctx* ctx, const spsp_params* p, double rate, const cha
     uint8_t* text = nullptr; uint64_t tlen = 0;
     int rc = spsp_read_file_host(fasta_path, &text, &tlen);
     if (rc) return rc;
-    uint8_t* bases = nullptr; uint64_t* off = nullptr; uint32_t n_rec = 0;
-    rc = spsp_fasta_clean_host((const char*)text, tlen, &bases, &off, &n_rec);
-    free(text);
-    if (rc) return rc;
-    spsp_superkmer* sk = nullptr; uint64_t n_sk = 0;
-    rc = spsp_scan(ctx, p, bases, off, n_rec, &sk, &n_sk);
+    // ingest (getLineFasta + clean_dna), scan and super-k-mer gather all run on the GPU
     uint8_t* payload = nullptr; uint64_t plen = 0;
-    if (!rc) rc = spsp_sketch_build_host(p, rate, bases, off, n_rec, sk, n_sk, &payload, &plen, stats);
-    free(bases); free(off); free(sk);
+    rc = spsp_sketch_text(ctx, p, rate, (const char*)text, tlen, &payload, &plen, stats);
+    free(text);
     if (rc) { free(payload); return rc; }
     rc = spsp_write_gz_host(out_path, payload, plen, 9);  // level 9: SubSampler.cpp:326
     free(payload);

@@ -1,0 +1,361 @@
+// spsp_ingest.hip -- "next" row N1 of SURVEY.md 8(f): FASTA ingest on the GPU.
+//
+// The reference reads a record with getLineFasta (utils.cpp:706-718): drop one
+// line, concatenate the following lines up to the next one that starts with
+// '>', then clean_dna (utils.cpp:675-702) deletes every byte that is not one of
+// ACGTacgt and upper-cases the rest.  Over a whole (gunzipped) file that is:
+//
+//   * line 0 and every line starting with '>' (or 0xFF, the reference's
+//     (char)peek()==EOF aliasing) is a DROP line and starts a new record;
+//   * every other byte survives iff it is in ACGTacgt.
+//
+// So ingest is a stream compaction with a one-bit line state.  Three launches:
+//   k_clean_tiles   per 4 KiB tile: state transform of the tile (does it end inside
+//                   a drop line?), survivor counts with the entry state left open,
+//                   record starts
+//   k_clean_scan    one workgroup: composes the tile transforms, turns the counts
+//                   into output / record offsets
+//   k_clean_write   per tile: compacts through LDS, coalesced stores, rec_off[]
+// 1 B read + 1 B written per input byte, twice over the input (L2-friendly).
+#include <cstdlib>
+#include <vector>
+
+#include "spsp_internal.h"
+
+namespace spsp {
+
+constexpr int kCleanThreads = 256;
+constexpr int kCleanChunk = 16;
+constexpr int kCleanTile = kCleanThreads * kCleanChunk;   // 4096 bytes
+
+__device__ __forceinline__ bool is_drop_start(uint32_t c) { return c == '>' || c == 0xFFu; }
+// upper-cased base for ACGTacgt, 0 otherwise
+__device__ __forceinline__ uint32_t keep_base(uint32_t c) {
+    const uint32_t u = c & 0xDFu;   // fold case
+    return (u == 'A' || u == 'C' || u == 'G' || u == 'T') ? u : 0u;
+}
+
+// Everything one lane needs to know about its 16 bytes.
+struct ChunkInfo {
+    uint32_t bytes[4];       // raw little-endian dwords (zero past the end of the text)
+    uint32_t valid;          // number of bytes inside the text
+    uint32_t keep_if_data;   // bit j: byte j is a base (survives if its line is a data line)
+    uint32_t nl_mask;        // bit j: byte j is '\n'
+    uint32_t drop_after;     // bit j: byte j is '\n' and the line starting at j+1 exists and is a drop line
+};
+
+__device__ __forceinline__ ChunkInfo load_chunk(const uint8_t* __restrict__ text, uint64_t n, uint64_t p0) {
+    ChunkInfo c;
+    c.valid = p0 >= n ? 0u : (uint32_t)((n - p0) < (uint64_t)kCleanChunk ? (n - p0) : (uint64_t)kCleanChunk);
+    if (c.valid == kCleanChunk) {
+        const uint4 v = *reinterpret_cast<const uint4*>(text + p0);
+        c.bytes[0] = v.x; c.bytes[1] = v.y; c.bytes[2] = v.z; c.bytes[3] = v.w;
+    } else {
+        c.bytes[0] = c.bytes[1] = c.bytes[2] = c.bytes[3] = 0;
+        for (uint32_t j = 0; j < c.valid; ++j) c.bytes[j >> 2] |= (uint32_t)text[p0 + j] << (8 * (j & 3));
+    }
+    const uint32_t next = (p0 + kCleanChunk < n) ? text[p0 + kCleanChunk] : 0x100u;   // 0x100: nothing follows
+    c.keep_if_data = 0; c.nl_mask = 0; c.drop_after = 0;
+#pragma unroll
+    for (int j = 0; j < kCleanChunk; ++j) {
+        const uint32_t b = (c.bytes[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+        const bool in = (uint32_t)j < c.valid;
+        if (in && keep_base(b)) c.keep_if_data |= 1u << j;
+        if (in && b == '\n') {
+            c.nl_mask |= 1u << j;
+            uint32_t follow;
+            if (j + 1 < kCleanChunk) follow = (uint32_t)(j + 1) < c.valid ? (c.bytes[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 0xFFu : 0x100u;
+            else follow = next;
+            if (follow != 0x100u && is_drop_start(follow)) c.drop_after |= 1u << j;
+        }
+    }
+    return c;
+}
+
+// Line-state transform of a span: 0 = identity (no newline inside), 2 = ends in a data
+// line, 3 = ends in a drop line.  compose(a, b): a first, then b.
+__device__ __forceinline__ uint32_t compose(uint32_t a, uint32_t b) { return b ? b : a; }
+__device__ __forceinline__ uint32_t chunk_transform(const ChunkInfo& c) {
+    if (!c.nl_mask) return 0u;
+    const int last = 31 - __clz(c.nl_mask);
+    return 2u | ((c.drop_after >> last) & 1u);
+}
+// bit j set iff byte j survives, given the state (1 = drop line) of the line entering the chunk
+__device__ __forceinline__ uint32_t chunk_keep(const ChunkInfo& c, uint32_t entry_drop) {
+    uint32_t keep = 0, drop = entry_drop;
+#pragma unroll
+    for (int j = 0; j < kCleanChunk; ++j) {
+        if (!drop) keep |= c.keep_if_data & (1u << j);
+        if (c.nl_mask & (1u << j)) drop = (c.drop_after >> j) & 1u;
+    }
+    return keep;
+}
+
+// exclusive scan of the line-state transforms over the workgroup (lane order = byte order)
+__device__ __forceinline__ uint32_t block_scan_transform(uint32_t t, uint32_t* s_wave, uint32_t* total) {
+    const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint32_t x = t;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d);
+        if (lane >= (uint32_t)d) x = compose(y, x);
+    }
+    if (lane == 63) s_wave[wid] = x;
+    __syncthreads();
+    uint32_t pre = 0, all = 0;
+    for (uint32_t w = 0; w < kCleanThreads / 64; ++w) { if (w < wid) pre = compose(pre, s_wave[w]); all = compose(all, s_wave[w]); }
+    uint32_t excl = __shfl_up(x, 1);
+    if (lane == 0) excl = 0;
+    *total = all;
+    __syncthreads();
+    return compose(pre, excl);
+}
+__device__ __forceinline__ uint32_t block_scan_add(uint32_t v, uint32_t* s_wave, uint32_t* total) {
+    const uint32_t lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d);
+        if (lane >= (uint32_t)d) x += y;
+    }
+    if (lane == 63) s_wave[wid] = x;
+    __syncthreads();
+    uint32_t pre = 0, all = 0;
+    for (uint32_t w = 0; w < kCleanThreads / 64; ++w) { if (w < wid) pre += s_wave[w]; all += s_wave[w]; }
+    *total = all;
+    __syncthreads();
+    return pre + x - v;
+}
+
+struct TileSummary { uint32_t transform, keep_fixed, keep_if_data, headers; };
+
+__global__ __launch_bounds__(kCleanThreads) void k_clean_tiles(const uint8_t* __restrict__ text, uint64_t n,
+                                                              TileSummary* __restrict__ tiles) {
+    __shared__ uint32_t s_wave[kCleanThreads / 64];
+    const uint64_t p0 = (uint64_t)blockIdx.x * kCleanTile + (uint64_t)threadIdx.x * kCleanChunk;
+    const ChunkInfo c = load_chunk(text, n, p0);
+    uint32_t tile_t;
+    const uint32_t pre = block_scan_transform(chunk_transform(c), s_wave, &tile_t);
+    // lanes before the tile's first newline inherit the (still unknown) entry state of the tile
+    const uint32_t fixed = pre ? __popc(chunk_keep(c, pre & 1u)) : __popc(chunk_keep(c, 1u));
+    const uint32_t extra = pre ? 0u : __popc(chunk_keep(c, 0u)) - fixed;
+    uint32_t tot_fixed, tot_extra, tot_hdr;
+    block_scan_add(fixed, s_wave, &tot_fixed);
+    block_scan_add(extra, s_wave, &tot_extra);
+    block_scan_add(__popc(c.drop_after), s_wave, &tot_hdr);
+    if (threadIdx.x == 0) tiles[blockIdx.x] = TileSummary{tile_t, tot_fixed, tot_extra, tot_hdr};
+}
+
+// one workgroup: entry state, output offset and record offset of every tile; totals
+__global__ __launch_bounds__(1024) void k_clean_scan(const TileSummary* __restrict__ tiles, uint64_t n_tiles,
+                                                    uint32_t* __restrict__ entry_drop, uint64_t* __restrict__ out_off,
+                                                    uint32_t* __restrict__ rec_base, uint64_t* __restrict__ totals) {
+    __shared__ uint32_t s_t[16];
+    __shared__ unsigned long long s_k[16];
+    __shared__ uint32_t s_h[16];
+    __shared__ uint32_t c_t;
+    __shared__ unsigned long long c_k;
+    __shared__ uint32_t c_h;
+    const uint32_t t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    if (t == 0) { c_t = 3u; c_k = 0; c_h = 1; }   // the file starts inside a drop line (line 0), which is record 0
+    __syncthreads();
+    for (uint64_t base = 0; base < n_tiles; base += 1024) {
+        const uint64_t i = base + t;
+        TileSummary me = {0, 0, 0, 0};
+        if (i < n_tiles) me = tiles[i];
+        // inclusive scan of transforms
+        uint32_t x = me.transform;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d);
+            if (lane >= (uint32_t)d) x = compose(y, x);
+        }
+        if (lane == 63) s_t[wid] = x;
+        __syncthreads();
+        uint32_t pre = c_t;
+        for (uint32_t w = 0; w < wid; ++w) pre = compose(pre, s_t[w]);
+        uint32_t excl = __shfl_up(x, 1);
+        if (lane == 0) excl = 0;
+        const uint32_t entry = compose(pre, excl) & 1u;      // always a constant: the carry starts as one
+        const unsigned long long keep = (unsigned long long)me.keep_fixed + (entry ? 0u : me.keep_if_data);
+        unsigned long long kx = keep;
+        uint32_t hx = me.headers;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long ky = __shfl_up(kx, d);
+            const uint32_t hy = __shfl_up(hx, d);
+            if (lane >= (uint32_t)d) { kx += ky; hx += hy; }
+        }
+        if (lane == 63) { s_k[wid] = kx; s_h[wid] = hx; }
+        __syncthreads();
+        unsigned long long kpre = c_k, kall = 0;
+        uint32_t hpre = c_h, hall = 0, tall = 0;
+        for (uint32_t w = 0; w < 16; ++w) {
+            if (w < wid) { kpre += s_k[w]; hpre += s_h[w]; }
+            kall += s_k[w]; hall += s_h[w]; tall = compose(tall, s_t[w]);
+        }
+        if (i < n_tiles) { entry_drop[i] = entry; out_off[i] = kpre + kx - keep; rec_base[i] = hpre + hx - me.headers; }
+        __syncthreads();
+        if (t == 0) { c_t = compose(c_t, tall); c_k += kall; c_h += hall; }
+        __syncthreads();
+    }
+    if (t == 0) { totals[0] = c_k; totals[1] = c_h; }
+}
+
+__global__ __launch_bounds__(kCleanThreads) void k_clean_write(const uint8_t* __restrict__ text, uint64_t n,
+                                                              const uint32_t* __restrict__ entry_drop,
+                                                              const uint64_t* __restrict__ out_off,
+                                                              const uint32_t* __restrict__ rec_base,
+                                                              uint8_t* __restrict__ bases, uint64_t* __restrict__ rec_off) {
+    __shared__ uint32_t s_wave[kCleanThreads / 64];
+    __shared__ uint8_t s_out[kCleanTile];
+    const uint64_t p0 = (uint64_t)blockIdx.x * kCleanTile + (uint64_t)threadIdx.x * kCleanChunk;
+    const ChunkInfo c = load_chunk(text, n, p0);
+    uint32_t tile_t;
+    const uint32_t pre = block_scan_transform(chunk_transform(c), s_wave, &tile_t);
+    const uint32_t entry = pre ? (pre & 1u) : entry_drop[blockIdx.x];
+    const uint32_t keep = chunk_keep(c, entry);
+    uint32_t tile_keep, tile_hdr;
+    const uint32_t koff = block_scan_add(__popc(keep), s_wave, &tile_keep);
+    const uint32_t hoff = block_scan_add(__popc(c.drop_after), s_wave, &tile_hdr);
+    const uint64_t obase = out_off[blockIdx.x];
+    // survivors -> LDS in order, record starts -> rec_off
+    uint32_t at = koff, hr = rec_base[blockIdx.x] + hoff;
+#pragma unroll
+    for (int j = 0; j < kCleanChunk; ++j) {
+        if (keep & (1u << j)) s_out[at++] = (uint8_t)keep_base((c.bytes[j >> 2] >> (8 * (j & 3))) & 0xFFu);
+        if (c.drop_after & (1u << j)) rec_off[hr++] = obase + at;   // the record begins where the next survivor will land
+    }
+    __syncthreads();
+    for (uint32_t x = threadIdx.x; x < tile_keep; x += kCleanThreads) bases[obase + x] = s_out[x];
+    if (blockIdx.x == 0 && threadIdx.x == 0) rec_off[0] = 0;
+}
+
+// copy the bases of every selected super-k-mer into one compact buffer (dst offsets = prefix sums of len)
+__global__ void k_gather_superkmers(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ rec_off,
+                                    const spsp_superkmer* __restrict__ sk, const uint32_t* __restrict__ dst_off,
+                                    uint32_t n_sk, uint8_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);   // one wave per super-k-mer
+    if (i >= n_sk) return;
+    const spsp_superkmer e = sk[i];
+    const uint8_t* src = bases + rec_off[e.rec] + e.start;
+    uint8_t* dst = out + dst_off[i];
+    for (uint32_t j = threadIdx.x & 63; j < e.len; j += 64) dst[j] = src[j];
+}
+__global__ void k_sk_lens(const spsp_superkmer* __restrict__ sk, uint32_t n_sk, uint32_t* __restrict__ lens) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_sk) lens[i] = sk[i].len;
+}
+
+int clean_device_impl(spsp_ctx* ctx, const uint8_t* d_text, uint64_t n_text, uint8_t** d_bases, uint64_t* n_bases,
+                      uint64_t** d_rec_off, uint32_t* n_rec) {
+    if (((uintptr_t)d_text & 15u) != 0) { set_error("d_text must be 16-byte aligned"); return SPSP_ERR_ARG; }
+    const uint64_t n_tiles = (n_text + kCleanTile - 1) / kCleanTile;
+    if (n_tiles > 0x7fffffffull) { set_error("text too large for one call"); return SPSP_ERR_OVERFLOW; }
+    int rc;
+    if ((rc = ctx->i_tiles.reserve((size_t)(n_tiles + 1) * sizeof(TileSummary)))) return rc;
+    if ((rc = ctx->i_entry.reserve((size_t)(n_tiles + 1) * 4))) return rc;
+    if ((rc = ctx->i_outoff.reserve((size_t)(n_tiles + 1) * 8))) return rc;
+    if ((rc = ctx->i_recbase.reserve((size_t)(n_tiles + 1) * 4))) return rc;
+    if ((rc = ctx->bases.reserve((size_t)n_text + 64))) return rc;     // survivors never outnumber the input
+    if ((rc = ctx->d_scalar.reserve(64))) return rc;
+    uint64_t* totals = ctx->h_scalar + 4;
+    if (n_tiles) {
+        hipLaunchKernelGGL(k_clean_tiles, dim3((uint32_t)n_tiles), dim3(kCleanThreads), 0, ctx->stream, d_text, n_text,
+                           ctx->i_tiles.as<TileSummary>());
+        SPSP_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_clean_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->i_tiles.as<TileSummary>(), n_tiles,
+                       ctx->i_entry.as<uint32_t>(), ctx->i_outoff.as<uint64_t>(), ctx->i_recbase.as<uint32_t>(), totals);
+    SPSP_HIP(hipGetLastError());
+    SPSP_HIP(hipStreamSynchronize(ctx->stream));
+    const uint64_t kept = totals[0], recs = totals[1];
+    if (recs > 0xfffffff0ull) { set_error("too many FASTA records for one call"); return SPSP_ERR_OVERFLOW; }
+    if ((rc = ctx->rec_off.reserve((size_t)(recs + 1) * 8))) return rc;
+    if (n_tiles) {
+        hipLaunchKernelGGL(k_clean_write, dim3((uint32_t)n_tiles), dim3(kCleanThreads), 0, ctx->stream, d_text, n_text,
+                           ctx->i_entry.as<uint32_t>(), ctx->i_outoff.as<uint64_t>(), ctx->i_recbase.as<uint32_t>(),
+                           ctx->bases.as<uint8_t>(), ctx->rec_off.as<uint64_t>());
+        SPSP_HIP(hipGetLastError());
+    }
+    // rec_off[0] (also for an empty text) and the closing offset
+    const uint64_t ends[1] = {kept};
+    if (!n_tiles) { const uint64_t zero = 0; SPSP_HIP(hipMemcpyAsync(ctx->rec_off.p, &zero, 8, hipMemcpyHostToDevice, ctx->stream)); }
+    SPSP_HIP(hipMemcpyAsync(ctx->rec_off.as<uint64_t>() + recs, ends, 8, hipMemcpyHostToDevice, ctx->stream));
+    SPSP_HIP(hipStreamSynchronize(ctx->stream));
+    *d_bases = ctx->bases.as<uint8_t>(); *n_bases = kept;
+    *d_rec_off = ctx->rec_off.as<uint64_t>(); *n_rec = (uint32_t)recs;
+    return SPSP_OK;
+}
+
+// bases of the selected super-k-mers -> one compact HOST buffer + offsets (malloc'd; n_sk+1 offsets)
+int gather_superkmers_impl(spsp_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_rec_off, const spsp_superkmer* d_sk,
+                           uint64_t n_sk, uint8_t** h_compact, uint32_t** h_off) {
+    *h_compact = nullptr; *h_off = nullptr;
+    uint32_t* off = (uint32_t*)malloc((size_t)(n_sk + 1) * 4);
+    if (!off) { set_error("out of host memory"); return SPSP_ERR_NOMEM; }
+    off[0] = 0;
+    if (n_sk == 0) { *h_off = off; *h_compact = (uint8_t*)malloc(1); return SPSP_OK; }
+    int rc;
+    if ((rc = ctx->i_lens.reserve((size_t)n_sk * 4)) || (rc = ctx->i_dst.reserve((size_t)(n_sk + 1) * 4))) { free(off); return rc; }
+    hipLaunchKernelGGL(k_sk_lens, dim3((uint32_t)((n_sk + 255) / 256)), dim3(256), 0, ctx->stream, d_sk, (uint32_t)n_sk,
+                       ctx->i_lens.as<uint32_t>());
+    if ((rc = launch_scan_u32(ctx, ctx->i_lens.as<uint32_t>(), ctx->i_dst.as<uint32_t>(), n_sk, ctx->h_scalar + 6))) { free(off); return rc; }
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { free(off); return hip_fail(e, "gather sizes", __FILE__, __LINE__); }
+    const uint64_t total = ctx->h_scalar[6];
+    if ((rc = ctx->i_compact.reserve((size_t)total + 64))) { free(off); return rc; }
+    hipLaunchKernelGGL(k_gather_superkmers, dim3((uint32_t)((n_sk + 3) / 4)), dim3(256), 0, ctx->stream, d_bases, d_rec_off,
+                       d_sk, ctx->i_dst.as<uint32_t>(), (uint32_t)n_sk, ctx->i_compact.as<uint8_t>());
+    uint8_t* buf = (uint8_t*)malloc((size_t)total + 1);
+    if (!buf) { free(off); set_error("out of host memory"); return SPSP_ERR_NOMEM; }
+    e = hipMemcpyAsync(buf, ctx->i_compact.p, (size_t)total, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(off, ctx->i_dst.p, (size_t)(n_sk + 1) * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { free(off); free(buf); return hip_fail(e, "gather copy", __FILE__, __LINE__); }
+    *h_compact = buf; *h_off = off;
+    return SPSP_OK;
+}
+
+}  // namespace spsp
+
+using namespace spsp;
+
+extern "C" {
+
+int spsp_fasta_clean_device(spsp_ctx* ctx, const void* d_text, uint64_t n_text, void** d_bases, uint64_t* n_bases,
+                            void** d_rec_off, uint32_t* n_rec) {
+    if (!ctx || !d_bases || !n_bases || !d_rec_off || !n_rec || (n_text && !d_text)) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    SPSP_HIP(hipSetDevice(ctx->device));
+    uint8_t* b = nullptr; uint64_t* o = nullptr;
+    const int rc = clean_device_impl(ctx, (const uint8_t*)d_text, n_text, &b, n_bases, &o, n_rec);
+    *d_bases = b; *d_rec_off = o;
+    return rc;
+}
+
+// FASTA text (host, gunzipped) -> sketch payload with ingest, scan and super-k-mer gather on the GPU:
+// only the selected super-k-mers' bases (~0.2 % of the genome at -s 1000) ever come back to the host.
+int spsp_sketch_text(spsp_ctx* ctx, const spsp_params* p, double rate, const char* text, uint64_t n_text,
+                     uint8_t** payload, uint64_t* payload_len, spsp_sketch_stats* stats) {
+    if (!ctx || !payload || !payload_len || (n_text && !text)) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    int rc = check_params(p);
+    if (rc) return rc;
+    SPSP_HIP(hipSetDevice(ctx->device));
+    if ((rc = ctx->i_text.reserve((size_t)n_text + 64))) return rc;
+    if (n_text) SPSP_HIP(hipMemcpyAsync(ctx->i_text.p, text, (size_t)n_text, hipMemcpyHostToDevice, ctx->stream));
+    uint8_t* d_bases = nullptr; uint64_t* d_off = nullptr; uint64_t n_bases = 0; uint32_t n_rec = 0;
+    if ((rc = clean_device_impl(ctx, ctx->i_text.as<uint8_t>(), n_text, &d_bases, &n_bases, &d_off, &n_rec))) return rc;
+    spsp_superkmer* d_sk = nullptr; uint64_t n_sk = 0;
+    if ((rc = scan_device_impl(ctx, p, d_bases, n_bases, d_off, n_rec, &d_sk, &n_sk))) return rc;
+    std::vector<uint64_t> rec_off((size_t)n_rec + 1);
+    std::vector<spsp_superkmer> sk((size_t)n_sk);
+    SPSP_HIP(hipMemcpyAsync(rec_off.data(), d_off, rec_off.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (n_sk) SPSP_HIP(hipMemcpyAsync(sk.data(), d_sk, (size_t)n_sk * sizeof(spsp_superkmer), hipMemcpyDeviceToHost, ctx->stream));
+    uint8_t* compact = nullptr; uint32_t* coff = nullptr;
+    if ((rc = gather_superkmers_impl(ctx, d_bases, d_off, d_sk, n_sk, &compact, &coff))) return rc;   // synchronises the stream
+    rc = sketch_build_core(p, rate, rec_off.data(), n_rec, sk.data(), n_sk, nullptr, compact, coff, payload, payload_len, stats);
+    free(compact); free(coff);
+    return rc;
+}
+
+}  // extern "C"

@@ -79,6 +79,8 @@ struct spsp_ctx {
     uint32_t pair_m = 0;
     uint64_t pair_thr = 0;
     bool pair_valid = false;
+    // ingest workspace (GPU-side getLineFasta + clean_dna)
+    spsp::DevBuf i_text, i_tiles, i_entry, i_outoff, i_recbase, i_lens, i_dst, i_compact;
     // compare workspace
     spsp::DevBuf c_min, c_lo, c_hi, c_table, c_owner, c_rowid, c_slot, c_row, c_matrix, c_inter, c_flags, c_skoff;
 };
@@ -94,4 +96,15 @@ int compare_device_impl(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min, const 
                         const uint64_t* d_hi, const uint64_t* h_sk_off, uint32_t n, uint32_t row_first,
                         uint32_t row_stride, uint32_t* d_inter);
 int check_params(const spsp_params* p);
+// ingest (spsp_ingest.hip)
+int clean_device_impl(spsp_ctx* ctx, const uint8_t* d_text, uint64_t n_text, uint8_t** d_bases, uint64_t* n_bases,
+                      uint64_t** d_rec_off, uint32_t* n_rec);
+int gather_superkmers_impl(spsp_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_rec_off, const spsp_superkmer* d_sk,
+                           uint64_t n_sk, uint8_t** h_compact, uint32_t** h_off);
+// out[i] = sum(in[0..i)), out[n] = total (also stored to *total_host, pinned)
+int launch_scan_u32(spsp_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, uint64_t n, uint64_t* total_host);
+// host sketch builder over per-super-k-mer base pointers (spsp_host.cpp)
+int sketch_build_core(const spsp_params* p, double rate, const uint64_t* rec_off, uint32_t n_rec, const spsp_superkmer* sk,
+                      uint64_t n_sk, const uint8_t* bases, const uint8_t* compact, const uint32_t* compact_off,
+                      uint8_t** payload, uint64_t* payload_len, spsp_sketch_stats* stats);
 }  // namespace spsp

@@ -767,6 +767,13 @@ __global__ void k_resolve(const Hit* __restrict__ hits, const uint32_t* __restri
     }
 }
 
+int launch_scan_u32(spsp_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, uint64_t n, uint64_t* total_host) {
+    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, ctx->stream, d_in, d_out, n, (const uint32_t*)nullptr,
+                       total_host, (uint32_t*)nullptr);
+    SPSP_HIP(hipGetLastError());
+    return SPSP_OK;
+}
+
 // ----------------------------------------------------------------- helpers --
 int check_params(const spsp_params* p) {
     if (!p) { set_error("params is NULL"); return SPSP_ERR_ARG; }

@@ -239,6 +239,77 @@ def test_cli_query_mode_abundance_and_flag_rules(tmp_path):
         assert gzip.open(tmp_path / fn, "rb").read() == orc.csv(jac, order, inter, card, 2, 4, 0.2)
 
 
+FASTA_TEXTS = [
+    b">r1 desc\nACGTNNacgt\r\nGG\n>r2\n\nTTTT\n>empty\n>r4\nAC",
+    b"ACGT\nGGGG\n", b"", b">only header", b">h\n", b"\n\n>x\nAC\n\n\nGT\n>y\nNNNN\n>z\nacgtn",
+    b">a\nAC\xffGT\n\xff\nTT\n", b">a\nACGT", b"\n", b">\n>\n>", b"ACGT",
+]
+
+
+def _random_fasta_text(rng, n_lines, max_len):
+    out = []
+    for _ in range(n_lines):
+        r = rng.random()
+        if r < 0.08:
+            out.append(b">" + bytes(rng.integers(32, 127, size=int(rng.integers(0, 40))).astype(np.uint8)))
+        elif r < 0.10:
+            out.append(b"")
+        elif r < 0.12:
+            out.append(b"\xff" + bytes(synth.random_genome(rng, int(rng.integers(0, 30)))))
+        else:
+            L = int(rng.integers(1, max_len))
+            line = synth.random_genome(rng, L).copy()
+            if rng.random() < 0.3:
+                line[rng.integers(0, L, size=max(1, L // 10))] = ord("N")
+            if rng.random() < 0.3:
+                line = np.frombuffer(bytes(line).lower(), dtype=np.uint8).copy()
+            if rng.random() < 0.1:
+                line = np.concatenate([line, np.frombuffer(b"\r", np.uint8)])
+            out.append(bytes(line))
+    sep = b"\n"
+    return sep.join(out) + (b"\n" if rng.random() < 0.5 else b"")
+
+
+def test_gpu_ingest_matches_oracle(ctx):
+    """row N1: getLineFasta + clean_dna on the GPU == the oracle's cleaned records and offsets, including the
+    first-line rule, empty records, CR/LF, lower case, N's, 0xFF and texts spanning many 4 KiB tiles."""
+    import torch
+    rng = np.random.default_rng(2024)
+    texts = list(FASTA_TEXTS)
+    texts += [_random_fasta_text(rng, n, ml) for (n, ml) in ((30, 80), (400, 120), (3000, 90), (50, 20000), (5, 70000))]
+    texts.append(synth.to_fasta(synth.random_genome(rng, 300_000), "g", n_records=3))
+    texts.append(b">x\n" + bytes(synth.random_genome(rng, 4096 * 3 - 3)))          # newline exactly at tile seams
+    texts.append(b"A" * 4095 + b"\n>" + b"C" * 4094 + b"\nG" * 3000)
+    for text in texts:
+        want_b, want_o = orc.clean_fasta(text)
+        d = torch.from_numpy(np.frombuffer(text + b"\0" * 16, dtype=np.uint8).copy()).cuda()
+        torch.cuda.synchronize()
+        db, nb, do, nr = ctx.clean_fasta_device(d.data_ptr(), len(text))
+        assert nr == len(want_o) - 1 and nb == len(want_b), (len(text), nr, nb, len(want_o) - 1, len(want_b))
+        got_b = np.zeros(nb, np.uint8)
+        got_o = np.zeros(nr + 1, np.uint64)
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        if nb:
+            assert hip.hipMemcpy(ctypes.c_void_p(got_b.ctypes.data), ctypes.c_void_p(db), ctypes.c_size_t(nb), 2) == 0
+        assert hip.hipMemcpy(ctypes.c_void_p(got_o.ctypes.data), ctypes.c_void_p(do), ctypes.c_size_t(8 * (nr + 1)), 2) == 0
+        assert got_o.tolist() == want_o.tolist()
+        assert got_b.tobytes() == want_b.tobytes()
+
+
+@pytest.mark.parametrize("k,m,s", [(31, 11, 100), (63, 15, 20), (21, 11, 1.0)])
+def test_sketch_text_gpu_ingest_equals_oracle(ctx, k, m, s):
+    rng = np.random.default_rng(k + m)
+    g = synth.random_genome(rng, 200_000)
+    text = synth.to_fasta(g[:120_000], "a", n_records=2) + b">short\nACGT\n>n\nNNNNNN\n" + synth.to_fasta(g[120_000:], "b")
+    text = text.replace(b"ACGTA", b"acgNa", 50)
+    got, gst = ctx.sketch_text(text, k, m, s)
+    want, wst = orc.sketch_fasta(text, k, m, s)
+    assert got == want
+    for f in ("selected_kmer_number", "read_kmer", "nb_mmer_selected", "seen_kmers_at_reconstruction"):
+        assert gst[f] == wst[f], f
+
+
 def test_scan_buffer_overflow_retries():
     """the sparse stages are launched with capacity-sized buffers; a call that overflows them
     re-runs with room (hits: from the dense pass, super-k-mers: the write pass only)."""
