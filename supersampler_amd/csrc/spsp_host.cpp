@@ -3,6 +3,7 @@
 // These are the stages SURVEY.md 8(a) keeps on the host (A4, A7-A11, A16);
 // they work on 2-bit integers throughout instead of the reference's
 // std::string substr/find chains, but produce the same bytes.
+#include <sys/stat.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -540,19 +541,38 @@ int spsp_csv_host(int jaccard, const char* const* names, uint32_t n, uint32_t n_
     return SPSP_OK;
 }
 
-int spsp_read_file_host(const char* path, uint8_t** data, uint64_t* len) {
-    if (!path || !data || !len) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+static int slurp(const char* path, uint8_t** raw, uint64_t* n) {
     FILE* f = fopen(path, "rb");
     if (!f) { set_error("cannot open '%s'", path); return SPSP_ERR_IO; }
-    std::vector<uint8_t> raw;
-    std::vector<uint8_t> chunk(1 << 20);
-    size_t got;
-    while ((got = fread(chunk.data(), 1, chunk.size(), f)) > 0) raw.insert(raw.end(), chunk.data(), chunk.data() + got);
+    struct stat st;
+    size_t cap = (fstat(fileno(f), &st) == 0 && st.st_size > 0) ? (size_t)st.st_size + 1 : (1u << 20);
+    uint8_t* buf = (uint8_t*)malloc(cap + 64);
+    size_t got = 0;
+    while (buf) {
+        const size_t r = fread(buf + got, 1, cap - got, f);
+        got += r;
+        if (r == 0) break;
+        if (got == cap) { cap *= 2; uint8_t* nb = (uint8_t*)realloc(buf, cap + 64); if (!nb) { free(buf); buf = nullptr; } else buf = nb; }
+    }
     fclose(f);
-    std::vector<uint8_t> plain;
-    int rc = inflate_all(raw.data(), raw.size(), plain);
+    if (!buf) { set_error("out of host memory"); return SPSP_ERR_NOMEM; }
+    *raw = buf; *n = got;
+    return SPSP_OK;
+}
+
+int spsp_read_file_host(const char* path, uint8_t** data, uint64_t* len) {
+    if (!path || !data || !len) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    uint8_t* raw = nullptr; uint64_t n = 0;
+    int rc = slurp(path, &raw, &n);
     if (rc) return rc;
-    *data = (uint8_t*)malloc(plain.size() + 1);
+    const bool packed = n >= 2 && ((raw[0] == 0x1F && raw[1] == 0x8B) ||
+                                   (raw[0] == 0x78 && (raw[1] == 0x01 || raw[1] == 0x9C || raw[1] == 0xDA)));
+    if (!packed) { *data = raw; *len = n; return SPSP_OK; }   // plain text passes through (zstr autodetect)
+    std::vector<uint8_t> plain;
+    rc = inflate_all(raw, n, plain);
+    free(raw);
+    if (rc) return rc;
+    *data = (uint8_t*)malloc(plain.size() + 64);
     if (!*data) { set_error("out of host memory"); return SPSP_ERR_NOMEM; }
     if (!plain.empty()) memcpy(*data, plain.data(), plain.size());
     *len = plain.size();
@@ -594,9 +614,19 @@ int spsp_sketch_file(spsp_ctx* ctx, const spsp_params* p, double rate, const cha
     uint8_t* text = nullptr; uint64_t tlen = 0;
     int rc = spsp_read_file_host(fasta_path, &text, &tlen);
     if (rc) return rc;
-    // ingest (getLineFasta + clean_dna), scan and super-k-mer gather all run on the GPU
     uint8_t* payload = nullptr; uint64_t plen = 0;
-    rc = spsp_sketch_text(ctx, p, rate, (const char*)text, tlen, &payload, &plen, stats);
+    static const bool host_ingest = getenv("SPSP_HOST_INGEST") != nullptr;   // A/B switch: clean on the host, scan on the GPU
+    if (host_ingest) {
+        uint8_t* bases = nullptr; uint64_t* off = nullptr; uint32_t n_rec = 0;
+        rc = spsp_fasta_clean_host((const char*)text, tlen, &bases, &off, &n_rec);
+        spsp_superkmer* sk = nullptr; uint64_t n_sk = 0;
+        if (!rc) rc = spsp_scan(ctx, p, bases, off, n_rec, &sk, &n_sk);
+        if (!rc) rc = spsp_sketch_build_host(p, rate, bases, off, n_rec, sk, n_sk, &payload, &plen, stats);
+        free(bases); free(off); free(sk);
+    } else {
+        // ingest (getLineFasta + clean_dna), scan and super-k-mer gather all run on the GPU
+        rc = spsp_sketch_text(ctx, p, rate, (const char*)text, tlen, &payload, &plen, stats);
+    }
     free(text);
     if (rc) { free(payload); return rc; }
     rc = spsp_write_gz_host(out_path, payload, plen, 9);  // level 9: SubSampler.cpp:326
