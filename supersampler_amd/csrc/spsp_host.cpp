@@ -7,11 +7,13 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "spsp_internal.h"
@@ -638,22 +640,46 @@ int spsp_compare_files(spsp_ctx* ctx, const char* const* paths, uint32_t n, uint
                        double min_threshold, const char* out_prefix) {
     if (!paths || !out_prefix) { set_error("NULL argument"); return SPSP_ERR_ARG; }
     std::vector<spsp_sketch_view> views(n);
-    std::vector<void*> owned;
-    int rc = SPSP_OK;
-    uint32_t k0 = 0, m0 = 0;
-    for (uint32_t i = 0; i < n && !rc; ++i) {  // one sketch at a time: no N open streams (Comparator.cpp:45-50)
-        uint8_t* data = nullptr; uint64_t len = 0;
-        rc = spsp_read_file_host(paths[i], &data, &len);
-        if (rc) break;
-        uint32_t k = 0, m = 0; uint32_t* mn = nullptr; uint64_t *lo = nullptr, *hi = nullptr; uint64_t cnt = 0;
-        rc = spsp_sketch_parse_host(data, len, &k, &m, &mn, &lo, &hi, &cnt);
-        free(data);
-        if (rc) break;
-        owned.push_back(mn); owned.push_back(lo); owned.push_back(hi);
-        if (i == 0) { k0 = k; m0 = m; }
-        else if (k != k0 || m != m0) { set_error("'%s' was sketched with k=%u m=%u, expected k=%u m=%u", paths[i], k, m, k0, m0); rc = SPSP_ERR_FORMAT; break; }
-        views[i].minimizer = mn; views[i].kmer_lo = lo; views[i].kmer_hi = (k > 32) ? hi : nullptr; views[i].n = cnt;
+    std::vector<void*> owned((size_t)n * 3, nullptr);
+    std::vector<uint32_t> ks(n, 0), ms(n, 0);
+    std::vector<int> rcs(n, SPSP_OK);
+    std::vector<std::string> errs(n);
+    // One sketch at a time per worker: no N open streams (Comparator.cpp:45-50); gunzip + decode + sort of the
+    // sketches is independent work, spread over a few host threads.
+    {
+        unsigned workers = std::thread::hardware_concurrency();
+        if (workers == 0) workers = 1;
+        if (workers > 16) workers = 16;
+        if (workers > n) workers = n ? n : 1;
+        std::atomic<uint32_t> next(0);
+        auto work = [&]() {
+            for (;;) {
+                const uint32_t i = next.fetch_add(1);
+                if (i >= n) break;
+                uint8_t* data = nullptr; uint64_t len = 0;
+                int r = spsp_read_file_host(paths[i], &data, &len);
+                uint32_t* mn = nullptr; uint64_t *lo = nullptr, *hi = nullptr; uint64_t cnt = 0;
+                if (!r) r = spsp_sketch_parse_host(data, len, &ks[i], &ms[i], &mn, &lo, &hi, &cnt);
+                free(data);
+                if (r) { rcs[i] = r; errs[i] = spsp_last_error(); continue; }
+                owned[3 * (size_t)i] = mn; owned[3 * (size_t)i + 1] = lo; owned[3 * (size_t)i + 2] = hi;
+                views[i].minimizer = mn; views[i].kmer_lo = lo; views[i].kmer_hi = hi; views[i].n = cnt;
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned w = 1; w < workers; ++w) pool.emplace_back(work);
+        work();
+        for (auto& th : pool) th.join();
     }
+    int rc = SPSP_OK;
+    for (uint32_t i = 0; i < n && !rc; ++i) {
+        if (rcs[i]) { set_error("%s", errs[i].c_str()); rc = rcs[i]; }
+        else if (ks[i] != ks[0] || ms[i] != ms[0]) {
+            set_error("'%s' was sketched with k=%u m=%u, expected k=%u m=%u", paths[i], ks[i], ms[i], ks[0], ms[0]);
+            rc = SPSP_ERR_FORMAT;
+        }
+    }
+    if (!rc && n && ks[0] <= 32) for (uint32_t i = 0; i < n; ++i) views[i].kmer_hi = nullptr;
     std::vector<uint32_t> inter;
     std::vector<uint64_t> card(n, 0);
     if (!rc) {
