@@ -91,6 +91,37 @@ def test_scan_repeat_rich_genome(ctx):
             _assert_stream_equal(ctx.scan(p, bases, offs), _oracle_stream(k, m, p.threshold, bases, offs))
 
 
+def test_scan_randomised_configs(ctx):
+    """40 seeded random configurations: odd k in 11..63, odd m in 3..15 (m <= k), s from select-all to sparse,
+    genomes mixing random sequence, mutated copies, inverted repeats, homopolymer runs and short records."""
+    rng = np.random.default_rng(31337)
+    comp = np.zeros(256, np.uint8)
+    comp[[65, 67, 71, 84]] = [84, 71, 67, 65]
+    for it in range(40):
+        m = int(rng.choice([3, 5, 7, 9, 11, 13, 15]))
+        k = int(rng.choice([x for x in range(max(m, 11), 64, 2)]))
+        s = float(rng.choice([1.0, 1.5, 2, 3, 7, 20, 100, 1000]))
+        base = synth.random_genome(rng, int(rng.integers(2_000, 60_000)))
+        parts = [base, synth.mutate(rng, base, 0.02)[: len(base) // 2], comp[base[::-1]][: len(base) // 3]]
+        if rng.random() < 0.5:
+            parts.append(np.full(int(rng.integers(10, 300)), int(rng.choice([65, 67, 71, 84])), np.uint8))
+        if rng.random() < 0.5:
+            parts.append(np.tile(synth.random_genome(rng, int(rng.integers(2, 20))), int(rng.integers(5, 60))))
+        rng.shuffle(parts)
+        genome = np.concatenate(parts)
+        cuts = sorted(set([0, len(genome)] + [int(x) for x in rng.integers(0, len(genome), size=int(rng.integers(0, 5)))]))
+        recs = [genome[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
+        bases, offs = synth.concat_records(recs)
+        mode = [sp.SPSP_SCAN_DEFAULT, sp.SPSP_SCAN_DIRECT_HASH, sp.SPSP_SCAN_LDS_FILTER, sp.SPSP_SCAN_PAIR_FILTER][it % 4]
+        p = sp.make_params(k, m, s, flags=mode)
+        got = ctx.scan(p, bases, offs)
+        want = _oracle_stream(k, m, p.threshold, bases, offs)
+        try:
+            _assert_stream_equal(got, want)
+        except AssertionError as e:
+            raise AssertionError("config it=%d k=%d m=%d s=%g mode=%d n=%d: %s" % (it, k, m, s, mode, len(bases), e))
+
+
 def test_scan_edge_inputs(ctx):
     p = sp.make_params(31, 11, 10)
     assert len(ctx.scan(p, np.zeros(0, np.uint8), np.zeros(1, np.uint64))) == 0
