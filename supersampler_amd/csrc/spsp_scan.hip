@@ -135,7 +135,7 @@ __global__ __launch_bounds__(kThreads) void k_dense_direct(const uint8_t* __rest
 // published with global atomics into a pre-zeroed bitmap.
 constexpr int kPairWaves = 16;              // waves per workgroup (1024 lanes)
 constexpr int kPairTabBytes = 65536;        // 2^18 entries x 2 bits
-constexpr int kQueueCap = 256;              // survivor slots per wave (16 bytes each)
+constexpr int kQueueCap = 64;               // survivor slots per wave (16 bytes each): 64 KiB table + 16 KiB queues = 80 KiB, two workgroups per CU
 
 __global__ void k_build_key8(uint32_t m, uint64_t thr, uint32_t* __restrict__ key8) {
     const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -856,8 +856,9 @@ static int launch_dense(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_ba
         }
         const uint64_t n_rows = (n_bases + kRowPosPair63 - 1) / kRowPosPair63;
         const uint64_t want = (n_rows + kPairWaves - 1) / kPairWaves;
-        static const int per_cu = getenv("SPSP_PAIR_BLOCKS_PER_CU") ? atoi(getenv("SPSP_PAIR_BLOCKS_PER_CU")) : 1;  // tuning knob
-        const uint64_t cap = (uint64_t)ctx->n_cu * (per_cu > 0 ? per_cu : 1);   // one 1024-lane workgroup per CU
+        static const int per_cu = getenv("SPSP_PAIR_BLOCKS_PER_CU") ? atoi(getenv("SPSP_PAIR_BLOCKS_PER_CU")) : 0;  // tuning knob
+        // k_dense_pair: 80 KiB of LDS -> two 1024-lane workgroups per CU; k_dense_single: 152 KiB -> one
+        const uint64_t cap = (uint64_t)ctx->n_cu * (per_cu > 0 ? per_cu : (variant == kDensePair ? 2 : 1));
         const dim3 grid((uint32_t)(want < cap ? want : cap));
         if (variant == kDensePair) {
             const size_t lds = (size_t)kPairWaves * kQueueCap * 16;                // + 64 KiB static table
