@@ -177,6 +177,37 @@ def test_compare_many_sketches_multiword_columns(ctx):
     assert np.count_nonzero(want_inter) > 500
 
 
+@pytest.mark.parametrize("n,use_hi", [(3, False), (64, False), (65, True), (130, False), (200, True)])
+def test_compare_synthetic_key_sets(ctx, n, use_hi):
+    """spsp_compare on hand-made key sets (no sketching involved): intersections must equal Python set algebra,
+    for 1, 2 and 4 colour words per row, with and without the high k-mer word (k > 32), empty and identical sets."""
+    rng = np.random.default_rng(n * 7 + use_hi)
+    universe = [(int(rng.integers(0, 2**22)), int(rng.integers(0, 2**62)) if use_hi else 0, int(rng.integers(0, 2**62)))
+                for _ in range(3000)]
+    # same k-mer under two different minimizers must stay two different keys
+    universe += [(u[0] ^ 1, u[1], u[2]) for u in universe[:50]]
+    sets = []
+    for i in range(n):
+        if i % 17 == 5:
+            sets.append(set())
+        elif i % 11 == 3 and i > 0:
+            sets.append(set(sets[i - 1]))
+        else:
+            pick = rng.random(len(universe)) < rng.choice([0.01, 0.1, 0.4])
+            sets.append({universe[j] for j in np.nonzero(pick)[0]})
+    sketches = []
+    for st in sets:
+        keys = sorted(st)
+        sketches.append(sp.Sketch(63 if use_hi else 31, 11, np.array([x[0] for x in keys], np.uint32),
+                                  np.array([x[2] for x in keys], np.uint64), np.array([x[1] for x in keys], np.uint64)))
+    inter, card = ctx.compare(sketches)
+    for i in range(n):
+        assert card[i] == len(sets[i])
+        for j in range(n):
+            want = len(sets[i] & sets[j]) if j > i else 0
+            assert inter[i, j] == want, (i, j, int(inter[i, j]), want)
+
+
 def test_compare_rejects_unsorted_keys(ctx):
     sk = sp.sketch_parse(orc.sketch_fasta(synth.to_fasta(synth.random_genome(np.random.default_rng(1), 20000)),
                                           31, 11, 10)[0])
