@@ -11,7 +11,7 @@
 //   1. dictionary: every distinct (minimizer, k-mer) key of the rows this rank
 //      owns gets a row id (open-addressing table of 64-bit fingerprints,
 //      claimed with one CAS (the winner records itself as the slot's owner);
-//      full keys are verified against the owner afterwards, so a
+//      every later lookup compares the FULL key with the owner's, so a
 //      fingerprint collision is detected and the build retried with a new
 //      seed -- results never depend on the fingerprint).
 //   2. colour matrix A[row][N bits]: bit j set iff sketch j holds the key --
@@ -22,6 +22,7 @@
 //      adds per word), so the work is ~sum_i n_i * N/64 word-adds instead of
 //      the N^2 * n comparisons of pairwise merging.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -34,6 +35,7 @@ struct Keys {
     const uint32_t* mn;
     const uint64_t* lo;
     const uint64_t* hi;  // may be null (k <= 32)
+    uint64_t fp_mask;    // all ones; narrowed only by the collision-path test hook
 };
 
 __device__ __forceinline__ bool key_eq(const Keys& K, uint64_t a, uint64_t b) {
@@ -55,6 +57,7 @@ __device__ __forceinline__ uint64_t fingerprint(const Keys& K, uint64_t e, uint6
     uint64_t f = mix64(K.lo[e] + seed);
     f = mix64(f ^ ((uint64_t)K.mn[e] * 0x9E3779B97F4A7C15ULL));
     if (K.hi) f = mix64(f + K.hi[e]);
+    f &= K.fp_mask;
     return f ? f : 1;
 }
 __device__ __forceinline__ uint64_t home_slot(uint64_t fp, uint32_t log2cap) {
@@ -127,22 +130,13 @@ __global__ __launch_bounds__(kRowThreads) void k_assign_rows(const uint64_t* __r
         if (occ & (1u << u)) rowid[base_slot + (uint64_t)u * kRowThreads + t] = id++;
 }
 
-__global__ void k_verify(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n, uint64_t S, uint32_t row_first,
-                         uint32_t row_stride, const uint32_t* __restrict__ owner, const uint32_t* __restrict__ slot,
-                         uint32_t* __restrict__ flags) {
-    const uint32_t j = row_first + blockIdx.y * row_stride;   // owned sketches only
-    if (j >= n) return;
-    const uint64_t e = sk_off[j] + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= sk_off[j + 1]) return;
-    if (!key_eq(K, owner[slot[e]], e)) atomicOr(&flags[1], 1u);
-}
-
 // Colours: every entry of every sketch looks its key up; found => set bit j of
 // the key's row, and (for owned sketches) remember the row for the accumulation.
 __global__ void k_fill(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n, uint64_t S, uint32_t row_first,
                        uint32_t row_stride, uint64_t seed, const uint64_t* __restrict__ table, uint32_t log2cap,
                        const uint32_t* __restrict__ owner, const uint32_t* __restrict__ rowid, uint32_t W,
-                       unsigned long long* __restrict__ A, uint32_t* __restrict__ row_of_entry) {
+                       unsigned long long* __restrict__ A, uint32_t* __restrict__ row_of_entry,
+                       uint32_t* __restrict__ flags) {
     const uint32_t j = blockIdx.y;
     const uint64_t e = sk_off[j] + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= sk_off[j + 1]) return;
@@ -153,10 +147,15 @@ __global__ void k_fill(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n, 
         const uint64_t v = table[pos];
         if (v == 0) return;  // key not held by any owned sketch: contributes to no owned row
         if (v == fp) {
+            const bool own = j % row_stride == row_first;
             if (key_eq(K, owner[pos], e)) {
                 const uint32_t r = rowid[pos];
                 atomicOr(&A[(uint64_t)r * W + (j >> 6)], 1ull << (j & 63));
-                if (j % row_stride == row_first) row_of_entry[e] = r;
+                if (own) row_of_entry[e] = r;
+            } else if (own) {
+                // an owned key was inserted under this fingerprint, so this IS its slot: a different full key
+                // here means two distinct keys share a fingerprint -> the host rebuilds with another seed
+                atomicOr(&flags[1], 1u);
             }
             return;  // equal keys share the first slot with this fingerprint; nothing further down matches
         }
@@ -265,7 +264,9 @@ static int compare_device_inner(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min
     if ((rc = ctx->c_row.reserve((size_t)S * 4))) return rc;
     if ((rc = ctx->c_flags.reserve(64))) return rc;
     SPSP_HIP(hipMemcpyAsync(ctx->c_skoff.p, h_sk_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    Keys K{d_min, d_lo, (k > 32) ? d_hi : nullptr};
+    Keys K{d_min, d_lo, (k > 32) ? d_hi : nullptr, ~0ull};
+    // test hook: fingerprints of the first attempt cut to a few bits, so distinct keys collide and the retry runs
+    static const char* dbg_fp = getenv("SPSP_DEBUG_FP_BITS");
     const uint64_t* sk = ctx->c_skoff.as<uint64_t>();
     uint32_t* flags = ctx->c_flags.as<uint32_t>();  // [0] unsorted, [1] collision, [2] n_rows
     uint64_t max_all = 0, max_own = 0;
@@ -274,12 +275,13 @@ static int compare_device_inner(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min
         max_all = std::max(max_all, c);
         if (i % row_stride == row_first) max_own = std::max(max_own, c);
     }
-    const dim3 grid_all((uint32_t)((max_all + 255) / 256), n), grid_own((uint32_t)((max_own + 255) / 256), n_own);
+    const dim3 grid_all((uint32_t)((max_all + 255) / 256), n);
+    (void)max_own;
     const uint32_t sblocks = (uint32_t)((cap + (uint64_t)kRowThreads * kRowSlots - 1) / ((uint64_t)kRowThreads * kRowSlots));
     const uint32_t W = (n + 63) / 64;
     uint32_t lanes_per_key = 64;
     if (W < 64) { lanes_per_key = 1; while (lanes_per_key < W) lanes_per_key <<= 1; }
-    // dictionary build: table, row ids, full-key verification
+    // dictionary build: table and row ids
     auto front = [&](uint64_t seed) -> int {
         SPSP_HIP(hipMemsetAsync(ctx->c_table.p, 0, (size_t)cap * 8, ctx->stream));
         SPSP_HIP(hipMemsetAsync(flags, 0, 64, ctx->stream));
@@ -290,9 +292,6 @@ static int compare_device_inner(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min
         hipLaunchKernelGGL(k_assign_rows, dim3(sblocks), dim3(kRowThreads), 0, ctx->stream, ctx->c_table.as<uint64_t>(), cap,
                            ctx->c_rowid.as<uint32_t>(), flags + 2);
         SPSP_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k_verify, grid_own, dim3(256), 0, ctx->stream, K, sk, n, S, row_first, row_stride,
-                           ctx->c_owner.as<uint32_t>(), ctx->c_slot.as<uint32_t>(), flags);
-        SPSP_HIP(hipGetLastError());
         return SPSP_OK;
     };
     // colour matrix (room for `rows` rows) and the row sums
@@ -302,7 +301,7 @@ static int compare_device_inner(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min
         SPSP_HIP(hipMemsetAsync(ctx->c_matrix.p, 0, (size_t)rows * W * 8, ctx->stream));
         hipLaunchKernelGGL(k_fill, grid_all, dim3(256), 0, ctx->stream, K, sk, n, S, row_first, row_stride, seed,
                            ctx->c_table.as<uint64_t>(), log2cap, ctx->c_owner.as<uint32_t>(), ctx->c_rowid.as<uint32_t>(),
-                           W, ctx->c_matrix.as<unsigned long long>(), ctx->c_row.as<uint32_t>());
+                           W, ctx->c_matrix.as<unsigned long long>(), ctx->c_row.as<uint32_t>(), flags);
         SPSP_HIP(hipGetLastError());
         if ((r2 = ctx->ev_begin(kEvAccumulate))) return r2;
         hipLaunchKernelGGL(k_accumulate, dim3((W + 63) / 64, n_own), dim3(kAccThreads), 0, ctx->stream,
@@ -323,15 +322,16 @@ static int compare_device_inner(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min
     uint64_t seed = 0x5350535053505350ULL;
     for (int attempt = 0;; ++attempt) {
         uint32_t h_flags[3];
+        K.fp_mask = (dbg_fp && attempt == 0) ? ((1ull << atoi(dbg_fp)) - 1) : ~0ull;
         if ((rc = front(seed))) return rc;
         if (speculative) {
             if ((rc = back(seed, S_own))) return rc;
-            if ((rc = read_flags(h_flags))) return rc;
-            if (!h_flags[1]) return SPSP_OK;
         } else {
-            if ((rc = read_flags(h_flags))) return rc;
-            if (!h_flags[1]) return back(seed, h_flags[2]);
+            if ((rc = read_flags(h_flags))) return rc;          // the row count sizes the colour matrix
+            if ((rc = back(seed, h_flags[2]))) return rc;
         }
+        if ((rc = read_flags(h_flags))) return rc;              // collisions surface in k_fill
+        if (!h_flags[1]) return SPSP_OK;
         if (attempt >= 4) { set_error("fingerprint collisions persisted over 5 seeds"); return SPSP_ERR_HIP; }
         seed = seed * 6364136223846793005ULL + 1442695040888963407ULL;  // new fingerprints, try again
     }

@@ -208,6 +208,26 @@ def test_compare_synthetic_key_sets(ctx, n, use_hi):
             assert inter[i, j] == want, (i, j, int(inter[i, j]), want)
 
 
+def test_compare_fingerprint_collision_retry():
+    """fingerprints cut to 10 bits on the first attempt: distinct keys collide, the full-key check in k_fill
+    notices and the dictionary is rebuilt with a new seed -- results unchanged."""
+    code = (
+        "import numpy as np, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "import supersampler_amd as sp\n"
+        "rng = np.random.default_rng(1)\n"
+        "sets = [set(map(int, rng.integers(0, 5000, size=2000))) for _ in range(6)]\n"
+        "sk = [sp.Sketch(31, 11, np.zeros(len(s), np.uint32) + 7, np.array(sorted(s), np.uint64), np.zeros(len(s), np.uint64)) for s in sets]\n"
+        "ctx = sp.Context(0)\n"
+        "inter, card = ctx.compare(sk)\n"
+        "assert all(inter[i, j] == len(sets[i] & sets[j]) for i in range(6) for j in range(i + 1, 6))\n"
+        "assert [int(c) for c in card] == [len(s) for s in sets]\n"
+        "print('ok')\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SPSP_DEBUG_FP_BITS="10"), capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
 def test_compare_rejects_unsorted_keys(ctx):
     sk = sp.sketch_parse(orc.sketch_fasta(synth.to_fasta(synth.random_genome(np.random.default_rng(1), 20000)),
                                           31, 11, 10)[0])
