@@ -64,7 +64,7 @@ struct spsp_ctx {
     bool own_stream = false;
     uint64_t* h_scalar = nullptr;  // pinned, 8 slots
     // scan workspace
-    spsp::DevBuf bases, rec_off, bitmap, tile_count, tile_off, hits, emit_count, emit_off, scan_tmp, d_scalar;
+    spsp::DevBuf bases, rec_off, bitmap, tile_count, tile_off, hits, emit_count, emit_off, scan_tmp, d_scalar, seg_a, seg_b;
     uint64_t hits_cap = 0, out_cap = 0;  // entries the sparse-stage buffers are sized for (grow on overflow)
     uint64_t zeroed_tiles = 0;  // bitmap/tile_count tiles [0, zeroed_tiles) are zero unless dirty
     uint64_t dirty_tiles = 0;   // tiles [0, dirty_tiles) may hold hits of a call that never reached k_expand

@@ -519,6 +519,59 @@ __global__ __launch_bounds__(1024) void k_exclusive_scan(const uint32_t* __restr
     }
 }
 
+// Two-level form for the two scans on the scan pipeline's critical path: every workgroup scans its own
+// 8 Ki elements, a one-wave kernel scans the workgroup sums; consumers add seg_off[i >> 13] themselves.
+constexpr int kSegShift = 13, kSeg = 1 << kSegShift;   // 1024 lanes x 8 elements
+__global__ __launch_bounds__(1024) void k_scan_segments(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                       uint64_t n_max, const uint32_t* __restrict__ n_dev,
+                                                       uint32_t* __restrict__ seg_sum) {
+    __shared__ uint32_t wave_sum[16];
+    const uint32_t t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    uint64_t n = n_max;
+    if (n_dev) { const uint64_t v = *n_dev; n = v < n_max ? v : n_max; }
+    const uint64_t i0 = (uint64_t)blockIdx.x * kSeg + (uint64_t)t * 8;
+    uint32_t v[8];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { v[u] = i0 + u < n ? in[i0 + u] : 0u; sum += v[u]; }
+    uint32_t x = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d);
+        if (lane >= (uint32_t)d) x += y;
+    }
+    if (lane == 63) wave_sum[wid] = x;
+    __syncthreads();
+    uint32_t pre = 0, all = 0;
+    for (uint32_t w = 0; w < 16; ++w) { if (w < wid) pre += wave_sum[w]; all += wave_sum[w]; }
+    uint32_t run = pre + x - sum;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { if (i0 + u < n) out[i0 + u] = run; run += v[u]; }
+    if (t == 0) seg_sum[blockIdx.x] = all;
+}
+__global__ __launch_bounds__(64) void k_scan_top(const uint32_t* __restrict__ seg_sum, uint32_t* __restrict__ seg_off,
+                                                uint32_t n_seg, uint64_t* __restrict__ total_host,
+                                                uint32_t* __restrict__ total_dev) {
+    const uint32_t lane = threadIdx.x;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n_seg; base += 64) {
+        const uint32_t i = base + lane;
+        const uint32_t v = i < n_seg ? seg_sum[i] : 0u;
+        uint32_t x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d);
+            if (lane >= (uint32_t)d) x += y;
+        }
+        if (i < n_seg) seg_off[i] = carry + x - v;
+        carry += __shfl(x, 63);
+    }
+    if (lane == 0) {
+        if (total_host) *total_host = carry;
+        if (total_dev) *total_dev = carry;
+    }
+}
+
 // ------------------------------------------------------------- expand pass --
 // One WAVE per dense tile (four tiles per workgroup, no workgroup barrier): bitmap
 // bits -> Hit records in position order, and the tile's words/count are left zero.
@@ -551,7 +604,8 @@ __device__ __forceinline__ uint32_t mmer_at(const uint8_t* __restrict__ bases, u
 __global__ __launch_bounds__(kThreads) void k_expand(const uint8_t* __restrict__ bases, uint64_t n, uint32_t k,
                                                     uint32_t m, uint32_t* __restrict__ bitmap,
                                                     uint32_t* __restrict__ tile_count,
-                                                    const uint32_t* __restrict__ tile_off, uint64_t n_tiles,
+                                                    const uint32_t* __restrict__ tile_off,
+                                                    const uint32_t* __restrict__ seg_off, uint64_t n_tiles,
                                                     const uint64_t* __restrict__ rec_off, uint32_t n_rec,
                                                     Hit* __restrict__ hits, uint32_t hits_cap) {
     const uint32_t lane = threadIdx.x & 63;
@@ -573,7 +627,7 @@ __global__ __launch_bounds__(kThreads) void k_expand(const uint8_t* __restrict__
     }
     uint32_t cnt[2];
     uint32_t rank[2];
-    uint32_t run = tile_off[b];
+    uint32_t run = tile_off[b] + seg_off[b >> kSegShift];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         cnt[h] = __popc(q[h].x) + __popc(q[h].y) + __popc(q[h].z) + __popc(q[h].w);
@@ -733,7 +787,7 @@ template <bool WRITE>
 __global__ void k_resolve(const Hit* __restrict__ hits, const uint32_t* __restrict__ n_hits_dev, uint32_t hits_cap,
                           const uint64_t* __restrict__ rec_off, uint32_t k, uint32_t m,
                           uint32_t* __restrict__ emit_count, const uint32_t* __restrict__ emit_off,
-                          spsp_superkmer* __restrict__ out, uint32_t out_cap) {
+                          const uint32_t* __restrict__ seg_off, spsp_superkmer* __restrict__ out, uint32_t out_cap) {
     const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t n_hits = *n_hits_dev;
     if (n_hits > hits_cap) n_hits = hits_cap;   // overflowed: this pass is discarded by the host
@@ -760,7 +814,7 @@ __global__ void k_resolve(const Hit* __restrict__ hits, const uint32_t* __restri
     }
     const uint64_t r0 = rec_off[me.rec], r1 = rec_off[me.rec + 1];
     if (WRITE) {
-        const uint32_t at = emit_off[h];
+        const uint32_t at = emit_off[h] + seg_off[h >> kSegShift];
         run_cluster<true>(hits + h, cnt, r0, r1 - r0, k, m, me.rec, out + at, at < out_cap ? out_cap - at : 0u);
     } else {
         emit_count[h] = run_cluster<false>(hits + h, cnt, r0, r1 - r0, k, m, me.rec, nullptr, 0u);
@@ -893,9 +947,13 @@ static int launch_dense(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_ba
     if (n_tiles > ctx->dirty_tiles) ctx->dirty_tiles = n_tiles;   // until k_expand has consumed (and zeroed) them
     if (n_tiles > ctx->zeroed_tiles) ctx->zeroed_tiles = n_tiles; // ... after which this whole range is zero
     if ((rc = ctx->ev_end(kEvDense))) return rc;
-    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->tile_count.as<uint32_t>(),
-                       ctx->tile_off.as<uint32_t>(), n_tiles, (const uint32_t*)nullptr, ctx->h_scalar + 0,
-                       ctx->d_scalar.as<uint32_t>() + 0);
+    const uint32_t n_seg = (uint32_t)((n_tiles + kSeg - 1) / kSeg);
+    if ((rc = ctx->seg_a.reserve((size_t)n_seg * 8))) return rc;
+    hipLaunchKernelGGL(k_scan_segments, dim3(n_seg), dim3(1024), 0, ctx->stream, ctx->tile_count.as<uint32_t>(),
+                       ctx->tile_off.as<uint32_t>(), n_tiles, (const uint32_t*)nullptr, ctx->seg_a.as<uint32_t>());
+    SPSP_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(64), 0, ctx->stream, ctx->seg_a.as<uint32_t>(),
+                       ctx->seg_a.as<uint32_t>() + n_seg, n_seg, ctx->h_scalar + 0, ctx->d_scalar.as<uint32_t>() + 0);
     SPSP_HIP(hipGetLastError());
     return SPSP_OK;
 }
@@ -950,29 +1008,35 @@ static int scan_device_inner(spsp_ctx* ctx, const spsp_params* p, const uint8_t*
         if ((rc = ctx->emit_off.reserve((size_t)(hits_cap + 1) * 4))) return rc;
         if ((rc = ctx->scan_tmp.reserve((size_t)out_cap * sizeof(spsp_superkmer)))) return rc;
         const uint32_t rblocks = (hits_cap + 127) / 128;
+        const uint32_t n_seg_h = (hits_cap + kSeg - 1) / kSeg;
+        if ((rc = ctx->seg_b.reserve((size_t)n_seg_h * 8))) return rc;
         uint32_t* d_sc = nullptr;
         if (redo_dense) {
             if ((rc = launch_dense(ctx, p, d_bases, n_bases, n_tiles))) return rc;
             d_sc = ctx->d_scalar.as<uint32_t>();
+            const uint32_t n_seg_t = (uint32_t)((n_tiles + kSeg - 1) / kSeg);
             hipLaunchKernelGGL(k_expand, dim3((uint32_t)((n_tiles + kExpandTilesPerWg - 1) / kExpandTilesPerWg)),
                                dim3(kThreads), 0, ctx->stream, d_bases, n_bases, p->k, p->m, ctx->bitmap.as<uint32_t>(),
-                               ctx->tile_count.as<uint32_t>(), ctx->tile_off.as<uint32_t>(), n_tiles, d_rec_off, n_rec,
-                               ctx->hits.as<Hit>(), hits_cap);
+                               ctx->tile_count.as<uint32_t>(), ctx->tile_off.as<uint32_t>(),
+                               ctx->seg_a.as<uint32_t>() + n_seg_t, n_tiles, d_rec_off, n_rec, ctx->hits.as<Hit>(), hits_cap);
             SPSP_HIP(hipGetLastError());
             ctx->dirty_tiles = 0;   // k_expand leaves bitmap and tile counts zeroed
             hipLaunchKernelGGL(k_resolve<false>, dim3(rblocks), dim3(128), 0, ctx->stream, ctx->hits.as<Hit>(), d_sc + 0,
                                hits_cap, d_rec_off, p->k, p->m, ctx->emit_count.as<uint32_t>(),
-                               (const uint32_t*)nullptr, (spsp_superkmer*)nullptr, 0u);
+                               (const uint32_t*)nullptr, (const uint32_t*)nullptr, (spsp_superkmer*)nullptr, 0u);
             SPSP_HIP(hipGetLastError());
-            hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, ctx->stream, ctx->emit_count.as<uint32_t>(),
+            hipLaunchKernelGGL(k_scan_segments, dim3(n_seg_h), dim3(1024), 0, ctx->stream, ctx->emit_count.as<uint32_t>(),
                                ctx->emit_off.as<uint32_t>(), (uint64_t)hits_cap, (const uint32_t*)(d_sc + 0),
-                               ctx->h_scalar + 1, d_sc + 1);
+                               ctx->seg_b.as<uint32_t>());
+            SPSP_HIP(hipGetLastError());
+            hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(64), 0, ctx->stream, ctx->seg_b.as<uint32_t>(),
+                               ctx->seg_b.as<uint32_t>() + n_seg_h, n_seg_h, ctx->h_scalar + 1, d_sc + 1);
             SPSP_HIP(hipGetLastError());
         }
         d_sc = ctx->d_scalar.as<uint32_t>();
         hipLaunchKernelGGL(k_resolve<true>, dim3(rblocks), dim3(128), 0, ctx->stream, ctx->hits.as<Hit>(), d_sc + 0, hits_cap,
                            d_rec_off, p->k, p->m, (uint32_t*)nullptr, ctx->emit_off.as<uint32_t>(),
-                           ctx->scan_tmp.as<spsp_superkmer>(), out_cap);
+                           ctx->seg_b.as<uint32_t>() + n_seg_h, ctx->scan_tmp.as<spsp_superkmer>(), out_cap);
         SPSP_HIP(hipGetLastError());
         SPSP_HIP(hipStreamSynchronize(ctx->stream));
         const uint64_t n_hits = ctx->h_scalar[0], n_em = ctx->h_scalar[1];
