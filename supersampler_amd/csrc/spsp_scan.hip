@@ -620,10 +620,17 @@ __global__ __launch_bounds__(kThreads) void k_expand(const uint8_t* __restrict__
     // record holding the tile's first position: one wave-uniform binary search, the hits then
     // only step forward from it
     const uint64_t tile_pos = b * kTilePos;
+    // 64-ary search by the whole wave: each round the lanes probe 64 evenly spaced offsets and a ballot
+    // keeps the sub-range, so a few thousand records need two dependent loads instead of a dozen
     uint32_t rlo = 0, rhi = n_rec;              // invariant: rec_off[rlo] <= tile_pos < rec_off[rhi]
     while (rhi - rlo > 1) {
-        const uint32_t mid = (rlo + rhi) >> 1;
-        if (rec_off[mid] <= tile_pos) rlo = mid; else rhi = mid;
+        const uint32_t span = rhi - rlo, step = (span + 63) / 64;
+        const uint32_t probe = lane * step;
+        const bool below = probe < span && rec_off[rlo + probe] <= tile_pos;   // true for a prefix of the lanes (lane 0 always)
+        const uint32_t cnt = (uint32_t)__popcll(__ballot(below));
+        const uint32_t nlo = rlo + (cnt - 1) * step;
+        const uint32_t nhi = cnt * step < span ? rlo + cnt * step : rhi;
+        rlo = nlo; rhi = nhi;
     }
     uint32_t cnt[2];
     uint32_t rank[2];
