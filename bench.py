@@ -236,11 +236,25 @@ def cpu_baseline(recs, payloads, p):
         b, o = synth.concat_records([r])
         sec, km, _ = orc.scan_timed(K, M, p.threshold, b, o)
         spent += sec; kmers += km; used += 1
+    # the reference parallelises over FILES with OpenMP (SubSampler.cpp:771): same thing with host threads
+    # (ctypes releases the GIL), whole records as work items, bounded the same way
+    import concurrent.futures as cf
+    import os as _os
+    import time as _time
+    cores = max(1, len(_os.sched_getaffinity(0)))
+    items = [synth.concat_records([r]) for r in recs[:used]]
+    t0 = _time.perf_counter()
+    with cf.ThreadPoolExecutor(cores) as ex:
+        res = list(ex.map(lambda bo: orc.scan_timed(K, M, p.threshold, bo[0], bo[1]), items))
+    wall = _time.perf_counter() - t0
+    all_cores = {"value": sum(r[1] for r in res) / wall if wall > 0 else None, "cores": cores,
+                 "sample": "same records, one record per task over %d host threads, %.2f s wall" % (cores, wall)}
     n = len(payloads)
     _, _, csec = orc.compare(payloads, timed=True)  # the reference comparator is single-threaded too
     return {"value": kmers / spent if spent > 0 else None, "unit": "k-mers hashed/s", "cores": 1, "kind": "port",
             "sample": "oracle scan loop (SubSampler.cpp:357-455 restated), single thread, first %d of %d records "
                       "of the same workload, %.1f s" % (used, len(recs), spent),
+            "all_cores": all_cores,
             "sketch_pairs_per_s": (n * (n - 1) // 2) / csec if csec > 0 else None,
             "pairs_sample": "oracle compare_sketches (Comparator.cpp:39-287 restated) over the same %d sketches, "
                             "single thread, %.2f s" % (n, csec)}

@@ -44,12 +44,4 @@ __device__ __forceinline__ uint32_t rc_window32(uint32_t w) {
 // reverse complement of an m-mer held in the low 2m bits (reference rcbc, utils.cpp:449-462)
 __device__ __forceinline__ uint32_t rc_mmer32(uint32_t v, uint32_t m) { return rc_window32(v) >> (32 - 2 * m); }
 
-// reverse complement of a k-mer held in the low 2k bits of (hi:lo) (reference rcb, utils.cpp:397-438)
-__device__ __forceinline__ void rc_kmer128(uint64_t lo, uint64_t hi, uint32_t k, uint64_t* olo, uint64_t* ohi) {
-    const uint64_t nlo = rc_window64(hi), nhi = rc_window64(lo);  // full 128-bit reversal
-    const uint32_t s = 128 - 2 * k;                               // realign to the right, 2 <= s <= 126
-    if (s >= 64) { *olo = nhi >> (s - 64); *ohi = 0; }
-    else { *olo = (nlo >> s) | (nhi << (64 - s)); *ohi = nhi >> s; }
-}
-
 }  // namespace spsp
