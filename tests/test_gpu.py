@@ -417,6 +417,46 @@ def test_scan_buffer_overflow_retries():
         assert r.returncode == 0 and "ok" in r.stdout, (env_extra, r.stdout[-2000:], r.stderr[-2000:])
 
 
+def test_scan_across_the_4gib_seam(ctx):
+    """one call over > 2^32 bases: a 1 Mbp record that straddles position 2^32 and another one after it must
+    give the same super-k-mers as when scanned alone (queued survivor positions carry only their low 32 bits)."""
+    import ctypes
+    import torch
+    k, m, s = 31, 11, 100
+    rng = np.random.default_rng(99)
+    a = synth.random_genome(rng, 1_000_000)
+    b = synth.random_genome(rng, 300_000)
+    filler_len = (1 << 32) - 400_000
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev); gen.manual_seed(5)
+    acgt = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=dev)
+    total = filler_len + len(a) + len(b)
+    buf = torch.empty(total + 64, dtype=torch.uint8, device=dev)
+    step = 1 << 28
+    for off in range(0, filler_len, step):
+        n = min(step, filler_len - off)
+        buf[off:off + n] = acgt[torch.randint(0, 4, (n,), device=dev, generator=gen).to(torch.int64)]
+    buf[filler_len:filler_len + len(a)] = torch.from_numpy(a).to(dev)
+    buf[filler_len + len(a):total] = torch.from_numpy(b).to(dev)
+    rec_off = np.array([0, filler_len, filler_len + len(a), total], dtype=np.uint64)
+    d_off = torch.from_numpy(rec_off.view(np.int64)).to(dev)
+    torch.cuda.synchronize()
+    for mode in (sp.SPSP_SCAN_DEFAULT, sp.SPSP_SCAN_LDS_FILTER):
+        p = sp.make_params(k, m, s, flags=mode)
+        d_out, n_out = ctx.scan_device(p, buf.data_ptr(), total, d_off.data_ptr(), 3)
+        got = np.zeros(n_out, dtype=sp.SUPERKMER_DTYPE)
+        hip = ctypes.CDLL("libamdhip64.so")
+        assert hip.hipMemcpy(ctypes.c_void_p(got.ctypes.data), ctypes.c_void_p(d_out), ctypes.c_size_t(got.nbytes), 2) == 0
+        assert (np.diff(got["rec"].astype(np.int64)) >= 0).all()
+        for r, g in ((1, a), (2, b)):
+            want, _ = orc.scan(k, m, p.threshold, *synth.concat_records([g]))
+            mine = got[got["rec"] == r]
+            assert len(mine) == len(want) > 100
+            for f in ("minimizer", "start", "len", "rev"):
+                assert (mine[f] == want[f]).all(), (mode, r, f)
+    del buf
+
+
 # ----------------------------------------------------------------- full size --
 def _np_xxh64(x):
     """vectorised XXH64 of uint64 words, seed 1312 (first principles, not the oracle)."""
