@@ -418,8 +418,18 @@ __global__ __launch_bounds__(64 * kPairWaves) void k_dense_single(const uint8_t*
     const uint32_t mm = (1u << (2 * m)) - 1u;
     const uint64_t gw = (uint64_t)blockIdx.x * kPairWaves + wave, n_waves = (uint64_t)gridDim.x * kPairWaves;
     uint32_t qn = 0, qhigh = 0;
+    // inlined on purpose (unlike k_dense_pair's): at survivor rates of 5-20 % a row drains several times, and a
+    // real call would spill the caller's live registers every time; the plane loop below is not unrolled, so
+    // the hash body exists once per call site of handle()
     auto drain = [&](uint32_t keep_below) {
-        qn = drain_queue(queue, qn, keep_below, qhigh, n_mmers, m, thr, bitmap, tile_count);
+        while (qn >= keep_below && qn > 0) {
+            const uint32_t take = qn < 64 ? qn : 64;
+            if (lane < take) {
+                const uint2 e = queue[qn - take + lane];
+                verify_candidate(n_mmers, m, thr, ((uint64_t)qhigh << 32) | e.x, e.y, bitmap, tile_count);
+            }
+            qn -= take;
+        }
     };
     // queue one row's survivors, one bit-plane (= one position offset) at a time
     auto handle = [&](uint32_t cand, uint64_t p0, uint32_t hi, uint32_t nxt) {
