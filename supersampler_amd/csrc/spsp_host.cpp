@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <thread>
 #include <vector>
@@ -515,31 +516,55 @@ int spsp_sketch_parse_host(const uint8_t* payload, uint64_t len, uint32_t* k_out
 int spsp_csv_host(int jaccard, const char* const* names, uint32_t n, uint32_t n_query, const uint32_t* inter,
                   const uint64_t* card, int precision, double min_threshold, char** text, uint64_t* len) {
     if (!text || !len || (n && (!names || !inter || !card))) { set_error("NULL argument"); return SPSP_ERR_ARG; }
-    std::string out;
-    for (uint32_t i = 0; i < n; ++i) { out += names[i]; out += (i + 1 != n) ? ',' : '\n'; }
-    if (!jaccard) out += '\n';
-    char num[64];
-    for (uint32_t i = 0; i < n && i < n_query; ++i) {
-        for (uint32_t j = 0; j < n; ++j) {
-            if (i == j) out += '1';
-            else {
-                const uint32_t a = i < j ? i : j, b = i < j ? j : i;
-                const uint32_t sc = inter[(uint64_t)a * n + b];
-                if (sc == 0) out += '0';
+    std::string head;
+    for (uint32_t i = 0; i < n; ++i) { head += names[i]; head += (i + 1 != n) ? ',' : '\n'; }
+    if (!jaccard) head += '\n';
+    // rows are independent: formatted by a few host threads (row blocks), concatenated in order ("next" row N3)
+    const uint32_t rows = n < n_query ? n : n_query;
+    auto format_rows = [&](uint32_t r0, uint32_t r1, std::string& out) {
+        char num[64];
+        out.reserve((size_t)(r1 - r0) * n * 4);
+        for (uint32_t i = r0; i < r1; ++i) {
+            for (uint32_t j = 0; j < n; ++j) {
+                if (i == j) out += '1';
                 else {
-                    const double score = jaccard ? (double)sc / (double)(card[i] + card[j] - sc) : (double)sc / (double)card[i];
-                    if (score < min_threshold) out += '0';
-                    else { const int l = snprintf(num, sizeof num, "%.*g", precision, score); out.append(num, l); }
+                    const uint32_t a = i < j ? i : j, b = i < j ? j : i;
+                    const uint32_t sc = inter[(uint64_t)a * n + b];
+                    if (sc == 0) out += '0';
+                    else {
+                        const double score = jaccard ? (double)sc / (double)(card[i] + card[j] - sc) : (double)sc / (double)card[i];
+                        if (score < min_threshold) out += '0';
+                        else { const int l = snprintf(num, sizeof num, "%.*g", precision, score); out.append(num, l); }
+                    }
                 }
+                out += (j + 1 != n) ? ',' : '\n';
             }
-            out += (j + 1 != n) ? ',' : '\n';
         }
+    };
+    unsigned workers = std::thread::hardware_concurrency();
+    if (workers == 0) workers = 1;
+    if (workers > 16) workers = 16;
+    if ((uint64_t)rows * n < (1u << 18)) workers = 1;          // small matrices: not worth a thread
+    if (workers > rows) workers = rows ? rows : 1;
+    std::vector<std::string> parts(workers);
+    {
+        std::vector<std::thread> pool;
+        for (unsigned w = 0; w < workers; ++w) {
+            const uint32_t r0 = (uint32_t)((uint64_t)rows * w / workers), r1 = (uint32_t)((uint64_t)rows * (w + 1) / workers);
+            if (w + 1 == workers) format_rows(r0, r1, parts[w]);
+            else pool.emplace_back(format_rows, r0, r1, std::ref(parts[w]));
+        }
+        for (auto& th : pool) th.join();
     }
-    *text = (char*)malloc(out.size() + 1);
+    size_t total = head.size();
+    for (auto& p2 : parts) total += p2.size();
+    *text = (char*)malloc(total + 1);
     if (!*text) { set_error("out of host memory"); return SPSP_ERR_NOMEM; }
-    memcpy(*text, out.data(), out.size());
-    (*text)[out.size()] = 0;
-    *len = out.size();
+    size_t at = 0;
+    memcpy(*text, head.data(), head.size()); at += head.size();
+    for (auto& p2 : parts) { memcpy(*text + at, p2.data(), p2.size()); at += p2.size(); }
+    (*text)[total] = 0;
+    *len = total;
     return SPSP_OK;
 }
 
@@ -582,33 +607,57 @@ int spsp_read_file_host(const char* path, uint8_t** data, uint64_t* len) {
 }
 
 // zstr::ofstream(filename, expbuffer, level) -> gzip container (zstr.hpp:78-82)
+static int deflate_member(const uint8_t* data, uint64_t len, int level, std::vector<uint8_t>& out) {
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (deflateInit2(&zs, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return SPSP_ERR_IO;
+    out.resize(deflateBound(&zs, (uLong)len) + 64);
+    zs.next_in = const_cast<Bytef*>(data);
+    zs.avail_in = (uInt)len;
+    zs.next_out = out.data();
+    zs.avail_out = (uInt)out.size();
+    const int ret = deflate(&zs, Z_FINISH);
+    const size_t have = out.size() - zs.avail_out;
+    deflateEnd(&zs);
+    if (ret != Z_STREAM_END) return SPSP_ERR_IO;
+    out.resize(have);
+    return SPSP_OK;
+}
+
 int spsp_write_gz_host(const char* path, const uint8_t* data, uint64_t len, int level) {
     if (!path || (len && !data)) { set_error("NULL argument"); return SPSP_ERR_ARG; }
     FILE* f = fopen(path, "wb");
     if (!f) { set_error("cannot create '%s'", path); return SPSP_ERR_IO; }
-    z_stream zs;
-    memset(&zs, 0, sizeof zs);
-    if (deflateInit2(&zs, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) { fclose(f); set_error("deflateInit2 failed"); return SPSP_ERR_IO; }
-    std::vector<uint8_t> chunk(1 << 20);
-    uint64_t at = 0;
-    int ret = Z_OK;
-    do {
-        const uint64_t take = std::min<uint64_t>(len - at, 1u << 30);
-        zs.next_in = const_cast<Bytef*>(data + at);
-        zs.avail_in = (uInt)take;
-        at += take;
-        const int flush = at >= len ? Z_FINISH : Z_NO_FLUSH;
-        do {
-            zs.next_out = chunk.data();
-            zs.avail_out = (uInt)chunk.size();
-            ret = deflate(&zs, flush);
-            const size_t have = chunk.size() - zs.avail_out;
-            if (have && fwrite(chunk.data(), 1, have, f) != have) { deflateEnd(&zs); fclose(f); set_error("short write to '%s'", path); return SPSP_ERR_IO; }
-        } while (zs.avail_out == 0);
-    } while (ret != Z_STREAM_END);
-    deflateEnd(&zs);
-    if (fclose(f) != 0) { set_error("close failed for '%s'", path); return SPSP_ERR_IO; }
-    return SPSP_OK;
+    // One gzip member per 16 MiB of payload.  Small outputs (every sketch) are a single member, exactly what
+    // zstr::ofstream writes; large CSVs are compressed member by member on a few threads -- a valid gzip file
+    // that zstr / zlib / gunzip read back as one stream (zstr.hpp:198-203 restarts the inflator per member).
+    const uint64_t chunk = 16ull << 20;
+    const uint64_t n_chunks = len ? (len + chunk - 1) / chunk : 1;
+    unsigned workers = std::thread::hardware_concurrency();
+    if (workers == 0) workers = 1;
+    if (workers > 16) workers = 16;
+    if (workers > n_chunks) workers = (unsigned)n_chunks;
+    int rc = SPSP_OK;
+    for (uint64_t c0 = 0; c0 < n_chunks && !rc; c0 += workers) {
+        const unsigned batch = (unsigned)std::min<uint64_t>(workers, n_chunks - c0);
+        std::vector<std::vector<uint8_t>> outs(batch);
+        std::vector<int> rcs(batch, SPSP_OK);
+        std::vector<std::thread> pool;
+        auto job = [&](unsigned b) {
+            const uint64_t off = (c0 + b) * chunk;
+            const uint64_t take = len > off ? std::min<uint64_t>(chunk, len - off) : 0;
+            rcs[b] = deflate_member(data + off, take, level, outs[b]);
+        };
+        for (unsigned b = 1; b < batch; ++b) pool.emplace_back(job, b);
+        job(0);
+        for (auto& th : pool) th.join();
+        for (unsigned b = 0; b < batch && !rc; ++b) {
+            if (rcs[b]) { set_error("deflate failed"); rc = rcs[b]; break; }
+            if (fwrite(outs[b].data(), 1, outs[b].size(), f) != outs[b].size()) { set_error("short write to '%s'", path); rc = SPSP_ERR_IO; }
+        }
+    }
+    if (fclose(f) != 0 && !rc) { set_error("close failed for '%s'", path); rc = SPSP_ERR_IO; }
+    return rc;
 }
 
 int spsp_sketch_file(spsp_ctx* ctx, const spsp_params* p, double rate, const char* fasta_path, const char* out_path,

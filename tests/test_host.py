@@ -159,6 +159,18 @@ def test_csv_matches_oracle(prec, thr):
             assert sp.csv(jac, names, inter, card, nq, prec, thr) == orc.csv(jac, names, inter, card, nq, prec, thr)
 
 
+def test_csv_large_matrix_threaded_rows_match_oracle():
+    rng = np.random.default_rng(3)
+    n = 700                                           # 490 000 cells: formatted by several threads
+    card = rng.integers(1000, 9000, size=n).astype(np.uint64)
+    inter = np.triu(rng.integers(0, 1000, size=(n, n)), 1).astype(np.uint32)
+    inter[rng.random((n, n)) < 0.5] = 0
+    names = ["s%d" % i for i in range(n)]
+    for jac in (True, False):
+        assert sp.csv(jac, names, inter, card, n, 6, 0.0) == orc.csv(jac, names, inter, card, n, 6, 0.0)
+        assert sp.csv(jac, names, inter, card, 10, 3, 0.05) == orc.csv(jac, names, inter, card, 10, 3, 0.05)
+
+
 def test_gz_io_roundtrip(tmp_path):
     data = os.urandom(1000) + b"ACGT" * 100000
     p = str(tmp_path / "x.gz")
@@ -173,6 +185,10 @@ def test_gz_io_roundtrip(tmp_path):
         f.write(gzip.compress(b"hello "))
         f.write(gzip.compress(b"world"))
     assert sp.read_file(r) == b"hello world"
+    big = os.urandom(1 << 16) * 600                  # 37.5 MiB -> three 16 MiB members, compressed on threads
+    b = str(tmp_path / "big.gz")
+    sp.write_gz(b, big, 1)
+    assert gzip.open(b, "rb").read() == big and sp.read_file(b) == big
     e = str(tmp_path / "empty")
     open(e, "wb").close()
     assert sp.read_file(e) == b""
