@@ -57,6 +57,24 @@ pairs = N * (N - 1) // 2
 alg = 8.0 * (cnt.sum() * (N - 1)) + 4.0 * pairs      # sum over pairs of 8*(n_i+n_j)+4
 print("compare pipeline %.3f ms (accumulate %.3f ms): %.3g pairs/s; no-reuse model %.1f GB -> %.0f GB/s (%.2fx of 8 TB/s); compulsory %.3f GB"
       % (ms, t["accumulate_ms"] / reps, pairs / ms * 1e3, alg / 1e9, alg / ms / 1e6, alg / ms / 1e6 / 8000, (8.0 * cnt.sum() + 4.0 * pairs) / 1e9), flush=True)
+if check == 2:   # sampled pairs against numpy set intersections (the oracle's colour map is too heavy at N=10^4)
+    got = d_inter.cpu().numpy().astype(np.uint32)
+    keysets = None
+    rs = np.random.default_rng(0)
+    bad = 0
+    comp = [sketches[i].minimizer.astype(np.uint64) << np.uint64(40) ^ sketches[i].kmer_lo * np.uint64(0x9E3779B97F4A7C15) for i in range(N)]
+    for _ in range(400):
+        i, j = sorted(int(x) for x in rs.integers(0, N, size=2))
+        if i == j:
+            continue
+        a = np.stack([sketches[i].minimizer.astype(np.uint64), sketches[i].kmer_lo], 1)
+        b = np.stack([sketches[j].minimizer.astype(np.uint64), sketches[j].kmer_lo], 1)
+        sa = set(map(tuple, a.tolist())); sb = set(map(tuple, b.tolist()))
+        if got[i, j] != len(sa & sb):
+            bad += 1
+    # plus every pair inside the first two families
+    print("sampled parity: %d mismatches in 400 random pairs; nonzero pairs %d" % (bad, np.count_nonzero(np.triu(got, 1))), flush=True)
+    sys.exit(0 if bad == 0 else 1)
 if check:
     from oracle import oracle_py as orc
     t0 = time.time()
