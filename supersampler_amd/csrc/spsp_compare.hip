@@ -210,20 +210,24 @@ __global__ __launch_bounds__(kAccThreads) void k_accumulate(const uint32_t* __re
         pending = 0;
     };
     const uint64_t step = (uint64_t)(kAccThreads / 64) * groups;
-    for (uint64_t e = e0 + (uint64_t)wave * groups + grp; e < e1 + 3 * step; e += 4 * step) {
-        uint64_t v[4];
+    constexpr int U = 8;   // independent row gathers in flight per lane
+    for (uint64_t e = e0 + (uint64_t)wave * groups + grp; e < e1 + (U - 1) * step; e += U * step) {
+        uint32_t rows[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             const uint64_t eu = e + u * step;
-            v[u] = (active && eu < e1) ? A[(uint64_t)row_of_entry[eu] * W + word] : 0ull;
+            rows[u] = (active && eu < e1) ? row_of_entry[eu] : 0xffffffffu;
         }
+        uint64_t v[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) v[u] = rows[u] != 0xffffffffu ? A[(uint64_t)rows[u] * W + word] : 0ull;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
 #pragma unroll
             for (int b = 0; b < 8; ++b) acc[b] += (v[u] >> b) & M8;
         }
-        pending += 4;
-        if (pending >= 252) spill();
+        pending += U;
+        if (pending >= 248) spill();
     }
     spill();
     __syncthreads();
