@@ -127,12 +127,14 @@ int spsp_scan_hits_device(spsp_ctx* ctx, const spsp_params* p, const void* d_bas
 /* ------------------------------------------------------------- path B ---- */
 /* Replaces Comparator::count_intersection / skip_bucket / compute_scores
  * (Comparator.cpp:97-287): inter is n*n, entry [a*n+b] for a<b =
- * sum over buckets |A_a,b ∩ A_b,b| (zero elsewhere); card[i] = nb_kmer_seen_infile[i]. */
+ * sum over buckets |A_a,b ∩ A_b,b| (zero elsewhere); card[i] = nb_kmer_seen_infile[i].
+ * Query mode (n_query < n, the sketches of the -q file first): only rows a < n_query are computed --
+ * the rows print_jaccard / print_containment emit (Comparator.cpp:374,423); other rows stay zero. */
 int spsp_compare(spsp_ctx* ctx, const spsp_sketch_view* sk, uint32_t n, uint32_t n_query,
                  uint32_t* inter, uint64_t* card);
 
 /* Device-resident form over concatenated key arrays (sketch i owns entries
- * [d_sk_off[i], d_sk_off[i+1]) ). Only rows i with i % row_stride == row_first
+ * [d_sk_off[i], d_sk_off[i+1]) ). Only rows i < n_query with i % row_stride == row_first
  * are computed (the multi-GPU split of SURVEY.md 8e: every rank holds all
  * sketches after the all-gather and owns a strided set of rows). d_inter is a
  * dense n*n uint32 matrix; cells (i, j > i) of owned rows are overwritten, everything else is left
@@ -140,7 +142,8 @@ int spsp_compare(spsp_ctx* ctx, const spsp_sketch_view* sk, uint32_t n, uint32_t
  * drained. */
 int spsp_compare_device(spsp_ctx* ctx, uint32_t k, const void* d_minimizer, const void* d_kmer_lo,
                         const void* d_kmer_hi /* NULL if k<=32 */, const uint64_t* h_sk_off,
-                        uint32_t n, uint32_t row_first, uint32_t row_stride, void* d_inter);
+                        uint32_t n, uint32_t n_query /* = n for all-vs-all */, uint32_t row_first,
+                        uint32_t row_stride, void* d_inter);
 
 /* --------------------------------------------- host side of the two CLIs -- */
 /* getLineFasta + clean_dna (utils.cpp:675-718) over an already gunzipped

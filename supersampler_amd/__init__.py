@@ -87,7 +87,7 @@ def lib():
     L.spsp_scan_hits_device.argtypes = [vp, P(Params), vp, u64, P(u64)]
     L.spsp_compare.restype = i32; L.spsp_compare.argtypes = [vp, P(SketchView), u32, u32, vp, vp]
     L.spsp_compare_device.restype = i32
-    L.spsp_compare_device.argtypes = [vp, u32, vp, vp, vp, vp, u32, u32, u32, vp]
+    L.spsp_compare_device.argtypes = [vp, u32, vp, vp, vp, vp, u32, u32, u32, u32, vp]
     L.spsp_fasta_clean_host.restype = i32
     L.spsp_fasta_clean_host.argtypes = [cp, u64, P(vp), P(vp), P(u32)]
     L.spsp_fasta_clean_device.restype = i32
@@ -305,10 +305,10 @@ class Context:
         _check(lib().spsp_compare(self._h, views, n, nq, inter.ctypes.data, card.ctypes.data))
         return inter, card
 
-    def compare_device(self, k, d_min, d_lo, d_hi, sk_off, n, row_first, row_stride, d_inter):
+    def compare_device(self, k, d_min, d_lo, d_hi, sk_off, n, row_first, row_stride, d_inter, n_query=None):
         sk_off = np.ascontiguousarray(sk_off, dtype=np.uint64)
-        _check(lib().spsp_compare_device(self._h, k, d_min, d_lo, d_hi, sk_off.ctypes.data, n, row_first, row_stride,
-                                         d_inter))
+        _check(lib().spsp_compare_device(self._h, k, d_min, d_lo, d_hi, sk_off.ctypes.data, n,
+                                         n if n_query is None else n_query, row_first, row_stride, d_inter))
 
     def compare_files(self, paths, out_prefix, n_query=None, precision=6, min_threshold=0.0):
         n = len(paths)

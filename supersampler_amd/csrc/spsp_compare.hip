@@ -75,14 +75,14 @@ __device__ __forceinline__ uint32_t sketch_of(const uint64_t* __restrict__ sk_of
 
 // flags[0]: input not strictly sorted inside a sketch; flags[1]: fingerprint collision
 __global__ void k_insert(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n, uint64_t S, uint32_t row_first,
-                         uint32_t row_stride, uint64_t seed, uint64_t* __restrict__ table, uint32_t log2cap,
+                         uint32_t row_stride, uint32_t row_limit, uint64_t seed, uint64_t* __restrict__ table, uint32_t log2cap,
                          uint32_t* __restrict__ owner, uint32_t* __restrict__ slot, uint32_t* __restrict__ flags) {
     // grid.y = sketch, grid.x = 256-key chunk of it (no per-entry search for the owning sketch)
     const uint32_t j = blockIdx.y;
     const uint64_t e = sk_off[j] + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= sk_off[j + 1]) return;
     if (e > sk_off[j] && !key_less(K, e - 1, e)) atomicOr(&flags[0], 1u);
-    if (j % row_stride != row_first) return;
+    if (j % row_stride != row_first || j >= row_limit) return;   // not an owned (and printed) row
     const uint64_t fp = fingerprint(K, e, seed);
     const uint64_t mask = (1ull << log2cap) - 1;
     uint64_t pos = home_slot(fp, log2cap);
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kRowThreads) void k_assign_rows(const uint64_t* __r
 // Colours: every entry of every sketch looks its key up; found => set bit j of
 // the key's row, and (for owned sketches) remember the row for the accumulation.
 __global__ void k_fill(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n, uint64_t S, uint32_t row_first,
-                       uint32_t row_stride, uint64_t seed, const uint64_t* __restrict__ table, uint32_t log2cap,
+                       uint32_t row_stride, uint32_t row_limit, uint64_t seed, const uint64_t* __restrict__ table, uint32_t log2cap,
                        const uint32_t* __restrict__ owner, const uint32_t* __restrict__ rowid, uint32_t W,
                        unsigned long long* __restrict__ A, uint32_t* __restrict__ row_of_entry,
                        uint32_t* __restrict__ flags) {
@@ -147,7 +147,7 @@ __global__ void k_fill(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n, 
         const uint64_t v = table[pos];
         if (v == 0) return;  // key not held by any owned sketch: contributes to no owned row
         if (v == fp) {
-            const bool own = j % row_stride == row_first;
+            const bool own = j % row_stride == row_first && j < row_limit;
             if (key_eq(K, owner[pos], e)) {
                 const uint32_t r = rowid[pos];
                 atomicOr(&A[(uint64_t)r * W + (j >> 6)], 1ull << (j & 63));
@@ -177,10 +177,10 @@ __global__ __launch_bounds__(kAccThreads) void k_accumulate(const uint32_t* __re
                                                            const uint64_t* __restrict__ A, uint32_t W,
                                                            uint32_t lanes_per_key,
                                                            const uint64_t* __restrict__ sk_off, uint32_t n,
-                                                           uint32_t row_first, uint32_t row_stride,
+                                                           uint32_t row_first, uint32_t row_stride, uint32_t row_limit,
                                                            uint32_t* __restrict__ inter) {
     const uint32_t i = row_first + blockIdx.y * row_stride;
-    if (i >= n) return;
+    if (i >= n || i >= row_limit) return;
     const uint32_t wb = blockIdx.x;                         // block of 64 words
     const uint32_t first_wd = (i + 1) >> 6;                 // first word holding a column > i
     if (wb * 64 + 63 < first_wd) return;
@@ -243,8 +243,8 @@ __global__ __launch_bounds__(kAccThreads) void k_accumulate(const uint32_t* __re
 }
 
 static int compare_device_inner(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min, const uint64_t* d_lo,
-                                const uint64_t* d_hi, const uint64_t* h_sk_off, uint32_t n, uint32_t row_first,
-                                uint32_t row_stride, uint32_t* d_inter) {
+                                const uint64_t* d_hi, const uint64_t* h_sk_off, uint32_t n, uint32_t row_limit,
+                                uint32_t row_first, uint32_t row_stride, uint32_t* d_inter) {
     if (n == 0) return SPSP_OK;
     if (n > 65535) { set_error("at most 65535 sketches (the reference's uint32 pair key, Comparator.h:26)"); return SPSP_ERR_ARG; }
     if (row_stride == 0 || row_first >= row_stride) { set_error("bad row partition %u/%u", row_first, row_stride); return SPSP_ERR_ARG; }
@@ -254,7 +254,8 @@ static int compare_device_inner(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min
     if (S > 0xfffffff0ull) { set_error("too many sketch k-mers for one call"); return SPSP_ERR_OVERFLOW; }
     uint64_t S_own = 0;
     uint32_t n_own = 0;
-    for (uint32_t i = row_first; i < n; i += row_stride) { S_own += h_sk_off[i + 1] - h_sk_off[i]; ++n_own; }
+    if (row_limit > n) row_limit = n;
+    for (uint32_t i = row_first; i < row_limit; i += row_stride) { S_own += h_sk_off[i + 1] - h_sk_off[i]; ++n_own; }
     if (S_own == 0 || n_own == 0) return SPSP_OK;
     int rc;
     uint32_t log2cap = 10;
@@ -277,7 +278,7 @@ static int compare_device_inner(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min
     for (uint32_t i = 0; i < n; ++i) {
         const uint64_t c = h_sk_off[i + 1] - h_sk_off[i];
         max_all = std::max(max_all, c);
-        if (i % row_stride == row_first) max_own = std::max(max_own, c);
+        if (i % row_stride == row_first && i < row_limit) max_own = std::max(max_own, c);
     }
     const dim3 grid_all((uint32_t)((max_all + 255) / 256), n);
     (void)max_own;
@@ -289,7 +290,7 @@ static int compare_device_inner(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min
     auto front = [&](uint64_t seed) -> int {
         SPSP_HIP(hipMemsetAsync(ctx->c_table.p, 0, (size_t)cap * 8, ctx->stream));
         SPSP_HIP(hipMemsetAsync(flags, 0, 64, ctx->stream));
-        hipLaunchKernelGGL(k_insert, grid_all, dim3(256), 0, ctx->stream, K, sk, n, S, row_first, row_stride, seed,
+        hipLaunchKernelGGL(k_insert, grid_all, dim3(256), 0, ctx->stream, K, sk, n, S, row_first, row_stride, row_limit, seed,
                            ctx->c_table.as<uint64_t>(), log2cap, ctx->c_owner.as<uint32_t>(),
                            ctx->c_slot.as<uint32_t>(), flags);
         SPSP_HIP(hipGetLastError());
@@ -303,14 +304,14 @@ static int compare_device_inner(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min
         int r2;
         if ((r2 = ctx->c_matrix.reserve((size_t)rows * W * 8))) return r2;
         SPSP_HIP(hipMemsetAsync(ctx->c_matrix.p, 0, (size_t)rows * W * 8, ctx->stream));
-        hipLaunchKernelGGL(k_fill, grid_all, dim3(256), 0, ctx->stream, K, sk, n, S, row_first, row_stride, seed,
+        hipLaunchKernelGGL(k_fill, grid_all, dim3(256), 0, ctx->stream, K, sk, n, S, row_first, row_stride, row_limit, seed,
                            ctx->c_table.as<uint64_t>(), log2cap, ctx->c_owner.as<uint32_t>(), ctx->c_rowid.as<uint32_t>(),
                            W, ctx->c_matrix.as<unsigned long long>(), ctx->c_row.as<uint32_t>(), flags);
         SPSP_HIP(hipGetLastError());
         if ((r2 = ctx->ev_begin(kEvAccumulate))) return r2;
         hipLaunchKernelGGL(k_accumulate, dim3((W + 63) / 64, n_own), dim3(kAccThreads), 0, ctx->stream,
                            ctx->c_row.as<uint32_t>(), ctx->c_matrix.as<uint64_t>(), W, lanes_per_key, sk, n, row_first,
-                           row_stride, d_inter);
+                           row_stride, row_limit, d_inter);
         SPSP_HIP(hipGetLastError());
         return ctx->ev_end(kEvAccumulate);
     };
@@ -342,11 +343,11 @@ static int compare_device_inner(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min
 }
 
 int compare_device_impl(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min, const uint64_t* d_lo,
-                        const uint64_t* d_hi, const uint64_t* h_sk_off, uint32_t n, uint32_t row_first,
+                        const uint64_t* d_hi, const uint64_t* h_sk_off, uint32_t n, uint32_t row_limit, uint32_t row_first,
                         uint32_t row_stride, uint32_t* d_inter) {
     int rc = ctx->ev_begin(kEvCompare);
     if (rc) return rc;
-    rc = compare_device_inner(ctx, k, d_min, d_lo, d_hi, h_sk_off, n, row_first, row_stride, d_inter);
+    rc = compare_device_inner(ctx, k, d_min, d_lo, d_hi, h_sk_off, n, row_limit, row_first, row_stride, d_inter);
     const int rc2 = ctx->ev_end(kEvCompare);
     return rc ? rc : rc2;
 }
@@ -358,18 +359,17 @@ using namespace spsp;
 extern "C" {
 
 int spsp_compare_device(spsp_ctx* ctx, uint32_t k, const void* d_minimizer, const void* d_kmer_lo,
-                        const void* d_kmer_hi, const uint64_t* h_sk_off, uint32_t n, uint32_t row_first,
+                        const void* d_kmer_hi, const uint64_t* h_sk_off, uint32_t n, uint32_t n_query, uint32_t row_first,
                         uint32_t row_stride, void* d_inter) {
     if (!ctx || !h_sk_off || !d_inter) { set_error("NULL argument"); return SPSP_ERR_ARG; }
     SPSP_HIP(hipSetDevice(ctx->device));
     return compare_device_impl(ctx, k, (const uint32_t*)d_minimizer, (const uint64_t*)d_kmer_lo,
-                               (const uint64_t*)d_kmer_hi, h_sk_off, n, row_first, row_stride, (uint32_t*)d_inter);
+                               (const uint64_t*)d_kmer_hi, h_sk_off, n, n_query, row_first, row_stride, (uint32_t*)d_inter);
 }
 
 int spsp_compare(spsp_ctx* ctx, const spsp_sketch_view* sk, uint32_t n, uint32_t n_query, uint32_t* inter,
                  uint64_t* card) {
     if (!ctx || (n && (!sk || !inter || !card))) { set_error("NULL argument"); return SPSP_ERR_ARG; }
-    (void)n_query;  // rows of non-query sketches are simply never printed; counts are identical
     if (n == 0) return SPSP_OK;
     SPSP_HIP(hipSetDevice(ctx->device));
     std::vector<uint64_t> off(n + 1, 0);
@@ -398,7 +398,7 @@ int spsp_compare(spsp_ctx* ctx, const spsp_sketch_view* sk, uint32_t n, uint32_t
     }
     SPSP_HIP(hipMemsetAsync(ctx->c_inter.p, 0, (size_t)n * n * 4, ctx->stream));
     rc = compare_device_impl(ctx, need_hi ? 63 : 31, ctx->c_min.as<uint32_t>(), ctx->c_lo.as<uint64_t>(),
-                             need_hi ? ctx->c_hi.as<uint64_t>() : nullptr, off.data(), n, 0, 1, ctx->c_inter.as<uint32_t>());
+                             need_hi ? ctx->c_hi.as<uint64_t>() : nullptr, off.data(), n, n_query, 0, 1, ctx->c_inter.as<uint32_t>());
     if (rc) return rc;
     SPSP_HIP(hipMemcpyAsync(inter, ctx->c_inter.p, (size_t)n * n * 4, hipMemcpyDeviceToHost, ctx->stream));
     SPSP_HIP(hipStreamSynchronize(ctx->stream));

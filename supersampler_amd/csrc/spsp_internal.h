@@ -93,7 +93,7 @@ int scan_hits_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, 
                    uint64_t* n_hits);
 // compare pipeline (spsp_compare.hip)
 int compare_device_impl(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min, const uint64_t* d_lo,
-                        const uint64_t* d_hi, const uint64_t* h_sk_off, uint32_t n, uint32_t row_first,
+                        const uint64_t* d_hi, const uint64_t* h_sk_off, uint32_t n, uint32_t row_limit, uint32_t row_first,
                         uint32_t row_stride, uint32_t* d_inter);
 int check_params(const spsp_params* p);
 // ingest (spsp_ingest.hip)

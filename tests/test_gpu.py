@@ -165,6 +165,22 @@ def test_compare_equals_oracle(ctx, k, m, s):
     assert want_inter.sum() > 0 and card[n - 1] == 0
 
 
+def test_compare_query_mode_rows_only(ctx):
+    """-q mode: only the query rows (the ones the printers emit) are computed, and they equal the reference's."""
+    k, m, s = 31, 11, 30
+    gs = synth.family_genomes(8, 12, 30_000, 2, [0.0, 0.01, 0.03])
+    payloads = [orc.sketch_fasta(synth.to_fasta(g, "g%d" % i), k, m, s)[0] for i, g in enumerate(gs)]
+    nq = 3
+    want, wcard, _, _ = orc.compare(payloads, n_query=nq)
+    inter, card = ctx.compare([sp.sketch_parse(p) for p in payloads], n_query=nq)
+    assert (card == wcard).all()
+    assert (inter[:nq] == want[:nq]).all() and want[:nq].sum() > 0
+    assert (inter[nq:] == 0).all()
+    names = ["s%d" % i for i in range(len(gs))]
+    for jac in (True, False):
+        assert sp.csv(jac, names, inter, card, nq) == orc.csv(jac, names, want, wcard, nq)
+
+
 def test_compare_many_sketches_multiword_columns(ctx):
     """N > 64 so the colour matrix has several words per row and the triangle
     skips leading words."""
