@@ -81,6 +81,8 @@ void spsp_destroy(spsp_ctx* ctx);
 const char* spsp_last_error(void);
 const char* spsp_version(void);
 void spsp_free(void* host_ptr);
+/* copy `bytes` from a device buffer returned by this library to host memory, on the context's stream, and wait */
+int spsp_copy_to_host(spsp_ctx* ctx, void* dst, const void* d_src, uint64_t bytes);
 
 /* ------------------------------------------------------------ measurement -- */
 /* HIP-event timing of the two dominant kernels and of the whole pipelines, on

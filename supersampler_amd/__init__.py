@@ -53,7 +53,7 @@ SUPERKMER_DTYPE = np.dtype([("rec", "<u4"), ("minimizer", "<u4"), ("start", "<u8
 
 # every symbol include/spsp.h declares (tests check the .so exports them all)
 ABI_SYMBOLS = [
-    "spsp_create", "spsp_destroy", "spsp_last_error", "spsp_version", "spsp_free",
+    "spsp_create", "spsp_destroy", "spsp_last_error", "spsp_version", "spsp_free", "spsp_copy_to_host",
     "spsp_timing_enable", "spsp_timing_read", "spsp_threshold_host", "spsp_scan", "spsp_scan_device", "spsp_scan_hits_device", "spsp_compare",
     "spsp_compare_device", "spsp_fasta_clean_host", "spsp_fasta_clean_device", "spsp_sketch_text", "spsp_sketch_build_host", "spsp_sketch_parse_host",
     "spsp_csv_host", "spsp_read_file_host", "spsp_write_gz_host", "spsp_sketch_file", "spsp_compare_files",
@@ -77,6 +77,7 @@ def lib():
     L.spsp_last_error.restype = cp; L.spsp_last_error.argtypes = []
     L.spsp_version.restype = cp; L.spsp_version.argtypes = []
     L.spsp_free.restype = None; L.spsp_free.argtypes = [vp]
+    L.spsp_copy_to_host.restype = i32; L.spsp_copy_to_host.argtypes = [vp, vp, vp, u64]
     L.spsp_timing_enable.restype = i32; L.spsp_timing_enable.argtypes = [vp, i32]
     L.spsp_timing_read.restype = i32; L.spsp_timing_read.argtypes = [vp, P(Timing)]
     L.spsp_threshold_host.restype = u64; L.spsp_threshold_host.argtypes = [u32, u32, dbl]
@@ -225,6 +226,12 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def to_host(self, d_ptr, count, dtype):
+        """copy `count` items of numpy dtype from a device buffer returned by this context."""
+        out = np.zeros(count, dtype=dtype)
+        _check(lib().spsp_copy_to_host(self._h, out.ctypes.data, d_ptr, out.nbytes))
+        return out
 
     # ---- measurement
     def timing_enable(self, on=True):

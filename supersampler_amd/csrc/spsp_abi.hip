@@ -150,6 +150,15 @@ void spsp_destroy(spsp_ctx* c) {
 }
 
 void spsp_free(void* p) { free(p); }
+
+int spsp_copy_to_host(spsp_ctx* ctx, void* dst, const void* d_src, uint64_t bytes) {
+    if (!ctx || (bytes && (!dst || !d_src))) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    if (!bytes) return SPSP_OK;
+    SPSP_HIP(hipSetDevice(ctx->device));
+    SPSP_HIP(hipMemcpyAsync(dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SPSP_HIP(hipStreamSynchronize(ctx->stream));
+    return SPSP_OK;
+}
 int spsp_scan(spsp_ctx* ctx, const spsp_params* p, const uint8_t* bases, const uint64_t* rec_off, uint32_t n_rec,
               spsp_superkmer** out, uint64_t* n_out) {
     if (!ctx || !out || !n_out) { set_error("NULL argument"); return SPSP_ERR_ARG; }

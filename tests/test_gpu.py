@@ -384,13 +384,8 @@ def test_gpu_ingest_matches_oracle(ctx):
         torch.cuda.synchronize()
         db, nb, do, nr = ctx.clean_fasta_device(d.data_ptr(), len(text))
         assert nr == len(want_o) - 1 and nb == len(want_b), (len(text), nr, nb, len(want_o) - 1, len(want_b))
-        got_b = np.zeros(nb, np.uint8)
-        got_o = np.zeros(nr + 1, np.uint64)
-        import ctypes
-        hip = ctypes.CDLL("libamdhip64.so")
-        if nb:
-            assert hip.hipMemcpy(ctypes.c_void_p(got_b.ctypes.data), ctypes.c_void_p(db), ctypes.c_size_t(nb), 2) == 0
-        assert hip.hipMemcpy(ctypes.c_void_p(got_o.ctypes.data), ctypes.c_void_p(do), ctypes.c_size_t(8 * (nr + 1)), 2) == 0
+        got_b = ctx.to_host(db, nb, np.uint8)
+        got_o = ctx.to_host(do, nr + 1, np.uint64)
         assert got_o.tolist() == want_o.tolist()
         assert got_b.tobytes() == want_b.tobytes()
 
@@ -436,7 +431,6 @@ def test_scan_buffer_overflow_retries():
 def test_scan_across_the_4gib_seam(ctx):
     """one call over > 2^32 bases: a 1 Mbp record that straddles position 2^32 and another one after it must
     give the same super-k-mers as when scanned alone (queued survivor positions carry only their low 32 bits)."""
-    import ctypes
     import torch
     k, m, s = 31, 11, 100
     rng = np.random.default_rng(99)
@@ -460,9 +454,7 @@ def test_scan_across_the_4gib_seam(ctx):
     for mode in (sp.SPSP_SCAN_DEFAULT, sp.SPSP_SCAN_LDS_FILTER):
         p = sp.make_params(k, m, s, flags=mode)
         d_out, n_out = ctx.scan_device(p, buf.data_ptr(), total, d_off.data_ptr(), 3)
-        got = np.zeros(n_out, dtype=sp.SUPERKMER_DTYPE)
-        hip = ctypes.CDLL("libamdhip64.so")
-        assert hip.hipMemcpy(ctypes.c_void_p(got.ctypes.data), ctypes.c_void_p(d_out), ctypes.c_size_t(got.nbytes), 2) == 0
+        got = ctx.to_host(d_out, n_out, sp.SUPERKMER_DTYPE)
         assert (np.diff(got["rec"].astype(np.int64)) >= 0).all()
         for r, g in ((1, a), (2, b)):
             want, _ = orc.scan(k, m, p.threshold, *synth.concat_records([g]))
