@@ -559,6 +559,12 @@ __global__ __launch_bounds__(1024) void k_scan_segments(const uint32_t* __restri
     for (int u = 0; u < 8; ++u) { if (i0 + u < n) out[i0 + u] = run; run += v[u]; }
     if (t == 0) seg_sum[blockIdx.x] = all;
 }
+// prefix of the segment sums, computed by whoever needs it (a handful of segments: cheaper than a launch)
+__device__ __forceinline__ uint32_t seg_prefix(const uint32_t* __restrict__ seg_sum, uint32_t seg) {
+    uint32_t p = 0;
+    for (uint32_t i = 0; i < seg; ++i) p += seg_sum[i];
+    return p;
+}
 __global__ __launch_bounds__(64) void k_scan_top(const uint32_t* __restrict__ seg_sum, uint32_t* __restrict__ seg_off,
                                                 uint32_t n_seg, uint64_t* __restrict__ total_host,
                                                 uint32_t* __restrict__ total_dev) {
@@ -615,10 +621,15 @@ __global__ __launch_bounds__(kThreads) void k_expand(const uint8_t* __restrict__
                                                     uint32_t m, uint32_t* __restrict__ bitmap,
                                                     uint32_t* __restrict__ tile_count,
                                                     const uint32_t* __restrict__ tile_off,
-                                                    const uint32_t* __restrict__ seg_off, uint64_t n_tiles,
-                                                    const uint64_t* __restrict__ rec_off, uint32_t n_rec,
-                                                    Hit* __restrict__ hits, uint32_t hits_cap) {
+                                                    const uint32_t* __restrict__ seg_sum, uint32_t n_seg,
+                                                    uint64_t n_tiles, const uint64_t* __restrict__ rec_off, uint32_t n_rec,
+                                                    Hit* __restrict__ hits, uint32_t hits_cap,
+                                                    uint64_t* __restrict__ total_host, uint32_t* __restrict__ total_dev) {
     const uint32_t lane = threadIdx.x & 63;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {      // the hit total, for the host and for k_resolve
+        const uint32_t total = seg_prefix(seg_sum, n_seg);
+        *total_host = total; *total_dev = total;
+    }
     const uint64_t b = (uint64_t)blockIdx.x * kExpandTilesPerWg + (threadIdx.x >> 6);
     if (b >= n_tiles) return;
     if (tile_count[b] == 0) return;            // wave-uniform
@@ -644,7 +655,7 @@ __global__ __launch_bounds__(kThreads) void k_expand(const uint8_t* __restrict__
     }
     uint32_t cnt[2];
     uint32_t rank[2];
-    uint32_t run = tile_off[b] + seg_off[b >> kSegShift];
+    uint32_t run = tile_off[b] + seg_prefix(seg_sum, (uint32_t)(b >> kSegShift));
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         cnt[h] = __popc(q[h].x) + __popc(q[h].y) + __popc(q[h].z) + __popc(q[h].w);
@@ -804,8 +815,10 @@ template <bool WRITE>
 __global__ void k_resolve(const Hit* __restrict__ hits, const uint32_t* __restrict__ n_hits_dev, uint32_t hits_cap,
                           const uint64_t* __restrict__ rec_off, uint32_t k, uint32_t m,
                           uint32_t* __restrict__ emit_count, const uint32_t* __restrict__ emit_off,
-                          const uint32_t* __restrict__ seg_off, spsp_superkmer* __restrict__ out, uint32_t out_cap) {
+                          const uint32_t* __restrict__ seg_sum, uint32_t n_seg, uint64_t* __restrict__ total_host,
+                          spsp_superkmer* __restrict__ out, uint32_t out_cap) {
     const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (WRITE && h == 0) *total_host = seg_prefix(seg_sum, n_seg);   // number of super-k-mers, for the host
     uint32_t n_hits = *n_hits_dev;
     if (n_hits > hits_cap) n_hits = hits_cap;   // overflowed: this pass is discarded by the host
     if (h >= n_hits) return;
@@ -831,7 +844,7 @@ __global__ void k_resolve(const Hit* __restrict__ hits, const uint32_t* __restri
     }
     const uint64_t r0 = rec_off[me.rec], r1 = rec_off[me.rec + 1];
     if (WRITE) {
-        const uint32_t at = emit_off[h] + seg_off[h >> kSegShift];
+        const uint32_t at = emit_off[h] + seg_prefix(seg_sum, h >> kSegShift);
         run_cluster<true>(hits + h, cnt, r0, r1 - r0, k, m, me.rec, out + at, at < out_cap ? out_cap - at : 0u);
     } else {
         emit_count[h] = run_cluster<false>(hits + h, cnt, r0, r1 - r0, k, m, me.rec, nullptr, 0u);
@@ -898,7 +911,7 @@ static int ensure_pairtab(spsp_ctx* ctx, const spsp_params* p) {
 }
 
 static int launch_dense(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, uint64_t n_bases,
-                        uint64_t n_tiles) {
+                        uint64_t n_tiles, bool want_total) {
     int rc;
     const void *old_bm = ctx->bitmap.p, *old_tc = ctx->tile_count.p;
     if ((rc = ctx->bitmap.reserve((size_t)n_tiles * kTileWords * 4))) return rc;
@@ -969,9 +982,11 @@ static int launch_dense(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_ba
     hipLaunchKernelGGL(k_scan_segments, dim3(n_seg), dim3(1024), 0, ctx->stream, ctx->tile_count.as<uint32_t>(),
                        ctx->tile_off.as<uint32_t>(), n_tiles, (const uint32_t*)nullptr, ctx->seg_a.as<uint32_t>());
     SPSP_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(64), 0, ctx->stream, ctx->seg_a.as<uint32_t>(),
-                       ctx->seg_a.as<uint32_t>() + n_seg, n_seg, ctx->h_scalar + 0, ctx->d_scalar.as<uint32_t>() + 0);
-    SPSP_HIP(hipGetLastError());
+    if (want_total) {   // dense-only callers; the full pipeline lets k_expand publish the total
+        hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(64), 0, ctx->stream, ctx->seg_a.as<uint32_t>(),
+                           ctx->seg_a.as<uint32_t>() + n_seg, n_seg, ctx->h_scalar + 0, ctx->d_scalar.as<uint32_t>() + 0);
+        SPSP_HIP(hipGetLastError());
+    }
     return SPSP_OK;
 }
 
@@ -984,7 +999,7 @@ int scan_hits_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, 
     if (n_bases < p->m) return SPSP_OK;
     const uint64_t n_tiles = (n_bases + kTilePos - 1) / kTilePos;
     if (n_tiles > 0x7fffffffull) { set_error("input too large for one call"); return SPSP_ERR_OVERFLOW; }
-    if ((rc = launch_dense(ctx, p, d_bases, n_bases, n_tiles))) return rc;
+    if ((rc = launch_dense(ctx, p, d_bases, n_bases, n_tiles, true))) return rc;
     SPSP_HIP(hipStreamSynchronize(ctx->stream));
     *n_hits = ctx->h_scalar[0];
     return SPSP_OK;
@@ -1029,31 +1044,29 @@ static int scan_device_inner(spsp_ctx* ctx, const spsp_params* p, const uint8_t*
         if ((rc = ctx->seg_b.reserve((size_t)n_seg_h * 8))) return rc;
         uint32_t* d_sc = nullptr;
         if (redo_dense) {
-            if ((rc = launch_dense(ctx, p, d_bases, n_bases, n_tiles))) return rc;
+            if ((rc = launch_dense(ctx, p, d_bases, n_bases, n_tiles, false))) return rc;
             d_sc = ctx->d_scalar.as<uint32_t>();
             const uint32_t n_seg_t = (uint32_t)((n_tiles + kSeg - 1) / kSeg);
             hipLaunchKernelGGL(k_expand, dim3((uint32_t)((n_tiles + kExpandTilesPerWg - 1) / kExpandTilesPerWg)),
                                dim3(kThreads), 0, ctx->stream, d_bases, n_bases, p->k, p->m, ctx->bitmap.as<uint32_t>(),
-                               ctx->tile_count.as<uint32_t>(), ctx->tile_off.as<uint32_t>(),
-                               ctx->seg_a.as<uint32_t>() + n_seg_t, n_tiles, d_rec_off, n_rec, ctx->hits.as<Hit>(), hits_cap);
+                               ctx->tile_count.as<uint32_t>(), ctx->tile_off.as<uint32_t>(), ctx->seg_a.as<uint32_t>(),
+                               n_seg_t, n_tiles, d_rec_off, n_rec, ctx->hits.as<Hit>(), hits_cap, ctx->h_scalar + 0, d_sc + 0);
             SPSP_HIP(hipGetLastError());
             ctx->dirty_tiles = 0;   // k_expand leaves bitmap and tile counts zeroed
             hipLaunchKernelGGL(k_resolve<false>, dim3(rblocks), dim3(128), 0, ctx->stream, ctx->hits.as<Hit>(), d_sc + 0,
                                hits_cap, d_rec_off, p->k, p->m, ctx->emit_count.as<uint32_t>(),
-                               (const uint32_t*)nullptr, (const uint32_t*)nullptr, (spsp_superkmer*)nullptr, 0u);
+                               (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, (uint64_t*)nullptr,
+                               (spsp_superkmer*)nullptr, 0u);
             SPSP_HIP(hipGetLastError());
             hipLaunchKernelGGL(k_scan_segments, dim3(n_seg_h), dim3(1024), 0, ctx->stream, ctx->emit_count.as<uint32_t>(),
                                ctx->emit_off.as<uint32_t>(), (uint64_t)hits_cap, (const uint32_t*)(d_sc + 0),
                                ctx->seg_b.as<uint32_t>());
             SPSP_HIP(hipGetLastError());
-            hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(64), 0, ctx->stream, ctx->seg_b.as<uint32_t>(),
-                               ctx->seg_b.as<uint32_t>() + n_seg_h, n_seg_h, ctx->h_scalar + 1, d_sc + 1);
-            SPSP_HIP(hipGetLastError());
         }
         d_sc = ctx->d_scalar.as<uint32_t>();
         hipLaunchKernelGGL(k_resolve<true>, dim3(rblocks), dim3(128), 0, ctx->stream, ctx->hits.as<Hit>(), d_sc + 0, hits_cap,
                            d_rec_off, p->k, p->m, (uint32_t*)nullptr, ctx->emit_off.as<uint32_t>(),
-                           ctx->seg_b.as<uint32_t>() + n_seg_h, ctx->scan_tmp.as<spsp_superkmer>(), out_cap);
+                           ctx->seg_b.as<uint32_t>(), n_seg_h, ctx->h_scalar + 1, ctx->scan_tmp.as<spsp_superkmer>(), out_cap);
         SPSP_HIP(hipGetLastError());
         SPSP_HIP(hipStreamSynchronize(ctx->stream));
         const uint64_t n_hits = ctx->h_scalar[0], n_em = ctx->h_scalar[1];
