@@ -109,7 +109,14 @@ def main():
     d_my_min = torch.from_numpy(my_min.view(np.int32)).to(dev)
     d_my_lo = torch.from_numpy(my_lo.view(np.int64)).to(dev)
     n_total = args.genomes * world
-    if use_dist:
+    my_sk_off = np.zeros(args.genomes + 1, dtype=np.uint64)
+    my_sk_off[1:] = np.cumsum(my_n)
+    exchange_kind = os.environ.get("BENCH_EXCHANGE", "slots") if use_dist else "none"
+    if exchange_kind == "slots":      # key-partitioned: all-to-all of own keys + all-reduce of partial matrices
+        exchange = spd.SlotExchange(ctx, K, args.genomes, int(my_sk_off[-1]), dev)
+        sk_off = np.zeros(n_total + 1, dtype=np.uint64)
+        sk_off[-1] = exchange.max_keys * world           # log line only
+    elif exchange_kind == "gather":   # all-gather of every rank's keys + strided row ownership
         exchange = spd.KeyExchange(my_n, dev)
         sk_off = exchange.sk_off
     else:
@@ -124,8 +131,14 @@ def main():
             % (time.time() - t_setup, args.genomes, args.length, len(recs), kmers_per_step, int(sk_off[-1]), pairs_per_step))
 
     def step():
+        if exchange_kind == "slots":
+            # the key exchange (RCCL all-to-all over xGMI) is queued first and runs behind the scan kernels
+            h = exchange.begin(d_my_min.data_ptr(), d_my_lo.data_ptr(), None, my_sk_off)
+            d_out, n_out = ctx.scan_device(p, d_bases.data_ptr(), d_bases.numel(), d_off.data_ptr(), len(recs))
+            exchange.end(h, d_inter)                     # partial pair matrix + all-reduce
+            return n_out
         d_out, n_out = ctx.scan_device(p, d_bases.data_ptr(), d_bases.numel(), d_off.data_ptr(), len(recs))
-        if use_dist:  # the one data-path collective: packed sketch keys over RCCL/xGMI
+        if exchange_kind == "gather":
             g = exchange.exchange(d_my_min, d_my_lo)
             mn_ptr, lo_ptr = g.minimizer.data_ptr(), g.kmer_lo.data_ptr()
         else:
@@ -169,6 +182,23 @@ def main():
 
     # sanity: the comparison produced something (family structure => shared k-mers)
     inter_nonzero = int(torch.count_nonzero(d_inter).item())
+    # untimed cross-check of the two exchange forms: the key-partitioned result must equal the
+    # all-gather + owned-rows result on every rank count
+    exchange_check = None
+    if exchange_kind == "slots":
+        try:
+            if exchange.overflowed(d_inter):
+                exchange_check = "slot overflow"
+            else:
+                ge = spd.KeyExchange(my_n, dev)
+                g = ge.exchange(d_my_min, d_my_lo)
+                d_ref = torch.zeros_like(d_inter)
+                ctx.compare_device(K, g.minimizer.data_ptr(), g.kmer_lo.data_ptr(), None, ge.sk_off, n_total, rank, world,
+                                   d_ref.data_ptr())
+                dist.all_reduce(d_ref, op=dist.ReduceOp.SUM)
+                exchange_check = "equal to all-gather form" if bool(torch.equal(d_ref, d_inter)) else "MISMATCH"
+        except Exception as e:  # noqa: BLE001 -- the check must not take the bench line down
+            exchange_check = "check failed: %r" % (e,)
 
     if rank == 0:
         value = total_kmers_per_step * args.steps / elapsed
@@ -192,7 +222,12 @@ def main():
                                    "k=31 m=11 s=1000, scan + all-vs-all; inputs resident in HBM" % (args.genomes, args.length),
                        "k": K, "m": M, "s": S, "genomes_per_gpu": args.genomes, "genome_len": args.length,
                        "sketches_total": n_total, "scan_mode": args.mode,
-                       "parallelism": "genomes sharded by rank; pair-matrix rows i%N==rank after RCCL all-gather of sketch keys"},
+                       "parallelism": {"none": "single GPU",
+                                       "slots": "genomes sharded by rank; sketch keys partitioned by hash, RCCL all-to-all behind "
+                                                "the scan, per-rank partial pair matrix, RCCL all-reduce",
+                                       "gather": "genomes sharded by rank; pair-matrix rows i%N==rank after RCCL all-gather of "
+                                                 "sketch keys"}[exchange_kind],
+                       "exchange_check": exchange_check},
             "sketch_pairs_per_s": pairs_per_step / (compare_avg_ms / 1e3) if compare_avg_ms > 0 else None,
             "stage_ms": {"scan_pipeline": scan_ms / max(1, tm["scan_calls"]), "dense_kernel": dense_avg_ms,
                          "compare_pipeline": compare_avg_ms, "accumulate_kernel": acc_ms / max(1, tm["accumulate_launches"])},

@@ -147,6 +147,30 @@ int spsp_compare_device(spsp_ctx* ctx, uint32_t k, const void* d_minimizer, cons
                         uint32_t n, uint32_t n_query /* = n for all-vs-all */, uint32_t row_first,
                         uint32_t row_stride, void* d_inter);
 
+/* ----------------------------------- multi-GPU exchange ---- */
+/* The reference is single-process; its all-vs-all merge (Comparator.cpp:97-287) has no sharded form to mirror.
+ * Key-partitioned split: equal (minimizer, k-mer) keys hash to the same rank, every rank counts its own hash
+ * class for ALL pairs, and inter = the sum of the partial matrices (one all-reduce).  Each rank sends each of
+ * its keys exactly once (all-to-all) -- O(own keys) per rank, against O(all keys) for an all-gather.
+ *
+ * Sender: scatter this rank's n sketches (concatenated key arrays as in spsp_compare_device) into `parts`
+ * fixed-size slots, slot p for rank p, at d_slots + p * spsp_slot_bytes(n, slot_cap, k) (8-byte aligned).
+ * Slot layout: u32 magic, u32 n, u32 n_keys, u32 words; u32 cnt[n] (padded to even); slot_cap records of
+ * `words` u64 (kmer_lo, [kmer_hi if k > 32], minimizer | local sketch << 32), grouped by sketch, original
+ * order kept.  A slot with more than slot_cap keys keeps the first slot_cap and records the true n_keys: the
+ * receiver reports SPSP_ERR_OVERFLOW and the caller partitions again with a larger slot_cap. Asynchronous
+ * on the context's stream. */
+uint64_t spsp_slot_bytes(uint32_t n, uint32_t slot_cap, uint32_t k);
+int spsp_partition_keys_device(spsp_ctx* ctx, uint32_t k, const void* d_minimizer, const void* d_kmer_lo,
+                               const void* d_kmer_hi /* NULL if k<=32 */, const uint64_t* h_sk_off, uint32_t n,
+                               uint32_t parts, uint32_t slot_cap, void* d_slots);
+/* Receiver: d_slots holds `parts` slots, slot s as sent by rank s (same n, slot_cap, k everywhere). Global
+ * sketch id = s * n + local id; d_inter is the dense (parts*n)^2 uint32 partial matrix: cells (i, j > i)
+ * are overwritten with this rank's share of |K_i ∩ K_j|, everything else is left untouched.  Returns after
+ * one synchronisation of the context's stream (format / overflow / collision flags). */
+int spsp_compare_slots_device(spsp_ctx* ctx, uint32_t k, const void* d_slots, uint32_t parts, uint32_t n,
+                              uint32_t slot_cap, void* d_inter);
+
 /* --------------------------------------------- host side of the two CLIs -- */
 /* getLineFasta + clean_dna (utils.cpp:675-718) over an already gunzipped
  * buffer: records back to back + n_rec+1 offsets. */

@@ -24,7 +24,10 @@ SPSP_SCAN_PAIR_FILTER = 4
 
 
 class SpspError(RuntimeError):
-    pass
+    code = 0
+
+
+ERR_OVERFLOW = -7
 
 
 class Params(C.Structure):
@@ -55,7 +58,7 @@ SUPERKMER_DTYPE = np.dtype([("rec", "<u4"), ("minimizer", "<u4"), ("start", "<u8
 ABI_SYMBOLS = [
     "spsp_create", "spsp_destroy", "spsp_last_error", "spsp_version", "spsp_free", "spsp_copy_to_host",
     "spsp_timing_enable", "spsp_timing_read", "spsp_threshold_host", "spsp_scan", "spsp_scan_device", "spsp_scan_hits_device", "spsp_compare",
-    "spsp_compare_device", "spsp_fasta_clean_host", "spsp_fasta_clean_device", "spsp_sketch_text", "spsp_sketch_build_host", "spsp_sketch_parse_host",
+    "spsp_compare_device", "spsp_slot_bytes", "spsp_partition_keys_device", "spsp_compare_slots_device", "spsp_fasta_clean_host", "spsp_fasta_clean_device", "spsp_sketch_text", "spsp_sketch_build_host", "spsp_sketch_parse_host",
     "spsp_csv_host", "spsp_read_file_host", "spsp_write_gz_host", "spsp_sketch_file", "spsp_compare_files",
 ]
 
@@ -89,6 +92,11 @@ def lib():
     L.spsp_compare.restype = i32; L.spsp_compare.argtypes = [vp, P(SketchView), u32, u32, vp, vp]
     L.spsp_compare_device.restype = i32
     L.spsp_compare_device.argtypes = [vp, u32, vp, vp, vp, vp, u32, u32, u32, u32, vp]
+    L.spsp_slot_bytes.restype = u64; L.spsp_slot_bytes.argtypes = [u32, u32, u32]
+    L.spsp_partition_keys_device.restype = i32
+    L.spsp_partition_keys_device.argtypes = [vp, u32, vp, vp, vp, vp, u32, u32, u32, vp]
+    L.spsp_compare_slots_device.restype = i32
+    L.spsp_compare_slots_device.argtypes = [vp, u32, vp, u32, u32, u32, vp]
     L.spsp_fasta_clean_host.restype = i32
     L.spsp_fasta_clean_host.argtypes = [cp, u64, P(vp), P(vp), P(u32)]
     L.spsp_fasta_clean_device.restype = i32
@@ -113,13 +121,19 @@ def lib():
 
 def _check(rc):
     if rc != 0:
-        raise SpspError("libspsp error %d: %s" % (rc, lib().spsp_last_error().decode(errors="replace")))
+        e = SpspError("libspsp error %d: %s" % (rc, lib().spsp_last_error().decode(errors="replace")))
+        e.code = rc
+        raise e
 
 
 def _take(ptr, nbytes):
     data = C.string_at(ptr, nbytes) if nbytes else b""
     lib().spsp_free(ptr)
     return data
+
+
+def slot_bytes(n, slot_cap, k):
+    return int(lib().spsp_slot_bytes(n, slot_cap, k))
 
 
 def threshold(k, m, s):
@@ -316,6 +330,16 @@ class Context:
         sk_off = np.ascontiguousarray(sk_off, dtype=np.uint64)
         _check(lib().spsp_compare_device(self._h, k, d_min, d_lo, d_hi, sk_off.ctypes.data, n,
                                          n if n_query is None else n_query, row_first, row_stride, d_inter))
+
+    def partition_keys_device(self, k, d_min, d_lo, d_hi, sk_off, n, parts, slot_cap, d_slots):
+        """Scatter this rank's sketch keys into `parts` exchange slots (include/spsp.h); asynchronous."""
+        sk_off = np.ascontiguousarray(sk_off, dtype=np.uint64)
+        _check(lib().spsp_partition_keys_device(self._h, k, d_min, d_lo, d_hi, sk_off.ctypes.data, n, parts, slot_cap,
+                                                d_slots))
+
+    def compare_slots_device(self, k, d_slots, parts, n, slot_cap, d_inter):
+        """Partial pair matrix of the hash class this rank received (one slot per source rank)."""
+        _check(lib().spsp_compare_slots_device(self._h, k, d_slots, parts, n, slot_cap, d_inter))
 
     def compare_files(self, paths, out_prefix, n_query=None, precision=6, min_threshold=0.0):
         n = len(paths)

@@ -76,7 +76,7 @@ __device__ __forceinline__ uint32_t sketch_of(const uint64_t* __restrict__ sk_of
 // flags[0]: input not strictly sorted inside a sketch; flags[1]: fingerprint collision
 __global__ void k_insert(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n, uint64_t S, uint32_t row_first,
                          uint32_t row_stride, uint32_t row_limit, uint64_t seed, uint64_t* __restrict__ table, uint32_t log2cap,
-                         uint32_t* __restrict__ owner, uint32_t* __restrict__ slot, uint32_t* __restrict__ flags) {
+                         uint32_t* __restrict__ owner, uint32_t* __restrict__ flags) {
     // grid.y = sketch, grid.x = 256-key chunk of it (no per-entry search for the owning sketch)
     const uint32_t j = blockIdx.y;
     const uint64_t e = sk_off[j] + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -92,7 +92,6 @@ __global__ void k_insert(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n
         if (old == fp) break;
         pos = (pos + 1) & mask;
     }
-    slot[e] = (uint32_t)pos;
 }
 
 // Occupied slot -> dense row id.  Same-address atomics retire at ~90 per microsecond on this
@@ -176,7 +175,8 @@ constexpr int kAccThreads = 256;
 __global__ __launch_bounds__(kAccThreads) void k_accumulate(const uint32_t* __restrict__ row_of_entry,
                                                            const uint64_t* __restrict__ A, uint32_t W,
                                                            uint32_t lanes_per_key,
-                                                           const uint64_t* __restrict__ sk_off, uint32_t n,
+                                                           const uint64_t* __restrict__ sk_begin,
+                                                           const uint64_t* __restrict__ sk_end, uint32_t n,
                                                            uint32_t row_first, uint32_t row_stride, uint32_t row_limit,
                                                            uint32_t* __restrict__ inter) {
     const uint32_t i = row_first + blockIdx.y * row_stride;
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(kAccThreads) void k_accumulate(const uint32_t* __re
     const uint32_t grp = lane / lanes_per_key, wl = lane % lanes_per_key;
     const uint32_t word = wb * 64 + wl;
     const bool active = word < W && word >= first_wd;
-    const uint64_t e0 = sk_off[i], e1 = sk_off[i + 1];
+    const uint64_t e0 = sk_begin[i], e1 = sk_end[i];
     const uint64_t M8 = 0x0101010101010101ULL;
     uint32_t cnt[64];
 #pragma unroll
@@ -242,6 +242,87 @@ __global__ __launch_bounds__(kAccThreads) void k_accumulate(const uint32_t* __re
     }
 }
 
+// ---------------------------------------------------------------------------
+// Host driver shared by the two input forms (flat key arrays / exchange slots):
+// dictionary build -> colour matrix -> row sums, with the collision retry.
+struct ComparePlan {
+    uint64_t S_own;        // upper bound on the keys inserted (sizes the table and the speculative matrix)
+    uint64_t S_entries;    // entry index space (sizes row_of_entry)
+    uint32_t n, n_own, row_first, row_stride, row_limit;
+    const uint64_t *sk_begin, *sk_end;   // device: entry range of sketch i
+    uint32_t* d_inter;
+};
+// flags: [0] unsorted input, [1] fingerprint collision, [2] n_rows, [3] malformed slot, [4] slot overflow
+template <class Insert, class Fill>
+static int run_compare(spsp_ctx* ctx, const ComparePlan& P, Insert&& launch_insert, Fill&& launch_fill) {
+    int rc;
+    uint32_t log2cap = 10;
+    while ((1ull << log2cap) < 2 * P.S_own) ++log2cap;
+    const uint64_t cap = 1ull << log2cap;
+    if ((rc = ctx->c_table.reserve((size_t)cap * 8))) return rc;
+    if ((rc = ctx->c_owner.reserve((size_t)cap * 4))) return rc;
+    if ((rc = ctx->c_rowid.reserve((size_t)cap * 4))) return rc;
+    if ((rc = ctx->c_row.reserve((size_t)P.S_entries * 4))) return rc;
+    // test hook: fingerprints of the first attempt cut to a few bits, so distinct keys collide and the retry runs
+    static const char* dbg_fp = getenv("SPSP_DEBUG_FP_BITS");
+    uint32_t* flags = ctx->c_flags.as<uint32_t>();
+    const uint32_t sblocks = (uint32_t)((cap + (uint64_t)kRowThreads * kRowSlots - 1) / ((uint64_t)kRowThreads * kRowSlots));
+    const uint32_t W = (P.n + 63) / 64;
+    uint32_t lanes_per_key = 64;
+    if (W < 64) { lanes_per_key = 1; while (lanes_per_key < W) lanes_per_key <<= 1; }
+    // dictionary build: table and row ids
+    auto front = [&](uint64_t seed, uint64_t fp_mask) -> int {
+        SPSP_HIP(hipMemsetAsync(ctx->c_table.p, 0, (size_t)cap * 8, ctx->stream));
+        SPSP_HIP(hipMemsetAsync(flags, 0, 12, ctx->stream));   // [3], [4] belong to the slot index pass
+        int r2 = launch_insert(seed, fp_mask, log2cap);
+        if (r2) return r2;
+        hipLaunchKernelGGL(k_assign_rows, dim3(sblocks), dim3(kRowThreads), 0, ctx->stream, ctx->c_table.as<uint64_t>(), cap,
+                           ctx->c_rowid.as<uint32_t>(), flags + 2);
+        SPSP_HIP(hipGetLastError());
+        return SPSP_OK;
+    };
+    // colour matrix (room for `rows` rows) and the row sums
+    auto back = [&](uint64_t seed, uint64_t fp_mask, uint64_t rows) -> int {
+        int r2;
+        if ((r2 = ctx->c_matrix.reserve((size_t)rows * W * 8))) return r2;
+        SPSP_HIP(hipMemsetAsync(ctx->c_matrix.p, 0, (size_t)rows * W * 8, ctx->stream));
+        if ((r2 = launch_fill(seed, fp_mask, log2cap, W))) return r2;
+        if ((r2 = ctx->ev_begin(kEvAccumulate))) return r2;
+        hipLaunchKernelGGL(k_accumulate, dim3((W + 63) / 64, P.n_own), dim3(kAccThreads), 0, ctx->stream,
+                           ctx->c_row.as<uint32_t>(), ctx->c_matrix.as<uint64_t>(), W, lanes_per_key, P.sk_begin, P.sk_end,
+                           P.n, P.row_first, P.row_stride, P.row_limit, P.d_inter);
+        SPSP_HIP(hipGetLastError());
+        return ctx->ev_end(kEvAccumulate);
+    };
+    auto read_flags = [&](uint32_t* h_flags) -> int {
+        SPSP_HIP(hipMemcpyAsync(h_flags, flags, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        SPSP_HIP(hipStreamSynchronize(ctx->stream));
+        if (h_flags[3]) { set_error("malformed exchange slot (header, sketch count or key count does not match)"); return SPSP_ERR_FORMAT; }
+        if (h_flags[4]) { set_error("an exchange slot overflowed its capacity: partition again with a larger slot_cap"); return SPSP_ERR_OVERFLOW; }
+        if (h_flags[0]) { set_error("sketch keys must be strictly increasing by (minimizer, kmer_hi, kmer_lo)"); return SPSP_ERR_ARG; }
+        return SPSP_OK;
+    };
+    // A matrix with one row per inserted KEY (an upper bound on the distinct keys) is cheap for small inputs:
+    // then the whole pipeline is queued without waiting for the row count and checked once at the end.
+    const bool speculative = (uint64_t)P.S_own * W * 8 <= (256ull << 20);
+    uint64_t seed = 0x5350535053505350ULL;
+    for (int attempt = 0;; ++attempt) {
+        uint32_t h_flags[5];
+        const uint64_t fp_mask = (dbg_fp && attempt == 0) ? ((1ull << atoi(dbg_fp)) - 1) : ~0ull;
+        if ((rc = front(seed, fp_mask))) return rc;
+        if (speculative) {
+            if ((rc = back(seed, fp_mask, P.S_own))) return rc;
+        } else {
+            if ((rc = read_flags(h_flags))) return rc;          // the row count sizes the colour matrix
+            if ((rc = back(seed, fp_mask, h_flags[2]))) return rc;
+        }
+        if ((rc = read_flags(h_flags))) return rc;              // collisions surface in the fill pass
+        if (!h_flags[1]) return SPSP_OK;
+        if (attempt >= 4) { set_error("fingerprint collisions persisted over 5 seeds"); return SPSP_ERR_HIP; }
+        seed = seed * 6364136223846793005ULL + 1442695040888963407ULL;  // new fingerprints, try again
+    }
+}
+
 static int compare_device_inner(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min, const uint64_t* d_lo,
                                 const uint64_t* d_hi, const uint64_t* h_sk_off, uint32_t n, uint32_t row_limit,
                                 uint32_t row_first, uint32_t row_stride, uint32_t* d_inter) {
@@ -258,88 +339,360 @@ static int compare_device_inner(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min
     for (uint32_t i = row_first; i < row_limit; i += row_stride) { S_own += h_sk_off[i + 1] - h_sk_off[i]; ++n_own; }
     if (S_own == 0 || n_own == 0) return SPSP_OK;
     int rc;
-    uint32_t log2cap = 10;
-    while ((1ull << log2cap) < 2 * S_own) ++log2cap;
-    const uint64_t cap = 1ull << log2cap;
     if ((rc = ctx->c_skoff.reserve((size_t)(n + 1) * 8))) return rc;
-    if ((rc = ctx->c_table.reserve((size_t)cap * 8))) return rc;
-    if ((rc = ctx->c_owner.reserve((size_t)cap * 4))) return rc;
-    if ((rc = ctx->c_rowid.reserve((size_t)cap * 4))) return rc;
-    if ((rc = ctx->c_slot.reserve((size_t)S * 4))) return rc;
-    if ((rc = ctx->c_row.reserve((size_t)S * 4))) return rc;
     if ((rc = ctx->c_flags.reserve(64))) return rc;
     SPSP_HIP(hipMemcpyAsync(ctx->c_skoff.p, h_sk_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    SPSP_HIP(hipMemsetAsync(ctx->c_flags.p, 0, 64, ctx->stream));
     Keys K{d_min, d_lo, (k > 32) ? d_hi : nullptr, ~0ull};
-    // test hook: fingerprints of the first attempt cut to a few bits, so distinct keys collide and the retry runs
-    static const char* dbg_fp = getenv("SPSP_DEBUG_FP_BITS");
     const uint64_t* sk = ctx->c_skoff.as<uint64_t>();
-    uint32_t* flags = ctx->c_flags.as<uint32_t>();  // [0] unsorted, [1] collision, [2] n_rows
-    uint64_t max_all = 0, max_own = 0;
-    for (uint32_t i = 0; i < n; ++i) {
-        const uint64_t c = h_sk_off[i + 1] - h_sk_off[i];
-        max_all = std::max(max_all, c);
-        if (i % row_stride == row_first && i < row_limit) max_own = std::max(max_own, c);
-    }
+    uint32_t* flags = ctx->c_flags.as<uint32_t>();
+    uint64_t max_all = 0;
+    for (uint32_t i = 0; i < n; ++i) max_all = std::max(max_all, h_sk_off[i + 1] - h_sk_off[i]);
     const dim3 grid_all((uint32_t)((max_all + 255) / 256), n);
-    (void)max_own;
-    const uint32_t sblocks = (uint32_t)((cap + (uint64_t)kRowThreads * kRowSlots - 1) / ((uint64_t)kRowThreads * kRowSlots));
-    const uint32_t W = (n + 63) / 64;
-    uint32_t lanes_per_key = 64;
-    if (W < 64) { lanes_per_key = 1; while (lanes_per_key < W) lanes_per_key <<= 1; }
-    // dictionary build: table and row ids
-    auto front = [&](uint64_t seed) -> int {
-        SPSP_HIP(hipMemsetAsync(ctx->c_table.p, 0, (size_t)cap * 8, ctx->stream));
-        SPSP_HIP(hipMemsetAsync(flags, 0, 64, ctx->stream));
-        hipLaunchKernelGGL(k_insert, grid_all, dim3(256), 0, ctx->stream, K, sk, n, S, row_first, row_stride, row_limit, seed,
-                           ctx->c_table.as<uint64_t>(), log2cap, ctx->c_owner.as<uint32_t>(),
-                           ctx->c_slot.as<uint32_t>(), flags);
-        SPSP_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k_assign_rows, dim3(sblocks), dim3(kRowThreads), 0, ctx->stream, ctx->c_table.as<uint64_t>(), cap,
-                           ctx->c_rowid.as<uint32_t>(), flags + 2);
-        SPSP_HIP(hipGetLastError());
-        return SPSP_OK;
-    };
-    // colour matrix (room for `rows` rows) and the row sums
-    auto back = [&](uint64_t seed, uint64_t rows) -> int {
-        int r2;
-        if ((r2 = ctx->c_matrix.reserve((size_t)rows * W * 8))) return r2;
-        SPSP_HIP(hipMemsetAsync(ctx->c_matrix.p, 0, (size_t)rows * W * 8, ctx->stream));
-        hipLaunchKernelGGL(k_fill, grid_all, dim3(256), 0, ctx->stream, K, sk, n, S, row_first, row_stride, row_limit, seed,
-                           ctx->c_table.as<uint64_t>(), log2cap, ctx->c_owner.as<uint32_t>(), ctx->c_rowid.as<uint32_t>(),
-                           W, ctx->c_matrix.as<unsigned long long>(), ctx->c_row.as<uint32_t>(), flags);
-        SPSP_HIP(hipGetLastError());
-        if ((r2 = ctx->ev_begin(kEvAccumulate))) return r2;
-        hipLaunchKernelGGL(k_accumulate, dim3((W + 63) / 64, n_own), dim3(kAccThreads), 0, ctx->stream,
-                           ctx->c_row.as<uint32_t>(), ctx->c_matrix.as<uint64_t>(), W, lanes_per_key, sk, n, row_first,
-                           row_stride, row_limit, d_inter);
-        SPSP_HIP(hipGetLastError());
-        return ctx->ev_end(kEvAccumulate);
-    };
-    auto read_flags = [&](uint32_t* h_flags) -> int {
-        SPSP_HIP(hipMemcpyAsync(h_flags, flags, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-        SPSP_HIP(hipStreamSynchronize(ctx->stream));
-        if (h_flags[0]) { set_error("sketch keys must be strictly increasing by (minimizer, kmer_hi, kmer_lo)"); return SPSP_ERR_ARG; }
-        return SPSP_OK;
-    };
-    // A matrix with one row per OWNED KEY (an upper bound on the distinct keys) is cheap for small inputs:
-    // then the whole pipeline is queued without waiting for the row count and checked once at the end.
-    const bool speculative = (uint64_t)S_own * W * 8 <= (256ull << 20);
-    uint64_t seed = 0x5350535053505350ULL;
-    for (int attempt = 0;; ++attempt) {
-        uint32_t h_flags[3];
-        K.fp_mask = (dbg_fp && attempt == 0) ? ((1ull << atoi(dbg_fp)) - 1) : ~0ull;
-        if ((rc = front(seed))) return rc;
-        if (speculative) {
-            if ((rc = back(seed, S_own))) return rc;
-        } else {
-            if ((rc = read_flags(h_flags))) return rc;          // the row count sizes the colour matrix
-            if ((rc = back(seed, h_flags[2]))) return rc;
+    ComparePlan P{S_own, S, n, n_own, row_first, row_stride, row_limit, sk, sk + 1, d_inter};
+    return run_compare(
+        ctx, P,
+        [&](uint64_t seed, uint64_t fp_mask, uint32_t log2cap) -> int {
+            Keys Km = K; Km.fp_mask = fp_mask;
+            hipLaunchKernelGGL(k_insert, grid_all, dim3(256), 0, ctx->stream, Km, sk, n, S, row_first, row_stride, row_limit,
+                               seed, ctx->c_table.as<uint64_t>(), log2cap, ctx->c_owner.as<uint32_t>(), flags);
+            SPSP_HIP(hipGetLastError());
+            return SPSP_OK;
+        },
+        [&](uint64_t seed, uint64_t fp_mask, uint32_t log2cap, uint32_t W) -> int {
+            Keys Km = K; Km.fp_mask = fp_mask;
+            hipLaunchKernelGGL(k_fill, grid_all, dim3(256), 0, ctx->stream, Km, sk, n, S, row_first, row_stride, row_limit, seed,
+                               ctx->c_table.as<uint64_t>(), log2cap, ctx->c_owner.as<uint32_t>(),
+                               ctx->c_rowid.as<uint32_t>(), W, ctx->c_matrix.as<unsigned long long>(),
+                               ctx->c_row.as<uint32_t>(), flags);
+            SPSP_HIP(hipGetLastError());
+            return SPSP_OK;
+        });
+}
+
+// ===========================================================================
+// Multi-GPU exchange, key-partitioned form (DESIGN.md "multi-GPU").
+//
+// Equal keys hash to the same rank, so a rank that holds every sketch's keys of ONE hash class can count
+// that class's contribution to every pair; the classes are disjoint, hence inter = sum over ranks of the
+// partial matrices.  Each rank therefore sends every key exactly once (all-to-all, O(own keys)) instead
+// of receiving every rank's keys (all-gather, O(all keys)), and the table, the colour matrix and the row
+// sums all shrink by the number of ranks.
+//
+// Wire format = one fixed-size SLOT per destination rank (fixed size so that the all-to-all needs no
+// size negotiation):
+//     u32 magic, u32 n_sketches, u32 n_keys (> slot_cap signals overflow; only slot_cap are stored), u32 words
+//     u32 cnt[n_sketches]          keys per local sketch in this slot (padded to an even count)
+//     record[slot_cap]             words x u64: kmer_lo, (kmer_hi if k > 32), minimizer | local sketch << 32
+// Records are grouped by sketch, sketches in order, keys of a sketch in their original (sorted) order.
+constexpr uint32_t kSlotMagic = 0x4c535053u;   // "SPSL"
+constexpr uint32_t kMaxParts = 64;
+constexpr int kPartThreads = 256;
+
+__host__ __device__ inline uint64_t slot_rec_off(uint32_t n) { return 16 + (uint64_t)((n + 1) & ~1u) * 4; }
+__host__ __device__ inline uint32_t slot_words(uint32_t k) { return k > 32 ? 3u : 2u; }
+__host__ __device__ inline uint64_t slot_bytes(uint32_t n, uint32_t cap, uint32_t k) {
+    return slot_rec_off(n) + (uint64_t)cap * slot_words(k) * 8;
+}
+
+__device__ __forceinline__ uint32_t part_of(uint64_t lo, uint32_t mn, uint64_t hi, bool has_hi, uint32_t parts) {
+    uint64_t h = mix64(lo ^ 0xD6E8FEB86659FD93ULL);
+    h = mix64(h + (uint64_t)mn * 0xC2B2AE3D27D4EB4FULL);
+    if (has_hi) h = mix64(h ^ hi);
+    return (uint32_t)(((h >> 32) * parts) >> 32);
+}
+
+// sender 1/3: keys of sketch j per destination
+__global__ __launch_bounds__(kPartThreads) void k_part_count(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n,
+                                                            uint32_t parts, uint32_t* __restrict__ cnt /* [parts][n] */) {
+    __shared__ uint32_t hist[kMaxParts];
+    const uint32_t j = blockIdx.x, t = threadIdx.x;
+    if (t < kMaxParts) hist[t] = 0;
+    __syncthreads();
+    for (uint64_t e = sk_off[j] + t; e < sk_off[j + 1]; e += kPartThreads)
+        atomicAdd(&hist[part_of(K.lo[e], K.mn[e], K.hi ? K.hi[e] : 0, K.hi != nullptr, parts)], 1u);
+    __syncthreads();
+    if (t < parts) cnt[(uint64_t)t * n + j] = hist[t];
+}
+
+// sender 2/3: per destination, where each sketch's run starts; slot header + counts
+__global__ __launch_bounds__(kPartThreads) void k_part_offsets(const uint32_t* __restrict__ cnt, uint32_t n, uint32_t words,
+                                                              uint8_t* __restrict__ slots, uint64_t slot_sz,
+                                                              uint32_t* __restrict__ off /* [parts][n] */) {
+    __shared__ uint32_t wave_sum[kPartThreads / 64];
+    __shared__ uint32_t s_carry;
+    const uint32_t p = blockIdx.x, t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    uint32_t* hdr = reinterpret_cast<uint32_t*>(slots + (uint64_t)p * slot_sz);
+    if (t == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += kPartThreads) {
+        const uint32_t j = base + t;
+        const uint32_t v = j < n ? cnt[(uint64_t)p * n + j] : 0u;
+        uint32_t x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d);
+            if (lane >= (uint32_t)d) x += y;
         }
-        if ((rc = read_flags(h_flags))) return rc;              // collisions surface in k_fill
-        if (!h_flags[1]) return SPSP_OK;
-        if (attempt >= 4) { set_error("fingerprint collisions persisted over 5 seeds"); return SPSP_ERR_HIP; }
-        seed = seed * 6364136223846793005ULL + 1442695040888963407ULL;  // new fingerprints, try again
+        if (lane == 63) wave_sum[wid] = x;
+        __syncthreads();
+        uint32_t pre = s_carry, all = 0;
+        for (uint32_t w = 0; w < kPartThreads / 64; ++w) { if (w < wid) pre += wave_sum[w]; all += wave_sum[w]; }
+        if (j < n) { off[(uint64_t)p * n + j] = pre + x - v; hdr[4 + j] = v; }
+        __syncthreads();
+        if (t == 0) s_carry += all;
+        __syncthreads();
     }
+    if (t == 0) {
+        hdr[0] = kSlotMagic; hdr[1] = n; hdr[2] = s_carry; hdr[3] = words;
+        if (n & 1u) hdr[4 + n] = 0;
+    }
+}
+
+// sender 3/3: stable scatter of sketch j's keys into the slots
+__global__ __launch_bounds__(kPartThreads) void k_part_scatter(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n,
+                                                              uint32_t parts, const uint32_t* __restrict__ off,
+                                                              uint8_t* __restrict__ slots, uint64_t slot_sz, uint32_t cap,
+                                                              uint32_t words) {
+    __shared__ uint32_t cursor[kMaxParts];
+    __shared__ uint32_t wave_cnt[kPartThreads / 64][kMaxParts];
+    const uint32_t j = blockIdx.x, t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    if (t < kMaxParts) cursor[t] = t < parts ? off[(uint64_t)t * n + j] : 0u;
+    const uint64_t e0 = sk_off[j], e1 = sk_off[j + 1];
+    const uint64_t rec0 = slot_rec_off(n);
+    for (uint64_t base = e0; base < e1; base += kPartThreads) {
+        for (uint32_t x = t; x < (kPartThreads / 64) * kMaxParts; x += kPartThreads) (&wave_cnt[0][0])[x] = 0;
+        __syncthreads();
+        const uint64_t e = base + t;
+        const bool live = e < e1;
+        uint64_t lo = 0, hi = 0;
+        uint32_t mn = 0, p = 0xffffffffu;
+        if (live) {
+            lo = K.lo[e]; mn = K.mn[e]; hi = K.hi ? K.hi[e] : 0;
+            p = part_of(lo, mn, hi, K.hi != nullptr, parts);
+        }
+        // rank among the wave's earlier lanes with the same destination (keeps the original order)
+        uint32_t rank = 0;
+        uint64_t todo = __ballot(live);
+        while (todo) {
+            const uint32_t lead = (uint32_t)__ffsll((unsigned long long)todo) - 1;
+            const uint32_t pl = __shfl(p, lead);
+            const uint64_t same = __ballot(live && p == pl);
+            if (p == pl) rank = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+            if (lane == lead) wave_cnt[wid][pl] = (uint32_t)__popcll(same);
+            todo &= ~same;
+        }
+        __syncthreads();
+        if (live) {
+            uint32_t at = cursor[p] + rank;
+            for (uint32_t w = 0; w < wid; ++w) at += wave_cnt[w][p];
+            if (at < cap) {
+                uint64_t* rec = reinterpret_cast<uint64_t*>(slots + (uint64_t)p * slot_sz + rec0) + (uint64_t)at * words;
+                rec[0] = lo;
+                if (words == 3) rec[1] = hi;
+                rec[words - 1] = (uint64_t)mn | ((uint64_t)j << 32);
+            }
+        }
+        __syncthreads();
+        if (t < parts) {
+            uint32_t add = 0;
+            for (uint32_t w = 0; w < kPartThreads / 64; ++w) add += wave_cnt[w][t];
+            cursor[t] += add;
+        }
+        __syncthreads();
+    }
+}
+
+// --- receiver ---
+struct SlotView {
+    const uint8_t* base;
+    uint64_t slot_sz, rec_off;
+    uint32_t cap, n, words, parts;
+    uint64_t fp_mask;
+};
+__device__ __forceinline__ const uint64_t* slot_rec(const SlotView& V, uint32_t e) {
+    const uint32_t s = e / V.cap, idx = e - s * V.cap;
+    return reinterpret_cast<const uint64_t*>(V.base + (uint64_t)s * V.slot_sz + V.rec_off) + (uint64_t)idx * V.words;
+}
+__device__ __forceinline__ uint64_t rec_fingerprint(const uint64_t* r, uint32_t words, uint64_t seed, uint64_t fp_mask) {
+    uint64_t f = mix64(r[0] + seed);
+    f = mix64(f ^ ((r[words - 1] & 0xffffffffull) * 0x9E3779B97F4A7C15ULL));
+    if (words == 3) f = mix64(f + r[1]);
+    f &= fp_mask;
+    return f ? f : 1;
+}
+__device__ __forceinline__ bool rec_eq(const uint64_t* a, const uint64_t* b, uint32_t words) {
+    if (a[0] != b[0] || (uint32_t)a[words - 1] != (uint32_t)b[words - 1]) return false;
+    return words == 3 ? a[1] == b[1] : true;
+}
+
+// receiver 1/3: per source slot, validate the header and turn the counts into entry ranges of the
+// GLOBAL sketch ids source * n + j (entry index space: source * slot_cap + position in the slot)
+__global__ __launch_bounds__(kPartThreads) void k_slot_index(SlotView V, uint64_t* __restrict__ sk_begin,
+                                                            uint64_t* __restrict__ sk_end, uint32_t* __restrict__ tot,
+                                                            uint32_t* __restrict__ flags) {
+    __shared__ uint32_t wave_sum[kPartThreads / 64];
+    __shared__ uint32_t s_carry;
+    const uint32_t s = blockIdx.x, t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const uint32_t* hdr = reinterpret_cast<const uint32_t*>(V.base + (uint64_t)s * V.slot_sz);
+    const bool good = hdr[0] == kSlotMagic && hdr[1] == V.n && hdr[3] == V.words;
+    const uint32_t total = good ? hdr[2] : 0u;
+    if (t == 0) {
+        s_carry = 0;
+        if (!good) atomicOr(&flags[3], 1u);
+        else if (total > V.cap) atomicOr(&flags[4], 1u);
+        tot[s] = total > V.cap ? V.cap : total;
+    }
+    __syncthreads();
+    for (uint32_t base = 0; base < V.n; base += kPartThreads) {
+        const uint32_t j = base + t;
+        const uint32_t v = (good && j < V.n) ? hdr[4 + j] : 0u;
+        uint32_t x = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d);
+            if (lane >= (uint32_t)d) x += y;
+        }
+        if (lane == 63) wave_sum[wid] = x;
+        __syncthreads();
+        uint32_t pre = s_carry, all = 0;
+        for (uint32_t w = 0; w < kPartThreads / 64; ++w) { if (w < wid) pre += wave_sum[w]; all += wave_sum[w]; }
+        if (j < V.n) {
+            // a run never reaches past the stored records, whatever the counts claim
+            const uint64_t b = (uint64_t)pre + x - v, e = b + v;
+            const uint64_t lim = total > V.cap ? V.cap : total;
+            sk_begin[(uint64_t)s * V.n + j] = (uint64_t)s * V.cap + (b < lim ? b : lim);
+            sk_end[(uint64_t)s * V.n + j] = (uint64_t)s * V.cap + (e < lim ? e : lim);
+        }
+        __syncthreads();
+        if (t == 0) s_carry += all;
+        __syncthreads();
+    }
+    if (t == 0 && good && s_carry != total) atomicOr(&flags[3], 1u);
+}
+
+// receiver 2/3 and 3/3: k_insert / k_fill over slot records (every sketch is an owned row here)
+__global__ void k_insert_slots(SlotView V, const uint32_t* __restrict__ tot, uint64_t seed, uint64_t* __restrict__ table,
+                               uint32_t log2cap, uint32_t* __restrict__ owner) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= V.parts * V.cap) return;
+    if (e % V.cap >= tot[e / V.cap]) return;
+    const uint64_t fp = rec_fingerprint(slot_rec(V, e), V.words, seed, V.fp_mask);
+    const uint64_t mask = (1ull << log2cap) - 1;
+    uint64_t pos = home_slot(fp, log2cap);
+    for (;;) {
+        const unsigned long long old = atomicCAS((unsigned long long*)&table[pos], 0ull, (unsigned long long)fp);
+        if (old == 0ull) { owner[pos] = e; break; }
+        if (old == fp) break;
+        pos = (pos + 1) & mask;
+    }
+}
+__global__ void k_fill_slots(SlotView V, const uint32_t* __restrict__ tot, uint64_t seed, const uint64_t* __restrict__ table,
+                             uint32_t log2cap, const uint32_t* __restrict__ owner, const uint32_t* __restrict__ rowid,
+                             uint32_t W, unsigned long long* __restrict__ A, uint32_t* __restrict__ row_of_entry,
+                             uint32_t* __restrict__ flags) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= V.parts * V.cap) return;
+    const uint32_t s = e / V.cap;
+    if (e - s * V.cap >= tot[s]) return;
+    const uint64_t* r = slot_rec(V, e);
+    const uint32_t local = (uint32_t)(r[V.words - 1] >> 32);
+    if (local >= V.n) { atomicOr(&flags[3], 1u); return; }
+    const uint32_t g = s * V.n + local;                       // global sketch id = colour
+    const uint64_t fp = rec_fingerprint(r, V.words, seed, V.fp_mask);
+    const uint64_t mask = (1ull << log2cap) - 1;
+    uint64_t pos = home_slot(fp, log2cap);
+    for (;;) {
+        const uint64_t v = table[pos];
+        if (v == 0) { atomicOr(&flags[3], 1u); return; }     // every record was inserted: cannot happen
+        if (v == fp) {
+            if (rec_eq(slot_rec(V, owner[pos]), r, V.words)) {
+                const uint32_t row = rowid[pos];
+                atomicOr(&A[(uint64_t)row * W + (g >> 6)], 1ull << (g & 63));
+                row_of_entry[e] = row;
+            } else {
+                atomicOr(&flags[1], 1u);                      // two distinct keys, one fingerprint: rebuild
+            }
+            return;
+        }
+        pos = (pos + 1) & mask;
+    }
+}
+
+int partition_keys_impl(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min, const uint64_t* d_lo, const uint64_t* d_hi,
+                        const uint64_t* h_sk_off, uint32_t n, uint32_t parts, uint32_t cap, uint8_t* d_slots) {
+    if (n == 0 || n > 65535) { set_error("1..65535 sketches per rank"); return SPSP_ERR_ARG; }
+    if (parts == 0 || parts > kMaxParts) { set_error("1..%u destinations", kMaxParts); return SPSP_ERR_ARG; }
+    if (cap == 0) { set_error("slot_cap must be positive"); return SPSP_ERR_ARG; }
+    if (k > 32 && !d_hi) { set_error("k=%u needs kmer_hi", k); return SPSP_ERR_ARG; }
+    if (((uintptr_t)d_slots & 7u) != 0) { set_error("d_slots must be 8-byte aligned"); return SPSP_ERR_ARG; }
+    if (h_sk_off[n] > 0xfffffff0ull) { set_error("too many sketch k-mers for one call"); return SPSP_ERR_OVERFLOW; }
+    int rc;
+    if ((rc = ctx->c_skoff.reserve((size_t)(n + 1) * 8))) return rc;
+    if ((rc = ctx->x_cnt.reserve((size_t)parts * n * 4))) return rc;
+    if ((rc = ctx->x_off.reserve((size_t)parts * n * 4))) return rc;
+    SPSP_HIP(hipMemcpyAsync(ctx->c_skoff.p, h_sk_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    Keys K{d_min, d_lo, (k > 32) ? d_hi : nullptr, ~0ull};
+    const uint64_t* sk = ctx->c_skoff.as<uint64_t>();
+    const uint32_t words = slot_words(k);
+    const uint64_t sz = slot_bytes(n, cap, k);
+    hipLaunchKernelGGL(k_part_count, dim3(n), dim3(kPartThreads), 0, ctx->stream, K, sk, n, parts, ctx->x_cnt.as<uint32_t>());
+    SPSP_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_part_offsets, dim3(parts), dim3(kPartThreads), 0, ctx->stream, ctx->x_cnt.as<uint32_t>(), n, words,
+                       d_slots, sz, ctx->x_off.as<uint32_t>());
+    SPSP_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_part_scatter, dim3(n), dim3(kPartThreads), 0, ctx->stream, K, sk, n, parts, ctx->x_off.as<uint32_t>(),
+                       d_slots, sz, cap, words);
+    SPSP_HIP(hipGetLastError());
+    return SPSP_OK;
+}
+
+int compare_slots_impl(spsp_ctx* ctx, uint32_t k, const uint8_t* d_slots, uint32_t parts, uint32_t n, uint32_t cap,
+                       uint32_t* d_inter) {
+    if (n == 0 || parts == 0 || parts > kMaxParts) { set_error("bad slot geometry"); return SPSP_ERR_ARG; }
+    const uint64_t N = (uint64_t)parts * n;
+    if (N > 65535) { set_error("at most 65535 sketches (the reference's uint32 pair key, Comparator.h:26)"); return SPSP_ERR_ARG; }
+    const uint64_t E = (uint64_t)parts * cap;
+    if (cap == 0 || E > 0xfffffff0ull) { set_error("too many sketch k-mers for one call"); return SPSP_ERR_OVERFLOW; }
+    if (((uintptr_t)d_slots & 7u) != 0) { set_error("d_slots must be 8-byte aligned"); return SPSP_ERR_ARG; }
+    int rc = ctx->ev_begin(kEvCompare);
+    if (rc) return rc;
+    auto body = [&]() -> int {
+        int r2;
+        if ((r2 = ctx->x_begin.reserve((size_t)N * 8))) return r2;
+        if ((r2 = ctx->x_end.reserve((size_t)N * 8))) return r2;
+        if ((r2 = ctx->x_tot.reserve((size_t)parts * 4))) return r2;
+        if ((r2 = ctx->c_flags.reserve(64))) return r2;
+        SPSP_HIP(hipMemsetAsync(ctx->c_flags.p, 0, 64, ctx->stream));
+        uint32_t* flags = ctx->c_flags.as<uint32_t>();
+        SlotView V{d_slots, slot_bytes(n, cap, k), slot_rec_off(n), cap, n, slot_words(k), parts, ~0ull};
+        hipLaunchKernelGGL(k_slot_index, dim3(parts), dim3(kPartThreads), 0, ctx->stream, V, ctx->x_begin.as<uint64_t>(),
+                           ctx->x_end.as<uint64_t>(), ctx->x_tot.as<uint32_t>(), flags);
+        SPSP_HIP(hipGetLastError());
+        const uint32_t* tot = ctx->x_tot.as<uint32_t>();
+        const dim3 grid((uint32_t)((E + 255) / 256));
+        ComparePlan P{E, E, (uint32_t)N, (uint32_t)N, 0, 1, (uint32_t)N, ctx->x_begin.as<uint64_t>(), ctx->x_end.as<uint64_t>(), d_inter};
+        return run_compare(
+            ctx, P,
+            [&](uint64_t seed, uint64_t fp_mask, uint32_t log2cap) -> int {
+                SlotView Vm = V; Vm.fp_mask = fp_mask;
+                hipLaunchKernelGGL(k_insert_slots, grid, dim3(256), 0, ctx->stream, Vm, tot, seed, ctx->c_table.as<uint64_t>(),
+                                   log2cap, ctx->c_owner.as<uint32_t>());
+                SPSP_HIP(hipGetLastError());
+                return SPSP_OK;
+            },
+            [&](uint64_t seed, uint64_t fp_mask, uint32_t log2cap, uint32_t W) -> int {
+                SlotView Vm = V; Vm.fp_mask = fp_mask;
+                hipLaunchKernelGGL(k_fill_slots, grid, dim3(256), 0, ctx->stream, Vm, tot, seed, ctx->c_table.as<uint64_t>(), log2cap,
+                                   ctx->c_owner.as<uint32_t>(), ctx->c_rowid.as<uint32_t>(), W,
+                                   ctx->c_matrix.as<unsigned long long>(), ctx->c_row.as<uint32_t>(), flags);
+                SPSP_HIP(hipGetLastError());
+                return SPSP_OK;
+            });
+    };
+    rc = body();
+    const int rc2 = ctx->ev_end(kEvCompare);
+    return rc ? rc : rc2;
 }
 
 int compare_device_impl(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min, const uint64_t* d_lo,
@@ -365,6 +718,24 @@ int spsp_compare_device(spsp_ctx* ctx, uint32_t k, const void* d_minimizer, cons
     SPSP_HIP(hipSetDevice(ctx->device));
     return compare_device_impl(ctx, k, (const uint32_t*)d_minimizer, (const uint64_t*)d_kmer_lo,
                                (const uint64_t*)d_kmer_hi, h_sk_off, n, n_query, row_first, row_stride, (uint32_t*)d_inter);
+}
+
+uint64_t spsp_slot_bytes(uint32_t n, uint32_t slot_cap, uint32_t k) { return slot_bytes(n, slot_cap, k); }
+
+int spsp_partition_keys_device(spsp_ctx* ctx, uint32_t k, const void* d_minimizer, const void* d_kmer_lo,
+                               const void* d_kmer_hi, const uint64_t* h_sk_off, uint32_t n, uint32_t parts,
+                               uint32_t slot_cap, void* d_slots) {
+    if (!ctx || !h_sk_off || !d_slots) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    SPSP_HIP(hipSetDevice(ctx->device));
+    return partition_keys_impl(ctx, k, (const uint32_t*)d_minimizer, (const uint64_t*)d_kmer_lo, (const uint64_t*)d_kmer_hi,
+                               h_sk_off, n, parts, slot_cap, (uint8_t*)d_slots);
+}
+
+int spsp_compare_slots_device(spsp_ctx* ctx, uint32_t k, const void* d_slots, uint32_t parts, uint32_t n,
+                              uint32_t slot_cap, void* d_inter) {
+    if (!ctx || !d_slots || !d_inter) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    SPSP_HIP(hipSetDevice(ctx->device));
+    return compare_slots_impl(ctx, k, (const uint8_t*)d_slots, parts, n, slot_cap, (uint32_t*)d_inter);
 }
 
 int spsp_compare(spsp_ctx* ctx, const spsp_sketch_view* sk, uint32_t n, uint32_t n_query, uint32_t* inter,

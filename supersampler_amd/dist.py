@@ -1,12 +1,21 @@
 """Multi-GPU plumbing for the all-vs-all comparison.
 
 One process per GPU.  Sketching shards genomes by rank with no collective.  The
-comparison has ONE exchange step: an all-gather of the packed sketch keys, after
-which every rank holds all sketches and owns the pair-matrix rows
-`i % world == rank` (round-robin rows balance the upper triangle).  Works with
-backend "nccl" (= RCCL over xGMI, device tensors) and "gloo" (CPU tensors, used
-by the CPU tests).
+comparison has ONE key exchange step, in two forms:
+
+* `SlotExchange` (default): keys are partitioned by hash, every rank sends each
+  of its keys once (all-to-all of fixed-size slots), counts its hash class for
+  ALL pairs and the partial matrices are summed (all-reduce).  Per-rank traffic
+  and table size stay O(own keys) as ranks are added.
+* `KeyExchange`: an all-gather of the packed keys, after which every rank holds
+  all sketches and owns the pair-matrix rows `i % world == rank`.  O(all keys)
+  per rank; kept for query mode and as the simple form.
+
+Both work with backend "nccl" (= RCCL over xGMI, device tensors) and "gloo"
+(CPU tensors, used by the CPU tests).
 """
+import math
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -86,3 +95,88 @@ def merge_rows(inter_local, n_total, rank, world, group=None):
     t = inter_local.clone()
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
+
+
+class SlotExchange:
+    """Key-partitioned exchange (include/spsp.h "multi-GPU exchange").
+
+    begin(): spsp_partition_keys_device -> all-to-all of one fixed-size slot per peer (asynchronous with
+             nccl, so the caller can queue other GPU work -- e.g. the next scan -- behind it);
+    end():   wait, spsp_compare_slots_device on the received slots, all-reduce of the partial matrices.
+    Every rank must hold the same number of sketches `n_local`; global sketch id = rank * n_local + local id.
+    """
+
+    def __init__(self, ctx, k, n_local, n_keys_local, device, slack=1.25, group=None):
+        self.ctx, self.k, self.n_local, self.device, self.group = ctx, k, n_local, device, group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.backend = dist.get_backend(group)
+        # all ranks must agree on the slot size: size it for the largest rank
+        t = torch.tensor([int(n_keys_local), int(n_local)], dtype=torch.int64, device=self._comm_device())
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        if int(t[1].item()) != n_local:
+            raise ValueError("every rank must hold the same number of sketches")
+        self.max_keys = int(t[0].item())
+        self.slot_cap = self.max_keys if self.world == 1 else int(math.ceil(self.max_keys / self.world * slack)) + 1024
+        self._alloc()
+
+    def _comm_device(self):
+        return self.device if self.backend == "nccl" else torch.device("cpu")
+
+    def _alloc(self):
+        from . import slot_bytes
+        self.slot_bytes = slot_bytes(self.n_local, self.slot_cap, self.k)
+        self.send = torch.zeros(self.world * self.slot_bytes, dtype=torch.uint8, device=self.device)
+        self.recv = torch.zeros(self.world * self.slot_bytes, dtype=torch.uint8, device=self.device)
+
+    @property
+    def n_total(self):
+        return self.n_local * self.world
+
+    def grow(self):
+        """After an overflow (every rank calls this together): double the slots."""
+        self.slot_cap *= 2
+        self._alloc()
+
+    def begin(self, d_min, d_lo, d_hi, sk_off):
+        """device pointers of this rank's concatenated keys + host sk_off (n_local+1) -> handle for end()"""
+        self.ctx.partition_keys_device(self.k, d_min, d_lo, d_hi, sk_off, self.n_local, self.world, self.slot_cap,
+                                       self.send.data_ptr())
+        if self.backend == "nccl":
+            return dist.all_to_all_single(self.recv, self.send, group=self.group, async_op=True)
+        if self.send.is_cuda:   # gloo with GPU compute (tests): stage through the host
+            torch.cuda.synchronize()
+            h_send, h_recv = self.send.cpu(), torch.empty(self.send.numel(), dtype=torch.uint8)
+            dist.all_to_all_single(h_recv, h_send, group=self.group)
+            self.recv.copy_(h_recv)
+            torch.cuda.synchronize()
+        else:
+            dist.all_to_all_single(self.recv, self.send, group=self.group)
+        return None
+
+    def end(self, handle, d_inter):
+        """d_inter: zero-initialised int32 [n_total, n_total] device tensor -> summed over ranks in place.
+        Cell [0, 0] (unused by the pair matrix) counts the ranks whose slots overflowed: see overflowed()."""
+        from . import SpspError, ERR_OVERFLOW
+        if handle is not None:
+            handle.wait()
+        try:
+            self.ctx.compare_slots_device(self.k, self.recv.data_ptr(), self.world, self.n_local, self.slot_cap,
+                                          d_inter.data_ptr())
+        except SpspError as e:
+            if e.code != ERR_OVERFLOW:
+                raise
+            d_inter.view(-1)[0] += 1
+        if self.backend == "nccl" or not d_inter.is_cuda:
+            dist.all_reduce(d_inter, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            torch.cuda.synchronize()
+            h = d_inter.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            d_inter.copy_(h)
+            torch.cuda.synchronize()
+
+    @staticmethod
+    def overflowed(d_inter):
+        """Host check (synchronises): did any rank report a slot overflow in the last end()?"""
+        return int(d_inter.view(-1)[0].item()) != 0

@@ -4,6 +4,10 @@ mode cpu: gloo, CPU tensors; the key exchange and the row partition are real,
           the per-row intersections are plain numpy set algebra (no GPU here).
 mode gpu: gloo for the exchange, then every rank calls spsp_compare_device on
           the GPU for its own rows (two processes share the one test GPU).
+mode cpu_slots / gpu_slots: the key-partitioned exchange (SlotExchange): all-to-all
+          of fixed-size slots + all-reduce of partial matrices.  On the CPU the
+          slots are built and counted by a numpy stand-in (the layout and the
+          collectives are what is tested); on the GPU by the real kernels.
 Rank 0 checks the merged matrix against the oracle and exits non-zero on a
 mismatch."""
 import os
@@ -21,6 +25,88 @@ from supersampler_amd import dist as spd  # noqa: E402
 from supersampler_amd import synth  # noqa: E402
 
 
+def np_build_slots(minimizer, kmer_lo, counts, world, cap, n_local):
+    """numpy stand-in for spsp_partition_keys_device (k <= 32): same wire format, any deterministic hash"""
+    sb = sp.slot_bytes(n_local, cap, 31)
+    rec_off = 16 + ((n_local + 1) & ~1) * 4
+    out = np.zeros((world, sb), dtype=np.uint8)
+    dest = ((kmer_lo * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(40)) % np.uint64(world)
+    sk_of = np.repeat(np.arange(n_local), counts)
+    for d in range(world):
+        sel = dest == d
+        hdr = out[d, :16].view(np.uint32)
+        hdr[:] = [0x4C535053, n_local, int(sel.sum()), 2]
+        out[d, 16:16 + 4 * n_local].view(np.uint32)[:] = np.bincount(sk_of[sel], minlength=n_local)
+        rec = out[d, rec_off:].view(np.uint64).reshape(cap, 2)
+        m = int(sel.sum())
+        rec[:m, 0] = kmer_lo[sel]
+        rec[:m, 1] = minimizer[sel].astype(np.uint64) | (sk_of[sel].astype(np.uint64) << np.uint64(32))
+    return out.reshape(-1)
+
+
+def np_partial_from_slots(recv, world, cap, n_local):
+    """numpy stand-in for spsp_compare_slots_device: partial pair matrix of the received hash class"""
+    sb = sp.slot_bytes(n_local, cap, 31)
+    rec_off = 16 + ((n_local + 1) & ~1) * 4
+    recv = recv.reshape(world, sb)
+    n_total = world * n_local
+    sets = [set() for _ in range(n_total)]
+    for s in range(world):
+        hdr = recv[s, :16].view(np.uint32)
+        assert hdr[0] == 0x4C535053 and hdr[1] == n_local and hdr[2] <= cap
+        rec = recv[s, rec_off:].view(np.uint64).reshape(cap, 2)[:int(hdr[2])]
+        for lo, w in rec.tolist():
+            sets[s * n_local + (w >> 32)].add((w & 0xFFFFFFFF, lo))
+    part = torch.zeros((n_total, n_total), dtype=torch.int32)
+    for i in range(n_total):
+        for j in range(i + 1, n_total):
+            part[i, j] = len(sets[i] & sets[j])
+    return part
+
+
+def main_slots(mode, rank, world, k, payloads, mine, counts, my_min, my_lo, per_rank):
+    n_total = per_rank * world
+    sk_off = np.zeros(per_rank + 1, dtype=np.uint64)
+    sk_off[1:] = np.cumsum(counts)
+    if mode == "gpu_slots":
+        dev = torch.device("cuda", 0)
+        ctx = sp.Context(0)
+        ex = spd.SlotExchange(ctx, k, per_rank, int(sk_off[-1]), dev)
+        d_min, d_lo = my_min.to(dev), my_lo.to(dev)
+        d_inter = torch.zeros((n_total, n_total), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        for _ in range(2):                                   # twice: buffers are reused step after step
+            h = ex.begin(d_min.data_ptr(), d_lo.data_ptr(), None, sk_off)
+            ex.end(h, d_inter)
+        assert not ex.overflowed(d_inter)
+        merged = d_inter.cpu()
+        # an undersized exchange is noticed by every rank, and growing it fixes it
+        small = spd.SlotExchange(ctx, k, per_rank, int(sk_off[-1]), dev)
+        small.slot_cap = 8
+        small._alloc()
+        d2 = torch.zeros_like(d_inter)
+        small.end(small.begin(d_min.data_ptr(), d_lo.data_ptr(), None, sk_off), d2)
+        assert small.overflowed(d2)
+        while small.overflowed(d2):
+            small.grow()
+            d2.zero_()
+            small.end(small.begin(d_min.data_ptr(), d_lo.data_ptr(), None, sk_off), d2)
+        assert bool((d2.cpu() == merged).all())
+        ctx.close()
+    else:
+        ex = spd.SlotExchange(None, k, per_rank, int(sk_off[-1]), torch.device("cpu"))
+        ex.send.copy_(torch.from_numpy(np_build_slots(my_min.numpy().view(np.uint32), my_lo.numpy().view(np.uint64),
+                                                     np.asarray(counts), world, ex.slot_cap, per_rank)))
+        dist.all_to_all_single(ex.recv, ex.send)
+        merged = np_partial_from_slots(ex.recv.numpy(), world, ex.slot_cap, per_rank)
+        dist.all_reduce(merged, op=dist.ReduceOp.SUM)
+    ok = True
+    if rank == 0:
+        want, card, _, _ = orc.compare(payloads)
+        ok = bool((merged.numpy().astype(np.uint32) == want).all()) and int(want.sum()) > 0
+    return ok
+
+
 def main():
     mode = sys.argv[1]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -33,6 +119,11 @@ def main():
     my_min = torch.from_numpy(np.concatenate([x.minimizer for x in mine]).view(np.int32))
     my_lo = torch.from_numpy(np.concatenate([x.kmer_lo for x in mine]).view(np.int64))
     n_total = per_rank * world
+    if mode.endswith("_slots"):
+        ok = main_slots(mode, rank, world, k, payloads, mine, counts, my_min, my_lo, per_rank)
+        dist.barrier()
+        dist.destroy_process_group()
+        sys.exit(0 if ok else 1)
     if mode == "gpu":
         dev = torch.device("cuda", 0)
         ex = spd.KeyExchange(counts, torch.device("cpu"))

@@ -27,6 +27,15 @@ def test_key_exchange_and_row_partition_gloo_cpu():
     _launch("cpu", 29611)
 
 
+def test_slot_exchange_and_partial_sum_gloo_cpu():
+    _launch("cpu_slots", 29613)
+
+
 @pytest.mark.gpu
 def test_two_ranks_compare_device_rows():
     _launch("gpu", 29612)
+
+
+@pytest.mark.gpu
+def test_two_ranks_key_partitioned_exchange():
+    _launch("gpu_slots", 29614)

@@ -1,0 +1,220 @@
+"""GPU tests of the key-partitioned multi-GPU exchange (include/spsp.h "multi-GPU exchange"), with the
+all-to-all played in-process: `world` ranks are partitioned one after another on the one test GPU, their
+slots transposed on the host exactly as the collective would, every rank's partial matrix computed by
+spsp_compare_slots_device and the partials summed.  The sum must equal plain set algebra (and the
+single-GPU spsp_compare), whatever the number of ranks."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import supersampler_amd as sp
+
+torch = pytest.importorskip("torch")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+MAGIC = 0x4C535053
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = sp.Context(0)
+    yield c
+    c.close()
+
+
+def make_sets(rng, n, use_hi, universe_size=4000):
+    universe = [(int(rng.integers(0, 2**22)), int(rng.integers(0, 2**62)) if use_hi else 0, int(rng.integers(0, 2**62)))
+                for _ in range(universe_size)]
+    universe += [(u[0] ^ 1, u[1], u[2]) for u in universe[:50]]      # same k-mer, another minimizer: another key
+    sets = []
+    for i in range(n):
+        if i % 13 == 5:
+            sets.append(set())
+        elif i % 7 == 3:
+            sets.append(set(sets[i - 1]))
+        else:
+            pick = rng.random(len(universe)) < rng.choice([0.02, 0.1, 0.4])
+            sets.append({universe[j] for j in np.nonzero(pick)[0]})
+    return sets
+
+
+def rank_arrays(sets):
+    """sorted key arrays of one rank's sketches, concatenated, + offsets"""
+    keys = [sorted(st) for st in sets]
+    off = np.zeros(len(sets) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(x) for x in keys])
+    flat = [x for ks in keys for x in ks]
+    mn = np.array([x[0] for x in flat], dtype=np.uint32)
+    hi = np.array([x[1] for x in flat], dtype=np.uint64)
+    lo = np.array([x[2] for x in flat], dtype=np.uint64)
+    return mn, lo, hi, off
+
+
+def partition(ctx, k, mn, lo, hi, off, n_local, world, cap):
+    dev = torch.device("cuda", 0)
+    d_mn = torch.from_numpy(mn.view(np.int32)).to(dev)
+    d_lo = torch.from_numpy(lo.view(np.int64)).to(dev)
+    d_hi = torch.from_numpy(hi.view(np.int64)).to(dev)
+    sb = sp.slot_bytes(n_local, cap, k)
+    d_slots = torch.full((world * sb,), 0xEE, dtype=torch.uint8, device=dev)    # stale bytes must not matter
+    torch.cuda.synchronize()
+    ctx.partition_keys_device(k, d_mn.data_ptr(), d_lo.data_ptr(), d_hi.data_ptr() if k > 32 else None, off, n_local,
+                              world, cap, d_slots.data_ptr())
+    out = ctx.to_host(d_slots.data_ptr(), world * sb, np.uint8)                 # drains the context's stream
+    return out.reshape(world, sb)
+
+
+def parse_slot(slot, n_local, cap, k):
+    """-> (per-sketch key lists in stored order, n_keys in the header)"""
+    hdr = slot[:16].view(np.uint32)
+    assert hdr[0] == MAGIC and hdr[1] == n_local and hdr[3] == (3 if k > 32 else 2)
+    cnt = slot[16:16 + 4 * n_local].view(np.uint32)
+    words = int(hdr[3])
+    rec_off = 16 + ((n_local + 1) & ~1) * 4
+    rec = slot[rec_off:rec_off + cap * words * 8].view(np.uint64).reshape(cap, words)
+    out, at = [], 0
+    for j in range(n_local):
+        c = int(cnt[j])
+        rows = rec[at:min(at + c, cap)]
+        assert all(int(r[-1]) >> 32 == j for r in rows)
+        out.append([(int(r[-1]) & 0xFFFFFFFF, int(r[1]) if words == 3 else 0, int(r[0])) for r in rows])
+        at += c
+    assert at == int(hdr[2])
+    return out, int(hdr[2])
+
+
+def exchange_and_compare(ctx, k, per_rank_sets, cap):
+    world, n_local = len(per_rank_sets), len(per_rank_sets[0])
+    sent = [partition(ctx, k, *rank_arrays(sets), n_local, world, cap) for sets in per_rank_sets]
+    dev = torch.device("cuda", 0)
+    n_total = world * n_local
+    total = np.zeros((n_total, n_total), dtype=np.int64)
+    for d in range(world):
+        recv = np.concatenate([sent[s][d] for s in range(world)])               # what the all-to-all delivers to rank d
+        d_recv = torch.from_numpy(recv).to(dev)
+        d_inter = torch.zeros((n_total, n_total), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        ctx.compare_slots_device(k, d_recv.data_ptr(), world, n_local, cap, d_inter.data_ptr())
+        torch.cuda.synchronize()
+        total += d_inter.cpu().numpy()
+    return sent, total
+
+
+@pytest.mark.parametrize("world,n_local,use_hi", [(1, 5, False), (2, 7, False), (3, 11, True), (8, 9, False), (4, 40, True)])
+def test_partitioned_compare_equals_set_algebra(ctx, world, n_local, use_hi):
+    rng = np.random.default_rng(world * 100 + n_local)
+    k = 63 if use_hi else 31
+    sets = make_sets(rng, world * n_local, use_hi)
+    per_rank = [sets[r * n_local:(r + 1) * n_local] for r in range(world)]
+    biggest = max(sum(len(s) for s in pr) for pr in per_rank)
+    cap = biggest if world == 1 else int(biggest / world * 1.3) + 64
+    sent, total = exchange_and_compare(ctx, k, per_rank, cap)
+    n_total = world * n_local
+    for i in range(n_total):
+        for j in range(n_total):
+            want = len(sets[i] & sets[j]) if j > i else 0
+            assert total[i, j] == want, (i, j, int(total[i, j]), want)
+    # wire format: every key of every sketch sits in exactly one slot, grouped by sketch, in sorted order,
+    # and equal keys of different ranks land in the same destination
+    where = {}
+    for r in range(world):
+        got = [[] for _ in range(n_local)]
+        for d in range(world):
+            per_sketch, n_keys = parse_slot(sent[r][d], n_local, cap, k)
+            assert n_keys <= cap
+            for j, keys in enumerate(per_sketch):
+                assert keys == sorted(keys)
+                got[j] += keys
+                for key in keys:
+                    assert where.setdefault(key, d) == d
+        for j in range(n_local):
+            assert sorted(got[j]) == sorted(per_rank[r][j])
+            assert len(got[j]) == len(per_rank[r][j])
+    if world > 1:   # the hash spreads the keys: no slot far from its share
+        sizes = [parse_slot(sent[r][d], n_local, cap, k)[1] for r in range(world) for d in range(world)]
+        assert max(sizes) <= cap
+
+
+def test_partitioned_compare_matches_single_gpu_compare(ctx):
+    """the same sketches through spsp_compare (one GPU) and through 4 simulated ranks"""
+    rng = np.random.default_rng(5)
+    world, n_local = 4, 6
+    sets = make_sets(rng, world * n_local, False, universe_size=20000)
+    sketches = []
+    for st in sets:
+        keys = sorted(st)
+        sketches.append(sp.Sketch(31, 11, np.array([x[0] for x in keys], np.uint32), np.array([x[2] for x in keys], np.uint64),
+                                  np.array([x[1] for x in keys], np.uint64)))
+    inter, _ = ctx.compare(sketches)
+    per_rank = [sets[r * n_local:(r + 1) * n_local] for r in range(world)]
+    cap = int(max(sum(len(s) for s in pr) for pr in per_rank) / world * 1.3) + 64
+    _, total = exchange_and_compare(ctx, 31, per_rank, cap)
+    assert (total == inter.astype(np.int64)).all() and total.sum() > 0
+
+
+def test_slot_overflow_is_reported_and_a_larger_cap_succeeds(ctx):
+    rng = np.random.default_rng(9)
+    sets = make_sets(rng, 8, False)
+    per_rank = [sets[:4], sets[4:]]
+    with pytest.raises(sp.SpspError) as e:
+        exchange_and_compare(ctx, 31, per_rank, 100)      # far too small: slots keep 100 keys and say so
+    assert e.value.code == sp.ERR_OVERFLOW
+    _, total = exchange_and_compare(ctx, 31, per_rank, 4000)
+    assert all(total[i, j] == len(sets[i] & sets[j]) for i in range(8) for j in range(i + 1, 8))
+
+
+def test_malformed_slots_are_rejected(ctx):
+    rng = np.random.default_rng(10)
+    sets = make_sets(rng, 6, False)
+    n_local, world, cap, k = 3, 2, 3000, 31
+    sent = [partition(ctx, k, *rank_arrays(sets[r * 3:(r + 1) * 3]), n_local, world, cap) for r in range(2)]
+    dev = torch.device("cuda", 0)
+    d_inter = torch.zeros((6, 6), dtype=torch.int32, device=dev)
+
+    def run(recv):
+        d = torch.from_numpy(recv).to(dev)
+        torch.cuda.synchronize()
+        ctx.compare_slots_device(k, d.data_ptr(), world, n_local, cap, d_inter.data_ptr())
+
+    good = np.concatenate([sent[0][0], sent[1][0]])
+    run(good)
+    for corrupt in ("magic", "n", "count", "sketch"):
+        bad = good.copy()
+        h = bad[:16].view(np.uint32)
+        if corrupt == "magic":
+            h[0] ^= 1
+        elif corrupt == "n":
+            h[1] += 1
+        elif corrupt == "count":
+            bad[16:20].view(np.uint32)[0] += 1            # counts no longer add up to n_keys
+        else:
+            rec_off = 16 + ((n_local + 1) & ~1) * 4
+            bad[rec_off + 8:rec_off + 16].view(np.uint64)[0] |= np.uint64(77) << np.uint64(32)   # sketch id out of range
+        with pytest.raises(sp.SpspError):
+            run(bad)
+    with pytest.raises(sp.SpspError):
+        ctx.compare_slots_device(k, 0, world, n_local, cap, d_inter.data_ptr())
+    with pytest.raises(sp.SpspError):
+        ctx.partition_keys_device(k, 1, 1, None, np.zeros(4, np.uint64), 3, 65, cap, 8)     # too many destinations
+
+
+def test_partitioned_compare_collision_retry():
+    """fingerprints cut to 8 bits on the first attempt: the slot form detects the collisions and rebuilds"""
+    code = (
+        "import sys\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np, torch\n"
+        "import supersampler_amd as sp\n"
+        "import test_exchange as tx\n"
+        "ctx = sp.Context(0)\n"
+        "sets = tx.make_sets(np.random.default_rng(3), 6, False)\n"
+        "_, total = tx.exchange_and_compare(ctx, 31, [sets[:3], sets[3:]], 4000)\n"
+        "assert all(total[i, j] == len(sets[i] & sets[j]) for i in range(6) for j in range(i + 1, 6))\n"
+        "print('ok')\n") % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SPSP_DEBUG_FP_BITS="8"), capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
