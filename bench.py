@@ -19,8 +19,13 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch  # device memory, streams, torch.distributed -- plumbing (imported before libspsp, see package docstring)
+# The pipelined step keeps several HIP streams busy at once (scan, comparison, RCCL's own stream). The runtime maps
+# streams onto 4 hardware queues by default; two streams sharing a queue serialise (a kernel waiting on an event blocks
+# whatever is queued behind it), which cost the multi-GPU step ~0.1 ms in rehearsal. Must be set before HIP starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402  device memory, streams, torch.distributed -- plumbing (imported before libspsp, see package docstring)
 import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -79,6 +84,16 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     ctx = sp.Context(local_rank, stream.cuda_stream)
+    # Pipelined step (default): the scan of one batch and the all-vs-all of the previous batch's sketches are
+    # independent, so they are queued on TWO HIP streams (two contexts, the begin/end forms of the ABI): the dense
+    # pass has the GPU to itself, then the latency-bound sparse stages of the scan and the comparison fill each
+    # other's idle CUs.  BENCH_PIPELINE=0 runs the two halves back to back on one stream.
+    pipelined = os.environ.get("BENCH_PIPELINE", "1") != "0"
+    if pipelined:
+        stream_b = torch.cuda.Stream(device=dev)
+        ctx_cmp = sp.Context(local_rank, stream_b.cuda_stream)
+    else:
+        stream_b, ctx_cmp = stream, ctx
 
     # ------------------------------------------------------------------ setup (untimed)
     t_setup = time.time()
@@ -113,7 +128,7 @@ def main():
     my_sk_off[1:] = np.cumsum(my_n)
     exchange_kind = os.environ.get("BENCH_EXCHANGE", "slots") if use_dist else "none"
     if exchange_kind == "slots":      # key-partitioned: all-to-all of own keys + all-reduce of partial matrices
-        exchange = spd.SlotExchange(ctx, K, args.genomes, int(my_sk_off[-1]), dev)
+        exchange = spd.SlotExchange(ctx_cmp, K, args.genomes, int(my_sk_off[-1]), dev)
         sk_off = np.zeros(n_total + 1, dtype=np.uint64)
         sk_off[-1] = exchange.max_keys * world           # log line only
     elif exchange_kind == "gather":   # all-gather of every rank's keys + strided row ownership
@@ -130,21 +145,48 @@ def main():
         log("setup %.1fs: %d genomes x %d bp per GPU, %d records, %d k-mers/step/GPU, %d sketch keys, %d pairs"
             % (time.time() - t_setup, args.genomes, args.length, len(recs), kmers_per_step, int(sk_off[-1]), pairs_per_step))
 
-    def step():
-        if exchange_kind == "slots":
-            # the key exchange (RCCL all-to-all over xGMI) is queued first and runs behind the scan kernels
-            h = exchange.begin(d_my_min.data_ptr(), d_my_lo.data_ptr(), None, my_sk_off)
-            d_out, n_out = ctx.scan_device(p, d_bases.data_ptr(), d_bases.numel(), d_off.data_ptr(), len(recs))
-            exchange.end(h, d_inter)                     # partial pair matrix + all-reduce
-            return n_out
-        d_out, n_out = ctx.scan_device(p, d_bases.data_ptr(), d_bases.numel(), d_off.data_ptr(), len(recs))
-        if exchange_kind == "gather":
-            g = exchange.exchange(d_my_min, d_my_lo)
-            mn_ptr, lo_ptr = g.minimizer.data_ptr(), g.kmer_lo.data_ptr()
-        else:
-            mn_ptr, lo_ptr = d_all_min.data_ptr(), d_all_lo.data_ptr()
-        ctx.compare_device(K, mn_ptr, lo_ptr, None, sk_off, n_total, rank, world, d_inter.data_ptr())
-        return n_out
+    def run_steps(n):
+        """n steps = n scans + n comparisons"""
+        n_out = 0
+        for _ in range(n):
+            if not pipelined:
+                # one stream: the key exchange (RCCL all-to-all) is queued first and runs behind the scan kernels
+                h = exchange.begin(d_my_min.data_ptr(), d_my_lo.data_ptr(), None, my_sk_off) if exchange_kind == "slots" else None
+                d_out, n_out = ctx.scan_device(p, d_bases.data_ptr(), d_bases.numel(), d_off.data_ptr(), len(recs))
+                if exchange_kind == "slots":
+                    exchange.end(h, d_inter)             # partial pair matrix + RCCL all-reduce
+                    continue
+                if exchange_kind == "gather":
+                    g = exchange.exchange(d_my_min, d_my_lo)
+                    mn_ptr, lo_ptr = g.minimizer.data_ptr(), g.kmer_lo.data_ptr()
+                else:
+                    mn_ptr, lo_ptr = d_all_min.data_ptr(), d_all_lo.data_ptr()
+                ctx.compare_device(K, mn_ptr, lo_ptr, None, sk_off, n_total, rank, world, d_inter.data_ptr())
+                continue
+            # two streams, one host thread: everything is queued before anything is waited for
+            ctx.scan_device_begin(p, d_bases.data_ptr(), d_bases.numel(), d_off.data_ptr(), len(recs))      # stream A
+            with torch.cuda.stream(stream_b):            # key partition + RCCL all-to-all, queued while the dense pass runs
+                h = exchange.begin(d_my_min.data_ptr(), d_my_lo.data_ptr(), None, my_sk_off) if exchange_kind == "slots" else None
+            ctx_cmp.wait_dense(ctx)                      # the comparison itself starts behind A's dense pass
+            with torch.cuda.stream(stream_b):
+                if exchange_kind == "slots":
+                    exchange.end_queue(h, d_inter)
+                else:
+                    if exchange_kind == "gather":
+                        g = exchange.exchange(d_my_min, d_my_lo)
+                        mn_ptr, lo_ptr = g.minimizer.data_ptr(), g.kmer_lo.data_ptr()
+                    else:
+                        mn_ptr, lo_ptr = d_all_min.data_ptr(), d_all_lo.data_ptr()
+                    ctx_cmp.compare_device_begin(K, mn_ptr, lo_ptr, None, sk_off, n_total, rank, world, d_inter.data_ptr())
+            d_out, n_out = ctx.scan_device_end()
+            with torch.cuda.stream(stream_b):
+                if exchange_kind == "slots":
+                    exchange.end_collect(d_inter)
+                else:
+                    ctx_cmp.compare_end()
+        last["n_out"] = n_out
+
+    last = {"n_out": 0}
 
     def fence():
         torch.cuda.synchronize()
@@ -152,18 +194,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    ctx.timing_enable(True)
-    ctx.timing_read()
+    run_steps(args.warmup)
+    for c in {ctx, ctx_cmp}:
+        c.timing_enable(True)
+        c.timing_read()
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        n_out = step()
+    run_steps(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
+    n_out = last["n_out"]
     tm = ctx.timing_read()
-    ctx.timing_enable(False)
+    tm_c = ctx_cmp.timing_read() if ctx_cmp is not ctx else tm
+    for key in ("compare_ms", "compare_calls", "accumulate_ms", "accumulate_launches"):
+        tm[key] = tm_c[key]
+    for c in {ctx, ctx_cmp}:
+        c.timing_enable(False)
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     agg = torch.tensor([float(kmers_per_step), tm["dense_ms"], tm["compare_ms"], tm["scan_ms"], tm["accumulate_ms"]],
@@ -227,7 +273,9 @@ def main():
                                                 "the scan, per-rank partial pair matrix, RCCL all-reduce",
                                        "gather": "genomes sharded by rank; pair-matrix rows i%N==rank after RCCL all-gather of "
                                                  "sketch keys"}[exchange_kind],
-                       "exchange_check": exchange_check},
+                       "exchange_check": exchange_check,
+                       "step": ("scan(batch t) on stream A || all-vs-all(sketches of batch t-1) on stream B" if pipelined
+                                else "scan then all-vs-all on one stream")},
             "sketch_pairs_per_s": pairs_per_step / (compare_avg_ms / 1e3) if compare_avg_ms > 0 else None,
             "stage_ms": {"scan_pipeline": scan_ms / max(1, tm["scan_calls"]), "dense_kernel": dense_avg_ms,
                          "compare_pipeline": compare_avg_ms, "accumulate_kernel": acc_ms / max(1, tm["accumulate_launches"])},

@@ -121,6 +121,18 @@ int spsp_scan(spsp_ctx* ctx, const spsp_params* p, const uint8_t* bases, const u
 int spsp_scan_device(spsp_ctx* ctx, const spsp_params* p, const void* d_bases, uint64_t n_bases,
                      const void* d_rec_off, uint32_t n_rec, void** d_out, uint64_t* n_out);
 
+/* The same call split at its host synchronisation, for callers that pipeline several streams (one context
+ * per stream): _begin queues the whole scan on the context's stream and returns at once; _end waits for it,
+ * and re-runs the affected stages in the rare call whose hit / super-k-mer buffers overflowed.  One scan
+ * may be pending per context.  d_bases / d_rec_off must stay valid until _end returns. */
+int spsp_scan_device_begin(spsp_ctx* ctx, const spsp_params* p, const void* d_bases, uint64_t n_bases,
+                           const void* d_rec_off, uint32_t n_rec);
+int spsp_scan_device_end(spsp_ctx* ctx, void** d_out, uint64_t* n_out);
+/* Stream ordering between two contexts of one device: work queued on `waiter` after this call starts only
+ * once the dense pass of `scanner`'s most recently queued scan has finished (the dense pass fills every CU;
+ * latency-bound work of another stream overlaps best with the sparse stages behind it). */
+int spsp_wait_dense(spsp_ctx* waiter, spsp_ctx* scanner);
+
 /* Dense stage only (hash + threshold + hit bitmap), for the roofline
  * measurement: returns the number of m-mers with hash <= threshold. */
 int spsp_scan_hits_device(spsp_ctx* ctx, const spsp_params* p, const void* d_bases, uint64_t n_bases,
@@ -170,6 +182,18 @@ int spsp_partition_keys_device(spsp_ctx* ctx, uint32_t k, const void* d_minimize
  * one synchronisation of the context's stream (format / overflow / collision flags). */
 int spsp_compare_slots_device(spsp_ctx* ctx, uint32_t k, const void* d_slots, uint32_t parts, uint32_t n,
                               uint32_t slot_cap, void* d_inter);
+
+/* spsp_compare_device / spsp_compare_slots_device split at their host synchronisation (see
+ * spsp_scan_device_begin): _begin queues the dictionary build, colour matrix and row sums and returns;
+ * spsp_compare_end waits, checks the input / collision flags and, after a fingerprint collision, rebuilds
+ * with a new seed.  One comparison may be pending per context; h_sk_off is copied before _begin returns,
+ * the device arrays must stay valid until spsp_compare_end returns. */
+int spsp_compare_device_begin(spsp_ctx* ctx, uint32_t k, const void* d_minimizer, const void* d_kmer_lo,
+                              const void* d_kmer_hi, const uint64_t* h_sk_off, uint32_t n, uint32_t n_query,
+                              uint32_t row_first, uint32_t row_stride, void* d_inter);
+int spsp_compare_slots_device_begin(spsp_ctx* ctx, uint32_t k, const void* d_slots, uint32_t parts, uint32_t n,
+                                    uint32_t slot_cap, void* d_inter);
+int spsp_compare_end(spsp_ctx* ctx);
 
 /* --------------------------------------------- host side of the two CLIs -- */
 /* getLineFasta + clean_dna (utils.cpp:675-718) over an already gunzipped

@@ -57,8 +57,8 @@ SUPERKMER_DTYPE = np.dtype([("rec", "<u4"), ("minimizer", "<u4"), ("start", "<u8
 # every symbol include/spsp.h declares (tests check the .so exports them all)
 ABI_SYMBOLS = [
     "spsp_create", "spsp_destroy", "spsp_last_error", "spsp_version", "spsp_free", "spsp_copy_to_host",
-    "spsp_timing_enable", "spsp_timing_read", "spsp_threshold_host", "spsp_scan", "spsp_scan_device", "spsp_scan_hits_device", "spsp_compare",
-    "spsp_compare_device", "spsp_slot_bytes", "spsp_partition_keys_device", "spsp_compare_slots_device", "spsp_fasta_clean_host", "spsp_fasta_clean_device", "spsp_sketch_text", "spsp_sketch_build_host", "spsp_sketch_parse_host",
+    "spsp_timing_enable", "spsp_timing_read", "spsp_threshold_host", "spsp_scan", "spsp_scan_device", "spsp_scan_device_begin", "spsp_scan_device_end", "spsp_wait_dense", "spsp_scan_hits_device", "spsp_compare",
+    "spsp_compare_device", "spsp_slot_bytes", "spsp_partition_keys_device", "spsp_compare_slots_device", "spsp_compare_device_begin", "spsp_compare_slots_device_begin", "spsp_compare_end", "spsp_fasta_clean_host", "spsp_fasta_clean_device", "spsp_sketch_text", "spsp_sketch_build_host", "spsp_sketch_parse_host",
     "spsp_csv_host", "spsp_read_file_host", "spsp_write_gz_host", "spsp_sketch_file", "spsp_compare_files",
 ]
 
@@ -87,6 +87,15 @@ def lib():
     L.spsp_scan.restype = i32; L.spsp_scan.argtypes = [vp, P(Params), vp, vp, u32, P(vp), P(u64)]
     L.spsp_scan_device.restype = i32
     L.spsp_scan_device.argtypes = [vp, P(Params), vp, u64, vp, u32, P(vp), P(u64)]
+    L.spsp_scan_device_begin.restype = i32
+    L.spsp_scan_device_begin.argtypes = [vp, P(Params), vp, u64, vp, u32]
+    L.spsp_scan_device_end.restype = i32; L.spsp_scan_device_end.argtypes = [vp, P(vp), P(u64)]
+    L.spsp_wait_dense.restype = i32; L.spsp_wait_dense.argtypes = [vp, vp]
+    L.spsp_compare_device_begin.restype = i32
+    L.spsp_compare_device_begin.argtypes = [vp, u32, vp, vp, vp, vp, u32, u32, u32, u32, vp]
+    L.spsp_compare_slots_device_begin.restype = i32
+    L.spsp_compare_slots_device_begin.argtypes = [vp, u32, vp, u32, u32, u32, vp]
+    L.spsp_compare_end.restype = i32; L.spsp_compare_end.argtypes = [vp]
     L.spsp_scan_hits_device.restype = i32
     L.spsp_scan_hits_device.argtypes = [vp, P(Params), vp, u64, P(u64)]
     L.spsp_compare.restype = i32; L.spsp_compare.argtypes = [vp, P(SketchView), u32, u32, vp, vp]
@@ -277,6 +286,19 @@ class Context:
                                       C.byref(n)))
         return out.value, n.value
 
+    def scan_device_begin(self, params, d_bases, n_bases, d_rec_off, n_rec):
+        """queue the scan on the context's stream and return; collect with scan_device_end()"""
+        _check(lib().spsp_scan_device_begin(self._h, C.byref(params), d_bases, n_bases, d_rec_off, n_rec))
+
+    def scan_device_end(self):
+        out, n = C.c_void_p(), C.c_uint64()
+        _check(lib().spsp_scan_device_end(self._h, C.byref(out), C.byref(n)))
+        return out.value, n.value
+
+    def wait_dense(self, scanner):
+        """work queued on this context from now on starts behind `scanner`'s latest dense pass"""
+        _check(lib().spsp_wait_dense(self._h, scanner._h))
+
     def scan_hits_device(self, params, d_bases, n_bases):
         n = C.c_uint64()
         _check(lib().spsp_scan_hits_device(self._h, C.byref(params), d_bases, n_bases, C.byref(n)))
@@ -330,6 +352,17 @@ class Context:
         sk_off = np.ascontiguousarray(sk_off, dtype=np.uint64)
         _check(lib().spsp_compare_device(self._h, k, d_min, d_lo, d_hi, sk_off.ctypes.data, n,
                                          n if n_query is None else n_query, row_first, row_stride, d_inter))
+
+    def compare_device_begin(self, k, d_min, d_lo, d_hi, sk_off, n, row_first, row_stride, d_inter, n_query=None):
+        sk_off = np.ascontiguousarray(sk_off, dtype=np.uint64)
+        _check(lib().spsp_compare_device_begin(self._h, k, d_min, d_lo, d_hi, sk_off.ctypes.data, n,
+                                               n if n_query is None else n_query, row_first, row_stride, d_inter))
+
+    def compare_slots_device_begin(self, k, d_slots, parts, n, slot_cap, d_inter):
+        _check(lib().spsp_compare_slots_device_begin(self._h, k, d_slots, parts, n, slot_cap, d_inter))
+
+    def compare_end(self):
+        _check(lib().spsp_compare_end(self._h))
 
     def partition_keys_device(self, k, d_min, d_lo, d_hi, sk_off, n, parts, slot_cap, d_slots):
         """Scatter this rank's sketch keys into `parts` exchange slots (include/spsp.h); asynchronous."""

@@ -134,6 +134,9 @@ void spsp_destroy(spsp_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    compare_job_drop(c);
+    if (c->h_skoff) (void)hipHostFree(c->h_skoff);
+    if (c->dense_done) (void)hipEventDestroy(c->dense_done);
     DevBuf* bufs[] = {&c->bases, &c->rec_off, &c->bitmap, &c->tile_count, &c->tile_off, &c->hits, &c->emit_count,
                       &c->emit_off, &c->scan_tmp, &c->d_scalar, &c->seg_a, &c->seg_b, &c->filter, &c->pairtab, &c->c_min, &c->c_lo, &c->c_hi, &c->c_table,
                       &c->c_owner, &c->c_rowid, &c->c_row, &c->x_cnt, &c->x_off, &c->x_begin, &c->x_end, &c->x_tot, &c->c_matrix, &c->c_inter, &c->c_flags,
@@ -199,6 +202,31 @@ int spsp_scan_device(spsp_ctx* ctx, const spsp_params* p, const void* d_bases, u
     int rc = scan_device_impl(ctx, p, (const uint8_t*)d_bases, n_bases, (const uint64_t*)d_rec_off, n_rec, &o, n_out);
     *d_out = o;
     return rc;
+}
+
+int spsp_scan_device_begin(spsp_ctx* ctx, const spsp_params* p, const void* d_bases, uint64_t n_bases,
+                           const void* d_rec_off, uint32_t n_rec) {
+    if (!ctx || !p) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    SPSP_HIP(hipSetDevice(ctx->device));
+    return scan_begin_impl(ctx, p, (const uint8_t*)d_bases, n_bases, (const uint64_t*)d_rec_off, n_rec);
+}
+
+int spsp_scan_device_end(spsp_ctx* ctx, void** d_out, uint64_t* n_out) {
+    if (!ctx || !d_out || !n_out) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    SPSP_HIP(hipSetDevice(ctx->device));
+    spsp_superkmer* o = nullptr;
+    int rc = scan_end_impl(ctx, &o, n_out);
+    *d_out = o;
+    return rc;
+}
+
+int spsp_wait_dense(spsp_ctx* waiter, spsp_ctx* scanner) {
+    if (!waiter || !scanner) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    if (waiter->device != scanner->device) { set_error("both contexts must be on the same device"); return SPSP_ERR_ARG; }
+    SPSP_HIP(hipSetDevice(waiter->device));
+    if (scanner->dense_done && waiter->stream != scanner->stream)
+        SPSP_HIP(hipStreamWaitEvent(waiter->stream, scanner->dense_done, 0));
+    return SPSP_OK;
 }
 
 int spsp_scan_hits_device(spsp_ctx* ctx, const spsp_params* p, const void* d_bases, uint64_t n_bases,

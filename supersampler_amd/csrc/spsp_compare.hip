@@ -24,6 +24,8 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <memory>
 #include <vector>
 
 #include "spsp_internal.h"
@@ -245,6 +247,9 @@ __global__ __launch_bounds__(kAccThreads) void k_accumulate(const uint32_t* __re
 // ---------------------------------------------------------------------------
 // Host driver shared by the two input forms (flat key arrays / exchange slots):
 // dictionary build -> colour matrix -> row sums, with the collision retry.
+// Like the scan it is split at its host synchronisation: compare_job_begin queues the
+// (speculative) pipeline and returns, compare_job_end waits, checks the flags and --
+// only after a fingerprint collision or for inputs too large to speculate -- queues more.
 struct ComparePlan {
     uint64_t S_own;        // upper bound on the keys inserted (sizes the table and the speculative matrix)
     uint64_t S_entries;    // entry index space (sizes row_of_entry)
@@ -252,96 +257,146 @@ struct ComparePlan {
     const uint64_t *sk_begin, *sk_end;   // device: entry range of sketch i
     uint32_t* d_inter;
 };
+struct CompareJob {
+    ComparePlan P;
+    std::function<int(uint64_t seed, uint64_t fp_mask, uint32_t log2cap)> insert;
+    std::function<int(uint64_t seed, uint64_t fp_mask, uint32_t log2cap, uint32_t W)> fill;
+    uint32_t log2cap = 0, W = 0, lanes_per_key = 64, sblocks = 0;
+    uint64_t cap = 0, seed = 0x5350535053505350ULL;
+    bool speculative = false;
+    int attempt = 0;
+};
 // flags: [0] unsorted input, [1] fingerprint collision, [2] n_rows, [3] malformed slot, [4] slot overflow
-template <class Insert, class Fill>
-static int run_compare(spsp_ctx* ctx, const ComparePlan& P, Insert&& launch_insert, Fill&& launch_fill) {
-    int rc;
-    uint32_t log2cap = 10;
-    while ((1ull << log2cap) < 2 * P.S_own) ++log2cap;
-    const uint64_t cap = 1ull << log2cap;
-    if ((rc = ctx->c_table.reserve((size_t)cap * 8))) return rc;
-    if ((rc = ctx->c_owner.reserve((size_t)cap * 4))) return rc;
-    if ((rc = ctx->c_rowid.reserve((size_t)cap * 4))) return rc;
-    if ((rc = ctx->c_row.reserve((size_t)P.S_entries * 4))) return rc;
+static uint64_t job_fp_mask(const CompareJob& J) {
     // test hook: fingerprints of the first attempt cut to a few bits, so distinct keys collide and the retry runs
     static const char* dbg_fp = getenv("SPSP_DEBUG_FP_BITS");
+    return (dbg_fp && J.attempt == 0) ? ((1ull << atoi(dbg_fp)) - 1) : ~0ull;
+}
+// dictionary build: table and row ids
+static int job_front(spsp_ctx* ctx, CompareJob& J) {
     uint32_t* flags = ctx->c_flags.as<uint32_t>();
-    const uint32_t sblocks = (uint32_t)((cap + (uint64_t)kRowThreads * kRowSlots - 1) / ((uint64_t)kRowThreads * kRowSlots));
-    const uint32_t W = (P.n + 63) / 64;
-    uint32_t lanes_per_key = 64;
-    if (W < 64) { lanes_per_key = 1; while (lanes_per_key < W) lanes_per_key <<= 1; }
-    // dictionary build: table and row ids
-    auto front = [&](uint64_t seed, uint64_t fp_mask) -> int {
-        SPSP_HIP(hipMemsetAsync(ctx->c_table.p, 0, (size_t)cap * 8, ctx->stream));
-        SPSP_HIP(hipMemsetAsync(flags, 0, 12, ctx->stream));   // [3], [4] belong to the slot index pass
-        int r2 = launch_insert(seed, fp_mask, log2cap);
-        if (r2) return r2;
-        hipLaunchKernelGGL(k_assign_rows, dim3(sblocks), dim3(kRowThreads), 0, ctx->stream, ctx->c_table.as<uint64_t>(), cap,
-                           ctx->c_rowid.as<uint32_t>(), flags + 2);
-        SPSP_HIP(hipGetLastError());
-        return SPSP_OK;
-    };
-    // colour matrix (room for `rows` rows) and the row sums
-    auto back = [&](uint64_t seed, uint64_t fp_mask, uint64_t rows) -> int {
-        int r2;
-        if ((r2 = ctx->c_matrix.reserve((size_t)rows * W * 8))) return r2;
-        SPSP_HIP(hipMemsetAsync(ctx->c_matrix.p, 0, (size_t)rows * W * 8, ctx->stream));
-        if ((r2 = launch_fill(seed, fp_mask, log2cap, W))) return r2;
-        if ((r2 = ctx->ev_begin(kEvAccumulate))) return r2;
-        hipLaunchKernelGGL(k_accumulate, dim3((W + 63) / 64, P.n_own), dim3(kAccThreads), 0, ctx->stream,
-                           ctx->c_row.as<uint32_t>(), ctx->c_matrix.as<uint64_t>(), W, lanes_per_key, P.sk_begin, P.sk_end,
-                           P.n, P.row_first, P.row_stride, P.row_limit, P.d_inter);
-        SPSP_HIP(hipGetLastError());
-        return ctx->ev_end(kEvAccumulate);
-    };
-    auto read_flags = [&](uint32_t* h_flags) -> int {
-        SPSP_HIP(hipMemcpyAsync(h_flags, flags, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-        SPSP_HIP(hipStreamSynchronize(ctx->stream));
-        if (h_flags[3]) { set_error("malformed exchange slot (header, sketch count or key count does not match)"); return SPSP_ERR_FORMAT; }
-        if (h_flags[4]) { set_error("an exchange slot overflowed its capacity: partition again with a larger slot_cap"); return SPSP_ERR_OVERFLOW; }
-        if (h_flags[0]) { set_error("sketch keys must be strictly increasing by (minimizer, kmer_hi, kmer_lo)"); return SPSP_ERR_ARG; }
-        return SPSP_OK;
-    };
+    SPSP_HIP(hipMemsetAsync(ctx->c_table.p, 0, (size_t)J.cap * 8, ctx->stream));
+    SPSP_HIP(hipMemsetAsync(flags, 0, 12, ctx->stream));   // [3], [4] belong to the slot index pass
+    int rc = J.insert(J.seed, job_fp_mask(J), J.log2cap);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_assign_rows, dim3(J.sblocks), dim3(kRowThreads), 0, ctx->stream, ctx->c_table.as<uint64_t>(), J.cap,
+                       ctx->c_rowid.as<uint32_t>(), flags + 2);
+    SPSP_HIP(hipGetLastError());
+    return SPSP_OK;
+}
+// colour matrix (room for `rows` rows), the row sums, and the flags on their way to the host
+static int job_back(spsp_ctx* ctx, CompareJob& J, uint64_t rows) {
+    int rc;
+    const ComparePlan& P = J.P;
+    if ((rc = ctx->c_matrix.reserve((size_t)rows * J.W * 8))) return rc;
+    SPSP_HIP(hipMemsetAsync(ctx->c_matrix.p, 0, (size_t)rows * J.W * 8, ctx->stream));
+    if ((rc = J.fill(J.seed, job_fp_mask(J), J.log2cap, J.W))) return rc;
+    if ((rc = ctx->ev_begin(kEvAccumulate))) return rc;
+    hipLaunchKernelGGL(k_accumulate, dim3((J.W + 63) / 64, P.n_own), dim3(kAccThreads), 0, ctx->stream,
+                       ctx->c_row.as<uint32_t>(), ctx->c_matrix.as<uint64_t>(), J.W, J.lanes_per_key, P.sk_begin, P.sk_end,
+                       P.n, P.row_first, P.row_stride, P.row_limit, P.d_inter);
+    SPSP_HIP(hipGetLastError());
+    return ctx->ev_end(kEvAccumulate);
+}
+static int job_read_flags(spsp_ctx* ctx, uint32_t* h_flags) {
+    uint32_t* pinned = reinterpret_cast<uint32_t*>(ctx->h_scalar + 4);
+    SPSP_HIP(hipMemcpyAsync(pinned, ctx->c_flags.p, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    SPSP_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(h_flags, pinned, 5 * sizeof(uint32_t));
+    if (h_flags[3]) { set_error("malformed exchange slot (header, sketch count or key count does not match)"); return SPSP_ERR_FORMAT; }
+    if (h_flags[4]) { set_error("an exchange slot overflowed its capacity: partition again with a larger slot_cap"); return SPSP_ERR_OVERFLOW; }
+    if (h_flags[0]) { set_error("sketch keys must be strictly increasing by (minimizer, kmer_hi, kmer_lo)"); return SPSP_ERR_ARG; }
+    return SPSP_OK;
+}
+
+// takes ownership of `job`; on success it is pending on the context until compare_job_end
+static int compare_job_begin(spsp_ctx* ctx, CompareJob* job) {
+    std::unique_ptr<CompareJob> J(job);
+    const ComparePlan& P = J->P;
+    int rc;
+    J->log2cap = 10;
+    while ((1ull << J->log2cap) < 2 * P.S_own) ++J->log2cap;
+    J->cap = 1ull << J->log2cap;
+    if ((rc = ctx->c_table.reserve((size_t)J->cap * 8))) return rc;
+    if ((rc = ctx->c_owner.reserve((size_t)J->cap * 4))) return rc;
+    if ((rc = ctx->c_rowid.reserve((size_t)J->cap * 4))) return rc;
+    if ((rc = ctx->c_row.reserve((size_t)P.S_entries * 4))) return rc;
+    J->sblocks = (uint32_t)((J->cap + (uint64_t)kRowThreads * kRowSlots - 1) / ((uint64_t)kRowThreads * kRowSlots));
+    J->W = (P.n + 63) / 64;
+    J->lanes_per_key = 64;
+    if (J->W < 64) { J->lanes_per_key = 1; while (J->lanes_per_key < J->W) J->lanes_per_key <<= 1; }
     // A matrix with one row per inserted KEY (an upper bound on the distinct keys) is cheap for small inputs:
     // then the whole pipeline is queued without waiting for the row count and checked once at the end.
-    const bool speculative = (uint64_t)P.S_own * W * 8 <= (256ull << 20);
-    uint64_t seed = 0x5350535053505350ULL;
-    for (int attempt = 0;; ++attempt) {
+    J->speculative = (uint64_t)P.S_own * J->W * 8 <= (256ull << 20);
+    if ((rc = job_front(ctx, *J))) return rc;
+    if (J->speculative && (rc = job_back(ctx, *J, P.S_own))) return rc;
+    ctx->compare_job = J.release();
+    return SPSP_OK;
+}
+
+int compare_job_end(spsp_ctx* ctx) {
+    if (!ctx->compare_job) { set_error("no comparison is pending on this context"); return SPSP_ERR_ARG; }
+    std::unique_ptr<CompareJob> J(ctx->compare_job);
+    ctx->compare_job = nullptr;
+    int rc;
+    for (;;) {
         uint32_t h_flags[5];
-        const uint64_t fp_mask = (dbg_fp && attempt == 0) ? ((1ull << atoi(dbg_fp)) - 1) : ~0ull;
-        if ((rc = front(seed, fp_mask))) return rc;
-        if (speculative) {
-            if ((rc = back(seed, fp_mask, P.S_own))) return rc;
-        } else {
-            if ((rc = read_flags(h_flags))) return rc;          // the row count sizes the colour matrix
-            if ((rc = back(seed, fp_mask, h_flags[2]))) return rc;
+        if (!J->speculative) {
+            if ((rc = job_read_flags(ctx, h_flags))) return rc;          // the row count sizes the colour matrix
+            if ((rc = job_back(ctx, *J, h_flags[2]))) return rc;
         }
-        if ((rc = read_flags(h_flags))) return rc;              // collisions surface in the fill pass
+        if ((rc = job_read_flags(ctx, h_flags))) return rc;              // collisions surface in the fill pass
         if (!h_flags[1]) return SPSP_OK;
-        if (attempt >= 4) { set_error("fingerprint collisions persisted over 5 seeds"); return SPSP_ERR_HIP; }
-        seed = seed * 6364136223846793005ULL + 1442695040888963407ULL;  // new fingerprints, try again
+        if (J->attempt >= 4) { set_error("fingerprint collisions persisted over 5 seeds"); return SPSP_ERR_HIP; }
+        ++J->attempt;
+        J->seed = J->seed * 6364136223846793005ULL + 1442695040888963407ULL;  // new fingerprints, try again
+        if ((rc = job_front(ctx, *J))) return rc;
+        if (J->speculative && (rc = job_back(ctx, *J, J->P.S_own))) return rc;
     }
 }
 
-static int compare_device_inner(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min, const uint64_t* d_lo,
-                                const uint64_t* d_hi, const uint64_t* h_sk_off, uint32_t n, uint32_t row_limit,
-                                uint32_t row_first, uint32_t row_stride, uint32_t* d_inter) {
-    if (n == 0) return SPSP_OK;
+void compare_job_drop(spsp_ctx* ctx) {
+    delete ctx->compare_job;
+    ctx->compare_job = nullptr;
+}
+
+// pinned copy of the caller's offsets: the queued H2D copy must not read memory the caller may free
+static int stage_sk_off(spsp_ctx* ctx, const uint64_t* h_sk_off, uint32_t n) {
+    const size_t need = (size_t)(n + 1);
+    if (ctx->h_skoff_cap < need) {
+        if (ctx->h_skoff) { SPSP_HIP(hipStreamSynchronize(ctx->stream)); (void)hipHostFree(ctx->h_skoff); ctx->h_skoff = nullptr; ctx->h_skoff_cap = 0; }
+        size_t cap = 1024;
+        while (cap < need) cap *= 2;
+        SPSP_HIP(hipHostMalloc((void**)&ctx->h_skoff, cap * 8, hipHostMallocDefault));
+        ctx->h_skoff_cap = cap;
+    }
+    memcpy(ctx->h_skoff, h_sk_off, need * 8);
+    int rc;
+    if ((rc = ctx->c_skoff.reserve(need * 8))) return rc;
+    SPSP_HIP(hipMemcpyAsync(ctx->c_skoff.p, ctx->h_skoff, need * 8, hipMemcpyHostToDevice, ctx->stream));
+    return SPSP_OK;
+}
+
+// returns 1 when there is nothing to do (no job queued), 0 when a job is pending, < 0 on error
+static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min, const uint64_t* d_lo,
+                                      const uint64_t* d_hi, const uint64_t* h_sk_off, uint32_t n, uint32_t row_limit,
+                                      uint32_t row_first, uint32_t row_stride, uint32_t* d_inter) {
+    if (n == 0) return 1;
     if (n > 65535) { set_error("at most 65535 sketches (the reference's uint32 pair key, Comparator.h:26)"); return SPSP_ERR_ARG; }
     if (row_stride == 0 || row_first >= row_stride) { set_error("bad row partition %u/%u", row_first, row_stride); return SPSP_ERR_ARG; }
     if (k > 32 && !d_hi) { set_error("k=%u needs kmer_hi", k); return SPSP_ERR_ARG; }
     const uint64_t S = h_sk_off[n];
-    if (S == 0) return SPSP_OK;
+    if (S == 0) return 1;
     if (S > 0xfffffff0ull) { set_error("too many sketch k-mers for one call"); return SPSP_ERR_OVERFLOW; }
     uint64_t S_own = 0;
     uint32_t n_own = 0;
     if (row_limit > n) row_limit = n;
     for (uint32_t i = row_first; i < row_limit; i += row_stride) { S_own += h_sk_off[i + 1] - h_sk_off[i]; ++n_own; }
-    if (S_own == 0 || n_own == 0) return SPSP_OK;
+    if (S_own == 0 || n_own == 0) return 1;
     int rc;
-    if ((rc = ctx->c_skoff.reserve((size_t)(n + 1) * 8))) return rc;
+    // a queued-but-unsynchronised earlier copy from h_skoff is ordered before this one on the same stream
+    if ((rc = stage_sk_off(ctx, h_sk_off, n))) return rc;
     if ((rc = ctx->c_flags.reserve(64))) return rc;
-    SPSP_HIP(hipMemcpyAsync(ctx->c_skoff.p, h_sk_off, (size_t)(n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     SPSP_HIP(hipMemsetAsync(ctx->c_flags.p, 0, 64, ctx->stream));
     Keys K{d_min, d_lo, (k > 32) ? d_hi : nullptr, ~0ull};
     const uint64_t* sk = ctx->c_skoff.as<uint64_t>();
@@ -349,25 +404,25 @@ static int compare_device_inner(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min
     uint64_t max_all = 0;
     for (uint32_t i = 0; i < n; ++i) max_all = std::max(max_all, h_sk_off[i + 1] - h_sk_off[i]);
     const dim3 grid_all((uint32_t)((max_all + 255) / 256), n);
-    ComparePlan P{S_own, S, n, n_own, row_first, row_stride, row_limit, sk, sk + 1, d_inter};
-    return run_compare(
-        ctx, P,
-        [&](uint64_t seed, uint64_t fp_mask, uint32_t log2cap) -> int {
-            Keys Km = K; Km.fp_mask = fp_mask;
-            hipLaunchKernelGGL(k_insert, grid_all, dim3(256), 0, ctx->stream, Km, sk, n, S, row_first, row_stride, row_limit,
-                               seed, ctx->c_table.as<uint64_t>(), log2cap, ctx->c_owner.as<uint32_t>(), flags);
-            SPSP_HIP(hipGetLastError());
-            return SPSP_OK;
-        },
-        [&](uint64_t seed, uint64_t fp_mask, uint32_t log2cap, uint32_t W) -> int {
-            Keys Km = K; Km.fp_mask = fp_mask;
-            hipLaunchKernelGGL(k_fill, grid_all, dim3(256), 0, ctx->stream, Km, sk, n, S, row_first, row_stride, row_limit, seed,
-                               ctx->c_table.as<uint64_t>(), log2cap, ctx->c_owner.as<uint32_t>(),
-                               ctx->c_rowid.as<uint32_t>(), W, ctx->c_matrix.as<unsigned long long>(),
-                               ctx->c_row.as<uint32_t>(), flags);
-            SPSP_HIP(hipGetLastError());
-            return SPSP_OK;
-        });
+    CompareJob* J = new CompareJob;
+    J->P = ComparePlan{S_own, S, n, n_own, row_first, row_stride, row_limit, sk, sk + 1, d_inter};
+    J->insert = [=](uint64_t seed, uint64_t fp_mask, uint32_t log2cap) -> int {
+        Keys Km = K; Km.fp_mask = fp_mask;
+        hipLaunchKernelGGL(k_insert, grid_all, dim3(256), 0, ctx->stream, Km, sk, n, S, row_first, row_stride, row_limit,
+                           seed, ctx->c_table.as<uint64_t>(), log2cap, ctx->c_owner.as<uint32_t>(), flags);
+        SPSP_HIP(hipGetLastError());
+        return SPSP_OK;
+    };
+    J->fill = [=](uint64_t seed, uint64_t fp_mask, uint32_t log2cap, uint32_t W) -> int {
+        Keys Km = K; Km.fp_mask = fp_mask;
+        hipLaunchKernelGGL(k_fill, grid_all, dim3(256), 0, ctx->stream, Km, sk, n, S, row_first, row_stride, row_limit, seed,
+                           ctx->c_table.as<uint64_t>(), log2cap, ctx->c_owner.as<uint32_t>(),
+                           ctx->c_rowid.as<uint32_t>(), W, ctx->c_matrix.as<unsigned long long>(),
+                           ctx->c_row.as<uint32_t>(), flags);
+        SPSP_HIP(hipGetLastError());
+        return SPSP_OK;
+    };
+    return compare_job_begin(ctx, J);
 }
 
 // ===========================================================================
@@ -647,8 +702,10 @@ int partition_keys_impl(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min, const 
     return SPSP_OK;
 }
 
-int compare_slots_impl(spsp_ctx* ctx, uint32_t k, const uint8_t* d_slots, uint32_t parts, uint32_t n, uint32_t cap,
-                       uint32_t* d_inter) {
+// returns 0 with a job pending, < 0 on error
+int compare_slots_begin_impl(spsp_ctx* ctx, uint32_t k, const uint8_t* d_slots, uint32_t parts, uint32_t n, uint32_t cap,
+                             uint32_t* d_inter) {
+    if (ctx->compare_job) { set_error("a comparison is already pending on this context: call spsp_compare_end first"); return SPSP_ERR_ARG; }
     if (n == 0 || parts == 0 || parts > kMaxParts) { set_error("bad slot geometry"); return SPSP_ERR_ARG; }
     const uint64_t N = (uint64_t)parts * n;
     if (N > 65535) { set_error("at most 65535 sketches (the reference's uint32 pair key, Comparator.h:26)"); return SPSP_ERR_ARG; }
@@ -665,44 +722,73 @@ int compare_slots_impl(spsp_ctx* ctx, uint32_t k, const uint8_t* d_slots, uint32
         if ((r2 = ctx->c_flags.reserve(64))) return r2;
         SPSP_HIP(hipMemsetAsync(ctx->c_flags.p, 0, 64, ctx->stream));
         uint32_t* flags = ctx->c_flags.as<uint32_t>();
-        SlotView V{d_slots, slot_bytes(n, cap, k), slot_rec_off(n), cap, n, slot_words(k), parts, ~0ull};
+        const SlotView V{d_slots, slot_bytes(n, cap, k), slot_rec_off(n), cap, n, slot_words(k), parts, ~0ull};
         hipLaunchKernelGGL(k_slot_index, dim3(parts), dim3(kPartThreads), 0, ctx->stream, V, ctx->x_begin.as<uint64_t>(),
                            ctx->x_end.as<uint64_t>(), ctx->x_tot.as<uint32_t>(), flags);
         SPSP_HIP(hipGetLastError());
         const uint32_t* tot = ctx->x_tot.as<uint32_t>();
         const dim3 grid((uint32_t)((E + 255) / 256));
-        ComparePlan P{E, E, (uint32_t)N, (uint32_t)N, 0, 1, (uint32_t)N, ctx->x_begin.as<uint64_t>(), ctx->x_end.as<uint64_t>(), d_inter};
-        return run_compare(
-            ctx, P,
-            [&](uint64_t seed, uint64_t fp_mask, uint32_t log2cap) -> int {
-                SlotView Vm = V; Vm.fp_mask = fp_mask;
-                hipLaunchKernelGGL(k_insert_slots, grid, dim3(256), 0, ctx->stream, Vm, tot, seed, ctx->c_table.as<uint64_t>(),
-                                   log2cap, ctx->c_owner.as<uint32_t>());
-                SPSP_HIP(hipGetLastError());
-                return SPSP_OK;
-            },
-            [&](uint64_t seed, uint64_t fp_mask, uint32_t log2cap, uint32_t W) -> int {
-                SlotView Vm = V; Vm.fp_mask = fp_mask;
-                hipLaunchKernelGGL(k_fill_slots, grid, dim3(256), 0, ctx->stream, Vm, tot, seed, ctx->c_table.as<uint64_t>(), log2cap,
-                                   ctx->c_owner.as<uint32_t>(), ctx->c_rowid.as<uint32_t>(), W,
-                                   ctx->c_matrix.as<unsigned long long>(), ctx->c_row.as<uint32_t>(), flags);
-                SPSP_HIP(hipGetLastError());
-                return SPSP_OK;
-            });
+        CompareJob* J = new CompareJob;
+        J->P = ComparePlan{E, E, (uint32_t)N, (uint32_t)N, 0, 1, (uint32_t)N, ctx->x_begin.as<uint64_t>(), ctx->x_end.as<uint64_t>(), d_inter};
+        J->insert = [=](uint64_t seed, uint64_t fp_mask, uint32_t log2cap) -> int {
+            SlotView Vm = V; Vm.fp_mask = fp_mask;
+            hipLaunchKernelGGL(k_insert_slots, grid, dim3(256), 0, ctx->stream, Vm, tot, seed, ctx->c_table.as<uint64_t>(),
+                               log2cap, ctx->c_owner.as<uint32_t>());
+            SPSP_HIP(hipGetLastError());
+            return SPSP_OK;
+        };
+        J->fill = [=](uint64_t seed, uint64_t fp_mask, uint32_t log2cap, uint32_t W) -> int {
+            SlotView Vm = V; Vm.fp_mask = fp_mask;
+            hipLaunchKernelGGL(k_fill_slots, grid, dim3(256), 0, ctx->stream, Vm, tot, seed, ctx->c_table.as<uint64_t>(), log2cap,
+                               ctx->c_owner.as<uint32_t>(), ctx->c_rowid.as<uint32_t>(), W,
+                               ctx->c_matrix.as<unsigned long long>(), ctx->c_row.as<uint32_t>(), flags);
+            SPSP_HIP(hipGetLastError());
+            return SPSP_OK;
+        };
+        return compare_job_begin(ctx, J);
     };
     rc = body();
-    const int rc2 = ctx->ev_end(kEvCompare);
+    const int rc2 = ctx->ev_end(kEvCompare);   // brackets the speculative pipeline (retries are not timed)
     return rc ? rc : rc2;
+}
+
+int compare_device_begin_impl(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min, const uint64_t* d_lo,
+                              const uint64_t* d_hi, const uint64_t* h_sk_off, uint32_t n, uint32_t row_limit,
+                              uint32_t row_first, uint32_t row_stride, uint32_t* d_inter) {
+    if (ctx->compare_job) { set_error("a comparison is already pending on this context: call spsp_compare_end first"); return SPSP_ERR_ARG; }
+    int rc = ctx->ev_begin(kEvCompare);
+    if (rc) return rc;
+    rc = compare_device_begin_inner(ctx, k, d_min, d_lo, d_hi, h_sk_off, n, row_limit, row_first, row_stride, d_inter);
+    const int rc2 = ctx->ev_end(kEvCompare);
+    if (rc < 0) return rc;
+    if (rc == 1) {                       // nothing to compare: leave an empty job so that begin/end stay paired
+        CompareJob* J = new CompareJob;
+        J->speculative = true;
+        J->P = ComparePlan{};
+        ctx->compare_job = J;
+        J->attempt = -1;
+    }
+    return rc2;
+}
+
+int compare_end_impl(spsp_ctx* ctx) {
+    if (ctx->compare_job && ctx->compare_job->attempt == -1) { compare_job_drop(ctx); return SPSP_OK; }
+    return compare_job_end(ctx);
+}
+
+int compare_slots_impl(spsp_ctx* ctx, uint32_t k, const uint8_t* d_slots, uint32_t parts, uint32_t n, uint32_t cap,
+                       uint32_t* d_inter) {
+    int rc = compare_slots_begin_impl(ctx, k, d_slots, parts, n, cap, d_inter);
+    if (rc) return rc;
+    return compare_end_impl(ctx);
 }
 
 int compare_device_impl(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min, const uint64_t* d_lo,
                         const uint64_t* d_hi, const uint64_t* h_sk_off, uint32_t n, uint32_t row_limit, uint32_t row_first,
                         uint32_t row_stride, uint32_t* d_inter) {
-    int rc = ctx->ev_begin(kEvCompare);
+    int rc = compare_device_begin_impl(ctx, k, d_min, d_lo, d_hi, h_sk_off, n, row_limit, row_first, row_stride, d_inter);
     if (rc) return rc;
-    rc = compare_device_inner(ctx, k, d_min, d_lo, d_hi, h_sk_off, n, row_limit, row_first, row_stride, d_inter);
-    const int rc2 = ctx->ev_end(kEvCompare);
-    return rc ? rc : rc2;
+    return compare_end_impl(ctx);
 }
 
 }  // namespace spsp
@@ -736,6 +822,28 @@ int spsp_compare_slots_device(spsp_ctx* ctx, uint32_t k, const void* d_slots, ui
     if (!ctx || !d_slots || !d_inter) { set_error("NULL argument"); return SPSP_ERR_ARG; }
     SPSP_HIP(hipSetDevice(ctx->device));
     return compare_slots_impl(ctx, k, (const uint8_t*)d_slots, parts, n, slot_cap, (uint32_t*)d_inter);
+}
+
+int spsp_compare_device_begin(spsp_ctx* ctx, uint32_t k, const void* d_minimizer, const void* d_kmer_lo,
+                              const void* d_kmer_hi, const uint64_t* h_sk_off, uint32_t n, uint32_t n_query,
+                              uint32_t row_first, uint32_t row_stride, void* d_inter) {
+    if (!ctx || !h_sk_off || !d_inter) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    SPSP_HIP(hipSetDevice(ctx->device));
+    return compare_device_begin_impl(ctx, k, (const uint32_t*)d_minimizer, (const uint64_t*)d_kmer_lo,
+                                     (const uint64_t*)d_kmer_hi, h_sk_off, n, n_query, row_first, row_stride, (uint32_t*)d_inter);
+}
+
+int spsp_compare_slots_device_begin(spsp_ctx* ctx, uint32_t k, const void* d_slots, uint32_t parts, uint32_t n,
+                                    uint32_t slot_cap, void* d_inter) {
+    if (!ctx || !d_slots || !d_inter) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    SPSP_HIP(hipSetDevice(ctx->device));
+    return compare_slots_begin_impl(ctx, k, (const uint8_t*)d_slots, parts, n, slot_cap, (uint32_t*)d_inter);
+}
+
+int spsp_compare_end(spsp_ctx* ctx) {
+    if (!ctx) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    SPSP_HIP(hipSetDevice(ctx->device));
+    return compare_end_impl(ctx);
 }
 
 int spsp_compare(spsp_ctx* ctx, const spsp_sketch_view* sk, uint32_t n, uint32_t n_query, uint32_t* inter,

@@ -52,6 +52,19 @@ struct EventLog {
 enum { kEvDense = 0, kEvScan = 1, kEvAccumulate = 2, kEvCompare = 3, kEvKinds = 4 };
 }  // namespace spsp
 
+namespace spsp {
+// a scan queued by scan_begin_impl and not yet collected by scan_end_impl
+struct ScanJob {
+    bool pending = false, empty = false, redo_dense = true;
+    spsp_params p{};
+    const uint8_t* d_bases = nullptr;
+    uint64_t n_bases = 0, n_tiles = 0;
+    const uint64_t* d_rec_off = nullptr;
+    uint32_t n_rec = 0, hits_cap = 0, out_cap = 0;
+};
+struct CompareJob;   // spsp_compare.hip
+}  // namespace spsp
+
 struct spsp_ctx {
     bool timing = false;
     spsp::EventLog evlog[spsp::kEvKinds];
@@ -62,7 +75,12 @@ struct spsp_ctx {
     int n_cu = 256;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    uint64_t* h_scalar = nullptr;  // pinned, 8 slots
+    uint64_t* h_scalar = nullptr;  // pinned, 8 slots: [0] hits, [1] super-k-mers, [4..6] compare flags
+    hipEvent_t dense_done = nullptr;   // recorded behind every dense pass
+    spsp::ScanJob scan_job;
+    spsp::CompareJob* compare_job = nullptr;
+    uint64_t* h_skoff = nullptr;       // pinned staging for the sketch offsets of a queued comparison
+    size_t h_skoff_cap = 0;
     // scan workspace
     spsp::DevBuf bases, rec_off, bitmap, tile_count, tile_off, hits, emit_count, emit_off, scan_tmp, d_scalar, seg_a, seg_b;
     uint64_t hits_cap = 0, out_cap = 0;  // entries the sparse-stage buffers are sized for (grow on overflow)
@@ -90,12 +108,20 @@ namespace spsp {
 // scan pipeline (spsp_scan.hip)
 int scan_device_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, uint64_t n_bases,
                      const uint64_t* d_rec_off, uint32_t n_rec, spsp_superkmer** d_out, uint64_t* n_out);
+int scan_begin_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, uint64_t n_bases,
+                    const uint64_t* d_rec_off, uint32_t n_rec);
+int scan_end_impl(spsp_ctx* ctx, spsp_superkmer** d_out, uint64_t* n_out);
 int scan_hits_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, uint64_t n_bases,
                    uint64_t* n_hits);
 // compare pipeline (spsp_compare.hip)
 int compare_device_impl(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min, const uint64_t* d_lo,
                         const uint64_t* d_hi, const uint64_t* h_sk_off, uint32_t n, uint32_t row_limit, uint32_t row_first,
                         uint32_t row_stride, uint32_t* d_inter);
+int compare_device_begin_impl(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min, const uint64_t* d_lo,
+                              const uint64_t* d_hi, const uint64_t* h_sk_off, uint32_t n, uint32_t row_limit,
+                              uint32_t row_first, uint32_t row_stride, uint32_t* d_inter);
+int compare_end_impl(spsp_ctx* ctx);
+void compare_job_drop(spsp_ctx* ctx);
 int check_params(const spsp_params* p);
 // ingest (spsp_ingest.hip)
 int clean_device_impl(spsp_ctx* ctx, const uint8_t* d_text, uint64_t n_text, uint8_t** d_bases, uint64_t* n_bases,

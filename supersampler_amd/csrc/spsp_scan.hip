@@ -977,6 +977,8 @@ static int launch_dense(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_ba
     if (n_tiles > ctx->dirty_tiles) ctx->dirty_tiles = n_tiles;   // until k_expand has consumed (and zeroed) them
     if (n_tiles > ctx->zeroed_tiles) ctx->zeroed_tiles = n_tiles; // ... after which this whole range is zero
     if ((rc = ctx->ev_end(kEvDense))) return rc;
+    if (!ctx->dense_done) SPSP_HIP(hipEventCreateWithFlags(&ctx->dense_done, hipEventDisableTiming));
+    SPSP_HIP(hipEventRecord(ctx->dense_done, ctx->stream));   // spsp_wait_dense: other streams may start behind the dense pass
     const uint32_t n_seg = (uint32_t)((n_tiles + kSeg - 1) / kSeg);
     if ((rc = ctx->seg_a.reserve((size_t)n_seg * 8))) return rc;
     hipLaunchKernelGGL(k_scan_segments, dim3(n_seg), dim3(1024), 0, ctx->stream, ctx->tile_count.as<uint32_t>(),
@@ -1009,15 +1011,71 @@ int scan_hits_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, 
 // stages are launched with grids sized by buffer capacity and read the live counts
 // from device memory.  Capacities start from the expected hit density and grow (and
 // the affected stages re-run) in the rare call that overflows them.
-static int scan_device_inner(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, uint64_t n_bases,
-                             const uint64_t* d_rec_off, uint32_t n_rec, spsp_superkmer** d_out, uint64_t* n_out) {
+//
+// The job is split at that synchronisation: scan_begin queues one attempt and returns,
+// scan_end waits, inspects the counts and -- only on overflow -- queues again.  Between
+// the two the host is free to queue other work (another stream's comparison, the next
+// batch's copy); spsp_scan_device is begin + end.
+static int scan_enqueue(spsp_ctx* ctx) {
+    ScanJob& J = ctx->scan_job;
+    const spsp_params* p = &J.p;
+    int rc;
+    if (ctx->hits_cap > 0xfffffff0ull || ctx->out_cap > 0xfffffff0ull) {
+        set_error("too many selected m-mers / super-k-mers for one call; split the input");
+        return SPSP_ERR_OVERFLOW;
+    }
+    const uint32_t hits_cap = (uint32_t)ctx->hits_cap, out_cap = (uint32_t)ctx->out_cap;
+    J.hits_cap = hits_cap; J.out_cap = out_cap;
+    if ((rc = ctx->hits.reserve((size_t)hits_cap * sizeof(Hit)))) return rc;
+    if ((rc = ctx->emit_count.reserve((size_t)hits_cap * 4))) return rc;
+    if ((rc = ctx->emit_off.reserve((size_t)(hits_cap + 1) * 4))) return rc;
+    if ((rc = ctx->scan_tmp.reserve((size_t)out_cap * sizeof(spsp_superkmer)))) return rc;
+    const uint32_t rblocks = (hits_cap + 127) / 128;
+    const uint32_t n_seg_h = (hits_cap + kSeg - 1) / kSeg;
+    if ((rc = ctx->seg_b.reserve((size_t)n_seg_h * 8))) return rc;
+    uint32_t* d_sc = nullptr;
+    if (J.redo_dense) {
+        if ((rc = launch_dense(ctx, p, J.d_bases, J.n_bases, J.n_tiles, false))) return rc;
+        d_sc = ctx->d_scalar.as<uint32_t>();
+        const uint32_t n_seg_t = (uint32_t)((J.n_tiles + kSeg - 1) / kSeg);
+        hipLaunchKernelGGL(k_expand, dim3((uint32_t)((J.n_tiles + kExpandTilesPerWg - 1) / kExpandTilesPerWg)),
+                           dim3(kThreads), 0, ctx->stream, J.d_bases, J.n_bases, p->k, p->m, ctx->bitmap.as<uint32_t>(),
+                           ctx->tile_count.as<uint32_t>(), ctx->tile_off.as<uint32_t>(), ctx->seg_a.as<uint32_t>(),
+                           n_seg_t, J.n_tiles, J.d_rec_off, J.n_rec, ctx->hits.as<Hit>(), hits_cap, ctx->h_scalar + 0, d_sc + 0);
+        SPSP_HIP(hipGetLastError());
+        ctx->dirty_tiles = 0;   // k_expand leaves bitmap and tile counts zeroed
+        hipLaunchKernelGGL(k_resolve<false>, dim3(rblocks), dim3(128), 0, ctx->stream, ctx->hits.as<Hit>(), d_sc + 0,
+                           hits_cap, J.d_rec_off, p->k, p->m, ctx->emit_count.as<uint32_t>(),
+                           (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, (uint64_t*)nullptr,
+                           (spsp_superkmer*)nullptr, 0u);
+        SPSP_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_scan_segments, dim3(n_seg_h), dim3(1024), 0, ctx->stream, ctx->emit_count.as<uint32_t>(),
+                           ctx->emit_off.as<uint32_t>(), (uint64_t)hits_cap, (const uint32_t*)(d_sc + 0),
+                           ctx->seg_b.as<uint32_t>());
+        SPSP_HIP(hipGetLastError());
+    }
+    d_sc = ctx->d_scalar.as<uint32_t>();
+    hipLaunchKernelGGL(k_resolve<true>, dim3(rblocks), dim3(128), 0, ctx->stream, ctx->hits.as<Hit>(), d_sc + 0, hits_cap,
+                       J.d_rec_off, p->k, p->m, (uint32_t*)nullptr, ctx->emit_off.as<uint32_t>(),
+                       ctx->seg_b.as<uint32_t>(), n_seg_h, ctx->h_scalar + 1, ctx->scan_tmp.as<spsp_superkmer>(), out_cap);
+    SPSP_HIP(hipGetLastError());
+    return SPSP_OK;
+}
+
+int scan_begin_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, uint64_t n_bases,
+                    const uint64_t* d_rec_off, uint32_t n_rec) {
+    ScanJob& J = ctx->scan_job;
+    if (J.pending) { set_error("a scan is already pending on this context: call spsp_scan_device_end first"); return SPSP_ERR_ARG; }
     int rc = check_params(p);
     if (rc) return rc;
-    *d_out = nullptr; *n_out = 0;
     if (((uintptr_t)d_bases & 15u) != 0) { set_error("d_bases must be 16-byte aligned"); return SPSP_ERR_ARG; }
-    if (n_rec == 0 || n_bases < p->k) return SPSP_OK;
-    const uint64_t n_tiles = (n_bases + kTilePos - 1) / kTilePos;
-    if (n_tiles > 0x7fffffffull) { set_error("input too large for one call"); return SPSP_ERR_OVERFLOW; }
+    J = ScanJob{};
+    J.p = *p; J.d_bases = d_bases; J.n_bases = n_bases; J.d_rec_off = d_rec_off; J.n_rec = n_rec;
+    J.pending = true;
+    J.empty = (n_rec == 0 || n_bases < p->k);
+    if (J.empty) return SPSP_OK;
+    J.n_tiles = (n_bases + kTilePos - 1) / kTilePos;
+    if (J.n_tiles > 0x7fffffffull) { J.pending = false; set_error("input too large for one call"); return SPSP_ERR_OVERFLOW; }
     const double frac = (double)p->threshold / 18446744073709551616.0;
     uint64_t want_hits = (uint64_t)((double)n_bases * frac * 1.25) + 4096;
     if (want_hits > n_bases) want_hits = n_bases;
@@ -1028,62 +1086,39 @@ static int scan_device_inner(spsp_ctx* ctx, const spsp_params* p, const uint8_t*
     static const char* dbg_out = getenv("SPSP_DEBUG_OUT_CAP");
     if (dbg_hits) ctx->hits_cap = (uint64_t)atoll(dbg_hits);
     if (dbg_out) ctx->out_cap = (uint64_t)atoll(dbg_out);
-    bool redo_dense = true;
+    J.redo_dense = true;
+    if ((rc = ctx->ev_begin(kEvScan))) { J.pending = false; return rc; }
+    rc = scan_enqueue(ctx);
+    const int rc2 = ctx->ev_end(kEvScan);   // brackets the first attempt (a retry after an overflow is not timed)
+    if (rc || rc2) J.pending = false;
+    return rc ? rc : rc2;
+}
+
+int scan_end_impl(spsp_ctx* ctx, spsp_superkmer** d_out, uint64_t* n_out) {
+    ScanJob& J = ctx->scan_job;
+    *d_out = nullptr; *n_out = 0;
+    if (!J.pending) { set_error("no scan is pending on this context"); return SPSP_ERR_ARG; }
+    J.pending = false;
+    if (J.empty) return SPSP_OK;
+    static const char* dbg_out = getenv("SPSP_DEBUG_OUT_CAP");
+    int rc;
     for (int attempt = 0; attempt < 4; ++attempt) {
-        if (ctx->hits_cap > 0xfffffff0ull || ctx->out_cap > 0xfffffff0ull) {
-            set_error("too many selected m-mers / super-k-mers for one call; split the input");
-            return SPSP_ERR_OVERFLOW;
-        }
-        const uint32_t hits_cap = (uint32_t)ctx->hits_cap, out_cap = (uint32_t)ctx->out_cap;
-        if ((rc = ctx->hits.reserve((size_t)hits_cap * sizeof(Hit)))) return rc;
-        if ((rc = ctx->emit_count.reserve((size_t)hits_cap * 4))) return rc;
-        if ((rc = ctx->emit_off.reserve((size_t)(hits_cap + 1) * 4))) return rc;
-        if ((rc = ctx->scan_tmp.reserve((size_t)out_cap * sizeof(spsp_superkmer)))) return rc;
-        const uint32_t rblocks = (hits_cap + 127) / 128;
-        const uint32_t n_seg_h = (hits_cap + kSeg - 1) / kSeg;
-        if ((rc = ctx->seg_b.reserve((size_t)n_seg_h * 8))) return rc;
-        uint32_t* d_sc = nullptr;
-        if (redo_dense) {
-            if ((rc = launch_dense(ctx, p, d_bases, n_bases, n_tiles, false))) return rc;
-            d_sc = ctx->d_scalar.as<uint32_t>();
-            const uint32_t n_seg_t = (uint32_t)((n_tiles + kSeg - 1) / kSeg);
-            hipLaunchKernelGGL(k_expand, dim3((uint32_t)((n_tiles + kExpandTilesPerWg - 1) / kExpandTilesPerWg)),
-                               dim3(kThreads), 0, ctx->stream, d_bases, n_bases, p->k, p->m, ctx->bitmap.as<uint32_t>(),
-                               ctx->tile_count.as<uint32_t>(), ctx->tile_off.as<uint32_t>(), ctx->seg_a.as<uint32_t>(),
-                               n_seg_t, n_tiles, d_rec_off, n_rec, ctx->hits.as<Hit>(), hits_cap, ctx->h_scalar + 0, d_sc + 0);
-            SPSP_HIP(hipGetLastError());
-            ctx->dirty_tiles = 0;   // k_expand leaves bitmap and tile counts zeroed
-            hipLaunchKernelGGL(k_resolve<false>, dim3(rblocks), dim3(128), 0, ctx->stream, ctx->hits.as<Hit>(), d_sc + 0,
-                               hits_cap, d_rec_off, p->k, p->m, ctx->emit_count.as<uint32_t>(),
-                               (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, (uint64_t*)nullptr,
-                               (spsp_superkmer*)nullptr, 0u);
-            SPSP_HIP(hipGetLastError());
-            hipLaunchKernelGGL(k_scan_segments, dim3(n_seg_h), dim3(1024), 0, ctx->stream, ctx->emit_count.as<uint32_t>(),
-                               ctx->emit_off.as<uint32_t>(), (uint64_t)hits_cap, (const uint32_t*)(d_sc + 0),
-                               ctx->seg_b.as<uint32_t>());
-            SPSP_HIP(hipGetLastError());
-        }
-        d_sc = ctx->d_scalar.as<uint32_t>();
-        hipLaunchKernelGGL(k_resolve<true>, dim3(rblocks), dim3(128), 0, ctx->stream, ctx->hits.as<Hit>(), d_sc + 0, hits_cap,
-                           d_rec_off, p->k, p->m, (uint32_t*)nullptr, ctx->emit_off.as<uint32_t>(),
-                           ctx->seg_b.as<uint32_t>(), n_seg_h, ctx->h_scalar + 1, ctx->scan_tmp.as<spsp_superkmer>(), out_cap);
-        SPSP_HIP(hipGetLastError());
         SPSP_HIP(hipStreamSynchronize(ctx->stream));
         const uint64_t n_hits = ctx->h_scalar[0], n_em = ctx->h_scalar[1];
-        if (n_hits > hits_cap) {           // the bitmap has been consumed: start over with room for every hit
+        if (n_hits > J.hits_cap) {         // the bitmap has been consumed: start over with room for every hit
             ctx->hits_cap = n_hits + n_hits / 8 + 1024;
             if (ctx->out_cap < ctx->hits_cap && !dbg_out) ctx->out_cap = ctx->hits_cap;
-            redo_dense = true;
-            continue;
-        }
-        if (n_em > out_cap) {              // hits and offsets are intact: only the write pass repeats
+            J.redo_dense = true;
+        } else if (n_em > J.out_cap) {     // hits and offsets are intact: only the write pass repeats
             ctx->out_cap = n_em + n_em / 8 + 1024;
-            redo_dense = false;
-            continue;
+            J.redo_dense = false;
+        } else {
+            *d_out = n_em ? ctx->scan_tmp.as<spsp_superkmer>() : nullptr;
+            *n_out = n_em;
+            return SPSP_OK;
         }
-        *d_out = n_em ? ctx->scan_tmp.as<spsp_superkmer>() : nullptr;
-        *n_out = n_em;
-        return SPSP_OK;
+        if (attempt == 3) break;
+        if ((rc = scan_enqueue(ctx))) return rc;
     }
     set_error("scan buffers kept overflowing");
     return SPSP_ERR_OVERFLOW;
@@ -1091,11 +1126,10 @@ static int scan_device_inner(spsp_ctx* ctx, const spsp_params* p, const uint8_t*
 
 int scan_device_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, uint64_t n_bases,
                      const uint64_t* d_rec_off, uint32_t n_rec, spsp_superkmer** d_out, uint64_t* n_out) {
-    int rc = ctx->ev_begin(kEvScan);
+    *d_out = nullptr; *n_out = 0;
+    int rc = scan_begin_impl(ctx, p, d_bases, n_bases, d_rec_off, n_rec);
     if (rc) return rc;
-    rc = scan_device_inner(ctx, p, d_bases, n_bases, d_rec_off, n_rec, d_out, n_out);
-    const int rc2 = ctx->ev_end(kEvScan);
-    return rc ? rc : rc2;
+    return scan_end_impl(ctx, d_out, n_out);
 }
 
 }  // namespace spsp

@@ -157,12 +157,21 @@ class SlotExchange:
     def end(self, handle, d_inter):
         """d_inter: zero-initialised int32 [n_total, n_total] device tensor -> summed over ranks in place.
         Cell [0, 0] (unused by the pair matrix) counts the ranks whose slots overflowed: see overflowed()."""
-        from . import SpspError, ERR_OVERFLOW
+        self.end_queue(handle, d_inter)
+        self.end_collect(d_inter)
+
+    def end_queue(self, handle, d_inter):
+        """first half of end(): wait for the slots, queue the partial comparison (returns without waiting)"""
         if handle is not None:
             handle.wait()
+        self.ctx.compare_slots_device_begin(self.k, self.recv.data_ptr(), self.world, self.n_local, self.slot_cap,
+                                            d_inter.data_ptr())
+
+    def end_collect(self, d_inter):
+        """second half of end(): wait for the partial matrix, all-reduce it"""
+        from . import SpspError, ERR_OVERFLOW
         try:
-            self.ctx.compare_slots_device(self.k, self.recv.data_ptr(), self.world, self.n_local, self.slot_cap,
-                                          d_inter.data_ptr())
+            self.ctx.compare_end()
         except SpspError as e:
             if e.code != ERR_OVERFLOW:
                 raise

@@ -218,3 +218,55 @@ def test_partitioned_compare_collision_retry():
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SPSP_DEBUG_FP_BITS="8"), capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+# ----------------------------------------------------------------- begin / end (pipelined) forms of the ABI
+def test_begin_end_forms_on_two_streams_match_the_blocking_calls(ctx):
+    """scan on one context/stream and the comparison on another, both queued before either is waited for
+    (bench.py's pipelined step): results identical to the blocking calls, step after step."""
+    from oracle import oracle_py as orc
+    from supersampler_amd import synth
+    dev = torch.device("cuda", 0)
+    k, m, s = 31, 11, 50
+    p = sp.make_params(k, m, s)
+    genomes = synth.family_genomes(11, 6, 300_000, 2, [0.0, 0.01, 0.02])
+    bases, rec_off = synth.concat_records(genomes)
+    d_bases = torch.from_numpy(bases).to(dev)
+    d_off = torch.from_numpy(rec_off.view(np.int64)).to(dev)
+    sets = make_sets(np.random.default_rng(21), 70, False)
+    mn, lo, hi, off = rank_arrays(sets)
+    d_mn, d_lo = torch.from_numpy(mn.view(np.int32)).to(dev), torch.from_numpy(lo.view(np.int64)).to(dev)
+    torch.cuda.synchronize()
+    want_stream = ctx.scan(p, bases, rec_off)
+    want_inter = np.array([[len(sets[i] & sets[j]) if j > i else 0 for j in range(70)] for i in range(70)])
+    a, b = sp.Context(0), sp.Context(0)
+    try:
+        for step in range(3):
+            d_inter = torch.zeros((70, 70), dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            a.scan_device_begin(p, d_bases.data_ptr(), d_bases.numel(), d_off.data_ptr(), len(genomes))
+            b.wait_dense(a)
+            b.compare_device_begin(k, d_mn.data_ptr(), d_lo.data_ptr(), None, off, 70, 0, 1, d_inter.data_ptr())
+            with pytest.raises(sp.SpspError):      # one pending job of each kind per context
+                a.scan_device_begin(p, d_bases.data_ptr(), d_bases.numel(), d_off.data_ptr(), len(genomes))
+            with pytest.raises(sp.SpspError):
+                b.compare_device_begin(k, d_mn.data_ptr(), d_lo.data_ptr(), None, off, 70, 0, 1, d_inter.data_ptr())
+            d_out, n_out = a.scan_device_end()
+            b.compare_end()
+            got = a.to_host(d_out, n_out, sp.SUPERKMER_DTYPE)
+            assert n_out == len(want_stream) and got.tobytes() == np.asarray(want_stream).tobytes()
+            assert (d_inter.cpu().numpy() == want_inter).all()
+        with pytest.raises(sp.SpspError):
+            a.scan_device_end()                    # nothing pending
+        with pytest.raises(sp.SpspError):
+            b.compare_end()
+        # empty inputs keep begin/end paired
+        a.scan_device_begin(p, d_bases.data_ptr(), 5, d_off.data_ptr(), 1)
+        assert a.scan_device_end() == (None, 0)
+        b.compare_device_begin(k, d_mn.data_ptr(), d_lo.data_ptr(), None, np.zeros(3, np.uint64), 2, 0, 1, d_inter.data_ptr())
+        b.compare_end()
+    finally:
+        a.close()
+        b.close()
+    em_oracle, _ = orc.scan(k, m, orc.threshold(k, m, s), bases, rec_off)
+    assert len(em_oracle) == len(want_stream)
