@@ -165,21 +165,24 @@ def main():
                 continue
             # two streams, one host thread: everything is queued before anything is waited for
             ctx.scan_device_begin(p, d_bases.data_ptr(), d_bases.numel(), d_off.data_ptr(), len(recs))      # stream A
-            with torch.cuda.stream(stream_b):            # key partition + RCCL all-to-all, queued while the dense pass runs
-                h = exchange.begin(d_my_min.data_ptr(), d_my_lo.data_ptr(), None, my_sk_off) if exchange_kind == "slots" else None
-            ctx_cmp.wait_dense(ctx)                      # the comparison itself starts behind A's dense pass
-            with torch.cuda.stream(stream_b):
-                if exchange_kind == "slots":
+            if exchange_kind == "none":
+                ctx_cmp.wait_dense(ctx)                  # the comparison starts behind A's dense pass
+                ctx_cmp.compare_device_begin(K, d_all_min.data_ptr(), d_all_lo.data_ptr(), None, sk_off, n_total, rank, world,
+                                             d_inter.data_ptr())                                           # stream B
+                d_out, n_out = ctx.scan_device_end()
+                ctx_cmp.compare_end()
+                continue
+            with torch.cuda.stream(stream_b):            # torch ops and RCCL order themselves against stream B
+                if exchange_kind == "slots":             # key partition + all-to-all, queued while the dense pass runs
+                    h = exchange.begin(d_my_min.data_ptr(), d_my_lo.data_ptr(), None, my_sk_off)
+                    ctx_cmp.wait_dense(ctx)
                     exchange.end_queue(h, d_inter)
                 else:
-                    if exchange_kind == "gather":
-                        g = exchange.exchange(d_my_min, d_my_lo)
-                        mn_ptr, lo_ptr = g.minimizer.data_ptr(), g.kmer_lo.data_ptr()
-                    else:
-                        mn_ptr, lo_ptr = d_all_min.data_ptr(), d_all_lo.data_ptr()
-                    ctx_cmp.compare_device_begin(K, mn_ptr, lo_ptr, None, sk_off, n_total, rank, world, d_inter.data_ptr())
-            d_out, n_out = ctx.scan_device_end()
-            with torch.cuda.stream(stream_b):
+                    g = exchange.exchange(d_my_min, d_my_lo)
+                    ctx_cmp.wait_dense(ctx)
+                    ctx_cmp.compare_device_begin(K, g.minimizer.data_ptr(), g.kmer_lo.data_ptr(), None, sk_off, n_total, rank,
+                                                 world, d_inter.data_ptr())
+                d_out, n_out = ctx.scan_device_end()
                 if exchange_kind == "slots":
                     exchange.end_collect(d_inter)
                 else:

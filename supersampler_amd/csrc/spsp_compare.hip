@@ -40,10 +40,14 @@ struct Keys {
     uint64_t fp_mask;    // all ones; narrowed only by the collision-path test hook
 };
 
-__device__ __forceinline__ bool key_eq(const Keys& K, uint64_t a, uint64_t b) {
-    if (K.lo[a] != K.lo[b] || K.mn[a] != K.mn[b]) return false;
-    return K.hi ? K.hi[a] == K.hi[b] : true;
-}
+// full key of every occupied table slot (written once by the slot's owner in the insert pass): the fill pass
+// checks a candidate slot with loads that depend on the slot index only, not on a second hop through the owner
+struct SlotKeys {
+    uint64_t* lo;
+    uint64_t* hi;
+    uint32_t* mn;
+};
+
 __device__ __forceinline__ bool key_less(const Keys& K, uint64_t a, uint64_t b) {
     if (K.mn[a] != K.mn[b]) return K.mn[a] < K.mn[b];
     if (K.hi && K.hi[a] != K.hi[b]) return K.hi[a] < K.hi[b];
@@ -75,10 +79,22 @@ __device__ __forceinline__ uint32_t sketch_of(const uint64_t* __restrict__ sk_of
     return lo;
 }
 
+// One launch clears everything a dictionary build starts from: the table, the colour matrix (when its size is
+// already known) and the per-attempt flags -- three memsets' worth of launches and gaps otherwise.
+__global__ __launch_bounds__(256) void k_prepare(uint4* __restrict__ table, uint64_t table_vec, uint4* __restrict__ matrix,
+                                                uint64_t matrix_vec, uint32_t* __restrict__ flags, uint32_t n_flags) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    for (uint64_t i = t; i < table_vec; i += stride) table[i] = z;
+    for (uint64_t i = t; i < matrix_vec; i += stride) matrix[i] = z;
+    if (t < n_flags) flags[t] = 0;
+}
+
 // flags[0]: input not strictly sorted inside a sketch; flags[1]: fingerprint collision
 __global__ void k_insert(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n, uint64_t S, uint32_t row_first,
                          uint32_t row_stride, uint32_t row_limit, uint64_t seed, uint64_t* __restrict__ table, uint32_t log2cap,
-                         uint32_t* __restrict__ owner, uint32_t* __restrict__ flags) {
+                         uint32_t* __restrict__ owner, SlotKeys SK, uint32_t* __restrict__ flags) {
     // grid.y = sketch, grid.x = 256-key chunk of it (no per-entry search for the owning sketch)
     const uint32_t j = blockIdx.y;
     const uint64_t e = sk_off[j] + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -90,7 +106,12 @@ __global__ void k_insert(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n
     uint64_t pos = home_slot(fp, log2cap);
     for (;;) {
         const unsigned long long old = atomicCAS((unsigned long long*)&table[pos], 0ull, (unsigned long long)fp);
-        if (old == 0ull) { owner[pos] = (uint32_t)e; break; }   // the claiming entry is the slot's owner: one plain store
+        if (old == 0ull) {   // the claiming entry is the slot's owner: its index and its full key go next to the slot
+            owner[pos] = (uint32_t)e;
+            SK.lo[pos] = K.lo[e]; SK.mn[pos] = K.mn[e];
+            if (K.hi) SK.hi[pos] = K.hi[e];
+            break;
+        }
         if (old == fp) break;
         pos = (pos + 1) & mask;
     }
@@ -135,7 +156,7 @@ __global__ __launch_bounds__(kRowThreads) void k_assign_rows(const uint64_t* __r
 // the key's row, and (for owned sketches) remember the row for the accumulation.
 __global__ void k_fill(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n, uint64_t S, uint32_t row_first,
                        uint32_t row_stride, uint32_t row_limit, uint64_t seed, const uint64_t* __restrict__ table, uint32_t log2cap,
-                       const uint32_t* __restrict__ owner, const uint32_t* __restrict__ rowid, uint32_t W,
+                       const uint32_t* __restrict__ owner, const uint32_t* __restrict__ rowid, SlotKeys SK, uint32_t W,
                        unsigned long long* __restrict__ A, uint32_t* __restrict__ row_of_entry,
                        uint32_t* __restrict__ flags) {
     const uint32_t j = blockIdx.y;
@@ -149,8 +170,9 @@ __global__ void k_fill(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n, 
         if (v == 0) return;  // key not held by any owned sketch: contributes to no owned row
         if (v == fp) {
             const bool own = j % row_stride == row_first && j < row_limit;
-            if (key_eq(K, owner[pos], e)) {
-                const uint32_t r = rowid[pos];
+            const bool same = SK.lo[pos] == K.lo[e] && SK.mn[pos] == K.mn[e] && (!K.hi || SK.hi[pos] == K.hi[e]);
+            if (same) {
+                const uint32_t r = rowid ? rowid[pos] : owner[pos];   // direct mode: the owner's entry index is the row
                 atomicOr(&A[(uint64_t)r * W + (j >> 6)], 1ull << (j & 63));
                 if (own) row_of_entry[e] = r;
             } else if (own) {
@@ -260,10 +282,12 @@ struct ComparePlan {
 struct CompareJob {
     ComparePlan P;
     std::function<int(uint64_t seed, uint64_t fp_mask, uint32_t log2cap)> insert;
-    std::function<int(uint64_t seed, uint64_t fp_mask, uint32_t log2cap, uint32_t W)> fill;
+    std::function<int(uint64_t seed, uint64_t fp_mask, uint32_t log2cap, uint32_t W, bool direct_rows)> fill;
     uint32_t log2cap = 0, W = 0, lanes_per_key = 64, sblocks = 0;
     uint64_t cap = 0, seed = 0x5350535053505350ULL;
     bool speculative = false;
+    bool clear_all_flags = false;   // no pass before the first attempt has written flags
+    bool direct_rows = false;   // speculative and every row owned from entry 0: row id = the owner's entry index
     int attempt = 0;
 };
 // flags: [0] unsorted input, [1] fingerprint collision, [2] n_rows, [3] malformed slot, [4] slot overflow
@@ -272,25 +296,36 @@ static uint64_t job_fp_mask(const CompareJob& J) {
     static const char* dbg_fp = getenv("SPSP_DEBUG_FP_BITS");
     return (dbg_fp && J.attempt == 0) ? ((1ull << atoi(dbg_fp)) - 1) : ~0ull;
 }
-// dictionary build: table and row ids
+// dictionary build: table (and row ids unless the owner's entry index serves as the row)
 static int job_front(spsp_ctx* ctx, CompareJob& J) {
     uint32_t* flags = ctx->c_flags.as<uint32_t>();
-    SPSP_HIP(hipMemsetAsync(ctx->c_table.p, 0, (size_t)J.cap * 8, ctx->stream));
-    SPSP_HIP(hipMemsetAsync(flags, 0, 12, ctx->stream));   // [3], [4] belong to the slot index pass
-    int rc = J.insert(J.seed, job_fp_mask(J), J.log2cap);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_assign_rows, dim3(J.sblocks), dim3(kRowThreads), 0, ctx->stream, ctx->c_table.as<uint64_t>(), J.cap,
-                       ctx->c_rowid.as<uint32_t>(), flags + 2);
+    int rc;
+    // speculative: the matrix size is known now (one row per inserted key), so it is cleared by the same launch
+    const uint64_t m_bytes = J.speculative ? (uint64_t)J.P.S_own * J.W * 8 : 0;
+    if (m_bytes && (rc = ctx->c_matrix.reserve((size_t)((m_bytes + 15) & ~15ull)))) return rc;
+    const uint64_t t_vec = J.cap * 8 / 16, m_vec = (m_bytes + 15) / 16;
+    const uint64_t want = (t_vec + m_vec + 255) / 256, cap_blocks = (uint64_t)ctx->n_cu * 8;
+    hipLaunchKernelGGL(k_prepare, dim3((uint32_t)std::max<uint64_t>(1, std::min(want, cap_blocks))), dim3(256), 0, ctx->stream,
+                       ctx->c_table.as<uint4>(), t_vec, ctx->c_matrix.as<uint4>(), m_vec, flags,
+                       (J.attempt == 0 && J.clear_all_flags) ? 16u : 3u);   // [3], [4] belong to the slot index pass
     SPSP_HIP(hipGetLastError());
+    if ((rc = J.insert(J.seed, job_fp_mask(J), J.log2cap))) return rc;
+    if (!J.direct_rows) {
+        hipLaunchKernelGGL(k_assign_rows, dim3(J.sblocks), dim3(kRowThreads), 0, ctx->stream, ctx->c_table.as<uint64_t>(), J.cap,
+                           ctx->c_rowid.as<uint32_t>(), flags + 2);
+        SPSP_HIP(hipGetLastError());
+    }
     return SPSP_OK;
 }
 // colour matrix (room for `rows` rows), the row sums, and the flags on their way to the host
 static int job_back(spsp_ctx* ctx, CompareJob& J, uint64_t rows) {
     int rc;
     const ComparePlan& P = J.P;
-    if ((rc = ctx->c_matrix.reserve((size_t)rows * J.W * 8))) return rc;
-    SPSP_HIP(hipMemsetAsync(ctx->c_matrix.p, 0, (size_t)rows * J.W * 8, ctx->stream));
-    if ((rc = J.fill(J.seed, job_fp_mask(J), J.log2cap, J.W))) return rc;
+    if (!J.speculative) {   // sized by the row count just read back
+        if ((rc = ctx->c_matrix.reserve((size_t)rows * J.W * 8))) return rc;
+        SPSP_HIP(hipMemsetAsync(ctx->c_matrix.p, 0, (size_t)rows * J.W * 8, ctx->stream));
+    }
+    if ((rc = J.fill(J.seed, job_fp_mask(J), J.log2cap, J.W, J.direct_rows))) return rc;
     if ((rc = ctx->ev_begin(kEvAccumulate))) return rc;
     hipLaunchKernelGGL(k_accumulate, dim3((J.W + 63) / 64, P.n_own), dim3(kAccThreads), 0, ctx->stream,
                        ctx->c_row.as<uint32_t>(), ctx->c_matrix.as<uint64_t>(), J.W, J.lanes_per_key, P.sk_begin, P.sk_end,
@@ -328,6 +363,11 @@ static int compare_job_begin(spsp_ctx* ctx, CompareJob* job) {
     // A matrix with one row per inserted KEY (an upper bound on the distinct keys) is cheap for small inputs:
     // then the whole pipeline is queued without waiting for the row count and checked once at the end.
     J->speculative = (uint64_t)P.S_own * J->W * 8 <= (256ull << 20);
+    // owned entries form the prefix [0, S_own) of the entry space when rows are not strided over ranks
+    J->direct_rows = J->speculative && P.row_stride == 1 && P.row_first == 0;
+    if ((rc = ctx->c_slot_lo.reserve((size_t)J->cap * 8))) return rc;
+    if ((rc = ctx->c_slot_hi.reserve((size_t)J->cap * 8))) return rc;
+    if ((rc = ctx->c_slot_mn.reserve((size_t)J->cap * 4))) return rc;
     if ((rc = job_front(ctx, *J))) return rc;
     if (J->speculative && (rc = job_back(ctx, *J, P.S_own))) return rc;
     ctx->compare_job = J.release();
@@ -397,7 +437,6 @@ static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t*
     // a queued-but-unsynchronised earlier copy from h_skoff is ordered before this one on the same stream
     if ((rc = stage_sk_off(ctx, h_sk_off, n))) return rc;
     if ((rc = ctx->c_flags.reserve(64))) return rc;
-    SPSP_HIP(hipMemsetAsync(ctx->c_flags.p, 0, 64, ctx->stream));
     Keys K{d_min, d_lo, (k > 32) ? d_hi : nullptr, ~0ull};
     const uint64_t* sk = ctx->c_skoff.as<uint64_t>();
     uint32_t* flags = ctx->c_flags.as<uint32_t>();
@@ -406,19 +445,22 @@ static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t*
     const dim3 grid_all((uint32_t)((max_all + 255) / 256), n);
     CompareJob* J = new CompareJob;
     J->P = ComparePlan{S_own, S, n, n_own, row_first, row_stride, row_limit, sk, sk + 1, d_inter};
+    J->clear_all_flags = true;
     J->insert = [=](uint64_t seed, uint64_t fp_mask, uint32_t log2cap) -> int {
         Keys Km = K; Km.fp_mask = fp_mask;
         hipLaunchKernelGGL(k_insert, grid_all, dim3(256), 0, ctx->stream, Km, sk, n, S, row_first, row_stride, row_limit,
-                           seed, ctx->c_table.as<uint64_t>(), log2cap, ctx->c_owner.as<uint32_t>(), flags);
+                           seed, ctx->c_table.as<uint64_t>(), log2cap, ctx->c_owner.as<uint32_t>(),
+                           SlotKeys{ctx->c_slot_lo.as<uint64_t>(), ctx->c_slot_hi.as<uint64_t>(), ctx->c_slot_mn.as<uint32_t>()}, flags);
         SPSP_HIP(hipGetLastError());
         return SPSP_OK;
     };
-    J->fill = [=](uint64_t seed, uint64_t fp_mask, uint32_t log2cap, uint32_t W) -> int {
+    J->fill = [=](uint64_t seed, uint64_t fp_mask, uint32_t log2cap, uint32_t W, bool direct_rows) -> int {
         Keys Km = K; Km.fp_mask = fp_mask;
         hipLaunchKernelGGL(k_fill, grid_all, dim3(256), 0, ctx->stream, Km, sk, n, S, row_first, row_stride, row_limit, seed,
                            ctx->c_table.as<uint64_t>(), log2cap, ctx->c_owner.as<uint32_t>(),
-                           ctx->c_rowid.as<uint32_t>(), W, ctx->c_matrix.as<unsigned long long>(),
-                           ctx->c_row.as<uint32_t>(), flags);
+                           direct_rows ? (const uint32_t*)nullptr : ctx->c_rowid.as<uint32_t>(),
+                           SlotKeys{ctx->c_slot_lo.as<uint64_t>(), ctx->c_slot_hi.as<uint64_t>(), ctx->c_slot_mn.as<uint32_t>()},
+                           W, ctx->c_matrix.as<unsigned long long>(), ctx->c_row.as<uint32_t>(), flags);
         SPSP_HIP(hipGetLastError());
         return SPSP_OK;
     };
@@ -576,11 +618,6 @@ __device__ __forceinline__ uint64_t rec_fingerprint(const uint64_t* r, uint32_t 
     f &= fp_mask;
     return f ? f : 1;
 }
-__device__ __forceinline__ bool rec_eq(const uint64_t* a, const uint64_t* b, uint32_t words) {
-    if (a[0] != b[0] || (uint32_t)a[words - 1] != (uint32_t)b[words - 1]) return false;
-    return words == 3 ? a[1] == b[1] : true;
-}
-
 // receiver 1/3: per source slot, validate the header and turn the counts into entry ranges of the
 // GLOBAL sketch ids source * n + j (entry index space: source * slot_cap + position in the slot)
 __global__ __launch_bounds__(kPartThreads) void k_slot_index(SlotView V, uint64_t* __restrict__ sk_begin,
@@ -628,24 +665,30 @@ __global__ __launch_bounds__(kPartThreads) void k_slot_index(SlotView V, uint64_
 
 // receiver 2/3 and 3/3: k_insert / k_fill over slot records (every sketch is an owned row here)
 __global__ void k_insert_slots(SlotView V, const uint32_t* __restrict__ tot, uint64_t seed, uint64_t* __restrict__ table,
-                               uint32_t log2cap, uint32_t* __restrict__ owner) {
+                               uint32_t log2cap, uint32_t* __restrict__ owner, SlotKeys SK) {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= V.parts * V.cap) return;
     if (e % V.cap >= tot[e / V.cap]) return;
-    const uint64_t fp = rec_fingerprint(slot_rec(V, e), V.words, seed, V.fp_mask);
+    const uint64_t* r = slot_rec(V, e);
+    const uint64_t fp = rec_fingerprint(r, V.words, seed, V.fp_mask);
     const uint64_t mask = (1ull << log2cap) - 1;
     uint64_t pos = home_slot(fp, log2cap);
     for (;;) {
         const unsigned long long old = atomicCAS((unsigned long long*)&table[pos], 0ull, (unsigned long long)fp);
-        if (old == 0ull) { owner[pos] = e; break; }
+        if (old == 0ull) {
+            owner[pos] = e;
+            SK.lo[pos] = r[0]; SK.mn[pos] = (uint32_t)r[V.words - 1];
+            if (V.words == 3) SK.hi[pos] = r[1];
+            break;
+        }
         if (old == fp) break;
         pos = (pos + 1) & mask;
     }
 }
 __global__ void k_fill_slots(SlotView V, const uint32_t* __restrict__ tot, uint64_t seed, const uint64_t* __restrict__ table,
                              uint32_t log2cap, const uint32_t* __restrict__ owner, const uint32_t* __restrict__ rowid,
-                             uint32_t W, unsigned long long* __restrict__ A, uint32_t* __restrict__ row_of_entry,
-                             uint32_t* __restrict__ flags) {
+                             SlotKeys SK, uint32_t W, unsigned long long* __restrict__ A,
+                             uint32_t* __restrict__ row_of_entry, uint32_t* __restrict__ flags) {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= V.parts * V.cap) return;
     const uint32_t s = e / V.cap;
@@ -661,8 +704,10 @@ __global__ void k_fill_slots(SlotView V, const uint32_t* __restrict__ tot, uint6
         const uint64_t v = table[pos];
         if (v == 0) { atomicOr(&flags[3], 1u); return; }     // every record was inserted: cannot happen
         if (v == fp) {
-            if (rec_eq(slot_rec(V, owner[pos]), r, V.words)) {
-                const uint32_t row = rowid[pos];
+            const bool same = SK.lo[pos] == r[0] && SK.mn[pos] == (uint32_t)r[V.words - 1] &&
+                              (V.words != 3 || SK.hi[pos] == r[1]);
+            if (same) {
+                const uint32_t row = rowid ? rowid[pos] : owner[pos];
                 atomicOr(&A[(uint64_t)row * W + (g >> 6)], 1ull << (g & 63));
                 row_of_entry[e] = row;
             } else {
@@ -733,15 +778,17 @@ int compare_slots_begin_impl(spsp_ctx* ctx, uint32_t k, const uint8_t* d_slots, 
         J->insert = [=](uint64_t seed, uint64_t fp_mask, uint32_t log2cap) -> int {
             SlotView Vm = V; Vm.fp_mask = fp_mask;
             hipLaunchKernelGGL(k_insert_slots, grid, dim3(256), 0, ctx->stream, Vm, tot, seed, ctx->c_table.as<uint64_t>(),
-                               log2cap, ctx->c_owner.as<uint32_t>());
+                               log2cap, ctx->c_owner.as<uint32_t>(),
+                               SlotKeys{ctx->c_slot_lo.as<uint64_t>(), ctx->c_slot_hi.as<uint64_t>(), ctx->c_slot_mn.as<uint32_t>()});
             SPSP_HIP(hipGetLastError());
             return SPSP_OK;
         };
-        J->fill = [=](uint64_t seed, uint64_t fp_mask, uint32_t log2cap, uint32_t W) -> int {
+        J->fill = [=](uint64_t seed, uint64_t fp_mask, uint32_t log2cap, uint32_t W, bool direct_rows) -> int {
             SlotView Vm = V; Vm.fp_mask = fp_mask;
             hipLaunchKernelGGL(k_fill_slots, grid, dim3(256), 0, ctx->stream, Vm, tot, seed, ctx->c_table.as<uint64_t>(), log2cap,
-                               ctx->c_owner.as<uint32_t>(), ctx->c_rowid.as<uint32_t>(), W,
-                               ctx->c_matrix.as<unsigned long long>(), ctx->c_row.as<uint32_t>(), flags);
+                               ctx->c_owner.as<uint32_t>(), direct_rows ? (const uint32_t*)nullptr : ctx->c_rowid.as<uint32_t>(),
+                               SlotKeys{ctx->c_slot_lo.as<uint64_t>(), ctx->c_slot_hi.as<uint64_t>(), ctx->c_slot_mn.as<uint32_t>()},
+                               W, ctx->c_matrix.as<unsigned long long>(), ctx->c_row.as<uint32_t>(), flags);
             SPSP_HIP(hipGetLastError());
             return SPSP_OK;
         };

@@ -100,7 +100,7 @@ struct spsp_ctx {
     // ingest workspace (GPU-side getLineFasta + clean_dna)
     spsp::DevBuf i_text, i_tiles, i_entry, i_outoff, i_recbase, i_lens, i_dst, i_compact;
     // compare workspace
-    spsp::DevBuf c_min, c_lo, c_hi, c_table, c_owner, c_rowid, c_row, c_matrix, c_inter, c_flags, c_skoff;
+    spsp::DevBuf c_min, c_lo, c_hi, c_table, c_owner, c_rowid, c_row, c_matrix, c_inter, c_flags, c_skoff, c_slot_lo, c_slot_hi, c_slot_mn;
     spsp::DevBuf x_cnt, x_off, x_begin, x_end, x_tot;   // key-partitioned exchange (spsp_compare.hip)
 };
 

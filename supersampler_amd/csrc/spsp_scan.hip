@@ -630,32 +630,32 @@ __global__ __launch_bounds__(kThreads) void k_expand(const uint8_t* __restrict__
         const uint32_t total = seg_prefix(seg_sum, n_seg);
         *total_host = total; *total_dev = total;
     }
-    const uint64_t b = (uint64_t)blockIdx.x * kExpandTilesPerWg + (threadIdx.x >> 6);
+    // the tile index is wave-uniform: held in an SGPR so that every per-tile lookup below is a scalar load
+    const uint64_t b = (uint64_t)blockIdx.x * kExpandTilesPerWg + (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (b >= n_tiles) return;
-    if (tile_count[b] == 0) return;            // wave-uniform
+    if (tile_count[b] == 0) return;
     // the tile's 512 words as two coalesced 16-byte loads per lane: lane holds words
     // [4*lane, 4*lane+4) of each 256-word half, so position order = (half, lane, word)
     uint4* tile = reinterpret_cast<uint4*>(bitmap + b * kTileWords);
     uint4 q[2];
     q[0] = tile[lane]; q[1] = tile[64 + lane];
-    // record holding the tile's first position: one wave-uniform binary search, the hits then
-    // only step forward from it
+    // record holding the tile's first position: a binary search on the scalar unit (wave-uniform operands; the
+    // record table sits in the scalar cache) -- a vector load with 64 scattered probe addresses costs the
+    // texture path ~64 cycles per instruction, which was this kernel's largest item.  The hits then only step forward.
     const uint64_t tile_pos = b * kTilePos;
-    // 64-ary search by the whole wave: each round the lanes probe 64 evenly spaced offsets and a ballot
-    // keeps the sub-range, so a few thousand records need two dependent loads instead of a dozen
     uint32_t rlo = 0, rhi = n_rec;              // invariant: rec_off[rlo] <= tile_pos < rec_off[rhi]
     while (rhi - rlo > 1) {
-        const uint32_t span = rhi - rlo, step = (span + 63) / 64;
-        const uint32_t probe = lane * step;
-        const bool below = probe < span && rec_off[rlo + probe] <= tile_pos;   // true for a prefix of the lanes (lane 0 always)
-        const uint32_t cnt = (uint32_t)__popcll(__ballot(below));
-        const uint32_t nlo = rlo + (cnt - 1) * step;
-        const uint32_t nhi = cnt * step < span ? rlo + cnt * step : rhi;
-        rlo = nlo; rhi = nhi;
+        const uint32_t mid = (rlo + rhi) >> 1;
+        if (rec_off[mid] <= tile_pos) rlo = mid; else rhi = mid;
     }
+    // bounds of the three records a tile usually touches
+    const uint64_t ro0 = rec_off[rlo];
+    const uint64_t ro1 = rec_off[rlo + 1 <= n_rec ? rlo + 1 : n_rec];
+    const uint64_t ro2 = rec_off[rlo + 2 <= n_rec ? rlo + 2 : n_rec];
+    const uint32_t base_off = tile_off[b] + seg_prefix(seg_sum, (uint32_t)(b >> kSegShift));
     uint32_t cnt[2];
-    uint32_t rank[2];
-    uint32_t run = tile_off[b] + seg_prefix(seg_sum, (uint32_t)(b >> kSegShift));
+    uint32_t lrank[2];                          // tile-local rank of the lane's first hit in each half
+    uint32_t total = 0;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         cnt[h] = __popc(q[h].x) + __popc(q[h].y) + __popc(q[h].z) + __popc(q[h].w);
@@ -665,40 +665,57 @@ __global__ __launch_bounds__(kThreads) void k_expand(const uint8_t* __restrict__
             const uint32_t y = __shfl_up(x, d);
             if (lane >= (uint32_t)d) x += y;
         }
-        rank[h] = run + x - cnt[h];
-        run += __shfl(x, 63);
+        lrank[h] = total + x - cnt[h];
+        total += __shfl(x, 63);
         // leave the bitmap all-zero behind us: the pair-table dense pass publishes hits with
         // atomicOr into a zeroed bitmap, and this saves it a 1/8 B-per-position memset
         if (cnt[h]) tile[64 * h + lane] = make_uint4(0, 0, 0, 0);
     }
     if (lane == 0) tile_count[b] = 0;          // every lane has read it (same wave, program order)
+    // Hits are few and scattered over the lanes (one or two per tile at the default rate), so the lanes first
+    // hand their hit positions over through LDS in rank order and then lane l builds the record of hit l: one
+    // pass of m-mer loads + hash + store with up to 64 hits in flight, whatever lane found them.
+    __shared__ uint32_t s_pos[kExpandTilesPerWg][64];
+    uint32_t* my_pos = s_pos[threadIdx.x >> 6];
+    uint32_t w[2][4] = {{q[0].x, q[0].y, q[0].z, q[0].w}, {q[1].x, q[1].y, q[1].z, q[1].w}};
+    uint32_t next[2] = {lrank[0], lrank[1]};    // rank of the lane's next unpublished hit in each half
+    for (uint32_t cb = 0; cb < total; cb += 64) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const uint32_t w4[4] = {q[h].x, q[h].y, q[h].z, q[h].w};
-        uint32_t rk = rank[h];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            uint32_t bits = w4[i];
-            while (bits) {
-                const int bit = __ffs(bits) - 1;
-                bits &= bits - 1;
-                const uint64_t pos = tile_pos + (uint64_t)(256 * h + 4 * lane + i) * 32 + bit;
-                const uint32_t f = mmer_at(bases, n, pos, m);
-                const uint32_t rc = rc_mmer32(f, m);
-                Hit hrec;
-                hrec.pos = pos;
-                hrec.canon = f < rc ? f : rc;
-                hrec.hash = xxh64_u64(hrec.canon);
-                uint32_t r = rlo;
-                while (r + 1 < n_rec && rec_off[r + 1] <= pos) ++r;   // records shorter than a tile are rare
-                hrec.rec = r;
-                const uint64_t r0 = rec_off[r], r1 = rec_off[r + 1];
-                const bool usable = (pos + m <= r1) && (r1 - r0 >= k);
-                hrec.flags = (hrec.canon != f ? 1u : 0u) | (usable ? 2u : 0u);
-                hrec.pad = 0;
-                if (rk < hits_cap) hits[rk] = hrec;   // the host sees n_hits > hits_cap and retries with room
-                ++rk;
+        for (int h = 0; h < 2; ++h) {
+            while (next[h] < cb + 64 && next[h] < lrank[h] + cnt[h]) {
+                uint32_t wi, bit;
+                if (w[h][0]) { wi = 0; bit = __ffs(w[h][0]) - 1; w[h][0] &= w[h][0] - 1; }
+                else if (w[h][1]) { wi = 1; bit = __ffs(w[h][1]) - 1; w[h][1] &= w[h][1] - 1; }
+                else if (w[h][2]) { wi = 2; bit = __ffs(w[h][2]) - 1; w[h][2] &= w[h][2] - 1; }
+                else { wi = 3; bit = __ffs(w[h][3]) - 1; w[h][3] &= w[h][3] - 1; }
+                my_pos[next[h] - cb] = (256u * h + 4u * lane + wi) * 32u + bit;
+                ++next[h];
             }
+        }
+        // same wave, LDS operations complete in issue order: the reads below see the writes above
+        if (cb + lane < total) {
+            const uint64_t pos = tile_pos + my_pos[lane];
+            const uint32_t f = mmer_at(bases, n, pos, m);
+            const uint32_t rc = rc_mmer32(f, m);
+            Hit hrec;
+            hrec.pos = pos;
+            hrec.canon = f < rc ? f : rc;
+            hrec.hash = xxh64_u64(hrec.canon);
+            uint32_t r = rlo;
+            uint64_t r0 = ro0, r1 = ro1;
+            if (pos >= ro1 && rlo + 1 < n_rec) {
+                r = rlo + 1; r0 = ro1; r1 = ro2;
+                if (pos >= ro2 && rlo + 2 < n_rec) {              // several records inside one tile: rare
+                    while (r + 1 < n_rec && rec_off[r + 1] <= pos) ++r;
+                    r0 = rec_off[r]; r1 = rec_off[r + 1];
+                }
+            }
+            hrec.rec = r;
+            const bool usable = (pos + m <= r1) && (r1 - r0 >= k);
+            hrec.flags = (hrec.canon != f ? 1u : 0u) | (usable ? 2u : 0u);
+            hrec.pad = 0;
+            const uint32_t rk = base_off + cb + lane;
+            if (rk < hits_cap) hits[rk] = hrec;   // the host sees n_hits > hits_cap and retries with room
         }
     }
 }
