@@ -624,8 +624,11 @@ __global__ __launch_bounds__(kThreads) void k_expand(const uint8_t* __restrict__
                                                     const uint32_t* __restrict__ seg_sum, uint32_t n_seg,
                                                     uint64_t n_tiles, const uint64_t* __restrict__ rec_off, uint32_t n_rec,
                                                     Hit* __restrict__ hits, uint32_t hits_cap,
-                                                    uint64_t* __restrict__ total_host, uint32_t* __restrict__ total_dev) {
+                                                    uint64_t* __restrict__ total_host, uint32_t* __restrict__ total_dev,
+                                                    uint32_t* __restrict__ chunk_sum, uint32_t n_chunks) {
     const uint32_t lane = threadIdx.x & 63;
+    if (blockIdx.x == 0)                            // the count pass of k_resolve adds into these
+        for (uint32_t i = threadIdx.x; i < n_chunks; i += kThreads) chunk_sum[i] = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) {      // the hit total, for the host and for k_resolve
         const uint32_t total = seg_prefix(seg_sum, n_seg);
         *total_host = total; *total_dev = total;
@@ -828,43 +831,81 @@ __device__ uint32_t run_cluster(const Hit* __restrict__ H, uint32_t cnt, uint64_
     return nem;
 }
 
+// One lane per hit; cluster heads replay their cluster.  The count pass (WRITE = false) leaves, besides the
+// per-hit counts, one sum per wave and -- with one atomic per wave -- one sum per chunk of 64 waves; the write
+// pass turns those into its output offset itself (a masked wave load of each level + one wave reduction), so
+// no scan kernel sits between the two passes.
+constexpr int kResolveThreads = 128;
 template <bool WRITE>
-__global__ void k_resolve(const Hit* __restrict__ hits, const uint32_t* __restrict__ n_hits_dev, uint32_t hits_cap,
-                          const uint64_t* __restrict__ rec_off, uint32_t k, uint32_t m,
-                          uint32_t* __restrict__ emit_count, const uint32_t* __restrict__ emit_off,
-                          const uint32_t* __restrict__ seg_sum, uint32_t n_seg, uint64_t* __restrict__ total_host,
-                          spsp_superkmer* __restrict__ out, uint32_t out_cap) {
-    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
-    if (WRITE && h == 0) *total_host = seg_prefix(seg_sum, n_seg);   // number of super-k-mers, for the host
+__global__ __launch_bounds__(kResolveThreads) void k_resolve(const Hit* __restrict__ hits, const uint32_t* __restrict__ n_hits_dev,
+                                                             uint32_t hits_cap, const uint64_t* __restrict__ rec_off, uint32_t k,
+                                                             uint32_t m, uint32_t* __restrict__ emit_count,
+                                                             uint32_t* __restrict__ wave_sum, uint32_t* __restrict__ chunk_sum,
+                                                             uint32_t n_chunks, uint64_t* __restrict__ total_host,
+                                                             spsp_superkmer* __restrict__ out, uint32_t out_cap) {
+    const uint32_t h = blockIdx.x * kResolveThreads + threadIdx.x, lane = threadIdx.x & 63, gw = h >> 6;
     uint32_t n_hits = *n_hits_dev;
     if (n_hits > hits_cap) n_hits = hits_cap;   // overflowed: this pass is discarded by the host
-    if (h >= n_hits) return;
     const uint64_t w = k - m + 1;
-    const Hit me = hits[h];
-    bool head = (me.flags & 2u) != 0;
-    if (head) {
-        for (uint32_t g = h; g-- > 0;) {
-            const Hit o = hits[g];
-            if (me.pos - o.pos > w) break;
-            if ((o.flags & 2u) && o.rec == me.rec) { head = false; break; }
+    Hit me{};
+    bool head = false;
+    uint32_t cnt = 0;
+    if (h < n_hits) {
+        me = hits[h];
+        head = (me.flags & 2u) != 0;
+        if (head) {
+            for (uint32_t g = h; g-- > 0;) {
+                const Hit o = hits[g];
+                if (me.pos - o.pos > w) break;
+                if ((o.flags & 2u) && o.rec == me.rec) { head = false; break; }
+            }
+        }
+        if (head) {
+            cnt = 1;
+            while (h + cnt < n_hits) {
+                const Hit a = hits[h + cnt - 1], b = hits[h + cnt];
+                if (!(b.flags & 2u) || b.rec != me.rec || b.pos - a.pos > w) break;
+                ++cnt;
+            }
         }
     }
-    if (!head) {
-        if (!WRITE) emit_count[h] = 0;
+    uint64_t r0 = 0, r1 = 0;
+    if (head) { r0 = rec_off[me.rec]; r1 = rec_off[me.rec + 1]; }
+    if (!WRITE) {
+        const uint32_t c = head ? run_cluster<false>(hits + h, cnt, r0, r1 - r0, k, m, me.rec, nullptr, 0u) : 0u;
+        if (h < hits_cap) emit_count[h] = c;
+        uint32_t t = c;
+#pragma unroll
+        for (int d = 32; d; d >>= 1) t += __shfl_xor(t, d);
+        if (lane == 0) {
+            wave_sum[gw] = t;
+            if (t) atomicAdd(&chunk_sum[gw >> 6], t);
+        }
         return;
     }
-    uint32_t cnt = 1;
-    while (h + cnt < n_hits) {
-        const Hit a = hits[h + cnt - 1], b = hits[h + cnt];
-        if (!(b.flags & 2u) || b.rec != me.rec || b.pos - a.pos > w) break;
-        ++cnt;
+    // write pass: offset = chunks before mine + waves of my chunk before mine + lanes of my wave before me
+    const uint32_t c = h < hits_cap ? emit_count[h] : 0u;
+    uint32_t x = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d);
+        if (lane >= (uint32_t)d) x += y;
     }
-    const uint64_t r0 = rec_off[me.rec], r1 = rec_off[me.rec + 1];
-    if (WRITE) {
-        const uint32_t at = emit_off[h] + seg_prefix(seg_sum, h >> kSegShift);
+    const uint32_t wi = gw & 63u, ci = gw >> 6;
+    uint32_t v = lane < wi ? wave_sum[(gw & ~63u) + lane] : 0u;
+    for (uint32_t j = lane; j < ci; j += 64) v += chunk_sum[j];
+#pragma unroll
+    for (int d = 32; d; d >>= 1) v += __shfl_xor(v, d);
+    if (gw == 0) {   // number of super-k-mers, for the host
+        uint32_t tv = 0;
+        for (uint32_t j = lane; j < n_chunks; j += 64) tv += chunk_sum[j];
+#pragma unroll
+        for (int d = 32; d; d >>= 1) tv += __shfl_xor(tv, d);
+        if (lane == 0) *total_host = tv;
+    }
+    if (head) {
+        const uint32_t at = v + x - c;
         run_cluster<true>(hits + h, cnt, r0, r1 - r0, k, m, me.rec, out + at, at < out_cap ? out_cap - at : 0u);
-    } else {
-        emit_count[h] = run_cluster<false>(hits + h, cnt, r0, r1 - r0, k, m, me.rec, nullptr, 0u);
     }
 }
 
@@ -1045,11 +1086,12 @@ static int scan_enqueue(spsp_ctx* ctx) {
     J.hits_cap = hits_cap; J.out_cap = out_cap;
     if ((rc = ctx->hits.reserve((size_t)hits_cap * sizeof(Hit)))) return rc;
     if ((rc = ctx->emit_count.reserve((size_t)hits_cap * 4))) return rc;
-    if ((rc = ctx->emit_off.reserve((size_t)(hits_cap + 1) * 4))) return rc;
     if ((rc = ctx->scan_tmp.reserve((size_t)out_cap * sizeof(spsp_superkmer)))) return rc;
-    const uint32_t rblocks = (hits_cap + 127) / 128;
-    const uint32_t n_seg_h = (hits_cap + kSeg - 1) / kSeg;
-    if ((rc = ctx->seg_b.reserve((size_t)n_seg_h * 8))) return rc;
+    const uint32_t rblocks = (hits_cap + kResolveThreads - 1) / kResolveThreads;
+    const uint32_t n_waves = rblocks * (kResolveThreads / 64), n_chunks = (n_waves + 63) / 64;
+    if ((rc = ctx->seg_b.reserve((size_t)(n_chunks + n_waves) * 4))) return rc;
+    uint32_t* chunk_sum = ctx->seg_b.as<uint32_t>();
+    uint32_t* wave_sum = chunk_sum + n_chunks;
     uint32_t* d_sc = nullptr;
     if (J.redo_dense) {
         if ((rc = launch_dense(ctx, p, J.d_bases, J.n_bases, J.n_tiles, false))) return rc;
@@ -1058,23 +1100,19 @@ static int scan_enqueue(spsp_ctx* ctx) {
         hipLaunchKernelGGL(k_expand, dim3((uint32_t)((J.n_tiles + kExpandTilesPerWg - 1) / kExpandTilesPerWg)),
                            dim3(kThreads), 0, ctx->stream, J.d_bases, J.n_bases, p->k, p->m, ctx->bitmap.as<uint32_t>(),
                            ctx->tile_count.as<uint32_t>(), ctx->tile_off.as<uint32_t>(), ctx->seg_a.as<uint32_t>(),
-                           n_seg_t, J.n_tiles, J.d_rec_off, J.n_rec, ctx->hits.as<Hit>(), hits_cap, ctx->h_scalar + 0, d_sc + 0);
+                           n_seg_t, J.n_tiles, J.d_rec_off, J.n_rec, ctx->hits.as<Hit>(), hits_cap, ctx->h_scalar + 0, d_sc + 0,
+                           chunk_sum, n_chunks);
         SPSP_HIP(hipGetLastError());
         ctx->dirty_tiles = 0;   // k_expand leaves bitmap and tile counts zeroed
-        hipLaunchKernelGGL(k_resolve<false>, dim3(rblocks), dim3(128), 0, ctx->stream, ctx->hits.as<Hit>(), d_sc + 0,
-                           hits_cap, J.d_rec_off, p->k, p->m, ctx->emit_count.as<uint32_t>(),
-                           (const uint32_t*)nullptr, (const uint32_t*)nullptr, 0u, (uint64_t*)nullptr,
-                           (spsp_superkmer*)nullptr, 0u);
-        SPSP_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k_scan_segments, dim3(n_seg_h), dim3(1024), 0, ctx->stream, ctx->emit_count.as<uint32_t>(),
-                           ctx->emit_off.as<uint32_t>(), (uint64_t)hits_cap, (const uint32_t*)(d_sc + 0),
-                           ctx->seg_b.as<uint32_t>());
+        hipLaunchKernelGGL(k_resolve<false>, dim3(rblocks), dim3(kResolveThreads), 0, ctx->stream, ctx->hits.as<Hit>(), d_sc + 0,
+                           hits_cap, J.d_rec_off, p->k, p->m, ctx->emit_count.as<uint32_t>(), wave_sum, chunk_sum, n_chunks,
+                           (uint64_t*)nullptr, (spsp_superkmer*)nullptr, 0u);
         SPSP_HIP(hipGetLastError());
     }
     d_sc = ctx->d_scalar.as<uint32_t>();
-    hipLaunchKernelGGL(k_resolve<true>, dim3(rblocks), dim3(128), 0, ctx->stream, ctx->hits.as<Hit>(), d_sc + 0, hits_cap,
-                       J.d_rec_off, p->k, p->m, (uint32_t*)nullptr, ctx->emit_off.as<uint32_t>(),
-                       ctx->seg_b.as<uint32_t>(), n_seg_h, ctx->h_scalar + 1, ctx->scan_tmp.as<spsp_superkmer>(), out_cap);
+    hipLaunchKernelGGL(k_resolve<true>, dim3(rblocks), dim3(kResolveThreads), 0, ctx->stream, ctx->hits.as<Hit>(), d_sc + 0,
+                       hits_cap, J.d_rec_off, p->k, p->m, ctx->emit_count.as<uint32_t>(), wave_sum, chunk_sum, n_chunks,
+                       ctx->h_scalar + 1, ctx->scan_tmp.as<spsp_superkmer>(), out_cap);
     SPSP_HIP(hipGetLastError());
     return SPSP_OK;
 }
