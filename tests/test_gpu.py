@@ -122,6 +122,20 @@ def test_scan_randomised_configs(ctx):
             raise AssertionError("config it=%d k=%d m=%d s=%g mode=%d n=%d: %s" % (it, k, m, s, mode, len(bases), e))
 
 
+def test_scan_dense_selection_many_hits(ctx):
+    """a dense selection over 3 Mbp: several hundred thousand hits and super-k-mers, so the write pass of the
+    sparse stage sums more than 64 chunk totals and several 16-Ki-position tiles carry thousands of hits each"""
+    rng = np.random.default_rng(77)
+    gen = [synth.random_genome(rng, n) for n in (2_000_000, 999_983, 40)]
+    bases, offs = synth.concat_records(gen)
+    for k, m, s in [(15, 11, 2), (21, 15, 1.2)]:
+        p = sp.make_params(k, m, s)
+        got = ctx.scan(p, bases, offs)
+        want = _oracle_stream(k, m, p.threshold, bases, offs)
+        assert len(want) > 300_000
+        _assert_stream_equal(got, want)
+
+
 def test_scan_edge_inputs(ctx):
     p = sp.make_params(31, 11, 10)
     assert len(ctx.scan(p, np.zeros(0, np.uint8), np.zeros(1, np.uint64))) == 0
