@@ -333,11 +333,16 @@ static int job_back(spsp_ctx* ctx, CompareJob& J, uint64_t rows) {
     SPSP_HIP(hipGetLastError());
     return ctx->ev_end(kEvAccumulate);
 }
-static int job_read_flags(spsp_ctx* ctx, uint32_t* h_flags) {
+// the flags travel to pinned host memory as the last item of whatever has been queued ...
+static int job_queue_flags(spsp_ctx* ctx) {
     uint32_t* pinned = reinterpret_cast<uint32_t*>(ctx->h_scalar + 4);
     SPSP_HIP(hipMemcpyAsync(pinned, ctx->c_flags.p, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    return SPSP_OK;
+}
+// ... and are read after the one synchronisation
+static int job_wait_flags(spsp_ctx* ctx, uint32_t* h_flags) {
     SPSP_HIP(hipStreamSynchronize(ctx->stream));
-    memcpy(h_flags, pinned, 5 * sizeof(uint32_t));
+    memcpy(h_flags, ctx->h_scalar + 4, 5 * sizeof(uint32_t));
     if (h_flags[3]) { set_error("malformed exchange slot (header, sketch count or key count does not match)"); return SPSP_ERR_FORMAT; }
     if (h_flags[4]) { set_error("an exchange slot overflowed its capacity: partition again with a larger slot_cap"); return SPSP_ERR_OVERFLOW; }
     if (h_flags[0]) { set_error("sketch keys must be strictly increasing by (minimizer, kmer_hi, kmer_lo)"); return SPSP_ERR_ARG; }
@@ -370,6 +375,7 @@ static int compare_job_begin(spsp_ctx* ctx, CompareJob* job) {
     if ((rc = ctx->c_slot_mn.reserve((size_t)J->cap * 4))) return rc;
     if ((rc = job_front(ctx, *J))) return rc;
     if (J->speculative && (rc = job_back(ctx, *J, P.S_own))) return rc;
+    if ((rc = job_queue_flags(ctx))) return rc;
     ctx->compare_job = J.release();
     return SPSP_OK;
 }
@@ -382,16 +388,18 @@ int compare_job_end(spsp_ctx* ctx) {
     for (;;) {
         uint32_t h_flags[5];
         if (!J->speculative) {
-            if ((rc = job_read_flags(ctx, h_flags))) return rc;          // the row count sizes the colour matrix
+            if ((rc = job_wait_flags(ctx, h_flags))) return rc;          // the row count sizes the colour matrix
             if ((rc = job_back(ctx, *J, h_flags[2]))) return rc;
+            if ((rc = job_queue_flags(ctx))) return rc;
         }
-        if ((rc = job_read_flags(ctx, h_flags))) return rc;              // collisions surface in the fill pass
+        if ((rc = job_wait_flags(ctx, h_flags))) return rc;              // collisions surface in the fill pass
         if (!h_flags[1]) return SPSP_OK;
         if (J->attempt >= 4) { set_error("fingerprint collisions persisted over 5 seeds"); return SPSP_ERR_HIP; }
         ++J->attempt;
         J->seed = J->seed * 6364136223846793005ULL + 1442695040888963407ULL;  // new fingerprints, try again
         if ((rc = job_front(ctx, *J))) return rc;
         if (J->speculative && (rc = job_back(ctx, *J, J->P.S_own))) return rc;
+        if ((rc = job_queue_flags(ctx))) return rc;
     }
 }
 

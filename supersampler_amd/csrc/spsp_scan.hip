@@ -542,35 +542,59 @@ __global__ __launch_bounds__(1024) void k_exclusive_scan(const uint32_t* __restr
     }
 }
 
-// Two-level form for the two scans on the scan pipeline's critical path: every workgroup scans its own
-// 8 Ki elements, a one-wave kernel scans the workgroup sums; consumers add seg_off[i >> 13] themselves.
-constexpr int kSegShift = 13, kSeg = 1 << kSegShift;   // 1024 lanes x 8 elements
-__global__ __launch_bounds__(1024) void k_scan_segments(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
-                                                       uint64_t n_max, const uint32_t* __restrict__ n_dev,
-                                                       uint32_t* __restrict__ seg_sum) {
-    __shared__ uint32_t wave_sum[16];
+// Two-level form for the tile-count scan on the scan pipeline's critical path: every workgroup scans its own
+// segment (a power of two >= 1 Ki elements, chosen so that there are at most 64 segments) and leaves the
+// segment sum; consumers add the few preceding segment sums themselves.
+constexpr int kSegThreads = 256, kSegChunk = 4 * kSegThreads;
+static inline uint32_t seg_shift_for(uint64_t n) {
+    uint32_t sh = 10;
+    while (((n + (1ull << sh) - 1) >> sh) > 64) ++sh;
+    return sh;
+}
+__global__ __launch_bounds__(kSegThreads) void k_scan_segments(const uint32_t* __restrict__ in, uint32_t* __restrict__ out,
+                                                              uint64_t n, uint32_t seg_shift,
+                                                              uint32_t* __restrict__ seg_sum) {
+    __shared__ uint32_t wave_sum[kSegThreads / 64];
+    __shared__ uint32_t s_carry;
     const uint32_t t = threadIdx.x, lane = t & 63, wid = t >> 6;
-    uint64_t n = n_max;
-    if (n_dev) { const uint64_t v = *n_dev; n = v < n_max ? v : n_max; }
-    const uint64_t i0 = (uint64_t)blockIdx.x * kSeg + (uint64_t)t * 8;
-    uint32_t v[8];
-    uint32_t sum = 0;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) { v[u] = i0 + u < n ? in[i0 + u] : 0u; sum += v[u]; }
-    uint32_t x = sum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t y = __shfl_up(x, d);
-        if (lane >= (uint32_t)d) x += y;
-    }
-    if (lane == 63) wave_sum[wid] = x;
+    const uint64_t seg0 = (uint64_t)blockIdx.x << seg_shift;
+    const uint64_t seg1 = seg0 + (1ull << seg_shift) < n ? seg0 + (1ull << seg_shift) : n;
+    if (t == 0) s_carry = 0;
     __syncthreads();
-    uint32_t pre = 0, all = 0;
-    for (uint32_t w = 0; w < 16; ++w) { if (w < wid) pre += wave_sum[w]; all += wave_sum[w]; }
-    uint32_t run = pre + x - sum;
+    for (uint64_t c0 = seg0; c0 < seg1; c0 += kSegChunk) {
+        const uint64_t i0 = c0 + (uint64_t)t * 4;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (i0 + 4 <= seg1) v = *reinterpret_cast<const uint4*>(in + i0);   // segments start on 4 KiB boundaries
+        else {
+            if (i0 < seg1) v.x = in[i0];
+            if (i0 + 1 < seg1) v.y = in[i0 + 1];
+            if (i0 + 2 < seg1) v.z = in[i0 + 2];
+        }
+        const uint32_t sum = v.x + v.y + v.z + v.w;
+        uint32_t x = sum;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) { if (i0 + u < n) out[i0 + u] = run; run += v[u]; }
-    if (t == 0) seg_sum[blockIdx.x] = all;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d);
+            if (lane >= (uint32_t)d) x += y;
+        }
+        if (lane == 63) wave_sum[wid] = x;
+        __syncthreads();
+        uint32_t pre = s_carry, all = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < kSegThreads / 64; ++w) { if (w < wid) pre += wave_sum[w]; all += wave_sum[w]; }
+        const uint32_t e0 = pre + x - sum;
+        const uint4 o = make_uint4(e0, e0 + v.x, e0 + v.x + v.y, e0 + v.x + v.y + v.z);
+        if (i0 + 4 <= seg1) *reinterpret_cast<uint4*>(out + i0) = o;
+        else {
+            if (i0 < seg1) out[i0] = o.x;
+            if (i0 + 1 < seg1) out[i0 + 1] = o.y;
+            if (i0 + 2 < seg1) out[i0 + 2] = o.z;
+        }
+        __syncthreads();
+        if (t == 0) s_carry += all;
+        __syncthreads();
+    }
+    if (t == 0) seg_sum[blockIdx.x] = s_carry;
 }
 // prefix of the segment sums, computed by whoever needs it (a handful of segments: cheaper than a launch)
 __device__ __forceinline__ uint32_t seg_prefix(const uint32_t* __restrict__ seg_sum, uint32_t seg) {
@@ -635,7 +659,7 @@ __global__ __launch_bounds__(kThreads) void k_expand(const uint8_t* __restrict__
                                                     uint32_t* __restrict__ tile_count,
                                                     const uint32_t* __restrict__ tile_off,
                                                     const uint32_t* __restrict__ seg_sum, uint32_t n_seg,
-                                                    uint64_t n_tiles, const uint64_t* __restrict__ rec_off, uint32_t n_rec,
+                                                    uint32_t seg_shift, uint64_t n_tiles, const uint64_t* __restrict__ rec_off, uint32_t n_rec,
                                                     Hit* __restrict__ hits, uint32_t hits_cap,
                                                     uint64_t* __restrict__ total_host, uint32_t* __restrict__ total_dev,
                                                     uint32_t* __restrict__ chunk_sum, uint32_t n_chunks) {
@@ -668,7 +692,7 @@ __global__ __launch_bounds__(kThreads) void k_expand(const uint8_t* __restrict__
     const uint64_t ro0 = rec_off[rlo];
     const uint64_t ro1 = rec_off[rlo + 1 <= n_rec ? rlo + 1 : n_rec];
     const uint64_t ro2 = rec_off[rlo + 2 <= n_rec ? rlo + 2 : n_rec];
-    const uint32_t base_off = tile_off[b] + seg_prefix(seg_sum, (uint32_t)(b >> kSegShift));
+    const uint32_t base_off = tile_off[b] + seg_prefix(seg_sum, (uint32_t)(b >> seg_shift));
     uint32_t cnt[2];
     uint32_t lrank[2];                          // tile-local rank of the lane's first hit in each half
     uint32_t total = 0;
@@ -1051,10 +1075,11 @@ static int launch_dense(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_ba
     if ((rc = ctx->ev_end(kEvDense))) return rc;
     if (!ctx->dense_done) SPSP_HIP(hipEventCreateWithFlags(&ctx->dense_done, hipEventDisableTiming));
     SPSP_HIP(hipEventRecord(ctx->dense_done, ctx->stream));   // spsp_wait_dense: other streams may start behind the dense pass
-    const uint32_t n_seg = (uint32_t)((n_tiles + kSeg - 1) / kSeg);
+    const uint32_t seg_shift = seg_shift_for(n_tiles);
+    const uint32_t n_seg = (uint32_t)((n_tiles + (1ull << seg_shift) - 1) >> seg_shift);
     if ((rc = ctx->seg_a.reserve((size_t)n_seg * 8))) return rc;
-    hipLaunchKernelGGL(k_scan_segments, dim3(n_seg), dim3(1024), 0, ctx->stream, ctx->tile_count.as<uint32_t>(),
-                       ctx->tile_off.as<uint32_t>(), n_tiles, (const uint32_t*)nullptr, ctx->seg_a.as<uint32_t>());
+    hipLaunchKernelGGL(k_scan_segments, dim3(n_seg), dim3(kSegThreads), 0, ctx->stream, ctx->tile_count.as<uint32_t>(),
+                       ctx->tile_off.as<uint32_t>(), n_tiles, seg_shift, ctx->seg_a.as<uint32_t>());
     SPSP_HIP(hipGetLastError());
     if (want_total) {   // dense-only callers; the full pipeline lets k_expand publish the total
         hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(64), 0, ctx->stream, ctx->seg_a.as<uint32_t>(),
@@ -1110,11 +1135,12 @@ static int scan_enqueue(spsp_ctx* ctx) {
     if (J.redo_dense) {
         if ((rc = launch_dense(ctx, p, J.d_bases, J.n_bases, J.n_tiles, false))) return rc;
         d_sc = ctx->d_scalar.as<uint32_t>();
-        const uint32_t n_seg_t = (uint32_t)((J.n_tiles + kSeg - 1) / kSeg);
+        const uint32_t seg_shift = seg_shift_for(J.n_tiles);
+        const uint32_t n_seg_t = (uint32_t)((J.n_tiles + (1ull << seg_shift) - 1) >> seg_shift);
         hipLaunchKernelGGL(k_expand, dim3((uint32_t)((J.n_tiles + kExpandTilesPerWg - 1) / kExpandTilesPerWg)),
                            dim3(kThreads), 0, ctx->stream, J.d_bases, J.n_bases, p->k, p->m, ctx->bitmap.as<uint32_t>(),
                            ctx->tile_count.as<uint32_t>(), ctx->tile_off.as<uint32_t>(), ctx->seg_a.as<uint32_t>(),
-                           n_seg_t, J.n_tiles, J.d_rec_off, J.n_rec, ctx->hits.as<Hit>(), hits_cap, ctx->h_scalar + 0, d_sc + 0,
+                           n_seg_t, seg_shift, J.n_tiles, J.d_rec_off, J.n_rec, ctx->hits.as<Hit>(), hits_cap, ctx->h_scalar + 0, d_sc + 0,
                            chunk_sum, n_chunks);
         SPSP_HIP(hipGetLastError());
         ctx->dirty_tiles = 0;   // k_expand leaves bitmap and tile counts zeroed
