@@ -86,14 +86,33 @@ def main():
     ctx = sp.Context(local_rank, stream.cuda_stream)
     # Pipelined step (default): the scan of one batch and the all-vs-all of the previous batch's sketches are
     # independent, so they are queued on TWO HIP streams (two contexts, the begin/end forms of the ABI): the dense
-    # pass has the GPU to itself, then the latency-bound sparse stages of the scan and the comparison fill each
-    # other's idle CUs.  BENCH_PIPELINE=0 runs the two halves back to back on one stream.
+    # pass has the GPU to itself (stream order / spsp_wait_dense), then the
+    # latency-bound sparse stages of the scan and the comparison fill each other's idle CUs.  The host stays one
+    # step ahead: two such stream pairs alternate, step t+1 is queued before step t is collected, so the GPU never
+    # waits for the host.  BENCH_PIPELINE=0 runs the two halves back to back on one stream, one step at a time.
     pipelined = os.environ.get("BENCH_PIPELINE", "1") != "0"
-    if pipelined:
-        stream_b = torch.cuda.Stream(device=dev)
-        ctx_cmp = sp.Context(local_rank, stream_b.cuda_stream)
-    else:
-        stream_b, ctx_cmp = stream, ctx
+    strict_order = os.environ.get("BENCH_STRICT_ORDER") == "1"
+
+    class Slot:
+        pass
+
+    slots = []
+    for i in range(2 if pipelined else 1):
+        sl = Slot()
+        if pipelined:
+            sl.stream_a = stream                          # the scans of all steps share stream A: in order, no event waits
+            sl.scan = ctx if i == 0 else sp.Context(local_rank, stream.cuda_stream)   # (own workspace and results)
+            sl.stream_b = torch.cuda.Stream(device=dev)
+            sl.cmp = sp.Context(local_rank, sl.stream_b.cuda_stream)
+        else:
+            sl.stream_a = sl.stream_b = stream
+            sl.scan = sl.cmp = ctx
+        slots.append(sl)
+    all_ctx = []
+    for sl in slots:
+        for c in (sl.scan, sl.cmp):
+            if c not in all_ctx:
+                all_ctx.append(c)
 
     # ------------------------------------------------------------------ setup (untimed)
     t_setup = time.time()
@@ -128,68 +147,92 @@ def main():
     my_sk_off[1:] = np.cumsum(my_n)
     exchange_kind = os.environ.get("BENCH_EXCHANGE", "slots") if use_dist else "none"
     if exchange_kind == "slots":      # key-partitioned: all-to-all of own keys + all-reduce of partial matrices
-        exchange = spd.SlotExchange(ctx_cmp, K, args.genomes, int(my_sk_off[-1]), dev)
+        for sl in slots:
+            sl.exchange = spd.SlotExchange(sl.cmp, K, args.genomes, int(my_sk_off[-1]), dev)
         sk_off = np.zeros(n_total + 1, dtype=np.uint64)
-        sk_off[-1] = exchange.max_keys * world           # log line only
+        sk_off[-1] = slots[0].exchange.max_keys * world           # log line only
     elif exchange_kind == "gather":   # all-gather of every rank's keys + strided row ownership
-        exchange = spd.KeyExchange(my_n, dev)
-        sk_off = exchange.sk_off
+        for sl in slots:
+            sl.exchange = spd.KeyExchange(my_n, dev)
+        sk_off = slots[0].exchange.sk_off
     else:
         sk_off = np.zeros(n_total + 1, dtype=np.uint64)
         sk_off[1:] = np.cumsum(my_n)
         d_all_min, d_all_lo = d_my_min, d_my_lo
-    d_inter = torch.zeros((n_total, n_total), dtype=torch.int32, device=dev)
+    for sl in slots:
+        sl.d_inter = torch.zeros((n_total, n_total), dtype=torch.int32, device=dev)
+    d_inter = slots[0].d_inter
     pairs_per_step = n_total * (n_total - 1) // 2
     torch.cuda.synchronize()
     if rank == 0:
         log("setup %.1fs: %d genomes x %d bp per GPU, %d records, %d k-mers/step/GPU, %d sketch keys, %d pairs"
             % (time.time() - t_setup, args.genomes, args.length, len(recs), kmers_per_step, int(sk_off[-1]), pairs_per_step))
 
+    scan_args = (p, d_bases.data_ptr(), d_bases.numel(), d_off.data_ptr(), len(recs))
+
+    def queue_step(sl, prev):
+        """queue one whole step on slot sl without waiting for anything; on the GPU it starts behind slot prev"""
+        # stream A: behind the previous step's scan.  The previous comparison is all but done by then (its last
+        # kernel may overlap the start of this dense pass); a full spsp_wait_stream(prev.cmp) costs more in
+        # cross-queue latency than that overlap (BENCH_STRICT_ORDER=1 adds it).
+        if prev is not None and strict_order:
+            sl.scan.wait_stream(prev.cmp)
+        sl.scan.scan_device_begin(*scan_args)
+        if exchange_kind == "none":
+            sl.cmp.wait_dense(sl.scan)                    # the comparison starts behind A's dense pass
+            sl.cmp.compare_device_begin(K, d_all_min.data_ptr(), d_all_lo.data_ptr(), None, sk_off, n_total, rank, world,
+                                        sl.d_inter.data_ptr())                                             # stream B
+            return
+        with torch.cuda.stream(sl.stream_b):              # torch ops and RCCL order themselves against stream B
+            if exchange_kind == "slots":                  # key partition + all-to-all, queued while the dense pass runs
+                sl.handle = sl.exchange.begin(d_my_min.data_ptr(), d_my_lo.data_ptr(), None, my_sk_off)
+                sl.cmp.wait_dense(sl.scan)
+                sl.exchange.end_queue(sl.handle, sl.d_inter)
+            else:
+                g = sl.exchange.exchange(d_my_min, d_my_lo)
+                sl.cmp.wait_dense(sl.scan)
+                sl.cmp.compare_device_begin(K, g.minimizer.data_ptr(), g.kmer_lo.data_ptr(), None, sk_off, n_total, rank,
+                                            world, sl.d_inter.data_ptr())
+
+    def collect_step(sl):
+        d_out, n_out = sl.scan.scan_device_end()
+        if exchange_kind == "slots":
+            with torch.cuda.stream(sl.stream_b):
+                sl.exchange.end_collect(sl.d_inter)       # partial pair matrix done -> RCCL all-reduce
+        else:
+            sl.cmp.compare_end()
+        last["n_out"], last["slot"] = n_out, sl
+
     def run_steps(n):
         """n steps = n scans + n comparisons"""
-        n_out = 0
-        for _ in range(n):
-            if not pipelined:
+        if not pipelined:
+            sl = slots[0]
+            for _ in range(n):
                 # one stream: the key exchange (RCCL all-to-all) is queued first and runs behind the scan kernels
-                h = exchange.begin(d_my_min.data_ptr(), d_my_lo.data_ptr(), None, my_sk_off) if exchange_kind == "slots" else None
-                d_out, n_out = ctx.scan_device(p, d_bases.data_ptr(), d_bases.numel(), d_off.data_ptr(), len(recs))
+                h = sl.exchange.begin(d_my_min.data_ptr(), d_my_lo.data_ptr(), None, my_sk_off) if exchange_kind == "slots" else None
+                d_out, n_out = ctx.scan_device(*scan_args)
                 if exchange_kind == "slots":
-                    exchange.end(h, d_inter)             # partial pair matrix + RCCL all-reduce
-                    continue
-                if exchange_kind == "gather":
-                    g = exchange.exchange(d_my_min, d_my_lo)
-                    mn_ptr, lo_ptr = g.minimizer.data_ptr(), g.kmer_lo.data_ptr()
+                    sl.exchange.end(h, sl.d_inter)        # partial pair matrix + RCCL all-reduce
                 else:
-                    mn_ptr, lo_ptr = d_all_min.data_ptr(), d_all_lo.data_ptr()
-                ctx.compare_device(K, mn_ptr, lo_ptr, None, sk_off, n_total, rank, world, d_inter.data_ptr())
-                continue
-            # two streams, one host thread: everything is queued before anything is waited for
-            ctx.scan_device_begin(p, d_bases.data_ptr(), d_bases.numel(), d_off.data_ptr(), len(recs))      # stream A
-            if exchange_kind == "none":
-                ctx_cmp.wait_dense(ctx)                  # the comparison starts behind A's dense pass
-                ctx_cmp.compare_device_begin(K, d_all_min.data_ptr(), d_all_lo.data_ptr(), None, sk_off, n_total, rank, world,
-                                             d_inter.data_ptr())                                           # stream B
-                d_out, n_out = ctx.scan_device_end()
-                ctx_cmp.compare_end()
-                continue
-            with torch.cuda.stream(stream_b):            # torch ops and RCCL order themselves against stream B
-                if exchange_kind == "slots":             # key partition + all-to-all, queued while the dense pass runs
-                    h = exchange.begin(d_my_min.data_ptr(), d_my_lo.data_ptr(), None, my_sk_off)
-                    ctx_cmp.wait_dense(ctx)
-                    exchange.end_queue(h, d_inter)
-                else:
-                    g = exchange.exchange(d_my_min, d_my_lo)
-                    ctx_cmp.wait_dense(ctx)
-                    ctx_cmp.compare_device_begin(K, g.minimizer.data_ptr(), g.kmer_lo.data_ptr(), None, sk_off, n_total, rank,
-                                                 world, d_inter.data_ptr())
-                d_out, n_out = ctx.scan_device_end()
-                if exchange_kind == "slots":
-                    exchange.end_collect(d_inter)
-                else:
-                    ctx_cmp.compare_end()
-        last["n_out"] = n_out
+                    if exchange_kind == "gather":
+                        g = sl.exchange.exchange(d_my_min, d_my_lo)
+                        mn_ptr, lo_ptr = g.minimizer.data_ptr(), g.kmer_lo.data_ptr()
+                    else:
+                        mn_ptr, lo_ptr = d_all_min.data_ptr(), d_all_lo.data_ptr()
+                    ctx.compare_device(K, mn_ptr, lo_ptr, None, sk_off, n_total, rank, world, sl.d_inter.data_ptr())
+                last["n_out"], last["slot"] = n_out, sl
+            return
+        pending = None
+        for i in range(n):
+            sl = slots[i % len(slots)]
+            queue_step(sl, pending)                       # step i is on the GPU's queues ...
+            if pending is not None:
+                collect_step(pending)                     # ... before the host waits for step i-1
+            pending = sl
+        if pending is not None:
+            collect_step(pending)
 
-    last = {"n_out": 0}
+    last = {"n_out": 0, "slot": slots[0]}
 
     def fence():
         torch.cuda.synchronize()
@@ -198,8 +241,11 @@ def main():
         torch.cuda.synchronize()
 
     run_steps(args.warmup)
-    for c in {ctx, ctx_cmp}:
-        c.timing_enable(True)
+    # the roofline needs the dense kernel's duration from HIP events in the timed region; the other brackets
+    # (whole pipelines, accumulate kernel) are extra packets on the streams and are only recorded on request
+    kinds = sp.TIME_ALL if os.environ.get("BENCH_STAGE_TIMING", "0") == "1" or not pipelined else sp.TIME_DENSE
+    for c in all_ctx:
+        c.timing_enable(True, kinds)
         c.timing_read()
     fence()
     t0 = time.perf_counter()
@@ -207,12 +253,17 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     n_out = last["n_out"]
-    tm = ctx.timing_read()
-    tm_c = ctx_cmp.timing_read() if ctx_cmp is not ctx else tm
-    for key in ("compare_ms", "compare_calls", "accumulate_ms", "accumulate_launches"):
-        tm[key] = tm_c[key]
-    for c in {ctx, ctx_cmp}:
+    d_inter = last["slot"].d_inter
+    exchange = getattr(last["slot"], "exchange", None)
+    tm = None
+    for c in all_ctx:                                     # HIP-event logs of all contexts, summed
+        t = c.timing_read()
         c.timing_enable(False)
+        if tm is None:
+            tm = dict(t)
+        else:
+            for key in tm:
+                tm[key] += t[key]
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     agg = torch.tensor([float(kmers_per_step), tm["dense_ms"], tm["compare_ms"], tm["scan_ms"], tm["accumulate_ms"]],
@@ -277,11 +328,16 @@ def main():
                                        "gather": "genomes sharded by rank; pair-matrix rows i%N==rank after RCCL all-gather of "
                                                  "sketch keys"}[exchange_kind],
                        "exchange_check": exchange_check,
-                       "step": ("scan(batch t) on stream A || all-vs-all(sketches of batch t-1) on stream B" if pipelined
-                                else "scan then all-vs-all on one stream")},
-            "sketch_pairs_per_s": pairs_per_step / (compare_avg_ms / 1e3) if compare_avg_ms > 0 else None,
-            "stage_ms": {"scan_pipeline": scan_ms / max(1, tm["scan_calls"]), "dense_kernel": dense_avg_ms,
-                         "compare_pipeline": compare_avg_ms, "accumulate_kernel": acc_ms / max(1, tm["accumulate_launches"])},
+                       "step": ("scan(batch t) on stream A || all-vs-all(sketches of batch t-1) on stream B; two stream pairs "
+                                "alternate and the host queues step t+1 before collecting step t" if pipelined
+                                else "scan then all-vs-all on one stream, one step at a time")},
+            # with the comparison's own bracket: pairs / its pipeline time; otherwise the sustained rate of the whole step
+            "sketch_pairs_per_s": (pairs_per_step / (compare_avg_ms / 1e3) if compare_avg_ms > 0
+                                   else pairs_per_step * args.steps / elapsed),
+            "sketch_pairs_per_s_basis": "compare pipeline (HIP events)" if compare_avg_ms > 0 else "whole step (scan + all-vs-all)",
+            "stage_ms": {"scan_pipeline": scan_ms / tm["scan_calls"] if tm["scan_calls"] else None, "dense_kernel": dense_avg_ms,
+                         "compare_pipeline": compare_avg_ms if tm["compare_calls"] else None,
+                         "accumulate_kernel": acc_ms / tm["accumulate_launches"] if tm["accumulate_launches"] else None},
             "superkmers_per_step": int(n_out), "inter_nonzero": inter_nonzero,
             "roofline": {"kernel": "k_dense_pair (2-bit pack + LDS pair-table test of every m-mer position; XXH64 on survivors)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

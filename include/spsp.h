@@ -97,7 +97,14 @@ typedef struct spsp_timing {
     double compare_ms;     /* whole spsp_compare_device pipeline */
     uint64_t compare_calls;
 } spsp_timing;
-int spsp_timing_enable(spsp_ctx* ctx, int on);
+/* `kinds` = OR of SPSP_TIME_* (0 = off).  Every bracketed region costs two event records on the stream, i.e. two
+ * packets the following kernels queue behind (~5 us each on an otherwise idle queue): enable what you read. */
+#define SPSP_TIME_DENSE 1
+#define SPSP_TIME_SCAN 2
+#define SPSP_TIME_ACCUMULATE 4
+#define SPSP_TIME_COMPARE 8
+#define SPSP_TIME_ALL 15
+int spsp_timing_enable(spsp_ctx* ctx, int kinds);
 /* synchronises the stream, returns the totals since the previous read and resets them */
 int spsp_timing_read(spsp_ctx* ctx, spsp_timing* out);
 
@@ -132,6 +139,8 @@ int spsp_scan_device_end(spsp_ctx* ctx, void** d_out, uint64_t* n_out);
  * once the dense pass of `scanner`'s most recently queued scan has finished (the dense pass fills every CU;
  * latency-bound work of another stream overlaps best with the sparse stages behind it). */
 int spsp_wait_dense(spsp_ctx* waiter, spsp_ctx* scanner);
+/* ... only once everything queued on `other` so far has finished. */
+int spsp_wait_stream(spsp_ctx* waiter, spsp_ctx* other);
 
 /* Dense stage only (hash + threshold + hit bitmap), for the roofline
  * measurement: returns the number of m-mers with hash <= threshold. */

@@ -28,6 +28,7 @@ class SpspError(RuntimeError):
 
 
 ERR_OVERFLOW = -7
+TIME_DENSE, TIME_SCAN, TIME_ACCUMULATE, TIME_COMPARE, TIME_ALL = 1, 2, 4, 8, 15
 
 
 class Params(C.Structure):
@@ -57,7 +58,7 @@ SUPERKMER_DTYPE = np.dtype([("rec", "<u4"), ("minimizer", "<u4"), ("start", "<u8
 # every symbol include/spsp.h declares (tests check the .so exports them all)
 ABI_SYMBOLS = [
     "spsp_create", "spsp_destroy", "spsp_last_error", "spsp_version", "spsp_free", "spsp_copy_to_host",
-    "spsp_timing_enable", "spsp_timing_read", "spsp_threshold_host", "spsp_scan", "spsp_scan_device", "spsp_scan_device_begin", "spsp_scan_device_end", "spsp_wait_dense", "spsp_scan_hits_device", "spsp_compare",
+    "spsp_timing_enable", "spsp_timing_read", "spsp_threshold_host", "spsp_scan", "spsp_scan_device", "spsp_scan_device_begin", "spsp_scan_device_end", "spsp_wait_dense", "spsp_wait_stream", "spsp_scan_hits_device", "spsp_compare",
     "spsp_compare_device", "spsp_slot_bytes", "spsp_partition_keys_device", "spsp_compare_slots_device", "spsp_compare_device_begin", "spsp_compare_slots_device_begin", "spsp_compare_end", "spsp_fasta_clean_host", "spsp_fasta_clean_device", "spsp_sketch_text", "spsp_sketch_build_host", "spsp_sketch_parse_host",
     "spsp_csv_host", "spsp_read_file_host", "spsp_write_gz_host", "spsp_sketch_file", "spsp_compare_files",
 ]
@@ -91,6 +92,7 @@ def lib():
     L.spsp_scan_device_begin.argtypes = [vp, P(Params), vp, u64, vp, u32]
     L.spsp_scan_device_end.restype = i32; L.spsp_scan_device_end.argtypes = [vp, P(vp), P(u64)]
     L.spsp_wait_dense.restype = i32; L.spsp_wait_dense.argtypes = [vp, vp]
+    L.spsp_wait_stream.restype = i32; L.spsp_wait_stream.argtypes = [vp, vp]
     L.spsp_compare_device_begin.restype = i32
     L.spsp_compare_device_begin.argtypes = [vp, u32, vp, vp, vp, vp, u32, u32, u32, u32, vp]
     L.spsp_compare_slots_device_begin.restype = i32
@@ -257,8 +259,9 @@ class Context:
         return out
 
     # ---- measurement
-    def timing_enable(self, on=True):
-        _check(lib().spsp_timing_enable(self._h, 1 if on else 0))
+    def timing_enable(self, on=True, kinds=TIME_ALL):
+        """HIP-event brackets for the regions in `kinds` (TIME_DENSE | TIME_SCAN | TIME_ACCUMULATE | TIME_COMPARE)"""
+        _check(lib().spsp_timing_enable(self._h, int(kinds) if on else 0))
 
     def timing_read(self):
         """HIP-event totals since the last read (synchronises the stream) as a dict."""
@@ -298,6 +301,10 @@ class Context:
     def wait_dense(self, scanner):
         """work queued on this context from now on starts behind `scanner`'s latest dense pass"""
         _check(lib().spsp_wait_dense(self._h, scanner._h))
+
+    def wait_stream(self, other):
+        """work queued on this context from now on starts behind everything queued on `other` so far"""
+        _check(lib().spsp_wait_stream(self._h, other._h))
 
     def scan_hits_device(self, params, d_bases, n_bases):
         n = C.c_uint64()

@@ -47,7 +47,7 @@ void DevBuf::release() {
 using namespace spsp;
 
 int spsp_ctx::ev_begin(int kind) {
-    if (!timing) return SPSP_OK;
+    if (!(timing_mask & (1u << kind))) return SPSP_OK;
     EventLog& L = evlog[kind];
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (!L.spare.empty()) { ev = L.spare.back(); L.spare.pop_back(); }
@@ -57,7 +57,7 @@ int spsp_ctx::ev_begin(int kind) {
     return SPSP_OK;
 }
 int spsp_ctx::ev_end(int kind) {
-    if (!timing) return SPSP_OK;
+    if (!(timing_mask & (1u << kind))) return SPSP_OK;
     SPSP_HIP(hipEventRecord(evlog[kind].used.back().second, stream));
     return SPSP_OK;
 }
@@ -66,7 +66,9 @@ extern "C" {
 
 int spsp_timing_enable(spsp_ctx* ctx, int on) {
     if (!ctx) { set_error("NULL argument"); return SPSP_ERR_ARG; }
-    ctx->timing = on != 0;
+    // SPSP_TIME_*: bit 0 dense kernel, 1 scan pipeline, 2 accumulate kernel, 3 compare pipeline
+    ctx->timing_mask = (uint32_t)on & 15u;
+    ctx->timing = ctx->timing_mask != 0;
     return SPSP_OK;
 }
 
@@ -137,6 +139,7 @@ void spsp_destroy(spsp_ctx* c) {
     compare_job_drop(c);
     if (c->h_skoff) (void)hipHostFree(c->h_skoff);
     if (c->dense_done) (void)hipEventDestroy(c->dense_done);
+    if (c->tail_event) (void)hipEventDestroy(c->tail_event);
     DevBuf* bufs[] = {&c->bases, &c->rec_off, &c->bitmap, &c->tile_count, &c->tile_off, &c->hits, &c->emit_count,
                       &c->emit_off, &c->scan_tmp, &c->d_scalar, &c->seg_a, &c->seg_b, &c->filter, &c->pairtab, &c->c_min, &c->c_lo, &c->c_hi, &c->c_table,
                       &c->c_owner, &c->c_rowid, &c->c_row, &c->x_cnt, &c->x_off, &c->x_begin, &c->x_end, &c->x_tot, &c->c_matrix, &c->c_inter, &c->c_flags, &c->c_slot_lo, &c->c_slot_hi, &c->c_slot_mn,
@@ -224,8 +227,19 @@ int spsp_wait_dense(spsp_ctx* waiter, spsp_ctx* scanner) {
     if (!waiter || !scanner) { set_error("NULL argument"); return SPSP_ERR_ARG; }
     if (waiter->device != scanner->device) { set_error("both contexts must be on the same device"); return SPSP_ERR_ARG; }
     SPSP_HIP(hipSetDevice(waiter->device));
-    if (scanner->dense_done && waiter->stream != scanner->stream)
-        SPSP_HIP(hipStreamWaitEvent(waiter->stream, scanner->dense_done, 0));
+    if (scanner->dense_marker && waiter->stream != scanner->stream)
+        SPSP_HIP(hipStreamWaitEvent(waiter->stream, scanner->dense_marker, 0));
+    return SPSP_OK;
+}
+
+int spsp_wait_stream(spsp_ctx* waiter, spsp_ctx* other) {
+    if (!waiter || !other) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    if (waiter->device != other->device) { set_error("both contexts must be on the same device"); return SPSP_ERR_ARG; }
+    if (waiter->stream == other->stream) return SPSP_OK;
+    SPSP_HIP(hipSetDevice(waiter->device));
+    if (!other->tail_event) SPSP_HIP(hipEventCreateWithFlags(&other->tail_event, hipEventDisableTiming));
+    SPSP_HIP(hipEventRecord(other->tail_event, other->stream));
+    SPSP_HIP(hipStreamWaitEvent(waiter->stream, other->tail_event, 0));
     return SPSP_OK;
 }
 

@@ -82,13 +82,18 @@ __device__ __forceinline__ uint32_t sketch_of(const uint64_t* __restrict__ sk_of
 // One launch clears everything a dictionary build starts from: the table, the colour matrix (when its size is
 // already known) and the per-attempt flags -- three memsets' worth of launches and gaps otherwise.
 __global__ __launch_bounds__(256) void k_prepare(uint4* __restrict__ table, uint64_t table_vec, uint4* __restrict__ matrix,
-                                                uint64_t matrix_vec, uint32_t* __restrict__ flags, uint32_t n_flags) {
+                                                uint64_t matrix_vec, uint32_t* __restrict__ flags, uint32_t n_flags,
+                                                const uint64_t* __restrict__ host_skoff, uint64_t* __restrict__ dev_skoff,
+                                                uint32_t n_skoff) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint4 z = make_uint4(0, 0, 0, 0);
     for (uint64_t i = t; i < table_vec; i += stride) table[i] = z;
     for (uint64_t i = t; i < matrix_vec; i += stride) matrix[i] = z;
     if (t < n_flags) flags[t] = 0;
+    // the sketch offsets come straight out of the caller's (pinned, device-visible) staging copy: no separate
+    // host-to-device copy, and its completion wait, in front of the pipeline
+    for (uint64_t i = t; i < n_skoff; i += stride) dev_skoff[i] = host_skoff[i];
 }
 
 // flags[0]: input not strictly sorted inside a sketch; flags[1]: fingerprint collision
@@ -202,7 +207,11 @@ __global__ __launch_bounds__(kAccThreads) void k_accumulate(const uint32_t* __re
                                                            const uint64_t* __restrict__ sk_begin,
                                                            const uint64_t* __restrict__ sk_end, uint32_t n,
                                                            uint32_t row_first, uint32_t row_stride, uint32_t row_limit,
-                                                           uint32_t* __restrict__ inter) {
+                                                           uint32_t* __restrict__ inter, const uint32_t* __restrict__ flags,
+                                                           uint32_t* __restrict__ host_flags) {
+    // every pass that can raise a flag has finished: hand them to the host (pinned memory) from here, so the
+    // pipeline ends with this kernel and not with a device-to-host copy behind it
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 5) host_flags[threadIdx.x] = flags[threadIdx.x];
     const uint32_t i = row_first + blockIdx.y * row_stride;
     if (i >= n || i >= row_limit) return;
     const uint32_t wb = blockIdx.x;                         // block of 64 words
@@ -286,6 +295,7 @@ struct CompareJob {
     uint32_t log2cap = 0, W = 0, lanes_per_key = 64, sblocks = 0;
     uint64_t cap = 0, seed = 0x5350535053505350ULL;
     bool speculative = false;
+    uint32_t n_skoff = 0;           // flat form: sketch offsets to bring over from the pinned staging copy
     bool clear_all_flags = false;   // no pass before the first attempt has written flags
     bool direct_rows = false;   // speculative and every row owned from entry 0: row id = the owner's entry index
     int attempt = 0;
@@ -307,7 +317,8 @@ static int job_front(spsp_ctx* ctx, CompareJob& J) {
     const uint64_t want = (t_vec + m_vec + 255) / 256, cap_blocks = (uint64_t)ctx->n_cu * 8;
     hipLaunchKernelGGL(k_prepare, dim3((uint32_t)std::max<uint64_t>(1, std::min(want, cap_blocks))), dim3(256), 0, ctx->stream,
                        ctx->c_table.as<uint4>(), t_vec, ctx->c_matrix.as<uint4>(), m_vec, flags,
-                       (J.attempt == 0 && J.clear_all_flags) ? 16u : 3u);   // [3], [4] belong to the slot index pass
+                       (J.attempt == 0 && J.clear_all_flags) ? 16u : 3u,    // [3], [4] belong to the slot index pass
+                       (const uint64_t*)ctx->h_skoff, ctx->c_skoff.as<uint64_t>(), J.n_skoff);
     SPSP_HIP(hipGetLastError());
     if ((rc = J.insert(J.seed, job_fp_mask(J), J.log2cap))) return rc;
     if (!J.direct_rows) {
@@ -329,7 +340,8 @@ static int job_back(spsp_ctx* ctx, CompareJob& J, uint64_t rows) {
     if ((rc = ctx->ev_begin(kEvAccumulate))) return rc;
     hipLaunchKernelGGL(k_accumulate, dim3((J.W + 63) / 64, P.n_own), dim3(kAccThreads), 0, ctx->stream,
                        ctx->c_row.as<uint32_t>(), ctx->c_matrix.as<uint64_t>(), J.W, J.lanes_per_key, P.sk_begin, P.sk_end,
-                       P.n, P.row_first, P.row_stride, P.row_limit, P.d_inter);
+                       P.n, P.row_first, P.row_stride, P.row_limit, P.d_inter, ctx->c_flags.as<uint32_t>(),
+                       reinterpret_cast<uint32_t*>(ctx->h_scalar + 4));
     SPSP_HIP(hipGetLastError());
     return ctx->ev_end(kEvAccumulate);
 }
@@ -374,8 +386,8 @@ static int compare_job_begin(spsp_ctx* ctx, CompareJob* job) {
     if ((rc = ctx->c_slot_hi.reserve((size_t)J->cap * 8))) return rc;
     if ((rc = ctx->c_slot_mn.reserve((size_t)J->cap * 4))) return rc;
     if ((rc = job_front(ctx, *J))) return rc;
-    if (J->speculative && (rc = job_back(ctx, *J, P.S_own))) return rc;
-    if ((rc = job_queue_flags(ctx))) return rc;
+    if (J->speculative) { if ((rc = job_back(ctx, *J, P.S_own))) return rc; }   // k_accumulate forwards the flags
+    else if ((rc = job_queue_flags(ctx))) return rc;                             // the row count is needed first
     ctx->compare_job = J.release();
     return SPSP_OK;
 }
@@ -390,7 +402,6 @@ int compare_job_end(spsp_ctx* ctx) {
         if (!J->speculative) {
             if ((rc = job_wait_flags(ctx, h_flags))) return rc;          // the row count sizes the colour matrix
             if ((rc = job_back(ctx, *J, h_flags[2]))) return rc;
-            if ((rc = job_queue_flags(ctx))) return rc;
         }
         if ((rc = job_wait_flags(ctx, h_flags))) return rc;              // collisions surface in the fill pass
         if (!h_flags[1]) return SPSP_OK;
@@ -398,8 +409,8 @@ int compare_job_end(spsp_ctx* ctx) {
         ++J->attempt;
         J->seed = J->seed * 6364136223846793005ULL + 1442695040888963407ULL;  // new fingerprints, try again
         if ((rc = job_front(ctx, *J))) return rc;
-        if (J->speculative && (rc = job_back(ctx, *J, J->P.S_own))) return rc;
-        if ((rc = job_queue_flags(ctx))) return rc;
+        if (J->speculative) { if ((rc = job_back(ctx, *J, J->P.S_own))) return rc; }
+        else if ((rc = job_queue_flags(ctx))) return rc;
     }
 }
 
@@ -418,11 +429,8 @@ static int stage_sk_off(spsp_ctx* ctx, const uint64_t* h_sk_off, uint32_t n) {
         SPSP_HIP(hipHostMalloc((void**)&ctx->h_skoff, cap * 8, hipHostMallocDefault));
         ctx->h_skoff_cap = cap;
     }
-    memcpy(ctx->h_skoff, h_sk_off, need * 8);
-    int rc;
-    if ((rc = ctx->c_skoff.reserve(need * 8))) return rc;
-    SPSP_HIP(hipMemcpyAsync(ctx->c_skoff.p, ctx->h_skoff, need * 8, hipMemcpyHostToDevice, ctx->stream));
-    return SPSP_OK;
+    memcpy(ctx->h_skoff, h_sk_off, need * 8);   // k_prepare copies it to c_skoff; no job is pending, so the stream has drained
+    return ctx->c_skoff.reserve(need * 8);
 }
 
 // returns 1 when there is nothing to do (no job queued), 0 when a job is pending, < 0 on error
@@ -454,6 +462,7 @@ static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t*
     CompareJob* J = new CompareJob;
     J->P = ComparePlan{S_own, S, n, n_own, row_first, row_stride, row_limit, sk, sk + 1, d_inter};
     J->clear_all_flags = true;
+    J->n_skoff = n + 1;
     J->insert = [=](uint64_t seed, uint64_t fp_mask, uint32_t log2cap) -> int {
         Keys Km = K; Km.fp_mask = fp_mask;
         hipLaunchKernelGGL(k_insert, grid_all, dim3(256), 0, ctx->stream, Km, sk, n, S, row_first, row_stride, row_limit,

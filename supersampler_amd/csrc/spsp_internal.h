@@ -66,7 +66,8 @@ struct CompareJob;   // spsp_compare.hip
 }  // namespace spsp
 
 struct spsp_ctx {
-    bool timing = false;
+    bool timing = false;          // any kind enabled
+    uint32_t timing_mask = 0;     // bit k: regions of kind k (kEvDense ...) are bracketed by events
     spsp::EventLog evlog[spsp::kEvKinds];
     // begin/end bracket for one timed region; no-ops unless timing is on
     int ev_begin(int kind);
@@ -76,7 +77,9 @@ struct spsp_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     uint64_t* h_scalar = nullptr;  // pinned, 8 slots: [0] hits, [1] super-k-mers, [4..6] compare flags
-    hipEvent_t dense_done = nullptr;   // recorded behind every dense pass
+    hipEvent_t dense_done = nullptr;   // recorded behind every dense pass (unless a timing event already is)
+    hipEvent_t dense_marker = nullptr; // what spsp_wait_dense waits on
+    hipEvent_t tail_event = nullptr;   // spsp_wait_stream: marks the current end of this context's stream
     spsp::ScanJob scan_job;
     spsp::CompareJob* compare_job = nullptr;
     uint64_t* h_skoff = nullptr;       // pinned staging for the sketch offsets of a queued comparison

@@ -1073,8 +1073,15 @@ static int launch_dense(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_ba
     if (n_tiles > ctx->dirty_tiles) ctx->dirty_tiles = n_tiles;   // until k_expand has consumed (and zeroed) them
     if (n_tiles > ctx->zeroed_tiles) ctx->zeroed_tiles = n_tiles; // ... after which this whole range is zero
     if ((rc = ctx->ev_end(kEvDense))) return rc;
-    if (!ctx->dense_done) SPSP_HIP(hipEventCreateWithFlags(&ctx->dense_done, hipEventDisableTiming));
-    SPSP_HIP(hipEventRecord(ctx->dense_done, ctx->stream));   // spsp_wait_dense: other streams may start behind the dense pass
+    // spsp_wait_dense: other streams may start behind the dense pass.  Every event recorded here is a packet the
+    // sparse stages queue behind, so with timing on the timing end-event doubles as the marker.
+    if (ctx->timing_mask & (1u << kEvDense)) {
+        ctx->dense_marker = ctx->evlog[kEvDense].used.back().second;
+    } else {
+        if (!ctx->dense_done) SPSP_HIP(hipEventCreateWithFlags(&ctx->dense_done, hipEventDisableTiming));
+        SPSP_HIP(hipEventRecord(ctx->dense_done, ctx->stream));
+        ctx->dense_marker = ctx->dense_done;
+    }
     const uint32_t seg_shift = seg_shift_for(n_tiles);
     const uint32_t n_seg = (uint32_t)((n_tiles + (1ull << seg_shift) - 1) >> seg_shift);
     if ((rc = ctx->seg_a.reserve((size_t)n_seg * 8))) return rc;
