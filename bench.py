@@ -355,10 +355,10 @@ def main():
 
 def pmc_traffic(args):
     """HBM bytes per launch of the dense kernel from the PMC counters (FETCH_SIZE/WRITE_SIZE, separate
-    rocprofv3 --pmc passes of this same command, gfx950 correction applied: profiles/r01_c_pmc_hbm_traffic.json).
+    rocprofv3 --pmc passes of this same command, gfx950 correction applied: profiles/r01_d_pmc_hbm_traffic.json).
     Counters cannot be read from inside this process, so the figure is looked up for the matching workload."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_c_pmc_hbm_traffic.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_d_pmc_hbm_traffic.json")))
         w = d["workload"]
         if (w["genomes"], w["genome_len"], w["k"], w["m"], w["s"], w["scan_mode"]) != (args.genomes, args.length, K, M, S, args.mode):
             return None
