@@ -125,9 +125,9 @@ int spsp_create(int device, void* hip_stream, spsp_ctx** out) {
         if (e != hipSuccess) { delete c; return hip_fail(e, "hipStreamCreate", __FILE__, __LINE__); }
         c->own_stream = true;
     }
-    e = hipHostMalloc((void**)&c->h_scalar, 8 * sizeof(uint64_t), hipHostMallocDefault);
+    e = hipHostMalloc((void**)&c->h_scalar, 16 * sizeof(uint64_t), hipHostMallocDefault);
     if (e != hipSuccess) { if (c->own_stream) (void)hipStreamDestroy(c->stream); delete c; return hip_fail(e, "hipHostMalloc", __FILE__, __LINE__); }
-    memset(c->h_scalar, 0, 8 * sizeof(uint64_t));
+    memset(c->h_scalar, 0, 16 * sizeof(uint64_t));
     *out = c;
     return SPSP_OK;
 }
@@ -141,7 +141,7 @@ void spsp_destroy(spsp_ctx* c) {
     if (c->dense_done) (void)hipEventDestroy(c->dense_done);
     if (c->tail_event) (void)hipEventDestroy(c->tail_event);
     DevBuf* bufs[] = {&c->bases, &c->rec_off, &c->bitmap, &c->tile_count, &c->tile_off, &c->hits, &c->emit_count,
-                      &c->emit_off, &c->scan_tmp, &c->d_scalar, &c->seg_a, &c->seg_b, &c->filter, &c->pairtab, &c->c_min, &c->c_lo, &c->c_hi, &c->c_table,
+                      &c->scan_tmp, &c->d_scalar, &c->seg_a, &c->seg_b, &c->filter, &c->pairtab, &c->c_min, &c->c_lo, &c->c_hi, &c->c_table,
                       &c->c_owner, &c->c_rowid, &c->c_row, &c->x_cnt, &c->x_off, &c->x_begin, &c->x_end, &c->x_tot, &c->c_matrix, &c->c_inter, &c->c_flags, &c->c_slot_lo, &c->c_slot_hi, &c->c_slot_mn,
                       &c->c_skoff, &c->i_text, &c->i_tiles, &c->i_entry, &c->i_outoff, &c->i_recbase, &c->i_lens, &c->i_dst,
                       &c->i_compact};

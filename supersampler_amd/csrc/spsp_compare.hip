@@ -341,20 +341,20 @@ static int job_back(spsp_ctx* ctx, CompareJob& J, uint64_t rows) {
     hipLaunchKernelGGL(k_accumulate, dim3((J.W + 63) / 64, P.n_own), dim3(kAccThreads), 0, ctx->stream,
                        ctx->c_row.as<uint32_t>(), ctx->c_matrix.as<uint64_t>(), J.W, J.lanes_per_key, P.sk_begin, P.sk_end,
                        P.n, P.row_first, P.row_stride, P.row_limit, P.d_inter, ctx->c_flags.as<uint32_t>(),
-                       reinterpret_cast<uint32_t*>(ctx->h_scalar + 4));
+                       reinterpret_cast<uint32_t*>(ctx->h_scalar + 8));
     SPSP_HIP(hipGetLastError());
     return ctx->ev_end(kEvAccumulate);
 }
 // the flags travel to pinned host memory as the last item of whatever has been queued ...
 static int job_queue_flags(spsp_ctx* ctx) {
-    uint32_t* pinned = reinterpret_cast<uint32_t*>(ctx->h_scalar + 4);
+    uint32_t* pinned = reinterpret_cast<uint32_t*>(ctx->h_scalar + 8);
     SPSP_HIP(hipMemcpyAsync(pinned, ctx->c_flags.p, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     return SPSP_OK;
 }
 // ... and are read after the one synchronisation
 static int job_wait_flags(spsp_ctx* ctx, uint32_t* h_flags) {
     SPSP_HIP(hipStreamSynchronize(ctx->stream));
-    memcpy(h_flags, ctx->h_scalar + 4, 5 * sizeof(uint32_t));
+    memcpy(h_flags, ctx->h_scalar + 8, 5 * sizeof(uint32_t));
     if (h_flags[3]) { set_error("malformed exchange slot (header, sketch count or key count does not match)"); return SPSP_ERR_FORMAT; }
     if (h_flags[4]) { set_error("an exchange slot overflowed its capacity: partition again with a larger slot_cap"); return SPSP_ERR_OVERFLOW; }
     if (h_flags[0]) { set_error("sketch keys must be strictly increasing by (minimizer, kmer_hi, kmer_lo)"); return SPSP_ERR_ARG; }

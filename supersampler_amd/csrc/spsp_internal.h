@@ -76,7 +76,7 @@ struct spsp_ctx {
     int n_cu = 256;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    uint64_t* h_scalar = nullptr;  // pinned, 8 slots: [0] hits, [1] super-k-mers, [4..6] compare flags
+    uint64_t* h_scalar = nullptr;  // pinned, 16 slots: [0] hits, [1] super-k-mers (scan); [4..6] ingest totals; [8..10] compare flags
     hipEvent_t dense_done = nullptr;   // recorded behind every dense pass (unless a timing event already is)
     hipEvent_t dense_marker = nullptr; // what spsp_wait_dense waits on
     hipEvent_t tail_event = nullptr;   // spsp_wait_stream: marks the current end of this context's stream
@@ -85,7 +85,7 @@ struct spsp_ctx {
     uint64_t* h_skoff = nullptr;       // pinned staging for the sketch offsets of a queued comparison
     size_t h_skoff_cap = 0;
     // scan workspace
-    spsp::DevBuf bases, rec_off, bitmap, tile_count, tile_off, hits, emit_count, emit_off, scan_tmp, d_scalar, seg_a, seg_b;
+    spsp::DevBuf bases, rec_off, bitmap, tile_count, tile_off, hits, emit_count, scan_tmp, d_scalar, seg_a, seg_b;
     uint64_t hits_cap = 0, out_cap = 0;  // entries the sparse-stage buffers are sized for (grow on overflow)
     uint64_t zeroed_tiles = 0;  // bitmap/tile_count tiles [0, zeroed_tiles) are zero unless dirty
     uint64_t dirty_tiles = 0;   // tiles [0, dirty_tiles) may hold hits of a call that never reached k_expand

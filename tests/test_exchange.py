@@ -256,6 +256,21 @@ def test_begin_end_forms_on_two_streams_match_the_blocking_calls(ctx):
             got = a.to_host(d_out, n_out, sp.SUPERKMER_DTYPE)
             assert n_out == len(want_stream) and got.tobytes() == np.asarray(want_stream).tobytes()
             assert (d_inter.cpu().numpy() == want_inter).all()
+        # stream ordering helpers and the timing mask: only the requested regions are bracketed
+        a.timing_enable(True, sp.TIME_DENSE)
+        b.timing_enable(True, sp.TIME_COMPARE | sp.TIME_ACCUMULATE)
+        a.timing_read(); b.timing_read()
+        a.wait_stream(b)
+        a.scan_device_begin(p, d_bases.data_ptr(), d_bases.numel(), d_off.data_ptr(), len(genomes))
+        b.wait_stream(a)
+        b.compare_device_begin(k, d_mn.data_ptr(), d_lo.data_ptr(), None, off, 70, 0, 1, d_inter.data_ptr())
+        assert a.scan_device_end()[1] == len(want_stream)
+        b.compare_end()
+        ta, tb = a.timing_read(), b.timing_read()
+        assert ta["dense_launches"] == 1 and ta["dense_ms"] > 0 and ta["scan_calls"] == 0
+        assert tb["compare_calls"] == 1 and tb["accumulate_launches"] == 1 and tb["dense_launches"] == 0
+        a.timing_enable(False); b.timing_enable(False)
+        assert (d_inter.cpu().numpy() == want_inter).all()
         with pytest.raises(sp.SpspError):
             a.scan_device_end()                    # nothing pending
         with pytest.raises(sp.SpspError):
