@@ -92,6 +92,10 @@ def main():
     # waits for the host.  BENCH_PIPELINE=0 runs the two halves back to back on one stream, one step at a time.
     pipelined = os.environ.get("BENCH_PIPELINE", "1") != "0"
     strict_order = os.environ.get("BENCH_STRICT_ORDER") == "1"
+    # BENCH_FREE_RUN=1 (experiment): no ordering between the streams at all -- every scan on its own stream, the
+    # comparison does not wait for the dense pass.  Highest throughput when the dense kernel leaves room on the CUs
+    # (SPSP_PAIR_BLOCKS_PER_CU=1), but the dense kernel then shares the GPU and its roofline figure drops.
+    free_run = os.environ.get("BENCH_FREE_RUN") == "1"
 
     class Slot:
         pass
@@ -100,8 +104,9 @@ def main():
     for i in range(2 if pipelined else 1):
         sl = Slot()
         if pipelined:
-            sl.stream_a = stream                          # the scans of all steps share stream A: in order, no event waits
-            sl.scan = ctx if i == 0 else sp.Context(local_rank, stream.cuda_stream)   # (own workspace and results)
+            # the scans of all steps share stream A: in order, no event waits (own workspace and results per slot)
+            sl.stream_a = stream if (i == 0 or not free_run) else torch.cuda.Stream(device=dev)
+            sl.scan = ctx if i == 0 else sp.Context(local_rank, sl.stream_a.cuda_stream)
             sl.stream_b = torch.cuda.Stream(device=dev)
             sl.cmp = sp.Context(local_rank, sl.stream_b.cuda_stream)
         else:
@@ -179,7 +184,8 @@ def main():
             sl.scan.wait_stream(prev.cmp)
         sl.scan.scan_device_begin(*scan_args)
         if exchange_kind == "none":
-            sl.cmp.wait_dense(sl.scan)                    # the comparison starts behind A's dense pass
+            if not free_run:
+                sl.cmp.wait_dense(sl.scan)                # the comparison starts behind A's dense pass
             sl.cmp.compare_device_begin(K, d_all_min.data_ptr(), d_all_lo.data_ptr(), None, sk_off, n_total, rank, world,
                                         sl.d_inter.data_ptr())                                             # stream B
             return
