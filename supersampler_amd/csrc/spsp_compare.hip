@@ -402,6 +402,7 @@ int compare_job_end(spsp_ctx* ctx) {
         if (!J->speculative) {
             if ((rc = job_wait_flags(ctx, h_flags))) return rc;          // the row count sizes the colour matrix
             if ((rc = job_back(ctx, *J, h_flags[2]))) return rc;
+            if (J->attempt == 0 && (rc = ctx->ev_end(kEvCompare))) return rc;   // the bracket opened by the begin call
         }
         if ((rc = job_wait_flags(ctx, h_flags))) return rc;              // collisions surface in the fill pass
         if (!h_flags[1]) return SPSP_OK;
@@ -812,7 +813,9 @@ int compare_slots_begin_impl(spsp_ctx* ctx, uint32_t k, const uint8_t* d_slots, 
         return compare_job_begin(ctx, J);
     };
     rc = body();
-    const int rc2 = ctx->ev_end(kEvCompare);   // brackets the speculative pipeline (retries are not timed)
+    // the bracket closes behind the last queued kernel: here for speculative builds, in compare_job_end otherwise
+    const bool deferred = !rc && ctx->compare_job && !ctx->compare_job->speculative;
+    const int rc2 = deferred ? SPSP_OK : ctx->ev_end(kEvCompare);
     return rc ? rc : rc2;
 }
 
@@ -823,7 +826,8 @@ int compare_device_begin_impl(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min, 
     int rc = ctx->ev_begin(kEvCompare);
     if (rc) return rc;
     rc = compare_device_begin_inner(ctx, k, d_min, d_lo, d_hi, h_sk_off, n, row_limit, row_first, row_stride, d_inter);
-    const int rc2 = ctx->ev_end(kEvCompare);
+    const bool deferred = rc == 0 && ctx->compare_job && !ctx->compare_job->speculative;   // closed in compare_job_end
+    const int rc2 = deferred ? SPSP_OK : ctx->ev_end(kEvCompare);
     if (rc < 0) return rc;
     if (rc == 1) {                       // nothing to compare: leave an empty job so that begin/end stay paired
         CompareJob* J = new CompareJob;
