@@ -59,6 +59,14 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
     x ^= x >> 31;
     return x;
 }
+// Which of `passes` key classes a key belongs to, for builds whose colour matrix is capped (see run loop in
+// compare_job_end).  Independent of the table fingerprint and of the exchange's rank partition (other hash bits).
+__device__ __forceinline__ uint32_t pass_of(uint64_t lo, uint32_t mn, uint64_t hi, bool has_hi, uint32_t passes) {
+    uint64_t h = mix64(lo ^ 0xD6E8FEB86659FD93ULL);
+    h = mix64(h + (uint64_t)mn * 0xC2B2AE3D27D4EB4FULL);
+    if (has_hi) h = mix64(h ^ hi);
+    return (uint32_t)(((h & 0xffffffffull) * passes) >> 32);
+}
 __device__ __forceinline__ uint64_t fingerprint(const Keys& K, uint64_t e, uint64_t seed) {
     uint64_t f = mix64(K.lo[e] + seed);
     f = mix64(f ^ ((uint64_t)K.mn[e] * 0x9E3779B97F4A7C15ULL));
@@ -99,17 +107,19 @@ __global__ __launch_bounds__(256) void k_prepare(uint4* __restrict__ table, uint
 // flags[0]: input not strictly sorted inside a sketch; flags[1]: fingerprint collision
 __global__ void k_insert(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n, uint64_t S, uint32_t row_first,
                          uint32_t row_stride, uint32_t row_limit, uint64_t seed, uint64_t* __restrict__ table, uint32_t log2cap,
-                         uint32_t* __restrict__ owner, SlotKeys SK, uint32_t* __restrict__ flags) {
+                         uint32_t* __restrict__ owner, SlotKeys SK, uint32_t* __restrict__ flags, uint32_t passes,
+                         uint32_t pass) {
     // grid.y = sketch, grid.x = 256-key chunk of it (no per-entry search for the owning sketch)
     const uint32_t j = blockIdx.y;
     const uint64_t e = sk_off[j] + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= sk_off[j + 1]) return;
     if (e > sk_off[j] && !key_less(K, e - 1, e)) atomicOr(&flags[0], 1u);
     if (j % row_stride != row_first || j >= row_limit) return;   // not an owned (and printed) row
+    if (passes > 1 && pass_of(K.lo[e], K.mn[e], K.hi ? K.hi[e] : 0, K.hi != nullptr, passes) != pass) return;
     const uint64_t fp = fingerprint(K, e, seed);
     const uint64_t mask = (1ull << log2cap) - 1;
     uint64_t pos = home_slot(fp, log2cap);
-    for (;;) {
+    for (uint64_t probes = 0;; ++probes) {
         const unsigned long long old = atomicCAS((unsigned long long*)&table[pos], 0ull, (unsigned long long)fp);
         if (old == 0ull) {   // the claiming entry is the slot's owner: its index and its full key go next to the slot
             owner[pos] = (uint32_t)e;
@@ -118,6 +128,7 @@ __global__ void k_insert(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n
             break;
         }
         if (old == fp) break;
+        if (probes > mask) { atomicOr(&flags[5], 1u); break; }   // table full (cannot happen at load <= 1/2): never spin
         pos = (pos + 1) & mask;
     }
 }
@@ -163,14 +174,19 @@ __global__ void k_fill(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n, 
                        uint32_t row_stride, uint32_t row_limit, uint64_t seed, const uint64_t* __restrict__ table, uint32_t log2cap,
                        const uint32_t* __restrict__ owner, const uint32_t* __restrict__ rowid, SlotKeys SK, uint32_t W,
                        unsigned long long* __restrict__ A, uint32_t* __restrict__ row_of_entry,
-                       uint32_t* __restrict__ flags) {
+                       uint32_t* __restrict__ flags, uint32_t passes, uint32_t pass) {
     const uint32_t j = blockIdx.y;
     const uint64_t e = sk_off[j] + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= sk_off[j + 1]) return;
+    if (passes > 1 && pass_of(K.lo[e], K.mn[e], K.hi ? K.hi[e] : 0, K.hi != nullptr, passes) != pass) {
+        if (j % row_stride == row_first && j < row_limit) row_of_entry[e] = 0xffffffffu;   // not in this pass: k_accumulate skips it
+        return;
+    }
     const uint64_t fp = fingerprint(K, e, seed);
     const uint64_t mask = (1ull << log2cap) - 1;
     uint64_t pos = home_slot(fp, log2cap);
-    for (;;) {
+    for (uint64_t probes = 0;; ++probes) {
+        if (probes > mask) { atomicOr(&flags[5], 1u); return; }
         const uint64_t v = table[pos];
         if (v == 0) return;  // key not held by any owned sketch: contributes to no owned row
         if (v == fp) {
@@ -208,10 +224,10 @@ __global__ __launch_bounds__(kAccThreads) void k_accumulate(const uint32_t* __re
                                                            const uint64_t* __restrict__ sk_end, uint32_t n,
                                                            uint32_t row_first, uint32_t row_stride, uint32_t row_limit,
                                                            uint32_t* __restrict__ inter, const uint32_t* __restrict__ flags,
-                                                           uint32_t* __restrict__ host_flags) {
+                                                           uint32_t* __restrict__ host_flags, bool add) {
     // every pass that can raise a flag has finished: hand them to the host (pinned memory) from here, so the
     // pipeline ends with this kernel and not with a device-to-host copy behind it
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 5) host_flags[threadIdx.x] = flags[threadIdx.x];
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 6) host_flags[threadIdx.x] = flags[threadIdx.x];
     const uint32_t i = row_first + blockIdx.y * row_stride;
     if (i >= n || i >= row_limit) return;
     const uint32_t wb = blockIdx.x;                         // block of 64 words
@@ -271,7 +287,10 @@ __global__ __launch_bounds__(kAccThreads) void k_accumulate(const uint32_t* __re
     const uint32_t cols = lanes_per_key * 64;
     for (uint32_t x = t; x < cols; x += kAccThreads) {
         const uint32_t col = wb * 4096 + x;
-        if (col > i && col < n) inter[(uint64_t)i * n + col] = s_cnt[x];
+        if (col > i && col < n) {   // every cell has one writer; later key-class passes add to the first pass's counts
+            uint32_t* cell = &inter[(uint64_t)i * n + col];
+            *cell = add ? *cell + s_cnt[x] : s_cnt[x];
+        }
     }
 }
 
@@ -290,8 +309,8 @@ struct ComparePlan {
 };
 struct CompareJob {
     ComparePlan P;
-    std::function<int(uint64_t seed, uint64_t fp_mask, uint32_t log2cap)> insert;
-    std::function<int(uint64_t seed, uint64_t fp_mask, uint32_t log2cap, uint32_t W, bool direct_rows)> fill;
+    std::function<int(uint64_t seed, uint64_t fp_mask, uint32_t log2cap, uint32_t passes, uint32_t pass)> insert;
+    std::function<int(uint64_t seed, uint64_t fp_mask, uint32_t log2cap, uint32_t W, bool direct_rows, uint32_t passes, uint32_t pass)> fill;
     uint32_t log2cap = 0, W = 0, lanes_per_key = 64, sblocks = 0;
     uint64_t cap = 0, seed = 0x5350535053505350ULL;
     bool speculative = false;
@@ -299,8 +318,10 @@ struct CompareJob {
     bool clear_all_flags = false;   // no pass before the first attempt has written flags
     bool direct_rows = false;   // speculative and every row owned from entry 0: row id = the owner's entry index
     int attempt = 0;
+    uint32_t passes = 1, pass = 0;  // large builds: the keys are split into classes and the dictionary + colour
+                                    // matrix are built class by class, so the matrix never exceeds its budget
 };
-// flags: [0] unsorted input, [1] fingerprint collision, [2] n_rows, [3] malformed slot, [4] slot overflow
+// flags: [0] unsorted input, [1] fingerprint collision, [2] n_rows, [3] malformed slot, [4] slot overflow, [5] table full
 static uint64_t job_fp_mask(const CompareJob& J) {
     // test hook: fingerprints of the first attempt cut to a few bits, so distinct keys collide and the retry runs
     static const char* dbg_fp = getenv("SPSP_DEBUG_FP_BITS");
@@ -320,7 +341,7 @@ static int job_front(spsp_ctx* ctx, CompareJob& J) {
                        (J.attempt == 0 && J.clear_all_flags) ? 16u : 3u,    // [3], [4] belong to the slot index pass
                        (const uint64_t*)ctx->h_skoff, ctx->c_skoff.as<uint64_t>(), J.n_skoff);
     SPSP_HIP(hipGetLastError());
-    if ((rc = J.insert(J.seed, job_fp_mask(J), J.log2cap))) return rc;
+    if ((rc = J.insert(J.seed, job_fp_mask(J), J.log2cap, J.passes, J.pass))) return rc;
     if (!J.direct_rows) {
         hipLaunchKernelGGL(k_assign_rows, dim3(J.sblocks), dim3(kRowThreads), 0, ctx->stream, ctx->c_table.as<uint64_t>(), J.cap,
                            ctx->c_rowid.as<uint32_t>(), flags + 2);
@@ -336,25 +357,26 @@ static int job_back(spsp_ctx* ctx, CompareJob& J, uint64_t rows) {
         if ((rc = ctx->c_matrix.reserve((size_t)rows * J.W * 8))) return rc;
         SPSP_HIP(hipMemsetAsync(ctx->c_matrix.p, 0, (size_t)rows * J.W * 8, ctx->stream));
     }
-    if ((rc = J.fill(J.seed, job_fp_mask(J), J.log2cap, J.W, J.direct_rows))) return rc;
+    if ((rc = J.fill(J.seed, job_fp_mask(J), J.log2cap, J.W, J.direct_rows, J.passes, J.pass))) return rc;
     if ((rc = ctx->ev_begin(kEvAccumulate))) return rc;
     hipLaunchKernelGGL(k_accumulate, dim3((J.W + 63) / 64, P.n_own), dim3(kAccThreads), 0, ctx->stream,
                        ctx->c_row.as<uint32_t>(), ctx->c_matrix.as<uint64_t>(), J.W, J.lanes_per_key, P.sk_begin, P.sk_end,
                        P.n, P.row_first, P.row_stride, P.row_limit, P.d_inter, ctx->c_flags.as<uint32_t>(),
-                       reinterpret_cast<uint32_t*>(ctx->h_scalar + 8));
+                       reinterpret_cast<uint32_t*>(ctx->h_scalar + 8), J.pass > 0);
     SPSP_HIP(hipGetLastError());
     return ctx->ev_end(kEvAccumulate);
 }
 // the flags travel to pinned host memory as the last item of whatever has been queued ...
 static int job_queue_flags(spsp_ctx* ctx) {
     uint32_t* pinned = reinterpret_cast<uint32_t*>(ctx->h_scalar + 8);
-    SPSP_HIP(hipMemcpyAsync(pinned, ctx->c_flags.p, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    SPSP_HIP(hipMemcpyAsync(pinned, ctx->c_flags.p, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     return SPSP_OK;
 }
 // ... and are read after the one synchronisation
 static int job_wait_flags(spsp_ctx* ctx, uint32_t* h_flags) {
     SPSP_HIP(hipStreamSynchronize(ctx->stream));
-    memcpy(h_flags, ctx->h_scalar + 8, 5 * sizeof(uint32_t));
+    memcpy(h_flags, ctx->h_scalar + 8, 6 * sizeof(uint32_t));
+    if (h_flags[5]) { set_error("dictionary table overflow (internal sizing error)"); return SPSP_ERR_HIP; }
     if (h_flags[3]) { set_error("malformed exchange slot (header, sketch count or key count does not match)"); return SPSP_ERR_FORMAT; }
     if (h_flags[4]) { set_error("an exchange slot overflowed its capacity: partition again with a larger slot_cap"); return SPSP_ERR_OVERFLOW; }
     if (h_flags[0]) { set_error("sketch keys must be strictly increasing by (minimizer, kmer_hi, kmer_lo)"); return SPSP_ERR_ARG; }
@@ -366,20 +388,40 @@ static int compare_job_begin(spsp_ctx* ctx, CompareJob* job) {
     std::unique_ptr<CompareJob> J(job);
     const ComparePlan& P = J->P;
     int rc;
+    J->W = (P.n + 63) / 64;
+    J->lanes_per_key = 64;
+    if (J->W < 64) { J->lanes_per_key = 1; while (J->lanes_per_key < J->W) J->lanes_per_key <<= 1; }
+    // A matrix with one row per inserted KEY (an upper bound on the distinct keys) is cheap for small inputs:
+    // then the whole pipeline is queued without waiting for the row count and checked once at the end.
+    static const char* dbg_budget = getenv("SPSP_DEBUG_MATRIX_BUDGET");    // test hook: bytes the matrix may take
+    const uint64_t worst_matrix = (uint64_t)P.S_own * J->W * 8;
+    J->speculative = !dbg_budget && worst_matrix <= (256ull << 20);
+    // Large builds: the colour matrix is rows x N bits and grows with N * (distinct keys) -- at tens of thousands of
+    // sketches it would outgrow the card.  The reference bounds the same structure by working bucket by bucket
+    // (Comparator.cpp:58-68); here the keys are split into hash classes and one class is built and summed at a time.
+    J->passes = 1;
+    if (!J->speculative) {
+        uint64_t budget;
+        if (dbg_budget) budget = (uint64_t)atoll(dbg_budget);
+        else {
+            size_t free_b = 0, total_b = 0;
+            SPSP_HIP(hipMemGetInfo(&free_b, &total_b));
+            budget = (uint64_t)free_b / 2 + ctx->c_matrix.cap / 2;          // what is already reserved counts as available
+        }
+        if (budget < (1ull << 16)) budget = 1ull << 16;
+        const uint64_t want = (worst_matrix + budget - 1) / budget;
+        J->passes = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(want, 1), 4096);
+    }
+    // table for one class: twice its keys (+25 % for the spread of the class sizes)
+    const uint64_t class_keys = J->passes == 1 ? P.S_own : P.S_own / J->passes + P.S_own / J->passes / 4 + 1024;
     J->log2cap = 10;
-    while ((1ull << J->log2cap) < 2 * P.S_own) ++J->log2cap;
+    while ((1ull << J->log2cap) < 2 * class_keys) ++J->log2cap;
     J->cap = 1ull << J->log2cap;
     if ((rc = ctx->c_table.reserve((size_t)J->cap * 8))) return rc;
     if ((rc = ctx->c_owner.reserve((size_t)J->cap * 4))) return rc;
     if ((rc = ctx->c_rowid.reserve((size_t)J->cap * 4))) return rc;
     if ((rc = ctx->c_row.reserve((size_t)P.S_entries * 4))) return rc;
     J->sblocks = (uint32_t)((J->cap + (uint64_t)kRowThreads * kRowSlots - 1) / ((uint64_t)kRowThreads * kRowSlots));
-    J->W = (P.n + 63) / 64;
-    J->lanes_per_key = 64;
-    if (J->W < 64) { J->lanes_per_key = 1; while (J->lanes_per_key < J->W) J->lanes_per_key <<= 1; }
-    // A matrix with one row per inserted KEY (an upper bound on the distinct keys) is cheap for small inputs:
-    // then the whole pipeline is queued without waiting for the row count and checked once at the end.
-    J->speculative = (uint64_t)P.S_own * J->W * 8 <= (256ull << 20);
     // owned entries form the prefix [0, S_own) of the entry space when rows are not strided over ranks
     J->direct_rows = J->speculative && P.row_stride == 1 && P.row_first == 0;
     if ((rc = ctx->c_slot_lo.reserve((size_t)J->cap * 8))) return rc;
@@ -398,16 +440,27 @@ int compare_job_end(spsp_ctx* ctx) {
     ctx->compare_job = nullptr;
     int rc;
     for (;;) {
-        uint32_t h_flags[5];
-        if (!J->speculative) {
-            if ((rc = job_wait_flags(ctx, h_flags))) return rc;          // the row count sizes the colour matrix
-            if ((rc = job_back(ctx, *J, h_flags[2]))) return rc;
-            if (J->attempt == 0 && (rc = ctx->ev_end(kEvCompare))) return rc;   // the bracket opened by the begin call
+        uint32_t h_flags[6];
+        bool collided = false;
+        if (J->speculative) {
+            if ((rc = job_wait_flags(ctx, h_flags))) return rc;              // collisions surface in the fill pass
+            collided = h_flags[1] != 0;
+        } else {
+            for (;;) {   // key class by key class; the first class (front part) was queued by the begin call / the retry below
+                if ((rc = job_wait_flags(ctx, h_flags))) return rc;          // the row count sizes the colour matrix
+                if ((rc = job_back(ctx, *J, h_flags[2]))) return rc;
+                if (J->attempt == 0 && J->pass + 1 == J->passes && (rc = ctx->ev_end(kEvCompare))) return rc;   // bracket of the begin call
+                if ((rc = job_wait_flags(ctx, h_flags))) return rc;          // collisions of this class
+                if (h_flags[1]) { collided = true; break; }
+                if (++J->pass == J->passes) break;
+                if ((rc = job_front(ctx, *J))) return rc;
+                if ((rc = job_queue_flags(ctx))) return rc;
+            }
         }
-        if ((rc = job_wait_flags(ctx, h_flags))) return rc;              // collisions surface in the fill pass
-        if (!h_flags[1]) return SPSP_OK;
+        if (!collided) return SPSP_OK;
         if (J->attempt >= 4) { set_error("fingerprint collisions persisted over 5 seeds"); return SPSP_ERR_HIP; }
         ++J->attempt;
+        J->pass = 0;   // a class that collided has already been added into the counts: start over (the first class overwrites)
         J->seed = J->seed * 6364136223846793005ULL + 1442695040888963407ULL;  // new fingerprints, try again
         if ((rc = job_front(ctx, *J))) return rc;
         if (J->speculative) { if ((rc = job_back(ctx, *J, J->P.S_own))) return rc; }
@@ -464,21 +517,22 @@ static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t*
     J->P = ComparePlan{S_own, S, n, n_own, row_first, row_stride, row_limit, sk, sk + 1, d_inter};
     J->clear_all_flags = true;
     J->n_skoff = n + 1;
-    J->insert = [=](uint64_t seed, uint64_t fp_mask, uint32_t log2cap) -> int {
+    J->insert = [=](uint64_t seed, uint64_t fp_mask, uint32_t log2cap, uint32_t passes, uint32_t pass) -> int {
         Keys Km = K; Km.fp_mask = fp_mask;
         hipLaunchKernelGGL(k_insert, grid_all, dim3(256), 0, ctx->stream, Km, sk, n, S, row_first, row_stride, row_limit,
                            seed, ctx->c_table.as<uint64_t>(), log2cap, ctx->c_owner.as<uint32_t>(),
-                           SlotKeys{ctx->c_slot_lo.as<uint64_t>(), ctx->c_slot_hi.as<uint64_t>(), ctx->c_slot_mn.as<uint32_t>()}, flags);
+                           SlotKeys{ctx->c_slot_lo.as<uint64_t>(), ctx->c_slot_hi.as<uint64_t>(), ctx->c_slot_mn.as<uint32_t>()}, flags,
+                           passes, pass);
         SPSP_HIP(hipGetLastError());
         return SPSP_OK;
     };
-    J->fill = [=](uint64_t seed, uint64_t fp_mask, uint32_t log2cap, uint32_t W, bool direct_rows) -> int {
+    J->fill = [=](uint64_t seed, uint64_t fp_mask, uint32_t log2cap, uint32_t W, bool direct_rows, uint32_t passes, uint32_t pass) -> int {
         Keys Km = K; Km.fp_mask = fp_mask;
         hipLaunchKernelGGL(k_fill, grid_all, dim3(256), 0, ctx->stream, Km, sk, n, S, row_first, row_stride, row_limit, seed,
                            ctx->c_table.as<uint64_t>(), log2cap, ctx->c_owner.as<uint32_t>(),
                            direct_rows ? (const uint32_t*)nullptr : ctx->c_rowid.as<uint32_t>(),
                            SlotKeys{ctx->c_slot_lo.as<uint64_t>(), ctx->c_slot_hi.as<uint64_t>(), ctx->c_slot_mn.as<uint32_t>()},
-                           W, ctx->c_matrix.as<unsigned long long>(), ctx->c_row.as<uint32_t>(), flags);
+                           W, ctx->c_matrix.as<unsigned long long>(), ctx->c_row.as<uint32_t>(), flags, passes, pass);
         SPSP_HIP(hipGetLastError());
         return SPSP_OK;
     };
@@ -683,15 +737,16 @@ __global__ __launch_bounds__(kPartThreads) void k_slot_index(SlotView V, uint64_
 
 // receiver 2/3 and 3/3: k_insert / k_fill over slot records (every sketch is an owned row here)
 __global__ void k_insert_slots(SlotView V, const uint32_t* __restrict__ tot, uint64_t seed, uint64_t* __restrict__ table,
-                               uint32_t log2cap, uint32_t* __restrict__ owner, SlotKeys SK) {
+                               uint32_t log2cap, uint32_t* __restrict__ owner, SlotKeys SK, uint32_t passes, uint32_t pass) {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= V.parts * V.cap) return;
     if (e % V.cap >= tot[e / V.cap]) return;
     const uint64_t* r = slot_rec(V, e);
+    if (passes > 1 && pass_of(r[0], (uint32_t)r[V.words - 1], V.words == 3 ? r[1] : 0, V.words == 3, passes) != pass) return;
     const uint64_t fp = rec_fingerprint(r, V.words, seed, V.fp_mask);
     const uint64_t mask = (1ull << log2cap) - 1;
     uint64_t pos = home_slot(fp, log2cap);
-    for (;;) {
+    for (uint64_t probes = 0; probes <= mask; ++probes) {    // bounded: a full table must not spin (k_fill_slots reports it)
         const unsigned long long old = atomicCAS((unsigned long long*)&table[pos], 0ull, (unsigned long long)fp);
         if (old == 0ull) {
             owner[pos] = e;
@@ -706,21 +761,27 @@ __global__ void k_insert_slots(SlotView V, const uint32_t* __restrict__ tot, uin
 __global__ void k_fill_slots(SlotView V, const uint32_t* __restrict__ tot, uint64_t seed, const uint64_t* __restrict__ table,
                              uint32_t log2cap, const uint32_t* __restrict__ owner, const uint32_t* __restrict__ rowid,
                              SlotKeys SK, uint32_t W, unsigned long long* __restrict__ A,
-                             uint32_t* __restrict__ row_of_entry, uint32_t* __restrict__ flags) {
+                             uint32_t* __restrict__ row_of_entry, uint32_t* __restrict__ flags, uint32_t passes,
+                             uint32_t pass) {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= V.parts * V.cap) return;
     const uint32_t s = e / V.cap;
     if (e - s * V.cap >= tot[s]) return;
     const uint64_t* r = slot_rec(V, e);
+    if (passes > 1 && pass_of(r[0], (uint32_t)r[V.words - 1], V.words == 3 ? r[1] : 0, V.words == 3, passes) != pass) {
+        row_of_entry[e] = 0xffffffffu;
+        return;
+    }
     const uint32_t local = (uint32_t)(r[V.words - 1] >> 32);
     if (local >= V.n) { atomicOr(&flags[3], 1u); return; }
     const uint32_t g = s * V.n + local;                       // global sketch id = colour
     const uint64_t fp = rec_fingerprint(r, V.words, seed, V.fp_mask);
     const uint64_t mask = (1ull << log2cap) - 1;
     uint64_t pos = home_slot(fp, log2cap);
-    for (;;) {
+    for (uint64_t probes = 0;; ++probes) {
+        if (probes > mask) { atomicOr(&flags[5], 1u); return; }
         const uint64_t v = table[pos];
-        if (v == 0) { atomicOr(&flags[3], 1u); return; }     // every record was inserted: cannot happen
+        if (v == 0) { atomicOr(&flags[5], 1u); return; }     // every record was inserted: only a full table gets here
         if (v == fp) {
             const bool same = SK.lo[pos] == r[0] && SK.mn[pos] == (uint32_t)r[V.words - 1] &&
                               (V.words != 3 || SK.hi[pos] == r[1]);
@@ -793,20 +854,21 @@ int compare_slots_begin_impl(spsp_ctx* ctx, uint32_t k, const uint8_t* d_slots, 
         const dim3 grid((uint32_t)((E + 255) / 256));
         CompareJob* J = new CompareJob;
         J->P = ComparePlan{E, E, (uint32_t)N, (uint32_t)N, 0, 1, (uint32_t)N, ctx->x_begin.as<uint64_t>(), ctx->x_end.as<uint64_t>(), d_inter};
-        J->insert = [=](uint64_t seed, uint64_t fp_mask, uint32_t log2cap) -> int {
+        J->insert = [=](uint64_t seed, uint64_t fp_mask, uint32_t log2cap, uint32_t passes, uint32_t pass) -> int {
             SlotView Vm = V; Vm.fp_mask = fp_mask;
             hipLaunchKernelGGL(k_insert_slots, grid, dim3(256), 0, ctx->stream, Vm, tot, seed, ctx->c_table.as<uint64_t>(),
                                log2cap, ctx->c_owner.as<uint32_t>(),
-                               SlotKeys{ctx->c_slot_lo.as<uint64_t>(), ctx->c_slot_hi.as<uint64_t>(), ctx->c_slot_mn.as<uint32_t>()});
+                               SlotKeys{ctx->c_slot_lo.as<uint64_t>(), ctx->c_slot_hi.as<uint64_t>(), ctx->c_slot_mn.as<uint32_t>()},
+                               passes, pass);
             SPSP_HIP(hipGetLastError());
             return SPSP_OK;
         };
-        J->fill = [=](uint64_t seed, uint64_t fp_mask, uint32_t log2cap, uint32_t W, bool direct_rows) -> int {
+        J->fill = [=](uint64_t seed, uint64_t fp_mask, uint32_t log2cap, uint32_t W, bool direct_rows, uint32_t passes, uint32_t pass) -> int {
             SlotView Vm = V; Vm.fp_mask = fp_mask;
             hipLaunchKernelGGL(k_fill_slots, grid, dim3(256), 0, ctx->stream, Vm, tot, seed, ctx->c_table.as<uint64_t>(), log2cap,
                                ctx->c_owner.as<uint32_t>(), direct_rows ? (const uint32_t*)nullptr : ctx->c_rowid.as<uint32_t>(),
                                SlotKeys{ctx->c_slot_lo.as<uint64_t>(), ctx->c_slot_hi.as<uint64_t>(), ctx->c_slot_mn.as<uint32_t>()},
-                               W, ctx->c_matrix.as<unsigned long long>(), ctx->c_row.as<uint32_t>(), flags);
+                               W, ctx->c_matrix.as<unsigned long long>(), ctx->c_row.as<uint32_t>(), flags, passes, pass);
             SPSP_HIP(hipGetLastError());
             return SPSP_OK;
         };

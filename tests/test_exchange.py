@@ -285,3 +285,36 @@ def test_begin_end_forms_on_two_streams_match_the_blocking_calls(ctx):
         b.close()
     em_oracle, _ = orc.scan(k, m, orc.threshold(k, m, s), bases, rec_off)
     assert len(em_oracle) == len(want_stream)
+
+
+def test_capped_colour_matrix_runs_key_class_passes():
+    """SPSP_DEBUG_MATRIX_BUDGET caps the colour matrix at a few KiB, so the comparison is built and summed in many
+    key-class passes (the path taken for tens of thousands of sketches): flat form, query mode, exchange slots --
+    results unchanged; with cut fingerprints on top, a colliding class restarts the whole sum."""
+    code = (
+        "import sys\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np, torch\n"
+        "import supersampler_amd as sp\n"
+        "import test_exchange as tx\n"
+        "ctx = sp.Context(0)\n"
+        "sets = tx.make_sets(np.random.default_rng(8), 70, True)\n"
+        "sk = []\n"
+        "for st in sets:\n"
+        "    keys = sorted(st)\n"
+        "    sk.append(sp.Sketch(63, 15, np.array([x[0] for x in keys], np.uint32), np.array([x[2] for x in keys], np.uint64),\n"
+        "                        np.array([x[1] for x in keys], np.uint64)))\n"
+        "inter, card = ctx.compare(sk)\n"
+        "assert all(inter[i, j] == (len(sets[i] & sets[j]) if j > i else 0) for i in range(70) for j in range(70))\n"
+        "assert [int(c) for c in card] == [len(s) for s in sets]\n"
+        "interq, _ = ctx.compare(sk, n_query=9)\n"
+        "assert all(interq[i, j] == (len(sets[i] & sets[j]) if (j > i and i < 9) else 0) for i in range(70) for j in range(70))\n"
+        "per_rank = [sets[r * 14:(r + 1) * 14] for r in range(5)]\n"
+        "cap = int(max(sum(len(s) for s in pr) for pr in per_rank) / 5 * 1.3) + 64\n"
+        "_, total = tx.exchange_and_compare(ctx, 63, per_rank, cap)\n"
+        "assert all(total[i, j] == (len(sets[i] & sets[j]) if j > i else 0) for i in range(70) for j in range(70))\n"
+        "print('ok')\n") % (ROOT, os.path.join(ROOT, "tests"))
+    for extra in ({}, {"SPSP_DEBUG_FP_BITS": "9"}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SPSP_DEBUG_MATRIX_BUDGET="6000", **extra),
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "ok" in r.stdout, (extra, r.stdout[-2000:], r.stderr[-3000:])
