@@ -504,7 +504,7 @@ static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t*
     for (uint32_t i = row_first; i < row_limit; i += row_stride) { S_own += h_sk_off[i + 1] - h_sk_off[i]; ++n_own; }
     if (S_own == 0 || n_own == 0) return 1;
     int rc;
-    // a queued-but-unsynchronised earlier copy from h_skoff is ordered before this one on the same stream
+    // staging copy of the offsets (one job may be pending per context, and the previous one has been collected)
     if ((rc = stage_sk_off(ctx, h_sk_off, n))) return rc;
     if ((rc = ctx->c_flags.reserve(64))) return rc;
     Keys K{d_min, d_lo, (k > 32) ? d_hi : nullptr, ~0ull};
