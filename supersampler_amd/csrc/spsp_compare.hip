@@ -207,6 +207,123 @@ __global__ void k_fill(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n, 
     }
 }
 
+// ---------------------------------------------------------------------------
+// Sparse form, for many sketches.  A key is held by a handful of sketches however many there are, so a dense
+// colour row (N bits) is almost all zeros once N reaches the thousands: at 10^4 sketches the matrix is 21 GB
+// and the row sums stream 65 GB.  Here every distinct key gets the LIST of the sketches holding it (u16 ids,
+// length first) and the row sums walk the lists:
+//   k_insert_sparse  CAS insert + one count per key on its slot; the slot of every entry is remembered
+//   k_assign_ranges  slot -> list position (workgroup prefix + one atomic per 16 Ki slots), writes the lengths
+//   k_fill_sparse    full-key check (collision flag), then each entry takes a place in its slot's list (count-down)
+//   k_accumulate_sparse  one workgroup per sketch and block of 16 Ki columns: LDS counters, one LDS add per
+//                    (key of i, other holder of the key)
+// Traffic per key is its list (a few bytes) instead of N/8 bytes.  Used when all rows are owned (single GPU).
+__global__ void k_insert_sparse(Keys K, const uint64_t* __restrict__ sk_off, uint64_t seed, uint64_t* __restrict__ table,
+                                uint32_t log2cap, uint32_t* __restrict__ cnt, SlotKeys SK, uint32_t* __restrict__ slot_of_entry,
+                                uint32_t* __restrict__ flags) {
+    const uint32_t j = blockIdx.y;
+    const uint64_t e = sk_off[j] + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= sk_off[j + 1]) return;
+    if (e > sk_off[j] && !key_less(K, e - 1, e)) atomicOr(&flags[0], 1u);
+    const uint64_t fp = fingerprint(K, e, seed);
+    const uint64_t mask = (1ull << log2cap) - 1;
+    uint64_t pos = home_slot(fp, log2cap);
+    for (uint64_t probes = 0;; ++probes) {
+        const unsigned long long old = atomicCAS((unsigned long long*)&table[pos], 0ull, (unsigned long long)fp);
+        if (old == 0ull) {
+            SK.lo[pos] = K.lo[e]; SK.mn[pos] = K.mn[e];
+            if (K.hi) SK.hi[pos] = K.hi[e];
+            break;
+        }
+        if (old == fp) break;
+        if (probes > mask) { atomicOr(&flags[5], 1u); return; }
+        pos = (pos + 1) & mask;
+    }
+    atomicAdd(&cnt[pos], 1u);                   // result unused: a returning atomic here costs 60 % more (measured)
+    slot_of_entry[e] = (uint32_t)pos;
+}
+
+__global__ __launch_bounds__(kRowThreads) void k_assign_ranges(const uint32_t* __restrict__ cnt, uint64_t cap,
+                                                              uint32_t* __restrict__ off, uint16_t* __restrict__ ids,
+                                                              uint32_t* __restrict__ total) {
+    __shared__ uint32_t wave_sum[kRowThreads / 64];
+    __shared__ uint32_t s_base;
+    const uint32_t t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const uint64_t base_slot = ((uint64_t)blockIdx.x * kRowThreads + t) * kRowSlots;   // 16 consecutive slots per lane
+    uint32_t c[kRowSlots];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int u = 0; u < kRowSlots; ++u) {
+        const uint64_t sl = base_slot + u;
+        c[u] = sl < cap ? cnt[sl] : 0u;
+        sum += c[u] ? c[u] + 1 : 0u;            // list = length word + ids
+    }
+    uint32_t x = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d);
+        if (lane >= (uint32_t)d) x += y;
+    }
+    if (lane == 63) wave_sum[wid] = x;
+    __syncthreads();
+    uint32_t pre = 0, all = 0;
+    for (uint32_t w = 0; w < kRowThreads / 64; ++w) { if (w < wid) pre += wave_sum[w]; all += wave_sum[w]; }
+    if (t == 0) s_base = all ? atomicAdd(total, all) : 0u;
+    __syncthreads();
+    uint32_t at = s_base + pre + x - sum;
+#pragma unroll
+    for (int u = 0; u < kRowSlots; ++u) {
+        if (!c[u]) continue;
+        off[base_slot + u] = at;
+        ids[at] = (uint16_t)c[u];               // a key is held at most once per sketch: length <= 65535
+        at += c[u] + 1;
+    }
+}
+
+__global__ void k_fill_sparse(Keys K, const uint64_t* __restrict__ sk_off, uint32_t* __restrict__ slot_of_entry, SlotKeys SK,
+                              uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off, uint16_t* __restrict__ ids,
+                              uint32_t* __restrict__ flags) {
+    const uint32_t j = blockIdx.y;
+    const uint64_t e = sk_off[j] + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= sk_off[j + 1]) return;
+    const uint32_t pos = slot_of_entry[e];
+    const bool same = SK.lo[pos] == K.lo[e] && SK.mn[pos] == K.mn[e] && (!K.hi || SK.hi[pos] == K.hi[e]);
+    if (!same) atomicOr(&flags[1], 1u);         // two distinct keys, one fingerprint: the host rebuilds with another seed
+    const uint32_t o = off[pos];
+    const uint32_t idx = atomicSub(&cnt[pos], 1u);   // counts down c .. 1: the places behind the length word
+    ids[o + idx] = (uint16_t)j;
+    slot_of_entry[e] = o;                       // the row sums go straight to the list
+}
+
+constexpr int kSparseCols = 16384, kSparseThreads = 256;
+__global__ __launch_bounds__(kSparseThreads) void k_accumulate_sparse(const uint32_t* __restrict__ list_of_entry,
+                                                                     const uint16_t* __restrict__ ids,
+                                                                     const uint64_t* __restrict__ sk_begin,
+                                                                     const uint64_t* __restrict__ sk_end, uint32_t n,
+                                                                     uint32_t* __restrict__ inter,
+                                                                     const uint32_t* __restrict__ flags,
+                                                                     uint32_t* __restrict__ host_flags) {
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 6) host_flags[threadIdx.x] = flags[threadIdx.x];
+    const uint32_t i = blockIdx.y, col0 = blockIdx.x * kSparseCols;
+    if (col0 + kSparseCols <= i + 1) return;                // no column > i in this block
+    __shared__ uint32_t s_cnt[kSparseCols];
+    for (uint32_t x = threadIdx.x; x < kSparseCols; x += kSparseThreads) s_cnt[x] = 0;
+    __syncthreads();
+    for (uint64_t e = sk_begin[i] + threadIdx.x; e < sk_end[i]; e += kSparseThreads) {
+        const uint32_t o = list_of_entry[e];
+        const uint32_t len = ids[o];
+        for (uint32_t t = 1; t <= len; ++t) {
+            const uint32_t jj = ids[o + t];
+            if (jj > i && jj - col0 < (uint32_t)kSparseCols) atomicAdd(&s_cnt[jj - col0], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t x = threadIdx.x; x < kSparseCols; x += kSparseThreads) {
+        const uint32_t col = col0 + x;
+        if (col > i && col < n) inter[(uint64_t)i * n + col] = s_cnt[x];
+    }
+}
+
 // inter[i][*] for one owned sketch i and one block of 64 colour words (4096 columns).
 // A lane owns ONE 64-bit word of the colour rows (64 columns): a key's row is read
 // with one coalesced wave load and every lane adds its word's 64 bits into 64 private
@@ -318,6 +435,10 @@ struct CompareJob {
     bool clear_all_flags = false;   // no pass before the first attempt has written flags
     bool direct_rows = false;   // speculative and every row owned from entry 0: row id = the owner's entry index
     int attempt = 0;
+    // sparse form (many sketches, all rows owned): set by the flat entry point, see k_insert_sparse
+    std::function<int(uint64_t seed, uint64_t fp_mask, uint32_t log2cap)> insert_sparse;
+    std::function<int()> fill_sparse;
+    bool sparse = false;
     uint32_t passes = 1, pass = 0;  // large builds: the keys are split into classes and the dictionary + colour
                                     // matrix are built class by class, so the matrix never exceeds its budget
 };
@@ -327,6 +448,32 @@ static uint64_t job_fp_mask(const CompareJob& J) {
     static const char* dbg_fp = getenv("SPSP_DEBUG_FP_BITS");
     return (dbg_fp && J.attempt == 0) ? ((1ull << atoi(dbg_fp)) - 1) : ~0ull;
 }
+// sparse form: the whole pipeline in one go (no size depends on a count the host has to read)
+static int job_sparse(spsp_ctx* ctx, CompareJob& J) {
+    uint32_t* flags = ctx->c_flags.as<uint32_t>();
+    const ComparePlan& P = J.P;
+    int rc;
+    // table and per-slot counts are cleared together (the counts live where the dense form keeps slot owners)
+    const uint64_t t_vec = J.cap * 8 / 16, c_vec = (J.cap * 4 + 15) / 16;
+    const uint64_t want = (t_vec + c_vec + 255) / 256, cap_blocks = (uint64_t)ctx->n_cu * 8;
+    hipLaunchKernelGGL(k_prepare, dim3((uint32_t)std::max<uint64_t>(1, std::min(want, cap_blocks))), dim3(256), 0, ctx->stream,
+                       ctx->c_table.as<uint4>(), t_vec, ctx->c_owner.as<uint4>(), c_vec, flags,
+                       (J.attempt == 0 && J.clear_all_flags) ? 16u : 3u,
+                       (const uint64_t*)ctx->h_skoff, ctx->c_skoff.as<uint64_t>(), J.n_skoff);
+    SPSP_HIP(hipGetLastError());
+    if ((rc = J.insert_sparse(J.seed, job_fp_mask(J), J.log2cap))) return rc;
+    hipLaunchKernelGGL(k_assign_ranges, dim3(J.sblocks), dim3(kRowThreads), 0, ctx->stream, ctx->c_owner.as<uint32_t>(), J.cap,
+                       ctx->c_rowid.as<uint32_t>(), ctx->c_matrix.as<uint16_t>(), flags + 2);
+    SPSP_HIP(hipGetLastError());
+    if ((rc = J.fill_sparse())) return rc;
+    if ((rc = ctx->ev_begin(kEvAccumulate))) return rc;
+    hipLaunchKernelGGL(k_accumulate_sparse, dim3((P.n + kSparseCols - 1) / kSparseCols, P.n), dim3(kSparseThreads), 0, ctx->stream,
+                       ctx->c_row.as<uint32_t>(), ctx->c_matrix.as<uint16_t>(), P.sk_begin, P.sk_end,
+                       P.n, P.d_inter, flags, reinterpret_cast<uint32_t*>(ctx->h_scalar + 8));
+    SPSP_HIP(hipGetLastError());
+    return ctx->ev_end(kEvAccumulate);
+}
+
 // dictionary build: table (and row ids unless the owner's entry index serves as the row)
 static int job_front(spsp_ctx* ctx, CompareJob& J) {
     uint32_t* flags = ctx->c_flags.as<uint32_t>();
@@ -396,11 +543,17 @@ static int compare_job_begin(spsp_ctx* ctx, CompareJob* job) {
     static const char* dbg_budget = getenv("SPSP_DEBUG_MATRIX_BUDGET");    // test hook: bytes the matrix may take
     const uint64_t worst_matrix = (uint64_t)P.S_own * J->W * 8;
     J->speculative = !dbg_budget && worst_matrix <= (256ull << 20);
+    // many sketches, every row owned: sketch lists instead of colour rows (SPSP_DEBUG_SPARSE=1/0 forces the choice)
+    static const char* dbg_sparse = getenv("SPSP_DEBUG_SPARSE");
+    const bool all_owned = P.row_stride == 1 && P.row_first == 0 && P.row_limit >= P.n && P.n_own == P.n;
+    J->sparse = J->insert_sparse && all_owned && 2 * P.S_entries < 0xfffffff0ull &&
+                (dbg_sparse ? atoi(dbg_sparse) != 0 : (J->W >= 64 && !dbg_budget));
+    if (J->sparse) J->speculative = true;       // queued in one go, checked once
     // Large builds: the colour matrix is rows x N bits and grows with N * (distinct keys) -- at tens of thousands of
     // sketches it would outgrow the card.  The reference bounds the same structure by working bucket by bucket
     // (Comparator.cpp:58-68); here the keys are split into hash classes and one class is built and summed at a time.
     J->passes = 1;
-    if (!J->speculative) {
+    if (!J->speculative && !J->sparse) {
         uint64_t budget;
         if (dbg_budget) budget = (uint64_t)atoll(dbg_budget);
         else {
@@ -423,13 +576,18 @@ static int compare_job_begin(spsp_ctx* ctx, CompareJob* job) {
     if ((rc = ctx->c_row.reserve((size_t)P.S_entries * 4))) return rc;
     J->sblocks = (uint32_t)((J->cap + (uint64_t)kRowThreads * kRowSlots - 1) / ((uint64_t)kRowThreads * kRowSlots));
     // owned entries form the prefix [0, S_own) of the entry space when rows are not strided over ranks
-    J->direct_rows = J->speculative && P.row_stride == 1 && P.row_first == 0;
+    J->direct_rows = J->speculative && !J->sparse && P.row_stride == 1 && P.row_first == 0;
     if ((rc = ctx->c_slot_lo.reserve((size_t)J->cap * 8))) return rc;
     if ((rc = ctx->c_slot_hi.reserve((size_t)J->cap * 8))) return rc;
     if ((rc = ctx->c_slot_mn.reserve((size_t)J->cap * 4))) return rc;
-    if ((rc = job_front(ctx, *J))) return rc;
-    if (J->speculative) { if ((rc = job_back(ctx, *J, P.S_own))) return rc; }   // k_accumulate forwards the flags
-    else if ((rc = job_queue_flags(ctx))) return rc;                             // the row count is needed first
+    if (J->sparse) {
+        if ((rc = ctx->c_matrix.reserve((size_t)2 * P.S_entries * sizeof(uint16_t) + 16))) return rc;   // lists: ids + lengths
+        if ((rc = job_sparse(ctx, *J))) return rc;
+    } else {
+        if ((rc = job_front(ctx, *J))) return rc;
+        if (J->speculative) { if ((rc = job_back(ctx, *J, P.S_own))) return rc; }   // k_accumulate forwards the flags
+        else if ((rc = job_queue_flags(ctx))) return rc;                             // the row count is needed first
+    }
     ctx->compare_job = J.release();
     return SPSP_OK;
 }
@@ -462,6 +620,7 @@ int compare_job_end(spsp_ctx* ctx) {
         ++J->attempt;
         J->pass = 0;   // a class that collided has already been added into the counts: start over (the first class overwrites)
         J->seed = J->seed * 6364136223846793005ULL + 1442695040888963407ULL;  // new fingerprints, try again
+        if (J->sparse) { if ((rc = job_sparse(ctx, *J))) return rc; continue; }
         if ((rc = job_front(ctx, *J))) return rc;
         if (J->speculative) { if ((rc = job_back(ctx, *J, J->P.S_own))) return rc; }
         else if ((rc = job_queue_flags(ctx))) return rc;
@@ -533,6 +692,22 @@ static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t*
                            direct_rows ? (const uint32_t*)nullptr : ctx->c_rowid.as<uint32_t>(),
                            SlotKeys{ctx->c_slot_lo.as<uint64_t>(), ctx->c_slot_hi.as<uint64_t>(), ctx->c_slot_mn.as<uint32_t>()},
                            W, ctx->c_matrix.as<unsigned long long>(), ctx->c_row.as<uint32_t>(), flags, passes, pass);
+        SPSP_HIP(hipGetLastError());
+        return SPSP_OK;
+    };
+    J->insert_sparse = [=](uint64_t seed, uint64_t fp_mask, uint32_t log2cap) -> int {
+        Keys Km = K; Km.fp_mask = fp_mask;
+        hipLaunchKernelGGL(k_insert_sparse, grid_all, dim3(256), 0, ctx->stream, Km, sk, seed, ctx->c_table.as<uint64_t>(), log2cap,
+                           ctx->c_owner.as<uint32_t>(),
+                           SlotKeys{ctx->c_slot_lo.as<uint64_t>(), ctx->c_slot_hi.as<uint64_t>(), ctx->c_slot_mn.as<uint32_t>()},
+                           ctx->c_row.as<uint32_t>(), flags);
+        SPSP_HIP(hipGetLastError());
+        return SPSP_OK;
+    };
+    J->fill_sparse = [=]() -> int {
+        hipLaunchKernelGGL(k_fill_sparse, grid_all, dim3(256), 0, ctx->stream, K, sk, ctx->c_row.as<uint32_t>(),
+                           SlotKeys{ctx->c_slot_lo.as<uint64_t>(), ctx->c_slot_hi.as<uint64_t>(), ctx->c_slot_mn.as<uint32_t>()},
+                           ctx->c_owner.as<uint32_t>(), ctx->c_rowid.as<uint32_t>(), ctx->c_matrix.as<uint16_t>(), flags);
         SPSP_HIP(hipGetLastError());
         return SPSP_OK;
     };

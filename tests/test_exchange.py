@@ -318,3 +318,66 @@ def test_capped_colour_matrix_runs_key_class_passes():
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SPSP_DEBUG_MATRIX_BUDGET="6000", **extra),
                            capture_output=True, text=True, timeout=900)
         assert r.returncode == 0 and "ok" in r.stdout, (extra, r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_sparse_list_form_many_sketches(ctx):
+    """4 300 sketches (67 colour words): the comparison takes the sketch-list form by itself.  Checked against a
+    plain Python count of shared keys over all 9.2 million pairs."""
+    rng = np.random.default_rng(123)
+    n = 4300
+    universe = rng.integers(1, 2**62, size=60_000, dtype=np.int64)
+    fam = [rng.choice(universe, size=120, replace=False) for _ in range(200)]          # 200 families share their keys
+    sketches, sets = [], []
+    for i in range(n):
+        base = fam[i % 200]
+        keep = base[rng.random(len(base)) < 0.8]
+        extra = rng.choice(universe, size=int(rng.integers(0, 15)), replace=False)
+        keys = np.unique(np.concatenate([keep, extra])).astype(np.uint64) if i % 97 else np.zeros(0, np.uint64)
+        sets.append(keys)
+        sketches.append(sp.Sketch(31, 11, np.full(len(keys), 5, np.uint32), keys, np.zeros(len(keys), np.uint64)))
+    inter, card = ctx.compare(sketches)
+    assert [int(c) for c in card] == [len(s) for s in sets]
+    holders = {}
+    for i, keys in enumerate(sets):
+        for key in keys.tolist():
+            holders.setdefault(key, []).append(i)
+    want = np.zeros((n, n), dtype=np.uint32)
+    for hs in holders.values():
+        if len(hs) > 1:
+            a = np.array(hs)
+            ii, jj = np.triu_indices(len(a), 1)
+            np.add.at(want, (a[ii], a[jj]), 1)
+    assert want.sum() > 1_000_000
+    assert (inter == want).all()
+
+
+def test_sparse_list_form_forced_on_small_inputs():
+    """SPSP_DEBUG_SPARSE=1: the sketch-list form on the inputs of the dense tests (k > 32 keys, empty and duplicate
+    sketches, 1-3 colour words) and, with cut fingerprints, through its collision retry."""
+    code = (
+        "import sys\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np, torch\n"
+        "import supersampler_amd as sp\n"
+        "import test_exchange as tx\n"
+        "ctx = sp.Context(0)\n"
+        "for n, use_hi in ((3, False), (70, True), (150, False)):\n"
+        "    sets = tx.make_sets(np.random.default_rng(n), n, use_hi)\n"
+        "    sk = []\n"
+        "    for st in sets:\n"
+        "        keys = sorted(st)\n"
+        "        sk.append(sp.Sketch(63 if use_hi else 31, 15, np.array([x[0] for x in keys], np.uint32),\n"
+        "                            np.array([x[2] for x in keys], np.uint64), np.array([x[1] for x in keys], np.uint64)))\n"
+        "    inter, card = ctx.compare(sk)\n"
+        "    assert all(inter[i, j] == (len(sets[i] & sets[j]) if j > i else 0) for i in range(n) for j in range(n)), n\n"
+        "    assert [int(c) for c in card] == [len(s) for s in sets]\n"
+        "sk[4].kmer_lo[[1, 2]] = sk[4].kmer_lo[[2, 1]]; sk[4].minimizer[[1, 2]] = sk[4].minimizer[[2, 1]]\n"
+        "try:\n"
+        "    ctx.compare(sk); raise SystemExit('unsorted keys were accepted')\n"
+        "except sp.SpspError:\n"
+        "    pass\n"
+        "print('ok')\n") % (ROOT, os.path.join(ROOT, "tests"))
+    for extra in ({}, {"SPSP_DEBUG_FP_BITS": "9"}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SPSP_DEBUG_SPARSE="1", **extra),
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "ok" in r.stdout, (extra, r.stdout[-2000:], r.stderr[-3000:])
