@@ -231,14 +231,19 @@ def main():
         pending = None
         for i in range(n):
             sl = slots[i % len(slots)]
+            t_a = time.perf_counter()
             queue_step(sl, pending)                       # step i is on the GPU's queues ...
+            t_b = time.perf_counter()
             if pending is not None:
                 collect_step(pending)                     # ... before the host waits for step i-1
+            host["queue"] += t_b - t_a
+            host["collect"] += time.perf_counter() - t_b
             pending = sl
         if pending is not None:
             collect_step(pending)
 
     last = {"n_out": 0, "slot": slots[0]}
+    host = {"queue": 0.0, "collect": 0.0}   # host seconds spent queueing / waiting (pipelined mode)
 
     def fence():
         torch.cuda.synchronize()
@@ -254,6 +259,7 @@ def main():
         c.timing_enable(True, kinds)
         c.timing_read()
     fence()
+    host["queue"] = host["collect"] = 0.0
     t0 = time.perf_counter()
     run_steps(args.steps)
     fence()
@@ -345,6 +351,7 @@ def main():
                          "compare_pipeline": compare_avg_ms if tm["compare_calls"] else None,
                          "accumulate_kernel": acc_ms / tm["accumulate_launches"] if tm["accumulate_launches"] else None},
             "superkmers_per_step": int(n_out), "inter_nonzero": inter_nonzero,
+            "host_ms_per_step": {"queueing": host["queue"] * 1e3 / args.steps, "waiting": host["collect"] * 1e3 / args.steps},
             "roofline": {"kernel": "k_dense_pair (2-bit pack + LDS pair-table test of every m-mer position; XXH64 on survivors)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(args),
