@@ -247,6 +247,11 @@ int spsp_csv_host(int jaccard, const char* const* names, uint32_t n, uint32_t n_
                   const uint32_t* inter, const uint64_t* card, int precision, double min_threshold,
                   char** text, uint64_t* len);
 
+/* sortCSV (sort_csv.cpp:26-111): rows and columns of a symmetric all-vs-all Jaccard CSV (gunzipped text) put into
+ * the order of the original file of files.  Inputs the reference mishandles (name missing from the fof or listed
+ * twice, short or unparsable rows, diagonal != 1) are rejected with SPSP_ERR_FORMAT. */
+int spsp_sort_csv_host(const char* csv, uint64_t csv_len, const char* fof, uint64_t fof_len, char** text, uint64_t* len);
+
 /* zstr-compatible I/O (include/zstr.hpp:136-209 autodetect, :392-407 gzip
  * writer): whole-file read with gzip/zlib/plain autodetection; gzip write. */
 int spsp_read_file_host(const char* path, uint8_t** data, uint64_t* len);

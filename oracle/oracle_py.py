@@ -79,6 +79,8 @@ def lib():
                               C.POINTER(u32), C.POINTER(u32)]
     L.orc_compare_timed.restype = dbl
     L.orc_compare_timed.argtypes = [C.POINTER(cp), C.POINTER(u64), u32, u32, vp, vp]
+    L.orc_sort_csv.restype = vp
+    L.orc_sort_csv.argtypes = [cp, u64, cp, u64, C.POINTER(u64)]
     L.orc_csv.restype = vp
     L.orc_csv.argtypes = [C.c_int, cp, u32, u32, vp, vp, C.c_int, dbl, C.POINTER(u64)]
     _lib = L
@@ -203,4 +205,14 @@ def csv(jaccard, names, inter, card, n_query=None, precision=6, min_threshold=0.
     ln = C.c_uint64()
     p = lib().orc_csv(1 if jaccard else 0, "\n".join(names).encode(), n, nq, inter.ctypes.data,
                       card.ctypes.data, precision, float(min_threshold), C.byref(ln))
+    return _take(p, ln.value)
+
+
+def sort_csv(csv_text, fof_text):
+    """sortCSV (sort_csv.cpp:26-111) on gunzipped CSV bytes + fof bytes -> output file bytes, or None where the
+    reference's behaviour is undefined (see orc_sort_csv)."""
+    ln = C.c_uint64()
+    p = lib().orc_sort_csv(csv_text, len(csv_text), fof_text, len(fof_text), C.byref(ln))
+    if not p:
+        return None
     return _take(p, ln.value)

@@ -885,4 +885,69 @@ char* orc_csv(int jaccard, const char* names_nl, uint32_t n, uint32_t n_query, c
     return dup_bytes(print_matrix(jaccard != 0, names, n, n_query, inter, card, precision, min_threshold), out_len);
 }
 
+// sortCSV (sort_csv.cpp:26-111 with split(), utils.cpp:609-629): reorder a Jaccard CSV (already gunzipped) to the
+// order of the original file-of-files.  Returns NULL where the reference reads memory it never wrote, throws or
+// blocks on cin.get(): a header name missing from the fof or listed twice, a row with fewer than N values or an
+// unparsable one, fewer than N rows, a diagonal entry != 1.  The reference's stdout chatter is not reproduced.
+char* orc_sort_csv(const char* csv, uint64_t csv_len, const char* fof, uint64_t fof_len, uint64_t* out_len) {
+    auto lines_of = [](const char* p, uint64_t n) {          // getline until eof: a trailing newline yields a last ""
+        std::vector<std::string> v;
+        std::string cur;
+        for (uint64_t i = 0; i < n; ++i) { if (p[i] == '\n') { v.push_back(cur); cur.clear(); } else cur += p[i]; }
+        v.push_back(cur);
+        return v;
+    };
+    auto split = [](const std::string& str) {                // utils.cpp:609-629: the last token stops at the first non-printable
+        std::vector<std::string> res;
+        size_t pred = 0;
+        for (size_t i = 0; i < str.size(); ++i) if (str[i] == ',') { res.push_back(str.substr(pred, i - pred)); pred = i + 1; }
+        std::string last;
+        for (char c : str.substr(pred)) { if (isprint((unsigned char)c)) last += c; else break; }
+        res.push_back(last);
+        return res;
+    };
+    const std::vector<std::string> names_ordered = lines_of(fof, fof_len);          // :35-38
+    const std::vector<std::string> in = lines_of(csv, csv_len);
+    if (in.empty()) return nullptr;
+    const std::vector<std::string> files_names = split(in[0]);                      // :39-40
+    const size_t N = files_names.size();
+    std::map<uint32_t, uint32_t> sorted_names, old2new;
+    std::map<uint32_t, std::string> names;
+    for (size_t i = 0; i < N; ++i) {                                                // :49-56
+        const size_t pos = std::find(names_ordered.begin(), names_ordered.end(), files_names[i]) - names_ordered.begin();
+        if (pos == names_ordered.size() || sorted_names.count((uint32_t)pos)) return nullptr;
+        sorted_names[(uint32_t)pos] = (uint32_t)i;
+        names[(uint32_t)pos] = files_names[i];
+    }
+    uint32_t id = 0;
+    for (auto const& kv : sorted_names) old2new[kv.second] = id++;                  // :60-65
+    std::ostringstream out;
+    id = 0;
+    for (auto const& kv : names) { out << kv.second; if (++id != N) out << ','; }   // :66-71
+    out << std::endl;
+    std::vector<double> matrix(N * N, 0.0);
+    size_t line_id = 0;
+    for (size_t l = 1; l < in.size(); ++l) {                                        // :76-85
+        const std::string& line = in[l];
+        if (line.size() < N) break;
+        if (line_id >= N) return nullptr;
+        const std::vector<std::string> values = split(line);
+        if (values.size() < N) return nullptr;
+        for (size_t i = 0; i < N; ++i) {
+            char* endp = nullptr;
+            const double v = strtod(values[i].c_str(), &endp);                      // stod: leading number, rest ignored
+            if (endp == values[i].c_str()) return nullptr;
+            matrix[old2new[(uint32_t)i] * N + old2new[(uint32_t)line_id]] = v;
+        }
+        ++line_id;
+    }
+    if (line_id != N) return nullptr;
+    for (size_t i = 0; i < N; ++i) {                                                // :89-109
+        if (matrix[i * N + i] != 1) return nullptr;                                 // "bug2" + cin.get()
+        for (size_t j = 0; j < N; ++j) { out << matrix[i * N + j]; if (j != N - 1) out << ','; }
+        out << std::endl;
+    }
+    return dup_bytes(out.str(), out_len);
+}
+
 }  // extern "C"

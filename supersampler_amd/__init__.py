@@ -60,7 +60,7 @@ ABI_SYMBOLS = [
     "spsp_create", "spsp_destroy", "spsp_last_error", "spsp_version", "spsp_free", "spsp_copy_to_host",
     "spsp_timing_enable", "spsp_timing_read", "spsp_threshold_host", "spsp_scan", "spsp_scan_device", "spsp_scan_device_begin", "spsp_scan_device_end", "spsp_wait_dense", "spsp_wait_stream", "spsp_scan_hits_device", "spsp_compare",
     "spsp_compare_device", "spsp_slot_bytes", "spsp_partition_keys_device", "spsp_compare_slots_device", "spsp_compare_device_begin", "spsp_compare_slots_device_begin", "spsp_compare_end", "spsp_fasta_clean_host", "spsp_fasta_clean_device", "spsp_sketch_text", "spsp_sketch_build_host", "spsp_sketch_parse_host",
-    "spsp_csv_host", "spsp_read_file_host", "spsp_write_gz_host", "spsp_sketch_file", "spsp_compare_files",
+    "spsp_csv_host", "spsp_sort_csv_host", "spsp_read_file_host", "spsp_write_gz_host", "spsp_sketch_file", "spsp_compare_files",
 ]
 
 _lib = None
@@ -120,6 +120,8 @@ def lib():
     L.spsp_sketch_parse_host.argtypes = [cp, u64, P(u32), P(u32), P(vp), P(vp), P(vp), P(u64)]
     L.spsp_csv_host.restype = i32
     L.spsp_csv_host.argtypes = [i32, P(cp), u32, u32, vp, vp, i32, dbl, P(vp), P(u64)]
+    L.spsp_sort_csv_host.restype = i32
+    L.spsp_sort_csv_host.argtypes = [cp, u64, cp, u64, P(vp), P(u64)]
     L.spsp_read_file_host.restype = i32; L.spsp_read_file_host.argtypes = [cp, P(vp), P(u64)]
     L.spsp_write_gz_host.restype = i32; L.spsp_write_gz_host.argtypes = [cp, cp, u64, i32]
     L.spsp_sketch_file.restype = i32
@@ -216,6 +218,13 @@ def csv(jaccard, names, inter, card, n_query=None, precision=6, min_threshold=0.
     _check(lib().spsp_csv_host(1 if jaccard else 0, arr, n, nq, inter.ctypes.data, card.ctypes.data, precision,
                                float(min_threshold), C.byref(out), C.byref(ln)))
     return _take(out, ln.value)
+
+
+def sort_csv(csv_text, fof_text):
+    """sortCSV on gunzipped CSV bytes + file-of-files bytes -> reordered CSV bytes"""
+    out, n = C.c_void_p(), C.c_uint64()
+    _check(lib().spsp_sort_csv_host(csv_text, len(csv_text), fof_text, len(fof_text), C.byref(out), C.byref(n)))
+    return _take(out, n.value)
 
 
 def read_file(path):

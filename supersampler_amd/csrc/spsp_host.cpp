@@ -15,6 +15,7 @@
 #include <functional>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "spsp_internal.h"
@@ -513,6 +514,82 @@ int spsp_sketch_parse_host(const uint8_t* payload, uint64_t len, uint32_t* k_out
 
 // print_containment / print_jaccard (Comparator.cpp:362-460); operator<<(double)
 // with setprecision(p) in the default float format is printf's %.*g.
+// sortCSV (sort_csv.cpp:26-111): put the rows and columns of a (symmetric, all-vs-all) Jaccard CSV into the order of
+// the original file-of-files -- sub_sampler's output list is in OpenMP completion order (SubSampler.cpp:782-786).
+// Values pass through a double and are printed with six significant digits, as the reference's `out << double`.
+int spsp_sort_csv_host(const char* csv, uint64_t csv_len, const char* fof, uint64_t fof_len, char** text, uint64_t* len) {
+    if (!text || !len || (csv_len && !csv) || (fof_len && !fof)) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    *text = nullptr; *len = 0;
+    // fof lines -> rank (first occurrence wins, as std::find does; a final newline yields one empty last name)
+    std::unordered_map<std::string, uint32_t> rank_of;
+    {
+        uint32_t line_no = 0;
+        uint64_t a = 0;
+        for (uint64_t i = 0; i <= fof_len; ++i) {
+            if (i == fof_len || fof[i] == '\n') { rank_of.emplace(std::string(fof + a, i - a), line_no++); a = i + 1; }
+        }
+    }
+    // CSV lines
+    std::vector<std::pair<const char*, size_t>> lines;
+    for (uint64_t a = 0, i = 0; i <= csv_len; ++i)
+        if (i == csv_len || csv[i] == '\n') { lines.emplace_back(csv + a, (size_t)(i - a)); a = i + 1; }
+    auto tokens = [](const char* p, size_t n) {   // split() of utils.cpp:609-629: the last field ends at the first non-printable byte
+        std::vector<std::string> t;
+        size_t a = 0;
+        for (size_t i = 0; i < n; ++i) if (p[i] == ',') { t.emplace_back(p + a, i - a); a = i + 1; }
+        size_t e = a;
+        while (e < n && isprint((unsigned char)p[e])) ++e;
+        t.emplace_back(p + a, e - a);
+        return t;
+    };
+    if (lines.empty()) { set_error("empty CSV"); return SPSP_ERR_FORMAT; }
+    const std::vector<std::string> head = tokens(lines[0].first, lines[0].second);
+    const size_t N = head.size();
+    std::vector<std::pair<uint32_t, uint32_t>> order;   // (rank in the fof, column in the input)
+    for (size_t c = 0; c < N; ++c) {
+        auto it = rank_of.find(head[c]);
+        if (it == rank_of.end()) { set_error("column '%s' is not in the file of files", head[c].c_str()); return SPSP_ERR_FORMAT; }
+        order.emplace_back(it->second, (uint32_t)c);
+    }
+    std::sort(order.begin(), order.end());
+    for (size_t c = 1; c < N; ++c)
+        if (order[c].first == order[c - 1].first) { set_error("column '%s' appears twice", head[order[c].second].c_str()); return SPSP_ERR_FORMAT; }
+    std::vector<uint32_t> new_of(N);
+    for (size_t r = 0; r < N; ++r) new_of[order[r].second] = (uint32_t)r;
+    std::vector<double> m(N * N, 0.0);
+    size_t row = 0;
+    for (size_t l = 1; l < lines.size(); ++l) {
+        if (lines[l].second < N) break;                 // sort_csv.cpp:80 (also what stops at a containment file's blank line)
+        if (row >= N) { set_error("more than %zu rows", N); return SPSP_ERR_FORMAT; }
+        const std::vector<std::string> v = tokens(lines[l].first, lines[l].second);
+        if (v.size() < N) { set_error("row %zu has %zu values, expected %zu", row, v.size(), N); return SPSP_ERR_FORMAT; }
+        for (size_t c = 0; c < N; ++c) {
+            char* endp = nullptr;
+            const double x = strtod(v[c].c_str(), &endp);
+            if (endp == v[c].c_str()) { set_error("row %zu, column %zu: not a number", row, c); return SPSP_ERR_FORMAT; }
+            m[(size_t)new_of[c] * N + new_of[row]] = x;   // the reference fills the transposed cell (sort_csv.cpp:83)
+        }
+        ++row;
+    }
+    if (row != N) { set_error("%zu rows for %zu columns (a containment file, or a query-mode matrix?)", row, N); return SPSP_ERR_FORMAT; }
+    std::string out;
+    for (size_t r = 0; r < N; ++r) { out += head[order[r].second]; out += (r + 1 != N) ? ',' : '\n'; }
+    char num[40];
+    for (size_t i = 0; i < N; ++i) {
+        if (m[i * N + i] != 1) { set_error("diagonal entry %zu is not 1 (the reference stops here)", i); return SPSP_ERR_FORMAT; }
+        for (size_t j = 0; j < N; ++j) {
+            out.append(num, (size_t)snprintf(num, sizeof num, "%g", m[i * N + j]));
+            out += (j + 1 != N) ? ',' : '\n';
+        }
+    }
+    char* buf = (char*)malloc(out.size() + 1);
+    if (!buf) { set_error("out of host memory"); return SPSP_ERR_NOMEM; }
+    memcpy(buf, out.data(), out.size());
+    buf[out.size()] = 0;
+    *text = buf; *len = out.size();
+    return SPSP_OK;
+}
+
 int spsp_csv_host(int jaccard, const char* const* names, uint32_t n, uint32_t n_query, const uint32_t* inter,
                   const uint64_t* card, int precision, double min_threshold, char** text, uint64_t* len) {
     if (!text || !len || (n && (!names || !inter || !card))) { set_error("NULL argument"); return SPSP_ERR_ARG; }

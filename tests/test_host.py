@@ -204,3 +204,75 @@ def test_synth_generators_are_seeded():
     fa = synth.to_fasta(a[0], "g0", n_records=3)
     bases, off = sp.clean_fasta(fa)
     assert bases.tobytes() == a[0].tobytes() and len(off) == 4
+
+
+def _jaccard_csv(rng, n, precision=6):
+    """a symmetric all-vs-all Jaccard CSV as bin/comparator writes it (oracle printer), names in shuffled order"""
+    card = rng.integers(500, 5000, size=n).astype(np.uint64)
+    inter = np.zeros((n, n), dtype=np.uint32)
+    for i in range(n):
+        for j in range(i + 1, n):
+            if rng.random() < 0.6:
+                inter[i, j] = rng.integers(1, int(min(card[i], card[j])) + 1)
+    names = ["out/sk_genome_%d.gz" % i for i in range(n)]
+    order = rng.permutation(n)
+    shuffled = [names[i] for i in order]
+    inter_s = np.zeros_like(inter)
+    for a in range(n):
+        for b in range(a + 1, n):
+            i, j = sorted((order[a], order[b]))
+            inter_s[a, b] = inter[i, j]
+    csv = orc.csv(True, shuffled, inter_s, card[order], n, precision, 0.0)
+    return names, shuffled, csv
+
+
+@pytest.mark.parametrize("n,precision", [(1, 6), (2, 6), (9, 6), (40, 3), (17, 12)])
+def test_sort_csv_matches_oracle_and_restores_fof_order(n, precision):
+    rng = np.random.default_rng(n * 31 + precision)
+    names, shuffled, csv = _jaccard_csv(rng, n, precision)
+    for fof in ("\n".join(names) + "\n", "\n".join(names), "\n".join(["unrelated.gz"] + names + ["tail.gz"]) + "\n"):
+        want = orc.sort_csv(csv, fof.encode())
+        assert want is not None
+        got = sp.sort_csv(csv, fof.encode())
+        assert got == want
+        lines = got.decode().split("\n")
+        assert lines[0].split(",") == names and len(lines) == n + 2 and lines[-1] == ""
+    # sorting an already sorted file is the identity up to the six-digit reprint
+    again = sp.sort_csv(got, ("\n".join(names) + "\n").encode())
+    assert again == orc.sort_csv(got, ("\n".join(names) + "\n").encode())
+    if precision <= 6:
+        assert again == got
+
+
+def test_sort_csv_rejects_what_the_reference_mishandles():
+    rng = np.random.default_rng(5)
+    names, shuffled, csv = _jaccard_csv(rng, 6)
+    fof = ("\n".join(names) + "\n").encode()
+    assert sp.sort_csv(csv, fof) == orc.sort_csv(csv, fof)
+    text = csv.decode()
+    rows = text.split("\n")
+    cases = {
+        "name not in fof": (csv, ("\n".join(names[:-1]) + "\n").encode()),
+        "duplicate column": ((",".join([shuffled[0]] * 2 + shuffled[2:]) + "\n" + "\n".join(rows[1:])).encode(), fof),
+        "missing row": ("\n".join(rows[:-2]).encode() + b"\n", fof),
+        "not a number": (text.replace(rows[2], "x" + rows[2][1:]).encode(), fof),
+        "containment (blank line after the header)": ((rows[0] + "\n\n" + "\n".join(rows[1:])).encode(), fof),
+        "diagonal not 1": (text.replace(rows[1], "0.5" + rows[1][1:], 1).encode() if rows[1].startswith("1,") else csv[:0], fof),
+    }
+    for what, (c, f) in cases.items():
+        assert orc.sort_csv(c, f) is None, what
+        with pytest.raises(sp.SpspError):
+            sp.sort_csv(c, f)
+
+
+def test_sort_csv_cli(tmp_path):
+    rng = np.random.default_rng(12)
+    names, shuffled, csv = _jaccard_csv(rng, 12)
+    src, dst, fof = str(tmp_path / "j.csv.gz"), str(tmp_path / "sorted.csv"), str(tmp_path / "fof.txt")
+    sp.write_gz(src, csv, 1)
+    open(fof, "w").write("\n".join(names) + "\n")
+    r = subprocess.run([os.path.join(ROOT, "bin", "sortCSV"), src, dst, fof], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "The end" in r.stdout, (r.stdout, r.stderr)
+    assert open(dst, "rb").read() == orc.sort_csv(csv, open(fof, "rb").read())
+    r = subprocess.run([os.path.join(ROOT, "bin", "sortCSV"), src], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and "Need input" in r.stdout
