@@ -51,8 +51,8 @@ def main():
     os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--genomes", type=int, default=N_GENOMES, help="genomes per GPU (default = BASELINE config)")
     ap.add_argument("--length", type=int, default=GENOME_LEN)
     ap.add_argument("--mode", choices=["default", "direct", "filter", "pair"], default="default")
