@@ -182,6 +182,9 @@ __global__ void k_fill(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n, 
         if (j % row_stride == row_first && j < row_limit) row_of_entry[e] = 0xffffffffu;   // not in this pass: k_accumulate skips it
         return;
     }
+    // every exit that does not find the key's row (collision, full table: attempts the host discards) must still leave
+    // a valid marker behind, or the row sums queued behind this pass would follow a stale index
+    if (j % row_stride == row_first && j < row_limit) row_of_entry[e] = 0xffffffffu;
     const uint64_t fp = fingerprint(K, e, seed);
     const uint64_t mask = (1ull << log2cap) - 1;
     uint64_t pos = home_slot(fp, log2cap);
@@ -236,7 +239,7 @@ __global__ void k_insert_sparse(Keys K, const uint64_t* __restrict__ sk_off, uin
             break;
         }
         if (old == fp) break;
-        if (probes > mask) { atomicOr(&flags[5], 1u); return; }
+        if (probes > mask) { atomicOr(&flags[5], 1u); slot_of_entry[e] = 0xffffffffu; return; }   // later passes skip the entry
         pos = (pos + 1) & mask;
     }
     atomicAdd(&cnt[pos], 1u);                   // result unused: a returning atomic here costs 60 % more (measured)
@@ -287,6 +290,7 @@ __global__ void k_fill_sparse(Keys K, const uint64_t* __restrict__ sk_off, uint3
     const uint64_t e = sk_off[j] + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= sk_off[j + 1]) return;
     const uint32_t pos = slot_of_entry[e];
+    if (pos == 0xffffffffu) return;             // table overflow was flagged by the insert pass
     const bool same = SK.lo[pos] == K.lo[e] && SK.mn[pos] == K.mn[e] && (!K.hi || SK.hi[pos] == K.hi[e]);
     if (!same) atomicOr(&flags[1], 1u);         // two distinct keys, one fingerprint: the host rebuilds with another seed
     const uint32_t o = off[pos];
@@ -311,6 +315,7 @@ __global__ __launch_bounds__(kSparseThreads) void k_accumulate_sparse(const uint
     __syncthreads();
     for (uint64_t e = sk_begin[i] + threadIdx.x; e < sk_end[i]; e += kSparseThreads) {
         const uint32_t o = list_of_entry[e];
+        if (o == 0xffffffffu) continue;
         const uint32_t len = ids[o];
         for (uint32_t t = 1; t <= len; ++t) {
             const uint32_t jj = ids[o + t];
@@ -947,6 +952,7 @@ __global__ void k_fill_slots(SlotView V, const uint32_t* __restrict__ tot, uint6
         row_of_entry[e] = 0xffffffffu;
         return;
     }
+    row_of_entry[e] = 0xffffffffu;                            // until the row is found (see k_fill)
     const uint32_t local = (uint32_t)(r[V.words - 1] >> 32);
     if (local >= V.n) { atomicOr(&flags[3], 1u); return; }
     const uint32_t g = s * V.n + local;                       // global sketch id = colour
