@@ -381,3 +381,51 @@ def test_sparse_list_form_forced_on_small_inputs():
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SPSP_DEBUG_SPARSE="1", **extra),
                            capture_output=True, text=True, timeout=900)
         assert r.returncode == 0 and "ok" in r.stdout, (extra, r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_comparison_forms_agree_on_random_inputs():
+    """the same twelve random comparison problems (2-260 sketches, k <= 32 and k > 32, empty / duplicate / nested
+    sketches, query mode) through the default form, the sketch-list form and the capped colour matrix: identical
+    matrices, and equal to Python set algebra."""
+    code = (
+        "import sys, hashlib\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np, torch\n"
+        "import supersampler_amd as sp\n"
+        "ctx = sp.Context(0)\n"
+        "rng = np.random.default_rng(2024)\n"
+        "digest = hashlib.sha256()\n"
+        "for case in range(12):\n"
+        "    n = int(rng.choice([2, 3, 17, 64, 65, 130, 260]))\n"
+        "    use_hi = bool(rng.integers(0, 2))\n"
+        "    uni = [(int(rng.integers(0, 2**22)), int(rng.integers(0, 2**62)) if use_hi else 0, int(rng.integers(0, 2**62)))\n"
+        "           for _ in range(int(rng.integers(50, 3000)))]\n"
+        "    sets = []\n"
+        "    for i in range(n):\n"
+        "        r = rng.random()\n"
+        "        if r < 0.1: st = set()\n"
+        "        elif r < 0.2 and i: st = set(sets[int(rng.integers(0, i))])\n"
+        "        elif r < 0.3 and i: st = set(list(sets[int(rng.integers(0, i))])[::2])\n"
+        "        else: st = {uni[j] for j in np.nonzero(rng.random(len(uni)) < rng.choice([0.01, 0.1, 0.5]))[0]}\n"
+        "        sets.append(st)\n"
+        "    sk = []\n"
+        "    for st in sets:\n"
+        "        keys = sorted(st)\n"
+        "        sk.append(sp.Sketch(63 if use_hi else 31, 11, np.array([x[0] for x in keys], np.uint32),\n"
+        "                            np.array([x[2] for x in keys], np.uint64), np.array([x[1] for x in keys], np.uint64)))\n"
+        "    nq = n if case %% 3 else max(1, n // 3)\n"
+        "    inter, card = ctx.compare(sk, n_query=nq)\n"
+        "    want = np.zeros((n, n), np.uint32)\n"
+        "    for i in range(nq):\n"
+        "        for j in range(i + 1, n):\n"
+        "            want[i, j] = len(sets[i] & sets[j])\n"
+        "    assert (inter == want).all(), case\n"
+        "    assert [int(c) for c in card] == [len(s) for s in sets]\n"
+        "    digest.update(inter.tobytes())\n"
+        "print('digest', digest.hexdigest())\n") % (ROOT, os.path.join(ROOT, "tests"))
+    digests = []
+    for env in ({}, {"SPSP_DEBUG_SPARSE": "1"}, {"SPSP_DEBUG_MATRIX_BUDGET": "9000"}, {"SPSP_DEBUG_SPARSE": "0"}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "digest" in r.stdout, (env, r.stdout[-2000:], r.stderr[-3000:])
+        digests.append(r.stdout.strip().split()[-1])
+    assert len(set(digests)) == 1
