@@ -241,6 +241,13 @@ int spsp_sketch_text(spsp_ctx* ctx, const spsp_params* p, double rate, const cha
 int spsp_sketch_parse_host(const uint8_t* payload, uint64_t len, uint32_t* k, uint32_t* m,
                            uint32_t** minimizer, uint64_t** kmer_lo, uint64_t** kmer_hi, uint64_t* n);
 
+/* The comparator's N-way merge reads every file's first minimizer into one shared buffer without an end-of-file
+ * check (Comparator.cpp:294,316-319).  Call this for the sketches IN FILE ORDER with the same `read_buffer` (m bytes,
+ * initialised to 'A'): it performs that read and, for a sketch without any bucket when k == m, returns the one
+ * phantom key the reference then counts for it (has_key = 1).  spsp_compare_files does this itself. */
+int spsp_sketch_chain_host(const uint8_t* payload, uint64_t len, uint32_t k, uint32_t m, char* read_buffer, int* has_key,
+                           uint32_t* minimizer, uint64_t* kmer_lo, uint64_t* kmer_hi);
+
 /* print_jaccard / print_containment (Comparator.cpp:362-460), IEEE division.
  * names: n NUL-terminated strings. */
 int spsp_csv_host(int jaccard, const char* const* names, uint32_t n, uint32_t n_query,

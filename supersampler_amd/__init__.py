@@ -59,7 +59,7 @@ SUPERKMER_DTYPE = np.dtype([("rec", "<u4"), ("minimizer", "<u4"), ("start", "<u8
 ABI_SYMBOLS = [
     "spsp_create", "spsp_destroy", "spsp_last_error", "spsp_version", "spsp_free", "spsp_copy_to_host",
     "spsp_timing_enable", "spsp_timing_read", "spsp_threshold_host", "spsp_scan", "spsp_scan_device", "spsp_scan_device_begin", "spsp_scan_device_end", "spsp_wait_dense", "spsp_wait_stream", "spsp_scan_hits_device", "spsp_compare",
-    "spsp_compare_device", "spsp_slot_bytes", "spsp_partition_keys_device", "spsp_compare_slots_device", "spsp_compare_device_begin", "spsp_compare_slots_device_begin", "spsp_compare_end", "spsp_fasta_clean_host", "spsp_fasta_clean_device", "spsp_sketch_text", "spsp_sketch_build_host", "spsp_sketch_parse_host",
+    "spsp_compare_device", "spsp_slot_bytes", "spsp_partition_keys_device", "spsp_compare_slots_device", "spsp_compare_device_begin", "spsp_compare_slots_device_begin", "spsp_compare_end", "spsp_fasta_clean_host", "spsp_fasta_clean_device", "spsp_sketch_text", "spsp_sketch_build_host", "spsp_sketch_parse_host", "spsp_sketch_chain_host",
     "spsp_csv_host", "spsp_sort_csv_host", "spsp_read_file_host", "spsp_write_gz_host", "spsp_sketch_file", "spsp_compare_files",
 ]
 
@@ -118,6 +118,8 @@ def lib():
     L.spsp_sketch_build_host.argtypes = [P(Params), dbl, vp, vp, u32, vp, u64, P(vp), P(u64), P(SketchStats)]
     L.spsp_sketch_parse_host.restype = i32
     L.spsp_sketch_parse_host.argtypes = [cp, u64, P(u32), P(u32), P(vp), P(vp), P(vp), P(u64)]
+    L.spsp_sketch_chain_host.restype = i32
+    L.spsp_sketch_chain_host.argtypes = [cp, u64, u32, u32, C.c_char_p, P(i32), P(u32), P(u64), P(u64)]
     L.spsp_csv_host.restype = i32
     L.spsp_csv_host.argtypes = [i32, P(cp), u32, u32, vp, vp, i32, dbl, P(vp), P(u64)]
     L.spsp_sort_csv_host.restype = i32
@@ -218,6 +220,25 @@ def csv(jaccard, names, inter, card, n_query=None, precision=6, min_threshold=0.
     _check(lib().spsp_csv_host(1 if jaccard else 0, arr, n, nq, inter.ctypes.data, card.ctypes.data, precision,
                                float(min_threshold), C.byref(out), C.byref(ln)))
     return _take(out, ln.value)
+
+
+def sketches_from_payloads(payloads):
+    """Parse sketch payloads IN FILE ORDER, as the comparator reads them: besides sketch_parse this applies the
+    merge's first-read rule (spsp_sketch_chain_host), which gives an empty sketch one phantom key when k == m."""
+    out = []
+    buf = None
+    for pl in payloads:
+        sk = sketch_parse(pl)
+        if buf is None:
+            buf = C.create_string_buffer(b"A" * 16, 16)
+        has, mn, lo, hi = C.c_int32(), C.c_uint32(), C.c_uint64(), C.c_uint64()
+        _check(lib().spsp_sketch_chain_host(pl, len(pl), out[0].k if out else sk.k, out[0].m if out else sk.m, buf,
+                                            C.byref(has), C.byref(mn), C.byref(lo), C.byref(hi)))
+        if has.value and len(sk) == 0:
+            sk = Sketch(sk.k, sk.m, np.array([mn.value], np.uint32), np.array([lo.value], np.uint64),
+                        np.array([hi.value], np.uint64))
+        out.append(sk)
+    return out
 
 
 def sort_csv(csv_text, fof_text):

@@ -512,6 +512,32 @@ int spsp_sketch_parse_host(const uint8_t* payload, uint64_t len, uint32_t* k_out
     return SPSP_OK;
 }
 
+// The N-way merge starts by reading every file's first minimizer into ONE shared buffer, without an end-of-file
+// check (increment_files INITIALIZATION, Comparator.cpp:316-319; buffer = m times 'A', :294).  A sketch with no
+// bucket therefore leaves the buffer as the previous file filled it and enters the merge with that minimizer and an
+// empty blob; inject_minimizer turns an empty blob into the bare minimizer (:88-90), which is dropped when m < k
+// (:193-195) but IS a k-mer when k == m.  So with k == m an empty sketch holds one phantom k-mer that depends on
+// its predecessor in the file list.  This emulates that read for one sketch, in file order.
+int spsp_sketch_chain_host(const uint8_t* payload, uint64_t len, uint32_t k, uint32_t m, char* read_buffer, int* has_key,
+                           uint32_t* minimizer, uint64_t* kmer_lo, uint64_t* kmer_hi) {
+    if (!payload || !read_buffer || !has_key || !minimizer || !kmer_lo || !kmer_hi) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    *has_key = 0;
+    const uint8_t* nl = (const uint8_t*)memchr(payload, '\n', len);
+    if (!nl) { set_error("sketch has no header line"); return SPSP_ERR_FORMAT; }
+    const uint64_t body = len - (uint64_t)(nl + 1 - payload);
+    const uint64_t got = body < m ? body : m;
+    memcpy(read_buffer, nl + 1, (size_t)got);          // istream::read stores what it could read
+    if (got == m || k != m) return SPSP_OK;            // a real first bucket, or a phantom that is dropped (m < k)
+    uint32_t mn = 0;
+    u128 kv = 0;
+    for (uint32_t j = 0; j < m; ++j) { const uint32_t c = code_of((uint8_t)read_buffer[j]); mn = (mn << 2) | c; kv = (kv << 2) | c; }
+    const u128 rc = revcomp_kmer(kv, k);
+    const u128 c = kv < rc ? kv : rc;
+    *minimizer = mn; *kmer_lo = (uint64_t)c; *kmer_hi = (uint64_t)(c >> 64);
+    *has_key = 1;
+    return SPSP_OK;
+}
+
 // print_containment / print_jaccard (Comparator.cpp:362-460); operator<<(double)
 // with setprecision(p) in the default float format is printf's %.*g.
 // sortCSV (sort_csv.cpp:26-111): put the rows and columns of a (symmetric, all-vs-all) Jaccard CSV into the order of
@@ -770,6 +796,7 @@ int spsp_compare_files(spsp_ctx* ctx, const char* const* paths, uint32_t n, uint
     std::vector<uint32_t> ks(n, 0), ms(n, 0);
     std::vector<int> rcs(n, SPSP_OK);
     std::vector<std::string> errs(n);
+    std::vector<std::string> heads(n);   // header line + the first m bytes behind it: what the merge's first read sees
     // One sketch at a time per worker: no N open streams (Comparator.cpp:45-50); gunzip + decode + sort of the
     // sketches is independent work, spread over a few host threads.
     {
@@ -786,6 +813,11 @@ int spsp_compare_files(spsp_ctx* ctx, const char* const* paths, uint32_t n, uint
                 int r = spsp_read_file_host(paths[i], &data, &len);
                 uint32_t* mn = nullptr; uint64_t *lo = nullptr, *hi = nullptr; uint64_t cnt = 0;
                 if (!r) r = spsp_sketch_parse_host(data, len, &ks[i], &ms[i], &mn, &lo, &hi, &cnt);
+                if (!r) {
+                    const uint8_t* nl = (const uint8_t*)memchr(data, '\n', len);
+                    const uint64_t keep = std::min<uint64_t>(len, (uint64_t)(nl + 1 - data) + 16);
+                    heads[i].assign((const char*)data, (size_t)keep);
+                }
                 free(data);
                 if (r) { rcs[i] = r; errs[i] = spsp_last_error(); continue; }
                 owned[3 * (size_t)i] = mn; owned[3 * (size_t)i + 1] = lo; owned[3 * (size_t)i + 2] = hi;
@@ -803,6 +835,18 @@ int spsp_compare_files(spsp_ctx* ctx, const char* const* paths, uint32_t n, uint
         else if (ks[i] != ks[0] || ms[i] != ms[0]) {
             set_error("'%s' was sketched with k=%u m=%u, expected k=%u m=%u", paths[i], ks[i], ms[i], ks[0], ms[0]);
             rc = SPSP_ERR_FORMAT;
+        }
+    }
+    if (!rc && n) {   // the merge's shared first-read buffer, in file order (see spsp_sketch_chain_host)
+        char buffer[16];
+        memset(buffer, 'A', sizeof buffer);
+        for (uint32_t i = 0; i < n && !rc; ++i) {
+            int has = 0; uint32_t mn = 0; uint64_t lo = 0, hi = 0;
+            rc = spsp_sketch_chain_host((const uint8_t*)heads[i].data(), heads[i].size(), ks[0], ms[0], buffer, &has, &mn, &lo, &hi);
+            if (rc || !has || views[i].n) continue;
+            uint32_t* pm = (uint32_t*)owned[3 * (size_t)i]; uint64_t* pl = (uint64_t*)owned[3 * (size_t)i + 1]; uint64_t* ph = (uint64_t*)owned[3 * (size_t)i + 2];
+            pm[0] = mn; pl[0] = lo; ph[0] = hi;      // the parser allocates room for at least one key
+            views[i].n = 1;
         }
     }
     if (!rc && n && ks[0] <= 32) for (uint32_t i = 0; i < n; ++i) views[i].kmer_hi = nullptr;

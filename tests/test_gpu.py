@@ -307,6 +307,42 @@ def test_cli_end_to_end_matches_oracle(tmp_path):
         assert gzip.open(tmp_path / fn, "rb").read() == orc.csv(jac, listed, inter, card, None, 5, 0.0)
 
 
+def test_cli_k_equals_m_with_empty_sketches(tmp_path):
+    """k == m = 15 and genomes shorter than k in the list: their sketches are header-only, and the comparator's merge
+    gives each of them its predecessor's first minimizer as a phantom k-mer (Comparator.cpp:294,316-319).  The
+    drop-in CLIs must print the reference algorithm's matrices here too."""
+    k = m = 15
+    s = 4
+    rng = np.random.default_rng(99)
+    anc = synth.random_genome(rng, 30_000)
+    gs = [synth.random_genome(rng, 9), anc, synth.mutate(rng, anc, 0.01), synth.random_genome(rng, 14),
+          synth.random_genome(rng, 3), synth.random_genome(rng, 20_000), synth.mutate(rng, anc, 0.05)]
+    names = []
+    for i, g in enumerate(gs):
+        path = tmp_path / ("genome%d.fa" % i)
+        path.write_bytes(synth.to_fasta(g, "g%d" % i))
+        names.append(str(path))
+    (tmp_path / "genomes.txt").write_text("\n".join(names) + "\n")
+    r = subprocess.run([os.path.join(ROOT, "bin", "sub_sampler"), "-f", "genomes.txt", "-k", str(k), "-m", str(m), "-s", str(s),
+                        "-t", "1", "-p", "sk_"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    listed = (tmp_path / "sk_genomes.txt").read_text().split()
+    payloads = []
+    for i, nm in enumerate(listed):
+        got = gzip.open(tmp_path / nm, "rb").read()
+        want, _ = orc.sketch_fasta(sp.read_file(names[i]), k, m, float(np.float32(s)))
+        assert got == want, nm
+        payloads.append(want)
+    assert sum(1 for pl in payloads if pl.count(b"\n") == 1) == 3
+    inter, card, _, _ = orc.compare(payloads)
+    assert int(card[0]) == 1 and int(card[3]) == 1 and int(card[4]) == 1 and int(inter[2, 3]) == 1   # the phantoms count
+    r = subprocess.run([os.path.join(ROOT, "bin", "comparator"), "-f", "sk_genomes.txt", "-o", "res"], cwd=tmp_path,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for jac, fn in ((True, "res_jaccard.csv.gz"), (False, "res_containment.csv.gz")):
+        assert gzip.open(tmp_path / fn, "rb").read() == orc.csv(jac, listed, inter, card, None, 6, 0.0)
+
+
 def test_cli_query_mode_abundance_and_flag_rules(tmp_path):
     """-q query fof (rows = queries, columns = queries then index), -a abundance, -m/-p of the comparator, and the
     sketcher's flag rules: even k and m are bumped to odd, m is clamped to 15 (SubSampler.cpp:732-746)."""

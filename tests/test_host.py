@@ -276,3 +276,29 @@ def test_sort_csv_cli(tmp_path):
     assert open(dst, "rb").read() == orc.sort_csv(csv, open(fof, "rb").read())
     r = subprocess.run([os.path.join(ROOT, "bin", "sortCSV"), src], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and "Need input" in r.stdout
+
+
+@pytest.mark.parametrize("k,m", [(7, 7), (15, 15), (11, 11), (21, 11)])
+def test_empty_sketches_follow_the_merges_first_read_rule(k, m):
+    """Comparator.cpp:294,316-319: the N-way merge reads every file's first minimizer into one shared buffer without
+    an end-of-file check, so with k == m an empty sketch inherits its predecessor's first minimizer as a phantom
+    k-mer (a leading empty sketch gets AAA...).  sketches_from_payloads must reproduce what the oracle's literal
+    merge counts; with m < k nothing changes."""
+    rng = np.random.default_rng(k * 3 + m)
+    anc = synth.random_genome(rng, 6000)
+    short = synth.random_genome(rng, max(1, k - 2))                       # shorter than k: an empty sketch
+    genomes = [short, anc, short, synth.mutate(rng, anc, 0.02), synth.random_genome(rng, 3000), short, short, anc[:2000]]
+    payloads = [orc.sketch_fasta(synth.to_fasta(g, "g%d" % i), k, m, 3.0)[0] for i, g in enumerate(genomes)]
+    assert sum(1 for pl in payloads if pl.count(b"\n") == 1) >= 4          # header-only payloads
+    inter, card, kk, mm = orc.compare(payloads)
+    sks = sp.sketches_from_payloads(payloads)
+    sets = [s.key_set() for s in sks]
+    assert [len(s) for s in sets] == [int(c) for c in card]
+    for i in range(len(genomes)):
+        for j in range(i + 1, len(genomes)):
+            assert len(sets[i] & sets[j]) == inter[i, j], (i, j)
+    plain = [len(sp.sketch_parse(pl)) for pl in payloads]
+    if k == m:
+        assert [len(s) for s in sets] != plain and len(sets[0]) == 1     # the phantom keys are there
+    else:
+        assert [len(s) for s in sets] == plain

@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Randomised parity soak on the GPU box: scan (all dense variants) and comparison against the oracle for as long
+as the time budget allows.  Prints the first mismatch with the configuration that produced it.
+usage: python tools/soak.py [seconds=300] [seed=1]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: F401,E402  (before libspsp)
+import supersampler_amd as sp  # noqa: E402
+from oracle import oracle_py as orc  # noqa: E402
+from supersampler_amd import synth  # noqa: E402
+
+COMP = np.zeros(256, np.uint8)
+COMP[[65, 67, 71, 84]] = [84, 71, 67, 65]
+
+
+def random_genome(rng):
+    base = synth.random_genome(rng, int(rng.integers(50, 120_000)))
+    parts = [base]
+    for _ in range(int(rng.integers(0, 5))):
+        kind = rng.integers(0, 6)
+        if kind == 0:
+            parts.append(synth.mutate(rng, base, float(rng.choice([0.001, 0.02, 0.2])))[: int(rng.integers(1, len(base) + 1))])
+        elif kind == 1:
+            parts.append(COMP[base[::-1]][: int(rng.integers(1, len(base) + 1))])
+        elif kind == 2:
+            parts.append(np.full(int(rng.integers(1, 400)), int(rng.choice([65, 67, 71, 84])), np.uint8))
+        elif kind == 3:
+            parts.append(np.tile(synth.random_genome(rng, int(rng.integers(1, 40))), int(rng.integers(2, 80))))
+        elif kind == 4:
+            a = int(rng.integers(0, len(base)))
+            parts.append(base[a:a + int(rng.integers(1, 3000))])
+        else:
+            parts.append(synth.random_genome(rng, int(rng.integers(1, 70))))
+    rng.shuffle(parts)
+    genome = np.concatenate(parts)
+    cuts = sorted(set([0, len(genome)] + [int(x) for x in rng.integers(0, len(genome) + 1, size=int(rng.integers(0, 8)))]))
+    return [genome[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    ctx = sp.Context(0)
+    t0 = time.time()
+    n_scan = n_cmp = 0
+    modes = [sp.SPSP_SCAN_DEFAULT, sp.SPSP_SCAN_DIRECT_HASH, sp.SPSP_SCAN_LDS_FILTER, sp.SPSP_SCAN_PAIR_FILTER]
+    while time.time() - t0 < budget:
+        m = int(rng.choice([3, 5, 7, 9, 11, 13, 15]))
+        k = int(rng.choice([x for x in range(max(m, 5) | 1, 64, 2)]))
+        s = float(rng.choice([1.0, 1.2, 2, 3, 7, 20, 100, 1000, 5000]))
+        recs = random_genome(rng)
+        bases, offs = synth.concat_records(recs)
+        mode = int(rng.choice(modes))
+        p = sp.make_params(k, m, s, flags=mode)
+        got = ctx.scan(p, bases, offs)
+        want, _ = orc.scan(k, m, p.threshold, bases, offs)
+        ok = len(got) == len(want) and all((np.asarray(got[f]) == np.asarray(want[f])).all() for f in ("rec", "minimizer", "start", "len", "rev"))
+        if not ok:
+            print("SCAN MISMATCH k=%d m=%d s=%g mode=%d n=%d records=%d got=%d want=%d" % (k, m, s, mode, len(bases), len(recs), len(got), len(want)))
+            np.save(os.path.join(ROOT, "gpurun_out", "soak_bases.npy"), bases)
+            np.save(os.path.join(ROOT, "gpurun_out", "soak_offs.npy"), offs)
+            sys.exit(1)
+        n_scan += 1
+        if n_scan % 8 == 0:      # a comparison problem from sketches of related genomes
+            n = int(rng.integers(2, 40))
+            anc = synth.random_genome(rng, int(rng.integers(2000, 30_000)))
+            payloads = []
+            for i in range(n):
+                g = anc if rng.random() < 0.2 else synth.mutate(rng, anc, float(rng.choice([0.0, 0.005, 0.05])))
+                if rng.random() < 0.1:
+                    g = synth.random_genome(rng, int(rng.integers(10, 3000)))
+                payloads.append(orc.sketch_fasta(synth.to_fasta(g, "g%d" % i, n_records=int(rng.integers(1, 4))), k, m, max(s, 1.0))[0])
+            nq = n if rng.random() < 0.6 else int(rng.integers(1, n + 1))
+            want_inter, want_card, _, _ = orc.compare(payloads, n_query=nq)
+            sketches = sp.sketches_from_payloads(payloads)     # incl. the merge's first-read rule for empty sketches
+            inter, card = ctx.compare(sketches, n_query=nq)
+            if not ((inter[:nq] == want_inter[:nq]).all() and [int(c) for c in card] == [int(c) for c in want_card]):   # printed rows
+                print("COMPARE MISMATCH k=%d m=%d s=%g n=%d nq=%d" % (k, m, s, n, nq))
+                bad = np.argwhere(inter[:nq] != want_inter[:nq])
+                print("cells:", [(int(a), int(b), int(inter[a, b]), int(want_inter[a, b])) for a, b in bad[:10]])
+                print("card got/want:", [(i, int(card[i]), int(want_card[i])) for i in range(n) if int(card[i]) != int(want_card[i])][:10])
+                import pickle
+                pickle.dump({"payloads": payloads, "nq": nq, "k": k, "m": m}, open(os.path.join(ROOT, "gpurun_out", "soak_cmp.pkl"), "wb"))
+                sys.exit(1)
+            n_cmp += 1
+    print("soak ok: %d scans, %d comparisons in %.0f s" % (n_scan, n_cmp, time.time() - t0))
+
+
+if __name__ == "__main__":
+    main()
