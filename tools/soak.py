@@ -43,12 +43,37 @@ def random_genome(rng):
     return [genome[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
 
 
+def random_fasta_text(rng):
+    """FASTA text with everything getLineFasta / clean_dna have to cope with"""
+    out = []
+    repeat = synth.random_genome(rng, int(rng.integers(20, 400)))
+    for _ in range(int(rng.integers(1, 120))):
+        r = rng.random()
+        if r < 0.08:
+            out.append(b">" + bytes(rng.integers(32, 127, size=int(rng.integers(0, 40))).astype(np.uint8)))
+        elif r < 0.10:
+            out.append(b"")
+        elif r < 0.12:
+            out.append(b"\xff" + bytes(synth.random_genome(rng, int(rng.integers(0, 30)))))
+        else:
+            L = int(rng.integers(1, 300))
+            line = (repeat[:L] if rng.random() < 0.3 and L <= len(repeat) else synth.random_genome(rng, L)).copy()
+            if rng.random() < 0.3:
+                line[rng.integers(0, L, size=max(1, L // 10))] = ord("N")
+            if rng.random() < 0.3:
+                line = np.frombuffer(bytes(line).lower(), dtype=np.uint8).copy()
+            if rng.random() < 0.1:
+                line = np.concatenate([line, np.frombuffer(b"\r", np.uint8)])
+            out.append(bytes(line))
+    return b"\n".join(out) + (b"\n" if rng.random() < 0.5 else b"")
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     ctx = sp.Context(0)
     t0 = time.time()
-    n_scan = n_cmp = 0
+    n_scan = n_cmp = n_sk = 0
     modes = [sp.SPSP_SCAN_DEFAULT, sp.SPSP_SCAN_DIRECT_HASH, sp.SPSP_SCAN_LDS_FILTER, sp.SPSP_SCAN_PAIR_FILTER]
     while time.time() - t0 < budget:
         m = int(rng.choice([3, 5, 7, 9, 11, 13, 15]))
@@ -67,6 +92,17 @@ def main():
             np.save(os.path.join(ROOT, "gpurun_out", "soak_offs.npy"), offs)
             sys.exit(1)
         n_scan += 1
+        if n_scan % 5 == 0:      # whole sketch payload through the GPU ingest path, bytes vs the oracle
+            text = random_fasta_text(rng)
+            ab = int(rng.choice([1, 1, 2, 3]))
+            s2 = max(s, 1.0) if rng.random() < 0.7 else float(rng.choice([1.0, 2.0, 4.0]))
+            got_pl, got_st = ctx.sketch_text(text, k, m, s2, ab, mode)
+            want_pl, want_st = orc.sketch_fasta(text, k, m, float(np.float32(s2)), ab)
+            if got_pl != want_pl:
+                print("SKETCH MISMATCH k=%d m=%d s=%g ab=%d mode=%d text=%d bytes" % (k, m, s2, ab, mode, len(text)))
+                open(os.path.join(ROOT, "gpurun_out", "soak_text.fa"), "wb").write(text)
+                sys.exit(1)
+            n_sk += 1
         if n_scan % 8 == 0:      # a comparison problem from sketches of related genomes
             n = int(rng.integers(2, 40))
             anc = synth.random_genome(rng, int(rng.integers(2000, 30_000)))
@@ -89,7 +125,7 @@ def main():
                 pickle.dump({"payloads": payloads, "nq": nq, "k": k, "m": m}, open(os.path.join(ROOT, "gpurun_out", "soak_cmp.pkl"), "wb"))
                 sys.exit(1)
             n_cmp += 1
-    print("soak ok: %d scans, %d comparisons in %.0f s" % (n_scan, n_cmp, time.time() - t0))
+    print("soak ok: %d scans, %d sketch payloads, %d comparisons in %.0f s" % (n_scan, n_sk, n_cmp, time.time() - t0))
 
 
 if __name__ == "__main__":
