@@ -10,6 +10,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: F401,E402  (before libspsp)
 import supersampler_amd as sp  # noqa: E402
 from oracle import oracle_py as orc  # noqa: E402
@@ -73,7 +74,7 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     ctx = sp.Context(0)
     t0 = time.time()
-    n_scan = n_cmp = n_sk = 0
+    n_scan = n_cmp = n_sk = n_ex = 0
     modes = [sp.SPSP_SCAN_DEFAULT, sp.SPSP_SCAN_DIRECT_HASH, sp.SPSP_SCAN_LDS_FILTER, sp.SPSP_SCAN_PAIR_FILTER]
     while time.time() - t0 < budget:
         m = int(rng.choice([3, 5, 7, 9, 11, 13, 15]))
@@ -103,6 +104,33 @@ def main():
                 open(os.path.join(ROOT, "gpurun_out", "soak_text.fa"), "wb").write(text)
                 sys.exit(1)
             n_sk += 1
+        if n_scan % 40 == 0:     # key-partitioned exchange with simulated ranks + CSV text, vs set algebra / the oracle printer
+            import test_exchange as tx
+            world, n_local = int(rng.integers(1, 9)), int(rng.integers(1, 12))
+            use_hi = bool(rng.integers(0, 2))
+            sets = tx.make_sets(rng, world * n_local, use_hi, universe_size=int(rng.integers(60, 3000)))
+            per_rank = [sets[r * n_local:(r + 1) * n_local] for r in range(world)]
+            biggest = max(1, max(sum(len(x) for x in pr) for pr in per_rank))
+            cap = biggest if world == 1 else int(biggest / world * 1.5) + 64
+            try:
+                _, total = tx.exchange_and_compare(ctx, 63 if use_hi else 31, per_rank, cap)
+            except sp.SpspError as e:
+                if e.code != sp.ERR_OVERFLOW:
+                    raise
+                _, total = tx.exchange_and_compare(ctx, 63 if use_hi else 31, per_rank, biggest + 64)
+            nt = world * n_local
+            want_t = np.array([[len(sets[i] & sets[j]) if j > i else 0 for j in range(nt)] for i in range(nt)])
+            if not (total == want_t).all():
+                print("EXCHANGE MISMATCH world=%d n_local=%d use_hi=%d" % (world, n_local, use_hi))
+                sys.exit(1)
+            cardx = np.array([len(x) for x in sets], dtype=np.uint64)
+            names = ["s%d.gz" % i for i in range(nt)]
+            prec, thr, nqx = int(rng.integers(0, 13)), float(rng.choice([0.0, 0.0, 0.01, 0.3])), int(rng.integers(1, nt + 1))
+            for jac in (True, False):
+                if sp.csv(jac, names, total.astype(np.uint32), cardx, nqx, prec, thr) != orc.csv(jac, names, total.astype(np.uint32), cardx, nqx, prec, thr):
+                    print("CSV MISMATCH jac=%d prec=%d thr=%g nq=%d" % (jac, prec, thr, nqx))
+                    sys.exit(1)
+            n_ex += 1
         if n_scan % 8 == 0:      # a comparison problem from sketches of related genomes
             n = int(rng.integers(2, 40))
             anc = synth.random_genome(rng, int(rng.integers(2000, 30_000)))
@@ -125,7 +153,7 @@ def main():
                 pickle.dump({"payloads": payloads, "nq": nq, "k": k, "m": m}, open(os.path.join(ROOT, "gpurun_out", "soak_cmp.pkl"), "wb"))
                 sys.exit(1)
             n_cmp += 1
-    print("soak ok: %d scans, %d sketch payloads, %d comparisons in %.0f s" % (n_scan, n_sk, n_cmp, time.time() - t0))
+    print("soak ok: %d scans, %d sketch payloads, %d comparisons, %d exchanges + CSV pairs in %.0f s" % (n_scan, n_sk, n_cmp, n_ex, time.time() - t0))
 
 
 if __name__ == "__main__":
