@@ -358,7 +358,7 @@ def main():
                          "algorithmic_bytes_per_launch": int(d_bases.numel())},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(recs, payloads, p)
+            out["cpu_baseline"] = cpu_baseline(recs, payloads, p, int(n_out), d_inter)
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
@@ -380,17 +380,18 @@ def pmc_traffic(args):
         return None
 
 
-def cpu_baseline(recs, payloads, p):
+def cpu_baseline(recs, payloads, p, gpu_superkmers, d_inter):
     """The reference-algorithm CPU restatement (oracle/) timed on this host, rank 0, N=1 only.
-    Checker code used as a reported baseline -- never on the product path."""
+    Checker code used as a reported baseline -- never on the product path.  While it is at it, it checks the
+    timed GPU step against it: super-k-mers emitted over the same records, pair matrix over the same sketches."""
     from oracle import oracle_py as orc
-    budget, spent, kmers, used = 12.0, 0.0, 0, 0
+    budget, spent, kmers, used, emitted = 12.0, 0.0, 0, 0, 0
     for r in recs:  # bounded sample: whole records until ~12 s of single-thread CPU work
         if spent >= budget:
             break
         b, o = synth.concat_records([r])
-        sec, km, _ = orc.scan_timed(K, M, p.threshold, b, o)
-        spent += sec; kmers += km; used += 1
+        sec, km, nem = orc.scan_timed(K, M, p.threshold, b, o)
+        spent += sec; kmers += km; used += 1; emitted += nem
     # the reference parallelises over FILES with OpenMP (SubSampler.cpp:771): same thing with host threads
     # (ctypes releases the GIL), whole records as work items, bounded the same way
     import concurrent.futures as cf
@@ -405,8 +406,11 @@ def cpu_baseline(recs, payloads, p):
     all_cores = {"value": sum(r[1] for r in res) / wall if wall > 0 else None, "cores": cores,
                  "sample": "same records, one record per task over %d host threads, %.2f s wall" % (cores, wall)}
     n = len(payloads)
-    _, _, csec = orc.compare(payloads, timed=True)  # the reference comparator is single-threaded too
-    return {"value": kmers / spent if spent > 0 else None, "unit": "k-mers hashed/s", "cores": 1, "kind": "port",
+    want_inter, _, csec = orc.compare(payloads, timed=True)  # the reference comparator is single-threaded too
+    parity = {"pair_matrix": bool((d_inter.cpu().numpy().astype(np.uint32) == want_inter).all())}
+    if used == len(recs):
+        parity["superkmers_per_step"] = bool(emitted == gpu_superkmers)
+    return {"parity_vs_oracle": parity, "value": kmers / spent if spent > 0 else None, "unit": "k-mers hashed/s", "cores": 1, "kind": "port",
             "sample": "oracle scan loop (SubSampler.cpp:357-455 restated), single thread, first %d of %d records "
                       "of the same workload, %.1f s" % (used, len(recs), spent),
             "all_cores": all_cores,

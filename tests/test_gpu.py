@@ -136,6 +136,23 @@ def test_scan_dense_selection_many_hits(ctx):
         _assert_stream_equal(got, want)
 
 
+def test_scan_40_mbp_stream_equals_oracle(ctx):
+    """40 Mbp in 23 records: 2 441 tiles, i.e. several scan segments, tens of thousands of waves in the expand pass and
+    (at s = 5) more than 64 chunk sums in the write pass -- the full stream against the oracle, not just invariants."""
+    rng = np.random.default_rng(4040)
+    lens = [int(x) for x in rng.integers(20, 4_000_000, size=22)] + [31]
+    total = 40_000_000
+    lens = [max(1, int(x * (total - 31) / sum(lens[:-1]))) for x in lens[:-1]] + [31]
+    bases, offs = synth.concat_records([synth.random_genome(rng, n) for n in lens])
+    for k, m, s, mode in [(31, 11, 1000, sp.SPSP_SCAN_DEFAULT), (31, 11, 50, sp.SPSP_SCAN_PAIR_FILTER), (31, 11, 5, sp.SPSP_SCAN_DEFAULT),
+                          (63, 15, 100, sp.SPSP_SCAN_DEFAULT), (21, 9, 30, sp.SPSP_SCAN_DIRECT_HASH)]:
+        p = sp.make_params(k, m, s, flags=mode)
+        got = ctx.scan(p, bases, offs)
+        want = _oracle_stream(k, m, p.threshold, bases, offs)
+        assert len(want) > 1000
+        _assert_stream_equal(got, want)
+
+
 def test_scan_edge_inputs(ctx):
     p = sp.make_params(31, 11, 10)
     assert len(ctx.scan(p, np.zeros(0, np.uint8), np.zeros(1, np.uint64))) == 0
