@@ -80,7 +80,14 @@ def main():
         m = int(rng.choice([3, 5, 7, 9, 11, 13, 15]))
         k = int(rng.choice([x for x in range(max(m, 5) | 1, 64, 2)]))
         s = float(rng.choice([1.0, 1.2, 2, 3, 7, 20, 100, 1000, 5000]))
-        recs = random_genome(rng)
+        if n_scan % 60 == 59:    # now and then a large input: many tiles, several scan segments, many chunk sums
+            big = int(rng.integers(17_000_000, 60_000_000))
+            cuts = sorted(set([0, big] + [int(x) for x in rng.integers(0, big, size=int(rng.integers(0, 30)))]))
+            recs = [synth.random_genome(rng, b - a) for a, b in zip(cuts[:-1], cuts[1:])]
+            if s < 3:
+                s = float(rng.choice([3, 10, 100, 1000]))     # keep the oracle's stream (and the run) small
+        else:
+            recs = random_genome(rng)
         bases, offs = synth.concat_records(recs)
         mode = int(rng.choice(modes))
         p = sp.make_params(k, m, s, flags=mode)
