@@ -414,7 +414,8 @@ int spsp_sketch_parse_host(const uint8_t* payload, uint64_t len, uint32_t* k_out
     const std::string header((const char*)payload, nl - payload);
     const long skm = strtol(header.c_str(), &endp, 10);
     const long mm = strtol(endp, &endp, 10);
-    if (skm <= 0 || mm <= 0 || mm > 15 || (skm + mm) / 2 > 63 || (skm + mm) / 2 < mm) { set_error("bad sketch header '%s'", header.c_str()); return SPSP_ERR_FORMAT; }
+    // (range checks first: strtol saturates at LONG_MAX on garbage and the sums below must not overflow)
+    if (skm <= 0 || skm > 126 || mm <= 0 || mm > 15 || (skm + mm) / 2 > 63 || (skm + mm) / 2 < mm) { set_error("bad sketch header '%.60s'", header.c_str()); return SPSP_ERR_FORMAT; }
     const uint32_t m = (uint32_t)mm, k = (uint32_t)((skm + mm) / 2), half = (uint32_t)((skm - mm) / 2);
     const u128 kmask = (((u128)1) << (2 * k)) - 1;
     struct Key { uint32_t mn; uint64_t hi, lo; };
