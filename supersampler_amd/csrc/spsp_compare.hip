@@ -658,6 +658,8 @@ static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t*
     if (n == 0) return 1;
     if (n > 65535) { set_error("at most 65535 sketches (the reference's uint32 pair key, Comparator.h:26)"); return SPSP_ERR_ARG; }
     if (row_stride == 0 || row_first >= row_stride) { set_error("bad row partition %u/%u", row_first, row_stride); return SPSP_ERR_ARG; }
+    for (uint32_t i = 0; i < n; ++i)   // grids and ranges are derived from these: a decreasing offset must not reach a kernel
+        if (h_sk_off[i + 1] < h_sk_off[i]) { set_error("sketch offsets must be non-decreasing (sketch %u)", i); return SPSP_ERR_ARG; }
     const uint64_t S = h_sk_off[n];
     if (S == 0) return 1;
     if (k > 32 && !d_hi) { set_error("k=%u needs kmer_hi", k); return SPSP_ERR_ARG; }
@@ -984,6 +986,8 @@ int partition_keys_impl(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min, const 
     if (n == 0 || n > 65535) { set_error("1..65535 sketches per rank"); return SPSP_ERR_ARG; }
     if (parts == 0 || parts > kMaxParts) { set_error("1..%u destinations", kMaxParts); return SPSP_ERR_ARG; }
     if (cap == 0) { set_error("slot_cap must be positive"); return SPSP_ERR_ARG; }
+    for (uint32_t i = 0; i < n; ++i)
+        if (h_sk_off[i + 1] < h_sk_off[i]) { set_error("sketch offsets must be non-decreasing (sketch %u)", i); return SPSP_ERR_ARG; }
     if (k > 32 && !d_hi && h_sk_off[n] > 0) { set_error("k=%u needs kmer_hi", k); return SPSP_ERR_ARG; }   // (no keys: nothing to read)
     if (((uintptr_t)d_slots & 7u) != 0) { set_error("d_slots must be 8-byte aligned"); return SPSP_ERR_ARG; }
     if (h_sk_off[n] > 0xfffffff0ull) { set_error("too many sketch k-mers for one call"); return SPSP_ERR_OVERFLOW; }

@@ -200,6 +200,11 @@ def test_malformed_slots_are_rejected(ctx):
         ctx.compare_slots_device(k, 0, world, n_local, cap, d_inter.data_ptr())
     with pytest.raises(sp.SpspError):
         ctx.partition_keys_device(k, 1, 1, None, np.zeros(4, np.uint64), 3, 65, cap, 8)     # too many destinations
+    bad_off = np.array([0, 50, 20, 60], np.uint64)                                          # decreasing offsets never reach a kernel
+    with pytest.raises(sp.SpspError):
+        ctx.partition_keys_device(k, 8, 8, None, bad_off, 3, 2, cap, 8)
+    with pytest.raises(sp.SpspError):
+        ctx.compare_device(k, 8, 8, None, bad_off, 3, 0, 1, d_inter.data_ptr())
 
 
 def test_partitioned_compare_collision_retry():
