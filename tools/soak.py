@@ -76,7 +76,11 @@ def main():
     t0 = time.time()
     n_scan = n_cmp = n_sk = n_ex = 0
     modes = [sp.SPSP_SCAN_DEFAULT, sp.SPSP_SCAN_DIRECT_HASH, sp.SPSP_SCAN_LDS_FILTER, sp.SPSP_SCAN_PAIR_FILTER]
+    t_report = t0
     while time.time() - t0 < budget:
+        if time.time() - t_report > 45:      # a long run must keep talking (the GPU pool kills silent commands)
+            print("  ... %d scans, %d sketch payloads, %d comparisons, %d exchanges after %.0f s" % (n_scan, n_sk, n_cmp, n_ex, time.time() - t0), flush=True)
+            t_report = time.time()
         m = int(rng.choice([3, 5, 7, 9, 11, 13, 15]))
         k = int(rng.choice([x for x in range(max(m, 5) | 1, 64, 2)]))
         s = float(rng.choice([1.0, 1.2, 2, 3, 7, 20, 100, 1000, 5000]))
