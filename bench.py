@@ -175,8 +175,9 @@ def main():
 
     scan_args = (p, d_bases.data_ptr(), d_bases.numel(), d_off.data_ptr(), len(recs))
 
-    def queue_step(sl, prev):
-        """queue one whole step on slot sl without waiting for anything; on the GPU it starts behind slot prev"""
+    def queue_step(sl, prev, nxt=None):
+        """queue one whole step on slot sl without waiting for anything; on the GPU it starts behind slot prev.
+        nxt = the slot of the following step (its key exchange is started from here, behind this dense pass)"""
         # stream A: behind the previous step's scan.  The previous comparison is all but done by then (its last
         # kernel may overlap the start of this dense pass); a full spsp_wait_stream(prev.cmp) costs more in
         # cross-queue latency than that overlap (BENCH_STRICT_ORDER=1 adds it).
@@ -190,15 +191,24 @@ def main():
                                         sl.d_inter.data_ptr())                                             # stream B
             return
         with torch.cuda.stream(sl.stream_b):              # torch ops and RCCL order themselves against stream B
-            if exchange_kind == "slots":                  # key partition + all-to-all, queued while the dense pass runs
-                sl.handle = sl.exchange.begin(d_my_min.data_ptr(), d_my_lo.data_ptr(), None, my_sk_off)
+            if exchange_kind == "slots":
+                if getattr(sl, "handle", None) is None:   # first steps only: later ones were started a step ahead (below)
+                    sl.handle = sl.exchange.begin(d_my_min.data_ptr(), d_my_lo.data_ptr(), None, my_sk_off)
                 sl.cmp.wait_dense(sl.scan)
                 sl.exchange.end_queue(sl.handle, sl.d_inter)
+                sl.handle = None
             else:
                 g = sl.exchange.exchange(d_my_min, d_my_lo)
                 sl.cmp.wait_dense(sl.scan)
                 sl.cmp.compare_device_begin(K, g.minimizer.data_ptr(), g.kmer_lo.data_ptr(), None, sk_off, n_total, rank,
                                             world, sl.d_inter.data_ptr())
+
+        if exchange_kind == "slots" and nxt is not None and nxt is not sl and getattr(nxt, "handle", None) is None:
+            # the NEXT step's key partition + RCCL all-to-all: behind this step's dense pass (so the dense kernel keeps the
+            # GPU to itself), long before the next dense pass, and behind the comparison still queued on that stream
+            with torch.cuda.stream(nxt.stream_b):
+                nxt.cmp.wait_dense(sl.scan)
+                nxt.handle = nxt.exchange.begin(d_my_min.data_ptr(), d_my_lo.data_ptr(), None, my_sk_off)
 
     def collect_step(sl):
         d_out, n_out = sl.scan.scan_device_end()
@@ -232,7 +242,7 @@ def main():
         for i in range(n):
             sl = slots[i % len(slots)]
             t_a = time.perf_counter()
-            queue_step(sl, pending)                       # step i is on the GPU's queues ...
+            queue_step(sl, pending, slots[(i + 1) % len(slots)] if i + 1 < n else None)   # step i is on the GPU's queues ...
             t_b = time.perf_counter()
             if pending is not None:
                 collect_step(pending)                     # ... before the host waits for step i-1
