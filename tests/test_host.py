@@ -305,10 +305,10 @@ def test_empty_sketches_follow_the_merges_first_read_rule(k, m):
 
 
 def test_host_parsers_under_address_and_ub_sanitizers():
-    """tools/host_asan: spsp_host.cpp compiled with -fsanitize=address,undefined and fed valid and thousands of
+    """tests/tools/host_asan: spsp_host.cpp compiled with -fsanitize=address,undefined and fed valid and thousands of
     randomly corrupted sketch payloads, CSVs, file-of-files and FASTA text: every call returns, none crashes or reads
     out of bounds; the threaded host functions (CSV rows, parallel gzip members) run under ThreadSanitizer (sanitizers
     cannot run on the GPU side of this pool, so the host side is where they run)."""
-    r = subprocess.run([os.path.join(ROOT, "tools", "host_asan", "run.sh"), "2500"], env=dict(os.environ, SPSP_ROOT=ROOT),
+    r = subprocess.run([os.path.join(ROOT, "tests", "tools", "host_asan", "run.sh"), "2500"], env=dict(os.environ, SPSP_ROOT=ROOT),
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "no crash" in r.stdout and "read-back OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])

@@ -3,7 +3,7 @@
 GPU spsp_compare_device timing (+ optional oracle check).  Genomes are shortened and s lowered so that
 each sketch still holds ~L/s ~ 5000 k-mers without generating 5 Gbp.
 
-usage: tools/compare_bench.py [N=1000] [check=1]"""
+usage: tests/tools/compare_bench.py [N=1000] [check=1]"""
 import os
 import sys
 import time
@@ -11,7 +11,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import supersampler_amd as sp  # noqa: E402
 from supersampler_amd import synth  # noqa: E402
 

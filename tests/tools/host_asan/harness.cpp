@@ -2,7 +2,7 @@
 // points it calls are stubbed out): feeds valid sketch payloads, CSVs and FASTA text plus thousands of randomly
 // corrupted variants to the parsers.  Every call must return (OK or an error code) -- never crash, never read out of
 // bounds.  Sanitizers cannot run on the GPU side of this pool, so this is where they run.
-//   build + run: tools/host_asan/run.sh
+//   build + run: tests/tools/host_asan/run.sh
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -13,7 +13,7 @@
 #include <string>
 #include <vector>
 
-#include "../../supersampler_amd/csrc/spsp_internal.h"
+#include "../../../supersampler_amd/csrc/spsp_internal.h"
 
 namespace spsp {
 static thread_local std::string g_err;

@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """Randomised parity soak on the GPU box: scan (all dense variants) and comparison against the oracle for as long
 as the time budget allows.  Prints the first mismatch with the configuration that produced it.
-usage: python tools/soak.py [seconds=300] [seed=1]"""
+usage: python tests/tools/soak.py [seconds=300] [seed=1]"""
 import os
 import sys
 import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: F401,E402  (before libspsp)
