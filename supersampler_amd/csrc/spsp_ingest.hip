@@ -44,6 +44,21 @@ struct ChunkInfo {
     uint32_t drop_after;     // bit j: byte j is '\n' and the line starting at j+1 exists and is a drop line
 };
 
+// Byte-parallel classification (four bytes per register, no per-byte loop):
+//   zero_bytes(v)  0x80 in every byte of v that is zero (exact, no borrow between bytes)
+//   pack_flags(z)  the four 0x80 flags of a word -> 4 bits (byte 0 -> bit 0)
+__device__ __forceinline__ uint32_t zero_bytes(uint32_t v) {
+    return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v | 0x7F7F7F7Fu);
+}
+__device__ __forceinline__ uint32_t pack_flags(uint32_t z) { return (((z >> 7) * 0x01020408u) >> 24) & 0xFu; }   // bits 0,8,16,24 -> 24..27, no carries
+// 0x80 where the byte is one of ACGTacgt: fold the case, look the base of its 2-bit code (c >> 1) & 3 up with one
+// byte permute (A, C, T, G) and compare
+__device__ __forceinline__ uint32_t base_bytes(uint32_t w) {
+    const uint32_t code = (w >> 1) & 0x03030303u;
+    const uint32_t expect = __builtin_amdgcn_perm(0u, 0x47544341u, code);   // selector bytes 0..3 pick 'A','C','T','G'
+    return zero_bytes((w & 0xDFDFDFDFu) ^ expect);
+}
+
 __device__ __forceinline__ ChunkInfo load_chunk(const uint8_t* __restrict__ text, uint64_t n, uint64_t p0) {
     ChunkInfo c;
     c.valid = p0 >= n ? 0u : (uint32_t)((n - p0) < (uint64_t)kCleanChunk ? (n - p0) : (uint64_t)kCleanChunk);
@@ -54,18 +69,29 @@ __device__ __forceinline__ ChunkInfo load_chunk(const uint8_t* __restrict__ text
         c.bytes[0] = c.bytes[1] = c.bytes[2] = c.bytes[3] = 0;
         for (uint32_t j = 0; j < c.valid; ++j) c.bytes[j >> 2] |= (uint32_t)text[p0 + j] << (8 * (j & 3));
     }
-    const uint32_t next = (p0 + kCleanChunk < n) ? text[p0 + kCleanChunk] : 0x100u;   // 0x100: nothing follows
-    c.keep_if_data = 0; c.nl_mask = 0; c.drop_after = 0;
+    const uint32_t in_mask = c.valid >= 16 ? 0xFFFFu : ((1u << c.valid) - 1u);
+    uint32_t keep = 0, nl = 0;
 #pragma unroll
-    for (int j = 0; j < kCleanChunk; ++j) {
-        const uint32_t b = (c.bytes[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-        const bool in = (uint32_t)j < c.valid;
-        if (in && keep_base(b)) c.keep_if_data |= 1u << j;
-        if (in && b == '\n') {
-            c.nl_mask |= 1u << j;
+    for (int d = 0; d < 4; ++d) {
+        keep |= pack_flags(base_bytes(c.bytes[d])) << (4 * d);
+        nl |= pack_flags(zero_bytes(c.bytes[d] ^ 0x0A0A0A0Au)) << (4 * d);
+    }
+    c.keep_if_data = keep & in_mask;
+    c.nl_mask = nl & in_mask;
+    // what follows each newline decides the next line's kind: newlines are rare (one per line), so a loop over them
+    c.drop_after = 0;
+    if (c.nl_mask) {
+        const uint32_t next = (p0 + kCleanChunk < n) ? text[p0 + kCleanChunk] : 0x100u;   // 0x100: nothing follows
+        const uint64_t lo = ((uint64_t)c.bytes[1] << 32) | c.bytes[0], hi = ((uint64_t)c.bytes[3] << 32) | c.bytes[2];
+        uint32_t rem = c.nl_mask;
+        while (rem) {
+            const uint32_t j = __ffs(rem) - 1;
+            rem &= rem - 1;
             uint32_t follow;
-            if (j + 1 < kCleanChunk) follow = (uint32_t)(j + 1) < c.valid ? (c.bytes[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 0xFFu : 0x100u;
-            else follow = next;
+            if (j + 1 < (uint32_t)kCleanChunk) {
+                const uint32_t f = j + 1;
+                follow = f < c.valid ? (uint32_t)((f < 8 ? lo >> (8 * f) : hi >> (8 * (f - 8))) & 0xFFu) : 0x100u;
+            } else follow = next;
             if (follow != 0x100u && is_drop_start(follow)) c.drop_after |= 1u << j;
         }
     }
@@ -80,14 +106,18 @@ __device__ __forceinline__ uint32_t chunk_transform(const ChunkInfo& c) {
     const int last = 31 - __clz(c.nl_mask);
     return 2u | ((c.drop_after >> last) & 1u);
 }
-// bit j set iff byte j survives, given the state (1 = drop line) of the line entering the chunk
+// bit j set iff byte j survives, given the state (1 = drop line) of the line entering the chunk: the bytes between
+// two newlines share their line's state, so the walk is over the (rare) newlines, not over the bytes
 __device__ __forceinline__ uint32_t chunk_keep(const ChunkInfo& c, uint32_t entry_drop) {
-    uint32_t keep = 0, drop = entry_drop;
-#pragma unroll
-    for (int j = 0; j < kCleanChunk; ++j) {
-        if (!drop) keep |= c.keep_if_data & (1u << j);
-        if (c.nl_mask & (1u << j)) drop = (c.drop_after >> j) & 1u;
+    uint32_t keep = 0, drop = entry_drop, from = 0, rem = c.nl_mask;
+    while (rem) {
+        const uint32_t j = __ffs(rem) - 1;
+        rem &= rem - 1;
+        if (!drop) keep |= c.keep_if_data & ((2u << j) - 1u) & ~((1u << from) - 1u);    // bytes from..j
+        drop = (c.drop_after >> j) & 1u;
+        from = j + 1;
     }
+    if (!drop) keep |= c.keep_if_data & ~((1u << from) - 1u) & 0xFFFFu;
     return keep;
 }
 
@@ -139,14 +169,25 @@ __global__ __launch_bounds__(kCleanThreads) void k_clean_tiles(const uint8_t* __
     // lanes before the tile's first newline inherit the (still unknown) entry state of the tile
     const uint32_t fixed = pre ? __popc(chunk_keep(c, pre & 1u)) : __popc(chunk_keep(c, 1u));
     const uint32_t extra = pre ? 0u : __popc(chunk_keep(c, 0u)) - fixed;
-    uint32_t tot_fixed, tot_extra, tot_hdr;
-    block_scan_add(fixed, s_wave, &tot_fixed);
-    block_scan_add(extra, s_wave, &tot_extra);
-    block_scan_add(__popc(c.drop_after), s_wave, &tot_hdr);
-    if (threadIdx.x == 0) tiles[blockIdx.x] = TileSummary{tile_t, tot_fixed, tot_extra, tot_hdr};
+    // only the three totals are needed: one packed 64-bit reduction (each count fits in 20 bits)
+    unsigned long long packed = (unsigned long long)fixed | ((unsigned long long)extra << 20) |
+                                ((unsigned long long)__popc(c.drop_after) << 40);
+#pragma unroll
+    for (int d = 32; d; d >>= 1) packed += __shfl_xor(packed, d);
+    __shared__ unsigned long long s_tot[kCleanThreads / 64];
+    if ((threadIdx.x & 63) == 0) s_tot[threadIdx.x >> 6] = packed;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long all = 0;
+        for (int w = 0; w < kCleanThreads / 64; ++w) all += s_tot[w];
+        tiles[blockIdx.x] = TileSummary{tile_t, (uint32_t)(all & 0xFFFFFu), (uint32_t)((all >> 20) & 0xFFFFFu), (uint32_t)(all >> 40)};
+    }
 }
 
-// one workgroup: entry state, output offset and record offset of every tile; totals
+// one workgroup: entry state, output offset and record offset of every tile; totals.  A lane owns kScanTiles
+// consecutive tiles per round (composed locally, then one workgroup scan over the lanes), so a round covers
+// 1024 * kScanTiles tiles and a 200 MB text needs a dozen rounds.
+constexpr int kScanTiles = 4;
 __global__ __launch_bounds__(1024) void k_clean_scan(const TileSummary* __restrict__ tiles, uint64_t n_tiles,
                                                     uint32_t* __restrict__ entry_drop, uint64_t* __restrict__ out_off,
                                                     uint32_t* __restrict__ rec_base, uint64_t* __restrict__ totals) {
@@ -159,12 +200,17 @@ __global__ __launch_bounds__(1024) void k_clean_scan(const TileSummary* __restri
     const uint32_t t = threadIdx.x, lane = t & 63, wid = t >> 6;
     if (t == 0) { c_t = 3u; c_k = 0; c_h = 1; }   // the file starts inside a drop line (line 0), which is record 0
     __syncthreads();
-    for (uint64_t base = 0; base < n_tiles; base += 1024) {
-        const uint64_t i = base + t;
-        TileSummary me = {0, 0, 0, 0};
-        if (i < n_tiles) me = tiles[i];
-        // inclusive scan of transforms
-        uint32_t x = me.transform;
+    for (uint64_t base = 0; base < n_tiles; base += 1024ull * kScanTiles) {
+        const uint64_t i0 = base + (uint64_t)t * kScanTiles;
+        TileSummary me[kScanTiles];
+        uint32_t tl = 0;                                    // transform of this lane's tiles
+#pragma unroll
+        for (int u = 0; u < kScanTiles; ++u) {
+            me[u] = (i0 + u < n_tiles) ? tiles[i0 + u] : TileSummary{0, 0, 0, 0};
+            tl = compose(tl, me[u].transform);
+        }
+        // inclusive scan of the lanes' transforms
+        uint32_t x = tl;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const uint32_t y = __shfl_up(x, d);
@@ -176,10 +222,20 @@ __global__ __launch_bounds__(1024) void k_clean_scan(const TileSummary* __restri
         for (uint32_t w = 0; w < wid; ++w) pre = compose(pre, s_t[w]);
         uint32_t excl = __shfl_up(x, 1);
         if (lane == 0) excl = 0;
-        const uint32_t entry = compose(pre, excl) & 1u;      // always a constant: the carry starts as one
-        const unsigned long long keep = (unsigned long long)me.keep_fixed + (entry ? 0u : me.keep_if_data);
-        unsigned long long kx = keep;
-        uint32_t hx = me.headers;
+        uint32_t state = compose(pre, excl);                // always a constant: the carry starts as one
+        // entry state of each of the lane's tiles, their survivor counts, the lane's sums
+        uint32_t entry[kScanTiles];
+        unsigned long long keep[kScanTiles], ksum = 0;
+        uint32_t hsum = 0;
+#pragma unroll
+        for (int u = 0; u < kScanTiles; ++u) {
+            entry[u] = state & 1u;
+            keep[u] = (unsigned long long)me[u].keep_fixed + (entry[u] ? 0u : me[u].keep_if_data);
+            ksum += keep[u]; hsum += me[u].headers;
+            state = compose(state, me[u].transform);
+        }
+        unsigned long long kx = ksum;
+        uint32_t hx = hsum;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const unsigned long long ky = __shfl_up(kx, d);
@@ -194,7 +250,13 @@ __global__ __launch_bounds__(1024) void k_clean_scan(const TileSummary* __restri
             if (w < wid) { kpre += s_k[w]; hpre += s_h[w]; }
             kall += s_k[w]; hall += s_h[w]; tall = compose(tall, s_t[w]);
         }
-        if (i < n_tiles) { entry_drop[i] = entry; out_off[i] = kpre + kx - keep; rec_base[i] = hpre + hx - me.headers; }
+        unsigned long long ko = kpre + kx - ksum;
+        uint32_t ho = hpre + hx - hsum;
+#pragma unroll
+        for (int u = 0; u < kScanTiles; ++u) {
+            if (i0 + u < n_tiles) { entry_drop[i0 + u] = entry[u]; out_off[i0 + u] = ko; rec_base[i0 + u] = ho; }
+            ko += keep[u]; ho += me[u].headers;
+        }
         __syncthreads();
         if (t == 0) { c_t = compose(c_t, tall); c_k += kall; c_h += hall; }
         __syncthreads();
@@ -208,26 +270,66 @@ __global__ __launch_bounds__(kCleanThreads) void k_clean_write(const uint8_t* __
                                                               const uint32_t* __restrict__ rec_base,
                                                               uint8_t* __restrict__ bases, uint64_t* __restrict__ rec_off) {
     __shared__ uint32_t s_wave[kCleanThreads / 64];
-    __shared__ uint8_t s_out[kCleanTile];
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[kCleanTile + 16];
     const uint64_t p0 = (uint64_t)blockIdx.x * kCleanTile + (uint64_t)threadIdx.x * kCleanChunk;
     const ChunkInfo c = load_chunk(text, n, p0);
     uint32_t tile_t;
     const uint32_t pre = block_scan_transform(chunk_transform(c), s_wave, &tile_t);
     const uint32_t entry = pre ? (pre & 1u) : entry_drop[blockIdx.x];
     const uint32_t keep = chunk_keep(c, entry);
-    uint32_t tile_keep, tile_hdr;
-    const uint32_t koff = block_scan_add(__popc(keep), s_wave, &tile_keep);
-    const uint32_t hoff = block_scan_add(__popc(c.drop_after), s_wave, &tile_hdr);
+    // survivors and record starts before this lane: one scan over the packed pair of counts
+    uint32_t tile_both;
+    const uint32_t both = block_scan_add(__popc(keep) | (__popc(c.drop_after) << 16), s_wave, &tile_both);
+    const uint32_t koff = both & 0xFFFFu, hoff = both >> 16, tile_keep = tile_both & 0xFFFFu;
     const uint64_t obase = out_off[blockIdx.x];
-    // survivors -> LDS in order, record starts -> rec_off
+    // survivors -> LDS in order, shifted so that LDS offset and global address agree modulo 16: the tile then
+    // leaves as aligned 16-byte stores; record starts -> rec_off
+    const uint32_t sh = (uint32_t)(obase & 15u);
     uint32_t at = koff, hr = rec_base[blockIdx.x] + hoff;
-#pragma unroll
-    for (int j = 0; j < kCleanChunk; ++j) {
-        if (keep & (1u << j)) s_out[at++] = (uint8_t)keep_base((c.bytes[j >> 2] >> (8 * (j & 3))) & 0xFFu);
-        if (c.drop_after & (1u << j)) rec_off[hr++] = obase + at;   // the record begins where the next survivor will land
+    uint8_t* dst = s_out + sh + at;
+    const uint64_t lo = (((uint64_t)c.bytes[1] << 32) | c.bytes[0]) & 0xDFDFDFDFDFDFDFDFull;   // survivors are ACGTacgt:
+    const uint64_t hi = (((uint64_t)c.bytes[3] << 32) | c.bytes[2]) & 0xDFDFDFDFDFDFDFDFull;   // clearing bit 5 upper-cases them
+    if (keep == 0xFFFFu && !c.drop_after) {
+        // four lanes out of five: the whole chunk survives -- one (unaligned) 16-byte LDS store
+        const uint64_t both[2] = {lo, hi};
+        __builtin_memcpy(dst, both, 16);
+    } else if (c.valid == kCleanChunk && __popc(keep) == 15 && !c.drop_after) {
+        // most of the rest: one byte (the newline) goes -- close the gap in registers, store 8 + 4 + 2 + 1 bytes
+        const uint32_t j = __ffs(~keep & 0xFFFFu) - 1;
+        uint64_t l2 = lo, h2 = hi >> 8;
+        if (j < 8) {
+            const uint64_t m = (1ull << (8 * j)) - 1ull;
+            l2 = (lo & m) | (((lo >> 8) | (hi << 56)) & ~m);
+        } else {
+            const uint64_t m = (1ull << (8 * (j - 8))) - 1ull;
+            h2 = (hi & m) | ((hi >> 8) & ~m);
+        }
+        const uint32_t h4 = (uint32_t)h2;
+        const uint16_t h2b = (uint16_t)(h2 >> 32);
+        __builtin_memcpy(dst, &l2, 8);
+        __builtin_memcpy(dst + 8, &h4, 4);
+        __builtin_memcpy(dst + 12, &h2b, 2);
+        dst[14] = (uint8_t)(h2 >> 48);
+    } else {
+        uint32_t todo = keep | c.drop_after;
+        while (todo) {                                  // header lines, N runs, the end of the text: byte by byte
+            const uint32_t j = __ffs(todo) - 1;
+            todo &= todo - 1;
+            if (keep & (1u << j)) s_out[sh + at++] = (uint8_t)((j < 8 ? lo >> (8 * j) : hi >> (8 * (j - 8))) & 0xFFu);
+            if (c.drop_after & (1u << j)) rec_off[hr++] = obase + at;   // the record begins where the next survivor will land
+        }
     }
     __syncthreads();
-    for (uint32_t x = threadIdx.x; x < tile_keep; x += kCleanThreads) bases[obase + x] = s_out[x];
+    const uint32_t end = sh + tile_keep;                // LDS range [sh, end) holds this tile's output
+    uint8_t* gbase = bases + (obase - sh);              // 16-byte aligned
+    for (uint32_t g = threadIdx.x; g * 16 < end; g += kCleanThreads) {
+        const uint32_t lo = g * 16, hi = lo + 16;
+        if (lo >= sh && hi <= end) {
+            *reinterpret_cast<uint4*>(gbase + lo) = *reinterpret_cast<const uint4*>(s_out + lo);
+        } else {                                        // first / last group of the tile: shared with the neighbours
+            for (uint32_t x = lo < sh ? sh : lo; x < (hi < end ? hi : end); ++x) gbase[x] = s_out[x];
+        }
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) rec_off[0] = 0;
 }
 
