@@ -445,6 +445,12 @@ def test_gpu_ingest_matches_oracle(ctx):
     texts.append(synth.to_fasta(synth.random_genome(rng, 300_000), "g", n_records=3))
     texts.append(b">x\n" + bytes(synth.random_genome(rng, 4096 * 3 - 3)))          # newline exactly at tile seams
     texts.append(b"A" * 4095 + b"\n>" + b"C" * 4094 + b"\nG" * 3000)
+    # 38 MB: more than two rounds of the single-workgroup tile scan (4 096 tiles x 4 tiles per lane per round), with
+    # lower case, N runs and headers sprinkled in
+    big = np.frombuffer(synth.to_fasta(synth.random_genome(rng, 37_000_000), "big", n_records=7), dtype=np.uint8).copy()
+    for a in rng.integers(0, len(big) - 200, size=2000):
+        big[a:a + int(rng.integers(1, 150))] = ord("N") if rng.random() < 0.5 else ord("a")
+    texts.append(bytes(big))
     for text in texts:
         want_b, want_o = orc.clean_fasta(text)
         d = torch.from_numpy(np.frombuffer(text + b"\0" * 16, dtype=np.uint8).copy()).cuda()
