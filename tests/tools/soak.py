@@ -107,7 +107,7 @@ def main():
         if n_scan % 5 == 0:      # whole sketch payload through the GPU ingest path, bytes vs the oracle
             text = random_fasta_text(rng)
             ab = int(rng.choice([1, 1, 2, 3]))
-            s2 = max(s, 1.0) if rng.random() < 0.7 else float(rng.choice([1.0, 2.0, 4.0]))
+            s2 = float(np.float32(max(s, 1.0) if rng.random() < 0.7 else float(rng.choice([1.0, 2.0, 4.0]))))   # the CLI parses -s with stof
             got_pl, got_st = ctx.sketch_text(text, k, m, s2, ab, mode)
             want_pl, want_st = orc.sketch_fasta(text, k, m, float(np.float32(s2)), ab)
             if got_pl != want_pl:
