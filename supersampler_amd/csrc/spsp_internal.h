@@ -55,12 +55,17 @@ enum { kEvDense = 0, kEvScan = 1, kEvAccumulate = 2, kEvCompare = 3, kEvKinds = 
 namespace spsp {
 // a scan queued by scan_begin_impl and not yet collected by scan_end_impl
 struct ScanJob {
-    bool pending = false, empty = false, redo_dense = true;
+    bool pending = false, empty = false;
+    int redo_from = 0;           // first stage the next attempt runs: 0 dense, 1 compact (lists intact), 2 write pass
+    bool use_bitmap = false;     // hit bitmap + k_expand (dense selections, list-overflow fallback) instead of per-wave lists
+    bool lists = false;          // the attempt in flight used per-wave hit lists
     spsp_params p{};
     const uint8_t* d_bases = nullptr;
     uint64_t n_bases = 0, n_tiles = 0;
     const uint64_t* d_rec_off = nullptr;
     uint32_t n_rec = 0, hits_cap = 0, out_cap = 0;
+    uint32_t n_lists = 0, list_cap = 0;   // geometry of the per-wave hit lists of the attempt in flight
+    uint64_t rows_per_wave = 0;
 };
 struct CompareJob;   // spsp_compare.hip
 }  // namespace spsp
@@ -80,15 +85,18 @@ struct spsp_ctx {
     hipEvent_t dense_done = nullptr;   // recorded behind every dense pass (unless a timing event already is)
     hipEvent_t dense_marker = nullptr; // what spsp_wait_dense waits on
     hipEvent_t tail_event = nullptr;   // spsp_wait_stream: marks the current end of this context's stream
+    hipEvent_t scan_done = nullptr;    // behind the last kernel of the queued scan: what spsp_scan_device_end waits on
+    hipEvent_t compare_done = nullptr; // likewise for the queued comparison
+    bool attr_pair_set = false, attr_single_set = false, attr_bloom_set = false;   // dynamic-LDS attributes set on this context's device
     spsp::ScanJob scan_job;
     spsp::CompareJob* compare_job = nullptr;
     uint64_t* h_skoff = nullptr;       // pinned staging for the sketch offsets of a queued comparison
     size_t h_skoff_cap = 0;
     // scan workspace
     spsp::DevBuf bases, rec_off, bitmap, tile_count, tile_off, hits, emit_count, scan_tmp, d_scalar, seg_a, seg_b;
+    spsp::DevBuf wave_hits, wave_cnt;    // per-wave hit lists of the table variants of the dense pass
     uint64_t hits_cap = 0, out_cap = 0;  // entries the sparse-stage buffers are sized for (grow on overflow)
-    uint64_t zeroed_tiles = 0;  // bitmap/tile_count tiles [0, zeroed_tiles) are zero unless dirty
-    uint64_t dirty_tiles = 0;   // tiles [0, dirty_tiles) may hold hits of a call that never reached k_expand
+    uint64_t list_cap = 0;               // hits one wave's list holds (grows on overflow)
     // LDS pre-filter table cache (keyed by m, threshold)
     spsp::DevBuf filter;
     uint32_t filter_m = 0;

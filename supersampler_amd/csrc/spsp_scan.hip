@@ -20,6 +20,7 @@
 //                        132-166) that split super-k-mers.
 //
 // Output = exactly the argument stream of Subsampler::handle_superkmer.
+#include <algorithm>
 #include <cstdlib>
 
 #include "spsp_internal.h"
@@ -176,57 +177,33 @@ __global__ void k_build_pairtab(const uint32_t* __restrict__ key8, const uint32_
     tab[byte] = (uint8_t)v;
 }
 
-// hash one surviving m-mer (forward value f at position pos) and publish it if it really is a hit
-__device__ __forceinline__ void verify_candidate(uint64_t n_mmers, uint32_t m, uint64_t thr, uint64_t pos, uint32_t f,
-                                                 uint32_t* __restrict__ bitmap, uint32_t* __restrict__ tile_count) {
-    if (pos >= n_mmers) return;
-    const uint32_t rc = rc_mmer32(f, m);
-    const uint32_t x = f < rc ? f : rc;
-    if (xxh64_u64(x) <= thr) {
-        atomicOr(&bitmap[pos >> 5], 1u << (pos & 31));
-        atomicAdd(&tile_count[pos / kTilePos], 1u);
-    }
-}
+// ------------------------------------------------- per-wave hit lists --------
+// The table variants of the dense pass give every wave a CONTIGUOUS range of rows and its own slice of a
+// raw hit array: survivors are verified in position order (the queue is first in, first out and a drain round
+// keeps lane order), so a wave's slice is sorted and wave w's hits all precede wave w+1's.  No bitmap, no
+// atomics, no memset: k_compact only has to prefix the per-wave counts.  A wave that finds more hits than
+// its slice holds keeps counting (stores are suppressed); the host grows the slices and runs the pass again.
+struct WaveLists {
+    Hit* raw;            // [n_waves][cap]
+    uint32_t* cnt;       // [n_waves] hits found (may exceed cap)
+    uint32_t cap;
+    uint64_t rows_per_wave;
+};
 
-// Verify queued survivors {pos low 32 bits, m-mer}, 64 per round with every lane busy, until fewer than
-// keep_below remain; returns the new queue length.  Deliberately NOT inlined: the hash is ~150
-// instructions and the scan kernels reach this from several places -- inlined copies blow the
-// instruction cache of the hot loop.
-__device__ __attribute__((noinline)) uint32_t drain_queue(const uint2* __restrict__ queue, uint32_t qn, uint32_t keep_below,
-                                                          uint32_t qhigh, uint64_t n_mmers, uint32_t m, uint64_t thr,
-                                                          uint32_t* __restrict__ bitmap, uint32_t* __restrict__ tile_count) {
-    const uint32_t lane = threadIdx.x & 63;
-    while (qn >= keep_below && qn > 0) {
-        const uint32_t take = qn < 64 ? qn : 64;
-        if (lane < take) {
-            const uint2 e = queue[qn - take + lane];
-            verify_candidate(n_mmers, m, thr, ((uint64_t)qhigh << 32) | e.x, e.y, bitmap, tile_count);
-        }
-        qn -= take;
+// one drain round: lane i holds candidate i (or none); real hits are appended in lane order
+__device__ __forceinline__ uint32_t append_hits(bool is_hit, uint64_t pos, uint32_t canon, uint32_t f, uint64_t hash,
+                                                Hit* __restrict__ out, uint32_t out_cap, uint32_t out_n) {
+    const unsigned long long hitmask = __ballot(is_hit);
+    if (!hitmask) return out_n;
+    const uint32_t at = out_n + __builtin_amdgcn_mbcnt_hi((uint32_t)(hitmask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hitmask, 0u));
+    if (is_hit && at < out_cap) {
+        Hit h;
+        h.pos = pos; h.hash = hash; h.canon = canon; h.rec = 0;
+        h.flags = canon != f ? 1u : 0u;      // rec / usable are filled in by k_compact
+        h.pad = 0;
+        out[at] = h;
     }
-    return qn;
-}
-
-// Pair-kernel flavour: entries are {row position low 32 bits, survivor bit index, window hi, window nxt};
-// offset and m-mer are decoded here, with all 64 lanes busy, instead of in the divergent push loop.
-__device__ __forceinline__ uint32_t pair_bit_to_offset(uint32_t b);
-__device__ __attribute__((noinline)) uint32_t drain_queue_raw(const uint4* __restrict__ queue, uint32_t qn, uint32_t keep_below,
-                                                              uint32_t qhigh, uint64_t n_mmers, uint32_t m, uint64_t thr,
-                                                              uint32_t* __restrict__ bitmap, uint32_t* __restrict__ tile_count) {
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t mm = (1u << (2 * m)) - 1u;
-    while (qn >= keep_below && qn > 0) {
-        const uint32_t take = qn < 64 ? qn : 64;
-        if (lane < take) {
-            const uint4 e = queue[qn - take + lane];
-            const uint32_t off = pair_bit_to_offset(e.y);
-            const uint64_t W = ((uint64_t)e.z << 32) | e.w;
-            verify_candidate(n_mmers, m, thr, (((uint64_t)qhigh << 32) | e.x) + off,
-                             (uint32_t)(W >> (64 - 2 * m - 2 * off)) & mm, bitmap, tile_count);
-        }
-        qn -= take;
-    }
-    return qn;
+    return out_n + (uint32_t)__popcll(hitmask);
 }
 
 // A wave-row is 63 chunks of 16 positions: lane 63 only supplies the halo of lane
@@ -256,12 +233,38 @@ __device__ __forceinline__ uint32_t pair_bit_to_offset(uint32_t b) {
     return 2 * (4 * grp + q) + second;
 }
 
+// Verify the queued survivors of one wave (all of them: the queue never holds more than 64), lane i taking
+// entry i.  Entries are {position of the lane's chunk relative to the wave's first position, survivor bit
+// (or 0x100 | offset), window hi, window nxt}: offset and m-mer are decoded here, with all lanes busy, not in
+// the push.  Deliberately NOT inlined: the hash is ~150 instructions and the scan kernel reaches this
+// from several places -- inlined copies blow the instruction cache of the hot loop.
+__device__ __attribute__((noinline)) uint32_t drain_pair(const uint4* __restrict__ queue, uint32_t qn, uint64_t base_pos,
+                                                         uint64_t n_mmers, uint32_t m, uint64_t thr,
+                                                         Hit* __restrict__ out, uint32_t out_cap, uint32_t out_n) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t mm = (1u << (2 * m)) - 1u;
+    bool is_hit = false;
+    uint64_t pos = 0, hash = 0;
+    uint32_t f = 0, x = 0;
+    if (lane < qn) {
+        const uint4 e = queue[lane];
+        const uint32_t off = (e.y & 0x100u) ? (e.y & 15u) : pair_bit_to_offset(e.y);
+        const uint64_t W = ((uint64_t)e.z << 32) | e.w;
+        pos = base_pos + e.x + off;
+        f = (uint32_t)(W >> (64 - 2 * m - 2 * off)) & mm;
+        const uint32_t rc = rc_mmer32(f, m);
+        x = f < rc ? f : rc;
+        hash = xxh64_u64(x);
+        is_hit = pos < n_mmers && hash <= thr;
+    }
+    return append_hits(is_hit, pos, x, f, hash, out, out_cap, out_n);
+}
+
 __global__ __launch_bounds__(64 * kPairWaves) void k_dense_pair(const uint8_t* __restrict__ bases, uint64_t n, uint32_t m,
                                                                uint64_t thr, const uint8_t* __restrict__ pairtab,
-                                                               uint64_t n_rows, uint32_t* __restrict__ bitmap,
-                                                               uint32_t* __restrict__ tile_count) {
+                                                               uint64_t n_rows, WaveLists L) {
     __shared__ __attribute__((aligned(16))) uint8_t tab[kPairTabBytes];
-    extern __shared__ __attribute__((aligned(16))) uint32_t qbase[];   // per wave: kQueueCap x {row pos low 32, bit, hi, nxt}
+    extern __shared__ __attribute__((aligned(16))) uint32_t qbase[];   // per wave: kQueueCap x {rel pos, bit, hi, nxt}
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: row bookkeeping stays on the SALU
     uint4* queue = reinterpret_cast<uint4*>(qbase) + wave * kQueueCap;
@@ -272,106 +275,112 @@ __global__ __launch_bounds__(64 * kPairWaves) void k_dense_pair(const uint8_t* _
     }
     __syncthreads();
     const uint64_t n_mmers = n >= m ? n - m + 1 : 0;
-    const uint64_t gw = (uint64_t)blockIdx.x * kPairWaves + wave, n_waves = (uint64_t)gridDim.x * kPairWaves;
+    const uint64_t gw = (uint64_t)blockIdx.x * kPairWaves + wave;
+    // rows of this wave: [first, first + n_my), a contiguous range (measured: strided rows, the streaming order,
+    // are 3 % faster in the dense kernel alone -- and would need a merge of the lists afterwards)
+    const uint64_t first = gw * L.rows_per_wave;
+    const uint64_t lim = first + L.rows_per_wave < n_rows ? first + L.rows_per_wave : n_rows;
+    const uint64_t n_my = first < lim ? lim - first : 0;
+    const uint64_t base_pos = first * kRowPosPair63;
+    constexpr uint64_t row_bytes = kRowPosPair63;
+    Hit* out = L.raw + gw * L.cap;
+    uint32_t out_n = 0;       // hits of this wave so far (wave-uniform)
     uint32_t qn = 0;          // survivors waiting in this wave's queue (wave-uniform, lives in an SGPR)
-    uint32_t qhigh = 0;       // bits 32.. of every queued position (the queue is drained before they change)
 
-    auto drain = [&](uint32_t keep_below) {
-        qn = drain_queue_raw(queue, qn, keep_below, qhigh, n_mmers, m, thr, bitmap, tile_count);
+    auto drain = [&]() {
+        out_n = drain_pair(queue, qn, base_pos, n_mmers, m, thr, out, L.cap, out_n);
+        qn = 0;
     };
-    // Queue (or hash in place) the survivors of TWO rows of this wave at once: cand bits 0..15 belong to
-    // the row at p0a with window (hia,nxa), bits 16..31 to the row at p0b with (hib,nxb).
-    auto handle = [&](uint32_t cand, uint64_t p0a, uint32_t hia, uint32_t nxa, uint64_t p0b, uint32_t hib, uint32_t nxb) {
-        const unsigned long long holders = __ballot(cand != 0);
-        if (!holders) return;
-        // exclusive prefix and total of the per-lane survivor counts.  Usually no lane holds more
-        // than one survivor and one ballot does it; otherwise the counts are bit-sliced over ballots.
-        uint32_t prefix, total;
-        if (!__ballot((cand & (cand - 1)) != 0)) {
-            prefix = __builtin_amdgcn_mbcnt_hi((uint32_t)(holders >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)holders, 0u));
-            total = (uint32_t)__popcll(holders);
-        } else {
-            const uint32_t cnt = __popc(cand);
-            prefix = 0; total = 0;
+    // rare: queue the survivors of ONE row in position order, 64 at a time, whatever their number
+    auto slow_row = [&](uint32_t c, uint32_t rel, uint32_t hi, uint32_t nxt) {
+        if (!__ballot(c != 0)) return;
+        uint32_t pm = 0;                                  // bit j = position offset j survives
+        for (uint32_t t = c; t; t &= t - 1) pm |= 1u << pair_bit_to_offset(__ffs(t) - 1);
+        const uint32_t cnt = __popc(pm);
+        uint32_t idx = 0, total = 0;                      // exclusive prefix / total of cnt over the lanes
 #pragma unroll
-            for (int b = 0; b < 6; ++b) {
-                const unsigned long long plane = __ballot((cnt >> b) & 1u);
-                if (plane) {
-                    prefix += __builtin_amdgcn_mbcnt_hi((uint32_t)(plane >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)plane, 0u)) << b;
-                    total += (uint32_t)__popcll(plane) << b;
-                }
-            }
+        for (int b = 0; b < 5; ++b) {
+            const unsigned long long plane = __ballot((cnt >> b) & 1u);
+            idx += __builtin_amdgcn_mbcnt_hi((uint32_t)(plane >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)plane, 0u)) << b;
+            total += (uint32_t)__popcll(plane) << b;
         }
-        // every queued position shares its bits 32.. (qhigh): drain before they change (4 GiB seams)
-        const uint32_t high_a = (uint32_t)(p0a >> 32), high_b = (uint32_t)(p0b >> 32);
-        if ((qn && high_a != qhigh) || qn + total > (uint32_t)kQueueCap) drain(1);
-        const bool in_place = total > (uint32_t)kQueueCap || high_a != high_b;
-        qhigh = high_a;
-        if (in_place) {                                   // adversarial input / a 4 GiB seam between the two rows
-            const uint32_t mm = (1u << (2 * m)) - 1u;
-            while (cand) {
-                const uint32_t bit = __ffs(cand) - 1;
-                cand &= cand - 1;
-                const bool second = bit >= 16;
-                const uint32_t off = pair_bit_to_offset(bit & 15);
-                const uint64_t W = second ? (((uint64_t)hib << 32) | nxb) : (((uint64_t)hia << 32) | nxa);
-                verify_candidate(n_mmers, m, thr, (second ? p0b : p0a) + off, (uint32_t)(W >> (64 - 2 * m - 2 * off)) & mm,
-                                 bitmap, tile_count);
+        for (uint32_t base = 0; base < total; base += 64) {
+            while (pm && idx < base + 64) {
+                const uint32_t off = __ffs(pm) - 1;
+                pm &= pm - 1;
+                queue[idx - base] = make_uint4(rel, 0x100u | off, hi, nxt);
+                ++idx;
             }
+            qn = total - base < 64 ? total - base : 64;
+            drain();
+        }
+    };
+    // Queue the survivors of TWO consecutive rows of this wave: ca belongs to the row whose lane chunk starts at
+    // rel_a (relative to base_pos) with window (hia,nxa), cb to the next row.  Usual case: no lane holds two
+    // survivors of one row -- one ballot per row gives the queue places, row a first (position order).
+    auto handle = [&](uint32_t ca, uint32_t cb, uint32_t rel_a, uint32_t hia, uint32_t nxa, uint32_t rel_b, uint32_t hib, uint32_t nxb) {
+        const unsigned long long ha = __ballot(ca != 0), hb = __ballot(cb != 0);
+        if (!(ha | hb)) return;
+        const uint32_t na = (uint32_t)__popcll(ha), total = na + (uint32_t)__popcll(hb);
+        if (!__ballot(((ca & (ca - 1)) | (cb & (cb - 1))) != 0) && total <= (uint32_t)kQueueCap) {
+            if (qn + total > (uint32_t)kQueueCap) drain();
+            if (ca) queue[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(ha >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ha, 0u))] =
+                        make_uint4(rel_a, __ffs(ca) - 1, hia, nxa);
+            if (cb) queue[qn + na + __builtin_amdgcn_mbcnt_hi((uint32_t)(hb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hb, 0u))] =
+                        make_uint4(rel_b, __ffs(cb) - 1, hib, nxb);
+            qn += total;
+            if (qn >= (uint32_t)kQueueCap) drain();
             return;
         }
-        uint4* e = queue + qn + prefix;
-        while (cand) {                                    // divergent, but only an ffs and one 16-byte LDS store per survivor
-            const uint32_t bit = __ffs(cand) - 1;
-            cand &= cand - 1;
-            *e++ = bit >= 16 ? make_uint4((uint32_t)p0b, bit & 15, hib, nxb) : make_uint4((uint32_t)p0a, bit, hia, nxa);
-        }
-        qn += total;
-        if (qn >= 64) drain(64);
+        drain();                                          // adversarial input: repeats, more than a queue-full
+        slow_row(ca, rel_a, hia, nxa);
+        slow_row(cb, rel_b, hib, nxb);
     };
 
     // rows whose 64 chunks lie completely inside the buffer take the vector path
     const uint64_t full_rows = n >= 64 * kChunk ? (n - 64 * kChunk) / kRowPosPair63 + 1 : 0;
-    const uint64_t fast_rows = full_rows < n_rows ? full_rows : n_rows;
-    const uint64_t stride = n_waves * kRowPosPair63;           // bytes between two rows of this wave
-    uint64_t row = gw;
-    const uint8_t* ptr = bases + row * kRowPosPair63 + (uint64_t)lane * kChunk;
+    const uint64_t n_fast_all = first < full_rows ? full_rows - first : 0;
+    const uint64_t n_fast = n_fast_all < n_my ? n_fast_all : n_my;
+    uint64_t i = 0;                                            // index among this wave's rows
+    const uint8_t* ptr = bases + first * kRowPosPair63 + (uint64_t)lane * kChunk;
     // Two rows in flight per wave, in two named register sets: each set is refilled
     // right after it has been packed, so its wait sits a whole loop trip later.
     uint4 raw0 = make_uint4(0, 0, 0, 0), raw1 = raw0;
-    if (row < fast_rows) raw0 = *reinterpret_cast<const uint4*>(ptr);
-    if (row + n_waves < fast_rows) raw1 = *reinterpret_cast<const uint4*>(ptr + stride);
+    if (i < n_fast) raw0 = *reinterpret_cast<const uint4*>(ptr);
+    if (i + 1 < n_fast) raw1 = *reinterpret_cast<const uint4*>(ptr + row_bytes);
     const bool halo_lane = lane >= kRowChunks;                 // lane 63 only feeds lane 62
     auto body = [&](uint4& raw, uint64_t r, const uint8_t* at, uint32_t& hi, uint32_t& nxt) -> uint32_t {
         hi = pack16(raw);
         // unconditional refill (a branch around the load would force a full vmcnt(0) wait right here):
         // past the last row the wave re-reads its current row, whose value is never used
-        raw = *reinterpret_cast<const uint4*>(r + 2 * n_waves < fast_rows ? at + 2 * stride : at);
+        raw = *reinterpret_cast<const uint4*>(r + 2 < n_fast ? at + 2 * row_bytes : at);
         nxt = __shfl_down(hi, 1);
         const uint32_t c = pair_lookup16(tab, hi, nxt);
         return halo_lane ? 0u : c;
     };
-    const uint64_t lane_off = (uint64_t)lane * kChunk;
-    for (; row + n_waves < fast_rows; row += 2 * n_waves, ptr += 2 * stride) {
+    uint32_t rel = lane * kChunk;                              // this lane's chunk of the current row, relative to base_pos
+    const uint32_t rel_step = (uint32_t)row_bytes;
+    for (; i + 1 < n_fast; i += 2, ptr += 2 * row_bytes, rel += 2 * rel_step) {
         uint32_t hia, nxa, hib, nxb;
-        const uint32_t ca = body(raw0, row, ptr, hia, nxa);
-        const uint32_t cb = body(raw1, row + n_waves, ptr + stride, hib, nxb);
-        handle(ca | (cb << 16), row * kRowPosPair63 + lane_off, hia, nxa, (row + n_waves) * kRowPosPair63 + lane_off, hib, nxb);
+        const uint32_t ca = body(raw0, i, ptr, hia, nxa);
+        const uint32_t cb = body(raw1, i + 1, ptr + row_bytes, hib, nxb);
+        handle(ca, cb, rel, hia, nxa, rel + rel_step, hib, nxb);
     }
-    if (row < fast_rows) {
+    if (i < n_fast) {
         uint32_t hia, nxa;
-        const uint32_t ca = body(raw0, row, ptr, hia, nxa);
-        handle(ca, row * kRowPosPair63 + lane_off, hia, nxa, row * kRowPosPair63 + lane_off, hia, nxa);
+        const uint32_t ca = body(raw0, i, ptr, hia, nxa);
+        handle(ca, 0u, rel, hia, nxa, rel, hia, nxa);
+        ++i; rel += rel_step;
     }
-    // the last (at most two) rows touch the end of the buffer: byte-wise loads
-    for (row = fast_rows + ((gw + n_waves - fast_rows % n_waves) % n_waves); row < n_rows; row += n_waves) {
-        const uint64_t p0 = row * kRowPosPair63 + lane_off;
-        const uint32_t hi = load_pack(bases, n, p0);
+    // the last (at most two) rows of the buffer touch its end: byte-wise loads
+    for (; i < n_my; ++i, rel += rel_step) {
+        const uint32_t hi = load_pack(bases, n, (first + i) * kRowPosPair63 + (uint64_t)lane * kChunk);
         const uint32_t nxt = __shfl_down(hi, 1);
         const uint32_t c = pair_lookup16(tab, hi, nxt);
-        handle(halo_lane ? 0u : c, p0, hi, nxt, p0, hi, nxt);
+        handle(halo_lane ? 0u : c, 0u, rel, hi, nxt, rel, hi, nxt);
     }
-    drain(1);
+    drain();
+    if (lane == 0) L.cnt[gw] = out_n;
 }
 
 // ------------------------------------- dense pass, single-position table form ---
@@ -379,10 +388,11 @@ __global__ __launch_bounds__(64 * kPairWaves) void k_dense_pair(const uint8_t* _
 // configurations whose 8-base pair keys are too crowded (m = 13, 15, or dense
 // sampling): K10[q] = some m-mer (either strand) whose first 10 bases are q has
 // XXH64(canonical) <= T; 2^20 bits = 128 KiB of LDS, one ds_read_u8 per position.
-// Survivor rates up to ~30 % are queued bit-plane by bit-plane, so the queue never
-// overflows and every hash round runs with 64 busy lanes.
+// Survivor rates up to ~30 % go through a first-in-first-out ring per wave, so every
+// hash round runs with 64 busy lanes and the verified hits stay in position order.
 constexpr int kKey10Bytes = 131072;
 constexpr int kQueueCap1 = 192;              // 16 waves x 192 x 8 B + table = 152 KiB
+constexpr int kPushWindow = 128;             // survivors queued between two drains: < 64 left + 128 <= kQueueCap1
 
 __global__ void k_build_key10(uint32_t m, uint64_t thr, uint32_t* __restrict__ key10) {
     const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -414,13 +424,12 @@ __device__ __forceinline__ uint32_t single_lookup16(const uint8_t* __restrict__ 
 
 __global__ __launch_bounds__(64 * kPairWaves) void k_dense_single(const uint8_t* __restrict__ bases, uint64_t n, uint32_t m,
                                                                  uint64_t thr, const uint8_t* __restrict__ key10,
-                                                                 uint64_t n_rows, uint32_t* __restrict__ bitmap,
-                                                                 uint32_t* __restrict__ tile_count) {
+                                                                 uint64_t n_rows, WaveLists L) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds1[];
     uint8_t* tab = lds1;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    uint2* queue = reinterpret_cast<uint2*>(lds1 + kKey10Bytes) + wave * kQueueCap1;
+    uint2* queue = reinterpret_cast<uint2*>(lds1 + kKey10Bytes) + wave * kQueueCap1;   // ring of {rel pos, m-mer}
     {
         const uint4* src = reinterpret_cast<const uint4*>(key10);
         uint4* dst = reinterpret_cast<uint4*>(tab);
@@ -429,70 +438,96 @@ __global__ __launch_bounds__(64 * kPairWaves) void k_dense_single(const uint8_t*
     __syncthreads();
     const uint64_t n_mmers = n >= m ? n - m + 1 : 0;
     const uint32_t mm = (1u << (2 * m)) - 1u;
-    const uint64_t gw = (uint64_t)blockIdx.x * kPairWaves + wave, n_waves = (uint64_t)gridDim.x * kPairWaves;
-    uint32_t qn = 0, qhigh = 0;
+    const uint64_t gw = (uint64_t)blockIdx.x * kPairWaves + wave;
+    const uint64_t first = gw * L.rows_per_wave;              // see k_dense_pair
+    const uint64_t lim = first + L.rows_per_wave < n_rows ? first + L.rows_per_wave : n_rows;
+    const uint64_t n_my = first < lim ? lim - first : 0;
+    const uint64_t base_pos = first * kRowPosPair63;
+    constexpr uint64_t row_bytes = kRowPosPair63;
+    Hit* out = L.raw + gw * L.cap;
+    uint32_t out_n = 0, qn = 0, head = 0;
     // inlined on purpose (unlike k_dense_pair's): at survivor rates of 5-20 % a row drains several times, and a
-    // real call would spill the caller's live registers every time; the plane loop below is not unrolled, so
-    // the hash body exists once per call site of handle()
+    // real call would spill the caller's live registers every time
     auto drain = [&](uint32_t keep_below) {
         while (qn >= keep_below && qn > 0) {
             const uint32_t take = qn < 64 ? qn : 64;
+            bool is_hit = false;
+            uint64_t pos = 0, hash = 0;
+            uint32_t f = 0, x = 0;
             if (lane < take) {
-                const uint2 e = queue[qn - take + lane];
-                verify_candidate(n_mmers, m, thr, ((uint64_t)qhigh << 32) | e.x, e.y, bitmap, tile_count);
+                uint32_t at = head + lane;
+                if (at >= (uint32_t)kQueueCap1) at -= kQueueCap1;
+                const uint2 e = queue[at];
+                pos = base_pos + e.x; f = e.y;
+                const uint32_t rc = rc_mmer32(f, m);
+                x = f < rc ? f : rc;
+                hash = xxh64_u64(x);
+                is_hit = pos < n_mmers && hash <= thr;
             }
+            out_n = append_hits(is_hit, pos, x, f, hash, out, L.cap, out_n);
+            head += take; if (head >= (uint32_t)kQueueCap1) head -= kQueueCap1;
             qn -= take;
         }
     };
-    // queue one row's survivors, one bit-plane (= one position offset) at a time
-    auto handle = [&](uint32_t cand, uint64_t p0, uint32_t hi, uint32_t nxt) {
+    // queue one row's survivors in position order (lane-major), kPushWindow at a time
+    auto handle = [&](uint32_t cand, uint32_t rel, uint32_t hi, uint32_t nxt) {
         if (!__ballot(cand != 0)) return;
-        const uint32_t high = (uint32_t)(p0 >> 32);
-        if (qn && high != qhigh) drain(1);
-        qhigh = high;
+        const uint32_t cnt = __popc(cand);
+        uint32_t idx = 0, total = 0;
+#pragma unroll
+        for (int b = 0; b < 5; ++b) {
+            const unsigned long long plane = __ballot((cnt >> b) & 1u);
+            idx += __builtin_amdgcn_mbcnt_hi((uint32_t)(plane >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)plane, 0u)) << b;
+            total += (uint32_t)__popcll(plane) << b;
+        }
         const uint64_t W = ((uint64_t)hi << 32) | nxt;
-#pragma unroll 1
-        for (int j = 0; j < 16; ++j) {
-            const unsigned long long plane = __ballot((cand >> j) & 1u);
-            if (!plane) continue;
-            if ((cand >> j) & 1u) {
-                const uint32_t at = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(plane >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)plane, 0u));
-                queue[at] = make_uint2((uint32_t)(p0 + j), (uint32_t)(W >> (64 - 2 * m - 2 * j)) & mm);
+        uint32_t c = cand;
+        for (uint32_t base = 0; base < total; base += kPushWindow) {
+            const uint32_t tail = head + qn;              // ring slot of survivor `base` (before wrapping)
+            while (c && idx < base + kPushWindow) {
+                const uint32_t j = __ffs(c) - 1;
+                c &= c - 1;
+                uint32_t at = tail + (idx - base);
+                if (at >= (uint32_t)kQueueCap1) at -= kQueueCap1;
+                if (at >= (uint32_t)kQueueCap1) at -= kQueueCap1;
+                queue[at] = make_uint2(rel + j, (uint32_t)(W >> (64 - 2 * m - 2 * j)) & mm);
+                ++idx;
             }
-            qn += (uint32_t)__popcll(plane);      // < 64 + 64 <= kQueueCap1
-            if (qn >= 64) drain(64);
+            qn += total - base < (uint32_t)kPushWindow ? total - base : (uint32_t)kPushWindow;
+            drain(64);
         }
     };
     const uint64_t full_rows = n >= 64 * kChunk ? (n - 64 * kChunk) / kRowPosPair63 + 1 : 0;
-    const uint64_t fast_rows = full_rows < n_rows ? full_rows : n_rows;
-    const uint64_t stride = n_waves * kRowPosPair63;
-    uint64_t row = gw;
-    const uint8_t* ptr = bases + row * kRowPosPair63 + (uint64_t)lane * kChunk;
+    const uint64_t n_fast_all = first < full_rows ? full_rows - first : 0;
+    const uint64_t n_fast = n_fast_all < n_my ? n_fast_all : n_my;
+    uint64_t i = 0;
+    const uint8_t* ptr = bases + first * kRowPosPair63 + (uint64_t)lane * kChunk;
     uint4 raw0 = make_uint4(0, 0, 0, 0), raw1 = raw0;
-    if (row < fast_rows) raw0 = *reinterpret_cast<const uint4*>(ptr);
-    if (row + n_waves < fast_rows) raw1 = *reinterpret_cast<const uint4*>(ptr + stride);
+    if (i < n_fast) raw0 = *reinterpret_cast<const uint4*>(ptr);
+    if (i + 1 < n_fast) raw1 = *reinterpret_cast<const uint4*>(ptr + row_bytes);
     const bool halo_lane = lane >= kRowChunks;
-    const uint64_t lane_off = (uint64_t)lane * kChunk;
-    auto body = [&](uint4& raw, uint64_t r, const uint8_t* at) {
+    uint32_t rel = lane * kChunk;
+    const uint32_t rel_step = (uint32_t)row_bytes;
+    auto body = [&](uint4& raw, uint64_t r, const uint8_t* at, uint32_t rl) {
         const uint32_t hi = pack16(raw);
-        raw = *reinterpret_cast<const uint4*>(r + 2 * n_waves < fast_rows ? at + 2 * stride : at);
+        raw = *reinterpret_cast<const uint4*>(r + 2 < n_fast ? at + 2 * row_bytes : at);
         const uint32_t nxt = __shfl_down(hi, 1);
         const uint32_t c = single_lookup16(tab, hi, nxt);
-        handle(halo_lane ? 0u : c, r * kRowPosPair63 + lane_off, hi, nxt);
+        handle(halo_lane ? 0u : c, rl, hi, nxt);
     };
-    for (; row + n_waves < fast_rows; row += 2 * n_waves, ptr += 2 * stride) {
-        body(raw0, row, ptr);
-        body(raw1, row + n_waves, ptr + stride);
+    for (; i + 1 < n_fast; i += 2, ptr += 2 * row_bytes, rel += 2 * rel_step) {
+        body(raw0, i, ptr, rel);
+        body(raw1, i + 1, ptr + row_bytes, rel + rel_step);
     }
-    if (row < fast_rows) body(raw0, row, ptr);
-    for (row = fast_rows + ((gw + n_waves - fast_rows % n_waves) % n_waves); row < n_rows; row += n_waves) {
-        const uint64_t p0 = row * kRowPosPair63 + lane_off;
-        const uint32_t hi = load_pack(bases, n, p0);
+    if (i < n_fast) { body(raw0, i, ptr, rel); ++i; rel += rel_step; }
+    for (; i < n_my; ++i, rel += rel_step) {
+        const uint32_t hi = load_pack(bases, n, (first + i) * kRowPosPair63 + (uint64_t)lane * kChunk);
         const uint32_t nxt = __shfl_down(hi, 1);
         const uint32_t c = single_lookup16(tab, hi, nxt);
-        handle(halo_lane ? 0u : c, p0, hi, nxt);
+        handle(halo_lane ? 0u : c, rel, hi, nxt);
     }
     drain(1);
+    if (lane == 0) L.cnt[gw] = out_n;
 }
 
 // ------------------------------------------------- exclusive scan (1 block) --
@@ -760,6 +795,108 @@ __global__ __launch_bounds__(kThreads) void k_expand(const uint8_t* __restrict__
     }
 }
 
+// ------------------------------------------------------------ compact pass --
+// Per-wave hit lists of the table variants -> one array in position order, with the record of every hit
+// filled in.  Wave w's hits precede wave w+1's and each list is sorted, so the place of a hit is the sum of
+// the counts before its wave plus its index: every workgroup sums the counts in front of its own
+// kCompactWaves lists itself (a few KiB from L2 -- cheaper than a scan launch); the LAST workgroup thereby
+// holds the grand total and the largest count and publishes them (overflow of a list = largest > cap).
+constexpr int kCompactThreads = 256, kCompactWaves = 64;
+__global__ __launch_bounds__(kCompactThreads) void k_compact(WaveLists L, uint32_t n_lists, uint64_t n, uint32_t k, uint32_t m,
+                                                            const uint64_t* __restrict__ rec_off, uint32_t n_rec,
+                                                            Hit* __restrict__ hits, uint32_t hits_cap,
+                                                            uint64_t* __restrict__ total_host, uint32_t* __restrict__ total_dev,
+                                                            uint32_t* __restrict__ chunk_sum, uint32_t n_chunks) {
+    __shared__ uint32_t s_red[kCompactThreads / 64][2];
+    __shared__ uint32_t s_pre[kCompactWaves + 1];
+    __shared__ uint32_t s_rec[2];
+    const uint32_t t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    if (blockIdx.x == 0)                            // the count pass of k_resolve adds into these
+        for (uint32_t i = t; i < n_chunks; i += kCompactThreads) chunk_sum[i] = 0;
+    const uint32_t w0 = blockIdx.x * kCompactWaves;
+    // sum and maximum of the counts in front of this workgroup's lists
+    uint32_t sum = 0, mx = 0;
+    for (uint32_t i = t; i < w0; i += kCompactThreads) {
+        const uint32_t c = L.cnt[i];
+        sum += c < L.cap ? c : L.cap;
+        mx = c > mx ? c : mx;
+    }
+    // own lists: clamped counts -> exclusive prefix (first wave)
+    uint32_t own = 0, own_raw = 0;
+    if (t < (uint32_t)kCompactWaves && w0 + t < n_lists) { own_raw = L.cnt[w0 + t]; own = own_raw < L.cap ? own_raw : L.cap; }
+    if (wid == 0) {
+        uint32_t x = own;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d);
+            if (lane >= (uint32_t)d) x += y;
+        }
+        s_pre[lane] = x - own;
+        if (lane == 63) s_pre[64] = x;
+        mx = own_raw > mx ? own_raw : mx;
+    }
+#pragma unroll
+    for (int d = 32; d; d >>= 1) { sum += __shfl_xor(sum, d); const uint32_t o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
+    if (lane == 0) { s_red[wid][0] = sum; s_red[wid][1] = mx; }
+    // records this workgroup's positions can fall into: [rlo, rhi]
+    const uint64_t span = L.rows_per_wave * kRowPosPair63;
+    if (t == 64 || t == 128) {
+        const uint64_t want = t == 64 ? (uint64_t)w0 * span : ((uint64_t)w0 + kCompactWaves) * span;
+        uint32_t rlo = 0, rhi = n_rec;              // invariant: rec_off[rlo] <= want (rec_off[0] = 0) < rec_off[rhi] or rhi = n_rec
+        while (rhi - rlo > 1) {
+            const uint32_t mid = (rlo + rhi) >> 1;
+            if (rec_off[mid] <= want) rlo = mid; else rhi = mid;
+        }
+        s_rec[t == 64 ? 0 : 1] = rlo;
+    }
+    __syncthreads();
+    uint32_t base = 0, gmax = 0;
+#pragma unroll
+    for (int w = 0; w < kCompactThreads / 64; ++w) { base += s_red[w][0]; gmax = s_red[w][1] > gmax ? s_red[w][1] : gmax; }
+    const uint32_t mine = s_pre[kCompactWaves];
+    if (blockIdx.x == gridDim.x - 1 && t == 0) {    // the hit total and the fullest list, for the host and for k_resolve
+        total_host[0] = (uint64_t)base + mine;
+        total_host[2] = gmax;
+        *total_dev = base + mine;
+    }
+    const uint32_t rec_lo = s_rec[0], rec_hi = s_rec[1];
+    for (uint32_t i = t; i < mine; i += kCompactThreads) {
+        uint32_t lo = 0, hi = kCompactWaves;        // list holding item i: last l with s_pre[l] <= i
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (s_pre[mid] <= i) lo = mid; else hi = mid;
+        }
+        Hit h = L.raw[(uint64_t)(w0 + lo) * L.cap + (i - s_pre[lo])];
+        uint32_t a = rec_lo, b = rec_hi + 1 < n_rec ? rec_hi + 1 : n_rec;   // rec_off[a] <= pos < rec_off[b]
+        while (b - a > 1) {
+            const uint32_t mid = (a + b) >> 1;
+            if (rec_off[mid] <= h.pos) a = mid; else b = mid;
+        }
+        // equal offsets (empty records): the record holding pos is the LAST one starting at or before it
+        const uint64_t r0 = rec_off[a], r1 = rec_off[a + 1];
+        h.rec = a;
+        const bool usable = (h.pos + m <= r1) && (r1 - r0 >= k);
+        h.flags = (h.flags & 1u) | (usable ? 2u : 0u);
+        const uint32_t rk = base + i;
+        if (rk < hits_cap) hits[rk] = h;            // the host sees n_hits > hits_cap and retries with room
+    }
+}
+
+// dense-only callers (spsp_scan_hits_device): the number of hits = sum of the per-wave counts
+__global__ __launch_bounds__(1024) void k_sum_counts(const uint32_t* __restrict__ cnt, uint32_t n_lists,
+                                                    uint64_t* __restrict__ total_host) {
+    __shared__ unsigned long long s_sum;
+    if (threadIdx.x == 0) s_sum = 0;
+    __syncthreads();
+    unsigned long long s = 0;
+    for (uint32_t i = threadIdx.x; i < n_lists; i += 1024) s += cnt[i];
+#pragma unroll
+    for (int d = 32; d; d >>= 1) s += __shfl_xor(s, d);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&s_sum, s);
+    __syncthreads();
+    if (threadIdx.x == 0) *total_host = s_sum;
+}
+
 // ------------------------------------------------------------ resolve pass --
 // Literal replay of the reference state machine over one cluster of hits.
 struct Rescan { uint32_t mini; uint32_t rev; uint64_t position; uint64_t hash; };
@@ -1006,72 +1143,80 @@ static int ensure_pairtab(spsp_ctx* ctx, const spsp_params* p) {
     return SPSP_OK;
 }
 
+// geometry of the per-wave hit lists for one dense launch of a table variant
+struct ListPlan { uint32_t grid, n_lists, cap; uint64_t n_rows, rows_per_wave; };
+static int plan_lists(spsp_ctx* ctx, const spsp_params* p, int variant, uint64_t n_bases, ListPlan* P) {
+    P->n_rows = (n_bases + kRowPosPair63 - 1) / kRowPosPair63;
+    const uint64_t want = (P->n_rows + kPairWaves - 1) / kPairWaves;
+    static const int per_cu = getenv("SPSP_PAIR_BLOCKS_PER_CU") ? atoi(getenv("SPSP_PAIR_BLOCKS_PER_CU")) : 0;  // tuning knob
+    // k_dense_pair: 80 KiB of LDS -> two 1024-lane workgroups per CU; k_dense_single: 152 KiB -> one
+    const uint64_t cap_blocks = (uint64_t)ctx->n_cu * (per_cu > 0 ? per_cu : (variant == kDensePair ? 2 : 1));
+    P->grid = (uint32_t)(want < cap_blocks ? want : cap_blocks);
+    P->n_lists = P->grid * kPairWaves;
+    P->rows_per_wave = (P->n_rows + P->n_lists - 1) / P->n_lists;
+    if (P->rows_per_wave * kRowPosPair63 >= 0xffff0000ull) { set_error("input too large for one call"); return SPSP_ERR_OVERFLOW; }
+    // slice per wave: 1.5 x the expected hits + slack for the Poisson tail; grown by the caller after an overflow
+    const double frac = (double)p->threshold / 18446744073709551616.0;
+    const double expect = (double)P->rows_per_wave * kRowPosPair63 * frac;
+    uint64_t cap = (uint64_t)(expect * 1.5) + 48;
+    static const char* dbg_hits = getenv("SPSP_DEBUG_HITS_CAP");      // test hook: tiny lists, so the overflow paths run
+    if (dbg_hits && ctx->list_cap == 0) cap = (uint64_t)atoll(dbg_hits) / 8 + 1;
+    if (ctx->list_cap > cap) cap = ctx->list_cap;                     // grown by an earlier overflow: keep
+    const uint64_t most = P->rows_per_wave * kRowPosPair63;           // a wave cannot find more hits than it has positions
+    if (cap > most) cap = most;
+    if (cap > 0xfffffff0ull) { set_error("input too large for one call"); return SPSP_ERR_OVERFLOW; }
+    P->cap = (uint32_t)cap;
+    return SPSP_OK;
+}
+
+// dense pass of one attempt; *lists = per-wave hit lists were produced (table variants), else bitmap + tile counts
 static int launch_dense(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, uint64_t n_bases,
-                        uint64_t n_tiles, bool want_total) {
+                        uint64_t n_tiles, bool use_bitmap, ListPlan* LP, bool* lists) {
     int rc;
-    const void *old_bm = ctx->bitmap.p, *old_tc = ctx->tile_count.p;
-    if ((rc = ctx->bitmap.reserve((size_t)n_tiles * kTileWords * 4))) return rc;
-    if ((rc = ctx->tile_count.reserve((size_t)n_tiles * 4))) return rc;
-    if ((rc = ctx->tile_off.reserve((size_t)(n_tiles + 1) * 4))) return rc;
+    const int variant = use_bitmap ? kDenseDirect : pick_dense(p);
+    *lists = variant != kDenseDirect;
     if ((rc = ctx->d_scalar.reserve(64))) return rc;
-    if (ctx->bitmap.p != old_bm || ctx->tile_count.p != old_tc) { ctx->zeroed_tiles = 0; ctx->dirty_tiles = 0; }
-    const int variant = pick_dense(p);
-    if (variant == kDenseSingle && (rc = ensure_key10(ctx, p))) return rc;
-    if (variant == kDensePair && (rc = ensure_pairtab(ctx, p))) return rc;
+    if (*lists) {
+        if ((rc = plan_lists(ctx, p, variant, n_bases, LP))) return rc;
+        if ((rc = ctx->wave_hits.reserve((size_t)LP->n_lists * LP->cap * sizeof(Hit)))) return rc;
+        if ((rc = ctx->wave_cnt.reserve((size_t)LP->n_lists * 4))) return rc;
+        if (variant == kDenseSingle && (rc = ensure_key10(ctx, p))) return rc;
+        if (variant == kDensePair && (rc = ensure_pairtab(ctx, p))) return rc;
+    } else {
+        if ((rc = ctx->bitmap.reserve((size_t)n_tiles * kTileWords * 4))) return rc;
+        if ((rc = ctx->tile_count.reserve((size_t)n_tiles * 4))) return rc;
+        if ((rc = ctx->tile_off.reserve((size_t)(n_tiles + 1) * 4))) return rc;
+    }
     if ((rc = ctx->ev_begin(kEvDense))) return rc;
-    if (variant == kDensePair || variant == kDenseSingle) {
-        // hits are published with atomics into a zeroed bitmap.  k_expand zeroes what it
-        // consumes, so in a batch loop nothing has to be cleared here: only tiles never used
-        // before, or left dirty by a call that did not reach k_expand, are memset.
-        if (ctx->dirty_tiles) {
-            SPSP_HIP(hipMemsetAsync(ctx->bitmap.p, 0, (size_t)ctx->dirty_tiles * kTileWords * 4, ctx->stream));
-            SPSP_HIP(hipMemsetAsync(ctx->tile_count.p, 0, (size_t)ctx->dirty_tiles * 4, ctx->stream));
-            ctx->dirty_tiles = 0;
-        }
-        if (ctx->zeroed_tiles < n_tiles) {
-            const uint64_t from = ctx->zeroed_tiles;
-            SPSP_HIP(hipMemsetAsync(ctx->bitmap.as<uint32_t>() + from * kTileWords, 0, (size_t)(n_tiles - from) * kTileWords * 4, ctx->stream));
-            SPSP_HIP(hipMemsetAsync(ctx->tile_count.as<uint32_t>() + from, 0, (size_t)(n_tiles - from) * 4, ctx->stream));
-            ctx->zeroed_tiles = n_tiles;
-        }
-        const uint64_t n_rows = (n_bases + kRowPosPair63 - 1) / kRowPosPair63;
-        const uint64_t want = (n_rows + kPairWaves - 1) / kPairWaves;
-        static const int per_cu = getenv("SPSP_PAIR_BLOCKS_PER_CU") ? atoi(getenv("SPSP_PAIR_BLOCKS_PER_CU")) : 0;  // tuning knob
-        // k_dense_pair: 80 KiB of LDS -> two 1024-lane workgroups per CU; k_dense_single: 152 KiB -> one
-        const uint64_t cap = (uint64_t)ctx->n_cu * (per_cu > 0 ? per_cu : (variant == kDensePair ? 2 : 1));
-        const dim3 grid((uint32_t)(want < cap ? want : cap));
+    if (*lists) {
+        const WaveLists L{ctx->wave_hits.as<Hit>(), ctx->wave_cnt.as<uint32_t>(), LP->cap, LP->rows_per_wave};
         if (variant == kDensePair) {
             const size_t lds = (size_t)kPairWaves * kQueueCap * 16;                // + 64 KiB static table
-            static bool attr_set = false;
-            if (!attr_set) {
+            if (!ctx->attr_pair_set) {
                 SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_pair),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                attr_set = true;
+                ctx->attr_pair_set = true;
             }
-            hipLaunchKernelGGL(k_dense_pair, grid, dim3(64 * kPairWaves), lds, ctx->stream, d_bases, n_bases, p->m,
-                               p->threshold, ctx->pairtab.as<uint8_t>(), n_rows, ctx->bitmap.as<uint32_t>(),
-                               ctx->tile_count.as<uint32_t>());
+            hipLaunchKernelGGL(k_dense_pair, dim3(LP->grid), dim3(64 * kPairWaves), lds, ctx->stream, d_bases, n_bases, p->m,
+                               p->threshold, ctx->pairtab.as<uint8_t>(), LP->n_rows, L);
         } else {
             const size_t lds = (size_t)kKey10Bytes + (size_t)kPairWaves * kQueueCap1 * 8;
-            static bool attr_set = false;
-            if (!attr_set) {
+            if (!ctx->attr_single_set) {
                 SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_single),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                attr_set = true;
+                ctx->attr_single_set = true;
             }
-            hipLaunchKernelGGL(k_dense_single, grid, dim3(64 * kPairWaves), lds, ctx->stream, d_bases, n_bases, p->m,
-                               p->threshold, ctx->filter.as<uint8_t>(), n_rows, ctx->bitmap.as<uint32_t>(),
-                               ctx->tile_count.as<uint32_t>());
+            hipLaunchKernelGGL(k_dense_single, dim3(LP->grid), dim3(64 * kPairWaves), lds, ctx->stream, d_bases, n_bases, p->m,
+                               p->threshold, ctx->filter.as<uint8_t>(), LP->n_rows, L);
         }
     } else {
+        // k_dense_direct stores every bitmap word and tile count of the tiles it covers: nothing to clear
         const uint64_t cap = (uint64_t)ctx->n_cu * 16;
         const uint32_t grid = (uint32_t)(n_tiles < cap ? n_tiles : cap);
         hipLaunchKernelGGL(k_dense_direct, dim3(grid), dim3(kThreads), 0, ctx->stream, d_bases, n_bases, p->m,
                            p->threshold, n_tiles, ctx->bitmap.as<uint32_t>(), ctx->tile_count.as<uint32_t>());
     }
     SPSP_HIP(hipGetLastError());
-    if (n_tiles > ctx->dirty_tiles) ctx->dirty_tiles = n_tiles;   // until k_expand has consumed (and zeroed) them
-    if (n_tiles > ctx->zeroed_tiles) ctx->zeroed_tiles = n_tiles; // ... after which this whole range is zero
     if ((rc = ctx->ev_end(kEvDense))) return rc;
     // spsp_wait_dense: other streams may start behind the dense pass.  Every event recorded here is a packet the
     // sparse stages queue behind, so with timing on the timing end-event doubles as the marker.
@@ -1082,15 +1227,12 @@ static int launch_dense(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_ba
         SPSP_HIP(hipEventRecord(ctx->dense_done, ctx->stream));
         ctx->dense_marker = ctx->dense_done;
     }
-    const uint32_t seg_shift = seg_shift_for(n_tiles);
-    const uint32_t n_seg = (uint32_t)((n_tiles + (1ull << seg_shift) - 1) >> seg_shift);
-    if ((rc = ctx->seg_a.reserve((size_t)n_seg * 8))) return rc;
-    hipLaunchKernelGGL(k_scan_segments, dim3(n_seg), dim3(kSegThreads), 0, ctx->stream, ctx->tile_count.as<uint32_t>(),
-                       ctx->tile_off.as<uint32_t>(), n_tiles, seg_shift, ctx->seg_a.as<uint32_t>());
-    SPSP_HIP(hipGetLastError());
-    if (want_total) {   // dense-only callers; the full pipeline lets k_expand publish the total
-        hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(64), 0, ctx->stream, ctx->seg_a.as<uint32_t>(),
-                           ctx->seg_a.as<uint32_t>() + n_seg, n_seg, ctx->h_scalar + 0, ctx->d_scalar.as<uint32_t>() + 0);
+    if (!*lists) {
+        const uint32_t seg_shift = seg_shift_for(n_tiles);
+        const uint32_t n_seg = (uint32_t)((n_tiles + (1ull << seg_shift) - 1) >> seg_shift);
+        if ((rc = ctx->seg_a.reserve((size_t)n_seg * 8))) return rc;
+        hipLaunchKernelGGL(k_scan_segments, dim3(n_seg), dim3(kSegThreads), 0, ctx->stream, ctx->tile_count.as<uint32_t>(),
+                           ctx->tile_off.as<uint32_t>(), n_tiles, seg_shift, ctx->seg_a.as<uint32_t>());
         SPSP_HIP(hipGetLastError());
     }
     return SPSP_OK;
@@ -1105,7 +1247,19 @@ int scan_hits_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, 
     if (n_bases < p->m) return SPSP_OK;
     const uint64_t n_tiles = (n_bases + kTilePos - 1) / kTilePos;
     if (n_tiles > 0x7fffffffull) { set_error("input too large for one call"); return SPSP_ERR_OVERFLOW; }
-    if ((rc = launch_dense(ctx, p, d_bases, n_bases, n_tiles, true))) return rc;
+    ListPlan LP{};
+    bool lists = false;
+    if ((rc = launch_dense(ctx, p, d_bases, n_bases, n_tiles, false, &LP, &lists))) return rc;
+    if (lists) {
+        hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(1024), 0, ctx->stream, ctx->wave_cnt.as<uint32_t>(), LP.n_lists,
+                           ctx->h_scalar + 0);
+    } else {
+        const uint32_t seg_shift = seg_shift_for(n_tiles);
+        const uint32_t n_seg = (uint32_t)((n_tiles + (1ull << seg_shift) - 1) >> seg_shift);
+        hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(64), 0, ctx->stream, ctx->seg_a.as<uint32_t>(),
+                           ctx->seg_a.as<uint32_t>() + n_seg, n_seg, ctx->h_scalar + 0, ctx->d_scalar.as<uint32_t>() + 0);
+    }
+    SPSP_HIP(hipGetLastError());
     SPSP_HIP(hipStreamSynchronize(ctx->stream));
     *n_hits = ctx->h_scalar[0];
     return SPSP_OK;
@@ -1138,29 +1292,43 @@ static int scan_enqueue(spsp_ctx* ctx) {
     if ((rc = ctx->seg_b.reserve((size_t)(n_chunks + n_waves) * 4))) return rc;
     uint32_t* chunk_sum = ctx->seg_b.as<uint32_t>();
     uint32_t* wave_sum = chunk_sum + n_chunks;
-    uint32_t* d_sc = nullptr;
-    if (J.redo_dense) {
-        if ((rc = launch_dense(ctx, p, J.d_bases, J.n_bases, J.n_tiles, false))) return rc;
-        d_sc = ctx->d_scalar.as<uint32_t>();
-        const uint32_t seg_shift = seg_shift_for(J.n_tiles);
-        const uint32_t n_seg_t = (uint32_t)((J.n_tiles + (1ull << seg_shift) - 1) >> seg_shift);
-        hipLaunchKernelGGL(k_expand, dim3((uint32_t)((J.n_tiles + kExpandTilesPerWg - 1) / kExpandTilesPerWg)),
-                           dim3(kThreads), 0, ctx->stream, J.d_bases, J.n_bases, p->k, p->m, ctx->bitmap.as<uint32_t>(),
-                           ctx->tile_count.as<uint32_t>(), ctx->tile_off.as<uint32_t>(), ctx->seg_a.as<uint32_t>(),
-                           n_seg_t, seg_shift, J.n_tiles, J.d_rec_off, J.n_rec, ctx->hits.as<Hit>(), hits_cap, ctx->h_scalar + 0, d_sc + 0,
-                           chunk_sum, n_chunks);
+    if ((rc = ctx->d_scalar.reserve(64))) return rc;
+    uint32_t* d_sc = ctx->d_scalar.as<uint32_t>();
+    if (J.redo_from == 0) {
+        ListPlan LP{};
+        if ((rc = launch_dense(ctx, p, J.d_bases, J.n_bases, J.n_tiles, J.use_bitmap, &LP, &J.lists))) return rc;
+        if (J.lists) { J.n_lists = LP.n_lists; J.list_cap = LP.cap; J.rows_per_wave = LP.rows_per_wave; }
+    }
+    if (J.redo_from <= 1) {
+        if (J.lists) {
+            const WaveLists L{ctx->wave_hits.as<Hit>(), ctx->wave_cnt.as<uint32_t>(), J.list_cap, J.rows_per_wave};
+            hipLaunchKernelGGL(k_compact, dim3((J.n_lists + kCompactWaves - 1) / kCompactWaves), dim3(kCompactThreads), 0, ctx->stream,
+                               L, J.n_lists, J.n_bases, p->k, p->m, J.d_rec_off, J.n_rec, ctx->hits.as<Hit>(), hits_cap,
+                               ctx->h_scalar + 0, d_sc + 0, chunk_sum, n_chunks);
+        } else {
+            ctx->h_scalar[2] = 0;   // no lists: nothing can overflow them (no kernel of this attempt writes the slot)
+            const uint32_t seg_shift = seg_shift_for(J.n_tiles);
+            const uint32_t n_seg_t = (uint32_t)((J.n_tiles + (1ull << seg_shift) - 1) >> seg_shift);
+            hipLaunchKernelGGL(k_expand, dim3((uint32_t)((J.n_tiles + kExpandTilesPerWg - 1) / kExpandTilesPerWg)),
+                               dim3(kThreads), 0, ctx->stream, J.d_bases, J.n_bases, p->k, p->m, ctx->bitmap.as<uint32_t>(),
+                               ctx->tile_count.as<uint32_t>(), ctx->tile_off.as<uint32_t>(), ctx->seg_a.as<uint32_t>(),
+                               n_seg_t, seg_shift, J.n_tiles, J.d_rec_off, J.n_rec, ctx->hits.as<Hit>(), hits_cap, ctx->h_scalar + 0, d_sc + 0,
+                               chunk_sum, n_chunks);
+        }
         SPSP_HIP(hipGetLastError());
-        ctx->dirty_tiles = 0;   // k_expand leaves bitmap and tile counts zeroed
         hipLaunchKernelGGL(k_resolve<false>, dim3(rblocks), dim3(kResolveThreads), 0, ctx->stream, ctx->hits.as<Hit>(), d_sc + 0,
                            hits_cap, J.d_rec_off, p->k, p->m, ctx->emit_count.as<uint32_t>(), wave_sum, chunk_sum, n_chunks,
                            (uint64_t*)nullptr, (spsp_superkmer*)nullptr, 0u);
         SPSP_HIP(hipGetLastError());
     }
-    d_sc = ctx->d_scalar.as<uint32_t>();
     hipLaunchKernelGGL(k_resolve<true>, dim3(rblocks), dim3(kResolveThreads), 0, ctx->stream, ctx->hits.as<Hit>(), d_sc + 0,
                        hits_cap, J.d_rec_off, p->k, p->m, ctx->emit_count.as<uint32_t>(), wave_sum, chunk_sum, n_chunks,
                        ctx->h_scalar + 1, ctx->scan_tmp.as<spsp_superkmer>(), out_cap);
     SPSP_HIP(hipGetLastError());
+    // what scan_end waits on: this job's last kernel, not the whole stream (a caller may already have queued
+    // the next batch's work behind it)
+    if (!ctx->scan_done) SPSP_HIP(hipEventCreateWithFlags(&ctx->scan_done, hipEventDisableTiming));
+    SPSP_HIP(hipEventRecord(ctx->scan_done, ctx->stream));
     return SPSP_OK;
 }
 
@@ -1188,7 +1356,9 @@ int scan_begin_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases,
     static const char* dbg_out = getenv("SPSP_DEBUG_OUT_CAP");
     if (dbg_hits) ctx->hits_cap = (uint64_t)atoll(dbg_hits);
     if (dbg_out) ctx->out_cap = (uint64_t)atoll(dbg_out);
-    J.redo_dense = true;
+    if (dbg_hits) ctx->list_cap = 0;
+    J.redo_from = 0;
+    J.use_bitmap = false;
     if ((rc = ctx->ev_begin(kEvScan))) { J.pending = false; return rc; }
     rc = scan_enqueue(ctx);
     const int rc2 = ctx->ev_end(kEvScan);   // brackets the first attempt (a retry after an overflow is not timed)
@@ -1203,23 +1373,35 @@ int scan_end_impl(spsp_ctx* ctx, spsp_superkmer** d_out, uint64_t* n_out) {
     J.pending = false;
     if (J.empty) return SPSP_OK;
     static const char* dbg_out = getenv("SPSP_DEBUG_OUT_CAP");
+    static const char* dbg_budget = getenv("SPSP_DEBUG_LIST_BUDGET");   // test hook: bytes the grown hit lists may take
     int rc;
-    for (int attempt = 0; attempt < 4; ++attempt) {
-        SPSP_HIP(hipStreamSynchronize(ctx->stream));
-        const uint64_t n_hits = ctx->h_scalar[0], n_em = ctx->h_scalar[1];
-        if (n_hits > J.hits_cap) {         // the bitmap has been consumed: start over with room for every hit
+    for (int attempt = 0; attempt < 5; ++attempt) {
+        SPSP_HIP(hipEventSynchronize(ctx->scan_done));
+        const uint64_t n_hits = ctx->h_scalar[0], n_em = ctx->h_scalar[1], fullest = J.lists ? ctx->h_scalar[2] : 0;
+        if (fullest > J.list_cap) {
+            // a wave found more hits than its list holds (it kept counting): run the dense pass again with lists
+            // that fit -- unless they would be out of proportion (an input that is nearly all hits in places),
+            // where the bitmap form of the dense pass takes over
+            const uint64_t want = fullest + fullest / 8 + 16;
+            const uint64_t budget = dbg_budget ? (uint64_t)atoll(dbg_budget) : std::max<uint64_t>(256ull << 20, 8 * J.n_bases);
+            if (want * J.n_lists * sizeof(Hit) > budget) J.use_bitmap = true;
+            else ctx->list_cap = want;
+            if (n_hits > J.hits_cap) ctx->hits_cap = n_hits + n_hits / 8 + 1024;   // (clamped counts: a lower bound)
+            if (ctx->out_cap < ctx->hits_cap && !dbg_out) ctx->out_cap = ctx->hits_cap;
+            J.redo_from = 0;
+        } else if (n_hits > J.hits_cap) {  // room for every hit; the lists are intact, a consumed bitmap is not
             ctx->hits_cap = n_hits + n_hits / 8 + 1024;
             if (ctx->out_cap < ctx->hits_cap && !dbg_out) ctx->out_cap = ctx->hits_cap;
-            J.redo_dense = true;
+            J.redo_from = J.lists ? 1 : 0;
         } else if (n_em > J.out_cap) {     // hits and offsets are intact: only the write pass repeats
             ctx->out_cap = n_em + n_em / 8 + 1024;
-            J.redo_dense = false;
+            J.redo_from = 2;
         } else {
             *d_out = n_em ? ctx->scan_tmp.as<spsp_superkmer>() : nullptr;
             *n_out = n_em;
             return SPSP_OK;
         }
-        if (attempt == 3) break;
+        if (attempt == 4) break;
         if ((rc = scan_enqueue(ctx))) return rc;
     }
     set_error("scan buffers kept overflowing");

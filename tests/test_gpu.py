@@ -494,8 +494,11 @@ def test_scan_buffer_overflow_retries():
         "    want, _ = orc.scan(k, m, p.threshold, b, o)\n"
         "    assert len(got) == len(want) > 50 and all((got[f] == want[f]).all() for f in got.dtype.names)\n"
         "print('ok')\n") % (ROOT, os.path.join(ROOT, "tests"))
+    # HITS_CAP also shrinks the per-wave hit lists of the table variants (list overflow -> grown lists);
+    # LIST_BUDGET=0 forbids growing them, so the bitmap form of the dense pass takes over
     for env_extra in ({"SPSP_DEBUG_HITS_CAP": "16"}, {"SPSP_DEBUG_OUT_CAP": "8"},
-                      {"SPSP_DEBUG_HITS_CAP": "100", "SPSP_DEBUG_OUT_CAP": "3"}):
+                      {"SPSP_DEBUG_HITS_CAP": "100", "SPSP_DEBUG_OUT_CAP": "3"},
+                      {"SPSP_DEBUG_HITS_CAP": "16", "SPSP_DEBUG_LIST_BUDGET": "0"}):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env_extra), capture_output=True,
                            text=True, timeout=600)
         assert r.returncode == 0 and "ok" in r.stdout, (env_extra, r.stdout[-2000:], r.stderr[-2000:])
