@@ -53,11 +53,15 @@ int spsp_ctx::ev_begin(int kind) {
     if (!L.spare.empty()) { ev = L.spare.back(); L.spare.pop_back(); }
     else { SPSP_HIP(hipEventCreate(&ev.first)); SPSP_HIP(hipEventCreate(&ev.second)); }
     L.used.push_back(ev);
+    ev_open[kind] = true;
     SPSP_HIP(hipEventRecord(ev.first, stream));
     return SPSP_OK;
 }
 int spsp_ctx::ev_end(int kind) {
-    if (!(timing_mask & (1u << kind))) return SPSP_OK;
+    // closes the bracket opened by the matching ev_begin only: timing may have been switched on, off or read
+    // between the two calls (the comparison's bracket spans API calls)
+    if (!ev_open[kind] || evlog[kind].used.empty()) { ev_open[kind] = false; return SPSP_OK; }
+    ev_open[kind] = false;
     SPSP_HIP(hipEventRecord(evlog[kind].used.back().second, stream));
     return SPSP_OK;
 }
@@ -80,13 +84,16 @@ int spsp_timing_read(spsp_ctx* ctx, spsp_timing* out) {
     for (int kind = 0; kind < kEvKinds; ++kind) {
         ms[kind] = 0; cnt[kind] = 0;
         EventLog& L = ctx->evlog[kind];
-        for (auto& ev : L.used) {
+        // a bracket whose end has not been recorded yet (a comparison between its begin and end calls) stays open
+        const size_t done = L.used.size() - ((ctx->ev_open[kind] && !L.used.empty()) ? 1 : 0);
+        for (size_t i = 0; i < done; ++i) {
+            auto& ev = L.used[i];
             float t = 0;
             SPSP_HIP(hipEventElapsedTime(&t, ev.first, ev.second));
             ms[kind] += t; ++cnt[kind];
             L.spare.push_back(ev);
         }
-        L.used.clear();
+        L.used.erase(L.used.begin(), L.used.begin() + done);
     }
     out->dense_ms = ms[kEvDense]; out->dense_launches = cnt[kEvDense];
     out->scan_ms = ms[kEvScan]; out->scan_calls = cnt[kEvScan];
@@ -144,7 +151,7 @@ void spsp_destroy(spsp_ctx* c) {
     if (c->compare_done) (void)hipEventDestroy(c->compare_done);
     DevBuf* bufs[] = {&c->bases, &c->rec_off, &c->bitmap, &c->tile_count, &c->tile_off, &c->hits, &c->emit_count,
                       &c->scan_tmp, &c->d_scalar, &c->seg_a, &c->seg_b, &c->wave_hits, &c->wave_cnt, &c->filter, &c->pairtab, &c->c_min, &c->c_lo, &c->c_hi, &c->c_table,
-                      &c->c_owner, &c->c_rowid, &c->c_row, &c->x_cnt, &c->x_off, &c->x_begin, &c->x_end, &c->x_tot, &c->c_matrix, &c->c_inter, &c->c_flags, &c->c_slot_lo, &c->c_slot_hi, &c->c_slot_mn,
+                      &c->c_owner, &c->c_rowid, &c->c_row, &c->x_cnt, &c->x_off, &c->x_begin, &c->x_end, &c->x_tot, &c->c_matrix, &c->c_inter, &c->c_flags, &c->c_slot_lo, &c->c_slot_hi, &c->c_slot_mn, &c->c_part_cnt, &c->c_recs,
                       &c->c_skoff, &c->i_text, &c->i_tiles, &c->i_entry, &c->i_outoff, &c->i_recbase, &c->i_lens, &c->i_dst,
                       &c->i_compact};
     for (DevBuf* b : bufs) b->release();

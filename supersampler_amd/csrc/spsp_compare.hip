@@ -221,6 +221,13 @@ __global__ void k_fill(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n, 
 //   k_accumulate_sparse  one workgroup per sketch and block of 16 Ki columns: LDS counters, one LDS add per
 //                    (key of i, other holder of the key)
 // Traffic per key is its list (a few bytes) instead of N/8 bytes.  Used when all rows are owned (single GPU).
+// A sketch list = u16 length, then the u16 ids of the sketches holding the key, starting on a 16-byte boundary
+// of `ids`.  Its reference (one u32 per sketch entry) carries the place in 16-byte units and, for lists shorter
+// than 127, the length -- so the row sums issue the list's loads without first waiting for its length word.
+__host__ __device__ __forceinline__ uint32_t list_u16(uint32_t len) { return (len + 1 + 7) & ~7u; }
+__device__ __forceinline__ uint32_t list_ref(uint32_t o, uint32_t len) { return (o >> 3) | ((len < 127 ? len : 127u) << 25); }
+constexpr uint32_t kNoList = 0xffffffffu;       // the key takes part in no pair of this job
+
 __global__ void k_insert_sparse(Keys K, const uint64_t* __restrict__ sk_off, uint64_t seed, uint64_t* __restrict__ table,
                                 uint32_t log2cap, uint32_t* __restrict__ cnt, SlotKeys SK, uint32_t* __restrict__ slot_of_entry,
                                 uint32_t* __restrict__ flags) {
@@ -259,7 +266,7 @@ __global__ __launch_bounds__(kRowThreads) void k_assign_ranges(const uint32_t* _
     for (int u = 0; u < kRowSlots; ++u) {
         const uint64_t sl = base_slot + u;
         c[u] = sl < cap ? cnt[sl] : 0u;
-        sum += c[u] ? c[u] + 1 : 0u;            // list = length word + ids
+        sum += c[u] ? list_u16(c[u]) : 0u;      // list = length word + ids, padded to whole 16-byte words
     }
     uint32_t x = sum;
 #pragma unroll
@@ -279,7 +286,7 @@ __global__ __launch_bounds__(kRowThreads) void k_assign_ranges(const uint32_t* _
         if (!c[u]) continue;
         off[base_slot + u] = at;
         ids[at] = (uint16_t)c[u];               // a key is held at most once per sketch: length <= 65535
-        at += c[u] + 1;
+        at += list_u16(c[u]);
     }
 }
 
@@ -296,36 +303,290 @@ __global__ void k_fill_sparse(Keys K, const uint64_t* __restrict__ sk_off, uint3
     const uint32_t o = off[pos];
     const uint32_t idx = atomicSub(&cnt[pos], 1u);   // counts down c .. 1: the places behind the length word
     ids[o + idx] = (uint16_t)j;
-    slot_of_entry[e] = o;                       // the row sums go straight to the list
+    slot_of_entry[e] = list_ref(o, ids[o]);     // the row sums go straight to the list
 }
 
-constexpr int kSparseCols = 16384, kSparseThreads = 256;
+constexpr int kSparseCols = 16384;
+constexpr int kFlags = 8;   // [0] unsorted input, [1] fingerprint collision, [2] n_rows, [3] malformed slot, [4] slot overflow,
+                            // [5] table full, [6] a key part overflowed its capacity (partition form)
+// grid.y = owned row (sketch row_first + y * row_stride), grid.x = block of `cols` columns, grid.z = slice of the
+// row's keys (split > 1: the slices add into cells zeroed by k_zero_rows).  Counters live in dynamic LDS,
+// `copies` of each, interleaved (counter c of copy k at c * copies + k): the lists of one row's keys name the
+// same few sketches over and over, and 64 lanes adding to ONE LDS word serialise -- with a copy per lane
+// group the same column is spread over `copies` banks.  A thread takes kAccU keys at a time: the list
+// references are one coalesced load and the lists' first words are issued together.
+constexpr int kSparseThreads = 1024, kAccU = 2, kAccW = 4;
 __global__ __launch_bounds__(kSparseThreads) void k_accumulate_sparse(const uint32_t* __restrict__ list_of_entry,
                                                                      const uint16_t* __restrict__ ids,
                                                                      const uint64_t* __restrict__ sk_begin,
                                                                      const uint64_t* __restrict__ sk_end, uint32_t n,
+                                                                     uint32_t row_first, uint32_t row_stride, uint32_t row_limit,
+                                                                     uint32_t cols, uint32_t copies_log2, uint32_t split,
                                                                      uint32_t* __restrict__ inter,
                                                                      const uint32_t* __restrict__ flags,
                                                                      uint32_t* __restrict__ host_flags) {
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 6) host_flags[threadIdx.x] = flags[threadIdx.x];
-    const uint32_t i = blockIdx.y, col0 = blockIdx.x * kSparseCols;
-    if (col0 + kSparseCols <= i + 1) return;                // no column > i in this block
-    __shared__ uint32_t s_cnt[kSparseCols];
-    for (uint32_t x = threadIdx.x; x < kSparseCols; x += kSparseThreads) s_cnt[x] = 0;
+    extern __shared__ uint32_t s_cnt[];
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < kFlags) host_flags[threadIdx.x] = flags[threadIdx.x];
+    const uint32_t i = row_first + blockIdx.y * row_stride, col0 = blockIdx.x * cols;
+    if (i >= n || i >= row_limit) return;
+    if (col0 + cols <= i + 1) return;                       // no column > i in this block
+    uint64_t e0 = sk_begin[i], e1 = sk_end[i];
+    if (split > 1) {
+        const uint64_t per = (e1 - e0 + split - 1) / split;
+        e0 += per * blockIdx.z;
+        if (e0 + per < e1) e1 = e0 + per;
+        if (e0 >= e1) return;
+    }
+    const uint32_t copies = 1u << copies_log2, mine = threadIdx.x & (copies - 1);
+    for (uint32_t x = threadIdx.x; x < (cols << copies_log2); x += kSparseThreads) s_cnt[x] = 0;
     __syncthreads();
-    for (uint64_t e = sk_begin[i] + threadIdx.x; e < sk_end[i]; e += kSparseThreads) {
-        const uint32_t o = list_of_entry[e];
-        if (o == 0xffffffffu) continue;
-        const uint32_t len = ids[o];
-        for (uint32_t t = 1; t <= len; ++t) {
-            const uint32_t jj = ids[o + t];
-            if (jj > i && jj - col0 < (uint32_t)kSparseCols) atomicAdd(&s_cnt[jj - col0], 1u);
+    auto count = [&](uint32_t jj) { if (jj > i && jj - col0 < cols) atomicAdd(&s_cnt[((jj - col0) << copies_log2) + mine], 1u); };
+    for (uint64_t e = e0 + threadIdx.x; e < e1 + (kAccU - 1) * (uint64_t)kSparseThreads; e += (uint64_t)kAccU * kSparseThreads) {
+        uint32_t ref[kAccU];
+#pragma unroll
+        for (int u = 0; u < kAccU; ++u) { const uint64_t eu = e + (uint64_t)u * kSparseThreads; ref[u] = eu < e1 ? list_of_entry[eu] : kNoList; }
+        // the first kAccW 16-byte words of each list (length + 31 ids) are requested together; longer lists loop
+        uint4 w[kAccU][kAccW];
+#pragma unroll
+        for (int u = 0; u < kAccU; ++u) {
+            const uint4* L = reinterpret_cast<const uint4*>(ids) + (ref[u] & 0x1ffffffu);
+            const uint32_t len = ref[u] >> 25;
+#pragma unroll
+            for (int q = 0; q < kAccW; ++q)
+                w[u][q] = (ref[u] != kNoList && (q == 0 || len >= 8u * q)) ? L[q] : make_uint4(0, 0, 0, 0);   // (len 127 = "127 or more")
+        }
+#pragma unroll
+        for (int u = 0; u < kAccU; ++u) {
+            if (ref[u] == kNoList) continue;
+            const uint4* L = reinterpret_cast<const uint4*>(ids) + (ref[u] & 0x1ffffffu);
+            uint32_t len = ref[u] >> 25;
+            if (len == 127) len = w[u][0].x & 0xffffu;
+            // list element t (element 0 is the length, ids are 1..len) = half-word t & 7 of word t >> 3
+            auto word = [&](const uint4& v, uint32_t first) {
+                const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (uint32_t h = 0; h < 8; ++h) {
+                    const uint32_t t = first + h;
+                    if (t >= 1 && t <= len) count((d[h >> 1] >> (16 * (h & 1))) & 0xffffu);
+                }
+            };
+#pragma unroll
+            for (int q = 0; q < kAccW; ++q) if (q == 0 || len >= 8u * q) word(w[u][q], 8u * q);
+            for (uint32_t q = kAccW; 8 * q <= len; ++q) word(L[q], 8 * q);
         }
     }
     __syncthreads();
-    for (uint32_t x = threadIdx.x; x < kSparseCols; x += kSparseThreads) {
+    for (uint32_t x = threadIdx.x; x < cols; x += kSparseThreads) {
         const uint32_t col = col0 + x;
-        if (col > i && col < n) inter[(uint64_t)i * n + col] = s_cnt[x];
+        if (col > i && col < n) {
+            uint32_t v = 0;
+            for (uint32_t k = 0; k < copies; ++k) v += s_cnt[(x << copies_log2) + k];
+            if (split > 1) { if (v) atomicAdd(&inter[(uint64_t)i * n + col], v); }
+            else inter[(uint64_t)i * n + col] = v;
+        }
+    }
+}
+// cells (i, j > i) of the owned rows = 0 (only needed when the row sums are split over several workgroups)
+__global__ __launch_bounds__(256) void k_zero_rows(uint32_t n, uint32_t row_first, uint32_t row_stride, uint32_t row_limit,
+                                                  uint32_t* __restrict__ inter) {
+    const uint32_t i = row_first + blockIdx.y * row_stride;
+    if (i >= n || i >= row_limit) return;
+    for (uint32_t col = i + 1 + blockIdx.x * 256 + threadIdx.x; col < n; col += gridDim.x * 256) inter[(uint64_t)i * n + col] = 0;
+}
+
+// ---------------------------------------------------------------------------
+// Partition form: the dictionary without global atomics.  Equal keys have equal hashes, so the keys are first
+// dealt into P hash classes ("parts", a few thousand records each) and every part is then grouped by ONE
+// workgroup entirely in LDS -- full keys are compared, so there is no fingerprint and no collision retry.
+//   k_parts_prepare   part counters and flags cleared, sketch offsets brought over from the pinned staging copy
+//   k_parts_scatter   record {kmer_lo, minimizer | sketch << 32, entry, [kmer_hi]} -> its part; a workgroup counts
+//                     its chunk per part in LDS and reserves room with ONE global atomic per part it touches
+//   k_parts_group     per part: LDS hash of record indices (CAS claims a slot, later holders of the key chain
+//                     themselves in with an exchange); every chain head then writes the key's sketch list
+//                     (length + u16 ids) into the part's slice of `ids` and the list's place for each of its entries
+//   k_accumulate_sparse  as in the sketch-list form above: row sums by walking the lists
+// Parts have a fixed capacity; one that overflows (heavily duplicated keys) raises flags[6] and the host
+// falls back to the global-dictionary forms.
+constexpr int kPartCap = 4096, kPartSlots = 7936, kGroupThreads = 1024;   // (record index + 1 fits the 13 low bits of a slot word)
+constexpr int kScatThreads = 1024, kScatPer = 4, kScatSub = kScatThreads * kScatPer;   // entries per sub-chunk
+constexpr int kMaxKeyParts = 4096;
+
+__device__ __forceinline__ uint64_t key_hash(uint64_t lo, uint32_t mn, uint64_t hi, bool has_hi) {
+    uint64_t h = mix64(lo ^ 0xA0761D6478BD642FULL);
+    h = mix64(h + (uint64_t)mn * 0xE7037ED1A0B428DBULL);
+    if (has_hi) h = mix64(h ^ hi);
+    return h;
+}
+
+// sub_sk[c] = sketch holding entry c * kScatSub (worked out by the host, which has the offsets anyway)
+__global__ __launch_bounds__(256) void k_parts_prepare(uint32_t* __restrict__ part_cnt, uint32_t n_parts, uint32_t* __restrict__ flags,
+                                                      const uint64_t* __restrict__ host_skoff, uint64_t* __restrict__ dev_skoff,
+                                                      uint32_t n_skoff, const uint32_t* __restrict__ host_sub, uint32_t* __restrict__ dev_sub,
+                                                      uint32_t n_sub) {
+    const uint32_t stride = gridDim.x * blockDim.x, t = blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint32_t i = t; i < n_parts; i += stride) part_cnt[i] = 0;
+    if (t < 16) flags[t] = 0;
+    for (uint32_t i = t; i < n_skoff; i += stride) dev_skoff[i] = host_skoff[i];
+    for (uint32_t i = t; i < n_sub; i += stride) dev_sub[i] = host_sub[i];
+}
+
+// A workgroup owns E x kScatThreads consecutive entries of the concatenated key arrays, E per thread, all held in
+// registers: one round of (independent) loads, LDS counts per part with the entry's rank, ONE global atomic per
+// part the chunk touches (lane p takes part p: a wave's atomics are one contiguous 256-byte request), stores.
+// (E = 4: with 8 or 16 the unrolled hashes spill registers -- measured 20x slower.)
+template <bool HAS_HI, int E>
+__global__ __launch_bounds__(kScatThreads, 4) void k_parts_scatter(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n,
+                                                               const uint32_t* __restrict__ sub_sk, uint64_t S, uint32_t n_parts,
+                                                               uint32_t* __restrict__ part_cnt, uint64_t* __restrict__ recs,
+                                                               uint32_t* __restrict__ flags) {
+    constexpr uint32_t W = HAS_HI ? 4 : 3;
+    __shared__ uint32_t hist[kMaxKeyParts];
+    const uint32_t t = threadIdx.x, lane = t & 63;
+    const uint64_t base = (uint64_t)blockIdx.x * E * kScatThreads;
+    for (uint32_t p = t; p < n_parts; p += kScatThreads) hist[p] = 0;
+    uint64_t lo[E], hi[E];
+    uint32_t mn[E], pr[E];                                // pr = part | rank << 12
+#pragma unroll
+    for (int u = 0; u < E; ++u) {
+        const uint64_t e = base + (uint64_t)u * kScatThreads + t;
+        lo[u] = 0; mn[u] = 0; hi[u] = 0;
+        if (e < S) { lo[u] = K.lo[e]; mn[u] = K.mn[e]; if (HAS_HI) hi[u] = K.hi[e]; }
+    }
+    // sketch of every entry and the sortedness check, while the keys are the only thing in flight
+    uint32_t sk_of[E];
+#pragma unroll
+    for (int u = 0; u < E; ++u) {
+        const uint64_t e = base + (uint64_t)u * kScatThreads + t;
+        // the key in front of e: the neighbouring lane's, except for the first lane of a wave
+        uint64_t plo = __shfl_up(lo[u], 1), phi = HAS_HI ? __shfl_up(hi[u], 1) : 0ull;
+        uint32_t pmn = __shfl_up(mn[u], 1);
+        sk_of[u] = 0;
+        if (e >= S) continue;
+        if (lane == 0 && e > 0) { plo = K.lo[e - 1]; pmn = K.mn[e - 1]; if (HAS_HI) phi = K.hi[e - 1]; }
+        uint32_t j = sub_sk[e / kScatSub];
+        while (j + 1 < n && sk_off[j + 1] <= e) ++j;      // sketch of entry e (empty sketches are stepped over)
+        sk_of[u] = j;
+        if (e > sk_off[j]) {                              // strictly increasing inside a sketch
+            const bool less = pmn != mn[u] ? pmn < mn[u] : (HAS_HI && phi != hi[u]) ? phi < hi[u] : plo < lo[u];
+            if (!less) atomicOr(&flags[0], 1u);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < E; ++u) {
+        const uint64_t e = base + (uint64_t)u * kScatThreads + t;
+        pr[u] = 0xffffffffu;
+        if (e < S) {
+            const uint32_t part = (uint32_t)(((key_hash(lo[u], mn[u], hi[u], HAS_HI) >> 32) * n_parts) >> 32);
+            pr[u] = part | (atomicAdd(&hist[part], 1u) << 12);
+        }
+    }
+    __syncthreads();
+    for (uint32_t p = t; p < n_parts; p += kScatThreads) {
+        const uint32_t c = hist[p];
+        if (c) hist[p] = atomicAdd(&part_cnt[p], c);     // the chunk's records of part p start here
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < E; ++u) {
+        const uint64_t e = base + (uint64_t)u * kScatThreads + t;
+        if (e >= S) continue;
+        const uint32_t j = sk_of[u];
+        const uint32_t part = pr[u] & 0xfffu, at = hist[part] + (pr[u] >> 12);
+        if (at >= (uint32_t)kPartCap) continue;          // overflow: k_parts_group sees the count and raises the flag
+        uint64_t* r = recs + ((uint64_t)part * kPartCap + at) * W;
+        r[0] = lo[u];
+        r[1] = (uint64_t)mn[u] | ((uint64_t)j << 32);
+        r[2] = e;
+        if (HAS_HI) r[3] = hi[u];
+    }
+}
+
+// One workgroup per part.  A slot word is (records of the slot's key so far) << 13 | (claiming record + 1): a
+// record CASes its index into the first free slot of its probe sequence or finds the slot of its key (full-key
+// compare against the claiming record, kept in LDS), then draws its rank in the key's list by adding 1 << 13.
+// The claiming record of every key held by >= 2 sketches reserves the list in the part's slice of `ids`, and
+// every record writes its sketch id and its list reference.  80 KiB of LDS: two workgroups per CU.
+template <bool HAS_HI>
+__global__ __launch_bounds__(kGroupThreads) void k_parts_group(const uint64_t* __restrict__ recs, const uint32_t* __restrict__ part_cnt,
+                                                              uint16_t* __restrict__ ids, uint32_t* __restrict__ list_of_entry,
+                                                              uint32_t* __restrict__ flags) {
+    constexpr uint32_t W = HAS_HI ? 4 : 3;
+    constexpr uint32_t R = kPartCap / kGroupThreads;      // records per thread
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_g[];
+    uint64_t* k_lo = reinterpret_cast<uint64_t*>(lds_g);                                  // [kPartCap]
+    uint64_t* k_hi = k_lo + kPartCap;                                                     // [kPartCap] (HAS_HI only)
+    uint32_t* k_mn = reinterpret_cast<uint32_t*>(k_hi + (HAS_HI ? kPartCap : 0));         // [kPartCap]
+    uint32_t* slot = k_mn + kPartCap;                                                     // [kPartSlots]
+    uint32_t* cursor = slot + kPartSlots;
+    const uint32_t p = blockIdx.x, t = threadIdx.x;
+    const uint32_t n = part_cnt[p];
+    if (n > (uint32_t)kPartCap) { if (t == 0) atomicOr(&flags[6], 1u); return; }
+    for (uint32_t x = t; x < (uint32_t)kPartSlots; x += kGroupThreads) slot[x] = 0;
+    if (t == 0) *cursor = 0;
+    const uint64_t* base = recs + (uint64_t)p * kPartCap * W;
+    uint64_t lo[R], hi[R];
+    uint32_t mn[R], sk[R], en[R], hs[R], rank[R];
+#pragma unroll
+    for (uint32_t u = 0; u < R; ++u) {
+        const uint32_t r = u * kGroupThreads + t;
+        hs[u] = 0; lo[u] = 0; hi[u] = 0; mn[u] = 0; sk[u] = 0; en[u] = 0; rank[u] = 0;
+        {   // loaded whether or not the record exists (the slice is allocated in full): no wait for the count first
+            lo[u] = base[(uint64_t)r * W];
+            const uint64_t w1 = base[(uint64_t)r * W + 1];
+            en[u] = (uint32_t)base[(uint64_t)r * W + 2];
+            hi[u] = HAS_HI ? base[(uint64_t)r * W + 3] : 0ull;
+            mn[u] = (uint32_t)w1; sk[u] = (uint32_t)(w1 >> 32);
+            k_lo[r] = lo[u]; k_mn[r] = mn[u];
+            if (HAS_HI) k_hi[r] = hi[u];
+            hs[u] = (uint32_t)(((key_hash(lo[u], mn[u], hi[u], HAS_HI) & 0xffffffffull) * kPartSlots) >> 32);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t u = 0; u < R; ++u) {
+        const uint32_t r = u * kGroupThreads + t;
+        if (r >= n) continue;
+        uint32_t h = hs[u];
+        for (;;) {                                        // ends: the table has about twice as many slots as a part has records
+            uint32_t cur = slot[h];
+            if (cur == 0) cur = atomicCAS(&slot[h], 0u, r + 1);
+            if (cur == 0) break;                          // claimed
+            const uint32_t c = (cur & 0x1fffu) - 1;
+            if (k_lo[c] == lo[u] && k_mn[c] == mn[u] && (!HAS_HI || k_hi[c] == hi[u])) break;
+            h = h + 1 == (uint32_t)kPartSlots ? 0u : h + 1;
+        }
+        hs[u] = h;
+        rank[u] = atomicAdd(&slot[h], 1u << 13) >> 13;
+    }
+    __syncthreads();
+    uint32_t cnt[R];
+    bool claimer[R];
+#pragma unroll
+    for (uint32_t u = 0; u < R; ++u) {
+        const uint32_t r = u * kGroupThreads + t;
+        const uint32_t w = r < n ? slot[hs[u]] : 0u;
+        cnt[u] = w >> 13;
+        claimer[u] = r < n && (w & 0x1fffu) == r + 1;
+    }
+    __syncthreads();
+    const uint32_t ids_base = p * (4u * kPartCap);
+#pragma unroll
+    for (uint32_t u = 0; u < R; ++u) {
+        if (!claimer[u] || cnt[u] < 2) continue;          // one thread per key held by >= 2 sketches
+        const uint32_t o = ids_base + atomicAdd(cursor, list_u16(cnt[u]));   // 8 u16 per 2..7 records: fits 4 x kPartCap
+        ids[o] = (uint16_t)cnt[u];                        // a key is held at most once per sketch: <= 65535
+        slot[hs[u]] = o;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t u = 0; u < R; ++u) {
+        const uint32_t r = u * kGroupThreads + t;
+        if (r >= n) continue;
+        if (cnt[u] < 2) { list_of_entry[en[u]] = kNoList; continue; }    // held by one sketch: no pair to count
+        const uint32_t o = slot[hs[u]];
+        ids[o + 1 + rank[u]] = (uint16_t)sk[u];
+        list_of_entry[en[u]] = list_ref(o, cnt[u]);
     }
 }
 
@@ -349,7 +610,7 @@ __global__ __launch_bounds__(kAccThreads) void k_accumulate(const uint32_t* __re
                                                            uint32_t* __restrict__ host_flags, bool add) {
     // every pass that can raise a flag has finished: hand them to the host (pinned memory) from here, so the
     // pipeline ends with this kernel and not with a device-to-host copy behind it
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 6) host_flags[threadIdx.x] = flags[threadIdx.x];
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < kFlags) host_flags[threadIdx.x] = flags[threadIdx.x];
     const uint32_t i = row_first + blockIdx.y * row_stride;
     if (i >= n || i >= row_limit) return;
     const uint32_t wb = blockIdx.x;                         // block of 64 words
@@ -446,6 +707,12 @@ struct CompareJob {
     bool sparse = false;
     uint32_t passes = 1, pass = 0;  // large builds: the keys are split into classes and the dictionary + colour
                                     // matrix are built class by class, so the matrix never exceeds its budget
+    // partition form (flat entry point): see k_parts_scatter
+    std::function<int(uint32_t n_parts)> scatter_parts;
+    std::function<int(uint32_t n_parts)> group_parts;
+    bool parts = false;
+    uint32_t n_parts = 0, parts_attempt = 0, n_sub = 0;
+    bool bracket_closed = false;    // the kEvCompare bracket of the begin call has been closed already
 };
 // flags: [0] unsorted input, [1] fingerprint collision, [2] n_rows, [3] malformed slot, [4] slot overflow, [5] table full
 static uint64_t job_fp_mask(const CompareJob& J) {
@@ -453,6 +720,54 @@ static uint64_t job_fp_mask(const CompareJob& J) {
     static const char* dbg_fp = getenv("SPSP_DEBUG_FP_BITS");
     return (dbg_fp && J.attempt == 0) ? ((1ull << atoi(dbg_fp)) - 1) : ~0ull;
 }
+// what compare_end waits on: the job's last queued kernel / copy, not the whole stream
+static int job_mark_done(spsp_ctx* ctx) {
+    if (!ctx->compare_done) SPSP_HIP(hipEventCreateWithFlags(&ctx->compare_done, hipEventDisableTiming));
+    SPSP_HIP(hipEventRecord(ctx->compare_done, ctx->stream));
+    return SPSP_OK;
+}
+static int launch_accumulate_sparse(spsp_ctx* ctx, const ComparePlan& P, uint32_t* flags) {
+    uint32_t cols = 64;
+    while (cols < P.n && cols < (uint32_t)kSparseCols) cols <<= 1;
+    // a row's keys are walked by ONE workgroup unless the sketches are huge (few sketches of millions of keys):
+    // then slices of the row add into cells cleared first
+    const uint64_t per_row = P.n_own ? P.S_own / P.n_own : 0;
+    const uint32_t split = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, per_row / 65536), 64);
+    if (split > 1) {
+        hipLaunchKernelGGL(k_zero_rows, dim3(std::max(1u, std::min((P.n + 255) / 256, 64u)), P.n_own), dim3(256), 0, ctx->stream,
+                           P.n, P.row_first, P.row_stride, P.row_limit, P.d_inter);
+        SPSP_HIP(hipGetLastError());
+    }
+    uint32_t copies_log2 = 0;                                // as many copies of the counters as 64 KiB of LDS hold, up to 16
+    while (copies_log2 < 4 && ((size_t)cols << (copies_log2 + 1)) * 4 <= (size_t)kSparseCols * 4) ++copies_log2;
+    hipLaunchKernelGGL(k_accumulate_sparse, dim3((P.n + cols - 1) / cols, P.n_own, split), dim3(kSparseThreads),
+                       ((size_t)cols << copies_log2) * 4, ctx->stream,
+                       ctx->c_row.as<uint32_t>(), ctx->c_matrix.as<uint16_t>(), P.sk_begin, P.sk_end,
+                       P.n, P.row_first, P.row_stride, P.row_limit, cols, copies_log2, split, P.d_inter, flags,
+                       reinterpret_cast<uint32_t*>(ctx->h_scalar + 8));
+    SPSP_HIP(hipGetLastError());
+    return SPSP_OK;
+}
+// partition form: prepare -> scatter -> group -> row sums, queued in one go
+static int job_parts(spsp_ctx* ctx, CompareJob& J) {
+    uint32_t* flags = ctx->c_flags.as<uint32_t>();
+    int rc;
+    if ((rc = ctx->c_part_cnt.reserve((size_t)J.n_parts * 4))) return rc;
+    if ((rc = ctx->c_matrix.reserve((size_t)J.n_parts * 4 * kPartCap * sizeof(uint16_t)))) return rc;     // sketch lists
+    const uint32_t most = std::max(std::max(J.n_parts, J.n_skoff), J.n_sub);
+    hipLaunchKernelGGL(k_parts_prepare, dim3(std::min<uint32_t>((most + 255) / 256, 64u)), dim3(256), 0, ctx->stream,
+                       ctx->c_part_cnt.as<uint32_t>(), J.n_parts, flags, (const uint64_t*)ctx->h_skoff,
+                       ctx->c_skoff.as<uint64_t>(), J.n_skoff, reinterpret_cast<const uint32_t*>(ctx->h_skoff + J.n_skoff),
+                       reinterpret_cast<uint32_t*>(ctx->c_skoff.as<uint64_t>() + J.n_skoff), J.n_sub);
+    SPSP_HIP(hipGetLastError());
+    if ((rc = J.scatter_parts(J.n_parts))) return rc;
+    if ((rc = J.group_parts(J.n_parts))) return rc;
+    if ((rc = ctx->ev_begin(kEvAccumulate))) return rc;
+    if ((rc = launch_accumulate_sparse(ctx, J.P, flags))) return rc;
+    if ((rc = ctx->ev_end(kEvAccumulate))) return rc;
+    return job_mark_done(ctx);
+}
+
 // sparse form: the whole pipeline in one go (no size depends on a count the host has to read)
 static int job_sparse(spsp_ctx* ctx, CompareJob& J) {
     uint32_t* flags = ctx->c_flags.as<uint32_t>();
@@ -472,11 +787,9 @@ static int job_sparse(spsp_ctx* ctx, CompareJob& J) {
     SPSP_HIP(hipGetLastError());
     if ((rc = J.fill_sparse())) return rc;
     if ((rc = ctx->ev_begin(kEvAccumulate))) return rc;
-    hipLaunchKernelGGL(k_accumulate_sparse, dim3((P.n + kSparseCols - 1) / kSparseCols, P.n), dim3(kSparseThreads), 0, ctx->stream,
-                       ctx->c_row.as<uint32_t>(), ctx->c_matrix.as<uint16_t>(), P.sk_begin, P.sk_end,
-                       P.n, P.d_inter, flags, reinterpret_cast<uint32_t*>(ctx->h_scalar + 8));
-    SPSP_HIP(hipGetLastError());
-    return ctx->ev_end(kEvAccumulate);
+    if ((rc = launch_accumulate_sparse(ctx, P, flags))) return rc;
+    if ((rc = ctx->ev_end(kEvAccumulate))) return rc;
+    return job_mark_done(ctx);
 }
 
 // dictionary build: table (and row ids unless the owner's entry index serves as the row)
@@ -516,18 +829,19 @@ static int job_back(spsp_ctx* ctx, CompareJob& J, uint64_t rows) {
                        P.n, P.row_first, P.row_stride, P.row_limit, P.d_inter, ctx->c_flags.as<uint32_t>(),
                        reinterpret_cast<uint32_t*>(ctx->h_scalar + 8), J.pass > 0);
     SPSP_HIP(hipGetLastError());
-    return ctx->ev_end(kEvAccumulate);
+    if ((rc = ctx->ev_end(kEvAccumulate))) return rc;
+    return job_mark_done(ctx);
 }
 // the flags travel to pinned host memory as the last item of whatever has been queued ...
 static int job_queue_flags(spsp_ctx* ctx) {
     uint32_t* pinned = reinterpret_cast<uint32_t*>(ctx->h_scalar + 8);
-    SPSP_HIP(hipMemcpyAsync(pinned, ctx->c_flags.p, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
-    return SPSP_OK;
+    SPSP_HIP(hipMemcpyAsync(pinned, ctx->c_flags.p, kFlags * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    return job_mark_done(ctx);
 }
 // ... and are read after the one synchronisation
 static int job_wait_flags(spsp_ctx* ctx, uint32_t* h_flags) {
-    SPSP_HIP(hipStreamSynchronize(ctx->stream));
-    memcpy(h_flags, ctx->h_scalar + 8, 6 * sizeof(uint32_t));
+    SPSP_HIP(hipEventSynchronize(ctx->compare_done));
+    memcpy(h_flags, ctx->h_scalar + 8, kFlags * sizeof(uint32_t));
     if (h_flags[5]) { set_error("dictionary table overflow (internal sizing error)"); return SPSP_ERR_HIP; }
     if (h_flags[3]) { set_error("malformed exchange slot (header, sketch count or key count does not match)"); return SPSP_ERR_FORMAT; }
     if (h_flags[4]) { set_error("an exchange slot overflowed its capacity: partition again with a larger slot_cap"); return SPSP_ERR_OVERFLOW; }
@@ -535,9 +849,8 @@ static int job_wait_flags(spsp_ctx* ctx, uint32_t* h_flags) {
     return SPSP_OK;
 }
 
-// takes ownership of `job`; on success it is pending on the context until compare_job_end
-static int compare_job_begin(spsp_ctx* ctx, CompareJob* job) {
-    std::unique_ptr<CompareJob> J(job);
+// global-dictionary forms (dense colour matrix / sketch lists): plan and queue the first attempt
+static int job_begin_dictionary(spsp_ctx* ctx, CompareJob* J) {
     const ComparePlan& P = J->P;
     int rc;
     J->W = (P.n + 63) / 64;
@@ -551,7 +864,7 @@ static int compare_job_begin(spsp_ctx* ctx, CompareJob* job) {
     // many sketches, every row owned: sketch lists instead of colour rows (SPSP_DEBUG_SPARSE=1/0 forces the choice)
     static const char* dbg_sparse = getenv("SPSP_DEBUG_SPARSE");
     const bool all_owned = P.row_stride == 1 && P.row_first == 0 && P.row_limit >= P.n && P.n_own == P.n;
-    J->sparse = J->insert_sparse && all_owned && 2 * P.S_entries < 0xfffffff0ull &&
+    J->sparse = J->insert_sparse && all_owned && 8 * P.S_entries < 0xffffff00ull &&
                 (dbg_sparse ? atoi(dbg_sparse) != 0 : (J->W >= 64 && !dbg_budget));
     if (J->sparse) J->speculative = true;       // queued in one go, checked once
     // Large builds: the colour matrix is rows x N bits and grows with N * (distinct keys) -- at tens of thousands of
@@ -586,13 +899,39 @@ static int compare_job_begin(spsp_ctx* ctx, CompareJob* job) {
     if ((rc = ctx->c_slot_hi.reserve((size_t)J->cap * 8))) return rc;
     if ((rc = ctx->c_slot_mn.reserve((size_t)J->cap * 4))) return rc;
     if (J->sparse) {
-        if ((rc = ctx->c_matrix.reserve((size_t)2 * P.S_entries * sizeof(uint16_t) + 16))) return rc;   // lists: ids + lengths
+        if ((rc = ctx->c_matrix.reserve((size_t)8 * P.S_entries * sizeof(uint16_t) + 16))) return rc;   // lists: length + ids, in whole 16-byte words
         if ((rc = job_sparse(ctx, *J))) return rc;
     } else {
         if ((rc = job_front(ctx, *J))) return rc;
         if (J->speculative) { if ((rc = job_back(ctx, *J, P.S_own))) return rc; }   // k_accumulate forwards the flags
         else if ((rc = job_queue_flags(ctx))) return rc;                             // the row count is needed first
     }
+    return SPSP_OK;
+}
+
+// records a part is planned to hold on average: kPartCap less the spread of the part sizes (keys shared by c
+// sketches arrive c at a time); halved for the second attempt
+static uint32_t parts_for(uint64_t entries, uint32_t attempt) {
+    const uint64_t mean = attempt == 0 ? 2900 : 1400;
+    return (uint32_t)std::max<uint64_t>(1, (entries + mean - 1) / mean);
+}
+
+// takes ownership of `job`; on success it is pending on the context until compare_job_end
+static int compare_job_begin(spsp_ctx* ctx, CompareJob* job) {
+    std::unique_ptr<CompareJob> J(job);
+    const ComparePlan& P = J->P;
+    int rc;
+    // Partition form unless a test hook asks for one of the global-dictionary forms (SPSP_DEBUG_PARTS=0 by name)
+    static const bool hooks = getenv("SPSP_DEBUG_MATRIX_BUDGET") || getenv("SPSP_DEBUG_SPARSE") || getenv("SPSP_DEBUG_FP_BITS");
+    static const char* dbg_parts = getenv("SPSP_DEBUG_PARTS");
+    J->parts = J->scatter_parts && (dbg_parts ? atoi(dbg_parts) != 0 : !hooks) &&
+               parts_for(P.S_entries, 1) <= (uint32_t)kMaxKeyParts;
+    if (J->parts) {
+        J->speculative = true;                      // queued in one go, checked once
+        J->n_parts = parts_for(P.S_entries, 0);
+        if ((rc = ctx->c_row.reserve((size_t)P.S_entries * 4))) return rc;
+        if ((rc = job_parts(ctx, *J))) return rc;
+    } else if ((rc = job_begin_dictionary(ctx, J.get()))) return rc;
     ctx->compare_job = J.release();
     return SPSP_OK;
 }
@@ -602,8 +941,25 @@ int compare_job_end(spsp_ctx* ctx) {
     std::unique_ptr<CompareJob> J(ctx->compare_job);
     ctx->compare_job = nullptr;
     int rc;
+    while (J->parts) {
+        uint32_t h_flags[kFlags];
+        if ((rc = job_wait_flags(ctx, h_flags))) return rc;
+        if (!h_flags[6]) return SPSP_OK;
+        // a part overflowed (many sketches share their keys): once more with parts half the size, then the
+        // global-dictionary forms, which have no such limit
+        J->bracket_closed = true;
+        if (J->parts_attempt == 0 && parts_for(J->P.S_entries, 1) <= (uint32_t)kMaxKeyParts) {
+            J->parts_attempt = 1;
+            J->n_parts = parts_for(J->P.S_entries, 1);
+            if ((rc = job_parts(ctx, *J))) return rc;
+            continue;
+        }
+        J->parts = false;
+        J->clear_all_flags = true;
+        if ((rc = job_begin_dictionary(ctx, J.get()))) return rc;
+    }
     for (;;) {
-        uint32_t h_flags[6];
+        uint32_t h_flags[kFlags];
         bool collided = false;
         if (J->speculative) {
             if ((rc = job_wait_flags(ctx, h_flags))) return rc;              // collisions surface in the fill pass
@@ -612,7 +968,7 @@ int compare_job_end(spsp_ctx* ctx) {
             for (;;) {   // key class by key class; the first class (front part) was queued by the begin call / the retry below
                 if ((rc = job_wait_flags(ctx, h_flags))) return rc;          // the row count sizes the colour matrix
                 if ((rc = job_back(ctx, *J, h_flags[2]))) return rc;
-                if (J->attempt == 0 && J->pass + 1 == J->passes && (rc = ctx->ev_end(kEvCompare))) return rc;   // bracket of the begin call
+                if (J->attempt == 0 && J->pass + 1 == J->passes && !J->bracket_closed && (rc = ctx->ev_end(kEvCompare))) return rc;   // bracket of the begin call
                 if ((rc = job_wait_flags(ctx, h_flags))) return rc;          // collisions of this class
                 if (h_flags[1]) { collided = true; break; }
                 if (++J->pass == J->passes) break;
@@ -639,7 +995,10 @@ void compare_job_drop(spsp_ctx* ctx) {
 
 // pinned copy of the caller's offsets: the queued H2D copy must not read memory the caller may free
 static int stage_sk_off(spsp_ctx* ctx, const uint64_t* h_sk_off, uint32_t n) {
-    const size_t need = (size_t)(n + 1);
+    // n + 1 offsets, then (partition form) one u32 per sub-chunk of kScatSub entries: the sketch holding its first entry
+    const uint64_t S = h_sk_off[n];
+    const size_t n_sub = (size_t)((S + kScatSub - 1) / kScatSub);
+    const size_t need = (size_t)(n + 1) + (n_sub + 1) / 2;
     if (ctx->h_skoff_cap < need) {
         if (ctx->h_skoff) { SPSP_HIP(hipStreamSynchronize(ctx->stream)); (void)hipHostFree(ctx->h_skoff); ctx->h_skoff = nullptr; ctx->h_skoff_cap = 0; }
         size_t cap = 1024;
@@ -647,7 +1006,14 @@ static int stage_sk_off(spsp_ctx* ctx, const uint64_t* h_sk_off, uint32_t n) {
         SPSP_HIP(hipHostMalloc((void**)&ctx->h_skoff, cap * 8, hipHostMallocDefault));
         ctx->h_skoff_cap = cap;
     }
-    memcpy(ctx->h_skoff, h_sk_off, need * 8);   // k_prepare copies it to c_skoff; no job is pending, so the stream has drained
+    memcpy(ctx->h_skoff, h_sk_off, (size_t)(n + 1) * 8);   // the prepare kernel copies it to c_skoff; no job is pending, so the stream has drained
+    uint32_t* sub = reinterpret_cast<uint32_t*>(ctx->h_skoff + n + 1);
+    uint32_t j = 0;
+    for (size_t c = 0; c < n_sub; ++c) {
+        const uint64_t e = (uint64_t)c * kScatSub;
+        while (j + 1 < n && h_sk_off[j + 1] <= e) ++j;
+        sub[c] = j;
+    }
     return ctx->c_skoff.reserve(need * 8);
 }
 
@@ -718,6 +1084,42 @@ static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t*
         SPSP_HIP(hipGetLastError());
         return SPSP_OK;
     };
+    const bool has_hi = K.hi != nullptr;
+    const uint32_t* sub_sk = reinterpret_cast<const uint32_t*>(sk + n + 1);
+    J->n_sub = (uint32_t)((S + kScatSub - 1) / kScatSub);
+    J->scatter_parts = [=](uint32_t n_parts) -> int {
+        int r2 = ctx->c_recs.reserve((size_t)n_parts * kPartCap * (has_hi ? 32 : 24));
+        if (r2) return r2;
+        const uint32_t per_wg = 4u * kScatThreads;
+        const dim3 grid((uint32_t)((S + per_wg - 1) / per_wg));
+#define SPSP_SCATTER(HI, E) hipLaunchKernelGGL((k_parts_scatter<HI, E>), grid, dim3(kScatThreads), 0, ctx->stream, K, sk, n, sub_sk, S, \
+                                               n_parts, ctx->c_part_cnt.as<uint32_t>(), ctx->c_recs.as<uint64_t>(), flags)
+        if (has_hi) SPSP_SCATTER(true, 4);
+        else SPSP_SCATTER(false, 4);
+#undef SPSP_SCATTER
+        SPSP_HIP(hipGetLastError());
+        return SPSP_OK;
+    };
+    J->group_parts = [=](uint32_t n_parts) -> int {
+        const size_t lds = (size_t)kPartCap * (8 + (has_hi ? 8 : 0) + 4) + (size_t)kPartSlots * 4 + 16;
+        if (has_hi) {
+            if (!ctx->attr_group_hi_set) {
+                SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_parts_group<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                ctx->attr_group_hi_set = true;
+            }
+            hipLaunchKernelGGL(k_parts_group<true>, dim3(n_parts), dim3(kGroupThreads), lds, ctx->stream, ctx->c_recs.as<uint64_t>(),
+                               ctx->c_part_cnt.as<uint32_t>(), ctx->c_matrix.as<uint16_t>(), ctx->c_row.as<uint32_t>(), flags);
+        } else {
+            if (!ctx->attr_group_set) {
+                SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_parts_group<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                ctx->attr_group_set = true;
+            }
+            hipLaunchKernelGGL(k_parts_group<false>, dim3(n_parts), dim3(kGroupThreads), lds, ctx->stream, ctx->c_recs.as<uint64_t>(),
+                               ctx->c_part_cnt.as<uint32_t>(), ctx->c_matrix.as<uint16_t>(), ctx->c_row.as<uint32_t>(), flags);
+        }
+        SPSP_HIP(hipGetLastError());
+        return SPSP_OK;
+    };
     return compare_job_begin(ctx, J);
 }
 
@@ -756,7 +1158,7 @@ __device__ __forceinline__ uint32_t part_of(uint64_t lo, uint32_t mn, uint64_t h
 // sender 1/3: keys of sketch j per destination
 __global__ __launch_bounds__(kPartThreads) void k_part_count(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n,
                                                             uint32_t parts, uint32_t* __restrict__ cnt /* [parts][n] */) {
-    __shared__ uint32_t hist[kMaxParts];
+    __shared__ uint32_t hist[kMaxKeyParts];
     const uint32_t j = blockIdx.x, t = threadIdx.x;
     if (t < kMaxParts) hist[t] = 0;
     __syncthreads();

@@ -77,6 +77,7 @@ struct spsp_ctx {
     // begin/end bracket for one timed region; no-ops unless timing is on
     int ev_begin(int kind);
     int ev_end(int kind);
+    bool ev_open[spsp::kEvKinds] = {false, false, false, false};   // a begin without its end is outstanding
     int device = 0;
     int n_cu = 256;
     hipStream_t stream = nullptr;
@@ -87,7 +88,7 @@ struct spsp_ctx {
     hipEvent_t tail_event = nullptr;   // spsp_wait_stream: marks the current end of this context's stream
     hipEvent_t scan_done = nullptr;    // behind the last kernel of the queued scan: what spsp_scan_device_end waits on
     hipEvent_t compare_done = nullptr; // likewise for the queued comparison
-    bool attr_pair_set = false, attr_single_set = false, attr_bloom_set = false;   // dynamic-LDS attributes set on this context's device
+    bool attr_pair_set = false, attr_single_set = false, attr_bloom_set = false, attr_group_set = false, attr_group_hi_set = false;   // dynamic-LDS attributes set on this context's device
     spsp::ScanJob scan_job;
     spsp::CompareJob* compare_job = nullptr;
     uint64_t* h_skoff = nullptr;       // pinned staging for the sketch offsets of a queued comparison
@@ -111,7 +112,7 @@ struct spsp_ctx {
     // ingest workspace (GPU-side getLineFasta + clean_dna)
     spsp::DevBuf i_text, i_tiles, i_entry, i_outoff, i_recbase, i_lens, i_dst, i_compact;
     // compare workspace
-    spsp::DevBuf c_min, c_lo, c_hi, c_table, c_owner, c_rowid, c_row, c_matrix, c_inter, c_flags, c_skoff, c_slot_lo, c_slot_hi, c_slot_mn;
+    spsp::DevBuf c_min, c_lo, c_hi, c_table, c_owner, c_rowid, c_row, c_matrix, c_inter, c_flags, c_skoff, c_slot_lo, c_slot_hi, c_slot_mn, c_part_cnt, c_recs;
     spsp::DevBuf x_cnt, x_off, x_begin, x_end, x_tot;   // key-partitioned exchange (spsp_compare.hip)
 };
 

@@ -326,7 +326,8 @@ def test_capped_colour_matrix_runs_key_class_passes():
 
 
 def test_sparse_list_form_many_sketches(ctx):
-    """4 300 sketches (67 colour words): the comparison takes the sketch-list form by itself.  Checked against a
+    """4 300 sketches (67 colour words): partition form (default) -- with SPSP_DEBUG_PARTS=0 the global-dictionary
+    comparison takes the sketch-list form by itself (test_many_sketches_global_dictionary).  Checked against a
     plain Python count of shared keys over all 9.2 million pairs."""
     rng = np.random.default_rng(123)
     n = 4300
@@ -429,8 +430,36 @@ def test_comparison_forms_agree_on_random_inputs():
         "    digest.update(inter.tobytes())\n"
         "print('digest', digest.hexdigest())\n") % (ROOT, os.path.join(ROOT, "tests"))
     digests = []
-    for env in ({}, {"SPSP_DEBUG_SPARSE": "1"}, {"SPSP_DEBUG_MATRIX_BUDGET": "9000"}, {"SPSP_DEBUG_SPARSE": "0"}):
+    # {} = the partition form (LDS dictionary per key class), the others force the global-dictionary forms
+    for env in ({}, {"SPSP_DEBUG_SPARSE": "1"}, {"SPSP_DEBUG_MATRIX_BUDGET": "9000"}, {"SPSP_DEBUG_SPARSE": "0"}, {"SPSP_DEBUG_PARTS": "0"}):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0 and "digest" in r.stdout, (env, r.stdout[-2000:], r.stderr[-3000:])
         digests.append(r.stdout.strip().split()[-1])
     assert len(set(digests)) == 1
+
+
+def test_many_sketches_global_dictionary():
+    """the same 4 300 sketches with the partition form switched off: sketch-list form over the global dictionary"""
+    code = ("import sys\nsys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import supersampler_amd as sp, test_exchange as tx\n"
+            "ctx = sp.Context(0)\ntx.test_sparse_list_form_many_sketches(ctx)\nprint('ok')\n") % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SPSP_DEBUG_PARTS="0"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_partition_form_overflow_falls_back(ctx):
+    """600 sketches holding the SAME 4 000 keys (+ a few private ones): every key class receives its keys 600 at a
+    time, the fixed-capacity parts overflow on both attempts and the global-dictionary form takes over."""
+    rng = np.random.default_rng(77)
+    n = 600
+    shared = np.unique(rng.integers(1, 2**62, size=4000, dtype=np.int64)).astype(np.uint64)
+    sketches, sets = [], []
+    for i in range(n):
+        extra = np.unique(rng.integers(1, 2**62, size=i % 5, dtype=np.int64)).astype(np.uint64)
+        keys = np.unique(np.concatenate([shared, extra]))
+        sets.append(keys)
+        sketches.append(sp.Sketch(31, 11, np.full(len(keys), 9, np.uint32), keys, np.zeros(len(keys), np.uint64)))
+    inter, card = ctx.compare(sketches)
+    assert [int(c) for c in card] == [len(s) for s in sets]
+    want = np.triu(np.full((n, n), len(shared), dtype=np.uint32), 1)
+    assert (inter == want).all()
