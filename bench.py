@@ -11,11 +11,16 @@ N > 1: genomes are sharded by rank (no data-path collective for the scan); the
 comparison all-gathers the packed sketch keys over RCCL and every rank owns the
 rows i % N == rank of the (100 N) x (100 N) pair matrix.
 
+Besides the timed step, rank 0 of a single-GPU run measures (untimed, after the
+step loop) the comparator alone at BASELINE configs[2] scale (`compare`) and
+the whole-file drivers end to end (`end_to_end`), each beside the oracle.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -43,6 +48,16 @@ def log(msg):
     print("[bench] " + msg, file=sys.stderr, flush=True)
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def main():
     # stdout carries exactly ONE JSON line: anything native libraries print there (RCCL's version banner,
     # for one) is sent to stderr by pointing fd 1 at fd 2 until the result is written
@@ -57,6 +72,7 @@ def main():
     ap.add_argument("--length", type=int, default=GENOME_LEN)
     ap.add_argument("--mode", choices=["default", "direct", "filter", "pair"], default="default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the `compare` (config 3) and `end_to_end` objects")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -79,23 +95,23 @@ def main():
     flags = {"default": sp.SPSP_SCAN_DEFAULT, "direct": sp.SPSP_SCAN_DIRECT_HASH, "filter": sp.SPSP_SCAN_LDS_FILTER,
              "pair": sp.SPSP_SCAN_PAIR_FILTER}[args.mode]
     p = sp.make_params(K, M, S, flags=flags)
-    # ONE explicit HIP stream for everything in a step: torch copies/collectives (RCCL orders itself against the
-    # current stream) and libspsp's kernels (the context is created on the same stream handle)
+    # ONE explicit HIP stream for the torch side (copies, collectives: RCCL orders itself against the current stream)
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     ctx = sp.Context(local_rank, stream.cuda_stream)
-    # Pipelined step (default): the scan of one batch and the all-vs-all of the previous batch's sketches are
-    # independent, so they are queued on TWO HIP streams (two contexts, the begin/end forms of the ABI): the dense
-    # pass has the GPU to itself (stream order / spsp_wait_dense), then the
-    # latency-bound sparse stages of the scan and the comparison fill each other's idle CUs.  The host stays one
-    # step ahead: two such stream pairs alternate, step t+1 is queued before step t is collected, so the GPU never
-    # waits for the host.  BENCH_PIPELINE=0 runs the two halves back to back on one stream, one step at a time.
+    # Pipelined step (default): two slots alternate, each with a scan stream and a comparison stream.  The only
+    # ordering between them: the dense pass of step t+1 starts behind the dense pass of step t (spsp_wait_dense), and
+    # the comparison of step t behind its own dense pass.  The dense kernels -- the HBM-bound part -- never run two
+    # at once; the latency-bound sparse stages and the comparison of step t get their CUs in the gap between two
+    # dense passes and finish beside the next one.  The host queues step t+1 before it collects step t (scan_end /
+    # compare_end wait on per-job events, not on the streams).
+    # BENCH_PIPELINE=0 runs the two halves back to back on one stream, one step at a time.
     pipelined = os.environ.get("BENCH_PIPELINE", "1") != "0"
-    strict_order = os.environ.get("BENCH_STRICT_ORDER") == "1"
-    # BENCH_FREE_RUN=1 (experiment): no ordering between the streams at all -- every scan on its own stream, the
-    # comparison does not wait for the dense pass.  Highest throughput when the dense kernel leaves room on the CUs
-    # (SPSP_PAIR_BLOCKS_PER_CU=1), but the dense kernel then shares the GPU and its roofline figure drops.
-    free_run = os.environ.get("BENCH_FREE_RUN") == "1"
+    # BENCH_SCHEDULE: "streams" = as above (measured best: 0.153 ms); "tail" = both scans on ONE stream, their sparse
+    # stages on spsp_scan_tail_stream streams (0.19 ms: a dense pass that fills every wave slot leaves the sparse
+    # kernels no CU until it ends); "single" = all scans in order on one stream (0.18 ms)
+    schedule = os.environ.get("BENCH_SCHEDULE", "streams")
+    tail_streams = schedule == "tail"
 
     class Slot:
         pass
@@ -104,9 +120,10 @@ def main():
     for i in range(2 if pipelined else 1):
         sl = Slot()
         if pipelined:
-            # the scans of all steps share stream A: in order, no event waits (own workspace and results per slot)
-            sl.stream_a = stream if (i == 0 or not free_run) else torch.cuda.Stream(device=dev)
+            sl.stream_a = stream if (i == 0 or schedule != "streams") else torch.cuda.Stream(device=dev)
             sl.scan = ctx if i == 0 else sp.Context(local_rank, sl.stream_a.cuda_stream)
+            if tail_streams:
+                sl.scan.scan_tail_stream(True)
             sl.stream_b = torch.cuda.Stream(device=dev)
             sl.cmp = sp.Context(local_rank, sl.stream_b.cuda_stream)
         else:
@@ -150,7 +167,9 @@ def main():
     n_total = args.genomes * world
     my_sk_off = np.zeros(args.genomes + 1, dtype=np.uint64)
     my_sk_off[1:] = np.cumsum(my_n)
-    exchange_kind = os.environ.get("BENCH_EXCHANGE", "slots") if use_dist else "none"
+    # multi-GPU exchange: north_star's form (RCCL all-gather of the packed keys + strided row ownership) by default;
+    # BENCH_EXCHANGE=slots selects the key-partitioned all-to-all + partial-matrix reduction (DESIGN.md 5 prices both)
+    exchange_kind = os.environ.get("BENCH_EXCHANGE", "gather") if use_dist else "none"
     if exchange_kind == "slots":      # key-partitioned: all-to-all of own keys + all-reduce of partial matrices
         for sl in slots:
             sl.exchange = spd.SlotExchange(sl.cmp, K, args.genomes, int(my_sk_off[-1]), dev)
@@ -176,17 +195,14 @@ def main():
     scan_args = (p, d_bases.data_ptr(), d_bases.numel(), d_off.data_ptr(), len(recs))
 
     def queue_step(sl, prev, nxt=None):
-        """queue one whole step on slot sl without waiting for anything; on the GPU it starts behind slot prev.
-        nxt = the slot of the following step (its key exchange is started from here, behind this dense pass)"""
-        # stream A: behind the previous step's scan.  The previous comparison is all but done by then (its last
-        # kernel may overlap the start of this dense pass); a full spsp_wait_stream(prev.cmp) costs more in
-        # cross-queue latency than that overlap (BENCH_STRICT_ORDER=1 adds it).
-        if prev is not None and strict_order:
-            sl.scan.wait_stream(prev.cmp)
-        sl.scan.scan_device_begin(*scan_args)
+        """queue one whole step on slot sl without waiting for anything; on the GPU its dense pass starts behind
+        the dense pass of slot prev.  nxt = the slot of the following step (slots exchange: its key partition is
+        started from here, behind this dense pass)"""
+        if prev is not None and prev.stream_a is not sl.stream_a:
+            sl.scan.wait_dense(prev.scan)                 # "streams": dense passes never overlap each other
+        sl.scan.scan_device_begin(*scan_args)             # "tail" / "single": dense passes in order on the one scan stream
         if exchange_kind == "none":
-            if not free_run:
-                sl.cmp.wait_dense(sl.scan)                # the comparison starts behind A's dense pass
+            sl.cmp.wait_dense(sl.scan)                    # the comparison starts behind this step's dense pass
             sl.cmp.compare_device_begin(K, d_all_min.data_ptr(), d_all_lo.data_ptr(), None, sk_off, n_total, rank, world,
                                         sl.d_inter.data_ptr())                                             # stream B
             return
@@ -204,8 +220,8 @@ def main():
                                             world, sl.d_inter.data_ptr())
 
         if exchange_kind == "slots" and nxt is not None and nxt is not sl and getattr(nxt, "handle", None) is None:
-            # the NEXT step's key partition + RCCL all-to-all: behind this step's dense pass (so the dense kernel keeps the
-            # GPU to itself), long before the next dense pass, and behind the comparison still queued on that stream
+            # the NEXT step's key partition + RCCL all-to-all: behind this step's dense pass, long before the next
+            # comparison needs it, and behind the comparison still queued on that stream
             with torch.cuda.stream(nxt.stream_b):
                 nxt.cmp.wait_dense(sl.scan)
                 nxt.handle = nxt.exchange.begin(d_my_min.data_ptr(), d_my_lo.data_ptr(), None, my_sk_off)
@@ -214,7 +230,7 @@ def main():
         d_out, n_out = sl.scan.scan_device_end()
         if exchange_kind == "slots":
             with torch.cuda.stream(sl.stream_b):
-                sl.exchange.end_collect(sl.d_inter)       # partial pair matrix done -> RCCL all-reduce
+                sl.exchange.end_collect(sl.d_inter)       # partial pair matrix done -> RCCL reduction
         else:
             sl.cmp.compare_end()
         last["n_out"], last["slot"] = n_out, sl
@@ -228,7 +244,7 @@ def main():
                 h = sl.exchange.begin(d_my_min.data_ptr(), d_my_lo.data_ptr(), None, my_sk_off) if exchange_kind == "slots" else None
                 d_out, n_out = ctx.scan_device(*scan_args)
                 if exchange_kind == "slots":
-                    sl.exchange.end(h, sl.d_inter)        # partial pair matrix + RCCL all-reduce
+                    sl.exchange.end(h, sl.d_inter)        # partial pair matrix + RCCL reduction
                 else:
                     if exchange_kind == "gather":
                         g = sl.exchange.exchange(d_my_min, d_my_lo)
@@ -324,8 +340,10 @@ def main():
 
     if rank == 0:
         value = total_kmers_per_step * args.steps / elapsed
+        ms_per_step = elapsed * 1e3 / args.steps
         dense_avg_ms = dense_ms / max(1, tm["dense_launches"])
         achieved = (d_bases.numel() / 1e9) / (dense_avg_ms / 1e3) if dense_avg_ms > 0 else 0.0  # 1 B per position (ASCII)
+        step_achieved = (d_bases.numel() / 1e9) / (ms_per_step / 1e3)
         compare_avg_ms = compare_ms / max(1, tm["compare_calls"])
         out = {
             "metric": "k-mers hashed/s (sketch) + sketch-pairs/s (all-vs-all)",
@@ -334,7 +352,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed * 1e3 / args.steps,
+            "ms_per_step": ms_per_step,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -346,14 +364,15 @@ def main():
                        "sketches_total": n_total, "scan_mode": args.mode,
                        "parallelism": {"none": "single GPU",
                                        "slots": "genomes sharded by rank; sketch keys partitioned by hash, RCCL all-to-all behind "
-                                                "the scan, per-rank partial pair matrix, RCCL all-reduce",
-                                       "gather": "genomes sharded by rank; pair-matrix rows i%N==rank after RCCL all-gather of "
-                                                 "sketch keys"}[exchange_kind],
+                                                "the scan, per-rank partial pair matrix, RCCL reduction",
+                                       "gather": "genomes sharded by rank; RCCL all-gather of the packed sketch keys, every rank "
+                                                 "computes the pair-matrix rows i % N == rank (SURVEY.md 8e)"}[exchange_kind],
                        "exchange_check": exchange_check,
-                       "step": ("scan(batch t) on stream A || all-vs-all(sketches of batch t-1) on stream B; two stream pairs "
-                                "alternate and the host queues step t+1 before collecting step t" if pipelined
+                       "step": ("scan(batch t) || all-vs-all(sketches of batch t-1): two slots with their own scan and comparison "
+                                "streams; dense passes never overlap each other, sparse stages and comparison run between and "
+                                "beside them; the host queues step t+1 before collecting step t [schedule %s]" % schedule if pipelined
                                 else "scan then all-vs-all on one stream, one step at a time")},
-            # with the comparison's own bracket: pairs / its pipeline time; otherwise the sustained rate of the whole step
+            # the rate of the comparison inside the step: its own HIP-event bracket when one was recorded, else pairs per step time
             "sketch_pairs_per_s": (pairs_per_step / (compare_avg_ms / 1e3) if compare_avg_ms > 0
                                    else pairs_per_step * args.steps / elapsed),
             "sketch_pairs_per_s_basis": "compare pipeline (HIP events)" if compare_avg_ms > 0 else "whole step (scan + all-vs-all)",
@@ -364,11 +383,23 @@ def main():
             "host_ms_per_step": {"queueing": host["queue"] * 1e3 / args.steps, "waiting": host["collect"] * 1e3 / args.steps},
             "roofline": {"kernel": "k_dense_pair (2-bit pack + LDS pair-table test of every m-mer position; XXH64 on survivors)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(args),
-                         "algorithmic_bytes_per_launch": int(d_bases.numel())},
+                         "traffic": None, "algorithmic_bytes_per_launch": int(d_bases.numel()),
+                         "byte_model": "1 B per m-mer position (cleaned ASCII, as getLineFasta returns it)",
+                         # the whole step against the same roofline: bytes of one batch / ms_per_step
+                         "step_achieved": step_achieved, "step_frac": step_achieved / HBM_PEAK_GBS},
         }
+        out["roofline"].update(pmc_traffic(args, "k_dense_pair"))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(recs, payloads, p, int(n_out), d_inter)
+        if world == 1 and not args.no_extras:
+            try:
+                out["compare"] = compare_config3(ctx, dev, args.no_cpu_baseline)
+            except Exception as e:  # noqa: BLE001 -- an extra must not take the headline down
+                out["compare"] = {"error": repr(e)}
+            try:
+                out["end_to_end"] = end_to_end(ctx, args.no_cpu_baseline)
+            except Exception as e:  # noqa: BLE001
+                out["end_to_end"] = {"error": repr(e)}
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
@@ -376,18 +407,22 @@ def main():
         dist.destroy_process_group()
 
 
-def pmc_traffic(args):
-    """HBM bytes per launch of the dense kernel from the PMC counters (FETCH_SIZE/WRITE_SIZE, separate
-    rocprofv3 --pmc passes of this same command, gfx950 correction applied: profiles/r01_d_pmc_hbm_traffic.json).
-    Counters cannot be read from inside this process, so the figure is looked up for the matching workload."""
+def pmc_traffic(args, kernel):
+    """HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes of this
+    same command, gfx950 correction applied).  Counters cannot be read from inside this process: the figure comes from
+    the committed profile of the matching workload, with its provenance; null when there is none."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_d_pmc_hbm_traffic.json")))
+        name = os.environ.get("BENCH_PMC_FILE", "r02_pmc_hbm_traffic.json")
+        path = os.path.join(ROOT, "profiles", name)
+        d = json.load(open(path))
         w = d["workload"]
         if (w["genomes"], w["genome_len"], w["k"], w["m"], w["s"], w["scan_mode"]) != (args.genomes, args.length, K, M, S, args.mode):
-            return None
-        return d["kernels"]["k_dense_pair"]["hbm_bytes_per_launch_corrected"]
+            return {"traffic": None}
+        return {"traffic": d["kernels"][kernel]["hbm_bytes_per_launch_corrected"],
+                "traffic_provenance": {"file": "profiles/" + name, "commit": d.get("commit"),
+                                       "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled (gfx950)"}}
     except Exception:
-        return None
+        return {"traffic": None}
 
 
 def cpu_baseline(recs, payloads, p, gpu_superkmers, d_inter):
@@ -405,14 +440,12 @@ def cpu_baseline(recs, payloads, p, gpu_superkmers, d_inter):
     # the reference parallelises over FILES with OpenMP (SubSampler.cpp:771): same thing with host threads
     # (ctypes releases the GIL), whole records as work items, bounded the same way
     import concurrent.futures as cf
-    import os as _os
-    import time as _time
-    cores = max(1, len(_os.sched_getaffinity(0)))
+    cores = max(1, len(os.sched_getaffinity(0)))
     items = [synth.concat_records([r]) for r in recs[:used]]
-    t0 = _time.perf_counter()
+    t0 = time.perf_counter()
     with cf.ThreadPoolExecutor(cores) as ex:
         res = list(ex.map(lambda bo: orc.scan_timed(K, M, p.threshold, bo[0], bo[1]), items))
-    wall = _time.perf_counter() - t0
+    wall = time.perf_counter() - t0
     all_cores = {"value": sum(r[1] for r in res) / wall if wall > 0 else None, "cores": cores,
                  "sample": "same records, one record per task over %d host threads, %.2f s wall" % (cores, wall)}
     n = len(payloads)
@@ -421,12 +454,197 @@ def cpu_baseline(recs, payloads, p, gpu_superkmers, d_inter):
     if used == len(recs):
         parity["superkmers_per_step"] = bool(emitted == gpu_superkmers)
     return {"parity_vs_oracle": parity, "value": kmers / spent if spent > 0 else None, "unit": "k-mers hashed/s", "cores": 1, "kind": "port",
+            "cpu_model": cpu_model(), "host_threads_available": cores,
+            "build": "oracle/Makefile: g++ " + oracle_flags(),
             "sample": "oracle scan loop (SubSampler.cpp:357-455 restated), single thread, first %d of %d records "
                       "of the same workload, %.1f s" % (used, len(recs), spent),
             "all_cores": all_cores,
             "sketch_pairs_per_s": (n * (n - 1) // 2) / csec if csec > 0 else None,
             "pairs_sample": "oracle compare_sketches (Comparator.cpp:39-287 restated) over the same %d sketches, "
                             "single thread, %.2f s" % (n, csec)}
+
+
+def oracle_flags():
+    try:
+        for line in open(os.path.join(ROOT, "oracle", "Makefile")):
+            if line.startswith("CXXFLAGS"):
+                return line.split("=", 1)[1].strip()
+    except OSError:
+        pass
+    return "?"
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def compare_config3(ctx, dev, skip_oracle):
+    """BASELINE configs[2]: 1000 RefSeq-like sketches (~5 000 k-mers each, 50 families of 20 at mu 0.001/0.01/0.05,
+    sizes spread over 2-8 k keys), all-vs-all on one GPU, keys resident in HBM.  Genomes are shortened and sampled
+    at s=50 so that a sketch still holds ~L/s keys without generating 5 Gbp (SURVEY.md 8d allows direct synthesis;
+    these go through the real scan + sketch builder so that the oracle can read the same payloads)."""
+    n, k, m, s = 1000, 31, 11, 50.0
+    rng = np.random.default_rng(3)
+    fam = n // 20
+    t0 = time.time()
+    genomes = []
+    for f in range(fam):
+        L = int(rng.integers(100_000, 400_000))
+        anc = synth.random_genome(rng, L)
+        for j in range(n // fam):
+            genomes.append(synth.mutate(rng, anc, [0.001, 0.01, 0.05][j % 3]))
+    p = sp.make_params(k, m, s)
+    sketches, payloads = [], []
+    for g in genomes:
+        b, o = synth.concat_records([g])
+        pl, _ = sp.sketch_build(p, s, b, o, ctx.scan(p, b, o))
+        payloads.append(pl)
+        sketches.append(sp.sketch_parse(pl))
+    cnt = np.array([len(x) for x in sketches], dtype=np.int64)
+    d_min = torch.from_numpy(np.concatenate([x.minimizer for x in sketches]).view(np.int32)).to(dev)
+    d_lo = torch.from_numpy(np.concatenate([x.kmer_lo for x in sketches]).view(np.int64)).to(dev)
+    sk_off = np.zeros(n + 1, np.uint64)
+    sk_off[1:] = np.cumsum(cnt)
+    d_inter = torch.zeros((n, n), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    setup_s = time.time() - t0
+    call = lambda: ctx.compare_device(k, d_min.data_ptr(), d_lo.data_ptr(), None, sk_off, n, 0, 1, d_inter.data_ptr())  # noqa: E731
+    for _ in range(3):
+        call()
+    reps = 20
+    ctx.timing_enable(True, sp.TIME_ALL)
+    ctx.timing_read()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        call()
+    torch.cuda.synchronize()
+    wall_ms = (time.perf_counter() - t0) * 1e3 / reps
+    t = ctx.timing_read()
+    ctx.timing_enable(False)
+    ms = t["compare_ms"] / max(1, t["compare_calls"])
+    pairs = n * (n - 1) // 2
+    total = int(cnt.sum())
+    no_reuse = 8.0 * total * (n - 1) + 4.0 * pairs           # sum over pairs of 8 (n_i + n_j) + 4
+    compulsory = 8.0 * total + 4.0 * pairs
+    out = {"workload": "BASELINE configs[2]: %d sketches, %d keys (mean %.0f, min %d, max %d), 50 families x 20, k=31 m=11; "
+                       "keys resident in HBM" % (n, total, cnt.mean(), cnt.min(), cnt.max()),
+           "pairs": pairs, "pipeline_ms": ms, "host_wall_ms_per_call": wall_ms,
+           "sketch_pairs_per_s": pairs / (ms / 1e3) if ms > 0 else None,
+           "kernel_ms": {"k_parts_scatter": t["scatter_ms"] / max(1, t["scatter_launches"]),
+                         "k_parts_group": t["group_ms"] / max(1, t["group_launches"]),
+                         "k_accumulate_sparse": t["accumulate_ms"] / max(1, t["accumulate_launches"])},
+           "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "no_reuse_model": {"bytes": no_reuse, "achieved": no_reuse / ms / 1e6 if ms > 0 else None,
+                                           "frac": no_reuse / ms / 1e6 / HBM_PEAK_GBS if ms > 0 else None,
+                                           "model": "sum over pairs of 8 (n_i + n_j) + 4 bytes (SURVEY.md 8d); reuse pushes it above 1"},
+                        "compulsory_model": {"bytes": compulsory, "achieved": compulsory / ms / 1e6 if ms > 0 else None,
+                                             "frac": compulsory / ms / 1e6 / HBM_PEAK_GBS if ms > 0 else None,
+                                             "model": "8 sum(n_i) + 4 N(N-1)/2 bytes: every key read once, every cell written once"}},
+           "setup_s": setup_s}
+    out["roofline"].update(pmc_compare())
+    if not skip_oracle:
+        from oracle import oracle_py as orc
+        want, card, sec = orc.compare(payloads, timed=True)
+        got = d_inter.cpu().numpy().astype(np.uint32)
+        out["cpu_baseline"] = {"sketch_pairs_per_s": pairs / sec if sec > 0 else None, "cores": 1, "kind": "port", "cpu_model": cpu_model(),
+                               "sample": "oracle compare_sketches (Comparator.cpp:39-287 restated) over the same %d sketch payloads, "
+                                         "single thread, %.2f s" % (n, sec)}
+        out["parity_vs_oracle"] = bool((np.triu(got, 1) == np.triu(want, 1)).all() and (card == cnt).all())
+        out["nonzero_pairs"] = int(np.count_nonzero(want))
+    return out
+
+
+def pmc_compare():
+    try:
+        name = "r02_compare_pmc_hbm_traffic.json"
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
+        return {"traffic": {kname: v["hbm_bytes_per_launch_corrected"] for kname, v in d["kernels"].items()},
+                "traffic_provenance": {"file": "profiles/" + name, "commit": d.get("commit"),
+                                       "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of tests/tools/compare_bench.py 1000"}}
+    except Exception:
+        return {"traffic": None}
+
+
+def end_to_end(ctx, skip_oracle):
+    """The whole-file drivers, host I/O and PCIe included: spsp_sketch_file over FASTA files on tmpfs (plain and
+    gzip) and spsp_compare_files over the resulting sketches, with the stage times the library keeps, beside the
+    oracle run over the same files (Subsampler::parse_fasta_test SubSampler.cpp:306-510, Comparator::compare_sketches
+    + printers Comparator.cpp:39-74,362-460)."""
+    import gzip
+    import shutil
+    import tempfile
+    n, length = 16, GENOME_LEN
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    tmp = tempfile.mkdtemp(prefix="spsp_e2e_", dir=base)
+    try:
+        gs = synth.family_genomes(7, n, length, 2, MUS)
+        plain, gz, texts = [], [], []
+        for i, g in enumerate(gs):
+            data = synth.to_fasta(g, "g%d" % i, n_records=1 + i % 3)
+            texts.append(data)
+            pth = os.path.join(tmp, "genome%02d.fa" % i)
+            open(pth, "wb").write(data)
+            plain.append(pth)
+            open(pth + ".gz", "wb").write(gzip.compress(data, 1))
+            gz.append(pth + ".gz")
+        kmers = sum(len(g) - K + 1 for g in gs)
+        fasta_bytes = sum(len(t) for t in texts)
+        out = {"workload": "%d synthetic %d bp genomes (2 families) as FASTA files on %s, k=31 m=11 s=1000; one context, one host thread "
+                           "for the sketches (the CLI runs -t of these side by side)" % (n, length, base or "the temp dir"),
+               "kmers": kmers, "fasta_bytes": fasta_bytes}
+        ctx.sketch_file(plain[0], os.path.join(tmp, "warm.gz"), K, M, S)   # buffers, tables
+        for label, files in (("plain", plain), ("gzip", gz)):
+            ctx.stage_times(reset=True)
+            t0 = time.perf_counter()
+            outs = []
+            for i, f in enumerate(files):
+                o = os.path.join(tmp, "sk_%s_%02d.gz" % (label, i))
+                ctx.sketch_file(f, o, K, M, S)
+                outs.append(o)
+            wall = time.perf_counter() - t0
+            st = ctx.stage_times(reset=True)
+            out["sketch_" + label] = {"wall_s": wall, "kmers_per_s": kmers / wall, "fasta_GB_per_s": fasta_bytes / wall / 1e9,
+                                      "stage_s": {key: st[key] for key in ("read_s", "ingest_s", "scan_s", "gather_s", "build_s", "gzip_s")}}
+            sk_files = outs
+        t0 = time.perf_counter()
+        ctx.compare_files(sk_files, os.path.join(tmp, "res"))
+        wall = time.perf_counter() - t0
+        st = ctx.stage_times(reset=True)
+        out["compare_files"] = {"sketches": n, "wall_s": wall, "pairs_per_s": n * (n - 1) / 2 / wall,
+                                "stage_s": {key: st[key] for key in ("load_s", "compare_s", "csv_s", "csv_gzip_s")}}
+        # the CLIs themselves (process start, HIP initialisation, -t 4 threads)
+        fof = os.path.join(tmp, "fof.txt")
+        open(fof, "w").write("\n".join(plain) + "\n")
+        cli = os.path.join(ROOT, "bin", "sub_sampler")
+        if os.path.exists(cli):
+            t0 = time.perf_counter()
+            r = subprocess.run([cli, "-f", "fof.txt", "-t", "4", "-v", "0", "-p", "cli_"], cwd=tmp, capture_output=True, text=True)
+            t1 = time.perf_counter()
+            r2 = subprocess.run([os.path.join(ROOT, "bin", "comparator"), "-f", "cli_fof.txt", "-o", "cli_res"], cwd=tmp,
+                                capture_output=True, text=True)
+            t2 = time.perf_counter()
+            out["cli"] = {"sub_sampler_-t4_wall_s": t1 - t0, "sub_sampler_kmers_per_s": kmers / (t1 - t0), "sub_sampler_rc": r.returncode,
+                          "comparator_wall_s": t2 - t1, "comparator_rc": r2.returncode,
+                          "note": "includes process start and HIP initialisation (~0.2 s each)"}
+        if not skip_oracle:
+            from oracle import oracle_py as orc
+            m_files = 4                                     # bounded sample of the same files
+            t0 = time.perf_counter()
+            pls = [orc.sketch_fasta(texts[i], K, M, S)[0] for i in range(m_files)]
+            t1 = time.perf_counter()
+            gz_s = 0.0
+            for pl in pls:
+                tz = time.perf_counter()
+                gzip.compress(pl, 9)
+                gz_s += time.perf_counter() - tz
+            inter, card, csec = orc.compare(pls, timed=True)
+            okm = sum(len(gs[i]) - K + 1 for i in range(m_files))
+            out["cpu_baseline"] = {"kind": "port", "cores": 1, "cpu_model": cpu_model(),
+                                   "sketch_kmers_per_s": okm / (t1 - t0 + gz_s),
+                                   "sample": "oracle parse_fasta_test restated (clean + scan + handle_superkmer + emission) + gzip -9 over the first "
+                                             "%d files from memory, single thread, %.2f s" % (m_files, t1 - t0 + gz_s)}
+            mine = [sp.read_file(sk_files[i]) for i in range(m_files)]
+            out["parity_vs_oracle"] = bool(all(mine[i] == pls[i] for i in range(m_files)))
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 if __name__ == "__main__":

@@ -96,14 +96,21 @@ typedef struct spsp_timing {
     uint64_t accumulate_launches;
     double compare_ms;     /* whole spsp_compare_device pipeline */
     uint64_t compare_calls;
+    double scatter_ms;     /* k_parts_scatter: keys dealt into hash classes (partition form of the comparison) */
+    uint64_t scatter_launches;
+    double group_ms;       /* k_parts_group: per-class LDS dictionary -> sketch lists */
+    uint64_t group_launches;
 } spsp_timing;
 /* `kinds` = OR of SPSP_TIME_* (0 = off).  Every bracketed region costs two event records on the stream, i.e. two
- * packets the following kernels queue behind (~5 us each on an otherwise idle queue): enable what you read. */
+ * packets the following kernels queue behind (~5 us each on an otherwise idle queue): enable what you read.
+ * The scan / compare pipeline brackets close behind the FIRST attempt a begin call queues: the re-run of a call
+ * whose buffers overflowed (or whose key classes did) is not inside the bracket. */
 #define SPSP_TIME_DENSE 1
 #define SPSP_TIME_SCAN 2
 #define SPSP_TIME_ACCUMULATE 4
 #define SPSP_TIME_COMPARE 8
-#define SPSP_TIME_ALL 15
+#define SPSP_TIME_PARTS 16 /* scatter + group kernels */
+#define SPSP_TIME_ALL 31
 int spsp_timing_enable(spsp_ctx* ctx, int kinds);
 /* synchronises the stream, returns the totals since the previous read and resets them */
 int spsp_timing_read(spsp_ctx* ctx, spsp_timing* out);
@@ -135,6 +142,11 @@ int spsp_scan_device(spsp_ctx* ctx, const spsp_params* p, const void* d_bases, u
 int spsp_scan_device_begin(spsp_ctx* ctx, const spsp_params* p, const void* d_bases, uint64_t n_bases,
                            const void* d_rec_off, uint32_t n_rec);
 int spsp_scan_device_end(spsp_ctx* ctx, void** d_out, uint64_t* n_out);
+/* Optional second stream for the scan's sparse stages: everything behind the dense pass (hit compaction, cluster
+ * replay) is queued on `hip_stream` (NULL = a stream the context creates itself; pass tail = 0 to switch back),
+ * ordered behind the dense pass by an event.  Several contexts created on ONE stream then run their dense passes
+ * back to back in that stream's order while each context's sparse stages overlap the next dense pass. */
+int spsp_scan_tail_stream(spsp_ctx* ctx, int tail, void* hip_stream);
 /* Stream ordering between two contexts of one device: work queued on `waiter` after this call starts only
  * once the dense pass of `scanner`'s most recently queued scan has finished (the dense pass fills every CU;
  * latency-bound work of another stream overlaps best with the sparse stages behind it). */
@@ -269,6 +281,22 @@ int spsp_write_gz_host(const char* path, const uint8_t* data, uint64_t len, int 
  * Comparator.cpp:39-74, 362-460). */
 int spsp_sketch_file(spsp_ctx* ctx, const spsp_params* p, double rate, const char* fasta_path,
                      const char* out_path, spsp_sketch_stats* stats);
+/* Wall-clock seconds the two whole-file drivers have spent per stage on this context (end-to-end measurement:
+ * bench.py's `end_to_end` object).  GPU stages include the host synchronisation that ends them. */
+typedef struct spsp_stage_times {
+    double read_s;     /* sketch: file read + gunzip (zstr autodetect)                      utils.cpp:357-364 */
+    double ingest_s;   /* sketch: H2D copy + getLineFasta/clean_dna on the GPU               utils.cpp:675-718 */
+    double scan_s;     /* sketch: the minimizer scan                                         SubSampler.cpp:357-455 */
+    double gather_s;   /* sketch: selected super-k-mers' bases back to the host */
+    double build_s;    /* sketch: handle_superkmer + emission on the host                    SubSampler.cpp:243-302,458-504 */
+    double gzip_s;     /* sketch: gzip level 9 + write                                       SubSampler.cpp:326 */
+    double load_s;     /* compare: read + gunzip + decode + sort of all sketches (host threads)  Comparator.cpp:186-260 */
+    double compare_s;  /* compare: H2D + all-vs-all on the GPU + D2H                         Comparator.cpp:97-287 */
+    double csv_s;      /* compare: both matrices formatted                                   Comparator.cpp:362-460 */
+    double csv_gzip_s; /* compare: gzip level 1 + write */
+    uint64_t sketch_files, compare_calls;
+} spsp_stage_times;
+int spsp_stage_times_read(spsp_ctx* ctx, spsp_stage_times* out, int reset);
 int spsp_compare_files(spsp_ctx* ctx, const char* const* paths, uint32_t n, uint32_t n_query,
                        int precision, double min_threshold, const char* out_prefix);
 

@@ -28,7 +28,7 @@ class SpspError(RuntimeError):
 
 
 ERR_OVERFLOW = -7
-TIME_DENSE, TIME_SCAN, TIME_ACCUMULATE, TIME_COMPARE, TIME_ALL = 1, 2, 4, 8, 15
+TIME_DENSE, TIME_SCAN, TIME_ACCUMULATE, TIME_COMPARE, TIME_PARTS, TIME_ALL = 1, 2, 4, 8, 16, 31
 
 
 class Params(C.Structure):
@@ -50,7 +50,14 @@ class SketchStats(C.Structure):
 class Timing(C.Structure):
     _fields_ = [("dense_ms", C.c_double), ("dense_launches", C.c_uint64), ("scan_ms", C.c_double),
                 ("scan_calls", C.c_uint64), ("accumulate_ms", C.c_double), ("accumulate_launches", C.c_uint64),
-                ("compare_ms", C.c_double), ("compare_calls", C.c_uint64)]
+                ("compare_ms", C.c_double), ("compare_calls", C.c_uint64),
+                ("scatter_ms", C.c_double), ("scatter_launches", C.c_uint64),
+                ("group_ms", C.c_double), ("group_launches", C.c_uint64)]
+
+
+class StageTimes(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("read_s", "ingest_s", "scan_s", "gather_s", "build_s", "gzip_s", "load_s",
+                                          "compare_s", "csv_s", "csv_gzip_s")] + [("sketch_files", C.c_uint64), ("compare_calls", C.c_uint64)]
 
 
 SUPERKMER_DTYPE = np.dtype([("rec", "<u4"), ("minimizer", "<u4"), ("start", "<u8"), ("len", "<u4"), ("rev", "<u4")])
@@ -58,9 +65,9 @@ SUPERKMER_DTYPE = np.dtype([("rec", "<u4"), ("minimizer", "<u4"), ("start", "<u8
 # every symbol include/spsp.h declares (tests check the .so exports them all)
 ABI_SYMBOLS = [
     "spsp_create", "spsp_destroy", "spsp_last_error", "spsp_version", "spsp_free", "spsp_copy_to_host",
-    "spsp_timing_enable", "spsp_timing_read", "spsp_threshold_host", "spsp_scan", "spsp_scan_device", "spsp_scan_device_begin", "spsp_scan_device_end", "spsp_wait_dense", "spsp_wait_stream", "spsp_scan_hits_device", "spsp_compare",
+    "spsp_timing_enable", "spsp_timing_read", "spsp_threshold_host", "spsp_scan", "spsp_scan_device", "spsp_scan_device_begin", "spsp_scan_device_end", "spsp_scan_tail_stream", "spsp_wait_dense", "spsp_wait_stream", "spsp_scan_hits_device", "spsp_compare",
     "spsp_compare_device", "spsp_slot_bytes", "spsp_partition_keys_device", "spsp_compare_slots_device", "spsp_compare_device_begin", "spsp_compare_slots_device_begin", "spsp_compare_end", "spsp_fasta_clean_host", "spsp_fasta_clean_device", "spsp_sketch_text", "spsp_sketch_build_host", "spsp_sketch_parse_host", "spsp_sketch_chain_host",
-    "spsp_csv_host", "spsp_sort_csv_host", "spsp_read_file_host", "spsp_write_gz_host", "spsp_sketch_file", "spsp_compare_files",
+    "spsp_csv_host", "spsp_sort_csv_host", "spsp_read_file_host", "spsp_write_gz_host", "spsp_sketch_file", "spsp_compare_files", "spsp_stage_times_read",
 ]
 
 _lib = None
@@ -130,6 +137,8 @@ def lib():
     L.spsp_sketch_file.argtypes = [vp, P(Params), dbl, cp, cp, P(SketchStats)]
     L.spsp_compare_files.restype = i32
     L.spsp_compare_files.argtypes = [vp, P(cp), u32, u32, i32, dbl, cp]
+    L.spsp_scan_tail_stream.restype = i32; L.spsp_scan_tail_stream.argtypes = [vp, i32, vp]
+    L.spsp_stage_times_read.restype = i32; L.spsp_stage_times_read.argtypes = [vp, P(StageTimes), i32]
     _lib = L
     return L
 
@@ -328,6 +337,10 @@ class Context:
         _check(lib().spsp_scan_device_end(self._h, C.byref(out), C.byref(n)))
         return out.value, n.value
 
+    def scan_tail_stream(self, on=True, stream=None):
+        """sparse stages of the scan on a second stream (None = one the context creates)"""
+        _check(lib().spsp_scan_tail_stream(self._h, 1 if on else 0, stream))
+
     def wait_dense(self, scanner):
         """work queued on this context from now on starts behind `scanner`'s latest dense pass"""
         _check(lib().spsp_wait_dense(self._h, scanner._h))
@@ -367,6 +380,12 @@ class Context:
         _check(lib().spsp_sketch_file(self._h, C.byref(p), float(s), fasta_path.encode(), out_path.encode(),
                                       C.byref(st)))
         return {f: getattr(st, f) for f, _ in SketchStats._fields_}
+
+    def stage_times(self, reset=True):
+        """wall seconds the whole-file drivers (sketch_file / compare_files) spent per stage on this context"""
+        st = StageTimes()
+        _check(lib().spsp_stage_times_read(self._h, C.byref(st), 1 if reset else 0))
+        return {f: getattr(st, f) for f, _ in StageTimes._fields_}
 
     # ---- path B
     def compare(self, sketches, n_query=None):

@@ -47,7 +47,7 @@ void DevBuf::release() {
 using namespace spsp;
 
 int spsp_ctx::ev_begin(int kind) {
-    if (!(timing_mask & (1u << kind))) return SPSP_OK;
+    if (!(timing_mask & (1u << kind))) return SPSP_OK;   // (scatter and group share one bit)
     EventLog& L = evlog[kind];
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (!L.spare.empty()) { ev = L.spare.back(); L.spare.pop_back(); }
@@ -72,6 +72,7 @@ int spsp_timing_enable(spsp_ctx* ctx, int on) {
     if (!ctx) { set_error("NULL argument"); return SPSP_ERR_ARG; }
     // SPSP_TIME_*: bit 0 dense kernel, 1 scan pipeline, 2 accumulate kernel, 3 compare pipeline
     ctx->timing_mask = (uint32_t)on & 15u;
+    if (on & SPSP_TIME_PARTS) ctx->timing_mask |= (1u << kEvScatter) | (1u << kEvGroup);
     ctx->timing = ctx->timing_mask != 0;
     return SPSP_OK;
 }
@@ -99,6 +100,8 @@ int spsp_timing_read(spsp_ctx* ctx, spsp_timing* out) {
     out->scan_ms = ms[kEvScan]; out->scan_calls = cnt[kEvScan];
     out->accumulate_ms = ms[kEvAccumulate]; out->accumulate_launches = cnt[kEvAccumulate];
     out->compare_ms = ms[kEvCompare]; out->compare_calls = cnt[kEvCompare];
+    out->scatter_ms = ms[kEvScatter]; out->scatter_launches = cnt[kEvScatter];
+    out->group_ms = ms[kEvGroup]; out->group_launches = cnt[kEvGroup];
     return SPSP_OK;
 }
 
@@ -143,6 +146,7 @@ void spsp_destroy(spsp_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->tail_stream) (void)hipStreamSynchronize(c->tail_stream);
     compare_job_drop(c);
     if (c->h_skoff) (void)hipHostFree(c->h_skoff);
     if (c->dense_done) (void)hipEventDestroy(c->dense_done);
@@ -160,6 +164,7 @@ void spsp_destroy(spsp_ctx* c) {
             for (auto& ev : *v) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     }
     if (c->h_scalar) (void)hipHostFree(c->h_scalar);
+    if (c->own_tail_stream && c->tail_stream) { (void)hipStreamSynchronize(c->tail_stream); (void)hipStreamDestroy(c->tail_stream); }
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -230,6 +235,22 @@ int spsp_scan_device_end(spsp_ctx* ctx, void** d_out, uint64_t* n_out) {
     int rc = scan_end_impl(ctx, &o, n_out);
     *d_out = o;
     return rc;
+}
+
+int spsp_scan_tail_stream(spsp_ctx* ctx, int tail, void* hip_stream) {
+    if (!ctx) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    if (ctx->scan_job.pending) { set_error("a scan is pending on this context"); return SPSP_ERR_ARG; }
+    SPSP_HIP(hipSetDevice(ctx->device));
+    if (ctx->tail_stream) {
+        SPSP_HIP(hipStreamSynchronize(ctx->tail_stream));
+        if (ctx->own_tail_stream) (void)hipStreamDestroy(ctx->tail_stream);
+        ctx->tail_stream = nullptr; ctx->own_tail_stream = false;
+    }
+    if (!tail) return SPSP_OK;
+    if (hip_stream) { ctx->tail_stream = (hipStream_t)hip_stream; return SPSP_OK; }
+    SPSP_HIP(hipStreamCreateWithFlags(&ctx->tail_stream, hipStreamNonBlocking));
+    ctx->own_tail_stream = true;
+    return SPSP_OK;
 }
 
 int spsp_wait_dense(spsp_ctx* waiter, spsp_ctx* scanner) {

@@ -760,8 +760,12 @@ static int job_parts(spsp_ctx* ctx, CompareJob& J) {
                        ctx->c_skoff.as<uint64_t>(), J.n_skoff, reinterpret_cast<const uint32_t*>(ctx->h_skoff + J.n_skoff),
                        reinterpret_cast<uint32_t*>(ctx->c_skoff.as<uint64_t>() + J.n_skoff), J.n_sub);
     SPSP_HIP(hipGetLastError());
+    if ((rc = ctx->ev_begin(kEvScatter))) return rc;
     if ((rc = J.scatter_parts(J.n_parts))) return rc;
+    if ((rc = ctx->ev_end(kEvScatter))) return rc;
+    if ((rc = ctx->ev_begin(kEvGroup))) return rc;
     if ((rc = J.group_parts(J.n_parts))) return rc;
+    if ((rc = ctx->ev_end(kEvGroup))) return rc;
     if ((rc = ctx->ev_begin(kEvAccumulate))) return rc;
     if ((rc = launch_accumulate_sparse(ctx, J.P, flags))) return rc;
     if ((rc = ctx->ev_end(kEvAccumulate))) return rc;

@@ -25,6 +25,7 @@ typedef unsigned __int128 u128;
 namespace {
 
 using spsp::set_error;
+using spsp::now_s;
 
 inline uint32_t code_of(uint8_t c) { return (c >> 1) & 3u; }  // A=0 C=1 T=2 G=3 (utils.cpp:13-16)
 const char kNuc[4] = {'A', 'C', 'T', 'G'};                     // int2nuc (utils.cpp:26-45)
@@ -766,9 +767,13 @@ int spsp_write_gz_host(const char* path, const uint8_t* data, uint64_t len, int 
 
 int spsp_sketch_file(spsp_ctx* ctx, const spsp_params* p, double rate, const char* fasta_path, const char* out_path,
                      spsp_sketch_stats* stats) {
+    if (!ctx) { set_error("NULL argument"); return SPSP_ERR_ARG; }
     uint8_t* text = nullptr; uint64_t tlen = 0;
+    double t0 = now_s();
     int rc = spsp_read_file_host(fasta_path, &text, &tlen);
     if (rc) return rc;
+    ctx->stages.read_s += now_s() - t0;
+    ctx->stages.sketch_files += 1;
     uint8_t* payload = nullptr; uint64_t plen = 0;
     static const bool host_ingest = getenv("SPSP_HOST_INGEST") != nullptr;   // A/B switch: clean on the host, scan on the GPU
     if (host_ingest) {
@@ -784,14 +789,25 @@ int spsp_sketch_file(spsp_ctx* ctx, const spsp_params* p, double rate, const cha
     }
     free(text);
     if (rc) { free(payload); return rc; }
+    t0 = now_s();
     rc = spsp_write_gz_host(out_path, payload, plen, 9);  // level 9: SubSampler.cpp:326
+    ctx->stages.gzip_s += now_s() - t0;
     free(payload);
     return rc;
 }
 
+int spsp_stage_times_read(spsp_ctx* ctx, spsp_stage_times* out, int reset) {
+    if (!ctx || !out) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    *out = ctx->stages;
+    if (reset) ctx->stages = spsp_stage_times{};
+    return SPSP_OK;
+}
+
 int spsp_compare_files(spsp_ctx* ctx, const char* const* paths, uint32_t n, uint32_t n_query, int precision,
                        double min_threshold, const char* out_prefix) {
-    if (!paths || !out_prefix) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    if (!ctx || !paths || !out_prefix) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    double t0 = now_s(), t1;
+    ctx->stages.compare_calls += 1;
     std::vector<spsp_sketch_view> views(n);
     std::vector<void*> owned((size_t)n * 3, nullptr);
     std::vector<uint32_t> ks(n, 0), ms(n, 0);
@@ -853,18 +869,23 @@ int spsp_compare_files(spsp_ctx* ctx, const char* const* paths, uint32_t n, uint
     if (!rc && n && ks[0] <= 32) for (uint32_t i = 0; i < n; ++i) views[i].kmer_hi = nullptr;
     std::vector<uint32_t> inter;
     std::vector<uint64_t> card(n, 0);
+    t1 = now_s(); ctx->stages.load_s += t1 - t0; t0 = t1;
     if (!rc) {
         inter.assign((size_t)n * n, 0);
         rc = spsp_compare(ctx, views.data(), n, n_query, inter.data(), card.data());
     }
     for (void* p : owned) free(p);
+    t1 = now_s(); ctx->stages.compare_s += t1 - t0;
     if (rc) return rc;
     for (int jac = 0; jac < 2 && !rc; ++jac) {
         char* text = nullptr; uint64_t len = 0;
+        t0 = now_s();
         rc = spsp_csv_host(jac, paths, n, n_query, inter.data(), card.data(), precision, min_threshold, &text, &len);
+        t1 = now_s(); ctx->stages.csv_s += t1 - t0;
         if (rc) break;
         const std::string out = std::string(out_prefix) + (jac ? "_jaccard.csv.gz" : "_containment.csv.gz");
         rc = spsp_write_gz_host(out.c_str(), (const uint8_t*)text, len, 1);  // level 1: Comparator.cpp:363,413
+        ctx->stages.csv_gzip_s += now_s() - t1;
         free(text);
     }
     return rc;

@@ -443,19 +443,24 @@ int spsp_sketch_text(spsp_ctx* ctx, const spsp_params* p, double rate, const cha
     int rc = check_params(p);
     if (rc) return rc;
     SPSP_HIP(hipSetDevice(ctx->device));
+    double t0 = now_s(), t1;
     if ((rc = ctx->i_text.reserve((size_t)n_text + 64))) return rc;
     if (n_text) SPSP_HIP(hipMemcpyAsync(ctx->i_text.p, text, (size_t)n_text, hipMemcpyHostToDevice, ctx->stream));
     uint8_t* d_bases = nullptr; uint64_t* d_off = nullptr; uint64_t n_bases = 0; uint32_t n_rec = 0;
     if ((rc = clean_device_impl(ctx, ctx->i_text.as<uint8_t>(), n_text, &d_bases, &n_bases, &d_off, &n_rec))) return rc;
+    t1 = now_s(); ctx->stages.ingest_s += t1 - t0; t0 = t1;
     spsp_superkmer* d_sk = nullptr; uint64_t n_sk = 0;
     if ((rc = scan_device_impl(ctx, p, d_bases, n_bases, d_off, n_rec, &d_sk, &n_sk))) return rc;
+    t1 = now_s(); ctx->stages.scan_s += t1 - t0; t0 = t1;
     std::vector<uint64_t> rec_off((size_t)n_rec + 1);
     std::vector<spsp_superkmer> sk((size_t)n_sk);
     SPSP_HIP(hipMemcpyAsync(rec_off.data(), d_off, rec_off.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (n_sk) SPSP_HIP(hipMemcpyAsync(sk.data(), d_sk, (size_t)n_sk * sizeof(spsp_superkmer), hipMemcpyDeviceToHost, ctx->stream));
     uint8_t* compact = nullptr; uint32_t* coff = nullptr;
     if ((rc = gather_superkmers_impl(ctx, d_bases, d_off, d_sk, n_sk, &compact, &coff))) return rc;   // synchronises the stream
+    t1 = now_s(); ctx->stages.gather_s += t1 - t0; t0 = t1;
     rc = sketch_build_core(p, rate, rec_off.data(), n_rec, sk.data(), n_sk, nullptr, compact, coff, payload, payload_len, stats);
+    ctx->stages.build_s += now_s() - t0;
     free(compact); free(coff);
     return rc;
 }

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -49,7 +50,7 @@ namespace spsp {
 struct EventLog {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> used, spare;
 };
-enum { kEvDense = 0, kEvScan = 1, kEvAccumulate = 2, kEvCompare = 3, kEvKinds = 4 };
+enum { kEvDense = 0, kEvScan = 1, kEvAccumulate = 2, kEvCompare = 3, kEvScatter = 4, kEvGroup = 5, kEvKinds = 6 };
 }  // namespace spsp
 
 namespace spsp {
@@ -77,11 +78,15 @@ struct spsp_ctx {
     // begin/end bracket for one timed region; no-ops unless timing is on
     int ev_begin(int kind);
     int ev_end(int kind);
-    bool ev_open[spsp::kEvKinds] = {false, false, false, false};   // a begin without its end is outstanding
+    bool ev_open[spsp::kEvKinds] = {};   // a begin without its end is outstanding
+    spsp_stage_times stages{};    // whole-file drivers: wall seconds per stage (spsp_stage_times_read)
     int device = 0;
     int n_cu = 256;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t tail_stream = nullptr;   // sparse stages of the scan (spsp_scan_tail_stream); nullptr = the main stream
+    bool own_tail_stream = false;
+    hipStream_t sparse_stream() const { return tail_stream ? tail_stream : stream; }
     uint64_t* h_scalar = nullptr;  // pinned, 16 slots: [0] hits, [1] super-k-mers (scan); [4..6] ingest totals; [8..10] compare flags
     hipEvent_t dense_done = nullptr;   // recorded behind every dense pass (unless a timing event already is)
     hipEvent_t dense_marker = nullptr; // what spsp_wait_dense waits on
@@ -117,6 +122,7 @@ struct spsp_ctx {
 };
 
 namespace spsp {
+inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 // scan pipeline (spsp_scan.hip)
 int scan_device_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, uint64_t n_bases,
                      const uint64_t* d_rec_off, uint32_t n_rec, spsp_superkmer** d_out, uint64_t* n_out);

@@ -1227,14 +1227,17 @@ static int launch_dense(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_ba
         SPSP_HIP(hipEventRecord(ctx->dense_done, ctx->stream));
         ctx->dense_marker = ctx->dense_done;
     }
-    if (!*lists) {
-        const uint32_t seg_shift = seg_shift_for(n_tiles);
-        const uint32_t n_seg = (uint32_t)((n_tiles + (1ull << seg_shift) - 1) >> seg_shift);
-        if ((rc = ctx->seg_a.reserve((size_t)n_seg * 8))) return rc;
-        hipLaunchKernelGGL(k_scan_segments, dim3(n_seg), dim3(kSegThreads), 0, ctx->stream, ctx->tile_count.as<uint32_t>(),
-                           ctx->tile_off.as<uint32_t>(), n_tiles, seg_shift, ctx->seg_a.as<uint32_t>());
-        SPSP_HIP(hipGetLastError());
-    }
+    return SPSP_OK;
+}
+// bitmap form: tile counts -> tile offsets (first of the sparse stages)
+static int launch_tile_scan(spsp_ctx* ctx, uint64_t n_tiles, hipStream_t stream) {
+    int rc;
+    const uint32_t seg_shift = seg_shift_for(n_tiles);
+    const uint32_t n_seg = (uint32_t)((n_tiles + (1ull << seg_shift) - 1) >> seg_shift);
+    if ((rc = ctx->seg_a.reserve((size_t)n_seg * 8))) return rc;
+    hipLaunchKernelGGL(k_scan_segments, dim3(n_seg), dim3(kSegThreads), 0, stream, ctx->tile_count.as<uint32_t>(),
+                       ctx->tile_off.as<uint32_t>(), n_tiles, seg_shift, ctx->seg_a.as<uint32_t>());
+    SPSP_HIP(hipGetLastError());
     return SPSP_OK;
 }
 
@@ -1254,6 +1257,7 @@ int scan_hits_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, 
         hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(1024), 0, ctx->stream, ctx->wave_cnt.as<uint32_t>(), LP.n_lists,
                            ctx->h_scalar + 0);
     } else {
+        if ((rc = launch_tile_scan(ctx, n_tiles, ctx->stream))) return rc;
         const uint32_t seg_shift = seg_shift_for(n_tiles);
         const uint32_t n_seg = (uint32_t)((n_tiles + (1ull << seg_shift) - 1) >> seg_shift);
         hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(64), 0, ctx->stream, ctx->seg_a.as<uint32_t>(),
@@ -1299,10 +1303,14 @@ static int scan_enqueue(spsp_ctx* ctx) {
         if ((rc = launch_dense(ctx, p, J.d_bases, J.n_bases, J.n_tiles, J.use_bitmap, &LP, &J.lists))) return rc;
         if (J.lists) { J.n_lists = LP.n_lists; J.list_cap = LP.cap; J.rows_per_wave = LP.rows_per_wave; }
     }
+    // the sparse stages may have a stream of their own (spsp_scan_tail_stream): behind this dense pass, beside the next
+    const hipStream_t sparse = ctx->sparse_stream();
+    if (sparse != ctx->stream && J.redo_from == 0) SPSP_HIP(hipStreamWaitEvent(sparse, ctx->dense_marker, 0));
+    if (J.redo_from == 0 && !J.lists && (rc = launch_tile_scan(ctx, J.n_tiles, sparse))) return rc;
     if (J.redo_from <= 1) {
         if (J.lists) {
             const WaveLists L{ctx->wave_hits.as<Hit>(), ctx->wave_cnt.as<uint32_t>(), J.list_cap, J.rows_per_wave};
-            hipLaunchKernelGGL(k_compact, dim3((J.n_lists + kCompactWaves - 1) / kCompactWaves), dim3(kCompactThreads), 0, ctx->stream,
+            hipLaunchKernelGGL(k_compact, dim3((J.n_lists + kCompactWaves - 1) / kCompactWaves), dim3(kCompactThreads), 0, sparse,
                                L, J.n_lists, J.n_bases, p->k, p->m, J.d_rec_off, J.n_rec, ctx->hits.as<Hit>(), hits_cap,
                                ctx->h_scalar + 0, d_sc + 0, chunk_sum, n_chunks);
         } else {
@@ -1310,25 +1318,25 @@ static int scan_enqueue(spsp_ctx* ctx) {
             const uint32_t seg_shift = seg_shift_for(J.n_tiles);
             const uint32_t n_seg_t = (uint32_t)((J.n_tiles + (1ull << seg_shift) - 1) >> seg_shift);
             hipLaunchKernelGGL(k_expand, dim3((uint32_t)((J.n_tiles + kExpandTilesPerWg - 1) / kExpandTilesPerWg)),
-                               dim3(kThreads), 0, ctx->stream, J.d_bases, J.n_bases, p->k, p->m, ctx->bitmap.as<uint32_t>(),
+                               dim3(kThreads), 0, sparse, J.d_bases, J.n_bases, p->k, p->m, ctx->bitmap.as<uint32_t>(),
                                ctx->tile_count.as<uint32_t>(), ctx->tile_off.as<uint32_t>(), ctx->seg_a.as<uint32_t>(),
                                n_seg_t, seg_shift, J.n_tiles, J.d_rec_off, J.n_rec, ctx->hits.as<Hit>(), hits_cap, ctx->h_scalar + 0, d_sc + 0,
                                chunk_sum, n_chunks);
         }
         SPSP_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k_resolve<false>, dim3(rblocks), dim3(kResolveThreads), 0, ctx->stream, ctx->hits.as<Hit>(), d_sc + 0,
+        hipLaunchKernelGGL(k_resolve<false>, dim3(rblocks), dim3(kResolveThreads), 0, sparse, ctx->hits.as<Hit>(), d_sc + 0,
                            hits_cap, J.d_rec_off, p->k, p->m, ctx->emit_count.as<uint32_t>(), wave_sum, chunk_sum, n_chunks,
                            (uint64_t*)nullptr, (spsp_superkmer*)nullptr, 0u);
         SPSP_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_resolve<true>, dim3(rblocks), dim3(kResolveThreads), 0, ctx->stream, ctx->hits.as<Hit>(), d_sc + 0,
+    hipLaunchKernelGGL(k_resolve<true>, dim3(rblocks), dim3(kResolveThreads), 0, sparse, ctx->hits.as<Hit>(), d_sc + 0,
                        hits_cap, J.d_rec_off, p->k, p->m, ctx->emit_count.as<uint32_t>(), wave_sum, chunk_sum, n_chunks,
                        ctx->h_scalar + 1, ctx->scan_tmp.as<spsp_superkmer>(), out_cap);
     SPSP_HIP(hipGetLastError());
     // what scan_end waits on: this job's last kernel, not the whole stream (a caller may already have queued
     // the next batch's work behind it)
     if (!ctx->scan_done) SPSP_HIP(hipEventCreateWithFlags(&ctx->scan_done, hipEventDisableTiming));
-    SPSP_HIP(hipEventRecord(ctx->scan_done, ctx->stream));
+    SPSP_HIP(hipEventRecord(ctx->scan_done, sparse));
     return SPSP_OK;
 }
 
