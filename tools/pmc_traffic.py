@@ -26,6 +26,12 @@ def per_kernel(path, counter):
     return out
 
 
+def commit():
+    """the code state the counters were collected on (set by the caller: the GPU box has no .git)"""
+    import os
+    return os.environ.get("SPSP_COMMIT")
+
+
 def main():
     fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
     kernels = {}
@@ -43,6 +49,7 @@ def main():
                 "WRITE_SIZE is exact for 16 B/lane stores and per-dword atomics. Per-launch averages over the timed-step "
                 "launches (largest grid, >= half of the largest value).",
         "workload": {"genomes": 100, "genome_len": 5000000, "k": 31, "m": 11, "s": 1000.0, "scan_mode": "default"},
+        "commit": commit(),
         "kernels": kernels,
     }
     json.dump(doc, open(sys.argv[3], "w"), indent=1)
