@@ -52,6 +52,8 @@ typedef struct spsp_params {
 #define SPSP_SCAN_DIRECT_HASH 1u /* force XXH64 at every position (no LDS pre-filter) */
 #define SPSP_SCAN_LDS_FILTER 2u  /* force the 2^20-bit memoised LDS pre-filter (one lookup per position) */
 #define SPSP_SCAN_PAIR_FILTER 4u /* force the 64 KiB pair table (one lookup per two positions, m >= 9) */
+#define SPSP_SCAN_STATS 8u       /* spsp_sketch_text / spsp_sketch_file: also count EVERY super-k-mer of the input
+                                    (total_superkmer_number of print_stat, SubSampler.cpp:430,452) -- an extra pass */
 
 /* One selected super-k-mer == one call of Subsampler::handle_superkmer
  * (SubSampler.cpp:426,448): ref.substr(start,len) of record `rec`, its
@@ -154,6 +156,12 @@ int spsp_wait_dense(spsp_ctx* waiter, spsp_ctx* scanner);
 /* ... only once everything queued on `other` so far has finished. */
 int spsp_wait_stream(spsp_ctx* waiter, spsp_ctx* other);
 
+/* total_superkmer_number of Subsampler::print_stat (SubSampler.cpp:430,452,641): how many super-k-mers the scan
+ * loop cuts over ALL k-mers of the input, selected or not -- including the cuts its position tracking makes
+ * when one m-mer occurs twice in a window (`dump`, :391-398).  Not needed for the sketch: a separate pass. */
+int spsp_count_superkmers_device(spsp_ctx* ctx, const spsp_params* p, const void* d_bases, uint64_t n_bases,
+                                 const void* d_rec_off, uint32_t n_rec, uint64_t* total_superkmers);
+
 /* Dense stage only (hash + threshold + hit bitmap), for the roofline
  * measurement: returns the number of m-mers with hash <= threshold. */
 int spsp_scan_hits_device(spsp_ctx* ctx, const spsp_params* p, const void* d_bases, uint64_t n_bases,
@@ -231,6 +239,7 @@ typedef struct spsp_sketch_stats {
     uint64_t read_kmer, selected_kmer_number, selected_superkmer_number, count_maximal_skmer;
     uint64_t seen_kmers_at_reconstruction, seen_superkmers_at_reconstruction;
     uint64_t seen_max_superkmers_at_reconstruction, actual_minimizer_number, nb_mmer_selected;
+    uint64_t total_kmer_number, total_superkmer_number;   /* filled when SPSP_SCAN_STATS is set, else 0 */
 } spsp_sketch_stats;
 
 /* handle_superkmer + the emission half of parse_fasta_test
@@ -299,6 +308,10 @@ typedef struct spsp_stage_times {
 int spsp_stage_times_read(spsp_ctx* ctx, spsp_stage_times* out, int reset);
 int spsp_compare_files(spsp_ctx* ctx, const char* const* paths, uint32_t n, uint32_t n_query,
                        int precision, double min_threshold, const char* out_prefix);
+/* the same, printing the progress lines of the reference's comparator on stdout where it prints them
+ * (Comparator.cpp:56,69,364,414; all-versus-all runs also :503,509) -- for bin/comparator */
+int spsp_compare_files_chatty(spsp_ctx* ctx, const char* const* paths, uint32_t n, uint32_t n_query,
+                              int precision, double min_threshold, const char* out_prefix, int all_versus_all);
 
 #ifdef __cplusplus
 }

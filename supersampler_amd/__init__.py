@@ -21,6 +21,7 @@ SPSP_SCAN_DEFAULT = 0
 SPSP_SCAN_DIRECT_HASH = 1
 SPSP_SCAN_LDS_FILTER = 2
 SPSP_SCAN_PAIR_FILTER = 4
+SPSP_SCAN_STATS = 8
 
 
 class SpspError(RuntimeError):
@@ -44,7 +45,8 @@ class SketchStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in
                 ("read_kmer", "selected_kmer_number", "selected_superkmer_number", "count_maximal_skmer",
                  "seen_kmers_at_reconstruction", "seen_superkmers_at_reconstruction",
-                 "seen_max_superkmers_at_reconstruction", "actual_minimizer_number", "nb_mmer_selected")]
+                 "seen_max_superkmers_at_reconstruction", "actual_minimizer_number", "nb_mmer_selected",
+                 "total_kmer_number", "total_superkmer_number")]
 
 
 class Timing(C.Structure):
@@ -65,9 +67,9 @@ SUPERKMER_DTYPE = np.dtype([("rec", "<u4"), ("minimizer", "<u4"), ("start", "<u8
 # every symbol include/spsp.h declares (tests check the .so exports them all)
 ABI_SYMBOLS = [
     "spsp_create", "spsp_destroy", "spsp_last_error", "spsp_version", "spsp_free", "spsp_copy_to_host",
-    "spsp_timing_enable", "spsp_timing_read", "spsp_threshold_host", "spsp_scan", "spsp_scan_device", "spsp_scan_device_begin", "spsp_scan_device_end", "spsp_scan_tail_stream", "spsp_wait_dense", "spsp_wait_stream", "spsp_scan_hits_device", "spsp_compare",
+    "spsp_timing_enable", "spsp_timing_read", "spsp_threshold_host", "spsp_scan", "spsp_scan_device", "spsp_scan_device_begin", "spsp_scan_device_end", "spsp_scan_tail_stream", "spsp_wait_dense", "spsp_wait_stream", "spsp_scan_hits_device", "spsp_count_superkmers_device", "spsp_compare",
     "spsp_compare_device", "spsp_slot_bytes", "spsp_partition_keys_device", "spsp_compare_slots_device", "spsp_compare_device_begin", "spsp_compare_slots_device_begin", "spsp_compare_end", "spsp_fasta_clean_host", "spsp_fasta_clean_device", "spsp_sketch_text", "spsp_sketch_build_host", "spsp_sketch_parse_host", "spsp_sketch_chain_host",
-    "spsp_csv_host", "spsp_sort_csv_host", "spsp_read_file_host", "spsp_write_gz_host", "spsp_sketch_file", "spsp_compare_files", "spsp_stage_times_read",
+    "spsp_csv_host", "spsp_sort_csv_host", "spsp_read_file_host", "spsp_write_gz_host", "spsp_sketch_file", "spsp_compare_files", "spsp_compare_files_chatty", "spsp_stage_times_read",
 ]
 
 _lib = None
@@ -137,6 +139,8 @@ def lib():
     L.spsp_sketch_file.argtypes = [vp, P(Params), dbl, cp, cp, P(SketchStats)]
     L.spsp_compare_files.restype = i32
     L.spsp_compare_files.argtypes = [vp, P(cp), u32, u32, i32, dbl, cp]
+    L.spsp_count_superkmers_device.restype = i32
+    L.spsp_count_superkmers_device.argtypes = [vp, P(Params), vp, u64, vp, u32, P(u64)]
     L.spsp_scan_tail_stream.restype = i32; L.spsp_scan_tail_stream.argtypes = [vp, i32, vp]
     L.spsp_stage_times_read.restype = i32; L.spsp_stage_times_read.argtypes = [vp, P(StageTimes), i32]
     _lib = L
@@ -352,6 +356,12 @@ class Context:
     def scan_hits_device(self, params, d_bases, n_bases):
         n = C.c_uint64()
         _check(lib().spsp_scan_hits_device(self._h, C.byref(params), d_bases, n_bases, C.byref(n)))
+        return n.value
+
+    def count_superkmers_device(self, params, d_bases, n_bases, d_rec_off, n_rec):
+        """total_superkmer_number of print_stat: every super-k-mer of the input, selected or not"""
+        n = C.c_uint64()
+        _check(lib().spsp_count_superkmers_device(self._h, C.byref(params), d_bases, n_bases, d_rec_off, n_rec, C.byref(n)))
         return n.value
 
     def clean_fasta_device(self, d_text, n_text):

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <iostream>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -803,10 +804,13 @@ int spsp_stage_times_read(spsp_ctx* ctx, spsp_stage_times* out, int reset) {
     return SPSP_OK;
 }
 
-int spsp_compare_files(spsp_ctx* ctx, const char* const* paths, uint32_t n, uint32_t n_query, int precision,
-                       double min_threshold, const char* out_prefix) {
+// chatter: 0 = silent; 1 = the stdout lines of the reference's all-versus-all run (Comparator.cpp:56,69,364,414,
+// 503,509); 2 = those of its query run (:56,69,364,414)
+static int compare_files_impl(spsp_ctx* ctx, const char* const* paths, uint32_t n, uint32_t n_query, int precision,
+                              double min_threshold, const char* out_prefix, int chatter) {
     if (!ctx || !paths || !out_prefix) { set_error("NULL argument"); return SPSP_ERR_ARG; }
     double t0 = now_s(), t1;
+    const double t_start = t0;
     ctx->stages.compare_calls += 1;
     std::vector<spsp_sketch_view> views(n);
     std::vector<void*> owned((size_t)n * 3, nullptr);
@@ -867,6 +871,7 @@ int spsp_compare_files(spsp_ctx* ctx, const char* const* paths, uint32_t n, uint
         }
     }
     if (!rc && n && ks[0] <= 32) for (uint32_t i = 0; i < n; ++i) views[i].kmer_hi = nullptr;
+    if (!rc && chatter && n) { printf("kmers evaluated are of length: %u minimizer size is %u\n", ks[0], ms[0]); fflush(stdout); }   // :56
     std::vector<uint32_t> inter;
     std::vector<uint64_t> card(n, 0);
     t1 = now_s(); ctx->stages.load_s += t1 - t0; t0 = t1;
@@ -877,9 +882,16 @@ int spsp_compare_files(spsp_ctx* ctx, const char* const* paths, uint32_t n, uint
     for (void* p : owned) free(p);
     t1 = now_s(); ctx->stages.compare_s += t1 - t0;
     if (rc) return rc;
+    if (chatter) {
+        printf("Comparisons done\n");                                                         // :69
+        if (chatter == 1) std::cout << "Comparisons lasted " << (t1 - t_start) << " sec" << std::endl;   // :503 (cout's default float format)
+        fflush(stdout);
+    }
+    const double t_middle = t1;
     for (int jac = 0; jac < 2 && !rc; ++jac) {
         char* text = nullptr; uint64_t len = 0;
         t0 = now_s();
+        if (chatter) { printf(jac ? "Jackard index dump\n" : "Containement index dump \n"); fflush(stdout); }   // :364, :414
         rc = spsp_csv_host(jac, paths, n, n_query, inter.data(), card.data(), precision, min_threshold, &text, &len);
         t1 = now_s(); ctx->stages.csv_s += t1 - t0;
         if (rc) break;
@@ -888,7 +900,17 @@ int spsp_compare_files(spsp_ctx* ctx, const char* const* paths, uint32_t n, uint
         ctx->stages.csv_gzip_s += now_s() - t1;
         free(text);
     }
+    if (!rc && chatter == 1) std::cout << "Jaccard output lasted " << (now_s() - t_middle) << " sec" << std::endl;   // :509
     return rc;
+}
+
+int spsp_compare_files(spsp_ctx* ctx, const char* const* paths, uint32_t n, uint32_t n_query, int precision,
+                       double min_threshold, const char* out_prefix) {
+    return compare_files_impl(ctx, paths, n, n_query, precision, min_threshold, out_prefix, 0);
+}
+int spsp_compare_files_chatty(spsp_ctx* ctx, const char* const* paths, uint32_t n, uint32_t n_query, int precision,
+                              double min_threshold, const char* out_prefix, int all_versus_all) {
+    return compare_files_impl(ctx, paths, n, n_query, precision, min_threshold, out_prefix, all_versus_all ? 1 : 2);
 }
 
 }  // extern "C"

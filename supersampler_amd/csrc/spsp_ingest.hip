@@ -461,6 +461,12 @@ int spsp_sketch_text(spsp_ctx* ctx, const spsp_params* p, double rate, const cha
     t1 = now_s(); ctx->stages.gather_s += t1 - t0; t0 = t1;
     rc = sketch_build_core(p, rate, rec_off.data(), n_rec, sk.data(), n_sk, nullptr, compact, coff, payload, payload_len, stats);
     ctx->stages.build_s += now_s() - t0;
+    if (!rc && stats && (p->flags & SPSP_SCAN_STATS)) {   // print_stat's counters over ALL super-k-mers (SubSampler.cpp:429-430,451-452)
+        t0 = now_s();
+        rc = count_superkmers_impl(ctx, p, d_bases, n_bases, d_off, n_rec, &stats->total_superkmer_number);
+        stats->total_kmer_number = stats->read_kmer;      // every k-mer of a record lies in exactly one super-k-mer
+        ctx->stages.scan_s += now_s() - t0;
+    }
     free(compact); free(coff);
     return rc;
 }

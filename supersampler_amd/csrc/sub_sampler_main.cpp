@@ -45,19 +45,22 @@ static uint64_t file_size(const string& p) {
     return stat(p.c_str(), &st) == 0 ? (uint64_t)st.st_size : 0;
 }
 
-// print_stat (SubSampler.cpp:633-665).  Lines that need the count of
-// UNSELECTED super-k-mers are not reproduced: the GPU scan never materialises
-// them (see DESIGN.md "known deviations").
+// print_stat (SubSampler.cpp:633-665), line for line.  total_kmer_number / total_superkmer_number cover ALL
+// super-k-mers of the input: the library counts them in an extra pass when SPSP_SCAN_STATS is set (-v 1).
 static void print_stat(const spsp_sketch_stats& s, uint32_t k, uint32_t m, const string& file) {
     if (s.selected_kmer_number == 0) { cout << "No kmer selected ***Crickets noise***" << endl; return; }
-    cout << "I have seen " << with_commas(s.read_kmer) << " kmers and I selected " << with_commas(s.selected_kmer_number) << " kmers" << endl;
+    cout << "I have seen " << with_commas(s.total_kmer_number) << " kmers and I selected " << with_commas(s.selected_kmer_number) << " kmers" << endl;
     cout << "After removing duplicate kmers, I selected " << with_commas(s.seen_kmers_at_reconstruction) << " kmers" << endl;
-    cout << "This means a practical subsampling rate of " << (double)s.read_kmer / s.selected_kmer_number << " with duplicates" << endl;
-    cout << "This means a practical subsampling rate of " << (double)s.read_kmer / s.seen_kmers_at_reconstruction << " without duplicates" << endl;
-    cout << "I selected " << with_commas(s.selected_superkmer_number) << " superkmers" << endl;
+    cout << "This means a practical subsampling rate of " << (double)s.total_kmer_number / s.selected_kmer_number << " with duplicates" << endl;
+    cout << "This means a practical subsampling rate of " << (double)s.total_kmer_number / s.seen_kmers_at_reconstruction << " without duplicates" << endl;
+    cout << "I have seen " << with_commas(s.total_superkmer_number) << " superkmers and I selected " << with_commas(s.selected_superkmer_number) << " superkmers" << endl;
     cout << "After reconstruction and filtering with abundance, I have selected " << with_commas(s.seen_superkmers_at_reconstruction) << " superkmers" << endl;
+    cout << "This means a practical subsampling rate of " << (double)s.total_superkmer_number / s.selected_superkmer_number << " with duplicates" << endl;
+    cout << "This means a practical subsampling rate of " << (double)s.total_superkmer_number / s.seen_superkmers_at_reconstruction << " without duplicates" << endl;
+    cout << "This means a mean superkmer size of " << (double)s.total_kmer_number / s.total_superkmer_number << " kmer per superkmer in the input" << endl;
     cout << "This means a mean superkmer size of " << (double)s.selected_kmer_number / s.selected_superkmer_number << " kmer per superkmer with duplicates" << endl;
     cout << "This means a mean superkmer size of " << (double)s.seen_kmers_at_reconstruction / s.seen_superkmers_at_reconstruction << " kmer per superkmer in the output" << endl;
+
     cout << "Actual output file size is " << with_commas(file_size(file) / 1000) << "KB" << endl;
     cout << "This mean " << ((double)file_size(file) * 8 / s.seen_kmers_at_reconstruction) << " bits per kmer" << endl;
     cout << "Minimizer number: " << with_commas(s.actual_minimizer_number) << " Skmer/minimizer:                    " << s.selected_superkmer_number / s.actual_minimizer_number << endl;
@@ -112,7 +115,8 @@ int main(int argc, char** argv) {
     if (k > 63 || m1 > k) { cout << "k must satisfy m <= k <= 63" << endl; return 0; }
 
     spsp_params P;
-    P.k = k; P.m = m1; P.abundance = abundance; P.flags = SPSP_SCAN_DEFAULT;
+    P.k = k; P.m = m1; P.abundance = abundance;
+    P.flags = verbose ? SPSP_SCAN_STATS : SPSP_SCAN_DEFAULT;   // print_stat needs the count of ALL super-k-mers
     P.threshold = spsp_threshold_host(k, m1, s);
 
     mutex io;

@@ -324,6 +324,89 @@ def test_cli_end_to_end_matches_oracle(tmp_path):
         assert gzip.open(tmp_path / fn, "rb").read() == orc.csv(jac, listed, inter, card, None, 5, 0.0)
 
 
+def _fmt_commas(n):
+    return "{:,}".format(int(n))
+
+
+def test_count_all_superkmers_matches_oracle(ctx):
+    """total_superkmer_number of print_stat (SubSampler.cpp:430,452): every super-k-mer of the input, cut by the
+    literal state machine incl. its `dump` cuts on repeated m-mers -- random, mutated-repeat, tandem-repeat and
+    homopolymer records (no state-resetting event for whole chunks: the second pass), short and empty records."""
+    import torch
+    rng = np.random.default_rng(321)
+    unit = synth.random_genome(rng, 37)
+    lib = synth.random_genome(rng, 300)
+    pieces = [synth.random_genome(rng, 40_000), np.tile(unit, 400), np.full(9_000, ord("A"), np.uint8),
+              np.concatenate([lib if i % 3 else synth.mutate(rng, lib, 0.02) for i in range(40)]),
+              synth.random_genome(rng, 10), np.zeros(0, np.uint8), np.tile(np.frombuffer(b"ACG", np.uint8), 2000),
+              synth.random_genome(rng, 3_000), np.full(33, ord("C"), np.uint8)]
+    bases, off = synth.concat_records(pieces)
+    d_b = torch.from_numpy(np.concatenate([bases, np.zeros(64, np.uint8)])).cuda()
+    d_o = torch.from_numpy(off.view(np.int64)).cuda()
+    for k, m in ((31, 11), (21, 11), (63, 15), (15, 15), (33, 13), (15, 9)):
+        p = sp.make_params(k, m, 50)
+        _, st = orc.scan(k, m, p.threshold, bases, off)
+        got = ctx.count_superkmers_device(p, d_b.data_ptr(), len(bases), d_o.data_ptr(), len(pieces))
+        assert got == st["total_superkmer_number"], (k, m, got, st)
+    # one long random record: chunks far from the record start
+    g = synth.random_genome(rng, 700_000)
+    b2, o2 = synth.concat_records([g])
+    d_b2 = torch.from_numpy(b2).cuda()
+    d_o2 = torch.from_numpy(o2.view(np.int64)).cuda()
+    p = sp.make_params(31, 11, 1000)
+    _, st = orc.scan(31, 11, p.threshold, b2, o2)
+    assert ctx.count_superkmers_device(p, d_b2.data_ptr(), len(b2), d_o2.data_ptr(), 1) == st["total_superkmer_number"]
+
+
+def test_cli_default_verbose_stdout_matches_reference_lines(tmp_path):
+    """-v 1 (the default): print_stat's lines (SubSampler.cpp:633-665) with the numbers of the oracle, in the
+    reference's wording and order, and the comparator's progress lines (Comparator.cpp:56,69,364,414,494,498,503,509)."""
+    k, m, s = 31, 11, 20
+    gs = synth.family_genomes(5, 2, 60_000, 1, [0.0, 0.02])
+    names = []
+    for i, g in enumerate(gs):
+        path = tmp_path / ("v%d.fa" % i)
+        path.write_bytes(synth.to_fasta(g, "g%d" % i, n_records=2))
+        names.append(str(path))
+    (tmp_path / "g.txt").write_text("\n".join(names) + "\n")
+    r = subprocess.run([os.path.join(ROOT, "bin", "sub_sampler"), "-f", "g.txt", "-k", str(k), "-m", str(m), "-s", str(s), "-t", "1"],
+                       cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = r.stdout
+    assert out.startswith(" I use k=31 m=11 s=20\nMaximal super kmer are of length 51 or 21 kmers\n")
+    at = 0
+    for i, nm in enumerate(names):
+        _, st = orc.sketch_fasta(open(nm, "rb").read(), k, m, float(np.float32(s)))
+        want = [nm,
+                "I have seen %s kmers and I selected %s kmers" % (_fmt_commas(st["total_kmer_number"]), _fmt_commas(st["selected_kmer_number"])),
+                "After removing duplicate kmers, I selected %s kmers" % _fmt_commas(st["seen_kmers_at_reconstruction"]),
+                "This means a practical subsampling rate of ", "This means a practical subsampling rate of ",
+                "I have seen %s superkmers and I selected %s superkmers" % (_fmt_commas(st["total_superkmer_number"]), _fmt_commas(st["selected_superkmer_number"])),
+                "After reconstruction and filtering with abundance, I have selected %s superkmers" % _fmt_commas(st["seen_superkmers_at_reconstruction"]),
+                "This means a practical subsampling rate of ", "This means a practical subsampling rate of ",
+                "This means a mean superkmer size of ", "This means a mean superkmer size of ", "This means a mean superkmer size of ",
+                "Actual output file size is ", "This mean ", "Minimizer number: %s Skmer/minimizer:  " % _fmt_commas(st["actual_minimizer_number"]),
+                "Minimizer number: %s Skmer/minimizer without duplicates: " % _fmt_commas(st["actual_minimizer_number"]),
+                "Density is: ", "Number of maximal skmer was:       %s" % _fmt_commas(st["count_maximal_skmer"]),
+                "Actual number of maximal skmer is: %s" % _fmt_commas(st["seen_max_superkmers_at_reconstruction"]),
+                "Proportion of max skmers:        ", "Actual proportion of max skmers: "]
+        for line in want:
+            nxt = out.find(line, at)
+            assert nxt >= 0, (line, out[at:at + 400])
+            at = nxt + len(line)
+    # a number printed with cout's default formatting: total / selected super-k-mers, 6 significant digits
+    _, st0 = orc.sketch_fasta(open(names[0], "rb").read(), k, m, float(np.float32(s)))
+    assert ("This means a mean superkmer size of %g kmer per superkmer in the input" % (st0["total_kmer_number"] / st0["total_superkmer_number"])) in out
+    r = subprocess.run([os.path.join(ROOT, "bin", "comparator"), "-f", "subsampled_g.txt"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = r.stdout.split("\n")
+    assert lines[0] == "No query file, I will perform a all versus all comparison" and lines[1] == "I found 2 documents"
+    assert lines[2] == "kmers evaluated are of length: 31 minimizer size is 11" and lines[3] == "Comparisons done"
+    assert lines[4].startswith("Comparisons lasted ") and lines[4].endswith(" sec")
+    assert lines[5] == "Containement index dump " and lines[6] == "Jackard index dump"
+    assert lines[7].startswith("Jaccard output lasted ") and lines[7].endswith(" sec")
+
+
 def test_cli_k_equals_m_with_empty_sketches(tmp_path):
     """k == m = 15 and genomes shorter than k in the list: their sketches are header-only, and the comparator's merge
     gives each of them its predecessor's first minimizer as a phantom k-mer (Comparator.cpp:294,316-319).  The
