@@ -430,6 +430,7 @@ def cpu_baseline(recs, payloads, p, gpu_superkmers, d_inter):
     Checker code used as a reported baseline -- never on the product path.  While it is at it, it checks the
     timed GPU step against it: super-k-mers emitted over the same records, pair matrix over the same sketches."""
     from oracle import oracle_py as orc
+    build_flags = orc.use_native()      # BASELINE.md 2: -O3 -march=native -fopenmp, for this host's CPU
     budget, spent, kmers, used, emitted = 12.0, 0.0, 0, 0, 0
     for r in recs:  # bounded sample: whole records until ~12 s of single-thread CPU work
         if spent >= budget:
@@ -455,23 +456,13 @@ def cpu_baseline(recs, payloads, p, gpu_superkmers, d_inter):
         parity["superkmers_per_step"] = bool(emitted == gpu_superkmers)
     return {"parity_vs_oracle": parity, "value": kmers / spent if spent > 0 else None, "unit": "k-mers hashed/s", "cores": 1, "kind": "port",
             "cpu_model": cpu_model(), "host_threads_available": cores,
-            "build": "oracle/Makefile: g++ " + oracle_flags(),
+            "build": "g++ " + str(build_flags),
             "sample": "oracle scan loop (SubSampler.cpp:357-455 restated), single thread, first %d of %d records "
                       "of the same workload, %.1f s" % (used, len(recs), spent),
             "all_cores": all_cores,
             "sketch_pairs_per_s": (n * (n - 1) // 2) / csec if csec > 0 else None,
             "pairs_sample": "oracle compare_sketches (Comparator.cpp:39-287 restated) over the same %d sketches, "
                             "single thread, %.2f s" % (n, csec)}
-
-
-def oracle_flags():
-    try:
-        for line in open(os.path.join(ROOT, "oracle", "Makefile")):
-            if line.startswith("CXXFLAGS"):
-                return line.split("=", 1)[1].strip()
-    except OSError:
-        pass
-    return "?"
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -44,6 +44,28 @@ def build(force=False):
 
 
 _lib = None
+BUILD_FLAGS = None     # set by use_native(): the flags of the library in use, for bench.py's report
+
+
+def use_native():
+    """bench.py's timed leg: (re)build the oracle with BASELINE.md's flags for THIS host (-O3 -march=native -fopenmp)
+    and switch to it.  Returns the flags in use; falls back to the shipped portable build if the box has no compiler."""
+    global _lib, _SO, BUILD_FLAGS
+    flags = None
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        native = os.path.join(_HERE, "liboracle_native.so")
+        if os.path.exists(native):
+            _SO, _lib = native, None
+            flags = "-O3 -march=native -fopenmp -std=c++17 (built on this host)"
+    except Exception:  # noqa: BLE001
+        pass
+    if flags is None:
+        for line in open(os.path.join(_HERE, "Makefile")):
+            if line.startswith("CXXFLAGS"):
+                flags = line.split("=", 1)[1].strip() + " (portable build shipped with the repository)"
+    BUILD_FLAGS = flags
+    return flags
 
 
 def lib():

@@ -139,3 +139,76 @@ def payload_set(payload):
             for j in range(len(q) - k + 1):
                 s.add((b, canon_val(q[j:j + k])))
     return s
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Second witness for the reference's tie rules.  Written from SubSampler.cpp:81-169 and :357-455
+# as DESCRIPTIONS over strings -- occurrences of the winning m-mer, their strands and distances -- not as a
+# transcription of the bit-level loop, and not derived from oracle/.
+def model_rescan(kmer_str, k, m):
+    """what regular_minimizer_pos returns for one k-mer: (canonical value, believed position, is_rev).
+
+    The k-mer is read right to left.  The winner is the canonical m-mer of smallest hash (XXH64 on 8 bytes is a
+    bijection, so equal hashes mean equal m-mers); it is first met at its RIGHTMOST occurrence, whose strand
+    becomes the winner's strand.  Position: that occurrence's offset -- except that the very first m-mer looked at
+    (the rightmost of the k-mer), when it reads reverse, starts at position 0 (:89-93).  Every further occurrence
+    to the left ON THE SAME STRAND then pulls the position: a forward winner moves to the leftmost such offset
+    (:158-164); a reverse winner compares the position with the DISTANCE FROM THE RIGHT END (the loop index,
+    :151-157) and takes the smaller.  Occurrences on the other strand change nothing (:137-149)."""
+    km = k - m
+    occ = []                                   # (offset, canonical value, hash, reads_reverse), right to left
+    for off in range(km, -1, -1):
+        sub = kmer_str[off:off + m]
+        c = canon_val(sub)
+        occ.append((off, c, h64(c), val(sub) != c))
+    best_hash = min(o[2] for o in occ)
+    hits = [o for o in occ if o[2] == best_hash]          # right to left
+    off0, value, _, rev0 = hits[0]
+    position = 0 if (off0 == km and rev0) else off0
+    for off, _, _, rev in hits[1:]:
+        if rev != rev0:
+            continue
+        if rev0:
+            position = min(position, km - off)
+        else:
+            position = min(position, off)
+    return value, position, int(rev0)
+
+
+def model_scan(seq, k, m, T):
+    """the scan loop of one record (SubSampler.cpp:357-455) over a string: ([(start, len, minimizer, rev)] of the
+    selected super-k-mers, number of ALL super-k-mers).  State: the current minimizer, its hash, where the scan
+    believes it sits and on which strand; `dump` after every rescan."""
+    if len(seq) < k:
+        return [], 0
+    w1 = k - m + 1
+    out, total = [], 0
+    mini, pos, rev = model_rescan(seq[:k], k, m)
+    old_mini, old_rev = mini, rev
+    hmin = h64(mini)
+    last = 0
+    i = 0
+    while i + k < len(seq):
+        sub = seq[i + w1:i + w1 + m]                      # the m-mer entering on the right
+        c = canon_val(sub)
+        hc = h64(c)
+        dump = False
+        if hc < hmin:
+            mini, hmin, pos, rev = c, hc, i + w1, int(val(sub) != c)
+        elif i >= pos:
+            mini, rel, rev = model_rescan(seq[i + 1:i + 1 + k], k, m)
+            hmin = h64(mini)
+            pos = rel + i + 1
+            dump = True
+        if old_mini != mini or dump:
+            if h64(old_mini) <= T:
+                out.append((last, i + k - last, old_mini, old_rev))
+            total += 1
+            last = i + 1
+            old_mini, old_rev = mini, rev
+        i += 1
+    if len(seq) - last > k - 1:
+        if h64(old_mini) <= T:
+            out.append((last, len(seq) - last, old_mini, old_rev))
+        total += 1
+    return out, total

@@ -109,6 +109,64 @@ def test_rescan_equals_bruteforce_minimum():
                 assert pos == best
 
 
+def _repeat_rich(rng, n):
+    """DNA in which m-mers recur inside one window, on both strands: short tandem units, a small library of
+    pieces and their reverse complements, low-complexity stretches."""
+    lib = [bf.random_dna(rng, int(rng.integers(4, 40))) for _ in range(6)]
+    out = []
+    while sum(map(len, out)) < n:
+        r = rng.random()
+        piece = lib[int(rng.integers(0, len(lib)))]
+        if r < 0.3:
+            out.append(piece * int(rng.integers(2, 6)))
+        elif r < 0.5:
+            out.append(bf.rc_str(piece))
+        elif r < 0.6:
+            out.append("ACGT"[int(rng.integers(0, 4))] * int(rng.integers(5, 60)))
+        elif r < 0.7:
+            out.append(bf.mutate(rng, piece, 0.1))
+        elif r < 0.8:
+            out.append(bf.random_dna(rng, int(rng.integers(1, 30))))
+        else:
+            out.append(piece)
+    return "".join(out)[:n]
+
+
+def test_tie_rules_second_witness_rescan():
+    """H5: windows that hold their minimizer more than once, on either strand.  The oracle's regular_minimizer_pos
+    against bruteforce.model_rescan, a description of SubSampler.cpp:81-169 over occurrences (not a transcription of
+    the loop) -- ~7 000 windows, ~2 000 of them with a repeated m-mer."""
+    rng = np.random.default_rng(2718)
+    checked = repeated = 0
+    for (k, m) in [(31, 11), (21, 11), (15, 9), (33, 13), (63, 15), (15, 15), (17, 5)]:
+        text = _repeat_rich(rng, 3000)
+        for j in range(0, len(text) - k + 1, 3):
+            s = text[j:j + k]
+            cv = [bf.canon_val(s[p:p + m]) for p in range(k - m + 1)]
+            repeated += len(set(cv)) != len(cv)
+            assert orc.rescan(k, m, s) == bf.model_rescan(s, k, m), (k, m, s)
+            checked += 1
+    assert checked > 6000 and repeated > 1500
+
+
+def test_tie_rules_second_witness_scan():
+    """the whole scan loop on repeat-rich records: selected super-k-mers (start, length, minimizer, strand) and the
+    count of ALL super-k-mers (the `dump` cuts of the believed position) against bruteforce.model_scan."""
+    rng = np.random.default_rng(31415)
+    for (k, m, s) in [(31, 11, 3), (21, 11, 1.0), (15, 9, 2), (33, 13, 5), (63, 15, 4), (15, 15, 2), (17, 5, 1.5)]:
+        T = orc.threshold(k, m, s)
+        recs = [_repeat_rich(rng, int(rng.integers(200, 1500))) for _ in range(6)] + [bf.random_dna(rng, 600), "A" * 200, "ACG" * 100]
+        bases, offs = orc.clean_fasta(bf.fasta(recs))
+        got, st = orc.scan(k, m, T, bases, offs)
+        want, total = [], 0
+        for r, seq in enumerate(recs):
+            em, n_all = bf.model_scan(seq, k, m, T)
+            want += [(r, a, b, c, d) for (a, b, c, d) in em]
+            total += n_all
+        assert [(int(e["rec"]), int(e["start"]), int(e["len"]), int(e["minimizer"]), int(e["rev"])) for e in got] == want, (k, m, s)
+        assert st["total_superkmer_number"] == total, (k, m, s)
+
+
 def _records(rng, lens):
     return [bf.random_dna(rng, n) for n in lens]
 
