@@ -52,6 +52,7 @@ typedef struct spsp_params {
 #define SPSP_SCAN_DIRECT_HASH 1u /* force XXH64 at every position (no LDS pre-filter) */
 #define SPSP_SCAN_LDS_FILTER 2u  /* force the 2^20-bit memoised LDS pre-filter (one lookup per position) */
 #define SPSP_SCAN_PAIR_FILTER 4u /* force the 64 KiB pair table (one lookup per two positions, m >= 9) */
+#define SPSP_SCAN_BLOOM_FILTER 16u /* force the blocked Bloom filter over canonical m-mers (m = 13 or 15) */
 #define SPSP_SCAN_STATS 8u       /* spsp_sketch_text / spsp_sketch_file: also count EVERY super-k-mer of the input
                                     (total_superkmer_number of print_stat, SubSampler.cpp:430,452) -- an extra pass */
 

@@ -22,6 +22,7 @@ SPSP_SCAN_DIRECT_HASH = 1
 SPSP_SCAN_LDS_FILTER = 2
 SPSP_SCAN_PAIR_FILTER = 4
 SPSP_SCAN_STATS = 8
+SPSP_SCAN_BLOOM_FILTER = 16
 
 
 class SpspError(RuntimeError):

@@ -110,6 +110,11 @@ struct spsp_ctx {
     uint64_t filter_thr = 0;
     uint32_t filter_shift = 0;
     bool filter_valid = false;
+    // blocked Bloom filter over canonical m-mers (k_dense_bloom)
+    spsp::DevBuf bloom;
+    uint32_t bloom_m = 0;
+    uint64_t bloom_thr = 0;
+    bool bloom_valid = false;
     // pair-lookup table cache (64 KiB table + 8 KiB key bitmap)
     spsp::DevBuf pairtab;
     uint32_t pair_m = 0;

@@ -21,6 +21,7 @@
 //
 // Output = exactly the argument stream of Subsampler::handle_superkmer.
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 
 #include "spsp_internal.h"
@@ -795,6 +796,154 @@ __global__ __launch_bounds__(kThreads) void k_expand(const uint8_t* __restrict__
     }
 }
 
+// ------------------------------------------ dense pass, blocked-Bloom form ---
+// Fine sampling at long minimizers (k63 m15 s100: 1.1 x 10^5 selectable canonical 15-mers) fills a fifth of the
+// 10-base prefix table, and hashing a fifth of all positions costs more than the table test of all of them.  The
+// prefix table cannot be sharpened: 2^20 bits hold 2.2 x 10^5 keys (both strands) at ~5 bits each, whatever the
+// index.  So this form halves the keys -- it tests the CANONICAL m-mer, two extra instructions per position --
+// and spends the bits as a blocked Bloom filter: the top 15 bits of the canonical value pick one 32-bit word of a
+// 128 KiB table, three 5-bit fields of the rest pick three bits in it; ONE ds_read_b32 per position, ~2 % of the
+// positions (instead of ~20 %) go on to XXH64.  Everything else is k_dense_single.
+template <int M>
+__global__ void k_build_bloom(uint64_t thr, uint32_t* __restrict__ tab) {
+    const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= (1ull << (2 * M))) return;
+    const uint32_t v = (uint32_t)x;
+    if (rc_mmer32(v, M) < v) return;          // canonical values only
+    if (xxh64_u64(v) > thr) return;
+    atomicOr(&tab[v >> (2 * M - 15)], (1u << (v & 31u)) | (1u << ((v >> 5) & 31u)) | (1u << ((v >> 10) & 31u)));
+}
+
+// survivors of one lane's 16 positions: bit j = the canonical m-mer at offset j passes the filter
+template <int M>
+__device__ __forceinline__ uint32_t bloom_lookup16(const uint32_t* __restrict__ tab, uint32_t hi, uint32_t nxt) {
+    const uint64_t R = rc_window64(((uint64_t)hi << 32) | nxt);
+    const uint32_t rhi = (uint32_t)(R >> 32), rlo = (uint32_t)R;
+    uint32_t acc = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        // m-mer in the top 2M bits of a word; the bits below are other bases: they only ever break ties between a
+        // palindromic m-mer and itself
+        const uint32_t f = j == 0 ? hi : __builtin_amdgcn_alignbit(hi, nxt, 32 - 2 * j);
+        const int rs = 2 * j + 2 * M - 32;                 // the reverse complement of offset j: bits [2j, 2j + 2M) of R
+        const uint32_t r = rs < 0 ? (rlo << -rs) : (rs == 0 ? rlo : __builtin_amdgcn_alignbit(rhi, rlo, rs & 31));
+        const uint32_t c = f < r ? f : r;
+        const uint32_t w = tab[c >> 17];
+        const uint32_t v = c >> (32 - 2 * M);
+        const uint32_t t = (w >> (v & 31u)) & (w >> ((v >> 5) & 31u)) & (w >> ((v >> 10) & 31u));
+        acc = __builtin_amdgcn_alignbit(t, acc, 1);
+    }
+    return acc >> 16;
+}
+
+constexpr int kBloomBytes = 131072;
+
+template <int M>
+__global__ __launch_bounds__(64 * kPairWaves) void k_dense_bloom(const uint8_t* __restrict__ bases, uint64_t n, uint64_t thr,
+                                                                const uint32_t* __restrict__ bloom, uint64_t n_rows, WaveLists L) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds1[];
+    uint32_t* tab = reinterpret_cast<uint32_t*>(lds1);
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    uint2* queue = reinterpret_cast<uint2*>(lds1 + kBloomBytes) + wave * kQueueCap1;   // ring of {rel pos, m-mer}
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(bloom);
+        uint4* dst = reinterpret_cast<uint4*>(tab);
+        for (uint32_t i = threadIdx.x; i < kBloomBytes / 16; i += 64 * kPairWaves) dst[i] = src[i];
+    }
+    __syncthreads();
+    constexpr uint32_t m = M;
+    const uint64_t n_mmers = n >= m ? n - m + 1 : 0;
+    const uint32_t mm = (1u << (2 * m)) - 1u;
+    const uint64_t gw = (uint64_t)blockIdx.x * kPairWaves + wave;
+    const uint64_t first = gw * L.rows_per_wave;              // see k_dense_pair
+    const uint64_t lim = first + L.rows_per_wave < n_rows ? first + L.rows_per_wave : n_rows;
+    const uint64_t n_my = first < lim ? lim - first : 0;
+    const uint64_t base_pos = first * kRowPosPair63;
+    constexpr uint64_t row_bytes = kRowPosPair63;
+    Hit* out = L.raw + gw * L.cap;
+    uint32_t out_n = 0, qn = 0, head = 0;
+    auto drain = [&](uint32_t keep_below) {
+        while (qn >= keep_below && qn > 0) {
+            const uint32_t take = qn < 64 ? qn : 64;
+            bool is_hit = false;
+            uint64_t pos = 0, hash = 0;
+            uint32_t f = 0, x = 0;
+            if (lane < take) {
+                uint32_t at = head + lane;
+                if (at >= (uint32_t)kQueueCap1) at -= kQueueCap1;
+                const uint2 e = queue[at];
+                pos = base_pos + e.x; f = e.y;
+                const uint32_t rc = rc_mmer32(f, m);
+                x = f < rc ? f : rc;
+                hash = xxh64_u64(x);
+                is_hit = pos < n_mmers && hash <= thr;
+            }
+            out_n = append_hits(is_hit, pos, x, f, hash, out, L.cap, out_n);
+            head += take; if (head >= (uint32_t)kQueueCap1) head -= kQueueCap1;
+            qn -= take;
+        }
+    };
+    auto handle = [&](uint32_t cand, uint32_t rel, uint32_t hi, uint32_t nxt) {
+        if (!__ballot(cand != 0)) return;
+        const uint32_t cnt = __popc(cand);
+        uint32_t idx = 0, total = 0;
+#pragma unroll
+        for (int b = 0; b < 5; ++b) {
+            const unsigned long long plane = __ballot((cnt >> b) & 1u);
+            idx += __builtin_amdgcn_mbcnt_hi((uint32_t)(plane >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)plane, 0u)) << b;
+            total += (uint32_t)__popcll(plane) << b;
+        }
+        const uint64_t W = ((uint64_t)hi << 32) | nxt;
+        uint32_t c = cand;
+        for (uint32_t base = 0; base < total; base += kPushWindow) {
+            const uint32_t tail = head + qn;
+            while (c && idx < base + kPushWindow) {
+                const uint32_t j = __ffs(c) - 1;
+                c &= c - 1;
+                uint32_t at = tail + (idx - base);
+                if (at >= (uint32_t)kQueueCap1) at -= kQueueCap1;
+                if (at >= (uint32_t)kQueueCap1) at -= kQueueCap1;
+                queue[at] = make_uint2(rel + j, (uint32_t)(W >> (64 - 2 * m - 2 * j)) & mm);
+                ++idx;
+            }
+            qn += total - base < (uint32_t)kPushWindow ? total - base : (uint32_t)kPushWindow;
+            drain(64);
+        }
+    };
+    const uint64_t full_rows = n >= 64 * kChunk ? (n - 64 * kChunk) / kRowPosPair63 + 1 : 0;
+    const uint64_t n_fast_all = first < full_rows ? full_rows - first : 0;
+    const uint64_t n_fast = n_fast_all < n_my ? n_fast_all : n_my;
+    uint64_t i = 0;
+    const uint8_t* ptr = bases + first * kRowPosPair63 + (uint64_t)lane * kChunk;
+    uint4 raw0 = make_uint4(0, 0, 0, 0), raw1 = raw0;
+    if (i < n_fast) raw0 = *reinterpret_cast<const uint4*>(ptr);
+    if (i + 1 < n_fast) raw1 = *reinterpret_cast<const uint4*>(ptr + row_bytes);
+    const bool halo_lane = lane >= kRowChunks;
+    uint32_t rel = lane * kChunk;
+    const uint32_t rel_step = (uint32_t)row_bytes;
+    auto body = [&](uint4& raw, uint64_t r, const uint8_t* at, uint32_t rl) {
+        const uint32_t hi = pack16(raw);
+        raw = *reinterpret_cast<const uint4*>(r + 2 < n_fast ? at + 2 * row_bytes : at);
+        const uint32_t nxt = __shfl_down(hi, 1);
+        const uint32_t c = bloom_lookup16<M>(tab, hi, nxt);
+        handle(halo_lane ? 0u : c, rl, hi, nxt);
+    };
+    for (; i + 1 < n_fast; i += 2, ptr += 2 * row_bytes, rel += 2 * rel_step) {
+        body(raw0, i, ptr, rel);
+        body(raw1, i + 1, ptr + row_bytes, rel + rel_step);
+    }
+    if (i < n_fast) { body(raw0, i, ptr, rel); ++i; rel += rel_step; }
+    for (; i < n_my; ++i, rel += rel_step) {
+        const uint32_t hi = load_pack(bases, n, (first + i) * kRowPosPair63 + (uint64_t)lane * kChunk);
+        const uint32_t nxt = __shfl_down(hi, 1);
+        const uint32_t c = bloom_lookup16<M>(tab, hi, nxt);
+        handle(halo_lane ? 0u : c, rel, hi, nxt);
+    }
+    drain(1);
+    if (lane == 0) L.cnt[gw] = out_n;
+}
+
 // ------------------------------------------------------------ compact pass --
 // Per-wave hit lists of the table variants -> one array in position order, with the record of every hit
 // filled in.  Wave w's hits precede wave w+1's and each list is sorted, so the place of a hit is the sum of
@@ -1100,16 +1249,42 @@ int check_params(const spsp_params* p) {
 
 // Picks the dense-pass variant from the expected survivor rate of each memoised table:
 // P(hash <= T) times the m-mers (both strands) that share one table bit.
-enum { kDenseDirect = 0, kDenseSingle = 1, kDensePair = 2 };
+enum { kDenseDirect = 0, kDenseSingle = 1, kDensePair = 2, kDenseBloom = 3 };
 static int pick_dense(const spsp_params* p) {
+    const bool bloom_ok = p->m == 13 || p->m == 15;
     if (p->flags & SPSP_SCAN_DIRECT_HASH) return kDenseDirect;
+    if ((p->flags & SPSP_SCAN_BLOOM_FILTER) && bloom_ok) return kDenseBloom;
     if ((p->flags & SPSP_SCAN_LDS_FILTER) && p->m >= 10) return kDenseSingle;
     if ((p->flags & SPSP_SCAN_PAIR_FILTER) && p->m >= 9) return kDensePair;
     const double frac = (double)p->threshold / 18446744073709551616.0;  // P(hash <= T)
     const uint32_t bits = 2 * p->m;
     if (p->m >= 9 && frac * (double)(1u << (bits - 16)) < 0.01) return kDensePair;
-    if (p->m >= 10 && frac * (double)(1u << (bits - 20)) < 0.30) return kDenseSingle;
+    // expected share of positions that go on to XXH64: prefix table (both strands' m-mers per 10-base prefix) against
+    // the blocked Bloom filter (three bits per canonical m-mer in one of 2^15 words, ~fill^3)
+    const double single = p->m >= 10 ? frac * (double)(1u << (bits - 20)) : 1.0;
+    double bloom = 1.0;
+    if (bloom_ok) {
+        const double keys_per_word = frac * (double)(1ull << bits) / 2.0 / 32768.0;
+        const double fill = 1.0 - exp(-3.0 * keys_per_word / 32.0);
+        bloom = fill * fill * fill;
+    }
+    // measured on 5 x 10^8 positions: prefix-table test 0.235 ms + ~1.0 ms x (share hashed); Bloom test 0.26 ms + the same
+    if (single < 0.10 || (single < 0.30 && !(bloom < 0.5 * single))) return kDenseSingle;
+    if (bloom < 0.30) return kDenseBloom;
     return kDenseDirect;
+}
+
+static int ensure_bloom(spsp_ctx* ctx, const spsp_params* p) {
+    if (ctx->bloom_valid && ctx->bloom_m == p->m && ctx->bloom_thr == p->threshold) return SPSP_OK;
+    int rc = ctx->bloom.reserve((size_t)kBloomBytes);
+    if (rc) return rc;
+    SPSP_HIP(hipMemsetAsync(ctx->bloom.p, 0, (size_t)kBloomBytes, ctx->stream));
+    const uint64_t total = 1ull << (2 * p->m);
+    if (p->m == 15) hipLaunchKernelGGL(k_build_bloom<15>, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, ctx->stream, p->threshold, ctx->bloom.as<uint32_t>());
+    else hipLaunchKernelGGL(k_build_bloom<13>, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, ctx->stream, p->threshold, ctx->bloom.as<uint32_t>());
+    SPSP_HIP(hipGetLastError());
+    ctx->bloom_m = p->m; ctx->bloom_thr = p->threshold; ctx->bloom_valid = true;
+    return SPSP_OK;
 }
 
 static int ensure_key10(spsp_ctx* ctx, const spsp_params* p) {
@@ -1182,6 +1357,7 @@ static int launch_dense(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_ba
         if ((rc = ctx->wave_cnt.reserve((size_t)LP->n_lists * 4))) return rc;
         if (variant == kDenseSingle && (rc = ensure_key10(ctx, p))) return rc;
         if (variant == kDensePair && (rc = ensure_pairtab(ctx, p))) return rc;
+        if (variant == kDenseBloom && (rc = ensure_bloom(ctx, p))) return rc;
     } else {
         if ((rc = ctx->bitmap.reserve((size_t)n_tiles * kTileWords * 4))) return rc;
         if ((rc = ctx->tile_count.reserve((size_t)n_tiles * 4))) return rc;
@@ -1199,6 +1375,17 @@ static int launch_dense(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_ba
             }
             hipLaunchKernelGGL(k_dense_pair, dim3(LP->grid), dim3(64 * kPairWaves), lds, ctx->stream, d_bases, n_bases, p->m,
                                p->threshold, ctx->pairtab.as<uint8_t>(), LP->n_rows, L);
+        } else if (variant == kDenseBloom) {
+            const size_t lds = (size_t)kBloomBytes + (size_t)kPairWaves * kQueueCap1 * 8;
+            if (!ctx->attr_bloom_set) {
+                SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_bloom<15>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_bloom<13>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                ctx->attr_bloom_set = true;
+            }
+            if (p->m == 15) hipLaunchKernelGGL(k_dense_bloom<15>, dim3(LP->grid), dim3(64 * kPairWaves), lds, ctx->stream, d_bases, n_bases,
+                                               p->threshold, ctx->bloom.as<uint32_t>(), LP->n_rows, L);
+            else hipLaunchKernelGGL(k_dense_bloom<13>, dim3(LP->grid), dim3(64 * kPairWaves), lds, ctx->stream, d_bases, n_bases,
+                                    p->threshold, ctx->bloom.as<uint32_t>(), LP->n_rows, L);
         } else {
             const size_t lds = (size_t)kKey10Bytes + (size_t)kPairWaves * kQueueCap1 * 8;
             if (!ctx->attr_single_set) {

@@ -37,7 +37,8 @@ def _assert_stream_equal(got, want):
         assert bad.size == 0, (f, int(bad[0]), got[bad[0]], want[bad[0]])
 
 
-MODES = [sp.SPSP_SCAN_DIRECT_HASH, sp.SPSP_SCAN_LDS_FILTER, sp.SPSP_SCAN_PAIR_FILTER, sp.SPSP_SCAN_DEFAULT]
+# (the blocked-Bloom variant exists for m = 13 and m = 15; with other m the flag leaves the choice to the library)
+MODES = [sp.SPSP_SCAN_DIRECT_HASH, sp.SPSP_SCAN_LDS_FILTER, sp.SPSP_SCAN_PAIR_FILTER, sp.SPSP_SCAN_DEFAULT, sp.SPSP_SCAN_BLOOM_FILTER]
 
 
 @pytest.mark.parametrize("mode", MODES)
@@ -112,7 +113,7 @@ def test_scan_randomised_configs(ctx):
         cuts = sorted(set([0, len(genome)] + [int(x) for x in rng.integers(0, len(genome), size=int(rng.integers(0, 5)))]))
         recs = [genome[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
         bases, offs = synth.concat_records(recs)
-        mode = [sp.SPSP_SCAN_DEFAULT, sp.SPSP_SCAN_DIRECT_HASH, sp.SPSP_SCAN_LDS_FILTER, sp.SPSP_SCAN_PAIR_FILTER][it % 4]
+        mode = [sp.SPSP_SCAN_DEFAULT, sp.SPSP_SCAN_DIRECT_HASH, sp.SPSP_SCAN_LDS_FILTER, sp.SPSP_SCAN_PAIR_FILTER, sp.SPSP_SCAN_BLOOM_FILTER][it % 5]
         p = sp.make_params(k, m, s, flags=mode)
         got = ctx.scan(p, bases, offs)
         want = _oracle_stream(k, m, p.threshold, bases, offs)
@@ -693,3 +694,40 @@ def test_full_size_genome_properties(ctx, mode):
     assert sk_f.key_set() == sk_r.key_set()  # canonical k-mers do not depend on the strand read
     inter, card = ctx.compare([sk_f, sk_r])
     assert inter[0, 1] == card[0] == card[1]
+
+
+def test_c5_shape_one_gbp_properties(ctx):
+    """BASELINE configs[4] shape (k63 m15 s100, records of 10^6 bp) at 1 Gbp, generated on the GPU: the first 12
+    records' super-k-mers equal the oracle's; over the whole gigabase the stream is ordered, disjoint and inside
+    its records, and the number of selected k-mers is n/s within 2 %; the dense pass alone finds as many hits as the
+    prefix-table and direct-hash variants (three independent dense kernels)."""
+    import torch
+    k, m, s = 63, 15, 100.0
+    rec_len, n_rec = 1_000_000, 1000
+    n = rec_len * n_rec
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev); gen.manual_seed(55)
+    lut = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=dev)
+    bases = torch.empty(n + 64, dtype=torch.uint8, device=dev)
+    for a in range(0, n, 1 << 27):
+        b = min(n, a + (1 << 27))
+        bases[a:b] = lut[torch.randint(0, 4, (b - a,), device=dev, generator=gen, dtype=torch.int64)]
+    off = torch.arange(0, n_rec + 1, dtype=torch.int64, device=dev) * rec_len
+    torch.cuda.synchronize()
+    p = sp.make_params(k, m, s)
+    d_out, n_out = ctx.scan_device(p, bases.data_ptr(), n, off.data_ptr(), n_rec)
+    sk = ctx.to_host(d_out, n_out, sp.SUPERKMER_DTYPE)
+    rec, start, ln = sk["rec"].astype(np.int64), sk["start"].astype(np.int64), sk["len"].astype(np.int64)
+    assert (np.diff(rec) >= 0).all() and (ln >= k).all() and (ln <= 2 * k - m).all() and (start + ln <= rec_len).all()
+    same = rec[1:] == rec[:-1]
+    assert (start[1:][same] >= start[:-1][same] + ln[:-1][same] - k + 1).all()
+    sel = int((ln - k + 1).sum())
+    assert abs(sel / ((n - n_rec * (k - 1)) / s) - 1.0) < 0.02
+    head = bases[:12 * rec_len].cpu().numpy()
+    want, _ = orc.scan(k, m, p.threshold, head, np.arange(13, dtype=np.uint64) * rec_len)
+    mine = sk[sk["rec"] < 12]
+    _assert_stream_equal(mine, want)
+    hits = [ctx.scan_hits_device(sp.make_params(k, m, s, flags=f), bases.data_ptr(), 200_000_000)
+            for f in (sp.SPSP_SCAN_BLOOM_FILTER, sp.SPSP_SCAN_LDS_FILTER, sp.SPSP_SCAN_DIRECT_HASH)]
+    assert hits[0] == hits[1] == hits[2] > 30_000
+    del bases

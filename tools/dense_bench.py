@@ -22,8 +22,8 @@ acgt = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=dev)
 bases = acgt[torch.randint(0, 4, (n,), device=dev, generator=g)]
 torch.cuda.synchronize()
 ctx = sp.Context(0, torch.cuda.current_stream().cuda_stream or None)
-for name, flag in (("pair", sp.SPSP_SCAN_PAIR_FILTER), ("single", sp.SPSP_SCAN_LDS_FILTER), ("direct", sp.SPSP_SCAN_DIRECT_HASH),
-                   ("default", sp.SPSP_SCAN_DEFAULT)):
+for name, flag in (("pair", sp.SPSP_SCAN_PAIR_FILTER), ("single", sp.SPSP_SCAN_LDS_FILTER), ("bloom", sp.SPSP_SCAN_BLOOM_FILTER),
+                   ("direct", sp.SPSP_SCAN_DIRECT_HASH), ("default", sp.SPSP_SCAN_DEFAULT)):
     if os.environ.get("ONLY") and os.environ["ONLY"] != name:
         continue
     p = sp.make_params(k, m, s, flags=flag)
