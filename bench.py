@@ -172,12 +172,13 @@ def main():
     exchange_kind = os.environ.get("BENCH_EXCHANGE", "gather") if use_dist else "none"
     if exchange_kind == "slots":      # key-partitioned: all-to-all of own keys + all-reduce of partial matrices
         for sl in slots:
-            sl.exchange = spd.SlotExchange(sl.cmp, K, args.genomes, int(my_sk_off[-1]), dev)
+            sl.exchange = spd.SlotExchange(sl.cmp, K, args.genomes, int(my_sk_off[-1]), dev, stream=sl.stream_b,
+                                           reduce=os.environ.get("BENCH_SLOT_REDUCE", "scatter"))
         sk_off = np.zeros(n_total + 1, dtype=np.uint64)
         sk_off[-1] = slots[0].exchange.max_keys * world           # log line only
     elif exchange_kind == "gather":   # all-gather of every rank's keys + strided row ownership
         for sl in slots:
-            sl.exchange = spd.KeyExchange(my_n, dev)
+            sl.exchange = spd.KeyExchange(my_n, dev, stream=sl.stream_b)
         sk_off = slots[0].exchange.sk_off
     else:
         sk_off = np.zeros(n_total + 1, dtype=np.uint64)
@@ -233,6 +234,8 @@ def main():
                 sl.exchange.end_collect(sl.d_inter)       # partial pair matrix done -> RCCL reduction
         else:
             sl.cmp.compare_end()
+            if exchange_kind == "gather":
+                sl.exchange.collect_rows(sl.d_inter)      # strips -> rank 0, on stream B
         last["n_out"], last["slot"] = n_out, sl
 
     def run_steps(n):
@@ -252,6 +255,8 @@ def main():
                     else:
                         mn_ptr, lo_ptr = d_all_min.data_ptr(), d_all_lo.data_ptr()
                     ctx.compare_device(K, mn_ptr, lo_ptr, None, sk_off, n_total, rank, world, sl.d_inter.data_ptr())
+                    if exchange_kind == "gather":
+                        sl.exchange.collect_rows(sl.d_inter)
                 last["n_out"], last["slot"] = n_out, sl
             return
         pending = None
@@ -366,7 +371,7 @@ def main():
                                        "slots": "genomes sharded by rank; sketch keys partitioned by hash, RCCL all-to-all behind "
                                                 "the scan, per-rank partial pair matrix, RCCL reduction",
                                        "gather": "genomes sharded by rank; RCCL all-gather of the packed sketch keys, every rank "
-                                                 "computes the pair-matrix rows i % N == rank (SURVEY.md 8e)"}[exchange_kind],
+                                                 "computes the pair-matrix rows i % N == rank, strips gathered on rank 0 (SURVEY.md 8e)"}[exchange_kind],
                        "exchange_check": exchange_check,
                        "step": ("scan(batch t) || all-vs-all(sketches of batch t-1): two slots with their own scan and comparison "
                                 "streams; dense passes never overlap each other, sparse stages and comparison run between and "

@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256) void k_zero_rows(uint32_t n, uint32_t row_firs
 // falls back to the global-dictionary forms.
 constexpr int kPartCap = 4096, kPartSlots = 7936, kGroupThreads = 1024;   // (record index + 1 fits the 13 low bits of a slot word)
 constexpr int kScatThreads = 1024, kScatPer = 4, kScatSub = kScatThreads * kScatPer;   // entries per sub-chunk
-constexpr int kMaxKeyParts = 4096;
+constexpr int kMaxKeyParts = 32768;   // x ~2 900 records: 9.5 x 10^7 keys per comparison (BASELINE configs[3] has 5.2 x 10^7)
 
 __device__ __forceinline__ uint64_t key_hash(uint64_t lo, uint32_t mn, uint64_t hi, bool has_hi) {
     uint64_t h = mix64(lo ^ 0xA0761D6478BD642FULL);
@@ -440,12 +440,12 @@ __global__ __launch_bounds__(kScatThreads, 4) void k_parts_scatter(Keys K, const
                                                                uint32_t* __restrict__ part_cnt, uint64_t* __restrict__ recs,
                                                                uint32_t* __restrict__ flags) {
     constexpr uint32_t W = HAS_HI ? 4 : 3;
-    __shared__ uint32_t hist[kMaxKeyParts];
+    extern __shared__ uint32_t hist[];                   // [n_parts]
     const uint32_t t = threadIdx.x, lane = t & 63;
     const uint64_t base = (uint64_t)blockIdx.x * E * kScatThreads;
     for (uint32_t p = t; p < n_parts; p += kScatThreads) hist[p] = 0;
     uint64_t lo[E], hi[E];
-    uint32_t mn[E], pr[E];                                // pr = part | rank << 12
+    uint32_t mn[E], pr[E];                                // pr = part | rank << 15
 #pragma unroll
     for (int u = 0; u < E; ++u) {
         const uint64_t e = base + (uint64_t)u * kScatThreads + t;
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(kScatThreads, 4) void k_parts_scatter(Keys K, const
         pr[u] = 0xffffffffu;
         if (e < S) {
             const uint32_t part = (uint32_t)(((key_hash(lo[u], mn[u], hi[u], HAS_HI) >> 32) * n_parts) >> 32);
-            pr[u] = part | (atomicAdd(&hist[part], 1u) << 12);
+            pr[u] = part | (atomicAdd(&hist[part], 1u) << 15);
         }
     }
     __syncthreads();
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(kScatThreads, 4) void k_parts_scatter(Keys K, const
         const uint64_t e = base + (uint64_t)u * kScatThreads + t;
         if (e >= S) continue;
         const uint32_t j = sk_of[u];
-        const uint32_t part = pr[u] & 0xfffu, at = hist[part] + (pr[u] >> 12);
+        const uint32_t part = pr[u] & 0x7fffu, at = hist[part] + (pr[u] >> 15);
         if (at >= (uint32_t)kPartCap) continue;          // overflow: k_parts_group sees the count and raises the flag
         uint64_t* r = recs + ((uint64_t)part * kPartCap + at) * W;
         r[0] = lo[u];
@@ -1096,7 +1096,13 @@ static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t*
         if (r2) return r2;
         const uint32_t per_wg = 4u * kScatThreads;
         const dim3 grid((uint32_t)((S + per_wg - 1) / per_wg));
-#define SPSP_SCATTER(HI, E) hipLaunchKernelGGL((k_parts_scatter<HI, E>), grid, dim3(kScatThreads), 0, ctx->stream, K, sk, n, sub_sk, S, \
+        const size_t lds = (size_t)n_parts * 4;
+        if (lds > 48 * 1024 && !ctx->attr_scatter_set) {
+            SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_parts_scatter<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxKeyParts * 4));
+            SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_parts_scatter<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxKeyParts * 4));
+            ctx->attr_scatter_set = true;
+        }
+#define SPSP_SCATTER(HI, E) hipLaunchKernelGGL((k_parts_scatter<HI, E>), grid, dim3(kScatThreads), lds, ctx->stream, K, sk, n, sub_sk, S, \
                                                n_parts, ctx->c_part_cnt.as<uint32_t>(), ctx->c_recs.as<uint64_t>(), flags)
         if (has_hi) SPSP_SCATTER(true, 4);
         else SPSP_SCATTER(false, 4);

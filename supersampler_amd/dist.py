@@ -3,17 +3,24 @@
 One process per GPU.  Sketching shards genomes by rank with no collective.  The
 comparison has ONE key exchange step, in two forms:
 
-* `SlotExchange` (default): keys are partitioned by hash, every rank sends each
-  of its keys once (all-to-all of fixed-size slots), counts its hash class for
-  ALL pairs and the partial matrices are summed (all-reduce).  Per-rank traffic
-  and table size stay O(own keys) as ranks are added.
-* `KeyExchange`: an all-gather of the packed keys, after which every rank holds
-  all sketches and owns the pair-matrix rows `i % world == rank`.  O(all keys)
-  per rank; kept for query mode and as the simple form.
+* `KeyExchange` (default of bench.py, north_star's form): an all-gather of the
+  packed keys, after which every rank holds all sketches and computes the
+  pair-matrix rows `i % world == rank`; `collect_rows` returns the strips to
+  one rank (each cell crosses the fabric once).
+* `SlotExchange`: keys are partitioned by hash, every rank sends each of its
+  keys once (all-to-all of fixed-size slots), counts its hash class for ALL
+  pairs and the partial N x N matrices are summed (reduce-scatter by row
+  blocks, or all-reduce).  Per-rank key traffic stays O(own keys), but every
+  rank holds and reduces a full N x N partial matrix: DESIGN.md 5 prices both.
 
 Both work with backend "nccl" (= RCCL over xGMI, device tensors) and "gloo"
-(CPU tensors, used by the CPU tests).
+(CPU tensors, used by the CPU tests).  With "nccl", pass `stream=` (the
+torch.cuda.Stream the libspsp context was created on): RCCL orders itself
+against torch's CURRENT stream, so every collective and every torch copy of
+these classes runs inside `torch.cuda.stream(stream)` -- the same stream the
+context's kernels are queued on.
 """
+import contextlib
 import math
 
 import numpy as np
@@ -45,8 +52,9 @@ class KeyExchange:
     """Pre-sized all-gather of sketch keys.  `counts` = keys per local sketch
     (every rank must hold the same number of sketches)."""
 
-    def __init__(self, counts, device, use_hi=False, group=None):
+    def __init__(self, counts, device, use_hi=False, group=None, stream=None):
         self.group = group
+        self.stream = stream
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.device = device
@@ -62,6 +70,9 @@ class KeyExchange:
         self.starts = np.concatenate([[0], np.cumsum(self.per_rank)]).astype(np.int64)
         total = int(self.per_rank.sum())
         mk = lambda dt, n: torch.zeros(n, dtype=dt, device=device)
+        # compact position -> position in the padded gather buffer: ONE gather kernel per key array instead of a copy per rank
+        idx = np.concatenate([np.arange(int(self.per_rank[r]), dtype=np.int64) + r * self.pad for r in range(self.world)]) if total else np.zeros(0, np.int64)
+        self._idx = torch.from_numpy(idx.astype(np.int32 if self.world * self.pad < 2**31 else np.int64)).to(device)
         self._pad_min, self._pad_lo = mk(torch.int32, self.pad), mk(torch.int64, self.pad)
         self._g_min, self._g_lo = mk(torch.int32, self.world * self.pad), mk(torch.int64, self.world * self.pad)
         self.all_min, self.all_lo = mk(torch.int32, total), mk(torch.int64, total)
@@ -78,16 +89,41 @@ class KeyExchange:
             g.copy_(torch.cat(parts))
         else:
             dist.all_gather_into_tensor(g, padded, group=self.group)
-        for r in range(self.world):
-            out[self.starts[r]:self.starts[r + 1]] = g[r * self.pad:r * self.pad + int(self.per_rank[r])]
+        torch.index_select(g, 0, self._idx, out=out)
+
+    def _on_stream(self):
+        return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
 
     def exchange(self, my_min, my_lo, my_hi=None):
         """int32/int64 tensors (bit patterns of the uint32/uint64 keys) of this rank -> GatheredSketches."""
-        self._gather_one(self._g_min, self._pad_min, my_min, self.all_min)
-        self._gather_one(self._g_lo, self._pad_lo, my_lo, self.all_lo)
-        if self.use_hi:
-            self._gather_one(self._g_hi, self._pad_hi, my_hi, self.all_hi)
+        with self._on_stream():
+            self._gather_one(self._g_min, self._pad_min, my_min, self.all_min)
+            self._gather_one(self._g_lo, self._pad_lo, my_lo, self.all_lo)
+            if self.use_hi:
+                self._gather_one(self._g_hi, self._pad_hi, my_hi, self.all_hi)
         return GatheredSketches(self.all_min, self.all_lo, self.all_hi, self.sk_off)
+
+    def collect_rows(self, inter_local, dst=0):
+        """strips -> one rank: every rank sends the rows it owns (i % world == rank) of its n x n
+        int32 matrix; on `dst` they are put in place in `inter_local`, which then holds the whole matrix.  Each
+        cell crosses the fabric once (an all-reduce of the n x n matrices moves 2 (world-1)/world of ALL of them)."""
+        n = inter_local.shape[0]
+        with self._on_stream():
+            rows = -(-n // self.world)                                   # rows per rank, padded
+            mine = torch.zeros((rows, n), dtype=inter_local.dtype, device=inter_local.device)
+            own = inter_local[self.rank::self.world]
+            mine[:own.shape[0]] = own
+            if dist.get_backend(self.group) == "gloo" and mine.is_cuda:
+                torch.cuda.synchronize()
+                mine = mine.cpu()
+            parts = [torch.empty_like(mine) for _ in range(self.world)] if self.rank == dst else None
+            dist.gather(mine, parts, dst=dst, group=self.group)
+            if self.rank == dst:
+                for r in range(self.world):
+                    k = len(range(r, n, self.world))
+                    if r != dst:
+                        inter_local[r::self.world] = parts[r][:k].to(inter_local.device)
+        return inter_local
 
 
 def merge_rows(inter_local, n_total, rank, world, group=None):
@@ -106,8 +142,10 @@ class SlotExchange:
     Every rank must hold the same number of sketches `n_local`; global sketch id = rank * n_local + local id.
     """
 
-    def __init__(self, ctx, k, n_local, n_keys_local, device, slack=1.25, group=None):
+    def __init__(self, ctx, k, n_local, n_keys_local, device, slack=1.25, group=None, stream=None, reduce="all"):
         self.ctx, self.k, self.n_local, self.device, self.group = ctx, k, n_local, device, group
+        self.stream = stream      # torch.cuda.Stream wrapping ctx's stream (nccl): see the module docstring
+        self.reduce = reduce      # "all": all-reduce of the partial matrices; "scatter": reduce-scatter by row blocks
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.backend = dist.get_backend(group)
@@ -138,12 +176,16 @@ class SlotExchange:
         self.slot_cap *= 2
         self._alloc()
 
+    def _on_stream(self):
+        return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+
     def begin(self, d_min, d_lo, d_hi, sk_off):
         """device pointers of this rank's concatenated keys + host sk_off (n_local+1) -> handle for end()"""
         self.ctx.partition_keys_device(self.k, d_min, d_lo, d_hi, sk_off, self.n_local, self.world, self.slot_cap,
                                        self.send.data_ptr())
         if self.backend == "nccl":
-            return dist.all_to_all_single(self.recv, self.send, group=self.group, async_op=True)
+            with self._on_stream():
+                return dist.all_to_all_single(self.recv, self.send, group=self.group, async_op=True)
         if self.send.is_cuda:   # gloo with GPU compute (tests): stage through the host
             torch.cuda.synchronize()
             h_send, h_recv = self.send.cpu(), torch.empty(self.send.numel(), dtype=torch.uint8)
@@ -163,7 +205,8 @@ class SlotExchange:
     def end_queue(self, handle, d_inter):
         """first half of end(): wait for the slots, queue the partial comparison (returns without waiting)"""
         if handle is not None:
-            handle.wait()
+            with self._on_stream():
+                handle.wait()
         self.ctx.compare_slots_device_begin(self.k, self.recv.data_ptr(), self.world, self.n_local, self.slot_cap,
                                             d_inter.data_ptr())
 
@@ -177,7 +220,15 @@ class SlotExchange:
                 raise
             d_inter.view(-1)[0] += 1
         if self.backend == "nccl" or not d_inter.is_cuda:
-            dist.all_reduce(d_inter, op=dist.ReduceOp.SUM, group=self.group)
+            with self._on_stream():
+                n = d_inter.shape[0]
+                if self.reduce == "scatter" and n % self.world == 0 and self.backend == "nccl":
+                    # every rank ends with the summed rows [rank n/world, (rank+1) n/world) in place; (world-1)/world
+                    # of ONE matrix per rank on the wire instead of twice that
+                    blk = n // self.world
+                    dist.reduce_scatter_tensor(d_inter[self.rank * blk:(self.rank + 1) * blk], d_inter, op=dist.ReduceOp.SUM, group=self.group)
+                else:
+                    dist.all_reduce(d_inter, op=dist.ReduceOp.SUM, group=self.group)
         else:
             torch.cuda.synchronize()
             h = d_inter.cpu()

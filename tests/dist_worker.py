@@ -107,10 +107,133 @@ def main_slots(mode, rank, world, k, payloads, mine, counts, my_min, my_lo, per_
     return ok
 
 
+def c4_shaped_sets(n, keys_per_sketch, seed=4):
+    """BASELINE configs[3] shape in small: n sketches in families of 16, a member keeps ~80 % of its family's keys
+    and adds a few of its own.  Returns sorted uint64 key arrays (one bucket: minimizer 7)."""
+    rng = np.random.default_rng(seed)
+    fams = [np.unique(rng.integers(1, 2**62, size=keys_per_sketch + keys_per_sketch // 4, dtype=np.int64)) for _ in range((n + 15) // 16)]
+    out = []
+    for i in range(n):
+        base = fams[i // 16]
+        keep = base[rng.random(len(base)) < 0.8]
+        extra = rng.integers(1, 2**62, size=int(rng.integers(0, 4)), dtype=np.int64)
+        out.append(np.unique(np.concatenate([keep, extra])).astype(np.uint64) if i % 37 else np.zeros(0, np.uint64))
+    return out
+
+
+def expected_inter(sets):
+    """pair counts by an inverted index (plain numpy / Python)"""
+    n = len(sets)
+    holders = {}
+    for i, keys in enumerate(sets):
+        for key in keys.tolist():
+            holders.setdefault(key, []).append(i)
+    want = np.zeros((n, n), dtype=np.int32)
+    for hs in holders.values():
+        if len(hs) > 1:
+            a = np.array(hs)
+            ii, jj = np.triu_indices(len(a), 1)
+            np.add.at(want, (a[ii], a[jj]), 1)
+    return want
+
+
+def main_c4(mode, rank, world):
+    """8 ranks, 2 048 sketches: all-gather of the keys, rows i % world == rank, strips collected on rank 0.
+    cpu_c4: gloo, rows counted by numpy; nccl modes use the GPU kernels (see main_nccl)."""
+    per_rank = 256 if world >= 8 else 64
+    n_total = per_rank * world
+    sets = c4_shaped_sets(n_total, 24)
+    mine = sets[rank * per_rank:(rank + 1) * per_rank]
+    counts = [len(x) for x in mine]
+    my_lo = torch.from_numpy(np.concatenate(mine).view(np.int64))
+    my_min = torch.full((int(sum(counts)),), 7, dtype=torch.int32)
+    ex = spd.KeyExchange(counts, torch.device("cpu"))
+    g = ex.exchange(my_min, my_lo)
+    lo = g.kmer_lo.numpy().view(np.uint64)
+    for i in (0, 1, n_total // 2, n_total - 1):                       # gathered keys == every sketch's keys in global order
+        assert (lo[int(g.sk_off[i]):int(g.sk_off[i + 1])] == sets[i]).all(), i
+    gathered = [lo[int(g.sk_off[i]):int(g.sk_off[i + 1])] for i in range(n_total)]
+    holders = {}
+    for i, keys in enumerate(gathered):
+        for key in keys.tolist():
+            holders.setdefault(key, []).append(i)
+    local = torch.zeros((n_total, n_total), dtype=torch.int32)
+    ln = local.numpy()
+    for hs in holders.values():
+        for a_i, a in enumerate(hs):
+            if a % world == rank:                                     # only the rows this rank owns
+                for b in hs[a_i + 1:]:
+                    ln[a, b] += 1
+    full = ex.collect_rows(local)
+    ok = True
+    if rank == 0:
+        want = expected_inter(sets)
+        ok = bool((full.numpy() == want).all()) and int(want.sum()) > 10_000
+    return ok
+
+
+def main_nccl(rank, world):
+    """RCCL with more than one rank (needs >= 2 GPUs): both exchange forms with the real kernels, every collective
+    on the stream the libspsp context runs on."""
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", rank)))
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    stream = torch.cuda.Stream(device=dev)
+    ctx = sp.Context(dev.index, stream.cuda_stream)
+    k, per_rank = 31, 64
+    n_total = per_rank * world
+    sets = c4_shaped_sets(n_total, 300)
+    mine = sets[rank * per_rank:(rank + 1) * per_rank]
+    counts = [len(x) for x in mine]
+    with torch.cuda.stream(stream):
+        d_lo = torch.from_numpy(np.concatenate(mine).view(np.int64)).to(dev)
+        d_min = torch.full((int(sum(counts)),), 7, dtype=torch.int32, device=dev)
+        d_inter = torch.zeros((n_total, n_total), dtype=torch.int32, device=dev)
+    want = expected_inter(sets)
+    ex = spd.KeyExchange(counts, dev, stream=stream)
+    for _ in range(2):
+        g = ex.exchange(d_min, d_lo)
+        ctx.compare_device(k, g.minimizer.data_ptr(), g.kmer_lo.data_ptr(), None, g.sk_off, n_total, rank, world, d_inter.data_ptr())
+        full = ex.collect_rows(d_inter)
+    stream.synchronize()
+    ok = rank != 0 or bool((full.cpu().numpy() == want).all())
+    sk_off = np.zeros(per_rank + 1, dtype=np.uint64)
+    sk_off[1:] = np.cumsum(counts)
+    for reduce in ("all", "scatter"):
+        sx = spd.SlotExchange(ctx, k, per_rank, int(sk_off[-1]), dev, stream=stream, reduce=reduce)
+        with torch.cuda.stream(stream):
+            d2 = torch.zeros((n_total, n_total), dtype=torch.int32, device=dev)
+        sx.end(sx.begin(d_min.data_ptr(), d_lo.data_ptr(), None, sk_off), d2)
+        stream.synchronize()
+        got = d2.cpu().numpy()
+        if reduce == "all":
+            got[0, 0] = 0                                              # the overflow tally lives in an unused cell
+            ok = ok and bool((got == want).all())
+        else:
+            blk = n_total // world
+            rows = got[rank * blk:(rank + 1) * blk].copy()
+            if rank == 0:
+                rows[0, 0] = 0
+            ok = ok and bool((rows == want[rank * blk:(rank + 1) * blk]).all())
+    t = torch.tensor([1 if ok else 0], device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    ctx.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0 if int(t.item()) == 1 else 1)
+
+
 def main():
     mode = sys.argv[1]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    if mode == "nccl":
+        main_nccl(rank, world)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    if mode == "cpu_c4":
+        ok = main_c4(mode, rank, world)
+        dist.barrier()
+        dist.destroy_process_group()
+        sys.exit(0 if ok else 1)
     k, m, s, per_rank = 31, 11, 20, 5
     gs = synth.family_genomes(9, per_rank * world, 8_000, 2, [0.0, 0.01, 0.03])
     payloads = [orc.sketch_fasta(synth.to_fasta(g, "g%d" % i), k, m, s)[0] for i, g in enumerate(gs)]

@@ -10,11 +10,11 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _launch(mode, port):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2",
-               HSA_ENABLE_IPC_MODE_LEGACY="0")
+def _launch(mode, port, world=2):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world),
+               HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
     procs = []
-    for r in range(2):
+    for r in range(world):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dist_worker.py"), mode], env=e,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
@@ -39,3 +39,18 @@ def test_two_ranks_compare_device_rows():
 @pytest.mark.gpu
 def test_two_ranks_key_partitioned_exchange():
     _launch("gpu_slots", 29614)
+
+
+def test_eight_ranks_c4_shape_gloo_cpu():
+    """world_size 8, 2 048 sketches in families (BASELINE configs[3] in small): key all-gather, row ownership
+    i % 8 == rank, strips collected on rank 0 equal an inverted-index count over all 2.1 million pairs."""
+    _launch("cpu_c4", 29621, world=8)
+
+
+@pytest.mark.gpu
+def test_two_ranks_rccl_both_exchange_forms():
+    """backend "nccl" with two ranks, collectives on the contexts' own streams (needs two GPUs: skipped on a 1-GPU box)"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    _launch("nccl", 29623, world=2)

@@ -463,3 +463,31 @@ def test_partition_form_overflow_falls_back(ctx):
     assert [int(c) for c in card] == [len(s) for s in sets]
     want = np.triu(np.full((n, n), len(shared), dtype=np.uint32), 1)
     assert (inter == want).all()
+
+
+def test_eight_simulated_ranks_c4_shaped(ctx):
+    """BASELINE configs[3] shape on one GPU: 2 048 sketches (families of 16, ~600 keys each), the all-gather form's
+    per-rank call (rows i % 8 == rank over ALL keys) for each of 8 ranks; the strips together equal the single
+    call and an inverted-index count."""
+    import dist_worker as dw
+    n, world = 2048, 8
+    sets = dw.c4_shaped_sets(n, 600, seed=44)
+    want = dw.expected_inter(sets)
+    dev = torch.device("cuda", 0)
+    cnt = np.array([len(x) for x in sets])
+    sk_off = np.zeros(n + 1, np.uint64); sk_off[1:] = np.cumsum(cnt)
+    d_lo = torch.from_numpy(np.concatenate(sets).view(np.int64)).to(dev)
+    d_min = torch.full((int(cnt.sum()),), 7, dtype=torch.int32, device=dev)
+    merged = torch.zeros((n, n), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    for r in range(world):
+        part = torch.full((n, n), -1, dtype=torch.int32, device=dev)     # cells outside the owned rows must stay untouched
+        torch.cuda.synchronize()
+        ctx.compare_device(31, d_min.data_ptr(), d_lo.data_ptr(), None, sk_off, n, r, world, part.data_ptr())
+        torch.cuda.synchronize()
+        p = part.cpu().numpy()
+        own = np.zeros((n, n), bool)
+        own[r::world] = np.triu(np.ones((n, n), bool), 1)[r::world]
+        assert (p[~own] == -1).all()
+        merged[r::world] = torch.triu(part, 1)[r::world]
+    assert (merged.cpu().numpy() == want).all() and int(want.sum()) > 1_000_000
