@@ -263,6 +263,15 @@ int spsp_sketch_text(spsp_ctx* ctx, const spsp_params* p, double rate, const cha
 int spsp_sketch_parse_host(const uint8_t* payload, uint64_t len, uint32_t* k, uint32_t* m,
                            uint32_t** minimizer, uint64_t** kmer_lo, uint64_t** kmer_hi, uint64_t* n);
 
+/* The same decode for MANY sketches at once on the GPU ("next" row N2): payloads[i] = gunzipped sketch i.  The
+ * sorted distinct keys of all sketches end up back to back in device arrays OWNED BY THE CONTEXT (valid until the
+ * next decode / spsp_compare call on it; *d_kmer_hi = NULL when k <= 32), ready for spsp_compare_device; sk_off gets
+ * n + 1 offsets.  Sketches too large for the GPU sort, or not laid out as the sketcher writes them, go through
+ * spsp_sketch_parse_host internally: same keys. */
+int spsp_sketch_decode_device(spsp_ctx* ctx, const uint8_t* const* payloads, const uint64_t* lens, uint32_t n,
+                              uint32_t* k, uint32_t* m, void** d_minimizer, void** d_kmer_lo, void** d_kmer_hi,
+                              uint64_t* sk_off);
+
 /* The comparator's N-way merge reads every file's first minimizer into one shared buffer without an end-of-file
  * check (Comparator.cpp:294,316-319).  Call this for the sketches IN FILE ORDER with the same `read_buffer` (m bytes,
  * initialised to 'A'): it performs that read and, for a sketch without any bucket when k == m, returns the one

@@ -69,7 +69,7 @@ SUPERKMER_DTYPE = np.dtype([("rec", "<u4"), ("minimizer", "<u4"), ("start", "<u8
 ABI_SYMBOLS = [
     "spsp_create", "spsp_destroy", "spsp_last_error", "spsp_version", "spsp_free", "spsp_copy_to_host",
     "spsp_timing_enable", "spsp_timing_read", "spsp_threshold_host", "spsp_scan", "spsp_scan_device", "spsp_scan_device_begin", "spsp_scan_device_end", "spsp_scan_tail_stream", "spsp_wait_dense", "spsp_wait_stream", "spsp_scan_hits_device", "spsp_count_superkmers_device", "spsp_compare",
-    "spsp_compare_device", "spsp_slot_bytes", "spsp_partition_keys_device", "spsp_compare_slots_device", "spsp_compare_device_begin", "spsp_compare_slots_device_begin", "spsp_compare_end", "spsp_fasta_clean_host", "spsp_fasta_clean_device", "spsp_sketch_text", "spsp_sketch_build_host", "spsp_sketch_parse_host", "spsp_sketch_chain_host",
+    "spsp_compare_device", "spsp_slot_bytes", "spsp_partition_keys_device", "spsp_compare_slots_device", "spsp_compare_device_begin", "spsp_compare_slots_device_begin", "spsp_compare_end", "spsp_fasta_clean_host", "spsp_fasta_clean_device", "spsp_sketch_text", "spsp_sketch_build_host", "spsp_sketch_parse_host", "spsp_sketch_decode_device", "spsp_sketch_chain_host",
     "spsp_csv_host", "spsp_sort_csv_host", "spsp_read_file_host", "spsp_write_gz_host", "spsp_sketch_file", "spsp_compare_files", "spsp_compare_files_chatty", "spsp_stage_times_read",
 ]
 
@@ -140,6 +140,8 @@ def lib():
     L.spsp_sketch_file.argtypes = [vp, P(Params), dbl, cp, cp, P(SketchStats)]
     L.spsp_compare_files.restype = i32
     L.spsp_compare_files.argtypes = [vp, P(cp), u32, u32, i32, dbl, cp]
+    L.spsp_sketch_decode_device.restype = i32
+    L.spsp_sketch_decode_device.argtypes = [vp, P(cp), P(u64), u32, P(u32), P(u32), P(vp), P(vp), P(vp), P(u64)]
     L.spsp_count_superkmers_device.restype = i32
     L.spsp_count_superkmers_device.argtypes = [vp, P(Params), vp, u64, vp, u32, P(u64)]
     L.spsp_scan_tail_stream.restype = i32; L.spsp_scan_tail_stream.argtypes = [vp, i32, vp]
@@ -391,6 +393,19 @@ class Context:
         _check(lib().spsp_sketch_file(self._h, C.byref(p), float(s), fasta_path.encode(), out_path.encode(),
                                       C.byref(st)))
         return {f: getattr(st, f) for f, _ in SketchStats._fields_}
+
+    def sketch_decode_device(self, payloads):
+        """list of gunzipped sketch payloads -> (k, m, d_minimizer, d_kmer_lo, d_kmer_hi or None, sk_off np.uint64[n+1]);
+        the device pointers belong to the context (valid until its next decode / compare call)"""
+        n = len(payloads)
+        arr = (C.c_char_p * n)(*payloads)
+        lens = (C.c_uint64 * n)(*[len(p) for p in payloads])
+        k, m = C.c_uint32(), C.c_uint32()
+        d_mn, d_lo, d_hi = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        sk_off = np.zeros(n + 1, dtype=np.uint64)
+        _check(lib().spsp_sketch_decode_device(self._h, arr, lens, n, C.byref(k), C.byref(m), C.byref(d_mn), C.byref(d_lo),
+                                                C.byref(d_hi), sk_off.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return k.value, m.value, d_mn.value, d_lo.value, d_hi.value, sk_off
 
     def stage_times(self, reset=True):
         """wall seconds the whole-file drivers (sketch_file / compare_files) spent per stage on this context"""

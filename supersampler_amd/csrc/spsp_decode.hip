@@ -1,0 +1,397 @@
+// spsp_decode.hip -- "next" row N2: bulk decode of sketch payloads on the GPU.
+//
+// What the reference's comparator does per bucket and file while it merges (strDecompressor utils.cpp:71-111,
+// inject_minimizer Comparator.cpp:78-92, the k-mer walks :196-260, canonize(128 bit) utils.cpp:470-472) happens
+// here for ALL sketches at once: the host only finds the structure of every payload (header, bucket boundaries,
+// line ends: a memchr walk), the GPU rebuilds every super-k-mer (prefix + minimizer + suffix), rolls the k-mers
+// and their reverse complements, sorts each sketch's canonical (minimizer, k-mer) keys and drops duplicates -- the
+// arrays spsp_compare_device takes, already in HBM.
+//
+//   k_decode_emit     one lane per stored super-k-mer: 2-bit blob bases / ASCII lines -> canonical keys
+//   k_decode_sort     one workgroup per sketch: bitonic sort in LDS by (minimizer, kmer_hi, kmer_lo), unique,
+//                     distinct count
+//   k_exclusive_scan  distinct counts -> offsets (spsp_scan.hip)
+//   k_decode_compact  sketches back to back
+//
+// A sketch that does not fit the sort's LDS (more than 8192 keys, 4096 with k > 32) or is not laid out as the
+// sketcher writes it (partial blob bytes, over-long lines, truncated) is decoded by spsp_sketch_parse_host and
+// uploaded: same keys, already sorted.
+#include <algorithm>
+#include <atomic>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "spsp_internal.h"
+#include "spsp_device.h"
+
+namespace spsp {
+
+struct DecDesc {
+    uint64_t off;    // byte offset in the concatenated payload buffer: blob bytes (kind 0) / prefix line (kind 1)
+    uint32_t mn;     // minimizer of the bucket (2-bit value)
+    uint32_t info;   // bits 0-1 kind: 0 maximal super-k-mer in the blob, 1 "prefix\nsuffix\n" pair, 2 the bare minimizer (k == m);
+                     // kind 1: prefix length bits 2-9, suffix length bits 10-17
+    uint32_t out;    // first raw key of this super-k-mer
+    uint32_t pad;
+};
+
+constexpr int kSortThreads = 1024;
+constexpr uint32_t kSortCapLo = 8192, kSortCapHi = 4096;
+
+__device__ __forceinline__ void rc128(uint64_t hi, uint64_t lo, uint32_t k, uint64_t* rhi, uint64_t* rlo) {
+    // reverse complement of the k-mer in the low 2k bits of (hi:lo): reverse all 64 groups, then shift down
+    const uint64_t a = rc_window64(lo), b = rc_window64(hi);       // (a:b) = reverse complement of the 64-base window
+    const uint32_t sh = 128 - 2 * k;                               // >= 2
+    if (sh >= 64) { *rhi = 0; *rlo = sh == 64 ? a : a >> (sh - 64); }
+    else { *rhi = a >> sh; *rlo = (b >> sh) | (a << (64 - sh)); }
+}
+
+__global__ __launch_bounds__(256) void k_decode_emit(const uint8_t* __restrict__ text, const DecDesc* __restrict__ desc, uint32_t n_desc,
+                                                    uint32_t k, uint32_t m, uint32_t* __restrict__ r_mn, uint64_t* __restrict__ r_lo,
+                                                    uint64_t* __restrict__ r_hi) {
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n_desc) return;
+    const DecDesc D = desc[d];
+    const uint32_t kind = D.info & 3u;
+    const uint32_t side = k - m;                                   // maximal: k - m stored bases on either side of the minimizer
+    uint32_t n_pre, n_suf;
+    if (kind == 0) { n_pre = side; n_suf = side; }
+    else if (kind == 1) { n_pre = (D.info >> 2) & 0xffu; n_suf = (D.info >> 10) & 0xffu; }
+    else { n_pre = 0; n_suf = 0; }
+    const uint32_t total = n_pre + m + n_suf;
+    const uint8_t* src = text + D.off;
+    uint64_t hi = 0, lo = 0;
+    const uint64_t mask_hi = k > 32 ? (k == 64 ? ~0ull : ((1ull << (2 * k - 64)) - 1)) : 0ull;
+    const uint64_t mask_lo = k >= 32 ? ~0ull : ((1ull << (2 * k)) - 1);
+    uint32_t made = 0;
+    for (uint32_t t = 0; t < total; ++t) {
+        uint32_t c;
+        if (t < n_pre) c = kind == 0 ? (src[t >> 2] >> (6 - 2 * (t & 3))) & 3u : ((uint32_t)src[t] >> 1) & 3u;
+        else if (t < n_pre + m) c = (D.mn >> (2 * (m - 1 - (t - n_pre)))) & 3u;
+        else {
+            const uint32_t u = t - n_pre - m;
+            c = kind == 0 ? (src[(n_pre + u) >> 2] >> (6 - 2 * ((n_pre + u) & 3))) & 3u : ((uint32_t)src[n_pre + 1 + u] >> 1) & 3u;
+        }
+        hi = ((hi << 2) | (lo >> 62)) & mask_hi;
+        lo = ((lo << 2) | c) & mask_lo;
+        if (t + 1 < k) continue;
+        uint64_t rh, rl;
+        rc128(hi, lo, k, &rh, &rl);
+        const bool fwd = hi != rh ? hi < rh : lo <= rl;
+        const uint32_t o = D.out + made;
+        r_mn[o] = D.mn; r_lo[o] = fwd ? lo : rl;
+        if (r_hi) r_hi[o] = fwd ? hi : rh;
+        ++made;
+    }
+}
+
+// sort + unique of one sketch's raw keys [raw_off[s], raw_off[s] + raw_cnt[s]) in LDS; sketches with presorted[s]
+// (decoded by the host) are only counted
+template <bool HAS_HI>
+__global__ __launch_bounds__(kSortThreads) void k_decode_sort(uint32_t* __restrict__ r_mn, uint64_t* __restrict__ r_lo,
+                                                             uint64_t* __restrict__ r_hi, const uint64_t* __restrict__ raw_off,
+                                                             const uint32_t* __restrict__ raw_cnt, const uint8_t* __restrict__ presorted,
+                                                             uint32_t* __restrict__ distinct) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_s[];
+    constexpr uint32_t CAP = HAS_HI ? kSortCapHi : kSortCapLo;
+    uint64_t* s_lo = reinterpret_cast<uint64_t*>(lds_s);
+    uint64_t* s_hi = s_lo + CAP;                                   // (HAS_HI only)
+    uint32_t* s_mn = reinterpret_cast<uint32_t*>(s_hi + (HAS_HI ? CAP : 0));
+    __shared__ uint32_t wave_sum[kSortThreads / 64];
+    const uint32_t s = blockIdx.x, t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const uint32_t n = raw_cnt[s];
+    const uint64_t r0 = raw_off[s];
+    if (presorted[s]) { if (t == 0) distinct[s] = n; return; }
+    if (n == 0) { if (t == 0) distinct[s] = 0; return; }
+    uint32_t n2 = 1;
+    while (n2 < n) n2 <<= 1;
+    for (uint32_t i = t; i < n2; i += kSortThreads) {
+        if (i < n) { s_mn[i] = r_mn[r0 + i]; s_lo[i] = r_lo[r0 + i]; if (HAS_HI) s_hi[i] = r_hi[r0 + i]; }
+        else { s_mn[i] = 0xffffffffu; s_lo[i] = ~0ull; if (HAS_HI) s_hi[i] = ~0ull; }
+    }
+    __syncthreads();
+    auto greater = [&](uint32_t a, uint32_t b) {
+        if (s_mn[a] != s_mn[b]) return s_mn[a] > s_mn[b];
+        if (HAS_HI && s_hi[a] != s_hi[b]) return s_hi[a] > s_hi[b];
+        return s_lo[a] > s_lo[b];
+    };
+    for (uint32_t size = 2; size <= n2; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t idx = t; idx < (n2 >> 1); idx += kSortThreads) {
+                const uint32_t i = ((idx / stride) * (stride << 1)) + (idx % stride), j = i + stride;
+                const bool asc = (i & size) == 0;
+                if (greater(i, j) == asc) {
+                    const uint32_t tm = s_mn[i]; s_mn[i] = s_mn[j]; s_mn[j] = tm;
+                    const uint64_t tl = s_lo[i]; s_lo[i] = s_lo[j]; s_lo[j] = tl;
+                    if (HAS_HI) { const uint64_t th = s_hi[i]; s_hi[i] = s_hi[j]; s_hi[j] = th; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // unique: first of every run of equal keys, ranks by a workgroup prefix sum (CAP / kSortThreads consecutive elements per lane)
+    constexpr uint32_t PER = CAP / kSortThreads;
+    uint32_t first[PER];
+    uint32_t cnt = 0;
+#pragma unroll
+    for (uint32_t u = 0; u < PER; ++u) {
+        const uint32_t i = t * PER + u;
+        first[u] = 0;
+        if (i < n) first[u] = (i == 0 || s_mn[i] != s_mn[i - 1] || s_lo[i] != s_lo[i - 1] || (HAS_HI && s_hi[i] != s_hi[i - 1])) ? 1u : 0u;
+        cnt += first[u];
+    }
+    uint32_t x = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d); if (lane >= (uint32_t)d) x += y; }
+    if (lane == 63) wave_sum[wid] = x;
+    __syncthreads();
+    uint32_t pre = 0, all = 0;
+    for (uint32_t w = 0; w < kSortThreads / 64; ++w) { if (w < wid) pre += wave_sum[w]; all += wave_sum[w]; }
+    uint32_t rank = pre + x - cnt;
+#pragma unroll
+    for (uint32_t u = 0; u < PER; ++u) {
+        const uint32_t i = t * PER + u;
+        if (!first[u]) continue;
+        r_mn[r0 + rank] = s_mn[i]; r_lo[r0 + rank] = s_lo[i];
+        if (HAS_HI) r_hi[r0 + rank] = s_hi[i];
+        ++rank;
+    }
+    if (t == 0) distinct[s] = all;
+}
+
+__global__ __launch_bounds__(256) void k_decode_compact(const uint32_t* __restrict__ r_mn, const uint64_t* __restrict__ r_lo,
+                                                       const uint64_t* __restrict__ r_hi, const uint64_t* __restrict__ raw_off,
+                                                       const uint32_t* __restrict__ distinct, const uint32_t* __restrict__ out_off,
+                                                       uint32_t* __restrict__ o_mn, uint64_t* __restrict__ o_lo, uint64_t* __restrict__ o_hi) {
+    const uint32_t s = blockIdx.y;
+    const uint32_t n = distinct[s];
+    const uint64_t r0 = raw_off[s];
+    const uint32_t o0 = out_off[s];
+    for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+        o_mn[o0 + e] = r_mn[r0 + e]; o_lo[o0 + e] = r_lo[r0 + e];
+        if (o_hi) o_hi[o0 + e] = r_hi[r0 + e];
+    }
+}
+
+// ------------------------------------------------------------------ host side --
+struct ParsedSketch {
+    uint32_t k = 0, m = 0;
+    bool standard = true;        // laid out as the sketcher writes it: the GPU path applies
+    uint64_t n_keys = 0;         // raw keys (duplicates included)
+    std::vector<DecDesc> desc;   // offsets relative to the payload; `out` relative to the sketch
+};
+
+static inline uint32_t code_of(uint8_t c) { return (c >> 1) & 3u; }
+
+// structure of one payload: header (Comparator.cpp:23-37) and, per bucket, [m ASCII][u32 n][blob][lines]["\n\n"]
+static int parse_structure(const uint8_t* payload, uint64_t len, ParsedSketch* P) {
+    const uint8_t* nl = (const uint8_t*)memchr(payload, '\n', len);
+    if (!nl) { set_error("sketch has no header line"); return SPSP_ERR_FORMAT; }
+    char* endp = nullptr;
+    const std::string header((const char*)payload, nl - payload);
+    const long skm = strtol(header.c_str(), &endp, 10);
+    const long mm = strtol(endp, &endp, 10);
+    if (skm <= 0 || skm > 126 || mm <= 0 || mm > 15 || (skm + mm) / 2 > 63 || (skm + mm) / 2 < mm) { set_error("bad sketch header '%.60s'", header.c_str()); return SPSP_ERR_FORMAT; }
+    const uint32_t m = (uint32_t)mm, k = (uint32_t)((skm + mm) / 2), half = (uint32_t)((skm - mm) / 2);
+    P->k = k; P->m = m;
+    uint64_t pos = (uint64_t)(nl - payload) + 1;
+    uint64_t out = 0;
+    auto push = [&](uint64_t off, uint32_t mn, uint32_t info, uint64_t count) {
+        if (count == 0) return;
+        if (out + count > 0xfffffff0ull) { P->standard = false; return; }
+        P->desc.push_back(DecDesc{off, mn, info, (uint32_t)out, 0});
+        out += count;
+    };
+    while (pos + m <= len) {
+        uint32_t mn = 0;
+        for (uint32_t j = 0; j < m; ++j) mn = (mn << 2) | code_of(payload[pos + j]);
+        pos += m;
+        uint32_t nbytes = 0;
+        if (pos + 4 > len) break;
+        memcpy(&nbytes, payload + pos, 4);
+        pos += 4;
+        if (pos + nbytes > len) { set_error("bucket blob runs past the end of the sketch"); return SPSP_ERR_FORMAT; }
+        uint64_t seq_len = 0;
+        if (nbytes) {
+            if (payload[pos] != 0) P->standard = false;           // a partial last byte: never written by the sketcher (k, m odd)
+            seq_len = (uint64_t)(nbytes - 1) * 4;
+        }
+        if (half > 0) {
+            if ((2 * half) % 4 != 0) P->standard = false;         // (k - m odd: a foreign file)
+            for (uint64_t i = 0; (i + 1) * 2 * half <= seq_len; ++i) push(pos + 1 + i * (half / 2), mn, 0u, k - m + 1);
+        } else if (seq_len == 0) {
+            push(pos, mn, 2u, 1);                                  // k == m: the bare minimizer is one k-mer (Comparator.cpp:88-90,193-198)
+        }
+        pos += nbytes;
+        for (;;) {                                                 // "prefix\nsuffix\n" until an empty pair (:226-260)
+            if (pos >= len) break;
+            const uint8_t* e1 = (const uint8_t*)memchr(payload + pos, '\n', len - pos);
+            const uint64_t s1 = pos, l1 = e1 ? (uint64_t)(e1 - payload) - pos : len - pos;
+            pos = e1 ? s1 + l1 + 1 : len;
+            const uint8_t* e2 = pos < len ? (const uint8_t*)memchr(payload + pos, '\n', len - pos) : nullptr;
+            const uint64_t s2 = pos, l2 = pos < len ? (e2 ? (uint64_t)(e2 - payload) - pos : len - pos) : 0;
+            pos = e2 ? s2 + l2 + 1 : len;
+            if (l1 == 0 && l2 == 0) break;
+            if (!e1 || l1 > 255 || l2 > 255 || s2 != s1 + l1 + 1) { P->standard = false; continue; }
+            const uint64_t total = l1 + m + l2;
+            push(s1, mn, 1u | ((uint32_t)l1 << 2) | ((uint32_t)l2 << 10), total >= k ? total - k + 1 : 0);
+        }
+    }
+    P->n_keys = out;
+    return SPSP_OK;
+}
+
+// payloads (gunzipped sketch files, host) -> context-owned device key arrays (c_min / c_lo / c_hi: the buffers
+// spsp_compare's host form uploads into) + host offsets.  extra[i] (optional): one more key for sketch i, given as a
+// bare minimizer -- the phantom key of the comparator's first-read rule (spsp_sketch_chain_host)
+int sketch_decode_device_impl(spsp_ctx* ctx, const uint8_t* const* payloads, const uint64_t* lens, uint32_t n,
+                              const int* extra_has, const uint32_t* extra_mn, uint32_t* k_out, uint32_t* m_out, uint64_t* sk_off) {
+    int rc = SPSP_OK;
+    std::vector<ParsedSketch> P(n);
+    std::vector<int> rcs(n, SPSP_OK);
+    std::vector<std::string> errs(n);
+    {
+        unsigned workers = std::thread::hardware_concurrency();
+        if (workers == 0) workers = 1;
+        if (workers > 16) workers = 16;
+        if (workers > n) workers = n ? n : 1;
+        std::atomic<uint32_t> next(0);
+        auto work = [&]() {
+            for (;;) {
+                const uint32_t i = next.fetch_add(1);
+                if (i >= n) break;
+                rcs[i] = parse_structure(payloads[i], lens[i], &P[i]);
+                if (rcs[i]) errs[i] = spsp_last_error();
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned w = 1; w < workers; ++w) pool.emplace_back(work);
+        work();
+        for (auto& th : pool) th.join();
+    }
+    for (uint32_t i = 0; i < n; ++i) if (rcs[i]) { set_error("%s", errs[i].c_str()); return rcs[i]; }
+    for (uint32_t i = 1; i < n; ++i)
+        if (P[i].k != P[0].k || P[i].m != P[0].m) { set_error("sketch %u was made with k=%u m=%u, expected k=%u m=%u", i, P[i].k, P[i].m, P[0].k, P[0].m); return SPSP_ERR_FORMAT; }
+    const uint32_t k = n ? P[0].k : 0, m = n ? P[0].m : 0;
+    *k_out = k; *m_out = m;
+    sk_off[0] = 0;
+    if (n == 0) return SPSP_OK;
+    const bool has_hi = k > 32;
+    const uint32_t cap = has_hi ? kSortCapHi : kSortCapLo;
+    // sketches the GPU path cannot take are decoded on the host (sorted, distinct) and uploaded in place
+    struct HostKeys { uint32_t* mn = nullptr; uint64_t *lo = nullptr, *hi = nullptr; uint64_t n = 0; };
+    std::vector<HostKeys> hk(n);
+    std::vector<uint8_t> presorted(n, 0);
+    std::vector<uint64_t> raw_off(n + 1, 0), text_off(n + 1, 0);
+    std::vector<uint32_t> raw_cnt(n, 0);
+    auto free_hk = [&]() { for (auto& h : hk) { free(h.mn); free(h.lo); free(h.hi); } };
+    for (uint32_t i = 0; i < n; ++i) {
+        uint64_t keys = P[i].n_keys + ((extra_has && extra_has[i]) ? 1 : 0);
+        if (!P[i].standard || keys > cap) {
+            uint32_t kk, mm2;
+            if ((rc = spsp_sketch_parse_host(payloads[i], lens[i], &kk, &mm2, &hk[i].mn, &hk[i].lo, &hk[i].hi, &hk[i].n))) { free_hk(); return rc; }
+            if (extra_has && extra_has[i] && hk[i].n == 0) {       // (the phantom only ever joins an empty sketch)
+                hk[i].mn[0] = extra_mn[i];
+                // k == m: the k-mer is the minimizer; canonical = min(value, reverse complement)
+                uint64_t v = extra_mn[i], r = 0;
+                for (uint32_t j = 0; j < m; ++j) r |= (uint64_t)(((v >> (2 * j)) & 3u) ^ 2u) << (2 * (m - 1 - j));
+                hk[i].lo[0] = v < r ? v : r; hk[i].hi[0] = 0; hk[i].n = 1;
+            }
+            presorted[i] = 1;
+            keys = hk[i].n;
+            P[i].desc.clear();
+        }
+        if (keys > 0xfffffff0ull) { free_hk(); set_error("too many sketch k-mers for one call"); return SPSP_ERR_OVERFLOW; }
+        raw_cnt[i] = (uint32_t)keys;
+        raw_off[i + 1] = raw_off[i] + keys;
+        text_off[i + 1] = text_off[i] + (presorted[i] ? 0 : ((lens[i] + 15) & ~15ull));
+    }
+    const uint64_t R = raw_off[n];
+    if (R > 0xfffffff0ull) { free_hk(); set_error("too many sketch k-mers for one call"); return SPSP_ERR_OVERFLOW; }
+    // descriptors with absolute offsets
+    std::vector<DecDesc> desc;
+    {
+        size_t total = 0;
+        for (uint32_t i = 0; i < n; ++i) total += P[i].desc.size() + 1;
+        desc.reserve(total);
+        for (uint32_t i = 0; i < n; ++i) {
+            if (presorted[i]) continue;
+            for (DecDesc d : P[i].desc) { d.off += text_off[i]; d.out += (uint32_t)raw_off[i]; desc.push_back(d); }
+            if (extra_has && extra_has[i]) desc.push_back(DecDesc{text_off[i], extra_mn[i], 2u, (uint32_t)(raw_off[i] + P[i].n_keys), 0});
+        }
+    }
+    auto fail = [&](int r) { free_hk(); return r; };
+    if ((rc = ctx->dc_text.reserve((size_t)text_off[n] + 64))) return fail(rc);
+    if ((rc = ctx->dc_desc.reserve(desc.size() * sizeof(DecDesc) + 64))) return fail(rc);
+    if ((rc = ctx->dc_mn.reserve((size_t)R * 4 + 64))) return fail(rc);
+    if ((rc = ctx->dc_lo.reserve((size_t)R * 8 + 64))) return fail(rc);
+    if (has_hi && (rc = ctx->dc_hi.reserve((size_t)R * 8 + 64))) return fail(rc);
+    if ((rc = ctx->dc_meta.reserve((size_t)(n + 1) * 8 + (size_t)n * 4 * 3 + (size_t)n + 64))) return fail(rc);
+    if ((rc = ctx->c_min.reserve((size_t)R * 4 + 64))) return fail(rc);
+    if ((rc = ctx->c_lo.reserve((size_t)R * 8 + 64))) return fail(rc);
+    if (has_hi && (rc = ctx->c_hi.reserve((size_t)R * 8 + 64))) return fail(rc);
+    uint8_t* d_text = ctx->dc_text.as<uint8_t>();
+    uint64_t* d_raw_off = ctx->dc_meta.as<uint64_t>();
+    uint32_t* d_raw_cnt = reinterpret_cast<uint32_t*>(d_raw_off + n + 1);
+    uint32_t* d_distinct = d_raw_cnt + n;
+    uint32_t* d_out_off = d_distinct + n;            // n + 1 entries follow... (scan writes n + 1)
+    uint8_t* d_presorted = reinterpret_cast<uint8_t*>(d_out_off + n + 1);
+    hipError_t e = hipSuccess;
+    for (uint32_t i = 0; i < n && e == hipSuccess; ++i) {
+        if (!presorted[i]) { if (lens[i]) e = hipMemcpyAsync(d_text + text_off[i], payloads[i], (size_t)lens[i], hipMemcpyHostToDevice, ctx->stream); }
+        else if (hk[i].n) {
+            e = hipMemcpyAsync(ctx->dc_mn.as<uint32_t>() + raw_off[i], hk[i].mn, hk[i].n * 4, hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(ctx->dc_lo.as<uint64_t>() + raw_off[i], hk[i].lo, hk[i].n * 8, hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess && has_hi) e = hipMemcpyAsync(ctx->dc_hi.as<uint64_t>() + raw_off[i], hk[i].hi, hk[i].n * 8, hipMemcpyHostToDevice, ctx->stream);
+        }
+    }
+    if (e == hipSuccess && !desc.empty()) e = hipMemcpyAsync(ctx->dc_desc.p, desc.data(), desc.size() * sizeof(DecDesc), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_raw_off, raw_off.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_raw_cnt, raw_cnt.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_presorted, presorted.data(), (size_t)n, hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) { free_hk(); return hip_fail(e, "sketch upload", __FILE__, __LINE__); }
+    if (!desc.empty()) {
+        hipLaunchKernelGGL(k_decode_emit, dim3((uint32_t)((desc.size() + 255) / 256)), dim3(256), 0, ctx->stream, d_text,
+                           ctx->dc_desc.as<DecDesc>(), (uint32_t)desc.size(), k, m, ctx->dc_mn.as<uint32_t>(), ctx->dc_lo.as<uint64_t>(),
+                           has_hi ? ctx->dc_hi.as<uint64_t>() : (uint64_t*)nullptr);
+    }
+    const size_t lds = has_hi ? (size_t)kSortCapHi * 20 : (size_t)kSortCapLo * 12;
+    if (!ctx->attr_sort_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_sort<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kSortCapHi * 20));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_sort<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kSortCapLo * 12));
+        ctx->attr_sort_set = true;
+    }
+    if (has_hi) hipLaunchKernelGGL(k_decode_sort<true>, dim3(n), dim3(kSortThreads), lds, ctx->stream, ctx->dc_mn.as<uint32_t>(), ctx->dc_lo.as<uint64_t>(),
+                                   ctx->dc_hi.as<uint64_t>(), d_raw_off, d_raw_cnt, d_presorted, d_distinct);
+    else hipLaunchKernelGGL(k_decode_sort<false>, dim3(n), dim3(kSortThreads), lds, ctx->stream, ctx->dc_mn.as<uint32_t>(), ctx->dc_lo.as<uint64_t>(),
+                            (uint64_t*)nullptr, d_raw_off, d_raw_cnt, d_presorted, d_distinct);
+    if ((rc = launch_scan_u32(ctx, d_distinct, d_out_off, n, ctx->h_scalar + 7))) return fail(rc);
+    hipLaunchKernelGGL(k_decode_compact, dim3(8, n), dim3(256), 0, ctx->stream, ctx->dc_mn.as<uint32_t>(), ctx->dc_lo.as<uint64_t>(),
+                       has_hi ? ctx->dc_hi.as<uint64_t>() : (const uint64_t*)nullptr, d_raw_off, d_distinct, d_out_off, ctx->c_min.as<uint32_t>(),
+                       ctx->c_lo.as<uint64_t>(), has_hi ? ctx->c_hi.as<uint64_t>() : (uint64_t*)nullptr);
+    std::vector<uint32_t> off32(n + 1);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(off32.data(), d_out_off, (size_t)(n + 1) * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    free_hk();
+    if (e != hipSuccess) return hip_fail(e, "sketch decode", __FILE__, __LINE__);
+    for (uint32_t i = 0; i <= n; ++i) sk_off[i] = off32[i];
+    return SPSP_OK;
+}
+
+}  // namespace spsp
+
+using namespace spsp;
+
+extern "C" int spsp_sketch_decode_device(spsp_ctx* ctx, const uint8_t* const* payloads, const uint64_t* lens, uint32_t n,
+                                         uint32_t* k, uint32_t* m, void** d_minimizer, void** d_kmer_lo, void** d_kmer_hi,
+                                         uint64_t* sk_off) {
+    if (!ctx || !k || !m || !d_minimizer || !d_kmer_lo || !d_kmer_hi || !sk_off || (n && (!payloads || !lens))) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    SPSP_HIP(hipSetDevice(ctx->device));
+    const int rc = sketch_decode_device_impl(ctx, payloads, lens, n, nullptr, nullptr, k, m, sk_off);
+    if (rc) return rc;
+    *d_minimizer = ctx->c_min.p; *d_kmer_lo = ctx->c_lo.p; *d_kmer_hi = *k > 32 ? ctx->c_hi.p : nullptr;
+    return SPSP_OK;
+}

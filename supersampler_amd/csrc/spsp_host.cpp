@@ -812,14 +812,15 @@ static int compare_files_impl(spsp_ctx* ctx, const char* const* paths, uint32_t 
     double t0 = now_s(), t1;
     const double t_start = t0;
     ctx->stages.compare_calls += 1;
-    std::vector<spsp_sketch_view> views(n);
-    std::vector<void*> owned((size_t)n * 3, nullptr);
-    std::vector<uint32_t> ks(n, 0), ms(n, 0);
+    static const bool host_decode = getenv("SPSP_HOST_DECODE") != nullptr;   // A/B switch: decode + sort on host threads
+    std::vector<uint8_t*> datas(n, nullptr);
+    std::vector<uint64_t> lens(n, 0);
     std::vector<int> rcs(n, SPSP_OK);
     std::vector<std::string> errs(n);
-    std::vector<std::string> heads(n);   // header line + the first m bytes behind it: what the merge's first read sees
-    // One sketch at a time per worker: no N open streams (Comparator.cpp:45-50); gunzip + decode + sort of the
-    // sketches is independent work, spread over a few host threads.
+    auto free_datas = [&]() { for (auto*& d : datas) { free(d); d = nullptr; } };
+    // One file at a time per worker: no N open streams (Comparator.cpp:45-50); read + gunzip is independent work,
+    // spread over a few host threads.  Decoding (strDecompressor, inject_minimizer, the k-mer walks, sort, unique)
+    // happens for all sketches at once on the GPU (spsp_decode.hip).
     {
         unsigned workers = std::thread::hardware_concurrency();
         if (workers == 0) workers = 1;
@@ -830,19 +831,8 @@ static int compare_files_impl(spsp_ctx* ctx, const char* const* paths, uint32_t 
             for (;;) {
                 const uint32_t i = next.fetch_add(1);
                 if (i >= n) break;
-                uint8_t* data = nullptr; uint64_t len = 0;
-                int r = spsp_read_file_host(paths[i], &data, &len);
-                uint32_t* mn = nullptr; uint64_t *lo = nullptr, *hi = nullptr; uint64_t cnt = 0;
-                if (!r) r = spsp_sketch_parse_host(data, len, &ks[i], &ms[i], &mn, &lo, &hi, &cnt);
-                if (!r) {
-                    const uint8_t* nl = (const uint8_t*)memchr(data, '\n', len);
-                    const uint64_t keep = std::min<uint64_t>(len, (uint64_t)(nl + 1 - data) + 16);
-                    heads[i].assign((const char*)data, (size_t)keep);
-                }
-                free(data);
-                if (r) { rcs[i] = r; errs[i] = spsp_last_error(); continue; }
-                owned[3 * (size_t)i] = mn; owned[3 * (size_t)i + 1] = lo; owned[3 * (size_t)i + 2] = hi;
-                views[i].minimizer = mn; views[i].kmer_lo = lo; views[i].kmer_hi = hi; views[i].n = cnt;
+                rcs[i] = spsp_read_file_host(paths[i], &datas[i], &lens[i]);
+                if (rcs[i]) errs[i] = spsp_last_error();
             }
         };
         std::vector<std::thread> pool;
@@ -851,35 +841,84 @@ static int compare_files_impl(spsp_ctx* ctx, const char* const* paths, uint32_t 
         for (auto& th : pool) th.join();
     }
     int rc = SPSP_OK;
-    for (uint32_t i = 0; i < n && !rc; ++i) {
+    for (uint32_t i = 0; i < n && !rc; ++i)
         if (rcs[i]) { set_error("%s", errs[i].c_str()); rc = rcs[i]; }
-        else if (ks[i] != ks[0] || ms[i] != ms[0]) {
-            set_error("'%s' was sketched with k=%u m=%u, expected k=%u m=%u", paths[i], ks[i], ms[i], ks[0], ms[0]);
-            rc = SPSP_ERR_FORMAT;
-        }
+    // k and m of the first header (every sketch is checked against them by the decoder)
+    uint32_t k0 = 0, m0 = 0;
+    if (!rc && n) {
+        const uint8_t* nl = (const uint8_t*)memchr(datas[0], '\n', lens[0]);
+        long skm = 0, mm = 0;
+        if (nl) { char* e = nullptr; const std::string h((const char*)datas[0], nl - datas[0]); skm = strtol(h.c_str(), &e, 10); mm = strtol(e, &e, 10); }
+        if (!nl || skm <= 0 || skm > 126 || mm <= 0 || mm > 15 || (skm + mm) / 2 > 63 || (skm + mm) / 2 < mm) { set_error("bad sketch header in '%s'", paths[0]); rc = SPSP_ERR_FORMAT; }
+        else { m0 = (uint32_t)mm; k0 = (uint32_t)((skm + mm) / 2); }
     }
-    if (!rc && n) {   // the merge's shared first-read buffer, in file order (see spsp_sketch_chain_host)
+    // the merge's shared first-read buffer, in file order (see spsp_sketch_chain_host): phantom keys of empty sketches
+    std::vector<int> extra_has(n, 0);
+    std::vector<uint32_t> extra_mn(n, 0);
+    if (!rc && n) {
         char buffer[16];
         memset(buffer, 'A', sizeof buffer);
         for (uint32_t i = 0; i < n && !rc; ++i) {
             int has = 0; uint32_t mn = 0; uint64_t lo = 0, hi = 0;
-            rc = spsp_sketch_chain_host((const uint8_t*)heads[i].data(), heads[i].size(), ks[0], ms[0], buffer, &has, &mn, &lo, &hi);
-            if (rc || !has || views[i].n) continue;
-            uint32_t* pm = (uint32_t*)owned[3 * (size_t)i]; uint64_t* pl = (uint64_t*)owned[3 * (size_t)i + 1]; uint64_t* ph = (uint64_t*)owned[3 * (size_t)i + 2];
-            pm[0] = mn; pl[0] = lo; ph[0] = hi;      // the parser allocates room for at least one key
-            views[i].n = 1;
+            rc = spsp_sketch_chain_host(datas[i], lens[i], k0, m0, buffer, &has, &mn, &lo, &hi);
+            if (!rc && has) { extra_has[i] = 1; extra_mn[i] = mn; }
         }
     }
-    if (!rc && n && ks[0] <= 32) for (uint32_t i = 0; i < n; ++i) views[i].kmer_hi = nullptr;
-    if (!rc && chatter && n) { printf("kmers evaluated are of length: %u minimizer size is %u\n", ks[0], ms[0]); fflush(stdout); }   // :56
     std::vector<uint32_t> inter;
     std::vector<uint64_t> card(n, 0);
-    t1 = now_s(); ctx->stages.load_s += t1 - t0; t0 = t1;
-    if (!rc) {
-        inter.assign((size_t)n * n, 0);
-        rc = spsp_compare(ctx, views.data(), n, n_query, inter.data(), card.data());
+    if (!rc && host_decode) {
+        // round-1 path: every sketch decoded and sorted by spsp_sketch_parse_host on the host threads, keys uploaded by spsp_compare
+        std::vector<spsp_sketch_view> views(n);
+        std::vector<void*> owned((size_t)n * 3, nullptr);
+        for (uint32_t i = 0; i < n && !rc; ++i) {
+            uint32_t kk = 0, mm2 = 0; uint32_t* mn = nullptr; uint64_t *lo = nullptr, *hi = nullptr; uint64_t cnt = 0;
+            rc = spsp_sketch_parse_host(datas[i], lens[i], &kk, &mm2, &mn, &lo, &hi, &cnt);
+            if (rc) break;
+            owned[3 * (size_t)i] = mn; owned[3 * (size_t)i + 1] = lo; owned[3 * (size_t)i + 2] = hi;
+            if (kk != k0 || mm2 != m0) { set_error("'%s' was sketched with k=%u m=%u, expected k=%u m=%u", paths[i], kk, mm2, k0, m0); rc = SPSP_ERR_FORMAT; break; }
+            if (extra_has[i] && cnt == 0) {
+                int has = 0; char tmp[16]; memset(tmp, 'A', sizeof tmp);
+                // (recomputed from the stored minimizer: k == m, the k-mer is the minimizer's canonical form)
+                uint64_t v = extra_mn[i], r = 0;
+                for (uint32_t j = 0; j < m0; ++j) r |= (uint64_t)(((v >> (2 * j)) & 3u) ^ 2u) << (2 * (m0 - 1 - j));
+                mn[0] = extra_mn[i]; lo[0] = v < r ? v : r; hi[0] = 0; cnt = 1; (void)has; (void)tmp;
+            }
+            views[i].minimizer = mn; views[i].kmer_lo = lo; views[i].kmer_hi = k0 > 32 ? hi : nullptr; views[i].n = cnt;
+        }
+        free_datas();
+        if (!rc && chatter && n) { printf("kmers evaluated are of length: %u minimizer size is %u\n", k0, m0); fflush(stdout); }   // :56
+        t1 = now_s(); ctx->stages.load_s += t1 - t0; t0 = t1;
+        if (!rc) {
+            inter.assign((size_t)n * n, 0);
+            rc = spsp_compare(ctx, views.data(), n, n_query, inter.data(), card.data());
+        }
+        for (void* p : owned) free(p);
+    } else if (!rc) {
+        if (chatter && n) { printf("kmers evaluated are of length: %u minimizer size is %u\n", k0, m0); fflush(stdout); }   // :56
+        t1 = now_s(); ctx->stages.load_s += t1 - t0; t0 = t1;
+        std::vector<uint64_t> sk_off((size_t)n + 1, 0);
+        uint32_t kk = 0, mm2 = 0;
+        rc = spsp::sketch_decode_device_impl(ctx, datas.data(), lens.data(), n, extra_has.data(), extra_mn.data(), &kk, &mm2, sk_off.data());
+        free_datas();
+        if (!rc && n) {
+            for (uint32_t i = 0; i < n; ++i) card[i] = sk_off[i + 1] - sk_off[i];
+            inter.assign((size_t)n * n, 0);
+            if (sk_off[n] > 0) {
+                hipError_t e = hipSuccess;
+                if ((rc = ctx->c_inter.reserve((size_t)n * n * 4)) == SPSP_OK) {
+                    e = hipMemsetAsync(ctx->c_inter.p, 0, (size_t)n * n * 4, ctx->stream);
+                    if (e == hipSuccess)
+                        rc = spsp::compare_device_impl(ctx, kk, ctx->c_min.as<uint32_t>(), ctx->c_lo.as<uint64_t>(),
+                                                       kk > 32 ? ctx->c_hi.as<uint64_t>() : nullptr, sk_off.data(), n, n_query, 0, 1,
+                                                       ctx->c_inter.as<uint32_t>());
+                    if (!rc && e == hipSuccess) e = hipMemcpyAsync(inter.data(), ctx->c_inter.p, (size_t)n * n * 4, hipMemcpyDeviceToHost, ctx->stream);
+                    if (!rc && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+                    if (!rc && e != hipSuccess) rc = spsp::hip_fail(e, "comparison of decoded sketches", __FILE__, __LINE__);
+                }
+            }
+        }
     }
-    for (void* p : owned) free(p);
+    free_datas();
     t1 = now_s(); ctx->stages.compare_s += t1 - t0;
     if (rc) return rc;
     if (chatter) {

@@ -93,7 +93,7 @@ struct spsp_ctx {
     hipEvent_t tail_event = nullptr;   // spsp_wait_stream: marks the current end of this context's stream
     hipEvent_t scan_done = nullptr;    // behind the last kernel of the queued scan: what spsp_scan_device_end waits on
     hipEvent_t compare_done = nullptr; // likewise for the queued comparison
-    bool attr_pair_set = false, attr_single_set = false, attr_bloom_set = false, attr_group_set = false, attr_group_hi_set = false, attr_scatter_set = false;   // dynamic-LDS attributes set on this context's device
+    bool attr_pair_set = false, attr_single_set = false, attr_bloom_set = false, attr_group_set = false, attr_group_hi_set = false, attr_scatter_set = false, attr_sort_set = false;   // dynamic-LDS attributes set on this context's device
     spsp::ScanJob scan_job;
     spsp::CompareJob* compare_job = nullptr;
     uint64_t* h_skoff = nullptr;       // pinned staging for the sketch offsets of a queued comparison
@@ -125,6 +125,7 @@ struct spsp_ctx {
     // compare workspace
     spsp::DevBuf c_min, c_lo, c_hi, c_table, c_owner, c_rowid, c_row, c_matrix, c_inter, c_flags, c_skoff, c_slot_lo, c_slot_hi, c_slot_mn, c_part_cnt, c_recs;
     spsp::DevBuf x_cnt, x_off, x_begin, x_end, x_tot;   // key-partitioned exchange (spsp_compare.hip)
+    spsp::DevBuf dc_text, dc_desc, dc_mn, dc_lo, dc_hi, dc_meta;   // bulk sketch decode (spsp_decode.hip)
 };
 
 namespace spsp {
@@ -150,6 +151,9 @@ int check_params(const spsp_params* p);
 // every super-k-mer of the input, selected or not (spsp_stats.hip)
 int count_superkmers_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, uint64_t n_bases, const uint64_t* d_rec_off,
                           uint32_t n_rec, uint64_t* total);
+// bulk sketch decode (spsp_decode.hip): payloads -> ctx->c_min / c_lo / c_hi + host offsets
+int sketch_decode_device_impl(spsp_ctx* ctx, const uint8_t* const* payloads, const uint64_t* lens, uint32_t n,
+                              const int* extra_has, const uint32_t* extra_mn, uint32_t* k_out, uint32_t* m_out, uint64_t* sk_off);
 // ingest (spsp_ingest.hip)
 int clean_device_impl(spsp_ctx* ctx, const uint8_t* d_text, uint64_t n_text, uint8_t** d_bases, uint64_t* n_bases,
                       uint64_t** d_rec_off, uint32_t* n_rec);

@@ -731,3 +731,34 @@ def test_c5_shape_one_gbp_properties(ctx):
             for f in (sp.SPSP_SCAN_BLOOM_FILTER, sp.SPSP_SCAN_LDS_FILTER, sp.SPSP_SCAN_DIRECT_HASH)]
     assert hits[0] == hits[1] == hits[2] > 30_000
     del bases
+
+
+def test_gpu_sketch_decode_matches_host_parser(ctx):
+    """N2: bulk decode of sketch payloads on the GPU (blob + text super-k-mers -> canonical keys -> sort -> unique) gives
+    the arrays of spsp_sketch_parse_host, sketch by sketch: k <= 32 and k > 32, k == m (bare minimizers), empty sketches,
+    a sketch too large for the LDS sort (host decode inside the same call) and duplicate k-mers across super-k-mers."""
+    rng = np.random.default_rng(606)
+    for (k, m, s, sizes) in [(31, 11, 20, [60_000, 0, 25_000, 300, 700_000]), (63, 15, 10, [40_000, 9_000, 120_000]),
+                             (15, 15, 3, [20_000, 5, 8_000]), (21, 9, 4, [30_000, 30_000])]:
+        payloads = []
+        for i, L in enumerate(sizes):
+            g = synth.random_genome(rng, L) if L else np.zeros(0, np.uint8)
+            if i == 1 and L:
+                g = np.concatenate([g, g[: L // 2], g])          # repeated sequence: the same k-mers in several super-k-mers
+            text = synth.to_fasta(g, "g%d" % i, n_records=1 + i % 2) if len(g) else b">empty\n"
+            payloads.append(orc.sketch_fasta(text, k, m, s)[0])
+        kk, mm, d_mn, d_lo, d_hi, sk_off = ctx.sketch_decode_device(payloads)
+        assert (kk, mm) == (k, m)
+        total = int(sk_off[-1])
+        mn = ctx.to_host(d_mn, total, np.uint32)
+        lo = ctx.to_host(d_lo, total, np.uint64)
+        hi = ctx.to_host(d_hi, total, np.uint64) if k > 32 else np.zeros(total, np.uint64)
+        for i, pl in enumerate(payloads):
+            want = sp.sketch_parse(pl)
+            a, b = int(sk_off[i]), int(sk_off[i + 1])
+            assert b - a == len(want), (k, m, i, b - a, len(want))
+            assert (mn[a:b] == want.minimizer).all() and (lo[a:b] == want.kmer_lo).all(), (k, m, i)
+            if k > 32:
+                assert (hi[a:b] == want.kmer_hi).all(), (k, m, i)
+        if k == 31:
+            assert int(sk_off[5] - sk_off[4]) > 8192               # the large sketch went through the host decoder
