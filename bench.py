@@ -99,18 +99,17 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     ctx = sp.Context(local_rank, stream.cuda_stream)
-    # Pipelined step (default): two slots alternate, each with a scan stream and a comparison stream.  The only
-    # ordering between them: the dense pass of step t+1 starts behind the dense pass of step t (spsp_wait_dense), and
-    # the comparison of step t behind its own dense pass.  The dense kernels -- the HBM-bound part -- never run two
-    # at once; the latency-bound sparse stages and the comparison of step t get their CUs in the gap between two
-    # dense passes and finish beside the next one.  The host queues step t+1 before it collects step t (scan_end /
-    # compare_end wait on per-job events, not on the streams).
+    # Pipelined step (default): two slots alternate.  All scans are queued in order on ONE stream (dense pass, sparse
+    # stages, next dense pass ...); each slot's comparison has a stream of its own and starts behind its dense pass
+    # (spsp_wait_dense), so it runs beside the sparse stages and the next dense pass -- the dense kernel occupies one
+    # workgroup per CU and leaves the other half of every CU to it.  The host queues step t+1 before it collects
+    # step t (scan_end / compare_end wait on per-job events, not on the streams).
     # BENCH_PIPELINE=0 runs the two halves back to back on one stream, one step at a time.
     pipelined = os.environ.get("BENCH_PIPELINE", "1") != "0"
-    # BENCH_SCHEDULE: "streams" = as above (measured best: 0.153 ms); "tail" = both scans on ONE stream, their sparse
-    # stages on spsp_scan_tail_stream streams (0.19 ms: a dense pass that fills every wave slot leaves the sparse
-    # kernels no CU until it ends); "single" = all scans in order on one stream (0.18 ms)
-    schedule = os.environ.get("BENCH_SCHEDULE", "streams")
+    # BENCH_SCHEDULE: "single" = as above (0.158-0.163 ms); "streams" = every slot's scan on a stream of its own, its dense
+    # pass behind the previous slot's by an event (0.167 ms); "tail" = scans on one stream, their sparse stages on
+    # spsp_scan_tail_stream streams (0.18 ms)
+    schedule = os.environ.get("BENCH_SCHEDULE", "single")
     tail_streams = schedule == "tail"
 
     class Slot:
@@ -373,9 +372,9 @@ def main():
                                        "gather": "genomes sharded by rank; RCCL all-gather of the packed sketch keys, every rank "
                                                  "computes the pair-matrix rows i % N == rank, strips gathered on rank 0 (SURVEY.md 8e)"}[exchange_kind],
                        "exchange_check": exchange_check,
-                       "step": ("scan(batch t) || all-vs-all(sketches of batch t-1): two slots with their own scan and comparison "
-                                "streams; dense passes never overlap each other, sparse stages and comparison run between and "
-                                "beside them; the host queues step t+1 before collecting step t [schedule %s]" % schedule if pipelined
+                       "step": ("scan(batch t) || all-vs-all(sketches of batch t-1): scans in order on one stream, every slot's "
+                                "comparison on a stream of its own behind its dense pass; the host queues step t+1 before "
+                                "collecting step t [schedule %s]" % schedule if pipelined
                                 else "scan then all-vs-all on one stream, one step at a time")},
             # the rate of the comparison inside the step: its own HIP-event bracket when one was recorded, else pairs per step time
             "sketch_pairs_per_s": (pairs_per_step / (compare_avg_ms / 1e3) if compare_avg_ms > 0

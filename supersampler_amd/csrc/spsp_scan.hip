@@ -1050,22 +1050,32 @@ __global__ __launch_bounds__(1024) void k_sum_counts(const uint32_t* __restrict_
 // Literal replay of the reference state machine over one cluster of hits.
 struct Rescan { uint32_t mini; uint32_t rev; uint64_t position; uint64_t hash; };
 
+// The hits a workgroup of k_resolve works on, staged in LDS: a cluster is replayed with a chain of dependent reads
+// (next hit, window bounds, rescans), and from LDS a link of that chain costs ~100 cycles instead of an L2 round trip.
+// Indices outside the staged window (a cluster that runs far past the workgroup's hits) fall back to global memory.
+struct HitView {
+    const Hit* g;        // all hits, position order
+    const Hit* s;        // LDS copy of g[lo, hi)
+    uint32_t lo, hi;
+    __device__ __forceinline__ Hit at(uint32_t i) const { return (i >= lo && i < hi) ? s[i - lo] : g[i]; }
+};
+
 // regular_minimizer_pos (SubSampler.cpp:81-169) restricted to the hits
 // H[lo..hi] of the window starting at m-mer position ws.  Non-hit m-mers can
 // never win (their hash is > T >= any hit's) and can never tie (XXH64 on 8
 // bytes is a bijection), so skipping them leaves every assignment identical.
-__device__ __forceinline__ Rescan rescan_hits(const Hit* __restrict__ H, uint64_t r0, uint32_t lo, uint32_t hi,
+__device__ __forceinline__ Rescan rescan_hits(const HitView& V, uint32_t hb, uint64_t r0, uint32_t lo, uint32_t hi,
                                               uint64_t ws, uint64_t km) {
     Rescan r;
     {
-        const Hit h = H[hi];
+        const Hit h = V.at(hb + hi);
         const uint64_t off = (h.pos - r0) - ws;
         r.mini = h.canon; r.hash = h.hash; r.rev = h.flags & 1u;
         if (off == km) r.position = r.rev ? 0 : km;  // rightmost m-mer: :88-93 (reverse => position 0, sic)
         else r.position = off;                       // first hit met strictly beats the non-hits right of it
     }
     for (uint32_t idx = hi; idx-- > lo;) {
-        const Hit h = H[idx];
+        const Hit h = V.at(hb + idx);
         const uint64_t off = (h.pos - r0) - ws;
         const uint64_t ii = km - off;  // the reference's loop index i
         const uint32_t lrev = h.flags & 1u;
@@ -1081,11 +1091,12 @@ __device__ __forceinline__ Rescan rescan_hits(const Hit* __restrict__ H, uint64_
     return r;
 }
 
+// cluster = hits hb .. hb + cnt - 1 of V
 template <bool WRITE>
-__device__ uint32_t run_cluster(const Hit* __restrict__ H, uint32_t cnt, uint64_t r0, uint64_t n, uint32_t k,
+__device__ uint32_t run_cluster(const HitView& V, uint32_t hb, uint32_t cnt, uint64_t r0, uint64_t n, uint32_t k,
                                 uint32_t m, uint32_t rec, spsp_superkmer* __restrict__ out, uint32_t room) {
     const uint64_t km = k - m, w = km + 1;
-    auto q = [&](uint32_t i) -> uint64_t { return H[i].pos - r0; };
+    auto q = [&](uint32_t i) -> uint64_t { return V.at(hb + i).pos - r0; };
     uint32_t nem = 0;
     auto emit = [&](uint64_t start, uint64_t len, uint32_t mini, uint32_t rev) {
         if (WRITE && nem < room) {
@@ -1102,14 +1113,14 @@ __device__ uint32_t run_cluster(const Hit* __restrict__ H, uint32_t cnt, uint64_
     if (q0 > km) {
         // iteration i = q0-w: the hit enters as the rightmost m-mer and beats an
         // unselected minimum (SubSampler.cpp:374-388); the old super-k-mer is not selected.
-        const Hit h = H[0];
+        const Hit h = V.at(hb);
         minimizer = h.canon; hash_min = h.hash; position_min = q0; rev = h.flags & 1u;
         last_position = q0 - km; i = q0 - km;
     } else {
         // record start (SubSampler.cpp:359-365): rescan of k-mer 0
         uint32_t hi = 0;
         while (hi + 1 < cnt && q(hi + 1) <= km) ++hi;
-        const Rescan r = rescan_hits(H, r0, 0, hi, 0, km);
+        const Rescan r = rescan_hits(V, hb, r0, 0, hi, 0, km);
         minimizer = r.mini; hash_min = r.hash; position_min = r.position; rev = r.rev;
         last_position = 0; i = 0;
     }
@@ -1119,11 +1130,11 @@ __device__ uint32_t run_cluster(const Hit* __restrict__ H, uint32_t cnt, uint64_
     while (i + k < n) {                                           // :367
         const uint64_t pn = i + w;                                // position of the entering m-mer
         while (nh < cnt && q(nh) < pn) ++nh;
-        const bool enters = nh < cnt && q(nh) == pn;
+        const Hit hn = nh < cnt ? V.at(hb + nh) : Hit{};
+        const bool enters = nh < cnt && hn.pos - r0 == pn;
         bool dump = false;
-        if (enters && H[nh].hash < hash_min) {                    // :374-388
-            const Hit h = H[nh];
-            minimizer = h.canon; hash_min = h.hash; position_min = pn; rev = h.flags & 1u;
+        if (enters && hn.hash < hash_min) {                       // :374-388
+            minimizer = hn.canon; hash_min = hn.hash; position_min = pn; rev = hn.flags & 1u;
         } else if (i >= position_min) {                           // :391-398
             while (lo < cnt && q(lo) < i + 1) ++lo;
             if (lo >= cnt || q(lo) > pn) {
@@ -1134,7 +1145,7 @@ __device__ uint32_t run_cluster(const Hit* __restrict__ H, uint32_t cnt, uint64_
                 break;
             }
             const uint32_t hi = enters ? nh : nh - 1;
-            const Rescan r = rescan_hits(H, r0, lo, hi, i + 1, km);
+            const Rescan r = rescan_hits(V, hb, r0, lo, hi, i + 1, km);
             minimizer = r.mini; rev = r.rev; hash_min = r.hash;
             position_min = r.position + i + 1;
             dump = true;
@@ -1159,6 +1170,7 @@ __device__ uint32_t run_cluster(const Hit* __restrict__ H, uint32_t cnt, uint64_
 // pass turns those into its output offset itself (a masked wave load of each level + one wave reduction), so
 // no scan kernel sits between the two passes.
 constexpr int kResolveThreads = 128;
+constexpr int kResolveBefore = 8, kResolveAfter = 120;        // hits staged in LDS in front of / behind the workgroup's own
 template <bool WRITE>
 __global__ __launch_bounds__(kResolveThreads) void k_resolve(const Hit* __restrict__ hits, const uint32_t* __restrict__ n_hits_dev,
                                                              uint32_t hits_cap, const uint64_t* __restrict__ rec_off, uint32_t k,
@@ -1166,28 +1178,44 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(const Hit* __restri
                                                              uint32_t* __restrict__ wave_sum, uint32_t* __restrict__ chunk_sum,
                                                              uint32_t n_chunks, uint64_t* __restrict__ total_host,
                                                              spsp_superkmer* __restrict__ out, uint32_t out_cap) {
+    __shared__ __attribute__((aligned(16))) Hit s_hit[kResolveThreads + kResolveBefore + kResolveAfter];
     const uint32_t h = blockIdx.x * kResolveThreads + threadIdx.x, lane = threadIdx.x & 63, gw = h >> 6;
     uint32_t n_hits = *n_hits_dev;
     if (n_hits > hits_cap) n_hits = hits_cap;   // overflowed: this pass is discarded by the host
+    HitView V;
+    V.g = hits; V.s = s_hit;
+    {
+        const uint32_t b0 = blockIdx.x * kResolveThreads;
+        V.lo = b0 > (uint32_t)kResolveBefore ? b0 - kResolveBefore : 0u;
+        const uint64_t end = (uint64_t)b0 + kResolveThreads + kResolveAfter;
+        V.hi = end < n_hits ? (uint32_t)end : n_hits;
+        if (V.hi < V.lo) V.hi = V.lo;
+        const uint4* src = reinterpret_cast<const uint4*>(hits + V.lo);
+        uint4* dst = reinterpret_cast<uint4*>(s_hit);
+        for (uint32_t i = threadIdx.x; i < 2 * (V.hi - V.lo); i += kResolveThreads) dst[i] = src[i];
+    }
+    __syncthreads();
     const uint64_t w = k - m + 1;
     Hit me{};
     bool head = false;
     uint32_t cnt = 0;
     if (h < n_hits) {
-        me = hits[h];
+        me = V.at(h);
         head = (me.flags & 2u) != 0;
         if (head) {
             for (uint32_t g = h; g-- > 0;) {
-                const Hit o = hits[g];
+                const Hit o = V.at(g);
                 if (me.pos - o.pos > w) break;
                 if ((o.flags & 2u) && o.rec == me.rec) { head = false; break; }
             }
         }
         if (head) {
             cnt = 1;
+            Hit a = me;
             while (h + cnt < n_hits) {
-                const Hit a = hits[h + cnt - 1], b = hits[h + cnt];
+                const Hit b = V.at(h + cnt);
                 if (!(b.flags & 2u) || b.rec != me.rec || b.pos - a.pos > w) break;
+                a = b;
                 ++cnt;
             }
         }
@@ -1195,7 +1223,7 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(const Hit* __restri
     uint64_t r0 = 0, r1 = 0;
     if (head) { r0 = rec_off[me.rec]; r1 = rec_off[me.rec + 1]; }
     if (!WRITE) {
-        const uint32_t c = head ? run_cluster<false>(hits + h, cnt, r0, r1 - r0, k, m, me.rec, nullptr, 0u) : 0u;
+        const uint32_t c = head ? run_cluster<false>(V, h, cnt, r0, r1 - r0, k, m, me.rec, nullptr, 0u) : 0u;
         if (h < hits_cap) emit_count[h] = c;
         uint32_t t = c;
 #pragma unroll
@@ -1228,7 +1256,7 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(const Hit* __restri
     }
     if (head) {
         const uint32_t at = v + x - c;
-        run_cluster<true>(hits + h, cnt, r0, r1 - r0, k, m, me.rec, out + at, at < out_cap ? out_cap - at : 0u);
+        run_cluster<true>(V, h, cnt, r0, r1 - r0, k, m, me.rec, out + at, at < out_cap ? out_cap - at : 0u);
     }
 }
 
@@ -1324,8 +1352,10 @@ static int plan_lists(spsp_ctx* ctx, const spsp_params* p, int variant, uint64_t
     P->n_rows = (n_bases + kRowPosPair63 - 1) / kRowPosPair63;
     const uint64_t want = (P->n_rows + kPairWaves - 1) / kPairWaves;
     static const int per_cu = getenv("SPSP_PAIR_BLOCKS_PER_CU") ? atoi(getenv("SPSP_PAIR_BLOCKS_PER_CU")) : 0;  // tuning knob
-    // k_dense_pair: 80 KiB of LDS -> two 1024-lane workgroups per CU; k_dense_single: 152 KiB -> one
-    const uint64_t cap_blocks = (uint64_t)ctx->n_cu * (per_cu > 0 ? per_cu : (variant == kDensePair ? 2 : 1));
+    // One 1024-lane workgroup per CU for every variant.  k_dense_pair (80 KiB of LDS) would fit twice, and alone it runs
+    // as fast either way (0.103 vs 0.099 ms: it is limited by VALU issue, not by occupancy); with one, the other half of
+    // the CU's wave slots and LDS stays free for the kernels of other streams (a pipelined step: 0.158 vs 0.185 ms)
+    const uint64_t cap_blocks = (uint64_t)ctx->n_cu * (per_cu > 0 ? per_cu : 1);
     P->grid = (uint32_t)(want < cap_blocks ? want : cap_blocks);
     P->n_lists = P->grid * kPairWaves;
     P->rows_per_wave = (P->n_rows + P->n_lists - 1) / P->n_lists;
