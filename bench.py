@@ -116,7 +116,7 @@ def main():
         pass
 
     slots = []
-    for i in range(2 if pipelined else 1):
+    for i in range(int(os.environ.get("BENCH_SLOTS", "2")) if pipelined else 1):
         sl = Slot()
         if pipelined:
             sl.stream_a = stream if (i == 0 or schedule != "streams") else torch.cuda.Stream(device=dev)
@@ -258,19 +258,23 @@ def main():
                         sl.exchange.collect_rows(sl.d_inter)
                 last["n_out"], last["slot"] = n_out, sl
             return
-        pending = None
+        import collections
+        pending = collections.deque()                     # steps queued and not yet collected, oldest first
+        prev = None
         for i in range(n):
             sl = slots[i % len(slots)]
-            t_a = time.perf_counter()
-            queue_step(sl, pending, slots[(i + 1) % len(slots)] if i + 1 < n else None)   # step i is on the GPU's queues ...
+            t_c = time.perf_counter()
+            if len(pending) == len(slots):
+                collect_step(pending.popleft())           # the oldest step ran on `sl`: the host waits for it only now,
+            t_a = time.perf_counter()                     # with the steps queued since then already on the GPU's queues
+            queue_step(sl, prev, slots[(i + 1) % len(slots)] if i + 1 < n else None)
             t_b = time.perf_counter()
-            if pending is not None:
-                collect_step(pending)                     # ... before the host waits for step i-1
             host["queue"] += t_b - t_a
-            host["collect"] += time.perf_counter() - t_b
-            pending = sl
-        if pending is not None:
-            collect_step(pending)
+            host["collect"] += t_a - t_c
+            pending.append(sl)
+            prev = sl
+        while pending:
+            collect_step(pending.popleft())
 
     last = {"n_out": 0, "slot": slots[0]}
     host = {"queue": 0.0, "collect": 0.0}   # host seconds spent queueing / waiting (pipelined mode)
