@@ -397,6 +397,20 @@ def main():
                          "step_achieved": step_achieved, "step_frac": step_achieved / HBM_PEAK_GBS},
         }
         out["roofline"].update(pmc_traffic(args, "k_dense_pair"))
+        # the same kernel with the GPU to itself (dense stage only, untimed extra): what the kernel reaches when nothing
+        # shares its CUs -- `achieved` above is measured inside the pipelined step, beside the other streams' kernels
+        try:
+            ctx.timing_enable(True, sp.TIME_DENSE)
+            ctx.timing_read()
+            for _ in range(20):
+                ctx.scan_hits_device(p, d_bases.data_ptr(), d_bases.numel())
+            ta = ctx.timing_read()
+            ctx.timing_enable(False)
+            alone_ms = ta["dense_ms"] / max(1, ta["dense_launches"])
+            out["roofline"]["alone"] = {"dense_kernel_ms": alone_ms, "achieved": d_bases.numel() / 1e9 / (alone_ms / 1e3),
+                                        "frac": d_bases.numel() / 1e9 / (alone_ms / 1e3) / HBM_PEAK_GBS, "launches": int(ta["dense_launches"])}
+        except Exception as e:  # noqa: BLE001
+            out["roofline"]["alone"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(recs, payloads, p, int(n_out), d_inter)
         if world == 1 and not args.no_extras:

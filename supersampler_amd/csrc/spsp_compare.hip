@@ -222,10 +222,12 @@ __global__ void k_fill(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n, 
 //                    (key of i, other holder of the key)
 // Traffic per key is its list (a few bytes) instead of N/8 bytes.  Used when all rows are owned (single GPU).
 // A sketch list = u16 length, then the u16 ids of the sketches holding the key, starting on a 16-byte boundary
-// of `ids`.  Its reference (one u32 per sketch entry) carries the place in 16-byte units and, for lists shorter
-// than 127, the length -- so the row sums issue the list's loads without first waiting for its length word.
+// of `ids`.  Its reference (one u32 per sketch entry) carries the place in 16-byte units (26 bits: 2^29 u16 of
+// lists) and, for lists shorter than 63, the length -- so the row sums issue the list's loads without first
+// waiting for its length word.
+constexpr uint32_t kRefOffBits = 26, kRefOffMask = (1u << kRefOffBits) - 1, kRefLenMax = 63;
 __host__ __device__ __forceinline__ uint32_t list_u16(uint32_t len) { return (len + 1 + 7) & ~7u; }
-__device__ __forceinline__ uint32_t list_ref(uint32_t o, uint32_t len) { return (o >> 3) | ((len < 127 ? len : 127u) << 25); }
+__device__ __forceinline__ uint32_t list_ref(uint32_t o, uint32_t len) { return (o >> 3) | ((len < kRefLenMax ? len : kRefLenMax) << kRefOffBits); }
 constexpr uint32_t kNoList = 0xffffffffu;       // the key takes part in no pair of this job
 
 __global__ void k_insert_sparse(Keys K, const uint64_t* __restrict__ sk_off, uint64_t seed, uint64_t* __restrict__ table,
@@ -349,18 +351,18 @@ __global__ __launch_bounds__(kSparseThreads) void k_accumulate_sparse(const uint
         uint4 w[kAccU][kAccW];
 #pragma unroll
         for (int u = 0; u < kAccU; ++u) {
-            const uint4* L = reinterpret_cast<const uint4*>(ids) + (ref[u] & 0x1ffffffu);
-            const uint32_t len = ref[u] >> 25;
+            const uint4* L = reinterpret_cast<const uint4*>(ids) + (ref[u] & kRefOffMask);
+            const uint32_t len = ref[u] >> kRefOffBits;
 #pragma unroll
             for (int q = 0; q < kAccW; ++q)
-                w[u][q] = (ref[u] != kNoList && (q == 0 || len >= 8u * q)) ? L[q] : make_uint4(0, 0, 0, 0);   // (len 127 = "127 or more")
+                w[u][q] = (ref[u] != kNoList && (q == 0 || len >= 8u * q)) ? L[q] : make_uint4(0, 0, 0, 0);   // (len 63 = "63 or more")
         }
 #pragma unroll
         for (int u = 0; u < kAccU; ++u) {
             if (ref[u] == kNoList) continue;
-            const uint4* L = reinterpret_cast<const uint4*>(ids) + (ref[u] & 0x1ffffffu);
-            uint32_t len = ref[u] >> 25;
-            if (len == 127) len = w[u][0].x & 0xffffu;
+            const uint4* L = reinterpret_cast<const uint4*>(ids) + (ref[u] & kRefOffMask);
+            uint32_t len = ref[u] >> kRefOffBits;
+            if (len == kRefLenMax) len = w[u][0].x & 0xffffu;
             // list element t (element 0 is the length, ids are 1..len) = half-word t & 7 of word t >> 3
             auto word = [&](const uint4& v, uint32_t first) {
                 const uint32_t d[4] = {v.x, v.y, v.z, v.w};
@@ -409,7 +411,8 @@ __global__ __launch_bounds__(256) void k_zero_rows(uint32_t n, uint32_t row_firs
 // falls back to the global-dictionary forms.
 constexpr int kPartCap = 4096, kPartSlots = 7936, kGroupThreads = 1024;   // (record index + 1 fits the 13 low bits of a slot word)
 constexpr int kScatThreads = 1024, kScatPer = 4, kScatSub = kScatThreads * kScatPer;   // entries per sub-chunk
-constexpr int kMaxKeyParts = 32768;   // x ~2 900 records: 9.5 x 10^7 keys per comparison (BASELINE configs[3] has 5.2 x 10^7)
+constexpr int kMaxKeyParts = 32000;   // x ~2 900 records: 9 x 10^7 keys per comparison (BASELINE configs[3] has 5.2 x 10^7); x 16 Ki u16 of lists
+                                      // each stays inside the 2^29 u16 a list reference can address
 
 __device__ __forceinline__ uint64_t key_hash(uint64_t lo, uint32_t mn, uint64_t hi, bool has_hi) {
     uint64_t h = mix64(lo ^ 0xA0761D6478BD642FULL);
@@ -868,7 +871,7 @@ static int job_begin_dictionary(spsp_ctx* ctx, CompareJob* J) {
     // many sketches, every row owned: sketch lists instead of colour rows (SPSP_DEBUG_SPARSE=1/0 forces the choice)
     static const char* dbg_sparse = getenv("SPSP_DEBUG_SPARSE");
     const bool all_owned = P.row_stride == 1 && P.row_first == 0 && P.row_limit >= P.n && P.n_own == P.n;
-    J->sparse = J->insert_sparse && all_owned && 8 * P.S_entries < 0xffffff00ull &&
+    J->sparse = J->insert_sparse && all_owned && 8 * P.S_entries < (1ull << 29) &&
                 (dbg_sparse ? atoi(dbg_sparse) != 0 : (J->W >= 64 && !dbg_budget));
     if (J->sparse) J->speculative = true;       // queued in one go, checked once
     // Large builds: the colour matrix is rows x N bits and grows with N * (distinct keys) -- at tens of thousands of
@@ -916,7 +919,8 @@ static int job_begin_dictionary(spsp_ctx* ctx, CompareJob* J) {
 // records a part is planned to hold on average: kPartCap less the spread of the part sizes (keys shared by c
 // sketches arrive c at a time); halved for the second attempt
 static uint32_t parts_for(uint64_t entries, uint32_t attempt) {
-    const uint64_t mean = attempt == 0 ? 2900 : 1400;
+    static const char* dbg_mean = getenv("SPSP_DEBUG_PART_MEAN");   // test hook: tiny parts, so that small inputs reach tens of thousands of parts
+    const uint64_t mean = dbg_mean ? (uint64_t)std::max(1, atoi(dbg_mean)) : (attempt == 0 ? 2900 : 1400);
     return (uint32_t)std::max<uint64_t>(1, (entries + mean - 1) / mean);
 }
 
@@ -929,7 +933,7 @@ static int compare_job_begin(spsp_ctx* ctx, CompareJob* job) {
     static const bool hooks = getenv("SPSP_DEBUG_MATRIX_BUDGET") || getenv("SPSP_DEBUG_SPARSE") || getenv("SPSP_DEBUG_FP_BITS");
     static const char* dbg_parts = getenv("SPSP_DEBUG_PARTS");
     J->parts = J->scatter_parts && (dbg_parts ? atoi(dbg_parts) != 0 : !hooks) &&
-               parts_for(P.S_entries, 1) <= (uint32_t)kMaxKeyParts;
+               parts_for(P.S_entries, 0) <= (uint32_t)kMaxKeyParts;
     if (J->parts) {
         J->speculative = true;                      // queued in one go, checked once
         J->n_parts = parts_for(P.S_entries, 0);

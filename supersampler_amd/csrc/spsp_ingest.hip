@@ -394,6 +394,9 @@ int clean_device_impl(spsp_ctx* ctx, const uint8_t* d_text, uint64_t n_text, uin
 int gather_superkmers_impl(spsp_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_rec_off, const spsp_superkmer* d_sk,
                            uint64_t n_sk, uint8_t** h_compact, uint32_t** h_off) {
     *h_compact = nullptr; *h_off = nullptr;
+    // destination offsets are 32-bit prefix sums: a super-k-mer is at most 2k - m <= 125 bases long, so below this many
+    // of them the total cannot wrap (a whole-genome select-all of > 4 Gbp has to be split by the caller)
+    if (n_sk > 0xffffffffull / 126) { set_error("too many selected super-k-mers for one call (%llu): split the input", (unsigned long long)n_sk); return SPSP_ERR_OVERFLOW; }
     uint32_t* off = (uint32_t*)malloc((size_t)(n_sk + 1) * 4);
     if (!off) { set_error("out of host memory"); return SPSP_ERR_NOMEM; }
     off[0] = 0;

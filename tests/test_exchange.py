@@ -491,3 +491,17 @@ def test_eight_simulated_ranks_c4_shaped(ctx):
         assert (p[~own] == -1).all()
         merged[r::world] = torch.triu(part, 1)[r::world]
     assert (merged.cpu().numpy() == want).all() and int(want.sum()) > 1_000_000
+
+
+def test_partition_form_with_tens_of_thousands_of_parts():
+    """SPSP_DEBUG_PART_MEAN=40 cuts the keys into ~30 000 parts (the number BASELINE configs[3]'s 5 x 10^7 keys need):
+    list references, slice offsets and the scatter's per-part counters at that scale, on 2 048 C4-shaped sketches."""
+    code = ("import sys\nsys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np, torch\nimport supersampler_amd as sp, dist_worker as dw\n"
+            "n = 2048\nsets = dw.c4_shaped_sets(n, 600, seed=45)\nwant = dw.expected_inter(sets)\n"
+            "sk = [sp.Sketch(31, 11, np.full(len(x), 7, np.uint32), x, np.zeros(len(x), np.uint64)) for x in sets]\n"
+            "ctx = sp.Context(0)\ninter, card = ctx.compare(sk)\n"
+            "assert (inter.astype(np.int64) == want).all() and int(want.sum()) > 1_000_000\n"
+            "assert [int(c) for c in card] == [len(x) for x in sets]\nprint('ok')\n") % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SPSP_DEBUG_PART_MEAN="40"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
