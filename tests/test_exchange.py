@@ -505,3 +505,37 @@ def test_partition_form_with_tens_of_thousands_of_parts():
             "assert [int(c) for c in card] == [len(x) for x in sets]\nprint('ok')\n") % (ROOT, os.path.join(ROOT, "tests"))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SPSP_DEBUG_PART_MEAN="40"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_config4_full_size_on_one_gpu(ctx):
+    """BASELINE configs[3] at full size on ONE GPU: 10 000 sketches, 500 families of 20, ~5 000 keys each (5 x 10^7 keys,
+    ~18 000 key classes), synthesised directly.  All pairs inside five families and 2 000 random pairs
+    equal numpy set intersections; cardinalities and the number of non-zero pairs are as constructed."""
+    rng = np.random.default_rng(4)
+    n, fam_size = 10_000, 20
+    sets = []
+    for f in range(n // fam_size):
+        anc = np.unique(rng.integers(1, 2**62, size=int(rng.integers(2500, 10000)), dtype=np.int64))
+        for j in range(fam_size):
+            keep = anc[rng.random(len(anc)) < (0.97, 0.73, 0.45)[j % 3]]
+            extra = rng.integers(1, 2**62, size=len(anc) - len(keep), dtype=np.int64)
+            sets.append(np.unique(np.concatenate([keep, extra])).astype(np.uint64))
+    cnt = np.array([len(x) for x in sets])
+    assert cnt.sum() > 45_000_000
+    dev = torch.device("cuda", 0)
+    sk_off = np.zeros(n + 1, np.uint64); sk_off[1:] = np.cumsum(cnt)
+    d_lo = torch.from_numpy(np.concatenate(sets).view(np.int64)).to(dev)
+    d_min = torch.full((int(cnt.sum()),), 7, dtype=torch.int32, device=dev)
+    d_inter = torch.zeros((n, n), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ctx.compare_device(31, d_min.data_ptr(), d_lo.data_ptr(), None, sk_off, n, 0, 1, d_inter.data_ptr())
+    torch.cuda.synchronize()
+    got = d_inter.cpu().numpy()
+    del d_inter, d_lo, d_min
+    pairs = [(i, j) for f in (0, 1, 77, 250, 499) for i in range(f * fam_size, (f + 1) * fam_size) for j in range(i + 1, (f + 1) * fam_size)]
+    pairs += [tuple(sorted(int(x) for x in rng.integers(0, n, size=2))) for _ in range(2000)]
+    for i, j in pairs:
+        if i != j:
+            assert got[i, j] == len(np.intersect1d(sets[i], sets[j], assume_unique=True)), (i, j)
+    assert np.count_nonzero(np.triu(got, 1)) == (n // fam_size) * fam_size * (fam_size - 1) // 2      # random 62-bit keys: no chance matches
+    assert (np.tril(got) == 0).all()
