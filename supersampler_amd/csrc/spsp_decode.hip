@@ -28,15 +28,6 @@
 
 namespace spsp {
 
-struct DecDesc {
-    uint64_t off;    // byte offset in the concatenated payload buffer: blob bytes (kind 0) / prefix line (kind 1)
-    uint32_t mn;     // minimizer of the bucket (2-bit value)
-    uint32_t info;   // bits 0-1 kind: 0 maximal super-k-mer in the blob, 1 "prefix\nsuffix\n" pair, 2 the bare minimizer (k == m);
-                     // kind 1: prefix length bits 2-9, suffix length bits 10-17
-    uint32_t out;    // first raw key of this super-k-mer
-    uint32_t pad;
-};
-
 constexpr int kSortThreads = 1024;
 constexpr uint32_t kSortCapLo = 8192, kSortCapHi = 4096;
 
@@ -176,73 +167,6 @@ __global__ __launch_bounds__(256) void k_decode_compact(const uint32_t* __restri
 }
 
 // ------------------------------------------------------------------ host side --
-struct ParsedSketch {
-    uint32_t k = 0, m = 0;
-    bool standard = true;        // laid out as the sketcher writes it: the GPU path applies
-    uint64_t n_keys = 0;         // raw keys (duplicates included)
-    std::vector<DecDesc> desc;   // offsets relative to the payload; `out` relative to the sketch
-};
-
-static inline uint32_t code_of(uint8_t c) { return (c >> 1) & 3u; }
-
-// structure of one payload: header (Comparator.cpp:23-37) and, per bucket, [m ASCII][u32 n][blob][lines]["\n\n"]
-static int parse_structure(const uint8_t* payload, uint64_t len, ParsedSketch* P) {
-    const uint8_t* nl = (const uint8_t*)memchr(payload, '\n', len);
-    if (!nl) { set_error("sketch has no header line"); return SPSP_ERR_FORMAT; }
-    char* endp = nullptr;
-    const std::string header((const char*)payload, nl - payload);
-    const long skm = strtol(header.c_str(), &endp, 10);
-    const long mm = strtol(endp, &endp, 10);
-    if (skm <= 0 || skm > 126 || mm <= 0 || mm > 15 || (skm + mm) / 2 > 63 || (skm + mm) / 2 < mm) { set_error("bad sketch header '%.60s'", header.c_str()); return SPSP_ERR_FORMAT; }
-    const uint32_t m = (uint32_t)mm, k = (uint32_t)((skm + mm) / 2), half = (uint32_t)((skm - mm) / 2);
-    P->k = k; P->m = m;
-    uint64_t pos = (uint64_t)(nl - payload) + 1;
-    uint64_t out = 0;
-    auto push = [&](uint64_t off, uint32_t mn, uint32_t info, uint64_t count) {
-        if (count == 0) return;
-        if (out + count > 0xfffffff0ull) { P->standard = false; return; }
-        P->desc.push_back(DecDesc{off, mn, info, (uint32_t)out, 0});
-        out += count;
-    };
-    while (pos + m <= len) {
-        uint32_t mn = 0;
-        for (uint32_t j = 0; j < m; ++j) mn = (mn << 2) | code_of(payload[pos + j]);
-        pos += m;
-        uint32_t nbytes = 0;
-        if (pos + 4 > len) break;
-        memcpy(&nbytes, payload + pos, 4);
-        pos += 4;
-        if (pos + nbytes > len) { set_error("bucket blob runs past the end of the sketch"); return SPSP_ERR_FORMAT; }
-        uint64_t seq_len = 0;
-        if (nbytes) {
-            if (payload[pos] != 0) P->standard = false;           // a partial last byte: never written by the sketcher (k, m odd)
-            seq_len = (uint64_t)(nbytes - 1) * 4;
-        }
-        if (half > 0) {
-            if ((2 * half) % 4 != 0) P->standard = false;         // (k - m odd: a foreign file)
-            for (uint64_t i = 0; (i + 1) * 2 * half <= seq_len; ++i) push(pos + 1 + i * (half / 2), mn, 0u, k - m + 1);
-        } else if (seq_len == 0) {
-            push(pos, mn, 2u, 1);                                  // k == m: the bare minimizer is one k-mer (Comparator.cpp:88-90,193-198)
-        }
-        pos += nbytes;
-        for (;;) {                                                 // "prefix\nsuffix\n" until an empty pair (:226-260)
-            if (pos >= len) break;
-            const uint8_t* e1 = (const uint8_t*)memchr(payload + pos, '\n', len - pos);
-            const uint64_t s1 = pos, l1 = e1 ? (uint64_t)(e1 - payload) - pos : len - pos;
-            pos = e1 ? s1 + l1 + 1 : len;
-            const uint8_t* e2 = pos < len ? (const uint8_t*)memchr(payload + pos, '\n', len - pos) : nullptr;
-            const uint64_t s2 = pos, l2 = pos < len ? (e2 ? (uint64_t)(e2 - payload) - pos : len - pos) : 0;
-            pos = e2 ? s2 + l2 + 1 : len;
-            if (l1 == 0 && l2 == 0) break;
-            if (!e1 || l1 > 255 || l2 > 255 || s2 != s1 + l1 + 1) { P->standard = false; continue; }
-            const uint64_t total = l1 + m + l2;
-            push(s1, mn, 1u | ((uint32_t)l1 << 2) | ((uint32_t)l2 << 10), total >= k ? total - k + 1 : 0);
-        }
-    }
-    P->n_keys = out;
-    return SPSP_OK;
-}
-
 // payloads (gunzipped sketch files, host) -> context-owned device key arrays (c_min / c_lo / c_hi: the buffers
 // spsp_compare's host form uploads into) + host offsets.  extra[i] (optional): one more key for sketch i, given as a
 // bare minimizer -- the phantom key of the comparator's first-read rule (spsp_sketch_chain_host)
@@ -262,7 +186,7 @@ int sketch_decode_device_impl(spsp_ctx* ctx, const uint8_t* const* payloads, con
             for (;;) {
                 const uint32_t i = next.fetch_add(1);
                 if (i >= n) break;
-                rcs[i] = parse_structure(payloads[i], lens[i], &P[i]);
+                rcs[i] = sketch_parse_structure_host(payloads[i], lens[i], &P[i]);
                 if (rcs[i]) errs[i] = spsp_last_error();
             }
         };
@@ -378,6 +302,24 @@ int sketch_decode_device_impl(spsp_ctx* ctx, const uint8_t* const* payloads, con
     free_hk();
     if (e != hipSuccess) return hip_fail(e, "sketch decode", __FILE__, __LINE__);
     for (uint32_t i = 0; i <= n; ++i) sk_off[i] = off32[i];
+    return SPSP_OK;
+}
+
+int compare_payloads_impl(spsp_ctx* ctx, const uint8_t* const* payloads, const uint64_t* lens, uint32_t n, const int* extra_has,
+                          const uint32_t* extra_mn, uint32_t n_query, uint32_t* k_out, uint32_t* m_out, uint32_t* inter, uint64_t* card) {
+    std::vector<uint64_t> sk_off((size_t)n + 1, 0);
+    int rc = sketch_decode_device_impl(ctx, payloads, lens, n, extra_has, extra_mn, k_out, m_out, sk_off.data());
+    if (rc || n == 0) return rc;
+    for (uint32_t i = 0; i < n; ++i) card[i] = sk_off[i + 1] - sk_off[i];
+    memset(inter, 0, (size_t)n * n * 4);
+    if (sk_off[n] == 0) return SPSP_OK;
+    if ((rc = ctx->c_inter.reserve((size_t)n * n * 4))) return rc;
+    SPSP_HIP(hipMemsetAsync(ctx->c_inter.p, 0, (size_t)n * n * 4, ctx->stream));
+    const uint32_t k = *k_out;
+    if ((rc = compare_device_impl(ctx, k, ctx->c_min.as<uint32_t>(), ctx->c_lo.as<uint64_t>(), k > 32 ? ctx->c_hi.as<uint64_t>() : nullptr,
+                                  sk_off.data(), n, n_query, 0, 1, ctx->c_inter.as<uint32_t>()))) return rc;
+    SPSP_HIP(hipMemcpyAsync(inter, ctx->c_inter.p, (size_t)n * n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SPSP_HIP(hipStreamSynchronize(ctx->stream));
     return SPSP_OK;
 }
 

@@ -340,6 +340,65 @@ int sketch_build_core(const spsp_params* p, double rate, const uint64_t* rec_off
     return SPSP_OK;
 }
 
+// structure of one payload for the GPU decoder (spsp_decode.hip): header (Comparator.cpp:23-37) and, per bucket,
+// [m ASCII][u32 n][blob][lines]["\n\n"] (:186-260).  Every offset it hands to the device is checked against `len` here.
+int sketch_parse_structure_host(const uint8_t* payload, uint64_t len, ParsedSketch* P) {
+    const uint8_t* nl = (payload && len) ? (const uint8_t*)memchr(payload, '\n', len) : nullptr;
+    if (!nl) { set_error("sketch has no header line"); return SPSP_ERR_FORMAT; }
+    char* endp = nullptr;
+    const std::string header((const char*)payload, nl - payload);
+    const long skm = strtol(header.c_str(), &endp, 10);
+    const long mm = strtol(endp, &endp, 10);
+    if (skm <= 0 || skm > 126 || mm <= 0 || mm > 15 || (skm + mm) / 2 > 63 || (skm + mm) / 2 < mm) { set_error("bad sketch header '%.60s'", header.c_str()); return SPSP_ERR_FORMAT; }
+    const uint32_t m = (uint32_t)mm, k = (uint32_t)((skm + mm) / 2), half = (uint32_t)((skm - mm) / 2);
+    P->k = k; P->m = m;
+    uint64_t pos = (uint64_t)(nl - payload) + 1;
+    uint64_t out = 0;
+    auto push = [&](uint64_t off, uint32_t mn, uint32_t info, uint64_t count) {
+        if (count == 0) return;
+        if (out + count > 0xfffffff0ull) { P->standard = false; return; }
+        P->desc.push_back(DecDesc{off, mn, info, (uint32_t)out, 0});
+        out += count;
+    };
+    while (pos + m <= len) {
+        uint32_t mn = 0;
+        for (uint32_t j = 0; j < m; ++j) mn = (mn << 2) | code_of(payload[pos + j]);
+        pos += m;
+        uint32_t nbytes = 0;
+        if (pos + 4 > len) break;
+        memcpy(&nbytes, payload + pos, 4);
+        pos += 4;
+        if (pos + nbytes > len) { set_error("bucket blob runs past the end of the sketch"); return SPSP_ERR_FORMAT; }
+        uint64_t seq_len = 0;
+        if (nbytes) {
+            if (payload[pos] != 0) P->standard = false;           // a partial last byte: never written by the sketcher (k, m odd)
+            seq_len = (uint64_t)(nbytes - 1) * 4;
+        }
+        if (half > 0) {
+            if ((2 * half) % 4 != 0) P->standard = false;         // (k - m odd: a foreign file)
+            for (uint64_t i = 0; (i + 1) * 2 * half <= seq_len; ++i) push(pos + 1 + i * (half / 2), mn, 0u, k - m + 1);
+        } else if (seq_len == 0) {
+            push(pos, mn, 2u, 1);                                  // k == m: the bare minimizer is one k-mer (Comparator.cpp:88-90,193-198)
+        }
+        pos += nbytes;
+        for (;;) {                                                 // "prefix\nsuffix\n" until an empty pair (:226-260)
+            if (pos >= len) break;
+            const uint8_t* e1 = (const uint8_t*)memchr(payload + pos, '\n', len - pos);
+            const uint64_t s1 = pos, l1 = e1 ? (uint64_t)(e1 - payload) - pos : len - pos;
+            pos = e1 ? s1 + l1 + 1 : len;
+            const uint8_t* e2 = pos < len ? (const uint8_t*)memchr(payload + pos, '\n', len - pos) : nullptr;
+            const uint64_t s2 = pos, l2 = pos < len ? (e2 ? (uint64_t)(e2 - payload) - pos : len - pos) : 0;
+            pos = e2 ? s2 + l2 + 1 : len;
+            if (l1 == 0 && l2 == 0) break;
+            if (!e1 || l1 > 255 || l2 > 255 || s2 != s1 + l1 + 1) { P->standard = false; continue; }
+            const uint64_t total = l1 + m + l2;
+            push(s1, mn, 1u | ((uint32_t)l1 << 2) | ((uint32_t)l2 << 10), total >= k ? total - k + 1 : 0);
+        }
+    }
+    P->n_keys = out;
+    return SPSP_OK;
+}
+
 }  // namespace spsp
 
 extern "C" {
@@ -896,27 +955,10 @@ static int compare_files_impl(spsp_ctx* ctx, const char* const* paths, uint32_t 
     } else if (!rc) {
         if (chatter && n) { printf("kmers evaluated are of length: %u minimizer size is %u\n", k0, m0); fflush(stdout); }   // :56
         t1 = now_s(); ctx->stages.load_s += t1 - t0; t0 = t1;
-        std::vector<uint64_t> sk_off((size_t)n + 1, 0);
         uint32_t kk = 0, mm2 = 0;
-        rc = spsp::sketch_decode_device_impl(ctx, datas.data(), lens.data(), n, extra_has.data(), extra_mn.data(), &kk, &mm2, sk_off.data());
-        free_datas();
-        if (!rc && n) {
-            for (uint32_t i = 0; i < n; ++i) card[i] = sk_off[i + 1] - sk_off[i];
-            inter.assign((size_t)n * n, 0);
-            if (sk_off[n] > 0) {
-                hipError_t e = hipSuccess;
-                if ((rc = ctx->c_inter.reserve((size_t)n * n * 4)) == SPSP_OK) {
-                    e = hipMemsetAsync(ctx->c_inter.p, 0, (size_t)n * n * 4, ctx->stream);
-                    if (e == hipSuccess)
-                        rc = spsp::compare_device_impl(ctx, kk, ctx->c_min.as<uint32_t>(), ctx->c_lo.as<uint64_t>(),
-                                                       kk > 32 ? ctx->c_hi.as<uint64_t>() : nullptr, sk_off.data(), n, n_query, 0, 1,
-                                                       ctx->c_inter.as<uint32_t>());
-                    if (!rc && e == hipSuccess) e = hipMemcpyAsync(inter.data(), ctx->c_inter.p, (size_t)n * n * 4, hipMemcpyDeviceToHost, ctx->stream);
-                    if (!rc && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-                    if (!rc && e != hipSuccess) rc = spsp::hip_fail(e, "comparison of decoded sketches", __FILE__, __LINE__);
-                }
-            }
-        }
+        if (n) inter.assign((size_t)n * n, 0);
+        rc = spsp::compare_payloads_impl(ctx, datas.data(), lens.data(), n, extra_has.data(), extra_mn.data(), n_query, &kk, &mm2,
+                                         inter.data(), card.data());
     }
     free_datas();
     t1 = now_s(); ctx->stages.compare_s += t1 - t0;

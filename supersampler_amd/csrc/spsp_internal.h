@@ -151,7 +151,26 @@ int check_params(const spsp_params* p);
 // every super-k-mer of the input, selected or not (spsp_stats.hip)
 int count_superkmers_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, uint64_t n_bases, const uint64_t* d_rec_off,
                           uint32_t n_rec, uint64_t* total);
-// bulk sketch decode (spsp_decode.hip): payloads -> ctx->c_min / c_lo / c_hi + host offsets
+// bulk sketch decode (spsp_decode.hip): one stored super-k-mer of a sketch payload, as the host's structure walk finds it
+struct DecDesc {
+    uint64_t off;    // byte offset in the payload (later: in the concatenated payload buffer): blob bytes (kind 0) / prefix line (kind 1)
+    uint32_t mn;     // minimizer of the bucket (2-bit value)
+    uint32_t info;   // bits 0-1 kind: 0 maximal super-k-mer in the blob, 1 "prefix\nsuffix\n" pair, 2 the bare minimizer (k == m);
+                     // kind 1: prefix length bits 2-9, suffix length bits 10-17
+    uint32_t out;    // first raw key of this super-k-mer
+    uint32_t pad;
+};
+struct ParsedSketch {
+    uint32_t k = 0, m = 0;
+    bool standard = true;        // laid out as the sketcher writes it: the GPU path applies
+    uint64_t n_keys = 0;         // raw keys (duplicates included)
+    std::vector<DecDesc> desc;   // offsets relative to the payload; `out` relative to the sketch
+};
+// structure of one payload: header + bucket boundaries + line ends (spsp_host.cpp: pure host code, fuzzed under ASan)
+int sketch_parse_structure_host(const uint8_t* payload, uint64_t len, ParsedSketch* P);
+// decode on the GPU + all-vs-all + copy back: the device half of spsp_compare_files (spsp_decode.hip)
+int compare_payloads_impl(spsp_ctx* ctx, const uint8_t* const* payloads, const uint64_t* lens, uint32_t n, const int* extra_has,
+                          const uint32_t* extra_mn, uint32_t n_query, uint32_t* k_out, uint32_t* m_out, uint32_t* inter, uint64_t* card);
 int sketch_decode_device_impl(spsp_ctx* ctx, const uint8_t* const* payloads, const uint64_t* lens, uint32_t n,
                               const int* extra_has, const uint32_t* extra_mn, uint32_t* k_out, uint32_t* m_out, uint64_t* sk_off);
 // ingest (spsp_ingest.hip)

@@ -28,6 +28,7 @@ void set_error(const char* fmt, ...) {
 int gather_superkmers_impl(spsp_ctx*, const uint8_t*, const uint64_t*, const spsp_superkmer*, uint64_t, uint8_t**, uint32_t**) { return SPSP_ERR_NO_DEVICE; }
 int clean_device_impl(spsp_ctx*, const uint8_t*, uint64_t, uint8_t**, uint64_t*, uint64_t**, uint32_t*) { return SPSP_ERR_NO_DEVICE; }
 int scan_device_impl(spsp_ctx*, const spsp_params*, const uint8_t*, uint64_t, const uint64_t*, uint32_t, spsp_superkmer**, uint64_t*) { return SPSP_ERR_NO_DEVICE; }
+int compare_payloads_impl(spsp_ctx*, const uint8_t* const*, const uint64_t*, uint32_t, const int*, const uint32_t*, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint64_t*) { return SPSP_ERR_NO_DEVICE; }
 int check_params(const spsp_params* p) { return (p && p->m >= 1 && p->m <= 15 && p->k >= p->m && p->k <= 63) ? SPSP_OK : SPSP_ERR_ARG; }
 }  // namespace spsp
 extern "C" {
@@ -110,6 +111,25 @@ int main(int argc, char** argv) {
                 int has = 0; uint32_t pm; uint64_t pl, ph;
                 spsp_sketch_chain_host((const uint8_t*)p.data(), p.size(), k, m, buf, &has, &pm, &pl, &ph);
                 free(mn); free(lo); free(hi);
+            } else ++rejected;
+        }
+        {   // structure walk of the GPU decoder: every byte range a descriptor makes k_decode_emit read must lie inside the payload
+            const std::string p = it < (int)payloads.size() ? payloads[it] : mutate(payloads[rng() % payloads.size()]);
+            std::vector<uint8_t> exact(p.begin(), p.end());   // heap copy without slack: ASan sees one byte too far
+            spsp::ParsedSketch P;
+            if (spsp::sketch_parse_structure_host(exact.data(), exact.size(), &P) == SPSP_OK) {
+                ++ok;
+                uint64_t acc = 0, out = 0;
+                for (const spsp::DecDesc& D : P.desc) {
+                    const uint32_t kind = D.info & 3u, l1 = (D.info >> 2) & 0xffu, l2 = (D.info >> 10) & 0xffu;
+                    const uint64_t nbytes = kind == 0 ? (2ull * (P.k - P.m) + 3) / 4 : kind == 1 ? (uint64_t)l1 + 1 + l2 : 0;
+                    if (D.off + nbytes > exact.size() || D.out != out) { fprintf(stderr, "descriptor outside its payload\n"); return 9; }
+                    for (uint64_t b = 0; b < nbytes; ++b) acc += exact[D.off + b];
+                    const uint32_t total = kind == 0 ? 2 * P.k - P.m : kind == 1 ? l1 + P.m + l2 : P.m;
+                    out += total - P.k + 1;
+                }
+                if (out != P.n_keys) { fprintf(stderr, "key count mismatch\n"); return 9; }
+                if (acc == 0x1234567) printf("!");
             } else ++rejected;
         }
         {   // sortCSV
