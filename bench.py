@@ -109,8 +109,20 @@ def main():
     # BENCH_SCHEDULE: "single" = as above (0.158-0.163 ms); "streams" = every slot's scan on a stream of its own, its dense
     # pass behind the previous slot's by an event (0.167 ms); "tail" = scans on one stream, their sparse stages on
     # spsp_scan_tail_stream streams (0.18 ms)
-    schedule = os.environ.get("BENCH_SCHEDULE", "single")
-    tail_streams = schedule == "tail"
+    # "partition" = the chip is split (spsp_stream_create_cus): every dense pass runs on a stream that owns all but
+    # BENCH_SMALL_CUS compute units, the sparse stages of every scan and every comparison on streams that own the rest
+    # -- the dense passes run back to back and nothing that shares a CU with them slows them down
+    schedule = os.environ.get("BENCH_SCHEDULE", "partition")
+    tail_streams = schedule in ("tail", "partition")
+    small_cus = int(os.environ.get("BENCH_SMALL_CUS", "64"))
+    ctx_full, full_stream = ctx, stream                   # whole-device context: setup and the extras
+    if schedule == "partition" and pipelined:
+        n_dev_cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        masked = [sp.stream_create_cus(local_rank, small_cus, n_dev_cus - small_cus)]
+        stream = torch.cuda.ExternalStream(masked[0], device=dev)
+        torch.cuda.set_stream(stream)
+        ctx = sp.Context(local_rank, stream.cuda_stream)
+        ctx.set_cu_count(n_dev_cus - small_cus, 2)
 
     class Slot:
         pass
@@ -121,10 +133,22 @@ def main():
         if pipelined:
             sl.stream_a = stream if (i == 0 or schedule != "streams") else torch.cuda.Stream(device=dev)
             sl.scan = ctx if i == 0 else sp.Context(local_rank, sl.stream_a.cuda_stream)
-            if tail_streams:
-                sl.scan.scan_tail_stream(True)
-            sl.stream_b = torch.cuda.Stream(device=dev)
+            if schedule == "partition":
+                sl.scan.set_cu_count(n_dev_cus - small_cus, 2)
+                if i == 0 or os.environ.get("BENCH_SMALL_STREAMS", "shared") != "shared":
+                    # one stream for every slot's sparse stages and one for every comparison by default: every CU-masked
+                    # stream is a hardware queue of its own, and a handful of them already delay each other's packets
+                    masked += [sp.stream_create_cus(local_rank, 0, small_cus), sp.stream_create_cus(local_rank, 0, small_cus)]
+                    small_b = torch.cuda.ExternalStream(masked[-1], device=dev)
+                sl.scan.scan_tail_stream(True, masked[-2])
+                sl.stream_b = small_b
+            else:
+                if tail_streams:
+                    sl.scan.scan_tail_stream(True)
+                sl.stream_b = torch.cuda.Stream(device=dev)
             sl.cmp = sp.Context(local_rank, sl.stream_b.cuda_stream)
+            if schedule == "partition":
+                sl.cmp.set_cu_count(small_cus)
         else:
             sl.stream_a = sl.stream_b = stream
             sl.scan = sl.cmp = ctx
@@ -202,7 +226,8 @@ def main():
             sl.scan.wait_dense(prev.scan)                 # "streams": dense passes never overlap each other
         sl.scan.scan_device_begin(*scan_args)             # "tail" / "single": dense passes in order on the one scan stream
         if exchange_kind == "none":
-            sl.cmp.wait_dense(sl.scan)                    # the comparison starts behind this step's dense pass
+            if schedule != "partition":
+                sl.cmp.wait_dense(sl.scan)                # the comparison starts behind this step's dense pass
             sl.cmp.compare_device_begin(K, d_all_min.data_ptr(), d_all_lo.data_ptr(), None, sk_off, n_total, rank, world,
                                         sl.d_inter.data_ptr())                                             # stream B
             return
@@ -376,7 +401,11 @@ def main():
                                        "gather": "genomes sharded by rank; RCCL all-gather of the packed sketch keys, every rank "
                                                  "computes the pair-matrix rows i % N == rank, strips gathered on rank 0 (SURVEY.md 8e)"}[exchange_kind],
                        "exchange_check": exchange_check,
-                       "step": ("scan(batch t) || all-vs-all(sketches of batch t-1): scans in order on one stream, every slot's "
+                       "step": (("scan(batch t) || all-vs-all(sketches of batch t-1): the chip is partitioned by CU-masked streams -- "
+                                 "dense passes back to back on %d CUs (two workgroups each), the scans' sparse stages on one stream and "
+                                 "the comparisons on another that share the other %d CUs; the host queues step t+1 before collecting "
+                                 "step t [schedule partition]" % (n_dev_cus - small_cus, small_cus)) if pipelined and schedule == "partition"
+                                else "scan(batch t) || all-vs-all(sketches of batch t-1): scans in order on one stream, every slot's "
                                 "comparison on a stream of its own behind its dense pass; the host queues step t+1 before "
                                 "collecting step t [schedule %s]" % schedule if pipelined
                                 else "scan then all-vs-all on one stream, one step at a time")},
@@ -415,11 +444,11 @@ def main():
             out["cpu_baseline"] = cpu_baseline(recs, payloads, p, int(n_out), d_inter)
         if world == 1 and not args.no_extras:
             try:
-                out["compare"] = compare_config3(ctx, dev, args.no_cpu_baseline)
+                out["compare"] = compare_config3(ctx_full, dev, args.no_cpu_baseline)
             except Exception as e:  # noqa: BLE001 -- an extra must not take the headline down
                 out["compare"] = {"error": repr(e)}
             try:
-                out["end_to_end"] = end_to_end(ctx, args.no_cpu_baseline)
+                out["end_to_end"] = end_to_end(ctx_full, args.no_cpu_baseline)
             except Exception as e:  # noqa: BLE001
                 out["end_to_end"] = {"error": repr(e)}
         sys.stdout.flush()
@@ -427,6 +456,16 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    # contexts and CU-masked streams are released here, not by the interpreter's teardown (which may run after the
+    # HIP runtime's own: a profiler then sees a crash at exit)
+    torch.cuda.synchronize()
+    for c in all_ctx:
+        c.close()
+    ctx.close()
+    ctx_full.close()
+    del full_stream
+    for h in (masked if schedule == "partition" and pipelined else []):
+        sp.stream_destroy(local_rank, h)
 
 
 def pmc_traffic(args, kernel):

@@ -84,6 +84,20 @@ void spsp_destroy(spsp_ctx* ctx);
 const char* spsp_last_error(void);
 const char* spsp_version(void);
 void spsp_free(void* host_ptr);
+/* CU partitioning (MI355X: 256 CUs in 8 XCDs).  spsp_stream_create_cus makes a HIP stream whose kernels may only
+ * run on the `n_cu` logical compute units [first_cu, first_cu + n_cu) (hipExtStreamCreateWithCUMask; the mask's bits
+ * are dealt round-robin over the XCDs -- measured, tools/exp/exp_cumask.hip -- so a range of 8j bits is j CUs of every
+ * XCD).  A pipeline gives the bandwidth-bound dense pass most of the chip and the latency-bound kernels (sparse
+ * stages, comparison) a few CUs of their own: they then overlap without slowing each other down, which they do when
+ * they share CUs (a dense workgroup next to a comparison workgroup runs at half speed and the dense grid, a static
+ * partition, waits for it).  Take n_cu in multiples of 32: a CU count that is not the same in every shader engine
+ * (4 per XCD) makes the dispatcher double workgroups up on some CUs (dense pass 0.10 -> 0.15 ms with 240 CUs).
+ * spsp_set_cu_count tells a context how many CUs its stream owns (grid sizing; 0 = all) and how many dense-pass
+ * workgroups to put on each: 1 (the default) leaves half of every CU's wave slots and LDS to other streams' kernels,
+ * 2 is for a stream that has its CUs to itself. */
+int spsp_stream_create_cus(int device, uint32_t first_cu, uint32_t n_cu, void** hip_stream);
+int spsp_stream_destroy(int device, void* hip_stream);
+int spsp_set_cu_count(spsp_ctx* ctx, uint32_t n_cu, uint32_t dense_blocks_per_cu);
 /* copy `bytes` from a device buffer returned by this library to host memory, on the context's stream, and wait */
 int spsp_copy_to_host(spsp_ctx* ctx, void* dst, const void* d_src, uint64_t bytes);
 

@@ -68,6 +68,7 @@ SUPERKMER_DTYPE = np.dtype([("rec", "<u4"), ("minimizer", "<u4"), ("start", "<u8
 # every symbol include/spsp.h declares (tests check the .so exports them all)
 ABI_SYMBOLS = [
     "spsp_create", "spsp_destroy", "spsp_last_error", "spsp_version", "spsp_free", "spsp_copy_to_host",
+    "spsp_stream_create_cus", "spsp_stream_destroy", "spsp_set_cu_count",
     "spsp_timing_enable", "spsp_timing_read", "spsp_threshold_host", "spsp_scan", "spsp_scan_device", "spsp_scan_device_begin", "spsp_scan_device_end", "spsp_scan_tail_stream", "spsp_wait_dense", "spsp_wait_stream", "spsp_scan_hits_device", "spsp_count_superkmers_device", "spsp_compare",
     "spsp_compare_device", "spsp_slot_bytes", "spsp_partition_keys_device", "spsp_compare_slots_device", "spsp_compare_device_begin", "spsp_compare_slots_device_begin", "spsp_compare_end", "spsp_fasta_clean_host", "spsp_fasta_clean_device", "spsp_sketch_text", "spsp_sketch_build_host", "spsp_sketch_parse_host", "spsp_sketch_decode_device", "spsp_sketch_chain_host",
     "spsp_csv_host", "spsp_sort_csv_host", "spsp_read_file_host", "spsp_write_gz_host", "spsp_sketch_file", "spsp_compare_files", "spsp_compare_files_chatty", "spsp_stage_times_read",
@@ -92,6 +93,9 @@ def lib():
     L.spsp_version.restype = cp; L.spsp_version.argtypes = []
     L.spsp_free.restype = None; L.spsp_free.argtypes = [vp]
     L.spsp_copy_to_host.restype = i32; L.spsp_copy_to_host.argtypes = [vp, vp, vp, u64]
+    L.spsp_stream_create_cus.restype = i32; L.spsp_stream_create_cus.argtypes = [i32, u32, u32, P(vp)]
+    L.spsp_stream_destroy.restype = i32; L.spsp_stream_destroy.argtypes = [i32, vp]
+    L.spsp_set_cu_count.restype = i32; L.spsp_set_cu_count.argtypes = [vp, u32, u32]
     L.spsp_timing_enable.restype = i32; L.spsp_timing_enable.argtypes = [vp, i32]
     L.spsp_timing_read.restype = i32; L.spsp_timing_read.argtypes = [vp, P(Timing)]
     L.spsp_threshold_host.restype = u64; L.spsp_threshold_host.argtypes = [u32, u32, dbl]
@@ -274,6 +278,17 @@ def write_gz(path, data, level=9):
     _check(lib().spsp_write_gz_host(path.encode(), data, len(data), level))
 
 
+def stream_create_cus(device, first_cu, n_cu):
+    """a HIP stream (handle as int) whose kernels run on logical CUs [first_cu, first_cu + n_cu) only"""
+    h = C.c_void_p()
+    _check(lib().spsp_stream_create_cus(device, first_cu, n_cu, C.byref(h)))
+    return h.value
+
+
+def stream_destroy(device, stream):
+    _check(lib().spsp_stream_destroy(device, C.c_void_p(stream)))
+
+
 class Context:
     """One HIP device + one stream (spsp_create).  Raises SpspError without a gfx950 GPU."""
 
@@ -343,6 +358,11 @@ class Context:
         out, n = C.c_void_p(), C.c_uint64()
         _check(lib().spsp_scan_device_end(self._h, C.byref(out), C.byref(n)))
         return out.value, n.value
+
+    def set_cu_count(self, n_cu, dense_blocks_per_cu=1):
+        """how many CUs the context's stream owns (0 = the whole device) and how many dense workgroups go on each
+        (2 for a stream that has its CUs to itself): sizes the dense pass's grid"""
+        _check(lib().spsp_set_cu_count(self._h, n_cu, dense_blocks_per_cu))
 
     def scan_tail_stream(self, on=True, stream=None):
         """sparse stages of the scan on a second stream (None = one the context creates)"""

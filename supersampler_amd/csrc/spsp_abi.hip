@@ -128,7 +128,7 @@ int spsp_create(int device, void* hip_stream, spsp_ctx** out) {
     }
     spsp_ctx* c = new spsp_ctx();
     c->device = device;
-    c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    c->n_cu = c->n_cu_device = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; }
     else {
         e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
@@ -139,6 +139,43 @@ int spsp_create(int device, void* hip_stream, spsp_ctx** out) {
     if (e != hipSuccess) { if (c->own_stream) (void)hipStreamDestroy(c->stream); delete c; return hip_fail(e, "hipHostMalloc", __FILE__, __LINE__); }
     memset(c->h_scalar, 0, 16 * sizeof(uint64_t));
     *out = c;
+    return SPSP_OK;
+}
+
+int spsp_stream_create_cus(int device, uint32_t first_cu, uint32_t n_cu, void** hip_stream) {
+    if (!hip_stream) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    *hip_stream = nullptr;
+    SPSP_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    SPSP_HIP(hipGetDeviceProperties(&prop, device));
+    const uint32_t total = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
+    if (n_cu == 0 || first_cu >= total || n_cu > total - first_cu) {
+        set_error("CU range [%u, %u) outside the device's %u compute units", first_cu, first_cu + n_cu, total);
+        return SPSP_ERR_ARG;
+    }
+    std::vector<uint32_t> mask((total + 31) / 32, 0u);
+    for (uint32_t c = first_cu; c < first_cu + n_cu; ++c) mask[c >> 5] |= 1u << (c & 31);
+    hipStream_t s = nullptr;
+    SPSP_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()));
+    *hip_stream = (void*)s;
+    return SPSP_OK;
+}
+
+int spsp_stream_destroy(int device, void* hip_stream) {
+    if (!hip_stream) return SPSP_OK;
+    SPSP_HIP(hipSetDevice(device));
+    SPSP_HIP(hipStreamSynchronize((hipStream_t)hip_stream));
+    SPSP_HIP(hipStreamDestroy((hipStream_t)hip_stream));
+    return SPSP_OK;
+}
+
+int spsp_set_cu_count(spsp_ctx* ctx, uint32_t n_cu, uint32_t dense_blocks_per_cu) {
+    if (!ctx) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    if (ctx->scan_job.pending) { set_error("a scan is pending on this context"); return SPSP_ERR_ARG; }
+    if (n_cu > (uint32_t)ctx->n_cu_device) { set_error("the device has %d compute units", ctx->n_cu_device); return SPSP_ERR_ARG; }
+    if (dense_blocks_per_cu > 2) { set_error("at most two dense workgroups fit a CU"); return SPSP_ERR_ARG; }
+    ctx->n_cu = n_cu ? (int)n_cu : ctx->n_cu_device;
+    ctx->dense_blocks_per_cu = dense_blocks_per_cu ? (int)dense_blocks_per_cu : 1;
     return SPSP_OK;
 }
 

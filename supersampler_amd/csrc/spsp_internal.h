@@ -81,7 +81,9 @@ struct spsp_ctx {
     bool ev_open[spsp::kEvKinds] = {};   // a begin without its end is outstanding
     spsp_stage_times stages{};    // whole-file drivers: wall seconds per stage (spsp_stage_times_read)
     int device = 0;
-    int n_cu = 256;
+    int n_cu = 256;          // compute units this context's stream may use (spsp_set_cu_count)
+    int n_cu_device = 256;   // ... of the device
+    int dense_blocks_per_cu = 1;   // table variants of the dense pass: 1024-lane workgroups per CU (spsp_set_cu_count)
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipStream_t tail_stream = nullptr;   // sparse stages of the scan (spsp_scan_tail_stream); nullptr = the main stream

@@ -213,26 +213,48 @@ __device__ __forceinline__ uint32_t append_hits(bool is_hit, uint64_t pos, uint3
 constexpr int kRowChunks = 63;
 constexpr int kRowPosPair63 = kRowChunks * kChunk;   // 1008 positions per wave-row
 
-// survivors of one lane's 16 positions from its packed window (hi = own 16 bases, nxt = next 16)
-__device__ __forceinline__ uint32_t pair_lookup16(const uint8_t* __restrict__ tab, uint32_t hi, uint32_t nxt) {
-    const uint32_t mid = (hi << 16) | (nxt >> 16);   // bases 8..23
-    uint32_t accA = 0, accB = 0;
+// The next lane's packed chunk (lane 63: 0 -- it is the halo lane): one DPP move on the VALU instead of a
+// ds_bpermute, which would take a slot of the LDS pipeline the table reads saturate.
+__device__ __forceinline__ uint32_t next_lane(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+}
+
+// Survivors of one lane's 16 positions from its packed window (hi = own 16 bases, nxt = next 16).
+// Pair q (positions 2q, 2q+1) reads the table byte of its first 8 bases; the sub-entry of that byte is chosen by
+// the pair's 9th base s_q: bit s_q = first position, bit s_q + 4 = second.  The eight bytes are NOT shifted one by
+// one: the bytes of the even pairs (q = 0,2,4,6) are merged into one word, those of the odd pairs into another,
+// and each word is ANDed with a mask whose byte for pair q is 0x11 << s_q.  The s_q of the even pairs are 8 bits
+// apart in the window, so one v_alignbit brings them to bits 1:0 of the four bytes and ONE v_perm_b32 with the
+// constant 0x88442211 as byte table turns them into the mask.  ~20 VALU per 16 positions beside the address
+// extraction (the shifted form took 36).  Which position a surviving bit stands for is worked out when the
+// survivor is verified (pair_code_to_offset), not here.
+struct PairSurv { uint32_t e, o; };
+__device__ __forceinline__ PairSurv pair_lookup16(const uint8_t* __restrict__ tab, uint32_t hi, uint32_t nxt) {
+    const uint32_t mid = __builtin_amdgcn_alignbit(hi, nxt, 16);   // bases 8..23
+    uint32_t t[8];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {                    // pairs 0..3 from hi, 4..7 from mid
-        const uint32_t a0 = (hi >> (16 - 4 * q)) & 0xffffu, a1 = (mid >> (16 - 4 * q)) & 0xffffu;
-        const uint32_t s0 = (hi >> (14 - 4 * q)) & 3u, s1 = (mid >> (14 - 4 * q)) & 3u;
-        const uint32_t t0 = (uint32_t)tab[a0] >> s0, t1 = (uint32_t)tab[a1] >> s1;
-        accA = (accA << 1) | (t0 & 0x11u);
-        accB = (accB << 1) | (t1 & 0x11u);
+        t[q] = tab[(hi >> (16 - 4 * q)) & 0xffffu];
+        t[q + 4] = tab[(mid >> (16 - 4 * q)) & 0xffffu];
     }
-    // accX bit (3-q) = first position of pair q, bit (7-q) = second position
-    return accA | (accB << 8);
+    const uint32_t pe = ((t[0] << 8 | t[2]) << 16) | (t[4] << 8 | t[6]);    // byte 3 - q/2 = pair q (q even)
+    const uint32_t po = ((t[1] << 8 | t[3]) << 16) | (t[5] << 8 | t[7]);    // byte 3 - q/2 = pair q (q odd)
+    // base 2q+8 of the 64-bit window hi:nxt sits at bits 47-4q : 46-4q
+    const uint32_t se = __builtin_amdgcn_alignbit(hi, nxt, 22) & 0x03030303u;
+    const uint32_t so = __builtin_amdgcn_alignbit(hi, nxt, 18) & 0x03030303u;
+    PairSurv r;
+    r.e = pe & __builtin_amdgcn_perm(0u, 0x88442211u, se);
+    r.o = po & __builtin_amdgcn_perm(0u, 0x88442211u, so);
+    return r;
 }
-// position offset (0..15) of survivor bit b of pair_lookup16's result
-__device__ __forceinline__ uint32_t pair_bit_to_offset(uint32_t b) {
-    const uint32_t grp = b >> 3, w = b & 7, second = w >> 2, q = 3 - (w & 3);
-    return 2 * (4 * grp + q) + second;
+// survivor code = bit index in PairSurv::e (0..31) or 32 + bit index in PairSurv::o -> position offset (0..15)
+__device__ __forceinline__ uint32_t pair_code_to_offset(uint32_t code) {
+    const uint32_t q = 2 * (3 - ((code >> 3) & 3u)) + (code >> 5), second = (code >> 2) & 1u;
+    return 2 * q + second;
 }
+__device__ __forceinline__ uint32_t pair_count(PairSurv c) { return __popc(c.e) + __popc(c.o); }
+// code of the only survivor of a lane that holds exactly one
+__device__ __forceinline__ uint32_t pair_single_code(PairSurv c) { return (uint32_t)(__ffs(c.e | c.o) - 1) | (c.o ? 32u : 0u); }
 
 // Verify the queued survivors of one wave (all of them: the queue never holds more than 64), lane i taking
 // entry i.  Entries are {position of the lane's chunk relative to the wave's first position, survivor bit
@@ -249,7 +271,7 @@ __device__ __attribute__((noinline)) uint32_t drain_pair(const uint4* __restrict
     uint32_t f = 0, x = 0;
     if (lane < qn) {
         const uint4 e = queue[lane];
-        const uint32_t off = (e.y & 0x100u) ? (e.y & 15u) : pair_bit_to_offset(e.y);
+        const uint32_t off = (e.y & 0x100u) ? (e.y & 15u) : pair_code_to_offset(e.y);
         const uint64_t W = ((uint64_t)e.z << 32) | e.w;
         pos = base_pos + e.x + off;
         f = (uint32_t)(W >> (64 - 2 * m - 2 * off)) & mm;
@@ -292,11 +314,14 @@ __global__ __launch_bounds__(64 * kPairWaves) void k_dense_pair(const uint8_t* _
         out_n = drain_pair(queue, qn, base_pos, n_mmers, m, thr, out, L.cap, out_n);
         qn = 0;
     };
-    // rare: queue the survivors of ONE row in position order, 64 at a time, whatever their number
-    auto slow_row = [&](uint32_t c, uint32_t rel, uint32_t hi, uint32_t nxt) {
-        if (!__ballot(c != 0)) return;
+    // General form for ONE row: any number of survivors per lane, queued in position order.  Usual case (a lane or
+    // two holding two survivors: one row pair in five at the default sampling) -- they are appended behind what is
+    // queued and hashed with the next full round; only more than a queue-full is hashed 64 at a time on the spot.
+    auto push_row = [&](PairSurv c, uint32_t rel, uint32_t hi, uint32_t nxt) {
+        if (!__ballot((c.e | c.o) != 0)) return;
         uint32_t pm = 0;                                  // bit j = position offset j survives
-        for (uint32_t t = c; t; t &= t - 1) pm |= 1u << pair_bit_to_offset(__ffs(t) - 1);
+        for (uint32_t t = c.e; t; t &= t - 1) pm |= 1u << pair_code_to_offset(__ffs(t) - 1);
+        for (uint32_t t = c.o; t; t &= t - 1) pm |= 1u << pair_code_to_offset(32 + __ffs(t) - 1);
         const uint32_t cnt = __popc(pm);
         uint32_t idx = 0, total = 0;                      // exclusive prefix / total of cnt over the lanes
 #pragma unroll
@@ -305,7 +330,19 @@ __global__ __launch_bounds__(64 * kPairWaves) void k_dense_pair(const uint8_t* _
             idx += __builtin_amdgcn_mbcnt_hi((uint32_t)(plane >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)plane, 0u)) << b;
             total += (uint32_t)__popcll(plane) << b;
         }
-        for (uint32_t base = 0; base < total; base += 64) {
+        if (qn + total > (uint32_t)kQueueCap) drain();
+        if (total <= (uint32_t)kQueueCap) {
+            uint32_t at = qn + idx;
+            while (pm) {
+                const uint32_t off = __ffs(pm) - 1;
+                pm &= pm - 1;
+                queue[at++] = make_uint4(rel, 0x100u | off, hi, nxt);
+            }
+            qn += total;
+            if (qn >= (uint32_t)kQueueCap) drain();
+            return;
+        }
+        for (uint32_t base = 0; base < total; base += 64) {   // adversarial input: repeats
             while (pm && idx < base + 64) {
                 const uint32_t off = __ffs(pm) - 1;
                 pm &= pm - 1;
@@ -319,23 +356,26 @@ __global__ __launch_bounds__(64 * kPairWaves) void k_dense_pair(const uint8_t* _
     // Queue the survivors of TWO consecutive rows of this wave: ca belongs to the row whose lane chunk starts at
     // rel_a (relative to base_pos) with window (hia,nxa), cb to the next row.  Usual case: no lane holds two
     // survivors of one row -- one ballot per row gives the queue places, row a first (position order).
-    auto handle = [&](uint32_t ca, uint32_t cb, uint32_t rel_a, uint32_t hia, uint32_t nxa, uint32_t rel_b, uint32_t hib, uint32_t nxb) {
-        const unsigned long long ha = __ballot(ca != 0), hb = __ballot(cb != 0);
+    // (lane 63 only feeds lane 62: its own lookups are dropped from the ballots, on the scalar unit)
+    constexpr unsigned long long kRowLanes = (1ull << kRowChunks) - 1;
+    auto handle = [&](PairSurv ca, PairSurv cb, uint32_t rel_a, uint32_t hia, uint32_t nxa, uint32_t rel_b, uint32_t hib, uint32_t nxb) {
+        const unsigned long long ha = __ballot((ca.e | ca.o) != 0) & kRowLanes, hb = __ballot((cb.e | cb.o) != 0) & kRowLanes;
         if (!(ha | hb)) return;
+        const bool mine_a = (ha >> lane) & 1u, mine_b = (hb >> lane) & 1u;
         const uint32_t na = (uint32_t)__popcll(ha), total = na + (uint32_t)__popcll(hb);
-        if (!__ballot(((ca & (ca - 1)) | (cb & (cb - 1))) != 0) && total <= (uint32_t)kQueueCap) {
+        if (!(__ballot(pair_count(ca) > 1 || pair_count(cb) > 1) & kRowLanes) && total <= (uint32_t)kQueueCap) {
             if (qn + total > (uint32_t)kQueueCap) drain();
-            if (ca) queue[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(ha >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ha, 0u))] =
-                        make_uint4(rel_a, __ffs(ca) - 1, hia, nxa);
-            if (cb) queue[qn + na + __builtin_amdgcn_mbcnt_hi((uint32_t)(hb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hb, 0u))] =
-                        make_uint4(rel_b, __ffs(cb) - 1, hib, nxb);
+            if (mine_a) queue[qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(ha >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ha, 0u))] =
+                            make_uint4(rel_a, pair_single_code(ca), hia, nxa);
+            if (mine_b) queue[qn + na + __builtin_amdgcn_mbcnt_hi((uint32_t)(hb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hb, 0u))] =
+                            make_uint4(rel_b, pair_single_code(cb), hib, nxb);
             qn += total;
             if (qn >= (uint32_t)kQueueCap) drain();
             return;
         }
-        drain();                                          // adversarial input: repeats, more than a queue-full
-        slow_row(ca, rel_a, hia, nxa);
-        slow_row(cb, rel_b, hib, nxb);
+        const PairSurv none = {0u, 0u};
+        push_row(lane < (uint32_t)kRowChunks ? ca : none, rel_a, hia, nxa);
+        push_row(lane < (uint32_t)kRowChunks ? cb : none, rel_b, hib, nxb);
     };
 
     // rows whose 64 chunks lie completely inside the buffer take the vector path
@@ -349,36 +389,34 @@ __global__ __launch_bounds__(64 * kPairWaves) void k_dense_pair(const uint8_t* _
     uint4 raw0 = make_uint4(0, 0, 0, 0), raw1 = raw0;
     if (i < n_fast) raw0 = *reinterpret_cast<const uint4*>(ptr);
     if (i + 1 < n_fast) raw1 = *reinterpret_cast<const uint4*>(ptr + row_bytes);
-    const bool halo_lane = lane >= kRowChunks;                 // lane 63 only feeds lane 62
-    auto body = [&](uint4& raw, uint64_t r, const uint8_t* at, uint32_t& hi, uint32_t& nxt) -> uint32_t {
+    auto body = [&](uint4& raw, uint64_t r, const uint8_t* at, uint32_t& hi, uint32_t& nxt) -> PairSurv {
         hi = pack16(raw);
         // unconditional refill (a branch around the load would force a full vmcnt(0) wait right here):
         // past the last row the wave re-reads its current row, whose value is never used
         raw = *reinterpret_cast<const uint4*>(r + 2 < n_fast ? at + 2 * row_bytes : at);
-        nxt = __shfl_down(hi, 1);
-        const uint32_t c = pair_lookup16(tab, hi, nxt);
-        return halo_lane ? 0u : c;
+        nxt = next_lane(hi);
+        return pair_lookup16(tab, hi, nxt);
     };
     uint32_t rel = lane * kChunk;                              // this lane's chunk of the current row, relative to base_pos
     const uint32_t rel_step = (uint32_t)row_bytes;
     for (; i + 1 < n_fast; i += 2, ptr += 2 * row_bytes, rel += 2 * rel_step) {
         uint32_t hia, nxa, hib, nxb;
-        const uint32_t ca = body(raw0, i, ptr, hia, nxa);
-        const uint32_t cb = body(raw1, i + 1, ptr + row_bytes, hib, nxb);
+        const PairSurv ca = body(raw0, i, ptr, hia, nxa);
+        const PairSurv cb = body(raw1, i + 1, ptr + row_bytes, hib, nxb);
         handle(ca, cb, rel, hia, nxa, rel + rel_step, hib, nxb);
     }
+    const PairSurv no_row = {0u, 0u};
     if (i < n_fast) {
         uint32_t hia, nxa;
-        const uint32_t ca = body(raw0, i, ptr, hia, nxa);
-        handle(ca, 0u, rel, hia, nxa, rel, hia, nxa);
+        const PairSurv ca = body(raw0, i, ptr, hia, nxa);
+        handle(ca, no_row, rel, hia, nxa, rel, hia, nxa);
         ++i; rel += rel_step;
     }
     // the last (at most two) rows of the buffer touch its end: byte-wise loads
     for (; i < n_my; ++i, rel += rel_step) {
         const uint32_t hi = load_pack(bases, n, (first + i) * kRowPosPair63 + (uint64_t)lane * kChunk);
-        const uint32_t nxt = __shfl_down(hi, 1);
-        const uint32_t c = pair_lookup16(tab, hi, nxt);
-        handle(halo_lane ? 0u : c, 0u, rel, hi, nxt, rel, hi, nxt);
+        const uint32_t nxt = next_lane(hi);
+        handle(pair_lookup16(tab, hi, nxt), no_row, rel, hi, nxt, rel, hi, nxt);
     }
     drain();
     if (lane == 0) L.cnt[gw] = out_n;
@@ -1351,10 +1389,12 @@ struct ListPlan { uint32_t grid, n_lists, cap; uint64_t n_rows, rows_per_wave; }
 static int plan_lists(spsp_ctx* ctx, const spsp_params* p, int variant, uint64_t n_bases, ListPlan* P) {
     P->n_rows = (n_bases + kRowPosPair63 - 1) / kRowPosPair63;
     const uint64_t want = (P->n_rows + kPairWaves - 1) / kPairWaves;
-    static const int per_cu = getenv("SPSP_PAIR_BLOCKS_PER_CU") ? atoi(getenv("SPSP_PAIR_BLOCKS_PER_CU")) : 0;  // tuning knob
-    // One 1024-lane workgroup per CU for every variant.  k_dense_pair (80 KiB of LDS) would fit twice, and alone it runs
-    // as fast either way (0.103 vs 0.099 ms: it is limited by VALU issue, not by occupancy); with one, the other half of
-    // the CU's wave slots and LDS stays free for the kernels of other streams (a pipelined step: 0.158 vs 0.185 ms)
+    static const int per_cu_env = getenv("SPSP_PAIR_BLOCKS_PER_CU") ? atoi(getenv("SPSP_PAIR_BLOCKS_PER_CU")) : 0;  // tuning knob
+    // One 1024-lane workgroup per CU unless the caller says its stream owns its CUs (spsp_set_cu_count).  k_dense_pair
+    // (80 KiB of LDS) fits twice, and alone it runs 3-4 % faster that way (more loads in flight); with one, the other
+    // half of the CU's wave slots and LDS stays free for the kernels of other streams that share the CU (a pipelined step
+    // on unpartitioned streams: 0.158 vs 0.185 ms)
+    const int per_cu = per_cu_env > 0 ? per_cu_env : ctx->dense_blocks_per_cu;
     const uint64_t cap_blocks = (uint64_t)ctx->n_cu * (per_cu > 0 ? per_cu : 1);
     P->grid = (uint32_t)(want < cap_blocks ? want : cap_blocks);
     P->n_lists = P->grid * kPairWaves;
