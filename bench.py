@@ -314,8 +314,14 @@ def main():
     # the roofline needs the dense kernel's duration from HIP events in the timed region; the other brackets
     # (whole pipelines, accumulate kernel) are extra packets on the streams and are only recorded on request
     kinds = sp.TIME_ALL if os.environ.get("BENCH_STAGE_TIMING", "0") == "1" or not pipelined else sp.TIME_DENSE
+    if os.environ.get("BENCH_STAGE_TIMING") == "off":     # experiment: what the event packets themselves cost
+        kinds = 0
+    # every 8th dense pass is bracketed: two event packets per launch cost the pipelined step 8.6 us of 123 (measured,
+    # BENCH_STAGE_TIMING=off); BENCH_TIMING_EVERY=1 brackets them all
+    timing_every = int(os.environ.get("BENCH_TIMING_EVERY", "8")) if pipelined and kinds == sp.TIME_DENSE else 1
     for c in all_ctx:
         c.timing_enable(True, kinds)
+        c.timing_sample(timing_every)
         c.timing_read()
     fence()
     host["queue"] = host["collect"] = 0.0
@@ -330,6 +336,7 @@ def main():
     for c in all_ctx:                                     # HIP-event logs of all contexts, summed
         t = c.timing_read()
         c.timing_enable(False)
+        c.timing_sample(1)
         if tm is None:
             tm = dict(t)
         else:
@@ -414,6 +421,7 @@ def main():
                                    else pairs_per_step * args.steps / elapsed),
             "sketch_pairs_per_s_basis": "compare pipeline (HIP events)" if compare_avg_ms > 0 else "whole step (scan + all-vs-all)",
             "stage_ms": {"scan_pipeline": scan_ms / tm["scan_calls"] if tm["scan_calls"] else None, "dense_kernel": dense_avg_ms,
+                         "dense_launches_timed": int(tm["dense_launches"]), "dense_launches": args.steps,
                          "compare_pipeline": compare_avg_ms if tm["compare_calls"] else None,
                          "accumulate_kernel": acc_ms / tm["accumulate_launches"] if tm["accumulate_launches"] else None},
             "superkmers_per_step": int(n_out), "inter_nonzero": inter_nonzero,

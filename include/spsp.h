@@ -129,6 +129,9 @@ typedef struct spsp_timing {
 #define SPSP_TIME_PARTS 16 /* scatter + group kernels */
 #define SPSP_TIME_ALL 31
 int spsp_timing_enable(spsp_ctx* ctx, int kinds);
+/* bracket only every `every`-th region of each kind (1 = all): the two event packets of a bracket cost a pipelined
+ * stream ~4 us each (bench.py: 8.6 us of a 0.123 ms step with every dense pass bracketed) */
+int spsp_timing_sample(spsp_ctx* ctx, uint32_t every);
 /* synchronises the stream, returns the totals since the previous read and resets them */
 int spsp_timing_read(spsp_ctx* ctx, spsp_timing* out);
 

@@ -69,7 +69,7 @@ SUPERKMER_DTYPE = np.dtype([("rec", "<u4"), ("minimizer", "<u4"), ("start", "<u8
 ABI_SYMBOLS = [
     "spsp_create", "spsp_destroy", "spsp_last_error", "spsp_version", "spsp_free", "spsp_copy_to_host",
     "spsp_stream_create_cus", "spsp_stream_destroy", "spsp_set_cu_count",
-    "spsp_timing_enable", "spsp_timing_read", "spsp_threshold_host", "spsp_scan", "spsp_scan_device", "spsp_scan_device_begin", "spsp_scan_device_end", "spsp_scan_tail_stream", "spsp_wait_dense", "spsp_wait_stream", "spsp_scan_hits_device", "spsp_count_superkmers_device", "spsp_compare",
+    "spsp_timing_enable", "spsp_timing_sample", "spsp_timing_read", "spsp_threshold_host", "spsp_scan", "spsp_scan_device", "spsp_scan_device_begin", "spsp_scan_device_end", "spsp_scan_tail_stream", "spsp_wait_dense", "spsp_wait_stream", "spsp_scan_hits_device", "spsp_count_superkmers_device", "spsp_compare",
     "spsp_compare_device", "spsp_slot_bytes", "spsp_partition_keys_device", "spsp_compare_slots_device", "spsp_compare_device_begin", "spsp_compare_slots_device_begin", "spsp_compare_end", "spsp_fasta_clean_host", "spsp_fasta_clean_device", "spsp_sketch_text", "spsp_sketch_build_host", "spsp_sketch_parse_host", "spsp_sketch_decode_device", "spsp_sketch_chain_host",
     "spsp_csv_host", "spsp_sort_csv_host", "spsp_read_file_host", "spsp_write_gz_host", "spsp_sketch_file", "spsp_compare_files", "spsp_compare_files_chatty", "spsp_stage_times_read",
 ]
@@ -98,6 +98,7 @@ def lib():
     L.spsp_set_cu_count.restype = i32; L.spsp_set_cu_count.argtypes = [vp, u32, u32]
     L.spsp_timing_enable.restype = i32; L.spsp_timing_enable.argtypes = [vp, i32]
     L.spsp_timing_read.restype = i32; L.spsp_timing_read.argtypes = [vp, P(Timing)]
+    L.spsp_timing_sample.restype = i32; L.spsp_timing_sample.argtypes = [vp, u32]
     L.spsp_threshold_host.restype = u64; L.spsp_threshold_host.argtypes = [u32, u32, dbl]
     L.spsp_scan.restype = i32; L.spsp_scan.argtypes = [vp, P(Params), vp, vp, u32, P(vp), P(u64)]
     L.spsp_scan_device.restype = i32
@@ -323,6 +324,10 @@ class Context:
     def timing_enable(self, on=True, kinds=TIME_ALL):
         """HIP-event brackets for the regions in `kinds` (TIME_DENSE | TIME_SCAN | TIME_ACCUMULATE | TIME_COMPARE)"""
         _check(lib().spsp_timing_enable(self._h, int(kinds) if on else 0))
+
+    def timing_sample(self, every):
+        """bracket only every `every`-th region (the event packets themselves delay a pipelined stream)"""
+        _check(lib().spsp_timing_sample(self._h, every))
 
     def timing_read(self):
         """HIP-event totals since the last read (synchronises the stream) as a dict."""

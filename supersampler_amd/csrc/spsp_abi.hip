@@ -48,6 +48,7 @@ using namespace spsp;
 
 int spsp_ctx::ev_begin(int kind) {
     if (!(timing_mask & (1u << kind))) return SPSP_OK;   // (scatter and group share one bit)
+    if (timing_every > 1 && (ev_seq[kind]++ % timing_every) != 0) { ev_open[kind] = false; return SPSP_OK; }   // sampled: spsp_timing_sample
     EventLog& L = evlog[kind];
     std::pair<hipEvent_t, hipEvent_t> ev;
     if (!L.spare.empty()) { ev = L.spare.back(); L.spare.pop_back(); }
@@ -74,6 +75,13 @@ int spsp_timing_enable(spsp_ctx* ctx, int on) {
     ctx->timing_mask = (uint32_t)on & 15u;
     if (on & SPSP_TIME_PARTS) ctx->timing_mask |= (1u << kEvScatter) | (1u << kEvGroup);
     ctx->timing = ctx->timing_mask != 0;
+    return SPSP_OK;
+}
+
+int spsp_timing_sample(spsp_ctx* ctx, uint32_t every) {
+    if (!ctx) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    ctx->timing_every = every ? every : 1;
+    for (int kind = 0; kind < kEvKinds; ++kind) ctx->ev_seq[kind] = 0;
     return SPSP_OK;
 }
 

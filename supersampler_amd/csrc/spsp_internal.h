@@ -79,6 +79,8 @@ struct spsp_ctx {
     int ev_begin(int kind);
     int ev_end(int kind);
     bool ev_open[spsp::kEvKinds] = {};   // a begin without its end is outstanding
+    uint32_t timing_every = 1;           // spsp_timing_sample: every n-th region of a kind is bracketed
+    uint32_t ev_seq[spsp::kEvKinds] = {};
     spsp_stage_times stages{};    // whole-file drivers: wall seconds per stage (spsp_stage_times_read)
     int device = 0;
     int n_cu = 256;          // compute units this context's stream may use (spsp_set_cu_count)

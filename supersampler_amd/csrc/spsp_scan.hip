@@ -1474,10 +1474,11 @@ static int launch_dense(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_ba
                            p->threshold, n_tiles, ctx->bitmap.as<uint32_t>(), ctx->tile_count.as<uint32_t>());
     }
     SPSP_HIP(hipGetLastError());
+    const bool timed = ctx->ev_open[kEvDense];            // (a sampled-out launch has no bracket: spsp_timing_sample)
     if ((rc = ctx->ev_end(kEvDense))) return rc;
     // spsp_wait_dense: other streams may start behind the dense pass.  Every event recorded here is a packet the
     // sparse stages queue behind, so with timing on the timing end-event doubles as the marker.
-    if (ctx->timing_mask & (1u << kEvDense)) {
+    if (timed) {
         ctx->dense_marker = ctx->evlog[kEvDense].used.back().second;
     } else {
         if (!ctx->dense_done) SPSP_HIP(hipEventCreateWithFlags(&ctx->dense_done, hipEventDisableTiming));
