@@ -135,12 +135,18 @@ def main():
             sl.scan = ctx if i == 0 else sp.Context(local_rank, sl.stream_a.cuda_stream)
             if schedule == "partition":
                 sl.scan.set_cu_count(n_dev_cus - small_cus, 2)
-                if i == 0 or os.environ.get("BENCH_SMALL_STREAMS", "shared") != "shared":
+                mode = os.environ.get("BENCH_SMALL_STREAMS", "shared")
+                if i == 0 or mode == "own":
                     # one stream for every slot's sparse stages and one for every comparison by default: every CU-masked
                     # stream is a hardware queue of its own, and a handful of them already delay each other's packets
+                    # ("own": a pair per slot; "cmp": one for the sparse stages, one per slot for the comparisons)
                     masked += [sp.stream_create_cus(local_rank, 0, small_cus), sp.stream_create_cus(local_rank, 0, small_cus)]
+                    tail_h = masked[-2]
                     small_b = torch.cuda.ExternalStream(masked[-1], device=dev)
-                sl.scan.scan_tail_stream(True, masked[-2])
+                elif mode == "cmp":
+                    masked += [sp.stream_create_cus(local_rank, 0, small_cus)]
+                    small_b = torch.cuda.ExternalStream(masked[-1], device=dev)
+                sl.scan.scan_tail_stream(True, tail_h)
                 sl.stream_b = small_b
             else:
                 if tail_streams:
@@ -218,6 +224,10 @@ def main():
 
     scan_args = (p, d_bases.data_ptr(), d_bases.numel(), d_off.data_ptr(), len(recs))
 
+    # analysis only (the line it prints is not a valid measurement): the step without its comparison, to see what the
+    # comparison's kernels cost the dense pass they run beside
+    skip_compare = os.environ.get("BENCH_DEBUG_SKIP_COMPARE") == "1" and exchange_kind == "none"
+
     def queue_step(sl, prev, nxt=None):
         """queue one whole step on slot sl without waiting for anything; on the GPU its dense pass starts behind
         the dense pass of slot prev.  nxt = the slot of the following step (slots exchange: its key partition is
@@ -228,8 +238,9 @@ def main():
         if exchange_kind == "none":
             if schedule != "partition":
                 sl.cmp.wait_dense(sl.scan)                # the comparison starts behind this step's dense pass
-            sl.cmp.compare_device_begin(K, d_all_min.data_ptr(), d_all_lo.data_ptr(), None, sk_off, n_total, rank, world,
-                                        sl.d_inter.data_ptr())                                             # stream B
+            if not skip_compare:
+                sl.cmp.compare_device_begin(K, d_all_min.data_ptr(), d_all_lo.data_ptr(), None, sk_off, n_total, rank, world,
+                                            sl.d_inter.data_ptr())                                         # stream B
             return
         with torch.cuda.stream(sl.stream_b):              # torch ops and RCCL order themselves against stream B
             if exchange_kind == "slots":
@@ -257,7 +268,8 @@ def main():
             with torch.cuda.stream(sl.stream_b):
                 sl.exchange.end_collect(sl.d_inter)       # partial pair matrix done -> RCCL reduction
         else:
-            sl.cmp.compare_end()
+            if not skip_compare:
+                sl.cmp.compare_end()
             if exchange_kind == "gather":
                 sl.exchange.collect_rows(sl.d_inter)      # strips -> rank 0, on stream B
         last["n_out"], last["slot"] = n_out, sl
