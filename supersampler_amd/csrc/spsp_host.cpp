@@ -92,6 +92,8 @@ struct KmerIndex {
     }
 };
 
+constexpr uint32_t kPlaceholder = 0xffffffffu;   // `order` entry of a k-mer the device abundance pass dropped
+
 struct Builder {
     uint32_t k, m, abundance;
     u128 kmask;
@@ -101,8 +103,11 @@ struct Builder {
     std::vector<std::pair<uint32_t, uint32_t>> order;  // (minimizer, entry index) in insertion order
     spsp_sketch_stats st;
 
-    // Subsampler::handle_superkmer (SubSampler.cpp:243-302) on 2-bit codes.
-    void add_superkmer(const uint8_t* s, uint32_t len, uint32_t minimizer, bool rev) {
+    // Subsampler::handle_superkmer (SubSampler.cpp:243-302) on 2-bit codes.  fl (optional): the device abundance
+    // pass's verdict per k-mer of this super-k-mer (spsp_abund.hip) -- a k-mer that will stay below -a is not indexed;
+    // the first occurrence of each such k-mer leaves a placeholder, which is what the reference keeps of it (a map
+    // entry that is counted, makes its bucket exist and is never usable)
+    void add_superkmer(const uint8_t* s, uint32_t len, uint32_t minimizer, bool rev, const uint8_t* fl = nullptr) {
         st.selected_superkmer_number++;
         st.selected_kmer_number += len - k + 1;
         if (len == 2 * k - m) st.count_maximal_skmer++;
@@ -124,6 +129,10 @@ struct Builder {
             kv = ((kv << 2) | o[t]) & kmask;
             if (t + 1 < k) continue;
             const uint32_t i = t + 1 - k;  // k-mer start
+            if (fl && !(fl[i] & 1u)) {
+                if (fl[i] & 2u) order.emplace_back(minimizer, kPlaceholder);
+                continue;
+            }
             while (oc < occ.size() && occ[oc] < i) ++oc;
             // kmerstr.find(minimizer) : first occurrence inside the k-mer, else npos -> (uint8_t)
             const uint8_t pos_min = (oc < occ.size() && occ[oc] + m <= i + k) ? (uint8_t)(occ[oc] - i) : (uint8_t)0xff;
@@ -173,7 +182,7 @@ struct Builder {
             maxcodes.clear(); text.clear();
             size_t cursor = b0;  // find_first_kmer: `seen` only ever turns on, so a cursor visits the same k-mers
             for (;;) {
-                while (cursor < b1 && !usable(entries[order[cursor].second])) ++cursor;
+                while (cursor < b1 && (order[cursor].second == kPlaceholder || !usable(entries[order[cursor].second]))) ++cursor;
                 if (cursor >= b1) break;
                 Entry& start = entries[order[cursor].second];
                 start.seen = 1;
@@ -288,7 +297,7 @@ namespace spsp {
 // ingest ran on the GPU, from a compact buffer holding only the selected super-k-mers (compact + compact_off[i]).
 int sketch_build_core(const spsp_params* p, double rate, const uint64_t* rec_off, uint32_t n_rec, const spsp_superkmer* sk,
                       uint64_t n_sk, const uint8_t* bases, const uint8_t* compact, const uint32_t* compact_off,
-                      uint8_t** payload, uint64_t* payload_len, spsp_sketch_stats* stats) {
+                      uint8_t** payload, uint64_t* payload_len, spsp_sketch_stats* stats, const uint8_t* kmer_flags) {
     int rc = check_params(p);
     if (rc) return rc;
     if (!payload || !payload_len || (n_rec && !rec_off) || (n_sk && (!sk || (!bases && !(compact && compact_off))))) {
@@ -301,7 +310,7 @@ int sketch_build_core(const spsp_params* p, double rate, const uint64_t* rec_off
     b.mmask = (1u << (2 * p->m)) - 1;
     memset(&b.st, 0, sizeof b.st);
     b.index.init(1024);
-    uint64_t nb = 0, pos_end = 0;
+    uint64_t nb = 0, pos_end = 0, occ = 0;                // occ: k-mer occurrences so far (numbering of kmer_flags)
     uint32_t cur_rec = 0xffffffffu;
     for (uint32_t r = 0; r < n_rec; ++r) {
         const uint64_t len = rec_off[r + 1] - rec_off[r];
@@ -326,7 +335,8 @@ int sketch_build_core(const spsp_params* p, double rate, const uint64_t* rec_off
             pos_end = e.start + e.len - 1;
         }
         const uint8_t* src = compact ? compact + compact_off[i] : bases + rec_off[e.rec] + e.start;
-        b.add_superkmer(src, e.len, e.minimizer, e.rev != 0);
+        b.add_superkmer(src, e.len, e.minimizer, e.rev != 0, kmer_flags ? kmer_flags + occ : nullptr);
+        occ += e.len - p->k + 1;
     }
     nb -= p->m - 1;  // SubSampler.cpp:458
     b.st.nb_mmer_selected = nb;
@@ -462,7 +472,7 @@ int spsp_sketch_build_host(const spsp_params* p, double rate, const uint8_t* bas
                            uint32_t n_rec, const spsp_superkmer* sk, uint64_t n_sk, uint8_t** payload,
                            uint64_t* payload_len, spsp_sketch_stats* stats) {
     if (n_sk && !bases) { set_error("NULL argument"); return SPSP_ERR_ARG; }
-    return spsp::sketch_build_core(p, rate, rec_off, n_rec, sk, n_sk, bases, nullptr, nullptr, payload, payload_len, stats);
+    return spsp::sketch_build_core(p, rate, rec_off, n_rec, sk, n_sk, bases, nullptr, nullptr, payload, payload_len, stats, nullptr);
 }
 
 int spsp_sketch_parse_host(const uint8_t* payload, uint64_t len, uint32_t* k_out, uint32_t* m_out,

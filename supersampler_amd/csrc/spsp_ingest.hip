@@ -461,8 +461,18 @@ int spsp_sketch_text(spsp_ctx* ctx, const spsp_params* p, double rate, const cha
     if (n_sk) SPSP_HIP(hipMemcpyAsync(sk.data(), d_sk, (size_t)n_sk * sizeof(spsp_superkmer), hipMemcpyDeviceToHost, ctx->stream));
     uint8_t* compact = nullptr; uint32_t* coff = nullptr;
     if ((rc = gather_superkmers_impl(ctx, d_bases, d_off, d_sk, n_sk, &compact, &coff))) return rc;   // synchronises the stream
+    // -a > 1: the k-mers are counted here, over the gathered super-k-mers still on the device, and the host builder
+    // indexes the usable ones only (SPSP_HOST_ABUNDANCE=1 leaves the counting to the builder, as round 1 did)
+    uint8_t* kflags = nullptr; uint64_t n_occ = 0;
+    static const bool host_abundance = getenv("SPSP_HOST_ABUNDANCE") != nullptr;
+    if (p->abundance > 1 && !host_abundance) {
+        rc = abundance_flags_impl(ctx, p, d_sk, n_sk, &kflags, &n_occ);
+        if (rc == SPSP_ERR_OVERFLOW) { rc = SPSP_OK; kflags = nullptr; }   // too many occurrences for 32-bit numbering: the host counts
+        if (rc) { free(compact); free(coff); return rc; }
+    }
     t1 = now_s(); ctx->stages.gather_s += t1 - t0; t0 = t1;
-    rc = sketch_build_core(p, rate, rec_off.data(), n_rec, sk.data(), n_sk, nullptr, compact, coff, payload, payload_len, stats);
+    rc = sketch_build_core(p, rate, rec_off.data(), n_rec, sk.data(), n_sk, nullptr, compact, coff, payload, payload_len, stats, kflags);
+    free(kflags);
     ctx->stages.build_s += now_s() - t0;
     if (!rc && stats && (p->flags & SPSP_SCAN_STATS)) {   // print_stat's counters over ALL super-k-mers (SubSampler.cpp:429-430,451-452)
         t0 = now_s();

@@ -130,6 +130,7 @@ struct spsp_ctx {
     spsp::DevBuf c_min, c_lo, c_hi, c_table, c_owner, c_rowid, c_row, c_matrix, c_inter, c_flags, c_skoff, c_slot_lo, c_slot_hi, c_slot_mn, c_part_cnt, c_recs;
     spsp::DevBuf x_cnt, x_off, x_begin, x_end, x_tot;   // key-partitioned exchange (spsp_compare.hip)
     spsp::DevBuf dc_text, dc_desc, dc_mn, dc_lo, dc_hi, dc_meta;   // bulk sketch decode (spsp_decode.hip)
+    spsp::DevBuf a_cnt, a_off, a_mn, a_lo, a_hi, a_slot, a_slot_of, a_flags;   // -a abundance pass (spsp_abund.hip)
 };
 
 namespace spsp {
@@ -185,7 +186,9 @@ int gather_superkmers_impl(spsp_ctx* ctx, const uint8_t* d_bases, const uint64_t
 // out[i] = sum(in[0..i)), out[n] = total (also stored to *total_host, pinned)
 int launch_scan_u32(spsp_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, uint64_t n, uint64_t* total_host);
 // host sketch builder over per-super-k-mer base pointers (spsp_host.cpp)
+// -a on the device (spsp_abund.hip): per k-mer occurrence of the gathered super-k-mers, bit 0 usable, bit 1 first of a dropped k-mer
+int abundance_flags_impl(spsp_ctx* ctx, const spsp_params* p, const spsp_superkmer* d_sk, uint64_t n_sk, uint8_t** h_flags, uint64_t* n_occ);
 int sketch_build_core(const spsp_params* p, double rate, const uint64_t* rec_off, uint32_t n_rec, const spsp_superkmer* sk,
                       uint64_t n_sk, const uint8_t* bases, const uint8_t* compact, const uint32_t* compact_off,
-                      uint8_t** payload, uint64_t* payload_len, spsp_sketch_stats* stats);
+                      uint8_t** payload, uint64_t* payload_len, spsp_sketch_stats* stats, const uint8_t* kmer_flags);
 }  // namespace spsp

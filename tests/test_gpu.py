@@ -560,6 +560,29 @@ def test_sketch_text_gpu_ingest_equals_oracle(ctx, k, m, s):
         assert gst[f] == wst[f], f
 
 
+@pytest.mark.parametrize("k,m,s,ab", [(31, 11, 20, 2), (31, 11, 1.0, 3), (63, 15, 5, 2), (21, 11, 1.0, 2), (15, 15, 1.0, 2), (33, 13, 3, 300)])
+def test_abundance_filter_on_device_equals_oracle(ctx, k, m, s, ab):
+    """N4: -a > 1 is counted on the GPU (spsp_abund.hip) and the host builder indexes the usable k-mers only.  Segments
+    occur once, twice, three times and (a tandem unit) 256+ times -- the uint8 count wraps (H4) -- on both strands;
+    payload bytes and every statistic the reference prints must equal the oracle's (SubSampler.cpp:243-302,587,608)."""
+    rng = np.random.default_rng(1000 * k + ab)
+    a, b, c = (synth.random_genome(rng, n) for n in (30_000, 20_000, 8_000))
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    unit = synth.random_genome(rng, 70).tobytes()
+    recs = [a.tobytes() + b.tobytes(), b.tobytes()[::-1].translate(comp) + c.tobytes(), c.tobytes() + a.tobytes()[:10_000] + c.tobytes(),
+            unit * 257 + unit[:50], synth.random_genome(rng, 5_000).tobytes()]
+    text = b"".join(b">r%d\n%s\n" % (i, r) for i, r in enumerate(recs))
+    got, gst = ctx.sketch_text(text, k, m, s, abundance=ab)
+    want, wst = orc.sketch_fasta(text, k, m, s, ab)
+    assert got == want
+    for f in ("selected_kmer_number", "selected_superkmer_number", "count_maximal_skmer", "seen_kmers_at_reconstruction",
+              "seen_superkmers_at_reconstruction", "seen_max_superkmers_at_reconstruction", "actual_minimizer_number",
+              "read_kmer", "nb_mmer_selected"):
+        assert gst[f] == wst[f], f
+    if ab < 300 and k != m:   # (k == m: a bucket is its minimizer, nothing else is written either way)
+        assert 0 < wst["seen_superkmers_at_reconstruction"] and len(want) < len(orc.sketch_fasta(text, k, m, s, 1)[0])
+
+
 def test_scan_buffer_overflow_retries():
     """the sparse stages are launched with capacity-sized buffers; a call that overflows them
     re-runs with room (hits: from the dense pass, super-k-mers: the write pass only)."""
