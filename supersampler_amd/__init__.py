@@ -15,7 +15,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libspsp.so")
+LIB_PATH = os.environ.get("SPSP_LIB") or os.path.join(_HERE, "libspsp.so")   # (SPSP_LIB: A/B experiments with another build)
 
 SPSP_SCAN_DEFAULT = 0
 SPSP_SCAN_DIRECT_HASH = 1

@@ -229,6 +229,7 @@ constexpr uint32_t kRefOffBits = 26, kRefOffMask = (1u << kRefOffBits) - 1, kRef
 __host__ __device__ __forceinline__ uint32_t list_u16(uint32_t len) { return (len + 1 + 7) & ~7u; }
 __device__ __forceinline__ uint32_t list_ref(uint32_t o, uint32_t len) { return (o >> 3) | ((len < kRefLenMax ? len : kRefLenMax) << kRefOffBits); }
 constexpr uint32_t kNoList = 0xffffffffu;       // the key takes part in no pair of this job
+constexpr uint32_t kNoWhere = 0xffffffffu;      // partition form: the key's record did not fit its part (the call is redone)
 
 __global__ void k_insert_sparse(Keys K, const uint64_t* __restrict__ sk_off, uint64_t seed, uint64_t* __restrict__ table,
                                 uint32_t log2cap, uint32_t* __restrict__ cnt, SlotKeys SK, uint32_t* __restrict__ slot_of_entry,
@@ -317,8 +318,9 @@ constexpr int kFlags = 8;   // [0] unsorted input, [1] fingerprint collision, [2
 // same few sketches over and over, and 64 lanes adding to ONE LDS word serialise -- with a copy per lane
 // group the same column is spread over `copies` banks.  A thread takes kAccU keys at a time: the list
 // references are one coalesced load and the lists' first words are issued together.
-constexpr int kSparseThreads = 1024, kAccU = 2, kAccW = 4;
+constexpr int kSparseThreads = 1024, kAccU = 2, kAccW = 4, kAccR = 2;
 __global__ __launch_bounds__(kSparseThreads) void k_accumulate_sparse(const uint32_t* __restrict__ list_of_entry,
+                                                                     const uint32_t* __restrict__ where,
                                                                      const uint16_t* __restrict__ ids,
                                                                      const uint64_t* __restrict__ sk_begin,
                                                                      const uint64_t* __restrict__ sk_end, uint32_t n,
@@ -343,10 +345,25 @@ __global__ __launch_bounds__(kSparseThreads) void k_accumulate_sparse(const uint
     for (uint32_t x = threadIdx.x; x < (cols << copies_log2); x += kSparseThreads) s_cnt[x] = 0;
     __syncthreads();
     auto count = [&](uint32_t jj) { if (jj > i && jj - col0 < cols) atomicAdd(&s_cnt[((jj - col0) << copies_log2) + mine], 1u); };
-    for (uint64_t e = e0 + threadIdx.x; e < e1 + (kAccU - 1) * (uint64_t)kSparseThreads; e += (uint64_t)kAccU * kSparseThreads) {
+    // kAccR list references are fetched together (the partition form reaches them through `where`: two dependent
+    // loads, the second scattered -- eight of each in flight per thread hide the extra hop), then the lists kAccU at a time
+    for (uint64_t e = e0 + threadIdx.x; e < e1; e += (uint64_t)kAccR * kSparseThreads) {
+        uint32_t refs[kAccR];
+        if (where) {                                         // the reference sits where the key's record went
+            uint32_t at[kAccR];
+#pragma unroll
+            for (int r = 0; r < kAccR; ++r) { const uint64_t eu = e + (uint64_t)r * kSparseThreads; at[r] = eu < e1 ? where[eu] : kNoWhere; }
+#pragma unroll
+            for (int r = 0; r < kAccR; ++r) refs[r] = at[r] != kNoWhere ? list_of_entry[at[r]] : kNoList;
+        } else {
+#pragma unroll
+            for (int r = 0; r < kAccR; ++r) { const uint64_t eu = e + (uint64_t)r * kSparseThreads; refs[r] = eu < e1 ? list_of_entry[eu] : kNoList; }
+        }
+#pragma unroll
+        for (int g = 0; g < kAccR; g += kAccU) {
         uint32_t ref[kAccU];
 #pragma unroll
-        for (int u = 0; u < kAccU; ++u) { const uint64_t eu = e + (uint64_t)u * kSparseThreads; ref[u] = eu < e1 ? list_of_entry[eu] : kNoList; }
+        for (int u = 0; u < kAccU; ++u) ref[u] = refs[g + u];
         // the first kAccW 16-byte words of each list (length + 31 ids) are requested together; longer lists loop
         uint4 w[kAccU][kAccW];
 #pragma unroll
@@ -375,6 +392,7 @@ __global__ __launch_bounds__(kSparseThreads) void k_accumulate_sparse(const uint
 #pragma unroll
             for (int q = 0; q < kAccW; ++q) if (q == 0 || len >= 8u * q) word(w[u][q], 8u * q);
             for (uint32_t q = kAccW; 8 * q <= len; ++q) word(L[q], 8 * q);
+        }
         }
     }
     __syncthreads();
@@ -441,8 +459,8 @@ template <bool HAS_HI, int E>
 __global__ __launch_bounds__(kScatThreads, 4) void k_parts_scatter(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n,
                                                                const uint32_t* __restrict__ sub_sk, uint64_t S, uint32_t n_parts,
                                                                uint32_t* __restrict__ part_cnt, uint64_t* __restrict__ recs,
-                                                               uint32_t* __restrict__ flags) {
-    constexpr uint32_t W = HAS_HI ? 4 : 3;
+                                                               uint32_t* __restrict__ where, uint32_t* __restrict__ flags) {
+    constexpr uint32_t W = HAS_HI ? 3 : 2;
     extern __shared__ uint32_t hist[];                   // [n_parts]
     const uint32_t t = threadIdx.x, lane = t & 63;
     const uint64_t base = (uint64_t)blockIdx.x * E * kScatThreads;
@@ -496,12 +514,13 @@ __global__ __launch_bounds__(kScatThreads, 4) void k_parts_scatter(Keys K, const
         if (e >= S) continue;
         const uint32_t j = sk_of[u];
         const uint32_t part = pr[u] & 0x7fffu, at = hist[part] + (pr[u] >> 15);
+        // where the record goes, in entry order (coalesced): the row sums find the key's list through it, so the
+        // record need not carry its entry number and k_parts_group need not scatter one word per key back
+        where[e] = at < (uint32_t)kPartCap ? part * (uint32_t)kPartCap + at : kNoWhere;
         if (at >= (uint32_t)kPartCap) continue;          // overflow: k_parts_group sees the count and raises the flag
         uint64_t* r = recs + ((uint64_t)part * kPartCap + at) * W;
-        r[0] = lo[u];
-        r[1] = (uint64_t)mn[u] | ((uint64_t)j << 32);
-        r[2] = e;
-        if (HAS_HI) r[3] = hi[u];
+        if (HAS_HI) { r[0] = lo[u]; r[1] = (uint64_t)mn[u] | ((uint64_t)j << 32); r[2] = hi[u]; }
+        else *reinterpret_cast<ulonglong2*>(r) = make_ulonglong2(lo[u], (uint64_t)mn[u] | ((uint64_t)j << 32));   // one 16-byte store
     }
 }
 
@@ -512,9 +531,9 @@ __global__ __launch_bounds__(kScatThreads, 4) void k_parts_scatter(Keys K, const
 // every record writes its sketch id and its list reference.  80 KiB of LDS: two workgroups per CU.
 template <bool HAS_HI>
 __global__ __launch_bounds__(kGroupThreads) void k_parts_group(const uint64_t* __restrict__ recs, const uint32_t* __restrict__ part_cnt,
-                                                              uint16_t* __restrict__ ids, uint32_t* __restrict__ list_of_entry,
+                                                              uint16_t* __restrict__ ids, uint32_t* __restrict__ list_of_slot,
                                                               uint32_t* __restrict__ flags) {
-    constexpr uint32_t W = HAS_HI ? 4 : 3;
+    constexpr uint32_t W = HAS_HI ? 3 : 2;
     constexpr uint32_t R = kPartCap / kGroupThreads;      // records per thread
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_g[];
     uint64_t* k_lo = reinterpret_cast<uint64_t*>(lds_g);                                  // [kPartCap]
@@ -529,16 +548,15 @@ __global__ __launch_bounds__(kGroupThreads) void k_parts_group(const uint64_t* _
     if (t == 0) *cursor = 0;
     const uint64_t* base = recs + (uint64_t)p * kPartCap * W;
     uint64_t lo[R], hi[R];
-    uint32_t mn[R], sk[R], en[R], hs[R], rank[R];
+    uint32_t mn[R], sk[R], hs[R], rank[R];
 #pragma unroll
     for (uint32_t u = 0; u < R; ++u) {
         const uint32_t r = u * kGroupThreads + t;
-        hs[u] = 0; lo[u] = 0; hi[u] = 0; mn[u] = 0; sk[u] = 0; en[u] = 0; rank[u] = 0;
+        hs[u] = 0; lo[u] = 0; hi[u] = 0; mn[u] = 0; sk[u] = 0; rank[u] = 0;
         {   // loaded whether or not the record exists (the slice is allocated in full): no wait for the count first
-            lo[u] = base[(uint64_t)r * W];
-            const uint64_t w1 = base[(uint64_t)r * W + 1];
-            en[u] = (uint32_t)base[(uint64_t)r * W + 2];
-            hi[u] = HAS_HI ? base[(uint64_t)r * W + 3] : 0ull;
+            uint64_t w1;
+            if (HAS_HI) { lo[u] = base[(uint64_t)r * W]; w1 = base[(uint64_t)r * W + 1]; hi[u] = base[(uint64_t)r * W + 2]; }
+            else { const ulonglong2 v = reinterpret_cast<const ulonglong2*>(base)[r]; lo[u] = v.x; w1 = v.y; hi[u] = 0ull; }
             mn[u] = (uint32_t)w1; sk[u] = (uint32_t)(w1 >> 32);
             k_lo[r] = lo[u]; k_mn[r] = mn[u];
             if (HAS_HI) k_hi[r] = hi[u];
@@ -586,10 +604,11 @@ __global__ __launch_bounds__(kGroupThreads) void k_parts_group(const uint64_t* _
     for (uint32_t u = 0; u < R; ++u) {
         const uint32_t r = u * kGroupThreads + t;
         if (r >= n) continue;
-        if (cnt[u] < 2) { list_of_entry[en[u]] = kNoList; continue; }    // held by one sketch: no pair to count
+        uint32_t* out = list_of_slot + (size_t)p * kPartCap + r;         // record order: coalesced
+        if (cnt[u] < 2) { *out = kNoList; continue; }                    // held by one sketch: no pair to count
         const uint32_t o = slot[hs[u]];
         ids[o + 1 + rank[u]] = (uint16_t)sk[u];
-        list_of_entry[en[u]] = list_ref(o, cnt[u]);
+        *out = list_ref(o, cnt[u]);
     }
 }
 
@@ -692,6 +711,8 @@ struct ComparePlan {
     uint32_t n, n_own, row_first, row_stride, row_limit;
     const uint64_t *sk_begin, *sk_end;   // device: entry range of sketch i
     uint32_t* d_inter;
+    const uint32_t* list_ref = nullptr;  // list reference per entry -- or per record slot, with `where` = slot of every entry
+    const uint32_t* where = nullptr;
 };
 struct CompareJob {
     ComparePlan P;
@@ -745,7 +766,7 @@ static int launch_accumulate_sparse(spsp_ctx* ctx, const ComparePlan& P, uint32_
     while (copies_log2 < 4 && ((size_t)cols << (copies_log2 + 1)) * 4 <= (size_t)kSparseCols * 4) ++copies_log2;
     hipLaunchKernelGGL(k_accumulate_sparse, dim3((P.n + cols - 1) / cols, P.n_own, split), dim3(kSparseThreads),
                        ((size_t)cols << copies_log2) * 4, ctx->stream,
-                       ctx->c_row.as<uint32_t>(), ctx->c_matrix.as<uint16_t>(), P.sk_begin, P.sk_end,
+                       P.list_ref ? P.list_ref : ctx->c_row.as<uint32_t>(), P.where, ctx->c_matrix.as<uint16_t>(), P.sk_begin, P.sk_end,
                        P.n, P.row_first, P.row_stride, P.row_limit, cols, copies_log2, split, P.d_inter, flags,
                        reinterpret_cast<uint32_t*>(ctx->h_scalar + 8));
     SPSP_HIP(hipGetLastError());
@@ -763,14 +784,18 @@ static int job_parts(spsp_ctx* ctx, CompareJob& J) {
                        ctx->c_skoff.as<uint64_t>(), J.n_skoff, reinterpret_cast<const uint32_t*>(ctx->h_skoff + J.n_skoff),
                        reinterpret_cast<uint32_t*>(ctx->c_skoff.as<uint64_t>() + J.n_skoff), J.n_sub);
     SPSP_HIP(hipGetLastError());
+    // analysis hook (results are wrong with it): leave stages out to see what each costs a kernel of another stream
+    static const int skip = getenv("SPSP_DEBUG_SKIP_STAGES") ? atoi(getenv("SPSP_DEBUG_SKIP_STAGES")) : 0;
     if ((rc = ctx->ev_begin(kEvScatter))) return rc;
-    if ((rc = J.scatter_parts(J.n_parts))) return rc;
+    if (!(skip & 1) && (rc = J.scatter_parts(J.n_parts))) return rc;
     if ((rc = ctx->ev_end(kEvScatter))) return rc;
     if ((rc = ctx->ev_begin(kEvGroup))) return rc;
-    if ((rc = J.group_parts(J.n_parts))) return rc;
+    if (!(skip & 2) && (rc = J.group_parts(J.n_parts))) return rc;
     if ((rc = ctx->ev_end(kEvGroup))) return rc;
     if ((rc = ctx->ev_begin(kEvAccumulate))) return rc;
-    if ((rc = launch_accumulate_sparse(ctx, J.P, flags))) return rc;
+    ComparePlan PP = J.P;
+    PP.list_ref = ctx->c_lref.as<uint32_t>(); PP.where = ctx->c_where.as<uint32_t>();
+    if (!(skip & 4) && (rc = launch_accumulate_sparse(ctx, PP, flags))) return rc;
     if ((rc = ctx->ev_end(kEvAccumulate))) return rc;
     return job_mark_done(ctx);
 }
@@ -1096,8 +1121,10 @@ static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t*
     const uint32_t* sub_sk = reinterpret_cast<const uint32_t*>(sk + n + 1);
     J->n_sub = (uint32_t)((S + kScatSub - 1) / kScatSub);
     J->scatter_parts = [=](uint32_t n_parts) -> int {
-        int r2 = ctx->c_recs.reserve((size_t)n_parts * kPartCap * (has_hi ? 32 : 24));
+        int r2 = ctx->c_recs.reserve((size_t)n_parts * kPartCap * (has_hi ? 24 : 16));
         if (r2) return r2;
+        if ((r2 = ctx->c_where.reserve((size_t)S * 4 + 16))) return r2;
+        if ((r2 = ctx->c_lref.reserve((size_t)n_parts * kPartCap * 4))) return r2;
         const uint32_t per_wg = 4u * kScatThreads;
         const dim3 grid((uint32_t)((S + per_wg - 1) / per_wg));
         const size_t lds = (size_t)n_parts * 4;
@@ -1107,7 +1134,7 @@ static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t*
             ctx->attr_scatter_set = true;
         }
 #define SPSP_SCATTER(HI, E) hipLaunchKernelGGL((k_parts_scatter<HI, E>), grid, dim3(kScatThreads), lds, ctx->stream, K, sk, n, sub_sk, S, \
-                                               n_parts, ctx->c_part_cnt.as<uint32_t>(), ctx->c_recs.as<uint64_t>(), flags)
+                                               n_parts, ctx->c_part_cnt.as<uint32_t>(), ctx->c_recs.as<uint64_t>(), ctx->c_where.as<uint32_t>(), flags)
         if (has_hi) SPSP_SCATTER(true, 4);
         else SPSP_SCATTER(false, 4);
 #undef SPSP_SCATTER
@@ -1122,14 +1149,14 @@ static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t*
                 ctx->attr_group_hi_set = true;
             }
             hipLaunchKernelGGL(k_parts_group<true>, dim3(n_parts), dim3(kGroupThreads), lds, ctx->stream, ctx->c_recs.as<uint64_t>(),
-                               ctx->c_part_cnt.as<uint32_t>(), ctx->c_matrix.as<uint16_t>(), ctx->c_row.as<uint32_t>(), flags);
+                               ctx->c_part_cnt.as<uint32_t>(), ctx->c_matrix.as<uint16_t>(), ctx->c_lref.as<uint32_t>(), flags);
         } else {
             if (!ctx->attr_group_set) {
                 SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_parts_group<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 ctx->attr_group_set = true;
             }
             hipLaunchKernelGGL(k_parts_group<false>, dim3(n_parts), dim3(kGroupThreads), lds, ctx->stream, ctx->c_recs.as<uint64_t>(),
-                               ctx->c_part_cnt.as<uint32_t>(), ctx->c_matrix.as<uint16_t>(), ctx->c_row.as<uint32_t>(), flags);
+                               ctx->c_part_cnt.as<uint32_t>(), ctx->c_matrix.as<uint16_t>(), ctx->c_lref.as<uint32_t>(), flags);
         }
         SPSP_HIP(hipGetLastError());
         return SPSP_OK;
