@@ -21,7 +21,22 @@ __global__ __launch_bounds__(THREADS) void k_load(const uint8_t* __restrict__ ba
     uint64_t row, step, end;
     if (MODE == 0) { const uint64_t per = (n_rows + n_waves - 1) / n_waves; row = gw * per; step = 1; end = row + per < n_rows ? row + per : n_rows; }
     else if (MODE == 1) { row = gw; step = n_waves; end = n_rows; }
-    else { const uint64_t per = (n_rows + gridDim.x - 1) / gridDim.x; row = blockIdx.x * per + wave; step = kWaves; end = blockIdx.x * per + per < n_rows ? blockIdx.x * per + per : n_rows; }
+    else if (MODE == 2) { const uint64_t per = (n_rows + gridDim.x - 1) / gridDim.x; row = blockIdx.x * per + wave; step = kWaves; end = blockIdx.x * per + per < n_rows ? blockIdx.x * per + per : n_rows; }
+    else {   // MODE 3: PAIRS of adjacent rows strided over the grid (depth 2 = the two rows of a pair)
+        uint32_t sink3 = 0;
+        const uint64_t n_pairs = n_rows / 2;
+        const uint8_t* p = bases + gw * 2 * RB + (uint64_t)lane * 16;
+        const uint64_t st = n_waves * 2 * RB;
+        uint4 r0 = make_uint4(0,0,0,0), r1 = r0;
+        if (gw < n_pairs) { r0 = *(const uint4*)p; r1 = *(const uint4*)(p + RB); }
+        for (uint64_t j = gw; j < n_pairs; j += n_waves, p += st) {
+            const uint8_t* nx = j + n_waves < n_pairs ? p + st : p;
+            sink3 ^= pack16(r0); r0 = *(const uint4*)nx;
+            sink3 ^= pack16(r1); r1 = *(const uint4*)(nx + RB);
+        }
+        if (sink3 == 0x12345678) out[0] = sink3;
+        return;
+    }
     const uint64_t stride = step * RB;
     const uint8_t* ptr = bases + row * RB + (uint64_t)lane * 16;
     uint4 raw[DEPTH];
@@ -48,13 +63,21 @@ template <int RB, int MODE, int DEPTH, int THREADS> void run(const uint8_t* base
         float ms; CK(hipEventElapsedTime(&ms, a, b)); if (it) { tot += ms; if (ms < best) best = ms; }
     }
     printf("row %4d B  %-22s depth %d  threads %4d blocks %5d  avg %.4f ms  best %.4f ms  -> %.0f GB/s\n", RB,
-           MODE == 0 ? "contiguous per wave" : MODE == 1 ? "strided over grid" : "contiguous per group", DEPTH, THREADS, blocks, tot / 7, best, n / best / 1e6);
+           MODE == 0 ? "contiguous per wave" : MODE == 1 ? "strided over grid" : MODE == 2 ? "contiguous per group" : "pairs strided over grid", DEPTH, THREADS, blocks, tot / 7, best, n / best / 1e6);
 }
 int main() {
     const uint64_t n = 500000000ull;
     uint8_t* bases; uint32_t* out;
     CK(hipMalloc(&bases, n + 4096)); CK(hipMalloc(&out, 64)); CK(hipMemset(bases, 0x41, n + 4096)); CK(hipMemset(out, 0, 64));
-    for (int blocks : {256, 512}) {
+    for (int blocks : {256, 384, 512}) {
+        run<1008, 3, 2, 1024>(bases, n, out, blocks);
+        run<1008, 1, 2, 1024>(bases, n, out, blocks);
+        run<1008, 0, 2, 1024>(bases, n, out, blocks);
+        run<1008, 3, 2, 1024>(bases, n, out, blocks);
+        run<1008, 1, 2, 1024>(bases, n, out, blocks);
+        run<1008, 0, 2, 1024>(bases, n, out, blocks);
+    }
+    for (int blocks : {256}) {
         run<1008, 0, 2, 1024>(bases, n, out, blocks);
         run<1024, 0, 2, 1024>(bases, n, out, blocks);
         run<1008, 1, 2, 1024>(bases, n, out, blocks);
