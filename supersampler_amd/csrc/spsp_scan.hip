@@ -125,25 +125,28 @@ __global__ __launch_bounds__(kThreads) void k_dense_direct(const uint8_t* __rest
 // here be selected at all?" is memoised in LDS and XXH64 only runs on the rare
 // survivors.  One lookup answers it for TWO adjacent positions:
 //
-//   key table  K8[q]   q = first 8 bases (16 bits) of an m-mer, either strand:
-//                      set iff some m-mer x with that prefix has XXH64(canon(x)) <= T
-//   pair table P[e]    e = 9 consecutive bases (18 bits) -> 2 bits
-//                      bit0 = K8[first 8 bases of e], bit1 = K8[last 8 bases of e]
-//                      (64 KiB in LDS, 4 entries per byte)
+//   key tables    K9[q]   q = first 9 bases (18 bits) of an m-mer, either strand: set iff some m-mer x with that
+//                         prefix has XXH64(canon(x)) <= T;  M9[q] the same for bases 1..9 of x (m >= 10),
+//                         K8[q] for its first 8 bases (m = 9)
+//   pair table    P[e]    e = 9 consecutive bases (18 bits) starting at an even offset of the lane's chunk -> 2 bits
+//                         bit0 = K9[e]: the position AT e;  bit1 = M9[e]: the position IN FRONT of e, whose bases
+//                         1..9 are e (m = 9: K8[last 8 bases of e], the position behind)
+//                         (64 KiB in LDS, 4 entries per byte)
 //
 // A lane owns 16 consecutive positions; its 32-base register window gives the
-// eight 9-base pair keys with one bit-field extract each, so the hot loop is
-// ~5 VALU + 1 ds_read_u8 per TWO positions, with no branch and no hash.
+// 9-base pair keys with one bit-field extract each (eight, nine from m = 10 on: the
+// last position's entry starts in the next lane's chunk), so the hot loop is
+// ~3 VALU + 1 ds_read_u8 per TWO positions, with no branch and no hash (pair_lookup16).
 // Survivors (<1 % of positions when this variant is chosen) go to a per-wave
 // queue in LDS and are hashed 64 at a time with every lane busy.  Waves never
 // synchronise with each other: the 16-base halo comes from the neighbouring
-// lane by a wave shuffle (lane 63 loads its own), hits are rare enough to be
-// published with global atomics into a pre-zeroed bitmap.
+// lane by one DPP move (lane 63 is halo only), verified hits go to the wave's own list.
 constexpr int kPairWaves = 16;              // waves per workgroup (1024 lanes)
 constexpr int kPairTabBytes = 65536;        // 2^18 entries x 2 bits
 constexpr int kQueueCap = 64;               // survivor slots per wave (16 bytes each): 64 KiB table + 16 KiB queues = 80 KiB, two workgroups per CU
 
-__global__ void k_build_key8(uint32_t m, uint64_t thr, uint32_t* __restrict__ key8, uint32_t* __restrict__ key9) {
+__global__ void k_build_key8(uint32_t m, uint64_t thr, uint32_t* __restrict__ key8, uint32_t* __restrict__ key9,
+                             uint32_t* __restrict__ mid9) {
     const uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= (1ull << (2 * m))) return;
     const uint32_t v = (uint32_t)x;
@@ -159,10 +162,15 @@ __global__ void k_build_key8(uint32_t m, uint64_t thr, uint32_t* __restrict__ ke
         atomicOr(&key9[a9 >> 5], 1u << (a9 & 31));
         atomicOr(&key9[b9 >> 5], 1u << (b9 & 31));
     }
+    if (mid9) {                               // m >= 10: bases 1..9 of the m-mer, for the position IN FRONT of a pair
+        const uint32_t am = (v >> (2 * m - 20)) & 0x3ffffu, bm = (rc >> (2 * m - 20)) & 0x3ffffu;
+        atomicOr(&mid9[am >> 5], 1u << (am & 31));
+        atomicOr(&mid9[bm >> 5], 1u << (bm & 31));
+    }
 }
 
 __global__ void k_build_pairtab(const uint32_t* __restrict__ key8, const uint32_t* __restrict__ key9,
-                                uint8_t* __restrict__ tab) {
+                                const uint32_t* __restrict__ mid9, uint8_t* __restrict__ tab) {
     const uint32_t byte = blockIdx.x * blockDim.x + threadIdx.x;
     if (byte >= (uint32_t)kPairTabBytes) return;
     uint32_t v = 0;
@@ -172,7 +180,10 @@ __global__ void k_build_pairtab(const uint32_t* __restrict__ key8, const uint32_
         // the entry's 9 bases ARE the first position's 9-base prefix: test it with K9 (4x fewer false survivors
         // than K8, same byte); the second position only has 8 of its bases inside the entry
         (void)q0;
-        const uint32_t r0 = (key9[e >> 5] >> (e & 31)) & 1u, r1 = (key8[q1 >> 5] >> (q1 & 31)) & 1u;
+        // second bit: m = 9 -- the position behind (8 of its bases are in the entry); m >= 10 -- the position IN FRONT,
+        // whose bases 1..9 are this entry: a nine-base test, four times sharper (k_dense_pair<true>)
+        const uint32_t r0 = (key9[e >> 5] >> (e & 31)) & 1u;
+        const uint32_t r1 = mid9 ? (mid9[e >> 5] >> (e & 31)) & 1u : (key8[q1 >> 5] >> (q1 & 31)) & 1u;
         v |= (r0 << s2) | (r1 << (s2 + 4));   // sub-entry s2: bit s2 = first position, bit s2+4 = second
     }
     tab[byte] = (uint8_t)v;
@@ -228,7 +239,11 @@ __device__ __forceinline__ uint32_t next_lane(uint32_t v) {
 // constant 0x88442211 as byte table turns them into the mask.  ~20 VALU per 16 positions beside the address
 // extraction (the shifted form took 36).  Which position a surviving bit stands for is worked out when the
 // survivor is verified (pair_code_to_offset), not here.
-struct PairSurv { uint32_t e, o; };
+// MID (m >= 10): the second bit of an entry stands for the position in front of the pair (see k_build_pairtab), so
+// position 2q - 1 is answered by pair q: pair 0's second bit belongs to the lane in front and is masked out here, and
+// position 15 needs a ninth lookup, "pair 8" = bases 16..24 of the window (PairSurv::x).
+struct PairSurv { uint32_t e, o, x; };
+template <bool MID>
 __device__ __forceinline__ PairSurv pair_lookup16(const uint8_t* __restrict__ tab, uint32_t hi, uint32_t nxt) {
     const uint32_t mid = __builtin_amdgcn_alignbit(hi, nxt, 16);   // bases 8..23
     uint32_t t[8];
@@ -237,30 +252,40 @@ __device__ __forceinline__ PairSurv pair_lookup16(const uint8_t* __restrict__ ta
         t[q] = tab[(hi >> (16 - 4 * q)) & 0xffffu];
         t[q + 4] = tab[(mid >> (16 - 4 * q)) & 0xffffu];
     }
+    const uint32_t t8 = MID ? (uint32_t)tab[nxt >> 16] : 0u;                 // bases 16..23
     const uint32_t pe = ((t[0] << 8 | t[2]) << 16) | (t[4] << 8 | t[6]);    // byte 3 - q/2 = pair q (q even)
     const uint32_t po = ((t[1] << 8 | t[3]) << 16) | (t[5] << 8 | t[7]);    // byte 3 - q/2 = pair q (q odd)
     // base 2q+8 of the 64-bit window hi:nxt sits at bits 47-4q : 46-4q
-    const uint32_t se = __builtin_amdgcn_alignbit(hi, nxt, 22) & 0x03030303u;
+    uint32_t se = __builtin_amdgcn_alignbit(hi, nxt, 22) & 0x03030303u;
     const uint32_t so = __builtin_amdgcn_alignbit(hi, nxt, 18) & 0x03030303u;
+    if (MID) se |= 0x04000000u;                      // pair 0 (byte 3): selectors 4..7 = the first-bit-only masks
     PairSurv r;
-    r.e = pe & __builtin_amdgcn_perm(0u, 0x88442211u, se);
+    r.e = pe & __builtin_amdgcn_perm(0x08040201u, 0x88442211u, se);
     r.o = po & __builtin_amdgcn_perm(0u, 0x88442211u, so);
+    r.x = MID ? t8 & (0x10u << ((nxt >> 14) & 3u)) : 0u;                    // base 24 picks the sub-entry; second bit only
     return r;
 }
-// survivor code = bit index in PairSurv::e (0..31) or 32 + bit index in PairSurv::o -> position offset (0..15)
+// survivor code = bit index in PairSurv::e (0..31), 32 + bit index in PairSurv::o, 64 + bit index in PairSurv::x
+// -> position offset (0..15)
+template <bool MID>
 __device__ __forceinline__ uint32_t pair_code_to_offset(uint32_t code) {
-    const uint32_t q = 2 * (3 - ((code >> 3) & 3u)) + (code >> 5), second = (code >> 2) & 1u;
-    return 2 * q + second;
+    const uint32_t second = (code >> 2) & 1u;
+    if (code >= 64u) return 15u;
+    const uint32_t q = 2 * (3 - ((code >> 3) & 3u)) + (code >> 5);
+    return MID ? 2 * q - second : 2 * q + second;
 }
-__device__ __forceinline__ uint32_t pair_count(PairSurv c) { return __popc(c.e) + __popc(c.o); }
+__device__ __forceinline__ uint32_t pair_count(PairSurv c) { return __popc(c.e) + __popc(c.o) + __popc(c.x); }
 // code of the only survivor of a lane that holds exactly one
-__device__ __forceinline__ uint32_t pair_single_code(PairSurv c) { return (uint32_t)(__ffs(c.e | c.o) - 1) | (c.o ? 32u : 0u); }
+__device__ __forceinline__ uint32_t pair_single_code(PairSurv c) {
+    return (uint32_t)(__ffs(c.e | c.o | c.x) - 1) | (c.o ? 32u : 0u) | (c.x ? 64u : 0u);
+}
 
 // Verify the queued survivors of one wave (all of them: the queue never holds more than 64), lane i taking
 // entry i.  Entries are {position of the lane's chunk relative to the wave's first position, survivor bit
 // (or 0x100 | offset), window hi, window nxt}: offset and m-mer are decoded here, with all lanes busy, not in
 // the push.  Deliberately NOT inlined: the hash is ~150 instructions and the scan kernel reaches this
 // from several places -- inlined copies blow the instruction cache of the hot loop.
+template <bool MID>
 __device__ __attribute__((noinline)) uint32_t drain_pair(const uint4* __restrict__ queue, uint32_t qn, uint64_t base_pos,
                                                          uint64_t n_mmers, uint32_t m, uint64_t thr,
                                                          Hit* __restrict__ out, uint32_t out_cap, uint32_t out_n) {
@@ -271,7 +296,7 @@ __device__ __attribute__((noinline)) uint32_t drain_pair(const uint4* __restrict
     uint32_t f = 0, x = 0;
     if (lane < qn) {
         const uint4 e = queue[lane];
-        const uint32_t off = (e.y & 0x100u) ? (e.y & 15u) : pair_code_to_offset(e.y);
+        const uint32_t off = (e.y & 0x100u) ? (e.y & 15u) : pair_code_to_offset<MID>(e.y);
         const uint64_t W = ((uint64_t)e.z << 32) | e.w;
         pos = base_pos + e.x + off;
         f = (uint32_t)(W >> (64 - 2 * m - 2 * off)) & mm;
@@ -283,6 +308,7 @@ __device__ __attribute__((noinline)) uint32_t drain_pair(const uint4* __restrict
     return append_hits(is_hit, pos, x, f, hash, out, out_cap, out_n);
 }
 
+template <bool MID>
 __global__ __launch_bounds__(64 * kPairWaves) void k_dense_pair(const uint8_t* __restrict__ bases, uint64_t n, uint32_t m,
                                                                uint64_t thr, const uint8_t* __restrict__ pairtab,
                                                                uint64_t n_rows, WaveLists L) {
@@ -311,17 +337,17 @@ __global__ __launch_bounds__(64 * kPairWaves) void k_dense_pair(const uint8_t* _
     uint32_t qn = 0;          // survivors waiting in this wave's queue (wave-uniform, lives in an SGPR)
 
     auto drain = [&]() {
-        out_n = drain_pair(queue, qn, base_pos, n_mmers, m, thr, out, L.cap, out_n);
+        out_n = drain_pair<MID>(queue, qn, base_pos, n_mmers, m, thr, out, L.cap, out_n);
         qn = 0;
     };
     // General form for ONE row: any number of survivors per lane, queued in position order.  Usual case (a lane or
     // two holding two survivors: one row pair in five at the default sampling) -- they are appended behind what is
     // queued and hashed with the next full round; only more than a queue-full is hashed 64 at a time on the spot.
     auto push_row = [&](PairSurv c, uint32_t rel, uint32_t hi, uint32_t nxt) {
-        if (!__ballot((c.e | c.o) != 0)) return;
-        uint32_t pm = 0;                                  // bit j = position offset j survives
-        for (uint32_t t = c.e; t; t &= t - 1) pm |= 1u << pair_code_to_offset(__ffs(t) - 1);
-        for (uint32_t t = c.o; t; t &= t - 1) pm |= 1u << pair_code_to_offset(32 + __ffs(t) - 1);
+        if (!__ballot((c.e | c.o | c.x) != 0)) return;
+        uint32_t pm = c.x ? 0x8000u : 0u;                 // bit j = position offset j survives
+        for (uint32_t t = c.e; t; t &= t - 1) pm |= 1u << pair_code_to_offset<MID>(__ffs(t) - 1);
+        for (uint32_t t = c.o; t; t &= t - 1) pm |= 1u << pair_code_to_offset<MID>(32 + __ffs(t) - 1);
         const uint32_t cnt = __popc(pm);
         uint32_t idx = 0, total = 0;                      // exclusive prefix / total of cnt over the lanes
 #pragma unroll
@@ -359,7 +385,7 @@ __global__ __launch_bounds__(64 * kPairWaves) void k_dense_pair(const uint8_t* _
     // (lane 63 only feeds lane 62: its own lookups are dropped from the ballots, on the scalar unit)
     constexpr unsigned long long kRowLanes = (1ull << kRowChunks) - 1;
     auto handle = [&](PairSurv ca, PairSurv cb, uint32_t rel_a, uint32_t hia, uint32_t nxa, uint32_t rel_b, uint32_t hib, uint32_t nxb) {
-        const unsigned long long ha = __ballot((ca.e | ca.o) != 0) & kRowLanes, hb = __ballot((cb.e | cb.o) != 0) & kRowLanes;
+        const unsigned long long ha = __ballot((ca.e | ca.o | ca.x) != 0) & kRowLanes, hb = __ballot((cb.e | cb.o | cb.x) != 0) & kRowLanes;
         if (!(ha | hb)) return;
         const bool mine_a = (ha >> lane) & 1u, mine_b = (hb >> lane) & 1u;
         const uint32_t na = (uint32_t)__popcll(ha), total = na + (uint32_t)__popcll(hb);
@@ -373,7 +399,7 @@ __global__ __launch_bounds__(64 * kPairWaves) void k_dense_pair(const uint8_t* _
             if (qn >= (uint32_t)kQueueCap) drain();
             return;
         }
-        const PairSurv none = {0u, 0u};
+        const PairSurv none = {0u, 0u, 0u};
         push_row(lane < (uint32_t)kRowChunks ? ca : none, rel_a, hia, nxa);
         push_row(lane < (uint32_t)kRowChunks ? cb : none, rel_b, hib, nxb);
     };
@@ -395,7 +421,7 @@ __global__ __launch_bounds__(64 * kPairWaves) void k_dense_pair(const uint8_t* _
         // past the last row the wave re-reads its current row, whose value is never used
         raw = *reinterpret_cast<const uint4*>(r + 2 < n_fast ? at + 2 * row_bytes : at);
         nxt = next_lane(hi);
-        return pair_lookup16(tab, hi, nxt);
+        return pair_lookup16<MID>(tab, hi, nxt);
     };
     uint32_t rel = lane * kChunk;                              // this lane's chunk of the current row, relative to base_pos
     const uint32_t rel_step = (uint32_t)row_bytes;
@@ -405,7 +431,7 @@ __global__ __launch_bounds__(64 * kPairWaves) void k_dense_pair(const uint8_t* _
         const PairSurv cb = body(raw1, i + 1, ptr + row_bytes, hib, nxb);
         handle(ca, cb, rel, hia, nxa, rel + rel_step, hib, nxb);
     }
-    const PairSurv no_row = {0u, 0u};
+    const PairSurv no_row = {0u, 0u, 0u};
     if (i < n_fast) {
         uint32_t hia, nxa;
         const PairSurv ca = body(raw0, i, ptr, hia, nxa);
@@ -416,7 +442,7 @@ __global__ __launch_bounds__(64 * kPairWaves) void k_dense_pair(const uint8_t* _
     for (; i < n_my; ++i, rel += rel_step) {
         const uint32_t hi = load_pack(bases, n, (first + i) * kRowPosPair63 + (uint64_t)lane * kChunk);
         const uint32_t nxt = next_lane(hi);
-        handle(pair_lookup16(tab, hi, nxt), no_row, rel, hi, nxt, rel, hi, nxt);
+        handle(pair_lookup16<MID>(tab, hi, nxt), no_row, rel, hi, nxt, rel, hi, nxt);
     }
     drain();
     if (lane == 0) L.cnt[gw] = out_n;
@@ -1324,7 +1350,8 @@ static int pick_dense(const spsp_params* p) {
     if ((p->flags & SPSP_SCAN_PAIR_FILTER) && p->m >= 9) return kDensePair;
     const double frac = (double)p->threshold / 18446744073709551616.0;  // P(hash <= T)
     const uint32_t bits = 2 * p->m;
-    if (p->m >= 9 && frac * (double)(1u << (bits - 16)) < 0.01) return kDensePair;
+    // pair table: the weaker of an entry's two tests sees 8 bases at m = 9, nine from m = 10 on (k_build_pairtab)
+    if (p->m >= 9 && frac * (double)(1u << (bits - (p->m >= 10 ? 18 : 16))) < 0.01) return kDensePair;
     // expected share of positions that go on to XXH64: prefix table (both strands' m-mers per 10-base prefix) against
     // the blocked Bloom filter (three bits per canonical m-mer in one of 2^15 words, ~fill^3)
     const double single = p->m >= 10 ? frac * (double)(1u << (bits - 20)) : 1.0;
@@ -1368,16 +1395,17 @@ static int ensure_key10(spsp_ctx* ctx, const spsp_params* p) {
 
 static int ensure_pairtab(spsp_ctx* ctx, const spsp_params* p) {
     if (ctx->pair_valid && ctx->pair_m == p->m && ctx->pair_thr == p->threshold) return SPSP_OK;
-    int rc = ctx->pairtab.reserve((size_t)kPairTabBytes + 8192 + 32768);
+    int rc = ctx->pairtab.reserve((size_t)kPairTabBytes + 8192 + 32768 + 32768);
     if (rc) return rc;
     uint32_t* key8 = reinterpret_cast<uint32_t*>(ctx->pairtab.as<uint8_t>() + kPairTabBytes);  // 2^16 bits
     uint32_t* key9 = key8 + 8192 / 4;                                                           // 2^18 bits
-    SPSP_HIP(hipMemsetAsync(key8, 0, 8192 + 32768, ctx->stream));
+    uint32_t* mid9 = p->m >= 10 ? key9 + 32768 / 4 : nullptr;                                   // 2^18 bits
+    SPSP_HIP(hipMemsetAsync(key8, 0, 8192 + 32768 + 32768, ctx->stream));
     const uint64_t total = 1ull << (2 * p->m);
     hipLaunchKernelGGL(k_build_key8, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, ctx->stream, p->m,
-                       p->threshold, key8, key9);
+                       p->threshold, key8, key9, mid9);
     SPSP_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_build_pairtab, dim3(kPairTabBytes / 256), dim3(256), 0, ctx->stream, key8, key9,
+    hipLaunchKernelGGL(k_build_pairtab, dim3(kPairTabBytes / 256), dim3(256), 0, ctx->stream, key8, key9, mid9,
                        ctx->pairtab.as<uint8_t>());
     SPSP_HIP(hipGetLastError());
     ctx->pair_m = p->m; ctx->pair_thr = p->threshold; ctx->pair_valid = true;
@@ -1439,12 +1467,16 @@ static int launch_dense(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_ba
         if (variant == kDensePair) {
             const size_t lds = (size_t)kPairWaves * kQueueCap * 16;                // + 64 KiB static table
             if (!ctx->attr_pair_set) {
-                SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_pair),
+                SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_pair<false>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_pair<true>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 ctx->attr_pair_set = true;
             }
-            hipLaunchKernelGGL(k_dense_pair, dim3(LP->grid), dim3(64 * kPairWaves), lds, ctx->stream, d_bases, n_bases, p->m,
-                               p->threshold, ctx->pairtab.as<uint8_t>(), LP->n_rows, L);
+            if (p->m >= 10) hipLaunchKernelGGL(k_dense_pair<true>, dim3(LP->grid), dim3(64 * kPairWaves), lds, ctx->stream, d_bases, n_bases,
+                                               p->m, p->threshold, ctx->pairtab.as<uint8_t>(), LP->n_rows, L);
+            else hipLaunchKernelGGL(k_dense_pair<false>, dim3(LP->grid), dim3(64 * kPairWaves), lds, ctx->stream, d_bases, n_bases, p->m,
+                                    p->threshold, ctx->pairtab.as<uint8_t>(), LP->n_rows, L);
         } else if (variant == kDenseBloom) {
             const size_t lds = (size_t)kBloomBytes + (size_t)kPairWaves * kQueueCap1 * 8;
             if (!ctx->attr_bloom_set) {
