@@ -785,3 +785,60 @@ def test_gpu_sketch_decode_matches_host_parser(ctx):
                 assert (hi[a:b] == want.kmer_hi).all(), (k, m, i)
         if k == 31:
             assert int(sk_off[5] - sk_off[4]) > 8192               # the large sketch went through the host decoder
+
+
+def test_cu_partitioned_streams_and_sampled_timing():
+    """spsp_stream_create_cus / spsp_set_cu_count (bench.py's step schedule): a scan whose dense pass runs on a stream
+    that owns 192 CUs (two workgroups each) with its sparse stages on a 64-CU stream, next to a comparison on
+    another 64-CU stream, gives the same stream and matrix as the oracle; bad CU ranges are refused; with
+    spsp_timing_sample(4) every fourth dense pass is bracketed."""
+    import torch
+    k, m, s = 31, 11, 200.0
+    gs = synth.family_genomes(5, 6, 300_000, 2, [0.0, 0.01])
+    bases, offs = synth.concat_records(gs)
+    p = sp.make_params(k, m, s)
+    with pytest.raises(sp.SpspError):
+        sp.stream_create_cus(0, 250, 64)
+    with pytest.raises(sp.SpspError):
+        sp.stream_create_cus(0, 0, 0)
+    s_d, s_t, s_c = sp.stream_create_cus(0, 64, 192), sp.stream_create_cus(0, 0, 64), sp.stream_create_cus(0, 0, 64)
+    scan, cmpc = sp.Context(0, s_d), sp.Context(0, s_c)
+    try:
+        with pytest.raises(sp.SpspError):
+            scan.set_cu_count(10_000, 1)
+        scan.set_cu_count(192, 2)
+        scan.scan_tail_stream(True, s_t)
+        cmpc.set_cu_count(64)
+        d_b = torch.from_numpy(bases).cuda()
+        d_o = torch.from_numpy(offs.view(np.int64)).cuda()
+        payloads = [orc.sketch_fasta(synth.to_fasta(g, "g"), k, m, s)[0] for g in gs]
+        sk = [sp.sketch_parse(pl) for pl in payloads]
+        sk_off = np.zeros(len(sk) + 1, dtype=np.uint64)
+        sk_off[1:] = np.cumsum([len(x) for x in sk])
+        d_mn = torch.from_numpy(np.concatenate([x.minimizer for x in sk]).astype(np.uint32).view(np.int32)).cuda()
+        d_lo = torch.from_numpy(np.concatenate([x.kmer_lo for x in sk]).astype(np.uint64).view(np.int64)).cuda()
+        d_inter = torch.zeros((len(sk), len(sk)), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        scan.timing_enable(True, sp.TIME_DENSE)
+        scan.timing_sample(4)
+        scan.timing_read()
+        want = _oracle_stream(k, m, p.threshold, bases, offs)
+        for _ in range(8):
+            scan.scan_device_begin(p, d_b.data_ptr(), d_b.numel(), d_o.data_ptr(), len(gs))
+            cmpc.compare_device_begin(k, d_mn.data_ptr(), d_lo.data_ptr(), None, sk_off, len(sk), 0, 1, d_inter.data_ptr())
+            d_out, n_out = scan.scan_device_end()
+            cmpc.compare_end()
+            got = scan.to_host(d_out, n_out, sp.SUPERKMER_DTYPE)
+            _assert_stream_equal(got, want)
+        t = scan.timing_read()
+        assert t["dense_launches"] in (2, 3) and t["dense_ms"] > 0   # (3: a first call that grew its buffers)
+        scan.timing_sample(1)
+        scan.timing_enable(False)
+        inter, _, _, _ = orc.compare(payloads)
+        got_inter = d_inter.cpu().numpy().astype(np.uint32)
+        iu = np.triu_indices(len(sk), 1)
+        assert (got_inter[iu] == np.asarray(inter, dtype=np.uint32).reshape(len(sk), len(sk))[iu]).all()
+    finally:
+        scan.close(); cmpc.close()
+        for h in (s_d, s_t, s_c):
+            sp.stream_destroy(0, h)
