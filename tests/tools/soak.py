@@ -75,7 +75,7 @@ def main():
     ctx = sp.Context(0)
     t0 = time.time()
     n_scan = n_cmp = n_sk = n_ex = 0
-    modes = [sp.SPSP_SCAN_DEFAULT, sp.SPSP_SCAN_DIRECT_HASH, sp.SPSP_SCAN_LDS_FILTER, sp.SPSP_SCAN_PAIR_FILTER]
+    modes = [sp.SPSP_SCAN_DEFAULT, sp.SPSP_SCAN_DIRECT_HASH, sp.SPSP_SCAN_LDS_FILTER, sp.SPSP_SCAN_PAIR_FILTER, sp.SPSP_SCAN_PAIR_FILTER, sp.SPSP_SCAN_BLOOM_FILTER]
     t_report = t0
     while time.time() - t0 < budget:
         if time.time() - t_report > 45:      # a long run must keep talking (the GPU pool kills silent commands)
