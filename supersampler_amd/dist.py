@@ -70,38 +70,81 @@ class KeyExchange:
         self.starts = np.concatenate([[0], np.cumsum(self.per_rank)]).astype(np.int64)
         total = int(self.per_rank.sum())
         mk = lambda dt, n: torch.zeros(n, dtype=dt, device=device)
-        # compact position -> position in the padded gather buffer: ONE gather kernel per key array instead of a copy per rank
-        idx = np.concatenate([np.arange(int(self.per_rank[r]), dtype=np.int64) + r * self.pad for r in range(self.world)]) if total else np.zeros(0, np.int64)
-        self._idx = torch.from_numpy(idx.astype(np.int32 if self.world * self.pad < 2**31 else np.int64)).to(device)
-        self._pad_min, self._pad_lo = mk(torch.int32, self.pad), mk(torch.int64, self.pad)
-        self._g_min, self._g_lo = mk(torch.int32, self.world * self.pad), mk(torch.int64, self.world * self.pad)
+        # ONE all-gather per step for both key arrays (the step is host-bound with RCCL: a collective costs ~17 us of host
+        # time): every rank's padded block is [kmer_lo: pad x 8 B | minimizer: pad x 4 B] in one byte buffer; the
+        # gathered blocks are compacted by ONE gather kernel per array (index_select over the int64 / int32 view)
+        self.pad += self.pad & 1                                         # blocks stay 8-byte aligned
+        blk = self.pad * 12
+        self._pad_buf = mk(torch.uint8, blk)
+        self._pad_lo = self._pad_buf[:self.pad * 8].view(torch.int64)
+        self._pad_min = self._pad_buf[self.pad * 8:].view(torch.int32)
+        self._g_buf = mk(torch.uint8, self.world * blk)
+        self._g_as_lo, self._g_as_min = self._g_buf.view(torch.int64), self._g_buf.view(torch.int32)
+        idx_lo = np.concatenate([np.arange(int(self.per_rank[r]), dtype=np.int64) + r * (blk // 8) for r in range(self.world)]) if total else np.zeros(0, np.int64)
+        idx_mn = np.concatenate([np.arange(int(self.per_rank[r]), dtype=np.int64) + r * (blk // 4) + self.pad * 2 for r in range(self.world)]) if total else np.zeros(0, np.int64)
+        small = self.world * blk // 4 < 2**31
+        self._idx_lo = torch.from_numpy(idx_lo.astype(np.int32 if small else np.int64)).to(device)
+        self._idx_mn = torch.from_numpy(idx_mn.astype(np.int32 if small else np.int64)).to(device)
         self.all_min, self.all_lo = mk(torch.int32, total), mk(torch.int64, total)
         if use_hi:
+            idx = np.concatenate([np.arange(int(self.per_rank[r]), dtype=np.int64) + r * self.pad for r in range(self.world)]) if total else np.zeros(0, np.int64)
+            self._idx = torch.from_numpy(idx.astype(np.int32 if self.world * self.pad < 2**31 else np.int64)).to(device)
             self._pad_hi, self._g_hi, self.all_hi = mk(torch.int64, self.pad), mk(torch.int64, self.world * self.pad), mk(torch.int64, total)
         else:
             self.all_hi = None
 
-    def _gather_one(self, g, padded, mine, out):
-        padded[:mine.numel()] = mine
+    def _all_gather(self, g, padded):
         if dist.get_backend(self.group) == "gloo":
             parts = [torch.empty_like(padded) for _ in range(self.world)]
             dist.all_gather(parts, padded, group=self.group)
             g.copy_(torch.cat(parts))
         else:
             dist.all_gather_into_tensor(g, padded, group=self.group)
-        torch.index_select(g, 0, self._idx, out=out)
 
     def _on_stream(self):
-        return torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+        # (entering a stream context costs ~7 us of host time: skipped when the caller is on the stream already)
+        if self.stream is None or torch.cuda.current_stream(self.stream.device) == self.stream:
+            return contextlib.nullcontext()
+        return torch.cuda.stream(self.stream)
 
     def exchange(self, my_min, my_lo, my_hi=None):
         """int32/int64 tensors (bit patterns of the uint32/uint64 keys) of this rank -> GatheredSketches."""
         with self._on_stream():
-            self._gather_one(self._g_min, self._pad_min, my_min, self.all_min)
-            self._gather_one(self._g_lo, self._pad_lo, my_lo, self.all_lo)
+            self._pad_min[:my_min.numel()] = my_min
+            self._pad_lo[:my_lo.numel()] = my_lo
+            self._all_gather(self._g_buf, self._pad_buf)
+            torch.index_select(self._g_as_min, 0, self._idx_mn, out=self.all_min)
+            torch.index_select(self._g_as_lo, 0, self._idx_lo, out=self.all_lo)
             if self.use_hi:
-                self._gather_one(self._g_hi, self._pad_hi, my_hi, self.all_hi)
+                self._pad_hi[:my_hi.numel()] = my_hi
+                self._all_gather(self._g_hi, self._pad_hi)
+                torch.index_select(self._g_hi, 0, self._idx, out=self.all_hi)
         return GatheredSketches(self.all_min, self.all_lo, self.all_hi, self.sk_off)
+
+    def _collect_plan(self, inter_local, dst):
+        """index tensors and buffers of collect_rows for one matrix shape (built once: the step is host-bound)"""
+        n = inter_local.shape[0]
+        key = (n, dst, inter_local.dtype, str(inter_local.device))
+        plan = getattr(self, "_plans", {}).get(key)
+        if plan is None:
+            dev = inter_local.device
+            rows = -(-n // self.world)                                   # rows per rank, padded
+            own = torch.arange(self.rank, n, self.world, device=dev)
+            plan = {"rows": rows, "own": own, "mine": torch.zeros((rows, n), dtype=inter_local.dtype, device=dev)}
+            if self.rank == dst:
+                plan["all"] = torch.zeros((self.world, rows, n), dtype=inter_local.dtype, device=dev)
+                src, dstr = [], []
+                for r in range(self.world):
+                    if r == dst:
+                        continue
+                    k = len(range(r, n, self.world))
+                    src += [r * rows + j for j in range(k)]
+                    dstr += list(range(r, n, self.world))
+                plan["src"] = torch.tensor(src, dtype=torch.int64, device=dev)
+                plan["dst"] = torch.tensor(dstr, dtype=torch.int64, device=dev)
+            self._plans = getattr(self, "_plans", {})
+            self._plans[key] = plan
+        return plan
 
     def collect_rows(self, inter_local, dst=0):
         """strips -> one rank: every rank sends the rows it owns (i % world == rank) of its n x n
@@ -109,20 +152,30 @@ class KeyExchange:
         cell crosses the fabric once (an all-reduce of the n x n matrices moves 2 (world-1)/world of ALL of them)."""
         n = inter_local.shape[0]
         with self._on_stream():
-            rows = -(-n // self.world)                                   # rows per rank, padded
-            mine = torch.zeros((rows, n), dtype=inter_local.dtype, device=inter_local.device)
-            own = inter_local[self.rank::self.world]
-            mine[:own.shape[0]] = own
-            if dist.get_backend(self.group) == "gloo" and mine.is_cuda:
+            if dist.get_backend(self.group) == "gloo" and inter_local.is_cuda:
+                # (CPU-side collective in the tests: through host copies)
+                rows = -(-n // self.world)
+                mine = torch.zeros((rows, n), dtype=inter_local.dtype, device=inter_local.device)
+                own = inter_local[self.rank::self.world]
+                mine[:own.shape[0]] = own
                 torch.cuda.synchronize()
                 mine = mine.cpu()
-            parts = [torch.empty_like(mine) for _ in range(self.world)] if self.rank == dst else None
-            dist.gather(mine, parts, dst=dst, group=self.group)
-            if self.rank == dst:
-                for r in range(self.world):
-                    k = len(range(r, n, self.world))
-                    if r != dst:
-                        inter_local[r::self.world] = parts[r][:k].to(inter_local.device)
+                parts = [torch.empty_like(mine) for _ in range(self.world)] if self.rank == dst else None
+                dist.gather(mine, parts, dst=dst, group=self.group)
+                if self.rank == dst:
+                    for r in range(self.world):
+                        k = len(range(r, n, self.world))
+                        if r != dst:
+                            inter_local[r::self.world] = parts[r][:k].to(inter_local.device)
+                return inter_local
+            P = self._collect_plan(inter_local, dst)
+            k_own = P["own"].numel()
+            if k_own:
+                torch.index_select(inter_local, 0, P["own"], out=P["mine"][:k_own])      # own rows, one kernel
+            parts = list(P["all"].unbind(0)) if self.rank == dst else None
+            dist.gather(P["mine"], parts, dst=dst, group=self.group)
+            if self.rank == dst and P["src"].numel():
+                inter_local.index_copy_(0, P["dst"], P["all"].view(-1, n).index_select(0, P["src"]))
         return inter_local
 
 
