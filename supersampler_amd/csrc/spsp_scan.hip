@@ -63,6 +63,15 @@ __device__ __forceinline__ uint32_t load_pack(const uint8_t* __restrict__ bases,
     return w;
 }
 
+// One 16-byte chunk of a row, as a NON-TEMPORAL load (global_load_dwordx4 ... nt): the dense pass reads every byte
+// exactly once, and without the hint its stream churns through L2 -- measured on the pair-table pass, 5 x 10^8
+// positions on the whole chip: 0.096-0.099 ms with plain loads, 0.085-0.089 ms with nt (5.8 TB/s).
+typedef uint32_t spsp_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 load_row16(const uint8_t* __restrict__ p) {
+    const spsp_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const spsp_u32x4*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 // ------------------------------------------------- dense pass, direct form ---
 // XXH64 at every position: the variant for dense selections (small -s), where
 // nearly every lane has to hash anyway.  A workgroup stages one tile of kTilePos
@@ -413,13 +422,13 @@ __global__ __launch_bounds__(64 * kPairWaves) void k_dense_pair(const uint8_t* _
     // Two rows in flight per wave, in two named register sets: each set is refilled
     // right after it has been packed, so its wait sits a whole loop trip later.
     uint4 raw0 = make_uint4(0, 0, 0, 0), raw1 = raw0;
-    if (i < n_fast) raw0 = *reinterpret_cast<const uint4*>(ptr);
-    if (i + 1 < n_fast) raw1 = *reinterpret_cast<const uint4*>(ptr + row_bytes);
+    if (i < n_fast) raw0 = load_row16(ptr);
+    if (i + 1 < n_fast) raw1 = load_row16(ptr + row_bytes);
     auto body = [&](uint4& raw, uint64_t r, const uint8_t* at, uint32_t& hi, uint32_t& nxt) -> PairSurv {
         hi = pack16(raw);
         // unconditional refill (a branch around the load would force a full vmcnt(0) wait right here):
         // past the last row the wave re-reads its current row, whose value is never used
-        raw = *reinterpret_cast<const uint4*>(r + 2 < n_fast ? at + 2 * row_bytes : at);
+        raw = load_row16(r + 2 < n_fast ? at + 2 * row_bytes : at);
         nxt = next_lane(hi);
         return pair_lookup16<MID>(tab, hi, nxt);
     };
@@ -568,14 +577,14 @@ __global__ __launch_bounds__(64 * kPairWaves) void k_dense_single(const uint8_t*
     uint64_t i = 0;
     const uint8_t* ptr = bases + first * kRowPosPair63 + (uint64_t)lane * kChunk;
     uint4 raw0 = make_uint4(0, 0, 0, 0), raw1 = raw0;
-    if (i < n_fast) raw0 = *reinterpret_cast<const uint4*>(ptr);
-    if (i + 1 < n_fast) raw1 = *reinterpret_cast<const uint4*>(ptr + row_bytes);
+    if (i < n_fast) raw0 = load_row16(ptr);
+    if (i + 1 < n_fast) raw1 = load_row16(ptr + row_bytes);
     const bool halo_lane = lane >= kRowChunks;
     uint32_t rel = lane * kChunk;
     const uint32_t rel_step = (uint32_t)row_bytes;
     auto body = [&](uint4& raw, uint64_t r, const uint8_t* at, uint32_t rl) {
         const uint32_t hi = pack16(raw);
-        raw = *reinterpret_cast<const uint4*>(r + 2 < n_fast ? at + 2 * row_bytes : at);
+        raw = load_row16(r + 2 < n_fast ? at + 2 * row_bytes : at);
         const uint32_t nxt = __shfl_down(hi, 1);
         const uint32_t c = single_lookup16(tab, hi, nxt);
         handle(halo_lane ? 0u : c, rl, hi, nxt);
@@ -981,14 +990,14 @@ __global__ __launch_bounds__(64 * kPairWaves) void k_dense_bloom(const uint8_t* 
     uint64_t i = 0;
     const uint8_t* ptr = bases + first * kRowPosPair63 + (uint64_t)lane * kChunk;
     uint4 raw0 = make_uint4(0, 0, 0, 0), raw1 = raw0;
-    if (i < n_fast) raw0 = *reinterpret_cast<const uint4*>(ptr);
-    if (i + 1 < n_fast) raw1 = *reinterpret_cast<const uint4*>(ptr + row_bytes);
+    if (i < n_fast) raw0 = load_row16(ptr);
+    if (i + 1 < n_fast) raw1 = load_row16(ptr + row_bytes);
     const bool halo_lane = lane >= kRowChunks;
     uint32_t rel = lane * kChunk;
     const uint32_t rel_step = (uint32_t)row_bytes;
     auto body = [&](uint4& raw, uint64_t r, const uint8_t* at, uint32_t rl) {
         const uint32_t hi = pack16(raw);
-        raw = *reinterpret_cast<const uint4*>(r + 2 < n_fast ? at + 2 * row_bytes : at);
+        raw = load_row16(r + 2 < n_fast ? at + 2 * row_bytes : at);
         const uint32_t nxt = __shfl_down(hi, 1);
         const uint32_t c = bloom_lookup16<M>(tab, hi, nxt);
         handle(halo_lane ? 0u : c, rl, hi, nxt);
