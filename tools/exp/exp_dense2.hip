@@ -21,6 +21,12 @@ __device__ __forceinline__ uint32_t pack16(uint4 v) {
 }
 __device__ __forceinline__ uint32_t next_lane(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true); }
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 LD(const uint8_t* p) {   // non-temporal, as the product
+    const u32x4 v = __builtin_nontemporal_load((const u32x4*)p);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+static hipStream_t g_stream = 0;
 constexpr int kWaves = 16, kTab = 65536;
 // VAR 0 load+pack; 1 +halo; 2 +8 byte lookups, masked merge; 3 same, conflict-free addresses; 4 four byte lookups;
 // 5 four ds_read_b32 lookups (word table, 14-bit address) + 4 masks; 6 as 5 with conflict-free addresses; 7 as 2 with 2 lookups
@@ -42,12 +48,12 @@ __global__ __launch_bounds__(1024) void k_var(const uint8_t* __restrict__ bases,
     const uint64_t end = STRIDED ? n_rows : (row + per < n_rows ? row + per : n_rows);
     const uint8_t* ptr = bases + row * 1008 + (uint64_t)lane * 16;
     uint4 raw0 = make_uint4(0,0,0,0), raw1 = raw0;
-    if (row < end) raw0 = *(const uint4*)ptr;
-    if (row + step < end) raw1 = *(const uint4*)(ptr + stride);
+    if (row < end) raw0 = LD(ptr);
+    if (row + step < end) raw1 = LD(ptr + stride);
     uint32_t sink = 0;
     auto body = [&](uint4& raw, uint64_t r, const uint8_t* at) {
         const uint32_t hi = pack16(raw);
-        raw = *(const uint4*)(r + 2 * step < end ? at + 2 * stride : at);
+        raw = LD(r + 2 * step < end ? at + 2 * stride : at);
         if (VAR == 0) { sink ^= hi; return; }
         const uint32_t nxt = next_lane(hi);
         if (VAR == 1) { sink ^= hi ^ nxt; return; }
@@ -95,9 +101,9 @@ template <int VAR, bool STRIDED> void run(const char* name, const uint8_t* bases
     hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     float best = 1e9, tot = 0;
     for (int it = 0; it < 8; ++it) {
-        CK(hipEventRecord(a));
-        hipLaunchKernelGGL((k_var<VAR, STRIDED>), dim3(blocks), dim3(1024), 0, 0, bases, n, tab, n_rows, out);
-        CK(hipGetLastError()); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        CK(hipEventRecord(a, g_stream));
+        hipLaunchKernelGGL((k_var<VAR, STRIDED>), dim3(blocks), dim3(1024), 0, g_stream, bases, n, tab, n_rows, out);
+        CK(hipGetLastError()); CK(hipEventRecord(b, g_stream)); CK(hipEventSynchronize(b));
         float ms; CK(hipEventElapsedTime(&ms, a, b)); if (it) { tot += ms; if (ms < best) best = ms; }
     }
     printf("%-34s %s blocks=%4d  avg %.4f ms  best %.4f ms  -> %.0f GB/s\n", name, STRIDED ? "strided" : "contig ", blocks, tot / 7, best, n / best / 1e6);
@@ -112,6 +118,19 @@ int main(int argc, char** argv) {
     for (int i = 0; i < kTab; ++i) if ((i * 2654435761u >> 20) % 331 == 0) h[i] = 1u << (i & 7);   // ~0.3% of entries
     CK(hipMemcpy(tab, h.data(), kTab, hipMemcpyHostToDevice));
     CK(hipMemset(out, 0, 64));
+    if (argc > 1) {   // argv[1] = CUs of a masked stream (first 256 - argv[1] CUs are left out)
+        const int cus = atoi(argv[1]);
+        uint32_t mask[8] = {0};
+        for (int c = 256 - cus; c < 256; ++c) mask[c / 32] |= 1u << (c % 32);
+        CK(hipExtStreamCreateWithCUMask(&g_stream, 8, mask));
+        for (int blocks : {cus, 2 * cus}) {
+            run<0, false>("0 load+pack", bases, n, tab, out, blocks);
+            run<2, false>("2 +8 byte lookups, masked", bases, n, tab, out, blocks);
+            run<3, false>("3 same, conflict-free", bases, n, tab, out, blocks);
+            run<4, false>("4 four byte lookups", bases, n, tab, out, blocks);
+        }
+        return 0;
+    }
     for (int blocks : {256, 512}) {
         run<0, false>("0 load+pack", bases, n, tab, out, blocks);
         run<0, true>("0 load+pack", bases, n, tab, out, blocks);
