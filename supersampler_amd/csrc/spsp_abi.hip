@@ -58,6 +58,20 @@ int spsp_ctx::ev_begin(int kind) {
     SPSP_HIP(hipEventRecord(ev.first, stream));
     return SPSP_OK;
 }
+// a bracket whose two events the caller attaches to a kernel dispatch itself (hipExtLaunchKernelGGL): nothing is
+// recorded on the stream here.  false = this region is not timed (timing off, or sampled out)
+bool spsp_ctx::ev_pair(int kind, hipEvent_t* start, hipEvent_t* stop) {
+    *start = *stop = nullptr;
+    if (!(timing_mask & (1u << kind))) return false;
+    if (timing_every > 1 && (ev_seq[kind]++ % timing_every) != 0) return false;
+    EventLog& L = evlog[kind];
+    std::pair<hipEvent_t, hipEvent_t> ev;
+    if (!L.spare.empty()) { ev = L.spare.back(); L.spare.pop_back(); }
+    else if (hipEventCreate(&ev.first) != hipSuccess || hipEventCreate(&ev.second) != hipSuccess) return false;
+    L.used.push_back(ev);
+    *start = ev.first; *stop = ev.second;
+    return true;
+}
 int spsp_ctx::ev_end(int kind) {
     // closes the bracket opened by the matching ev_begin only: timing may have been switched on, off or read
     // between the two calls (the comparison's bracket spans API calls)

@@ -78,6 +78,7 @@ struct spsp_ctx {
     // begin/end bracket for one timed region; no-ops unless timing is on
     int ev_begin(int kind);
     int ev_end(int kind);
+    bool ev_pair(int kind, hipEvent_t* start, hipEvent_t* stop);   // events for hipExtLaunchKernelGGL (no stream packets)
     bool ev_open[spsp::kEvKinds] = {};   // a begin without its end is outstanding
     uint32_t timing_every = 1;           // spsp_timing_sample: every n-th region of a kind is bracketed
     uint32_t ev_seq[spsp::kEvKinds] = {};

@@ -24,6 +24,8 @@
 #include <cmath>
 #include <cstdlib>
 
+#include <hip/hip_ext.h>
+
 #include "spsp_internal.h"
 #include "spsp_device.h"
 
@@ -1470,7 +1472,16 @@ static int launch_dense(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_ba
         if ((rc = ctx->tile_count.reserve((size_t)n_tiles * 4))) return rc;
         if ((rc = ctx->tile_off.reserve((size_t)(n_tiles + 1) * 4))) return rc;
     }
-    if ((rc = ctx->ev_begin(kEvDense))) return rc;
+    // The kernel's own completion signal serves as the event other streams wait on (spsp_wait_dense, the sparse stages'
+    // stream) and, when this launch is bracketed, its start/stop as the timing pair: hipExtLaunchKernelGGL attaches
+    // both to the dispatch packet, so no event packet sits between two dense passes that run back to back
+    // (an event record of its own cost the pipelined step 3-7 us per dense pass).
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    const bool timed = ctx->ev_pair(kEvDense, &ev_start, &ev_stop);
+    if (!timed) {
+        if (!ctx->dense_done) SPSP_HIP(hipEventCreateWithFlags(&ctx->dense_done, hipEventDisableTiming));
+        ev_stop = ctx->dense_done;
+    }
     if (*lists) {
         const WaveLists L{ctx->wave_hits.as<Hit>(), ctx->wave_cnt.as<uint32_t>(), LP->cap, LP->rows_per_wave};
         if (variant == kDensePair) {
@@ -1482,9 +1493,9 @@ static int launch_dense(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_ba
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 ctx->attr_pair_set = true;
             }
-            if (p->m >= 10) hipLaunchKernelGGL(k_dense_pair<true>, dim3(LP->grid), dim3(64 * kPairWaves), lds, ctx->stream, d_bases, n_bases,
+            if (p->m >= 10) hipExtLaunchKernelGGL(k_dense_pair<true>, dim3(LP->grid), dim3(64 * kPairWaves), lds, ctx->stream, ev_start, ev_stop, 0, d_bases, n_bases,
                                                p->m, p->threshold, ctx->pairtab.as<uint8_t>(), LP->n_rows, L);
-            else hipLaunchKernelGGL(k_dense_pair<false>, dim3(LP->grid), dim3(64 * kPairWaves), lds, ctx->stream, d_bases, n_bases, p->m,
+            else hipExtLaunchKernelGGL(k_dense_pair<false>, dim3(LP->grid), dim3(64 * kPairWaves), lds, ctx->stream, ev_start, ev_stop, 0, d_bases, n_bases, p->m,
                                     p->threshold, ctx->pairtab.as<uint8_t>(), LP->n_rows, L);
         } else if (variant == kDenseBloom) {
             const size_t lds = (size_t)kBloomBytes + (size_t)kPairWaves * kQueueCap1 * 8;
@@ -1493,9 +1504,9 @@ static int launch_dense(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_ba
                 SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_bloom<13>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 ctx->attr_bloom_set = true;
             }
-            if (p->m == 15) hipLaunchKernelGGL(k_dense_bloom<15>, dim3(LP->grid), dim3(64 * kPairWaves), lds, ctx->stream, d_bases, n_bases,
+            if (p->m == 15) hipExtLaunchKernelGGL(k_dense_bloom<15>, dim3(LP->grid), dim3(64 * kPairWaves), lds, ctx->stream, ev_start, ev_stop, 0, d_bases, n_bases,
                                                p->threshold, ctx->bloom.as<uint32_t>(), LP->n_rows, L);
-            else hipLaunchKernelGGL(k_dense_bloom<13>, dim3(LP->grid), dim3(64 * kPairWaves), lds, ctx->stream, d_bases, n_bases,
+            else hipExtLaunchKernelGGL(k_dense_bloom<13>, dim3(LP->grid), dim3(64 * kPairWaves), lds, ctx->stream, ev_start, ev_stop, 0, d_bases, n_bases,
                                     p->threshold, ctx->bloom.as<uint32_t>(), LP->n_rows, L);
         } else {
             const size_t lds = (size_t)kKey10Bytes + (size_t)kPairWaves * kQueueCap1 * 8;
@@ -1504,28 +1515,18 @@ static int launch_dense(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_ba
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 ctx->attr_single_set = true;
             }
-            hipLaunchKernelGGL(k_dense_single, dim3(LP->grid), dim3(64 * kPairWaves), lds, ctx->stream, d_bases, n_bases, p->m,
+            hipExtLaunchKernelGGL(k_dense_single, dim3(LP->grid), dim3(64 * kPairWaves), lds, ctx->stream, ev_start, ev_stop, 0, d_bases, n_bases, p->m,
                                p->threshold, ctx->filter.as<uint8_t>(), LP->n_rows, L);
         }
     } else {
         // k_dense_direct stores every bitmap word and tile count of the tiles it covers: nothing to clear
         const uint64_t cap = (uint64_t)ctx->n_cu * 16;
         const uint32_t grid = (uint32_t)(n_tiles < cap ? n_tiles : cap);
-        hipLaunchKernelGGL(k_dense_direct, dim3(grid), dim3(kThreads), 0, ctx->stream, d_bases, n_bases, p->m,
+        hipExtLaunchKernelGGL(k_dense_direct, dim3(grid), dim3(kThreads), 0, ctx->stream, ev_start, ev_stop, 0, d_bases, n_bases, p->m,
                            p->threshold, n_tiles, ctx->bitmap.as<uint32_t>(), ctx->tile_count.as<uint32_t>());
     }
     SPSP_HIP(hipGetLastError());
-    const bool timed = ctx->ev_open[kEvDense];            // (a sampled-out launch has no bracket: spsp_timing_sample)
-    if ((rc = ctx->ev_end(kEvDense))) return rc;
-    // spsp_wait_dense: other streams may start behind the dense pass.  Every event recorded here is a packet the
-    // sparse stages queue behind, so with timing on the timing end-event doubles as the marker.
-    if (timed) {
-        ctx->dense_marker = ctx->evlog[kEvDense].used.back().second;
-    } else {
-        if (!ctx->dense_done) SPSP_HIP(hipEventCreateWithFlags(&ctx->dense_done, hipEventDisableTiming));
-        SPSP_HIP(hipEventRecord(ctx->dense_done, ctx->stream));
-        ctx->dense_marker = ctx->dense_done;
-    }
+    ctx->dense_marker = ev_stop;
     return SPSP_OK;
 }
 // bitmap form: tile counts -> tile offsets (first of the sparse stages)

@@ -17,7 +17,7 @@ echo "bench line done"
 rm -rf /tmp/kt && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o r -- python3 $R/bench.py --no-cpu-baseline --no-extras > $out/bench_line_under_rocprof.json 2>/dev/null || exit 1
 kt=$(find /tmp/kt -name "*kernel_trace.csv"); ks=$(find /tmp/kt -name "*kernel_stats.csv")
 python3 $R/tools/prof_summary.py $kt $out/bench_kernel_summary.md > /dev/null && cp $ks $out/bench_kernel_stats.csv
-python3 $R/tools/timeline.py $kt 3 > $out/bench_timeline.txt
+python3 $R/tools/timeline_mid.py $kt 400 48 > $out/bench_timeline.txt
 echo "kernel trace done"
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$c && timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -o r -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2>&1 || exit 1
