@@ -842,3 +842,58 @@ def test_cu_partitioned_streams_and_sampled_timing():
         scan.close(); cmpc.close()
         for h in (s_d, s_t, s_c):
             sp.stream_destroy(0, h)
+
+
+def test_config2_full_size_stream_and_matrix_equal_oracle(ctx):
+    """BASELINE configs[1] at FULL size (100 genomes x 5 Mbp in 10 families, k31 m11 s1000 -- the workload of bench.py):
+    the whole super-k-mer stream of the 5 x 10^8-base batch, field by field, and the 100 x 100 pair matrix of its
+    sketches equal the oracle's (the oracle needs ~4 s for the scan of the batch)."""
+    import torch
+    k, m, s = 31, 11, 1000.0
+    genomes = synth.family_genomes(2, 100, 5_000_000, 10, [0.001, 0.01])
+    recs = []
+    for i, g in enumerate(genomes):          # 1-3 records per genome, as in bench.py
+        nr = 1 + i % 3
+        cuts = [len(g) * j // nr for j in range(nr + 1)]
+        recs += [g[cuts[j]:cuts[j + 1]] for j in range(nr)]
+    bases, offs = synth.concat_records(recs)
+    p = sp.make_params(k, m, s)
+    d_b = torch.from_numpy(bases).cuda()
+    d_o = torch.from_numpy(offs.view(np.int64)).cuda()
+    d_out, n_out = ctx.scan_device(p, d_b.data_ptr(), d_b.numel(), d_o.data_ptr(), len(recs))
+    got = ctx.to_host(d_out, n_out, sp.SUPERKMER_DTYPE)
+    want = _oracle_stream(k, m, p.threshold, bases, offs)
+    _assert_stream_equal(got, want)
+    assert len(got) > 15_000
+    # sketches of the genomes (host builder over the GPU stream) -> all-vs-all on the GPU vs the oracle's comparator
+    payloads, r0 = [], 0
+    for i, g in enumerate(genomes):
+        nr = 1 + i % 3
+        sel = got[(got["rec"] >= r0) & (got["rec"] < r0 + nr)].copy()
+        sel["rec"] -= r0
+        gb, go = synth.concat_records(recs[r0:r0 + nr])
+        r0 += nr
+        payloads.append(sp.sketch_build(p, s, gb, go, sel)[0])
+    inter, card = ctx.compare(sp.sketches_from_payloads(payloads))
+    want_inter, want_card, _, _ = orc.compare(payloads)
+    assert (inter == want_inter).all() and [int(c) for c in card] == [int(c) for c in want_card]
+    assert int((want_inter > 0).sum()) >= 400          # the family structure is there
+
+
+def test_config3_thousand_sketches_equal_oracle(ctx):
+    """BASELINE configs[2] at full count: 1000 sketches in 50 families of 20 (2-8 k keys each, as bench.py's `compare`
+    object builds them), all 499 500 pairs and every cardinality against the oracle's comparator."""
+    n, k, m, s = 1000, 31, 11, 50.0
+    rng = np.random.default_rng(3)
+    payloads = []
+    p = sp.make_params(k, m, s)
+    for f in range(n // 20):
+        anc = synth.random_genome(rng, int(rng.integers(100_000, 400_000)))
+        for j in range(20):
+            b, o = synth.concat_records([synth.mutate(rng, anc, [0.001, 0.01, 0.05][j % 3])])
+            payloads.append(sp.sketch_build(p, s, b, o, ctx.scan(p, b, o))[0])
+    inter, card = ctx.compare(sp.sketches_from_payloads(payloads))
+    want_inter, want_card, _, _ = orc.compare(payloads)
+    assert (inter == want_inter).all()
+    assert [int(c) for c in card] == [int(c) for c in want_card]
+    assert int((want_inter > 0).sum()) >= 9_000
