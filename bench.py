@@ -118,11 +118,14 @@ def main():
     ctx_full, full_stream = ctx, stream                   # whole-device context: setup and the extras
     if schedule == "partition" and pipelined:
         n_dev_cus = torch.cuda.get_device_properties(dev).multi_processor_count
-        masked = [sp.stream_create_cus(local_rank, small_cus, n_dev_cus - small_cus)]
+        # BENCH_DENSE_FIRST_CU (experiment): the dense stream may start below the small streams' upper end, i.e. share CUs
+        dense_first = int(os.environ.get("BENCH_DENSE_FIRST_CU", str(small_cus)))
+        dense_cus = n_dev_cus - dense_first
+        masked = [sp.stream_create_cus(local_rank, dense_first, dense_cus)]
         stream = torch.cuda.ExternalStream(masked[0], device=dev)
         torch.cuda.set_stream(stream)
         ctx = sp.Context(local_rank, stream.cuda_stream)
-        ctx.set_cu_count(n_dev_cus - small_cus, 2)
+        ctx.set_cu_count(dense_cus, 2)
 
     class Slot:
         pass
@@ -134,7 +137,7 @@ def main():
             sl.stream_a = stream if (i == 0 or schedule != "streams") else torch.cuda.Stream(device=dev)
             sl.scan = ctx if i == 0 else sp.Context(local_rank, sl.stream_a.cuda_stream)
             if schedule == "partition":
-                sl.scan.set_cu_count(n_dev_cus - small_cus, 2)
+                sl.scan.set_cu_count(dense_cus, 2)
                 mode = os.environ.get("BENCH_SMALL_STREAMS", "shared")
                 if i == 0 or mode == "own":
                     # one stream for every slot's sparse stages and one for every comparison by default: every CU-masked
@@ -430,7 +433,7 @@ def main():
                        "step": (("scan(batch t) || all-vs-all(sketches of batch t-1): the chip is partitioned by CU-masked streams -- "
                                  "dense passes back to back on %d CUs (two workgroups each), the scans' sparse stages on one stream and "
                                  "the comparisons on another that share the other %d CUs; the host queues step t+1 before collecting "
-                                 "step t [schedule partition]" % (n_dev_cus - small_cus, small_cus)) if pipelined and schedule == "partition"
+                                 "step t [schedule partition]" % (dense_cus, small_cus)) if pipelined and schedule == "partition"
                                 else "scan(batch t) || all-vs-all(sketches of batch t-1): scans in order on one stream, every slot's "
                                 "comparison on a stream of its own behind its dense pass; the host queues step t+1 before "
                                 "collecting step t [schedule %s]" % schedule if pipelined
