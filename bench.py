@@ -448,7 +448,7 @@ def main():
                          "accumulate_kernel": acc_ms / tm["accumulate_launches"] if tm["accumulate_launches"] else None},
             "superkmers_per_step": int(n_out), "inter_nonzero": inter_nonzero,
             "host_ms_per_step": {"queueing": host["queue"] * 1e3 / args.steps, "waiting": host["collect"] * 1e3 / args.steps},
-            "roofline": {"kernel": "k_dense_pair (2-bit pack + LDS pair-table test of every m-mer position; XXH64 on survivors)", "bound": "hbm",
+            "roofline": {"kernel": "k_dense_pair (non-temporal 16-byte loads, 2-bit pack, LDS pair-table test of every m-mer position; XXH64 on survivors)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "algorithmic_bytes_per_launch": int(d_bases.numel()),
                          "byte_model": "1 B per m-mer position (cleaned ASCII, as getLineFasta returns it)",
@@ -509,7 +509,8 @@ def pmc_traffic(args, kernel):
         w = d["workload"]
         if (w["genomes"], w["genome_len"], w["k"], w["m"], w["s"], w["scan_mode"]) != (args.genomes, args.length, K, M, S, args.mode):
             return {"traffic": None}
-        return {"traffic": d["kernels"][kernel]["hbm_bytes_per_launch_corrected"],
+        names = [n for n in d["kernels"] if n == kernel or n.startswith(kernel + "<")]     # (template instances: k_dense_pair<true>)
+        return {"traffic": d["kernels"][names[0]]["hbm_bytes_per_launch_corrected"],
                 "traffic_provenance": {"file": "profiles/" + name, "commit": d.get("commit"),
                                        "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled (gfx950)"}}
     except Exception:
