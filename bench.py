@@ -470,6 +470,29 @@ def main():
                                         "frac": d_bases.numel() / 1e9 / (alone_ms / 1e3) / HBM_PEAK_GBS, "launches": int(ta["dense_launches"])}
         except Exception as e:  # noqa: BLE001
             out["roofline"]["alone"] = {"error": repr(e)}
+        # ... on the whole chip (context without CU mask), ASCII and 2-bit input (SURVEY.md 8d's second byte model: the
+        # same positions from a quarter of the bytes -- that form is bound by the LDS table reads, not by HBM)
+        try:
+            out["roofline"]["whole_chip"] = {}
+            ctx_full.set_cu_count(0, 2)
+            torch.cuda.synchronize()
+            d_pk = ctx_full.pack_bases_device(d_bases.data_ptr(), d_bases.numel())
+            for name, src, flg, bpp in (("ascii", d_bases.data_ptr(), 0, 1.0), ("packed_2bit", d_pk, sp.SPSP_SCAN_PACKED_INPUT, 0.25)):
+                pw = sp.make_params(K, M, S, flags=flags | flg)
+                ctx_full.scan_hits_device(pw, src, d_bases.numel())
+                ctx_full.timing_enable(True, sp.TIME_DENSE)
+                ctx_full.timing_read()
+                for _ in range(20):
+                    ctx_full.scan_hits_device(pw, src, d_bases.numel())
+                tw = ctx_full.timing_read()
+                ctx_full.timing_enable(False)
+                ms_w = tw["dense_ms"] / max(1, tw["dense_launches"])
+                gbs = bpp * d_bases.numel() / 1e9 / (ms_w / 1e3)
+                out["roofline"]["whole_chip"][name] = {"dense_kernel_ms": ms_w, "positions_per_s": d_bases.numel() / (ms_w / 1e3),
+                                                       "byte_model": "%g B per m-mer position" % bpp, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS}
+            ctx_full.set_cu_count(0, 1)
+        except Exception as e:  # noqa: BLE001
+            out["roofline"]["whole_chip"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(recs, payloads, p, int(n_out), d_inter)
         if world == 1 and not args.no_extras:

@@ -52,6 +52,7 @@ typedef struct spsp_params {
 #define SPSP_SCAN_DIRECT_HASH 1u /* force XXH64 at every position (no LDS pre-filter) */
 #define SPSP_SCAN_LDS_FILTER 2u  /* force the 2^20-bit memoised LDS pre-filter (one lookup per position) */
 #define SPSP_SCAN_PAIR_FILTER 4u /* force the 64 KiB pair table (one lookup per two positions, m >= 9) */
+#define SPSP_SCAN_PACKED_INPUT 32u /* device forms only: d_bases holds 2-bit codes (spsp_pack_bases_device), not ASCII */
 #define SPSP_SCAN_BLOOM_FILTER 16u /* force the blocked Bloom filter over canonical m-mers (m = 13 or 15) */
 #define SPSP_SCAN_STATS 8u       /* spsp_sketch_text / spsp_sketch_file: also count EVERY super-k-mer of the input
                                     (total_superkmer_number of print_stat, SubSampler.cpp:430,452) -- an extra pass */
@@ -154,6 +155,14 @@ int spsp_scan(spsp_ctx* ctx, const spsp_params* p, const uint8_t* bases, const u
  * host synchronisation that reads back *n_out. */
 int spsp_scan_device(spsp_ctx* ctx, const spsp_params* p, const void* d_bases, uint64_t n_bases,
                      const void* d_rec_off, uint32_t n_rec, void** d_out, uint64_t* n_out);
+
+/* 2-bit input (0.25 B per k-mer hashed).  spsp_pack_bases_device turns `n_bases` cleaned ASCII bases on the
+ * device into the packed form -- 16 bases per little-endian 32-bit word, first base in bits 31:30, A=0 C=1 T=2 G=3, the
+ * last word zero-filled and 256 readable bytes behind it -- in a buffer the context owns (valid until its next pack call).
+ * A scan whose spsp_params.flags carry SPSP_SCAN_PACKED_INPUT takes that buffer as d_bases (n_bases stays the number of
+ * BASES; record offsets are base offsets as ever).  The pair-table dense pass reads it directly: a quarter of the
+ * traffic, no packing arithmetic; the other variants unpack it into an ASCII copy first.  Same stream out. */
+int spsp_pack_bases_device(spsp_ctx* ctx, const void* d_bases, uint64_t n_bases, void** d_packed);
 
 /* The same call split at its host synchronisation, for callers that pipeline several streams (one context
  * per stream): _begin queues the whole scan on the context's stream and returns at once; _end waits for it,

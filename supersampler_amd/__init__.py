@@ -23,6 +23,7 @@ SPSP_SCAN_LDS_FILTER = 2
 SPSP_SCAN_PAIR_FILTER = 4
 SPSP_SCAN_STATS = 8
 SPSP_SCAN_BLOOM_FILTER = 16
+SPSP_SCAN_PACKED_INPUT = 32
 
 
 class SpspError(RuntimeError):
@@ -68,7 +69,7 @@ SUPERKMER_DTYPE = np.dtype([("rec", "<u4"), ("minimizer", "<u4"), ("start", "<u8
 # every symbol include/spsp.h declares (tests check the .so exports them all)
 ABI_SYMBOLS = [
     "spsp_create", "spsp_destroy", "spsp_last_error", "spsp_version", "spsp_free", "spsp_copy_to_host",
-    "spsp_stream_create_cus", "spsp_stream_destroy", "spsp_set_cu_count",
+    "spsp_stream_create_cus", "spsp_stream_destroy", "spsp_set_cu_count", "spsp_pack_bases_device",
     "spsp_timing_enable", "spsp_timing_sample", "spsp_timing_read", "spsp_threshold_host", "spsp_scan", "spsp_scan_device", "spsp_scan_device_begin", "spsp_scan_device_end", "spsp_scan_tail_stream", "spsp_wait_dense", "spsp_wait_stream", "spsp_scan_hits_device", "spsp_count_superkmers_device", "spsp_compare",
     "spsp_compare_device", "spsp_slot_bytes", "spsp_partition_keys_device", "spsp_compare_slots_device", "spsp_compare_device_begin", "spsp_compare_slots_device_begin", "spsp_compare_end", "spsp_fasta_clean_host", "spsp_fasta_clean_device", "spsp_sketch_text", "spsp_sketch_build_host", "spsp_sketch_parse_host", "spsp_sketch_decode_device", "spsp_sketch_chain_host",
     "spsp_csv_host", "spsp_sort_csv_host", "spsp_read_file_host", "spsp_write_gz_host", "spsp_sketch_file", "spsp_compare_files", "spsp_compare_files_chatty", "spsp_stage_times_read",
@@ -96,6 +97,7 @@ def lib():
     L.spsp_stream_create_cus.restype = i32; L.spsp_stream_create_cus.argtypes = [i32, u32, u32, P(vp)]
     L.spsp_stream_destroy.restype = i32; L.spsp_stream_destroy.argtypes = [i32, vp]
     L.spsp_set_cu_count.restype = i32; L.spsp_set_cu_count.argtypes = [vp, u32, u32]
+    L.spsp_pack_bases_device.restype = i32; L.spsp_pack_bases_device.argtypes = [vp, vp, u64, P(vp)]
     L.spsp_timing_enable.restype = i32; L.spsp_timing_enable.argtypes = [vp, i32]
     L.spsp_timing_read.restype = i32; L.spsp_timing_read.argtypes = [vp, P(Timing)]
     L.spsp_timing_sample.restype = i32; L.spsp_timing_sample.argtypes = [vp, u32]
@@ -354,6 +356,12 @@ class Context:
         _check(lib().spsp_scan_device(self._h, C.byref(params), d_bases, n_bases, d_rec_off, n_rec, C.byref(out),
                                       C.byref(n)))
         return out.value, n.value
+
+    def pack_bases_device(self, d_bases, n_bases):
+        """cleaned ASCII bases on the device -> 2-bit packed buffer owned by the context (for SPSP_SCAN_PACKED_INPUT)"""
+        out = C.c_void_p()
+        _check(lib().spsp_pack_bases_device(self._h, d_bases, n_bases, C.byref(out)))
+        return out.value
 
     def scan_device_begin(self, params, d_bases, n_bases, d_rec_off, n_rec):
         """queue the scan on the context's stream and return; collect with scan_device_end()"""

@@ -213,7 +213,7 @@ void spsp_destroy(spsp_ctx* c) {
     if (c->scan_done) (void)hipEventDestroy(c->scan_done);
     if (c->compare_done) (void)hipEventDestroy(c->compare_done);
     DevBuf* bufs[] = {&c->bases, &c->rec_off, &c->bitmap, &c->tile_count, &c->tile_off, &c->hits, &c->emit_count,
-                      &c->scan_tmp, &c->d_scalar, &c->seg_a, &c->seg_b, &c->wave_hits, &c->wave_cnt, &c->st_count, &c->st_open, &c->filter, &c->bloom, &c->pairtab, &c->c_min, &c->c_lo, &c->c_hi, &c->c_table,
+                      &c->scan_tmp, &c->d_scalar, &c->seg_a, &c->seg_b, &c->wave_hits, &c->wave_cnt, &c->packed, &c->unpacked, &c->st_count, &c->st_open, &c->filter, &c->bloom, &c->pairtab, &c->c_min, &c->c_lo, &c->c_hi, &c->c_table,
                       &c->c_owner, &c->c_rowid, &c->c_row, &c->x_cnt, &c->x_off, &c->x_begin, &c->x_end, &c->x_tot, &c->dc_text, &c->dc_desc, &c->dc_mn, &c->dc_lo, &c->dc_hi, &c->dc_meta, &c->a_cnt, &c->a_off, &c->a_mn, &c->a_lo, &c->a_hi, &c->a_slot, &c->a_slot_of, &c->a_flags, &c->c_matrix, &c->c_inter, &c->c_flags, &c->c_slot_lo, &c->c_slot_hi, &c->c_slot_mn, &c->c_part_cnt, &c->c_recs, &c->c_where, &c->c_lref,
                       &c->c_skoff, &c->i_text, &c->i_tiles, &c->i_entry, &c->i_outoff, &c->i_recbase, &c->i_lens, &c->i_dst,
                       &c->i_compact};
@@ -244,6 +244,7 @@ int spsp_scan(spsp_ctx* ctx, const spsp_params* p, const uint8_t* bases, const u
     *out = nullptr; *n_out = 0;
     int rc = check_params(p);
     if (rc) return rc;
+    if (p->flags & SPSP_SCAN_PACKED_INPUT) { set_error("SPSP_SCAN_PACKED_INPUT is for the device forms (spsp_scan_device...)"); return SPSP_ERR_ARG; }
     if (n_rec == 0) return SPSP_OK;
     if (!bases || !rec_off) { set_error("NULL argument"); return SPSP_ERR_ARG; }
     if (rec_off[0] != 0) { set_error("rec_off[0] must be 0"); return SPSP_ERR_ARG; }
@@ -277,6 +278,15 @@ int spsp_scan_device(spsp_ctx* ctx, const spsp_params* p, const void* d_bases, u
     spsp_superkmer* o = nullptr;
     int rc = scan_device_impl(ctx, p, (const uint8_t*)d_bases, n_bases, (const uint64_t*)d_rec_off, n_rec, &o, n_out);
     *d_out = o;
+    return rc;
+}
+
+int spsp_pack_bases_device(spsp_ctx* ctx, const void* d_bases, uint64_t n_bases, void** d_packed) {
+    if (!ctx || !d_packed || (n_bases && !d_bases)) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    SPSP_HIP(hipSetDevice(ctx->device));
+    uint32_t* o = nullptr;
+    const int rc = pack_bases_impl(ctx, (const uint8_t*)d_bases, n_bases, &o);
+    *d_packed = o;
     return rc;
 }
 

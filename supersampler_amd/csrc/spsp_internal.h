@@ -106,6 +106,7 @@ struct spsp_ctx {
     // scan workspace
     spsp::DevBuf bases, rec_off, bitmap, tile_count, tile_off, hits, emit_count, scan_tmp, d_scalar, seg_a, seg_b;
     spsp::DevBuf wave_hits, wave_cnt;    // per-wave hit lists of the table variants of the dense pass
+    spsp::DevBuf packed, unpacked;       // SPSP_SCAN_PACKED_INPUT: spsp_pack_bases_device's output; ASCII copy for the variants that need one
     spsp::DevBuf st_count, st_open;      // print_stat counting pass (spsp_stats.hip)
     uint64_t hits_cap = 0, out_cap = 0;  // entries the sparse-stage buffers are sized for (grow on overflow)
     uint64_t list_cap = 0;               // hits one wave's list holds (grows on overflow)
@@ -154,6 +155,7 @@ int compare_device_begin_impl(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min, 
 int compare_end_impl(spsp_ctx* ctx);
 void compare_job_drop(spsp_ctx* ctx);
 int check_params(const spsp_params* p);
+int pack_bases_impl(spsp_ctx* ctx, const uint8_t* d_bases, uint64_t n_bases, uint32_t** d_packed);
 // every super-k-mer of the input, selected or not (spsp_stats.hip)
 int count_superkmers_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, uint64_t n_bases, const uint64_t* d_rec_off,
                           uint32_t n_rec, uint64_t* total);

@@ -74,6 +74,18 @@ __device__ __forceinline__ uint4 load_row16(const uint8_t* __restrict__ p) {
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
+// ASCII <-> packed input (SPSP_SCAN_PACKED_INPUT): thread t makes / expands dword t = bases 16t .. 16t+15
+__global__ __launch_bounds__(256) void k_pack_bases(const uint8_t* __restrict__ bases, uint64_t n, uint32_t* __restrict__ packed, uint64_t n_dw_padded) {
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_dw_padded; t += (uint64_t)gridDim.x * blockDim.x)
+        packed[t] = t * kChunk < n ? load_pack(bases, n, t * kChunk) : 0u;
+}
+__global__ __launch_bounds__(256) void k_unpack_bases(const uint32_t* __restrict__ packed, uint64_t n, uint8_t* __restrict__ bases) {
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t * kChunk < n; t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t w = packed[t];
+        for (uint32_t j = 0; j < (uint32_t)kChunk && t * kChunk + j < n; ++j) bases[t * kChunk + j] = "ACTG"[(w >> (30 - 2 * j)) & 3u];
+    }
+}
+
 // ------------------------------------------------- dense pass, direct form ---
 // XXH64 at every position: the variant for dense selections (small -s), where
 // nearly every lane has to hash anyway.  A workgroup stages one tile of kTilePos
@@ -319,7 +331,11 @@ __device__ __attribute__((noinline)) uint32_t drain_pair(const uint4* __restrict
     return append_hits(is_hit, pos, x, f, hash, out, out_cap, out_n);
 }
 
-template <bool MID>
+// PACKED: `bases` holds 2-bit codes, 16 bases per little-endian dword with the first base in bits 31:30 -- exactly the
+// word pack16 makes of 16 ASCII bytes (k_pack_bases; SPSP_SCAN_PACKED_INPUT).  A lane's chunk is ONE dword, a wave-row
+// 252 bytes: a quarter of the traffic, no packing arithmetic, four rows in flight per wave.  On this byte model
+// (0.25 B per position) the pass is bound by its LDS lookups, not by HBM.
+template <bool MID, bool PACKED>
 __global__ __launch_bounds__(64 * kPairWaves) void k_dense_pair(const uint8_t* __restrict__ bases, uint64_t n, uint32_t m,
                                                                uint64_t thr, const uint8_t* __restrict__ pairtab,
                                                                uint64_t n_rows, WaveLists L) {
@@ -415,6 +431,50 @@ __global__ __launch_bounds__(64 * kPairWaves) void k_dense_pair(const uint8_t* _
         push_row(lane < (uint32_t)kRowChunks ? cb : none, rel_b, hib, nxb);
     };
 
+    if (PACKED) {
+        const uint32_t* b32 = reinterpret_cast<const uint32_t*>(bases);
+        const uint64_t n_dw = (n + kChunk - 1) / kChunk;                        // dwords that hold bases (the tail of the last one is 0)
+        const uint64_t full_p = n_dw >= 64 ? (n_dw - 64) / kRowChunks + 1 : 0;  // rows whose 64 dwords (halo included) exist
+        const uint64_t nf_all = first < full_p ? full_p - first : 0;
+        const uint64_t nf = nf_all < n_my ? nf_all : n_my;
+        const uint32_t* p = b32 + first * kRowChunks + lane;
+        constexpr uint32_t rs = kRowChunks;                                     // dwords per row
+        uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+        if (0 < nf) r0 = __builtin_nontemporal_load(p);
+        if (1 < nf) r1 = __builtin_nontemporal_load(p + rs);
+        if (2 < nf) r2 = __builtin_nontemporal_load(p + 2 * rs);
+        if (3 < nf) r3 = __builtin_nontemporal_load(p + 3 * rs);
+        uint64_t i = 0;
+        uint32_t rel = lane * kChunk;
+        const uint32_t rel_step = (uint32_t)kRowPosPair63;
+        for (; i + 3 < nf; i += 4, p += 4 * rs, rel += 4 * rel_step) {
+            // unconditional refills (see the ASCII form): past its last row a wave re-reads its current one
+            const uint32_t hia = r0; r0 = __builtin_nontemporal_load(i + 4 < nf ? p + 4 * rs : p);
+            const uint32_t nxa = next_lane(hia);
+            const PairSurv ca = pair_lookup16<MID>(tab, hia, nxa);
+            const uint32_t hib = r1; r1 = __builtin_nontemporal_load(i + 5 < nf ? p + 5 * rs : p);
+            const uint32_t nxb = next_lane(hib);
+            const PairSurv cb = pair_lookup16<MID>(tab, hib, nxb);
+            handle(ca, cb, rel, hia, nxa, rel + rel_step, hib, nxb);
+            const uint32_t hic = r2; r2 = __builtin_nontemporal_load(i + 6 < nf ? p + 6 * rs : p);
+            const uint32_t nxc = next_lane(hic);
+            const PairSurv cc = pair_lookup16<MID>(tab, hic, nxc);
+            const uint32_t hid = r3; r3 = __builtin_nontemporal_load(i + 7 < nf ? p + 7 * rs : p);
+            const uint32_t nxd = next_lane(hid);
+            const PairSurv cd = pair_lookup16<MID>(tab, hid, nxd);
+            handle(cc, cd, rel + 2 * rel_step, hic, nxc, rel + 3 * rel_step, hid, nxd);
+        }
+        const PairSurv none = {0u, 0u, 0u};
+        for (; i < n_my; ++i, rel += rel_step) {        // up to three rows left, and the rows at the end of the buffer
+            const uint64_t at = (first + i) * kRowChunks + lane;
+            const uint32_t hi = at < n_dw ? b32[at] : 0u;
+            const uint32_t nxt = next_lane(hi);
+            handle(pair_lookup16<MID>(tab, hi, nxt), none, rel, hi, nxt, rel, hi, nxt);
+        }
+        drain();
+        if (lane == 0) L.cnt[gw] = out_n;
+        return;
+    }
     // rows whose 64 chunks lie completely inside the buffer take the vector path
     const uint64_t full_rows = n >= 64 * kChunk ? (n - 64 * kChunk) / kRowPosPair63 + 1 : 0;
     const uint64_t n_fast_all = first < full_rows ? full_rows - first : 0;
@@ -1453,12 +1513,40 @@ static int plan_lists(spsp_ctx* ctx, const spsp_params* p, int variant, uint64_t
     return SPSP_OK;
 }
 
+// SPSP_SCAN_PACKED_INPUT: only the pair-table pass reads 2-bit input; every other variant (and the bitmap fallback) gets
+// an ASCII copy made on the device.  Returns the buffer and flags the pass should use.
+static int unpack_if_needed(spsp_ctx* ctx, spsp_params* p, const uint8_t** d_bases, uint64_t n_bases, bool use_bitmap) {
+    if (!(p->flags & SPSP_SCAN_PACKED_INPUT)) return SPSP_OK;
+    if (!use_bitmap && pick_dense(p) == kDensePair) return SPSP_OK;
+    int rc = ctx->unpacked.reserve((size_t)n_bases + 64);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_unpack_bases, dim3((uint32_t)std::min<uint64_t>((n_bases / kChunk + 256) / 256, (uint64_t)ctx->n_cu * 32)), dim3(256), 0,
+                       ctx->stream, reinterpret_cast<const uint32_t*>(*d_bases), n_bases, ctx->unpacked.as<uint8_t>());
+    SPSP_HIP(hipGetLastError());
+    *d_bases = ctx->unpacked.as<uint8_t>();
+    p->flags &= ~SPSP_SCAN_PACKED_INPUT;
+    return SPSP_OK;
+}
+
+int pack_bases_impl(spsp_ctx* ctx, const uint8_t* d_bases, uint64_t n_bases, uint32_t** d_packed) {
+    const uint64_t n_dw = (n_bases + kChunk - 1) / kChunk + 64;           // + halo dwords, zero
+    int rc = ctx->packed.reserve((size_t)n_dw * 4);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_pack_bases, dim3((uint32_t)std::min<uint64_t>((n_dw + 255) / 256, (uint64_t)ctx->n_cu * 32)), dim3(256), 0, ctx->stream,
+                       d_bases, n_bases, ctx->packed.as<uint32_t>(), n_dw);
+    SPSP_HIP(hipGetLastError());
+    *d_packed = ctx->packed.as<uint32_t>();
+    return SPSP_OK;
+}
+
 // dense pass of one attempt; *lists = per-wave hit lists were produced (table variants), else bitmap + tile counts
 static int launch_dense(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, uint64_t n_bases,
                         uint64_t n_tiles, bool use_bitmap, ListPlan* LP, bool* lists) {
     int rc;
     const int variant = use_bitmap ? kDenseDirect : pick_dense(p);
     *lists = variant != kDenseDirect;
+    const bool packed_in = (p->flags & SPSP_SCAN_PACKED_INPUT) != 0;      // (only the pair-table pass gets here with it: unpack_if_needed)
+    if (packed_in && variant != kDensePair) { set_error("internal: packed input reached the %d dense variant", variant); return SPSP_ERR_ARG; }
     if ((rc = ctx->d_scalar.reserve(64))) return rc;
     if (*lists) {
         if ((rc = plan_lists(ctx, p, variant, n_bases, LP))) return rc;
@@ -1487,16 +1575,16 @@ static int launch_dense(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_ba
         if (variant == kDensePair) {
             const size_t lds = (size_t)kPairWaves * kQueueCap * 16;                // + 64 KiB static table
             if (!ctx->attr_pair_set) {
-                SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_pair<false>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_pair<true>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                const void* ks[4] = {reinterpret_cast<const void*>(&k_dense_pair<false, false>), reinterpret_cast<const void*>(&k_dense_pair<true, false>),
+                                     reinterpret_cast<const void*>(&k_dense_pair<false, true>), reinterpret_cast<const void*>(&k_dense_pair<true, true>)};
+                for (const void* kf : ks) SPSP_HIP(hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 ctx->attr_pair_set = true;
             }
-            if (p->m >= 10) hipExtLaunchKernelGGL(k_dense_pair<true>, dim3(LP->grid), dim3(64 * kPairWaves), lds, ctx->stream, ev_start, ev_stop, 0, d_bases, n_bases,
-                                               p->m, p->threshold, ctx->pairtab.as<uint8_t>(), LP->n_rows, L);
-            else hipExtLaunchKernelGGL(k_dense_pair<false>, dim3(LP->grid), dim3(64 * kPairWaves), lds, ctx->stream, ev_start, ev_stop, 0, d_bases, n_bases, p->m,
-                                    p->threshold, ctx->pairtab.as<uint8_t>(), LP->n_rows, L);
+#define SPSP_PAIR(MIDV, PK) hipExtLaunchKernelGGL((k_dense_pair<MIDV, PK>), dim3(LP->grid), dim3(64 * kPairWaves), lds, ctx->stream, ev_start, ev_stop, 0, \
+                                                  d_bases, n_bases, p->m, p->threshold, ctx->pairtab.as<uint8_t>(), LP->n_rows, L)
+            if (packed_in) { if (p->m >= 10) SPSP_PAIR(true, true); else SPSP_PAIR(false, true); }
+            else { if (p->m >= 10) SPSP_PAIR(true, false); else SPSP_PAIR(false, false); }
+#undef SPSP_PAIR
         } else if (variant == kDenseBloom) {
             const size_t lds = (size_t)kBloomBytes + (size_t)kPairWaves * kQueueCap1 * 8;
             if (!ctx->attr_bloom_set) {
@@ -1552,6 +1640,9 @@ int scan_hits_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, 
     if (n_tiles > 0x7fffffffull) { set_error("input too large for one call"); return SPSP_ERR_OVERFLOW; }
     ListPlan LP{};
     bool lists = false;
+    spsp_params pp = *p;
+    if ((rc = unpack_if_needed(ctx, &pp, &d_bases, n_bases, false))) return rc;
+    p = &pp;
     if ((rc = launch_dense(ctx, p, d_bases, n_bases, n_tiles, false, &LP, &lists))) return rc;
     if (lists) {
         hipLaunchKernelGGL(k_sum_counts, dim3(1), dim3(1024), 0, ctx->stream, ctx->wave_cnt.as<uint32_t>(), LP.n_lists,
@@ -1600,6 +1691,7 @@ static int scan_enqueue(spsp_ctx* ctx) {
     uint32_t* d_sc = ctx->d_scalar.as<uint32_t>();
     if (J.redo_from == 0) {
         ListPlan LP{};
+        if ((rc = unpack_if_needed(ctx, &J.p, &J.d_bases, J.n_bases, J.use_bitmap))) return rc;
         if ((rc = launch_dense(ctx, p, J.d_bases, J.n_bases, J.n_tiles, J.use_bitmap, &LP, &J.lists))) return rc;
         if (J.lists) { J.n_lists = LP.n_lists; J.list_cap = LP.cap; J.rows_per_wave = LP.rows_per_wave; }
     }

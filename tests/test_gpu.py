@@ -897,3 +897,31 @@ def test_config3_thousand_sketches_equal_oracle(ctx):
     assert (inter == want_inter).all()
     assert [int(c) for c in card] == [int(c) for c in want_card]
     assert int((want_inter > 0).sum()) >= 9_000
+
+
+@pytest.mark.parametrize("k,m,s,mode", [(31, 11, 1000, 0), (31, 11, 150, 0), (21, 9, 300, sp.SPSP_SCAN_PAIR_FILTER), (31, 11, 20, 0), (63, 15, 100, 0), (31, 11, 1.0, 0),
+                                        (33, 13, 50, 0), (31, 11, 1000, sp.SPSP_SCAN_PAIR_FILTER)])
+def test_scan_packed_input_equals_oracle(ctx, k, m, s, mode):
+    """SPSP_SCAN_PACKED_INPUT: the same records as 2-bit words (spsp_pack_bases_device) give the oracle's stream -- read
+    directly by the pair-table pass (both flavours of its second bit, m = 9 and m >= 10), through an ASCII copy made on the
+    device by every other variant; record lengths that are no multiple of 16, inputs shorter than a wave-row, the
+    dense-only entry point."""
+    import torch
+    rng = np.random.default_rng(31 * k + m)
+    for lens in ([700_003, 5, 40_000, 1_234_567, 17], [900], [64 * 16 + 3], [130_001]):
+        recs = [synth.random_genome(rng, n) for n in lens]
+        if len(lens) > 1:
+            recs[2] = np.tile(synth.random_genome(rng, 37), 1100)[:40_000]      # a tandem repeat: duplicate minimizers
+        bases, offs = synth.concat_records(recs)
+        p = sp.make_params(k, m, s, flags=mode | sp.SPSP_SCAN_PACKED_INPUT)
+        d_b = torch.from_numpy(bases).cuda()
+        d_o = torch.from_numpy(offs.view(np.int64)).cuda()
+        torch.cuda.synchronize()
+        d_pk = ctx.pack_bases_device(d_b.data_ptr(), d_b.numel())
+        d_out, n_out = ctx.scan_device(p, d_pk, d_b.numel(), d_o.data_ptr(), len(recs))
+        got = ctx.to_host(d_out, n_out, sp.SUPERKMER_DTYPE) if n_out else np.zeros(0, sp.SUPERKMER_DTYPE)
+        _assert_stream_equal(got, _oracle_stream(k, m, p.threshold, bases, offs))
+        pa = sp.make_params(k, m, s, flags=mode)
+        assert ctx.scan_hits_device(p, d_pk, d_b.numel()) == ctx.scan_hits_device(pa, d_b.data_ptr(), d_b.numel())
+    with pytest.raises(sp.SpspError):            # the host-buffer form takes ASCII only
+        ctx.scan(sp.make_params(k, m, s, flags=sp.SPSP_SCAN_PACKED_INPUT), bases, offs)

@@ -22,16 +22,19 @@ acgt = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=dev)
 bases = acgt[torch.randint(0, 4, (n,), device=dev, generator=g)]
 torch.cuda.synchronize()
 ctx = sp.Context(0, torch.cuda.current_stream().cuda_stream or None)
-for name, flag in (("pair", sp.SPSP_SCAN_PAIR_FILTER), ("single", sp.SPSP_SCAN_LDS_FILTER), ("bloom", sp.SPSP_SCAN_BLOOM_FILTER),
-                   ("direct", sp.SPSP_SCAN_DIRECT_HASH), ("default", sp.SPSP_SCAN_DEFAULT)):
+d_packed = ctx.pack_bases_device(bases.data_ptr(), n)
+for name, flag in (("pair", sp.SPSP_SCAN_PAIR_FILTER), ("pair2bit", sp.SPSP_SCAN_PAIR_FILTER | sp.SPSP_SCAN_PACKED_INPUT), ("single", sp.SPSP_SCAN_LDS_FILTER),
+                   ("bloom", sp.SPSP_SCAN_BLOOM_FILTER), ("direct", sp.SPSP_SCAN_DIRECT_HASH), ("default", sp.SPSP_SCAN_DEFAULT)):
     if os.environ.get("ONLY") and os.environ["ONLY"] != name:
         continue
     p = sp.make_params(k, m, s, flags=flag)
-    hits = ctx.scan_hits_device(p, bases.data_ptr(), n)
+    src = d_packed if flag & sp.SPSP_SCAN_PACKED_INPUT else bases.data_ptr()
+    hits = ctx.scan_hits_device(p, src, n)
     ctx.timing_enable(True); ctx.timing_read()
     reps = 10
     for _ in range(reps):
-        ctx.scan_hits_device(p, bases.data_ptr(), n)
+        ctx.scan_hits_device(p, src, n)
     t = ctx.timing_read()
     ms = t["dense_ms"] / t["dense_launches"]
-    print("%-9s hits=%d  dense %.4f ms  -> %.1f GB/s (%.1f%% of 8 TB/s)" % (name, hits, ms, n / ms / 1e6, n / ms / 1e6 / 80.0), flush=True)
+    byts = n / 4 if flag & sp.SPSP_SCAN_PACKED_INPUT else n
+    print("%-9s hits=%d  dense %.4f ms  -> %.2e positions/s, %.1f GB/s (%.1f%% of 8 TB/s)" % (name, hits, ms, n / ms * 1e3, byts / ms / 1e6, byts / ms / 1e6 / 80.0), flush=True)
