@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 --pmc counter_collection CSVs for one kernel: per-launch averages of the largest-grid launches.
+"""Summarise rocprofv3 --pmc counter_collection CSVs for one kernel: per-launch averages of the launches with the most frequent grid (the steps).
 usage: tools/pmc_sq.py <kernel substring> <counter_collection.csv> [more csv ...]"""
 import csv
 import sys
@@ -13,7 +13,8 @@ def main():
         rows = [r for r in csv.DictReader(open(path)) if want in r["Kernel_Name"]]
         if not rows:
             continue
-        gmax = max(int(r["Grid_Size"]) for r in rows)
+        from collections import Counter
+        gmax = Counter(int(r["Grid_Size"]) for r in rows).most_common(1)[0][0]    # the steps' grid (extras launch others)
         per = defaultdict(dict)
         for r in rows:
             if int(r["Grid_Size"]) == gmax:

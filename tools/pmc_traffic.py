@@ -19,7 +19,8 @@ def per_kernel(path, counter):
         by[name].append((int(r["Grid_Size"]), float(r["Counter_Value"])))
     out = {}
     for name, rows in by.items():
-        gmax = max(g for g, _ in rows)
+        from collections import Counter
+        gmax = Counter(g for g, v in rows if v >= 0.5 * max(x for _, x in rows)).most_common(1)[0][0]   # the steps' grid
         vals = sorted(v for g, v in rows if g == gmax)
         vals = [v for v in vals if v >= 0.5 * vals[-1]] or vals
         out[name] = sum(vals) / len(vals)
@@ -47,7 +48,7 @@ def main():
         "note": "FETCH_SIZE/WRITE_SIZE are reported in KiB. MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports exactly 1/2 "
                 "of the bytes of a wide coalesced streaming read (16 B/lane), so fetch_bytes_corrected = 2 * FETCH_SIZE * 1024; "
                 "WRITE_SIZE is exact for 16 B/lane stores and per-dword atomics. Per-launch averages over the timed-step "
-                "launches (largest grid, >= half of the largest value).",
+                "launches (most frequent grid among the large ones, >= half of the largest value).",
         "workload": {"genomes": 100, "genome_len": 5000000, "k": 31, "m": 11, "s": 1000.0, "scan_mode": "default"},
         "commit": commit(),
         "kernels": kernels,

@@ -29,8 +29,8 @@ for set in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES SQ_INSTS_LDS" "S
   d=/tmp/pmc_sq_$(echo $set | cut -d" " -f1); rm -rf $d
   timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d $d -o r -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2>&1 || exit 1
 done
-python3 $R/tools/pmc_sq.py k_dense_pair $(find /tmp/pmc_sq_* -name "*counter_collection.csv") > $out/pmc_sq_k_dense_pair.txt
-python3 $R/tools/pmc_sq.py k_dense_pair $out/pmc_FETCH_SIZE.csv $out/pmc_WRITE_SIZE.csv >> $out/pmc_sq_k_dense_pair.txt
+python3 $R/tools/pmc_sq.py "k_dense_pair<true, false>" $(find /tmp/pmc_sq_* -name "*counter_collection.csv") > $out/pmc_sq_k_dense_pair.txt
+python3 $R/tools/pmc_sq.py "k_dense_pair<true, false>" $out/pmc_FETCH_SIZE.csv $out/pmc_WRITE_SIZE.csv >> $out/pmc_sq_k_dense_pair.txt
 rm -f $out/pmc_FETCH_SIZE.csv $out/pmc_WRITE_SIZE.csv
 echo "sq done"
 fi
