@@ -95,7 +95,15 @@ def main():
         bases, offs = synth.concat_records(recs)
         mode = int(rng.choice(modes))
         p = sp.make_params(k, m, s, flags=mode)
-        got = ctx.scan(p, bases, offs)
+        if n_scan % 3 == 1 and len(bases) >= k:      # the same records as 2-bit words (SPSP_SCAN_PACKED_INPUT), device form
+            d_b = torch.from_numpy(bases).cuda()
+            d_o = torch.from_numpy(offs.view(np.int64)).cuda()
+            torch.cuda.synchronize()
+            pp = sp.make_params(k, m, s, flags=mode | sp.SPSP_SCAN_PACKED_INPUT)
+            d_out, n_out = ctx.scan_device(pp, ctx.pack_bases_device(d_b.data_ptr(), d_b.numel()), d_b.numel(), d_o.data_ptr(), len(recs))
+            got = ctx.to_host(d_out, n_out, sp.SUPERKMER_DTYPE) if n_out else np.zeros(0, sp.SUPERKMER_DTYPE)
+        else:
+            got = ctx.scan(p, bases, offs)
         want, _ = orc.scan(k, m, p.threshold, bases, offs)
         ok = len(got) == len(want) and all((np.asarray(got[f]) == np.asarray(want[f])).all() for f in ("rec", "minimizer", "start", "len", "rev"))
         if not ok:
