@@ -117,6 +117,12 @@ def main():
     small_cus = int(os.environ.get("BENCH_SMALL_CUS", "64"))
     ctx_full, full_stream = ctx, stream                   # whole-device context: setup and the extras
     if schedule == "partition" and pipelined:
+        try:                                              # (a runtime without CU masks: fall back to the unpartitioned schedule)
+            sp.stream_destroy(local_rank, sp.stream_create_cus(local_rank, 0, 32))
+        except sp.SpspError as e:
+            log("CU-masked streams unavailable (%s): schedule 'single'" % e)
+            schedule, tail_streams = "single", False
+    if schedule == "partition" and pipelined:
         n_dev_cus = torch.cuda.get_device_properties(dev).multi_processor_count
         # BENCH_DENSE_FIRST_CU (experiment): the dense stream may start below the small streams' upper end, i.e. share CUs
         dense_first = int(os.environ.get("BENCH_DENSE_FIRST_CU", str(small_cus)))

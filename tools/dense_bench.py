@@ -21,7 +21,13 @@ g = torch.Generator(device=dev); g.manual_seed(1)
 acgt = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=dev)
 bases = acgt[torch.randint(0, 4, (n,), device=dev, generator=g)]
 torch.cuda.synchronize()
-ctx = sp.Context(0, torch.cuda.current_stream().cuda_stream or None)
+cus = int(os.environ.get("DENSE_CUS", "0"))          # DENSE_CUS=192: on a stream that owns the last 192 CUs, two workgroups each
+if cus:
+    h = sp.stream_create_cus(0, 256 - cus, cus)
+    ctx = sp.Context(0, h)
+    ctx.set_cu_count(cus, int(os.environ.get("DENSE_WG_PER_CU", "2")))
+else:
+    ctx = sp.Context(0, torch.cuda.current_stream().cuda_stream or None)
 d_packed = ctx.pack_bases_device(bases.data_ptr(), n)
 for name, flag in (("pair", sp.SPSP_SCAN_PAIR_FILTER), ("pair2bit", sp.SPSP_SCAN_PAIR_FILTER | sp.SPSP_SCAN_PACKED_INPUT), ("single", sp.SPSP_SCAN_LDS_FILTER),
                    ("bloom", sp.SPSP_SCAN_BLOOM_FILTER), ("direct", sp.SPSP_SCAN_DIRECT_HASH), ("default", sp.SPSP_SCAN_DEFAULT)):

@@ -207,7 +207,9 @@ int main(int argc, char** argv) {
         CK(hipExtStreamCreateWithCUMask(&g_stream, 8, mask));
         for (int blocks : {cus, 2 * cus}) {
             run<0, false>("0 load+pack", bases, n, tab, out, blocks);
+            run<0, true>("0 load+pack", bases, n, tab, out, blocks);
             run<2, false>("2 +8 byte lookups, masked", bases, n, tab, out, blocks);
+            run<2, true>("2 +8 byte lookups, masked", bases, n, tab, out, blocks);
             run<3, false>("3 same, conflict-free", bases, n, tab, out, blocks);
             run<4, false>("4 four byte lookups", bases, n, tab, out, blocks);
         }

@@ -5,6 +5,8 @@
 #include <cstdlib>
 #include <cstdint>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 LDNT(const uint8_t* p) { const u32x4 v = __builtin_nontemporal_load((const u32x4*)p); return make_uint4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ uint32_t pack4x2(uint32_t d) { return __builtin_amdgcn_udot4(d & 0x06060606u, 0x01041040u, 0u, false); }
 __device__ __forceinline__ uint32_t pack16(uint4 v) {
     const uint32_t a = (pack4x2(v.x) << 8) | pack4x2(v.y), b = (pack4x2(v.z) << 8) | pack4x2(v.w);
@@ -28,11 +30,11 @@ __global__ __launch_bounds__(THREADS) void k_load(const uint8_t* __restrict__ ba
         const uint8_t* p = bases + gw * 2 * RB + (uint64_t)lane * 16;
         const uint64_t st = n_waves * 2 * RB;
         uint4 r0 = make_uint4(0,0,0,0), r1 = r0;
-        if (gw < n_pairs) { r0 = *(const uint4*)p; r1 = *(const uint4*)(p + RB); }
+        if (gw < n_pairs) { r0 = LDNT(p); r1 = LDNT(p + RB); }
         for (uint64_t j = gw; j < n_pairs; j += n_waves, p += st) {
             const uint8_t* nx = j + n_waves < n_pairs ? p + st : p;
-            sink3 ^= pack16(r0); r0 = *(const uint4*)nx;
-            sink3 ^= pack16(r1); r1 = *(const uint4*)(nx + RB);
+            sink3 ^= pack16(r0); r0 = LDNT(nx);
+            sink3 ^= pack16(r1); r1 = LDNT(nx + RB);
         }
         if (sink3 == 0x12345678) out[0] = sink3;
         return;
@@ -41,13 +43,13 @@ __global__ __launch_bounds__(THREADS) void k_load(const uint8_t* __restrict__ ba
     const uint8_t* ptr = bases + row * RB + (uint64_t)lane * 16;
     uint4 raw[DEPTH];
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) raw[d] = (row + d * step < end) ? *(const uint4*)(ptr + d * stride) : make_uint4(0, 0, 0, 0);
+    for (int d = 0; d < DEPTH; ++d) raw[d] = (row + d * step < end) ? LDNT(ptr + d * stride) : make_uint4(0, 0, 0, 0);
     uint32_t sink = 0;
     for (; row < end; row += DEPTH * step, ptr += DEPTH * stride) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
             sink ^= pack16(raw[d]);
-            raw[d] = *(const uint4*)(row + (d + DEPTH) * step < end ? ptr + (d + DEPTH) * stride : ptr);
+            raw[d] = LDNT(row + (d + DEPTH) * step < end ? ptr + (d + DEPTH) * stride : ptr);
         }
     }
     if (sink == 0x12345678) out[0] = sink;
