@@ -212,3 +212,105 @@ def model_scan(seq, k, m, T):
             out.append((last, len(seq) - last, old_mini, old_rev))
         total += 1
     return out, total
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# second witness for the sketch PAYLOAD (handle_superkmer SubSampler.cpp:243-302, emission :458-504, find_first_kmer
+# :604-620, find_next :566-602, reconstruct_superkmer :512-564, strCompressor utils.cpp:48-68): a description over
+# strings and Python dicts, written from the reference text -- it shares no code with oracle/ or with the product's
+# 2-bit builder, and takes its super-k-mers from model_scan above.
+def _compress(bases):
+    """strCompressor with the accumulator starting at 0: first byte len % 4, then 4 bases per byte, first
+    base in the top bits; a partial last byte carries one extra shift"""
+    if not bases:
+        return b""
+    out = bytearray([len(bases) % 4])
+    c = 0
+    for i, ch in enumerate(bases):
+        c = (c + ((ord(ch) >> 1) & 3)) & 0xff
+        if (i + 1) % 4 == 0:
+            out.append(c)
+            c = 0
+        c = (c << 2) & 0xff
+    if len(bases) % 4:
+        out.append(c)
+    return bytes(out)
+
+
+def model_payload(records, k, m, T, rate, abundance=1):
+    """the bytes parse_fasta_test hands to its gzip writer for these (already cleaned) records"""
+    buckets = {}                 # minimizer value -> {k-mer string: [count (uint8), position of the minimizer, seen]}, insertion order
+    selected = 0
+    for seq in records:
+        for start, ln, mini, rev in model_scan(seq, k, m, T)[0]:
+            s = seq[start:start + ln]
+            if rev:
+                s = rc_str(s)
+            selected += len(s) - k + 1
+            mstr = to_str(mini, m)
+            d = buckets.setdefault(mini, {})
+            for i in range(len(s) - k + 1):
+                km = s[i:i + k]
+                if km in d:
+                    d[km][0] = (d[km][0] + 1) & 0xff
+                else:
+                    d[km] = [1, km.find(mstr) & 0xff, False]
+    out = bytearray(("%d %d %d %f\n" % (k - 1 + (k - m + 1), m, selected, rate)).encode())
+
+    def usable(e):
+        return (not e[2]) and e[0] >= abundance
+
+    for mini in sorted(buckets):
+        d = buckets[mini]
+        mstr = to_str(mini, m)
+        out += mstr.encode()
+
+        def take(cand):
+            e = d.get(cand)
+            if e is not None and usable(e):
+                e[2] = True
+                return True
+            return False
+
+        def find_next(cur, left):
+            for nuc in "ATCG":                                   # the order the reference tries them in (:568)
+                cand = nuc + cur[:-1] if left else cur[1:] + nuc
+                if take(cand):
+                    return cand
+            return cur
+
+        max_bases, text = "", ""
+        while True:
+            first = next((km for km, e in d.items() if usable(e)), None)
+            if first is None:
+                break
+            d[first][2] = True
+            sk = first
+            n_left, n_right = (k - m) - d[first][1], d[first][1]
+            cur = first
+            while len(sk) != 2 * k - m:
+                if n_left != 0:
+                    nx = find_next(cur, True)
+                    n_left -= 1
+                    if nx != cur:
+                        sk = nx[0] + sk
+                    else:
+                        n_left = 0
+                    cur = first if n_left == 0 else nx
+                elif n_right != 0:
+                    nx = find_next(cur, False)
+                    n_right -= 1
+                    if nx == cur:
+                        break
+                    sk += nx[-1]
+                    cur = nx
+                else:
+                    break
+            if len(sk) == 2 * k - m:
+                max_bases += sk[:k - m] + sk[k:k + (k - m)]
+            else:
+                p = sk.find(mstr)
+                text += sk[:p] + "\n" + sk[p + m:] + "\n"
+        blob = _compress(max_bases)
+        out += len(blob).to_bytes(4, "little") + blob + text.encode() + b"\n\n"
+    return bytes(out)

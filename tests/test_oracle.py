@@ -302,3 +302,19 @@ def test_low_complexity_and_repeats_do_not_lose_kmers():
         assert cover == list(range(len(seq) - k + 1))
         payload, _ = orc.sketch_fasta(bf.fasta([seq]), k, m, 1.0)
         assert bf.payload_set(payload) == bf.sketch_set([seq], k, m, T)
+
+
+@pytest.mark.parametrize("k,m,s,ab", [(31, 11, 20.0, 1), (21, 11, 3.0, 1), (15, 7, 1.0, 1), (31, 11, 5.0, 2), (63, 15, 10.0, 1), (15, 15, 2.0, 1), (21, 9, 1.0, 3)])
+def test_payload_second_witness(k, m, s, ab):
+    """the oracle's sketch payload (handle_superkmer + emission + strCompressor restated in C++) against an independent
+    description of the same reference text over Python strings and dicts (tests/bruteforce.py::model_payload, which
+    takes its super-k-mers from model_scan): byte for byte, on random records, a mutated copy (shared k-mers: counts
+    above 1), a reverse-complemented copy, a tandem repeat and -- for the uint8 count -- a unit repeated 257 times."""
+    rng = np.random.default_rng(100 * k + m + ab)
+    a = bf.random_dna(rng, 2500)
+    unit = bf.random_dna(rng, 55)
+    records = [a, bf.mutate(rng, a, 0.02), bf.rc_str(a[300:1500]), bf.random_dna(rng, 17) * 40, bf.random_dna(rng, k - 1), unit * 257 + unit[:30], a[:1200]]
+    T = orc.threshold(k, m, s)
+    want = bf.model_payload(records, k, m, T, s, ab)
+    got, _ = orc.sketch_fasta(bf.fasta(records), k, m, s, ab)
+    assert got == want
