@@ -443,9 +443,10 @@ __device__ __forceinline__ uint64_t key_hash(uint64_t lo, uint32_t mn, uint64_t 
 __global__ __launch_bounds__(256) void k_parts_prepare(uint32_t* __restrict__ part_cnt, uint32_t n_parts, uint32_t* __restrict__ flags,
                                                       const uint64_t* __restrict__ host_skoff, uint64_t* __restrict__ dev_skoff,
                                                       uint32_t n_skoff, const uint32_t* __restrict__ host_sub, uint32_t* __restrict__ dev_sub,
-                                                      uint32_t n_sub) {
+                                                      uint32_t n_sub, uint32_t* __restrict__ zero_inter, uint32_t zero_cells) {
     const uint32_t stride = gridDim.x * blockDim.x, t = blockIdx.x * blockDim.x + threadIdx.x;
     for (uint32_t i = t; i < n_parts; i += stride) part_cnt[i] = 0;
+    for (uint32_t i = t; i < zero_cells; i += stride) zero_inter[i] = 0;     // small-problem form: the parts ADD into the pair matrix
     if (t < 16) flags[t] = 0;
     for (uint32_t i = t; i < n_skoff; i += stride) dev_skoff[i] = host_skoff[i];
     for (uint32_t i = t; i < n_sub; i += stride) dev_sub[i] = host_sub[i];
@@ -458,7 +459,7 @@ __global__ __launch_bounds__(256) void k_parts_prepare(uint32_t* __restrict__ pa
 template <bool HAS_HI, int E>
 __global__ __launch_bounds__(kScatThreads, 4) void k_parts_scatter(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n,
                                                                const uint32_t* __restrict__ sub_sk, uint64_t S, uint32_t n_parts,
-                                                               uint32_t* __restrict__ part_cnt, uint64_t* __restrict__ recs,
+                                                               uint32_t cap, uint32_t* __restrict__ part_cnt, uint64_t* __restrict__ recs,
                                                                uint32_t* __restrict__ where, uint32_t* __restrict__ flags) {
     constexpr uint32_t W = HAS_HI ? 3 : 2;
     extern __shared__ uint32_t hist[];                   // [n_parts]
@@ -516,9 +517,9 @@ __global__ __launch_bounds__(kScatThreads, 4) void k_parts_scatter(Keys K, const
         const uint32_t part = pr[u] & 0x7fffu, at = hist[part] + (pr[u] >> 15);
         // where the record goes, in entry order (coalesced): the row sums find the key's list through it, so the
         // record need not carry its entry number and k_parts_group need not scatter one word per key back
-        where[e] = at < (uint32_t)kPartCap ? part * (uint32_t)kPartCap + at : kNoWhere;
-        if (at >= (uint32_t)kPartCap) continue;          // overflow: k_parts_group sees the count and raises the flag
-        uint64_t* r = recs + ((uint64_t)part * kPartCap + at) * W;
+        if (where) where[e] = at < cap ? part * cap + at : kNoWhere;     // (the small-problem form keeps no index: k_parts_group_small)
+        if (at >= cap) continue;                         // overflow: the grouping kernel sees the count and raises the flag
+        uint64_t* r = recs + ((uint64_t)part * cap + at) * W;
         if (HAS_HI) { r[0] = lo[u]; r[1] = (uint64_t)mn[u] | ((uint64_t)j << 32); r[2] = hi[u]; }
         else *reinterpret_cast<ulonglong2*>(r) = make_ulonglong2(lo[u], (uint64_t)mn[u] | ((uint64_t)j << 32));   // one 16-byte store
     }
@@ -609,6 +610,102 @@ __global__ __launch_bounds__(kGroupThreads) void k_parts_group(const uint64_t* _
         const uint32_t o = slot[hs[u]];
         ids[o + 1 + rank[u]] = (uint16_t)sk[u];
         *out = list_ref(o, cnt[u]);
+    }
+}
+
+// Small problems (at most kSmallN sketches, k <= 32, every row owned): grouping AND counting in one kernel.  Parts of
+// half the size (2048 records: 40 KiB of keys and slots), the holders of every key are listed in LDS, every record adds
+// 1 to the cell (its sketch, other holder) for the holders above it -- an N x N matrix of 16-bit counters in LDS,
+// two per word -- and the part's non-zero cells go to the pair matrix with global atomics (a few hundred per part when
+// the sketches fall into families).  No list references, no `where` index, no row-sum kernel: the chain is three
+// launches instead of four and moves a third of the bytes; it is what lets the comparison of bench.py's 100
+// sketches run beside a dense pass on 32 CUs instead of 64.
+constexpr int kSmallCap = 2048, kSmallSlots = 3968, kSmallN = 128, kSmallMean = 1450;
+__global__ __launch_bounds__(kGroupThreads) void k_parts_group_small(const uint64_t* __restrict__ recs, const uint32_t* __restrict__ part_cnt,
+                                                                    uint32_t n_sk, uint32_t* __restrict__ inter, uint32_t* __restrict__ flags) {
+    constexpr uint32_t R = kSmallCap / kGroupThreads;     // records per thread
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_s[];
+    uint64_t* k_lo = reinterpret_cast<uint64_t*>(lds_s);                    // [kSmallCap]
+    uint32_t* k_mn = reinterpret_cast<uint32_t*>(k_lo + kSmallCap);         // [kSmallCap]
+    uint32_t* slot = k_mn + kSmallCap;                                      // [kSmallSlots]
+    uint32_t* mat = slot + kSmallSlots;                                     // [kSmallN * kSmallN / 2]: cell c in half c & 1 of word c >> 1
+    uint8_t* hl = reinterpret_cast<uint8_t*>(mat + kSmallN * kSmallN / 2);  // [kSmallCap]: holder lists, one byte per record
+    uint32_t* cursor = reinterpret_cast<uint32_t*>(hl + kSmallCap);
+    const uint32_t p = blockIdx.x, t = threadIdx.x;
+    const uint32_t n = part_cnt[p];
+    if (n > (uint32_t)kSmallCap) { if (t == 0) atomicOr(&flags[6], 1u); return; }
+    for (uint32_t x = t; x < (uint32_t)kSmallSlots; x += kGroupThreads) slot[x] = 0;
+    for (uint32_t x = t; x < (uint32_t)(kSmallN * kSmallN / 2); x += kGroupThreads) mat[x] = 0;
+    if (t == 0) *cursor = 0;
+    const ulonglong2* base = reinterpret_cast<const ulonglong2*>(recs) + (uint64_t)p * kSmallCap;
+    uint64_t lo[R];
+    uint32_t mn[R], sk[R], hs[R], rank[R];
+#pragma unroll
+    for (uint32_t u = 0; u < R; ++u) {
+        const uint32_t r = u * kGroupThreads + t;
+        const ulonglong2 v = base[r];                     // (loaded whether or not the record exists: the slice is allocated in full)
+        lo[u] = v.x; mn[u] = (uint32_t)v.y; sk[u] = (uint32_t)(v.y >> 32); rank[u] = 0;
+        k_lo[r] = lo[u]; k_mn[r] = mn[u];
+        hs[u] = (uint32_t)(((key_hash(lo[u], mn[u], 0ull, false) & 0xffffffffull) * kSmallSlots) >> 32);
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t u = 0; u < R; ++u) {
+        const uint32_t r = u * kGroupThreads + t;
+        if (r >= n) continue;
+        uint32_t h = hs[u];
+        for (;;) {                                        // ends: about twice as many slots as a part has records
+            uint32_t cur = slot[h];
+            if (cur == 0) cur = atomicCAS(&slot[h], 0u, r + 1);
+            if (cur == 0) break;                          // claimed
+            const uint32_t c = (cur & 0x1fffu) - 1;
+            if (k_lo[c] == lo[u] && k_mn[c] == mn[u]) break;
+            h = h + 1 == (uint32_t)kSmallSlots ? 0u : h + 1;
+        }
+        hs[u] = h;
+        rank[u] = atomicAdd(&slot[h], 1u << 13) >> 13;
+    }
+    __syncthreads();
+    uint32_t cnt[R];
+    bool claimer[R];
+#pragma unroll
+    for (uint32_t u = 0; u < R; ++u) {
+        const uint32_t r = u * kGroupThreads + t;
+        const uint32_t w = r < n ? slot[hs[u]] : 0u;
+        cnt[u] = w >> 13;
+        claimer[u] = r < n && (w & 0x1fffu) == r + 1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t u = 0; u < R; ++u)
+        if (claimer[u]) slot[hs[u]] = atomicAdd(cursor, cnt[u]);          // where the key's holders are listed in hl
+    __syncthreads();
+#pragma unroll
+    for (uint32_t u = 0; u < R; ++u) {
+        const uint32_t r = u * kGroupThreads + t;
+        if (r < n) hl[slot[hs[u]] + rank[u]] = (uint8_t)sk[u];
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t u = 0; u < R; ++u) {
+        const uint32_t r = u * kGroupThreads + t;
+        if (r >= n || cnt[u] < 2) continue;               // held by one sketch: no pair to count
+        const uint32_t o = slot[hs[u]];
+        for (uint32_t j = 0; j < cnt[u]; ++j) {
+            const uint32_t other = hl[o + j];
+            if (other > sk[u]) {                          // (a sketch holds a key at most once: the scatter checked the order)
+                const uint32_t cell = sk[u] * kSmallN + other;
+                atomicAdd(&mat[cell >> 1], (cell & 1u) ? 0x10000u : 1u);    // a part holds 2048 records: no half overflows
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t x = t; x < (uint32_t)(kSmallN * kSmallN / 2); x += kGroupThreads) {
+        const uint32_t w = mat[x];
+        if (!w) continue;
+        const uint32_t c0 = 2 * x, a = c0 / kSmallN, b = c0 % kSmallN;      // cells c0 and c0 + 1 share row a (kSmallN is even)
+        if (w & 0xffffu) atomicAdd(&inter[(uint64_t)a * n_sk + b], w & 0xffffu);
+        if (w >> 16) atomicAdd(&inter[(uint64_t)a * n_sk + b + 1], w >> 16);
     }
 }
 
@@ -732,9 +829,10 @@ struct CompareJob {
     uint32_t passes = 1, pass = 0;  // large builds: the keys are split into classes and the dictionary + colour
                                     // matrix are built class by class, so the matrix never exceeds its budget
     // partition form (flat entry point): see k_parts_scatter
-    std::function<int(uint32_t n_parts)> scatter_parts;
+    std::function<int(uint32_t n_parts, bool small)> scatter_parts;
     std::function<int(uint32_t n_parts)> group_parts;
-    bool parts = false;
+    std::function<int(uint32_t n_parts)> group_small;     // small problems: grouping + counting in one kernel (k_parts_group_small)
+    bool parts = false, small = false;
     uint32_t n_parts = 0, parts_attempt = 0, n_sub = 0;
     bool bracket_closed = false;    // the kEvCompare bracket of the begin call has been closed already
 };
@@ -772,26 +870,29 @@ static int launch_accumulate_sparse(spsp_ctx* ctx, const ComparePlan& P, uint32_
     SPSP_HIP(hipGetLastError());
     return SPSP_OK;
 }
-// partition form: prepare -> scatter -> group -> row sums, queued in one go
+static int job_queue_flags(spsp_ctx* ctx);
+// partition form: prepare -> scatter -> group -> row sums, queued in one go (small problems: prepare -> scatter -> group + count)
 static int job_parts(spsp_ctx* ctx, CompareJob& J) {
     uint32_t* flags = ctx->c_flags.as<uint32_t>();
     int rc;
     if ((rc = ctx->c_part_cnt.reserve((size_t)J.n_parts * 4))) return rc;
-    if ((rc = ctx->c_matrix.reserve((size_t)J.n_parts * 4 * kPartCap * sizeof(uint16_t)))) return rc;     // sketch lists
-    const uint32_t most = std::max(std::max(J.n_parts, J.n_skoff), J.n_sub);
+    if (!J.small && (rc = ctx->c_matrix.reserve((size_t)J.n_parts * 4 * kPartCap * sizeof(uint16_t)))) return rc;     // sketch lists
+    const uint32_t most = std::max(std::max(J.n_parts, J.n_skoff), std::max(J.n_sub, J.small ? J.P.n * J.P.n : 0u));
     hipLaunchKernelGGL(k_parts_prepare, dim3(std::min<uint32_t>((most + 255) / 256, 64u)), dim3(256), 0, ctx->stream,
                        ctx->c_part_cnt.as<uint32_t>(), J.n_parts, flags, (const uint64_t*)ctx->h_skoff,
                        ctx->c_skoff.as<uint64_t>(), J.n_skoff, reinterpret_cast<const uint32_t*>(ctx->h_skoff + J.n_skoff),
-                       reinterpret_cast<uint32_t*>(ctx->c_skoff.as<uint64_t>() + J.n_skoff), J.n_sub);
+                       reinterpret_cast<uint32_t*>(ctx->c_skoff.as<uint64_t>() + J.n_skoff), J.n_sub,
+                       J.small ? J.P.d_inter : (uint32_t*)nullptr, J.small ? J.P.n * J.P.n : 0u);
     SPSP_HIP(hipGetLastError());
     // analysis hook (results are wrong with it): leave stages out to see what each costs a kernel of another stream
     static const int skip = getenv("SPSP_DEBUG_SKIP_STAGES") ? atoi(getenv("SPSP_DEBUG_SKIP_STAGES")) : 0;
     if ((rc = ctx->ev_begin(kEvScatter))) return rc;
-    if (!(skip & 1) && (rc = J.scatter_parts(J.n_parts))) return rc;
+    if (!(skip & 1) && (rc = J.scatter_parts(J.n_parts, J.small))) return rc;
     if ((rc = ctx->ev_end(kEvScatter))) return rc;
     if ((rc = ctx->ev_begin(kEvGroup))) return rc;
-    if (!(skip & 2) && (rc = J.group_parts(J.n_parts))) return rc;
+    if (!(skip & 2) && (rc = J.small ? J.group_small(J.n_parts) : J.group_parts(J.n_parts))) return rc;
     if ((rc = ctx->ev_end(kEvGroup))) return rc;
+    if (J.small) return job_queue_flags(ctx);             // (no later kernel forwards the flags)
     if ((rc = ctx->ev_begin(kEvAccumulate))) return rc;
     ComparePlan PP = J.P;
     PP.list_ref = ctx->c_lref.as<uint32_t>(); PP.where = ctx->c_where.as<uint32_t>();
@@ -943,6 +1044,8 @@ static int job_begin_dictionary(spsp_ctx* ctx, CompareJob* J) {
 
 // records a part is planned to hold on average: kPartCap less the spread of the part sizes (keys shared by c
 // sketches arrive c at a time); halved for the second attempt
+static bool dbg_mean_set() { static const bool v = getenv("SPSP_DEBUG_PART_MEAN") != nullptr; return v; }
+static uint32_t parts_small(uint64_t entries) { return (uint32_t)std::max<uint64_t>(1, (entries + kSmallMean - 1) / kSmallMean); }
 static uint32_t parts_for(uint64_t entries, uint32_t attempt) {
     static const char* dbg_mean = getenv("SPSP_DEBUG_PART_MEAN");   // test hook: tiny parts, so that small inputs reach tens of thousands of parts
     const uint64_t mean = dbg_mean ? (uint64_t)std::max(1, atoi(dbg_mean)) : (attempt == 0 ? 2900 : 1400);
@@ -961,7 +1064,12 @@ static int compare_job_begin(spsp_ctx* ctx, CompareJob* job) {
                parts_for(P.S_entries, 0) <= (uint32_t)kMaxKeyParts;
     if (J->parts) {
         J->speculative = true;                      // queued in one go, checked once
-        J->n_parts = parts_for(P.S_entries, 0);
+        // small problems (bench.py's 100 sketches): one kernel groups and counts.  Every row must be owned (the parts
+        // add into the whole matrix, which is cleared first) and k <= 32; SPSP_DEBUG_SMALL=0 keeps the general form
+        static const bool small_off = getenv("SPSP_DEBUG_SMALL") && atoi(getenv("SPSP_DEBUG_SMALL")) == 0;
+        J->small = J->group_small && !small_off && !dbg_mean_set() && P.n <= (uint32_t)kSmallN && P.n_own == P.n && P.row_first == 0 && P.row_stride == 1 &&
+                   P.row_limit >= P.n;
+        J->n_parts = J->small ? parts_small(P.S_entries) : parts_for(P.S_entries, 0);
         if ((rc = ctx->c_row.reserve((size_t)P.S_entries * 4))) return rc;
         if ((rc = job_parts(ctx, *J))) return rc;
     } else if ((rc = job_begin_dictionary(ctx, J.get()))) return rc;
@@ -981,6 +1089,13 @@ int compare_job_end(spsp_ctx* ctx) {
         // a part overflowed (many sketches share their keys): once more with parts half the size, then the
         // global-dictionary forms, which have no such limit
         J->bracket_closed = true;
+        if (J->small) {                             // the small-problem form's parts are half the size: the general form next
+            J->small = false;
+            J->n_parts = parts_for(J->P.S_entries, 0);
+            if ((rc = ctx->c_row.reserve((size_t)J->P.S_entries * 4))) return rc;
+            if ((rc = job_parts(ctx, *J))) return rc;
+            continue;
+        }
         if (J->parts_attempt == 0 && parts_for(J->P.S_entries, 1) <= (uint32_t)kMaxKeyParts) {
             J->parts_attempt = 1;
             J->n_parts = parts_for(J->P.S_entries, 1);
@@ -1120,11 +1235,13 @@ static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t*
     const bool has_hi = K.hi != nullptr;
     const uint32_t* sub_sk = reinterpret_cast<const uint32_t*>(sk + n + 1);
     J->n_sub = (uint32_t)((S + kScatSub - 1) / kScatSub);
-    J->scatter_parts = [=](uint32_t n_parts) -> int {
-        int r2 = ctx->c_recs.reserve((size_t)n_parts * kPartCap * (has_hi ? 24 : 16));
+    J->scatter_parts = [=](uint32_t n_parts, bool small) -> int {
+        const uint32_t cap = small ? (uint32_t)kSmallCap : (uint32_t)kPartCap;
+        int r2 = ctx->c_recs.reserve((size_t)n_parts * cap * (has_hi ? 24 : 16));
         if (r2) return r2;
-        if ((r2 = ctx->c_where.reserve((size_t)S * 4 + 16))) return r2;
-        if ((r2 = ctx->c_lref.reserve((size_t)n_parts * kPartCap * 4))) return r2;
+        if (!small && (r2 = ctx->c_where.reserve((size_t)S * 4 + 16))) return r2;
+        if (!small && (r2 = ctx->c_lref.reserve((size_t)n_parts * kPartCap * 4))) return r2;
+        uint32_t* where = small ? nullptr : ctx->c_where.as<uint32_t>();
         const uint32_t per_wg = 4u * kScatThreads;
         const dim3 grid((uint32_t)((S + per_wg - 1) / per_wg));
         const size_t lds = (size_t)n_parts * 4;
@@ -1134,7 +1251,7 @@ static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t*
             ctx->attr_scatter_set = true;
         }
 #define SPSP_SCATTER(HI, E) hipLaunchKernelGGL((k_parts_scatter<HI, E>), grid, dim3(kScatThreads), lds, ctx->stream, K, sk, n, sub_sk, S, \
-                                               n_parts, ctx->c_part_cnt.as<uint32_t>(), ctx->c_recs.as<uint64_t>(), ctx->c_where.as<uint32_t>(), flags)
+                                               n_parts, cap, ctx->c_part_cnt.as<uint32_t>(), ctx->c_recs.as<uint64_t>(), where, flags)
         if (has_hi) SPSP_SCATTER(true, 4);
         else SPSP_SCATTER(false, 4);
 #undef SPSP_SCATTER
@@ -1158,6 +1275,17 @@ static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t*
             hipLaunchKernelGGL(k_parts_group<false>, dim3(n_parts), dim3(kGroupThreads), lds, ctx->stream, ctx->c_recs.as<uint64_t>(),
                                ctx->c_part_cnt.as<uint32_t>(), ctx->c_matrix.as<uint16_t>(), ctx->c_lref.as<uint32_t>(), flags);
         }
+        SPSP_HIP(hipGetLastError());
+        return SPSP_OK;
+    };
+    if (!has_hi) J->group_small = [=](uint32_t n_parts) -> int {
+        const size_t lds = (size_t)kSmallCap * (8 + 4 + 1) + (size_t)kSmallSlots * 4 + (size_t)kSmallN * kSmallN * 2 + 16;
+        if (!ctx->attr_small_set) {
+            SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_parts_group_small), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            ctx->attr_small_set = true;
+        }
+        hipLaunchKernelGGL(k_parts_group_small, dim3(n_parts), dim3(kGroupThreads), lds, ctx->stream, ctx->c_recs.as<uint64_t>(),
+                           ctx->c_part_cnt.as<uint32_t>(), n, d_inter, flags);
         SPSP_HIP(hipGetLastError());
         return SPSP_OK;
     };
