@@ -82,6 +82,13 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
                              % (args.gpus, args.gpus))
+    # BENCH_SHARE_GPU=1 + BENCH_BACKEND=gloo (rehearsal on a one-GPU box): every rank computes on cuda:0 and the collectives
+    # go through gloo -- the N > 1 code path of this file end to end, without RCCL's transport; the timing means nothing
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    if os.environ.get("BENCH_SHARE_GPU") == "1":
+        if backend == "nccl" and world > 1:
+            raise SystemExit("BENCH_SHARE_GPU=1 needs BENCH_BACKEND=gloo (RCCL refuses two ranks on one device)")
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # BENCH_FORCE_DIST=1 takes the multi-GPU code path (RCCL key all-gather, strided rows) even with one rank,
@@ -90,7 +97,10 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     flags = {"default": sp.SPSP_SCAN_DEFAULT, "direct": sp.SPSP_SCAN_DIRECT_HASH, "filter": sp.SPSP_SCAN_LDS_FILTER,
              "pair": sp.SPSP_SCAN_PAIR_FILTER}[args.mode]
@@ -114,7 +124,12 @@ def main():
     # -- the dense passes run back to back and nothing that shares a CU with them slows them down
     schedule = os.environ.get("BENCH_SCHEDULE", "partition")
     tail_streams = schedule in ("tail", "partition")
-    small_cus = int(os.environ.get("BENCH_SMALL_CUS", "64"))
+    # CUs of the small streams: a rank's share of the comparison grows with the world size (all keys are partitioned on
+    # every rank, the rows are shared out), so its streams get more of the chip -- measured with BENCH_SIM_WORLD
+    # (tools/sim_world_sweep.sh, ms per step at 64 / 96 / 128 CUs): W = 2: 0.113 / 0.124 / 0.143, W = 4: 0.156 / 0.135 /
+    # 0.150, W = 8: 0.267 / 0.197 / 0.167
+    sim_w = max(world, int(os.environ.get("BENCH_SIM_WORLD", "1")))
+    small_cus = int(os.environ.get("BENCH_SMALL_CUS", "64" if sim_w <= 2 else "96" if sim_w <= 4 else "128"))
     ctx_full, full_stream = ctx, stream                   # whole-device context: setup and the extras
     if schedule == "partition" and pipelined:
         try:                                              # (a runtime without CU masks: fall back to the unpartitioned schedule)
@@ -203,6 +218,7 @@ def main():
     d_my_min = torch.from_numpy(my_min.view(np.int32)).to(dev)
     d_my_lo = torch.from_numpy(my_lo.view(np.int64)).to(dev)
     n_total = args.genomes * world
+    sim_world = int(os.environ.get("BENCH_SIM_WORLD", "1")) if not use_dist else 1
     my_sk_off = np.zeros(args.genomes + 1, dtype=np.uint64)
     my_sk_off[1:] = np.cumsum(my_n)
     # multi-GPU exchange: north_star's form (RCCL all-gather of the packed keys + strided row ownership) by default;
@@ -218,6 +234,21 @@ def main():
         for sl in slots:
             sl.exchange = spd.KeyExchange(my_n, dev, stream=sl.stream_b)
         sk_off = slots[0].exchange.sk_off
+    elif sim_world > 1:
+        # BENCH_SIM_WORLD=W on one GPU (analysis only, the line is not a measurement): this rank's share of the
+        # comparison at world size W -- the keys of W x genomes sketches resident (as after the all-gather), rows
+        # i % W == 0 -- next to the usual scan, to size the CU partition for W ranks; no exchange is simulated
+        mins, los, ns = [my_min], [my_lo], [my_n]
+        for r in range(1, sim_world):
+            for g in synth.family_genomes(2 + 1000 * r, args.genomes, args.length, N_FAMILIES, MUS):
+                gb, go = synth.concat_records([g])
+                sk = sp.sketch_parse(sp.sketch_build(p, S, gb, go, ctx.scan(p, gb, go))[0])
+                mins.append(sk.minimizer.astype(np.uint32)), los.append(sk.kmer_lo.astype(np.uint64)), ns.append([len(sk)])
+        n_total = args.genomes * sim_world
+        sk_off = np.zeros(n_total + 1, dtype=np.uint64)
+        sk_off[1:] = np.cumsum(np.concatenate(ns))
+        d_all_min = torch.from_numpy(np.concatenate(mins).view(np.int32)).to(dev)
+        d_all_lo = torch.from_numpy(np.concatenate(los).view(np.int64)).to(dev)
     else:
         sk_off = np.zeros(n_total + 1, dtype=np.uint64)
         sk_off[1:] = np.cumsum(my_n)
@@ -248,7 +279,7 @@ def main():
             if schedule != "partition":
                 sl.cmp.wait_dense(sl.scan)                # the comparison starts behind this step's dense pass
             if not skip_compare:
-                sl.cmp.compare_device_begin(K, d_all_min.data_ptr(), d_all_lo.data_ptr(), None, sk_off, n_total, rank, world,
+                sl.cmp.compare_device_begin(K, d_all_min.data_ptr(), d_all_lo.data_ptr(), None, sk_off, n_total, rank, max(world, sim_world),
                                             sl.d_inter.data_ptr())                                         # stream B
             return
         with torch.cuda.stream(sl.stream_b):              # torch ops and RCCL order themselves against stream B
@@ -299,7 +330,7 @@ def main():
                         mn_ptr, lo_ptr = g.minimizer.data_ptr(), g.kmer_lo.data_ptr()
                     else:
                         mn_ptr, lo_ptr = d_all_min.data_ptr(), d_all_lo.data_ptr()
-                    ctx.compare_device(K, mn_ptr, lo_ptr, None, sk_off, n_total, rank, world, sl.d_inter.data_ptr())
+                    ctx.compare_device(K, mn_ptr, lo_ptr, None, sk_off, n_total, rank, max(world, sim_world), sl.d_inter.data_ptr())
                     if exchange_kind == "gather":
                         sl.exchange.collect_rows(sl.d_inter)
                 last["n_out"], last["slot"] = n_out, sl
@@ -404,6 +435,21 @@ def main():
                 exchange_check = "equal to all-gather form" if bool(torch.equal(d_ref, d_inter)) else "MISMATCH"
         except Exception as e:  # noqa: BLE001 -- the check must not take the bench line down
             exchange_check = "check failed: %r" % (e,)
+    elif exchange_kind == "gather":
+        # untimed: the strips collected on rank 0 (rows i % N of N ranks) must equal ONE device's comparison of all rows
+        # over the gathered keys (that single-device result is what the gpu tests hold against the oracle)
+        try:
+            with torch.cuda.stream(last["slot"].stream_b):
+                g = last["slot"].exchange.exchange(d_my_min, d_my_lo)
+                d_ref = torch.zeros_like(d_inter)
+                last["slot"].cmp.compare_device(K, g.minimizer.data_ptr(), g.kmer_lo.data_ptr(), None, sk_off, n_total, 0, 1,
+                                                d_ref.data_ptr())
+            torch.cuda.synchronize()
+            if rank == 0:
+                exchange_check = ("collected strips equal a one-device comparison of all %d sketches" % n_total
+                                  if bool(torch.equal(d_ref, d_inter)) else "MISMATCH")
+        except Exception as e:  # noqa: BLE001
+            exchange_check = "check failed: %r" % (e,)
 
     if rank == 0:
         value = total_kmers_per_step * args.steps / elapsed
@@ -436,6 +482,10 @@ def main():
                                        "gather": "genomes sharded by rank; RCCL all-gather of the packed sketch keys, every rank "
                                                  "computes the pair-matrix rows i % N == rank, strips gathered on rank 0 (SURVEY.md 8e)"}[exchange_kind],
                        "exchange_check": exchange_check,
+                       **({"simulation": "BENCH_SIM_WORLD=%d: one rank's share of the comparison at that world size, no exchange: "
+                                         "NOT a measurement" % sim_world} if sim_world > 1 else {}),
+                       **({"rehearsal": "BENCH_BACKEND=%s, all ranks on one device: NOT a measurement" % backend}
+                          if (use_dist and (backend != "nccl" or os.environ.get("BENCH_SHARE_GPU") == "1")) else {}),
                        "step": (("scan(batch t) || all-vs-all(sketches of batch t-1): the chip is partitioned by CU-masked streams -- "
                                  "dense passes back to back on %d CUs (two workgroups each), the scans' sparse stages on one stream and "
                                  "the comparisons on another that share the other %d CUs; the host queues step t+1 before collecting "
