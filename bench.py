@@ -18,6 +18,7 @@ the whole-file drivers end to end (`end_to_end`), each beside the oracle.
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import contextlib
 import json
 import os
 import subprocess
@@ -268,6 +269,13 @@ def main():
     # comparison's kernels cost the dense pass they run beside
     skip_compare = os.environ.get("BENCH_DEBUG_SKIP_COMPARE") == "1" and exchange_kind == "none"
 
+    def on_b(sl):
+        # torch ops and RCCL order themselves against torch's CURRENT stream: stream B of the slot.  Entering a stream
+        # context costs ~7 us of host time, so the thread simply stays on stream B when all slots share it (below)
+        if torch.cuda.current_stream(dev) == sl.stream_b:
+            return contextlib.nullcontext()
+        return torch.cuda.stream(sl.stream_b)
+
     def queue_step(sl, prev, nxt=None):
         """queue one whole step on slot sl without waiting for anything; on the GPU its dense pass starts behind
         the dense pass of slot prev.  nxt = the slot of the following step (slots exchange: its key partition is
@@ -282,7 +290,7 @@ def main():
                 sl.cmp.compare_device_begin(K, d_all_min.data_ptr(), d_all_lo.data_ptr(), None, sk_off, n_total, rank, max(world, sim_world),
                                             sl.d_inter.data_ptr())                                         # stream B
             return
-        with torch.cuda.stream(sl.stream_b):              # torch ops and RCCL order themselves against stream B
+        with on_b(sl):
             if exchange_kind == "slots":
                 if getattr(sl, "handle", None) is None:   # first steps only: later ones were started a step ahead (below)
                     sl.handle = sl.exchange.begin(d_my_min.data_ptr(), d_my_lo.data_ptr(), None, my_sk_off)
@@ -291,6 +299,7 @@ def main():
                 sl.handle = None
             else:
                 g = sl.exchange.exchange(d_my_min, d_my_lo)
+                sl.exchange.prepare_rows(sl.d_inter)      # (rank 0, small matrices: the strips arrive by one reduce)
                 sl.cmp.wait_dense(sl.scan)
                 sl.cmp.compare_device_begin(K, g.minimizer.data_ptr(), g.kmer_lo.data_ptr(), None, sk_off, n_total, rank,
                                             world, sl.d_inter.data_ptr())
@@ -298,14 +307,14 @@ def main():
         if exchange_kind == "slots" and nxt is not None and nxt is not sl and getattr(nxt, "handle", None) is None:
             # the NEXT step's key partition + RCCL all-to-all: behind this step's dense pass, long before the next
             # comparison needs it, and behind the comparison still queued on that stream
-            with torch.cuda.stream(nxt.stream_b):
+            with on_b(nxt):
                 nxt.cmp.wait_dense(sl.scan)
                 nxt.handle = nxt.exchange.begin(d_my_min.data_ptr(), d_my_lo.data_ptr(), None, my_sk_off)
 
     def collect_step(sl):
         d_out, n_out = sl.scan.scan_device_end()
         if exchange_kind == "slots":
-            with torch.cuda.stream(sl.stream_b):
+            with on_b(sl):
                 sl.exchange.end_collect(sl.d_inter)       # partial pair matrix done -> RCCL reduction
         else:
             if not skip_compare:
@@ -327,6 +336,7 @@ def main():
                 else:
                     if exchange_kind == "gather":
                         g = sl.exchange.exchange(d_my_min, d_my_lo)
+                        sl.exchange.prepare_rows(sl.d_inter)
                         mn_ptr, lo_ptr = g.minimizer.data_ptr(), g.kmer_lo.data_ptr()
                     else:
                         mn_ptr, lo_ptr = d_all_min.data_ptr(), d_all_lo.data_ptr()
@@ -365,6 +375,9 @@ def main():
     # Clocks and caches: the GPU has idled through the setup above (host-side synthesis, uploads) and takes ~100 steps
     # to come back to its sustained clocks (200 timed steps: 0.124-0.127 ms each; 600: 0.117).  An untimed run-in of the
     # same steps precedes the W warm-up steps, so that short runs measure the same machine state as long ones.
+    stay_on_b = use_dist and pipelined and all(sl.stream_b is slots[0].stream_b for sl in slots)
+    if stay_on_b:
+        torch.cuda.set_stream(slots[0].stream_b)          # see on_b(); the scans name their streams themselves
     prewarm = int(os.environ.get("BENCH_PREWARM_STEPS", "300"))
     if prewarm > 0:
         run_steps(prewarm)
@@ -387,6 +400,8 @@ def main():
     run_steps(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
+    if stay_on_b:
+        torch.cuda.set_stream(stream)
     n_out = last["n_out"]
     d_inter = last["slot"].d_inter
     exchange = getattr(last["slot"], "exchange", None)
@@ -480,7 +495,8 @@ def main():
                                        "slots": "genomes sharded by rank; sketch keys partitioned by hash, RCCL all-to-all behind "
                                                 "the scan, per-rank partial pair matrix, RCCL reduction",
                                        "gather": "genomes sharded by rank; RCCL all-gather of the packed sketch keys, every rank "
-                                                 "computes the pair-matrix rows i % N == rank, strips gathered on rank 0 (SURVEY.md 8e)"}[exchange_kind],
+                                                 "computes the pair-matrix rows i % N == rank, strips collected on rank 0 (SURVEY.md 8e; "
+                                                 "matrices <= 16 MB by one RCCL reduce of the zero-padded strips)"}[exchange_kind],
                        "exchange_check": exchange_check,
                        **({"simulation": "BENCH_SIM_WORLD=%d: one rank's share of the comparison at that world size, no exchange: "
                                          "NOT a measurement" % sim_world} if sim_world > 1 else {}),

@@ -83,9 +83,12 @@ class KeyExchange:
         idx_lo = np.concatenate([np.arange(int(self.per_rank[r]), dtype=np.int64) + r * (blk // 8) for r in range(self.world)]) if total else np.zeros(0, np.int64)
         idx_mn = np.concatenate([np.arange(int(self.per_rank[r]), dtype=np.int64) + r * (blk // 4) + self.pad * 2 for r in range(self.world)]) if total else np.zeros(0, np.int64)
         small = self.world * blk // 4 < 2**31
-        self._idx_lo = torch.from_numpy(idx_lo.astype(np.int32 if small else np.int64)).to(device)
-        self._idx_mn = torch.from_numpy(idx_mn.astype(np.int32 if small else np.int64)).to(device)
-        self.all_min, self.all_lo = mk(torch.int32, total), mk(torch.int64, total)
+        # ONE gather kernel for both arrays: the gathered bytes as int32 words -> [kmer_lo: 2 words per key | minimizer]
+        idx_all = np.concatenate([np.stack([2 * idx_lo, 2 * idx_lo + 1], axis=1).reshape(-1), idx_mn])
+        self._idx_all = torch.from_numpy(idx_all.astype(np.int32 if small else np.int64)).to(device)
+        self._all_buf = mk(torch.int32, 3 * total)
+        self.all_lo, self.all_min = self._all_buf[:2 * total].view(torch.int64), self._all_buf[2 * total:]
+        self.n_mine = int(self.per_rank[self.rank])
         if use_hi:
             idx = np.concatenate([np.arange(int(self.per_rank[r]), dtype=np.int64) + r * self.pad for r in range(self.world)]) if total else np.zeros(0, np.int64)
             self._idx = torch.from_numpy(idx.astype(np.int32 if self.world * self.pad < 2**31 else np.int64)).to(device)
@@ -107,16 +110,32 @@ class KeyExchange:
             return contextlib.nullcontext()
         return torch.cuda.stream(self.stream)
 
-    def exchange(self, my_min, my_lo, my_hi=None):
-        """int32/int64 tensors (bit patterns of the uint32/uint64 keys) of this rank -> GatheredSketches."""
+    @property
+    def send_min(self):
+        """this rank's slice of the send buffer (int32): keys written here need no copy (`exchange()` without arguments)"""
+        return self._pad_min[:self.n_mine]
+
+    @property
+    def send_lo(self):
+        return self._pad_lo[:self.n_mine]
+
+    @property
+    def send_hi(self):
+        return self._pad_hi[:self.n_mine] if self.use_hi else None
+
+    def exchange(self, my_min=None, my_lo=None, my_hi=None):
+        """int32/int64 tensors (bit patterns of the uint32/uint64 keys) of this rank -> GatheredSketches.
+        Without arguments the keys are taken from where `send_min` / `send_lo` / `send_hi` point (for a caller that
+        assembles its keys there; bench.py passes them and pays the two copies)."""
         with self._on_stream():
-            self._pad_min[:my_min.numel()] = my_min
-            self._pad_lo[:my_lo.numel()] = my_lo
+            if my_min is not None:
+                self._pad_min[:my_min.numel()] = my_min
+                self._pad_lo[:my_lo.numel()] = my_lo
             self._all_gather(self._g_buf, self._pad_buf)
-            torch.index_select(self._g_as_min, 0, self._idx_mn, out=self.all_min)
-            torch.index_select(self._g_as_lo, 0, self._idx_lo, out=self.all_lo)
-            if self.use_hi:
+            torch.index_select(self._g_as_min, 0, self._idx_all, out=self._all_buf)
+            if self.use_hi and my_hi is not None:
                 self._pad_hi[:my_hi.numel()] = my_hi
+            if self.use_hi:
                 self._all_gather(self._g_hi, self._pad_hi)
                 torch.index_select(self._g_hi, 0, self._idx, out=self.all_hi)
         return GatheredSketches(self.all_min, self.all_lo, self.all_hi, self.sk_off)
@@ -146,11 +165,35 @@ class KeyExchange:
             self._plans[key] = plan
         return plan
 
+    # matrices up to this many bytes are collected by ONE reduce instead of strips (see collect_rows)
+    REDUCE_BYTES = 16 << 20
+
+    def rows_by_reduce(self, inter_local):
+        return inter_local.numel() * inter_local.element_size() <= self.REDUCE_BYTES
+
+    def prepare_rows(self, inter_local, dst=0):
+        """Call BEFORE the comparison that fills `inter_local` when the same tensor is collected every step: in the
+        reduce form (small matrices) the rows of the other ranks must be zero when the sum is taken; on `dst` they
+        still hold the previous step's collected rows, and elsewhere a backend may have used the tensor as scratch
+        (gloo's reduce does)."""
+        if self.world > 1 and self.rows_by_reduce(inter_local):
+            with self._on_stream():
+                inter_local.zero_()
+
     def collect_rows(self, inter_local, dst=0):
         """strips -> one rank: every rank sends the rows it owns (i % world == rank) of its n x n
         int32 matrix; on `dst` they are put in place in `inter_local`, which then holds the whole matrix.  Each
-        cell crosses the fabric once (an all-reduce of the n x n matrices moves 2 (world-1)/world of ALL of them)."""
+        cell crosses the fabric once (an all-reduce of the n x n matrices moves 2 (world-1)/world of ALL of them).
+        Small matrices (<= REDUCE_BYTES: every bench.py world size; 800 x 800 cells = 2.6 MB) take a shortcut that
+        costs the host one call instead of four: every rank's matrix is zero outside its own rows (spsp_compare_device
+        leaves those cells untouched and `prepare_rows` zeroed them), so ONE reduce (sum) onto `dst` puts
+        every strip in place."""
         n = inter_local.shape[0]
+        if self.rows_by_reduce(inter_local) and not (dist.get_backend(self.group) == "gloo" and inter_local.is_cuda):
+            if self.world > 1:
+                with self._on_stream():
+                    dist.reduce(inter_local, dst=dst, op=dist.ReduceOp.SUM, group=self.group)
+            return inter_local
         with self._on_stream():
             if dist.get_backend(self.group) == "gloo" and inter_local.is_cuda:
                 # (CPU-side collective in the tests: through host copies)

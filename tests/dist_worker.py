@@ -164,11 +164,20 @@ def main_c4(mode, rank, world):
             if a % world == rank:                                     # only the rows this rank owns
                 for b in hs[a_i + 1:]:
                     ln[a, b] += 1
-    full = ex.collect_rows(local)
+    own_rows = local.clone()
     ok = True
-    if rank == 0:
-        want = expected_inter(sets)
-        ok = bool((full.numpy() == want).all()) and int(want.sum()) > 10_000
+    want = expected_inter(sets) if rank == 0 else None
+    for limit in (spd.KeyExchange.REDUCE_BYTES, 0, 1 << 40):          # as sized (strips at 2 048 sketches), strips, one reduce
+        ex.REDUCE_BYTES = limit
+        for _ in range(2):                                            # twice: the same tensor is collected step after step
+            ex.prepare_rows(local)
+            ln[rank::world] = own_rows.numpy()[rank::world]           # "the comparison": writes this rank's rows only
+            full = ex.collect_rows(local)
+            if rank == 0:
+                good = bool((full.numpy() == want).all()) and int(want.sum()) > 10_000
+                if not good:
+                    print("c4 collect mismatch: limit", limit, "cells", int((full.numpy() != want).sum()), flush=True)
+                ok = ok and good
     return ok
 
 
@@ -193,6 +202,7 @@ def main_nccl(rank, world):
     ex = spd.KeyExchange(counts, dev, stream=stream)
     for _ in range(2):
         g = ex.exchange(d_min, d_lo)
+        ex.prepare_rows(d_inter)
         ctx.compare_device(k, g.minimizer.data_ptr(), g.kmer_lo.data_ptr(), None, g.sk_off, n_total, rank, world, d_inter.data_ptr())
         full = ex.collect_rows(d_inter)
     stream.synchronize()

@@ -45,13 +45,15 @@ steps = 300
 for it in range(steps + 20):
     if it == 20:
         acc.clear()
-    g = timed("exchange (2 copies, 1 all_gather, 2 index_selects)", lambda: ex.exchange(d_mn, d_lo))
+    g = timed("exchange (2 copies, 1 all_gather, 1 gather kernel)", lambda: ex.exchange(d_mn, d_lo))
     timed("compare_device_begin", lambda: ctx.compare_device_begin(31, g.minimizer.data_ptr(), g.kmer_lo.data_ptr(), None, ex.sk_off, n, 0, 1, d_inter.data_ptr()))
     timed("compare_end", lambda: ctx.compare_end())
-    timed("collect_rows", lambda: ex.collect_rows(d_inter))
+    timed("collect_rows (world 1: nothing to move)", lambda: ex.collect_rows(d_inter))
+    timed("  prepare_rows' zero_() alone", lambda: d_inter.zero_())
+    timed("  one reduce alone", lambda: dist.reduce(d_inter, dst=0))
     with torch.cuda.stream(st):
         timed("  one all_gather_into_tensor alone", lambda: dist.all_gather_into_tensor(ex._g_buf, ex._pad_buf))
-        timed("  one index_select alone", lambda: torch.index_select(ex._g_as_lo, 0, ex._idx_lo, out=ex.all_lo))
+        timed("  the compaction gather alone", lambda: torch.index_select(ex._g_as_min, 0, ex._idx_all, out=ex._all_buf))
     def enter_leave():
         with torch.cuda.stream(st):
             pass
