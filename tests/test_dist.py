@@ -54,3 +54,29 @@ def test_two_ranks_rccl_both_exchange_forms():
     if torch.cuda.device_count() < 2:
         pytest.skip("needs 2 GPUs")
     _launch("nccl", 29623, world=2)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_rehearsal_on_one_gpu():
+    """bench.py as the driver launches it for N = 2 (torch.distributed.run, one process per rank), rehearsed on ONE
+    GPU: both ranks compute on cuda:0 and the collectives go through gloo (BENCH_BACKEND / BENCH_SHARE_GPU).  The
+    whole N > 1 path of the file runs -- rank-sharded genomes, key all-gather, rows i % 2, strips to rank 0, barrier,
+    max over ranks, ONE JSON line from rank 0 -- and the line's untimed check says the collected matrix equals a
+    one-device comparison of all sketches."""
+    import json
+    env = dict(os.environ, BENCH_BACKEND="gloo", BENCH_SHARE_GPU="1", BENCH_PREWARM_STEPS="0", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               OMP_NUM_THREADS="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29631", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+           "--genomes", "6", "--length", "300000", "--no-extras", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]                # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 4
+    assert d["config"]["sketches_total"] == 12
+    assert d["config"]["exchange_check"].startswith("collected strips equal"), d["config"]["exchange_check"]
+    assert "rehearsal" in d["config"] and d["value"] > 0
