@@ -539,3 +539,44 @@ def test_config4_full_size_on_one_gpu(ctx):
             assert got[i, j] == len(np.intersect1d(sets[i], sets[j], assume_unique=True)), (i, j)
     assert np.count_nonzero(np.triu(got, 1)) == (n // fam_size) * fam_size * (fam_size - 1) // 2      # random 62-bit keys: no chance matches
     assert (np.tril(got) == 0).all()
+
+
+def test_small_problem_form_at_bench_size():
+    """k_parts_group_small: 100 sketches in families of 10, ~4 000 keys each (about 280 parts), on a whole-device
+    context and on contexts that say they own 32 and 2 CUs (grids and part counts follow the CU count) -- every matrix
+    equals an inverted-index count in numpy; a pair of identical sketches makes single cells large (LDS counters are
+    16 bits wide), one sketch is empty."""
+    rng = np.random.default_rng(17)
+    n, per = 100, 4000
+    fams = [np.unique(rng.integers(1, 2**62, size=per + per // 4, dtype=np.int64)) for _ in range(n // 10)]
+    sets = []
+    for i in range(n):
+        base = fams[i // 10]
+        keep = base[rng.random(len(base)) < 0.8]
+        extra = rng.integers(1, 2**62, size=int(rng.integers(0, 50)), dtype=np.int64)
+        sets.append(np.unique(np.concatenate([keep, extra])).astype(np.uint64))
+    sets[11] = sets[10].copy()                            # identical sketches: cells of ~4 000
+    sets[37] = np.zeros(0, np.uint64)                     # an empty one
+    holders = {}
+    for i, keys in enumerate(sets):
+        for key in keys.tolist():
+            holders.setdefault(key, []).append(i)
+    want = np.zeros((n, n), dtype=np.int64)
+    for hs in holders.values():
+        if len(hs) > 1:
+            a = np.array(hs)
+            ii, jj = np.triu_indices(len(a), 1)
+            np.add.at(want, (a[ii], a[jj]), 1)
+    assert want[10, 11] == len(sets[10]) and want.sum() > 1_000_000
+    sk = [sp.Sketch(31, 11, np.full(len(s), 5, np.uint32), s, None) for s in sets]
+    for cus in (0, 32, 2):
+        ctx = sp.Context(0)
+        if cus:
+            ctx.set_cu_count(cus)
+        ctx.timing_enable(True)
+        inter, card = ctx.compare(sk)
+        tm = ctx.timing_read()
+        assert tm["accumulate_launches"] == 0, "expected the small-problem form (no row-sum kernel)"
+        assert (inter.astype(np.int64) == want).all(), cus
+        assert [int(c) for c in card] == [len(s) for s in sets]
+        ctx.close()
