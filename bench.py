@@ -299,7 +299,6 @@ def main():
                 sl.handle = None
             else:
                 g = sl.exchange.exchange(d_my_min, d_my_lo)
-                sl.exchange.prepare_rows(sl.d_inter)      # (rank 0, small matrices: the strips arrive by one reduce)
                 sl.cmp.wait_dense(sl.scan)
                 sl.cmp.compare_device_begin(K, g.minimizer.data_ptr(), g.kmer_lo.data_ptr(), None, sk_off, n_total, rank,
                                             world, sl.d_inter.data_ptr())
@@ -336,7 +335,6 @@ def main():
                 else:
                     if exchange_kind == "gather":
                         g = sl.exchange.exchange(d_my_min, d_my_lo)
-                        sl.exchange.prepare_rows(sl.d_inter)
                         mn_ptr, lo_ptr = g.minimizer.data_ptr(), g.kmer_lo.data_ptr()
                     else:
                         mn_ptr, lo_ptr = d_all_min.data_ptr(), d_all_lo.data_ptr()

@@ -15,7 +15,10 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("SPSP_LIB") or os.path.join(_HERE, "libspsp.so")   # (SPSP_LIB: A/B experiments with another build)
+# SPSP_LIB: A/B experiments with another build (tools/ab_small.sh).  Whatever is loaded is reported: library_info() goes
+# into bench.py's JSON line and the pytest header, and an override is announced on stderr when it is loaded.
+LIB_OVERRIDDEN = bool(os.environ.get("SPSP_LIB"))
+LIB_PATH = os.environ.get("SPSP_LIB") or os.path.join(_HERE, "libspsp.so")
 
 SPSP_SCAN_DEFAULT = 0
 SPSP_SCAN_DIRECT_HASH = 1
@@ -86,6 +89,9 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise SpspError("%s not found: build the HIP extension first (make -C supersampler_amd/csrc)" % LIB_PATH)
     L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    if LIB_OVERRIDDEN:
+        import sys
+        print("[supersampler_amd] SPSP_LIB is set: loaded %s instead of the in-tree libspsp.so" % LIB_PATH, file=sys.stderr, flush=True)
     u64, u32, vp, cp, dbl, i32 = C.c_uint64, C.c_uint32, C.c_void_p, C.c_char_p, C.c_double, C.c_int
     P = C.POINTER
     L.spsp_create.restype = i32; L.spsp_create.argtypes = [i32, vp, P(vp)]
@@ -155,6 +161,12 @@ def lib():
     L.spsp_stage_times_read.restype = i32; L.spsp_stage_times_read.argtypes = [vp, P(StageTimes), i32]
     _lib = L
     return L
+
+
+def library_info():
+    """which shared library this process computes with (path, version string, whether SPSP_LIB replaced the in-tree build)"""
+    return {"path": os.path.relpath(LIB_PATH, os.path.dirname(_HERE)) if not LIB_OVERRIDDEN else LIB_PATH,
+            "version": lib().spsp_version().decode(), "overridden_by_SPSP_LIB": LIB_OVERRIDDEN}
 
 
 def _check(rc):

@@ -443,10 +443,13 @@ __device__ __forceinline__ uint64_t key_hash(uint64_t lo, uint32_t mn, uint64_t 
 __global__ __launch_bounds__(256) void k_parts_prepare(uint32_t* __restrict__ part_cnt, uint32_t n_parts, uint32_t* __restrict__ flags,
                                                       const uint64_t* __restrict__ host_skoff, uint64_t* __restrict__ dev_skoff,
                                                       uint32_t n_skoff, const uint32_t* __restrict__ host_sub, uint32_t* __restrict__ dev_sub,
-                                                      uint32_t n_sub, uint32_t* __restrict__ zero_inter, uint32_t zero_cells) {
+                                                      uint32_t n_sub, uint32_t* __restrict__ zero_inter, uint32_t zero_n) {
     const uint32_t stride = gridDim.x * blockDim.x, t = blockIdx.x * blockDim.x + threadIdx.x;
     for (uint32_t i = t; i < n_parts; i += stride) part_cnt[i] = 0;
-    for (uint32_t i = t; i < zero_cells; i += stride) zero_inter[i] = 0;     // small-problem form: the parts ADD into the pair matrix
+    // small-problem form: the parts ADD into the pair matrix, so the cells they add into -- (i, j > i), the cells every
+    // form of the comparison owns -- start from zero; the diagonal and the lower triangle stay the caller's (spsp.h)
+    for (uint32_t i = t; i < zero_n * zero_n; i += stride)
+        if (i % zero_n > i / zero_n) zero_inter[i] = 0;
     if (t < 16) flags[t] = 0;
     for (uint32_t i = t; i < n_skoff; i += stride) dev_skoff[i] = host_skoff[i];
     for (uint32_t i = t; i < n_sub; i += stride) dev_sub[i] = host_sub[i];
@@ -882,7 +885,7 @@ static int job_parts(spsp_ctx* ctx, CompareJob& J) {
                        ctx->c_part_cnt.as<uint32_t>(), J.n_parts, flags, (const uint64_t*)ctx->h_skoff,
                        ctx->c_skoff.as<uint64_t>(), J.n_skoff, reinterpret_cast<const uint32_t*>(ctx->h_skoff + J.n_skoff),
                        reinterpret_cast<uint32_t*>(ctx->c_skoff.as<uint64_t>() + J.n_skoff), J.n_sub,
-                       J.small ? J.P.d_inter : (uint32_t*)nullptr, J.small ? J.P.n * J.P.n : 0u);
+                       J.small ? J.P.d_inter : (uint32_t*)nullptr, J.small ? J.P.n : 0u);
     SPSP_HIP(hipGetLastError());
     // analysis hook (results are wrong with it): leave stages out to see what each costs a kernel of another stream
     static const int skip = getenv("SPSP_DEBUG_SKIP_STAGES") ? atoi(getenv("SPSP_DEBUG_SKIP_STAGES")) : 0;
@@ -1045,7 +1048,11 @@ static int job_begin_dictionary(spsp_ctx* ctx, CompareJob* J) {
 // records a part is planned to hold on average: kPartCap less the spread of the part sizes (keys shared by c
 // sketches arrive c at a time); halved for the second attempt
 static bool dbg_mean_set() { static const bool v = getenv("SPSP_DEBUG_PART_MEAN") != nullptr; return v; }
-static uint32_t parts_small(uint64_t entries) { return (uint32_t)std::max<uint64_t>(1, (entries + kSmallMean - 1) / kSmallMean); }
+static uint32_t parts_small(uint64_t entries) {
+    static const char* dbg_small_mean = getenv("SPSP_DEBUG_SMALL_MEAN");   // test hook: tiny parts, so that a small input reaches the part limit
+    const uint64_t mean = dbg_small_mean ? (uint64_t)std::max(1, atoi(dbg_small_mean)) : (uint64_t)kSmallMean;
+    return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, (entries + mean - 1) / mean), 0xffffffffull);
+}
 static uint32_t parts_for(uint64_t entries, uint32_t attempt) {
     static const char* dbg_mean = getenv("SPSP_DEBUG_PART_MEAN");   // test hook: tiny parts, so that small inputs reach tens of thousands of parts
     const uint64_t mean = dbg_mean ? (uint64_t)std::max(1, atoi(dbg_mean)) : (attempt == 0 ? 2900 : 1400);
@@ -1067,8 +1074,11 @@ static int compare_job_begin(spsp_ctx* ctx, CompareJob* job) {
         // small problems (bench.py's 100 sketches): one kernel groups and counts.  Every row must be owned (the parts
         // add into the whole matrix, which is cleared first) and k <= 32; SPSP_DEBUG_SMALL=0 keeps the general form
         static const bool small_off = getenv("SPSP_DEBUG_SMALL") && atoi(getenv("SPSP_DEBUG_SMALL")) == 0;
+        // ... and its parts are half the size, so the part count is checked on its own: the scatter's LDS counters and
+        // the 15 part bits of its (part, rank) word hold kMaxKeyParts parts, not more (two sketches of 3 x 10^7 keys each
+        // would otherwise ask for 41 000)
         J->small = J->group_small && !small_off && !dbg_mean_set() && P.n <= (uint32_t)kSmallN && P.n_own == P.n && P.row_first == 0 && P.row_stride == 1 &&
-                   P.row_limit >= P.n;
+                   P.row_limit >= P.n && parts_small(P.S_entries) <= (uint32_t)kMaxKeyParts;
         J->n_parts = J->small ? parts_small(P.S_entries) : parts_for(P.S_entries, 0);
         if ((rc = ctx->c_row.reserve((size_t)P.S_entries * 4))) return rc;
         if ((rc = job_parts(ctx, *J))) return rc;
@@ -1242,6 +1252,8 @@ static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t*
         if (!small && (r2 = ctx->c_where.reserve((size_t)S * 4 + 16))) return r2;
         if (!small && (r2 = ctx->c_lref.reserve((size_t)n_parts * kPartCap * 4))) return r2;
         uint32_t* where = small ? nullptr : ctx->c_where.as<uint32_t>();
+        static_assert(kMaxKeyParts < (1 << 15), "k_parts_scatter keeps the part in 15 bits of its (part, rank) word");
+        if (n_parts > (uint32_t)kMaxKeyParts) { set_error("internal: %u key parts exceed the scatter's limit of %d", n_parts, kMaxKeyParts); return SPSP_ERR_ARG; }
         const uint32_t per_wg = 4u * kScatThreads;
         const dim3 grid((uint32_t)((S + per_wg - 1) / per_wg));
         const size_t lds = (size_t)n_parts * 4;

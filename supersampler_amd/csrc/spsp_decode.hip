@@ -176,6 +176,13 @@ int sketch_decode_device_impl(spsp_ctx* ctx, const uint8_t* const* payloads, con
     std::vector<ParsedSketch> P(n);
     std::vector<int> rcs(n, SPSP_OK);
     std::vector<std::string> errs(n);
+    // sketches the GPU path cannot take -- more raw keys than the LDS sort holds (a 5 Mbp genome at s <= ~500), or not
+    // laid out as the sketcher writes them -- are decoded on the host (sorted, distinct) and uploaded in place: by the
+    // SAME worker pool that walks the payload structures, not one after the other on the calling thread
+    struct HostKeys { uint32_t* mn = nullptr; uint64_t *lo = nullptr, *hi = nullptr; uint64_t n = 0; };
+    std::vector<HostKeys> hk(n);
+    std::vector<uint8_t> presorted(n, 0);
+    auto free_hk = [&]() { for (auto& h : hk) { free(h.mn); free(h.lo); free(h.hi); } };
     {
         unsigned workers = std::thread::hardware_concurrency();
         if (workers == 0) workers = 1;
@@ -187,7 +194,14 @@ int sketch_decode_device_impl(spsp_ctx* ctx, const uint8_t* const* payloads, con
                 const uint32_t i = next.fetch_add(1);
                 if (i >= n) break;
                 rcs[i] = sketch_parse_structure_host(payloads[i], lens[i], &P[i]);
-                if (rcs[i]) errs[i] = spsp_last_error();
+                if (rcs[i]) { errs[i] = spsp_last_error(); continue; }
+                const uint32_t cap_i = P[i].k > 32 ? kSortCapHi : kSortCapLo;
+                const uint64_t keys = P[i].n_keys + ((extra_has && extra_has[i]) ? 1 : 0);
+                if (P[i].standard && keys <= cap_i) continue;
+                uint32_t kk, mm2;
+                rcs[i] = spsp_sketch_parse_host(payloads[i], lens[i], &kk, &mm2, &hk[i].mn, &hk[i].lo, &hk[i].hi, &hk[i].n);
+                if (rcs[i]) { errs[i] = spsp_last_error(); continue; }
+                presorted[i] = 1;
             }
         };
         std::vector<std::thread> pool;
@@ -195,27 +209,19 @@ int sketch_decode_device_impl(spsp_ctx* ctx, const uint8_t* const* payloads, con
         work();
         for (auto& th : pool) th.join();
     }
-    for (uint32_t i = 0; i < n; ++i) if (rcs[i]) { set_error("%s", errs[i].c_str()); return rcs[i]; }
+    for (uint32_t i = 0; i < n; ++i) if (rcs[i]) { free_hk(); set_error("%s", errs[i].c_str()); return rcs[i]; }
     for (uint32_t i = 1; i < n; ++i)
-        if (P[i].k != P[0].k || P[i].m != P[0].m) { set_error("sketch %u was made with k=%u m=%u, expected k=%u m=%u", i, P[i].k, P[i].m, P[0].k, P[0].m); return SPSP_ERR_FORMAT; }
+        if (P[i].k != P[0].k || P[i].m != P[0].m) { free_hk(); set_error("sketch %u was made with k=%u m=%u, expected k=%u m=%u", i, P[i].k, P[i].m, P[0].k, P[0].m); return SPSP_ERR_FORMAT; }
     const uint32_t k = n ? P[0].k : 0, m = n ? P[0].m : 0;
     *k_out = k; *m_out = m;
     sk_off[0] = 0;
     if (n == 0) return SPSP_OK;
     const bool has_hi = k > 32;
-    const uint32_t cap = has_hi ? kSortCapHi : kSortCapLo;
-    // sketches the GPU path cannot take are decoded on the host (sorted, distinct) and uploaded in place
-    struct HostKeys { uint32_t* mn = nullptr; uint64_t *lo = nullptr, *hi = nullptr; uint64_t n = 0; };
-    std::vector<HostKeys> hk(n);
-    std::vector<uint8_t> presorted(n, 0);
     std::vector<uint64_t> raw_off(n + 1, 0), text_off(n + 1, 0);
     std::vector<uint32_t> raw_cnt(n, 0);
-    auto free_hk = [&]() { for (auto& h : hk) { free(h.mn); free(h.lo); free(h.hi); } };
     for (uint32_t i = 0; i < n; ++i) {
         uint64_t keys = P[i].n_keys + ((extra_has && extra_has[i]) ? 1 : 0);
-        if (!P[i].standard || keys > cap) {
-            uint32_t kk, mm2;
-            if ((rc = spsp_sketch_parse_host(payloads[i], lens[i], &kk, &mm2, &hk[i].mn, &hk[i].lo, &hk[i].hi, &hk[i].n))) { free_hk(); return rc; }
+        if (presorted[i]) {
             if (extra_has && extra_has[i] && hk[i].n == 0) {       // (the phantom only ever joins an empty sketch)
                 hk[i].mn[0] = extra_mn[i];
                 // k == m: the k-mer is the minimizer; canonical = min(value, reverse complement)
@@ -223,7 +229,6 @@ int sketch_decode_device_impl(spsp_ctx* ctx, const uint8_t* const* payloads, con
                 for (uint32_t j = 0; j < m; ++j) r |= (uint64_t)(((v >> (2 * j)) & 3u) ^ 2u) << (2 * (m - 1 - j));
                 hk[i].lo[0] = v < r ? v : r; hk[i].hi[0] = 0; hk[i].n = 1;
             }
-            presorted[i] = 1;
             keys = hk[i].n;
             P[i].desc.clear();
         }

@@ -385,7 +385,7 @@ int sketch_parse_structure_host(const uint8_t* payload, uint64_t len, ParsedSket
             seq_len = (uint64_t)(nbytes - 1) * 4;
         }
         if (half > 0) {
-            if ((2 * half) % 4 != 0) P->standard = false;         // (k - m odd: a foreign file)
+            if ((2 * half) % 4 != 0) P->standard = false;         // k - m odd (never from bin/sub_sampler, which forces k and m odd, SubSampler.cpp:732-741; possible through spsp_sketch_build_host): a blob byte then straddles two super-k-mers -- host decoder
             for (uint64_t i = 0; (i + 1) * 2 * half <= seq_len; ++i) push(pos + 1 + i * (half / 2), mn, 0u, k - m + 1);
         } else if (seq_len == 0) {
             push(pos, mn, 2u, 1);                                  // k == m: the bare minimizer is one k-mer (Comparator.cpp:88-90,193-198)
@@ -890,11 +890,11 @@ static int compare_files_impl(spsp_ctx* ctx, const char* const* paths, uint32_t 
     // One file at a time per worker: no N open streams (Comparator.cpp:45-50); read + gunzip is independent work,
     // spread over a few host threads.  Decoding (strDecompressor, inject_minimizer, the k-mer walks, sort, unique)
     // happens for all sketches at once on the GPU (spsp_decode.hip).
+    unsigned workers = std::thread::hardware_concurrency();
+    if (workers == 0) workers = 1;
+    if (workers > 16) workers = 16;
+    if (workers > n) workers = n ? n : 1;
     {
-        unsigned workers = std::thread::hardware_concurrency();
-        if (workers == 0) workers = 1;
-        if (workers > 16) workers = 16;
-        if (workers > n) workers = n ? n : 1;
         std::atomic<uint32_t> next(0);
         auto work = [&]() {
             for (;;) {
@@ -939,11 +939,33 @@ static int compare_files_impl(spsp_ctx* ctx, const char* const* paths, uint32_t 
         // round-1 path: every sketch decoded and sorted by spsp_sketch_parse_host on the host threads, keys uploaded by spsp_compare
         std::vector<spsp_sketch_view> views(n);
         std::vector<void*> owned((size_t)n * 3, nullptr);
+        // decode + sort on the host threads (one sketch per task), then the checks in file order
+        std::vector<uint32_t> kks(n, 0), mms(n, 0);
+        std::vector<uint64_t> cnts(n, 0);
+        {
+            std::fill(rcs.begin(), rcs.end(), SPSP_OK);
+            std::atomic<uint32_t> next(0);
+            auto work = [&]() {
+                for (;;) {
+                    const uint32_t i = next.fetch_add(1);
+                    if (i >= n) break;
+                    uint32_t* mn = nullptr; uint64_t *lo = nullptr, *hi = nullptr;
+                    rcs[i] = spsp_sketch_parse_host(datas[i], lens[i], &kks[i], &mms[i], &mn, &lo, &hi, &cnts[i]);
+                    if (rcs[i]) { errs[i] = spsp_last_error(); continue; }
+                    owned[3 * (size_t)i] = mn; owned[3 * (size_t)i + 1] = lo; owned[3 * (size_t)i + 2] = hi;
+                }
+            };
+            std::vector<std::thread> pool;
+            for (unsigned w = 1; w < workers; ++w) pool.emplace_back(work);
+            work();
+            for (auto& th : pool) th.join();
+            for (uint32_t i = 0; i < n && !rc; ++i)
+                if (rcs[i]) { set_error("%s", errs[i].c_str()); rc = rcs[i]; }
+        }
         for (uint32_t i = 0; i < n && !rc; ++i) {
-            uint32_t kk = 0, mm2 = 0; uint32_t* mn = nullptr; uint64_t *lo = nullptr, *hi = nullptr; uint64_t cnt = 0;
-            rc = spsp_sketch_parse_host(datas[i], lens[i], &kk, &mm2, &mn, &lo, &hi, &cnt);
-            if (rc) break;
-            owned[3 * (size_t)i] = mn; owned[3 * (size_t)i + 1] = lo; owned[3 * (size_t)i + 2] = hi;
+            const uint32_t kk = kks[i], mm2 = mms[i];
+            uint32_t* mn = (uint32_t*)owned[3 * (size_t)i]; uint64_t *lo = (uint64_t*)owned[3 * (size_t)i + 1], *hi = (uint64_t*)owned[3 * (size_t)i + 2];
+            uint64_t cnt = cnts[i];
             if (kk != k0 || mm2 != m0) { set_error("'%s' was sketched with k=%u m=%u, expected k=%u m=%u", paths[i], kk, mm2, k0, m0); rc = SPSP_ERR_FORMAT; break; }
             if (extra_has[i] && cnt == 0) {
                 int has = 0; char tmp[16]; memset(tmp, 'A', sizeof tmp);

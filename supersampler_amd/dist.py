@@ -150,6 +150,8 @@ class KeyExchange:
             rows = -(-n // self.world)                                   # rows per rank, padded
             own = torch.arange(self.rank, n, self.world, device=dev)
             plan = {"rows": rows, "own": own, "mine": torch.zeros((rows, n), dtype=inter_local.dtype, device=dev)}
+            # cells (i, j > i) of the owned rows: what the comparison wrote; the rest of a strip is not the sender's to send
+            plan["upper"] = (torch.arange(n, device=dev)[None, :] > own[:, None]).to(inter_local.dtype)
             if self.rank == dst:
                 plan["all"] = torch.zeros((self.world, rows, n), dtype=inter_local.dtype, device=dev)
                 src, dstr = [], []
@@ -172,26 +174,38 @@ class KeyExchange:
         return inter_local.numel() * inter_local.element_size() <= self.REDUCE_BYTES
 
     def prepare_rows(self, inter_local, dst=0):
-        """Call BEFORE the comparison that fills `inter_local` when the same tensor is collected every step: in the
-        reduce form (small matrices) the rows of the other ranks must be zero when the sum is taken; on `dst` they
-        still hold the previous step's collected rows, and elsewhere a backend may have used the tensor as scratch
-        (gloo's reduce does)."""
-        if self.world > 1 and self.rows_by_reduce(inter_local):
-            with self._on_stream():
-                inter_local.zero_()
+        """Kept for callers of earlier versions: does nothing.  `collect_rows` itself clears every cell this rank does
+        not own before the sum is taken (a caller that forgot this call, or made it after queueing the comparison, used
+        to get silently doubled counts in the reduce form and correct ones in the strip form)."""
+        return None
+
+    def _own_mask(self, inter_local):
+        """1 in the cells this rank's comparison writes -- (i, j > i) of the rows i % world == rank -- 0 elsewhere"""
+        n = inter_local.shape[0]
+        key = ("mask", n, inter_local.dtype, str(inter_local.device))
+        self._plans = getattr(self, "_plans", {})
+        m = self._plans.get(key)
+        if m is None:
+            i = torch.arange(n, device=inter_local.device)
+            m = ((i[:, None] % self.world == self.rank) & (i[None, :] > i[:, None])).to(inter_local.dtype)
+            self._plans[key] = m
+        return m
 
     def collect_rows(self, inter_local, dst=0):
         """strips -> one rank: every rank sends the rows it owns (i % world == rank) of its n x n
         int32 matrix; on `dst` they are put in place in `inter_local`, which then holds the whole matrix.  Each
         cell crosses the fabric once (an all-reduce of the n x n matrices moves 2 (world-1)/world of ALL of them).
         Small matrices (<= REDUCE_BYTES: every bench.py world size; 800 x 800 cells = 2.6 MB) take a shortcut that
-        costs the host one call instead of four: every rank's matrix is zero outside its own rows (spsp_compare_device
-        leaves those cells untouched and `prepare_rows` zeroed them), so ONE reduce (sum) onto `dst` puts
-        every strip in place."""
+        costs the host two calls instead of four: everything outside the cells this rank's comparison wrote is cleared
+        here (one multiply by a cached 0/1 mask: on `dst` the tensor still holds the previous step's collected rows,
+        elsewhere a backend may have used it as scratch -- gloo's reduce does -- and spsp_compare_device leaves such
+        cells untouched), then ONE reduce (sum) onto `dst` puts every strip in place.  Self-contained: no call before
+        the comparison is needed, and the result does not depend on which of the two forms the matrix size selects."""
         n = inter_local.shape[0]
         if self.rows_by_reduce(inter_local) and not (dist.get_backend(self.group) == "gloo" and inter_local.is_cuda):
             if self.world > 1:
                 with self._on_stream():
+                    inter_local.mul_(self._own_mask(inter_local))
                     dist.reduce(inter_local, dst=dst, op=dist.ReduceOp.SUM, group=self.group)
             return inter_local
         with self._on_stream():
@@ -200,7 +214,8 @@ class KeyExchange:
                 rows = -(-n // self.world)
                 mine = torch.zeros((rows, n), dtype=inter_local.dtype, device=inter_local.device)
                 own = inter_local[self.rank::self.world]
-                mine[:own.shape[0]] = own
+                mine[:own.shape[0]] = own * (torch.arange(n, device=own.device)[None, :] >
+                                             torch.arange(self.rank, n, self.world, device=own.device)[:, None]).to(own.dtype)
                 torch.cuda.synchronize()
                 mine = mine.cpu()
                 parts = [torch.empty_like(mine) for _ in range(self.world)] if self.rank == dst else None
@@ -215,6 +230,7 @@ class KeyExchange:
             k_own = P["own"].numel()
             if k_own:
                 torch.index_select(inter_local, 0, P["own"], out=P["mine"][:k_own])      # own rows, one kernel
+                P["mine"][:k_own].mul_(P["upper"])
             parts = list(P["all"].unbind(0)) if self.rank == dst else None
             dist.gather(P["mine"], parts, dst=dst, group=self.group)
             if self.rank == dst and P["src"].numel():

@@ -12,3 +12,12 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def pytest_report_header(config):
+    try:
+        import supersampler_amd as sp
+        i = sp.library_info()
+        return "libspsp: %s [%s]%s" % (i["path"], i["version"], "  ** SPSP_LIB override **" if i["overridden_by_SPSP_LIB"] else "")
+    except Exception as e:  # noqa: BLE001 -- the header must not stop collection (the ABI test reports a missing library)
+        return "libspsp: not loadable (%s)" % e

@@ -170,8 +170,14 @@ def main_c4(mode, rank, world):
     for limit in (spd.KeyExchange.REDUCE_BYTES, 0, 1 << 40):          # as sized (strips at 2 048 sketches), strips, one reduce
         ex.REDUCE_BYTES = limit
         for _ in range(2):                                            # twice: the same tensor is collected step after step
-            ex.prepare_rows(local)
-            ln[rank::world] = own_rows.numpy()[rank::world]           # "the comparison": writes this rank's rows only
+            # no prepare call: collect_rows is self-contained.  "The comparison" writes the cells (i, j > i) of this
+            # rank's rows only; everything else is whatever the previous collect (or a backend's scratch use) left --
+            # poisoned on the ranks that are not the destination
+            if rank != 0:
+                ln[:] = 12345
+            ln[rank::world] = own_rows.numpy()[rank::world]
+            if rank != 0:
+                ln[np.tril_indices(n_total)] = 12345                  # (the comparison never writes the diagonal or below)
             full = ex.collect_rows(local)
             if rank == 0:
                 good = bool((full.numpy() == want).all()) and int(want.sum()) > 10_000
@@ -202,7 +208,6 @@ def main_nccl(rank, world):
     ex = spd.KeyExchange(counts, dev, stream=stream)
     for _ in range(2):
         g = ex.exchange(d_min, d_lo)
-        ex.prepare_rows(d_inter)
         ctx.compare_device(k, g.minimizer.data_ptr(), g.kmer_lo.data_ptr(), None, g.sk_off, n_total, rank, world, d_inter.data_ptr())
         full = ex.collect_rows(d_inter)
     stream.synchronize()

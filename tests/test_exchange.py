@@ -580,3 +580,32 @@ def test_small_problem_form_at_bench_size():
         assert (inter.astype(np.int64) == want).all(), cus
         assert [int(c) for c in card] == [len(s) for s in sets]
         ctx.close()
+
+
+def test_small_problem_form_respects_the_part_limit():
+    """The small-problem form (<= 128 sketches) cuts the keys into parts of half the size, so its part count reaches
+    the scatter's limit (32 000 parts: LDS counters, 15 part bits) at half the keys the general form does -- two sketches
+    of 3 x 10^7 keys each, say.  SPSP_DEBUG_SMALL_MEAN shrinks the planned part size so that 96 sketches of ~450 keys
+    get there: at mean 1 (43 000 parts) the call must take the general form, at mean 2 (21 000 parts) the small-problem
+    form runs with that many parts; both equal the inverted-index count, and the small form leaves the diagonal and the
+    lower triangle of the caller's matrix untouched like every other form."""
+    code = ("import sys, os\nsys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np, torch\nimport supersampler_amd as sp, dist_worker as dw\n"
+            "n = 96\nsets = dw.c4_shaped_sets(n, 560, seed=46)\nwant = dw.expected_inter(sets)\n"
+            "cnt = np.array([len(x) for x in sets]); assert cnt.sum() > 40000\n"
+            "dev = torch.device('cuda', 0)\n"
+            "sk_off = np.zeros(n + 1, np.uint64); sk_off[1:] = np.cumsum(cnt)\n"
+            "d_lo = torch.from_numpy(np.concatenate(sets).view(np.int64)).to(dev)\n"
+            "d_min = torch.full((int(cnt.sum()),), 7, dtype=torch.int32, device=dev)\n"
+            "d_inter = torch.full((n, n), -7, dtype=torch.int32, device=dev)\ntorch.cuda.synchronize()\n"
+            "ctx = sp.Context(0)\nctx.timing_enable(True)\n"
+            "ctx.compare_device(31, d_min.data_ptr(), d_lo.data_ptr(), None, sk_off, n, 0, 1, d_inter.data_ptr())\n"
+            "tm = ctx.timing_read()\ngot = d_inter.cpu().numpy()\n"
+            "up = np.triu(np.ones((n, n), bool), 1)\n"
+            "assert (got[up] == want[up]).all() and int(want.sum()) > 100000\n"
+            "assert (got[~up] == -7).all(), 'cells outside (i, j > i) were written'\n"
+            "small = tm['accumulate_launches'] == 0\n"
+            "assert small == (os.environ['SPSP_DEBUG_SMALL_MEAN'] == '2'), (small, tm)\nprint('ok')\n") % (ROOT, os.path.join(ROOT, "tests"))
+    for mean in ("1", "2"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SPSP_DEBUG_SMALL_MEAN=mean), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "ok" in r.stdout, (mean, r.stdout[-2000:], r.stderr[-3000:])

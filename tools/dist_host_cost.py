@@ -49,7 +49,7 @@ for it in range(steps + 20):
     timed("compare_device_begin", lambda: ctx.compare_device_begin(31, g.minimizer.data_ptr(), g.kmer_lo.data_ptr(), None, ex.sk_off, n, 0, 1, d_inter.data_ptr()))
     timed("compare_end", lambda: ctx.compare_end())
     timed("collect_rows (world 1: nothing to move)", lambda: ex.collect_rows(d_inter))
-    timed("  prepare_rows' zero_() alone", lambda: d_inter.zero_())
+    timed("  collect_rows' mask multiply alone", lambda: d_inter.mul_(ex._own_mask(d_inter)))
     timed("  one reduce alone", lambda: dist.reduce(d_inter, dst=0))
     with torch.cuda.stream(st):
         timed("  one all_gather_into_tensor alone", lambda: dist.all_gather_into_tensor(ex._g_buf, ex._pad_buf))
