@@ -202,6 +202,21 @@ def main():
     kmers_per_step = int(sum(max(0, len(r) - K + 1) for r in recs))
     d_bases = torch.from_numpy(bases).to(dev)
     d_off = torch.from_numpy(rec_off.view(np.int64)).to(dev)
+    # Consecutive steps scan DIFFERENT batches: a ring of BENCH_BATCHES buffers of the same shape (default 3 x 500 MB), so
+    # that no step can be served by what the previous one left in the 256 MiB Infinity Cache (FETCH_SIZE counts its hits
+    # as if they were HBM reads).  Batch b > 0 = batch 0 under a fixed permutation of the alphabet (A->C->G->T->A applied b
+    # times): other k-mers, other minimizers, other hits -- the same records, family structure and base composition.
+    n_batches = max(1, int(os.environ.get("BENCH_BATCHES", "3")))
+    d_batches = [d_bases]
+    for b in range(1, n_batches):
+        lut = torch.arange(256, dtype=torch.uint8, device=dev)
+        for j, c in enumerate(b"ACGT"):
+            lut[c] = b"ACGT"[(j + b) % 4]
+        nb = torch.empty_like(d_bases)
+        for a in range(0, d_bases.numel(), 1 << 27):
+            nb[a:a + (1 << 27)] = lut[d_bases[a:a + (1 << 27)].long()]
+        d_batches.append(nb)
+    del bases
     # sketches of this rank's genomes -> packed keys (host side of the CLIs, outside the timed region)
     sketches, payloads = [], []
     r0 = 0
@@ -263,7 +278,8 @@ def main():
         log("setup %.1fs: %d genomes x %d bp per GPU, %d records, %d k-mers/step/GPU, %d sketch keys, %d pairs"
             % (time.time() - t_setup, args.genomes, args.length, len(recs), kmers_per_step, int(sk_off[-1]), pairs_per_step))
 
-    scan_args = (p, d_bases.data_ptr(), d_bases.numel(), d_off.data_ptr(), len(recs))
+    scan_args = [(p, t.data_ptr(), t.numel(), d_off.data_ptr(), len(recs)) for t in d_batches]
+    step_no = [0]                                             # steps queued so far: step i scans batch i % n_batches
 
     # analysis only (the line it prints is not a valid measurement): the step without its comparison, to see what the
     # comparison's kernels cost the dense pass they run beside
@@ -282,7 +298,9 @@ def main():
         started from here, behind this dense pass)"""
         if prev is not None and prev.stream_a is not sl.stream_a:
             sl.scan.wait_dense(prev.scan)                 # "streams": dense passes never overlap each other
-        sl.scan.scan_device_begin(*scan_args)             # "tail" / "single": dense passes in order on the one scan stream
+        sl.batch = step_no[0] % n_batches
+        step_no[0] += 1
+        sl.scan.scan_device_begin(*scan_args[sl.batch])   # "tail" / "single": dense passes in order on the one scan stream
         if exchange_kind == "none":
             if schedule != "partition":
                 sl.cmp.wait_dense(sl.scan)                # the comparison starts behind this step's dense pass
@@ -321,6 +339,7 @@ def main():
             if exchange_kind == "gather":
                 sl.exchange.collect_rows(sl.d_inter)      # strips -> rank 0, on stream B
         last["n_out"], last["slot"] = n_out, sl
+        last["n_out_batch"][sl.batch] = n_out
 
     def run_steps(n):
         """n steps = n scans + n comparisons"""
@@ -329,7 +348,9 @@ def main():
             for _ in range(n):
                 # one stream: the key exchange (RCCL all-to-all) is queued first and runs behind the scan kernels
                 h = sl.exchange.begin(d_my_min.data_ptr(), d_my_lo.data_ptr(), None, my_sk_off) if exchange_kind == "slots" else None
-                d_out, n_out = ctx.scan_device(*scan_args)
+                sl.batch = step_no[0] % n_batches
+                step_no[0] += 1
+                d_out, n_out = ctx.scan_device(*scan_args[sl.batch])
                 if exchange_kind == "slots":
                     sl.exchange.end(h, sl.d_inter)        # partial pair matrix + RCCL reduction
                 else:
@@ -342,6 +363,7 @@ def main():
                     if exchange_kind == "gather":
                         sl.exchange.collect_rows(sl.d_inter)
                 last["n_out"], last["slot"] = n_out, sl
+                last["n_out_batch"][sl.batch] = n_out
             return
         import collections
         pending = collections.deque()                     # steps queued and not yet collected, oldest first
@@ -361,7 +383,7 @@ def main():
         while pending:
             collect_step(pending.popleft())
 
-    last = {"n_out": 0, "slot": slots[0]}
+    last = {"n_out": 0, "slot": slots[0], "n_out_batch": {}}
     host = {"queue": 0.0, "collect": 0.0}   # host seconds spent queueing / waiting (pipelined mode)
 
     def fence():
@@ -400,7 +422,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if stay_on_b:
         torch.cuda.set_stream(stream)
-    n_out = last["n_out"]
+    n_out = last["n_out_batch"].get(0, last["n_out"])       # batch 0 = the records the oracle is run over (cpu_baseline)
     d_inter = last["slot"].d_inter
     exchange = getattr(last["slot"], "exchange", None)
     tm = None
@@ -486,7 +508,9 @@ def main():
             "dtype": "u64",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: %d synthetic %d bp genomes per GPU (10 families, mu 0.001/0.01), "
-                                   "k=31 m=11 s=1000, scan + all-vs-all; inputs resident in HBM" % (args.genomes, args.length),
+                                   "k=31 m=11 s=1000, scan + all-vs-all; inputs resident in HBM; consecutive steps scan different batches "
+                                   "(ring of %d x %d MB)" % (args.genomes, args.length, n_batches, d_bases.numel() // 1000000),
+                       "batches": n_batches,
                        "k": K, "m": M, "s": S, "genomes_per_gpu": args.genomes, "genome_len": args.length,
                        "sketches_total": n_total, "scan_mode": args.mode,
                        "parallelism": {"none": "single GPU",
@@ -527,17 +551,19 @@ def main():
         }
         out["roofline"].update(pmc_traffic(args, "k_dense_pair"))
         # the same kernel with the GPU to itself (dense stage only, untimed extra): what the kernel reaches when nothing
-        # shares its CUs -- `achieved` above is measured inside the pipelined step, beside the other streams' kernels
+        # shares its CUs -- `achieved` above is measured inside the pipelined step, beside the other streams' kernels.
+        # Like the steps, consecutive launches read different batches.
+        n_b = d_bases.numel()
         try:
             ctx.timing_enable(True, sp.TIME_DENSE)
             ctx.timing_read()
-            for _ in range(20):
-                ctx.scan_hits_device(p, d_bases.data_ptr(), d_bases.numel())
+            for i in range(21):
+                ctx.scan_hits_device(p, d_batches[i % n_batches].data_ptr(), n_b)
             ta = ctx.timing_read()
             ctx.timing_enable(False)
             alone_ms = ta["dense_ms"] / max(1, ta["dense_launches"])
-            out["roofline"]["alone"] = {"dense_kernel_ms": alone_ms, "achieved": d_bases.numel() / 1e9 / (alone_ms / 1e3),
-                                        "frac": d_bases.numel() / 1e9 / (alone_ms / 1e3) / HBM_PEAK_GBS, "launches": int(ta["dense_launches"])}
+            out["roofline"]["alone"] = {"dense_kernel_ms": alone_ms, "achieved": n_b / 1e9 / (alone_ms / 1e3),
+                                        "frac": n_b / 1e9 / (alone_ms / 1e3) / HBM_PEAK_GBS, "launches": int(ta["dense_launches"])}
         except Exception as e:  # noqa: BLE001
             out["roofline"]["alone"] = {"error": repr(e)}
         # ... on the whole chip (context without CU mask), ASCII and 2-bit input (SURVEY.md 8d's second byte model: the
@@ -546,23 +572,47 @@ def main():
             out["roofline"]["whole_chip"] = {}
             ctx_full.set_cu_count(0, 2)
             torch.cuda.synchronize()
-            d_pk = ctx_full.pack_bases_device(d_bases.data_ptr(), d_bases.numel())
-            for name, src, flg, bpp in (("ascii", d_bases.data_ptr(), 0, 1.0), ("packed_2bit", d_pk, sp.SPSP_SCAN_PACKED_INPUT, 0.25)):
+            packed = []                                   # one packed copy per batch (125 MB each: ONE would sit in the Infinity Cache)
+            for t in d_batches:
+                d_pk = ctx_full.pack_bases_device(t.data_ptr(), n_b)
+                packed.append(device_bytes_as_tensor(d_pk, (n_b + 15) // 16 * 4 + 256, dev).clone())
+            torch.cuda.synchronize()
+            for name, srcs, flg, bpp in (("ascii", [t.data_ptr() for t in d_batches], 0, 1.0),
+                                         ("packed_2bit", [t.data_ptr() for t in packed], sp.SPSP_SCAN_PACKED_INPUT, 0.25)):
                 pw = sp.make_params(K, M, S, flags=flags | flg)
-                ctx_full.scan_hits_device(pw, src, d_bases.numel())
+                ctx_full.scan_hits_device(pw, srcs[0], n_b)
                 ctx_full.timing_enable(True, sp.TIME_DENSE)
                 ctx_full.timing_read()
-                for _ in range(20):
-                    ctx_full.scan_hits_device(pw, src, d_bases.numel())
+                for i in range(21):
+                    ctx_full.scan_hits_device(pw, srcs[i % len(srcs)], n_b)
                 tw = ctx_full.timing_read()
                 ctx_full.timing_enable(False)
                 ms_w = tw["dense_ms"] / max(1, tw["dense_launches"])
-                gbs = bpp * d_bases.numel() / 1e9 / (ms_w / 1e3)
-                out["roofline"]["whole_chip"][name] = {"dense_kernel_ms": ms_w, "positions_per_s": d_bases.numel() / (ms_w / 1e3),
+                gbs = bpp * n_b / 1e9 / (ms_w / 1e3)
+                out["roofline"]["whole_chip"][name] = {"dense_kernel_ms": ms_w, "positions_per_s": n_b / (ms_w / 1e3),
                                                        "byte_model": "%g B per m-mer position" % bpp, "achieved": gbs, "frac": gbs / HBM_PEAK_GBS}
+            del packed
             ctx_full.set_cu_count(0, 1)
         except Exception as e:  # noqa: BLE001
             out["roofline"]["whole_chip"] = {"error": repr(e)}
+        # the roofline's denominator measured on this box in this process: streaming copy and streaming read
+        # of 2 x 1 GiB on the whole chip, and on the CUs the dense stream owns inside the step
+        try:
+            torch.cuda.synchronize()
+            pm = ctx_full.measure_hbm(1 << 30, 10)
+            rl = out["roofline"]
+            rl["peak_measured"] = {"copy_GBps": pm["copy_GBps"], "read_GBps": pm["read_GBps"], "bytes_per_buffer": pm["bytes"], "launches": pm["reps"],
+                                   "kernels": "k_measure_copy / k_measure_read (non-temporal 16-byte loads and stores, 2 x 1024 lanes per CU), "
+                                              "HIP events, after two warm-up launches; copy counts bytes read + written"}
+            if schedule == "partition" and pipelined:
+                pd = ctx.measure_hbm(1 << 30, 10)
+                rl["peak_measured"]["dense_stream"] = {"n_cu": pd["n_cu"], "copy_GBps": pd["copy_GBps"], "read_GBps": pd["read_GBps"]}
+            rl["frac_of_measured_copy"] = achieved / pm["copy_GBps"]
+            rl["frac_of_measured_read"] = achieved / pm["read_GBps"]
+            rl["step_frac_of_measured_read"] = step_achieved / pm["read_GBps"]
+        except Exception as e:  # noqa: BLE001
+            out["roofline"]["peak_measured"] = {"error": repr(e)}
+        out["roofline"].update(sq_counters("k_dense_pair", dense_avg_ms, dense_cus if (schedule == "partition" and pipelined) else 0))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(recs, payloads, p, int(n_out), d_inter)
         if world == 1 and not args.no_extras:
@@ -574,6 +624,16 @@ def main():
                 out["end_to_end"] = end_to_end(ctx_full, args.no_cpu_baseline)
             except Exception as e:  # noqa: BLE001
                 out["end_to_end"] = {"error": repr(e)}
+            del d_batches[1:]                              # room (and a quiet card) for the two large legs
+            pk = out["roofline"].get("peak_measured", {})
+            try:
+                out["compare_c4"] = compare_config4(ctx_full, dev, args.no_cpu_baseline, pk)
+            except Exception as e:  # noqa: BLE001
+                out["compare_c4"] = {"error": repr(e)}
+            try:
+                out["scan_c5"] = scan_config5(ctx_full, dev, args.no_cpu_baseline, pk)
+            except Exception as e:  # noqa: BLE001
+                out["scan_c5"] = {"error": repr(e)}
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
@@ -591,12 +651,43 @@ def main():
         sp.stream_destroy(local_rank, h)
 
 
+def device_bytes_as_tensor(ptr, nbytes, dev):
+    """a uint8 torch view of `nbytes` of device memory at `ptr` (a buffer libspsp owns): plumbing for the bench only"""
+    class _Arr:
+        __cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+    return torch.as_tensor(_Arr(), device=dev)
+
+
+def sq_counters(kernel, kernel_ms, n_cu):
+    """VALU-issue fraction of a kernel (SURVEY.md 8d asks for it next to the HBM fraction: the scan is ALU-bound in
+    practice).  SQ counters cannot be read from inside this process; they come from the committed rocprofv3 --pmc passes
+    of the matching command (profiles/, with provenance).  A wave64 VALU instruction holds its SIMD's issue port for 4
+    cycles when one wave issues alone and for 2 when several waves interleave (MI355X_MICROARCH.md, "Wave scheduling" and
+    the "vector-instruction ISSUE cost" row); with SQ_BUSY_CU_CYCLES counting the cycles of every busy CU (4 SIMDs each)
+    the fraction of the issue slots taken is  SQ_INSTS_VALU * c / (4 * SQ_BUSY_CU_CYCLES), c = 2 (floor) or 4."""
+    try:
+        name = os.environ.get("BENCH_SQ_FILE", "r03_pmc_sq.json")
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
+        ks = [n for n in d["kernels"] if n == kernel or n.startswith(kernel + "<")]
+        c = d["kernels"][ks[0]]
+        f2 = c["SQ_INSTS_VALU"] * 2.0 / (4.0 * c["SQ_BUSY_CU_CYCLES"])
+        return {"valu_issue_frac": f2 * 2.0, "valu_issue_frac_floor": f2,
+                "valu_issue": {"kernel": ks[0], "SQ_INSTS_VALU": c["SQ_INSTS_VALU"], "SQ_BUSY_CU_CYCLES": c["SQ_BUSY_CU_CYCLES"],
+                               "SQ_INSTS_LDS": c.get("SQ_INSTS_LDS"), "SQ_LDS_BANK_CONFLICT": c.get("SQ_LDS_BANK_CONFLICT"),
+                               "SQ_LDS_IDX_ACTIVE": c.get("SQ_LDS_IDX_ACTIVE"),
+                               "definition": "valu_issue_frac = SQ_INSTS_VALU x 4 cycles / (4 SIMDs x SQ_BUSY_CU_CYCLES); _floor: x 2 cycles "
+                                             "(interleaved waves, SIMD-32 issue over 2 cycles)",
+                               "provenance": {"file": "profiles/" + name, "commit": d.get("commit"), "command": d.get("command")}}}
+    except Exception:
+        return {"valu_issue_frac": None}
+
+
 def pmc_traffic(args, kernel):
     """HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc passes of this
     same command, gfx950 correction applied).  Counters cannot be read from inside this process: the figure comes from
     the committed profile of the matching workload, with its provenance; null when there is none."""
     try:
-        name = os.environ.get("BENCH_PMC_FILE", "r02_pmc_hbm_traffic.json")
+        name = os.environ.get("BENCH_PMC_FILE", "r03_pmc_hbm_traffic.json")
         path = os.path.join(ROOT, "profiles", name)
         d = json.load(open(path))
         w = d["workload"]
@@ -605,7 +696,8 @@ def pmc_traffic(args, kernel):
         names = [n for n in d["kernels"] if n == kernel or n.startswith(kernel + "<")]     # (template instances: k_dense_pair<true>)
         return {"traffic": d["kernels"][names[0]]["hbm_bytes_per_launch_corrected"],
                 "traffic_provenance": {"file": "profiles/" + name, "commit": d.get("commit"),
-                                       "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled (gfx950)"}}
+                                       "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled (gfx950: "
+                                                 "a wide coalesced streaming read, the calibrated case)"}}
     except Exception:
         return {"traffic": None}
 
@@ -651,6 +743,152 @@ def cpu_baseline(recs, payloads, p, gpu_superkmers, d_inter):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+def compare_config4(ctx, dev, skip_oracle, peak):
+    """BASELINE configs[3] on ONE GPU: 10 000 sketches of ~5 000 k-mers (500 families of 20 at mu 0.001/0.01/0.05),
+    synthesised directly at the super-k-mer level, keys resident in HBM; what the reference times
+    (Comparator.cpp:499-509 around compare_sketches).  The oracle cannot hold this size (one (N+1)-bit colour vector
+    per distinct key: ~30 GB), so it is timed and compared on the first `sub` sketches -- pair counts do not depend on
+    the other sketches -- and 300 pairs drawn from the whole matrix are held against numpy set intersections."""
+    n, k, m = 10_000, 31, 11
+    t0 = time.time()
+    D = synth.direct_family_sketches(n, fam_size=20, k=k, m=m, seed=4, device=dev, skm_range=(120, 360))
+    cnt = np.diff(D.sk_off.astype(np.int64))
+    d_inter = torch.zeros((n, n), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    setup_s = time.time() - t0
+    call = lambda: ctx.compare_device(k, D.minimizer.data_ptr(), D.kmer_lo.data_ptr(), None, D.sk_off, n, 0, 1, d_inter.data_ptr())  # noqa: E731
+    for _ in range(2):
+        call()
+    reps = 5
+    ctx.timing_enable(True, sp.TIME_ALL)
+    ctx.timing_read()
+    for _ in range(reps):
+        call()
+    t = ctx.timing_read()
+    ctx.timing_enable(False)
+    ms = t["compare_ms"] / max(1, t["compare_calls"])
+    pairs = n * (n - 1) // 2
+    total = int(cnt.sum())
+    no_reuse = 8.0 * total * (n - 1) + 4.0 * pairs
+    compulsory = 8.0 * total + 4.0 * pairs
+    out = {"workload": "BASELINE configs[3] on one GPU: %d sketches synthesised directly (500 families x 20, mu 0.001/0.01/0.05), %d keys "
+                       "(mean %.0f, min %d, max %d), k=31 m=11; keys resident in HBM" % (n, total, cnt.mean(), cnt.min(), cnt.max()),
+           "pairs": pairs, "pipeline_ms": ms, "sketch_pairs_per_s": pairs / (ms / 1e3) if ms > 0 else None,
+           "kernel_ms": {name: t[a] / max(1, t[b]) for name, a, b in (("k_parts_scatter", "scatter_ms", "scatter_launches"),
+                                                                        ("k_parts_group", "group_ms", "group_launches"),
+                                                                        ("k_accumulate_sparse", "accumulate_ms", "accumulate_launches"))},
+           "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBS, "peak_measured_read": peak.get("read_GBps"), "unit": "GB/s",
+                        "no_reuse_model": {"bytes": no_reuse, "achieved": no_reuse / ms / 1e6, "frac": no_reuse / ms / 1e6 / HBM_PEAK_GBS,
+                                           "model": "sum over pairs of 8 (n_i + n_j) + 4 bytes (SURVEY.md 8d); reuse pushes it above 1"},
+                        "compulsory_model": {"bytes": compulsory, "achieved": compulsory / ms / 1e6, "frac": compulsory / ms / 1e6 / HBM_PEAK_GBS,
+                                             "model": "8 sum(n_i) + 4 N(N-1)/2 bytes: every key read once, every cell written once"}},
+           "setup_s": setup_s}
+    out["roofline"].update(pmc_compare("r03_c4_pmc_hbm_traffic.json", total))
+    # sampled pairs against numpy set intersections (whole matrix)
+    rng = np.random.default_rng(0)
+    mn_all, lo_all = D.minimizer, D.kmer_lo
+
+    def keys_of(i):
+        a, b = int(D.sk_off[i]), int(D.sk_off[i + 1])
+        return set(zip(mn_all[a:b].cpu().numpy().tolist(), lo_all[a:b].cpu().numpy().tolist()))
+    bad = checked = 0
+    sample = [(20 * f + int(a), 20 * f + int(b)) for f in rng.integers(0, n // 20, size=150) for a, b in [sorted(rng.choice(20, 2, replace=False))]]
+    sample += [tuple(sorted(int(x) for x in rng.integers(0, n, size=2))) for _ in range(150)]
+    for i, j in sample:
+        if i == j:
+            continue
+        checked += 1
+        bad += int(d_inter[i, j].item()) != len(keys_of(i) & keys_of(j))
+    nz = int(torch.count_nonzero(torch.triu(d_inter, 1)).item())
+    out["parity_sampled_pairs"] = {"checked": checked, "mismatches": bad, "against": "numpy set intersections of the (minimizer, k-mer) keys",
+                                   "nonzero_pairs": nz, "nonzero_pairs_expected": (n // 20) * 190}
+    if not skip_oracle:
+        from oracle import oracle_py as orc
+        sub = 1600
+        pls = [D.payload(i) for i in range(sub)]
+        want, card, sec = orc.compare(pls, timed=True)
+        got = d_inter[:sub, :sub].cpu().numpy().astype(np.uint32)
+        out["cpu_baseline"] = {"sketch_pairs_per_s": (sub * (sub - 1) // 2) / sec if sec > 0 else None, "cores": 1, "kind": "port", "cpu_model": cpu_model(),
+                               "sample": "oracle compare_sketches (Comparator.cpp:39-287 restated) over the first %d sketches written out in the "
+                                         "sketch format (%d pairs), single thread, %.2f s" % (sub, sub * (sub - 1) // 2, sec)}
+        out["parity_vs_oracle"] = {"sketches": sub, "pairs": sub * (sub - 1) // 2,
+                                   "equal": bool((np.triu(got, 1) == np.triu(want, 1)).all() and (card == cnt[:sub]).all()),
+                                   "nonzero_pairs": int(np.count_nonzero(np.triu(want, 1)))}
+    return out
+
+
+def scan_config5(ctx, dev, skip_oracle, peak, gbp=4.0):
+    """BASELINE configs[4] shape: k=63 m=15 s=100 (fine sampling, long super-k-mers), records of 10^6 bp generated on
+    the GPU (seed 5), `gbp` Gbp per scan call -- the 50 Gbp of the config streamed through HBM segment by segment is
+    tools/c5_scan.py; this leg measures one segment: the scan loop of SubSampler.cpp:367-455 over it."""
+    k, m, s = 63, 15, 100.0
+    rec_len = 1_000_000
+    n_rec = int(gbp * 1e9) // rec_len
+    seg_n = n_rec * rec_len
+    lut = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=dev)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    bases = torch.empty(seg_n + 64, dtype=torch.uint8, device=dev)
+    bases[seg_n:] = 65
+    for a in range(0, seg_n, 1 << 27):
+        b = min(seg_n, a + (1 << 27))
+        bases[a:b] = lut[torch.randint(0, 4, (b - a,), device=dev, generator=g, dtype=torch.int64)]
+    off = torch.arange(0, n_rec + 1, dtype=torch.int64, device=dev) * rec_len
+    torch.cuda.synchronize()
+    p = sp.make_params(k, m, s)
+    ctx.scan_device(p, bases.data_ptr(), seg_n, off.data_ptr(), n_rec)          # tables, buffers
+    ctx.timing_enable(True, sp.TIME_DENSE | sp.TIME_SCAN)
+    ctx.timing_read()
+    reps = 3
+    for _ in range(reps):
+        d_out, n_out = ctx.scan_device(p, bases.data_ptr(), seg_n, off.data_ptr(), n_rec)
+    t = ctx.timing_read()
+    ctx.timing_enable(False)
+    dense_ms = t["dense_ms"] / max(1, t["dense_launches"])
+    scan_ms = t["scan_ms"] / max(1, t["scan_calls"])
+    kmers = seg_n - n_rec * (k - 1)
+    sk = ctx.to_host(d_out, n_out, sp.SUPERKMER_DTYPE)
+    rec, start, ln = sk["rec"].astype(np.int64), sk["start"].astype(np.int64), sk["len"].astype(np.int64)
+    same = rec[1:] == rec[:-1]
+    inv = bool((np.diff(rec) >= 0).all() and (ln >= k).all() and (start + ln <= rec_len).all() and (ln <= 2 * k - m).all()
+               and (start[1:][same] >= start[:-1][same] + ln[:-1][same] - k + 1).all())
+    sel = int((ln - k + 1).sum())
+    gbs = seg_n / 1e9 / (dense_ms / 1e3)
+    out = {"workload": "BASELINE configs[4] shape: %d records x 10^6 bp = %.1f Gbp generated on the GPU (seed 5), k=63 m=15 s=100; "
+                       "one spsp_scan_device call, input resident in HBM (%.1f GB: 16 x the Infinity Cache)" % (n_rec, seg_n / 1e9, seg_n / 1e9),
+           "kmers": kmers, "scan_pipeline_ms": scan_ms, "dense_kernel_ms": dense_ms, "launches_timed": int(t["dense_launches"]),
+           "kmers_per_s": kmers / (scan_ms / 1e3), "kmers_per_s_dense_kernel": kmers / (dense_ms / 1e3),
+           "superkmers": int(n_out), "selected_kmers": sel, "selected_over_expected": sel / (kmers / s), "stream_invariants_ok": inv,
+           "roofline": {"kernel": "k_dense_bloom<15> (blocked Bloom filter over canonical 15-mers in LDS; XXH64 on survivors)", "bound": "hbm",
+                        "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                        "frac_of_measured_read": gbs / peak["read_GBps"] if peak.get("read_GBps") else None,
+                        "algorithmic_bytes_per_launch": seg_n, "byte_model": "1 B per m-mer position (cleaned ASCII)"}}
+    out["roofline"].update(sq_counters("k_dense_bloom", dense_ms, 0))
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r03_c5_pmc_hbm_traffic.json")))
+        kn = [x for x in d["kernels"] if x.startswith("k_dense_bloom")][0]
+        out["roofline"]["traffic"] = d["kernels"][kn]["hbm_bytes_per_launch_corrected"] * (seg_n / d["workload"]["bases_per_launch"])
+        out["roofline"]["traffic_provenance"] = {"file": "profiles/r03_c5_pmc_hbm_traffic.json", "commit": d.get("commit"),
+                                                 "scaled_from_bases_per_launch": d["workload"]["bases_per_launch"]}
+    except Exception:  # noqa: BLE001
+        out["roofline"]["traffic"] = None
+    if not skip_oracle:
+        from oracle import oracle_py as orc
+        orc.use_native()
+        R = 12
+        hb = bases[:R * rec_len].cpu().numpy()
+        ho = np.arange(0, R + 1, dtype=np.uint64) * rec_len
+        sec, km, nem = orc.scan_timed(k, m, p.threshold, hb, ho)
+        want, _ = orc.scan(k, m, p.threshold, hb, ho)
+        mine = sk[sk["rec"] < R]
+        out["cpu_baseline"] = {"value": km / sec if sec > 0 else None, "unit": "k-mers hashed/s", "cores": 1, "kind": "port", "cpu_model": cpu_model(),
+                               "sample": "oracle scan loop (SubSampler.cpp:357-455 restated), single thread, the first %d records "
+                                         "(%d k-mers), %.2f s" % (R, km, sec)}
+        out["parity_vs_oracle"] = {"records": R, "superkmers": int(len(want)),
+                                   "equal": bool(len(mine) == len(want) and all((mine[f] == want[f]).all() for f in want.dtype.names))}
+    return out
+
+
 def compare_config3(ctx, dev, skip_oracle):
     """BASELINE configs[2]: 1000 RefSeq-like sketches (~5 000 k-mers each, 50 families of 20 at mu 0.001/0.01/0.05,
     sizes spread over 2-8 k keys), all-vs-all on one GPU, keys resident in HBM.  Genomes are shortened and sampled
@@ -714,7 +952,7 @@ def compare_config3(ctx, dev, skip_oracle):
                                              "frac": compulsory / ms / 1e6 / HBM_PEAK_GBS if ms > 0 else None,
                                              "model": "8 sum(n_i) + 4 N(N-1)/2 bytes: every key read once, every cell written once"}},
            "setup_s": setup_s}
-    out["roofline"].update(pmc_compare())
+    out["roofline"].update(pmc_compare("r03_compare_pmc_hbm_traffic.json", total))
     if not skip_oracle:
         from oracle import oracle_py as orc
         want, card, sec = orc.compare(payloads, timed=True)
@@ -727,13 +965,17 @@ def compare_config3(ctx, dev, skip_oracle):
     return out
 
 
-def pmc_compare():
+def pmc_compare(name="r03_compare_pmc_hbm_traffic.json", n_keys=None):
     try:
-        name = "r02_compare_pmc_hbm_traffic.json"
         d = json.load(open(os.path.join(ROOT, "profiles", name)))
-        return {"traffic": {kname: v["hbm_bytes_per_launch_corrected"] for kname, v in d["kernels"].items()},
-                "traffic_provenance": {"file": "profiles/" + name, "commit": d.get("commit"),
-                                       "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of tests/tools/compare_bench.py 1000"}}
+        tr = {kname: v["hbm_bytes_per_launch_corrected"] for kname, v in d["kernels"].items() if kname.startswith(("k_parts", "k_accumulate"))}
+        out = {"traffic": tr, "traffic_total": sum(tr.values()),
+               "traffic_provenance": {"file": "profiles/" + name, "commit": d.get("commit"), "command": d.get("command"),
+                                      "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; per-kernel correction as "
+                                                "calibrated in profiles/r03_fetch_calibration.md (tools/pmc_traffic.py)"}}
+        if n_keys:
+            out["traffic_bytes_per_key"] = sum(tr.values()) / n_keys
+        return out
     except Exception:
         return {"traffic": None}
 

@@ -136,6 +136,19 @@ int spsp_timing_sample(spsp_ctx* ctx, uint32_t every);
 /* synchronises the stream, returns the totals since the previous read and resets them */
 int spsp_timing_read(spsp_ctx* ctx, spsp_timing* out);
 
+/* HBM calibration for the roofline's denominator ("calibrate with a device copy kernel on the box and use
+ * the measured figure"; the reference has no counterpart -- its only timer is Comparator.cpp:499-509): a streaming copy
+ * and a streaming read of two freshly allocated buffers of `bytes` each (take >= 1 GiB: the 256 MiB Infinity Cache must
+ * not serve them), `reps` launches each behind two warm-up launches, timed with HIP events on the context's stream and
+ * on the CUs that stream owns.  copy_GBps counts bytes read + bytes written. */
+typedef struct spsp_hbm_rates {
+    double copy_GBps, copy_ms;   /* per launch */
+    double read_GBps, read_ms;
+    uint64_t bytes;
+    uint32_t reps, n_cu;
+} spsp_hbm_rates;
+int spsp_measure_hbm_device(spsp_ctx* ctx, uint64_t bytes, uint32_t reps, spsp_hbm_rates* out);
+
 /* ------------------------------------------------------------- path A ---- */
 /* Subsampler::compute_threshold + ctor selection (SubSampler.cpp:622-631,
  * SubSampler.h:79-83). Host long double, as the reference. */

@@ -101,6 +101,8 @@ def lib():
                               C.POINTER(u32), C.POINTER(u32)]
     L.orc_compare_timed.restype = dbl
     L.orc_compare_timed.argtypes = [C.POINTER(cp), C.POINTER(u64), u32, u32, vp, vp]
+    L.orc_sketch_keys.restype = u64
+    L.orc_sketch_keys.argtypes = [cp, u64, C.POINTER(u32), C.POINTER(u32), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     L.orc_sort_csv.restype = vp
     L.orc_sort_csv.argtypes = [cp, u64, cp, u64, C.POINTER(u64)]
     L.orc_csv.restype = vp
@@ -217,6 +219,20 @@ def compare(payloads, n_query=None, timed=False):
     if rc != 0:
         raise RuntimeError("orc_compare failed")
     return inter, card, k.value, m.value
+
+
+def sketch_keys(payload):
+    """gunzipped sketch payload -> (k, m, minimizer u32[n], kmer_lo u64[n], kmer_hi u64[n]): the sorted distinct keys the
+    comparator's bucket walk (Comparator.cpp:186-260) yields for this file"""
+    k, m = C.c_uint32(), C.c_uint32()
+    mn, lo, hi = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    n = lib().orc_sketch_keys(payload, len(payload), C.byref(k), C.byref(m), C.byref(mn), C.byref(lo), C.byref(hi))
+    a = np.frombuffer(C.string_at(mn, 4 * n), dtype=np.uint32).copy()
+    b = np.frombuffer(C.string_at(lo, 8 * n), dtype=np.uint64).copy()
+    d = np.frombuffer(C.string_at(hi, 8 * n), dtype=np.uint64).copy()
+    for ptr in (mn, lo, hi):
+        lib().orc_free(ptr)
+    return k.value, m.value, a, b, d
 
 
 def csv(jaccard, names, inter, card, n_query=None, precision=6, min_threshold=0.0):

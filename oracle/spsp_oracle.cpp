@@ -864,6 +864,43 @@ int orc_compare(const char* const* payloads, const uint64_t* sizes, uint32_t n, 
     if (m_out) *m_out = (uint32_t)c.m;
     return 0;
 }
+// The distinct (minimizer, canonical k-mer) keys ONE sketch contributes to the comparison: the comparator's own merge
+// (compare_sketches :39-74) run over this file alone, with the per-bucket enumeration of skip_bucket / count_intersection
+// (walk_bucket above: strDecompressor, inject_minimizer, the k-mer walks, canonize) collecting keys instead of counting
+// them.  Sorted by (minimizer, k-mer).  What tests hold spsp_sketch_decode_device / spsp_sketch_parse_host against.
+// Returns the key count; arrays are malloc'd (orc_free).
+uint64_t orc_sketch_keys(const char* payload, uint64_t size, uint32_t* k_out, uint32_t* m_out, uint32_t** mn_out, uint64_t** lo_out,
+                         uint64_t** hi_out) {
+    Comparator c;
+    c.files.resize(1);
+    c.files[0].p = payload; c.files[0].n = size; c.files[0].pos = 0; c.files[0].eof = false;
+    c.query_size = 1; c.nb_files = 1;
+    c.nb_kmer_seen_infile.assign(1, 0);
+    c.minimizers.assign(1, 0);
+    std::vector<uint64_t> indices;
+    c.get_header_info();
+    c.increment_files(indices);
+    std::vector<std::pair<uint32_t, u128>> keys;
+    while (c.run) {
+        c.findMin(indices);
+        if (indices.empty()) break;
+        const uint64_t mn = c.minimizers[indices[0]];
+        const std::string minstr = num2str(mn, c.m);
+        c.walk_bucket(0, minstr, [&](u128 canon) { keys.emplace_back((uint32_t)mn, canon); });
+        c.increment_files(indices);
+    }
+    std::sort(keys.begin(), keys.end());
+    keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+    const size_t n = keys.size();
+    *mn_out = (uint32_t*)malloc(std::max<size_t>(1, n) * 4);
+    *lo_out = (uint64_t*)malloc(std::max<size_t>(1, n) * 8);
+    *hi_out = (uint64_t*)malloc(std::max<size_t>(1, n) * 8);
+    for (size_t i = 0; i < n; ++i) { (*mn_out)[i] = keys[i].first; (*lo_out)[i] = (uint64_t)keys[i].second; (*hi_out)[i] = (uint64_t)(keys[i].second >> 64); }
+    if (k_out) *k_out = (uint32_t)c.k;
+    if (m_out) *m_out = (uint32_t)c.m;
+    return n;
+}
+
 double orc_compare_timed(const char* const* payloads, const uint64_t* sizes, uint32_t n, uint32_t n_query,
                          uint32_t* inter, uint64_t* card) {
     auto t0 = std::chrono::steady_clock::now();

@@ -67,6 +67,11 @@ class StageTimes(C.Structure):
                                           "compare_s", "csv_s", "csv_gzip_s")] + [("sketch_files", C.c_uint64), ("compare_calls", C.c_uint64)]
 
 
+class HbmRates(C.Structure):
+    _fields_ = [("copy_GBps", C.c_double), ("copy_ms", C.c_double), ("read_GBps", C.c_double), ("read_ms", C.c_double),
+                ("bytes", C.c_uint64), ("reps", C.c_uint32), ("n_cu", C.c_uint32)]
+
+
 SUPERKMER_DTYPE = np.dtype([("rec", "<u4"), ("minimizer", "<u4"), ("start", "<u8"), ("len", "<u4"), ("rev", "<u4")])
 
 # every symbol include/spsp.h declares (tests check the .so exports them all)
@@ -75,7 +80,7 @@ ABI_SYMBOLS = [
     "spsp_stream_create_cus", "spsp_stream_destroy", "spsp_set_cu_count", "spsp_pack_bases_device",
     "spsp_timing_enable", "spsp_timing_sample", "spsp_timing_read", "spsp_threshold_host", "spsp_scan", "spsp_scan_device", "spsp_scan_device_begin", "spsp_scan_device_end", "spsp_scan_tail_stream", "spsp_wait_dense", "spsp_wait_stream", "spsp_scan_hits_device", "spsp_count_superkmers_device", "spsp_compare",
     "spsp_compare_device", "spsp_slot_bytes", "spsp_partition_keys_device", "spsp_compare_slots_device", "spsp_compare_device_begin", "spsp_compare_slots_device_begin", "spsp_compare_end", "spsp_fasta_clean_host", "spsp_fasta_clean_device", "spsp_sketch_text", "spsp_sketch_build_host", "spsp_sketch_parse_host", "spsp_sketch_decode_device", "spsp_sketch_chain_host",
-    "spsp_csv_host", "spsp_sort_csv_host", "spsp_read_file_host", "spsp_write_gz_host", "spsp_sketch_file", "spsp_compare_files", "spsp_compare_files_chatty", "spsp_stage_times_read",
+    "spsp_csv_host", "spsp_sort_csv_host", "spsp_read_file_host", "spsp_write_gz_host", "spsp_sketch_file", "spsp_compare_files", "spsp_compare_files_chatty", "spsp_stage_times_read", "spsp_measure_hbm_device",
 ]
 
 _lib = None
@@ -159,6 +164,7 @@ def lib():
     L.spsp_count_superkmers_device.argtypes = [vp, P(Params), vp, u64, vp, u32, P(u64)]
     L.spsp_scan_tail_stream.restype = i32; L.spsp_scan_tail_stream.argtypes = [vp, i32, vp]
     L.spsp_stage_times_read.restype = i32; L.spsp_stage_times_read.argtypes = [vp, P(StageTimes), i32]
+    L.spsp_measure_hbm_device.restype = i32; L.spsp_measure_hbm_device.argtypes = [vp, u64, u32, P(HbmRates)]
     _lib = L
     return L
 
@@ -348,6 +354,12 @@ class Context:
         t = Timing()
         _check(lib().spsp_timing_read(self._h, C.byref(t)))
         return {f: getattr(t, f) for f, _ in Timing._fields_}
+
+    def measure_hbm(self, nbytes=1 << 30, reps=10):
+        """streaming copy / read rates of this device on this context's stream (roofline denominator) as a dict"""
+        r = HbmRates()
+        _check(lib().spsp_measure_hbm_device(self._h, nbytes, reps, C.byref(r)))
+        return {f: getattr(r, f) for f, _ in HbmRates._fields_}
 
     # ---- path A
     def scan(self, params, bases, rec_off):

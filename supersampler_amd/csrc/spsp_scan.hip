@@ -647,7 +647,7 @@ __global__ __launch_bounds__(64 * kPairWaves) void k_dense_single(const uint8_t*
     auto body = [&](uint4& raw, uint64_t r, const uint8_t* at, uint32_t rl) {
         const uint32_t hi = pack16(raw);
         raw = load_row16(r + 2 < n_fast ? at + 2 * row_bytes : at);
-        const uint32_t nxt = __shfl_down(hi, 1);
+        const uint32_t nxt = next_lane(hi);
         const uint32_t c = single_lookup16(tab, hi, nxt);
         handle(halo_lane ? 0u : c, rl, hi, nxt);
     };
@@ -658,7 +658,7 @@ __global__ __launch_bounds__(64 * kPairWaves) void k_dense_single(const uint8_t*
     if (i < n_fast) { body(raw0, i, ptr, rel); ++i; rel += rel_step; }
     for (; i < n_my; ++i, rel += rel_step) {
         const uint32_t hi = load_pack(bases, n, (first + i) * kRowPosPair63 + (uint64_t)lane * kChunk);
-        const uint32_t nxt = __shfl_down(hi, 1);
+        const uint32_t nxt = next_lane(hi);
         const uint32_t c = single_lookup16(tab, hi, nxt);
         handle(halo_lane ? 0u : c, rel, hi, nxt);
     }
@@ -1060,7 +1060,7 @@ __global__ __launch_bounds__(64 * kPairWaves) void k_dense_bloom(const uint8_t* 
     auto body = [&](uint4& raw, uint64_t r, const uint8_t* at, uint32_t rl) {
         const uint32_t hi = pack16(raw);
         raw = load_row16(r + 2 < n_fast ? at + 2 * row_bytes : at);
-        const uint32_t nxt = __shfl_down(hi, 1);
+        const uint32_t nxt = next_lane(hi);
         const uint32_t c = bloom_lookup16<M>(tab, hi, nxt);
         handle(halo_lane ? 0u : c, rl, hi, nxt);
     };
@@ -1071,7 +1071,7 @@ __global__ __launch_bounds__(64 * kPairWaves) void k_dense_bloom(const uint8_t* 
     if (i < n_fast) { body(raw0, i, ptr, rel); ++i; rel += rel_step; }
     for (; i < n_my; ++i, rel += rel_step) {
         const uint32_t hi = load_pack(bases, n, (first + i) * kRowPosPair63 + (uint64_t)lane * kChunk);
-        const uint32_t nxt = __shfl_down(hi, 1);
+        const uint32_t nxt = next_lane(hi);
         const uint32_t c = bloom_lookup16<M>(tab, hi, nxt);
         handle(halo_lane ? 0u : c, rel, hi, nxt);
     }

@@ -69,3 +69,109 @@ def concat_records(genomes):
     off = np.zeros(len(genomes) + 1, dtype=np.uint64)
     off[1:] = np.cumsum([len(g) for g in genomes])
     return (np.concatenate(genomes) if genomes else np.zeros(0, np.uint8)), off
+
+
+class DirectSketches:
+    """Sketches synthesised directly at the super-k-mer level (SURVEY.md 8d allows it for the comparator configs): the
+    sorted distinct (minimizer, canonical k-mer) keys of every sketch, ready for spsp_compare_device, plus the stored
+    super-k-mers they were rolled from, so that any sketch can also be written out in the on-disk sketch format
+    (`payload`) for a reader that starts from files (the oracle, spsp_sketch_decode_device)."""
+
+    def __init__(self, k, m, minimizer, kmer_lo, sk_off, universe, skm_off, skm_bucket, skm_flank):
+        self.k, self.m = k, m
+        self.minimizer, self.kmer_lo, self.sk_off = minimizer, kmer_lo, sk_off     # int32 / int64 tensors (bit patterns), np.uint64[n + 1]
+        self.universe = universe                                                   # int64 tensor: the selectable minimizer values, ascending
+        self.skm_off, self.skm_bucket, self.skm_flank = skm_off, skm_bucket, skm_flank
+
+    @property
+    def n(self):
+        return len(self.sk_off) - 1
+
+    def payload(self, i, rate=1000.0):
+        """sketch i as sub_sampler would have written it (gunzipped): header, then per bucket in ascending minimizer
+        order [m ASCII][u32 n][blob of the maximal super-k-mers' k-m prefix and suffix bases, 4 per byte]["\\n\\n"]"""
+        k, m, side = self.k, self.m, self.k - self.m
+        r0, r1 = int(self.skm_off[i]), int(self.skm_off[i + 1])
+        bucket = self.skm_bucket[r0:r1].cpu().numpy()
+        flank = self.skm_flank[r0:r1].cpu().numpy()
+        uni = self.universe.cpu().numpy()
+        out = [b"%d %d %d %f\n" % (2 * k - m, m, (r1 - r0) * (side + 1), rate)]
+        order = np.argsort(bucket, kind="stable")
+        bucket, flank = bucket[order], flank[order]
+        nuc = np.frombuffer(b"ACTG", dtype=np.uint8)                               # int2nuc: A=0 C=1 T=2 G=3
+        cuts = np.flatnonzero(np.diff(bucket)) + 1
+        for lo, hi in zip(np.concatenate([[0], cuts]), np.concatenate([cuts, [len(bucket)]])):
+            if hi == lo:
+                continue
+            mn = int(uni[bucket[lo]])
+            out.append(nuc[[(mn >> (2 * (m - 1 - j))) & 3 for j in range(m)]].tobytes())
+            codes = flank[lo:hi].reshape(-1, 4).astype(np.uint8)                   # 2 (k - m) is a multiple of 4 for k, m odd
+            blob = bytes([0]) + ((codes[:, 0] << 6) | (codes[:, 1] << 4) | (codes[:, 2] << 2) | codes[:, 3]).astype(np.uint8).tobytes()
+            out.append(len(blob).to_bytes(4, "little") + blob + b"\n\n")
+        return b"".join(out)
+
+
+def direct_family_sketches(n, fam_size=20, k=31, m=11, seed=4, device="cpu", skm_range=(120, 480), mus=(0.001, 0.01, 0.05),
+                           n_buckets=100):
+    """n sketches in families of fam_size (BASELINE configs[2] / configs[3] shape): a family's ancestor is a set of
+    maximal super-k-mers (k-m random bases either side of a minimizer drawn from a universe of n_buckets values -- at
+    k=31 m=11 s=1000 only ~100 minimizer values are selectable at all); member j carries every ancestral
+    super-k-mer with independent substitutions at rate mus[j % len(mus)] in the flanks, and loses it (a fresh random one
+    takes its place) when a substitution falls into the minimizer.  Each super-k-mer contributes its k-m+1 canonical
+    k-mers; a sketch = the sorted distinct (minimizer, k-mer) keys.  torch on `device` (plumbing: setup is untimed)."""
+    import torch
+    assert k <= 32 and (k - m) % 2 == 0 and m <= 15
+    dev = torch.device(device)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    side = k - m
+    n_fam = (n + fam_size - 1) // fam_size
+    universe = torch.unique(torch.randint(0, 4 ** m, (4 * n_buckets,), generator=g, device=dev, dtype=torch.int64))[:n_buckets]
+    n_buckets = int(universe.numel())
+    h_fam = torch.randint(skm_range[0], skm_range[1] + 1, (n_fam,), generator=g, device=dev, dtype=torch.int64)
+    fam_off = torch.cumsum(h_fam, 0) - h_fam
+    total_anc = int(h_fam.sum().item())
+    anc_bucket = torch.randint(0, n_buckets, (total_anc,), generator=g, device=dev, dtype=torch.int64)
+    anc_flank = torch.randint(0, 4, (total_anc, 2 * side), generator=g, device=dev, dtype=torch.uint8)
+    sk = torch.arange(n, device=dev)
+    h_sk = h_fam[sk // fam_size]
+    skm_off = torch.cumsum(h_sk, 0) - h_sk
+    total = int(h_sk.sum().item())
+    sk_of = torch.repeat_interleave(sk, h_sk)
+    row = fam_off[sk_of // fam_size] + (torch.arange(total, device=dev) - skm_off[sk_of])
+    mu = torch.tensor(mus, device=dev, dtype=torch.float32)[(sk_of % fam_size) % len(mus)]
+    bucket, flank = anc_bucket[row], anc_flank[row]
+    hit = torch.rand((total, 2 * side), generator=g, device=dev) < mu[:, None]
+    flank = torch.where(hit, (flank + torch.randint(1, 4, flank.shape, generator=g, device=dev, dtype=torch.uint8)) % 4, flank)
+    lost = torch.rand((total,), generator=g, device=dev) < 1.0 - (1.0 - mu) ** m
+    flank = torch.where(lost[:, None], torch.randint(0, 4, flank.shape, generator=g, device=dev, dtype=torch.uint8), flank)
+    bucket = torch.where(lost, torch.randint(0, n_buckets, (total,), generator=g, device=dev, dtype=torch.int64), bucket)
+    del hit, lost, row, mu
+    mn_val = universe[bucket]
+    shifts = 2 * (m - 1 - torch.arange(m, device=dev))
+    codes = torch.cat([flank[:, :side], ((mn_val[:, None] >> shifts[None, :]) & 3).to(torch.uint8), flank[:, side:]], dim=1)   # [total, 2k - m]
+    w = side + 1
+    fwd = torch.zeros((total, w), dtype=torch.int64, device=dev)
+    rev = torch.zeros((total, w), dtype=torch.int64, device=dev)
+    for t in range(k):                                    # k-mer starting at p: base t is codes[p + t]
+        c = codes[:, t:t + w].to(torch.int64)
+        fwd = (fwd << 2) | c
+        rev = rev | ((c ^ 2) << (2 * t))                  # complement, reversed: base t lands 2t bits up
+    lo = torch.minimum(fwd, rev).reshape(-1)              # (both < 2^62: signed order = unsigned order)
+    del fwd, rev, codes
+    key_hi = ((sk_of << 32) | mn_val).repeat_interleave(w)
+    lo, order = torch.sort(lo, stable=True)
+    key_hi = key_hi[order]
+    key_hi, order = torch.sort(key_hi, stable=True)
+    lo = lo[order]
+    del order
+    first = torch.ones(lo.numel(), dtype=torch.bool, device=dev)
+    first[1:] = (lo[1:] != lo[:-1]) | (key_hi[1:] != key_hi[:-1])
+    lo, key_hi = lo[first], key_hi[first]
+    cnt = torch.bincount(key_hi >> 32, minlength=n).cpu().numpy()
+    sk_off = np.zeros(n + 1, dtype=np.uint64)
+    sk_off[1:] = np.cumsum(cnt)
+    skm_off_np = np.zeros(n + 1, dtype=np.int64)
+    skm_off_np[1:] = np.cumsum(h_sk.cpu().numpy())
+    return DirectSketches(k, m, (key_hi & 0xffffffff).to(torch.int32).contiguous(), lo.contiguous(), sk_off, universe, skm_off_np,
+                          bucket, flank)

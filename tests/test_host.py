@@ -132,6 +132,46 @@ def test_sketch_reader_matches_bruteforce_and_oracle(k, m, s):
         assert keys == sorted(set(keys))
 
 
+@pytest.mark.parametrize("k,m,s", [(31, 11, 25), (63, 15, 8), (21, 11, 3), (15, 15, 2)])
+def test_oracle_key_enumeration_matches_bruteforce_and_host_parser(k, m, s):
+    """orc_sketch_keys (the oracle's merge + bucket walk over ONE file) is what the GPU decoder is held against in
+    tests/test_gpu.py: here it is pinned itself -- equal to the brute-force reading of the payload (tests/bruteforce.py)
+    and, array for array, to the product's host parser."""
+    rng = np.random.default_rng(100 + k + m)
+    anc = bf.random_dna(rng, 5000)
+    for g in ([anc, anc[:2000]], [bf.mutate(rng, anc, 0.03)], [bf.random_dna(rng, 40)]):
+        pl = orc.sketch_fasta(bf.fasta(g), k, m, s)[0]
+        kk, mm, mn, lo, hi = orc.sketch_keys(pl)
+        assert (kk, mm) == (k, m)
+        assert {(int(a), (int(h) << 64) | int(l)) for a, l, h in zip(mn, lo, hi)} == bf.payload_set(pl)
+        sk = sp.sketch_parse(pl)
+        assert (sk.minimizer == mn).all() and (sk.kmer_lo == lo).all() and (sk.kmer_hi == hi).all()
+
+
+def test_direct_sketch_synthesis_is_consistent():
+    """synth.direct_family_sketches (the workload of bench.py's configs[3] leg): the key arrays it returns are what the
+    oracle and the host parser read out of the payloads it writes for the same sketches, and pair counts by numpy set
+    algebra equal the oracle's comparison of those payloads."""
+    from supersampler_amd import synth
+    D = synth.direct_family_sketches(40, fam_size=20, seed=11, skm_range=(30, 60))
+    pls = [D.payload(i) for i in range(D.n)]
+    mn_all, lo_all = D.minimizer.numpy().view(np.uint32), D.kmer_lo.numpy().view(np.uint64)
+    sets = []
+    for i in range(D.n):
+        a, b = int(D.sk_off[i]), int(D.sk_off[i + 1])
+        kk, mm, mn, lo, hi = orc.sketch_keys(pls[i])
+        assert (kk, mm) == (31, 11) and (mn == mn_all[a:b]).all() and (lo == lo_all[a:b]).all() and not hi.any()
+        sk = sp.sketch_parse(pls[i])
+        assert (sk.minimizer == mn).all() and (sk.kmer_lo == lo).all()
+        sets.append(set(zip(mn.tolist(), lo.tolist())))
+    inter, card, _, _ = orc.compare(pls)
+    assert [int(c) for c in card] == [len(x) for x in sets]
+    for i in range(D.n):
+        for j in range(i + 1, D.n):
+            assert inter[i, j] == len(sets[i] & sets[j]), (i, j)
+    assert inter[0, 1] > 0 and inter[0, 20] == 0 and inter[20, 39] > 0
+
+
 def test_sketch_reader_empty_and_bad_input():
     payload, _ = orc.sketch_fasta(b">x\nACGT\n", 31, 11, 1000)
     sk = sp.sketch_parse(payload)

@@ -1,49 +1,88 @@
 #!/bin/bash
 # Run ON THE GPU BOX (via gpurun) from the repo root: refreshes gpurun_out/prof_<tag>/ with
-#   bench line (plain run), kernel-trace summary of the same command, bench line under rocprof,
-#   FETCH_SIZE / WRITE_SIZE PMC passes (separate runs), the SQ counters of the dense kernel,
-#   and the same for the comparator at BASELINE configs[2] scale (tests/tools/compare_bench.py 1000).
-# usage: tools/refresh_profiles.sh <tag> [bench|compare|all]
+#   bench    bench line (plain run), kernel-trace summary of the same command, bench line under rocprof,
+#            FETCH_SIZE / WRITE_SIZE PMC passes (separate runs), the SQ counters of the dense kernel
+#   compare  the same for the comparator at BASELINE configs[2] scale (tests/tools/compare_bench.py 1000)
+#   c4       ... at configs[3] scale on one GPU (tools/c4_compare.py 10000)
+#   c5       the configs[4]-shape scan (tools/c5_scan.py 4 4): kernel trace, FETCH/WRITE, SQ counters of k_dense_bloom
+#   fetchcal FETCH_SIZE / WRITE_SIZE per byte for known access shapes (tools/exp/exp_fetchcal)
+# usage: tools/refresh_profiles.sh <tag> [bench|compare|c4|c5|fetchcal|all]
 set -o pipefail
-tag=${1:-r02}
+tag=${1:-r03}
 what=${2:-all}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$R/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
+SQ_SETS=("SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES SQ_INSTS_LDS" "SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_CYCLES")
+# pmc_pair <prefix> <command...>: FETCH_SIZE and WRITE_SIZE passes -> $out/<prefix>_FETCH_SIZE.csv / _WRITE_SIZE.csv
+pmc_pair() {
+  pre=$1; shift
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/pmc_${pre}_$c && timeout -k 10 400 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_${pre}_$c -o r -- "$@" > /dev/null 2>&1 || return 1
+    cp $(find /tmp/pmc_${pre}_$c -name "*counter_collection.csv") $out/${pre}_$c.csv
+  done
+}
+# sq_sets <prefix> <command...>: the three SQ counter passes -> /tmp/pmc_<prefix>_sq_*/
+sq_sets() {
+  pre=$1; shift
+  i=0
+  for set in "${SQ_SETS[@]}"; do
+    d=/tmp/pmc_${pre}_sq_$i; rm -rf $d; i=$((i+1))
+    timeout -k 10 400 rocprofv3 --pmc $set --output-format csv -d $d -o r -- "$@" > /dev/null 2>&1 || return 1
+  done
+}
 if [ "$what" = all ] || [ "$what" = bench ]; then
-timeout -k 10 400 python3 $R/bench.py > $out/bench_line.json 2> $out/bench.err || exit 1
+timeout -k 10 900 python3 $R/bench.py > $out/bench_line.json 2> $out/bench.err || exit 1
 echo "bench line done"
 rm -rf /tmp/kt && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o r -- python3 $R/bench.py --no-cpu-baseline --no-extras > $out/bench_line_under_rocprof.json 2>/dev/null || exit 1
 kt=$(find /tmp/kt -name "*kernel_trace.csv"); ks=$(find /tmp/kt -name "*kernel_stats.csv")
 python3 $R/tools/prof_summary.py $kt $out/bench_kernel_summary.md > /dev/null && cp $ks $out/bench_kernel_stats.csv
 python3 $R/tools/timeline_mid.py $kt 400 48 > $out/bench_timeline.txt
 echo "kernel trace done"
-for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/pmc_$c && timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -o r -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2>&1 || exit 1
-  cp $(find /tmp/pmc_$c -name "*counter_collection.csv") $out/pmc_$c.csv
-done
-python3 $R/tools/pmc_traffic.py $out/pmc_FETCH_SIZE.csv $out/pmc_WRITE_SIZE.csv $out/pmc_hbm_traffic.json > /dev/null
+cmd="python3 $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-extras"
+pmc_pair bench $cmd || exit 1
+python3 $R/tools/pmc_traffic.py $out/bench_FETCH_SIZE.csv $out/bench_WRITE_SIZE.csv $out/pmc_hbm_traffic.json > /dev/null
 echo "traffic done"
-for set in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES SQ_INSTS_LDS" "SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_CYCLES"; do
-  d=/tmp/pmc_sq_$(echo $set | cut -d" " -f1); rm -rf $d
-  timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d $d -o r -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2>&1 || exit 1
-done
-python3 $R/tools/pmc_sq.py "k_dense_pair<true, false>" $(find /tmp/pmc_sq_* -name "*counter_collection.csv") > $out/pmc_sq_k_dense_pair.txt
-python3 $R/tools/pmc_sq.py "k_dense_pair<true, false>" $out/pmc_FETCH_SIZE.csv $out/pmc_WRITE_SIZE.csv >> $out/pmc_sq_k_dense_pair.txt
-rm -f $out/pmc_FETCH_SIZE.csv $out/pmc_WRITE_SIZE.csv
+sq_sets bench $cmd || exit 1
+python3 $R/tools/pmc_sq.py --json $out/pmc_sq_bench.json --command "rocprofv3 --pmc <4 SQ counters per pass> -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-extras" "k_dense_pair<true, false>" $(find /tmp/pmc_bench_sq_* -name "*counter_collection.csv") > $out/pmc_sq_k_dense_pair.txt
+rm -f $out/bench_FETCH_SIZE.csv $out/bench_WRITE_SIZE.csv
 echo "sq done"
 fi
 if [ "$what" = all ] || [ "$what" = compare ]; then
 cmd="python3 $R/tests/tools/compare_bench.py 1000 0"
 rm -rf /tmp/ktc && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktc -o r -- $cmd > $out/compare_line_under_rocprof.txt 2>/dev/null || exit 1
 python3 $R/tools/prof_summary.py $(find /tmp/ktc -name "*kernel_trace.csv") $out/compare_kernel_summary.md > /dev/null
-for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf /tmp/pmcc_$c && timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d /tmp/pmcc_$c -o r -- $cmd > /dev/null 2>&1 || exit 1
-  cp $(find /tmp/pmcc_$c -name "*counter_collection.csv") $out/cpmc_$c.csv
-done
-python3 $R/tools/pmc_traffic.py $out/cpmc_FETCH_SIZE.csv $out/cpmc_WRITE_SIZE.csv $out/compare_pmc_hbm_traffic.json "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 tests/tools/compare_bench.py 1000 0" > /dev/null
-rm -f $out/cpmc_FETCH_SIZE.csv $out/cpmc_WRITE_SIZE.csv
+pmc_pair cmp $cmd || exit 1
+python3 $R/tools/pmc_traffic.py $out/cmp_FETCH_SIZE.csv $out/cmp_WRITE_SIZE.csv $out/compare_pmc_hbm_traffic.json "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 tests/tools/compare_bench.py 1000 0" '{"sketches": 1000, "shape": "BASELINE configs[2]: 50 families x 20, ~5 400 keys per sketch, k=31 m=11"}' > /dev/null
+rm -f $out/cmp_FETCH_SIZE.csv $out/cmp_WRITE_SIZE.csv
 echo "compare done"
+fi
+if [ "$what" = all ] || [ "$what" = c4 ]; then
+cmd="python3 $R/tools/c4_compare.py 10000 5"
+rm -rf /tmp/kt4 && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt4 -o r -- $cmd > $out/c4_line_under_rocprof.json 2>/dev/null || exit 1
+python3 $R/tools/prof_summary.py $(find /tmp/kt4 -name "*kernel_trace.csv") $out/c4_kernel_summary.md > /dev/null
+pmc_pair c4 $cmd || exit 1
+python3 $R/tools/pmc_traffic.py $out/c4_FETCH_SIZE.csv $out/c4_WRITE_SIZE.csv $out/c4_pmc_hbm_traffic.json "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 tools/c4_compare.py 10000 5" '{"sketches": 10000, "shape": "BASELINE configs[3]: 500 families x 20 synthesised directly, ~5 000 keys per sketch, k=31 m=11"}' > /dev/null
+rm -f $out/c4_FETCH_SIZE.csv $out/c4_WRITE_SIZE.csv
+echo "c4 done"
+fi
+if [ "$what" = all ] || [ "$what" = c5 ]; then
+cmd="python3 $R/tools/c5_scan.py 4 4"
+rm -rf /tmp/kt5 && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt5 -o r -- $cmd > $out/c5_run_under_rocprof.json 2>/dev/null || exit 1
+python3 $R/tools/prof_summary.py $(find /tmp/kt5 -name "*kernel_trace.csv") $out/c5_kernel_summary.md > /dev/null
+pmc_pair c5 $cmd || exit 1
+python3 $R/tools/pmc_traffic.py $out/c5_FETCH_SIZE.csv $out/c5_WRITE_SIZE.csv $out/c5_pmc_hbm_traffic.json "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 tools/c5_scan.py 4 4" '{"bases_per_launch": 4000000000, "k": 63, "m": 15, "s": 100.0}' > /dev/null
+sq_sets c5 $cmd || exit 1
+python3 $R/tools/pmc_sq.py --json $out/pmc_sq_c5.json --command "rocprofv3 --pmc <4 SQ counters per pass> -- python3 tools/c5_scan.py 4 4" "k_dense_bloom<15>" $(find /tmp/pmc_c5_sq_* -name "*counter_collection.csv") > $out/pmc_sq_k_dense_bloom.txt
+rm -f $out/c5_FETCH_SIZE.csv $out/c5_WRITE_SIZE.csv
+echo "c5 done"
+fi
+if [ "$what" = all ] || [ "$what" = fetchcal ]; then
+cmd="$R/tools/exp/exp_fetchcal 67108864"
+pmc_pair cal $cmd || exit 1
+python3 $R/tools/fetchcal_summary.py $out/cal_FETCH_SIZE.csv $out/cal_WRITE_SIZE.csv 67108864 $out/fetch_calibration.md > /dev/null
+rm -f $out/cal_FETCH_SIZE.csv $out/cal_WRITE_SIZE.csv
+echo "fetchcal done"
 fi
 ls -la $out
