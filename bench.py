@@ -621,7 +621,7 @@ def main():
             except Exception as e:  # noqa: BLE001 -- an extra must not take the headline down
                 out["compare"] = {"error": repr(e)}
             try:
-                out["end_to_end"] = end_to_end(ctx_full, args.no_cpu_baseline)
+                out["end_to_end"] = end_to_end(ctx_full, args.no_cpu_baseline, genomes)
             except Exception as e:  # noqa: BLE001
                 out["end_to_end"] = {"error": repr(e)}
             del d_batches[1:]                              # room (and a quiet card) for the two large legs
@@ -658,7 +658,7 @@ def device_bytes_as_tensor(ptr, nbytes, dev):
     return torch.as_tensor(_Arr(), device=dev)
 
 
-def sq_counters(kernel, kernel_ms, n_cu):
+def sq_counters(kernel, kernel_ms, n_cu, default_file="r03_pmc_sq_bench.json"):
     """VALU-issue fraction of a kernel (SURVEY.md 8d asks for it next to the HBM fraction: the scan is ALU-bound in
     practice).  SQ counters cannot be read from inside this process; they come from the committed rocprofv3 --pmc passes
     of the matching command (profiles/, with provenance).  A wave64 VALU instruction holds its SIMD's issue port for 4
@@ -666,7 +666,7 @@ def sq_counters(kernel, kernel_ms, n_cu):
     the "vector-instruction ISSUE cost" row); with SQ_BUSY_CU_CYCLES counting the cycles of every busy CU (4 SIMDs each)
     the fraction of the issue slots taken is  SQ_INSTS_VALU * c / (4 * SQ_BUSY_CU_CYCLES), c = 2 (floor) or 4."""
     try:
-        name = os.environ.get("BENCH_SQ_FILE", "r03_pmc_sq.json")
+        name = os.environ.get("BENCH_SQ_FILE", default_file)
         d = json.load(open(os.path.join(ROOT, "profiles", name)))
         ks = [n for n in d["kernels"] if n == kernel or n.startswith(kernel + "<")]
         c = d["kernels"][ks[0]]
@@ -863,7 +863,7 @@ def scan_config5(ctx, dev, skip_oracle, peak, gbp=4.0):
                         "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                         "frac_of_measured_read": gbs / peak["read_GBps"] if peak.get("read_GBps") else None,
                         "algorithmic_bytes_per_launch": seg_n, "byte_model": "1 B per m-mer position (cleaned ASCII)"}}
-    out["roofline"].update(sq_counters("k_dense_bloom", dense_ms, 0))
+    out["roofline"].update(sq_counters("k_dense_bloom", dense_ms, 0, "r03_pmc_sq_c5.json"))
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "r03_c5_pmc_hbm_traffic.json")))
         kn = [x for x in d["kernels"] if x.startswith("k_dense_bloom")][0]
@@ -980,86 +980,121 @@ def pmc_compare(name="r03_compare_pmc_hbm_traffic.json", n_keys=None):
         return {"traffic": None}
 
 
-def end_to_end(ctx, skip_oracle):
-    """The whole-file drivers, host I/O and PCIe included: spsp_sketch_file over FASTA files on tmpfs (plain and
-    gzip) and spsp_compare_files over the resulting sketches, with the stage times the library keeps, beside the
-    oracle run over the same files (Subsampler::parse_fasta_test SubSampler.cpp:306-510, Comparator::compare_sketches
-    + printers Comparator.cpp:39-74,362-460)."""
+def end_to_end(ctx, skip_oracle, genomes=None):
+    """The whole-file drivers, host I/O and PCIe included, at BASELINE configs[1] size: the 100 genomes of the step as
+    FASTA files on tmpfs -> sketch files (spsp_sketch_files: the reference's OpenMP loop over the file of files,
+    SubSampler.cpp:771-793, with 1, 8 and all host threads; spsp_sketch_file on one context for the per-stage times),
+    spsp_compare_files over the sketches, the two CLIs as processes -- beside the oracle (Subsampler::parse_fasta_test
+    SubSampler.cpp:306-510 restated, one file per thread as the reference's OpenMP loop) at the SAME thread counts."""
+    import concurrent.futures as cf
     import gzip
     import shutil
     import tempfile
-    n, length = 16, GENOME_LEN
     base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
     tmp = tempfile.mkdtemp(prefix="spsp_e2e_", dir=base)
+    # "all": the host threads this job may use -- a one-GPU box shares its host with seven other GPUs' jobs (16 of its
+    # threads per GPU), so the pool is capped there even when the affinity mask shows every core
+    cores = max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("BENCH_HOST_THREADS", "16"))))
     try:
-        gs = synth.family_genomes(7, n, length, 2, MUS)
-        plain, gz, texts = [], [], []
+        gs = genomes if genomes is not None else synth.family_genomes(7, 16, GENOME_LEN, 2, MUS)
+        n = len(gs)
+        plain, texts = [], []
         for i, g in enumerate(gs):
             data = synth.to_fasta(g, "g%d" % i, n_records=1 + i % 3)
             texts.append(data)
-            pth = os.path.join(tmp, "genome%02d.fa" % i)
+            pth = os.path.join(tmp, "genome%03d.fa" % i)
             open(pth, "wb").write(data)
             plain.append(pth)
-            open(pth + ".gz", "wb").write(gzip.compress(data, 1))
-            gz.append(pth + ".gz")
+        n_gz = min(16, n)
+        gz = []
+        for i in range(n_gz):
+            open(plain[i] + ".gz", "wb").write(gzip.compress(texts[i], 1))
+            gz.append(plain[i] + ".gz")
         kmers = sum(len(g) - K + 1 for g in gs)
+        kmers_gz = sum(len(g) - K + 1 for g in gs[:n_gz])
         fasta_bytes = sum(len(t) for t in texts)
-        out = {"workload": "%d synthetic %d bp genomes (2 families) as FASTA files on %s, k=31 m=11 s=1000; one context, one host thread "
-                           "for the sketches (the CLI runs -t of these side by side)" % (n, length, base or "the temp dir"),
-               "kmers": kmers, "fasta_bytes": fasta_bytes}
+        out = {"workload": "%d synthetic %d bp genomes (the step's batch) as FASTA files on %s, k=31 m=11 s=1000" % (n, len(gs[0]), base or "the temp dir"),
+               "kmers": kmers, "fasta_bytes": fasta_bytes, "host_threads_available": cores}
+        # ---- one context, one host thread: where the time of ONE file goes
         ctx.sketch_file(plain[0], os.path.join(tmp, "warm.gz"), K, M, S)   # buffers, tables
-        for label, files in (("plain", plain), ("gzip", gz)):
+        for label, files, km in (("plain", plain[:n_gz], kmers_gz), ("gzip", gz, kmers_gz)):
             ctx.stage_times(reset=True)
             t0 = time.perf_counter()
-            outs = []
             for i, f in enumerate(files):
-                o = os.path.join(tmp, "sk_%s_%02d.gz" % (label, i))
-                ctx.sketch_file(f, o, K, M, S)
-                outs.append(o)
+                ctx.sketch_file(f, os.path.join(tmp, "one_%s_%03d.gz" % (label, i)), K, M, S)
             wall = time.perf_counter() - t0
             st = ctx.stage_times(reset=True)
-            out["sketch_" + label] = {"wall_s": wall, "kmers_per_s": kmers / wall, "fasta_GB_per_s": fasta_bytes / wall / 1e9,
-                                      "stage_s": {key: st[key] for key in ("read_s", "ingest_s", "scan_s", "gather_s", "build_s", "gzip_s")}}
-            sk_files = outs
+            out["sketch_one_thread_" + label] = {"files": len(files), "wall_s": wall, "kmers_per_s": km / wall,
+                                                 "stage_s": {key: st[key] for key in ("read_s", "ingest_s", "scan_s", "gather_s", "build_s", "gzip_s")}}
+        # ---- the worker pool (what bin/sub_sampler -t runs): all files, 1 / 8 / all host threads
+        thread_counts = sorted({1, min(8, cores), cores})
+        sk_files = [os.path.join(tmp, "sk_%03d.gz" % i) for i in range(n)]
+        out["sketch_files"] = {}
+        sp.sketch_files(plain[:min(n, cores)], sk_files[:min(n, cores)], K, M, S, threads=cores)      # warm: page cache, HIP modules
+        for T in thread_counts:
+            t0 = time.perf_counter()
+            res, st, _ = sp.sketch_files(plain, sk_files, K, M, S, threads=T)
+            wall = time.perf_counter() - t0
+            assert all(r[0] == 0 for r in res)
+            out["sketch_files"]["threads_%d" % T] = {"wall_s": wall, "kmers_per_s": kmers / wall, "fasta_GB_per_s": fasta_bytes / wall / 1e9,
+                                                     "stage_s_summed_over_workers": {key: st[key] for key in ("read_s", "ingest_s", "scan_s", "gather_s", "build_s", "gzip_s")}}
+        t0 = time.perf_counter()
+        res, st, _ = sp.sketch_files(gz, [os.path.join(tmp, "skz_%03d.gz" % i) for i in range(n_gz)], K, M, S, threads=cores)
+        wall = time.perf_counter() - t0
+        out["sketch_files"]["gzip_input_threads_%d" % cores] = {"files": n_gz, "wall_s": wall, "kmers_per_s": kmers_gz / wall}
         t0 = time.perf_counter()
         ctx.compare_files(sk_files, os.path.join(tmp, "res"))
         wall = time.perf_counter() - t0
         st = ctx.stage_times(reset=True)
         out["compare_files"] = {"sketches": n, "wall_s": wall, "pairs_per_s": n * (n - 1) / 2 / wall,
                                 "stage_s": {key: st[key] for key in ("load_s", "compare_s", "csv_s", "csv_gzip_s")}}
-        # the CLIs themselves (process start, HIP initialisation, -t 4 threads)
+        # ---- the CLIs themselves (process start and HIP initialisation included)
         fof = os.path.join(tmp, "fof.txt")
         open(fof, "w").write("\n".join(plain) + "\n")
         cli = os.path.join(ROOT, "bin", "sub_sampler")
         if os.path.exists(cli):
+            out["cli"] = {"note": "whole processes: start + HIP initialisation (~0.2 s) included"}
+            for T in thread_counts:
+                t0 = time.perf_counter()
+                r = subprocess.run([cli, "-f", "fof.txt", "-t", str(T), "-v", "0", "-p", "cli%d_" % T], cwd=tmp, capture_output=True, text=True)
+                wall = time.perf_counter() - t0
+                out["cli"]["sub_sampler_-t%d" % T] = {"wall_s": wall, "kmers_per_s": kmers / wall, "rc": r.returncode}
             t0 = time.perf_counter()
-            r = subprocess.run([cli, "-f", "fof.txt", "-t", "4", "-v", "0", "-p", "cli_"], cwd=tmp, capture_output=True, text=True)
-            t1 = time.perf_counter()
-            r2 = subprocess.run([os.path.join(ROOT, "bin", "comparator"), "-f", "cli_fof.txt", "-o", "cli_res"], cwd=tmp,
+            r2 = subprocess.run([os.path.join(ROOT, "bin", "comparator"), "-f", "cli%d_fof.txt" % thread_counts[-1], "-o", "cli_res"], cwd=tmp,
                                 capture_output=True, text=True)
-            t2 = time.perf_counter()
-            out["cli"] = {"sub_sampler_-t4_wall_s": t1 - t0, "sub_sampler_kmers_per_s": kmers / (t1 - t0), "sub_sampler_rc": r.returncode,
-                          "comparator_wall_s": t2 - t1, "comparator_rc": r2.returncode,
-                          "note": "includes process start and HIP initialisation (~0.2 s each)"}
+            out["cli"]["comparator"] = {"wall_s": time.perf_counter() - t0, "pairs_per_s": n * (n - 1) / 2 / (time.perf_counter() - t0), "rc": r2.returncode}
         if not skip_oracle:
             from oracle import oracle_py as orc
-            m_files = 4                                     # bounded sample of the same files
-            t0 = time.perf_counter()
-            pls = [orc.sketch_fasta(texts[i], K, M, S)[0] for i in range(m_files)]
-            t1 = time.perf_counter()
-            gz_s = 0.0
-            for pl in pls:
-                tz = time.perf_counter()
+            out["cpu_baseline"] = {"kind": "port", "cpu_model": cpu_model(), "unit": "k-mers/s (FASTA text in memory -> gzip -9 sketch bytes)",
+                                   "what": "oracle parse_fasta_test restated (clean + scan + handle_superkmer + emission) + gzip -9, one file per "
+                                           "thread as the reference's OpenMP loop (SubSampler.cpp:771); bounded sample: the first min(n, 4 x threads) files"}
+            pls = {}
+
+            def one(i):
+                pl = orc.sketch_fasta(texts[i], K, M, S)[0]
                 gzip.compress(pl, 9)
-                gz_s += time.perf_counter() - tz
-            inter, card, csec = orc.compare(pls, timed=True)
-            okm = sum(len(gs[i]) - K + 1 for i in range(m_files))
-            out["cpu_baseline"] = {"kind": "port", "cores": 1, "cpu_model": cpu_model(),
-                                   "sketch_kmers_per_s": okm / (t1 - t0 + gz_s),
-                                   "sample": "oracle parse_fasta_test restated (clean + scan + handle_superkmer + emission) + gzip -9 over the first "
-                                             "%d files from memory, single thread, %.2f s" % (m_files, t1 - t0 + gz_s)}
-            mine = [sp.read_file(sk_files[i]) for i in range(m_files)]
-            out["parity_vs_oracle"] = bool(all(mine[i] == pls[i] for i in range(m_files)))
+                return i, pl
+            for T in thread_counts:
+                m_files = min(n, 4 * T)
+                t0 = time.perf_counter()
+                with cf.ThreadPoolExecutor(T) as ex:
+                    for i, pl in ex.map(one, range(m_files)):
+                        pls[i] = pl
+                wall = time.perf_counter() - t0
+                okm = sum(len(gs[i]) - K + 1 for i in range(m_files))
+                out["cpu_baseline"]["threads_%d" % T] = {"cores": T, "files": m_files, "wall_s": wall, "kmers_per_s": okm / wall}
+            out["cpu_baseline"]["value"] = out["cpu_baseline"]["threads_1"]["kmers_per_s"]
+            out["cpu_baseline"]["cores"] = 1
+            out["speedup_at_equal_threads"] = {
+                "library_worker_pool": {("threads_%d" % T): out["sketch_files"]["threads_%d" % T]["kmers_per_s"] / out["cpu_baseline"]["threads_%d" % T]["kmers_per_s"]
+                                        for T in thread_counts},
+                **({"cli_process": {("threads_%d" % T): out["cli"]["sub_sampler_-t%d" % T]["kmers_per_s"] / out["cpu_baseline"]["threads_%d" % T]["kmers_per_s"]
+                                    for T in thread_counts}} if "cli" in out else {})}
+            mine = {i: sp.read_file(sk_files[i]) for i in pls}
+            out["parity_vs_oracle"] = {"files": len(pls), "payload_bytes_equal": bool(all(mine[i] == pls[i] for i in pls))}
+            k_files = min(n, 24)
+            inter, card, csec = orc.compare([pls.get(i) or orc.sketch_fasta(texts[i], K, M, S)[0] for i in range(k_files)], timed=True)
+            out["cpu_baseline"]["compare_pairs_per_s"] = k_files * (k_files - 1) / 2 / csec if csec > 0 else None
         return out
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

@@ -339,6 +339,18 @@ int spsp_write_gz_host(const char* path, const uint8_t* data, uint64_t len, int 
  * Comparator.cpp:39-74, 362-460). */
 int spsp_sketch_file(spsp_ctx* ctx, const spsp_params* p, double rate, const char* fasta_path,
                      const char* out_path, spsp_sketch_stats* stats);
+/* The file-of-files loop of the reference's main (`#pragma omp parallel num_threads(c)`, SubSampler.cpp:771-793) inside
+ * the library: `threads` workers -- each with a context, i.e. a HIP stream, of its own on `device` -- take the n files
+ * off one queue in list order and run spsp_sketch_file on them, so that reading / gunzipping one file, the PCIe copy of
+ * another, the kernels of a third and the sketch builder / gzip of a fourth overlap inside ONE process.  `cb` (may be
+ * NULL) is called with phase 0 when file `index` is taken off the queue (inside the queue's lock: the calls come in
+ * list order, like the reference's critical(fof) section that prints the name and appends to the output list) and with
+ * phase 1 when it is done (rc, its statistics, the error text when rc != 0; one call at a time, like critical(cout)).
+ * A file that fails does not stop the others; the call then returns SPSP_ERR_IO.  `times` (may be NULL) receives the
+ * stage seconds summed over the workers. */
+typedef void (*spsp_file_callback)(void* user, uint32_t index, int phase, int rc, const spsp_sketch_stats* stats, const char* error);
+int spsp_sketch_files(int device, const spsp_params* p, double rate, const char* const* fasta_paths, const char* const* out_paths,
+                      uint32_t n, uint32_t threads, spsp_file_callback cb, void* user, struct spsp_stage_times* times);
 /* Wall-clock seconds the two whole-file drivers have spent per stage on this context (end-to-end measurement:
  * bench.py's `end_to_end` object).  GPU stages include the host synchronisation that ends them. */
 typedef struct spsp_stage_times {

@@ -72,6 +72,8 @@ class HbmRates(C.Structure):
                 ("bytes", C.c_uint64), ("reps", C.c_uint32), ("n_cu", C.c_uint32)]
 
 
+FILE_CALLBACK = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.POINTER(SketchStats), C.c_char_p)
+
 SUPERKMER_DTYPE = np.dtype([("rec", "<u4"), ("minimizer", "<u4"), ("start", "<u8"), ("len", "<u4"), ("rev", "<u4")])
 
 # every symbol include/spsp.h declares (tests check the .so exports them all)
@@ -80,7 +82,7 @@ ABI_SYMBOLS = [
     "spsp_stream_create_cus", "spsp_stream_destroy", "spsp_set_cu_count", "spsp_pack_bases_device",
     "spsp_timing_enable", "spsp_timing_sample", "spsp_timing_read", "spsp_threshold_host", "spsp_scan", "spsp_scan_device", "spsp_scan_device_begin", "spsp_scan_device_end", "spsp_scan_tail_stream", "spsp_wait_dense", "spsp_wait_stream", "spsp_scan_hits_device", "spsp_count_superkmers_device", "spsp_compare",
     "spsp_compare_device", "spsp_slot_bytes", "spsp_partition_keys_device", "spsp_compare_slots_device", "spsp_compare_device_begin", "spsp_compare_slots_device_begin", "spsp_compare_end", "spsp_fasta_clean_host", "spsp_fasta_clean_device", "spsp_sketch_text", "spsp_sketch_build_host", "spsp_sketch_parse_host", "spsp_sketch_decode_device", "spsp_sketch_chain_host",
-    "spsp_csv_host", "spsp_sort_csv_host", "spsp_read_file_host", "spsp_write_gz_host", "spsp_sketch_file", "spsp_compare_files", "spsp_compare_files_chatty", "spsp_stage_times_read", "spsp_measure_hbm_device",
+    "spsp_csv_host", "spsp_sort_csv_host", "spsp_read_file_host", "spsp_write_gz_host", "spsp_sketch_file", "spsp_compare_files", "spsp_compare_files_chatty", "spsp_stage_times_read", "spsp_measure_hbm_device", "spsp_sketch_files",
 ]
 
 _lib = None
@@ -164,6 +166,8 @@ def lib():
     L.spsp_count_superkmers_device.argtypes = [vp, P(Params), vp, u64, vp, u32, P(u64)]
     L.spsp_scan_tail_stream.restype = i32; L.spsp_scan_tail_stream.argtypes = [vp, i32, vp]
     L.spsp_stage_times_read.restype = i32; L.spsp_stage_times_read.argtypes = [vp, P(StageTimes), i32]
+    L.spsp_sketch_files.restype = i32
+    L.spsp_sketch_files.argtypes = [i32, P(Params), dbl, P(cp), P(cp), u32, u32, FILE_CALLBACK, vp, P(StageTimes)]
     L.spsp_measure_hbm_device.restype = i32; L.spsp_measure_hbm_device.argtypes = [vp, u64, u32, P(HbmRates)]
     _lib = L
     return L
@@ -297,6 +301,29 @@ def read_file(path):
 
 def write_gz(path, data, level=9):
     _check(lib().spsp_write_gz_host(path.encode(), data, len(data), level))
+
+
+def sketch_files(fasta_paths, out_paths, k=31, m=11, s=1000.0, abundance=1, threads=8, device=0, flags=SPSP_SCAN_DEFAULT):
+    """many FASTA files -> many sketch files on `threads` workers, one context (HIP stream) each (spsp_sketch_files).
+    Returns (per-file list of (rc, stats dict or None, error text or None), stage seconds summed over the workers)."""
+    n = len(fasta_paths)
+    p = make_params(k, m, s, abundance, flags)
+    ins = (C.c_char_p * n)(*[x.encode() for x in fasta_paths])
+    outs = (C.c_char_p * n)(*[x.encode() for x in out_paths])
+    res = [None] * n
+    started = []
+
+    def on_file(user, i, phase, rc, st, err):
+        if phase == 0:
+            started.append(i)
+        else:
+            res[i] = (rc, {f: getattr(st.contents, f) for f, _ in SketchStats._fields_} if rc == 0 else None, err.decode() if err else None)
+    cb = FILE_CALLBACK(on_file)
+    times = StageTimes()
+    rc = lib().spsp_sketch_files(device, C.byref(p), float(s), ins, outs, n, threads, cb, None, C.byref(times))
+    if rc != 0 and not any(r is not None and r[0] != 0 for r in res):
+        _check(rc)
+    return res, {f: getattr(times, f) for f, _ in StageTimes._fields_}, started
 
 
 def stream_create_cus(device, first_cu, n_cu):

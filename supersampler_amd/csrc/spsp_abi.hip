@@ -208,6 +208,7 @@ void spsp_destroy(spsp_ctx* c) {
     if (c->tail_stream) (void)hipStreamSynchronize(c->tail_stream);
     compare_job_drop(c);
     if (c->h_skoff) (void)hipHostFree(c->h_skoff);
+    if (c->h_text) (void)hipHostFree(c->h_text);
     if (c->dense_done) (void)hipEventDestroy(c->dense_done);
     if (c->tail_event) (void)hipEventDestroy(c->tail_event);
     if (c->scan_done) (void)hipEventDestroy(c->scan_done);

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <functional>
 #include <iostream>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -835,17 +836,65 @@ int spsp_write_gz_host(const char* path, const uint8_t* data, uint64_t len, int 
     return rc;
 }
 
+// A whole file into the context's PINNED staging buffer (grown on demand, reused file after file): a plain FASTA then
+// goes to the GPU with one asynchronous copy at the link's rate, instead of malloc + fread + a runtime-staged copy out
+// of pageable memory.  Returns 1 when the file is gzip / zlib packed (zstr autodetect, zstr.hpp:154-167): the caller
+// inflates it.
+static int slurp_pinned(spsp_ctx* ctx, const char* path, uint64_t* n) {
+    FILE* f = fopen(path, "rb");
+    if (!f) { set_error("cannot open '%s'", path); return SPSP_ERR_IO; }
+    struct stat st;
+    size_t want = (fstat(fileno(f), &st) == 0 && st.st_size > 0) ? (size_t)st.st_size + 1 : (1u << 20);
+    size_t got = 0;
+    for (;;) {
+        if (ctx->h_text_cap < want + 64) {
+            size_t cap = std::max<size_t>(want + 64 + want / 4, (size_t)4 << 20);
+            uint8_t* nb = nullptr;
+            if (hipHostMalloc((void**)&nb, cap, hipHostMallocDefault) != hipSuccess) { fclose(f); set_error("out of pinned host memory"); return SPSP_ERR_NOMEM; }
+            if (ctx->h_text) {
+                (void)hipStreamSynchronize(ctx->stream);             // a copy out of the old buffer may still be queued
+                if (got) memcpy(nb, ctx->h_text, got);
+                (void)hipHostFree(ctx->h_text);
+            }
+            ctx->h_text = nb; ctx->h_text_cap = cap;
+        }
+        const size_t r = fread(ctx->h_text + got, 1, want - got, f);
+        got += r;
+        if (r == 0) break;
+        if (got == want) want *= 2;                                  // (a file that grew, or a size fstat could not tell)
+    }
+    fclose(f);
+    *n = got;
+    const uint8_t* raw = ctx->h_text;
+    return (got >= 2 && ((raw[0] == 0x1F && raw[1] == 0x8B) || (raw[0] == 0x78 && (raw[1] == 0x01 || raw[1] == 0x9C || raw[1] == 0xDA)))) ? 1 : 0;
+}
+
 int spsp_sketch_file(spsp_ctx* ctx, const spsp_params* p, double rate, const char* fasta_path, const char* out_path,
                      spsp_sketch_stats* stats) {
-    if (!ctx) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    if (!ctx || !fasta_path || !out_path) { set_error("NULL argument"); return SPSP_ERR_ARG; }
     uint8_t* text = nullptr; uint64_t tlen = 0;
+    bool text_owned = false;
     double t0 = now_s();
-    int rc = spsp_read_file_host(fasta_path, &text, &tlen);
+    static const bool host_ingest = getenv("SPSP_HOST_INGEST") != nullptr;   // A/B switch: clean on the host, scan on the GPU
+    int rc;
+    if (host_ingest) { rc = spsp_read_file_host(fasta_path, &text, &tlen); text_owned = true; }
+    else {
+        SPSP_HIP(hipSetDevice(ctx->device));
+        rc = slurp_pinned(ctx, fasta_path, &tlen);
+        if (rc == 1) {                                               // packed: inflate out of the pinned copy
+            std::vector<uint8_t> plain;
+            rc = inflate_all(ctx->h_text, tlen, plain);
+            if (!rc) {
+                text = (uint8_t*)malloc(plain.size() + 64);
+                if (!text) { set_error("out of host memory"); rc = SPSP_ERR_NOMEM; }
+                else { if (!plain.empty()) memcpy(text, plain.data(), plain.size()); tlen = plain.size(); text_owned = true; }
+            }
+        } else if (rc == 0) text = ctx->h_text;
+    }
     if (rc) return rc;
     ctx->stages.read_s += now_s() - t0;
     ctx->stages.sketch_files += 1;
     uint8_t* payload = nullptr; uint64_t plen = 0;
-    static const bool host_ingest = getenv("SPSP_HOST_INGEST") != nullptr;   // A/B switch: clean on the host, scan on the GPU
     if (host_ingest) {
         uint8_t* bases = nullptr; uint64_t* off = nullptr; uint32_t n_rec = 0;
         rc = spsp_fasta_clean_host((const char*)text, tlen, &bases, &off, &n_rec);
@@ -857,13 +906,73 @@ int spsp_sketch_file(spsp_ctx* ctx, const spsp_params* p, double rate, const cha
         // ingest (getLineFasta + clean_dna), scan and super-k-mer gather all run on the GPU
         rc = spsp_sketch_text(ctx, p, rate, (const char*)text, tlen, &payload, &plen, stats);
     }
-    free(text);
+    if (text_owned) free(text);
     if (rc) { free(payload); return rc; }
     t0 = now_s();
     rc = spsp_write_gz_host(out_path, payload, plen, 9);  // level 9: SubSampler.cpp:326
     ctx->stages.gzip_s += now_s() - t0;
     free(payload);
     return rc;
+}
+
+// The reference's `#pragma omp parallel num_threads(c)` block over the file of files (SubSampler.cpp:771-793) inside
+// the library: `threads` workers, each with a context (= a HIP stream, a pinned staging buffer, device work buffers) of
+// its own, take files off one queue in list order.  While one worker reads or gunzips its file, another's is crossing
+// PCIe, a third's is in the kernels, a fourth builds or gzips a sketch: the stages of different files overlap and the
+// contexts' buffers and tables are set up once per worker, not once per file.
+int spsp_sketch_files(int device, const spsp_params* p, double rate, const char* const* fasta_paths, const char* const* out_paths,
+                      uint32_t n, uint32_t threads, spsp_file_callback cb, void* user, spsp_stage_times* times) {
+    if (!p || (n && (!fasta_paths || !out_paths))) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    int rc0 = spsp::check_params(p);
+    if (rc0) return rc0;
+    if (threads == 0) threads = 1;
+    if (threads > n) threads = n ? n : 1;
+    std::atomic<uint32_t> next(0);
+    std::mutex queue_m, done_m;
+    std::vector<spsp_stage_times> per(threads);
+    std::vector<int> worker_rc(threads, SPSP_OK);
+    std::vector<std::string> worker_err(threads);
+    std::atomic<int> failed_files(0);
+    auto work = [&](uint32_t w) {
+        spsp_ctx* ctx = nullptr;
+        memset(&per[w], 0, sizeof per[w]);
+        if ((worker_rc[w] = spsp_create(device, nullptr, &ctx))) { worker_err[w] = spsp_last_error(); return; }
+        for (;;) {
+            uint32_t i;
+            {   // named critical section `fof` of the reference (:776-786): dequeue + the caller's "started" line, in list order
+                std::lock_guard<std::mutex> g(queue_m);
+                i = next.load();
+                if (i >= n) break;
+                next.store(i + 1);
+                if (cb) cb(user, i, 0, SPSP_OK, nullptr, nullptr);
+            }
+            spsp_sketch_stats st;
+            memset(&st, 0, sizeof st);
+            const int rc = spsp_sketch_file(ctx, p, rate, fasta_paths[i], out_paths[i], &st);
+            if (rc) failed_files.fetch_add(1);
+            if (cb) {   // critical section `cout` (:791): one file's report at a time
+                std::lock_guard<std::mutex> g(done_m);
+                cb(user, i, 1, rc, &st, rc ? spsp_last_error() : nullptr);
+            }
+        }
+        per[w] = ctx->stages;
+        spsp_destroy(ctx);
+    };
+    std::vector<std::thread> pool;
+    for (uint32_t w = 1; w < threads; ++w) pool.emplace_back(work, w);
+    work(0);
+    for (auto& th : pool) th.join();
+    if (times) {
+        memset(times, 0, sizeof *times);
+        for (const auto& s : per) {
+            times->read_s += s.read_s; times->ingest_s += s.ingest_s; times->scan_s += s.scan_s; times->gather_s += s.gather_s;
+            times->build_s += s.build_s; times->gzip_s += s.gzip_s; times->sketch_files += s.sketch_files;
+        }
+    }
+    for (uint32_t w = 0; w < threads; ++w)
+        if (worker_rc[w]) { set_error("%s", worker_err[w].c_str()); return worker_rc[w]; }
+    if (failed_files.load()) { set_error("%d of %u files could not be sketched (see the callback's reports)", failed_files.load(), n); return SPSP_ERR_IO; }
+    return SPSP_OK;
 }
 
 int spsp_stage_times_read(spsp_ctx* ctx, spsp_stage_times* out, int reset) {

@@ -119,66 +119,57 @@ int main(int argc, char** argv) {
     P.flags = verbose ? SPSP_SCAN_STATS : SPSP_SCAN_DEFAULT;   // print_stat needs the count of ALL super-k-mers
     P.threshold = spsp_threshold_host(k, m1, s);
 
-    mutex io;
-    auto run_one = [&](spsp_ctx* ctx, const string& file) {
-        const string out = out_name(file, output) + ".gz";  // written to the CWD, like the reference
-        spsp_sketch_stats st;
-        memset(&st, 0, sizeof st);
-        const int rc = spsp_sketch_file(ctx, &P, s, file.c_str(), out.c_str(), &st);
-        lock_guard<mutex> g(io);
-        if (rc != SPSP_OK) { cout << "Can't process file: " << file << " (" << spsp_last_error() << ")" << endl; return; }
-        if (verbose) print_stat(st, k, m1, out);
+    // The reference's `#pragma omp parallel num_threads(c)` loop (SubSampler.cpp:771-793) lives in the library
+    // (spsp_sketch_files): c workers, one context (= one HIP stream) each, files taken off the list in order.  The
+    // callbacks print what the reference prints where it prints it: the file name (and the line of the output list) when
+    // a file is taken, print_stat when it is done.
+    struct Run {
+        vector<string> files, outs;
+        ofstream* out_fof;
+        bool verbose; uint32_t k, m;
+        bool gpu_ok = true;
+    } run;
+    run.verbose = verbose; run.k = k; run.m = m1; run.out_fof = nullptr;
+    auto cb = [](void* user, uint32_t i, int phase, int rc, const spsp_sketch_stats* st, const char* err) {
+        Run& r = *(Run*)user;
+        if (phase == 0) {
+            if (r.out_fof) {                                  // :784-785 (file-of-files mode only)
+                cout << r.files[i] << endl;
+                *r.out_fof << r.outs[i] << "\n";
+            }
+            return;
+        }
+        if (rc != SPSP_OK) { cout << "Can't process file: " << r.files[i] << " (" << (err ? err : "") << ")" << endl; return; }
+        if (r.verbose) print_stat(*st, r.k, r.m, r.outs[i]);
+    };
+    auto sketch_all = [&](unsigned threads) {
+        vector<const char*> in, out;
+        for (auto& f : run.files) in.push_back(f.c_str());
+        for (auto& f : run.outs) out.push_back(f.c_str());
+        const int rc = spsp_sketch_files(0, &P, s, in.data(), out.data(), (uint32_t)in.size(), threads, cb, &run, nullptr);
+        if (rc == SPSP_ERR_NO_DEVICE || rc == SPSP_ERR_HIP) { cout << "GPU unavailable: " << spsp_last_error() << endl; run.gpu_ok = false; }
     };
 
     if (input != "") {
-        spsp_ctx* ctx = nullptr;
-        if (spsp_create(0, nullptr, &ctx) != SPSP_OK) { cout << "GPU unavailable: " << spsp_last_error() << endl; return 1; }
-        run_one(ctx, input);
-        spsp_destroy(ctx);
-        return 0;
+        run.files.push_back(input);
+        run.outs.push_back(out_name(input, output) + ".gz");  // written to the CWD, like the reference
+        sketch_all(1);
+        return run.gpu_ok ? 0 : 1;
     }
-    // file of files: one worker (= one context = one HIP stream) per in-flight genome
     uint8_t* fof_data = nullptr; uint64_t fof_len = 0;
     if (spsp_read_file_host(inputfof.c_str(), &fof_data, &fof_len) != SPSP_OK) { cout << "Can't open file of file " << inputfof << endl; return 0; }
-    vector<string> files;
     {
         istringstream is(string((const char*)fof_data, fof_len));
         string line;
         while (getline(is, line))
-            if (line.size() > 3) files.push_back(line);
+            if (line.size() > 3) { run.files.push_back(line); run.outs.push_back(out_name(line, output) + ".gz"); }
         spsp_free(fof_data);
     }
     ofstream out_fof(out_name(inputfof, output) + ".txt");
-    size_t next = 0;
-    mutex qm;
+    run.out_fof = &out_fof;
     if (c == 0) c = 1;
-    vector<thread> pool;
-    bool gpu_ok = true;
-    for (unsigned t = 0; t < c; ++t) {
-        pool.emplace_back([&]() {
-            spsp_ctx* ctx = nullptr;
-            if (spsp_create(0, nullptr, &ctx) != SPSP_OK) {
-                lock_guard<mutex> g(io);
-                if (gpu_ok) cout << "GPU unavailable: " << spsp_last_error() << endl;
-                gpu_ok = false;
-                return;
-            }
-            for (;;) {
-                string file;
-                {
-                    lock_guard<mutex> g(qm);
-                    if (next >= files.size()) break;
-                    file = files[next++];
-                    lock_guard<mutex> g2(io);
-                    cout << file << endl;
-                    out_fof << out_name(file, output) + ".gz\n";
-                }
-                run_one(ctx, file);
-            }
-            spsp_destroy(ctx);
-        });
-    }
-    for (auto& th : pool) th.join();
+    sketch_all(c);
     out_fof.close();
+    const bool gpu_ok = run.gpu_ok;
     return gpu_ok ? 0 : 1;
 }

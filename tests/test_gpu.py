@@ -933,3 +933,43 @@ def test_scan_packed_input_equals_oracle(ctx, k, m, s, mode):
         assert ctx.scan_hits_device(p, d_pk, d_b.numel()) == ctx.scan_hits_device(pa, d_b.data_ptr(), d_b.numel())
     with pytest.raises(sp.SpspError):            # the host-buffer form takes ASCII only
         ctx.scan(sp.make_params(k, m, s, flags=sp.SPSP_SCAN_PACKED_INPUT), bases, offs)
+
+
+def test_sketch_files_worker_pool_equals_oracle(tmp_path):
+    """spsp_sketch_files (the library's form of the reference's OpenMP loop over the file of files, SubSampler.cpp:771-793):
+    nine FASTA files -- plain, gzip, multi-record, one with Ns and lower case, one empty of k-mers -- on 1, 3 and 16 workers;
+    every output gunzips to the oracle's payload, statistics equal the oracle's, the "started" callbacks come in list order,
+    and a file that does not exist fails alone."""
+    import gzip
+    k, m, s = 31, 11, 50.0
+    rng = np.random.default_rng(77)
+    texts = []
+    for i in range(9):
+        g = synth.random_genome(rng, int(rng.integers(30_000, 400_000)))
+        t = synth.to_fasta(g, "g%d" % i, n_records=1 + i % 3)
+        if i == 4:
+            t = t.replace(b"ACG", b"NnG", 50).replace(b"TT", b"tt", 500)
+        if i == 7:
+            t = b">tiny\nACGTACGT\n"
+        texts.append(t)
+    ins = []
+    for i, t in enumerate(texts):
+        pth = str(tmp_path / ("in%d.fa" % i)) + (".gz" if i % 2 else "")
+        open(pth, "wb").write(gzip.compress(t, 1) if i % 2 else t)
+        ins.append(pth)
+    want = [orc.sketch_fasta(t, k, m, s) for t in texts]
+    for threads in (1, 3, 16):
+        outs = [str(tmp_path / ("out_t%d_%d.gz" % (threads, i))) for i in range(len(ins))]
+        res, times, started = sp.sketch_files(ins, outs, k, m, s, threads=threads)
+        assert started == list(range(len(ins)))
+        assert times["sketch_files"] == len(ins)
+        for i, (rc, st, err) in enumerate(res):
+            assert rc == 0 and err is None, (threads, i, rc, err)
+            assert sp.read_file(outs[i]) == want[i][0], (threads, i)
+            for f in ("selected_kmer_number", "selected_superkmer_number", "seen_kmers_at_reconstruction", "actual_minimizer_number", "read_kmer"):
+                assert st[f] == want[i][1][f], (threads, i, f)
+    bad = ins[:2] + [str(tmp_path / "missing.fa")] + ins[2:4]
+    outs = [str(tmp_path / ("out_bad_%d.gz" % i)) for i in range(len(bad))]
+    res, _, started = sp.sketch_files(bad, outs, k, m, s, threads=2)
+    assert [r[0] == 0 for r in res] == [True, True, False, True, True] and "missing.fa" in res[2][2]
+    assert sp.read_file(outs[4]) == want[3][0]

@@ -2,7 +2,7 @@
 """Summarise rocprofv3 --pmc counter_collection CSVs (SQ counters) per kernel: per-launch averages over the launches
 with the most frequent grid (the steps).  Text to stdout; with --json <out.json> also the file bench.py's
 `valu_issue_frac` is looked up from.
-usage: tools/pmc_sq.py [--json out.json] [--command "text"] <kernel substring>[,<kernel substring>...] <counter_collection.csv> [more csv ...]"""
+usage: tools/pmc_sq.py [--json out.json] [--command "text"] <kernel substring>[;<kernel substring>...] <counter_collection.csv> [more csv ...]"""
 import csv
 import json
 import os
@@ -43,7 +43,7 @@ def main():
             command = args[1]
         args = args[2:]
     kernels = {}
-    for want in args[0].split(","):
+    for want in args[0].split(";"):
         c = collect(want, args[1:])
         if not c:
             continue
