@@ -229,10 +229,6 @@ constexpr uint32_t kRefOffBits = 26, kRefOffMask = (1u << kRefOffBits) - 1, kRef
 __host__ __device__ __forceinline__ uint32_t list_u16(uint32_t len) { return (len + 1 + 7) & ~7u; }
 __device__ __forceinline__ uint32_t list_ref(uint32_t o, uint32_t len) { return (o >> 3) | ((len < kRefLenMax ? len : kRefLenMax) << kRefOffBits); }
 constexpr uint32_t kNoList = 0xffffffffu;       // the key takes part in no pair of this job
-// partition form, inline lists: one 16-byte slot per record = half-word 0: how many holders of the key have a larger
-// sketch id than the record's own (0 .. kInlineMax), half-words 1..: those ids -- or half-word 0 = kInlineList and
-// dword 1 = the reference of the key's full list (as above)
-constexpr uint32_t kInlineMax = 7, kInlineList = 0xffffu, kInlineScan = 64;
 constexpr uint32_t kNoWhere = 0xffffffffu;      // partition form: the key's record did not fit its part (the call is redone)
 
 __global__ void k_insert_sparse(Keys K, const uint64_t* __restrict__ sk_off, uint64_t seed, uint64_t* __restrict__ table,
@@ -325,7 +321,6 @@ constexpr int kFlags = 8;   // [0] unsorted input, [1] fingerprint collision, [2
 constexpr int kSparseThreads = 1024, kAccU = 2, kAccW = 4, kAccR = 2;
 __global__ __launch_bounds__(kSparseThreads) void k_accumulate_sparse(const uint32_t* __restrict__ list_of_entry,
                                                                      const uint32_t* __restrict__ where,
-                                                                     const uint4* __restrict__ inl,
                                                                      const uint16_t* __restrict__ ids,
                                                                      const uint64_t* __restrict__ sk_begin,
                                                                      const uint64_t* __restrict__ sk_end, uint32_t n,
@@ -354,27 +349,7 @@ __global__ __launch_bounds__(kSparseThreads) void k_accumulate_sparse(const uint
     // loads, the second scattered -- eight of each in flight per thread hide the extra hop), then the lists kAccU at a time
     for (uint64_t e = e0 + threadIdx.x; e < e1; e += (uint64_t)kAccR * kSparseThreads) {
         uint32_t refs[kAccR];
-        if (inl) {
-            // partition form: ONE hop.  The 16-byte slot at the key's record holds the holders above this sketch themselves
-            // (up to kInlineMax of them: no further load), or the reference of the key's full list
-            uint32_t at[kAccR];
-#pragma unroll
-            for (int r = 0; r < kAccR; ++r) { const uint64_t eu = e + (uint64_t)r * kSparseThreads; at[r] = eu < e1 ? where[eu] : kNoWhere; }
-            uint4 sl[kAccR];
-#pragma unroll
-            for (int r = 0; r < kAccR; ++r) sl[r] = at[r] != kNoWhere ? inl[at[r]] : make_uint4(0, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < kAccR; ++r) {
-                const uint32_t na = sl[r].x & 0xffffu;
-                refs[r] = kNoList;
-                if (na == kInlineList) { refs[r] = sl[r].y; continue; }
-                // ids 1..na in half-words 1..7; every one is above i by construction
-                const uint32_t d[4] = {sl[r].x, sl[r].y, sl[r].z, sl[r].w};
-#pragma unroll
-                for (uint32_t h = 1; h <= kInlineMax; ++h)
-                    if (h <= na) { const uint32_t jj = (d[h >> 1] >> (16 * (h & 1))) & 0xffffu; if (jj - col0 < cols) atomicAdd(&s_cnt[((jj - col0) << copies_log2) + mine], 1u); }
-            }
-        } else if (where) {                                  // the reference sits where the key's record went
+        if (where) {                                         // the reference sits where the key's record went
             uint32_t at[kAccR];
 #pragma unroll
             for (int r = 0; r < kAccR; ++r) { const uint64_t eu = e + (uint64_t)r * kSparseThreads; at[r] = eu < e1 ? where[eu] : kNoWhere; }
@@ -641,120 +616,6 @@ __global__ __launch_bounds__(kGroupThreads) void k_parts_group(const uint64_t* _
     }
 }
 
-// The same grouping, but what a record gets back is the LIST ITSELF, not a reference to it: every record's 16-byte slot
-// (record order: coalesced) holds the ids of the key's holders above the record's own sketch -- all the row sums need,
-// since row i counts (i, j > i) only.  The row sums then reach a key's holders in ONE dependent load behind `where`
-// instead of two (list reference, then list: two scattered requests per key, which is what k_accumulate_sparse was bound
-// by), and a key held by one sketch costs them nothing further.  Keys with more than kInlineMax + 1 holders also get the
-// full list in `ids` as before, for those of their records that have more than kInlineMax holders above them.
-// After the probe phase the key arrays in LDS are dead: the holder lists (u16 per record) overlay them.
-template <bool HAS_HI>
-__global__ __launch_bounds__(kGroupThreads) void k_parts_group_inline(const uint64_t* __restrict__ recs, const uint32_t* __restrict__ part_cnt,
-                                                                     uint16_t* __restrict__ ids, uint4* __restrict__ inl,
-                                                                     uint32_t* __restrict__ flags) {
-    constexpr uint32_t W = HAS_HI ? 3 : 2;
-    constexpr uint32_t R = kPartCap / kGroupThreads;      // records per thread
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds_g[];
-    uint64_t* k_lo = reinterpret_cast<uint64_t*>(lds_g);                                  // [kPartCap]
-    uint64_t* k_hi = k_lo + kPartCap;                                                     // [kPartCap] (HAS_HI only)
-    uint32_t* k_mn = reinterpret_cast<uint32_t*>(k_hi + (HAS_HI ? kPartCap : 0));         // [kPartCap]
-    uint32_t* slot = k_mn + kPartCap;                                                     // [kPartSlots]
-    uint32_t* cursor = slot + kPartSlots;                                                 // [0] holder lists (LDS), [1] full lists (global)
-    uint16_t* hl = reinterpret_cast<uint16_t*>(lds_g);                                    // [kPartCap], once the keys are dead
-    const uint32_t p = blockIdx.x, t = threadIdx.x;
-    const uint32_t n = part_cnt[p];
-    if (n > (uint32_t)kPartCap) { if (t == 0) atomicOr(&flags[6], 1u); return; }
-    for (uint32_t x = t; x < (uint32_t)kPartSlots; x += kGroupThreads) slot[x] = 0;
-    if (t < 2) cursor[t] = 0;
-    const uint64_t* base = recs + (uint64_t)p * kPartCap * W;
-    uint64_t lo[R], hi[R];
-    uint32_t mn[R], sk[R], hs[R], rank[R];
-#pragma unroll
-    for (uint32_t u = 0; u < R; ++u) {
-        const uint32_t r = u * kGroupThreads + t;
-        uint64_t w1;
-        if (HAS_HI) { lo[u] = base[(uint64_t)r * W]; w1 = base[(uint64_t)r * W + 1]; hi[u] = base[(uint64_t)r * W + 2]; }
-        else { const ulonglong2 v = reinterpret_cast<const ulonglong2*>(base)[r]; lo[u] = v.x; w1 = v.y; hi[u] = 0ull; }
-        mn[u] = (uint32_t)w1; sk[u] = (uint32_t)(w1 >> 32); rank[u] = 0;
-        k_lo[r] = lo[u]; k_mn[r] = mn[u];
-        if (HAS_HI) k_hi[r] = hi[u];
-        hs[u] = (uint32_t)(((key_hash(lo[u], mn[u], hi[u], HAS_HI) & 0xffffffffull) * kPartSlots) >> 32);
-    }
-    __syncthreads();
-#pragma unroll
-    for (uint32_t u = 0; u < R; ++u) {
-        const uint32_t r = u * kGroupThreads + t;
-        if (r >= n) continue;
-        uint32_t h = hs[u];
-        for (;;) {                                        // ends: the table has about twice as many slots as a part has records
-            uint32_t cur = slot[h];
-            if (cur == 0) cur = atomicCAS(&slot[h], 0u, r + 1);
-            if (cur == 0) break;                          // claimed
-            const uint32_t c = (cur & 0x1fffu) - 1;
-            if (k_lo[c] == lo[u] && k_mn[c] == mn[u] && (!HAS_HI || k_hi[c] == hi[u])) break;
-            h = h + 1 == (uint32_t)kPartSlots ? 0u : h + 1;
-        }
-        hs[u] = h;
-        rank[u] = atomicAdd(&slot[h], 1u << 13) >> 13;
-    }
-    __syncthreads();
-    uint32_t cnt[R];
-    bool claimer[R];
-#pragma unroll
-    for (uint32_t u = 0; u < R; ++u) {
-        const uint32_t r = u * kGroupThreads + t;
-        const uint32_t w = r < n ? slot[hs[u]] : 0u;
-        cnt[u] = w >> 13;
-        claimer[u] = r < n && (w & 0x1fffu) == r + 1;
-    }
-    __syncthreads();                                      // every thread has read its slot words: they are rewritten now, and the keys are dead
-    const uint32_t ids_base = p * (4u * kPartCap);
-#pragma unroll
-    for (uint32_t u = 0; u < R; ++u) {
-        if (!claimer[u] || cnt[u] < 2) continue;          // one thread per key held by >= 2 sketches
-        const uint32_t hoff = atomicAdd(&cursor[0], cnt[u]);                       // sum of cnt <= n <= kPartCap
-        uint32_t goff = 0;
-        if (cnt[u] > kInlineMax + 1) {                    // some holder has more than kInlineMax above it: the full list too
-            goff = atomicAdd(&cursor[1], list_u16(cnt[u]));                        // (cnt + 8 per key of >= 9 records: < 2 x kPartCap u16)
-            ids[ids_base + goff] = (uint16_t)cnt[u];
-        }
-        slot[hs[u]] = hoff | ((goff >> 3) << 13);
-    }
-    __syncthreads();
-#pragma unroll
-    for (uint32_t u = 0; u < R; ++u) {
-        const uint32_t r = u * kGroupThreads + t;
-        if (r >= n || cnt[u] < 2) continue;
-        const uint32_t w = slot[hs[u]];
-        hl[(w & 0x1fffu) + rank[u]] = (uint16_t)sk[u];
-        if (cnt[u] > kInlineMax + 1) ids[ids_base + ((w >> 13) << 3) + 1 + rank[u]] = (uint16_t)sk[u];
-    }
-    __syncthreads();
-#pragma unroll
-    for (uint32_t u = 0; u < R; ++u) {
-        const uint32_t r = u * kGroupThreads + t;
-        if (r >= n) continue;
-        uint64_t a = 0, b = 0;                            // the slot: half-word 0 of `a` = count, then the ids
-        if (cnt[u] >= 2) {
-            const uint32_t w = slot[hs[u]], hoff = w & 0x1fffu;
-            uint32_t na = kInlineMax + 1;
-            if (cnt[u] <= kInlineScan) {
-                na = 0;
-                for (uint32_t j = 0; j < cnt[u]; ++j) {
-                    const uint32_t o = hl[hoff + j];
-                    if (o <= sk[u]) continue;             // (a sketch holds a key at most once: the scatter checked the order)
-                    ++na;
-                    if (na < 4) a |= (uint64_t)o << (16 * na);
-                    else if (na <= kInlineMax) b |= (uint64_t)o << (16 * (na - 4));
-                }
-            }
-            if (na <= kInlineMax) a |= na;
-            else { a = kInlineList | ((uint64_t)list_ref(ids_base + ((w >> 13) << 3), cnt[u]) << 32); b = 0; }
-        }
-        inl[(size_t)p * kPartCap + r] = make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
-    }
-}
-
 // Small problems (at most kSmallN sketches, k <= 32, every row owned): grouping AND counting in one kernel.  Parts of
 // half the size (2048 records: 40 KiB of keys and slots), the holders of every key are listed in LDS, every record adds
 // 1 to the cell (its sketch, other holder) for the holders above it -- an N x N matrix of 16-bit counters in LDS,
@@ -952,7 +813,6 @@ struct ComparePlan {
     uint32_t* d_inter;
     const uint32_t* list_ref = nullptr;  // list reference per entry -- or per record slot, with `where` = slot of every entry
     const uint32_t* where = nullptr;
-    const uint4* inl = nullptr;          // partition form with inline lists: 16-byte slot per record (k_parts_group_inline)
 };
 struct CompareJob {
     ComparePlan P;
@@ -1007,14 +867,13 @@ static int launch_accumulate_sparse(spsp_ctx* ctx, const ComparePlan& P, uint32_
     while (copies_log2 < 4 && ((size_t)cols << (copies_log2 + 1)) * 4 <= (size_t)kSparseCols * 4) ++copies_log2;
     hipLaunchKernelGGL(k_accumulate_sparse, dim3((P.n + cols - 1) / cols, P.n_own, split), dim3(kSparseThreads),
                        ((size_t)cols << copies_log2) * 4, ctx->stream,
-                       P.list_ref ? P.list_ref : ctx->c_row.as<uint32_t>(), P.where, P.inl, ctx->c_matrix.as<uint16_t>(), P.sk_begin, P.sk_end,
+                       P.list_ref ? P.list_ref : ctx->c_row.as<uint32_t>(), P.where, ctx->c_matrix.as<uint16_t>(), P.sk_begin, P.sk_end,
                        P.n, P.row_first, P.row_stride, P.row_limit, cols, copies_log2, split, P.d_inter, flags,
                        reinterpret_cast<uint32_t*>(ctx->h_scalar + 8));
     SPSP_HIP(hipGetLastError());
     return SPSP_OK;
 }
 static int job_queue_flags(spsp_ctx* ctx);
-static bool parts_inline();
 // partition form: prepare -> scatter -> group -> row sums, queued in one go (small problems: prepare -> scatter -> group + count)
 static int job_parts(spsp_ctx* ctx, CompareJob& J) {
     uint32_t* flags = ctx->c_flags.as<uint32_t>();
@@ -1040,7 +899,6 @@ static int job_parts(spsp_ctx* ctx, CompareJob& J) {
     if ((rc = ctx->ev_begin(kEvAccumulate))) return rc;
     ComparePlan PP = J.P;
     PP.list_ref = ctx->c_lref.as<uint32_t>(); PP.where = ctx->c_where.as<uint32_t>();
-    if (parts_inline()) PP.inl = ctx->c_lref.as<uint4>();
     if (!(skip & 4) && (rc = launch_accumulate_sparse(ctx, PP, flags))) return rc;
     if ((rc = ctx->ev_end(kEvAccumulate))) return rc;
     return job_mark_done(ctx);
@@ -1200,9 +1058,6 @@ static uint32_t parts_for(uint64_t entries, uint32_t attempt) {
     const uint64_t mean = dbg_mean ? (uint64_t)std::max(1, atoi(dbg_mean)) : (attempt == 0 ? 2900 : 1400);
     return (uint32_t)std::max<uint64_t>(1, (entries + mean - 1) / mean);
 }
-
-// SPSP_DEBUG_INLINE=0: list references per record and shared lists (the round-2 form) instead of inline lists -- A/B and tests
-static bool parts_inline() { static const bool v = !(getenv("SPSP_DEBUG_INLINE") && atoi(getenv("SPSP_DEBUG_INLINE")) == 0); return v; }
 
 // takes ownership of `job`; on success it is pending on the context until compare_job_end
 static int compare_job_begin(spsp_ctx* ctx, CompareJob* job) {
@@ -1395,7 +1250,7 @@ static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t*
         int r2 = ctx->c_recs.reserve((size_t)n_parts * cap * (has_hi ? 24 : 16));
         if (r2) return r2;
         if (!small && (r2 = ctx->c_where.reserve((size_t)S * 4 + 16))) return r2;
-        if (!small && (r2 = ctx->c_lref.reserve((size_t)n_parts * kPartCap * (parts_inline() ? 16 : 4)))) return r2;
+        if (!small && (r2 = ctx->c_lref.reserve((size_t)n_parts * kPartCap * 4))) return r2;
         uint32_t* where = small ? nullptr : ctx->c_where.as<uint32_t>();
         static_assert(kMaxKeyParts < (1 << 15), "k_parts_scatter keeps the part in 15 bits of its (part, rank) word");
         if (n_parts > (uint32_t)kMaxKeyParts) { set_error("internal: %u key parts exceed the scatter's limit of %d", n_parts, kMaxKeyParts); return SPSP_ERR_ARG; }
@@ -1417,19 +1272,6 @@ static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t*
     };
     J->group_parts = [=](uint32_t n_parts) -> int {
         const size_t lds = (size_t)kPartCap * (8 + (has_hi ? 8 : 0) + 4) + (size_t)kPartSlots * 4 + 16;
-        if (parts_inline()) {
-            if (!ctx->attr_group_inl_set) {
-                SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_parts_group_inline<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kPartCap * 20 + (size_t)kPartSlots * 4 + 16)));
-                SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_parts_group_inline<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kPartCap * 12 + (size_t)kPartSlots * 4 + 16)));
-                ctx->attr_group_inl_set = true;
-            }
-            if (has_hi) hipLaunchKernelGGL(k_parts_group_inline<true>, dim3(n_parts), dim3(kGroupThreads), lds, ctx->stream, ctx->c_recs.as<uint64_t>(),
-                                           ctx->c_part_cnt.as<uint32_t>(), ctx->c_matrix.as<uint16_t>(), ctx->c_lref.as<uint4>(), flags);
-            else hipLaunchKernelGGL(k_parts_group_inline<false>, dim3(n_parts), dim3(kGroupThreads), lds, ctx->stream, ctx->c_recs.as<uint64_t>(),
-                                    ctx->c_part_cnt.as<uint32_t>(), ctx->c_matrix.as<uint16_t>(), ctx->c_lref.as<uint4>(), flags);
-            SPSP_HIP(hipGetLastError());
-            return SPSP_OK;
-        }
         if (has_hi) {
             if (!ctx->attr_group_hi_set) {
                 SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_parts_group<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

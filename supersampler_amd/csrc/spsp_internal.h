@@ -98,7 +98,7 @@ struct spsp_ctx {
     hipEvent_t tail_event = nullptr;   // spsp_wait_stream: marks the current end of this context's stream
     hipEvent_t scan_done = nullptr;    // behind the last kernel of the queued scan: what spsp_scan_device_end waits on
     hipEvent_t compare_done = nullptr; // likewise for the queued comparison
-    bool attr_pair_set = false, attr_single_set = false, attr_bloom_set = false, attr_small_set = false, attr_group_set = false, attr_group_hi_set = false, attr_group_inl_set = false, attr_scatter_set = false, attr_sort_set = false;   // dynamic-LDS attributes set on this context's device
+    bool attr_pair_set = false, attr_single_set = false, attr_bloom_set = false, attr_small_set = false, attr_group_set = false, attr_group_hi_set = false, attr_scatter_set = false, attr_sort_set = false;   // dynamic-LDS attributes set on this context's device
     spsp::ScanJob scan_job;
     spsp::CompareJob* compare_job = nullptr;
     uint8_t* h_text = nullptr;         // pinned staging for a whole FASTA file (spsp_sketch_file reads plain files straight into it)

@@ -431,10 +431,9 @@ def test_comparison_forms_agree_on_random_inputs():
         "print('digest', digest.hexdigest())\n") % (ROOT, os.path.join(ROOT, "tests"))
     digests = []
     # {} = the partition form (LDS dictionary per key class), the others force the global-dictionary forms
-    # SPSP_DEBUG_SMALL=0: the general partition form (inline lists) also for <= 128 sketches; SPSP_DEBUG_INLINE=0: with list
-    # references and shared lists instead of inline lists
+    # SPSP_DEBUG_SMALL=0: the general partition form also for <= 128 sketches
     for env in ({}, {"SPSP_DEBUG_SPARSE": "1"}, {"SPSP_DEBUG_MATRIX_BUDGET": "9000"}, {"SPSP_DEBUG_SPARSE": "0"}, {"SPSP_DEBUG_PARTS": "0"},
-                {"SPSP_DEBUG_SMALL": "0"}, {"SPSP_DEBUG_SMALL": "0", "SPSP_DEBUG_INLINE": "0"}):
+                {"SPSP_DEBUG_SMALL": "0"}):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0 and "digest" in r.stdout, (env, r.stdout[-2000:], r.stderr[-3000:])
         digests.append(r.stdout.strip().split()[-1])

@@ -53,6 +53,22 @@ int main(int argc, char** argv) {
            (unsigned long long)n_access, (unsigned long long)(n_access * 4), (unsigned long long)(n_access * 8), (unsigned long long)(n_access * 16),
            (unsigned long long)(n_access * 4), (unsigned long long)(n_access * 8), (unsigned long long)(n_access * 16), (unsigned long long)(n_access * 16),
            (unsigned long long)(n_access * 16));
+    // wall time per kernel (HIP events): a gather cannot have moved more bytes than its time allows at the measured
+    // ~6.5 TB/s read rate -- which settles whether a random access costs a 64-byte sector or a 128-byte line
+    {
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        auto timed = [&](const char* name, auto launch, double bytes_useful) {
+            launch(); CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0, 0)); launch(); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+            float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("time %-12s %8.3f ms  useful %7.1f GB/s  if 64 B/access %7.1f GB/s  if 128 B/access %7.1f GB/s\n", name, ms, bytes_useful / ms / 1e6,
+                   64.0 * n_access / ms / 1e6, 128.0 * n_access / ms / 1e6);
+        };
+        timed("stream16", [&] { hipLaunchKernelGGL(k_stream<uint4>, grid, block, 0, 0, (const uint4*)buf, n_access, out); }, 16.0 * n_access);
+        timed("gather4", [&] { hipLaunchKernelGGL(k_gather<uint32_t>, grid, block, 0, 0, (const uint32_t*)buf, bytes / 4, n_access, out); }, 4.0 * n_access);
+        timed("gather16", [&] { hipLaunchKernelGGL(k_gather<uint4>, grid, block, 0, 0, (const uint4*)buf, bytes / 16, n_access, out); }, 16.0 * n_access);
+        timed("scatter16", [&] { hipLaunchKernelGGL(k_scatter16, grid, block, 0, 0, (uint4*)buf, bytes / 16, n_access); }, 16.0 * n_access);
+    }
     for (int rep = 0; rep < 3; ++rep) {
         hipLaunchKernelGGL(k_stream<uint32_t>, grid, block, 0, 0, (const uint32_t*)buf, n_access, out);
         hipLaunchKernelGGL(k_stream<uint64_t>, grid, block, 0, 0, (const uint64_t*)buf, n_access, out);
