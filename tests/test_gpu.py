@@ -935,22 +935,34 @@ def test_scan_packed_input_equals_oracle(ctx, k, m, s, mode):
         ctx.scan(sp.make_params(k, m, s, flags=sp.SPSP_SCAN_PACKED_INPUT), bases, offs)
 
 
-def test_sketch_files_worker_pool_equals_oracle(tmp_path):
-    """spsp_sketch_files (the library's form of the reference's OpenMP loop over the file of files, SubSampler.cpp:771-793):
-    nine FASTA files -- plain, gzip, multi-record, one with Ns and lower case, one empty of k-mers -- on 1, 3 and 16 workers;
-    every output gunzips to the oracle's payload, statistics equal the oracle's, the "started" callbacks come in list order,
-    and a file that does not exist fails alone."""
+def test_sketch_files_pipeline_equals_oracle(tmp_path):
+    """spsp_sketch_files (the library's form of the reference's OpenMP loop over the file of files, SubSampler.cpp:771-793;
+    several files share one GPU job): thirteen FASTA files -- plain, gzip, multi-record, Ns and lower case, no k-mers, EMPTY,
+    first line not a header (the reference drops it all the same), no newline at the end, CRLF, exactly one ingest tile long --
+    on 1, 3 and 16 workers; every output gunzips to the oracle's payload, the statistics (with the count of ALL
+    super-k-mers, -v 1) equal the oracle's, the "started" reports come in list order, a file that does not exist fails
+    alone; -a 2 takes the one-job-per-file form."""
     import gzip
     k, m, s = 31, 11, 50.0
     rng = np.random.default_rng(77)
     texts = []
-    for i in range(9):
+    for i in range(13):
         g = synth.random_genome(rng, int(rng.integers(30_000, 400_000)))
         t = synth.to_fasta(g, "g%d" % i, n_records=1 + i % 3)
         if i == 4:
             t = t.replace(b"ACG", b"NnG", 50).replace(b"TT", b"tt", 500)
         if i == 7:
             t = b">tiny\nACGTACGT\n"
+        if i == 8:
+            t = b""
+        if i == 9:
+            t = t[1:]                                     # no '>' in front: line 0 is dropped anyway (getLineFasta)
+        if i == 10:
+            t = t.rstrip(b"\n")
+        if i == 11:
+            t = t.replace(b"\n", b"\r\n")
+        if i == 12:
+            t = t[:4095] + b"\n"                          # file + its newline fill one 4 KiB tile exactly
         texts.append(t)
     ins = []
     for i, t in enumerate(texts):
@@ -958,18 +970,27 @@ def test_sketch_files_worker_pool_equals_oracle(tmp_path):
         open(pth, "wb").write(gzip.compress(t, 1) if i % 2 else t)
         ins.append(pth)
     want = [orc.sketch_fasta(t, k, m, s) for t in texts]
+    fields = ("selected_kmer_number", "selected_superkmer_number", "seen_kmers_at_reconstruction", "actual_minimizer_number", "read_kmer",
+              "count_maximal_skmer", "nb_mmer_selected", "total_superkmer_number", "total_kmer_number")
     for threads in (1, 3, 16):
         outs = [str(tmp_path / ("out_t%d_%d.gz" % (threads, i))) for i in range(len(ins))]
-        res, times, started = sp.sketch_files(ins, outs, k, m, s, threads=threads)
+        res, times, started = sp.sketch_files(ins, outs, k, m, s, threads=threads, flags=sp.SPSP_SCAN_STATS)
         assert started == list(range(len(ins)))
         assert times["sketch_files"] == len(ins)
         for i, (rc, st, err) in enumerate(res):
             assert rc == 0 and err is None, (threads, i, rc, err)
             assert sp.read_file(outs[i]) == want[i][0], (threads, i)
-            for f in ("selected_kmer_number", "selected_superkmer_number", "seen_kmers_at_reconstruction", "actual_minimizer_number", "read_kmer"):
-                assert st[f] == want[i][1][f], (threads, i, f)
+            for f in fields:
+                assert st[f] == want[i][1][f], (threads, i, f, st[f], want[i][1][f])
     bad = ins[:2] + [str(tmp_path / "missing.fa")] + ins[2:4]
     outs = [str(tmp_path / ("out_bad_%d.gz" % i)) for i in range(len(bad))]
     res, _, started = sp.sketch_files(bad, outs, k, m, s, threads=2)
     assert [r[0] == 0 for r in res] == [True, True, False, True, True] and "missing.fa" in res[2][2]
     assert sp.read_file(outs[4]) == want[3][0]
+    # -a 2: k-mers are counted per file on the device -> one GPU job per file
+    dup = texts[0] + texts[0].replace(b">g0", b">again")
+    open(str(tmp_path / "dup.fa"), "wb").write(dup)
+    outs = [str(tmp_path / "dup.gz"), str(tmp_path / "single.gz")]
+    res, _, _ = sp.sketch_files([str(tmp_path / "dup.fa"), ins[0]], outs, k, m, s, abundance=2, threads=2)
+    assert all(r[0] == 0 for r in res)
+    assert sp.read_file(outs[0]) == orc.sketch_fasta(dup, k, m, s, 2)[0] and sp.read_file(outs[1]) == orc.sketch_fasta(texts[0], k, m, s, 2)[0]
