@@ -340,12 +340,16 @@ int spsp_write_gz_host(const char* path, const uint8_t* data, uint64_t len, int 
 int spsp_sketch_file(spsp_ctx* ctx, const spsp_params* p, double rate, const char* fasta_path,
                      const char* out_path, spsp_sketch_stats* stats);
 /* The file-of-files loop of the reference's main (`#pragma omp parallel num_threads(c)`, SubSampler.cpp:771-793) inside
- * the library: `threads` workers -- each with a context, i.e. a HIP stream, of its own on `device` -- take the n files
- * off one queue in list order and run spsp_sketch_file on them, so that reading / gunzipping one file, the PCIe copy of
- * another, the kernels of a third and the sketch builder / gzip of a fourth overlap inside ONE process.  `cb` (may be
+ * the library: the n files are taken in list order, a few at a time; `threads` workers read (and gunzip) a batch's files
+ * into one pinned buffer, the batch crosses PCIe in one copy and goes through ONE ingest, ONE scan and ONE gather on the
+ * GPU (a GPU job per file is a chain of launches and host waits that costs ~0.35 ms however small the file), and the
+ * workers then run the sketch builder, gzip and the write per file.  Up to three batches are in flight, each on a
+ * context (HIP stream) of its own, so reading, the GPU and the builders overlap inside ONE process.  With -a > 1 the
+ * k-mer counting pass is per file: one GPU job per file, one context per worker.  `cb` (may be
  * NULL) is called with phase 0 when file `index` is taken off the queue (inside the queue's lock: the calls come in
- * list order, like the reference's critical(fof) section that prints the name and appends to the output list) and with
- * phase 1 when it is done (rc, its statistics, the error text when rc != 0; one call at a time, like critical(cout)).
+ * list order, like the reference's critical(fof) section that prints the name and appends to the output list; with ONE
+ * worker right before the file's own phase-1 call, the way the reference's single thread alternates names and reports) and
+ * with phase 1 when it is done (rc, its statistics, the error text when rc != 0; one call at a time, like critical(cout)).
  * A file that fails does not stop the others; the call then returns SPSP_ERR_IO.  `times` (may be NULL) receives the
  * stage seconds summed over the workers. */
 typedef void (*spsp_file_callback)(void* user, uint32_t index, int phase, int rc, const spsp_sketch_stats* stats, const char* error);

@@ -1034,6 +1034,9 @@ public:
             total += sizes_[i];
         }
         budget_ = std::max<uint64_t>(8ull << 20, std::min<uint64_t>(64ull << 20, total / 6));
+        static const char* dbg_budget = getenv("SPSP_DEBUG_PIPE_BUDGET_MB");   // tuning knob
+        if (dbg_budget) budget_ = (uint64_t)std::max(1, atoi(dbg_budget)) << 20;
+        const double t_setup0 = now_s();
         const uint32_t n_slots = n_ > 1 ? 3 : 1;
         slots_.resize(n_slots);
         for (auto& s : slots_) s.reset(new PipeSlot());
@@ -1041,6 +1044,7 @@ public:
             const int rc = spsp_create(device_, nullptr, &s->ctx);
             if (rc) { fatal_rc_ = rc; fatal_err_ = spsp_last_error(); break; }
         }
+        setup_s_ += now_s() - t_setup0;
         if (!fatal_rc_) {
             {
                 std::lock_guard<std::mutex> g(m_);
@@ -1062,6 +1066,9 @@ public:
             spsp_destroy(s->ctx);
         }
         if (times) { times->read_s = read_s_; times->build_s = build_s_; times->gzip_s = gzip_s_; times->sketch_files = done_files_; }
+        if (getenv("SPSP_DEBUG_PIPE_TIMES"))
+            fprintf(stderr, "[spsp pipeline] contexts %.1f ms, pinned slabs %.1f ms, teardown follows; budget %llu MB, %u slots\n", setup_s_ * 1e3, slab_s_ * 1e3,
+                    (unsigned long long)(budget_ >> 20), (unsigned)slots_.size());
         if (fatal_rc_) { set_error("%s", fatal_err_.c_str()); return fatal_rc_; }
         if (failed_) { set_error("%u of %u files could not be sketched (see the callback's reports)", failed_, n_); return SPSP_ERR_IO; }
         return SPSP_OK;
@@ -1104,7 +1111,7 @@ private:
             f.index = next_;
             s.files.push_back(std::move(f));
             bytes += sz;
-            if (cb_) cb_(user_, next_, 0, SPSP_OK, nullptr, nullptr);
+            if (cb_ && threads_ > 1) cb_(user_, next_, 0, SPSP_OK, nullptr, nullptr);
             ++next_;
         }
         s.busy = true;
@@ -1160,7 +1167,10 @@ private:
             (void)hipSetDevice(device_);
             if (s.slab) { (void)hipStreamSynchronize(s.ctx->stream); (void)hipHostFree(s.slab); s.slab = nullptr; s.slab_cap = 0; }
             const size_t cap = (size_t)std::max<uint64_t>(at + at / 8 + 64, budget_ + budget_ / 4);
-            if (hipHostMalloc((void**)&s.slab, cap, hipHostMallocDefault) != hipSuccess) {
+            const double t_slab = now_s();
+            const hipError_t he = hipHostMalloc((void**)&s.slab, cap, hipHostMallocDefault);
+            add_time(slab_s_, now_s() - t_slab);
+            if (he != hipSuccess) {
                 for (auto& f : s.files) if (!f.rc) { f.rc = SPSP_ERR_NOMEM; f.err = "out of pinned host memory"; }
                 s.total = 0;
             } else s.slab_cap = cap;
@@ -1292,6 +1302,9 @@ private:
             std::lock_guard<std::mutex> g(report_m_);
             if (f.rc) ++failed_;
             ++done_files_;
+            // one worker: the reference's single thread prints a file's name, sketches it, prints its statistics, then takes
+            // the next file -- name and report alternate, in list order (this worker runs the batch's files in that order)
+            if (cb_ && threads_ == 1) cb_(user_, f.index, 0, SPSP_OK, nullptr, nullptr);
             if (cb_) cb_(user_, f.index, 1, f.rc, &f.st, f.rc ? f.err.c_str() : nullptr);
         }
         if (s.left.fetch_sub(1) == 1) {
@@ -1321,7 +1334,7 @@ private:
     int running_ = 0, batches_in_flight_ = 0;
     uint32_t next_ = 0, failed_ = 0;
     uint64_t done_files_ = 0;
-    double read_s_ = 0, build_s_ = 0, gzip_s_ = 0;
+    double read_s_ = 0, build_s_ = 0, gzip_s_ = 0, setup_s_ = 0, slab_s_ = 0;
     int fatal_rc_ = 0;
     std::string fatal_err_;
 };
