@@ -1097,6 +1097,7 @@ def end_to_end(ctx, skip_oracle, genomes=None):
             out["cpu_baseline"]["compare_pairs_per_s"] = k_files * (k_files - 1) / 2 / csec if csec > 0 else None
         return out
     finally:
+        sp.sketch_files_release()
         shutil.rmtree(tmp, ignore_errors=True)
 
 

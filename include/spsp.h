@@ -355,6 +355,10 @@ int spsp_sketch_file(spsp_ctx* ctx, const spsp_params* p, double rate, const cha
 typedef void (*spsp_file_callback)(void* user, uint32_t index, int phase, int rc, const spsp_sketch_stats* stats, const char* error);
 int spsp_sketch_files(int device, const spsp_params* p, double rate, const char* const* fasta_paths, const char* const* out_paths,
                       uint32_t n, uint32_t threads, spsp_file_callback cb, void* user, struct spsp_stage_times* times);
+/* spsp_sketch_files keeps its contexts, device buffers and pinned staging buffers for the next call on the same device
+ * (setting them up costs more than sketching a hundred genomes).  This releases the idle ones (device < 0: of every
+ * device); optional -- a process that simply exits never needs it. */
+void spsp_sketch_files_release(int device);
 /* Wall-clock seconds the two whole-file drivers have spent per stage on this context (end-to-end measurement:
  * bench.py's `end_to_end` object).  GPU stages include the host synchronisation that ends them. */
 typedef struct spsp_stage_times {

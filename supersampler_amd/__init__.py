@@ -82,7 +82,7 @@ ABI_SYMBOLS = [
     "spsp_stream_create_cus", "spsp_stream_destroy", "spsp_set_cu_count", "spsp_pack_bases_device",
     "spsp_timing_enable", "spsp_timing_sample", "spsp_timing_read", "spsp_threshold_host", "spsp_scan", "spsp_scan_device", "spsp_scan_device_begin", "spsp_scan_device_end", "spsp_scan_tail_stream", "spsp_wait_dense", "spsp_wait_stream", "spsp_scan_hits_device", "spsp_count_superkmers_device", "spsp_compare",
     "spsp_compare_device", "spsp_slot_bytes", "spsp_partition_keys_device", "spsp_compare_slots_device", "spsp_compare_device_begin", "spsp_compare_slots_device_begin", "spsp_compare_end", "spsp_fasta_clean_host", "spsp_fasta_clean_device", "spsp_sketch_text", "spsp_sketch_build_host", "spsp_sketch_parse_host", "spsp_sketch_decode_device", "spsp_sketch_chain_host",
-    "spsp_csv_host", "spsp_sort_csv_host", "spsp_read_file_host", "spsp_write_gz_host", "spsp_sketch_file", "spsp_compare_files", "spsp_compare_files_chatty", "spsp_stage_times_read", "spsp_measure_hbm_device", "spsp_sketch_files",
+    "spsp_csv_host", "spsp_sort_csv_host", "spsp_read_file_host", "spsp_write_gz_host", "spsp_sketch_file", "spsp_compare_files", "spsp_compare_files_chatty", "spsp_stage_times_read", "spsp_measure_hbm_device", "spsp_sketch_files", "spsp_sketch_files_release",
 ]
 
 _lib = None
@@ -168,6 +168,7 @@ def lib():
     L.spsp_stage_times_read.restype = i32; L.spsp_stage_times_read.argtypes = [vp, P(StageTimes), i32]
     L.spsp_sketch_files.restype = i32
     L.spsp_sketch_files.argtypes = [i32, P(Params), dbl, P(cp), P(cp), u32, u32, FILE_CALLBACK, vp, P(StageTimes)]
+    L.spsp_sketch_files_release.restype = None; L.spsp_sketch_files_release.argtypes = [i32]
     L.spsp_measure_hbm_device.restype = i32; L.spsp_measure_hbm_device.argtypes = [vp, u64, u32, P(HbmRates)]
     _lib = L
     return L
@@ -324,6 +325,11 @@ def sketch_files(fasta_paths, out_paths, k=31, m=11, s=1000.0, abundance=1, thre
     if rc != 0 and not any(r is not None and r[0] != 0 for r in res):
         _check(rc)
     return res, {f: getattr(times, f) for f, _ in StageTimes._fields_}, started
+
+
+def sketch_files_release(device=-1):
+    """release the contexts and pinned buffers spsp_sketch_files keeps between calls"""
+    lib().spsp_sketch_files_release(device)
 
 
 def stream_create_cus(device, first_cu, n_cu):

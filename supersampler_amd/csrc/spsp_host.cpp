@@ -1025,7 +1025,8 @@ public:
         : device_(device), p_(*p), rate_(rate), in_(in), out_(out), n_(n), threads_(threads), cb_(cb), user_(user) {}
 
     int run(spsp_stage_times* times) {
-        // sizes decide how many files travel together: batches of ~1/6 of the job, between 8 and 64 MB of text
+        // sizes decide how many files travel together: batches of ~1/12 of the job, between 8 and 32 MB of text (pinning
+        // the slabs costs ~0.2 ms per MB, once per process: the slots are kept for the next call)
         sizes_.assign(n_, 0);
         uint64_t total = 0;
         for (uint32_t i = 0; i < n_; ++i) {
@@ -1033,16 +1034,19 @@ public:
             if (stat(in_[i], &st) == 0 && st.st_size > 0) sizes_[i] = (uint64_t)st.st_size;
             total += sizes_[i];
         }
-        budget_ = std::max<uint64_t>(8ull << 20, std::min<uint64_t>(64ull << 20, total / 6));
+        budget_ = std::max<uint64_t>(8ull << 20, std::min<uint64_t>(32ull << 20, total / 12));
         static const char* dbg_budget = getenv("SPSP_DEBUG_PIPE_BUDGET_MB");   // tuning knob
         if (dbg_budget) budget_ = (uint64_t)std::max(1, atoi(dbg_budget)) << 20;
         const double t_setup0 = now_s();
-        const uint32_t n_slots = n_ > 1 ? 3 : 1;
+        const uint32_t n_slots = n_ > 1 ? 4 : 1;
         slots_.resize(n_slots);
-        for (auto& s : slots_) s.reset(new PipeSlot());
         for (auto& s : slots_) {
-            const int rc = spsp_create(device_, nullptr, &s->ctx);
-            if (rc) { fatal_rc_ = rc; fatal_err_ = spsp_last_error(); break; }
+            s = take_slot(device_);
+            if (!s->ctx) {
+                const int rc = spsp_create(device_, nullptr, &s->ctx);
+                if (rc) { fatal_rc_ = rc; fatal_err_ = spsp_last_error(); break; }
+            }
+            s->ctx->stages = spsp_stage_times{};
         }
         setup_s_ += now_s() - t_setup0;
         if (!fatal_rc_) {
@@ -1057,13 +1061,13 @@ public:
         }
         if (times) memset(times, 0, sizeof *times);
         for (auto& s : slots_) {
-            if (!s->ctx) continue;
-            if (times) {
+            if (s->ctx && times) {
                 const spsp_stage_times& t = s->ctx->stages;
                 times->ingest_s += t.ingest_s; times->scan_s += t.scan_s; times->gather_s += t.gather_s;
             }
-            if (s->slab) { (void)hipSetDevice(device_); (void)hipStreamSynchronize(s->ctx->stream); (void)hipHostFree(s->slab); }
-            spsp_destroy(s->ctx);
+            free(s->compact); free(s->coff); s->compact = nullptr; s->coff = nullptr;
+            std::vector<PipeFile>().swap(s->files);
+            give_slot(device_, std::move(s));
         }
         if (times) { times->read_s = read_s_; times->build_s = build_s_; times->gzip_s = gzip_s_; times->sketch_files = done_files_; }
         if (getenv("SPSP_DEBUG_PIPE_TIMES"))
@@ -1072,6 +1076,41 @@ public:
         if (fatal_rc_) { set_error("%s", fatal_err_.c_str()); return fatal_rc_; }
         if (failed_) { set_error("%u of %u files could not be sketched (see the callback's reports)", failed_, n_); return SPSP_ERR_IO; }
         return SPSP_OK;
+    }
+
+private:
+    // Slots (a context, its device buffers and tables, a pinned slab) outlive the call: the next call on this device takes
+    // them over instead of paying for contexts, device allocations and ~0.2 ms per MB of page pinning again.  They are
+    // never destroyed (no HIP call may run from a static destructor after the runtime has shut down); the process's end
+    // releases them.
+    struct SlotPool { std::mutex m; std::vector<std::pair<int, std::unique_ptr<PipeSlot>>> idle; };
+    static SlotPool& pool() { static SlotPool* p = new SlotPool(); return *p; }
+    static std::unique_ptr<PipeSlot> take_slot(int device) {
+        SlotPool& P = pool();
+        std::lock_guard<std::mutex> g(P.m);
+        for (size_t i = 0; i < P.idle.size(); ++i)
+            if (P.idle[i].first == device) { std::unique_ptr<PipeSlot> s = std::move(P.idle[i].second); P.idle.erase(P.idle.begin() + (ptrdiff_t)i); return s; }
+        return std::unique_ptr<PipeSlot>(new PipeSlot());
+    }
+    static void give_slot(int device, std::unique_ptr<PipeSlot> s) {
+        if (!s || !s->ctx) return;                           // (a slot whose context could not be created holds nothing)
+        SlotPool& P = pool();
+        std::lock_guard<std::mutex> g(P.m);
+        P.idle.emplace_back(device, std::move(s));
+    }
+
+public:
+    static void release_idle(int device) {
+        SlotPool& P = pool();
+        std::lock_guard<std::mutex> g(P.m);
+        for (size_t i = 0; i < P.idle.size();) {
+            if (device >= 0 && P.idle[i].first != device) { ++i; continue; }
+            PipeSlot& s = *P.idle[i].second;
+            (void)hipSetDevice(P.idle[i].first);
+            if (s.slab) { (void)hipStreamSynchronize(s.ctx->stream); (void)hipHostFree(s.slab); }
+            spsp_destroy(s.ctx);
+            P.idle.erase(P.idle.begin() + (ptrdiff_t)i);
+        }
     }
 
 private:
@@ -1340,6 +1379,8 @@ private:
 };
 
 }  // namespace
+
+void spsp_sketch_files_release(int device) { FilePipeline::release_idle(device); }
 
 int spsp_sketch_files(int device, const spsp_params* p, double rate, const char* const* fasta_paths, const char* const* out_paths,
                       uint32_t n, uint32_t threads, spsp_file_callback cb, void* user, spsp_stage_times* times) {

@@ -52,4 +52,5 @@ try:
     doc["parity_first_4"] = all(sp.read_file(outs[i]) == orc.sketch_fasta(texts[i], K, M, S)[0] for i in range(min(4, n)))
     print(json.dumps(doc))
 finally:
+    sp.sketch_files_release()
     shutil.rmtree(tmp, ignore_errors=True)
