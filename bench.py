@@ -1059,6 +1059,21 @@ def end_to_end(ctx, skip_oracle, genomes=None):
                 r = subprocess.run([cli, "-f", "fof.txt", "-t", str(T), "-v", "0", "-p", "cli%d_" % T], cwd=tmp, capture_output=True, text=True)
                 wall = time.perf_counter() - t0
                 out["cli"]["sub_sampler_-t%d" % T] = {"wall_s": wall, "kmers_per_s": kmers / wall, "rc": r.returncode}
+            # a job ten times the size (the same files under ten names each): process start and HIP initialisation amortised
+            big = os.path.join(tmp, "big")
+            os.mkdir(big)
+            links = []
+            for rep in range(10):
+                for i, pth in enumerate(plain):
+                    ln = os.path.join(big, "r%d_genome%03d.fa" % (rep, i))
+                    os.symlink(pth, ln)
+                    links.append(ln)
+            open(os.path.join(big, "fof.txt"), "w").write("\n".join(links) + "\n")
+            t0 = time.perf_counter()
+            r = subprocess.run([cli, "-f", "fof.txt", "-t", str(cores), "-v", "0", "-p", "big_"], cwd=big, capture_output=True, text=True)
+            wall = time.perf_counter() - t0
+            out["cli"]["sub_sampler_-t%d_1000_files" % cores] = {"files": len(links), "wall_s": wall, "kmers_per_s": 10 * kmers / wall, "rc": r.returncode}
+            shutil.rmtree(big, ignore_errors=True)
             t0 = time.perf_counter()
             r2 = subprocess.run([os.path.join(ROOT, "bin", "comparator"), "-f", "cli%d_fof.txt" % thread_counts[-1], "-o", "cli_res"], cwd=tmp,
                                 capture_output=True, text=True)
@@ -1088,8 +1103,10 @@ def end_to_end(ctx, skip_oracle, genomes=None):
             out["speedup_at_equal_threads"] = {
                 "library_worker_pool": {("threads_%d" % T): out["sketch_files"]["threads_%d" % T]["kmers_per_s"] / out["cpu_baseline"]["threads_%d" % T]["kmers_per_s"]
                                         for T in thread_counts},
-                **({"cli_process": {("threads_%d" % T): out["cli"]["sub_sampler_-t%d" % T]["kmers_per_s"] / out["cpu_baseline"]["threads_%d" % T]["kmers_per_s"]
-                                    for T in thread_counts}} if "cli" in out else {})}
+                **({"cli_process": {**{("threads_%d" % T): out["cli"]["sub_sampler_-t%d" % T]["kmers_per_s"] / out["cpu_baseline"]["threads_%d" % T]["kmers_per_s"]
+                                       for T in thread_counts},
+                                    ("threads_%d_1000_files" % cores): out["cli"]["sub_sampler_-t%d_1000_files" % cores]["kmers_per_s"] /
+                                    out["cpu_baseline"]["threads_%d" % cores]["kmers_per_s"]}} if "cli" in out else {})}
             mine = {i: sp.read_file(sk_files[i]) for i in pls}
             out["parity_vs_oracle"] = {"files": len(pls), "payload_bytes_equal": bool(all(mine[i] == pls[i] for i in pls))}
             k_files = min(n, 24)

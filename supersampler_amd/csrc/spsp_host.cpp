@@ -1038,7 +1038,9 @@ public:
         static const char* dbg_budget = getenv("SPSP_DEBUG_PIPE_BUDGET_MB");   // tuning knob
         if (dbg_budget) budget_ = (uint64_t)std::max(1, atoi(dbg_budget)) << 20;
         const double t_setup0 = now_s();
-        const uint32_t n_slots = n_ > 1 ? 4 : 1;
+        // batches in flight: with one worker nothing overlaps the host's work anyway (and every slot costs a context, a
+        // pinned slab and device buffers, which a short-lived process pays for in full)
+        const uint32_t n_slots = std::min<uint32_t>(std::min<uint32_t>(4, threads_), n_);
         slots_.resize(n_slots);
         for (auto& s : slots_) {
             s = take_slot(device_);
