@@ -8,6 +8,8 @@ on known byte counts (profiles/r03_fetch_calibration.md); the factors below are 
 its dominant read shape:
   stream  -- coalesced streams (dense passes, pack, ingest, scatter's key reads): fetch bytes = FETCH_FACTOR_STREAM x FETCH_SIZE
   gather  -- scattered 4-16 byte reads (list references, lists, records by slot): fetch bytes = FETCH_FACTOR_GATHER x FETCH_SIZE
+             (the counter shows 64 B per random access; by their time -- 2^26 accesses in 1.31 ms = the 6.5 TB/s read ceiling at
+             128 B each -- every one moves a whole 128-byte line: the factor is 2 here as well)
 WRITE_SIZE is taken as reported (exact for 16 B-per-lane stores and per-dword atomics; scattered 16-byte stores are
 counted as the 32-byte sectors they touch -- that IS the traffic).
 usage: tools/pmc_traffic.py <pmc_FETCH_SIZE.csv> <pmc_WRITE_SIZE.csv> <out.json> [command text] [workload json]"""
@@ -19,7 +21,7 @@ import sys
 from collections import Counter, defaultdict
 
 FETCH_FACTOR_STREAM = 2.0
-FETCH_FACTOR_GATHER = float(os.environ.get("SPSP_FETCH_FACTOR_GATHER", "1.0"))   # see profiles/r03_fetch_calibration.md
+FETCH_FACTOR_GATHER = float(os.environ.get("SPSP_FETCH_FACTOR_GATHER", "2.0"))   # see profiles/r03_fetch_calibration.md: 64 B counted, 128 B moved (timing)
 GATHER_KERNELS = ("k_accumulate_sparse", "k_accumulate", "k_parts_group", "k_fill", "k_fill_sparse", "k_insert", "k_insert_sparse",
                   "k_resolve", "k_compact", "k_decode_emit", "k_abund")
 
