@@ -275,6 +275,14 @@ int spsp_fasta_clean_host(const char* text, uint64_t n, uint8_t** bases, uint64_
 int spsp_fasta_clean_device(spsp_ctx* ctx, const void* d_text, uint64_t n_text, void** d_bases, uint64_t* n_bases,
                             void** d_rec_off, uint32_t* n_rec);
 
+/* ... with the cleaned bases written as 2-bit words straight away (utils.cpp:675-718 compacted AND packed in one pass:
+ * N1 of SURVEY.md 8f): *d_packed is the layout spsp_pack_bases_device makes -- 16 bases per little-endian dword, first
+ * base in bits 31:30, zero tail, 256 readable bytes behind -- in a context-owned buffer, ready for a scan with
+ * SPSP_SCAN_PACKED_INPUT; n_bases and the record offsets count BASES as ever.  spsp_sketch_text / spsp_sketch_file(s) use
+ * it whenever the dense pass of their parameters reads packed input (the pair-table pass: the default configuration). */
+int spsp_fasta_clean_packed_device(spsp_ctx* ctx, const void* d_text, uint64_t n_text, void** d_packed, uint64_t* n_bases,
+                                   void** d_rec_off, uint32_t* n_rec);
+
 typedef struct spsp_sketch_stats {
     uint64_t read_kmer, selected_kmer_number, selected_superkmer_number, count_maximal_skmer;
     uint64_t seen_kmers_at_reconstruction, seen_superkmers_at_reconstruction;

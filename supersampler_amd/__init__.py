@@ -81,7 +81,7 @@ ABI_SYMBOLS = [
     "spsp_create", "spsp_destroy", "spsp_last_error", "spsp_version", "spsp_free", "spsp_copy_to_host",
     "spsp_stream_create_cus", "spsp_stream_destroy", "spsp_set_cu_count", "spsp_pack_bases_device",
     "spsp_timing_enable", "spsp_timing_sample", "spsp_timing_read", "spsp_threshold_host", "spsp_scan", "spsp_scan_device", "spsp_scan_device_begin", "spsp_scan_device_end", "spsp_scan_tail_stream", "spsp_wait_dense", "spsp_wait_stream", "spsp_scan_hits_device", "spsp_count_superkmers_device", "spsp_compare",
-    "spsp_compare_device", "spsp_slot_bytes", "spsp_partition_keys_device", "spsp_compare_slots_device", "spsp_compare_device_begin", "spsp_compare_slots_device_begin", "spsp_compare_end", "spsp_fasta_clean_host", "spsp_fasta_clean_device", "spsp_sketch_text", "spsp_sketch_build_host", "spsp_sketch_parse_host", "spsp_sketch_decode_device", "spsp_sketch_chain_host",
+    "spsp_compare_device", "spsp_slot_bytes", "spsp_partition_keys_device", "spsp_compare_slots_device", "spsp_compare_device_begin", "spsp_compare_slots_device_begin", "spsp_compare_end", "spsp_fasta_clean_host", "spsp_fasta_clean_device", "spsp_fasta_clean_packed_device", "spsp_sketch_text", "spsp_sketch_build_host", "spsp_sketch_parse_host", "spsp_sketch_decode_device", "spsp_sketch_chain_host",
     "spsp_csv_host", "spsp_sort_csv_host", "spsp_read_file_host", "spsp_write_gz_host", "spsp_sketch_file", "spsp_compare_files", "spsp_compare_files_chatty", "spsp_stage_times_read", "spsp_measure_hbm_device", "spsp_sketch_files", "spsp_sketch_files_release",
 ]
 
@@ -142,6 +142,8 @@ def lib():
     L.spsp_fasta_clean_host.argtypes = [cp, u64, P(vp), P(vp), P(u32)]
     L.spsp_fasta_clean_device.restype = i32
     L.spsp_fasta_clean_device.argtypes = [vp, vp, u64, P(vp), P(u64), P(vp), P(u32)]
+    L.spsp_fasta_clean_packed_device.restype = i32
+    L.spsp_fasta_clean_packed_device.argtypes = [vp, vp, u64, P(vp), P(u64), P(vp), P(u32)]
     L.spsp_sketch_text.restype = i32
     L.spsp_sketch_text.argtypes = [vp, P(Params), dbl, cp, u64, P(vp), P(u64), P(SketchStats)]
     L.spsp_sketch_build_host.restype = i32
@@ -461,6 +463,12 @@ class Context:
         """raw FASTA text in HBM -> (d_bases, n_bases, d_rec_off, n_rec), context-owned device buffers."""
         b, o, nb, nr = C.c_void_p(), C.c_void_p(), C.c_uint64(), C.c_uint32()
         _check(lib().spsp_fasta_clean_device(self._h, d_text, n_text, C.byref(b), C.byref(nb), C.byref(o), C.byref(nr)))
+        return b.value, nb.value, o.value, nr.value
+
+    def clean_fasta_packed_device(self, d_text, n_text):
+        """raw FASTA text in HBM -> (d_packed 2-bit words, n_bases, d_rec_off, n_rec), context-owned device buffers"""
+        b, o, nb, nr = C.c_void_p(), C.c_void_p(), C.c_uint64(), C.c_uint32()
+        _check(lib().spsp_fasta_clean_packed_device(self._h, d_text, n_text, C.byref(b), C.byref(nb), C.byref(o), C.byref(nr)))
         return b.value, nb.value, o.value, nr.value
 
     def sketch_text(self, text, k=31, m=11, s=1000.0, abundance=1, flags=SPSP_SCAN_DEFAULT):

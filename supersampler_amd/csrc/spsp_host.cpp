@@ -1261,7 +1261,8 @@ private:
             if ((r = ctx->i_text.reserve((size_t)s.total + 64))) return r;
             SPSP_HIP(hipMemcpyAsync(ctx->i_text.p, s.slab, (size_t)s.total, hipMemcpyHostToDevice, ctx->stream));
             uint8_t* d_bases = nullptr; uint64_t* d_off = nullptr; uint64_t n_bases = 0; uint32_t n_rec = 0;
-            if ((r = spsp::clean_device_impl(ctx, ctx->i_text.as<uint8_t>(), s.total, &d_bases, &n_bases, &d_off, &n_rec))) return r;
+            const bool packed = spsp::ingest_packs(&p_);           // the ingest writes the 2-bit words the dense pass reads
+            if ((r = spsp::clean_device_impl(ctx, ctx->i_text.as<uint8_t>(), s.total, &d_bases, &n_bases, &d_off, &n_rec, packed))) return r;
             // records in front of every file: the ingest's per-tile record base at the file's first tile, less the file's own
             // first record (counted with the newline in front of its header line, i.e. in the tile before)
             const uint64_t n_tiles = (s.total + kSlabAlign - 1) / kSlabAlign;
@@ -1271,7 +1272,9 @@ private:
             SPSP_HIP(hipMemcpyAsync(s.rec_off.data(), d_off, s.rec_off.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
             t1 = now_s(); ctx->stages.ingest_s += t1 - t0; t0 = t1;
             spsp_superkmer* d_sk = nullptr; uint64_t n_sk = 0;
-            if ((r = spsp::scan_device_impl(ctx, &p_, d_bases, n_bases, d_off, n_rec, &d_sk, &n_sk))) return r;   // (its host wait also completes the copies above)
+            spsp_params ps = p_;
+            if (packed) ps.flags |= SPSP_SCAN_PACKED_INPUT;
+            if ((r = spsp::scan_device_impl(ctx, &ps, d_bases, n_bases, d_off, n_rec, &d_sk, &n_sk))) return r;   // (its host wait also completes the copies above)
             t1 = now_s(); ctx->stages.scan_s += t1 - t0; t0 = t1;
             PipeFile* prev = nullptr;
             for (auto& f : s.files) {
@@ -1283,7 +1286,7 @@ private:
             if (prev) prev->n_rec = n_rec - prev->first_rec;
             s.sk.resize((size_t)n_sk);
             if (n_sk) SPSP_HIP(hipMemcpyAsync(s.sk.data(), d_sk, (size_t)n_sk * sizeof(spsp_superkmer), hipMemcpyDeviceToHost, ctx->stream));
-            if ((r = spsp::gather_superkmers_impl(ctx, d_bases, d_off, d_sk, n_sk, &s.compact, &s.coff))) return r;   // synchronises the stream
+            if ((r = spsp::gather_superkmers_impl(ctx, d_bases, d_off, d_sk, n_sk, &s.compact, &s.coff, packed))) return r;   // synchronises the stream
             // the stream is in genome order: a file's super-k-mers are those of its records
             size_t at = 0;
             for (auto& f : s.files) {
@@ -1305,7 +1308,7 @@ private:
                     for (uint32_t q = 0; q <= f.n_rec; ++q) rel[q] = s.rec_off[f.first_rec + q] - b0;
                     if ((r = ctx->seg_a.reserve(rel.size() * 8))) return r;
                     SPSP_HIP(hipMemcpyAsync(ctx->seg_a.p, rel.data(), rel.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-                    if ((r = spsp::count_superkmers_impl(ctx, &p_, d_bases + b0, rel[f.n_rec], ctx->seg_a.as<uint64_t>(), f.n_rec, &f.total_superkmers))) return r;
+                    if ((r = spsp::count_superkmers_impl(ctx, &p_, d_bases, rel[f.n_rec], ctx->seg_a.as<uint64_t>(), f.n_rec, &f.total_superkmers, packed, b0))) return r;
                 }
                 ctx->stages.scan_s += now_s() - t0;
             }

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "spsp_internal.h"
+#include "spsp_device.h"
 
 namespace spsp {
 
@@ -264,6 +265,12 @@ __global__ __launch_bounds__(1024) void k_clean_scan(const TileSummary* __restri
     if (t == 0) { totals[0] = c_k; totals[1] = c_h; }
 }
 
+// PACK: the survivors leave as 2-bit words -- 16 bases per dword, first base in bits 31:30, the layout the dense pass
+// reads with SPSP_SCAN_PACKED_INPUT (N1 of SURVEY.md 8f: "2-bit packing + non-ACGT compaction").  The tile's survivors
+// sit in LDS at the output's alignment modulo 16, so an aligned 16-byte group of the staging buffer IS one output word:
+// whole groups are packed and stored, the first and last group of a tile (shared with the neighbouring tiles) are ORed
+// into the zero-initialised buffer.
+template <bool PACK>
 __global__ __launch_bounds__(kCleanThreads) void k_clean_write(const uint8_t* __restrict__ text, uint64_t n,
                                                               const uint32_t* __restrict__ entry_drop,
                                                               const uint64_t* __restrict__ out_off,
@@ -321,6 +328,20 @@ __global__ __launch_bounds__(kCleanThreads) void k_clean_write(const uint8_t* __
     }
     __syncthreads();
     const uint32_t end = sh + tile_keep;                // LDS range [sh, end) holds this tile's output
+    if (PACK) {
+        uint32_t* words = reinterpret_cast<uint32_t*>(bases) + ((obase - sh) >> 4);
+        for (uint32_t g = threadIdx.x; g * 16 < end; g += kCleanThreads) {
+            const uint32_t lo = g * 16, hi = lo + 16;
+            if (lo >= sh && hi <= end) words[g] = pack16(*reinterpret_cast<const uint4*>(s_out + lo));
+            else {
+                uint32_t w = 0;
+                for (uint32_t x = lo < sh ? sh : lo; x < (hi < end ? hi : end); ++x) w |= (((uint32_t)s_out[x] >> 1) & 3u) << (30u - 2u * (x - lo));
+                if (w) atomicOr(&words[g], w);
+            }
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) rec_off[0] = 0;
+        return;
+    }
     uint8_t* gbase = bases + (obase - sh);              // 16-byte aligned
     for (uint32_t g = threadIdx.x; g * 16 < end; g += kCleanThreads) {
         const uint32_t lo = g * 16, hi = lo + 16;
@@ -344,13 +365,26 @@ __global__ void k_gather_superkmers(const uint8_t* __restrict__ bases, const uin
     uint8_t* dst = out + dst_off[i];
     for (uint32_t j = threadIdx.x & 63; j < e.len; j += 64) dst[j] = src[j];
 }
+__global__ void k_gather_superkmers_packed(const uint32_t* __restrict__ words, const uint64_t* __restrict__ rec_off,
+                                           const spsp_superkmer* __restrict__ sk, const uint32_t* __restrict__ dst_off,
+                                           uint32_t n_sk, uint8_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);   // one wave per super-k-mer
+    if (i >= n_sk) return;
+    const spsp_superkmer e = sk[i];
+    const uint64_t src = rec_off[e.rec] + e.start;
+    uint8_t* dst = out + dst_off[i];
+    for (uint32_t j = threadIdx.x & 63; j < e.len; j += 64) {
+        const uint64_t q = src + j;
+        dst[j] = "ACTG"[(words[q >> 4] >> (30u - 2u * (uint32_t)(q & 15u))) & 3u];      // int2nuc (utils.cpp:26-45)
+    }
+}
 __global__ void k_sk_lens(const spsp_superkmer* __restrict__ sk, uint32_t n_sk, uint32_t* __restrict__ lens) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_sk) lens[i] = sk[i].len;
 }
 
 int clean_device_impl(spsp_ctx* ctx, const uint8_t* d_text, uint64_t n_text, uint8_t** d_bases, uint64_t* n_bases,
-                      uint64_t** d_rec_off, uint32_t* n_rec) {
+                      uint64_t** d_rec_off, uint32_t* n_rec, bool pack) {
     if (((uintptr_t)d_text & 15u) != 0) { set_error("d_text must be 16-byte aligned"); return SPSP_ERR_ARG; }
     const uint64_t n_tiles = (n_text + kCleanTile - 1) / kCleanTile;
     if (n_tiles > 0x7fffffffull) { set_error("text too large for one call"); return SPSP_ERR_OVERFLOW; }
@@ -359,7 +393,11 @@ int clean_device_impl(spsp_ctx* ctx, const uint8_t* d_text, uint64_t n_text, uin
     if ((rc = ctx->i_entry.reserve((size_t)(n_tiles + 1) * 4))) return rc;
     if ((rc = ctx->i_outoff.reserve((size_t)(n_tiles + 1) * 8))) return rc;
     if ((rc = ctx->i_recbase.reserve((size_t)(n_tiles + 1) * 4))) return rc;
-    if ((rc = ctx->bases.reserve((size_t)n_text + 64))) return rc;     // survivors never outnumber the input
+    const size_t packed_bytes = (size_t)((n_text + 15) / 16 + 64) * 4; // words of the survivors (never more than the input) + zero halo
+    if (pack) {
+        if ((rc = ctx->packed.reserve(packed_bytes))) return rc;
+        SPSP_HIP(hipMemsetAsync(ctx->packed.p, 0, packed_bytes, ctx->stream));   // tile seams are ORed in; tail and halo stay zero
+    } else if ((rc = ctx->bases.reserve((size_t)n_text + 64))) return rc;  // survivors never outnumber the input
     if ((rc = ctx->d_scalar.reserve(64))) return rc;
     uint64_t* totals = ctx->h_scalar + 4;
     if (n_tiles) {
@@ -375,9 +413,12 @@ int clean_device_impl(spsp_ctx* ctx, const uint8_t* d_text, uint64_t n_text, uin
     if (recs > 0xfffffff0ull) { set_error("too many FASTA records for one call"); return SPSP_ERR_OVERFLOW; }
     if ((rc = ctx->rec_off.reserve((size_t)(recs + 1) * 8))) return rc;
     if (n_tiles) {
-        hipLaunchKernelGGL(k_clean_write, dim3((uint32_t)n_tiles), dim3(kCleanThreads), 0, ctx->stream, d_text, n_text,
-                           ctx->i_entry.as<uint32_t>(), ctx->i_outoff.as<uint64_t>(), ctx->i_recbase.as<uint32_t>(),
-                           ctx->bases.as<uint8_t>(), ctx->rec_off.as<uint64_t>());
+        if (pack) hipLaunchKernelGGL(k_clean_write<true>, dim3((uint32_t)n_tiles), dim3(kCleanThreads), 0, ctx->stream, d_text, n_text,
+                                     ctx->i_entry.as<uint32_t>(), ctx->i_outoff.as<uint64_t>(), ctx->i_recbase.as<uint32_t>(),
+                                     ctx->packed.as<uint8_t>(), ctx->rec_off.as<uint64_t>());
+        else hipLaunchKernelGGL(k_clean_write<false>, dim3((uint32_t)n_tiles), dim3(kCleanThreads), 0, ctx->stream, d_text, n_text,
+                                ctx->i_entry.as<uint32_t>(), ctx->i_outoff.as<uint64_t>(), ctx->i_recbase.as<uint32_t>(),
+                                ctx->bases.as<uint8_t>(), ctx->rec_off.as<uint64_t>());
         SPSP_HIP(hipGetLastError());
     }
     // rec_off[0] (also for an empty text) and the closing offset
@@ -385,14 +426,14 @@ int clean_device_impl(spsp_ctx* ctx, const uint8_t* d_text, uint64_t n_text, uin
     if (!n_tiles) { const uint64_t zero = 0; SPSP_HIP(hipMemcpyAsync(ctx->rec_off.p, &zero, 8, hipMemcpyHostToDevice, ctx->stream)); }
     SPSP_HIP(hipMemcpyAsync(ctx->rec_off.as<uint64_t>() + recs, ends, 8, hipMemcpyHostToDevice, ctx->stream));
     SPSP_HIP(hipStreamSynchronize(ctx->stream));
-    *d_bases = ctx->bases.as<uint8_t>(); *n_bases = kept;
+    *d_bases = pack ? ctx->packed.as<uint8_t>() : ctx->bases.as<uint8_t>(); *n_bases = kept;
     *d_rec_off = ctx->rec_off.as<uint64_t>(); *n_rec = (uint32_t)recs;
     return SPSP_OK;
 }
 
 // bases of the selected super-k-mers -> one compact HOST buffer + offsets (malloc'd; n_sk+1 offsets)
 int gather_superkmers_impl(spsp_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_rec_off, const spsp_superkmer* d_sk,
-                           uint64_t n_sk, uint8_t** h_compact, uint32_t** h_off) {
+                           uint64_t n_sk, uint8_t** h_compact, uint32_t** h_off, bool packed) {
     *h_compact = nullptr; *h_off = nullptr;
     // destination offsets are 32-bit prefix sums: a super-k-mer is at most 2k - m <= 125 bases long, so below this many
     // of them the total cannot wrap (a whole-genome select-all of > 4 Gbp has to be split by the caller)
@@ -410,8 +451,11 @@ int gather_superkmers_impl(spsp_ctx* ctx, const uint8_t* d_bases, const uint64_t
     if (e != hipSuccess) { free(off); return hip_fail(e, "gather sizes", __FILE__, __LINE__); }
     const uint64_t total = ctx->h_scalar[6];
     if ((rc = ctx->i_compact.reserve((size_t)total + 64))) { free(off); return rc; }
-    hipLaunchKernelGGL(k_gather_superkmers, dim3((uint32_t)((n_sk + 3) / 4)), dim3(256), 0, ctx->stream, d_bases, d_rec_off,
-                       d_sk, ctx->i_dst.as<uint32_t>(), (uint32_t)n_sk, ctx->i_compact.as<uint8_t>());
+    if (packed) hipLaunchKernelGGL(k_gather_superkmers_packed, dim3((uint32_t)((n_sk + 3) / 4)), dim3(256), 0, ctx->stream,
+                                   reinterpret_cast<const uint32_t*>(d_bases), d_rec_off, d_sk, ctx->i_dst.as<uint32_t>(), (uint32_t)n_sk,
+                                   ctx->i_compact.as<uint8_t>());
+    else hipLaunchKernelGGL(k_gather_superkmers, dim3((uint32_t)((n_sk + 3) / 4)), dim3(256), 0, ctx->stream, d_bases, d_rec_off,
+                            d_sk, ctx->i_dst.as<uint32_t>(), (uint32_t)n_sk, ctx->i_compact.as<uint8_t>());
     uint8_t* buf = (uint8_t*)malloc((size_t)total + 1);
     if (!buf) { free(off); set_error("out of host memory"); return SPSP_ERR_NOMEM; }
     e = hipMemcpyAsync(buf, ctx->i_compact.p, (size_t)total, hipMemcpyDeviceToHost, ctx->stream);
@@ -422,11 +466,28 @@ int gather_superkmers_impl(spsp_ctx* ctx, const uint8_t* d_bases, const uint64_t
     return SPSP_OK;
 }
 
+bool ingest_packs(const spsp_params* p) {
+    static const bool ascii = getenv("SPSP_INGEST_ASCII") != nullptr;
+    return !ascii && !(p->flags & SPSP_SCAN_PACKED_INPUT) && scan_reads_packed(p);
+}
+
 }  // namespace spsp
 
 using namespace spsp;
 
 extern "C" {
+
+// the same with the cleaned bases as 2-bit words (the input form of SPSP_SCAN_PACKED_INPUT): what spsp_sketch_text /
+// spsp_sketch_files put in front of the pair-table dense pass
+int spsp_fasta_clean_packed_device(spsp_ctx* ctx, const void* d_text, uint64_t n_text, void** d_packed, uint64_t* n_bases,
+                                   void** d_rec_off, uint32_t* n_rec) {
+    if (!ctx || !d_packed || !n_bases || !d_rec_off || !n_rec || (n_text && !d_text)) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    SPSP_HIP(hipSetDevice(ctx->device));
+    uint8_t* b = nullptr; uint64_t* o = nullptr;
+    const int rc = clean_device_impl(ctx, (const uint8_t*)d_text, n_text, &b, n_bases, &o, n_rec, true);
+    *d_packed = b; *d_rec_off = o;
+    return rc;
+}
 
 int spsp_fasta_clean_device(spsp_ctx* ctx, const void* d_text, uint64_t n_text, void** d_bases, uint64_t* n_bases,
                             void** d_rec_off, uint32_t* n_rec) {
@@ -450,17 +511,21 @@ int spsp_sketch_text(spsp_ctx* ctx, const spsp_params* p, double rate, const cha
     if ((rc = ctx->i_text.reserve((size_t)n_text + 64))) return rc;
     if (n_text) SPSP_HIP(hipMemcpyAsync(ctx->i_text.p, text, (size_t)n_text, hipMemcpyHostToDevice, ctx->stream));
     uint8_t* d_bases = nullptr; uint64_t* d_off = nullptr; uint64_t n_bases = 0; uint32_t n_rec = 0;
-    if ((rc = clean_device_impl(ctx, ctx->i_text.as<uint8_t>(), n_text, &d_bases, &n_bases, &d_off, &n_rec))) return rc;
+    // the ingest writes 2-bit words when the dense pass of these parameters reads them (SPSP_INGEST_ASCII=1: A/B switch)
+    const bool packed = ingest_packs(p);
+    if ((rc = clean_device_impl(ctx, ctx->i_text.as<uint8_t>(), n_text, &d_bases, &n_bases, &d_off, &n_rec, packed))) return rc;
     t1 = now_s(); ctx->stages.ingest_s += t1 - t0; t0 = t1;
     spsp_superkmer* d_sk = nullptr; uint64_t n_sk = 0;
-    if ((rc = scan_device_impl(ctx, p, d_bases, n_bases, d_off, n_rec, &d_sk, &n_sk))) return rc;
+    spsp_params ps = *p;
+    if (packed) ps.flags |= SPSP_SCAN_PACKED_INPUT;
+    if ((rc = scan_device_impl(ctx, &ps, d_bases, n_bases, d_off, n_rec, &d_sk, &n_sk))) return rc;
     t1 = now_s(); ctx->stages.scan_s += t1 - t0; t0 = t1;
     std::vector<uint64_t> rec_off((size_t)n_rec + 1);
     std::vector<spsp_superkmer> sk((size_t)n_sk);
     SPSP_HIP(hipMemcpyAsync(rec_off.data(), d_off, rec_off.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (n_sk) SPSP_HIP(hipMemcpyAsync(sk.data(), d_sk, (size_t)n_sk * sizeof(spsp_superkmer), hipMemcpyDeviceToHost, ctx->stream));
     uint8_t* compact = nullptr; uint32_t* coff = nullptr;
-    if ((rc = gather_superkmers_impl(ctx, d_bases, d_off, d_sk, n_sk, &compact, &coff))) return rc;   // synchronises the stream
+    if ((rc = gather_superkmers_impl(ctx, d_bases, d_off, d_sk, n_sk, &compact, &coff, packed))) return rc;   // synchronises the stream
     // -a > 1: the k-mers are counted here, over the gathered super-k-mers still on the device, and the host builder
     // indexes the usable ones only (SPSP_HOST_ABUNDANCE=1 leaves the counting to the builder, as round 1 did)
     uint8_t* kflags = nullptr; uint64_t n_occ = 0;
@@ -476,7 +541,7 @@ int spsp_sketch_text(spsp_ctx* ctx, const spsp_params* p, double rate, const cha
     ctx->stages.build_s += now_s() - t0;
     if (!rc && stats && (p->flags & SPSP_SCAN_STATS)) {   // print_stat's counters over ALL super-k-mers (SubSampler.cpp:429-430,451-452)
         t0 = now_s();
-        rc = count_superkmers_impl(ctx, p, d_bases, n_bases, d_off, n_rec, &stats->total_superkmer_number);
+        rc = count_superkmers_impl(ctx, p, d_bases, n_bases, d_off, n_rec, &stats->total_superkmer_number, packed, 0);
         stats->total_kmer_number = stats->read_kmer;      // every k-mer of a record lies in exactly one super-k-mer
         ctx->stages.scan_s += now_s() - t0;
     }

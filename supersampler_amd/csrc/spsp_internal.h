@@ -159,8 +159,9 @@ void compare_job_drop(spsp_ctx* ctx);
 int check_params(const spsp_params* p);
 int pack_bases_impl(spsp_ctx* ctx, const uint8_t* d_bases, uint64_t n_bases, uint32_t** d_packed);
 // every super-k-mer of the input, selected or not (spsp_stats.hip)
+// packed: d_bases holds 2-bit words (16 bases per dword); base0: first base of rec_off[0]'s record in d_bases, added to every offset
 int count_superkmers_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, uint64_t n_bases, const uint64_t* d_rec_off,
-                          uint32_t n_rec, uint64_t* total);
+                          uint32_t n_rec, uint64_t* total, bool packed = false, uint64_t base0 = 0);
 // bulk sketch decode (spsp_decode.hip): one stored super-k-mer of a sketch payload, as the host's structure walk finds it
 struct DecDesc {
     uint64_t off;    // byte offset in the payload (later: in the concatenated payload buffer): blob bytes (kind 0) / prefix line (kind 1)
@@ -184,10 +185,16 @@ int compare_payloads_impl(spsp_ctx* ctx, const uint8_t* const* payloads, const u
 int sketch_decode_device_impl(spsp_ctx* ctx, const uint8_t* const* payloads, const uint64_t* lens, uint32_t n,
                               const int* extra_has, const uint32_t* extra_mn, uint32_t* k_out, uint32_t* m_out, uint64_t* sk_off);
 // ingest (spsp_ingest.hip)
+// pack: the cleaned bases leave as 2-bit words (ctx->packed: 16 bases per dword, first base in bits 31:30, zero-filled tail
+// + 256 readable bytes) instead of ASCII (ctx->bases); *d_bases then points at the words
 int clean_device_impl(spsp_ctx* ctx, const uint8_t* d_text, uint64_t n_text, uint8_t** d_bases, uint64_t* n_bases,
-                      uint64_t** d_rec_off, uint32_t* n_rec);
+                      uint64_t** d_rec_off, uint32_t* n_rec, bool pack = false);
+// does the dense pass chosen for these parameters read 2-bit input directly? (spsp_scan.hip)
+bool scan_reads_packed(const spsp_params* p);
+// should the whole-file drivers let the ingest write 2-bit words for these parameters? (spsp_ingest.hip)
+bool ingest_packs(const spsp_params* p);
 int gather_superkmers_impl(spsp_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_rec_off, const spsp_superkmer* d_sk,
-                           uint64_t n_sk, uint8_t** h_compact, uint32_t** h_off);
+                           uint64_t n_sk, uint8_t** h_compact, uint32_t** h_off, bool packed = false);
 // out[i] = sum(in[0..i)), out[n] = total (also stored to *total_host, pinned)
 int launch_scan_u32(spsp_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, uint64_t n, uint64_t* total_host);
 // host sketch builder over per-super-k-mer base pointers (spsp_host.cpp)

@@ -39,20 +39,6 @@ constexpr int kRowPos = kThreads * kChunk;   // 4096 positions per row
 constexpr int kTilePos = kRows * kRowPos;    // 16384 positions per workgroup
 constexpr int kTileWords = kTilePos / 32;    // 512 bitmap words per tile
 
-// 16 ASCII bases -> 32 bits, first base in the two most significant bits.
-// code = (c >> 1) & 3 (reference utils.cpp:13-16: A=0 C=1 T=2 G=3).
-// Four bases per dword with ONE dot instruction: bytes & 0x06 hold 2*code, and v_dot4_u32_u8 with byte
-// weights 64,16,4,1 (first base = lowest byte = most significant field) sums them into 2 * (b0<<6|b1<<4|b2<<2|b3).
-// The factor 2 is carried through the shift-or merges and dropped by the last shift, so 16 bases cost
-// 4 and + 4 dot4 + 4 merges (a 32-bit integer multiply, the previous form, is a quarter-rate instruction).
-__device__ __forceinline__ uint32_t pack4x2(uint32_t d) {
-    return __builtin_amdgcn_udot4(d & 0x06060606u, 0x01041040u, 0u, false);
-}
-__device__ __forceinline__ uint32_t pack16(uint4 v) {
-    const uint32_t a = (pack4x2(v.x) << 8) | pack4x2(v.y);   // 2 * (first 8 bases)
-    const uint32_t b = (pack4x2(v.z) << 8) | pack4x2(v.w);   // 2 * (last 8 bases)
-    return (a << 15) | (b >> 1);
-}
 __device__ __forceinline__ uint32_t load_pack(const uint8_t* __restrict__ bases, uint64_t n, uint64_t pos) {
     if (pos + kChunk <= n) {
         return pack16(*reinterpret_cast<const uint4*>(bases + pos));
@@ -1413,6 +1399,8 @@ int check_params(const spsp_params* p) {
 // Picks the dense-pass variant from the expected survivor rate of each memoised table:
 // P(hash <= T) times the m-mers (both strands) that share one table bit.
 enum { kDenseDirect = 0, kDenseSingle = 1, kDensePair = 2, kDenseBloom = 3 };
+static int pick_dense(const spsp_params* p);
+bool scan_reads_packed(const spsp_params* p) { return pick_dense(p) == kDensePair; }
 static int pick_dense(const spsp_params* p) {
     const bool bloom_ok = p->m == 13 || p->m == 15;
     if (p->flags & SPSP_SCAN_DIRECT_HASH) return kDenseDirect;

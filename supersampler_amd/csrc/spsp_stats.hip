@@ -20,14 +20,23 @@ constexpr int kStatChunk = 512;     // iterations (k-mers) per lane
 constexpr int kStatThreads = 128;
 
 struct StatMachine {
-    const uint8_t* rec;   // bases of the record
+    const uint8_t* rec;   // bases of the record (ASCII) ...
+    const uint32_t* pk;   // ... or the whole 2-bit buffer (16 bases per dword, first base in bits 31:30) and
+    uint64_t base;        //     the record's first base in it
     uint64_t len;
     uint32_t k, m, mask;
     // state
     uint64_t hash_min, position_min;
     uint32_t minimizer, old_minimizer, min_seq, min_rc;
 
-    __device__ __forceinline__ uint32_t code(uint64_t at) const { return ((uint32_t)rec[at] >> 1) & 3u; }
+    __device__ __forceinline__ uint32_t code(uint64_t at) const {
+        if (pk) { const uint64_t q = base + at; return (pk[q >> 4] >> (30u - 2u * (uint32_t)(q & 15u))) & 3u; }
+        return ((uint32_t)rec[at] >> 1) & 3u;
+    }
+    __device__ __forceinline__ void bind(const uint8_t* bases, bool packed, uint64_t first_base) {
+        if (packed) { pk = reinterpret_cast<const uint32_t*>(bases); base = first_base; rec = nullptr; }
+        else { pk = nullptr; base = 0; rec = bases + first_base; }
+    }
 
     // regular_minimizer_pos (SubSampler.cpp:81-169) of the k-mer starting at `ks`, literally, right to left
     __device__ void rescan(uint64_t ks, uint64_t* position) {
@@ -94,7 +103,7 @@ struct StatMachine {
 // chunk c covers the global k-mer iterations [c * kStatChunk, (c + 1) * kStatChunk) of the concatenated records:
 // iteration g of record r = its k-mer g - rec_off[r] (only iterations i with i + k < len run the loop; the tail
 // super-k-mer of every record with >= 1 k-mer is one more, added by whoever handles its k-mer 0)
-__global__ __launch_bounds__(kStatThreads) void k_stat_count(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ rec_off,
+__global__ __launch_bounds__(kStatThreads) void k_stat_count(const uint8_t* __restrict__ bases, bool packed, uint64_t base0, const uint64_t* __restrict__ rec_off,
                                                             uint32_t n_rec, uint32_t k, uint32_t m, uint64_t n_chunks,
                                                             uint32_t lookback, uint32_t* __restrict__ chunk_count,
                                                             uint8_t* __restrict__ chunk_open, unsigned long long* __restrict__ total) {
@@ -116,7 +125,7 @@ __global__ __launch_bounds__(kStatThreads) void k_stat_count(const uint8_t* __re
             bool open = false;
             if (a < b) {
                 StatMachine M;
-                M.rec = bases + r0; M.len = len; M.k = k; M.m = m; M.mask = (1u << (2 * m)) - 1u;
+                M.bind(bases, packed, base0 + r0); M.len = len; M.k = k; M.m = m; M.mask = (1u << (2 * m)) - 1u;
                 const uint64_t i0 = a > lookback ? a - lookback : 0;
                 M.start(i0);
                 bool exact = i0 == 0, reset;
@@ -139,7 +148,7 @@ __global__ __launch_bounds__(kStatThreads) void k_stat_count(const uint8_t* __re
 
 // second pass: every RUN of consecutive open chunks (inside one record) is replayed by one lane from the exact
 // state in front of the chunk before the run; the provisional counts are replaced
-__global__ __launch_bounds__(kStatThreads) void k_stat_fix(const uint8_t* __restrict__ bases, const uint64_t* __restrict__ rec_off,
+__global__ __launch_bounds__(kStatThreads) void k_stat_fix(const uint8_t* __restrict__ bases, bool packed, uint64_t base0, const uint64_t* __restrict__ rec_off,
                                                           uint32_t n_rec, uint32_t k, uint32_t m, uint64_t n_chunks,
                                                           uint32_t lookback, const uint32_t* __restrict__ chunk_count,
                                                           const uint8_t* __restrict__ chunk_open, unsigned long long* __restrict__ total) {
@@ -156,7 +165,7 @@ __global__ __launch_bounds__(kStatThreads) void k_stat_fix(const uint8_t* __rest
     const uint64_t prev_a = a > (uint64_t)kStatChunk ? a - kStatChunk : 0;
     const uint64_t i0 = prev_a > lookback ? prev_a - lookback : 0;
     StatMachine M;
-    M.rec = bases + r0; M.len = len; M.k = k; M.m = m; M.mask = (1u << (2 * m)) - 1u;
+    M.bind(bases, packed, base0 + r0); M.len = len; M.k = k; M.m = m; M.mask = (1u << (2 * m)) - 1u;
     M.start(i0);
     bool reset;
     for (uint64_t i = i0; i < a; ++i) M.step(i, &reset);
@@ -171,7 +180,7 @@ __global__ __launch_bounds__(kStatThreads) void k_stat_fix(const uint8_t* __rest
 }
 
 int count_superkmers_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, uint64_t n_bases, const uint64_t* d_rec_off,
-                          uint32_t n_rec, uint64_t* total) {
+                          uint32_t n_rec, uint64_t* total, bool packed, uint64_t base0) {
     *total = 0;
     int rc = check_params(p);
     if (rc) return rc;
@@ -186,10 +195,10 @@ int count_superkmers_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_
     const uint32_t w = p->k - p->m + 1;
     const uint32_t lookback = 8 * w < 64 ? 64 : 8 * w;
     const uint32_t blocks = (uint32_t)((n_chunks + kStatThreads - 1) / kStatThreads);
-    hipLaunchKernelGGL(k_stat_count, dim3(blocks), dim3(kStatThreads), 0, ctx->stream, d_bases, d_rec_off, n_rec, p->k, p->m, n_chunks,
+    hipLaunchKernelGGL(k_stat_count, dim3(blocks), dim3(kStatThreads), 0, ctx->stream, d_bases, packed, base0, d_rec_off, n_rec, p->k, p->m, n_chunks,
                        lookback, ctx->st_count.as<uint32_t>(), ctx->st_open.as<uint8_t>(), d_total);
     SPSP_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_stat_fix, dim3(blocks), dim3(kStatThreads), 0, ctx->stream, d_bases, d_rec_off, n_rec, p->k, p->m, n_chunks,
+    hipLaunchKernelGGL(k_stat_fix, dim3(blocks), dim3(kStatThreads), 0, ctx->stream, d_bases, packed, base0, d_rec_off, n_rec, p->k, p->m, n_chunks,
                        lookback, ctx->st_count.as<uint32_t>(), ctx->st_open.as<uint8_t>(), d_total);
     SPSP_HIP(hipGetLastError());
     SPSP_HIP(hipMemcpyAsync(ctx->h_scalar + 3, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));

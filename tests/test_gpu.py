@@ -545,18 +545,28 @@ def test_gpu_ingest_matches_oracle(ctx):
         got_o = ctx.to_host(do, nr + 1, np.uint64)
         assert got_o.tolist() == want_o.tolist()
         assert got_b.tobytes() == want_b.tobytes()
+        # the same ingest writing 2-bit words (16 bases per dword, first base in bits 31:30, zero tail): the oracle's
+        # cleaned bases, packed with numpy
+        dp, nb2, do2, nr2 = ctx.clean_fasta_packed_device(d.data_ptr(), len(text))
+        assert (nb2, nr2) == (nb, nr) and ctx.to_host(do2, nr + 1, np.uint64).tolist() == want_o.tolist()
+        n_dw = (nb + 15) // 16
+        codes = np.zeros(n_dw * 16, dtype=np.uint32)
+        codes[:nb] = (want_b.astype(np.uint32) >> 1) & 3
+        want_w = (codes.reshape(-1, 16) << (30 - 2 * np.arange(16, dtype=np.uint32))).sum(axis=1, dtype=np.uint64).astype(np.uint32)
+        got_w = ctx.to_host(dp, n_dw + 64, np.uint32)
+        assert (got_w[:n_dw] == want_w).all() and not got_w[n_dw:].any()
 
 
-@pytest.mark.parametrize("k,m,s", [(31, 11, 100), (63, 15, 20), (21, 11, 1.0)])
+@pytest.mark.parametrize("k,m,s", [(31, 11, 100), (31, 11, 1000), (63, 15, 20), (21, 11, 1.0)])
 def test_sketch_text_gpu_ingest_equals_oracle(ctx, k, m, s):
     rng = np.random.default_rng(k + m)
     g = synth.random_genome(rng, 200_000)
     text = synth.to_fasta(g[:120_000], "a", n_records=2) + b">short\nACGT\n>n\nNNNNNN\n" + synth.to_fasta(g[120_000:], "b")
     text = text.replace(b"ACGTA", b"acgNa", 50)
-    got, gst = ctx.sketch_text(text, k, m, s)
+    got, gst = ctx.sketch_text(text, k, m, s, flags=sp.SPSP_SCAN_STATS)
     want, wst = orc.sketch_fasta(text, k, m, s)
     assert got == want
-    for f in ("selected_kmer_number", "read_kmer", "nb_mmer_selected", "seen_kmers_at_reconstruction"):
+    for f in ("selected_kmer_number", "read_kmer", "nb_mmer_selected", "seen_kmers_at_reconstruction", "total_superkmer_number"):
         assert gst[f] == wst[f], f
 
 
@@ -982,6 +992,16 @@ def test_sketch_files_pipeline_equals_oracle(tmp_path):
             assert sp.read_file(outs[i]) == want[i][0], (threads, i)
             for f in fields:
                 assert st[f] == want[i][1][f], (threads, i, f, st[f], want[i][1][f])
+    # the default sampling (-s 1000): the pair-table dense pass, so the ingest writes 2-bit words and the gather and the
+    # count of all super-k-mers read them
+    want1k = [orc.sketch_fasta(t, k, m, 1000.0) for t in texts]
+    outs = [str(tmp_path / ("out_s1000_%d.gz" % i)) for i in range(len(ins))]
+    res, _, _ = sp.sketch_files(ins, outs, k, m, 1000.0, threads=4, flags=sp.SPSP_SCAN_STATS)
+    for i, (rc, st, err) in enumerate(res):
+        assert rc == 0 and sp.read_file(outs[i]) == want1k[i][0], (i, rc, err)
+        for f in fields:
+            assert st[f] == want1k[i][1][f], (i, f, st[f], want1k[i][1][f])
+    assert sum(w[1]["selected_kmer_number"] for w in want1k) > 500
     bad = ins[:2] + [str(tmp_path / "missing.fa")] + ins[2:4]
     outs = [str(tmp_path / ("out_bad_%d.gz" % i)) for i in range(len(bad))]
     res, _, started = sp.sketch_files(bad, outs, k, m, s, threads=2)
