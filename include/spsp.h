@@ -310,6 +310,25 @@ int spsp_sketch_text(spsp_ctx* ctx, const spsp_params* p, double rate, const cha
 int spsp_sketch_parse_host(const uint8_t* payload, uint64_t len, uint32_t* k, uint32_t* m,
                            uint32_t** minimizer, uint64_t** kmer_lo, uint64_t** kmer_hi, uint64_t* n);
 
+/* From a scan straight to the comparator's keys, without the sketch file in between.  Genome g = records
+ * [h_first_rec[g], h_first_rec[g + 1]) of ONE scan (d_bases / d_rec_off / d_superkmers as given to and returned by
+ * spsp_scan_device; SPSP_SCAN_PACKED_INPUT in p->flags when d_bases holds 2-bit words).  The result is what
+ * spsp_sketch_parse_host would return for the sketch parse_fasta_test writes for that genome: handle_superkmer's
+ * per-k-mer counts with their uint8 wrap and the -a rule (SubSampler.cpp:243-302, 587, 608), the emission / reader round
+ * trip (:458-620, Comparator.cpp:186-260) and canonize composed -- the DISTINCT (minimizer, canonical k-mer) keys of every
+ * genome, sorted, back to back in device arrays OWNED BY THE CONTEXT (the ones spsp_sketch_decode_device fills: valid
+ * until the next decode / keys / spsp_compare call on it; *d_kmer_hi = NULL when k <= 32), sk_off with n_genomes + 1
+ * offsets: ready for spsp_compare_device.  A genome with more than 8192 selected k-mer occurrences (4096 with k > 32)
+ * does not fit the per-genome sort: SPSP_ERR_OVERFLOW (sketch such genomes through files).  _begin queues the work on
+ * the context's stream and returns; _end waits for it (an event behind its last kernel).  One job may be pending per
+ * context. */
+int spsp_sketch_keys_device(spsp_ctx* ctx, const spsp_params* p, const void* d_bases, const void* d_rec_off, const void* d_superkmers,
+                            uint64_t n_superkmers, const uint32_t* h_first_rec, uint32_t n_genomes, void** d_minimizer, void** d_kmer_lo,
+                            void** d_kmer_hi, uint64_t* sk_off);
+int spsp_sketch_keys_device_begin(spsp_ctx* ctx, const spsp_params* p, const void* d_bases, const void* d_rec_off, const void* d_superkmers,
+                                  uint64_t n_superkmers, const uint32_t* h_first_rec, uint32_t n_genomes);
+int spsp_sketch_keys_device_end(spsp_ctx* ctx, void** d_minimizer, void** d_kmer_lo, void** d_kmer_hi, uint64_t* sk_off);
+
 /* The same decode for MANY sketches at once on the GPU ("next" row N2): payloads[i] = gunzipped sketch i.  The
  * sorted distinct keys of all sketches end up back to back in device arrays OWNED BY THE CONTEXT (valid until the
  * next decode / spsp_compare call on it; *d_kmer_hi = NULL when k <= 32), ready for spsp_compare_device; sk_off gets

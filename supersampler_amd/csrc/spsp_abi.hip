@@ -209,6 +209,8 @@ void spsp_destroy(spsp_ctx* c) {
     compare_job_drop(c);
     if (c->h_skoff) (void)hipHostFree(c->h_skoff);
     if (c->h_text) (void)hipHostFree(c->h_text);
+    if (c->h_keys) (void)hipHostFree(c->h_keys);
+    if (c->keys_done) (void)hipEventDestroy(c->keys_done);
     if (c->dense_done) (void)hipEventDestroy(c->dense_done);
     if (c->tail_event) (void)hipEventDestroy(c->tail_event);
     if (c->scan_done) (void)hipEventDestroy(c->scan_done);

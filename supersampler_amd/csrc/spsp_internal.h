@@ -101,6 +101,12 @@ struct spsp_ctx {
     bool attr_pair_set = false, attr_single_set = false, attr_bloom_set = false, attr_small_set = false, attr_group_set = false, attr_group_hi_set = false, attr_scatter_set = false, attr_sort_set = false;   // dynamic-LDS attributes set on this context's device
     spsp::ScanJob scan_job;
     spsp::CompareJob* compare_job = nullptr;
+    // spsp_sketch_keys_device_begin / _end (spsp_keys.hip)
+    bool keys_pending = false, keys_has_hi = false, attr_keys_set = false;
+    uint32_t keys_genomes = 0;
+    hipEvent_t keys_done = nullptr;
+    uint32_t* h_keys = nullptr;        // pinned: genome record ranges in, key offsets + overflow report out
+    size_t h_keys_cap = 0;
     uint8_t* h_text = nullptr;         // pinned staging for a whole FASTA file (spsp_sketch_file reads plain files straight into it)
     size_t h_text_cap = 0;
     uint64_t* h_skoff = nullptr;       // pinned staging for the sketch offsets of a queued comparison

@@ -1,0 +1,306 @@
+// spsp_keys.hip -- from the scan's super-k-mer stream straight to the comparator's keys, on the device.
+//
+// In the reference a genome reaches the comparison through a file: handle_superkmer explodes every selected
+// super-k-mer into its k-mers, oriented so that the minimizer reads canonically, and counts each one in a per-minimizer
+// map with a uint8 count (SubSampler.cpp:243-302, SubSampler.h:23-27); the emission writes every k-mer whose count is
+// >= abundance into some super-k-mer (:458-620: find_first_kmer / find_next only ever follow such k-mers, so a written
+// super-k-mer holds those and nothing else); the comparator reads the super-k-mers back, walks their k-mers and keeps
+// the DISTINCT canonical ones per bucket (Comparator.cpp:186-260).  Composed, a genome's keys are
+//
+//     { (minimizer, canon(x)) :  x an oriented k-mer of a selected super-k-mer,  (occurrences of x) mod 256 >= abundance }
+//
+// which needs neither the string reconstruction nor the file.  This is that composition for MANY genomes at once --
+// genome g = records [first_rec[g], first_rec[g+1]) of one scan -- producing the arrays spsp_compare_device takes:
+//
+//   k_keys_sizes    k-mers per selected super-k-mer -> (scan) first raw key of each
+//   k_keys_emit     one lane per super-k-mer: rolls the k-mers and their reverse complements from the bases (ASCII or
+//                   2-bit words) -> raw keys (minimizer, canonical k-mer, "the oriented form is the reverse complement")
+//   k_keys_ranges   one lane per genome: its super-k-mers (binary search on the record numbers) -> its raw key range
+//   k_keys_sort     one workgroup per genome: bitonic sort in LDS by (minimizer, k-mer, orientation); occurrences per
+//                   oriented k-mer -> the uint8 rule; distinct surviving canonical keys, compacted in place
+//   k_keys_compact  genomes back to back
+//
+// A genome with more raw keys than the LDS sort holds (8192; 4096 with k > 32) is reported (SPSP_ERR_OVERFLOW): such
+// inputs go through the sketch files, whose reader has a host path for them.
+#include <cstring>
+
+#include "spsp_internal.h"
+#include "spsp_device.h"
+
+namespace spsp {
+
+typedef unsigned __int128 u128d;
+constexpr int kKeySortThreads = 1024;
+constexpr uint32_t kKeyCapLo = 8192, kKeyCapHi = 4096;
+
+__global__ void k_keys_sizes(const spsp_superkmer* __restrict__ sk, uint32_t n_sk, uint32_t k, uint32_t* __restrict__ cnt) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_sk) cnt[i] = sk[i].len >= k ? sk[i].len - k + 1 : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_keys_emit(const uint8_t* __restrict__ bases, bool packed, const uint64_t* __restrict__ rec_off,
+                                                  const spsp_superkmer* __restrict__ sk, const uint32_t* __restrict__ raw_first,
+                                                  uint32_t n_sk, uint32_t k, uint32_t* __restrict__ r_mn, uint64_t* __restrict__ r_lo,
+                                                  uint64_t* __restrict__ r_hi, uint8_t* __restrict__ r_or) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_sk) return;
+    const spsp_superkmer e = sk[i];
+    if (e.len < k) return;
+    const uint64_t src = rec_off[e.rec] + e.start;
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(bases);
+    const u128d mask = k == 64 ? ~(u128d)0 : (((u128d)1 << (2 * k)) - 1);
+    u128d fwd = 0, rc = 0;
+    uint32_t o = raw_first[i];
+    for (uint32_t t = 0; t < e.len; ++t) {
+        const uint64_t q = src + t;
+        const uint32_t c = packed ? (words[q >> 4] >> (30u - 2u * (uint32_t)(q & 15u))) & 3u : ((uint32_t)bases[q] >> 1) & 3u;
+        fwd = ((fwd << 2) | c) & mask;
+        rc = (rc >> 2) | ((u128d)(c ^ 2u) << (2 * (k - 1)));
+        if (t + 1 < k) continue;
+        // handle_superkmer stores the k-mer as it reads in the super-k-mer's orientation (reverse complemented when the
+        // minimizer reads reversed, SubSampler.cpp:246-249); the comparator canonises (utils.cpp:470-472)
+        const u128d canon = fwd < rc ? fwd : rc;
+        const u128d oriented = e.rev ? rc : fwd;
+        r_mn[o] = e.minimizer; r_lo[o] = (uint64_t)canon;
+        if (r_hi) r_hi[o] = (uint64_t)(canon >> 64);
+        r_or[o] = oriented != canon ? 1 : 0;
+        ++o;
+    }
+}
+
+// genome g = records [first_rec[g], first_rec[g + 1]); the stream is in record order
+__global__ void k_keys_ranges(const spsp_superkmer* __restrict__ sk, uint32_t n_sk, const uint32_t* __restrict__ raw_first,
+                              const uint32_t* __restrict__ first_rec, uint32_t n_genomes, uint32_t* __restrict__ raw_off) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g > n_genomes) return;
+    const uint32_t want = first_rec[g];
+    uint32_t lo = 0, hi = n_sk;                              // first super-k-mer with rec >= want
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (sk[mid].rec < want) lo = mid + 1; else hi = mid; }
+    raw_off[g] = raw_first[lo];                              // (raw_first has n_sk + 1 entries)
+}
+
+template <bool HAS_HI>
+__global__ __launch_bounds__(kKeySortThreads) void k_keys_sort(uint32_t* __restrict__ r_mn, uint64_t* __restrict__ r_lo, uint64_t* __restrict__ r_hi,
+                                                              const uint8_t* __restrict__ r_or, const uint32_t* __restrict__ raw_off,
+                                                              uint32_t abundance, uint32_t* __restrict__ distinct, uint32_t* __restrict__ flags) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_k[];
+    constexpr uint32_t CAP = HAS_HI ? kKeyCapHi : kKeyCapLo;
+    uint64_t* s_lo = reinterpret_cast<uint64_t*>(lds_k);
+    uint64_t* s_hi = s_lo + CAP;                                   // (HAS_HI only)
+    uint32_t* s_mn = reinterpret_cast<uint32_t*>(s_hi + (HAS_HI ? CAP : 0));
+    uint8_t* s_or = reinterpret_cast<uint8_t*>(s_mn + CAP);
+    __shared__ uint32_t wave_sum[kKeySortThreads / 64];
+    const uint32_t g = blockIdx.x, t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const uint32_t r0 = raw_off[g], n = raw_off[g + 1] - r0;
+    if (n == 0) { if (t == 0) distinct[g] = 0; return; }
+    if (n > CAP) { if (t == 0) { distinct[g] = 0; atomicOr(&flags[0], 1u); atomicMax(&flags[1], n); } return; }
+    uint32_t n2 = 1;
+    while (n2 < n) n2 <<= 1;
+    for (uint32_t i = t; i < n2; i += kKeySortThreads) {
+        if (i < n) { s_mn[i] = r_mn[r0 + i]; s_lo[i] = r_lo[r0 + i]; if (HAS_HI) s_hi[i] = r_hi[r0 + i]; s_or[i] = r_or[r0 + i]; }
+        else { s_mn[i] = 0xffffffffu; s_lo[i] = ~0ull; if (HAS_HI) s_hi[i] = ~0ull; s_or[i] = 1; }
+    }
+    __syncthreads();
+    auto greater = [&](uint32_t a, uint32_t b) {                   // (minimizer, k-mer, orientation)
+        if (s_mn[a] != s_mn[b]) return s_mn[a] > s_mn[b];
+        if (HAS_HI && s_hi[a] != s_hi[b]) return s_hi[a] > s_hi[b];
+        if (s_lo[a] != s_lo[b]) return s_lo[a] > s_lo[b];
+        return s_or[a] > s_or[b];
+    };
+    for (uint32_t size = 2; size <= n2; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t idx = t; idx < (n2 >> 1); idx += kKeySortThreads) {
+                const uint32_t i = ((idx / stride) * (stride << 1)) + (idx % stride), j = i + stride;
+                const bool asc = (i & size) == 0;
+                if (greater(i, j) == asc) {
+                    const uint32_t tm = s_mn[i]; s_mn[i] = s_mn[j]; s_mn[j] = tm;
+                    const uint64_t tl = s_lo[i]; s_lo[i] = s_lo[j]; s_lo[j] = tl;
+                    if (HAS_HI) { const uint64_t th = s_hi[i]; s_hi[i] = s_hi[j]; s_hi[j] = th; }
+                    const uint8_t to = s_or[i]; s_or[i] = s_or[j]; s_or[j] = to;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    auto same_key = [&](uint32_t a, uint32_t b) { return s_mn[a] == s_mn[b] && s_lo[a] == s_lo[b] && (!HAS_HI || s_hi[a] == s_hi[b]); };
+    // occurrences of the oriented k-mer that starts at i (a run of equal key AND orientation), read through the
+    // reference's uint8 counter (SubSampler.h:24): 256 occurrences count as 0
+    auto usable_from = [&](uint32_t i, uint32_t* next) {
+        uint32_t j = i + 1;
+        while (j < n && same_key(i, j) && s_or[j] == s_or[i]) ++j;
+        *next = j;
+        return ((j - i) & 255u) >= abundance;
+    };
+    constexpr uint32_t PER = CAP / kKeySortThreads;
+    uint32_t keep[PER];
+    uint32_t cnt = 0;
+#pragma unroll
+    for (uint32_t u = 0; u < PER; ++u) {
+        const uint32_t i = t * PER + u;
+        keep[u] = 0;
+        if (i < n && (i == 0 || !same_key(i, i - 1))) {            // first record of a canonical key: its (at most two) orientations
+            uint32_t j;
+            bool ok = usable_from(i, &j);
+            if (j < n && same_key(i, j)) { uint32_t j2; ok = usable_from(j, &j2) || ok; }
+            keep[u] = ok ? 1u : 0u;
+        }
+        cnt += keep[u];
+    }
+    uint32_t x = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d); if (lane >= (uint32_t)d) x += y; }
+    if (lane == 63) wave_sum[wid] = x;
+    __syncthreads();
+    uint32_t pre = 0, all = 0;
+    for (uint32_t w = 0; w < kKeySortThreads / 64; ++w) { if (w < wid) pre += wave_sum[w]; all += wave_sum[w]; }
+    uint32_t rank = pre + x - cnt;
+#pragma unroll
+    for (uint32_t u = 0; u < PER; ++u) {
+        const uint32_t i = t * PER + u;
+        if (!keep[u]) continue;
+        r_mn[r0 + rank] = s_mn[i]; r_lo[r0 + rank] = s_lo[i];
+        if (HAS_HI) r_hi[r0 + rank] = s_hi[i];
+        ++rank;
+    }
+    if (t == 0) distinct[g] = all;
+}
+
+__global__ __launch_bounds__(256) void k_keys_compact(const uint32_t* __restrict__ r_mn, const uint64_t* __restrict__ r_lo,
+                                                     const uint64_t* __restrict__ r_hi, const uint32_t* __restrict__ raw_off,
+                                                     const uint32_t* __restrict__ distinct, const uint32_t* __restrict__ out_off,
+                                                     uint32_t* __restrict__ o_mn, uint64_t* __restrict__ o_lo, uint64_t* __restrict__ o_hi,
+                                                     uint32_t n_genomes, const uint32_t* __restrict__ flags, uint32_t* __restrict__ host_out) {
+    const uint32_t g = blockIdx.y;
+    const uint32_t n = distinct[g], r0 = raw_off[g], o0 = out_off[g];
+    for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
+        o_mn[o0 + e] = r_mn[r0 + e]; o_lo[o0 + e] = r_lo[r0 + e];
+        if (o_hi) o_hi[o0 + e] = r_hi[r0 + e];
+    }
+    // the offsets and the overflow report travel to pinned host memory from here: the job ends with this kernel
+    if (blockIdx.x == 0) {
+        if (threadIdx.x == 0) host_out[g] = o0;
+        if (g == n_genomes - 1 && threadIdx.x == 0) { host_out[n_genomes] = o0 + n; host_out[n_genomes + 1] = flags[0]; host_out[n_genomes + 2] = flags[1]; }
+    }
+}
+
+int sketch_keys_begin_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, bool packed, const uint64_t* d_rec_off,
+                           const spsp_superkmer* d_sk, uint64_t n_sk, const uint32_t* h_first_rec, uint32_t n_genomes) {
+    int rc = check_params(p);
+    if (rc) return rc;
+    if (ctx->keys_pending) { set_error("a key extraction is already pending on this context"); return SPSP_ERR_ARG; }
+    if (n_genomes == 0) { set_error("no genomes"); return SPSP_ERR_ARG; }
+    for (uint32_t g = 0; g < n_genomes; ++g)
+        if (h_first_rec[g + 1] < h_first_rec[g]) { set_error("genome record ranges must be non-decreasing (genome %u)", g); return SPSP_ERR_ARG; }
+    if (n_sk > 0x7ffffff0ull / 64) { set_error("too many super-k-mers for one call"); return SPSP_ERR_OVERFLOW; }
+    const uint32_t n = (uint32_t)n_sk;
+    const bool has_hi = p->k > 32;
+    const uint64_t bound = (uint64_t)n * (p->k - p->m + 1);        // raw keys: a super-k-mer holds at most k - m + 1 k-mers
+    if (bound > 0xfffffff0ull) { set_error("too many selected k-mers for one call"); return SPSP_ERR_OVERFLOW; }
+    // pinned staging: first_rec in, offsets + flags out
+    const size_t need = (size_t)(n_genomes + 1) + (size_t)(n_genomes + 3);
+    if (ctx->h_keys_cap < need) {
+        if (ctx->h_keys) { SPSP_HIP(hipStreamSynchronize(ctx->stream)); (void)hipHostFree(ctx->h_keys); ctx->h_keys = nullptr; ctx->h_keys_cap = 0; }
+        size_t cap = 1024;
+        while (cap < need) cap *= 2;
+        SPSP_HIP(hipHostMalloc((void**)&ctx->h_keys, cap * 4, hipHostMallocDefault));
+        ctx->h_keys_cap = cap;
+    }
+    memcpy(ctx->h_keys, h_first_rec, (size_t)(n_genomes + 1) * 4);
+    uint32_t* h_out = ctx->h_keys + (n_genomes + 1);
+    if ((rc = ctx->a_cnt.reserve((size_t)(n + 1) * 4)) || (rc = ctx->a_off.reserve((size_t)(n + 2) * 4)) ||
+        (rc = ctx->a_mn.reserve((size_t)bound * 4 + 64)) || (rc = ctx->a_lo.reserve((size_t)bound * 8 + 64)) ||
+        (has_hi && (rc = ctx->a_hi.reserve((size_t)bound * 8 + 64))) || (rc = ctx->a_flags.reserve((size_t)bound + 64)) ||
+        (rc = ctx->dc_meta.reserve((size_t)(n_genomes + 2) * 4 * 4 + 64)) ||
+        (rc = ctx->c_min.reserve((size_t)bound * 4 + 64)) || (rc = ctx->c_lo.reserve((size_t)bound * 8 + 64)) ||
+        (has_hi && (rc = ctx->c_hi.reserve((size_t)bound * 8 + 64)))) return rc;
+    uint32_t* d_first_rec = ctx->dc_meta.as<uint32_t>();
+    uint32_t* d_raw_off = d_first_rec + (n_genomes + 2);
+    uint32_t* d_distinct = d_raw_off + (n_genomes + 2);
+    uint32_t* d_out_off = d_distinct + (n_genomes + 2);
+    if ((rc = ctx->c_flags.reserve(64))) return rc;
+    uint32_t* d_flags = ctx->c_flags.as<uint32_t>() + 12;          // two words of the comparison's flag block that it does not use
+    SPSP_HIP(hipMemcpyAsync(d_first_rec, ctx->h_keys, (size_t)(n_genomes + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    SPSP_HIP(hipMemsetAsync(d_flags, 0, 8, ctx->stream));
+    if (n) {
+        hipLaunchKernelGGL(k_keys_sizes, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_sk, n, p->k, ctx->a_cnt.as<uint32_t>());
+        SPSP_HIP(hipGetLastError());
+    }
+    if ((rc = launch_scan_u32(ctx, ctx->a_cnt.as<uint32_t>(), ctx->a_off.as<uint32_t>(), n, ctx->h_scalar + 7))) return rc;
+    if (n) {
+        hipLaunchKernelGGL(k_keys_emit, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_bases, packed, d_rec_off, d_sk, ctx->a_off.as<uint32_t>(), n, p->k,
+                           ctx->a_mn.as<uint32_t>(), ctx->a_lo.as<uint64_t>(), has_hi ? ctx->a_hi.as<uint64_t>() : (uint64_t*)nullptr, ctx->a_flags.as<uint8_t>());
+        SPSP_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_keys_ranges, dim3((n_genomes + 1 + 255) / 256), dim3(256), 0, ctx->stream, d_sk, n, ctx->a_off.as<uint32_t>(), d_first_rec,
+                       n_genomes, d_raw_off);
+    SPSP_HIP(hipGetLastError());
+    const size_t lds = has_hi ? (size_t)kKeyCapHi * 21 : (size_t)kKeyCapLo * 13;
+    if (!ctx->attr_keys_set) {
+        SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keys_sort<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kKeyCapHi * 21)));
+        SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keys_sort<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kKeyCapLo * 13)));
+        ctx->attr_keys_set = true;
+    }
+    const uint32_t ab = p->abundance ? p->abundance : 1u;
+    if (has_hi) hipLaunchKernelGGL(k_keys_sort<true>, dim3(n_genomes), dim3(kKeySortThreads), lds, ctx->stream, ctx->a_mn.as<uint32_t>(), ctx->a_lo.as<uint64_t>(),
+                                   ctx->a_hi.as<uint64_t>(), ctx->a_flags.as<uint8_t>(), d_raw_off, ab, d_distinct, d_flags);
+    else hipLaunchKernelGGL(k_keys_sort<false>, dim3(n_genomes), dim3(kKeySortThreads), lds, ctx->stream, ctx->a_mn.as<uint32_t>(), ctx->a_lo.as<uint64_t>(),
+                            (uint64_t*)nullptr, ctx->a_flags.as<uint8_t>(), d_raw_off, ab, d_distinct, d_flags);
+    SPSP_HIP(hipGetLastError());
+    if ((rc = launch_scan_u32(ctx, d_distinct, d_out_off, n_genomes, ctx->h_scalar + 7))) return rc;
+    hipLaunchKernelGGL(k_keys_compact, dim3(8, n_genomes), dim3(256), 0, ctx->stream, ctx->a_mn.as<uint32_t>(), ctx->a_lo.as<uint64_t>(),
+                       has_hi ? ctx->a_hi.as<uint64_t>() : (const uint64_t*)nullptr, d_raw_off, d_distinct, d_out_off, ctx->c_min.as<uint32_t>(),
+                       ctx->c_lo.as<uint64_t>(), has_hi ? ctx->c_hi.as<uint64_t>() : (uint64_t*)nullptr, n_genomes, d_flags, h_out);
+    SPSP_HIP(hipGetLastError());
+    if (!ctx->keys_done) SPSP_HIP(hipEventCreateWithFlags(&ctx->keys_done, hipEventDisableTiming));
+    SPSP_HIP(hipEventRecord(ctx->keys_done, ctx->stream));
+    ctx->keys_pending = true;
+    ctx->keys_genomes = n_genomes;
+    ctx->keys_has_hi = has_hi;
+    return SPSP_OK;
+}
+
+int sketch_keys_end_impl(spsp_ctx* ctx, void** d_mn, void** d_lo, void** d_hi, uint64_t* sk_off) {
+    if (!ctx->keys_pending) { set_error("no key extraction is pending on this context"); return SPSP_ERR_ARG; }
+    ctx->keys_pending = false;
+    SPSP_HIP(hipEventSynchronize(ctx->keys_done));
+    const uint32_t n_genomes = ctx->keys_genomes;
+    const uint32_t* h_out = ctx->h_keys + (n_genomes + 1);
+    if (h_out[n_genomes + 1]) {
+        set_error("a genome has %u selected k-mer occurrences, more than the device's per-genome sort holds (%u): sketch it through a file",
+                  h_out[n_genomes + 2], ctx->keys_has_hi ? kKeyCapHi : kKeyCapLo);
+        return SPSP_ERR_OVERFLOW;
+    }
+    for (uint32_t g = 0; g <= n_genomes; ++g) sk_off[g] = h_out[g];
+    *d_mn = ctx->c_min.p; *d_lo = ctx->c_lo.p; *d_hi = ctx->keys_has_hi ? ctx->c_hi.p : nullptr;
+    return SPSP_OK;
+}
+
+}  // namespace spsp
+
+using namespace spsp;
+
+extern "C" {
+
+int spsp_sketch_keys_device_begin(spsp_ctx* ctx, const spsp_params* p, const void* d_bases, const void* d_rec_off, const void* d_superkmers,
+                                  uint64_t n_superkmers, const uint32_t* h_first_rec, uint32_t n_genomes) {
+    if (!ctx || !p || !h_first_rec || (n_superkmers && (!d_bases || !d_rec_off || !d_superkmers))) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    SPSP_HIP(hipSetDevice(ctx->device));
+    return sketch_keys_begin_impl(ctx, p, (const uint8_t*)d_bases, (p->flags & SPSP_SCAN_PACKED_INPUT) != 0, (const uint64_t*)d_rec_off,
+                                  (const spsp_superkmer*)d_superkmers, n_superkmers, h_first_rec, n_genomes);
+}
+
+int spsp_sketch_keys_device_end(spsp_ctx* ctx, void** d_minimizer, void** d_kmer_lo, void** d_kmer_hi, uint64_t* sk_off) {
+    if (!ctx || !d_minimizer || !d_kmer_lo || !d_kmer_hi || !sk_off) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    SPSP_HIP(hipSetDevice(ctx->device));
+    return sketch_keys_end_impl(ctx, d_minimizer, d_kmer_lo, d_kmer_hi, sk_off);
+}
+
+int spsp_sketch_keys_device(spsp_ctx* ctx, const spsp_params* p, const void* d_bases, const void* d_rec_off, const void* d_superkmers,
+                            uint64_t n_superkmers, const uint32_t* h_first_rec, uint32_t n_genomes, void** d_minimizer, void** d_kmer_lo,
+                            void** d_kmer_hi, uint64_t* sk_off) {
+    const int rc = spsp_sketch_keys_device_begin(ctx, p, d_bases, d_rec_off, d_superkmers, n_superkmers, h_first_rec, n_genomes);
+    if (rc) return rc;
+    return spsp_sketch_keys_device_end(ctx, d_minimizer, d_kmer_lo, d_kmer_hi, sk_off);
+}
+
+}  // extern "C"

@@ -1014,3 +1014,64 @@ def test_sketch_files_pipeline_equals_oracle(tmp_path):
     res, _, _ = sp.sketch_files([str(tmp_path / "dup.fa"), ins[0]], outs, k, m, s, abundance=2, threads=2)
     assert all(r[0] == 0 for r in res)
     assert sp.read_file(outs[0]) == orc.sketch_fasta(dup, k, m, s, 2)[0] and sp.read_file(outs[1]) == orc.sketch_fasta(texts[0], k, m, s, 2)[0]
+
+
+@pytest.mark.parametrize("k,m,s,ab", [(31, 11, 20.0, 1), (31, 11, 1000.0, 1), (63, 15, 10.0, 1), (21, 11, 3.0, 2), (33, 13, 4.0, 3)])
+def test_sketch_keys_on_device_equal_the_file_path(ctx, k, m, s, ab):
+    """spsp_sketch_keys_device: from ONE scan over the records of several genomes to the comparator's keys, without
+    sketch files -- equal, genome by genome, to what the ORACLE's comparator enumerates (orc_sketch_keys) from the sketch
+    the oracle writes for that genome (handle_superkmer's uint8 counts and the -a rule included): random and mutated
+    genomes, a genome followed by its reverse complement (both orientations of every k-mer), a unit repeated 257 and 256
+    times (the count wraps), a record too short for a k-mer; ASCII and 2-bit input; a genome too large for the
+    per-genome sort is refused."""
+    import torch
+    rng = np.random.default_rng(1000 + k)
+    L = 20_000 if k > 32 else (60_000 if s < 100 else 900_000)
+    a = synth.random_genome(rng, L)
+    comp = {65: 84, 67: 71, 71: 67, 84: 65}
+    rc = np.array([comp[c] for c in a[::-1].tolist()], dtype=np.uint8)
+    unit = synth.random_genome(rng, 3 * k)
+    genomes = [[a[: L // 2], a[L // 2:]], [synth.mutate(rng, a, 0.02)], [a[: L // 3], rc[: 2 * L // 3]],
+               [np.tile(unit, 257), np.tile(unit[::-1].copy(), 256), synth.random_genome(rng, 5000)], [synth.random_genome(rng, k - 1)],
+               [synth.random_genome(rng, L // 2)]]
+    recs, first_rec, texts = [], [0], []
+    for i, g in enumerate(genomes):
+        recs += g
+        first_rec.append(len(recs))
+        texts.append(b"".join(synth.to_fasta(r, "g%d_%d" % (i, j)) for j, r in enumerate(g)))
+    bases, off = synth.concat_records(recs)
+    d_b = torch.from_numpy(np.concatenate([bases, np.zeros(64, np.uint8)])).cuda()
+    d_o = torch.from_numpy(off.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    want = [orc.sketch_keys(orc.sketch_fasta(t, k, m, s, ab)[0]) for t in texts]
+    assert sum(len(w[2]) for w in want) > 500
+    for packed in (False, True):
+        p = sp.make_params(k, m, s, abundance=ab, flags=sp.SPSP_SCAN_PACKED_INPUT if packed else 0)
+        src = ctx.pack_bases_device(d_b.data_ptr(), len(bases)) if packed else d_b.data_ptr()
+        d_sk, n_sk = ctx.scan_device(p, src, len(bases), d_o.data_ptr(), len(recs))
+        d_mn, d_lo, d_hi, sk_off = ctx.sketch_keys_device(p, src, d_o.data_ptr(), d_sk, n_sk, first_rec)
+        total = int(sk_off[-1])
+        mn, lo = ctx.to_host(d_mn, total, np.uint32), ctx.to_host(d_lo, total, np.uint64)
+        hi = ctx.to_host(d_hi, total, np.uint64) if k > 32 else np.zeros(total, np.uint64)
+        for g, (_, _, w_mn, w_lo, w_hi) in enumerate(want):
+            x, y = int(sk_off[g]), int(sk_off[g + 1])
+            assert y - x == len(w_mn), (packed, g, y - x, len(w_mn))
+            assert (mn[x:y] == w_mn).all() and (lo[x:y] == w_lo).all() and (hi[x:y] == w_hi).all(), (packed, g)
+    # the keys feed the comparison as they are: pair counts equal the oracle's comparison of the sketch files
+    d_inter = torch.zeros((len(genomes), len(genomes)), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    ctx.compare_device(k, d_mn, d_lo, d_hi, sk_off, len(genomes), 0, 1, d_inter.data_ptr())
+    torch.cuda.synchronize()
+    w_inter, w_card, _, _ = orc.compare([orc.sketch_fasta(t, k, m, s, ab)[0] for t in texts])
+    assert (np.triu(d_inter.cpu().numpy(), 1) == np.triu(w_inter.astype(np.int64), 1)).all()
+    if k == 31 and s == 20.0:
+        big = synth.random_genome(rng, 400_000)
+        bb, bo = synth.concat_records([big])
+        d_b2 = torch.from_numpy(np.concatenate([bb, np.zeros(64, np.uint8)])).cuda()
+        d_o2 = torch.from_numpy(bo.view(np.int64)).cuda()
+        torch.cuda.synchronize()
+        p = sp.make_params(k, m, s)
+        d_sk, n_sk = ctx.scan_device(p, d_b2.data_ptr(), len(bb), d_o2.data_ptr(), 1)
+        with pytest.raises(sp.SpspError) as e:
+            ctx.sketch_keys_device(p, d_b2.data_ptr(), d_o2.data_ptr(), d_sk, n_sk, [0, 1])
+        assert e.value.code == sp.ERR_OVERFLOW
