@@ -1026,13 +1026,13 @@ def test_sketch_keys_on_device_equal_the_file_path(ctx, k, m, s, ab):
     per-genome sort is refused."""
     import torch
     rng = np.random.default_rng(1000 + k)
-    L = 20_000 if k > 32 else (60_000 if s < 100 else 900_000)
+    L = min(900_000, int((1500 if k > 32 else 3000) * s))     # a genome's selected k-mer occurrences stay inside the per-genome sort
     a = synth.random_genome(rng, L)
     comp = {65: 84, 67: 71, 71: 67, 84: 65}
     rc = np.array([comp[c] for c in a[::-1].tolist()], dtype=np.uint8)
-    unit = synth.random_genome(rng, 3 * k)
+    unit = synth.random_genome(rng, k + 2)
     genomes = [[a[: L // 2], a[L // 2:]], [synth.mutate(rng, a, 0.02)], [a[: L // 2], rc],                 # (every k-mer of the first half twice, once per strand)
-               [np.tile(unit, 257), np.tile(unit[::-1].copy(), 256), synth.random_genome(rng, 5000)], [synth.random_genome(rng, k - 1)],
+               [np.tile(unit, 257), synth.random_genome(rng, 500)], [np.tile(unit[::-1].copy(), 256)], [synth.random_genome(rng, k - 1)],
                [synth.random_genome(rng, L // 2)], [a[: L // 4]] * ab + [a[L // 4: L // 3]] * max(1, ab - 1)]     # seen ab and ab - 1 times
     recs, first_rec, texts = [], [0], []
     for i, g in enumerate(genomes):
