@@ -279,6 +279,15 @@ def main():
             % (time.time() - t_setup, args.genomes, args.length, len(recs), kmers_per_step, int(sk_off[-1]), pairs_per_step))
 
     scan_args = [(p, t.data_ptr(), t.numel(), d_off.data_ptr(), len(recs)) for t in d_batches]
+    # genome i = records [first_rec[i], first_rec[i + 1]) of the batch (1 + i % 3 records each, as laid out above)
+    first_rec = np.zeros(args.genomes + 1, dtype=np.uint32)
+    first_rec[1:] = np.cumsum([1 + i % 3 for i in range(args.genomes)])
+    # The step closes on itself (single GPU): the keys the comparison of step t works on are made ON THE DEVICE from the
+    # super-k-mer stream of an earlier step's scan (spsp_sketch_keys_device: what the comparator would read from the sketch
+    # files of those genomes) -- no setup-time sketches inside the timed region.  BENCH_DEVICE_KEYS=0: the round-2 step
+    # (keys of the setup's sketches, the same every step).
+    device_keys = (exchange_kind == "none" and sim_world == 1 and pipelined and os.environ.get("BENCH_DEVICE_KEYS", "1") != "0"
+                   and os.environ.get("BENCH_DEBUG_SKIP_COMPARE") != "1")
     step_no = [0]                                             # steps queued so far: step i scans batch i % n_batches
 
     # analysis only (the line it prints is not a valid measurement): the step without its comparison, to see what the
@@ -300,13 +309,23 @@ def main():
             sl.scan.wait_dense(prev.scan)                 # "streams": dense passes never overlap each other
         sl.batch = step_no[0] % n_batches
         step_no[0] += 1
+        if device_keys and getattr(sl, "keys_queued", False):
+            sl.scan.scan_output_wait(sl.cmp)              # this scan's last stage rewrites the buffer the queued key extraction reads
         sl.scan.scan_device_begin(*scan_args[sl.batch])   # "tail" / "single": dense passes in order on the one scan stream
         if exchange_kind == "none":
             if schedule != "partition":
                 sl.cmp.wait_dense(sl.scan)                # the comparison starts behind this step's dense pass
             if not skip_compare:
-                sl.cmp.compare_device_begin(K, d_all_min.data_ptr(), d_all_lo.data_ptr(), None, sk_off, n_total, rank, max(world, sim_world),
-                                            sl.d_inter.data_ptr())                                         # stream B
+                if device_keys and getattr(sl, "keys_queued", False):
+                    # the keys of this slot's previous scan (queued when that scan was collected, just above): stream B
+                    d_mn, d_lo, _, koff = sl.cmp.sketch_keys_device_end()
+                    sl.keys_queued = False
+                    sl.keys_batch = sl.keys_batch_queued
+                    last["keys_total"] = int(koff[-1])
+                    sl.cmp.compare_device_begin(K, d_mn, d_lo, None, koff, n_total, 0, 1, sl.d_inter.data_ptr())
+                else:
+                    sl.cmp.compare_device_begin(K, d_all_min.data_ptr(), d_all_lo.data_ptr(), None, sk_off, n_total, rank, max(world, sim_world),
+                                                sl.d_inter.data_ptr())                                     # stream B
             return
         with on_b(sl):
             if exchange_kind == "slots":
@@ -330,6 +349,13 @@ def main():
 
     def collect_step(sl):
         d_out, n_out = sl.scan.scan_device_end()
+        if device_keys:
+            sl.cmp.compare_end()                          # (the comparison queued with this step: its key arrays are free again)
+            sl.cmp.sketch_keys_device_begin(p, scan_args[sl.batch][1], d_off.data_ptr(), d_out, n_out, first_rec)   # stream B, no wait
+            sl.keys_queued, sl.keys_batch_queued = True, sl.batch
+            last["n_out"], last["slot"] = n_out, sl
+            last["n_out_batch"][sl.batch] = n_out
+            return
         if exchange_kind == "slots":
             with on_b(sl):
                 sl.exchange.end_collect(sl.d_inter)       # partial pair matrix done -> RCCL reduction
@@ -524,7 +550,8 @@ def main():
                                          "NOT a measurement" % sim_world} if sim_world > 1 else {}),
                        **({"rehearsal": "BENCH_BACKEND=%s, all ranks on one device: NOT a measurement" % backend}
                           if (use_dist and (backend != "nccl" or os.environ.get("BENCH_SHARE_GPU") == "1")) else {}),
-                       "step": (("scan(batch t) || all-vs-all(sketches of batch t-1): the chip is partitioned by CU-masked streams -- "
+                       "step": ((("scan(batch t) || keys(batch t-2, on the device) -> all-vs-all(those keys)" if device_keys else "scan(batch t) || all-vs-all(sketches of batch t-1)") +
+                                 ": the chip is partitioned by CU-masked streams -- "
                                  "dense passes back to back on %d CUs (two workgroups each), the scans' sparse stages on one stream and "
                                  "the comparisons on another that share the other %d CUs; the host queues step t+1 before collecting "
                                  "step t [schedule partition]" % (dense_cus, small_cus)) if pipelined and schedule == "partition"
@@ -613,8 +640,34 @@ def main():
         except Exception as e:  # noqa: BLE001
             out["roofline"]["peak_measured"] = {"error": repr(e)}
         out["roofline"].update(sq_counters("k_dense_pair", dense_avg_ms, dense_cus if (schedule == "partition" and pipelined) else 0))
+        d_parity = d_inter
+        if device_keys:
+            # untimed: the step's own path once more over batch 0 -- scan -> keys on the device -> comparison -- on the whole-device
+            # context; its keys must equal those parsed from the setup's sketch payloads (what the comparator reads from files)
+            # and its pair matrix goes to the oracle check below
+            try:
+                torch.cuda.synchronize()
+                d_o, n_o = ctx_full.scan_device(*scan_args[0])
+                kmn, klo, _, koff = ctx_full.sketch_keys_device(p, scan_args[0][1], d_off.data_ptr(), d_o, n_o, first_rec)
+                same = bool((koff == sk_off).all())
+                if same:
+                    tot = int(koff[-1])
+                    same = bool(torch.equal(device_bytes_as_tensor(kmn, 4 * tot, dev), d_all_min.view(torch.uint8)) and
+                                torch.equal(device_bytes_as_tensor(klo, 8 * tot, dev), d_all_lo.view(torch.uint8)))
+                d_parity = torch.zeros_like(d_inter)
+                torch.cuda.synchronize()
+                ctx_full.compare_device(K, kmn, klo, None, koff, n_total, 0, 1, d_parity.data_ptr())
+                torch.cuda.synchronize()
+                out["device_keys"] = {"in_timed_step": True, "keys_per_step": last.get("keys_total"),
+                                      "equal_to_keys_parsed_from_sketch_payloads": same,
+                                      "what": "spsp_sketch_keys_device: scan output -> sorted distinct (minimizer, canonical k-mer) keys per genome "
+                                              "(handle_superkmer's uint8 counts, the emission / reader round trip and canonize composed, "
+                                              "SubSampler.cpp:243-302,458-620, Comparator.cpp:186-260); the comparison of a step works on the "
+                                              "keys of the scan this slot collected two steps earlier"}
+            except Exception as e:  # noqa: BLE001
+                out["device_keys"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(recs, payloads, p, int(n_out), d_inter)
+            out["cpu_baseline"] = cpu_baseline(recs, payloads, p, int(n_out), d_parity)
         if world == 1 and not args.no_extras:
             try:
                 out["compare"] = compare_config3(ctx_full, dev, args.no_cpu_baseline)

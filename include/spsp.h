@@ -329,6 +329,12 @@ int spsp_sketch_keys_device_begin(spsp_ctx* ctx, const spsp_params* p, const voi
                                   uint64_t n_superkmers, const uint32_t* h_first_rec, uint32_t n_genomes);
 int spsp_sketch_keys_device_end(spsp_ctx* ctx, void** d_minimizer, void** d_kmer_lo, void** d_kmer_hi, uint64_t* sk_off);
 
+/* A scan's output buffer belongs to its context and is rewritten by that context's next scan.  A caller that pipelines --
+ * queues scan t + 1 on `scanner` while `reader`'s key extraction of scan t's output (spsp_sketch_keys_device_begin) may
+ * still be running on another stream -- calls this in between: the stage of the next scan that writes the output (its
+ * last) then starts only behind the reader's latest key extraction; the dense pass is not held up. */
+int spsp_scan_output_wait(spsp_ctx* scanner, spsp_ctx* reader);
+
 /* The same decode for MANY sketches at once on the GPU ("next" row N2): payloads[i] = gunzipped sketch i.  The
  * sorted distinct keys of all sketches end up back to back in device arrays OWNED BY THE CONTEXT (valid until the
  * next decode / spsp_compare call on it; *d_kmer_hi = NULL when k <= 32), ready for spsp_compare_device; sk_off gets

@@ -345,6 +345,17 @@ int spsp_wait_stream(spsp_ctx* waiter, spsp_ctx* other) {
     return SPSP_OK;
 }
 
+int spsp_scan_output_wait(spsp_ctx* scanner, spsp_ctx* reader) {
+    if (!scanner || !reader) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    if (scanner->device != reader->device) { set_error("both contexts must be on the same device"); return SPSP_ERR_ARG; }
+    if (!reader->keys_done) return SPSP_OK;                 // nothing of that kind was ever queued on `reader`
+    SPSP_HIP(hipSetDevice(scanner->device));
+    // the output buffer is written by the scan's LAST stage (the write pass of the cluster replay): only the stream that
+    // runs the sparse stages has to wait, the dense pass in front of them does not
+    SPSP_HIP(hipStreamWaitEvent(scanner->sparse_stream(), reader->keys_done, 0));
+    return SPSP_OK;
+}
+
 int spsp_scan_hits_device(spsp_ctx* ctx, const spsp_params* p, const void* d_bases, uint64_t n_bases,
                           uint64_t* n_hits) {
     if (!ctx || !n_hits) { set_error("NULL argument"); return SPSP_ERR_ARG; }
