@@ -288,6 +288,9 @@ def main():
     # (keys of the setup's sketches, the same every step).
     device_keys = (exchange_kind == "none" and sim_world == 1 and pipelined and os.environ.get("BENCH_DEVICE_KEYS", "1") != "0"
                    and os.environ.get("BENCH_DEBUG_SKIP_COMPARE") != "1")
+    if device_keys:
+        for sl in slots:
+            sl.cmp.compare_keys_unordered(True)           # the step's keys come out of an LDS table per genome: distinct, not sorted
     step_no = [0]                                             # steps queued so far: step i scans batch i % n_batches
 
     # analysis only (the line it prints is not a valid measurement): the step without its comparison, to see what the
@@ -351,7 +354,7 @@ def main():
         d_out, n_out = sl.scan.scan_device_end()
         if device_keys:
             sl.cmp.compare_end()                          # (the comparison queued with this step: its key arrays are free again)
-            sl.cmp.sketch_keys_device_begin(p, scan_args[sl.batch][1], d_off.data_ptr(), d_out, n_out, first_rec)   # stream B, no wait
+            sl.cmp.sketch_keys_device_begin(p, scan_args[sl.batch][1], d_off.data_ptr(), d_out, n_out, first_rec, unordered=True)   # stream B, no wait
             sl.keys_queued, sl.keys_batch_queued = True, sl.batch
             last["n_out"], last["slot"] = n_out, sl
             last["n_out_batch"][sl.batch] = n_out
@@ -648,6 +651,7 @@ def main():
             try:
                 torch.cuda.synchronize()
                 d_o, n_o = ctx_full.scan_device(*scan_args[0])
+                # (sorted form here: the arrays can be held against the parsed sketches element by element)
                 kmn, klo, _, koff = ctx_full.sketch_keys_device(p, scan_args[0][1], d_off.data_ptr(), d_o, n_o, first_rec)
                 same = bool((koff == sk_off).all())
                 if same:

@@ -321,12 +321,20 @@ int spsp_sketch_parse_host(const uint8_t* payload, uint64_t len, uint32_t* k, ui
  * offsets: ready for spsp_compare_device.  A genome with more than 8192 selected k-mer occurrences (4096 with k > 32)
  * does not fit the per-genome sort: SPSP_ERR_OVERFLOW (sketch such genomes through files).  _begin queues the work on
  * the context's stream and returns; _end waits for it (an event behind its last kernel).  One job may be pending per
- * context. */
+ * context.
+ * flags: SPSP_KEYS_UNORDERED -- every genome's keys DISTINCT but in no particular order: an LDS table per genome instead of
+ * the per-genome sort (a tenth of its time; at most 6144 occurrences per genome, 4096 with k > 32).  Such keys are for
+ * comparisons on a context that has been told so (spsp_compare_keys_unordered): the comparison itself only needs a
+ * sketch to hold a key once; the order is what lets it CHECK that on input it did not make. */
+#define SPSP_KEYS_UNORDERED 1u
 int spsp_sketch_keys_device(spsp_ctx* ctx, const spsp_params* p, const void* d_bases, const void* d_rec_off, const void* d_superkmers,
-                            uint64_t n_superkmers, const uint32_t* h_first_rec, uint32_t n_genomes, void** d_minimizer, void** d_kmer_lo,
-                            void** d_kmer_hi, uint64_t* sk_off);
+                            uint64_t n_superkmers, const uint32_t* h_first_rec, uint32_t n_genomes, uint32_t flags, void** d_minimizer,
+                            void** d_kmer_lo, void** d_kmer_hi, uint64_t* sk_off);
 int spsp_sketch_keys_device_begin(spsp_ctx* ctx, const spsp_params* p, const void* d_bases, const void* d_rec_off, const void* d_superkmers,
-                                  uint64_t n_superkmers, const uint32_t* h_first_rec, uint32_t n_genomes);
+                                  uint64_t n_superkmers, const uint32_t* h_first_rec, uint32_t n_genomes, uint32_t flags);
+/* on != 0: the device-form comparisons queued on this context from now on accept sketches whose keys are distinct but
+ * unsorted (the caller vouches for "distinct": duplicates inside a sketch would be counted twice) */
+int spsp_compare_keys_unordered(spsp_ctx* ctx, int on);
 int spsp_sketch_keys_device_end(spsp_ctx* ctx, void** d_minimizer, void** d_kmer_lo, void** d_kmer_hi, uint64_t* sk_off);
 
 /* A scan's output buffer belongs to its context and is rewritten by that context's next scan.  A caller that pipelines --

@@ -34,6 +34,7 @@ class SpspError(RuntimeError):
 
 
 ERR_OVERFLOW = -7
+KEYS_UNORDERED = 1
 TIME_DENSE, TIME_SCAN, TIME_ACCUMULATE, TIME_COMPARE, TIME_PARTS, TIME_ALL = 1, 2, 4, 8, 16, 31
 
 
@@ -81,7 +82,7 @@ ABI_SYMBOLS = [
     "spsp_create", "spsp_destroy", "spsp_last_error", "spsp_version", "spsp_free", "spsp_copy_to_host",
     "spsp_stream_create_cus", "spsp_stream_destroy", "spsp_set_cu_count", "spsp_pack_bases_device",
     "spsp_timing_enable", "spsp_timing_sample", "spsp_timing_read", "spsp_threshold_host", "spsp_scan", "spsp_scan_device", "spsp_scan_device_begin", "spsp_scan_device_end", "spsp_scan_tail_stream", "spsp_wait_dense", "spsp_wait_stream", "spsp_scan_hits_device", "spsp_count_superkmers_device", "spsp_compare",
-    "spsp_compare_device", "spsp_slot_bytes", "spsp_partition_keys_device", "spsp_compare_slots_device", "spsp_compare_device_begin", "spsp_compare_slots_device_begin", "spsp_compare_end", "spsp_fasta_clean_host", "spsp_fasta_clean_device", "spsp_fasta_clean_packed_device", "spsp_sketch_text", "spsp_sketch_build_host", "spsp_sketch_parse_host", "spsp_sketch_decode_device", "spsp_sketch_keys_device", "spsp_sketch_keys_device_begin", "spsp_sketch_keys_device_end", "spsp_scan_output_wait", "spsp_sketch_chain_host",
+    "spsp_compare_device", "spsp_slot_bytes", "spsp_partition_keys_device", "spsp_compare_slots_device", "spsp_compare_device_begin", "spsp_compare_slots_device_begin", "spsp_compare_end", "spsp_fasta_clean_host", "spsp_fasta_clean_device", "spsp_fasta_clean_packed_device", "spsp_sketch_text", "spsp_sketch_build_host", "spsp_sketch_parse_host", "spsp_sketch_decode_device", "spsp_sketch_keys_device", "spsp_sketch_keys_device_begin", "spsp_sketch_keys_device_end", "spsp_scan_output_wait", "spsp_compare_keys_unordered", "spsp_sketch_chain_host",
     "spsp_csv_host", "spsp_sort_csv_host", "spsp_read_file_host", "spsp_write_gz_host", "spsp_sketch_file", "spsp_compare_files", "spsp_compare_files_chatty", "spsp_stage_times_read", "spsp_measure_hbm_device", "spsp_sketch_files", "spsp_sketch_files_release",
 ]
 
@@ -163,9 +164,10 @@ def lib():
     L.spsp_compare_files.restype = i32
     L.spsp_compare_files.argtypes = [vp, P(cp), u32, u32, i32, dbl, cp]
     L.spsp_sketch_keys_device.restype = i32
-    L.spsp_sketch_keys_device.argtypes = [vp, P(Params), vp, vp, vp, u64, vp, u32, P(vp), P(vp), P(vp), vp]
+    L.spsp_sketch_keys_device.argtypes = [vp, P(Params), vp, vp, vp, u64, vp, u32, u32, P(vp), P(vp), P(vp), vp]
     L.spsp_sketch_keys_device_begin.restype = i32
-    L.spsp_sketch_keys_device_begin.argtypes = [vp, P(Params), vp, vp, vp, u64, vp, u32]
+    L.spsp_sketch_keys_device_begin.argtypes = [vp, P(Params), vp, vp, vp, u64, vp, u32, u32]
+    L.spsp_compare_keys_unordered.restype = i32; L.spsp_compare_keys_unordered.argtypes = [vp, i32]
     L.spsp_sketch_keys_device_end.restype = i32
     L.spsp_sketch_keys_device_end.argtypes = [vp, P(vp), P(vp), P(vp), vp]
     L.spsp_scan_output_wait.restype = i32; L.spsp_scan_output_wait.argtypes = [vp, vp]
@@ -516,10 +518,15 @@ class Context:
         """this context's next scan writes its output only behind `reader`'s latest sketch_keys_device_begin"""
         _check(lib().spsp_scan_output_wait(self._h, reader._h))
 
-    def sketch_keys_device_begin(self, params, d_bases, d_rec_off, d_sk, n_sk, first_rec):
+    def compare_keys_unordered(self, on=True):
+        """device-form comparisons of this context accept sketches whose keys are distinct but unsorted"""
+        _check(lib().spsp_compare_keys_unordered(self._h, 1 if on else 0))
+
+    def sketch_keys_device_begin(self, params, d_bases, d_rec_off, d_sk, n_sk, first_rec, unordered=False):
         """queue: scan output -> comparator keys of the genomes whose record ranges `first_rec` (n_genomes + 1) gives"""
         fr = np.ascontiguousarray(first_rec, dtype=np.uint32)
-        _check(lib().spsp_sketch_keys_device_begin(self._h, C.byref(params), d_bases, d_rec_off, d_sk, n_sk, fr.ctypes.data, len(fr) - 1))
+        _check(lib().spsp_sketch_keys_device_begin(self._h, C.byref(params), d_bases, d_rec_off, d_sk, n_sk, fr.ctypes.data, len(fr) - 1,
+                                                   KEYS_UNORDERED if unordered else 0))
         self._keys_n = len(fr) - 1
 
     def sketch_keys_device_end(self):
@@ -529,8 +536,8 @@ class Context:
         _check(lib().spsp_sketch_keys_device_end(self._h, C.byref(d_mn), C.byref(d_lo), C.byref(d_hi), sk_off.ctypes.data))
         return d_mn.value, d_lo.value, d_hi.value, sk_off
 
-    def sketch_keys_device(self, params, d_bases, d_rec_off, d_sk, n_sk, first_rec):
-        self.sketch_keys_device_begin(params, d_bases, d_rec_off, d_sk, n_sk, first_rec)
+    def sketch_keys_device(self, params, d_bases, d_rec_off, d_sk, n_sk, first_rec, unordered=False):
+        self.sketch_keys_device_begin(params, d_bases, d_rec_off, d_sk, n_sk, first_rec, unordered)
         return self.sketch_keys_device_end()
 
     def stage_times(self, reset=True):

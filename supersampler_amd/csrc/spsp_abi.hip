@@ -345,6 +345,12 @@ int spsp_wait_stream(spsp_ctx* waiter, spsp_ctx* other) {
     return SPSP_OK;
 }
 
+int spsp_compare_keys_unordered(spsp_ctx* ctx, int on) {
+    if (!ctx) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    ctx->keys_unordered = on != 0;
+    return SPSP_OK;
+}
+
 int spsp_scan_output_wait(spsp_ctx* scanner, spsp_ctx* reader) {
     if (!scanner || !reader) { set_error("NULL argument"); return SPSP_ERR_ARG; }
     if (scanner->device != reader->device) { set_error("both contexts must be on the same device"); return SPSP_ERR_ARG; }

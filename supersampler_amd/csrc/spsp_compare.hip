@@ -981,7 +981,7 @@ static int job_wait_flags(spsp_ctx* ctx, uint32_t* h_flags) {
     if (h_flags[5]) { set_error("dictionary table overflow (internal sizing error)"); return SPSP_ERR_HIP; }
     if (h_flags[3]) { set_error("malformed exchange slot (header, sketch count or key count does not match)"); return SPSP_ERR_FORMAT; }
     if (h_flags[4]) { set_error("an exchange slot overflowed its capacity: partition again with a larger slot_cap"); return SPSP_ERR_OVERFLOW; }
-    if (h_flags[0]) { set_error("sketch keys must be strictly increasing by (minimizer, kmer_hi, kmer_lo)"); return SPSP_ERR_ARG; }
+    if (h_flags[0] && !ctx->keys_unordered) { set_error("sketch keys must be strictly increasing by (minimizer, kmer_hi, kmer_lo)"); return SPSP_ERR_ARG; }
     return SPSP_OK;
 }
 

@@ -1058,11 +1058,32 @@ def test_sketch_keys_on_device_equal_the_file_path(ctx, k, m, s, ab):
             assert y - x == len(w_mn), (packed, g, y - x, len(w_mn))
             assert (mn[x:y] == w_mn).all() and (lo[x:y] == w_lo).all() and (hi[x:y] == w_hi).all(), (packed, g)
     # the keys feed the comparison as they are: pair counts equal the oracle's comparison of the sketch files
+    w_inter, w_card, _, _ = orc.compare([orc.sketch_fasta(t, k, m, s, ab)[0] for t in texts])
     d_inter = torch.zeros((len(genomes), len(genomes)), dtype=torch.int32, device="cuda")
     torch.cuda.synchronize()
     ctx.compare_device(k, d_mn, d_lo, d_hi, sk_off, len(genomes), 0, 1, d_inter.data_ptr())
     torch.cuda.synchronize()
-    w_inter, w_card, _, _ = orc.compare([orc.sketch_fasta(t, k, m, s, ab)[0] for t in texts])
+    assert (np.triu(d_inter.cpu().numpy(), 1) == np.triu(w_inter.astype(np.int64), 1)).all()
+    # SPSP_KEYS_UNORDERED: the same key SETS from an LDS table per genome instead of a sort; a comparison that has been told
+    # so takes them, one that has not refuses them (its order check is its duplicate check)
+    d_mn, d_lo, d_hi, sk_off2 = ctx.sketch_keys_device(p, src, d_o.data_ptr(), d_sk, n_sk, first_rec, unordered=True)
+    assert (sk_off2 == sk_off).all()
+    total = int(sk_off2[-1])
+    mn, lo = ctx.to_host(d_mn, total, np.uint32), ctx.to_host(d_lo, total, np.uint64)
+    hi = ctx.to_host(d_hi, total, np.uint64) if k > 32 else np.zeros(total, np.uint64)
+    for g, (_, _, w_mn, w_lo, w_hi) in enumerate(want):
+        x, y = int(sk_off2[g]), int(sk_off2[g + 1])
+        assert sorted(zip(mn[x:y].tolist(), hi[x:y].tolist(), lo[x:y].tolist())) == list(zip(w_mn.tolist(), w_hi.tolist(), w_lo.tolist())), g
+    d_inter.zero_()
+    torch.cuda.synchronize()
+    with pytest.raises(sp.SpspError):
+        ctx.compare_device(k, d_mn, d_lo, d_hi, sk_off2, len(genomes), 0, 1, d_inter.data_ptr())
+    ctx.compare_keys_unordered(True)
+    d_inter.zero_()
+    torch.cuda.synchronize()
+    ctx.compare_device(k, d_mn, d_lo, d_hi, sk_off2, len(genomes), 0, 1, d_inter.data_ptr())
+    torch.cuda.synchronize()
+    ctx.compare_keys_unordered(False)
     assert (np.triu(d_inter.cpu().numpy(), 1) == np.triu(w_inter.astype(np.int64), 1)).all()
     if k == 31 and s == 20.0:
         big = synth.random_genome(rng, 400_000)
