@@ -463,7 +463,7 @@ template <bool HAS_HI, int E>
 __global__ __launch_bounds__(kScatThreads, 4) void k_parts_scatter(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n,
                                                                const uint32_t* __restrict__ sub_sk, uint64_t S, uint32_t n_parts,
                                                                uint32_t cap, uint32_t* __restrict__ part_cnt, uint64_t* __restrict__ recs,
-                                                               uint32_t* __restrict__ where, uint32_t* __restrict__ flags) {
+                                                               uint32_t* __restrict__ where, uint32_t* __restrict__ flags, bool check_order) {
     constexpr uint32_t W = HAS_HI ? 3 : 2;
     extern __shared__ uint32_t hist[];                   // [n_parts]
     const uint32_t t = threadIdx.x, lane = t & 63;
@@ -491,8 +491,8 @@ __global__ __launch_bounds__(kScatThreads, 4) void k_parts_scatter(Keys K, const
         uint32_t j = sub_sk[e / kScatSub];
         while (j + 1 < n && sk_off[j + 1] <= e) ++j;      // sketch of entry e (empty sketches are stepped over)
         sk_of[u] = j;
-        if (e > sk_off[j]) {                              // strictly increasing inside a sketch
-            const bool less = pmn != mn[u] ? pmn < mn[u] : (HAS_HI && phi != hi[u]) ? phi < hi[u] : plo < lo[u];
+        if (check_order && e > sk_off[j]) {               // strictly increasing inside a sketch (spsp_compare_keys_unordered: the caller vouches
+            const bool less = pmn != mn[u] ? pmn < mn[u] : (HAS_HI && phi != hi[u]) ? phi < hi[u] : plo < lo[u];   // for distinct keys instead)
             if (!less) atomicOr(&flags[0], 1u);
         }
     }
@@ -1263,7 +1263,7 @@ static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t*
             ctx->attr_scatter_set = true;
         }
 #define SPSP_SCATTER(HI, E) hipLaunchKernelGGL((k_parts_scatter<HI, E>), grid, dim3(kScatThreads), lds, ctx->stream, K, sk, n, sub_sk, S, \
-                                               n_parts, cap, ctx->c_part_cnt.as<uint32_t>(), ctx->c_recs.as<uint64_t>(), where, flags)
+                                               n_parts, cap, ctx->c_part_cnt.as<uint32_t>(), ctx->c_recs.as<uint64_t>(), where, flags, !ctx->keys_unordered)
         if (has_hi) SPSP_SCATTER(true, 4);
         else SPSP_SCATTER(false, 4);
 #undef SPSP_SCATTER

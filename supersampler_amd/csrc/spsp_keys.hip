@@ -165,12 +165,15 @@ __global__ __launch_bounds__(kKeySortThreads) void k_keys_sort(uint32_t* __restr
     if (t == 0) distinct[g] = all;
 }
 
-// The same rule without the sort, for a caller that does not need the keys in order (the comparison's partition form
-// only needs them DISTINCT within a genome: spsp_compare_keys_unordered): one workgroup per genome groups the raw keys in
-// an LDS table -- a slot word is (occurrences << 13 | claiming record + 1), full keys are compared against the claiming
-// record -- per (canonical k-mer, orientation); the claimer of a usable group emits the key unless the other orientation's
-// group is usable too and comes first.  ~10x faster than the bitonic sort (91 barrier-separated passes over 13-byte
-// records), which is what lets the key extraction run inside a 0.1 ms step.
+// The same rule without the sort and without the raw arrays, for a caller that does not need the keys in order (the
+// comparison's partition form only needs them DISTINCT within a genome: spsp_compare_keys_unordered).  ONE kernel per
+// call, one workgroup per genome: it finds its super-k-mers (two binary searches on the record numbers), gives super-k-mer
+// q the table records [q w, (q + 1) w), w = k - m + 1 -- every lane rolls ONE k-mer and its reverse complement from the
+// bases -- groups them in an LDS table per (canonical k-mer, orientation) -- a slot word is (occurrences << 13 | claiming
+// record + 1), full keys are compared against the claiming record -- and the claimer of a usable group emits the key
+// unless the other orientation's group is usable too and comes first.  A tenth of the sorted form's time (its bitonic
+// sort is 91 barrier-separated passes over 13-byte records), which is what lets the key extraction run inside a 0.1 ms
+// step.
 constexpr uint32_t kDedupCapLo = 6144, kDedupCapHi = 4096;
 __device__ __forceinline__ uint64_t keys_mix(uint64_t x) {
     x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ULL;
@@ -178,18 +181,32 @@ __device__ __forceinline__ uint64_t keys_mix(uint64_t x) {
     return x ^ (x >> 31);
 }
 template <bool HAS_HI>
-__global__ __launch_bounds__(kKeySortThreads) void k_keys_dedupe(uint32_t* __restrict__ r_mn, uint64_t* __restrict__ r_lo, uint64_t* __restrict__ r_hi,
-                                                                const uint8_t* __restrict__ r_or, const uint32_t* __restrict__ raw_off,
-                                                                uint32_t abundance, uint32_t* __restrict__ distinct, uint32_t* __restrict__ flags) {
+__global__ __launch_bounds__(kKeySortThreads) void k_keys_fused(const uint8_t* __restrict__ bases, bool packed, const uint64_t* __restrict__ rec_off,
+                                                               const spsp_superkmer* __restrict__ sk, uint32_t n_sk, const uint32_t* __restrict__ first_rec,
+                                                               uint32_t k, uint32_t w, uint32_t abundance, uint32_t* __restrict__ r_mn,
+                                                               uint64_t* __restrict__ r_lo, uint64_t* __restrict__ r_hi, uint32_t* __restrict__ raw_off,
+                                                               uint32_t* __restrict__ distinct, uint32_t* __restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_d[];
     constexpr uint32_t CAP = HAS_HI ? kDedupCapHi : kDedupCapLo, SLOTS = 2 * CAP, PER = CAP / kKeySortThreads;
+    constexpr uint32_t kNone = 0xffffffffu;                        // record without a k-mer (a super-k-mer shorter than 2k - m)
     uint64_t* k_lo = reinterpret_cast<uint64_t*>(lds_d);
     uint64_t* k_hi = k_lo + CAP;                                   // (HAS_HI only)
     uint32_t* k_mn = reinterpret_cast<uint32_t*>(k_hi + (HAS_HI ? CAP : 0));   // minimizer | orientation << 31
     uint32_t* slot = k_mn + CAP;
     __shared__ uint32_t wave_sum[kKeySortThreads / 64];
     const uint32_t g = blockIdx.x, t = threadIdx.x, lane = t & 63, wid = t >> 6;
-    const uint32_t r0 = raw_off[g], n = raw_off[g + 1] - r0;
+    // this genome's super-k-mers: [q0, q1) (the stream is in record order)
+    uint32_t q0, q1;
+    {
+        const uint32_t want0 = first_rec[g], want1 = first_rec[g + 1];
+        uint32_t lo = 0, hi = n_sk;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (sk[mid].rec < want0) lo = mid + 1; else hi = mid; }
+        q0 = lo; hi = n_sk;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (sk[mid].rec < want1) lo = mid + 1; else hi = mid; }
+        q1 = lo;
+    }
+    const uint32_t r0 = q0 * w, n = (q1 - q0) * w;                 // table records (some empty) = room in the staging arrays
+    if (t == 0) raw_off[g] = r0;
     if (n == 0) { if (t == 0) distinct[g] = 0; return; }
     if (n > CAP) { if (t == 0) { distinct[g] = 0; atomicOr(&flags[0], 1u); atomicMax(&flags[1], n); } return; }
     for (uint32_t x = t; x < SLOTS; x += kKeySortThreads) slot[x] = 0;
@@ -199,24 +216,40 @@ __global__ __launch_bounds__(kKeySortThreads) void k_keys_dedupe(uint32_t* __res
         if (HAS_HI) h = keys_mix(h ^ hi);
         return (uint32_t)(((h & 0xffffffffull) * SLOTS) >> 32);
     };
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(bases);
+    const u128d mask = ((u128d)1 << (2 * k)) - 1;                  // k <= 63
     uint32_t hs[PER];
 #pragma unroll
-    for (uint32_t u = 0; u < PER; ++u) {                           // record r = u * threads + t: consecutive lanes, consecutive records
+    for (uint32_t u = 0; u < PER; ++u) {                           // record r = u * threads + t = k-mer r % w of super-k-mer q0 + r / w
         const uint32_t r = u * kKeySortThreads + t;
         hs[u] = 0;
-        if (r < n) {
-            const uint32_t mo = r_mn[r0 + r] | ((uint32_t)r_or[r0 + r] << 31);
-            const uint64_t lo = r_lo[r0 + r], hi = HAS_HI ? r_hi[r0 + r] : 0ull;
-            k_mn[r] = mo; k_lo[r] = lo;
-            if (HAS_HI) k_hi[r] = hi;
-            hs[u] = home(mo, lo, hi);
+        if (r >= n) continue;
+        const spsp_superkmer e = sk[q0 + r / w];
+        const uint32_t j = r % w;
+        if (e.len < k || j > e.len - k) { k_mn[r] = kNone; continue; }
+        const uint64_t src = rec_off[e.rec] + e.start + j;
+        u128d fwd = 0, rc = 0;
+        for (uint32_t b = 0; b < k; ++b) {
+            const uint64_t q = src + b;
+            const uint32_t c = packed ? (words[q >> 4] >> (30u - 2u * (uint32_t)(q & 15u))) & 3u : ((uint32_t)bases[q] >> 1) & 3u;
+            fwd = (fwd << 2) | c;
+            rc = (rc >> 2) | ((u128d)(c ^ 2u) << (2 * (k - 1)));
         }
+        fwd &= mask;
+        // handle_superkmer stores the k-mer as it reads in the super-k-mer's orientation (reverse complemented when the
+        // minimizer reads reversed, SubSampler.cpp:246-249); the comparator canonises (utils.cpp:470-472)
+        const u128d canon = fwd < rc ? fwd : rc;
+        const uint32_t mo = e.minimizer | (((e.rev ? rc : fwd) != canon) ? 0x80000000u : 0u);
+        const uint64_t lo = (uint64_t)canon, hi = (uint64_t)(canon >> 64);
+        k_mn[r] = mo; k_lo[r] = lo;
+        if (HAS_HI) k_hi[r] = hi;
+        hs[u] = home(mo, lo, hi);
     }
     __syncthreads();
 #pragma unroll
     for (uint32_t u = 0; u < PER; ++u) {
         const uint32_t r = u * kKeySortThreads + t;
-        if (r >= n) continue;
+        if (r >= n || k_mn[r] == kNone) continue;
         const uint32_t mo = k_mn[r];
         const uint64_t lo = k_lo[r], hi = HAS_HI ? k_hi[r] : 0ull;
         uint32_t h = hs[u];
@@ -233,16 +266,15 @@ __global__ __launch_bounds__(kKeySortThreads) void k_keys_dedupe(uint32_t* __res
     }
     __syncthreads();
     // the reference's uint8 counter per ORIENTED k-mer (SubSampler.h:24): 256 occurrences read as 0
-    auto usable = [&](uint32_t w) { return ((w >> 13) & 255u) >= abundance; };
+    auto usable = [&](uint32_t wd) { return ((wd >> 13) & 255u) >= abundance; };
     uint32_t keep[PER];
-    uint32_t cnt = 0;
 #pragma unroll
     for (uint32_t u = 0; u < PER; ++u) {
         const uint32_t r = u * kKeySortThreads + t;
         keep[u] = 0;
-        if (r >= n) continue;
-        const uint32_t w = slot[hs[u]];
-        if ((w & 0x1fffu) != r + 1 || !usable(w)) continue;        // one lane per (key, orientation) group: its claimer
+        if (r >= n || k_mn[r] == kNone) continue;
+        const uint32_t wd = slot[hs[u]];
+        if ((wd & 0x1fffu) != r + 1 || !usable(wd)) continue;      // one lane per (key, orientation) group: its claimer
         const uint32_t mo = k_mn[r];
         uint32_t emit = 1;
         if (mo >> 31) {                                            // the forward-oriented group of the same canonical key emits if it is usable
@@ -258,7 +290,6 @@ __global__ __launch_bounds__(kKeySortThreads) void k_keys_dedupe(uint32_t* __res
             }
         }
         keep[u] = emit;
-        cnt += emit;
     }
     // ranks in record order: lane t holds records t, t + threads, ...: a prefix per u-plane, planes one after the other
     uint32_t base = 0, rank[PER];
@@ -275,7 +306,6 @@ __global__ __launch_bounds__(kKeySortThreads) void k_keys_dedupe(uint32_t* __res
         base += all;
         __syncthreads();
     }
-    (void)cnt;
 #pragma unroll
     for (uint32_t u = 0; u < PER; ++u) {
         const uint32_t r = u * kKeySortThreads + t;
@@ -290,9 +320,21 @@ __global__ __launch_bounds__(256) void k_keys_compact(const uint32_t* __restrict
                                                      const uint64_t* __restrict__ r_hi, const uint32_t* __restrict__ raw_off,
                                                      const uint32_t* __restrict__ distinct, const uint32_t* __restrict__ out_off,
                                                      uint32_t* __restrict__ o_mn, uint64_t* __restrict__ o_lo, uint64_t* __restrict__ o_hi,
-                                                     uint32_t n_genomes, const uint32_t* __restrict__ flags, uint32_t* __restrict__ host_out) {
+                                                     uint32_t n_genomes, uint32_t* __restrict__ flags, uint32_t* __restrict__ host_out) {
     const uint32_t g = blockIdx.y;
-    const uint32_t n = distinct[g], r0 = raw_off[g], o0 = out_off[g];
+    __shared__ uint32_t s_o0;
+    if (!out_off) {                                          // unordered form: no scan launch in front -- the counts of the genomes before this one
+        uint32_t part = 0;
+        for (uint32_t j = threadIdx.x; j < g; j += 256) part += distinct[j];
+#pragma unroll
+        for (int d = 32; d; d >>= 1) part += __shfl_xor(part, d);
+        __shared__ uint32_t s_w[4];
+        if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = part;
+        __syncthreads();
+        if (threadIdx.x == 0) s_o0 = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        __syncthreads();
+    }
+    const uint32_t n = distinct[g], r0 = raw_off[g], o0 = out_off ? out_off[g] : s_o0;
     for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
         o_mn[o0 + e] = r_mn[r0 + e]; o_lo[o0 + e] = r_lo[r0 + e];
         if (o_hi) o_hi[o0 + e] = r_hi[r0 + e];
@@ -342,6 +384,32 @@ int sketch_keys_begin_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d
     uint32_t* d_flags = ctx->c_flags.as<uint32_t>() + 12;          // two words of the comparison's flag block that it does not use
     SPSP_HIP(hipMemcpyAsync(d_first_rec, ctx->h_keys, (size_t)(n_genomes + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
     SPSP_HIP(hipMemsetAsync(d_flags, 0, 8, ctx->stream));
+    const uint32_t ab = p->abundance ? p->abundance : 1u;
+    if (unordered) {
+        const uint32_t w = p->k - p->m + 1;
+        const size_t lds_d = has_hi ? (size_t)kDedupCapHi * 28 : (size_t)kDedupCapLo * 20;
+        if (!ctx->attr_dedupe_set) {
+            SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keys_fused<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kDedupCapHi * 28)));
+            SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keys_fused<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kDedupCapLo * 20)));
+            ctx->attr_dedupe_set = true;
+        }
+        if (has_hi) hipLaunchKernelGGL(k_keys_fused<true>, dim3(n_genomes), dim3(kKeySortThreads), lds_d, ctx->stream, d_bases, packed, d_rec_off, d_sk, n, d_first_rec,
+                                       p->k, w, ab, ctx->a_mn.as<uint32_t>(), ctx->a_lo.as<uint64_t>(), ctx->a_hi.as<uint64_t>(), d_raw_off, d_distinct, d_flags);
+        else hipLaunchKernelGGL(k_keys_fused<false>, dim3(n_genomes), dim3(kKeySortThreads), lds_d, ctx->stream, d_bases, packed, d_rec_off, d_sk, n, d_first_rec,
+                                p->k, w, ab, ctx->a_mn.as<uint32_t>(), ctx->a_lo.as<uint64_t>(), (uint64_t*)nullptr, d_raw_off, d_distinct, d_flags);
+        SPSP_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_keys_compact, dim3(8, n_genomes), dim3(256), 0, ctx->stream, ctx->a_mn.as<uint32_t>(), ctx->a_lo.as<uint64_t>(),
+                           has_hi ? ctx->a_hi.as<uint64_t>() : (const uint64_t*)nullptr, d_raw_off, d_distinct, (const uint32_t*)nullptr, ctx->c_min.as<uint32_t>(),
+                           ctx->c_lo.as<uint64_t>(), has_hi ? ctx->c_hi.as<uint64_t>() : (uint64_t*)nullptr, n_genomes, d_flags, h_out);
+        SPSP_HIP(hipGetLastError());
+        if (!ctx->keys_done) SPSP_HIP(hipEventCreateWithFlags(&ctx->keys_done, hipEventDisableTiming));
+        SPSP_HIP(hipEventRecord(ctx->keys_done, ctx->stream));
+        ctx->keys_pending = true;
+        ctx->keys_genomes = n_genomes;
+        ctx->keys_has_hi = has_hi;
+        ctx->keys_cap = has_hi ? kDedupCapHi : kDedupCapLo;
+        return SPSP_OK;
+    }
     if (n) {
         hipLaunchKernelGGL(k_keys_sizes, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_sk, n, p->k, ctx->a_cnt.as<uint32_t>());
         SPSP_HIP(hipGetLastError());
@@ -361,19 +429,6 @@ int sketch_keys_begin_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d
         SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keys_sort<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kKeyCapLo * 13)));
         ctx->attr_keys_set = true;
     }
-    const uint32_t ab = p->abundance ? p->abundance : 1u;
-    if (unordered) {
-        const size_t lds_d = has_hi ? (size_t)kDedupCapHi * (20 + 8) : (size_t)kDedupCapLo * (12 + 8);
-        if (!ctx->attr_dedupe_set) {
-            SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keys_dedupe<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kDedupCapHi * 28)));
-            SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keys_dedupe<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kDedupCapLo * 20)));
-            ctx->attr_dedupe_set = true;
-        }
-        if (has_hi) hipLaunchKernelGGL(k_keys_dedupe<true>, dim3(n_genomes), dim3(kKeySortThreads), lds_d, ctx->stream, ctx->a_mn.as<uint32_t>(), ctx->a_lo.as<uint64_t>(),
-                                       ctx->a_hi.as<uint64_t>(), ctx->a_flags.as<uint8_t>(), d_raw_off, ab, d_distinct, d_flags);
-        else hipLaunchKernelGGL(k_keys_dedupe<false>, dim3(n_genomes), dim3(kKeySortThreads), lds_d, ctx->stream, ctx->a_mn.as<uint32_t>(), ctx->a_lo.as<uint64_t>(),
-                                (uint64_t*)nullptr, ctx->a_flags.as<uint8_t>(), d_raw_off, ab, d_distinct, d_flags);
-    } else
     if (has_hi) hipLaunchKernelGGL(k_keys_sort<true>, dim3(n_genomes), dim3(kKeySortThreads), lds, ctx->stream, ctx->a_mn.as<uint32_t>(), ctx->a_lo.as<uint64_t>(),
                                    ctx->a_hi.as<uint64_t>(), ctx->a_flags.as<uint8_t>(), d_raw_off, ab, d_distinct, d_flags);
     else hipLaunchKernelGGL(k_keys_sort<false>, dim3(n_genomes), dim3(kKeySortThreads), lds, ctx->stream, ctx->a_mn.as<uint32_t>(), ctx->a_lo.as<uint64_t>(),
