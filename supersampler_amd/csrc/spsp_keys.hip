@@ -174,7 +174,7 @@ __global__ __launch_bounds__(kKeySortThreads) void k_keys_sort(uint32_t* __restr
 // unless the other orientation's group is usable too and comes first.  A tenth of the sorted form's time (its bitonic
 // sort is 91 barrier-separated passes over 13-byte records), which is what lets the key extraction run inside a 0.1 ms
 // step.
-constexpr uint32_t kDedupCapLo = 6144, kDedupCapHi = 4096;
+constexpr uint32_t kDedupCapLo = 6144, kDedupCapHi = 4096, kDedupSkmWords = 8192;   // records per genome; staged super-k-mer words (32 KiB)
 __device__ __forceinline__ uint64_t keys_mix(uint64_t x) {
     x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ULL;
     x ^= x >> 27; x *= 0x94d049bb133111ebULL;
@@ -193,6 +193,10 @@ __global__ __launch_bounds__(kKeySortThreads) void k_keys_fused(const uint8_t* _
     uint64_t* k_hi = k_lo + CAP;                                   // (HAS_HI only)
     uint32_t* k_mn = reinterpret_cast<uint32_t*>(k_hi + (HAS_HI ? CAP : 0));   // minimizer | orientation << 31
     uint32_t* slot = k_mn + CAP;
+    // the genome's super-k-mers as 2-bit words (16 bases per word, first base in bits 31:30), CH words each: staged once,
+    // so that a record's k-mer is two or three LDS words and a shift instead of k loads from global memory
+    constexpr uint32_t CH = HAS_HI ? 8 : 4, SKM_MAX = kDedupSkmWords / CH;
+    uint32_t* skw = slot + SLOTS;
     __shared__ uint32_t wave_sum[kKeySortThreads / 64];
     const uint32_t g = blockIdx.x, t = threadIdx.x, lane = t & 63, wid = t >> 6;
     // this genome's super-k-mers: [q0, q1) (the stream is in record order)
@@ -208,15 +212,36 @@ __global__ __launch_bounds__(kKeySortThreads) void k_keys_fused(const uint8_t* _
     const uint32_t r0 = q0 * w, n = (q1 - q0) * w;                 // table records (some empty) = room in the staging arrays
     if (t == 0) raw_off[g] = r0;
     if (n == 0) { if (t == 0) distinct[g] = 0; return; }
-    if (n > CAP) { if (t == 0) { distinct[g] = 0; atomicOr(&flags[0], 1u); atomicMax(&flags[1], n); } return; }
+    if (n > CAP || q1 - q0 > SKM_MAX) { if (t == 0) { distinct[g] = 0; atomicOr(&flags[0], 1u); atomicMax(&flags[1], n); } return; }
     for (uint32_t x = t; x < SLOTS; x += kKeySortThreads) slot[x] = 0;
+    {
+        const uint32_t* gw = reinterpret_cast<const uint32_t*>(bases);
+        for (uint32_t c = t; c < (q1 - q0) * CH; c += kKeySortThreads) {
+            const spsp_superkmer e = sk[q0 + c / CH];
+            const uint32_t b0 = (c % CH) * 16;                 // first base of this word inside the super-k-mer
+            uint32_t word = 0;
+            if (b0 < e.len) {
+                const uint64_t q = rec_off[e.rec] + e.start + b0;
+                const uint32_t have = e.len - b0 < 16 ? e.len - b0 : 16;
+                if (packed) {
+                    const uint32_t sh = 2u * (uint32_t)(q & 15u);
+                    const uint32_t w0 = gw[q >> 4], w1 = sh ? gw[(q >> 4) + 1] : 0u;   // (256 readable bytes follow the last word)
+                    word = sh ? (w0 << sh) | (w1 >> (32u - sh)) : w0;
+                } else {
+                    for (uint32_t b = 0; b < have; ++b) word |= (((uint32_t)bases[q + b] >> 1) & 3u) << (30u - 2u * b);
+                }
+                if (have < 16) word &= ~0u << (32u - 2u * have);
+            }
+            skw[c] = word;
+        }
+    }
+    __syncthreads();
     auto home = [&](uint32_t mo, uint64_t lo, uint64_t hi) {
         uint64_t h = keys_mix(lo ^ 0x9E3779B97F4A7C15ULL);
         h = keys_mix(h + (uint64_t)mo * 0xD6E8FEB86659FD93ULL);
         if (HAS_HI) h = keys_mix(h ^ hi);
         return (uint32_t)(((h & 0xffffffffull) * SLOTS) >> 32);
     };
-    const uint32_t* words = reinterpret_cast<const uint32_t*>(bases);
     const u128d mask = ((u128d)1 << (2 * k)) - 1;                  // k <= 63
     uint32_t hs[PER];
 #pragma unroll
@@ -227,15 +252,25 @@ __global__ __launch_bounds__(kKeySortThreads) void k_keys_fused(const uint8_t* _
         const spsp_superkmer e = sk[q0 + r / w];
         const uint32_t j = r % w;
         if (e.len < k || j > e.len - k) { k_mn[r] = kNone; continue; }
-        const uint64_t src = rec_off[e.rec] + e.start + j;
+        const uint32_t* sw = skw + (r / w) * CH;
         u128d fwd = 0, rc = 0;
-        for (uint32_t b = 0; b < k; ++b) {
-            const uint64_t q = src + b;
-            const uint32_t c = packed ? (words[q >> 4] >> (30u - 2u * (uint32_t)(q & 15u))) & 3u : ((uint32_t)bases[q] >> 1) & 3u;
-            fwd = (fwd << 2) | c;
-            rc = (rc >> 2) | ((u128d)(c ^ 2u) << (2 * (k - 1)));
+        if (!HAS_HI) {
+            // k <= 32: bases j .. j + k - 1 lie inside the three words from j / 16 on (48 bases, j % 16 + k <= 47)
+            const uint32_t p = j >> 4, o = j & 15u;
+            const uint32_t w0 = sw[p], w1 = p + 1 < CH ? sw[p + 1] : 0u, w2 = p + 2 < CH ? sw[p + 2] : 0u;
+            const u128d X = ((u128d)w0 << 64) | ((u128d)w1 << 32) | w2;
+            const uint64_t f = (uint64_t)(X >> (2u * (48u - o - k))) & (uint64_t)mask;
+            fwd = f;
+            rc = rc_window64(f << (64u - 2u * k)) & (uint64_t)mask;    // reversed and complemented; the padding lands above bit 2k
+        } else {
+            for (uint32_t b = 0; b < k; ++b) {
+                const uint32_t q = j + b;
+                const uint32_t c = (sw[q >> 4] >> (30u - 2u * (q & 15u))) & 3u;
+                fwd = (fwd << 2) | c;
+                rc = (rc >> 2) | ((u128d)(c ^ 2u) << (2 * (k - 1)));
+            }
+            fwd &= mask;
         }
-        fwd &= mask;
         // handle_superkmer stores the k-mer as it reads in the super-k-mer's orientation (reverse complemented when the
         // minimizer reads reversed, SubSampler.cpp:246-249); the comparator canonises (utils.cpp:470-472)
         const u128d canon = fwd < rc ? fwd : rc;
@@ -387,10 +422,10 @@ int sketch_keys_begin_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d
     const uint32_t ab = p->abundance ? p->abundance : 1u;
     if (unordered) {
         const uint32_t w = p->k - p->m + 1;
-        const size_t lds_d = has_hi ? (size_t)kDedupCapHi * 28 : (size_t)kDedupCapLo * 20;
+        const size_t lds_d = has_hi ? (size_t)kDedupCapHi * 28 + kDedupSkmWords * 4 : (size_t)kDedupCapLo * 20 + kDedupSkmWords * 4;
         if (!ctx->attr_dedupe_set) {
-            SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keys_fused<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kDedupCapHi * 28)));
-            SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keys_fused<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kDedupCapLo * 20)));
+            SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keys_fused<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kDedupCapHi * 28 + kDedupSkmWords * 4)));
+            SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keys_fused<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kDedupCapLo * 20 + kDedupSkmWords * 4)));
             ctx->attr_dedupe_set = true;
         }
         if (has_hi) hipLaunchKernelGGL(k_keys_fused<true>, dim3(n_genomes), dim3(kKeySortThreads), lds_d, ctx->stream, d_bases, packed, d_rec_off, d_sk, n, d_first_rec,
