@@ -318,17 +318,10 @@ def main():
         if exchange_kind == "none":
             if schedule != "partition":
                 sl.cmp.wait_dense(sl.scan)                # the comparison starts behind this step's dense pass
-            if not skip_compare:
-                if device_keys and getattr(sl, "keys_queued", False):
-                    # the keys of this slot's previous scan (queued when that scan was collected, just above): stream B
-                    d_mn, d_lo, _, koff = sl.cmp.sketch_keys_device_end()
-                    sl.keys_queued = False
-                    sl.keys_batch = sl.keys_batch_queued
-                    last["keys_total"] = int(koff[-1])
-                    sl.cmp.compare_device_begin(K, d_mn, d_lo, None, koff, n_total, 0, 1, sl.d_inter.data_ptr())
-                else:
-                    sl.cmp.compare_device_begin(K, d_all_min.data_ptr(), d_all_lo.data_ptr(), None, sk_off, n_total, rank, max(world, sim_world),
-                                                sl.d_inter.data_ptr())                                     # stream B
+            if not skip_compare and not (device_keys and getattr(sl, "compare_queued", False)):
+                sl.cmp.compare_device_begin(K, d_all_min.data_ptr(), d_all_lo.data_ptr(), None, sk_off, n_total, rank, max(world, sim_world),
+                                            sl.d_inter.data_ptr())                                         # stream B
+                sl.compare_queued = True
             return
         with on_b(sl):
             if exchange_kind == "slots":
@@ -353,9 +346,18 @@ def main():
     def collect_step(sl):
         d_out, n_out = sl.scan.scan_device_end()
         if device_keys:
-            sl.cmp.compare_end()                          # (the comparison queued with this step: its key arrays are free again)
-            sl.cmp.sketch_keys_device_begin(p, scan_args[sl.batch][1], d_off.data_ptr(), d_out, n_out, first_rec, unordered=True)   # stream B, no wait
-            sl.keys_queued, sl.keys_batch_queued = True, sl.batch
+            # stream B of this slot, in this order: [comparison of the keys made one visit ago] -> [keys of the scan collected now].
+            # The key arrays belong to the context: the comparison that reads them is queued in front of the extraction that
+            # rewrites them, and nothing here waits for work queued in this same visit.
+            sl.cmp.compare_end()                          # the comparison queued one visit ago
+            sl.compare_queued = False
+            if getattr(sl, "keys_queued", False):
+                d_mn, d_lo, _, koff = sl.cmp.sketch_keys_device_end()       # queued one visit ago: long done
+                last["keys_total"] = int(koff[-1])
+                sl.cmp.compare_device_begin(K, d_mn, d_lo, None, koff, n_total, 0, 1, sl.d_inter.data_ptr())
+                sl.compare_queued = True
+            sl.cmp.sketch_keys_device_begin(p, scan_args[sl.batch][1], scan_args[sl.batch][2], d_off.data_ptr(), d_out, n_out, first_rec, unordered=True)
+            sl.keys_queued = True
             last["n_out"], last["slot"] = n_out, sl
             last["n_out_batch"][sl.batch] = n_out
             return
@@ -553,7 +555,7 @@ def main():
                                          "NOT a measurement" % sim_world} if sim_world > 1 else {}),
                        **({"rehearsal": "BENCH_BACKEND=%s, all ranks on one device: NOT a measurement" % backend}
                           if (use_dist and (backend != "nccl" or os.environ.get("BENCH_SHARE_GPU") == "1")) else {}),
-                       "step": ((("scan(batch t) || keys(batch t-2, on the device) -> all-vs-all(those keys)" if device_keys else "scan(batch t) || all-vs-all(sketches of batch t-1)") +
+                       "step": ((("scan(batch t) || keys(scan t-2, on the device) || all-vs-all(keys of scan t-4)" if device_keys else "scan(batch t) || all-vs-all(sketches of batch t-1)") +
                                  ": the chip is partitioned by CU-masked streams -- "
                                  "dense passes back to back on %d CUs (two workgroups each), the scans' sparse stages on one stream and "
                                  "the comparisons on another that share the other %d CUs; the host queues step t+1 before collecting "
@@ -652,7 +654,7 @@ def main():
                 torch.cuda.synchronize()
                 d_o, n_o = ctx_full.scan_device(*scan_args[0])
                 # (sorted form here: the arrays can be held against the parsed sketches element by element)
-                kmn, klo, _, koff = ctx_full.sketch_keys_device(p, scan_args[0][1], d_off.data_ptr(), d_o, n_o, first_rec)
+                kmn, klo, _, koff = ctx_full.sketch_keys_device(p, scan_args[0][1], scan_args[0][2], d_off.data_ptr(), d_o, n_o, first_rec)
                 same = bool((koff == sk_off).all())
                 if same:
                     tot = int(koff[-1])

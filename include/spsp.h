@@ -311,7 +311,7 @@ int spsp_sketch_parse_host(const uint8_t* payload, uint64_t len, uint32_t* k, ui
                            uint32_t** minimizer, uint64_t** kmer_lo, uint64_t** kmer_hi, uint64_t* n);
 
 /* From a scan straight to the comparator's keys, without the sketch file in between.  Genome g = records
- * [h_first_rec[g], h_first_rec[g + 1]) of ONE scan (d_bases / d_rec_off / d_superkmers as given to and returned by
+ * [h_first_rec[g], h_first_rec[g + 1]) of ONE scan (d_bases / n_bases / d_rec_off / d_superkmers as given to and returned by
  * spsp_scan_device; SPSP_SCAN_PACKED_INPUT in p->flags when d_bases holds 2-bit words).  The result is what
  * spsp_sketch_parse_host would return for the sketch parse_fasta_test writes for that genome: handle_superkmer's
  * per-k-mer counts with their uint8 wrap and the -a rule (SubSampler.cpp:243-302, 587, 608), the emission / reader round
@@ -327,11 +327,11 @@ int spsp_sketch_parse_host(const uint8_t* payload, uint64_t len, uint32_t* k, ui
  * comparisons on a context that has been told so (spsp_compare_keys_unordered): the comparison itself only needs a
  * sketch to hold a key once; the order is what lets it CHECK that on input it did not make. */
 #define SPSP_KEYS_UNORDERED 1u
-int spsp_sketch_keys_device(spsp_ctx* ctx, const spsp_params* p, const void* d_bases, const void* d_rec_off, const void* d_superkmers,
-                            uint64_t n_superkmers, const uint32_t* h_first_rec, uint32_t n_genomes, uint32_t flags, void** d_minimizer,
-                            void** d_kmer_lo, void** d_kmer_hi, uint64_t* sk_off);
-int spsp_sketch_keys_device_begin(spsp_ctx* ctx, const spsp_params* p, const void* d_bases, const void* d_rec_off, const void* d_superkmers,
-                                  uint64_t n_superkmers, const uint32_t* h_first_rec, uint32_t n_genomes, uint32_t flags);
+int spsp_sketch_keys_device(spsp_ctx* ctx, const spsp_params* p, const void* d_bases, uint64_t n_bases, const void* d_rec_off,
+                            const void* d_superkmers, uint64_t n_superkmers, const uint32_t* h_first_rec, uint32_t n_genomes, uint32_t flags,
+                            void** d_minimizer, void** d_kmer_lo, void** d_kmer_hi, uint64_t* sk_off);
+int spsp_sketch_keys_device_begin(spsp_ctx* ctx, const spsp_params* p, const void* d_bases, uint64_t n_bases, const void* d_rec_off,
+                                  const void* d_superkmers, uint64_t n_superkmers, const uint32_t* h_first_rec, uint32_t n_genomes, uint32_t flags);
 /* on != 0: the device-form comparisons queued on this context from now on accept sketches whose keys are distinct but
  * unsorted (the caller vouches for "distinct": duplicates inside a sketch would be counted twice) */
 int spsp_compare_keys_unordered(spsp_ctx* ctx, int on);

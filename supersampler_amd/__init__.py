@@ -164,9 +164,9 @@ def lib():
     L.spsp_compare_files.restype = i32
     L.spsp_compare_files.argtypes = [vp, P(cp), u32, u32, i32, dbl, cp]
     L.spsp_sketch_keys_device.restype = i32
-    L.spsp_sketch_keys_device.argtypes = [vp, P(Params), vp, vp, vp, u64, vp, u32, u32, P(vp), P(vp), P(vp), vp]
+    L.spsp_sketch_keys_device.argtypes = [vp, P(Params), vp, u64, vp, vp, u64, vp, u32, u32, P(vp), P(vp), P(vp), vp]
     L.spsp_sketch_keys_device_begin.restype = i32
-    L.spsp_sketch_keys_device_begin.argtypes = [vp, P(Params), vp, vp, vp, u64, vp, u32, u32]
+    L.spsp_sketch_keys_device_begin.argtypes = [vp, P(Params), vp, u64, vp, vp, u64, vp, u32, u32]
     L.spsp_compare_keys_unordered.restype = i32; L.spsp_compare_keys_unordered.argtypes = [vp, i32]
     L.spsp_sketch_keys_device_end.restype = i32
     L.spsp_sketch_keys_device_end.argtypes = [vp, P(vp), P(vp), P(vp), vp]
@@ -522,10 +522,10 @@ class Context:
         """device-form comparisons of this context accept sketches whose keys are distinct but unsorted"""
         _check(lib().spsp_compare_keys_unordered(self._h, 1 if on else 0))
 
-    def sketch_keys_device_begin(self, params, d_bases, d_rec_off, d_sk, n_sk, first_rec, unordered=False):
+    def sketch_keys_device_begin(self, params, d_bases, n_bases, d_rec_off, d_sk, n_sk, first_rec, unordered=False):
         """queue: scan output -> comparator keys of the genomes whose record ranges `first_rec` (n_genomes + 1) gives"""
         fr = np.ascontiguousarray(first_rec, dtype=np.uint32)
-        _check(lib().spsp_sketch_keys_device_begin(self._h, C.byref(params), d_bases, d_rec_off, d_sk, n_sk, fr.ctypes.data, len(fr) - 1,
+        _check(lib().spsp_sketch_keys_device_begin(self._h, C.byref(params), d_bases, n_bases, d_rec_off, d_sk, n_sk, fr.ctypes.data, len(fr) - 1,
                                                    KEYS_UNORDERED if unordered else 0))
         self._keys_n = len(fr) - 1
 
@@ -536,8 +536,8 @@ class Context:
         _check(lib().spsp_sketch_keys_device_end(self._h, C.byref(d_mn), C.byref(d_lo), C.byref(d_hi), sk_off.ctypes.data))
         return d_mn.value, d_lo.value, d_hi.value, sk_off
 
-    def sketch_keys_device(self, params, d_bases, d_rec_off, d_sk, n_sk, first_rec, unordered=False):
-        self.sketch_keys_device_begin(params, d_bases, d_rec_off, d_sk, n_sk, first_rec, unordered)
+    def sketch_keys_device(self, params, d_bases, n_bases, d_rec_off, d_sk, n_sk, first_rec, unordered=False):
+        self.sketch_keys_device_begin(params, d_bases, n_bases, d_rec_off, d_sk, n_sk, first_rec, unordered)
         return self.sketch_keys_device_end()
 
     def stage_times(self, reset=True):

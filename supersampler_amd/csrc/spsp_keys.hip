@@ -181,7 +181,8 @@ __device__ __forceinline__ uint64_t keys_mix(uint64_t x) {
     return x ^ (x >> 31);
 }
 template <bool HAS_HI>
-__global__ __launch_bounds__(kKeySortThreads) void k_keys_fused(const uint8_t* __restrict__ bases, bool packed, const uint64_t* __restrict__ rec_off,
+__global__ __launch_bounds__(kKeySortThreads) void k_keys_fused(const uint8_t* __restrict__ bases, bool packed, uint64_t n_bases_readable,
+                                                               const uint64_t* __restrict__ rec_off,
                                                                const spsp_superkmer* __restrict__ sk, uint32_t n_sk, const uint32_t* __restrict__ first_rec,
                                                                uint32_t k, uint32_t w, uint32_t abundance, uint32_t* __restrict__ r_mn,
                                                                uint64_t* __restrict__ r_lo, uint64_t* __restrict__ r_hi, uint32_t* __restrict__ raw_off,
@@ -200,15 +201,28 @@ __global__ __launch_bounds__(kKeySortThreads) void k_keys_fused(const uint8_t* _
     __shared__ uint32_t wave_sum[kKeySortThreads / 64];
     const uint32_t g = blockIdx.x, t = threadIdx.x, lane = t & 63, wid = t >> 6;
     // this genome's super-k-mers: [q0, q1) (the stream is in record order)
-    uint32_t q0, q1;
-    {
-        const uint32_t want0 = first_rec[g], want1 = first_rec[g + 1];
-        uint32_t lo = 0, hi = n_sk;
-        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (sk[mid].rec < want0) lo = mid + 1; else hi = mid; }
-        q0 = lo; hi = n_sk;
-        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (sk[mid].rec < want1) lo = mid + 1; else hi = mid; }
-        q1 = lo;
+    // (wave 0 searches 64 ways at a time -- three dependent loads per bound instead of fifteen -- and tells the others)
+    __shared__ uint32_t s_q[2];
+    if (wid == 0) {
+        for (int which = 0; which < 2; ++which) {
+            const uint32_t want = first_rec[g + which];
+            uint32_t lo = 0, hi = n_sk;                      // answer = first index in [lo, hi] whose rec >= want (hi: none)
+            while (hi - lo > 0) {
+                const uint32_t span = hi - lo, step = (span + 63) / 64;
+                const uint32_t at = lo + lane * step;        // probes lo, lo + step, ...
+                const bool below = at < hi && sk[at].rec < want;
+                const uint32_t nb = (uint32_t)__popcll(__ballot(below));   // probes 0 .. nb - 1 are below (monotone)
+                if (nb == 0) { hi = lo; break; }
+                const uint32_t last_below = lo + (nb - 1) * step;
+                lo = last_below + 1;
+                const uint32_t next_probe = lo + step - 1;   // the first probe not below (or past the end)
+                hi = next_probe < hi ? next_probe : hi;
+            }
+            if (lane == 0) s_q[which] = lo;
+        }
     }
+    __syncthreads();
+    const uint32_t q0 = s_q[0], q1 = s_q[1];
     const uint32_t r0 = q0 * w, n = (q1 - q0) * w;                 // table records (some empty) = room in the staging arrays
     if (t == 0) raw_off[g] = r0;
     if (n == 0) { if (t == 0) distinct[g] = 0; return; }
@@ -227,6 +241,11 @@ __global__ __launch_bounds__(kKeySortThreads) void k_keys_fused(const uint8_t* _
                     const uint32_t sh = 2u * (uint32_t)(q & 15u);
                     const uint32_t w0 = gw[q >> 4], w1 = sh ? gw[(q >> 4) + 1] : 0u;   // (256 readable bytes follow the last word)
                     word = sh ? (w0 << sh) | (w1 >> (32u - sh)) : w0;
+                } else if (((q & ~15ull) + 32) <= n_bases_readable) {
+                    // two aligned 16-byte loads cover bases q .. q + 15: packed separately, joined, shifted into place
+                    const uint4* v = reinterpret_cast<const uint4*>(bases + (q & ~15ull));
+                    const uint64_t both = ((uint64_t)pack16(v[0]) << 32) | pack16(v[1]);
+                    word = (uint32_t)((both << (2u * (uint32_t)(q & 15u))) >> 32);
                 } else {
                     for (uint32_t b = 0; b < have; ++b) word |= (((uint32_t)bases[q + b] >> 1) & 3u) << (30u - 2u * b);
                 }
@@ -382,7 +401,8 @@ __global__ __launch_bounds__(256) void k_keys_compact(const uint32_t* __restrict
 }
 
 int sketch_keys_begin_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, bool packed, const uint64_t* d_rec_off,
-                           const spsp_superkmer* d_sk, uint64_t n_sk, const uint32_t* h_first_rec, uint32_t n_genomes, bool unordered) {
+                           const spsp_superkmer* d_sk, uint64_t n_sk, const uint32_t* h_first_rec, uint32_t n_genomes, bool unordered,
+                           uint64_t n_bases_readable) {
     int rc = check_params(p);
     if (rc) return rc;
     if (ctx->keys_pending) { set_error("a key extraction is already pending on this context"); return SPSP_ERR_ARG; }
@@ -428,9 +448,9 @@ int sketch_keys_begin_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d
             SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keys_fused<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kDedupCapLo * 20 + kDedupSkmWords * 4)));
             ctx->attr_dedupe_set = true;
         }
-        if (has_hi) hipLaunchKernelGGL(k_keys_fused<true>, dim3(n_genomes), dim3(kKeySortThreads), lds_d, ctx->stream, d_bases, packed, d_rec_off, d_sk, n, d_first_rec,
+        if (has_hi) hipLaunchKernelGGL(k_keys_fused<true>, dim3(n_genomes), dim3(kKeySortThreads), lds_d, ctx->stream, d_bases, packed, n_bases_readable, d_rec_off, d_sk, n, d_first_rec,
                                        p->k, w, ab, ctx->a_mn.as<uint32_t>(), ctx->a_lo.as<uint64_t>(), ctx->a_hi.as<uint64_t>(), d_raw_off, d_distinct, d_flags);
-        else hipLaunchKernelGGL(k_keys_fused<false>, dim3(n_genomes), dim3(kKeySortThreads), lds_d, ctx->stream, d_bases, packed, d_rec_off, d_sk, n, d_first_rec,
+        else hipLaunchKernelGGL(k_keys_fused<false>, dim3(n_genomes), dim3(kKeySortThreads), lds_d, ctx->stream, d_bases, packed, n_bases_readable, d_rec_off, d_sk, n, d_first_rec,
                                 p->k, w, ab, ctx->a_mn.as<uint32_t>(), ctx->a_lo.as<uint64_t>(), (uint64_t*)nullptr, d_raw_off, d_distinct, d_flags);
         SPSP_HIP(hipGetLastError());
         hipLaunchKernelGGL(k_keys_compact, dim3(8, n_genomes), dim3(256), 0, ctx->stream, ctx->a_mn.as<uint32_t>(), ctx->a_lo.as<uint64_t>(),
@@ -505,12 +525,12 @@ using namespace spsp;
 
 extern "C" {
 
-int spsp_sketch_keys_device_begin(spsp_ctx* ctx, const spsp_params* p, const void* d_bases, const void* d_rec_off, const void* d_superkmers,
-                                  uint64_t n_superkmers, const uint32_t* h_first_rec, uint32_t n_genomes, uint32_t flags) {
+int spsp_sketch_keys_device_begin(spsp_ctx* ctx, const spsp_params* p, const void* d_bases, uint64_t n_bases, const void* d_rec_off,
+                                  const void* d_superkmers, uint64_t n_superkmers, const uint32_t* h_first_rec, uint32_t n_genomes, uint32_t flags) {
     if (!ctx || !p || !h_first_rec || (n_superkmers && (!d_bases || !d_rec_off || !d_superkmers))) { set_error("NULL argument"); return SPSP_ERR_ARG; }
     SPSP_HIP(hipSetDevice(ctx->device));
     return sketch_keys_begin_impl(ctx, p, (const uint8_t*)d_bases, (p->flags & SPSP_SCAN_PACKED_INPUT) != 0, (const uint64_t*)d_rec_off,
-                                  (const spsp_superkmer*)d_superkmers, n_superkmers, h_first_rec, n_genomes, (flags & SPSP_KEYS_UNORDERED) != 0);
+                                  (const spsp_superkmer*)d_superkmers, n_superkmers, h_first_rec, n_genomes, (flags & SPSP_KEYS_UNORDERED) != 0, n_bases);
 }
 
 int spsp_sketch_keys_device_end(spsp_ctx* ctx, void** d_minimizer, void** d_kmer_lo, void** d_kmer_hi, uint64_t* sk_off) {
@@ -519,10 +539,10 @@ int spsp_sketch_keys_device_end(spsp_ctx* ctx, void** d_minimizer, void** d_kmer
     return sketch_keys_end_impl(ctx, d_minimizer, d_kmer_lo, d_kmer_hi, sk_off);
 }
 
-int spsp_sketch_keys_device(spsp_ctx* ctx, const spsp_params* p, const void* d_bases, const void* d_rec_off, const void* d_superkmers,
-                            uint64_t n_superkmers, const uint32_t* h_first_rec, uint32_t n_genomes, uint32_t flags, void** d_minimizer,
-                            void** d_kmer_lo, void** d_kmer_hi, uint64_t* sk_off) {
-    const int rc = spsp_sketch_keys_device_begin(ctx, p, d_bases, d_rec_off, d_superkmers, n_superkmers, h_first_rec, n_genomes, flags);
+int spsp_sketch_keys_device(spsp_ctx* ctx, const spsp_params* p, const void* d_bases, uint64_t n_bases, const void* d_rec_off,
+                            const void* d_superkmers, uint64_t n_superkmers, const uint32_t* h_first_rec, uint32_t n_genomes, uint32_t flags,
+                            void** d_minimizer, void** d_kmer_lo, void** d_kmer_hi, uint64_t* sk_off) {
+    const int rc = spsp_sketch_keys_device_begin(ctx, p, d_bases, n_bases, d_rec_off, d_superkmers, n_superkmers, h_first_rec, n_genomes, flags);
     if (rc) return rc;
     return spsp_sketch_keys_device_end(ctx, d_minimizer, d_kmer_lo, d_kmer_hi, sk_off);
 }

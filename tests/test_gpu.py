@@ -1049,7 +1049,7 @@ def test_sketch_keys_on_device_equal_the_file_path(ctx, k, m, s, ab):
         p = sp.make_params(k, m, s, abundance=ab, flags=sp.SPSP_SCAN_PACKED_INPUT if packed else 0)
         src = ctx.pack_bases_device(d_b.data_ptr(), len(bases)) if packed else d_b.data_ptr()
         d_sk, n_sk = ctx.scan_device(p, src, len(bases), d_o.data_ptr(), len(recs))
-        d_mn, d_lo, d_hi, sk_off = ctx.sketch_keys_device(p, src, d_o.data_ptr(), d_sk, n_sk, first_rec)
+        d_mn, d_lo, d_hi, sk_off = ctx.sketch_keys_device(p, src, len(bases), d_o.data_ptr(), d_sk, n_sk, first_rec)
         total = int(sk_off[-1])
         mn, lo = ctx.to_host(d_mn, total, np.uint32), ctx.to_host(d_lo, total, np.uint64)
         hi = ctx.to_host(d_hi, total, np.uint64) if k > 32 else np.zeros(total, np.uint64)
@@ -1066,7 +1066,7 @@ def test_sketch_keys_on_device_equal_the_file_path(ctx, k, m, s, ab):
     assert (np.triu(d_inter.cpu().numpy(), 1) == np.triu(w_inter.astype(np.int64), 1)).all()
     # SPSP_KEYS_UNORDERED: the same key SETS from an LDS table per genome instead of a sort; a comparison that has been told
     # so takes them, one that has not refuses them (its order check is its duplicate check)
-    d_mn, d_lo, d_hi, sk_off2 = ctx.sketch_keys_device(p, src, d_o.data_ptr(), d_sk, n_sk, first_rec, unordered=True)
+    d_mn, d_lo, d_hi, sk_off2 = ctx.sketch_keys_device(p, src, len(bases), d_o.data_ptr(), d_sk, n_sk, first_rec, unordered=True)
     assert (sk_off2 == sk_off).all()
     total = int(sk_off2[-1])
     mn, lo = ctx.to_host(d_mn, total, np.uint32), ctx.to_host(d_lo, total, np.uint64)
@@ -1094,5 +1094,5 @@ def test_sketch_keys_on_device_equal_the_file_path(ctx, k, m, s, ab):
         p = sp.make_params(k, m, s)
         d_sk, n_sk = ctx.scan_device(p, d_b2.data_ptr(), len(bb), d_o2.data_ptr(), 1)
         with pytest.raises(sp.SpspError) as e:
-            ctx.sketch_keys_device(p, d_b2.data_ptr(), d_o2.data_ptr(), d_sk, n_sk, [0, 1])
+            ctx.sketch_keys_device(p, d_b2.data_ptr(), len(bb), d_o2.data_ptr(), d_sk, n_sk, [0, 1])
         assert e.value.code == sp.ERR_OVERFLOW
