@@ -289,8 +289,22 @@ def main():
     device_keys = (exchange_kind == "none" and sim_world == 1 and pipelined and os.environ.get("BENCH_DEVICE_KEYS", "1") != "0"
                    and os.environ.get("BENCH_DEBUG_SKIP_COMPARE") != "1")
     if device_keys:
+        # a third stream on the small CUs for the key extraction, two key contexts per slot (one's arrays are read by the
+        # comparison in flight while the other's are being rewritten)
+        if schedule == "partition":
+            masked.append(sp.stream_create_cus(local_rank, 0, small_cus))
+            stream_k = torch.cuda.ExternalStream(masked[-1], device=dev)
+        else:
+            stream_k = torch.cuda.Stream(device=dev)
         for sl in slots:
             sl.cmp.compare_keys_unordered(True)           # the step's keys come out of an LDS table per genome: distinct, not sorted
+            sl.keys = [sp.Context(local_rank, stream_k.cuda_stream), sp.Context(local_rank, stream_k.cuda_stream)]
+            sl.kv = 0
+            sl.keys_job = [False, False]
+            for c in sl.keys:
+                if schedule == "partition":
+                    c.set_cu_count(small_cus)
+                all_ctx.append(c)
     step_no = [0]                                             # steps queued so far: step i scans batch i % n_batches
 
     # analysis only (the line it prints is not a valid measurement): the step without its comparison, to see what the
@@ -312,8 +326,8 @@ def main():
             sl.scan.wait_dense(prev.scan)                 # "streams": dense passes never overlap each other
         sl.batch = step_no[0] % n_batches
         step_no[0] += 1
-        if device_keys and getattr(sl, "keys_queued", False):
-            sl.scan.scan_output_wait(sl.cmp)              # this scan's last stage rewrites the buffer the queued key extraction reads
+        if device_keys and getattr(sl, "keys_reader", None) is not None:
+            sl.scan.scan_output_wait(sl.keys_reader)      # this scan's last stage rewrites the buffer the queued key extraction reads
         sl.scan.scan_device_begin(*scan_args[sl.batch])   # "tail" / "single": dense passes in order on the one scan stream
         if exchange_kind == "none":
             if schedule != "partition":
@@ -349,15 +363,20 @@ def main():
             # stream B of this slot, in this order: [comparison of the keys made one visit ago] -> [keys of the scan collected now].
             # The key arrays belong to the context: the comparison that reads them is queued in front of the extraction that
             # rewrites them, and nothing here waits for work queued in this same visit.
-            sl.cmp.compare_end()                          # the comparison queued one visit ago
+            sl.cmp.compare_end()                          # the comparison queued one visit ago (it read the arrays rewritten below)
             sl.compare_queued = False
-            if getattr(sl, "keys_queued", False):
-                d_mn, d_lo, _, koff = sl.cmp.sketch_keys_device_end()       # queued one visit ago: long done
+            kprev, kcur = sl.kv ^ 1, sl.kv
+            if sl.keys_job[kprev]:
+                d_mn, d_lo, _, koff = sl.keys[kprev].sketch_keys_device_end()   # queued one visit ago: long done
+                sl.keys_job[kprev] = False
                 last["keys_total"] = int(koff[-1])
-                sl.cmp.compare_device_begin(K, d_mn, d_lo, None, koff, n_total, 0, 1, sl.d_inter.data_ptr())
+                sl.cmp.compare_device_begin(K, d_mn, d_lo, None, koff, n_total, 0, 1, sl.d_inter.data_ptr())      # stream B
                 sl.compare_queued = True
-            sl.cmp.sketch_keys_device_begin(p, scan_args[sl.batch][1], scan_args[sl.batch][2], d_off.data_ptr(), d_out, n_out, first_rec, unordered=True)
-            sl.keys_queued = True
+            sl.keys[kcur].sketch_keys_device_begin(p, scan_args[sl.batch][1], scan_args[sl.batch][2], d_off.data_ptr(), d_out, n_out, first_rec,
+                                                   unordered=True)                                                  # stream K
+            sl.keys_job[kcur] = True
+            sl.keys_reader = sl.keys[kcur]
+            sl.kv ^= 1
             last["n_out"], last["slot"] = n_out, sl
             last["n_out_batch"][sl.batch] = n_out
             return

@@ -174,22 +174,24 @@ __global__ __launch_bounds__(kKeySortThreads) void k_keys_sort(uint32_t* __restr
 // unless the other orientation's group is usable too and comes first.  A tenth of the sorted form's time (its bitonic
 // sort is 91 barrier-separated passes over 13-byte records), which is what lets the key extraction run inside a 0.1 ms
 // step.
-constexpr uint32_t kDedupCapLo = 6144, kDedupCapHi = 4096, kDedupSkmWords = 8192;   // records per genome; staged super-k-mer words (32 KiB)
+constexpr uint32_t kDedupCapLo = 6144, kDedupCapHi = 4096, kDedupSkmWords = 4096, kDedupSplit = 2;   // k-mer places per genome; staged super-k-mer words (16 KiB); workgroups per genome
 __device__ __forceinline__ uint64_t keys_mix(uint64_t x) {
     x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ULL;
     x ^= x >> 27; x *= 0x94d049bb133111ebULL;
     return x ^ (x >> 31);
 }
-template <bool HAS_HI>
+template <bool HAS_HI, uint32_t S>
 __global__ __launch_bounds__(kKeySortThreads) void k_keys_fused(const uint8_t* __restrict__ bases, bool packed, uint64_t n_bases_readable,
                                                                const uint64_t* __restrict__ rec_off,
                                                                const spsp_superkmer* __restrict__ sk, uint32_t n_sk, const uint32_t* __restrict__ first_rec,
-                                                               uint32_t k, uint32_t w, uint32_t abundance, uint32_t* __restrict__ r_mn,
+                                                               uint32_t k, uint32_t w, uint32_t abundance, uint32_t stage_stride, uint32_t* __restrict__ r_mn,
                                                                uint64_t* __restrict__ r_lo, uint64_t* __restrict__ r_hi, uint32_t* __restrict__ raw_off,
                                                                uint32_t* __restrict__ distinct, uint32_t* __restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_d[];
-    constexpr uint32_t CAP = HAS_HI ? kDedupCapHi : kDedupCapLo, SLOTS = 2 * CAP, PER = CAP / kKeySortThreads;
-    constexpr uint32_t kNone = 0xffffffffu;                        // record without a k-mer (a super-k-mer shorter than 2k - m)
+    // S workgroups share a genome: every one of them stages the super-k-mers and rolls ALL k-mers (cheap), but tables only
+    // the keys of its hash class -- half the LDS each at S = 2 (78 KiB: two per CU, or one beside a comparison workgroup)
+    constexpr uint32_t FULL = HAS_HI ? kDedupCapHi : kDedupCapLo, CAP = FULL / S, SLOTS = 2 * CAP, PER = FULL / kKeySortThreads;
+    constexpr uint32_t kNone = 0xffffffffu;                        // record that is not this workgroup's (or holds no k-mer)
     uint64_t* k_lo = reinterpret_cast<uint64_t*>(lds_d);
     uint64_t* k_hi = k_lo + CAP;                                   // (HAS_HI only)
     uint32_t* k_mn = reinterpret_cast<uint32_t*>(k_hi + (HAS_HI ? CAP : 0));   // minimizer | orientation << 31
@@ -199,7 +201,8 @@ __global__ __launch_bounds__(kKeySortThreads) void k_keys_fused(const uint8_t* _
     constexpr uint32_t CH = HAS_HI ? 8 : 4, SKM_MAX = kDedupSkmWords / CH;
     uint32_t* skw = slot + SLOTS;
     __shared__ uint32_t wave_sum[kKeySortThreads / 64];
-    const uint32_t g = blockIdx.x, t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    __shared__ uint32_t s_count;
+    const uint32_t g = blockIdx.x / S, cls = blockIdx.x % S, seg = blockIdx.x, t = threadIdx.x, lane = t & 63, wid = t >> 6;
     // this genome's super-k-mers: [q0, q1) (the stream is in record order)
     // (wave 0 searches 64 ways at a time -- three dependent loads per bound instead of fifteen -- and tells the others)
     __shared__ uint32_t s_q[2];
@@ -223,10 +226,11 @@ __global__ __launch_bounds__(kKeySortThreads) void k_keys_fused(const uint8_t* _
     }
     __syncthreads();
     const uint32_t q0 = s_q[0], q1 = s_q[1];
-    const uint32_t r0 = q0 * w, n = (q1 - q0) * w;                 // table records (some empty) = room in the staging arrays
-    if (t == 0) raw_off[g] = r0;
-    if (n == 0) { if (t == 0) distinct[g] = 0; return; }
-    if (n > CAP || q1 - q0 > SKM_MAX) { if (t == 0) { distinct[g] = 0; atomicOr(&flags[0], 1u); atomicMax(&flags[1], n); } return; }
+    const uint32_t n = (q1 - q0) * w;                              // the genome's k-mer places (some empty)
+    const uint32_t r0 = cls * stage_stride + q0 * w;               // this workgroup's room in the staging arrays
+    if (t == 0) { raw_off[seg] = r0; s_count = 0; }
+    if (n == 0) { if (t == 0) distinct[seg] = 0; return; }
+    if (n > FULL || q1 - q0 > SKM_MAX) { if (t == 0) { distinct[seg] = 0; atomicOr(&flags[0], 1u); atomicMax(&flags[1], n); } return; }
     for (uint32_t x = t; x < SLOTS; x += kKeySortThreads) slot[x] = 0;
     {
         const uint32_t* gw = reinterpret_cast<const uint32_t*>(bases);
@@ -262,15 +266,15 @@ __global__ __launch_bounds__(kKeySortThreads) void k_keys_fused(const uint8_t* _
         return (uint32_t)(((h & 0xffffffffull) * SLOTS) >> 32);
     };
     const u128d mask = ((u128d)1 << (2 * k)) - 1;                  // k <= 63
-    uint32_t hs[PER];
+    uint32_t hs[PER], id[PER];                                     // home slot and table record of this lane's u-th k-mer (kNone: not ours)
 #pragma unroll
-    for (uint32_t u = 0; u < PER; ++u) {                           // record r = u * threads + t = k-mer r % w of super-k-mer q0 + r / w
+    for (uint32_t u = 0; u < PER; ++u) {                           // place r = u * threads + t = k-mer r % w of super-k-mer q0 + r / w
         const uint32_t r = u * kKeySortThreads + t;
-        hs[u] = 0;
+        hs[u] = 0; id[u] = kNone;
         if (r >= n) continue;
         const spsp_superkmer e = sk[q0 + r / w];
         const uint32_t j = r % w;
-        if (e.len < k || j > e.len - k) { k_mn[r] = kNone; continue; }
+        if (e.len < k || j > e.len - k) continue;
         const uint32_t* sw = skw + (r / w) * CH;
         u128d fwd = 0, rc = 0;
         if (!HAS_HI) {
@@ -295,15 +299,26 @@ __global__ __launch_bounds__(kKeySortThreads) void k_keys_fused(const uint8_t* _
         const u128d canon = fwd < rc ? fwd : rc;
         const uint32_t mo = e.minimizer | (((e.rev ? rc : fwd) != canon) ? 0x80000000u : 0u);
         const uint64_t lo = (uint64_t)canon, hi = (uint64_t)(canon >> 64);
-        k_mn[r] = mo; k_lo[r] = lo;
-        if (HAS_HI) k_hi[r] = hi;
+        if (S > 1) {                                               // both orientations of a canonical k-mer go to the same class
+            uint64_t hc = keys_mix(lo ^ 0xA0761D6478BD642FULL);
+            hc = keys_mix(hc + (uint64_t)e.minimizer * 0xE7037ED1A0B428DBULL);
+            if (HAS_HI) hc = keys_mix(hc ^ hi);
+            if ((uint32_t)(((hc >> 32) * S) >> 32) != cls) continue;
+        }
+        const uint32_t i = atomicAdd(&s_count, 1u);
+        if (i >= CAP) continue;                                    // (reported below: the class is fuller than its table)
+        id[u] = i;
+        k_mn[i] = mo; k_lo[i] = lo;
+        if (HAS_HI) k_hi[i] = hi;
         hs[u] = home(mo, lo, hi);
     }
     __syncthreads();
+    const uint32_t n_mine = s_count;
+    if (n_mine > CAP) { if (t == 0) { distinct[seg] = 0; atomicOr(&flags[0], 1u); atomicMax(&flags[1], n); } return; }
 #pragma unroll
     for (uint32_t u = 0; u < PER; ++u) {
-        const uint32_t r = u * kKeySortThreads + t;
-        if (r >= n || k_mn[r] == kNone) continue;
+        const uint32_t r = id[u];
+        if (r == kNone) continue;
         const uint32_t mo = k_mn[r];
         const uint64_t lo = k_lo[r], hi = HAS_HI ? k_hi[r] : 0ull;
         uint32_t h = hs[u];
@@ -324,9 +339,9 @@ __global__ __launch_bounds__(kKeySortThreads) void k_keys_fused(const uint8_t* _
     uint32_t keep[PER];
 #pragma unroll
     for (uint32_t u = 0; u < PER; ++u) {
-        const uint32_t r = u * kKeySortThreads + t;
+        const uint32_t r = id[u];
         keep[u] = 0;
-        if (r >= n || k_mn[r] == kNone) continue;
+        if (r == kNone) continue;
         const uint32_t wd = slot[hs[u]];
         if ((wd & 0x1fffu) != r + 1 || !usable(wd)) continue;      // one lane per (key, orientation) group: its claimer
         const uint32_t mo = k_mn[r];
@@ -362,22 +377,22 @@ __global__ __launch_bounds__(kKeySortThreads) void k_keys_fused(const uint8_t* _
     }
 #pragma unroll
     for (uint32_t u = 0; u < PER; ++u) {
-        const uint32_t r = u * kKeySortThreads + t;
+        const uint32_t r = id[u];
         if (!keep[u]) continue;
         r_mn[r0 + rank[u]] = k_mn[r] & 0x7fffffffu; r_lo[r0 + rank[u]] = k_lo[r];
         if (HAS_HI) r_hi[r0 + rank[u]] = k_hi[r];
     }
-    if (t == 0) distinct[g] = base;
+    if (t == 0) distinct[seg] = base;
 }
 
 __global__ __launch_bounds__(256) void k_keys_compact(const uint32_t* __restrict__ r_mn, const uint64_t* __restrict__ r_lo,
                                                      const uint64_t* __restrict__ r_hi, const uint32_t* __restrict__ raw_off,
                                                      const uint32_t* __restrict__ distinct, const uint32_t* __restrict__ out_off,
                                                      uint32_t* __restrict__ o_mn, uint64_t* __restrict__ o_lo, uint64_t* __restrict__ o_hi,
-                                                     uint32_t n_genomes, uint32_t* __restrict__ flags, uint32_t* __restrict__ host_out) {
-    const uint32_t g = blockIdx.y;
+                                                     uint32_t n_genomes, uint32_t per_genome, uint32_t* __restrict__ flags, uint32_t* __restrict__ host_out) {
+    const uint32_t g = blockIdx.y;                            // segment: a genome (sorted form) or one hash class of a genome (unordered form)
     __shared__ uint32_t s_o0;
-    if (!out_off) {                                          // unordered form: no scan launch in front -- the counts of the genomes before this one
+    if (!out_off) {                                          // unordered form: no scan launch in front -- the counts of the segments before this one
         uint32_t part = 0;
         for (uint32_t j = threadIdx.x; j < g; j += 256) part += distinct[j];
 #pragma unroll
@@ -394,9 +409,9 @@ __global__ __launch_bounds__(256) void k_keys_compact(const uint32_t* __restrict
         if (o_hi) o_hi[o0 + e] = r_hi[r0 + e];
     }
     // the offsets and the overflow report travel to pinned host memory from here: the job ends with this kernel
-    if (blockIdx.x == 0) {
-        if (threadIdx.x == 0) host_out[g] = o0;
-        if (g == n_genomes - 1 && threadIdx.x == 0) { host_out[n_genomes] = o0 + n; host_out[n_genomes + 1] = flags[0]; host_out[n_genomes + 2] = flags[1]; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (g % per_genome == 0) host_out[g / per_genome] = o0;
+        if (g == n_genomes * per_genome - 1) { host_out[n_genomes] = o0 + n; host_out[n_genomes + 1] = flags[0]; host_out[n_genomes + 2] = flags[1]; }
     }
 }
 
@@ -413,7 +428,9 @@ int sketch_keys_begin_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d
     const uint32_t n = (uint32_t)n_sk;
     const bool has_hi = p->k > 32;
     const uint64_t bound = (uint64_t)n * (p->k - p->m + 1);        // raw keys: a super-k-mer holds at most k - m + 1 k-mers
-    if (bound > 0xfffffff0ull) { set_error("too many selected k-mers for one call"); return SPSP_ERR_OVERFLOW; }
+    if (bound * (unordered ? kDedupSplit : 1) > 0xfffffff0ull) { set_error("too many selected k-mers for one call"); return SPSP_ERR_OVERFLOW; }
+    const uint64_t stage = bound * (unordered ? kDedupSplit : 1);  // (every hash class of a genome has room for all of its keys)
+    const uint32_t segs = n_genomes * (unordered ? kDedupSplit : 1);
     // pinned staging: first_rec in, offsets + flags out
     const size_t need = (size_t)(n_genomes + 1) + (size_t)(n_genomes + 3);
     if (ctx->h_keys_cap < need) {
@@ -426,15 +443,15 @@ int sketch_keys_begin_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d
     memcpy(ctx->h_keys, h_first_rec, (size_t)(n_genomes + 1) * 4);
     uint32_t* h_out = ctx->h_keys + (n_genomes + 1);
     if ((rc = ctx->a_cnt.reserve((size_t)(n + 1) * 4)) || (rc = ctx->a_off.reserve((size_t)(n + 2) * 4)) ||
-        (rc = ctx->a_mn.reserve((size_t)bound * 4 + 64)) || (rc = ctx->a_lo.reserve((size_t)bound * 8 + 64)) ||
-        (has_hi && (rc = ctx->a_hi.reserve((size_t)bound * 8 + 64))) || (rc = ctx->a_flags.reserve((size_t)bound + 64)) ||
-        (rc = ctx->dc_meta.reserve((size_t)(n_genomes + 2) * 4 * 4 + 64)) ||
+        (rc = ctx->a_mn.reserve((size_t)stage * 4 + 64)) || (rc = ctx->a_lo.reserve((size_t)stage * 8 + 64)) ||
+        (has_hi && (rc = ctx->a_hi.reserve((size_t)stage * 8 + 64))) || (rc = ctx->a_flags.reserve((size_t)bound + 64)) ||
+        (rc = ctx->dc_meta.reserve((size_t)(segs + 2) * 4 * 4 + 64)) ||
         (rc = ctx->c_min.reserve((size_t)bound * 4 + 64)) || (rc = ctx->c_lo.reserve((size_t)bound * 8 + 64)) ||
         (has_hi && (rc = ctx->c_hi.reserve((size_t)bound * 8 + 64)))) return rc;
     uint32_t* d_first_rec = ctx->dc_meta.as<uint32_t>();
-    uint32_t* d_raw_off = d_first_rec + (n_genomes + 2);
-    uint32_t* d_distinct = d_raw_off + (n_genomes + 2);
-    uint32_t* d_out_off = d_distinct + (n_genomes + 2);
+    uint32_t* d_raw_off = d_first_rec + (segs + 2);
+    uint32_t* d_distinct = d_raw_off + (segs + 2);
+    uint32_t* d_out_off = d_distinct + (segs + 2);
     if ((rc = ctx->c_flags.reserve(64))) return rc;
     uint32_t* d_flags = ctx->c_flags.as<uint32_t>() + 12;          // two words of the comparison's flag block that it does not use
     SPSP_HIP(hipMemcpyAsync(d_first_rec, ctx->h_keys, (size_t)(n_genomes + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -442,20 +459,21 @@ int sketch_keys_begin_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d
     const uint32_t ab = p->abundance ? p->abundance : 1u;
     if (unordered) {
         const uint32_t w = p->k - p->m + 1;
-        const size_t lds_d = has_hi ? (size_t)kDedupCapHi * 28 + kDedupSkmWords * 4 : (size_t)kDedupCapLo * 20 + kDedupSkmWords * 4;
+        const size_t lds_hi = (size_t)(kDedupCapHi / kDedupSplit) * 28 + kDedupSkmWords * 4, lds_lo = (size_t)(kDedupCapLo / kDedupSplit) * 20 + kDedupSkmWords * 4;
+        const size_t lds_d = has_hi ? lds_hi : lds_lo;
         if (!ctx->attr_dedupe_set) {
-            SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keys_fused<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kDedupCapHi * 28 + kDedupSkmWords * 4)));
-            SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keys_fused<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kDedupCapLo * 20 + kDedupSkmWords * 4)));
+            SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keys_fused<true, kDedupSplit>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hi));
+            SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keys_fused<false, kDedupSplit>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lo));
             ctx->attr_dedupe_set = true;
         }
-        if (has_hi) hipLaunchKernelGGL(k_keys_fused<true>, dim3(n_genomes), dim3(kKeySortThreads), lds_d, ctx->stream, d_bases, packed, n_bases_readable, d_rec_off, d_sk, n, d_first_rec,
-                                       p->k, w, ab, ctx->a_mn.as<uint32_t>(), ctx->a_lo.as<uint64_t>(), ctx->a_hi.as<uint64_t>(), d_raw_off, d_distinct, d_flags);
-        else hipLaunchKernelGGL(k_keys_fused<false>, dim3(n_genomes), dim3(kKeySortThreads), lds_d, ctx->stream, d_bases, packed, n_bases_readable, d_rec_off, d_sk, n, d_first_rec,
-                                p->k, w, ab, ctx->a_mn.as<uint32_t>(), ctx->a_lo.as<uint64_t>(), (uint64_t*)nullptr, d_raw_off, d_distinct, d_flags);
+        if (has_hi) hipLaunchKernelGGL((k_keys_fused<true, kDedupSplit>), dim3(segs), dim3(kKeySortThreads), lds_d, ctx->stream, d_bases, packed, n_bases_readable, d_rec_off, d_sk, n,
+                                       d_first_rec, p->k, w, ab, (uint32_t)bound, ctx->a_mn.as<uint32_t>(), ctx->a_lo.as<uint64_t>(), ctx->a_hi.as<uint64_t>(), d_raw_off, d_distinct, d_flags);
+        else hipLaunchKernelGGL((k_keys_fused<false, kDedupSplit>), dim3(segs), dim3(kKeySortThreads), lds_d, ctx->stream, d_bases, packed, n_bases_readable, d_rec_off, d_sk, n,
+                                d_first_rec, p->k, w, ab, (uint32_t)bound, ctx->a_mn.as<uint32_t>(), ctx->a_lo.as<uint64_t>(), (uint64_t*)nullptr, d_raw_off, d_distinct, d_flags);
         SPSP_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k_keys_compact, dim3(8, n_genomes), dim3(256), 0, ctx->stream, ctx->a_mn.as<uint32_t>(), ctx->a_lo.as<uint64_t>(),
+        hipLaunchKernelGGL(k_keys_compact, dim3(8, segs), dim3(256), 0, ctx->stream, ctx->a_mn.as<uint32_t>(), ctx->a_lo.as<uint64_t>(),
                            has_hi ? ctx->a_hi.as<uint64_t>() : (const uint64_t*)nullptr, d_raw_off, d_distinct, (const uint32_t*)nullptr, ctx->c_min.as<uint32_t>(),
-                           ctx->c_lo.as<uint64_t>(), has_hi ? ctx->c_hi.as<uint64_t>() : (uint64_t*)nullptr, n_genomes, d_flags, h_out);
+                           ctx->c_lo.as<uint64_t>(), has_hi ? ctx->c_hi.as<uint64_t>() : (uint64_t*)nullptr, n_genomes, kDedupSplit, d_flags, h_out);
         SPSP_HIP(hipGetLastError());
         if (!ctx->keys_done) SPSP_HIP(hipEventCreateWithFlags(&ctx->keys_done, hipEventDisableTiming));
         SPSP_HIP(hipEventRecord(ctx->keys_done, ctx->stream));
@@ -492,7 +510,7 @@ int sketch_keys_begin_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d
     if ((rc = launch_scan_u32(ctx, d_distinct, d_out_off, n_genomes, ctx->h_scalar + 7))) return rc;
     hipLaunchKernelGGL(k_keys_compact, dim3(8, n_genomes), dim3(256), 0, ctx->stream, ctx->a_mn.as<uint32_t>(), ctx->a_lo.as<uint64_t>(),
                        has_hi ? ctx->a_hi.as<uint64_t>() : (const uint64_t*)nullptr, d_raw_off, d_distinct, d_out_off, ctx->c_min.as<uint32_t>(),
-                       ctx->c_lo.as<uint64_t>(), has_hi ? ctx->c_hi.as<uint64_t>() : (uint64_t*)nullptr, n_genomes, d_flags, h_out);
+                       ctx->c_lo.as<uint64_t>(), has_hi ? ctx->c_hi.as<uint64_t>() : (uint64_t*)nullptr, n_genomes, 1u, d_flags, h_out);
     SPSP_HIP(hipGetLastError());
     if (!ctx->keys_done) SPSP_HIP(hipEventCreateWithFlags(&ctx->keys_done, hipEventDisableTiming));
     SPSP_HIP(hipEventRecord(ctx->keys_done, ctx->stream));
