@@ -291,7 +291,12 @@ def main():
     if device_keys:
         # a third stream on the small CUs for the key extraction, two key contexts per slot (one's arrays are read by the
         # comparison in flight while the other's are being rewritten)
-        if schedule == "partition":
+        keys_stream = os.environ.get("BENCH_KEYS_STREAM", "own")  # "own" | "cmp" (the comparisons' stream) | "dense" (behind every dense pass)
+        if keys_stream == "cmp":
+            stream_k = slots[0].stream_b
+        elif keys_stream == "dense":
+            stream_k = stream
+        elif schedule == "partition":
             masked.append(sp.stream_create_cus(local_rank, 0, small_cus))
             stream_k = torch.cuda.ExternalStream(masked[-1], device=dev)
         else:
@@ -303,7 +308,7 @@ def main():
             sl.keys_job = [False, False]
             for c in sl.keys:
                 if schedule == "partition":
-                    c.set_cu_count(small_cus)
+                    c.set_cu_count(dense_cus if keys_stream == "dense" else small_cus)
                 all_ctx.append(c)
     step_no = [0]                                             # steps queued so far: step i scans batch i % n_batches
 

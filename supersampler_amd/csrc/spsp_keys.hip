@@ -174,7 +174,7 @@ __global__ __launch_bounds__(kKeySortThreads) void k_keys_sort(uint32_t* __restr
 // unless the other orientation's group is usable too and comes first.  A tenth of the sorted form's time (its bitonic
 // sort is 91 barrier-separated passes over 13-byte records), which is what lets the key extraction run inside a 0.1 ms
 // step.
-constexpr uint32_t kDedupCapLo = 6144, kDedupCapHi = 4096, kDedupSkmWords = 4096, kDedupSplit = 2;   // k-mer places per genome; staged super-k-mer words (16 KiB); workgroups per genome
+constexpr uint32_t kDedupCapLo = 6144, kDedupCapHi = 4096, kDedupSkmWords = 4096;   // k-mer places per genome; staged super-k-mer words (16 KiB)
 __device__ __forceinline__ uint64_t keys_mix(uint64_t x) {
     x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ULL;
     x ^= x >> 27; x *= 0x94d049bb133111ebULL;
@@ -428,9 +428,13 @@ int sketch_keys_begin_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d
     const uint32_t n = (uint32_t)n_sk;
     const bool has_hi = p->k > 32;
     const uint64_t bound = (uint64_t)n * (p->k - p->m + 1);        // raw keys: a super-k-mer holds at most k - m + 1 k-mers
-    if (bound * (unordered ? kDedupSplit : 1) > 0xfffffff0ull) { set_error("too many selected k-mers for one call"); return SPSP_ERR_OVERFLOW; }
-    const uint64_t stage = bound * (unordered ? kDedupSplit : 1);  // (every hash class of a genome has room for all of its keys)
-    const uint32_t segs = n_genomes * (unordered ? kDedupSplit : 1);
+    // unordered form: one workgroup per genome, or -- SPSP_KEYS_SPLIT=2 -- two, each tabling one hash class of its keys in
+    // half the LDS (78 KiB: fits a CU beside a comparison workgroup; both roll all of the genome's k-mers)
+    static const uint32_t split_env = getenv("SPSP_KEYS_SPLIT") && atoi(getenv("SPSP_KEYS_SPLIT")) == 2 ? 2u : 1u;
+    const uint32_t split = unordered ? split_env : 1u;
+    if (bound * split > 0xfffffff0ull) { set_error("too many selected k-mers for one call"); return SPSP_ERR_OVERFLOW; }
+    const uint64_t stage = bound * split;                          // (every hash class of a genome has room for all of its keys)
+    const uint32_t segs = n_genomes * split;
     // pinned staging: first_rec in, offsets + flags out
     const size_t need = (size_t)(n_genomes + 1) + (size_t)(n_genomes + 3);
     if (ctx->h_keys_cap < need) {
@@ -459,21 +463,24 @@ int sketch_keys_begin_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d
     const uint32_t ab = p->abundance ? p->abundance : 1u;
     if (unordered) {
         const uint32_t w = p->k - p->m + 1;
-        const size_t lds_hi = (size_t)(kDedupCapHi / kDedupSplit) * 28 + kDedupSkmWords * 4, lds_lo = (size_t)(kDedupCapLo / kDedupSplit) * 20 + kDedupSkmWords * 4;
-        const size_t lds_d = has_hi ? lds_hi : lds_lo;
+        const size_t lds_d = (has_hi ? (size_t)(kDedupCapHi / split) * 28 : (size_t)(kDedupCapLo / split) * 20) + kDedupSkmWords * 4;
         if (!ctx->attr_dedupe_set) {
-            SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keys_fused<true, kDedupSplit>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_hi));
-            SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keys_fused<false, kDedupSplit>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lo));
+            SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keys_fused<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kDedupCapHi * 28 + kDedupSkmWords * 4)));
+            SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keys_fused<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kDedupCapLo * 20 + kDedupSkmWords * 4)));
+            SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keys_fused<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kDedupCapHi * 14 + kDedupSkmWords * 4)));
+            SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keys_fused<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kDedupCapLo * 10 + kDedupSkmWords * 4)));
             ctx->attr_dedupe_set = true;
         }
-        if (has_hi) hipLaunchKernelGGL((k_keys_fused<true, kDedupSplit>), dim3(segs), dim3(kKeySortThreads), lds_d, ctx->stream, d_bases, packed, n_bases_readable, d_rec_off, d_sk, n,
-                                       d_first_rec, p->k, w, ab, (uint32_t)bound, ctx->a_mn.as<uint32_t>(), ctx->a_lo.as<uint64_t>(), ctx->a_hi.as<uint64_t>(), d_raw_off, d_distinct, d_flags);
-        else hipLaunchKernelGGL((k_keys_fused<false, kDedupSplit>), dim3(segs), dim3(kKeySortThreads), lds_d, ctx->stream, d_bases, packed, n_bases_readable, d_rec_off, d_sk, n,
-                                d_first_rec, p->k, w, ab, (uint32_t)bound, ctx->a_mn.as<uint32_t>(), ctx->a_lo.as<uint64_t>(), (uint64_t*)nullptr, d_raw_off, d_distinct, d_flags);
+#define SPSP_KEYS_FUSED(HI, SP) hipLaunchKernelGGL((k_keys_fused<HI, SP>), dim3(segs), dim3(kKeySortThreads), lds_d, ctx->stream, d_bases, packed, n_bases_readable, d_rec_off, \
+                                                    d_sk, n, d_first_rec, p->k, w, ab, (uint32_t)bound, ctx->a_mn.as<uint32_t>(), ctx->a_lo.as<uint64_t>(),                   \
+                                                    HI ? ctx->a_hi.as<uint64_t>() : (uint64_t*)nullptr, d_raw_off, d_distinct, d_flags)
+        if (has_hi) { if (split == 2) SPSP_KEYS_FUSED(true, 2); else SPSP_KEYS_FUSED(true, 1); }
+        else { if (split == 2) SPSP_KEYS_FUSED(false, 2); else SPSP_KEYS_FUSED(false, 1); }
+#undef SPSP_KEYS_FUSED
         SPSP_HIP(hipGetLastError());
         hipLaunchKernelGGL(k_keys_compact, dim3(8, segs), dim3(256), 0, ctx->stream, ctx->a_mn.as<uint32_t>(), ctx->a_lo.as<uint64_t>(),
                            has_hi ? ctx->a_hi.as<uint64_t>() : (const uint64_t*)nullptr, d_raw_off, d_distinct, (const uint32_t*)nullptr, ctx->c_min.as<uint32_t>(),
-                           ctx->c_lo.as<uint64_t>(), has_hi ? ctx->c_hi.as<uint64_t>() : (uint64_t*)nullptr, n_genomes, kDedupSplit, d_flags, h_out);
+                           ctx->c_lo.as<uint64_t>(), has_hi ? ctx->c_hi.as<uint64_t>() : (uint64_t*)nullptr, n_genomes, split, d_flags, h_out);
         SPSP_HIP(hipGetLastError());
         if (!ctx->keys_done) SPSP_HIP(hipEventCreateWithFlags(&ctx->keys_done, hipEventDisableTiming));
         SPSP_HIP(hipEventRecord(ctx->keys_done, ctx->stream));
