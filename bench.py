@@ -490,6 +490,39 @@ def main():
         else:
             for key in tm:
                 tm[key] += t[key]
+    inter_nonzero_main = int(torch.count_nonzero(d_inter).item())
+    # Second, shorter timed region (single GPU): the OPEN step of rounds 1-2 -- the same scans, the comparison working on the
+    # keys of the setup's sketches (the same every step), no key extraction in the loop.  Reported beside the headline as
+    # `open_loop`: what the two kernels chains do when the hand-off between them is left out.
+    open_loop = None
+    if device_keys:
+        try:
+            for sl in slots:                              # finish what the closed steps left queued
+                if getattr(sl, "compare_queued", False):
+                    sl.cmp.compare_end()
+                    sl.compare_queued = False
+                for j in (0, 1):
+                    if sl.keys_job[j]:
+                        sl.keys[j].sketch_keys_device_end()
+                        sl.keys_job[j] = False
+                sl.keys_reader = None
+            closed_keys_total = last.get("keys_total")
+            device_keys = False
+            n_open = min(args.steps, 200)
+            run_steps(max(args.warmup, 10))
+            fence()
+            t0 = time.perf_counter()
+            run_steps(n_open)
+            fence()
+            e_open = time.perf_counter() - t0
+            open_loop = {"steps": n_open, "ms_per_step": e_open * 1e3 / n_open, "value": float(kmers_per_step) * n_open / e_open,
+                         "what": "scan(batch t) || all-vs-all(keys of the SETUP's sketches, the same every step): the step of rounds 1 and 2, "
+                                 "without the key extraction between the two halves"}
+            device_keys = True
+            last["keys_total"] = closed_keys_total
+        except Exception as e:  # noqa: BLE001
+            open_loop = {"error": repr(e)}
+            device_keys = True
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     agg = torch.tensor([float(kmers_per_step), tm["dense_ms"], tm["compare_ms"], tm["scan_ms"], tm["accumulate_ms"]],
@@ -507,7 +540,7 @@ def main():
     elapsed = float(el.item())
 
     # sanity: the comparison produced something (family structure => shared k-mers)
-    inter_nonzero = int(torch.count_nonzero(d_inter).item())
+    inter_nonzero = inter_nonzero_main
     # untimed cross-check of the two exchange forms: the key-partitioned result must equal the
     # all-gather + owned-rows result on every rank count
     exchange_check = None
@@ -597,6 +630,7 @@ def main():
                          "compare_pipeline": compare_avg_ms if tm["compare_calls"] else None,
                          "accumulate_kernel": acc_ms / tm["accumulate_launches"] if tm["accumulate_launches"] else None},
             "superkmers_per_step": int(n_out), "inter_nonzero": inter_nonzero,
+            **({"open_loop": open_loop} if open_loop is not None else {}),
             "host_ms_per_step": {"queueing": host["queue"] * 1e3 / args.steps, "waiting": host["collect"] * 1e3 / args.steps},
             "roofline": {"kernel": "k_dense_pair (non-temporal 16-byte loads, 2-bit pack, LDS pair-table test of every m-mer position; XXH64 on survivors)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
