@@ -153,7 +153,9 @@ def main():
         pass
 
     slots = []
-    for i in range(int(os.environ.get("BENCH_SLOTS", "2")) if pipelined else 1):
+    # (four steps in flight: the closed step has more host work per visit -- two more queueing calls -- and the scans'
+    # sparse stages finish later beside the key extraction: 0.134 / 0.127 / 0.124 ms per step with 2 / 3 / 4 slots)
+    for i in range(int(os.environ.get("BENCH_SLOTS", "4")) if pipelined else 1):
         sl = Slot()
         if pipelined:
             sl.stream_a = stream if (i == 0 or schedule != "streams") else torch.cuda.Stream(device=dev)
@@ -363,22 +365,33 @@ def main():
                 nxt.handle = nxt.exchange.begin(d_my_min.data_ptr(), d_my_lo.data_ptr(), None, my_sk_off)
 
     def collect_step(sl):
+        tq = time.perf_counter()
         d_out, n_out = sl.scan.scan_device_end()
+        host_detail["scan_end"] = host_detail.get("scan_end", 0.0) + time.perf_counter() - tq
         if device_keys:
             # stream B of this slot, in this order: [comparison of the keys made one visit ago] -> [keys of the scan collected now].
             # The key arrays belong to the context: the comparison that reads them is queued in front of the extraction that
             # rewrites them, and nothing here waits for work queued in this same visit.
+            tr0 = time.perf_counter()
             sl.cmp.compare_end()                          # the comparison queued one visit ago (it read the arrays rewritten below)
             sl.compare_queued = False
+            tr1 = time.perf_counter()
             kprev, kcur = sl.kv ^ 1, sl.kv
             if sl.keys_job[kprev]:
                 d_mn, d_lo, _, koff = sl.keys[kprev].sketch_keys_device_end()   # queued one visit ago: long done
                 sl.keys_job[kprev] = False
                 last["keys_total"] = int(koff[-1])
+                tr2 = time.perf_counter()
                 sl.cmp.compare_device_begin(K, d_mn, d_lo, None, koff, n_total, 0, 1, sl.d_inter.data_ptr())      # stream B
                 sl.compare_queued = True
+            else:
+                tr2 = tr1
+            tr3 = time.perf_counter()
             sl.keys[kcur].sketch_keys_device_begin(p, scan_args[sl.batch][1], scan_args[sl.batch][2], d_off.data_ptr(), d_out, n_out, first_rec,
                                                    unordered=True)                                                  # stream K
+            tr4 = time.perf_counter()
+            for name, dt in (("compare_end", tr1 - tr0), ("keys_end", tr2 - tr1), ("compare_begin", tr3 - tr2), ("keys_begin", tr4 - tr3)):
+                host_detail[name] = host_detail.get(name, 0.0) + dt
             sl.keys_job[kcur] = True
             sl.keys_reader = sl.keys[kcur]
             sl.kv ^= 1
@@ -439,6 +452,7 @@ def main():
             collect_step(pending.popleft())
 
     last = {"n_out": 0, "slot": slots[0], "n_out_batch": {}}
+    host_detail = {}                        # closed step: host seconds per call of a visit
     host = {"queue": 0.0, "collect": 0.0}   # host seconds spent queueing / waiting (pipelined mode)
 
     def fence():
@@ -471,10 +485,13 @@ def main():
         c.timing_read()
     fence()
     host["queue"] = host["collect"] = 0.0
+    host_detail.clear()
     t0 = time.perf_counter()
     run_steps(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
+    host_main = {"queueing": host["queue"] * 1e3 / args.steps, "waiting": host["collect"] * 1e3 / args.steps,
+                 **{("in_" + k): v * 1e3 / args.steps for k, v in host_detail.items()}}
     if stay_on_b:
         torch.cuda.set_stream(stream)
     n_out = last["n_out_batch"].get(0, last["n_out"])       # batch 0 = the records the oracle is run over (cpu_baseline)
@@ -631,7 +648,7 @@ def main():
                          "accumulate_kernel": acc_ms / tm["accumulate_launches"] if tm["accumulate_launches"] else None},
             "superkmers_per_step": int(n_out), "inter_nonzero": inter_nonzero,
             **({"open_loop": open_loop} if open_loop is not None else {}),
-            "host_ms_per_step": {"queueing": host["queue"] * 1e3 / args.steps, "waiting": host["collect"] * 1e3 / args.steps},
+            "host_ms_per_step": host_main,
             "roofline": {"kernel": "k_dense_pair (non-temporal 16-byte loads, 2-bit pack, LDS pair-table test of every m-mer position; XXH64 on survivors)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "algorithmic_bytes_per_launch": int(d_bases.numel()),

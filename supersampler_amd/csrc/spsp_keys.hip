@@ -360,27 +360,26 @@ __global__ __launch_bounds__(kKeySortThreads) void k_keys_fused(const uint8_t* _
         }
         keep[u] = emit;
     }
-    // ranks in record order: lane t holds records t, t + threads, ...: a prefix per u-plane, planes one after the other
-    uint32_t base = 0, rank[PER];
+    // places in the output: one workgroup prefix over the lanes' counts, a lane's keys one after the other (the order of the
+    // keys inside a genome means nothing in this form)
+    uint32_t cnt = 0;
 #pragma unroll
-    for (uint32_t u = 0; u < PER; ++u) {
-        uint32_t x = keep[u];
+    for (uint32_t u = 0; u < PER; ++u) cnt += keep[u];
+    uint32_t x = cnt;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d); if (lane >= (uint32_t)d) x += y; }
-        if (lane == 63) wave_sum[wid] = x;
-        __syncthreads();
-        uint32_t pre = 0, all = 0;
-        for (uint32_t w2 = 0; w2 < kKeySortThreads / 64; ++w2) { if (w2 < wid) pre += wave_sum[w2]; all += wave_sum[w2]; }
-        rank[u] = base + pre + x - keep[u];
-        base += all;
-        __syncthreads();
-    }
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d); if (lane >= (uint32_t)d) x += y; }
+    if (lane == 63) wave_sum[wid] = x;
+    __syncthreads();
+    uint32_t pre = 0, base = 0;
+    for (uint32_t w2 = 0; w2 < kKeySortThreads / 64; ++w2) { if (w2 < wid) pre += wave_sum[w2]; base += wave_sum[w2]; }
+    uint32_t at = r0 + pre + x - cnt;
 #pragma unroll
     for (uint32_t u = 0; u < PER; ++u) {
         const uint32_t r = id[u];
         if (!keep[u]) continue;
-        r_mn[r0 + rank[u]] = k_mn[r] & 0x7fffffffu; r_lo[r0 + rank[u]] = k_lo[r];
-        if (HAS_HI) r_hi[r0 + rank[u]] = k_hi[r];
+        r_mn[at] = k_mn[r] & 0x7fffffffu; r_lo[at] = k_lo[r];
+        if (HAS_HI) r_hi[at] = k_hi[r];
+        ++at;
     }
     if (t == 0) distinct[seg] = base;
 }
