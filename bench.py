@@ -3,8 +3,13 @@
 
 A "step" is one pass of the hot path over one batch of synthetic input that is
 already resident in HBM: the minimizer scan of this rank's genomes
-(spsp_scan_device) followed by this rank's share of the all-vs-all sketch
-comparison (spsp_compare_device).  Workload = BASELINE.json configs[1]:
+(spsp_scan_device), the comparator's keys of an earlier scan made on the device
+from its super-k-mer stream (spsp_sketch_keys_device: what the comparator would
+read from the sketch files of those genomes) and this rank's share of the
+all-vs-all comparison of earlier keys (spsp_compare_device) -- nothing from the
+setup inside the timed loop (single GPU; with N > 1 the comparison still works
+on the keys of the setup's sketches, see below).  Consecutive steps scan
+different batches (a ring of 3 x 500 MB).  Workload = BASELINE.json configs[1]:
 100 synthetic 5 Mbp genomes per GPU, k=31 m=11 s=1000.
 
 N > 1: genomes are sharded by rank (no data-path collective for the scan); the
@@ -12,8 +17,10 @@ comparison all-gathers the packed sketch keys over RCCL and every rank owns the
 rows i % N == rank of the (100 N) x (100 N) pair matrix.
 
 Besides the timed step, rank 0 of a single-GPU run measures (untimed, after the
-step loop) the comparator alone at BASELINE configs[2] scale (`compare`) and
-the whole-file drivers end to end (`end_to_end`), each beside the oracle.
+step loop): the open step of rounds 1-2 (`open_loop`), the comparator alone at
+BASELINE configs[2] and configs[3] scale (`compare`, `compare_c4`), the scan at
+the configs[4] shape (`scan_c5`) and the file-to-file drivers end to end
+(`end_to_end`), each beside the oracle.
 
 Prints ONE JSON line on rank 0.
 """

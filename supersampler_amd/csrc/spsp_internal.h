@@ -204,6 +204,8 @@ int gather_superkmers_impl(spsp_ctx* ctx, const uint8_t* d_bases, const uint64_t
                            uint64_t n_sk, uint8_t** h_compact, uint32_t** h_off, bool packed = false);
 // out[i] = sum(in[0..i)), out[n] = total (also stored to *total_host, pinned)
 int launch_scan_u32(spsp_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, uint64_t n, uint64_t* total_host);
+// zstr-style inflate of a whole buffer: gzip / zlib members, or the bytes as they are (spsp_host.cpp)
+int inflate_all_host(const uint8_t* in, size_t n, std::vector<uint8_t>& out);
 // host sketch builder over per-super-k-mer base pointers (spsp_host.cpp)
 // -a on the device (spsp_abund.hip): per k-mer occurrence of the gathered super-k-mers, bit 0 usable, bit 1 first of a dropped k-mer
 int abundance_flags_impl(spsp_ctx* ctx, const spsp_params* p, const spsp_superkmer* d_sk, uint64_t n_sk, uint8_t** h_flags, uint64_t* n_occ);
