@@ -162,7 +162,8 @@ def main():
     slots = []
     # (four steps in flight: the closed step has more host work per visit -- two more queueing calls -- and the scans'
     # sparse stages finish later beside the key extraction: 0.134 / 0.127 / 0.124 ms per step with 2 / 3 / 4 slots)
-    for i in range(int(os.environ.get("BENCH_SLOTS", "4")) if pipelined else 1):
+    # (the multi-GPU step, which still compares the setup's keys, keeps the two slots it was tuned with)
+    for i in range(int(os.environ.get("BENCH_SLOTS", "2" if use_dist else "4")) if pipelined else 1):
         sl = Slot()
         if pipelined:
             sl.stream_a = stream if (i == 0 or schedule != "streams") else torch.cuda.Stream(device=dev)
