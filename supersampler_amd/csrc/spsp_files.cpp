@@ -187,6 +187,7 @@ struct PipeFile {
     uint32_t first_rec = 0, n_rec = 0;
     uint64_t sk0 = 0, sk1 = 0;           // its super-k-mers in the batch's stream
     uint64_t total_superkmers = 0;       // SPSP_SCAN_STATS
+    bool done = false;                   // sketched and written already (one-job-per-file fallback of an over-large batch)
     spsp_sketch_stats st{};
 };
 
@@ -251,6 +252,7 @@ public:
         }
         if (times) memset(times, 0, sizeof *times);
         for (auto& s : slots_) {
+            if (!s) continue;                                // (context creation failed before this slot was reached)
             if (s->ctx && times) {
                 const spsp_stage_times& t = s->ctx->stages;
                 times->ingest_s += t.ingest_s; times->scan_s += t.scan_s; times->gather_s += t.gather_s;
@@ -503,6 +505,17 @@ private:
             return SPSP_OK;
         };
         rc = run();
+        if (rc == SPSP_ERR_OVERFLOW) {
+            // together the files exceed a limit of ONE job (32-bit offsets of the gathered super-k-mers at -s near 1, say):
+            // one job per file on this slot's context instead, the way spsp_sketch_file would have run them
+            for (auto& f : s.files) {
+                if (f.rc) continue;
+                f.rc = spsp_sketch_file(ctx, &p_, rate_, in_[f.index], out_[f.index], &f.st);
+                if (f.rc) f.err = spsp_last_error();
+                f.done = true;
+            }
+            rc = SPSP_OK;
+        }
         if (rc) { const std::string e = spsp_last_error(); for (auto& f : s.files) if (!f.rc) { f.rc = rc; f.err = e; } }
         s.left.store((int)s.files.size());
         for (size_t j = 0; j < s.files.size(); ++j) push([this, &s, j]() { finish(s, j); });
@@ -512,7 +525,7 @@ private:
     void finish(PipeSlot& s, size_t j) {
         PipeFile& f = s.files[j];
         uint8_t* payload = nullptr; uint64_t plen = 0;
-        if (!f.rc) {
+        if (!f.rc && !f.done) {
             double t0 = now_s();
             std::vector<spsp_superkmer> mine(s.sk.begin() + (ptrdiff_t)f.sk0, s.sk.begin() + (ptrdiff_t)f.sk1);
             for (auto& e : mine) e.rec -= f.first_rec;

@@ -1096,3 +1096,50 @@ def test_sketch_keys_on_device_equal_the_file_path(ctx, k, m, s, ab):
         with pytest.raises(sp.SpspError) as e:
             ctx.sketch_keys_device(p, d_b2.data_ptr(), len(bb), d_o2.data_ptr(), d_sk, n_sk, [0, 1])
         assert e.value.code == sp.ERR_OVERFLOW
+
+
+def test_sketch_keys_split_form_and_api_misuse(ctx):
+    """SPSP_KEYS_SPLIT=2 (two workgroups per genome, each tabling one hash class of its keys) gives the same key sets; a
+    second _begin on a context with a job pending and an _end without a job are refused; spsp_measure_hbm_device returns
+    rates a streaming kernel can have on this part."""
+    import torch
+    code = ("import sys\nsys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np, torch\nimport supersampler_amd as sp\nfrom supersampler_amd import synth\nfrom oracle import oracle_py as orc\n"
+            "k, m, s = 31, 11, 20.0\nrng = np.random.default_rng(5)\n"
+            "gs = [[synth.random_genome(rng, 50_000)], [synth.random_genome(rng, 30_000), synth.random_genome(rng, 20_000)], [synth.random_genome(rng, 10)]]\n"
+            "gs[1][1][:5000] = gs[0][0][:5000]\n"
+            "recs = [r for g in gs for r in g]\nfirst = np.cumsum([0] + [len(g) for g in gs]).astype(np.uint32)\n"
+            "bases, off = synth.concat_records(recs)\n"
+            "d_b = torch.from_numpy(np.concatenate([bases, np.zeros(64, np.uint8)])).cuda(); d_o = torch.from_numpy(off.view(np.int64)).cuda()\n"
+            "torch.cuda.synchronize()\nctx = sp.Context(0)\np = sp.make_params(k, m, s)\n"
+            "d_sk, n_sk = ctx.scan_device(p, d_b.data_ptr(), len(bases), d_o.data_ptr(), len(recs))\n"
+            "d_mn, d_lo, _, koff = ctx.sketch_keys_device(p, d_b.data_ptr(), len(bases), d_o.data_ptr(), d_sk, n_sk, first, unordered=True)\n"
+            "mn, lo = ctx.to_host(d_mn, int(koff[-1]), np.uint32), ctx.to_host(d_lo, int(koff[-1]), np.uint64)\n"
+            "for g, grecs in enumerate(gs):\n"
+            "    text = b''.join(synth.to_fasta(r, 'r%%d' %% j) for j, r in enumerate(grecs))\n"
+            "    _, _, w_mn, w_lo, _ = orc.sketch_keys(orc.sketch_fasta(text, k, m, s)[0])\n"
+            "    x, y = int(koff[g]), int(koff[g + 1])\n"
+            "    assert sorted(zip(mn[x:y].tolist(), lo[x:y].tolist())) == list(zip(w_mn.tolist(), w_lo.tolist())), g\n"
+            "assert int(koff[1]) > 1000\nprint('ok')\n") % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SPSP_KEYS_SPLIT="2"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+    rng = np.random.default_rng(6)
+    g = synth.random_genome(rng, 40_000)
+    bases, off = synth.concat_records([g])
+    d_b = torch.from_numpy(np.concatenate([bases, np.zeros(64, np.uint8)])).cuda()
+    d_o = torch.from_numpy(off.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    p = sp.make_params(31, 11, 20.0)
+    d_sk, n_sk = ctx.scan_device(p, d_b.data_ptr(), len(bases), d_o.data_ptr(), 1)
+    with pytest.raises(sp.SpspError):
+        ctx._keys_n = 1
+        ctx.sketch_keys_device_end()
+    ctx.sketch_keys_device_begin(p, d_b.data_ptr(), len(bases), d_o.data_ptr(), d_sk, n_sk, [0, 1])
+    with pytest.raises(sp.SpspError):
+        ctx.sketch_keys_device_begin(p, d_b.data_ptr(), len(bases), d_o.data_ptr(), d_sk, n_sk, [0, 1])
+    _, _, _, koff = ctx.sketch_keys_device_end()
+    assert int(koff[1]) > 1000
+    with pytest.raises(sp.SpspError):
+        ctx.sketch_keys_device_begin(p, d_b.data_ptr(), len(bases), d_o.data_ptr(), d_sk, n_sk, [1, 0])     # decreasing record ranges
+    rates = ctx.measure_hbm(256 << 20, 3)
+    assert 1000 < rates["copy_GBps"] < 8000 and 1000 < rates["read_GBps"] < 8000 and rates["bytes"] == 256 << 20
