@@ -74,12 +74,12 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     ctx = sp.Context(0)
     t0 = time.time()
-    n_scan = n_cmp = n_sk = n_ex = 0
+    n_scan = n_cmp = n_sk = n_ex = n_keys = n_files = 0
     modes = [sp.SPSP_SCAN_DEFAULT, sp.SPSP_SCAN_DIRECT_HASH, sp.SPSP_SCAN_LDS_FILTER, sp.SPSP_SCAN_PAIR_FILTER, sp.SPSP_SCAN_PAIR_FILTER, sp.SPSP_SCAN_BLOOM_FILTER]
     t_report = t0
     while time.time() - t0 < budget:
         if time.time() - t_report > 45:      # a long run must keep talking (the GPU pool kills silent commands)
-            print("  ... %d scans, %d sketch payloads, %d comparisons, %d exchanges after %.0f s" % (n_scan, n_sk, n_cmp, n_ex, time.time() - t0), flush=True)
+            print("  ... %d scans, %d sketch payloads, %d comparisons, %d exchanges, %d key extractions, %d files after %.0f s" % (n_scan, n_sk, n_cmp, n_ex, n_keys, n_files, time.time() - t0), flush=True)
             t_report = time.time()
         m = int(rng.choice([3, 5, 7, 9, 11, 13, 15]))
         k = int(rng.choice([x for x in range(max(m, 5) | 1, 64, 2)]))
@@ -150,6 +150,75 @@ def main():
                     print("CSV MISMATCH jac=%d prec=%d thr=%g nq=%d" % (jac, prec, thr, nqx))
                     sys.exit(1)
             n_ex += 1
+        if n_scan % 6 == 3:      # scan of several genomes at once -> the comparator's keys on the device, sorted and unordered, vs the oracle's file path
+            ng = int(rng.integers(1, 7))
+            groups = [random_genome(rng) for _ in range(ng)]
+            if rng.random() < 0.5 and ng > 1:
+                groups[1] = groups[0] + groups[1][:1]             # shared records: keys seen in two genomes, some twice in one
+            grecs = [r for g in groups for r in g]
+            first = np.cumsum([0] + [len(g) for g in groups]).astype(np.uint32)
+            gb, go = synth.concat_records(grecs)
+            ab = int(rng.choice([1, 1, 2, 3]))
+            pk = sp.make_params(k, m, s, abundance=ab, flags=mode)
+            d_b = torch.from_numpy(np.concatenate([gb, np.zeros(64, np.uint8)])).cuda()
+            d_o = torch.from_numpy(go.view(np.int64)).cuda()
+            torch.cuda.synchronize()
+            d_sk, n_skm = ctx.scan_device(pk, d_b.data_ptr(), len(gb), d_o.data_ptr(), len(grecs))
+            wants = []
+            for g in groups:
+                text = b"".join(synth.to_fasta(r, "r%d" % j) for j, r in enumerate(g)) if g else b">e\n"
+                wants.append(orc.sketch_keys(orc.sketch_fasta(text, k, m, s, ab)[0]))
+            for unordered in (False, True):
+                try:
+                    d_mn, d_lo, d_hi, koff = ctx.sketch_keys_device(pk, d_b.data_ptr(), len(gb), d_o.data_ptr(), d_sk, n_skm, first, unordered=unordered)
+                except sp.SpspError as e:
+                    if e.code != sp.ERR_OVERFLOW:
+                        raise
+                    continue                                      # a genome beyond the per-genome table: goes through files
+                tot = int(koff[-1])
+                mn, lo = ctx.to_host(d_mn, tot, np.uint32), ctx.to_host(d_lo, tot, np.uint64)
+                hi = ctx.to_host(d_hi, tot, np.uint64) if k > 32 else np.zeros(tot, np.uint64)
+                for gi, (_, _, w_mn, w_lo, w_hi) in enumerate(wants):
+                    x, y = int(koff[gi]), int(koff[gi + 1])
+                    if k == m and y == x and len(w_mn) == 1:
+                        continue                                  # the merge's phantom key of an empty sketch (spsp_sketch_chain_host): not in any file
+                    got_k = list(zip(mn[x:y].tolist(), hi[x:y].tolist(), lo[x:y].tolist()))
+                    if unordered:
+                        got_k = sorted(got_k)
+                    if got_k != list(zip(w_mn.tolist(), w_hi.tolist(), w_lo.tolist())):
+                        print("KEYS MISMATCH k=%d m=%d s=%g ab=%d mode=%d unordered=%d genome=%d of %d got=%d want=%d" % (k, m, s, ab, mode, unordered, gi, ng, y - x, len(w_mn)))
+                        np.save(os.path.join(ROOT, "gpurun_out", "soak_keys_bases.npy"), gb)
+                        np.save(os.path.join(ROOT, "gpurun_out", "soak_keys_offs.npy"), go)
+                        np.save(os.path.join(ROOT, "gpurun_out", "soak_keys_first.npy"), first)
+                        sys.exit(1)
+            n_keys += 1
+        if n_scan % 25 == 12:    # FASTA files -> sketch files through the batched pipeline, payload bytes and print_stat counters vs the oracle
+            import gzip
+            import shutil
+            import tempfile
+            tmp = tempfile.mkdtemp(prefix="soak_files_")
+            try:
+                nf = int(rng.integers(1, 12))
+                texts = [random_fasta_text(rng) if rng.random() < 0.6 else synth.to_fasta(np.concatenate(random_genome(rng) or [np.zeros(0, np.uint8)]), "g", n_records=int(rng.integers(1, 4)))
+                         for _ in range(nf)]
+                ins = []
+                for i, t in enumerate(texts):
+                    pth = os.path.join(tmp, "f%d.fa" % i) + (".gz" if i % 3 == 1 else "")
+                    open(pth, "wb").write(gzip.compress(t, 1) if i % 3 == 1 else t)
+                    ins.append(pth)
+                outs = [os.path.join(tmp, "o%d.gz" % i) for i in range(nf)]
+                s2 = float(np.float32(max(s, 1.0)))
+                ab = int(rng.choice([1, 1, 1, 2]))
+                res, _, _ = sp.sketch_files(ins, outs, k, m, s2, abundance=ab, threads=int(rng.integers(1, 9)), flags=mode | sp.SPSP_SCAN_STATS)
+                for i, (rc, st, err) in enumerate(res):
+                    want_pl, want_st = orc.sketch_fasta(texts[i], k, m, s2, ab)
+                    if rc != 0 or sp.read_file(outs[i]) != want_pl or st["total_superkmer_number"] != want_st["total_superkmer_number"] or st["nb_mmer_selected"] != want_st["nb_mmer_selected"]:
+                        print("FILES MISMATCH k=%d m=%d s=%g ab=%d mode=%d file %d of %d rc=%d err=%s" % (k, m, s2, ab, mode, i, nf, rc, err))
+                        open(os.path.join(ROOT, "gpurun_out", "soak_file.fa"), "wb").write(texts[i])
+                        sys.exit(1)
+                n_files += nf
+            finally:
+                shutil.rmtree(tmp, ignore_errors=True)
         if n_scan % 8 == 0:      # a comparison problem from sketches of related genomes
             n = int(rng.integers(2, 40))
             anc = synth.random_genome(rng, int(rng.integers(2000, 30_000)))
@@ -172,7 +241,8 @@ def main():
                 pickle.dump({"payloads": payloads, "nq": nq, "k": k, "m": m}, open(os.path.join(ROOT, "gpurun_out", "soak_cmp.pkl"), "wb"))
                 sys.exit(1)
             n_cmp += 1
-    print("soak ok: %d scans, %d sketch payloads, %d comparisons, %d exchanges + CSV pairs in %.0f s" % (n_scan, n_sk, n_cmp, n_ex, time.time() - t0))
+    sp.sketch_files_release()
+    print("soak ok: %d scans, %d sketch payloads, %d comparisons, %d exchanges + CSV pairs, %d key extractions, %d files through the pipeline in %.0f s" % (n_scan, n_sk, n_cmp, n_ex, n_keys, n_files, time.time() - t0))
 
 
 if __name__ == "__main__":
