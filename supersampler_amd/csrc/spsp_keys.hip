@@ -9,7 +9,8 @@
 //
 //     { (minimizer, canon(x)) :  x an oriented k-mer of a selected super-k-mer,  (occurrences of x) mod 256 >= abundance }
 //
-// which needs neither the string reconstruction nor the file.  This is that composition for MANY genomes at once --
+// (for k = m without the count condition: the reader takes the minimizer of every bucket that exists, see
+// sketch_keys_begin_impl) -- which needs neither the string reconstruction nor the file.  This is that composition for MANY genomes at once --
 // genome g = records [first_rec[g], first_rec[g+1]) of one scan -- producing the arrays spsp_compare_device takes:
 //
 //   k_keys_sizes    k-mers per selected super-k-mer -> (scan) first raw key of each
@@ -459,7 +460,10 @@ int sketch_keys_begin_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d
     uint32_t* d_flags = ctx->c_flags.as<uint32_t>() + 12;          // two words of the comparison's flag block that it does not use
     SPSP_HIP(hipMemcpyAsync(d_first_rec, ctx->h_keys, (size_t)(n_genomes + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
     SPSP_HIP(hipMemsetAsync(d_flags, 0, 8, ctx->stream));
-    const uint32_t ab = p->abundance ? p->abundance : 1u;
+    // k == m: a bucket's only k-mer is its minimizer, and the reader takes the minimizer of EVERY bucket that exists for a
+    // k-mer (an empty blob reads as the bare minimizer, Comparator.cpp:88-90,193-198) -- also of one whose k-mer stayed below
+    // -a or wrapped to 0: its map entry made the bucket exist (SubSampler.cpp:283-300).  The count rule does not apply.
+    const uint32_t ab = p->k == p->m ? 0u : (p->abundance ? p->abundance : 1u);
     if (unordered) {
         const uint32_t w = p->k - p->m + 1;
         const size_t lds_d = (has_hi ? (size_t)(kDedupCapHi / split) * 28 : (size_t)(kDedupCapLo / split) * 20) + kDedupSkmWords * 4;
