@@ -104,7 +104,7 @@ struct spsp_ctx {
     // spsp_sketch_keys_device_begin / _end (spsp_keys.hip)
     bool keys_pending = false, keys_has_hi = false, attr_keys_set = false, attr_dedupe_set = false;
     bool keys_unordered = false;       // spsp_compare_keys_unordered: the comparisons of this context do not insist on sorted sketches
-    uint32_t keys_genomes = 0, keys_cap = 0;
+    uint32_t keys_genomes = 0, keys_cap = 0, keys_skm_cap = 0;
     hipEvent_t keys_done = nullptr;
     uint32_t* h_keys = nullptr;        // pinned: genome record ranges in, key offsets + overflow report out
     size_t h_keys_cap = 0;

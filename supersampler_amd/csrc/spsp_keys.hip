@@ -24,6 +24,7 @@
 // A genome with more raw keys than the LDS sort holds (8192; 4096 with k > 32) is reported (SPSP_ERR_OVERFLOW): such
 // inputs go through the sketch files, whose reader has a host path for them.
 #include <cstring>
+#include <string>
 
 #include "spsp_internal.h"
 #include "spsp_device.h"
@@ -491,6 +492,7 @@ int sketch_keys_begin_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d
         ctx->keys_genomes = n_genomes;
         ctx->keys_has_hi = has_hi;
         ctx->keys_cap = has_hi ? kDedupCapHi : kDedupCapLo;
+        ctx->keys_skm_cap = kDedupSkmWords / (has_hi ? 8 : 4);
         return SPSP_OK;
     }
     if (n) {
@@ -527,7 +529,8 @@ int sketch_keys_begin_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d
     ctx->keys_pending = true;
     ctx->keys_genomes = n_genomes;
     ctx->keys_has_hi = has_hi;
-    ctx->keys_cap = unordered ? (has_hi ? kDedupCapHi : kDedupCapLo) : (has_hi ? kKeyCapHi : kKeyCapLo);
+    ctx->keys_cap = has_hi ? kKeyCapHi : kKeyCapLo;
+    ctx->keys_skm_cap = 0;
     return SPSP_OK;
 }
 
@@ -538,8 +541,8 @@ int sketch_keys_end_impl(spsp_ctx* ctx, void** d_mn, void** d_lo, void** d_hi, u
     const uint32_t n_genomes = ctx->keys_genomes;
     const uint32_t* h_out = ctx->h_keys + (n_genomes + 1);
     if (h_out[n_genomes + 1]) {
-        set_error("a genome has %u selected k-mer occurrences, more than the device's per-genome table holds (%u): sketch it through a file",
-                  h_out[n_genomes + 2], ctx->keys_cap);
+        set_error("a genome has %u selected k-mer places, more than the device's per-genome table holds (%u%s): sketch it through a file",
+                  h_out[n_genomes + 2], ctx->keys_cap, ctx->keys_skm_cap ? (", in at most " + std::to_string(ctx->keys_skm_cap) + " super-k-mers").c_str() : "");
         return SPSP_ERR_OVERFLOW;
     }
     for (uint32_t g = 0; g <= n_genomes; ++g) sk_off[g] = h_out[g];

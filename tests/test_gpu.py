@@ -1073,6 +1073,11 @@ def test_sketch_keys_on_device_equal_the_file_path(ctx, k, m, s, ab):
     assert (np.triu(d_inter.cpu().numpy(), 1) == np.triu(w_inter, 1)).all()
     # SPSP_KEYS_UNORDERED: the same key SETS from an LDS table per genome instead of a sort; a comparison that has been told
     # so takes them, one that has not refuses them (its order check is its duplicate check)
+    if k == m:       # (one k-mer per super-k-mer: thousands of super-k-mers per genome, more than the unordered form stages -- it says so)
+        with pytest.raises(sp.SpspError) as e:
+            ctx.sketch_keys_device(p, src, len(bases), d_o.data_ptr(), d_sk, n_sk, first_rec, unordered=True)
+        assert e.value.code == sp.ERR_OVERFLOW and "super-k-mers" in str(e.value)
+        return
     d_mn, d_lo, d_hi, sk_off2 = ctx.sketch_keys_device(p, src, len(bases), d_o.data_ptr(), d_sk, n_sk, first_rec, unordered=True)
     assert (sk_off2 == sk_off).all()
     total = int(sk_off2[-1])
