@@ -624,6 +624,7 @@ __global__ __launch_bounds__(kGroupThreads) void k_parts_group(const uint64_t* _
 // launches instead of four and moves a third of the bytes; it is what lets the comparison of bench.py's 100
 // sketches run beside a dense pass on 32 CUs instead of 64.
 constexpr int kSmallCap = 2048, kSmallSlots = 3968, kSmallN = 128, kSmallMean = 1450;
+constexpr int kSmallHl = kSmallCap + 3 * (kSmallCap / 2);   // lists of >= 2 holders padded to 4: at most cap / 2 such keys
 __global__ __launch_bounds__(kGroupThreads) void k_parts_group_small(const uint64_t* __restrict__ recs, const uint32_t* __restrict__ part_cnt,
                                                                     uint32_t n_sk, uint32_t* __restrict__ inter, uint32_t* __restrict__ flags) {
     constexpr uint32_t R = kSmallCap / kGroupThreads;     // records per thread
@@ -632,8 +633,8 @@ __global__ __launch_bounds__(kGroupThreads) void k_parts_group_small(const uint6
     uint32_t* k_mn = reinterpret_cast<uint32_t*>(k_lo + kSmallCap);         // [kSmallCap]
     uint32_t* slot = k_mn + kSmallCap;                                      // [kSmallSlots]
     uint32_t* mat = slot + kSmallSlots;                                     // [kSmallN * kSmallN / 2]: cell c in half c & 1 of word c >> 1
-    uint8_t* hl = reinterpret_cast<uint8_t*>(mat + kSmallN * kSmallN / 2);  // [kSmallCap]: holder lists, one byte per record
-    uint32_t* cursor = reinterpret_cast<uint32_t*>(hl + kSmallCap);
+    uint8_t* hl = reinterpret_cast<uint8_t*>(mat + kSmallN * kSmallN / 2);  // [kSmallHl]: holder lists of the keys held more than once, one byte per
+    uint32_t* cursor = reinterpret_cast<uint32_t*>(hl + kSmallHl);          // holder, every list on a 4-byte boundary (read a word at a time)
     const uint32_t p = blockIdx.x, t = threadIdx.x;
     const uint32_t n = part_cnt[p];
     if (n > (uint32_t)kSmallCap) { if (t == 0) atomicOr(&flags[6], 1u); return; }
@@ -681,24 +682,28 @@ __global__ __launch_bounds__(kGroupThreads) void k_parts_group_small(const uint6
     __syncthreads();
 #pragma unroll
     for (uint32_t u = 0; u < R; ++u)
-        if (claimer[u]) slot[hs[u]] = atomicAdd(cursor, cnt[u]);          // where the key's holders are listed in hl
+        if (claimer[u] && cnt[u] >= 2) slot[hs[u]] = atomicAdd(cursor, (cnt[u] + 3u) & ~3u);   // where the key's holders are listed in hl (4-aligned)
     __syncthreads();
 #pragma unroll
     for (uint32_t u = 0; u < R; ++u) {
         const uint32_t r = u * kGroupThreads + t;
-        if (r < n) hl[slot[hs[u]] + rank[u]] = (uint8_t)sk[u];
+        if (r < n && cnt[u] >= 2) hl[slot[hs[u]] + rank[u]] = (uint8_t)sk[u];
     }
     __syncthreads();
 #pragma unroll
     for (uint32_t u = 0; u < R; ++u) {
         const uint32_t r = u * kGroupThreads + t;
         if (r >= n || cnt[u] < 2) continue;               // held by one sketch: no pair to count
-        const uint32_t o = slot[hs[u]];
-        for (uint32_t j = 0; j < cnt[u]; ++j) {
-            const uint32_t other = hl[o + j];
-            if (other > sk[u]) {                          // (a sketch holds a key at most once: the scatter checked the order)
-                const uint32_t cell = sk[u] * kSmallN + other;
-                atomicAdd(&mat[cell >> 1], (cell & 1u) ? 0x10000u : 1u);    // a part holds 2048 records: no half overflows
+        const uint32_t* hw = reinterpret_cast<const uint32_t*>(hl + slot[hs[u]]);
+        for (uint32_t j = 0; j < cnt[u]; j += 4) {        // four holders per LDS word (the byte-wise walk was 17 of the kernel's ~30 LDS instructions per record)
+            const uint32_t four = hw[j >> 2];
+#pragma unroll
+            for (uint32_t b = 0; b < 4; ++b) {
+                const uint32_t other = (four >> (8 * b)) & 0xffu;
+                if (j + b < cnt[u] && other > sk[u]) {    // (a sketch holds a key at most once: the scatter checked the order)
+                    const uint32_t cell = sk[u] * kSmallN + other;
+                    atomicAdd(&mat[cell >> 1], (cell & 1u) ? 0x10000u : 1u);    // a part holds 2048 records: no half overflows
+                }
             }
         }
     }
@@ -1291,7 +1296,7 @@ static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t*
         return SPSP_OK;
     };
     if (!has_hi) J->group_small = [=](uint32_t n_parts) -> int {
-        const size_t lds = (size_t)kSmallCap * (8 + 4 + 1) + (size_t)kSmallSlots * 4 + (size_t)kSmallN * kSmallN * 2 + 16;
+        const size_t lds = (size_t)kSmallCap * (8 + 4) + (size_t)kSmallHl + (size_t)kSmallSlots * 4 + (size_t)kSmallN * kSmallN * 2 + 16;
         if (!ctx->attr_small_set) {
             SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_parts_group_small), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             ctx->attr_small_set = true;
