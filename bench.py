@@ -486,7 +486,8 @@ def main():
         kinds = 0
     # every 8th dense pass is bracketed: two event packets per launch cost the pipelined step 8.6 us of 123 (measured,
     # BENCH_STAGE_TIMING=off); BENCH_TIMING_EVERY=1 brackets them all
-    timing_every = int(os.environ.get("BENCH_TIMING_EVERY", "8")) if pipelined and kinds == sp.TIME_DENSE else 1
+    # (short runs -- the driver's --steps 20 -- bracket every 4th, so that a handful of launches is behind `roofline.achieved`)
+    timing_every = int(os.environ.get("BENCH_TIMING_EVERY", "8" if args.steps >= 64 else "4")) if pipelined and kinds == sp.TIME_DENSE else 1
     for c in all_ctx:
         c.timing_enable(True, kinds)
         c.timing_sample(timing_every)
