@@ -99,7 +99,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    # BENCH_FORCE_DIST=1 takes the multi-GPU code path (RCCL key all-gather, strided rows) even with one rank,
+    # BENCH_FORCE_DIST=1 takes the multi-GPU code path (RCCL key all-gather, row ownership) even with one rank,
     # so that path can be rehearsed on a single-GPU box
     use_dist = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
     if use_dist:
@@ -132,12 +132,13 @@ def main():
     # -- the dense passes run back to back and nothing that shares a CU with them slows them down
     schedule = os.environ.get("BENCH_SCHEDULE", "partition")
     tail_streams = schedule in ("tail", "partition")
-    # CUs of the small streams: a rank's share of the comparison grows with the world size (all keys are partitioned on
-    # every rank, the rows are shared out), so its streams get more of the chip -- measured with BENCH_SIM_WORLD
-    # (tools/sim_world_sweep.sh, ms per step at 64 / 96 / 128 CUs): W = 2: 0.113 / 0.124 / 0.143, W = 4: 0.156 / 0.135 /
-    # 0.150, W = 8: 0.267 / 0.197 / 0.167
+    # CUs of the small streams: a rank's share of the comparison grows with the world size (every rank streams the other
+    # ranks' keys through its filter), so its streams get more of the chip -- measured with BENCH_SIM_WORLD (rank 0's
+    # share, the largest; tools/sim_world_sweep.sh, ms per step at 64 / 96 / 128 CUs, rows in blocks): W = 2: 0.115 /
+    # 0.124 / 0.144, W = 4: 0.142 / 0.124 / 0.147, W = 8: 0.185 / 0.149 / 0.148 (round 2, strided rows, every key
+    # dealt on every rank: W = 4: 0.156 / 0.135 / 0.150, W = 8: 0.267 / 0.197 / 0.167)
     sim_w = max(world, int(os.environ.get("BENCH_SIM_WORLD", "1")))
-    small_cus = int(os.environ.get("BENCH_SMALL_CUS", "64" if sim_w <= 2 else "96" if sim_w <= 4 else "128"))
+    small_cus = int(os.environ.get("BENCH_SMALL_CUS", "64" if sim_w <= 2 else "96"))
     ctx_full, full_stream = ctx, stream                   # whole-device context: setup and the extras
     if schedule == "partition" and pipelined:
         try:                                              # (a runtime without CU masks: fall back to the unpartitioned schedule)
@@ -247,7 +248,10 @@ def main():
     sim_world = int(os.environ.get("BENCH_SIM_WORLD", "1")) if not use_dist else 1
     my_sk_off = np.zeros(args.genomes + 1, dtype=np.uint64)
     my_sk_off[1:] = np.cumsum(my_n)
-    # multi-GPU exchange: north_star's form (RCCL all-gather of the packed keys + strided row ownership) by default;
+    # rows of the pair matrix a rank owns after the all-gather: the BLOCK of the sketches it scanned (default: its
+    # dictionary holds its own keys + what passes the filter) or every world-th row (BENCH_ROWS=strided)
+    row_form = os.environ.get("BENCH_ROWS", "block")
+    # multi-GPU exchange: north_star's form (RCCL all-gather of the packed keys + row ownership) by default;
     # BENCH_EXCHANGE=slots selects the key-partitioned all-to-all + partial-matrix reduction (DESIGN.md 5 prices both)
     exchange_kind = os.environ.get("BENCH_EXCHANGE", "gather") if use_dist else "none"
     if exchange_kind == "slots":      # key-partitioned: all-to-all of own keys + all-reduce of partial matrices
@@ -256,14 +260,15 @@ def main():
                                            reduce=os.environ.get("BENCH_SLOT_REDUCE", "scatter"))
         sk_off = np.zeros(n_total + 1, dtype=np.uint64)
         sk_off[-1] = slots[0].exchange.max_keys * world           # log line only
-    elif exchange_kind == "gather":   # all-gather of every rank's keys + strided row ownership
+    elif exchange_kind == "gather":   # all-gather of every rank's keys; a rank owns the rows of the sketches it scanned
         for sl in slots:
-            sl.exchange = spd.KeyExchange(my_n, dev, stream=sl.stream_b)
+            sl.exchange = spd.KeyExchange(my_n, dev, stream=sl.stream_b, rows=row_form)
         sk_off = slots[0].exchange.sk_off
     elif sim_world > 1:
         # BENCH_SIM_WORLD=W on one GPU (analysis only, the line is not a measurement): this rank's share of the
-        # comparison at world size W -- the keys of W x genomes sketches resident (as after the all-gather), rows
-        # i % W == 0 -- next to the usual scan, to size the CU partition for W ranks; no exchange is simulated
+        # comparison at world size W -- the keys of W x genomes sketches resident (as after the all-gather), the rows
+        # of rank 0 (its own block, which sees every other rank's keys; BENCH_ROWS=strided: rows i % W == 0) -- next
+        # to the usual scan, to size the CU partition for W ranks; no exchange is simulated
         mins, los, ns = [my_min], [my_lo], [my_n]
         for r in range(1, sim_world):
             for g in synth.family_genomes(2 + 1000 * r, args.genomes, args.length, N_FAMILIES, MUS):
@@ -279,6 +284,12 @@ def main():
         sk_off = np.zeros(n_total + 1, dtype=np.uint64)
         sk_off[1:] = np.cumsum(my_n)
         d_all_min, d_all_lo = d_my_min, d_my_lo
+    if exchange_kind == "gather":
+        row_args = slots[0].exchange.row_args()
+    elif sim_world > 1:
+        row_args = (0, 1, args.genomes) if row_form == "block" else (0, sim_world, n_total)
+    else:
+        row_args = (0, 1, n_total)
     for sl in slots:
         sl.d_inter = torch.zeros((n_total, n_total), dtype=torch.int32, device=dev)
     d_inter = slots[0].d_inter
@@ -348,8 +359,8 @@ def main():
             if schedule != "partition":
                 sl.cmp.wait_dense(sl.scan)                # the comparison starts behind this step's dense pass
             if not skip_compare and not (device_keys and getattr(sl, "compare_queued", False)):
-                sl.cmp.compare_device_begin(K, d_all_min.data_ptr(), d_all_lo.data_ptr(), None, sk_off, n_total, rank, max(world, sim_world),
-                                            sl.d_inter.data_ptr())                                         # stream B
+                sl.cmp.compare_device_begin(K, d_all_min.data_ptr(), d_all_lo.data_ptr(), None, sk_off, n_total, row_args[0], row_args[1],
+                                            sl.d_inter.data_ptr(), n_query=row_args[2])                    # stream B
                 sl.compare_queued = True
             return
         with on_b(sl):
@@ -362,8 +373,8 @@ def main():
             else:
                 g = sl.exchange.exchange(d_my_min, d_my_lo)
                 sl.cmp.wait_dense(sl.scan)
-                sl.cmp.compare_device_begin(K, g.minimizer.data_ptr(), g.kmer_lo.data_ptr(), None, sk_off, n_total, rank,
-                                            world, sl.d_inter.data_ptr())
+                sl.cmp.compare_device_begin(K, g.minimizer.data_ptr(), g.kmer_lo.data_ptr(), None, sk_off, n_total, row_args[0],
+                                            row_args[1], sl.d_inter.data_ptr(), n_query=row_args[2])
 
         if exchange_kind == "slots" and nxt is not None and nxt is not sl and getattr(nxt, "handle", None) is None:
             # the NEXT step's key partition + RCCL all-to-all: behind this step's dense pass, long before the next
@@ -435,7 +446,7 @@ def main():
                         mn_ptr, lo_ptr = g.minimizer.data_ptr(), g.kmer_lo.data_ptr()
                     else:
                         mn_ptr, lo_ptr = d_all_min.data_ptr(), d_all_lo.data_ptr()
-                    ctx.compare_device(K, mn_ptr, lo_ptr, None, sk_off, n_total, rank, max(world, sim_world), sl.d_inter.data_ptr())
+                    ctx.compare_device(K, mn_ptr, lo_ptr, None, sk_off, n_total, row_args[0], row_args[1], sl.d_inter.data_ptr(), n_query=row_args[2])
                     if exchange_kind == "gather":
                         sl.exchange.collect_rows(sl.d_inter)
                 last["n_out"], last["slot"] = n_out, sl
@@ -578,14 +589,15 @@ def main():
                 ge = spd.KeyExchange(my_n, dev)
                 g = ge.exchange(d_my_min, d_my_lo)
                 d_ref = torch.zeros_like(d_inter)
-                ctx.compare_device(K, g.minimizer.data_ptr(), g.kmer_lo.data_ptr(), None, ge.sk_off, n_total, rank, world,
-                                   d_ref.data_ptr())
+                ra = ge.row_args()
+                ctx.compare_device(K, g.minimizer.data_ptr(), g.kmer_lo.data_ptr(), None, ge.sk_off, n_total, ra[0], ra[1],
+                                   d_ref.data_ptr(), n_query=ra[2])
                 dist.all_reduce(d_ref, op=dist.ReduceOp.SUM)
                 exchange_check = "equal to all-gather form" if bool(torch.equal(d_ref, d_inter)) else "MISMATCH"
         except Exception as e:  # noqa: BLE001 -- the check must not take the bench line down
             exchange_check = "check failed: %r" % (e,)
     elif exchange_kind == "gather":
-        # untimed: the strips collected on rank 0 (rows i % N of N ranks) must equal ONE device's comparison of all rows
+        # untimed: the strips collected on rank 0 (every rank's own rows) must equal ONE device's comparison of all rows
         # over the gathered keys (that single-device result is what the gpu tests hold against the oracle)
         try:
             with torch.cuda.stream(last["slot"].stream_b):
@@ -631,7 +643,9 @@ def main():
                                        "slots": "genomes sharded by rank; sketch keys partitioned by hash, RCCL all-to-all behind "
                                                 "the scan, per-rank partial pair matrix, RCCL reduction",
                                        "gather": "genomes sharded by rank; RCCL all-gather of the packed sketch keys, every rank "
-                                                 "computes the pair-matrix rows i % N == rank, strips collected on rank 0 (SURVEY.md 8e; "
+                                                 "computes the pair-matrix rows " + ("of its own sketches (dictionary of its own keys; "
+                                                 "the other ranks' keys pass a filter first)" if row_form == "block" else "i % N == rank") +
+                                                 ", strips collected on rank 0 (SURVEY.md 8e; "
                                                  "matrices <= 16 MB by one RCCL reduce of the zero-padded strips)"}[exchange_kind],
                        "exchange_check": exchange_check,
                        **({"simulation": "BENCH_SIM_WORLD=%d: one rank's share of the comparison at that world size, no exchange: "

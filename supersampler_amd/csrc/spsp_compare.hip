@@ -105,6 +105,12 @@ __global__ __launch_bounds__(256) void k_prepare(uint4* __restrict__ table, uint
 }
 
 // flags[0]: input not strictly sorted inside a sketch; flags[1]: fingerprint collision
+// rows a call owns: row_first, row_first + row_stride, ... below row_limit (strided over ranks: first < stride; a block
+// of rows: stride 1)
+__host__ __device__ __forceinline__ bool owned_row(uint32_t j, uint32_t row_first, uint32_t row_stride, uint32_t row_limit) {
+    return j >= row_first && j < row_limit && (j - row_first) % row_stride == 0;
+}
+
 __global__ void k_insert(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n, uint64_t S, uint32_t row_first,
                          uint32_t row_stride, uint32_t row_limit, uint64_t seed, uint64_t* __restrict__ table, uint32_t log2cap,
                          uint32_t* __restrict__ owner, SlotKeys SK, uint32_t* __restrict__ flags, uint32_t passes,
@@ -114,7 +120,7 @@ __global__ void k_insert(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n
     const uint64_t e = sk_off[j] + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= sk_off[j + 1]) return;
     if (e > sk_off[j] && !key_less(K, e - 1, e)) atomicOr(&flags[0], 1u);
-    if (j % row_stride != row_first || j >= row_limit) return;   // not an owned (and printed) row
+    if (!owned_row(j, row_first, row_stride, row_limit)) return;   // not an owned (and printed) row
     if (passes > 1 && pass_of(K.lo[e], K.mn[e], K.hi ? K.hi[e] : 0, K.hi != nullptr, passes) != pass) return;
     const uint64_t fp = fingerprint(K, e, seed);
     const uint64_t mask = (1ull << log2cap) - 1;
@@ -179,12 +185,12 @@ __global__ void k_fill(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n, 
     const uint64_t e = sk_off[j] + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= sk_off[j + 1]) return;
     if (passes > 1 && pass_of(K.lo[e], K.mn[e], K.hi ? K.hi[e] : 0, K.hi != nullptr, passes) != pass) {
-        if (j % row_stride == row_first && j < row_limit) row_of_entry[e] = 0xffffffffu;   // not in this pass: k_accumulate skips it
+        if (owned_row(j, row_first, row_stride, row_limit)) row_of_entry[e] = 0xffffffffu;   // not in this pass: k_accumulate skips it
         return;
     }
     // every exit that does not find the key's row (collision, full table: attempts the host discards) must still leave
     // a valid marker behind, or the row sums queued behind this pass would follow a stale index
-    if (j % row_stride == row_first && j < row_limit) row_of_entry[e] = 0xffffffffu;
+    if (owned_row(j, row_first, row_stride, row_limit)) row_of_entry[e] = 0xffffffffu;
     const uint64_t fp = fingerprint(K, e, seed);
     const uint64_t mask = (1ull << log2cap) - 1;
     uint64_t pos = home_slot(fp, log2cap);
@@ -193,7 +199,7 @@ __global__ void k_fill(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n, 
         const uint64_t v = table[pos];
         if (v == 0) return;  // key not held by any owned sketch: contributes to no owned row
         if (v == fp) {
-            const bool own = j % row_stride == row_first && j < row_limit;
+            const bool own = owned_row(j, row_first, row_stride, row_limit);
             const bool same = SK.lo[pos] == K.lo[e] && SK.mn[pos] == K.mn[e] && (!K.hi || SK.hi[pos] == K.hi[e]);
             if (same) {
                 const uint32_t r = rowid ? rowid[pos] : owner[pos];   // direct mode: the owner's entry index is the row
@@ -311,7 +317,7 @@ __global__ void k_fill_sparse(Keys K, const uint64_t* __restrict__ sk_off, uint3
 
 constexpr int kSparseCols = 16384;
 constexpr int kFlags = 8;   // [0] unsorted input, [1] fingerprint collision, [2] n_rows, [3] malformed slot, [4] slot overflow,
-                            // [5] table full, [6] a key part overflowed its capacity (partition form)
+                            // [5] table full, [6] a key part overflowed its capacity (partition form), [7] records dealt into parts
 // grid.y = owned row (sketch row_first + y * row_stride), grid.x = block of `cols` columns, grid.z = slice of the
 // row's keys (split > 1: the slices add into cells zeroed by k_zero_rows).  Counters live in dynamic LDS,
 // `copies` of each, interleaved (counter c of copy k at c * copies + k): the lists of one row's keys name the
@@ -443,9 +449,11 @@ __device__ __forceinline__ uint64_t key_hash(uint64_t lo, uint32_t mn, uint64_t 
 __global__ __launch_bounds__(256) void k_parts_prepare(uint32_t* __restrict__ part_cnt, uint32_t n_parts, uint32_t* __restrict__ flags,
                                                       const uint64_t* __restrict__ host_skoff, uint64_t* __restrict__ dev_skoff,
                                                       uint32_t n_skoff, const uint32_t* __restrict__ host_sub, uint32_t* __restrict__ dev_sub,
-                                                      uint32_t n_sub, uint32_t* __restrict__ zero_inter, uint32_t zero_n) {
+                                                      uint32_t n_sub, uint32_t* __restrict__ zero_inter, uint32_t zero_n,
+                                                      uint4* __restrict__ filter, uint32_t filter_vec) {
     const uint32_t stride = gridDim.x * blockDim.x, t = blockIdx.x * blockDim.x + threadIdx.x;
     for (uint32_t i = t; i < n_parts; i += stride) part_cnt[i] = 0;
+    for (uint32_t i = t; i < filter_vec; i += stride) filter[i] = make_uint4(0, 0, 0, 0);
     // small-problem form: the parts ADD into the pair matrix, so the cells they add into -- (i, j > i), the cells every
     // form of the comparison owns -- start from zero; the diagonal and the lower triangle stay the caller's (spsp.h)
     for (uint32_t i = t; i < zero_n * zero_n; i += stride)
@@ -453,6 +461,25 @@ __global__ __launch_bounds__(256) void k_parts_prepare(uint32_t* __restrict__ pa
     if (t < 16) flags[t] = 0;
     for (uint32_t i = t; i < n_skoff; i += stride) dev_skoff[i] = host_skoff[i];
     for (uint32_t i = t; i < n_sub; i += stride) dev_sub[i] = host_sub[i];
+}
+
+// Row-partitioned calls (a rank of a multi-GPU comparison owns some rows): only keys held by an OWNED
+// sketch can add to an owned row, so the dictionary is built from the owned sketches' keys and the keys of the other
+// sketches that one of them also holds.  A blocked Bloom filter over the owned keys (16 bits per key, two bits in one
+// 32-bit word: ~1.4 % false positives, no false negatives) stands in front of the scatter: a foreign key that misses
+// it is read once (12 or 20 bytes, coalesced) and dropped -- no record, no `where` word, no place in a part.  Foreign
+// keys that pass by accident only occupy a record: full keys are compared when the part is grouped.
+__device__ __forceinline__ uint32_t filter_bits(uint64_t h) { return (1u << ((h >> 32) & 31u)) | (1u << ((h >> 37) & 31u)); }
+template <bool HAS_HI>
+__global__ __launch_bounds__(256) void k_parts_filter(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n, uint32_t row_first,
+                                                     uint32_t row_stride, uint32_t row_limit, uint32_t* __restrict__ filter,
+                                                     uint32_t fmask) {
+    const uint32_t j = row_first + blockIdx.y * row_stride;        // grid.y = owned sketch, grid.x = 256-key chunk of it
+    if (j >= n || j >= row_limit) return;
+    const uint64_t e = sk_off[j] + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= sk_off[j + 1]) return;
+    const uint64_t h = key_hash(K.lo[e], K.mn[e], HAS_HI ? K.hi[e] : 0ull, HAS_HI);
+    atomicOr(&filter[(uint32_t)h & fmask], filter_bits(h));
 }
 
 // A workgroup owns E x kScatThreads consecutive entries of the concatenated key arrays, E per thread, all held in
@@ -463,11 +490,13 @@ template <bool HAS_HI, int E>
 __global__ __launch_bounds__(kScatThreads, 4) void k_parts_scatter(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n,
                                                                const uint32_t* __restrict__ sub_sk, uint64_t S, uint32_t n_parts,
                                                                uint32_t cap, uint32_t* __restrict__ part_cnt, uint64_t* __restrict__ recs,
-                                                               uint32_t* __restrict__ where, uint32_t* __restrict__ flags, bool check_order) {
+                                                               uint32_t* __restrict__ where, uint32_t* __restrict__ flags, bool check_order,
+                                                               const uint32_t* __restrict__ filter, uint32_t fmask, uint64_t e_first,
+                                                               uint32_t row_first, uint32_t row_stride, uint32_t row_limit) {
     constexpr uint32_t W = HAS_HI ? 3 : 2;
     extern __shared__ uint32_t hist[];                   // [n_parts]
     const uint32_t t = threadIdx.x, lane = t & 63;
-    const uint64_t base = (uint64_t)blockIdx.x * E * kScatThreads;
+    const uint64_t base = e_first + (uint64_t)blockIdx.x * E * kScatThreads;   // (the grid starts at the first owned sketch's chunk)
     for (uint32_t p = t; p < n_parts; p += kScatThreads) hist[p] = 0;
     uint64_t lo[E], hi[E];
     uint32_t mn[E], pr[E];                                // pr = part | rank << 15
@@ -496,13 +525,26 @@ __global__ __launch_bounds__(kScatThreads, 4) void k_parts_scatter(Keys K, const
             if (!less) atomicOr(&flags[0], 1u);
         }
     }
-    __syncthreads();
+    // an owned row i counts holders j > i only: nothing of the sketches in front of the first owned row is dealt.
+    // Filtered form: a key of a sketch this call does not own is kept only if an owned sketch may hold it too
+    uint64_t hsh[E];
+    bool keep[E];
 #pragma unroll
     for (int u = 0; u < E; ++u) {
         const uint64_t e = base + (uint64_t)u * kScatThreads + t;
+        hsh[u] = key_hash(lo[u], mn[u], hi[u], HAS_HI);
+        keep[u] = e < S && sk_of[u] >= row_first;        // (sketches in front of the first owned row are never counted by an owned row)
+        if (filter && keep[u] && !owned_row(sk_of[u], row_first, row_stride, row_limit)) {
+            const uint32_t bits = filter_bits(hsh[u]);
+            keep[u] = (filter[(uint32_t)hsh[u] & fmask] & bits) == bits;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < E; ++u) {
         pr[u] = 0xffffffffu;
-        if (e < S) {
-            const uint32_t part = (uint32_t)(((key_hash(lo[u], mn[u], hi[u], HAS_HI) >> 32) * n_parts) >> 32);
+        if (keep[u]) {
+            const uint32_t part = (uint32_t)(((hsh[u] >> 32) * n_parts) >> 32);
             pr[u] = part | (atomicAdd(&hist[part], 1u) << 15);
         }
     }
@@ -515,7 +557,7 @@ __global__ __launch_bounds__(kScatThreads, 4) void k_parts_scatter(Keys K, const
 #pragma unroll
     for (int u = 0; u < E; ++u) {
         const uint64_t e = base + (uint64_t)u * kScatThreads + t;
-        if (e >= S) continue;
+        if (!keep[u]) continue;                          // (beyond the end, or dropped by the filter: no row sum reads its `where`)
         const uint32_t j = sk_of[u];
         const uint32_t part = pr[u] & 0x7fffu, at = hist[part] + (pr[u] >> 15);
         // where the record goes, in entry order (coalesced): the row sums find the key's list through it, so the
@@ -547,6 +589,7 @@ __global__ __launch_bounds__(kGroupThreads) void k_parts_group(const uint64_t* _
     uint32_t* cursor = slot + kPartSlots;
     const uint32_t p = blockIdx.x, t = threadIdx.x;
     const uint32_t n = part_cnt[p];
+    if (t == 0) atomicAdd(&flags[7], n);                  // records in all parts: sizes the parts of a filtered call's next attempt
     if (n > (uint32_t)kPartCap) { if (t == 0) atomicOr(&flags[6], 1u); return; }
     for (uint32_t x = t; x < (uint32_t)kPartSlots; x += kGroupThreads) slot[x] = 0;
     if (t == 0) *cursor = 0;
@@ -837,11 +880,16 @@ struct CompareJob {
     uint32_t passes = 1, pass = 0;  // large builds: the keys are split into classes and the dictionary + colour
                                     // matrix are built class by class, so the matrix never exceeds its budget
     // partition form (flat entry point): see k_parts_scatter
-    std::function<int(uint32_t n_parts, bool small)> scatter_parts;
+    std::function<int(uint32_t n_parts, bool small, bool filtered, uint32_t fmask)> scatter_parts;
     std::function<int(uint32_t n_parts)> group_parts;
     std::function<int(uint32_t n_parts)> group_small;     // small problems: grouping + counting in one kernel (k_parts_group_small)
     bool parts = false, small = false;
     uint32_t n_parts = 0, parts_attempt = 0, n_sub = 0;
+    // filtered form (row-partitioned calls): Bloom filter over the owned sketches' keys in front of the scatter
+    std::function<int(uint32_t fmask)> build_filter;
+    bool filtered = false;
+    uint32_t filter_words = 0;
+    uint64_t parts_entries = 0;     // records the parts are sized for
     bool bracket_closed = false;    // the kEvCompare bracket of the begin call has been closed already
 };
 // flags: [0] unsorted input, [1] fingerprint collision, [2] n_rows, [3] malformed slot, [4] slot overflow, [5] table full
@@ -885,17 +933,21 @@ static int job_parts(spsp_ctx* ctx, CompareJob& J) {
     int rc;
     if ((rc = ctx->c_part_cnt.reserve((size_t)J.n_parts * 4))) return rc;
     if (!J.small && (rc = ctx->c_matrix.reserve((size_t)J.n_parts * 4 * kPartCap * sizeof(uint16_t)))) return rc;     // sketch lists
-    const uint32_t most = std::max(std::max(J.n_parts, J.n_skoff), std::max(J.n_sub, J.small ? J.P.n * J.P.n : 0u));
-    hipLaunchKernelGGL(k_parts_prepare, dim3(std::min<uint32_t>((most + 255) / 256, 64u)), dim3(256), 0, ctx->stream,
+    if (J.filtered && (rc = ctx->c_filter.reserve((size_t)J.filter_words * 4))) return rc;
+    const uint32_t filter_vec = J.filtered ? J.filter_words / 4 : 0u;
+    const uint32_t most = std::max(std::max(std::max(J.n_parts, J.n_skoff), std::max(J.n_sub, J.small ? J.P.n * J.P.n : 0u)), filter_vec);
+    hipLaunchKernelGGL(k_parts_prepare, dim3(std::min<uint32_t>((most + 255) / 256, J.filtered ? 1024u : 64u)), dim3(256), 0, ctx->stream,
                        ctx->c_part_cnt.as<uint32_t>(), J.n_parts, flags, (const uint64_t*)ctx->h_skoff,
                        ctx->c_skoff.as<uint64_t>(), J.n_skoff, reinterpret_cast<const uint32_t*>(ctx->h_skoff + J.n_skoff),
                        reinterpret_cast<uint32_t*>(ctx->c_skoff.as<uint64_t>() + J.n_skoff), J.n_sub,
-                       J.small ? J.P.d_inter : (uint32_t*)nullptr, J.small ? J.P.n : 0u);
+                       J.small ? J.P.d_inter : (uint32_t*)nullptr, J.small ? J.P.n : 0u,
+                       J.filtered ? ctx->c_filter.as<uint4>() : (uint4*)nullptr, filter_vec);
     SPSP_HIP(hipGetLastError());
     // analysis hook (results are wrong with it): leave stages out to see what each costs a kernel of another stream
     static const int skip = getenv("SPSP_DEBUG_SKIP_STAGES") ? atoi(getenv("SPSP_DEBUG_SKIP_STAGES")) : 0;
     if ((rc = ctx->ev_begin(kEvScatter))) return rc;
-    if (!(skip & 1) && (rc = J.scatter_parts(J.n_parts, J.small))) return rc;
+    if (J.filtered && (rc = J.build_filter(J.filter_words - 1))) return rc;
+    if (!(skip & 1) && (rc = J.scatter_parts(J.n_parts, J.small, J.filtered, J.filter_words - 1))) return rc;
     if ((rc = ctx->ev_end(kEvScatter))) return rc;
     if ((rc = ctx->ev_begin(kEvGroup))) return rc;
     if (!(skip & 2) && (rc = J.small ? J.group_small(J.n_parts) : J.group_parts(J.n_parts))) return rc;
@@ -1084,7 +1136,25 @@ static int compare_job_begin(spsp_ctx* ctx, CompareJob* job) {
         // would otherwise ask for 41 000)
         J->small = J->group_small && !small_off && !dbg_mean_set() && P.n <= (uint32_t)kSmallN && P.n_own == P.n && P.row_first == 0 && P.row_stride == 1 &&
                    P.row_limit >= P.n && parts_small(P.S_entries) <= (uint32_t)kMaxKeyParts;
-        J->n_parts = J->small ? parts_small(P.S_entries) : parts_for(P.S_entries, 0);
+        // row-partitioned call that owns at most 3/4 of the keys: the other sketches' keys go through a filter first
+        // (k_parts_filter) and the parts are sized for what got through last time (the count comes back with the flags;
+        // an attempt that overflows is repeated with the exact count).  SPSP_DEBUG_FILTER=0/1 forces the choice.
+        // A filter that lets most keys through costs more than it saves (rows dealt i % G over sketches that come in
+        // families: 65 % pass): once a call has measured that, later ones skip it and look again now and then.
+        static const char* dbg_filter = getenv("SPSP_DEBUG_FILTER");
+        const uint64_t S_behind = P.S_entries - ctx->h_skoff[std::min(P.row_first, P.n)];   // keys of the first owned row and later sketches
+        const bool pays = ctx->filter_ratio * (double)P.S_own <= 0.5 * (double)S_behind || (++ctx->filter_skipped & 255u) == 0;
+        J->filtered = !J->small && J->build_filter && P.n_own < P.n &&
+                      (dbg_filter ? atoi(dbg_filter) != 0 : (4 * P.S_own <= 3 * S_behind && pays));
+        J->parts_entries = S_behind;
+        if (J->filtered) {
+            uint32_t words = 1024;                  // 16 bits per owned key, a power of two of 32-bit words
+            while ((uint64_t)words * 2 < P.S_own && words < (1u << 28)) words <<= 1;
+            J->filter_words = words;
+            const double ratio = std::min(std::max(ctx->filter_ratio, 1.0), (double)S_behind / (double)P.S_own);
+            J->parts_entries = std::min<uint64_t>(S_behind, (uint64_t)((double)P.S_own * ratio * 1.08) + 2900);
+        }
+        J->n_parts = J->small ? parts_small(P.S_entries) : parts_for(J->parts_entries, 0);
         if ((rc = ctx->c_row.reserve((size_t)P.S_entries * 4))) return rc;
         if ((rc = job_parts(ctx, *J))) return rc;
     } else if ((rc = job_begin_dictionary(ctx, J.get()))) return rc;
@@ -1100,10 +1170,19 @@ int compare_job_end(spsp_ctx* ctx) {
     while (J->parts) {
         uint32_t h_flags[kFlags];
         if ((rc = job_wait_flags(ctx, h_flags))) return rc;
+        if (J->filtered && h_flags[7]) ctx->filter_ratio = (double)h_flags[7] / (double)J->P.S_own;
         if (!h_flags[6]) return SPSP_OK;
         // a part overflowed (many sketches share their keys): once more with parts half the size, then the
         // global-dictionary forms, which have no such limit
         J->bracket_closed = true;
+        if (J->filtered && h_flags[7] > J->parts_entries) {   // more keys passed the filter than the parts were sized for: now the count is known
+            J->parts_entries = (uint64_t)h_flags[7] + (uint64_t)h_flags[7] / 64 + 2900;
+            if (parts_for(J->parts_entries, J->parts_attempt) <= (uint32_t)kMaxKeyParts) {
+                J->n_parts = parts_for(J->parts_entries, J->parts_attempt);
+                if ((rc = job_parts(ctx, *J))) return rc;
+                continue;
+            }
+        }
         if (J->small) {                             // the small-problem form's parts are half the size: the general form next
             J->small = false;
             J->n_parts = parts_for(J->P.S_entries, 0);
@@ -1111,9 +1190,9 @@ int compare_job_end(spsp_ctx* ctx) {
             if ((rc = job_parts(ctx, *J))) return rc;
             continue;
         }
-        if (J->parts_attempt == 0 && parts_for(J->P.S_entries, 1) <= (uint32_t)kMaxKeyParts) {
+        if (J->parts_attempt == 0 && parts_for(J->parts_entries, 1) <= (uint32_t)kMaxKeyParts) {
             J->parts_attempt = 1;
-            J->n_parts = parts_for(J->P.S_entries, 1);
+            J->n_parts = parts_for(J->parts_entries, 1);
             if ((rc = job_parts(ctx, *J))) return rc;
             continue;
         }
@@ -1186,7 +1265,7 @@ static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t*
                                       uint32_t row_first, uint32_t row_stride, uint32_t* d_inter) {
     if (n == 0) return 1;
     if (n > 65535) { set_error("at most 65535 sketches (the reference's uint32 pair key, Comparator.h:26)"); return SPSP_ERR_ARG; }
-    if (row_stride == 0 || row_first >= row_stride) { set_error("bad row partition %u/%u", row_first, row_stride); return SPSP_ERR_ARG; }
+    if (row_stride == 0) { set_error("bad row partition %u/%u", row_first, row_stride); return SPSP_ERR_ARG; }
     for (uint32_t i = 0; i < n; ++i)   // grids and ranges are derived from these: a decreasing offset must not reach a kernel
         if (h_sk_off[i + 1] < h_sk_off[i]) { set_error("sketch offsets must be non-decreasing (sketch %u)", i); return SPSP_ERR_ARG; }
     const uint64_t S = h_sk_off[n];
@@ -1250,7 +1329,18 @@ static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t*
     const bool has_hi = K.hi != nullptr;
     const uint32_t* sub_sk = reinterpret_cast<const uint32_t*>(sk + n + 1);
     J->n_sub = (uint32_t)((S + kScatSub - 1) / kScatSub);
-    J->scatter_parts = [=](uint32_t n_parts, bool small) -> int {
+    J->build_filter = [=](uint32_t fmask) -> int {
+        uint64_t max_own = 0;
+        for (uint32_t i = row_first; i < row_limit; i += row_stride) max_own = std::max(max_own, ctx->h_skoff[i + 1] - ctx->h_skoff[i]);
+        const dim3 grid((uint32_t)std::max<uint64_t>(1, (max_own + 255) / 256), n_own);
+        if (has_hi) hipLaunchKernelGGL(k_parts_filter<true>, grid, dim3(256), 0, ctx->stream, K, sk, n, row_first, row_stride, row_limit, ctx->c_filter.as<uint32_t>(), fmask);
+        else hipLaunchKernelGGL(k_parts_filter<false>, grid, dim3(256), 0, ctx->stream, K, sk, n, row_first, row_stride, row_limit, ctx->c_filter.as<uint32_t>(), fmask);
+        SPSP_HIP(hipGetLastError());
+        return SPSP_OK;
+    };
+    // (nothing of the sketches in front of the first owned row is dealt: the grid starts at that row's chunk)
+    const uint64_t e_own = h_sk_off[row_first] / (4u * kScatThreads) * (4u * kScatThreads);
+    J->scatter_parts = [=](uint32_t n_parts, bool small, bool filtered, uint32_t fmask) -> int {
         const uint32_t cap = small ? (uint32_t)kSmallCap : (uint32_t)kPartCap;
         int r2 = ctx->c_recs.reserve((size_t)n_parts * cap * (has_hi ? 24 : 16));
         if (r2) return r2;
@@ -1260,7 +1350,9 @@ static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t*
         static_assert(kMaxKeyParts < (1 << 15), "k_parts_scatter keeps the part in 15 bits of its (part, rank) word");
         if (n_parts > (uint32_t)kMaxKeyParts) { set_error("internal: %u key parts exceed the scatter's limit of %d", n_parts, kMaxKeyParts); return SPSP_ERR_ARG; }
         const uint32_t per_wg = 4u * kScatThreads;
-        const dim3 grid((uint32_t)((S + per_wg - 1) / per_wg));
+        const uint64_t e_first = e_own;
+        const dim3 grid((uint32_t)((S - e_first + per_wg - 1) / per_wg));
+        const uint32_t* filter = filtered ? ctx->c_filter.as<uint32_t>() : nullptr;
         const size_t lds = (size_t)n_parts * 4;
         if (lds > 48 * 1024 && !ctx->attr_scatter_set) {
             SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_parts_scatter<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxKeyParts * 4));
@@ -1268,7 +1360,8 @@ static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t*
             ctx->attr_scatter_set = true;
         }
 #define SPSP_SCATTER(HI, E) hipLaunchKernelGGL((k_parts_scatter<HI, E>), grid, dim3(kScatThreads), lds, ctx->stream, K, sk, n, sub_sk, S, \
-                                               n_parts, cap, ctx->c_part_cnt.as<uint32_t>(), ctx->c_recs.as<uint64_t>(), where, flags, !ctx->keys_unordered)
+                                               n_parts, cap, ctx->c_part_cnt.as<uint32_t>(), ctx->c_recs.as<uint64_t>(), where, flags, !ctx->keys_unordered, \
+                                               filter, fmask, e_first, row_first, row_stride, row_limit)
         if (has_hi) SPSP_SCATTER(true, 4);
         else SPSP_SCATTER(false, 4);
 #undef SPSP_SCATTER

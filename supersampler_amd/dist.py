@@ -4,9 +4,13 @@ One process per GPU.  Sketching shards genomes by rank with no collective.  The
 comparison has ONE key exchange step, in two forms:
 
 * `KeyExchange` (default of bench.py, north_star's form): an all-gather of the
-  packed keys, after which every rank holds all sketches and computes the
-  pair-matrix rows `i % world == rank`; `collect_rows` returns the strips to
-  one rank (each cell crosses the fabric once).
+  packed keys, after which every rank holds all sketches and computes a share
+  of the pair-matrix rows -- by default the BLOCK of rows of the sketches it
+  scanned itself (`rows="block"`: its dictionary is then built from its own
+  keys, and the other ranks' keys only pass a filter: spsp_compare_device with
+  row_first = first row, row_stride = 1, n_query = end of the block), or the
+  rows `i % world == rank` (`rows="strided"`); `collect_rows` returns the
+  strips to one rank (each cell crosses the fabric once).
 * `SlotExchange`: keys are partitioned by hash, every rank sends each of its
   keys once (all-to-all of fixed-size slots), counts its hash class for ALL
   pairs and the partial N x N matrices are summed (reduce-scatter by row
@@ -28,7 +32,11 @@ import torch
 import torch.distributed as dist
 
 
-def owned_rows(n_total, rank, world):
+def owned_rows(n_total, rank, world, rows="strided"):
+    """the pair-matrix rows of `rank`: every world-th row, or (rows="block") its n_total / world consecutive rows"""
+    if rows == "block":
+        per = n_total // world
+        return list(range(rank * per, n_total if rank == world - 1 else (rank + 1) * per))
     return list(range(rank, n_total, world))
 
 
@@ -52,7 +60,10 @@ class KeyExchange:
     """Pre-sized all-gather of sketch keys.  `counts` = keys per local sketch
     (every rank must hold the same number of sketches)."""
 
-    def __init__(self, counts, device, use_hi=False, group=None, stream=None):
+    def __init__(self, counts, device, use_hi=False, group=None, stream=None, rows="block"):
+        if rows not in ("block", "strided"):
+            raise ValueError("rows must be 'block' or 'strided'")
+        self.rows = rows
         self.group = group
         self.stream = stream
         self.world = dist.get_world_size(group)
@@ -95,6 +106,21 @@ class KeyExchange:
             self._pad_hi, self._g_hi, self.all_hi = mk(torch.int64, self.pad), mk(torch.int64, self.world * self.pad), mk(torch.int64, total)
         else:
             self.all_hi = None
+
+    def row_args(self, n_total=None):
+        """(row_first, row_stride, n_query) of this rank's rows for spsp_compare_device over the gathered sketches"""
+        n = self.n_total if n_total is None else n_total
+        rows = self.own_rows(n)
+        if self.rows == "block":
+            return (rows[0] if rows else 0), 1, (rows[-1] + 1 if rows else 0)
+        return self.rank, self.world, n
+
+    @property
+    def n_total(self):
+        return len(self.sk_off) - 1
+
+    def own_rows(self, n_total=None, rank=None):
+        return owned_rows(self.n_total if n_total is None else n_total, self.rank if rank is None else rank, self.world, self.rows)
 
     def _all_gather(self, g, padded):
         if dist.get_backend(self.group) == "gloo":
@@ -147,8 +173,8 @@ class KeyExchange:
         plan = getattr(self, "_plans", {}).get(key)
         if plan is None:
             dev = inter_local.device
-            rows = -(-n // self.world)                                   # rows per rank, padded
-            own = torch.arange(self.rank, n, self.world, device=dev)
+            rows = max(len(self.own_rows(n, r)) for r in range(self.world))   # rows per rank, padded
+            own = torch.tensor(self.own_rows(n), dtype=torch.int64, device=dev)
             plan = {"rows": rows, "own": own, "mine": torch.zeros((rows, n), dtype=inter_local.dtype, device=dev)}
             # cells (i, j > i) of the owned rows: what the comparison wrote; the rest of a strip is not the sender's to send
             plan["upper"] = (torch.arange(n, device=dev)[None, :] > own[:, None]).to(inter_local.dtype)
@@ -158,9 +184,9 @@ class KeyExchange:
                 for r in range(self.world):
                     if r == dst:
                         continue
-                    k = len(range(r, n, self.world))
-                    src += [r * rows + j for j in range(k)]
-                    dstr += list(range(r, n, self.world))
+                    theirs = self.own_rows(n, r)
+                    src += [r * rows + j for j in range(len(theirs))]
+                    dstr += theirs
                 plan["src"] = torch.tensor(src, dtype=torch.int64, device=dev)
                 plan["dst"] = torch.tensor(dstr, dtype=torch.int64, device=dev)
             self._plans = getattr(self, "_plans", {})
@@ -180,19 +206,21 @@ class KeyExchange:
         return None
 
     def _own_mask(self, inter_local):
-        """1 in the cells this rank's comparison writes -- (i, j > i) of the rows i % world == rank -- 0 elsewhere"""
+        """1 in the cells this rank's comparison writes -- (i, j > i) of its own rows -- 0 elsewhere"""
         n = inter_local.shape[0]
         key = ("mask", n, inter_local.dtype, str(inter_local.device))
         self._plans = getattr(self, "_plans", {})
         m = self._plans.get(key)
         if m is None:
             i = torch.arange(n, device=inter_local.device)
-            m = ((i[:, None] % self.world == self.rank) & (i[None, :] > i[:, None])).to(inter_local.dtype)
+            mine = torch.zeros(n, dtype=torch.bool, device=inter_local.device)
+            mine[torch.tensor(self.own_rows(n), dtype=torch.int64, device=inter_local.device)] = True
+            m = (mine[:, None] & (i[None, :] > i[:, None])).to(inter_local.dtype)
             self._plans[key] = m
         return m
 
     def collect_rows(self, inter_local, dst=0):
-        """strips -> one rank: every rank sends the rows it owns (i % world == rank) of its n x n
+        """strips -> one rank: every rank sends the rows it owns (`own_rows`) of its n x n
         int32 matrix; on `dst` they are put in place in `inter_local`, which then holds the whole matrix.  Each
         cell crosses the fabric once (an all-reduce of the n x n matrices moves 2 (world-1)/world of ALL of them).
         Small matrices (<= REDUCE_BYTES: every bench.py world size; 800 x 800 cells = 2.6 MB) take a shortcut that
@@ -211,20 +239,20 @@ class KeyExchange:
         with self._on_stream():
             if dist.get_backend(self.group) == "gloo" and inter_local.is_cuda:
                 # (CPU-side collective in the tests: through host copies)
-                rows = -(-n // self.world)
+                rows = max(len(self.own_rows(n, r)) for r in range(self.world))
                 mine = torch.zeros((rows, n), dtype=inter_local.dtype, device=inter_local.device)
-                own = inter_local[self.rank::self.world]
-                mine[:own.shape[0]] = own * (torch.arange(n, device=own.device)[None, :] >
-                                             torch.arange(self.rank, n, self.world, device=own.device)[:, None]).to(own.dtype)
+                idx = torch.tensor(self.own_rows(n), dtype=torch.int64, device=inter_local.device)
+                own = inter_local[idx]
+                mine[:own.shape[0]] = own * (torch.arange(n, device=own.device)[None, :] > idx[:, None]).to(own.dtype)
                 torch.cuda.synchronize()
                 mine = mine.cpu()
                 parts = [torch.empty_like(mine) for _ in range(self.world)] if self.rank == dst else None
                 dist.gather(mine, parts, dst=dst, group=self.group)
                 if self.rank == dst:
                     for r in range(self.world):
-                        k = len(range(r, n, self.world))
+                        theirs = self.own_rows(n, r)
                         if r != dst:
-                            inter_local[r::self.world] = parts[r][:k].to(inter_local.device)
+                            inter_local[theirs] = parts[r][:len(theirs)].to(inter_local.device)
                 return inter_local
             P = self._collect_plan(inter_local, dst)
             k_own = P["own"].numel()

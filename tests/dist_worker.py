@@ -137,8 +137,11 @@ def expected_inter(sets):
     return want
 
 
+ROWS = os.environ.get("SPSP_TEST_ROWS", "block")     # row ownership after the all-gather: "block" (default of KeyExchange) or "strided"
+
+
 def main_c4(mode, rank, world):
-    """8 ranks, 2 048 sketches: all-gather of the keys, rows i % world == rank, strips collected on rank 0.
+    """8 ranks, 2 048 sketches: all-gather of the keys, every rank's own rows (ROWS), strips collected on rank 0.
     cpu_c4: gloo, rows counted by numpy; nccl modes use the GPU kernels (see main_nccl)."""
     per_rank = 256 if world >= 8 else 64
     n_total = per_rank * world
@@ -147,8 +150,10 @@ def main_c4(mode, rank, world):
     counts = [len(x) for x in mine]
     my_lo = torch.from_numpy(np.concatenate(mine).view(np.int64))
     my_min = torch.full((int(sum(counts)),), 7, dtype=torch.int32)
-    ex = spd.KeyExchange(counts, torch.device("cpu"))
+    ex = spd.KeyExchange(counts, torch.device("cpu"), rows=ROWS)
     g = ex.exchange(my_min, my_lo)
+    mine_rows = set(ex.own_rows())
+    assert sorted(r for q in range(world) for r in ex.own_rows(rank=q)) == list(range(n_total))   # every row has one owner
     lo = g.kmer_lo.numpy().view(np.uint64)
     for i in (0, 1, n_total // 2, n_total - 1):                       # gathered keys == every sketch's keys in global order
         assert (lo[int(g.sk_off[i]):int(g.sk_off[i + 1])] == sets[i]).all(), i
@@ -161,7 +166,7 @@ def main_c4(mode, rank, world):
     ln = local.numpy()
     for hs in holders.values():
         for a_i, a in enumerate(hs):
-            if a % world == rank:                                     # only the rows this rank owns
+            if a in mine_rows:                                        # only the rows this rank owns
                 for b in hs[a_i + 1:]:
                     ln[a, b] += 1
     own_rows = local.clone()
@@ -175,7 +180,7 @@ def main_c4(mode, rank, world):
             # poisoned on the ranks that are not the destination
             if rank != 0:
                 ln[:] = 12345
-            ln[rank::world] = own_rows.numpy()[rank::world]
+            ln[sorted(mine_rows)] = own_rows.numpy()[sorted(mine_rows)]
             if rank != 0:
                 ln[np.tril_indices(n_total)] = 12345                  # (the comparison never writes the diagonal or below)
             full = ex.collect_rows(local)
@@ -205,10 +210,11 @@ def main_nccl(rank, world):
         d_min = torch.full((int(sum(counts)),), 7, dtype=torch.int32, device=dev)
         d_inter = torch.zeros((n_total, n_total), dtype=torch.int32, device=dev)
     want = expected_inter(sets)
-    ex = spd.KeyExchange(counts, dev, stream=stream)
+    ex = spd.KeyExchange(counts, dev, stream=stream, rows=ROWS)
+    ra = ex.row_args()
     for _ in range(2):
         g = ex.exchange(d_min, d_lo)
-        ctx.compare_device(k, g.minimizer.data_ptr(), g.kmer_lo.data_ptr(), None, g.sk_off, n_total, rank, world, d_inter.data_ptr())
+        ctx.compare_device(k, g.minimizer.data_ptr(), g.kmer_lo.data_ptr(), None, g.sk_off, n_total, ra[0], ra[1], d_inter.data_ptr(), n_query=ra[2])
         full = ex.collect_rows(d_inter)
     stream.synchronize()
     ok = rank != 0 or bool((full.cpu().numpy() == want).all())
@@ -264,18 +270,19 @@ def main():
         sys.exit(0 if ok else 1)
     if mode == "gpu":
         dev = torch.device("cuda", 0)
-        ex = spd.KeyExchange(counts, torch.device("cpu"))
+        ex = spd.KeyExchange(counts, torch.device("cpu"), rows=ROWS)
         g = ex.exchange(my_min, my_lo)
+        ra = ex.row_args()
         ctx = sp.Context(0)
         d_min, d_lo = g.minimizer.to(dev), g.kmer_lo.to(dev)
         d_inter = torch.zeros((n_total, n_total), dtype=torch.int32, device=dev)
         torch.cuda.synchronize()   # torch fills on its own stream; the context has its own
-        ctx.compare_device(k, d_min.data_ptr(), d_lo.data_ptr(), None, g.sk_off, n_total, rank, world, d_inter.data_ptr())
+        ctx.compare_device(k, d_min.data_ptr(), d_lo.data_ptr(), None, g.sk_off, n_total, ra[0], ra[1], d_inter.data_ptr(), n_query=ra[2])
         torch.cuda.synchronize()
         local = d_inter.cpu()
         ctx.close()
     else:
-        ex = spd.KeyExchange(counts, torch.device("cpu"))
+        ex = spd.KeyExchange(counts, torch.device("cpu"), rows=ROWS)
         g = ex.exchange(my_min, my_lo)
         mn = g.minimizer.numpy().view(np.uint32)
         lo = g.kmer_lo.numpy().view(np.uint64)
@@ -287,7 +294,7 @@ def main():
         sets = [set(zip(mn[int(g.sk_off[i]):int(g.sk_off[i + 1])].tolist(), lo[int(g.sk_off[i]):int(g.sk_off[i + 1])].tolist()))
                 for i in range(n_total)]
         local = torch.zeros((n_total, n_total), dtype=torch.int32)
-        for i in spd.owned_rows(n_total, rank, world):
+        for i in spd.owned_rows(n_total, rank, world, ROWS):
             for j in range(i + 1, n_total):
                 local[i, j] = len(sets[i] & sets[j])
     merged = spd.merge_rows(local, n_total, rank, world)
@@ -298,7 +305,7 @@ def main():
         # every pair is owned by exactly one rank
         owners = np.zeros((n_total, n_total), dtype=np.int32)
         for r in range(world):
-            for i in spd.owned_rows(n_total, r, world):
+            for i in spd.owned_rows(n_total, r, world, ROWS):
                 owners[i, i + 1:] += 1
         ok = ok and bool((owners[np.triu_indices(n_total, 1)] == 1).all())
     dist.barrier()

@@ -1,6 +1,7 @@
 """world_size-2 tests of the multi-GPU comparison path: key
-all-gather + strided row ownership.  CPU variant runs here with gloo; the GPU
-variant runs the real spsp_compare_device in both ranks."""
+all-gather + row ownership (a rank's own block of rows, or every world-th
+row).  CPU variant runs here with gloo; the GPU variant runs the real
+spsp_compare_device in both ranks."""
 import os
 import subprocess
 import sys
@@ -10,9 +11,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _launch(mode, port, world=2):
+def _launch(mode, port, world=2, rows="block"):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world),
-               HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+               HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1", SPSP_TEST_ROWS=rows)
     procs = []
     for r in range(world):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
@@ -23,8 +24,9 @@ def _launch(mode, port, world=2):
         assert p.returncode == 0, o[-3000:]
 
 
-def test_key_exchange_and_row_partition_gloo_cpu():
-    _launch("cpu", 29611)
+@pytest.mark.parametrize("rows", ["block", "strided"])
+def test_key_exchange_and_row_partition_gloo_cpu(rows):
+    _launch("cpu", 29611 if rows == "block" else 29641, rows=rows)
 
 
 def test_slot_exchange_and_partial_sum_gloo_cpu():
@@ -32,8 +34,9 @@ def test_slot_exchange_and_partial_sum_gloo_cpu():
 
 
 @pytest.mark.gpu
-def test_two_ranks_compare_device_rows():
-    _launch("gpu", 29612)
+@pytest.mark.parametrize("rows", ["block", "strided"])
+def test_two_ranks_compare_device_rows(rows):
+    _launch("gpu", 29612 if rows == "block" else 29642, rows=rows)
 
 
 @pytest.mark.gpu
@@ -41,10 +44,12 @@ def test_two_ranks_key_partitioned_exchange():
     _launch("gpu_slots", 29614)
 
 
-def test_eight_ranks_c4_shape_gloo_cpu():
-    """world_size 8, 2 048 sketches in families (BASELINE configs[3] in small): key all-gather, row ownership
-    i % 8 == rank, strips collected on rank 0 equal an inverted-index count over all 2.1 million pairs."""
-    _launch("cpu_c4", 29621, world=8)
+@pytest.mark.parametrize("rows", ["block", "strided"])
+def test_eight_ranks_c4_shape_gloo_cpu(rows):
+    """world_size 8, 2 048 sketches in families (BASELINE configs[3] in small): key all-gather, row ownership (the
+    rank's own 256 sketches / i % 8 == rank), strips collected on rank 0 equal an inverted-index count over all 2.1
+    million pairs."""
+    _launch("cpu_c4", 29621 if rows == "block" else 29643, world=8, rows=rows)
 
 
 @pytest.mark.gpu
@@ -60,7 +65,7 @@ def test_two_ranks_rccl_both_exchange_forms():
 def test_bench_two_ranks_rehearsal_on_one_gpu():
     """bench.py as the driver launches it for N = 2 (torch.distributed.run, one process per rank), rehearsed on ONE
     GPU: both ranks compute on cuda:0 and the collectives go through gloo (BENCH_BACKEND / BENCH_SHARE_GPU).  The
-    whole N > 1 path of the file runs -- rank-sharded genomes, key all-gather, rows i % 2, strips to rank 0, barrier,
+    whole N > 1 path of the file runs -- rank-sharded genomes, key all-gather, own rows, strips to rank 0, barrier,
     max over ranks, ONE JSON line from rank 0 -- and the line's untimed check says the collected matrix equals a
     one-device comparison of all sketches."""
     import json

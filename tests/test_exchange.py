@@ -495,6 +495,86 @@ def test_eight_simulated_ranks_c4_shaped(ctx):
     assert (merged.cpu().numpy() == want).all() and int(want.sum()) > 1_000_000
 
 
+def test_eight_simulated_ranks_own_blocks_of_rows(ctx):
+    """The same 2 048 sketches with the rows dealt in BLOCKS (rank r owns rows [256 r, 256 r + 256): the sketches it
+    scanned itself -- dist.KeyExchange's default): row_first = first row, row_stride = 1, n_query = end of the block.
+    Each call builds its dictionary from its own block's keys and the keys of later sketches that pass the Bloom
+    filter; cells outside the block stay untouched, the blocks together equal the inverted-index count.  A second
+    round on the same context starts from the part size the first one measured."""
+    import dist_worker as dw
+    n, world = 2048, 8
+    sets = dw.c4_shaped_sets(n, 600, seed=46)
+    want = dw.expected_inter(sets)
+    dev = torch.device("cuda", 0)
+    cnt = np.array([len(x) for x in sets])
+    sk_off = np.zeros(n + 1, np.uint64); sk_off[1:] = np.cumsum(cnt)
+    d_lo = torch.from_numpy(np.concatenate(sets).view(np.int64)).to(dev)
+    d_min = torch.full((int(cnt.sum()),), 7, dtype=torch.int32, device=dev)
+    per = n // world
+    for rnd in range(2):
+        merged = torch.zeros((n, n), dtype=torch.int32, device=dev)
+        for r in (range(world) if rnd == 0 else reversed(range(world))):
+            part = torch.full((n, n), -1, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            ctx.compare_device(31, d_min.data_ptr(), d_lo.data_ptr(), None, sk_off, n, r * per, 1, part.data_ptr(), n_query=(r + 1) * per)
+            torch.cuda.synchronize()
+            p = part.cpu().numpy()
+            own = np.zeros((n, n), bool)
+            own[r * per:(r + 1) * per] = np.triu(np.ones((n, n), bool), 1)[r * per:(r + 1) * per]
+            assert (p[~own] == -1).all()
+            merged[r * per:(r + 1) * per] = torch.triu(part, 1)[r * per:(r + 1) * per]
+        assert (merged.cpu().numpy() == want).all() and int(want.sum()) > 1_000_000
+    # a block that is not aligned to anything, with a stride: rows 301, 304, 307, ... below 1500
+    part = torch.full((n, n), -1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ctx.compare_device(31, d_min.data_ptr(), d_lo.data_ptr(), None, sk_off, n, 301, 3, part.data_ptr(), n_query=1500)
+    torch.cuda.synchronize()
+    p = part.cpu().numpy()
+    rows = np.arange(301, 1500, 3)
+    own = np.zeros((n, n), bool)
+    own[rows] = np.triu(np.ones((n, n), bool), 1)[rows]
+    assert (p[~own] == -1).all() and (p[own] == want[own]).all()
+
+
+def test_filtered_rows_equal_unfiltered_rows_and_grow_their_parts():
+    """Row-partitioned calls with the filter forced off (SPSP_DEBUG_FILTER=0) and on give the same strips; with keys
+    that EVERY sketch shares almost everything passes the filter, the first attempt's parts (sized for the owned keys)
+    overflow and the call repeats itself with the count it measured."""
+    code = ("import sys, os\nsys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np, torch\nimport supersampler_amd as sp\n"
+            "rng = np.random.default_rng(5)\nn = 64\n"
+            "shared = np.unique(rng.integers(1, 2**62, size=30000, dtype=np.int64)).astype(np.uint64)\n"
+            "sets = [np.unique(np.concatenate([shared[rng.random(len(shared)) < 0.9], rng.integers(1, 2**62, size=2000, dtype=np.int64).astype(np.uint64)])) for _ in range(n)]\n"
+            "cnt = np.array([len(x) for x in sets]); sk_off = np.zeros(n + 1, np.uint64); sk_off[1:] = np.cumsum(cnt)\n"
+            "dev = torch.device('cuda', 0)\n"
+            "d_lo = torch.from_numpy(np.concatenate(sets).view(np.int64)).to(dev)\n"
+            "d_min = torch.full((int(cnt.sum()),), 7, dtype=torch.int32, device=dev)\n"
+            "ctx = sp.Context(0)\nout = []\n"
+            "for first, stride, limit in ((0, 1, 8), (8, 1, 16), (56, 1, 64), (3, 8, 64), (0, 1, 64)):\n"
+            "    part = torch.full((n, n), -1, dtype=torch.int32, device=dev)\n"
+            "    torch.cuda.synchronize()\n"
+            "    ctx.compare_device(31, d_min.data_ptr(), d_lo.data_ptr(), None, sk_off, n, first, stride, part.data_ptr(), n_query=limit)\n"
+            "    torch.cuda.synchronize()\n"
+            "    out.append(part.cpu().numpy())\n"
+            "np.save(sys.argv[1], np.stack(out))\n"
+            "full = out[-1]\n"
+            "assert full[0, 1] == len(np.intersect1d(sets[0], sets[1])) and full[5, 60] == len(np.intersect1d(sets[5], sets[60]))\n"
+            "for o, (first, stride, limit) in zip(out, ((0, 1, 8), (8, 1, 16), (56, 1, 64), (3, 8, 64))):\n"
+            "    rows = np.arange(first, limit, stride)\n"
+            "    own = np.zeros((n, n), bool); own[rows] = np.triu(np.ones((n, n), bool), 1)[rows]\n"
+            "    assert (o[~own] == -1).all() and (o[own] == full[own]).all(), (first, stride, limit)\n"
+            "print('ok')\n") % (ROOT, os.path.join(ROOT, "tests"))
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        outs = []
+        for flt in ("0", "1"):
+            f = os.path.join(d, "o%s.npy" % flt)
+            r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, SPSP_DEBUG_FILTER=flt), capture_output=True, text=True, timeout=900)
+            assert r.returncode == 0 and "ok" in r.stdout, (flt, r.stdout[-2000:], r.stderr[-3000:])
+            outs.append(np.load(f))
+        assert (outs[0] == outs[1]).all()
+
+
 def test_partition_form_with_tens_of_thousands_of_parts():
     """SPSP_DEBUG_PART_MEAN=40 cuts the keys into ~30 000 parts (the number BASELINE configs[3]'s 5 x 10^7 keys need):
     list references, slice offsets and the scatter's per-part counters at that scale, on 2 048 C4-shaped sketches."""
