@@ -217,9 +217,13 @@ int spsp_compare(spsp_ctx* ctx, const spsp_sketch_view* sk, uint32_t n, uint32_t
                  uint32_t* inter, uint64_t* card);
 
 /* Device-resident form over concatenated key arrays (sketch i owns entries
- * [d_sk_off[i], d_sk_off[i+1]) ). Only rows i < n_query with i % row_stride == row_first
- * are computed (the multi-GPU split of SURVEY.md 8e: every rank holds all
- * sketches after the all-gather and owns a strided set of rows). d_inter is a
+ * [d_sk_off[i], d_sk_off[i+1]) ). Only the rows row_first, row_first + row_stride, ... below n_query
+ * are computed (the multi-GPU split of SURVEY.md 8e: every rank holds all sketches after the
+ * all-gather and owns a share of the rows -- a block: row_first = its first row, row_stride = 1,
+ * n_query = the end of the block; or strided: row_first = rank, row_stride = ranks, n_query = n).
+ * A call that owns a part of the rows builds its dictionary from the owned sketches' keys; the other
+ * sketches' keys are read once and kept only where an owned sketch may hold them too, and sketches
+ * in front of row_first are not read at all (a row counts the sketches behind it). d_inter is a
  * dense n*n uint32 matrix; cells (i, j > i) of owned rows are overwritten, everything else is left
  * untouched. The work is queued on the context's stream: results are complete once that stream has
  * drained. */
