@@ -552,7 +552,7 @@ __global__ __launch_bounds__(kScatThreads, 4) void k_parts_scatter(Keys K, const
     for (uint32_t p = t; p < n_parts; p += kScatThreads) {
         const uint32_t c = hist[p];
         if (c) hist[p] = atomicAdd(&part_cnt[p], c);     // the chunk's records of part p start here
-    }
+    }                                                    // (eight reservations in flight per thread instead of one: no change at 17 000 parts, measured)
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < E; ++u) {
@@ -1269,14 +1269,19 @@ static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t*
     for (uint32_t i = 0; i < n; ++i)   // grids and ranges are derived from these: a decreasing offset must not reach a kernel
         if (h_sk_off[i + 1] < h_sk_off[i]) { set_error("sketch offsets must be non-decreasing (sketch %u)", i); return SPSP_ERR_ARG; }
     const uint64_t S = h_sk_off[n];
-    if (S == 0) return 1;
-    if (k > 32 && !d_hi) { set_error("k=%u needs kmer_hi", k); return SPSP_ERR_ARG; }
+    if (S && k > 32 && !d_hi) { set_error("k=%u needs kmer_hi", k); return SPSP_ERR_ARG; }
     if (S > 0xfffffff0ull) { set_error("too many sketch k-mers for one call"); return SPSP_ERR_OVERFLOW; }
     uint64_t S_own = 0;
     uint32_t n_own = 0;
     if (row_limit > n) row_limit = n;
     for (uint32_t i = row_first; i < row_limit; i += row_stride) { S_own += h_sk_off[i + 1] - h_sk_off[i]; ++n_own; }
-    if (S_own == 0 || n_own == 0) return 1;
+    if (n_own == 0) return 1;
+    if (S_own == 0) {   // the owned sketches are all empty: their rows are zero (the cells a call owns are always written, spsp.h)
+        hipLaunchKernelGGL(k_zero_rows, dim3(std::max(1u, std::min((n + 255) / 256, 64u)), n_own), dim3(256), 0, ctx->stream,
+                           n, row_first, row_stride, row_limit, d_inter);
+        SPSP_HIP(hipGetLastError());
+        return 1;
+    }
     int rc;
     // staging copy of the offsets (one job may be pending per context, and the previous one has been collected)
     if ((rc = stage_sk_off(ctx, h_sk_off, n))) return rc;

@@ -74,7 +74,7 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     ctx = sp.Context(0)
     t0 = time.time()
-    n_scan = n_cmp = n_sk = n_ex = n_keys = n_files = 0
+    n_scan = n_cmp = n_sk = n_ex = n_keys = n_files = n_rows = 0
     modes = [sp.SPSP_SCAN_DEFAULT, sp.SPSP_SCAN_DIRECT_HASH, sp.SPSP_SCAN_LDS_FILTER, sp.SPSP_SCAN_PAIR_FILTER, sp.SPSP_SCAN_PAIR_FILTER, sp.SPSP_SCAN_BLOOM_FILTER]
     t_report = t0
     while time.time() - t0 < budget:
@@ -142,6 +142,32 @@ def main():
             if not (total == want_t).all():
                 print("EXCHANGE MISMATCH world=%d n_local=%d use_hi=%d" % (world, n_local, use_hi))
                 sys.exit(1)
+            # the same sketches through the row-partitioned device form (a rank's block / strided rows, query limits):
+            # owned cells equal set algebra, every other cell untouched
+            if nt >= 2:
+                mn_a, lo_a, hi_a, off_a = tx.rank_arrays(sets)
+                if int(off_a[-1]) > 0:
+                    dev = torch.device("cuda", 0)
+                    d_mn = torch.from_numpy(mn_a.view(np.int32)).to(dev)
+                    d_lo = torch.from_numpy(lo_a.view(np.int64)).to(dev)
+                    d_hi = torch.from_numpy(hi_a.view(np.int64)).to(dev)
+                    for _ in range(3):
+                        first = int(rng.integers(0, nt))
+                        stride = int(rng.choice([1, 1, 2, 3, world]))
+                        limit = int(rng.integers(first + 1, nt + 1))
+                        d_part = torch.full((nt, nt), -1, dtype=torch.int32, device=dev)
+                        torch.cuda.synchronize()
+                        ctx.compare_device(63 if use_hi else 31, d_mn.data_ptr(), d_lo.data_ptr(), d_hi.data_ptr() if use_hi else None, off_a, nt,
+                                           first, stride, d_part.data_ptr(), n_query=limit)
+                        torch.cuda.synchronize()
+                        got_p = d_part.cpu().numpy()
+                        rows = np.arange(first, limit, stride)
+                        own = np.zeros((nt, nt), bool)
+                        own[rows] = np.triu(np.ones((nt, nt), bool), 1)[rows]
+                        if not ((got_p[~own] == -1).all() and (got_p[own] == want_t[own]).all()):
+                            print("ROW PARTITION MISMATCH nt=%d first=%d stride=%d limit=%d use_hi=%d" % (nt, first, stride, limit, use_hi))
+                            sys.exit(1)
+                        n_rows += 1
             cardx = np.array([len(x) for x in sets], dtype=np.uint64)
             names = ["s%d.gz" % i for i in range(nt)]
             prec, thr, nqx = int(rng.integers(0, 13)), float(rng.choice([0.0, 0.0, 0.01, 0.3])), int(rng.integers(1, nt + 1))
@@ -242,7 +268,8 @@ def main():
                 sys.exit(1)
             n_cmp += 1
     sp.sketch_files_release()
-    print("soak ok: %d scans, %d sketch payloads, %d comparisons, %d exchanges + CSV pairs, %d key extractions, %d files through the pipeline in %.0f s" % (n_scan, n_sk, n_cmp, n_ex, n_keys, n_files, time.time() - t0))
+    print("soak ok: %d scans, %d sketch payloads, %d comparisons, %d exchanges + CSV pairs, %d row-partitioned comparisons, %d key extractions, %d files through the pipeline in %.0f s"
+          % (n_scan, n_sk, n_cmp, n_ex, n_rows, n_keys, n_files, time.time() - t0))
 
 
 if __name__ == "__main__":
