@@ -337,6 +337,9 @@ __global__ __launch_bounds__(kSparseThreads) void k_accumulate_sparse(const uint
                                                                      uint32_t* __restrict__ host_flags) {
     extern __shared__ uint32_t s_cnt[];
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < kFlags) host_flags[threadIdx.x] = flags[threadIdx.x];
+    // a part overflowed: its workgroup of k_parts_group left without writing list references, so the ones in place are
+    // whatever the buffer held before -- nothing may be followed from them (the host repeats the call with more parts)
+    if (flags[6]) return;
     const uint32_t i = row_first + blockIdx.y * row_stride, col0 = blockIdx.x * cols;
     if (i >= n || i >= row_limit) return;
     if (col0 + cols <= i + 1) return;                       // no column > i in this block

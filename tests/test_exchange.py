@@ -549,17 +549,21 @@ def test_filtered_rows_equal_unfiltered_rows_and_grow_their_parts():
             "dev = torch.device('cuda', 0)\n"
             "d_lo = torch.from_numpy(np.concatenate(sets).view(np.int64)).to(dev)\n"
             "d_min = torch.full((int(cnt.sum()),), 7, dtype=torch.int32, device=dev)\n"
+            "d_hi = d_lo >> 8                                         # k > 32: the high word is part of the key (three-word records); order kept\n"
             "ctx = sp.Context(0)\nout = []\n"
-            "for first, stride, limit in ((0, 1, 8), (8, 1, 16), (56, 1, 64), (3, 8, 64), (0, 1, 64)):\n"
+            "forms = ((0, 1, 8), (8, 1, 16), (56, 1, 64), (3, 8, 64), (0, 1, 64))\n"
+            "for k in (31, 63):\n"
+            "  for first, stride, limit in forms:\n"
             "    part = torch.full((n, n), -1, dtype=torch.int32, device=dev)\n"
             "    torch.cuda.synchronize()\n"
-            "    ctx.compare_device(31, d_min.data_ptr(), d_lo.data_ptr(), None, sk_off, n, first, stride, part.data_ptr(), n_query=limit)\n"
+            "    ctx.compare_device(k, d_min.data_ptr(), d_lo.data_ptr(), d_hi.data_ptr() if k > 32 else None, sk_off, n, first, stride, part.data_ptr(), n_query=limit)\n"
             "    torch.cuda.synchronize()\n"
             "    out.append(part.cpu().numpy())\n"
             "np.save(sys.argv[1], np.stack(out))\n"
-            "full = out[-1]\n"
-            "assert full[0, 1] == len(np.intersect1d(sets[0], sets[1])) and full[5, 60] == len(np.intersect1d(sets[5], sets[60]))\n"
-            "for o, (first, stride, limit) in zip(out, ((0, 1, 8), (8, 1, 16), (56, 1, 64), (3, 8, 64))):\n"
+            "for half in (out[:5], out[5:]):\n"
+            "  full = half[-1]\n"
+            "  assert full[0, 1] == len(np.intersect1d(sets[0], sets[1])) and full[5, 60] == len(np.intersect1d(sets[5], sets[60]))\n"
+            "  for o, (first, stride, limit) in zip(half, forms[:4]):\n"
             "    rows = np.arange(first, limit, stride)\n"
             "    own = np.zeros((n, n), bool); own[rows] = np.triu(np.ones((n, n), bool), 1)[rows]\n"
             "    assert (o[~own] == -1).all() and (o[own] == full[own]).all(), (first, stride, limit)\n"

@@ -69,6 +69,13 @@ def random_fasta_text(rng):
     return b"\n".join(out) + (b"\n" if rng.random() < 0.5 else b"")
 
 
+def mark(msg):
+    """what is about to run, kept in a file: a GPU fault kills the process without a Python traceback"""
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "soak_last.txt"), "w") as f:
+        f.write(msg + "\n")
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
@@ -95,6 +102,7 @@ def main():
         bases, offs = synth.concat_records(recs)
         mode = int(rng.choice(modes))
         p = sp.make_params(k, m, s, flags=mode)
+        mark("scan %d: k=%d m=%d s=%g mode=%d bases=%d records=%d" % (n_scan + 1, k, m, s, mode, len(bases), len(recs)))
         if n_scan % 3 == 1 and len(bases) >= k:      # the same records as 2-bit words (SPSP_SCAN_PACKED_INPUT), device form
             d_b = torch.from_numpy(bases).cuda()
             d_o = torch.from_numpy(offs.view(np.int64)).cuda()
@@ -116,6 +124,7 @@ def main():
             text = random_fasta_text(rng)
             ab = int(rng.choice([1, 1, 2, 3]))
             s2 = float(np.float32(max(s, 1.0) if rng.random() < 0.7 else float(rng.choice([1.0, 2.0, 4.0]))))   # the CLI parses -s with stof
+            mark("sketch_text after scan %d: k=%d m=%d s=%g ab=%d mode=%d text=%d bytes" % (n_scan, k, m, s2, ab, mode, len(text)))
             got_pl, got_st = ctx.sketch_text(text, k, m, s2, ab, mode)
             want_pl, want_st = orc.sketch_fasta(text, k, m, float(np.float32(s2)), ab)
             if got_pl != want_pl:
@@ -131,6 +140,7 @@ def main():
             per_rank = [sets[r * n_local:(r + 1) * n_local] for r in range(world)]
             biggest = max(1, max(sum(len(x) for x in pr) for pr in per_rank))
             cap = biggest if world == 1 else int(biggest / world * 1.5) + 64
+            mark("exchange after scan %d: world=%d n_local=%d use_hi=%d" % (n_scan, world, n_local, use_hi))
             try:
                 _, total = tx.exchange_and_compare(ctx, 63 if use_hi else 31, per_rank, cap)
             except sp.SpspError as e:
@@ -157,6 +167,7 @@ def main():
                         limit = int(rng.integers(first + 1, nt + 1))
                         d_part = torch.full((nt, nt), -1, dtype=torch.int32, device=dev)
                         torch.cuda.synchronize()
+                        mark("row partition after scan %d: nt=%d first=%d stride=%d limit=%d use_hi=%d keys=%d" % (n_scan, nt, first, stride, limit, use_hi, int(off_a[-1])))
                         ctx.compare_device(63 if use_hi else 31, d_mn.data_ptr(), d_lo.data_ptr(), d_hi.data_ptr() if use_hi else None, off_a, nt,
                                            first, stride, d_part.data_ptr(), n_query=limit)
                         torch.cuda.synchronize()
@@ -189,6 +200,7 @@ def main():
             d_b = torch.from_numpy(np.concatenate([gb, np.zeros(64, np.uint8)])).cuda()
             d_o = torch.from_numpy(go.view(np.int64)).cuda()
             torch.cuda.synchronize()
+            mark("key extraction after scan %d: k=%d m=%d s=%g ab=%d mode=%d genomes=%d bases=%d" % (n_scan, k, m, s, ab, mode, ng, len(gb)))
             d_sk, n_skm = ctx.scan_device(pk, d_b.data_ptr(), len(gb), d_o.data_ptr(), len(grecs))
             wants = []
             for g in groups:
@@ -235,6 +247,7 @@ def main():
                 outs = [os.path.join(tmp, "o%d.gz" % i) for i in range(nf)]
                 s2 = float(np.float32(max(s, 1.0)))
                 ab = int(rng.choice([1, 1, 1, 2]))
+                mark("files after scan %d: k=%d m=%d s=%g ab=%d mode=%d files=%d" % (n_scan, k, m, s2, ab, mode, nf))
                 res, _, _ = sp.sketch_files(ins, outs, k, m, s2, abundance=ab, threads=int(rng.integers(1, 9)), flags=mode | sp.SPSP_SCAN_STATS)
                 for i, (rc, st, err) in enumerate(res):
                     want_pl, want_st = orc.sketch_fasta(texts[i], k, m, s2, ab)
@@ -257,6 +270,7 @@ def main():
             nq = n if rng.random() < 0.6 else int(rng.integers(1, n + 1))
             want_inter, want_card, _, _ = orc.compare(payloads, n_query=nq)
             sketches = sp.sketches_from_payloads(payloads)     # incl. the merge's first-read rule for empty sketches
+            mark("compare after scan %d: k=%d m=%d s=%g n=%d nq=%d keys=%d" % (n_scan, k, m, s, n, nq, sum(len(x) for x in sketches)))
             inter, card = ctx.compare(sketches, n_query=nq)
             if not ((inter[:nq] == want_inter[:nq]).all() and [int(c) for c in card] == [int(c) for c in want_card]):   # printed rows
                 print("COMPARE MISMATCH k=%d m=%d s=%g n=%d nq=%d" % (k, m, s, n, nq))
