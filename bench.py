@@ -14,7 +14,11 @@ different batches (a ring of 3 x 500 MB).  Workload = BASELINE.json configs[1]:
 
 N > 1: genomes are sharded by rank (no data-path collective for the scan); the
 comparison all-gathers the packed sketch keys over RCCL and every rank owns the
-rows i % N == rank of the (100 N) x (100 N) pair matrix.
+rows of its own 100 sketches in the (100 N) x (100 N) pair matrix (SURVEY.md 8e;
+its dictionary holds its own keys, the other ranks' keys pass a filter).  The
+all-gather is pre-sized from the setup's key counts, so with N > 1 the keys that
+travel are the setup's (the per-step key extraction would need the counts of
+every rank on the host first: one more collective and a host wait per step).
 
 Besides the timed step, rank 0 of a single-GPU run measures (untimed, after the
 step loop): the open step of rounds 1-2 (`open_loop`), the comparator alone at
