@@ -165,6 +165,8 @@ def main():
         pass
 
     slots = []
+    dense_streams = int(os.environ.get("BENCH_DENSE_STREAMS", "1")) if (schedule == "partition" and pipelined) else 1
+    dense_extra = []
     # (four steps in flight: the closed step has more host work per visit -- two more queueing calls -- and the scans'
     # sparse stages finish later beside the key extraction: 0.134 / 0.127 / 0.124 ms per step with 2 / 3 / 4 slots)
     # (the multi-GPU step, which still compares the setup's keys, keeps the two slots it was tuned with)
@@ -172,6 +174,13 @@ def main():
         sl = Slot()
         if pipelined:
             sl.stream_a = stream if (i == 0 or schedule != "streams") else torch.cuda.Stream(device=dev)
+            if schedule == "partition" and dense_streams > 1 and i % dense_streams:
+                # BENCH_DENSE_STREAMS=2 (experiment): consecutive dense passes on two streams that own the SAME CUs, not ordered
+                # against each other -- the next pass's workgroups move in as the previous one's leave
+                if len(dense_extra) < i % dense_streams:
+                    masked.append(sp.stream_create_cus(local_rank, dense_first, dense_cus))
+                    dense_extra.append(torch.cuda.ExternalStream(masked[-1], device=dev))
+                sl.stream_a = dense_extra[i % dense_streams - 1]
             sl.scan = ctx if i == 0 else sp.Context(local_rank, sl.stream_a.cuda_stream)
             if schedule == "partition":
                 sl.scan.set_cu_count(dense_cus, 2)
@@ -352,7 +361,7 @@ def main():
         """queue one whole step on slot sl without waiting for anything; on the GPU its dense pass starts behind
         the dense pass of slot prev.  nxt = the slot of the following step (slots exchange: its key partition is
         started from here, behind this dense pass)"""
-        if prev is not None and prev.stream_a is not sl.stream_a:
+        if prev is not None and prev.stream_a is not sl.stream_a and dense_streams == 1:
             sl.scan.wait_dense(prev.scan)                 # "streams": dense passes never overlap each other
         sl.batch = step_no[0] % n_batches
         step_no[0] += 1
