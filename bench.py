@@ -331,7 +331,9 @@ def main():
         elif keys_stream == "dense":
             stream_k = stream
         elif schedule == "partition":
-            masked.append(sp.stream_create_cus(local_rank, 0, small_cus))
+            # BENCH_KEYS_CUS="first,count" (experiment): the key extraction on a part of the small CUs only
+            k_first, k_cnt = (int(x) for x in os.environ.get("BENCH_KEYS_CUS", "0,%d" % small_cus).split(","))
+            masked.append(sp.stream_create_cus(local_rank, k_first, k_cnt))
             stream_k = torch.cuda.ExternalStream(masked[-1], device=dev)
         else:
             stream_k = torch.cuda.Stream(device=dev)
