@@ -473,32 +473,45 @@ __global__ __launch_bounds__(kKeySortThreads) void k_keys_lean(const uint8_t* __
         lo = f < rc ? f : rc;
         mo = (e & 0x7fffffffu) | ((((e >> 31) ? rc : f) != lo) ? 0x80000000u : 0u);
     };
-    auto home = [&](uint32_t mo, uint64_t lo) {
+    // slot word: claiming place + 1 (13 bits) | occurrences << 13 (13 bits: a genome has at most 6144 places) | six bits of
+    // the key's hash << 26 -- a probe reads a claimer's key back only when the six bits agree, i.e. for its own key and
+    // one in 64 of the others
+    auto hash_of = [&](uint32_t mo, uint64_t lo) {
         uint64_t h = keys_mix(lo ^ 0x9E3779B97F4A7C15ULL);
-        h = keys_mix(h + (uint64_t)mo * 0xD6E8FEB86659FD93ULL);
-        return (uint32_t)(((h & 0xffffffffull) * SLOTS) >> 32);
+        return keys_mix(h + (uint64_t)mo * 0xD6E8FEB86659FD93ULL);
     };
+    auto home_of = [&](uint64_t h) { return (uint32_t)(((h & 0xffffffffull) * SLOTS) >> 32); };
+    auto tag_of = [&](uint64_t h) { return (uint32_t)(h >> 40) & 63u; };
     uint64_t my_lo[PER];
-    uint32_t my_mo[PER], hs[PER];
+    uint32_t my_mo[PER], hs[PER], tg[PER];
     bool have[PER];
 #pragma unroll
-    for (uint32_t u = 0; u < PER; ++u) {                           // place r = u * threads + t
+    for (uint32_t u = 0; u < PER; ++u) {                           // place r = u * threads + t: its key, home slot and tag (independent: all six in flight)
         const uint32_t r = u * kKeySortThreads + t;
-        have[u] = false; hs[u] = 0; my_lo[u] = 0; my_mo[u] = 0;
+        have[u] = false; hs[u] = 0; tg[u] = 0; my_lo[u] = 0; my_mo[u] = 0;
         if (r >= n) continue;
         const uint32_t q = w == 1 ? r : __umulhi(r, w_magic), j = r - q * w;
         const uint32_t last = slast[q];
         if (last == 255u || j > last) continue;                    // no k-mer starts here
         key_at(r, my_mo[u], my_lo[u]);
         have[u] = true;
-        uint32_t h = home(my_mo[u], my_lo[u]);
+        const uint64_t h = hash_of(my_mo[u], my_lo[u]);
+        hs[u] = home_of(h); tg[u] = tag_of(h);
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < PER; ++u) {
+        if (!have[u]) continue;
+        const uint32_t r = u * kKeySortThreads + t;
+        uint32_t h = hs[u];
         for (;;) {                                                 // ends: twice as many slots as places
             uint32_t cur = slot[h];
-            if (cur == 0) cur = atomicCAS(&slot[h], 0u, r + 1);
+            if (cur == 0) cur = atomicCAS(&slot[h], 0u, (tg[u] << 26) | (r + 1));
             if (cur == 0) break;                                   // claimed
-            uint32_t cmo; uint64_t clo;
-            key_at((cur & 0x1fffu) - 1, cmo, clo);
-            if (clo == my_lo[u] && cmo == my_mo[u]) break;
+            if ((cur >> 26) == tg[u]) {
+                uint32_t cmo; uint64_t clo;
+                key_at((cur & 0x1fffu) - 1, cmo, clo);
+                if (clo == my_lo[u] && cmo == my_mo[u]) break;
+            }
             h = h + 1 == SLOTS ? 0u : h + 1;
         }
         hs[u] = h;
@@ -517,13 +530,17 @@ __global__ __launch_bounds__(kKeySortThreads) void k_keys_lean(const uint8_t* __
         uint32_t emit = 1;
         if (my_mo[u] >> 31) {                                      // the forward-oriented group of the same canonical key emits if it is usable
             const uint32_t sib = my_mo[u] & 0x7fffffffu;
-            uint32_t h = home(sib, my_lo[u]);
+            const uint64_t hh = hash_of(sib, my_lo[u]);
+            const uint32_t stag = tag_of(hh);
+            uint32_t h = home_of(hh);
             for (;;) {
                 const uint32_t cur = slot[h];
                 if (cur == 0) break;                               // no such group
-                uint32_t cmo; uint64_t clo;
-                key_at((cur & 0x1fffu) - 1, cmo, clo);
-                if (clo == my_lo[u] && cmo == sib) { if (usable(cur)) emit = 0; break; }
+                if ((cur >> 26) == stag) {
+                    uint32_t cmo; uint64_t clo;
+                    key_at((cur & 0x1fffu) - 1, cmo, clo);
+                    if (clo == my_lo[u] && cmo == sib) { if (usable(cur)) emit = 0; break; }
+                }
                 h = h + 1 == SLOTS ? 0u : h + 1;
             }
         }
