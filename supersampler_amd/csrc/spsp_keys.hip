@@ -386,186 +386,6 @@ __global__ __launch_bounds__(kKeySortThreads) void k_keys_fused(const uint8_t* _
     if (t == 0) distinct[seg] = base;
 }
 
-// k <= 32, one workgroup per genome, HALF the LDS: the table holds slot words only -- a record IS its k-mer place
-// r = (super-k-mer - q0) * w + j, and a key that has to be compared with a slot's claimer is read back out of the staged
-// super-k-mers (three LDS words, a shift, rc_window64) instead of out of a stored copy; every lane keeps its own six keys
-// in registers.  48 KiB of slots + 16 KiB of super-k-mer words + 4 KiB of (minimizer | reversed) = 68 KiB, so two
-// workgroups share a CU: the 100 genomes of bench.py's batch are ONE round on the 64 CUs of the small partition where
-// the full-copy table (136 KiB, one workgroup per CU) took two.
-constexpr uint32_t kLeanSkm = kDedupSkmWords / 4;                  // super-k-mers per genome (four words each: 2k - m <= 53 bases)
-__global__ __launch_bounds__(kKeySortThreads) void k_keys_lean(const uint8_t* __restrict__ bases, bool packed, uint64_t n_bases_readable,
-                                                              const uint64_t* __restrict__ rec_off,
-                                                              const spsp_superkmer* __restrict__ sk, uint32_t n_sk, const uint32_t* __restrict__ first_rec,
-                                                              uint32_t k, uint32_t w, uint32_t w_magic, uint32_t abundance, uint32_t* __restrict__ r_mn,
-                                                              uint64_t* __restrict__ r_lo, uint32_t* __restrict__ raw_off,
-                                                              uint32_t* __restrict__ distinct, uint32_t* __restrict__ flags) {
-    constexpr uint32_t FULL = kDedupCapLo, SLOTS = 2 * FULL, PER = FULL / kKeySortThreads, CH = 4;
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds_l[];
-    uint32_t* slot = reinterpret_cast<uint32_t*>(lds_l);           // [SLOTS]
-    uint32_t* skw = slot + SLOTS;                                  // [kDedupSkmWords]
-    uint32_t* smo = skw + kDedupSkmWords;                          // [kLeanSkm] minimizer | (reads reversed) << 31
-    uint8_t* slast = reinterpret_cast<uint8_t*>(smo + kLeanSkm);   // [kLeanSkm] start of the super-k-mer's last k-mer (255: shorter than k)
-    __shared__ uint32_t wave_sum[kKeySortThreads / 64];
-    __shared__ uint32_t s_q[2];
-    const uint32_t g = blockIdx.x, t = threadIdx.x, lane = t & 63, wid = t >> 6;
-    if (wid == 0) {                                                // this genome's super-k-mers [q0, q1): 64-way search (k_keys_fused)
-        for (int which = 0; which < 2; ++which) {
-            const uint32_t want = first_rec[g + which];
-            uint32_t lo = 0, hi = n_sk;
-            while (hi - lo > 0) {
-                const uint32_t span = hi - lo, step = (span + 63) / 64;
-                const uint32_t at = lo + lane * step;
-                const bool below = at < hi && sk[at].rec < want;
-                const uint32_t nb = (uint32_t)__popcll(__ballot(below));
-                if (nb == 0) { hi = lo; break; }
-                lo = lo + (nb - 1) * step + 1;
-                const uint32_t next_probe = lo + step - 1;
-                hi = next_probe < hi ? next_probe : hi;
-            }
-            if (lane == 0) s_q[which] = lo;
-        }
-    }
-    __syncthreads();
-    const uint32_t q0 = s_q[0], q1 = s_q[1];
-    const uint32_t n = (q1 - q0) * w, r0 = q0 * w;
-    if (t == 0) raw_off[g] = r0;
-    if (n == 0) { if (t == 0) distinct[g] = 0; return; }
-    if (n > FULL || q1 - q0 > kLeanSkm) { if (t == 0) { distinct[g] = 0; atomicOr(&flags[0], 1u); atomicMax(&flags[1], n); } return; }
-    for (uint32_t x = t; x < SLOTS; x += kKeySortThreads) slot[x] = 0;
-    {
-        const uint32_t* gw = reinterpret_cast<const uint32_t*>(bases);
-        for (uint32_t c = t; c < (q1 - q0) * CH; c += kKeySortThreads) {
-            const spsp_superkmer e = sk[q0 + c / CH];
-            const uint32_t b0 = (c % CH) * 16;
-            uint32_t word = 0;
-            if (b0 < e.len) {
-                const uint64_t q = rec_off[e.rec] + e.start + b0;
-                const uint32_t have = e.len - b0 < 16 ? e.len - b0 : 16;
-                if (packed) {
-                    const uint32_t sh = 2u * (uint32_t)(q & 15u);
-                    const uint32_t w0 = gw[q >> 4], w1 = sh ? gw[(q >> 4) + 1] : 0u;
-                    word = sh ? (w0 << sh) | (w1 >> (32u - sh)) : w0;
-                } else if (((q & ~15ull) + 32) <= n_bases_readable) {
-                    const uint4* v = reinterpret_cast<const uint4*>(bases + (q & ~15ull));
-                    const uint64_t both = ((uint64_t)pack16(v[0]) << 32) | pack16(v[1]);
-                    word = (uint32_t)((both << (2u * (uint32_t)(q & 15u))) >> 32);
-                } else {
-                    for (uint32_t b = 0; b < have; ++b) word |= (((uint32_t)bases[q + b] >> 1) & 3u) << (30u - 2u * b);
-                }
-                if (have < 16) word &= ~0u << (32u - 2u * have);
-            }
-            skw[c] = word;
-            if (c % CH == 0) { smo[c / CH] = e.minimizer | (e.rev ? 0x80000000u : 0u); slast[c / CH] = e.len < k ? (uint8_t)255 : (uint8_t)(e.len - k); }   // (len <= 2k - m: at most k - m <= 29)
-        }
-    }
-    __syncthreads();
-    const uint64_t mask = k == 32 ? ~0ull : ((1ull << (2 * k)) - 1);
-    // key of place r: (minimizer | orientation << 31, canonical k-mer).  The caller vouches that r holds a k-mer.
-    auto key_at = [&](uint32_t r, uint32_t& mo, uint64_t& lo) {
-        const uint32_t q = w == 1 ? r : __umulhi(r, w_magic), j = r - q * w;    // r / w, r % w  (w_magic = 2^32 / w rounded up, exact for r < 2^13; k == m: w = 1)
-        const uint32_t* sw = skw + q * CH;
-        const uint32_t p = j >> 4, o = j & 15u;
-        const uint32_t w0 = sw[p], w1 = p + 1 < CH ? sw[p + 1] : 0u, w2 = p + 2 < CH ? sw[p + 2] : 0u;
-        const u128d X = ((u128d)w0 << 64) | ((u128d)w1 << 32) | w2;
-        const uint64_t f = (uint64_t)(X >> (2u * (48u - o - k))) & mask;
-        const uint64_t rc = rc_window64(f << (64u - 2u * k)) & mask;
-        const uint32_t e = smo[q];
-        lo = f < rc ? f : rc;
-        mo = (e & 0x7fffffffu) | ((((e >> 31) ? rc : f) != lo) ? 0x80000000u : 0u);
-    };
-    // slot word: claiming place + 1 (13 bits) | occurrences << 13 (13 bits: a genome has at most 6144 places) | six bits of
-    // the key's hash << 26 -- a probe reads a claimer's key back only when the six bits agree, i.e. for its own key and
-    // one in 64 of the others
-    auto hash_of = [&](uint32_t mo, uint64_t lo) {
-        uint64_t h = keys_mix(lo ^ 0x9E3779B97F4A7C15ULL);
-        return keys_mix(h + (uint64_t)mo * 0xD6E8FEB86659FD93ULL);
-    };
-    auto home_of = [&](uint64_t h) { return (uint32_t)(((h & 0xffffffffull) * SLOTS) >> 32); };
-    auto tag_of = [&](uint64_t h) { return (uint32_t)(h >> 40) & 63u; };
-    uint64_t my_lo[PER];
-    uint32_t my_mo[PER], hs[PER], tg[PER];
-    bool have[PER];
-#pragma unroll
-    for (uint32_t u = 0; u < PER; ++u) {                           // place r = u * threads + t: its key, home slot and tag (independent: all six in flight)
-        const uint32_t r = u * kKeySortThreads + t;
-        have[u] = false; hs[u] = 0; tg[u] = 0; my_lo[u] = 0; my_mo[u] = 0;
-        if (r >= n) continue;
-        const uint32_t q = w == 1 ? r : __umulhi(r, w_magic), j = r - q * w;
-        const uint32_t last = slast[q];
-        if (last == 255u || j > last) continue;                    // no k-mer starts here
-        key_at(r, my_mo[u], my_lo[u]);
-        have[u] = true;
-        const uint64_t h = hash_of(my_mo[u], my_lo[u]);
-        hs[u] = home_of(h); tg[u] = tag_of(h);
-    }
-#pragma unroll
-    for (uint32_t u = 0; u < PER; ++u) {
-        if (!have[u]) continue;
-        const uint32_t r = u * kKeySortThreads + t;
-        uint32_t h = hs[u];
-        for (;;) {                                                 // ends: twice as many slots as places
-            uint32_t cur = slot[h];
-            if (cur == 0) cur = atomicCAS(&slot[h], 0u, (tg[u] << 26) | (r + 1));
-            if (cur == 0) break;                                   // claimed
-            if ((cur >> 26) == tg[u]) {
-                uint32_t cmo; uint64_t clo;
-                key_at((cur & 0x1fffu) - 1, cmo, clo);
-                if (clo == my_lo[u] && cmo == my_mo[u]) break;
-            }
-            h = h + 1 == SLOTS ? 0u : h + 1;
-        }
-        hs[u] = h;
-        atomicAdd(&slot[h], 1u << 13);
-    }
-    __syncthreads();
-    auto usable = [&](uint32_t wd) { return ((wd >> 13) & 255u) >= abundance; };   // the reference's uint8 counter: 256 occurrences read as 0
-    uint32_t keep[PER];
-#pragma unroll
-    for (uint32_t u = 0; u < PER; ++u) {
-        const uint32_t r = u * kKeySortThreads + t;
-        keep[u] = 0;
-        if (!have[u]) continue;
-        const uint32_t wd = slot[hs[u]];
-        if ((wd & 0x1fffu) != r + 1 || !usable(wd)) continue;      // one lane per (key, orientation) group: its claimer
-        uint32_t emit = 1;
-        if (my_mo[u] >> 31) {                                      // the forward-oriented group of the same canonical key emits if it is usable
-            const uint32_t sib = my_mo[u] & 0x7fffffffu;
-            const uint64_t hh = hash_of(sib, my_lo[u]);
-            const uint32_t stag = tag_of(hh);
-            uint32_t h = home_of(hh);
-            for (;;) {
-                const uint32_t cur = slot[h];
-                if (cur == 0) break;                               // no such group
-                if ((cur >> 26) == stag) {
-                    uint32_t cmo; uint64_t clo;
-                    key_at((cur & 0x1fffu) - 1, cmo, clo);
-                    if (clo == my_lo[u] && cmo == sib) { if (usable(cur)) emit = 0; break; }
-                }
-                h = h + 1 == SLOTS ? 0u : h + 1;
-            }
-        }
-        keep[u] = emit;
-    }
-    uint32_t cnt = 0;
-#pragma unroll
-    for (uint32_t u = 0; u < PER; ++u) cnt += keep[u];
-    uint32_t x = cnt;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d); if (lane >= (uint32_t)d) x += y; }
-    if (lane == 63) wave_sum[wid] = x;
-    __syncthreads();
-    uint32_t pre = 0, base = 0;
-    for (uint32_t w2 = 0; w2 < kKeySortThreads / 64; ++w2) { if (w2 < wid) pre += wave_sum[w2]; base += wave_sum[w2]; }
-    uint32_t at = r0 + pre + x - cnt;
-#pragma unroll
-    for (uint32_t u = 0; u < PER; ++u) {
-        if (!keep[u]) continue;
-        r_mn[at] = my_mo[u] & 0x7fffffffu; r_lo[at] = my_lo[u];
-        ++at;
-    }
-    if (t == 0) distinct[g] = base;
-}
-
 __global__ __launch_bounds__(256) void k_keys_compact(const uint32_t* __restrict__ r_mn, const uint64_t* __restrict__ r_lo,
                                                      const uint64_t* __restrict__ r_hi, const uint32_t* __restrict__ raw_off,
                                                      const uint32_t* __restrict__ distinct, const uint32_t* __restrict__ out_off,
@@ -664,26 +484,12 @@ int sketch_keys_begin_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d
             SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keys_fused<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kDedupCapLo * 10 + kDedupSkmWords * 4)));
             ctx->attr_dedupe_set = true;
         }
-        // k <= 32, one workgroup per genome: the table of slot words only (k_keys_lean; SPSP_KEYS_FULL=1 keeps the full-copy table)
-        static const bool full_table = getenv("SPSP_KEYS_FULL") && atoi(getenv("SPSP_KEYS_FULL")) != 0;
-        const bool lean = !has_hi && split == 1 && !full_table;
-        if (lean) {
-            constexpr size_t lds_l = (size_t)2 * kDedupCapLo * 4 + (size_t)kDedupSkmWords * 4 + (size_t)kLeanSkm * 4 + kLeanSkm;
-            if (!ctx->attr_lean_set) {
-                SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keys_lean), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l));
-                ctx->attr_lean_set = true;
-            }
-            const uint32_t w_magic = (uint32_t)(((1ull << 32) + w - 1) / w);
-            hipLaunchKernelGGL(k_keys_lean, dim3(segs), dim3(kKeySortThreads), lds_l, ctx->stream, d_bases, packed, n_bases_readable, d_rec_off, d_sk, n, d_first_rec,
-                               p->k, w, w_magic, ab, ctx->a_mn.as<uint32_t>(), ctx->a_lo.as<uint64_t>(), d_raw_off, d_distinct, d_flags);
-        } else {
 #define SPSP_KEYS_FUSED(HI, SP) hipLaunchKernelGGL((k_keys_fused<HI, SP>), dim3(segs), dim3(kKeySortThreads), lds_d, ctx->stream, d_bases, packed, n_bases_readable, d_rec_off, \
                                                     d_sk, n, d_first_rec, p->k, w, ab, (uint32_t)bound, ctx->a_mn.as<uint32_t>(), ctx->a_lo.as<uint64_t>(),                   \
                                                     HI ? ctx->a_hi.as<uint64_t>() : (uint64_t*)nullptr, d_raw_off, d_distinct, d_flags)
         if (has_hi) { if (split == 2) SPSP_KEYS_FUSED(true, 2); else SPSP_KEYS_FUSED(true, 1); }
         else { if (split == 2) SPSP_KEYS_FUSED(false, 2); else SPSP_KEYS_FUSED(false, 1); }
 #undef SPSP_KEYS_FUSED
-        }
         SPSP_HIP(hipGetLastError());
         hipLaunchKernelGGL(k_keys_compact, dim3(8, segs), dim3(256), 0, ctx->stream, ctx->a_mn.as<uint32_t>(), ctx->a_lo.as<uint64_t>(),
                            has_hi ? ctx->a_hi.as<uint64_t>() : (const uint64_t*)nullptr, d_raw_off, d_distinct, (const uint32_t*)nullptr, ctx->c_min.as<uint32_t>(),

@@ -1113,8 +1113,7 @@ def test_sketch_keys_on_device_equal_the_file_path(ctx, k, m, s, ab):
 
 
 def test_sketch_keys_split_form_and_api_misuse(ctx):
-    """SPSP_KEYS_SPLIT=2 (two workgroups per genome, each tabling one hash class of its keys) and SPSP_KEYS_FULL=1 (keys
-    copied into the table instead of read back from the staged super-k-mers) give the same key sets; a
+    """SPSP_KEYS_SPLIT=2 (two workgroups per genome, each tabling one hash class of its keys) gives the same key sets; a
     second _begin on a context with a job pending and an _end without a job are refused; spsp_measure_hbm_device returns
     rates a streaming kernel can have on this part."""
     import torch
@@ -1136,10 +1135,8 @@ def test_sketch_keys_split_form_and_api_misuse(ctx):
             "    x, y = int(koff[g]), int(koff[g + 1])\n"
             "    assert sorted(zip(mn[x:y].tolist(), lo[x:y].tolist())) == list(zip(w_mn.tolist(), w_lo.tolist())), g\n"
             "assert int(koff[1]) > 1000\nprint('ok')\n") % (ROOT, os.path.join(ROOT, "tests"))
-    # (the default at k <= 32 is the table of slot words only, k_keys_lean: SPSP_KEYS_FULL=1 selects the full-copy table it replaced)
-    for env in ({"SPSP_KEYS_SPLIT": "2"}, {"SPSP_KEYS_FULL": "1"}):
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0 and "ok" in r.stdout, (env, r.stdout[-2000:], r.stderr[-3000:])
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SPSP_KEYS_SPLIT="2"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
     rng = np.random.default_rng(6)
     g = synth.random_genome(rng, 40_000)
     bases, off = synth.concat_records([g])
