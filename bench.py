@@ -166,6 +166,7 @@ def main():
 
     slots = []
     dense_streams = int(os.environ.get("BENCH_DENSE_STREAMS", "1")) if (schedule == "partition" and pipelined) else 1
+    scan_buffers = int(os.environ.get("BENCH_SCAN_BUFFERS", "1")) if pipelined else 1
     dense_extra = []
     # (four steps in flight: the closed step has more host work per visit -- two more queueing calls -- and the scans'
     # sparse stages finish later beside the key extraction: 0.134 / 0.127 / 0.124 ms per step with 2 / 3 / 4 slots)
@@ -201,6 +202,18 @@ def main():
                 if tail_streams:
                     sl.scan.scan_tail_stream(True)
                 sl.stream_b = torch.cuda.Stream(device=dev)
+            sl.scans = [sl.scan]
+            if scan_buffers > 1:
+                # BENCH_SCAN_BUFFERS=2 (experiment): a slot alternates between two scan contexts, so the scan queued in a visit
+                # does not rewrite the super-k-mer stream the key extraction queued in the same visit still reads
+                extra = sp.Context(local_rank, sl.stream_a.cuda_stream)
+                if schedule == "partition":
+                    extra.set_cu_count(dense_cus, 2)
+                    extra.scan_tail_stream(True, tail_h)
+                elif tail_streams:
+                    extra.scan_tail_stream(True)
+                sl.scans.append(extra)
+            sl.sv = 0
             sl.cmp = sp.Context(local_rank, sl.stream_b.cuda_stream)
             if schedule == "partition":
                 sl.cmp.set_cu_count(small_cus)
@@ -210,7 +223,7 @@ def main():
         slots.append(sl)
     all_ctx = []
     for sl in slots:
-        for c in (sl.scan, sl.cmp):
+        for c in (*getattr(sl, "scans", [sl.scan]), sl.cmp):
             if c not in all_ctx:
                 all_ctx.append(c)
 
@@ -337,7 +350,13 @@ def main():
             stream_k = torch.cuda.ExternalStream(masked[-1], device=dev)
         else:
             stream_k = torch.cuda.Stream(device=dev)
-        for sl in slots:
+        # BENCH_KEYS_STREAMS=2 (experiment): the key extractions of consecutive steps on two streams over the same CUs
+        streams_k = [stream_k]
+        if int(os.environ.get("BENCH_KEYS_STREAMS", "1")) > 1 and schedule == "partition" and keys_stream == "own":
+            masked.append(sp.stream_create_cus(local_rank, k_first, k_cnt))
+            streams_k.append(torch.cuda.ExternalStream(masked[-1], device=dev))
+        for si, sl in enumerate(slots):
+            stream_k = streams_k[si % len(streams_k)]
             sl.cmp.compare_keys_unordered(True)           # the step's keys come out of an LDS table per genome: distinct, not sorted
             sl.keys = [sp.Context(local_rank, stream_k.cuda_stream), sp.Context(local_rank, stream_k.cuda_stream)]
             sl.kv = 0
@@ -367,8 +386,12 @@ def main():
             sl.scan.wait_dense(prev.scan)                 # "streams": dense passes never overlap each other
         sl.batch = step_no[0] % n_batches
         step_no[0] += 1
-        if device_keys and getattr(sl, "keys_reader", None) is not None:
-            sl.scan.scan_output_wait(sl.keys_reader)      # this scan's last stage rewrites the buffer the queued key extraction reads
+        if len(getattr(sl, "scans", ())) > 1:
+            sl.sv ^= 1
+            sl.scan = sl.scans[sl.sv]                     # the context whose output nothing queued in this visit reads
+        reader = getattr(sl.scan, "_reader", None)
+        if device_keys and reader is not None:
+            sl.scan.scan_output_wait(reader)              # this scan's last stage rewrites the buffer that key extraction read (or still reads)
         sl.scan.scan_device_begin(*scan_args[sl.batch])   # "tail" / "single": dense passes in order on the one scan stream
         if exchange_kind == "none":
             if schedule != "partition":
@@ -427,7 +450,7 @@ def main():
             for name, dt in (("compare_end", tr1 - tr0), ("keys_end", tr2 - tr1), ("compare_begin", tr3 - tr2), ("keys_begin", tr4 - tr3)):
                 host_detail[name] = host_detail.get(name, 0.0) + dt
             sl.keys_job[kcur] = True
-            sl.keys_reader = sl.keys[kcur]
+            sl.scan._reader = sl.keys[kcur]
             sl.kv ^= 1
             last["n_out"], last["slot"] = n_out, sl
             last["n_out_batch"][sl.batch] = n_out
@@ -557,7 +580,8 @@ def main():
                     if sl.keys_job[j]:
                         sl.keys[j].sketch_keys_device_end()
                         sl.keys_job[j] = False
-                sl.keys_reader = None
+                for c in getattr(sl, "scans", [sl.scan]):
+                    c._reader = None
             closed_keys_total = last.get("keys_total")
             device_keys = False
             n_open = min(args.steps, 200)
