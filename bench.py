@@ -378,6 +378,16 @@ def main():
             return contextlib.nullcontext()
         return torch.cuda.stream(sl.stream_b)
 
+    # BENCH_DEBUG_NOISE_KERNELS=n (analysis only): n empty launches per step on a stream of the small CUs -- what kernel
+    # boundaries beside a dense pass cost it, whatever the kernels do
+    noise_n = int(os.environ.get("BENCH_DEBUG_NOISE_KERNELS", "0"))
+    if noise_n and schedule == "partition" and pipelined:
+        masked.append(sp.stream_create_cus(local_rank, 0, small_cus))
+        noise_stream = torch.cuda.ExternalStream(masked[-1], device=dev)
+        noise_t = torch.zeros(64, dtype=torch.int32, device=dev)
+    else:
+        noise_n = 0
+
     def queue_step(sl, prev, nxt=None):
         """queue one whole step on slot sl without waiting for anything; on the GPU its dense pass starts behind
         the dense pass of slot prev.  nxt = the slot of the following step (slots exchange: its key partition is
@@ -393,6 +403,10 @@ def main():
         if device_keys and reader is not None:
             sl.scan.scan_output_wait(reader)              # this scan's last stage rewrites the buffer that key extraction read (or still reads)
         sl.scan.scan_device_begin(*scan_args[sl.batch])   # "tail" / "single": dense passes in order on the one scan stream
+        if noise_n:
+            with torch.cuda.stream(noise_stream):
+                for _ in range(noise_n):
+                    noise_t.add_(1)
         if exchange_kind == "none":
             if schedule != "partition":
                 sl.cmp.wait_dense(sl.scan)                # the comparison starts behind this step's dense pass
