@@ -316,9 +316,8 @@ __global__ void k_fill_sparse(Keys K, const uint64_t* __restrict__ sk_off, uint3
 }
 
 constexpr int kSparseCols = 16384;
-constexpr int kFlags = 12;  // [0] unsorted input, [1] fingerprint collision, [2] n_rows, [3] malformed slot, [4] slot overflow,
-                            // [5] table full, [6] a key part overflowed its capacity (partition form), [7] records dealt into parts,
-                            // [9] the survivor buffer of k_parts_foreign overflowed, [10] survivors (device-side counter)
+constexpr int kFlags = 8;   // [0] unsorted input, [1] fingerprint collision, [2] n_rows, [3] malformed slot, [4] slot overflow,
+                            // [5] table full, [6] a key part overflowed its capacity (partition form), [7] records dealt into parts
 // grid.y = owned row (sketch row_first + y * row_stride), grid.x = block of `cols` columns, grid.z = slice of the
 // row's keys (split > 1: the slices add into cells zeroed by k_zero_rows).  Counters live in dynamic LDS,
 // `copies` of each, interleaved (counter c of copy k at c * copies + k): the lists of one row's keys name the
@@ -496,7 +495,7 @@ __global__ __launch_bounds__(kScatThreads, 4) void k_parts_scatter(Keys K, const
                                                                uint32_t cap, uint32_t* __restrict__ part_cnt, uint64_t* __restrict__ recs,
                                                                uint32_t* __restrict__ where, uint32_t* __restrict__ flags, bool check_order,
                                                                const uint32_t* __restrict__ filter, uint32_t fmask, uint64_t e_first,
-                                                               uint32_t row_first, uint32_t row_stride, uint32_t row_limit, uint32_t row_stop) {
+                                                               uint32_t row_first, uint32_t row_stride, uint32_t row_limit) {
     constexpr uint32_t W = HAS_HI ? 3 : 2;
     extern __shared__ uint32_t hist[];                   // [n_parts]
     const uint32_t t = threadIdx.x, lane = t & 63;
@@ -537,8 +536,7 @@ __global__ __launch_bounds__(kScatThreads, 4) void k_parts_scatter(Keys K, const
     for (int u = 0; u < E; ++u) {
         const uint64_t e = base + (uint64_t)u * kScatThreads + t;
         hsh[u] = key_hash(lo[u], mn[u], hi[u], HAS_HI);
-        keep[u] = e < S && sk_of[u] >= row_first && sk_of[u] < row_stop;   // (sketches in front of the first owned row are never counted by an
-                                                                          // owned row; row_stop < n: the keys behind it went through k_parts_foreign)
+        keep[u] = e < S && sk_of[u] >= row_first;        // (sketches in front of the first owned row are never counted by an owned row)
         if (filter && keep[u] && !owned_row(sk_of[u], row_first, row_stride, row_limit)) {
             const uint32_t bits = filter_bits(hsh[u]);
             keep[u] = (filter[(uint32_t)hsh[u] & fmask] & bits) == bits;
@@ -572,97 +570,6 @@ __global__ __launch_bounds__(kScatThreads, 4) void k_parts_scatter(Keys K, const
         uint64_t* r = recs + ((uint64_t)part * cap + at) * W;
         if (HAS_HI) { r[0] = lo[u]; r[1] = (uint64_t)mn[u] | ((uint64_t)j << 32); r[2] = hi[u]; }
         else *reinterpret_cast<ulonglong2*>(r) = make_ulonglong2(lo[u], (uint64_t)mn[u] | ((uint64_t)j << 32));   // one 16-byte store
-    }
-}
-
-// Block-owned rows (row_stride 1: a rank's own sketches are consecutive): the keys behind the block are all foreign, and
-// nearly all of them miss the filter.  k_parts_scatter would drop them one workgroup of 4096 entries at a time, each
-// paying its loads, the sketch search, three barriers and the LDS counters for nothing (1.14 ms for the 5.4 x 10^7
-// foreign keys of rank 0 of 8 at BASELINE configs[3]).  This pass has no LDS and no barrier: a lane reads a key, probes
-// the filter and, if it passes, finds its sketch and appends the record {kmer_lo, minimizer | sketch << 32, [kmer_hi]}
-// to a survivor buffer (one global atomic per wave); k_parts_scatter_recs then deals the survivors into the parts.
-// A buffer that proves too small raises flags[9]: the host repeats the call with the filter inside the scatter.
-template <bool HAS_HI>
-__global__ __launch_bounds__(256) void k_parts_foreign(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n, const uint32_t* __restrict__ sub_sk,
-                                                      uint64_t e_begin, uint64_t S, const uint32_t* __restrict__ filter, uint32_t fmask,
-                                                      uint64_t* __restrict__ surv, uint32_t surv_cap, uint32_t* __restrict__ surv_cnt,
-                                                      uint32_t* __restrict__ flags) {
-    constexpr uint32_t W = HAS_HI ? 3 : 2;
-    const uint32_t lane = threadIdx.x & 63;
-    const uint64_t stride = (uint64_t)gridDim.x * 256;
-    for (uint64_t e0 = e_begin + (uint64_t)blockIdx.x * 256; e0 < S; e0 += stride) {      // (the wave stays together: ballot below)
-        const uint64_t e = e0 + threadIdx.x;
-        bool pass = false;
-        uint64_t lo = 0, hi = 0;
-        uint32_t mn = 0;
-        if (e < S) {
-            lo = K.lo[e]; mn = K.mn[e];
-            if (HAS_HI) hi = K.hi[e];
-            const uint64_t h = key_hash(lo, mn, hi, HAS_HI);
-            const uint32_t bits = filter_bits(h);
-            pass = (filter[(uint32_t)h & fmask] & bits) == bits;
-        }
-        const uint64_t m = __ballot(pass);
-        if (m == 0) continue;
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(surv_cnt, (uint32_t)__popcll(m));
-        base = __shfl(base, 0);
-        if (!pass) continue;
-        const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1));
-        if (at >= surv_cap) { atomicOr(&flags[9], 1u); continue; }
-        uint32_t j = sub_sk[e / kScatSub];
-        while (j + 1 < n && sk_off[j + 1] <= e) ++j;          // sketch of entry e
-        uint64_t* r = surv + (uint64_t)at * W;
-        r[0] = lo; r[1] = (uint64_t)mn | ((uint64_t)j << 32);
-        if (HAS_HI) r[2] = hi;
-    }
-}
-
-// the survivors of k_parts_foreign into the parts: k_parts_scatter's second half over ready-made records (no `where`
-// word: no owned row reads a foreign key's place)
-template <bool HAS_HI>
-__global__ __launch_bounds__(kScatThreads) void k_parts_scatter_recs(const uint64_t* __restrict__ surv, const uint32_t* __restrict__ surv_cnt,
-                                                                    uint32_t surv_cap, uint32_t n_parts, uint32_t cap,
-                                                                    uint32_t* __restrict__ part_cnt, uint64_t* __restrict__ recs) {
-    constexpr uint32_t W = HAS_HI ? 3 : 2, E = 4;
-    extern __shared__ uint32_t hist_r[];                 // [n_parts]
-    const uint32_t t = threadIdx.x;
-    const uint32_t total = min(*surv_cnt, surv_cap);
-    const uint32_t base = blockIdx.x * E * kScatThreads;
-    if (base >= total) return;                            // (the grid is sized for the buffer, not for what arrived)
-    for (uint32_t p = t; p < n_parts; p += kScatThreads) hist_r[p] = 0;
-    uint64_t lo[E], w1[E], hi[E];
-    uint32_t pr[E];
-#pragma unroll
-    for (int u = 0; u < E; ++u) {
-        const uint32_t i = base + u * kScatThreads + t;
-        lo[u] = 0; w1[u] = 0; hi[u] = 0;
-        if (i < total) { lo[u] = surv[(uint64_t)i * W]; w1[u] = surv[(uint64_t)i * W + 1]; if (HAS_HI) hi[u] = surv[(uint64_t)i * W + 2]; }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < E; ++u) {
-        const uint32_t i = base + u * kScatThreads + t;
-        pr[u] = 0xffffffffu;
-        if (i < total) {
-            const uint32_t part = (uint32_t)(((key_hash(lo[u], (uint32_t)w1[u], hi[u], HAS_HI) >> 32) * n_parts) >> 32);
-            pr[u] = part | (atomicAdd(&hist_r[part], 1u) << 15);
-        }
-    }
-    __syncthreads();
-    for (uint32_t p = t; p < n_parts; p += kScatThreads) {
-        const uint32_t c = hist_r[p];
-        if (c) hist_r[p] = atomicAdd(&part_cnt[p], c);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < E; ++u) {
-        if (pr[u] == 0xffffffffu) continue;
-        const uint32_t part = pr[u] & 0x7fffu, at = hist_r[part] + (pr[u] >> 15);
-        if (at >= cap) continue;                          // overflow: the grouping kernel sees the count and raises the flag
-        uint64_t* r = recs + ((uint64_t)part * cap + at) * W;
-        r[0] = lo[u]; r[1] = w1[u];
-        if (HAS_HI) r[2] = hi[u];
     }
 }
 
@@ -976,7 +883,7 @@ struct CompareJob {
     uint32_t passes = 1, pass = 0;  // large builds: the keys are split into classes and the dictionary + colour
                                     // matrix are built class by class, so the matrix never exceeds its budget
     // partition form (flat entry point): see k_parts_scatter
-    std::function<int(uint32_t n_parts, bool small, bool filtered, uint32_t fmask, bool foreign)> scatter_parts;
+    std::function<int(uint32_t n_parts, bool small, bool filtered, uint32_t fmask)> scatter_parts;
     std::function<int(uint32_t n_parts)> group_parts;
     std::function<int(uint32_t n_parts)> group_small;     // small problems: grouping + counting in one kernel (k_parts_group_small)
     bool parts = false, small = false;
@@ -984,7 +891,6 @@ struct CompareJob {
     // filtered form (row-partitioned calls): Bloom filter over the owned sketches' keys in front of the scatter
     std::function<int(uint32_t fmask)> build_filter;
     bool filtered = false;
-    bool foreign = false;           // block-owned rows: the keys behind the block go through k_parts_foreign
     uint32_t filter_words = 0;
     uint64_t parts_entries = 0;     // records the parts are sized for
     bool bracket_closed = false;    // the kEvCompare bracket of the begin call has been closed already
@@ -1044,7 +950,7 @@ static int job_parts(spsp_ctx* ctx, CompareJob& J) {
     static const int skip = getenv("SPSP_DEBUG_SKIP_STAGES") ? atoi(getenv("SPSP_DEBUG_SKIP_STAGES")) : 0;
     if ((rc = ctx->ev_begin(kEvScatter))) return rc;
     if (J.filtered && (rc = J.build_filter(J.filter_words - 1))) return rc;
-    if (!(skip & 1) && (rc = J.scatter_parts(J.n_parts, J.small, J.filtered, J.filter_words - 1, J.foreign))) return rc;
+    if (!(skip & 1) && (rc = J.scatter_parts(J.n_parts, J.small, J.filtered, J.filter_words - 1))) return rc;
     if ((rc = ctx->ev_end(kEvScatter))) return rc;
     if ((rc = ctx->ev_begin(kEvGroup))) return rc;
     if (!(skip & 2) && (rc = J.small ? J.group_small(J.n_parts) : J.group_parts(J.n_parts))) return rc;
@@ -1251,10 +1157,6 @@ static int compare_job_begin(spsp_ctx* ctx, CompareJob* job) {
             const double ratio = std::min(std::max(ctx->filter_ratio, 1.0), (double)S_behind / (double)P.S_own);
             J->parts_entries = std::min<uint64_t>(S_behind, (uint64_t)((double)P.S_own * ratio * 1.08) + 2900);
         }
-        // rows in ONE block with sketches behind it: those keys take the barrier-free pass (SPSP_DEBUG_FOREIGN=0: inside the scatter)
-        static const bool foreign_off = getenv("SPSP_DEBUG_FOREIGN") && atoi(getenv("SPSP_DEBUG_FOREIGN")) == 0;
-        J->foreign = J->filtered && !foreign_off && P.row_stride == 1 && P.row_limit < P.n &&
-                     P.S_entries - ctx->h_skoff[P.row_limit] >= 65536;
         J->n_parts = J->small ? parts_small(P.S_entries) : parts_for(J->parts_entries, 0);
         if ((rc = ctx->c_row.reserve((size_t)P.S_entries * 4))) return rc;
         if ((rc = job_parts(ctx, *J))) return rc;
@@ -1271,12 +1173,6 @@ int compare_job_end(spsp_ctx* ctx) {
     while (J->parts) {
         uint32_t h_flags[kFlags];
         if ((rc = job_wait_flags(ctx, h_flags))) return rc;
-        if (J->foreign && h_flags[9]) {               // more keys passed the filter than the survivor buffer holds: the filter inside the scatter
-            J->foreign = false;
-            J->bracket_closed = true;
-            if ((rc = job_parts(ctx, *J))) return rc;
-            continue;
-        }
         if (J->filtered && h_flags[7]) ctx->filter_ratio = (double)h_flags[7] / (double)J->P.S_own;
         if (!h_flags[6]) return SPSP_OK;
         // a part overflowed (many sketches share their keys): once more with parts half the size, then the
@@ -1452,10 +1348,7 @@ static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t*
     };
     // (nothing of the sketches in front of the first owned row is dealt: the grid starts at that row's chunk)
     const uint64_t e_own = h_sk_off[row_first] / (4u * kScatThreads) * (4u * kScatThreads);
-    const uint64_t e_stop_own = h_sk_off[std::min(row_limit, n)];      // first entry behind the owned block (block form)
-    const uint64_t J_S_own = S_own;
-    const double filter_ratio = ctx->filter_ratio;
-    J->scatter_parts = [=](uint32_t n_parts, bool small, bool filtered, uint32_t fmask, bool foreign) -> int {
+    J->scatter_parts = [=](uint32_t n_parts, bool small, bool filtered, uint32_t fmask) -> int {
         const uint32_t cap = small ? (uint32_t)kSmallCap : (uint32_t)kPartCap;
         int r2 = ctx->c_recs.reserve((size_t)n_parts * cap * (has_hi ? 24 : 16));
         if (r2) return r2;
@@ -1466,49 +1359,21 @@ static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t*
         if (n_parts > (uint32_t)kMaxKeyParts) { set_error("internal: %u key parts exceed the scatter's limit of %d", n_parts, kMaxKeyParts); return SPSP_ERR_ARG; }
         const uint32_t per_wg = 4u * kScatThreads;
         const uint64_t e_first = e_own;
-        const uint64_t e_end = foreign ? e_stop_own : S;              // (foreign: the scatter deals the owned block only)
-        const dim3 grid((uint32_t)std::max<uint64_t>(1, (e_end - e_first + per_wg - 1) / per_wg));
+        const dim3 grid((uint32_t)((S - e_first + per_wg - 1) / per_wg));
         const uint32_t* filter = filtered ? ctx->c_filter.as<uint32_t>() : nullptr;
-        const uint32_t row_stop = foreign ? row_limit : n;
-        uint32_t surv_cap = 0;
-        if (foreign) {
-            // survivors: the filter's false positives (1.4 %) and the foreign keys an owned sketch holds too (what the last
-            // filtered call on this context measured); SPSP_DEBUG_SURVIVOR_CAP: test hook
-            static const char* dbg_cap = getenv("SPSP_DEBUG_SURVIVOR_CAP");
-            const uint64_t n_foreign = S - e_stop_own;
-            const uint64_t est = n_foreign / 16 + (uint64_t)(std::max(0.0, filter_ratio - 1.0) * 1.25 * (double)J_S_own) + 65536;
-            surv_cap = (uint32_t)std::min<uint64_t>(n_foreign, dbg_cap ? (uint64_t)std::max(1, atoi(dbg_cap)) : est);
-            if ((r2 = ctx->c_surv.reserve((size_t)surv_cap * (has_hi ? 24 : 16)))) return r2;
-            const uint32_t fgrid = (uint32_t)std::min<uint64_t>((n_foreign + 255) / 256, (uint64_t)(ctx->n_cu ? ctx->n_cu : 256) * 16);
-            if (has_hi) hipLaunchKernelGGL(k_parts_foreign<true>, dim3(fgrid), dim3(256), 0, ctx->stream, K, sk, n, sub_sk, e_stop_own, S, filter, fmask,
-                                           ctx->c_surv.as<uint64_t>(), surv_cap, flags + 10, flags);
-            else hipLaunchKernelGGL(k_parts_foreign<false>, dim3(fgrid), dim3(256), 0, ctx->stream, K, sk, n, sub_sk, e_stop_own, S, filter, fmask,
-                                    ctx->c_surv.as<uint64_t>(), surv_cap, flags + 10, flags);
-            SPSP_HIP(hipGetLastError());
-        }
         const size_t lds = (size_t)n_parts * 4;
         if (lds > 48 * 1024 && !ctx->attr_scatter_set) {
             SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_parts_scatter<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxKeyParts * 4));
             SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_parts_scatter<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxKeyParts * 4));
-            SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_parts_scatter_recs<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxKeyParts * 4));
-            SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_parts_scatter_recs<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxKeyParts * 4));
             ctx->attr_scatter_set = true;
         }
 #define SPSP_SCATTER(HI, E) hipLaunchKernelGGL((k_parts_scatter<HI, E>), grid, dim3(kScatThreads), lds, ctx->stream, K, sk, n, sub_sk, S, \
                                                n_parts, cap, ctx->c_part_cnt.as<uint32_t>(), ctx->c_recs.as<uint64_t>(), where, flags, !ctx->keys_unordered, \
-                                               filter, fmask, e_first, row_first, row_stride, row_limit, row_stop)
+                                               filter, fmask, e_first, row_first, row_stride, row_limit)
         if (has_hi) SPSP_SCATTER(true, 4);
         else SPSP_SCATTER(false, 4);
 #undef SPSP_SCATTER
         SPSP_HIP(hipGetLastError());
-        if (foreign) {
-            const dim3 rgrid((surv_cap + per_wg - 1) / per_wg);
-            if (has_hi) hipLaunchKernelGGL(k_parts_scatter_recs<true>, rgrid, dim3(kScatThreads), lds, ctx->stream, ctx->c_surv.as<uint64_t>(), flags + 10, surv_cap,
-                                           n_parts, cap, ctx->c_part_cnt.as<uint32_t>(), ctx->c_recs.as<uint64_t>());
-            else hipLaunchKernelGGL(k_parts_scatter_recs<false>, rgrid, dim3(kScatThreads), lds, ctx->stream, ctx->c_surv.as<uint64_t>(), flags + 10, surv_cap,
-                                    n_parts, cap, ctx->c_part_cnt.as<uint32_t>(), ctx->c_recs.as<uint64_t>());
-            SPSP_HIP(hipGetLastError());
-        }
         return SPSP_OK;
     };
     J->group_parts = [=](uint32_t n_parts) -> int {
