@@ -534,6 +534,15 @@ def test_eight_simulated_ranks_own_blocks_of_rows(ctx):
     own = np.zeros((n, n), bool)
     own[rows] = np.triu(np.ones((n, n), bool), 1)[rows]
     assert (p[~own] == -1).all() and (p[own] == want[own]).all()
+    # misuse: a zero stride is refused; a first row behind the last sketch owns nothing and writes nothing
+    part.fill_(-1)
+    torch.cuda.synchronize()
+    with pytest.raises(sp.SpspError):
+        ctx.compare_device(31, d_min.data_ptr(), d_lo.data_ptr(), None, sk_off, n, 0, 0, part.data_ptr())
+    ctx.compare_device(31, d_min.data_ptr(), d_lo.data_ptr(), None, sk_off, n, n + 5, 1, part.data_ptr())
+    ctx.compare_device(31, d_min.data_ptr(), d_lo.data_ptr(), None, sk_off, n, 7, 3, part.data_ptr(), n_query=7)
+    torch.cuda.synchronize()
+    assert (part.cpu().numpy() == -1).all()
 
 
 def test_filtered_rows_equal_unfiltered_rows_and_grow_their_parts():
