@@ -505,12 +505,15 @@ def main():
                 last["n_out_batch"][sl.batch] = n_out
             return
         import collections
+        # a step is collected when `collect_depth` younger ones have been queued (default: when its slot comes round again).
+        # BENCH_COLLECT_DEPTH < slots: earlier -- fewer chains left for the drain at the end of a short run, less slack for the host
+        collect_depth = min(len(slots), int(os.environ.get("BENCH_COLLECT_DEPTH", str(len(slots)))))
         pending = collections.deque()                     # steps queued and not yet collected, oldest first
         prev = None
         for i in range(n):
             sl = slots[i % len(slots)]
             t_c = time.perf_counter()
-            if len(pending) == len(slots):
+            if len(pending) == collect_depth:
                 collect_step(pending.popleft())           # the oldest step ran on `sl`: the host waits for it only now,
             t_a = time.perf_counter()                     # with the steps queued since then already on the GPU's queues
             queue_step(sl, prev, slots[(i + 1) % len(slots)] if i + 1 < n else None)
