@@ -323,11 +323,14 @@ int spsp_sketch_parse_host(const uint8_t* payload, uint64_t len, uint32_t* k, ui
  * genome, sorted, back to back in device arrays OWNED BY THE CONTEXT (the ones spsp_sketch_decode_device fills: valid
  * until the next decode / keys / spsp_compare call on it; *d_kmer_hi = NULL when k <= 32), sk_off with n_genomes + 1
  * offsets: ready for spsp_compare_device.  A genome with more than 8192 selected k-mer occurrences (4096 with k > 32)
- * does not fit the per-genome sort: SPSP_ERR_OVERFLOW (sketch such genomes through files).  _begin queues the work on
- * the context's stream and returns; _end waits for it (an event behind its last kernel).  One job may be pending per
- * context.
+ * does not fit the per-genome sort: the call then takes the path those keys would take through a file, without the file
+ * (_end gathers the selected super-k-mers to the host, the sketch builder and the comparator's reader run there and the
+ * keys are uploaded into the same arrays: same result, host speed).  _begin queues the work on the context's stream and
+ * returns; _end waits for it (an event behind its last kernel); the device inputs must stay as they are until _end has
+ * returned.  One job may be pending per context.
  * flags: SPSP_KEYS_UNORDERED -- every genome's keys DISTINCT but in no particular order: an LDS table per genome instead of
- * the per-genome sort (a tenth of its time; at most 6144 occurrences per genome, 4096 with k > 32).  Such keys are for
+ * the per-genome sort (a tenth of its time; at most 6144 occurrences per genome, 4096 with k > 32, beyond that the host
+ * path above, whose keys come out sorted).  Such keys are for
  * comparisons on a context that has been told so (spsp_compare_keys_unordered): the comparison itself only needs a
  * sketch to hold a key once; the order is what lets it CHECK that on input it did not make. */
 #define SPSP_KEYS_UNORDERED 1u

@@ -105,6 +105,13 @@ struct spsp_ctx {
     bool keys_pending = false, keys_has_hi = false, attr_keys_set = false, keys_flags_clear = false, attr_dedupe_set = false;
     bool keys_unordered = false;       // spsp_compare_keys_unordered: the comparisons of this context do not insist on sorted sketches
     uint32_t keys_genomes = 0, keys_cap = 0, keys_skm_cap = 0;
+    // inputs of the pending key extraction, kept for the host path a genome beyond the per-genome table takes (spsp_keys.hip)
+    spsp_params keys_p{};
+    const uint8_t* keys_bases = nullptr;
+    const uint64_t* keys_rec_off = nullptr;
+    const spsp_superkmer* keys_sk = nullptr;
+    uint64_t keys_n_sk = 0;
+    bool keys_packed = false;
     hipEvent_t keys_done = nullptr;
     uint32_t* h_keys = nullptr;        // pinned: genome record ranges in, key offsets + overflow report out
     size_t h_keys_cap = 0;

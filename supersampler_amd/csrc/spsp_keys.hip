@@ -26,6 +26,7 @@
 #include <cstring>
 #include <string>
 
+#include <vector>
 #include "spsp_internal.h"
 #include "spsp_device.h"
 
@@ -431,6 +432,7 @@ int sketch_keys_begin_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d
     if (n_sk > 0x7ffffff0ull / 64) { set_error("too many super-k-mers for one call"); return SPSP_ERR_OVERFLOW; }
     const uint32_t n = (uint32_t)n_sk;
     const bool has_hi = p->k > 32;
+    ctx->keys_p = *p; ctx->keys_bases = d_bases; ctx->keys_rec_off = d_rec_off; ctx->keys_sk = d_sk; ctx->keys_n_sk = n_sk; ctx->keys_packed = packed;
     const uint64_t bound = (uint64_t)n * (p->k - p->m + 1);        // raw keys: a super-k-mer holds at most k - m + 1 k-mers
     // unordered form: one workgroup per genome, or -- SPSP_KEYS_SPLIT=2 -- two, each tabling one hash class of its keys in
     // half the LDS (78 KiB: fits a CU beside a comparison workgroup; both roll all of the genome's k-mers)
@@ -545,6 +547,63 @@ int sketch_keys_begin_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d
     return SPSP_OK;
 }
 
+// A genome beyond the per-genome table (dense sketches: s near 1, k == m, long genomes): the call takes the path its keys
+// would take through a file, without the file -- the selected super-k-mers are gathered to the host, the sketch builder
+// (handle_superkmer + emission, spsp_host.cpp) makes every genome's payload and the comparator's reader parses it back:
+// sorted distinct keys, uploaded into the same arrays.  Slow (host), correct for any size; SPSP_DEBUG_KEYS_NO_HOST=1 keeps
+// the error instead (test hook).
+static int keys_host_path(spsp_ctx* ctx, uint64_t* sk_off) {
+    const spsp_params& p = ctx->keys_p;
+    const uint32_t n_genomes = ctx->keys_genomes;
+    const uint32_t* first_rec = ctx->h_keys;
+    const uint32_t n_rec = first_rec[n_genomes];
+    const uint64_t n_sk = ctx->keys_n_sk;
+    std::vector<uint64_t> rec_off((size_t)n_rec + 1);
+    std::vector<spsp_superkmer> sk((size_t)n_sk);
+    SPSP_HIP(hipMemcpyAsync(rec_off.data(), ctx->keys_rec_off, rec_off.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (n_sk) SPSP_HIP(hipMemcpyAsync(sk.data(), ctx->keys_sk, (size_t)n_sk * sizeof(spsp_superkmer), hipMemcpyDeviceToHost, ctx->stream));
+    uint8_t* compact = nullptr; uint32_t* coff = nullptr;
+    int rc = gather_superkmers_impl(ctx, ctx->keys_bases, ctx->keys_rec_off, ctx->keys_sk, n_sk, &compact, &coff, ctx->keys_packed);   // synchronises the stream
+    if (rc) return rc;
+    std::vector<uint32_t> all_mn;
+    std::vector<uint64_t> all_lo, all_hi;
+    const bool has_hi = p.k > 32;
+    size_t at = 0;
+    sk_off[0] = 0;
+    for (uint32_t g = 0; g < n_genomes && !rc; ++g) {
+        while (at < sk.size() && sk[at].rec < first_rec[g]) ++at;
+        const size_t q0 = at;
+        while (at < sk.size() && sk[at].rec < first_rec[g + 1]) ++at;
+        std::vector<spsp_superkmer> mine(sk.begin() + (ptrdiff_t)q0, sk.begin() + (ptrdiff_t)at);
+        for (auto& e : mine) e.rec -= first_rec[g];
+        uint8_t* payload = nullptr; uint64_t plen = 0;
+        spsp_sketch_stats st;
+        // (-a > 1: the builder counts the k-mers itself, per genome -- the device's abundance pass numbers the occurrences of ONE file)
+        rc = sketch_build_core(&p, 1.0, rec_off.data() + first_rec[g], first_rec[g + 1] - first_rec[g], mine.data(), mine.size(), nullptr, compact,
+                               coff ? coff + q0 : nullptr, &payload, &plen, &st, nullptr);
+        uint32_t k2 = 0, m2 = 0; uint32_t* mn = nullptr; uint64_t *lo = nullptr, *hi = nullptr; uint64_t cnt = 0;
+        if (!rc) rc = spsp_sketch_parse_host(payload, plen, &k2, &m2, &mn, &lo, &hi, &cnt);
+        free(payload);
+        if (!rc) {
+            all_mn.insert(all_mn.end(), mn, mn + cnt); all_lo.insert(all_lo.end(), lo, lo + cnt);
+            if (has_hi) all_hi.insert(all_hi.end(), hi, hi + cnt);
+        }
+        free(mn); free(lo); free(hi);
+        sk_off[g + 1] = all_mn.size();
+    }
+    free(compact); free(coff);
+    if (rc) return rc;
+    const size_t tot = all_mn.size();
+    if ((rc = ctx->c_min.reserve(tot * 4 + 64)) || (rc = ctx->c_lo.reserve(tot * 8 + 64)) || (has_hi && (rc = ctx->c_hi.reserve(tot * 8 + 64)))) return rc;
+    if (tot) {
+        SPSP_HIP(hipMemcpyAsync(ctx->c_min.p, all_mn.data(), tot * 4, hipMemcpyHostToDevice, ctx->stream));
+        SPSP_HIP(hipMemcpyAsync(ctx->c_lo.p, all_lo.data(), tot * 8, hipMemcpyHostToDevice, ctx->stream));
+        if (has_hi) SPSP_HIP(hipMemcpyAsync(ctx->c_hi.p, all_hi.data(), tot * 8, hipMemcpyHostToDevice, ctx->stream));
+        SPSP_HIP(hipStreamSynchronize(ctx->stream));          // (the host vectors go out of scope)
+    }
+    return SPSP_OK;
+}
+
 int sketch_keys_end_impl(spsp_ctx* ctx, void** d_mn, void** d_lo, void** d_hi, uint64_t* sk_off) {
     if (!ctx->keys_pending) { set_error("no key extraction is pending on this context"); return SPSP_ERR_ARG; }
     ctx->keys_pending = false;
@@ -552,9 +611,16 @@ int sketch_keys_end_impl(spsp_ctx* ctx, void** d_mn, void** d_lo, void** d_hi, u
     const uint32_t n_genomes = ctx->keys_genomes;
     const uint32_t* h_out = ctx->h_keys + (n_genomes + 1);
     if (h_out[n_genomes + 1]) {
-        set_error("a genome has %u selected k-mer places, more than the device's per-genome table holds (%u%s): sketch it through a file",
-                  h_out[n_genomes + 2], ctx->keys_cap, ctx->keys_skm_cap ? (", in at most " + std::to_string(ctx->keys_skm_cap) + " super-k-mers").c_str() : "");
-        return SPSP_ERR_OVERFLOW;
+        static const bool no_host = getenv("SPSP_DEBUG_KEYS_NO_HOST") != nullptr;
+        if (no_host) {
+            set_error("a genome has %u selected k-mer places, more than the device's per-genome table holds (%u%s): sketch it through a file",
+                      h_out[n_genomes + 2], ctx->keys_cap, ctx->keys_skm_cap ? (", in at most " + std::to_string(ctx->keys_skm_cap) + " super-k-mers").c_str() : "");
+            return SPSP_ERR_OVERFLOW;
+        }
+        const int rc = keys_host_path(ctx, sk_off);
+        if (rc) return rc;
+        *d_mn = ctx->c_min.p; *d_lo = ctx->c_lo.p; *d_hi = ctx->keys_has_hi ? ctx->c_hi.p : nullptr;
+        return SPSP_OK;
     }
     for (uint32_t g = 0; g <= n_genomes; ++g) sk_off[g] = h_out[g];
     *d_mn = ctx->c_min.p; *d_lo = ctx->c_lo.p; *d_hi = ctx->keys_has_hi ? ctx->c_hi.p : nullptr;

@@ -1073,11 +1073,8 @@ def test_sketch_keys_on_device_equal_the_file_path(ctx, k, m, s, ab):
     assert (np.triu(d_inter.cpu().numpy(), 1) == np.triu(w_inter, 1)).all()
     # SPSP_KEYS_UNORDERED: the same key SETS from an LDS table per genome instead of a sort; a comparison that has been told
     # so takes them, one that has not refuses them (its order check is its duplicate check)
-    if k == m:       # (one k-mer per super-k-mer: thousands of super-k-mers per genome, more than the unordered form stages -- it says so)
-        with pytest.raises(sp.SpspError) as e:
-            ctx.sketch_keys_device(p, src, len(bases), d_o.data_ptr(), d_sk, n_sk, first_rec, unordered=True)
-        assert e.value.code == sp.ERR_OVERFLOW and "super-k-mers" in str(e.value)
-        return
+    # (k == m: one k-mer per super-k-mer, thousands of super-k-mers per genome -- more than the unordered form stages: the call
+    # takes the host path inside, same keys)
     d_mn, d_lo, d_hi, sk_off2 = ctx.sketch_keys_device(p, src, len(bases), d_o.data_ptr(), d_sk, n_sk, first_rec, unordered=True)
     assert (sk_off2 == sk_off).all()
     total = int(sk_off2[-1])
@@ -1090,8 +1087,9 @@ def test_sketch_keys_on_device_equal_the_file_path(ctx, k, m, s, ab):
         assert sorted(zip(mn[x:y].tolist(), hi[x:y].tolist(), lo[x:y].tolist())) == list(zip(w_mn.tolist(), w_hi.tolist(), w_lo.tolist())), g
     d_inter.zero_()
     torch.cuda.synchronize()
-    with pytest.raises(sp.SpspError):
-        ctx.compare_device(k, d_mn, d_lo, d_hi, sk_off2, len(genomes), 0, 1, d_inter.data_ptr())
+    if k != m:       # (the host path's keys come out sorted: nothing to refuse)
+        with pytest.raises(sp.SpspError):
+            ctx.compare_device(k, d_mn, d_lo, d_hi, sk_off2, len(genomes), 0, 1, d_inter.data_ptr())
     ctx.compare_keys_unordered(True)
     d_inter.zero_()
     torch.cuda.synchronize()
@@ -1107,9 +1105,12 @@ def test_sketch_keys_on_device_equal_the_file_path(ctx, k, m, s, ab):
         torch.cuda.synchronize()
         p = sp.make_params(k, m, s)
         d_sk, n_sk = ctx.scan_device(p, d_b2.data_ptr(), len(bb), d_o2.data_ptr(), 1)
-        with pytest.raises(sp.SpspError) as e:
-            ctx.sketch_keys_device(p, d_b2.data_ptr(), len(bb), d_o2.data_ptr(), d_sk, n_sk, [0, 1])
-        assert e.value.code == sp.ERR_OVERFLOW
+        # a genome beyond the per-genome sort (20 000 selected k-mers): the host path inside the call, the keys the file would give
+        for un in (False, True):
+            d_mn, d_lo, _, koff = ctx.sketch_keys_device(p, d_b2.data_ptr(), len(bb), d_o2.data_ptr(), d_sk, n_sk, [0, 1], unordered=un)
+            _, _, w_mn, w_lo, _ = orc.sketch_keys(orc.sketch_fasta(synth.to_fasta(big, "big"), k, m, s)[0])
+            assert int(koff[1]) == len(w_mn) > 8192
+            assert (ctx.to_host(d_mn, len(w_mn), np.uint32) == w_mn).all() and (ctx.to_host(d_lo, len(w_lo), np.uint64) == w_lo).all()
 
 
 def test_sketch_keys_split_form_and_api_misuse(ctx):
