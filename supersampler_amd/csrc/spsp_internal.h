@@ -102,7 +102,7 @@ struct spsp_ctx {
     spsp::ScanJob scan_job;
     spsp::CompareJob* compare_job = nullptr;
     // spsp_sketch_keys_device_begin / _end (spsp_keys.hip)
-    bool keys_pending = false, keys_has_hi = false, attr_keys_set = false, keys_flags_clear = false, attr_serial_set = false, attr_dedupe_set = false;
+    bool keys_pending = false, keys_has_hi = false, attr_keys_set = false, keys_flags_clear = false, attr_dedupe_set = false;
     bool keys_unordered = false;       // spsp_compare_keys_unordered: the comparisons of this context do not insist on sorted sketches
     uint32_t keys_genomes = 0, keys_cap = 0, keys_skm_cap = 0;
     // inputs of the pending key extraction, kept for the host path a genome beyond the per-genome table takes (spsp_keys.hip)

@@ -183,7 +183,7 @@ __device__ __forceinline__ uint64_t keys_mix(uint64_t x) {
     x ^= x >> 27; x *= 0x94d049bb133111ebULL;
     return x ^ (x >> 31);
 }
-template <bool HAS_HI, uint32_t S, bool SERIAL = false>
+template <bool HAS_HI, uint32_t S>
 __global__ __launch_bounds__(kKeySortThreads) void k_keys_fused(const uint8_t* __restrict__ bases, bool packed, uint64_t n_bases_readable,
                                                                const uint64_t* __restrict__ rec_off,
                                                                const spsp_superkmer* __restrict__ sk, uint32_t n_sk, const uint32_t* __restrict__ first_rec,
@@ -205,9 +205,7 @@ __global__ __launch_bounds__(kKeySortThreads) void k_keys_fused(const uint8_t* _
     uint32_t* skw = slot + SLOTS;
     __shared__ uint32_t wave_sum[kKeySortThreads / 64];
     __shared__ uint32_t s_count;
-    // SERIAL: ONE workgroup per genome takes the S hash classes one after the other in a table of 1 / S the size (76 KiB at
-    // S = 2, k <= 32: two workgroups share a CU, so that the 100 genomes of bench.py's batch are one round on 64 CUs)
-    const uint32_t g = SERIAL ? blockIdx.x : blockIdx.x / S, cls0 = SERIAL ? 0u : blockIdx.x % S, seg = blockIdx.x, t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const uint32_t g = blockIdx.x / S, cls = blockIdx.x % S, seg = blockIdx.x, t = threadIdx.x, lane = t & 63, wid = t >> 6;
     // this genome's super-k-mers: [q0, q1) (the stream is in record order)
     // (wave 0 searches 64 ways at a time -- three dependent loads per bound instead of fifteen -- and tells the others)
     __shared__ uint32_t s_q[2];
@@ -232,7 +230,7 @@ __global__ __launch_bounds__(kKeySortThreads) void k_keys_fused(const uint8_t* _
     __syncthreads();
     const uint32_t q0 = s_q[0], q1 = s_q[1];
     const uint32_t n = (q1 - q0) * w;                              // the genome's k-mer places (some empty)
-    const uint32_t r0 = (SERIAL ? 0u : cls0 * stage_stride) + q0 * w;   // this workgroup's room in the staging arrays
+    const uint32_t r0 = cls * stage_stride + q0 * w;               // this workgroup's room in the staging arrays
     if (t == 0) { raw_off[seg] = r0; s_count = 0; }
     if (n == 0) { if (t == 0) distinct[seg] = 0; return; }
     if (n > FULL || q1 - q0 > SKM_MAX) { if (t == 0) { distinct[seg] = 0; atomicOr(&flags[0], 1u); atomicMax(&flags[1], n); } return; }
@@ -264,15 +262,6 @@ __global__ __launch_bounds__(kKeySortThreads) void k_keys_fused(const uint8_t* _
         }
     }
     __syncthreads();
-    uint32_t out_at = r0, total_out = 0;
-    for (uint32_t pass = 0; pass < (SERIAL ? S : 1u); ++pass) {
-    const uint32_t cls = SERIAL ? pass : cls0;
-    if (SERIAL && pass) {                                          // the next class: an empty table
-        __syncthreads();
-        for (uint32_t x = t; x < SLOTS; x += kKeySortThreads) slot[x] = 0;
-        if (t == 0) s_count = 0;
-        __syncthreads();
-    }
     auto home = [&](uint32_t mo, uint64_t lo, uint64_t hi) {
         uint64_t h = keys_mix(lo ^ 0x9E3779B97F4A7C15ULL);
         h = keys_mix(h + (uint64_t)mo * 0xD6E8FEB86659FD93ULL);
@@ -386,7 +375,7 @@ __global__ __launch_bounds__(kKeySortThreads) void k_keys_fused(const uint8_t* _
     __syncthreads();
     uint32_t pre = 0, base = 0;
     for (uint32_t w2 = 0; w2 < kKeySortThreads / 64; ++w2) { if (w2 < wid) pre += wave_sum[w2]; base += wave_sum[w2]; }
-    uint32_t at = out_at + pre + x - cnt;
+    uint32_t at = r0 + pre + x - cnt;
 #pragma unroll
     for (uint32_t u = 0; u < PER; ++u) {
         const uint32_t r = id[u];
@@ -395,9 +384,7 @@ __global__ __launch_bounds__(kKeySortThreads) void k_keys_fused(const uint8_t* _
         if (HAS_HI) r_hi[at] = k_hi[r];
         ++at;
     }
-    out_at += base; total_out += base;
-    }
-    if (t == 0) distinct[seg] = total_out;
+    if (t == 0) distinct[seg] = base;
 }
 
 __global__ __launch_bounds__(256) void k_keys_compact(const uint32_t* __restrict__ r_mn, const uint64_t* __restrict__ r_lo,
@@ -451,9 +438,6 @@ int sketch_keys_begin_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d
     // half the LDS (78 KiB: fits a CU beside a comparison workgroup; both roll all of the genome's k-mers)
     static const uint32_t split_env = getenv("SPSP_KEYS_SPLIT") && atoi(getenv("SPSP_KEYS_SPLIT")) == 2 ? 2u : 1u;
     const uint32_t split = unordered ? split_env : 1u;
-    // SPSP_KEYS_SERIAL=1 (k <= 32): one workgroup per genome, its two hash classes one after the other in half the table
-    static const bool serial_env = getenv("SPSP_KEYS_SERIAL") && atoi(getenv("SPSP_KEYS_SERIAL")) != 0;
-    const bool serial = unordered && serial_env && split == 1 && p->k <= 32;
     if (bound * split > 0xfffffff0ull) { set_error("too many selected k-mers for one call"); return SPSP_ERR_OVERFLOW; }
     const uint64_t stage = bound * split;                          // (every hash class of a genome has room for all of its keys)
     const uint32_t segs = n_genomes * split;
@@ -505,16 +489,7 @@ int sketch_keys_begin_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d
 #define SPSP_KEYS_FUSED(HI, SP) hipLaunchKernelGGL((k_keys_fused<HI, SP>), dim3(segs), dim3(kKeySortThreads), lds_d, ctx->stream, d_bases, packed, n_bases_readable, d_rec_off, \
                                                     d_sk, n, d_first_rec, p->k, w, ab, (uint32_t)bound, ctx->a_mn.as<uint32_t>(), ctx->a_lo.as<uint64_t>(),                   \
                                                     HI ? ctx->a_hi.as<uint64_t>() : (uint64_t*)nullptr, d_raw_off, d_distinct, d_flags)
-        if (serial) {
-            const size_t lds_s = (size_t)(kDedupCapLo / 2) * 20 + kDedupSkmWords * 4;
-            if (!ctx->attr_serial_set) {
-                SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keys_fused<false, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s));
-                ctx->attr_serial_set = true;
-            }
-            hipLaunchKernelGGL((k_keys_fused<false, 2, true>), dim3(segs), dim3(kKeySortThreads), lds_s, ctx->stream, d_bases, packed, n_bases_readable, d_rec_off,
-                               d_sk, n, d_first_rec, p->k, w, ab, (uint32_t)bound, ctx->a_mn.as<uint32_t>(), ctx->a_lo.as<uint64_t>(), (uint64_t*)nullptr, d_raw_off,
-                               d_distinct, d_flags);
-        } else if (has_hi) { if (split == 2) SPSP_KEYS_FUSED(true, 2); else SPSP_KEYS_FUSED(true, 1); }
+        if (has_hi) { if (split == 2) SPSP_KEYS_FUSED(true, 2); else SPSP_KEYS_FUSED(true, 1); }
         else { if (split == 2) SPSP_KEYS_FUSED(false, 2); else SPSP_KEYS_FUSED(false, 1); }
 #undef SPSP_KEYS_FUSED
         SPSP_HIP(hipGetLastError());
