@@ -586,6 +586,28 @@ def main():
     # Second, shorter timed region (single GPU): the OPEN step of rounds 1-2 -- the same scans, the comparison working on the
     # keys of the setup's sketches (the same every step), no key extraction in the loop.  Reported beside the headline as
     # `open_loop`: what the two kernels chains do when the hand-off between them is left out.
+    # The same closed step over a longer run (single GPU, when the timed region was short -- the driver's --steps 20): what
+    # filling and draining the pipeline once costs a 20-step region.  Reported beside the headline.
+    long_run = None
+    if device_keys and args.steps < 200:
+        try:
+            for c in all_ctx:                             # the same event brackets as a --steps 200 run has (every 8th dense pass)
+                c.timing_enable(True, kinds)
+                c.timing_sample(8 if kinds == sp.TIME_DENSE else 1)
+            run_steps(args.warmup)
+            fence()
+            t0 = time.perf_counter()
+            run_steps(200)
+            fence()
+            e_long = time.perf_counter() - t0
+            for c in all_ctx:
+                c.timing_read()
+                c.timing_enable(False)
+                c.timing_sample(1)
+            long_run = {"steps": 200, "ms_per_step": e_long * 1e3 / 200, "value": float(kmers_per_step) * 200 / e_long,
+                        "what": "the closed step of the headline over 200 steps, measured right behind the timed region"}
+        except Exception as e:  # noqa: BLE001
+            long_run = {"error": repr(e)}
     open_loop = None
     if device_keys:
         try:
@@ -727,6 +749,7 @@ def main():
                          "accumulate_kernel": acc_ms / tm["accumulate_launches"] if tm["accumulate_launches"] else None},
             "superkmers_per_step": int(n_out), "inter_nonzero": inter_nonzero,
             **({"open_loop": open_loop} if open_loop is not None else {}),
+            **({"long_run": long_run} if long_run is not None else {}),
             "host_ms_per_step": host_main,
             "roofline": {"kernel": "k_dense_pair (non-temporal 16-byte loads, 2-bit pack, LDS pair-table test of every m-mer position; XXH64 on survivors)", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
