@@ -21,7 +21,8 @@ travel are the setup's (the per-step key extraction would need the counts of
 every rank on the host first: one more collective and a host wait per step).
 
 Besides the timed step, rank 0 of a single-GPU run measures (untimed, after the
-step loop): the open step of rounds 1-2 (`open_loop`), the comparator alone at
+step loop): the same closed step over 200 steps when the timed region was
+shorter (`long_run`), the open step of rounds 1-2 (`open_loop`), the comparator alone at
 BASELINE configs[2] and configs[3] scale (`compare`, `compare_c4`), the scan at
 the configs[4] shape (`scan_c5`) and the file-to-file drivers end to end
 (`end_to_end`), each beside the oracle.
