@@ -322,15 +322,18 @@ int spsp_sketch_parse_host(const uint8_t* payload, uint64_t len, uint32_t* k, ui
  * trip (:458-620, Comparator.cpp:186-260) and canonize composed -- the DISTINCT (minimizer, canonical k-mer) keys of every
  * genome, sorted, back to back in device arrays OWNED BY THE CONTEXT (the ones spsp_sketch_decode_device fills: valid
  * until the next decode / keys / spsp_compare call on it; *d_kmer_hi = NULL when k <= 32), sk_off with n_genomes + 1
- * offsets: ready for spsp_compare_device.  A genome with more than 8192 selected k-mer occurrences (4096 with k > 32)
- * does not fit the per-genome sort: the call then takes the path those keys would take through a file, without the file
- * (_end gathers the selected super-k-mers to the host, the sketch builder and the comparator's reader run there and the
- * keys are uploaded into the same arrays: same result, host speed).  _begin queues the work on the context's stream and
- * returns; _end waits for it (an event behind its last kernel); the device inputs must stay as they are until _end has
- * returned.  One job may be pending per context.
+ * offsets: ready for spsp_compare_device.  A genome of ANY size stays on the device, like the reference's unbounded
+ * minimizer_map (SubSampler.h:62): up to 8192 selected k-mer occurrences (4096 with k > 32) a workgroup handles a genome in
+ * its LDS; a larger one is flagged by that workgroup and taken by the global-memory stages queued behind it in the same
+ * call (one open-addressing table in HBM with the same per-(k-mer, orientation) counts and uint8 rule; then, for the
+ * sorted form, a merge sort of the genome's distinct keys where they finally lie, queued from _end).  There is no host
+ * path.  _begin queues the work on the context's stream and returns; _end waits for it (an event behind its last
+ * kernel).  The caller's device inputs (bases, record offsets, super-k-mers) are read by the work _begin queues and by
+ * nothing else: they may be rewritten once that work has run -- spsp_scan_output_wait orders a scan's next write
+ * behind it -- without waiting for _end.  One job may be pending per context.
  * flags: SPSP_KEYS_UNORDERED -- every genome's keys DISTINCT but in no particular order: an LDS table per genome instead of
- * the per-genome sort (a tenth of its time; at most 6144 occurrences per genome, 4096 with k > 32, beyond that the host
- * path above, whose keys come out sorted).  Such keys are for
+ * the per-genome sort (a tenth of its time; up to 6144 k-mer places and 1024 super-k-mers per genome, 4096 / 512 with
+ * k > 32, beyond that the same global-memory table, without the sort).  Such keys are for
  * comparisons on a context that has been told so (spsp_compare_keys_unordered): the comparison itself only needs a
  * sketch to hold a key once; the order is what lets it CHECK that on input it did not make. */
 #define SPSP_KEYS_UNORDERED 1u
@@ -343,6 +346,9 @@ int spsp_sketch_keys_device_begin(spsp_ctx* ctx, const spsp_params* p, const voi
  * unsorted (the caller vouches for "distinct": duplicates inside a sketch would be counted twice) */
 int spsp_compare_keys_unordered(spsp_ctx* ctx, int on);
 int spsp_sketch_keys_device_end(spsp_ctx* ctx, void** d_minimizer, void** d_kmer_lo, void** d_kmer_hi, uint64_t* sk_off);
+/* how many genomes of the extraction last collected on this context were beyond the per-genome LDS forms and went
+ * through the table in HBM (a diagnostic for tests and benchmarks) */
+uint32_t spsp_sketch_keys_big_genomes(spsp_ctx* ctx);
 
 /* A scan's output buffer belongs to its context and is rewritten by that context's next scan.  A caller that pipelines --
  * queues scan t + 1 on `scanner` while `reader`'s key extraction of scan t's output (spsp_sketch_keys_device_begin) may
@@ -353,8 +359,9 @@ int spsp_scan_output_wait(spsp_ctx* scanner, spsp_ctx* reader);
 /* The same decode for MANY sketches at once on the GPU ("next" row N2): payloads[i] = gunzipped sketch i.  The
  * sorted distinct keys of all sketches end up back to back in device arrays OWNED BY THE CONTEXT (valid until the
  * next decode / spsp_compare call on it; *d_kmer_hi = NULL when k <= 32), ready for spsp_compare_device; sk_off gets
- * n + 1 offsets.  Sketches too large for the GPU sort, or not laid out as the sketcher writes them, go through
- * spsp_sketch_parse_host internally: same keys. */
+ * n + 1 offsets.  A sketch of any size is decoded on the device (beyond 8192 raw keys -- 4096 with k > 32 -- through a
+ * table in HBM and a merge sort instead of the per-sketch LDS sort); only a sketch that is not laid out as the sketcher
+ * writes it goes through spsp_sketch_parse_host internally: same keys. */
 int spsp_sketch_decode_device(spsp_ctx* ctx, const uint8_t* const* payloads, const uint64_t* lens, uint32_t n,
                               uint32_t* k, uint32_t* m, void** d_minimizer, void** d_kmer_lo, void** d_kmer_hi,
                               uint64_t* sk_off);

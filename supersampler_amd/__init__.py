@@ -82,7 +82,7 @@ ABI_SYMBOLS = [
     "spsp_create", "spsp_destroy", "spsp_last_error", "spsp_version", "spsp_free", "spsp_copy_to_host",
     "spsp_stream_create_cus", "spsp_stream_destroy", "spsp_set_cu_count", "spsp_pack_bases_device",
     "spsp_timing_enable", "spsp_timing_sample", "spsp_timing_read", "spsp_threshold_host", "spsp_scan", "spsp_scan_device", "spsp_scan_device_begin", "spsp_scan_device_end", "spsp_scan_tail_stream", "spsp_wait_dense", "spsp_wait_stream", "spsp_scan_hits_device", "spsp_count_superkmers_device", "spsp_compare",
-    "spsp_compare_device", "spsp_slot_bytes", "spsp_partition_keys_device", "spsp_compare_slots_device", "spsp_compare_device_begin", "spsp_compare_slots_device_begin", "spsp_compare_end", "spsp_fasta_clean_host", "spsp_fasta_clean_device", "spsp_fasta_clean_packed_device", "spsp_sketch_text", "spsp_sketch_build_host", "spsp_sketch_parse_host", "spsp_sketch_decode_device", "spsp_sketch_keys_device", "spsp_sketch_keys_device_begin", "spsp_sketch_keys_device_end", "spsp_scan_output_wait", "spsp_compare_keys_unordered", "spsp_sketch_chain_host",
+    "spsp_compare_device", "spsp_slot_bytes", "spsp_partition_keys_device", "spsp_compare_slots_device", "spsp_compare_device_begin", "spsp_compare_slots_device_begin", "spsp_compare_end", "spsp_fasta_clean_host", "spsp_fasta_clean_device", "spsp_fasta_clean_packed_device", "spsp_sketch_text", "spsp_sketch_build_host", "spsp_sketch_parse_host", "spsp_sketch_decode_device", "spsp_sketch_keys_device", "spsp_sketch_keys_device_begin", "spsp_sketch_keys_device_end", "spsp_sketch_keys_big_genomes", "spsp_scan_output_wait", "spsp_compare_keys_unordered", "spsp_sketch_chain_host",
     "spsp_csv_host", "spsp_sort_csv_host", "spsp_read_file_host", "spsp_write_gz_host", "spsp_sketch_file", "spsp_compare_files", "spsp_compare_files_chatty", "spsp_stage_times_read", "spsp_measure_hbm_device", "spsp_sketch_files", "spsp_sketch_files_release",
 ]
 
@@ -170,6 +170,7 @@ def lib():
     L.spsp_compare_keys_unordered.restype = i32; L.spsp_compare_keys_unordered.argtypes = [vp, i32]
     L.spsp_sketch_keys_device_end.restype = i32
     L.spsp_sketch_keys_device_end.argtypes = [vp, P(vp), P(vp), P(vp), vp]
+    L.spsp_sketch_keys_big_genomes.restype = u32; L.spsp_sketch_keys_big_genomes.argtypes = [vp]
     L.spsp_scan_output_wait.restype = i32; L.spsp_scan_output_wait.argtypes = [vp, vp]
     L.spsp_sketch_decode_device.restype = i32
     L.spsp_sketch_decode_device.argtypes = [vp, P(cp), P(u64), u32, P(u32), P(u32), P(vp), P(vp), P(vp), P(u64)]
@@ -535,6 +536,10 @@ class Context:
         sk_off = np.zeros(self._keys_n + 1, dtype=np.uint64)
         _check(lib().spsp_sketch_keys_device_end(self._h, C.byref(d_mn), C.byref(d_lo), C.byref(d_hi), sk_off.ctypes.data))
         return d_mn.value, d_lo.value, d_hi.value, sk_off
+
+    def sketch_keys_big_genomes(self):
+        """genomes of the last collected key extraction that were beyond the per-genome LDS forms (table in HBM instead)"""
+        return int(lib().spsp_sketch_keys_big_genomes(self._h))
 
     def sketch_keys_device(self, params, d_bases, n_bases, d_rec_off, d_sk, n_sk, first_rec, unordered=False):
         self.sketch_keys_device_begin(params, d_bases, n_bases, d_rec_off, d_sk, n_sk, first_rec, unordered)

@@ -13,9 +13,10 @@
 //   k_exclusive_scan  distinct counts -> offsets (spsp_scan.hip)
 //   k_decode_compact  sketches back to back
 //
-// A sketch that does not fit the sort's LDS (more than 8192 keys, 4096 with k > 32) or is not laid out as the
-// sketcher writes it (partial blob bytes, over-long lines, truncated) is decoded by spsp_sketch_parse_host and
-// uploaded: same keys, already sorted.
+// A sketch that does not fit the sort's LDS (more than 8192 keys, 4096 with k > 32) stays on the device: its raw keys go
+// through the table in HBM and the merge sort of spsp_bigkeys.hip (the reference's color_map takes whatever a bucket
+// holds, Comparator.cpp:186-260).  Only a sketch that is not laid out as the sketcher writes it (partial blob bytes,
+// over-long lines, truncated) is decoded by spsp_sketch_parse_host and uploaded: same keys, already sorted.
 #include <algorithm>
 #include <atomic>
 #include <cstring>
@@ -84,7 +85,7 @@ template <bool HAS_HI>
 __global__ __launch_bounds__(kSortThreads) void k_decode_sort(uint32_t* __restrict__ r_mn, uint64_t* __restrict__ r_lo,
                                                              uint64_t* __restrict__ r_hi, const uint64_t* __restrict__ raw_off,
                                                              const uint32_t* __restrict__ raw_cnt, const uint8_t* __restrict__ presorted,
-                                                             uint32_t* __restrict__ distinct) {
+                                                             const uint32_t* __restrict__ big, uint32_t* __restrict__ distinct) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_s[];
     constexpr uint32_t CAP = HAS_HI ? kSortCapHi : kSortCapLo;
     uint64_t* s_lo = reinterpret_cast<uint64_t*>(lds_s);
@@ -95,6 +96,7 @@ __global__ __launch_bounds__(kSortThreads) void k_decode_sort(uint32_t* __restri
     const uint32_t n = raw_cnt[s];
     const uint64_t r0 = raw_off[s];
     if (presorted[s]) { if (t == 0) distinct[s] = n; return; }
+    if (big[s]) { if (t == 0) distinct[s] = 0; return; }           // beyond this workgroup's LDS: k_big_insert / k_big_emit count it
     if (n == 0) { if (t == 0) distinct[s] = 0; return; }
     uint32_t n2 = 1;
     while (n2 < n) n2 <<= 1;
@@ -153,16 +155,22 @@ __global__ __launch_bounds__(kSortThreads) void k_decode_sort(uint32_t* __restri
 }
 
 __global__ __launch_bounds__(256) void k_decode_compact(const uint32_t* __restrict__ r_mn, const uint64_t* __restrict__ r_lo,
-                                                       const uint64_t* __restrict__ r_hi, const uint64_t* __restrict__ raw_off,
+                                                       const uint64_t* __restrict__ r_hi, const uint32_t* __restrict__ b_mn,
+                                                       const uint64_t* __restrict__ b_lo, const uint64_t* __restrict__ b_hi,
+                                                       const uint64_t* __restrict__ raw_off, const uint32_t* __restrict__ big,
                                                        const uint32_t* __restrict__ distinct, const uint32_t* __restrict__ out_off,
                                                        uint32_t* __restrict__ o_mn, uint64_t* __restrict__ o_lo, uint64_t* __restrict__ o_hi) {
     const uint32_t s = blockIdx.y;
     const uint32_t n = distinct[s];
     const uint64_t r0 = raw_off[s];
     const uint32_t o0 = out_off[s];
+    const bool from_b = big[s] != 0;                               // (a sketch the global-memory stages took: its keys are in their output slices)
+    const uint32_t* s_mn = from_b ? b_mn : r_mn;
+    const uint64_t* s_lo = from_b ? b_lo : r_lo;
+    const uint64_t* s_hi = from_b ? b_hi : r_hi;
     for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
-        o_mn[o0 + e] = r_mn[r0 + e]; o_lo[o0 + e] = r_lo[r0 + e];
-        if (o_hi) o_hi[o0 + e] = r_hi[r0 + e];
+        o_mn[o0 + e] = s_mn[r0 + e]; o_lo[o0 + e] = s_lo[r0 + e];
+        if (o_hi) o_hi[o0 + e] = s_hi[r0 + e];
     }
 }
 
@@ -176,12 +184,13 @@ int sketch_decode_device_impl(spsp_ctx* ctx, const uint8_t* const* payloads, con
     std::vector<ParsedSketch> P(n);
     std::vector<int> rcs(n, SPSP_OK);
     std::vector<std::string> errs(n);
-    // sketches the GPU path cannot take -- more raw keys than the LDS sort holds (a 5 Mbp genome at s <= ~500), or not
-    // laid out as the sketcher writes them -- are decoded on the host (sorted, distinct) and uploaded in place: by the
-    // SAME worker pool that walks the payload structures, not one after the other on the calling thread
+    // sketches that are not laid out as the sketcher writes them are decoded on the host (sorted, distinct) and uploaded
+    // in place: by the SAME worker pool that walks the payload structures, not one after the other on the calling thread.
+    // A sketch of any SIZE stays on the device (big[]: more raw keys than the LDS sort holds)
     struct HostKeys { uint32_t* mn = nullptr; uint64_t *lo = nullptr, *hi = nullptr; uint64_t n = 0; };
     std::vector<HostKeys> hk(n);
     std::vector<uint8_t> presorted(n, 0);
+    std::vector<uint32_t> big(n, 0);
     auto free_hk = [&]() { for (auto& h : hk) { free(h.mn); free(h.lo); free(h.hi); } };
     {
         unsigned workers = std::thread::hardware_concurrency();
@@ -197,7 +206,7 @@ int sketch_decode_device_impl(spsp_ctx* ctx, const uint8_t* const* payloads, con
                 if (rcs[i]) { errs[i] = spsp_last_error(); continue; }
                 const uint32_t cap_i = P[i].k > 32 ? kSortCapHi : kSortCapLo;
                 const uint64_t keys = P[i].n_keys + ((extra_has && extra_has[i]) ? 1 : 0);
-                if (P[i].standard && keys <= cap_i) continue;
+                if (P[i].standard) { big[i] = keys > cap_i ? 1u : 0u; continue; }
                 uint32_t kk, mm2;
                 rcs[i] = spsp_sketch_parse_host(payloads[i], lens[i], &kk, &mm2, &hk[i].mn, &hk[i].lo, &hk[i].hi, &hk[i].n);
                 if (rcs[i]) { errs[i] = spsp_last_error(); continue; }
@@ -258,6 +267,15 @@ int sketch_decode_device_impl(spsp_ctx* ctx, const uint8_t* const* payloads, con
     if ((rc = ctx->dc_lo.reserve((size_t)R * 8 + 64))) return fail(rc);
     if (has_hi && (rc = ctx->dc_hi.reserve((size_t)R * 8 + 64))) return fail(rc);
     if ((rc = ctx->dc_meta.reserve((size_t)(n + 1) * 8 + (size_t)n * 4 * 3 + (size_t)n + 64))) return fail(rc);
+    if ((rc = ctx->b_seg.reserve((size_t)n * 4 * 2 + 64))) return fail(rc);
+    uint32_t any_big = 0;
+    for (uint32_t i = 0; i < n; ++i) any_big |= big[i];
+    if (any_big && ((rc = ctx->b_mn.reserve((size_t)R * 4 + 64)) || (rc = ctx->b_lo.reserve((size_t)R * 8 + 64)) ||
+                    (has_hi && (rc = ctx->b_hi.reserve((size_t)R * 8 + 64))))) return fail(rc);
+    uint32_t* d_first32 = ctx->b_seg.as<uint32_t>();
+    uint32_t* d_big = d_first32 + n;
+    std::vector<uint32_t> first32(n);
+    for (uint32_t i = 0; i < n; ++i) first32[i] = (uint32_t)raw_off[i];
     if ((rc = ctx->c_min.reserve((size_t)R * 4 + 64))) return fail(rc);
     if ((rc = ctx->c_lo.reserve((size_t)R * 8 + 64))) return fail(rc);
     if (has_hi && (rc = ctx->c_hi.reserve((size_t)R * 8 + 64))) return fail(rc);
@@ -280,6 +298,8 @@ int sketch_decode_device_impl(spsp_ctx* ctx, const uint8_t* const* payloads, con
     if (e == hipSuccess) e = hipMemcpyAsync(d_raw_off, raw_off.data(), (size_t)(n + 1) * 8, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_raw_cnt, raw_cnt.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_presorted, presorted.data(), (size_t)n, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_first32, first32.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_big, big.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
     if (e != hipSuccess) { free_hk(); return hip_fail(e, "sketch upload", __FILE__, __LINE__); }
     if (!desc.empty()) {
         hipLaunchKernelGGL(k_decode_emit, dim3((uint32_t)((desc.size() + 255) / 256)), dim3(256), 0, ctx->stream, d_text,
@@ -293,12 +313,18 @@ int sketch_decode_device_impl(spsp_ctx* ctx, const uint8_t* const* payloads, con
         ctx->attr_sort_set = true;
     }
     if (has_hi) hipLaunchKernelGGL(k_decode_sort<true>, dim3(n), dim3(kSortThreads), lds, ctx->stream, ctx->dc_mn.as<uint32_t>(), ctx->dc_lo.as<uint64_t>(),
-                                   ctx->dc_hi.as<uint64_t>(), d_raw_off, d_raw_cnt, d_presorted, d_distinct);
+                                   ctx->dc_hi.as<uint64_t>(), d_raw_off, d_raw_cnt, d_presorted, d_big, d_distinct);
     else hipLaunchKernelGGL(k_decode_sort<false>, dim3(n), dim3(kSortThreads), lds, ctx->stream, ctx->dc_mn.as<uint32_t>(), ctx->dc_lo.as<uint64_t>(),
-                            (uint64_t*)nullptr, d_raw_off, d_raw_cnt, d_presorted, d_distinct);
+                            (uint64_t*)nullptr, d_raw_off, d_raw_cnt, d_presorted, d_big, d_distinct);
+    // the sketches beyond the LDS sort: distinct keys through the table in HBM (no count rule here: the reader takes every
+    // k-mer a sketch holds; no orientation bit: k_decode_emit writes canonical keys), sorted once they lie in place
+    if (any_big && (rc = big_dedupe_launch(ctx, has_hi, ctx->dc_mn.as<uint32_t>(), ctx->dc_lo.as<uint64_t>(), has_hi ? ctx->dc_hi.as<uint64_t>() : nullptr,
+                                           d_first32, d_raw_cnt, d_big, n, R, nullptr, 0u, ctx->b_mn.as<uint32_t>(), ctx->b_lo.as<uint64_t>(),
+                                           has_hi ? ctx->b_hi.as<uint64_t>() : nullptr, d_distinct))) return fail(rc);
     if ((rc = launch_scan_u32(ctx, d_distinct, d_out_off, n, ctx->h_scalar + 7))) return fail(rc);
     hipLaunchKernelGGL(k_decode_compact, dim3(8, n), dim3(256), 0, ctx->stream, ctx->dc_mn.as<uint32_t>(), ctx->dc_lo.as<uint64_t>(),
-                       has_hi ? ctx->dc_hi.as<uint64_t>() : (const uint64_t*)nullptr, d_raw_off, d_distinct, d_out_off, ctx->c_min.as<uint32_t>(),
+                       has_hi ? ctx->dc_hi.as<uint64_t>() : (const uint64_t*)nullptr, ctx->b_mn.as<uint32_t>(), ctx->b_lo.as<uint64_t>(),
+                       has_hi ? ctx->b_hi.as<uint64_t>() : (const uint64_t*)nullptr, d_raw_off, d_big, d_distinct, d_out_off, ctx->c_min.as<uint32_t>(),
                        ctx->c_lo.as<uint64_t>(), has_hi ? ctx->c_hi.as<uint64_t>() : (uint64_t*)nullptr);
     std::vector<uint32_t> off32(n + 1);
     e = hipGetLastError();
@@ -307,6 +333,12 @@ int sketch_decode_device_impl(spsp_ctx* ctx, const uint8_t* const* payloads, con
     free_hk();
     if (e != hipSuccess) return hip_fail(e, "sketch decode", __FILE__, __LINE__);
     for (uint32_t i = 0; i <= n; ++i) sk_off[i] = off32[i];
+    if (any_big) {
+        std::vector<std::pair<uint32_t, uint32_t>> segs;
+        for (uint32_t i = 0; i < n; ++i) if (big[i]) segs.emplace_back(off32[i], off32[i + 1] - off32[i]);
+        if ((rc = big_sort_segments(ctx, has_hi, ctx->c_min.as<uint32_t>(), ctx->c_lo.as<uint64_t>(), has_hi ? ctx->c_hi.as<uint64_t>() : nullptr,
+                                    ctx->dc_mn.as<uint32_t>(), ctx->dc_lo.as<uint64_t>(), has_hi ? ctx->dc_hi.as<uint64_t>() : nullptr, segs))) return rc;
+    }
     return SPSP_OK;
 }
 

@@ -104,14 +104,9 @@ struct spsp_ctx {
     // spsp_sketch_keys_device_begin / _end (spsp_keys.hip)
     bool keys_pending = false, keys_has_hi = false, attr_keys_set = false, keys_flags_clear = false, attr_dedupe_set = false;
     bool keys_unordered = false;       // spsp_compare_keys_unordered: the comparisons of this context do not insist on sorted sketches
-    uint32_t keys_genomes = 0, keys_cap = 0, keys_skm_cap = 0;
-    // inputs of the pending key extraction, kept for the host path a genome beyond the per-genome table takes (spsp_keys.hip)
-    spsp_params keys_p{};
-    const uint8_t* keys_bases = nullptr;
-    const uint64_t* keys_rec_off = nullptr;
-    const spsp_superkmer* keys_sk = nullptr;
-    uint64_t keys_n_sk = 0;
-    bool keys_packed = false;
+    uint32_t keys_genomes = 0;
+    bool keys_sorted = false;          // the pending extraction promised sorted sketches (its big genomes are sorted in _end)
+    uint32_t keys_big_genomes = 0;     // genomes of the last collected extraction that went through the global-memory stages (spsp_bigkeys.hip)
     hipEvent_t keys_done = nullptr;
     uint32_t* h_keys = nullptr;        // pinned: genome record ranges in, key offsets + overflow report out
     size_t h_keys_cap = 0;
@@ -151,6 +146,10 @@ struct spsp_ctx {
     spsp::DevBuf x_cnt, x_off, x_begin, x_end, x_tot;   // key-partitioned exchange (spsp_compare.hip)
     spsp::DevBuf dc_text, dc_desc, dc_mn, dc_lo, dc_hi, dc_meta;   // bulk sketch decode (spsp_decode.hip)
     spsp::DevBuf a_cnt, a_off, a_mn, a_lo, a_hi, a_slot, a_slot_of, a_flags;   // -a abundance pass (spsp_abund.hip)
+    // genomes / sketches beyond the per-segment LDS forms (spsp_bigkeys.hip): output slices, the open-addressing table in HBM
+    // (slot words carry the epoch of the call that claimed them: never cleared between calls), the sort's tile list
+    spsp::DevBuf b_mn, b_lo, b_hi, b_table, b_tiles, b_seg;
+    uint32_t big_epoch = 0;
 };
 
 namespace spsp {
@@ -218,6 +217,12 @@ int inflate_all_host(const uint8_t* in, size_t n, std::vector<uint8_t>& out);
 // host sketch builder over per-super-k-mer base pointers (spsp_host.cpp)
 // -a on the device (spsp_abund.hip): per k-mer occurrence of the gathered super-k-mers, bit 0 usable, bit 1 first of a dropped k-mer
 int abundance_flags_impl(spsp_ctx* ctx, const spsp_params* p, const spsp_superkmer* d_sk, uint64_t n_sk, uint8_t** h_flags, uint64_t* n_occ);
+// spsp_bigkeys.hip: distinct keys of flagged segments through one table in HBM (queued, no host wait); segments sorted in place
+int big_dedupe_launch(spsp_ctx* ctx, bool has_hi, const uint32_t* raw_mn, const uint64_t* raw_lo, const uint64_t* raw_hi,
+                      const uint32_t* d_seg_first, const uint32_t* d_seg_cnt, const uint32_t* d_seg_big, uint32_t n_seg, uint64_t n_places,
+                      const uint32_t* d_gate, uint32_t abundance, uint32_t* out_mn, uint64_t* out_lo, uint64_t* out_hi, uint32_t* d_distinct);
+int big_sort_segments(spsp_ctx* ctx, bool has_hi, uint32_t* mn, uint64_t* lo, uint64_t* hi, uint32_t* t_mn, uint64_t* t_lo, uint64_t* t_hi,
+                      const std::vector<std::pair<uint32_t, uint32_t>>& segs);
 int sketch_build_core(const spsp_params* p, double rate, const uint64_t* rec_off, uint32_t n_rec, const spsp_superkmer* sk,
                       uint64_t n_sk, const uint8_t* bases, const uint8_t* compact, const uint32_t* compact_off,
                       uint8_t** payload, uint64_t* payload_len, spsp_sketch_stats* stats, const uint8_t* kmer_flags);

@@ -21,8 +21,11 @@
 //                   oriented k-mer -> the uint8 rule; distinct surviving canonical keys, compacted in place
 //   k_keys_compact  genomes back to back
 //
-// A genome with more raw keys than the LDS sort holds (8192; 4096 with k > 32) is reported (SPSP_ERR_OVERFLOW): such
-// inputs go through the sketch files, whose reader has a host path for them.
+// A genome with more raw keys than the per-genome LDS forms hold (8192 / 6144 k-mers; 4096 with k > 32) is flagged by the
+// workgroup that meets it and goes through the global-memory stages of spsp_bigkeys.hip, queued behind the LDS kernel in
+// the same _begin call: one open-addressing table in HBM with the same (key, orientation) groups, counts and uint8 rule,
+// and -- for the sorted form -- a merge sort of its distinct keys where they finally lie.  The reference's index is
+// unbounded (SubSampler.h:62, SubSampler.cpp:274-300); so is this one, and nothing of it runs on the host.
 #include <cstring>
 #include <string>
 
@@ -44,7 +47,7 @@ __global__ void k_keys_sizes(const spsp_superkmer* __restrict__ sk, uint32_t n_s
 __global__ __launch_bounds__(256) void k_keys_emit(const uint8_t* __restrict__ bases, bool packed, const uint64_t* __restrict__ rec_off,
                                                   const spsp_superkmer* __restrict__ sk, const uint32_t* __restrict__ raw_first,
                                                   uint32_t n_sk, uint32_t k, uint32_t* __restrict__ r_mn, uint64_t* __restrict__ r_lo,
-                                                  uint64_t* __restrict__ r_hi, uint8_t* __restrict__ r_or) {
+                                                  uint64_t* __restrict__ r_hi) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_sk) return;
     const spsp_superkmer e = sk[i];
@@ -64,9 +67,9 @@ __global__ __launch_bounds__(256) void k_keys_emit(const uint8_t* __restrict__ b
         // minimizer reads reversed, SubSampler.cpp:246-249); the comparator canonises (utils.cpp:470-472)
         const u128d canon = fwd < rc ? fwd : rc;
         const u128d oriented = e.rev ? rc : fwd;
-        r_mn[o] = e.minimizer; r_lo[o] = (uint64_t)canon;
+        r_mn[o] = e.minimizer | (oriented != canon ? 0x80000000u : 0u);   // bit 31: "the oriented form is the reverse complement"
+        r_lo[o] = (uint64_t)canon;
         if (r_hi) r_hi[o] = (uint64_t)(canon >> 64);
-        r_or[o] = oriented != canon ? 1 : 0;
         ++o;
     }
 }
@@ -84,8 +87,8 @@ __global__ void k_keys_ranges(const spsp_superkmer* __restrict__ sk, uint32_t n_
 
 template <bool HAS_HI>
 __global__ __launch_bounds__(kKeySortThreads) void k_keys_sort(uint32_t* __restrict__ r_mn, uint64_t* __restrict__ r_lo, uint64_t* __restrict__ r_hi,
-                                                              const uint8_t* __restrict__ r_or, const uint32_t* __restrict__ raw_off,
-                                                              uint32_t abundance, uint32_t* __restrict__ distinct, uint32_t* __restrict__ flags) {
+                                                              const uint32_t* __restrict__ raw_off, uint32_t abundance, uint32_t* __restrict__ distinct,
+                                                              uint32_t* __restrict__ raw_cnt, uint32_t* __restrict__ big, uint32_t* __restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_k[];
     constexpr uint32_t CAP = HAS_HI ? kKeyCapHi : kKeyCapLo;
     uint64_t* s_lo = reinterpret_cast<uint64_t*>(lds_k);
@@ -95,12 +98,14 @@ __global__ __launch_bounds__(kKeySortThreads) void k_keys_sort(uint32_t* __restr
     __shared__ uint32_t wave_sum[kKeySortThreads / 64];
     const uint32_t g = blockIdx.x, t = threadIdx.x, lane = t & 63, wid = t >> 6;
     const uint32_t r0 = raw_off[g], n = raw_off[g + 1] - r0;
+    if (t == 0) { raw_cnt[g] = n; big[g] = n > CAP ? 1u : 0u; }
     if (n == 0) { if (t == 0) distinct[g] = 0; return; }
-    if (n > CAP) { if (t == 0) { distinct[g] = 0; atomicOr(&flags[0], 1u); atomicMax(&flags[1], n); } return; }
+    // more than the LDS holds: the global-memory stages queued behind this kernel take the genome (spsp_bigkeys.hip)
+    if (n > CAP) { if (t == 0) { distinct[g] = 0; atomicOr(&flags[0], 1u); atomicAdd(&flags[1], 1u); } return; }
     uint32_t n2 = 1;
     while (n2 < n) n2 <<= 1;
     for (uint32_t i = t; i < n2; i += kKeySortThreads) {
-        if (i < n) { s_mn[i] = r_mn[r0 + i]; s_lo[i] = r_lo[r0 + i]; if (HAS_HI) s_hi[i] = r_hi[r0 + i]; s_or[i] = r_or[r0 + i]; }
+        if (i < n) { const uint32_t mo = r_mn[r0 + i]; s_mn[i] = mo & 0x7fffffffu; s_or[i] = (uint8_t)(mo >> 31); s_lo[i] = r_lo[r0 + i]; if (HAS_HI) s_hi[i] = r_hi[r0 + i]; }
         else { s_mn[i] = 0xffffffffu; s_lo[i] = ~0ull; if (HAS_HI) s_hi[i] = ~0ull; s_or[i] = 1; }
     }
     __syncthreads();
@@ -183,17 +188,16 @@ __device__ __forceinline__ uint64_t keys_mix(uint64_t x) {
     x ^= x >> 27; x *= 0x94d049bb133111ebULL;
     return x ^ (x >> 31);
 }
-template <bool HAS_HI, uint32_t S>
+template <bool HAS_HI>
 __global__ __launch_bounds__(kKeySortThreads) void k_keys_fused(const uint8_t* __restrict__ bases, bool packed, uint64_t n_bases_readable,
                                                                const uint64_t* __restrict__ rec_off,
                                                                const spsp_superkmer* __restrict__ sk, uint32_t n_sk, const uint32_t* __restrict__ first_rec,
-                                                               uint32_t k, uint32_t w, uint32_t abundance, uint32_t stage_stride, uint32_t* __restrict__ r_mn,
+                                                               uint32_t k, uint32_t w, uint32_t abundance, uint32_t* __restrict__ r_mn,
                                                                uint64_t* __restrict__ r_lo, uint64_t* __restrict__ r_hi, uint32_t* __restrict__ raw_off,
-                                                               uint32_t* __restrict__ distinct, uint32_t* __restrict__ flags) {
+                                                               uint32_t* __restrict__ distinct, uint32_t* __restrict__ raw_cnt, uint32_t* __restrict__ big,
+                                                               uint32_t* __restrict__ flags) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_d[];
-    // S workgroups share a genome: every one of them stages the super-k-mers and rolls ALL k-mers (cheap), but tables only
-    // the keys of its hash class -- half the LDS each at S = 2 (78 KiB: two per CU, or one beside a comparison workgroup)
-    constexpr uint32_t FULL = HAS_HI ? kDedupCapHi : kDedupCapLo, CAP = FULL / S, SLOTS = 2 * CAP, PER = FULL / kKeySortThreads;
+    constexpr uint32_t FULL = HAS_HI ? kDedupCapHi : kDedupCapLo, CAP = FULL, SLOTS = 2 * CAP, PER = FULL / kKeySortThreads;
     constexpr uint32_t kNone = 0xffffffffu;                        // record that is not this workgroup's (or holds no k-mer)
     uint64_t* k_lo = reinterpret_cast<uint64_t*>(lds_d);
     uint64_t* k_hi = k_lo + CAP;                                   // (HAS_HI only)
@@ -205,7 +209,7 @@ __global__ __launch_bounds__(kKeySortThreads) void k_keys_fused(const uint8_t* _
     uint32_t* skw = slot + SLOTS;
     __shared__ uint32_t wave_sum[kKeySortThreads / 64];
     __shared__ uint32_t s_count;
-    const uint32_t g = blockIdx.x / S, cls = blockIdx.x % S, seg = blockIdx.x, t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const uint32_t g = blockIdx.x, seg = blockIdx.x, t = threadIdx.x, lane = t & 63, wid = t >> 6;
     // this genome's super-k-mers: [q0, q1) (the stream is in record order)
     // (wave 0 searches 64 ways at a time -- three dependent loads per bound instead of fifteen -- and tells the others)
     __shared__ uint32_t s_q[2];
@@ -230,10 +234,13 @@ __global__ __launch_bounds__(kKeySortThreads) void k_keys_fused(const uint8_t* _
     __syncthreads();
     const uint32_t q0 = s_q[0], q1 = s_q[1];
     const uint32_t n = (q1 - q0) * w;                              // the genome's k-mer places (some empty)
-    const uint32_t r0 = cls * stage_stride + q0 * w;               // this workgroup's room in the staging arrays
-    if (t == 0) { raw_off[seg] = r0; s_count = 0; }
+    const uint32_t r0 = q0 * w;                                    // this genome's room in the staging arrays: its k-mer places
+    const bool too_big = n > FULL || q1 - q0 > SKM_MAX;
+    if (t == 0) { raw_off[seg] = r0; raw_cnt[seg] = n; big[seg] = too_big ? 1u : 0u; s_count = 0; }
     if (n == 0) { if (t == 0) distinct[seg] = 0; return; }
-    if (n > FULL || q1 - q0 > SKM_MAX) { if (t == 0) { distinct[seg] = 0; atomicOr(&flags[0], 1u); atomicMax(&flags[1], n); } return; }
+    // more k-mer places (or super-k-mers) than this workgroup's LDS holds: k_keys_big_roll and the global-memory table
+    // behind it (spsp_bigkeys.hip) take the genome; flags[0] is their gate, flags[1] counts such genomes for the report
+    if (too_big) { if (t == 0) { distinct[seg] = 0; atomicOr(&flags[0], 1u); atomicAdd(&flags[1], 1u); } return; }
     for (uint32_t x = t; x < SLOTS; x += kKeySortThreads) slot[x] = 0;
     {
         const uint32_t* gw = reinterpret_cast<const uint32_t*>(bases);
@@ -302,22 +309,13 @@ __global__ __launch_bounds__(kKeySortThreads) void k_keys_fused(const uint8_t* _
         const u128d canon = fwd < rc ? fwd : rc;
         const uint32_t mo = e.minimizer | (((e.rev ? rc : fwd) != canon) ? 0x80000000u : 0u);
         const uint64_t lo = (uint64_t)canon, hi = (uint64_t)(canon >> 64);
-        if (S > 1) {                                               // both orientations of a canonical k-mer go to the same class
-            uint64_t hc = keys_mix(lo ^ 0xA0761D6478BD642FULL);
-            hc = keys_mix(hc + (uint64_t)e.minimizer * 0xE7037ED1A0B428DBULL);
-            if (HAS_HI) hc = keys_mix(hc ^ hi);
-            if ((uint32_t)(((hc >> 32) * S) >> 32) != cls) continue;
-        }
-        const uint32_t i = atomicAdd(&s_count, 1u);
-        if (i >= CAP) continue;                                    // (reported below: the class is fuller than its table)
+        const uint32_t i = atomicAdd(&s_count, 1u);                // (at most n <= CAP records)
         id[u] = i;
         k_mn[i] = mo; k_lo[i] = lo;
         if (HAS_HI) k_hi[i] = hi;
         hs[u] = home(mo, lo, hi);
     }
     __syncthreads();
-    const uint32_t n_mine = s_count;
-    if (n_mine > CAP) { if (t == 0) { distinct[seg] = 0; atomicOr(&flags[0], 1u); atomicMax(&flags[1], n); } return; }
 #pragma unroll
     for (uint32_t u = 0; u < PER; ++u) {
         const uint32_t r = id[u];
@@ -387,14 +385,56 @@ __global__ __launch_bounds__(kKeySortThreads) void k_keys_fused(const uint8_t* _
     if (t == 0) distinct[seg] = base;
 }
 
+// The genomes k_keys_fused flagged: their k-mer places as raw records (minimizer | orientation << 31, canonical k-mer) in the
+// genome's slice of the staging arrays -- place q w + j = k-mer j of super-k-mer q, 0xffffffff where a super-k-mer has fewer
+// than w -- for the global-memory table of spsp_bigkeys.hip.  One lane per super-k-mer, launched over all of them; every
+// workgroup leaves at once when nothing was flagged (flags[0], the gate).
+__global__ __launch_bounds__(256) void k_keys_big_roll(const uint8_t* __restrict__ bases, bool packed, const uint64_t* __restrict__ rec_off,
+                                                      const spsp_superkmer* __restrict__ sk, uint32_t n_sk, uint32_t k, uint32_t w,
+                                                      const uint32_t* __restrict__ raw_off, const uint32_t* __restrict__ raw_cnt,
+                                                      const uint32_t* __restrict__ big, uint32_t n_genomes, const uint32_t* __restrict__ gate,
+                                                      uint32_t* __restrict__ r_mn, uint64_t* __restrict__ r_lo, uint64_t* __restrict__ r_hi) {
+    if (*gate == 0) return;
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_sk) return;
+    const uint32_t place0 = q * w;
+    uint32_t lo_g = 0, hi_g = n_genomes;                           // the last genome whose slice starts at or before this place
+    while (hi_g - lo_g > 1) { const uint32_t mid = (lo_g + hi_g) >> 1; if (raw_off[mid] <= place0) lo_g = mid; else hi_g = mid; }
+    if (!big[lo_g] || place0 - raw_off[lo_g] >= raw_cnt[lo_g]) return;
+    const spsp_superkmer e = sk[q];
+    const uint64_t src = rec_off[e.rec] + e.start;
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(bases);
+    const u128d mask = k == 64 ? ~(u128d)0 : (((u128d)1 << (2 * k)) - 1);
+    u128d fwd = 0, rc = 0;
+    uint32_t made = 0;
+    for (uint32_t t = 0; t < e.len && made < w; ++t) {
+        const uint64_t b = src + t;
+        const uint32_t c = packed ? (words[b >> 4] >> (30u - 2u * (uint32_t)(b & 15u))) & 3u : ((uint32_t)bases[b] >> 1) & 3u;
+        fwd = ((fwd << 2) | c) & mask;
+        rc = (rc >> 2) | ((u128d)(c ^ 2u) << (2 * (k - 1)));
+        if (t + 1 < k) continue;
+        const u128d canon = fwd < rc ? fwd : rc;                   // (orientation as in k_keys_emit)
+        const u128d oriented = e.rev ? rc : fwd;
+        r_mn[place0 + made] = e.minimizer | (oriented != canon ? 0x80000000u : 0u);
+        r_lo[place0 + made] = (uint64_t)canon;
+        if (r_hi) r_hi[place0 + made] = (uint64_t)(canon >> 64);
+        ++made;
+    }
+    for (; made < w; ++made) r_mn[place0 + made] = 0xffffffffu;
+}
+
+// genomes back to back: a genome's distinct keys lie at the start of its slice of the staging arrays -- (r_*) for the
+// LDS forms, (b_*) for a genome the global-memory stages took
 __global__ __launch_bounds__(256) void k_keys_compact(const uint32_t* __restrict__ r_mn, const uint64_t* __restrict__ r_lo,
-                                                     const uint64_t* __restrict__ r_hi, const uint32_t* __restrict__ raw_off,
-                                                     const uint32_t* __restrict__ distinct, const uint32_t* __restrict__ out_off,
+                                                     const uint64_t* __restrict__ r_hi, const uint32_t* __restrict__ b_mn,
+                                                     const uint64_t* __restrict__ b_lo, const uint64_t* __restrict__ b_hi,
+                                                     const uint32_t* __restrict__ raw_off, const uint32_t* __restrict__ distinct,
+                                                     const uint32_t* __restrict__ big, const uint32_t* __restrict__ out_off,
                                                      uint32_t* __restrict__ o_mn, uint64_t* __restrict__ o_lo, uint64_t* __restrict__ o_hi,
-                                                     uint32_t n_genomes, uint32_t per_genome, uint32_t* __restrict__ flags, uint32_t* __restrict__ host_out) {
-    const uint32_t g = blockIdx.y;                            // segment: a genome (sorted form) or one hash class of a genome (unordered form)
+                                                     uint32_t n_genomes, uint32_t* __restrict__ flags, uint32_t* __restrict__ host_out) {
+    const uint32_t g = blockIdx.y;
     __shared__ uint32_t s_o0;
-    if (!out_off) {                                          // unordered form: no scan launch in front -- the counts of the segments before this one
+    if (!out_off) {                                          // unordered form: no scan launch in front -- the counts of the genomes before this one
         uint32_t part = 0;
         for (uint32_t j = threadIdx.x; j < g; j += 256) part += distinct[j];
 #pragma unroll
@@ -406,16 +446,23 @@ __global__ __launch_bounds__(256) void k_keys_compact(const uint32_t* __restrict
         __syncthreads();
     }
     const uint32_t n = distinct[g], r0 = raw_off[g], o0 = out_off ? out_off[g] : s_o0;
+    const bool from_b = big[g] != 0;
+    const uint32_t* s_mn = from_b ? b_mn : r_mn;
+    const uint64_t* s_lo = from_b ? b_lo : r_lo;
+    const uint64_t* s_hi = from_b ? b_hi : r_hi;
     for (uint32_t e = blockIdx.x * 256 + threadIdx.x; e < n; e += gridDim.x * 256) {
-        o_mn[o0 + e] = r_mn[r0 + e]; o_lo[o0 + e] = r_lo[r0 + e];
-        if (o_hi) o_hi[o0 + e] = r_hi[r0 + e];
+        o_mn[o0 + e] = s_mn[r0 + e]; o_lo[o0 + e] = s_lo[r0 + e];
+        if (o_hi) o_hi[o0 + e] = s_hi[r0 + e];
     }
-    // the offsets and the overflow report travel to pinned host memory from here: the job ends with this kernel
+    // the offsets and the report travel to pinned host memory from here: the job ends with this kernel.
+    // host_out: [0, n_genomes] key offsets; [n_genomes + 1] number of genomes the global-memory stages took;
+    //           [n_genomes + 2 + g] "genome g was one of them" (the sorted form sorts those where they lie, in _end)
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (g % per_genome == 0) host_out[g / per_genome] = o0;
-        if (g == n_genomes * per_genome - 1) {
-            host_out[n_genomes] = o0 + n; host_out[n_genomes + 1] = flags[0]; host_out[n_genomes + 2] = flags[1];
-            flags[0] = 0; flags[1] = 0;                         // for the next extraction on this context (every writer of this one has finished)
+        host_out[g] = o0;
+        host_out[n_genomes + 2 + g] = from_b ? 1u : 0u;
+        if (g == n_genomes - 1) {
+            host_out[n_genomes] = o0 + n; host_out[n_genomes + 1] = flags[1];
+            flags[0] = 0; flags[1] = 0;                         // for the next extraction on this context (every reader of this one has finished)
         }
     }
 }
@@ -427,22 +474,16 @@ int sketch_keys_begin_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d
     if (rc) return rc;
     if (ctx->keys_pending) { set_error("a key extraction is already pending on this context"); return SPSP_ERR_ARG; }
     if (n_genomes == 0) { set_error("no genomes"); return SPSP_ERR_ARG; }
+    if (n_genomes > 65535) { set_error("at most 65535 genomes per call"); return SPSP_ERR_ARG; }
     for (uint32_t g = 0; g < n_genomes; ++g)
         if (h_first_rec[g + 1] < h_first_rec[g]) { set_error("genome record ranges must be non-decreasing (genome %u)", g); return SPSP_ERR_ARG; }
     if (n_sk > 0x7ffffff0ull / 64) { set_error("too many super-k-mers for one call"); return SPSP_ERR_OVERFLOW; }
     const uint32_t n = (uint32_t)n_sk;
     const bool has_hi = p->k > 32;
-    ctx->keys_p = *p; ctx->keys_bases = d_bases; ctx->keys_rec_off = d_rec_off; ctx->keys_sk = d_sk; ctx->keys_n_sk = n_sk; ctx->keys_packed = packed;
-    const uint64_t bound = (uint64_t)n * (p->k - p->m + 1);        // raw keys: a super-k-mer holds at most k - m + 1 k-mers
-    // unordered form: one workgroup per genome, or -- SPSP_KEYS_SPLIT=2 -- two, each tabling one hash class of its keys in
-    // half the LDS (78 KiB: fits a CU beside a comparison workgroup; both roll all of the genome's k-mers)
-    static const uint32_t split_env = getenv("SPSP_KEYS_SPLIT") && atoi(getenv("SPSP_KEYS_SPLIT")) == 2 ? 2u : 1u;
-    const uint32_t split = unordered ? split_env : 1u;
-    if (bound * split > 0xfffffff0ull) { set_error("too many selected k-mers for one call"); return SPSP_ERR_OVERFLOW; }
-    const uint64_t stage = bound * split;                          // (every hash class of a genome has room for all of its keys)
-    const uint32_t segs = n_genomes * split;
-    // pinned staging: first_rec in, offsets + flags out
-    const size_t need = (size_t)(n_genomes + 1) + (size_t)(n_genomes + 3);
+    const uint32_t w = p->k - p->m + 1;
+    const uint64_t bound = (uint64_t)n * w;                        // raw keys: a super-k-mer holds at most k - m + 1 k-mers
+    // pinned staging: first_rec in; offsets, report and per-genome flags out
+    const size_t need = (size_t)(n_genomes + 1) + (size_t)(2 * n_genomes + 2);
     if (ctx->h_keys_cap < need) {
         if (ctx->h_keys) { SPSP_HIP(hipStreamSynchronize(ctx->stream)); (void)hipHostFree(ctx->h_keys); ctx->h_keys = nullptr; ctx->h_keys_cap = 0; }
         size_t cap = 1024;
@@ -452,22 +493,28 @@ int sketch_keys_begin_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d
     }
     memcpy(ctx->h_keys, h_first_rec, (size_t)(n_genomes + 1) * 4);
     uint32_t* h_out = ctx->h_keys + (n_genomes + 1);
+    // a_*: the LDS forms' staging (raw records in, a genome's distinct keys out, slice by slice); b_*: the output slices of
+    // the genomes the global-memory stages take; c_*: the keys of all genomes back to back (what the comparison reads)
     if ((rc = ctx->a_cnt.reserve((size_t)(n + 1) * 4)) || (rc = ctx->a_off.reserve((size_t)(n + 2) * 4)) ||
-        (rc = ctx->a_mn.reserve((size_t)stage * 4 + 64)) || (rc = ctx->a_lo.reserve((size_t)stage * 8 + 64)) ||
-        (has_hi && (rc = ctx->a_hi.reserve((size_t)stage * 8 + 64))) || (rc = ctx->a_flags.reserve((size_t)bound + 64)) ||
-        (rc = ctx->dc_meta.reserve((size_t)(segs + 2) * 4 * 4 + 64)) ||
+        (rc = ctx->a_mn.reserve((size_t)bound * 4 + 64)) || (rc = ctx->a_lo.reserve((size_t)bound * 8 + 64)) ||
+        (has_hi && (rc = ctx->a_hi.reserve((size_t)bound * 8 + 64))) ||
+        (rc = ctx->b_mn.reserve((size_t)bound * 4 + 64)) || (rc = ctx->b_lo.reserve((size_t)bound * 8 + 64)) ||
+        (has_hi && (rc = ctx->b_hi.reserve((size_t)bound * 8 + 64))) ||
+        (rc = ctx->dc_meta.reserve((size_t)(n_genomes + 2) * 4 * 6 + 64)) ||
         (rc = ctx->c_min.reserve((size_t)bound * 4 + 64)) || (rc = ctx->c_lo.reserve((size_t)bound * 8 + 64)) ||
         (has_hi && (rc = ctx->c_hi.reserve((size_t)bound * 8 + 64)))) return rc;
     uint32_t* d_first_rec = ctx->dc_meta.as<uint32_t>();
-    uint32_t* d_raw_off = d_first_rec + (segs + 2);
-    uint32_t* d_distinct = d_raw_off + (segs + 2);
-    uint32_t* d_out_off = d_distinct + (segs + 2);
+    uint32_t* d_raw_off = d_first_rec + (n_genomes + 2);
+    uint32_t* d_distinct = d_raw_off + (n_genomes + 2);
+    uint32_t* d_out_off = d_distinct + (n_genomes + 2);
+    uint32_t* d_raw_cnt = d_out_off + (n_genomes + 2);
+    uint32_t* d_big = d_raw_cnt + (n_genomes + 2);
     if ((rc = ctx->c_flags.reserve(64))) return rc;
     uint32_t* d_flags = ctx->c_flags.as<uint32_t>() + 12;          // two words of the comparison's flag block that it does not use
-    // The unordered form is ONE kernel + the compaction on a stream that carries a key extraction per step: its workgroups
-    // read their two record bounds straight from the pinned staging block (no copy packet in front), and the overflow
-    // words are cleared by the compaction kernel that reports them (no fill packet either; cleared here after a call
-    // that did not get that far).  The sorted form keeps the copy: several of its kernels read the bounds.
+    // The unordered form runs on a stream that carries a key extraction per step: its workgroups read their two record
+    // bounds straight from the pinned staging block (no copy packet in front), and the gate words are cleared by the
+    // compaction kernel that reports them (no fill packet either; cleared here after a call that did not get that far).
+    // The sorted form keeps the copy: several of its kernels read the bounds.
     if (!unordered) SPSP_HIP(hipMemcpyAsync(d_first_rec, ctx->h_keys, (size_t)(n_genomes + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
     else d_first_rec = ctx->h_keys;
     if (!ctx->keys_flags_clear) SPSP_HIP(hipMemsetAsync(d_flags, 0, 8, ctx->stream));
@@ -476,131 +523,72 @@ int sketch_keys_begin_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d
     // k-mer (an empty blob reads as the bare minimizer, Comparator.cpp:88-90,193-198) -- also of one whose k-mer stayed below
     // -a or wrapped to 0: its map entry made the bucket exist (SubSampler.cpp:283-300).  The count rule does not apply.
     const uint32_t ab = p->k == p->m ? 0u : (p->abundance ? p->abundance : 1u);
+    uint32_t* a_mn = ctx->a_mn.as<uint32_t>();
+    uint64_t *a_lo = ctx->a_lo.as<uint64_t>(), *a_hi = has_hi ? ctx->a_hi.as<uint64_t>() : (uint64_t*)nullptr;
+    uint32_t* b_mn = ctx->b_mn.as<uint32_t>();
+    uint64_t *b_lo = ctx->b_lo.as<uint64_t>(), *b_hi = has_hi ? ctx->b_hi.as<uint64_t>() : (uint64_t*)nullptr;
+    uint32_t* c_mn = ctx->c_min.as<uint32_t>();
+    uint64_t *c_lo = ctx->c_lo.as<uint64_t>(), *c_hi = has_hi ? ctx->c_hi.as<uint64_t>() : (uint64_t*)nullptr;
     if (unordered) {
-        const uint32_t w = p->k - p->m + 1;
-        const size_t lds_d = (has_hi ? (size_t)(kDedupCapHi / split) * 28 : (size_t)(kDedupCapLo / split) * 20) + kDedupSkmWords * 4;
+        const size_t lds_d = (has_hi ? (size_t)kDedupCapHi * 28 : (size_t)kDedupCapLo * 20) + kDedupSkmWords * 4;
         if (!ctx->attr_dedupe_set) {
-            SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keys_fused<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kDedupCapHi * 28 + kDedupSkmWords * 4)));
-            SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keys_fused<false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kDedupCapLo * 20 + kDedupSkmWords * 4)));
-            SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keys_fused<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kDedupCapHi * 14 + kDedupSkmWords * 4)));
-            SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keys_fused<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kDedupCapLo * 10 + kDedupSkmWords * 4)));
+            SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keys_fused<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kDedupCapHi * 28 + kDedupSkmWords * 4)));
+            SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keys_fused<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kDedupCapLo * 20 + kDedupSkmWords * 4)));
             ctx->attr_dedupe_set = true;
         }
-#define SPSP_KEYS_FUSED(HI, SP) hipLaunchKernelGGL((k_keys_fused<HI, SP>), dim3(segs), dim3(kKeySortThreads), lds_d, ctx->stream, d_bases, packed, n_bases_readable, d_rec_off, \
-                                                    d_sk, n, d_first_rec, p->k, w, ab, (uint32_t)bound, ctx->a_mn.as<uint32_t>(), ctx->a_lo.as<uint64_t>(),                   \
-                                                    HI ? ctx->a_hi.as<uint64_t>() : (uint64_t*)nullptr, d_raw_off, d_distinct, d_flags)
-        if (has_hi) { if (split == 2) SPSP_KEYS_FUSED(true, 2); else SPSP_KEYS_FUSED(true, 1); }
-        else { if (split == 2) SPSP_KEYS_FUSED(false, 2); else SPSP_KEYS_FUSED(false, 1); }
-#undef SPSP_KEYS_FUSED
+        if (has_hi) hipLaunchKernelGGL((k_keys_fused<true>), dim3(n_genomes), dim3(kKeySortThreads), lds_d, ctx->stream, d_bases, packed, n_bases_readable, d_rec_off,
+                                       d_sk, n, d_first_rec, p->k, w, ab, a_mn, a_lo, a_hi, d_raw_off, d_distinct, d_raw_cnt, d_big, d_flags);
+        else hipLaunchKernelGGL((k_keys_fused<false>), dim3(n_genomes), dim3(kKeySortThreads), lds_d, ctx->stream, d_bases, packed, n_bases_readable, d_rec_off,
+                                d_sk, n, d_first_rec, p->k, w, ab, a_mn, a_lo, a_hi, d_raw_off, d_distinct, d_raw_cnt, d_big, d_flags);
         SPSP_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k_keys_compact, dim3(8, segs), dim3(256), 0, ctx->stream, ctx->a_mn.as<uint32_t>(), ctx->a_lo.as<uint64_t>(),
-                           has_hi ? ctx->a_hi.as<uint64_t>() : (const uint64_t*)nullptr, d_raw_off, d_distinct, (const uint32_t*)nullptr, ctx->c_min.as<uint32_t>(),
-                           ctx->c_lo.as<uint64_t>(), has_hi ? ctx->c_hi.as<uint64_t>() : (uint64_t*)nullptr, n_genomes, split, d_flags, h_out);
+        if (n) {
+            // genomes beyond the LDS table (none at the bench's 5 Mbp and s = 1000: three launches whose workgroups read the gate and leave)
+            hipLaunchKernelGGL(k_keys_big_roll, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_bases, packed, d_rec_off, d_sk, n, p->k, w,
+                               (const uint32_t*)d_raw_off, (const uint32_t*)d_raw_cnt, (const uint32_t*)d_big, n_genomes, (const uint32_t*)d_flags, a_mn, a_lo, a_hi);
+            SPSP_HIP(hipGetLastError());
+            if ((rc = big_dedupe_launch(ctx, has_hi, a_mn, a_lo, a_hi, d_raw_off, d_raw_cnt, d_big, n_genomes, bound, d_flags, ab, b_mn, b_lo, b_hi, d_distinct))) return rc;
+        }
+        hipLaunchKernelGGL(k_keys_compact, dim3(8, n_genomes), dim3(256), 0, ctx->stream, a_mn, a_lo, a_hi, b_mn, b_lo, b_hi, d_raw_off, d_distinct, d_big,
+                           (const uint32_t*)nullptr, c_mn, c_lo, c_hi, n_genomes, d_flags, h_out);
         SPSP_HIP(hipGetLastError());
-        if (!ctx->keys_done) SPSP_HIP(hipEventCreateWithFlags(&ctx->keys_done, hipEventDisableTiming));
-        SPSP_HIP(hipEventRecord(ctx->keys_done, ctx->stream));
-        ctx->keys_pending = true;
-        ctx->keys_genomes = n_genomes;
-        ctx->keys_has_hi = has_hi;
-        ctx->keys_cap = has_hi ? kDedupCapHi : kDedupCapLo;
-        ctx->keys_skm_cap = kDedupSkmWords / (has_hi ? 8 : 4);
-        ctx->keys_flags_clear = true;                              // (k_keys_compact leaves the words at zero)
-        return SPSP_OK;
-    }
-    if (n) {
-        hipLaunchKernelGGL(k_keys_sizes, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_sk, n, p->k, ctx->a_cnt.as<uint32_t>());
+    } else {
+        if (n) {
+            hipLaunchKernelGGL(k_keys_sizes, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_sk, n, p->k, ctx->a_cnt.as<uint32_t>());
+            SPSP_HIP(hipGetLastError());
+        }
+        if ((rc = launch_scan_u32(ctx, ctx->a_cnt.as<uint32_t>(), ctx->a_off.as<uint32_t>(), n, ctx->h_scalar + 7))) return rc;
+        if (n) {
+            hipLaunchKernelGGL(k_keys_emit, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_bases, packed, d_rec_off, d_sk, ctx->a_off.as<uint32_t>(), n, p->k,
+                               a_mn, a_lo, a_hi);
+            SPSP_HIP(hipGetLastError());
+        }
+        hipLaunchKernelGGL(k_keys_ranges, dim3((n_genomes + 1 + 255) / 256), dim3(256), 0, ctx->stream, d_sk, n, ctx->a_off.as<uint32_t>(), d_first_rec,
+                           n_genomes, d_raw_off);
+        SPSP_HIP(hipGetLastError());
+        const size_t lds = has_hi ? (size_t)kKeyCapHi * 21 : (size_t)kKeyCapLo * 13;
+        if (!ctx->attr_keys_set) {
+            SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keys_sort<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kKeyCapHi * 21)));
+            SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keys_sort<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kKeyCapLo * 13)));
+            ctx->attr_keys_set = true;
+        }
+        if (has_hi) hipLaunchKernelGGL(k_keys_sort<true>, dim3(n_genomes), dim3(kKeySortThreads), lds, ctx->stream, a_mn, a_lo, a_hi, d_raw_off, ab, d_distinct, d_raw_cnt, d_big, d_flags);
+        else hipLaunchKernelGGL(k_keys_sort<false>, dim3(n_genomes), dim3(kKeySortThreads), lds, ctx->stream, a_mn, a_lo, (uint64_t*)nullptr, d_raw_off, ab, d_distinct, d_raw_cnt, d_big, d_flags);
+        SPSP_HIP(hipGetLastError());
+        // a genome beyond the LDS sort: its raw records are where k_keys_emit left them -- the global-memory table makes its
+        // distinct keys (in no order: _end sorts them where the compaction puts them)
+        if (n && (rc = big_dedupe_launch(ctx, has_hi, a_mn, a_lo, a_hi, d_raw_off, d_raw_cnt, d_big, n_genomes, bound, d_flags, ab, b_mn, b_lo, b_hi, d_distinct))) return rc;
+        if ((rc = launch_scan_u32(ctx, d_distinct, d_out_off, n_genomes, ctx->h_scalar + 7))) return rc;
+        hipLaunchKernelGGL(k_keys_compact, dim3(8, n_genomes), dim3(256), 0, ctx->stream, a_mn, a_lo, a_hi, b_mn, b_lo, b_hi, d_raw_off, d_distinct, d_big,
+                           (const uint32_t*)d_out_off, c_mn, c_lo, c_hi, n_genomes, d_flags, h_out);
         SPSP_HIP(hipGetLastError());
     }
-    if ((rc = launch_scan_u32(ctx, ctx->a_cnt.as<uint32_t>(), ctx->a_off.as<uint32_t>(), n, ctx->h_scalar + 7))) return rc;
-    if (n) {
-        hipLaunchKernelGGL(k_keys_emit, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_bases, packed, d_rec_off, d_sk, ctx->a_off.as<uint32_t>(), n, p->k,
-                           ctx->a_mn.as<uint32_t>(), ctx->a_lo.as<uint64_t>(), has_hi ? ctx->a_hi.as<uint64_t>() : (uint64_t*)nullptr, ctx->a_flags.as<uint8_t>());
-        SPSP_HIP(hipGetLastError());
-    }
-    hipLaunchKernelGGL(k_keys_ranges, dim3((n_genomes + 1 + 255) / 256), dim3(256), 0, ctx->stream, d_sk, n, ctx->a_off.as<uint32_t>(), d_first_rec,
-                       n_genomes, d_raw_off);
-    SPSP_HIP(hipGetLastError());
-    const size_t lds = has_hi ? (size_t)kKeyCapHi * 21 : (size_t)kKeyCapLo * 13;
-    if (!ctx->attr_keys_set) {
-        SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keys_sort<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kKeyCapHi * 21)));
-        SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keys_sort<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kKeyCapLo * 13)));
-        ctx->attr_keys_set = true;
-    }
-    if (has_hi) hipLaunchKernelGGL(k_keys_sort<true>, dim3(n_genomes), dim3(kKeySortThreads), lds, ctx->stream, ctx->a_mn.as<uint32_t>(), ctx->a_lo.as<uint64_t>(),
-                                   ctx->a_hi.as<uint64_t>(), ctx->a_flags.as<uint8_t>(), d_raw_off, ab, d_distinct, d_flags);
-    else hipLaunchKernelGGL(k_keys_sort<false>, dim3(n_genomes), dim3(kKeySortThreads), lds, ctx->stream, ctx->a_mn.as<uint32_t>(), ctx->a_lo.as<uint64_t>(),
-                            (uint64_t*)nullptr, ctx->a_flags.as<uint8_t>(), d_raw_off, ab, d_distinct, d_flags);
-    SPSP_HIP(hipGetLastError());
-    if ((rc = launch_scan_u32(ctx, d_distinct, d_out_off, n_genomes, ctx->h_scalar + 7))) return rc;
-    hipLaunchKernelGGL(k_keys_compact, dim3(8, n_genomes), dim3(256), 0, ctx->stream, ctx->a_mn.as<uint32_t>(), ctx->a_lo.as<uint64_t>(),
-                       has_hi ? ctx->a_hi.as<uint64_t>() : (const uint64_t*)nullptr, d_raw_off, d_distinct, d_out_off, ctx->c_min.as<uint32_t>(),
-                       ctx->c_lo.as<uint64_t>(), has_hi ? ctx->c_hi.as<uint64_t>() : (uint64_t*)nullptr, n_genomes, 1u, d_flags, h_out);
-    SPSP_HIP(hipGetLastError());
     if (!ctx->keys_done) SPSP_HIP(hipEventCreateWithFlags(&ctx->keys_done, hipEventDisableTiming));
     SPSP_HIP(hipEventRecord(ctx->keys_done, ctx->stream));
     ctx->keys_pending = true;
     ctx->keys_genomes = n_genomes;
     ctx->keys_has_hi = has_hi;
-    ctx->keys_cap = has_hi ? kKeyCapHi : kKeyCapLo;
-    ctx->keys_skm_cap = 0;
-    ctx->keys_flags_clear = true;
-    return SPSP_OK;
-}
-
-// A genome beyond the per-genome table (dense sketches: s near 1, k == m, long genomes): the call takes the path its keys
-// would take through a file, without the file -- the selected super-k-mers are gathered to the host, the sketch builder
-// (handle_superkmer + emission, spsp_host.cpp) makes every genome's payload and the comparator's reader parses it back:
-// sorted distinct keys, uploaded into the same arrays.  Slow (host), correct for any size; SPSP_DEBUG_KEYS_NO_HOST=1 keeps
-// the error instead (test hook).
-static int keys_host_path(spsp_ctx* ctx, uint64_t* sk_off) {
-    const spsp_params& p = ctx->keys_p;
-    const uint32_t n_genomes = ctx->keys_genomes;
-    const uint32_t* first_rec = ctx->h_keys;
-    const uint32_t n_rec = first_rec[n_genomes];
-    const uint64_t n_sk = ctx->keys_n_sk;
-    std::vector<uint64_t> rec_off((size_t)n_rec + 1);
-    std::vector<spsp_superkmer> sk((size_t)n_sk);
-    SPSP_HIP(hipMemcpyAsync(rec_off.data(), ctx->keys_rec_off, rec_off.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (n_sk) SPSP_HIP(hipMemcpyAsync(sk.data(), ctx->keys_sk, (size_t)n_sk * sizeof(spsp_superkmer), hipMemcpyDeviceToHost, ctx->stream));
-    uint8_t* compact = nullptr; uint32_t* coff = nullptr;
-    int rc = gather_superkmers_impl(ctx, ctx->keys_bases, ctx->keys_rec_off, ctx->keys_sk, n_sk, &compact, &coff, ctx->keys_packed);   // synchronises the stream
-    if (rc) return rc;
-    std::vector<uint32_t> all_mn;
-    std::vector<uint64_t> all_lo, all_hi;
-    const bool has_hi = p.k > 32;
-    size_t at = 0;
-    sk_off[0] = 0;
-    for (uint32_t g = 0; g < n_genomes && !rc; ++g) {
-        while (at < sk.size() && sk[at].rec < first_rec[g]) ++at;
-        const size_t q0 = at;
-        while (at < sk.size() && sk[at].rec < first_rec[g + 1]) ++at;
-        std::vector<spsp_superkmer> mine(sk.begin() + (ptrdiff_t)q0, sk.begin() + (ptrdiff_t)at);
-        for (auto& e : mine) e.rec -= first_rec[g];
-        uint8_t* payload = nullptr; uint64_t plen = 0;
-        spsp_sketch_stats st;
-        // (-a > 1: the builder counts the k-mers itself, per genome -- the device's abundance pass numbers the occurrences of ONE file)
-        rc = sketch_build_core(&p, 1.0, rec_off.data() + first_rec[g], first_rec[g + 1] - first_rec[g], mine.data(), mine.size(), nullptr, compact,
-                               coff ? coff + q0 : nullptr, &payload, &plen, &st, nullptr);
-        uint32_t k2 = 0, m2 = 0; uint32_t* mn = nullptr; uint64_t *lo = nullptr, *hi = nullptr; uint64_t cnt = 0;
-        if (!rc) rc = spsp_sketch_parse_host(payload, plen, &k2, &m2, &mn, &lo, &hi, &cnt);
-        free(payload);
-        if (!rc) {
-            all_mn.insert(all_mn.end(), mn, mn + cnt); all_lo.insert(all_lo.end(), lo, lo + cnt);
-            if (has_hi) all_hi.insert(all_hi.end(), hi, hi + cnt);
-        }
-        free(mn); free(lo); free(hi);
-        sk_off[g + 1] = all_mn.size();
-    }
-    free(compact); free(coff);
-    if (rc) return rc;
-    const size_t tot = all_mn.size();
-    if ((rc = ctx->c_min.reserve(tot * 4 + 64)) || (rc = ctx->c_lo.reserve(tot * 8 + 64)) || (has_hi && (rc = ctx->c_hi.reserve(tot * 8 + 64)))) return rc;
-    if (tot) {
-        SPSP_HIP(hipMemcpyAsync(ctx->c_min.p, all_mn.data(), tot * 4, hipMemcpyHostToDevice, ctx->stream));
-        SPSP_HIP(hipMemcpyAsync(ctx->c_lo.p, all_lo.data(), tot * 8, hipMemcpyHostToDevice, ctx->stream));
-        if (has_hi) SPSP_HIP(hipMemcpyAsync(ctx->c_hi.p, all_hi.data(), tot * 8, hipMemcpyHostToDevice, ctx->stream));
-        SPSP_HIP(hipStreamSynchronize(ctx->stream));          // (the host vectors go out of scope)
-    }
+    ctx->keys_sorted = !unordered;
+    ctx->keys_flags_clear = true;                                  // (k_keys_compact leaves the words at zero)
     return SPSP_OK;
 }
 
@@ -610,20 +598,21 @@ int sketch_keys_end_impl(spsp_ctx* ctx, void** d_mn, void** d_lo, void** d_hi, u
     SPSP_HIP(hipEventSynchronize(ctx->keys_done));
     const uint32_t n_genomes = ctx->keys_genomes;
     const uint32_t* h_out = ctx->h_keys + (n_genomes + 1);
-    if (h_out[n_genomes + 1]) {
-        static const bool no_host = getenv("SPSP_DEBUG_KEYS_NO_HOST") != nullptr;
-        if (no_host) {
-            set_error("a genome has %u selected k-mer places, more than the device's per-genome table holds (%u%s): sketch it through a file",
-                      h_out[n_genomes + 2], ctx->keys_cap, ctx->keys_skm_cap ? (", in at most " + std::to_string(ctx->keys_skm_cap) + " super-k-mers").c_str() : "");
-            return SPSP_ERR_OVERFLOW;
-        }
-        const int rc = keys_host_path(ctx, sk_off);
-        if (rc) return rc;
-        *d_mn = ctx->c_min.p; *d_lo = ctx->c_lo.p; *d_hi = ctx->keys_has_hi ? ctx->c_hi.p : nullptr;
-        return SPSP_OK;
-    }
     for (uint32_t g = 0; g <= n_genomes; ++g) sk_off[g] = h_out[g];
+    ctx->keys_big_genomes = h_out[n_genomes + 1];
     *d_mn = ctx->c_min.p; *d_lo = ctx->c_lo.p; *d_hi = ctx->keys_has_hi ? ctx->c_hi.p : nullptr;
+    if (ctx->keys_sorted && ctx->keys_big_genomes) {
+        // the sorted form promises sorted sketches: the keys of the genomes the global-memory stages took are distinct and
+        // in place, in no order.  Sizes are known here, so this is the one part of the job that is queued from _end -- it
+        // reads and writes context-owned buffers only (the caller's inputs were last read by the work queued in _begin).
+        std::vector<std::pair<uint32_t, uint32_t>> segs;
+        for (uint32_t g = 0; g < n_genomes; ++g)
+            if (h_out[n_genomes + 2 + g]) segs.emplace_back(h_out[g], h_out[g + 1] - h_out[g]);
+        const bool hh = ctx->keys_has_hi;
+        const int rc = big_sort_segments(ctx, hh, ctx->c_min.as<uint32_t>(), ctx->c_lo.as<uint64_t>(), hh ? ctx->c_hi.as<uint64_t>() : nullptr,
+                                         ctx->a_mn.as<uint32_t>(), ctx->a_lo.as<uint64_t>(), hh ? ctx->a_hi.as<uint64_t>() : nullptr, segs);
+        if (rc) return rc;
+    }
     return SPSP_OK;
 }
 
@@ -646,6 +635,8 @@ int spsp_sketch_keys_device_end(spsp_ctx* ctx, void** d_minimizer, void** d_kmer
     SPSP_HIP(hipSetDevice(ctx->device));
     return sketch_keys_end_impl(ctx, d_minimizer, d_kmer_lo, d_kmer_hi, sk_off);
 }
+
+uint32_t spsp_sketch_keys_big_genomes(spsp_ctx* ctx) { return ctx ? ctx->keys_big_genomes : 0u; }
 
 int spsp_sketch_keys_device(spsp_ctx* ctx, const spsp_params* p, const void* d_bases, uint64_t n_bases, const void* d_rec_off,
                             const void* d_superkmers, uint64_t n_superkmers, const uint32_t* h_first_rec, uint32_t n_genomes, uint32_t flags,

@@ -770,7 +770,7 @@ def test_gpu_sketch_decode_matches_oracle_keys(ctx):
     """N2: bulk decode of sketch payloads on the GPU (blob + text super-k-mers -> canonical keys -> sort -> unique) gives
     the keys the ORACLE's comparator enumerates for each file (orc_sketch_keys: its merge + walk_bucket, Comparator.cpp:
     39-74, 186-260 restated), sketch by sketch: k <= 32 and k > 32, k == m (bare minimizers), empty sketches, a sketch too
-    large for the LDS sort (host decode inside the same call) and duplicate k-mers across super-k-mers."""
+    large for the LDS sort (the table in HBM + the merge sort of spsp_bigkeys.hip inside the same call) and duplicate k-mers across super-k-mers."""
     rng = np.random.default_rng(606)
     for (k, m, s, sizes) in [(31, 11, 20, [60_000, 0, 25_000, 300, 700_000]), (63, 15, 10, [40_000, 9_000, 120_000]),
                              (15, 15, 3, [20_000, 5, 8_000]), (21, 9, 4, [30_000, 30_000])]:
@@ -802,7 +802,7 @@ def test_gpu_sketch_decode_matches_oracle_keys(ctx):
             if k > 32:
                 assert (hi[a:b] == w_hi).all(), (k, m, i)
         if k == 31:
-            assert int(sk_off[5] - sk_off[4]) > 8192               # the large sketch went through the host decoder
+            assert int(sk_off[5] - sk_off[4]) > 8192               # the large sketch went through the table in HBM and the merge sort
 
 
 def test_cu_partitioned_streams_and_sampled_timing():
@@ -1023,7 +1023,7 @@ def test_sketch_keys_on_device_equal_the_file_path(ctx, k, m, s, ab):
     the oracle writes for that genome (handle_superkmer's uint8 counts and the -a rule included): random and mutated
     genomes, a genome followed by its reverse complement (both orientations of every k-mer), a unit repeated 257 and 256
     times (the count wraps), a record too short for a k-mer; ASCII and 2-bit input; a genome too large for the
-    per-genome sort is refused."""
+    per-genome LDS forms goes through the table in HBM (and the merge sort) inside the same call."""
     import torch
     rng = np.random.default_rng(1000 + k)
     L = min(900_000, int((1500 if k > 32 else 3000) * s))     # a genome's selected k-mer occurrences stay inside the per-genome sort
@@ -1073,8 +1073,8 @@ def test_sketch_keys_on_device_equal_the_file_path(ctx, k, m, s, ab):
     assert (np.triu(d_inter.cpu().numpy(), 1) == np.triu(w_inter, 1)).all()
     # SPSP_KEYS_UNORDERED: the same key SETS from an LDS table per genome instead of a sort; a comparison that has been told
     # so takes them, one that has not refuses them (its order check is its duplicate check)
-    # (k == m: one k-mer per super-k-mer, thousands of super-k-mers per genome -- more than the unordered form stages: the call
-    # takes the host path inside, same keys)
+    # (k == m: one k-mer per super-k-mer, thousands of super-k-mers per genome -- more than the unordered form stages in LDS:
+    # those genomes go through the table in HBM, same keys)
     d_mn, d_lo, d_hi, sk_off2 = ctx.sketch_keys_device(p, src, len(bases), d_o.data_ptr(), d_sk, n_sk, first_rec, unordered=True)
     assert (sk_off2 == sk_off).all()
     total = int(sk_off2[-1])
@@ -1087,7 +1087,7 @@ def test_sketch_keys_on_device_equal_the_file_path(ctx, k, m, s, ab):
         assert sorted(zip(mn[x:y].tolist(), hi[x:y].tolist(), lo[x:y].tolist())) == list(zip(w_mn.tolist(), w_hi.tolist(), w_lo.tolist())), g
     d_inter.zero_()
     torch.cuda.synchronize()
-    if k != m:       # (the host path's keys come out sorted: nothing to refuse)
+    if k != m:
         with pytest.raises(sp.SpspError):
             ctx.compare_device(k, d_mn, d_lo, d_hi, sk_off2, len(genomes), 0, 1, d_inter.data_ptr())
     ctx.compare_keys_unordered(True)
@@ -1105,39 +1105,24 @@ def test_sketch_keys_on_device_equal_the_file_path(ctx, k, m, s, ab):
         torch.cuda.synchronize()
         p = sp.make_params(k, m, s)
         d_sk, n_sk = ctx.scan_device(p, d_b2.data_ptr(), len(bb), d_o2.data_ptr(), 1)
-        # a genome beyond the per-genome sort (20 000 selected k-mers): the host path inside the call, the keys the file would give
+        # a genome beyond the per-genome LDS forms (20 000 selected k-mers): the table in HBM inside the call (+ the merge
+        # sort in the sorted form), the keys the file would give
         for un in (False, True):
             d_mn, d_lo, _, koff = ctx.sketch_keys_device(p, d_b2.data_ptr(), len(bb), d_o2.data_ptr(), d_sk, n_sk, [0, 1], unordered=un)
+            assert ctx.sketch_keys_big_genomes() == 1
             _, _, w_mn, w_lo, _ = orc.sketch_keys(orc.sketch_fasta(synth.to_fasta(big, "big"), k, m, s)[0])
             assert int(koff[1]) == len(w_mn) > 8192
-            assert (ctx.to_host(d_mn, len(w_mn), np.uint32) == w_mn).all() and (ctx.to_host(d_lo, len(w_lo), np.uint64) == w_lo).all()
+            g_mn, g_lo = ctx.to_host(d_mn, len(w_mn), np.uint32), ctx.to_host(d_lo, len(w_lo), np.uint64)
+            if un:
+                o = np.lexsort((g_lo, g_mn))
+                g_mn, g_lo = g_mn[o], g_lo[o]
+            assert (g_mn == w_mn).all() and (g_lo == w_lo).all(), un
 
 
-def test_sketch_keys_split_form_and_api_misuse(ctx):
-    """SPSP_KEYS_SPLIT=2 (two workgroups per genome, each tabling one hash class of its keys) gives the same key sets; a
-    second _begin on a context with a job pending and an _end without a job are refused; spsp_measure_hbm_device returns
-    rates a streaming kernel can have on this part."""
+def test_sketch_keys_api_misuse(ctx):
+    """a second _begin on a context with a job pending and an _end without a job are refused; spsp_measure_hbm_device
+    returns rates a streaming kernel can have on this part."""
     import torch
-    code = ("import sys\nsys.path.insert(0, %r); sys.path.insert(0, %r)\n"
-            "import numpy as np, torch\nimport supersampler_amd as sp\nfrom supersampler_amd import synth\nfrom oracle import oracle_py as orc\n"
-            "k, m, s = 31, 11, 20.0\nrng = np.random.default_rng(5)\n"
-            "gs = [[synth.random_genome(rng, 50_000)], [synth.random_genome(rng, 30_000), synth.random_genome(rng, 20_000)], [synth.random_genome(rng, 10)]]\n"
-            "gs[1][1][:5000] = gs[0][0][:5000]\n"
-            "recs = [r for g in gs for r in g]\nfirst = np.cumsum([0] + [len(g) for g in gs]).astype(np.uint32)\n"
-            "bases, off = synth.concat_records(recs)\n"
-            "d_b = torch.from_numpy(np.concatenate([bases, np.zeros(64, np.uint8)])).cuda(); d_o = torch.from_numpy(off.view(np.int64)).cuda()\n"
-            "torch.cuda.synchronize()\nctx = sp.Context(0)\np = sp.make_params(k, m, s)\n"
-            "d_sk, n_sk = ctx.scan_device(p, d_b.data_ptr(), len(bases), d_o.data_ptr(), len(recs))\n"
-            "d_mn, d_lo, _, koff = ctx.sketch_keys_device(p, d_b.data_ptr(), len(bases), d_o.data_ptr(), d_sk, n_sk, first, unordered=True)\n"
-            "mn, lo = ctx.to_host(d_mn, int(koff[-1]), np.uint32), ctx.to_host(d_lo, int(koff[-1]), np.uint64)\n"
-            "for g, grecs in enumerate(gs):\n"
-            "    text = b''.join(synth.to_fasta(r, 'r%%d' %% j) for j, r in enumerate(grecs))\n"
-            "    _, _, w_mn, w_lo, _ = orc.sketch_keys(orc.sketch_fasta(text, k, m, s)[0])\n"
-            "    x, y = int(koff[g]), int(koff[g + 1])\n"
-            "    assert sorted(zip(mn[x:y].tolist(), lo[x:y].tolist())) == list(zip(w_mn.tolist(), w_lo.tolist())), g\n"
-            "assert int(koff[1]) > 1000\nprint('ok')\n") % (ROOT, os.path.join(ROOT, "tests"))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SPSP_KEYS_SPLIT="2"), capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
     rng = np.random.default_rng(6)
     g = synth.random_genome(rng, 40_000)
     bases, off = synth.concat_records([g])
@@ -1158,3 +1143,134 @@ def test_sketch_keys_split_form_and_api_misuse(ctx):
         ctx.sketch_keys_device_begin(p, d_b.data_ptr(), len(bases), d_o.data_ptr(), d_sk, n_sk, [1, 0])     # decreasing record ranges
     rates = ctx.measure_hbm(256 << 20, 3)
     assert 1000 < rates["copy_GBps"] < 8000 and 1000 < rates["read_GBps"] < 8000 and rates["bytes"] == 256 << 20
+
+
+def _keys_want(texts, k, m, s, ab=1):
+    return [orc.sketch_keys(orc.sketch_fasta(t, k, m, s, ab)[0]) for t in texts]
+
+
+def _check_keys(ctx, got, want, k, sorted_form, tag):
+    d_mn, d_lo, d_hi, sk_off = got
+    total = int(sk_off[-1])
+    mn, lo = ctx.to_host(d_mn, total, np.uint32), ctx.to_host(d_lo, total, np.uint64)
+    hi = ctx.to_host(d_hi, total, np.uint64) if k > 32 else np.zeros(total, np.uint64)
+    for g, (_, _, w_mn, w_lo, w_hi) in enumerate(want):
+        x, y = int(sk_off[g]), int(sk_off[g + 1])
+        assert y - x == len(w_mn), (tag, g, y - x, len(w_mn))
+        a, b, c = mn[x:y], lo[x:y], hi[x:y]
+        if not sorted_form:
+            o = np.lexsort((b, c, a))
+            a, b, c = a[o], b[o], c[o]
+        assert (a == w_mn).all() and (b == w_lo).all() and (c == w_hi).all(), (tag, g)
+
+
+@pytest.mark.parametrize("k,m,s,ab", [(31, 11, 25.0, 1), (63, 15, 12.0, 1), (31, 11, 30.0, 2), (21, 11, 8.0, 1)])
+def test_sketch_keys_of_any_size_stay_on_the_device(ctx, k, m, s, ab):
+    """The reference's k-mer index is unbounded (SubSampler.h:62, SubSampler.cpp:274-300).  Genomes beyond the per-genome
+    LDS forms (8192 / 6144 k-mers) and genomes inside them in ONE call, both forms, ASCII and 2-bit input: the large ones go
+    through the table in HBM (spsp_bigkeys.hip), the others keep their workgroup; every genome equals the oracle's
+    comparator walk over the oracle's sketch.  A large genome that repeats a unit 257 / 256 times (the uint8 count wraps),
+    one that holds a segment on both strands, and with -a 2 segments seen once and twice."""
+    import torch
+    rng = np.random.default_rng(77 + k)
+    comp = {65: 84, 67: 71, 71: 67, 84: 65}
+    big = synth.random_genome(rng, int(14_000 * s))                      # ~14 000 selected k-mers
+    mid = synth.random_genome(rng, int(7_000 * s)) if k <= 32 else synth.random_genome(rng, int(5_000 * s))   # between the two LDS limits
+    small = synth.random_genome(rng, int(1_500 * s))
+    rcbig = np.array([comp[c] for c in big[: len(big) // 3][::-1].tolist()], dtype=np.uint8)
+    unit = synth.random_genome(rng, k + 3)
+    genomes = [[small], [big[: len(big) // 2], big[len(big) // 2:]], [synth.mutate(rng, small, 0.02)], [mid],
+               [big[: len(big) // 3], rcbig, np.tile(unit, 257), big[len(big) // 3:]],       # both strands + a wrapped count, large
+               [np.tile(unit[::-1].copy(), 256), synth.mutate(rng, big, 0.01)],
+               [synth.random_genome(rng, k - 1)], [small[: len(small) // 2]] * ab,
+               [big] + [big[: len(big) // 2]] * (ab - 1)]
+    recs, first_rec, texts = [], [0], []
+    for i, g in enumerate(genomes):
+        recs += g
+        first_rec.append(len(recs))
+        texts.append(b"".join(synth.to_fasta(r, "g%d_%d" % (i, j)) for j, r in enumerate(g)))
+    bases, off = synth.concat_records(recs)
+    d_b = torch.from_numpy(np.concatenate([bases, np.zeros(64, np.uint8)])).cuda()
+    d_o = torch.from_numpy(off.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    want = _keys_want(texts, k, m, s, ab)
+    n_big = 4                                                            # genomes 1, 4, 5 and 8 hold ~14 000 k-mer occurrences or more
+    if ab == 1:
+        assert sum(1 for w in want if len(w[2]) > 8192) >= n_big and sum(1 for w in want if 0 < len(w[2]) < 2048) >= 2
+    assert sum(len(w[2]) for w in want) > 5000
+    for packed in (False, True):
+        p = sp.make_params(k, m, s, abundance=ab, flags=sp.SPSP_SCAN_PACKED_INPUT if packed else 0)
+        src = ctx.pack_bases_device(d_b.data_ptr(), len(bases)) if packed else d_b.data_ptr()
+        d_sk, n_sk = ctx.scan_device(p, src, len(bases), d_o.data_ptr(), len(recs))
+        for un in (False, True):
+            got = ctx.sketch_keys_device(p, src, len(bases), d_o.data_ptr(), d_sk, n_sk, first_rec, unordered=un)
+            assert ctx.sketch_keys_big_genomes() >= n_big
+            _check_keys(ctx, got, want, k, not un, (packed, un))
+    # the keys feed the comparison as they are
+    w_inter, _, _, _ = orc.compare([orc.sketch_fasta(t, k, m, s, ab)[0] for t in texts])
+    d_inter = torch.zeros((len(genomes), len(genomes)), dtype=torch.int32, device="cuda")
+    ctx.compare_keys_unordered(True)
+    torch.cuda.synchronize()
+    ctx.compare_device(k, got[0], got[1], got[2], got[3], len(genomes), 0, 1, d_inter.data_ptr())
+    torch.cuda.synchronize()
+    ctx.compare_keys_unordered(False)
+    assert (np.triu(d_inter.cpu().numpy(), 1) == np.triu(w_inter.astype(np.int64), 1)).all()
+
+
+def test_sketch_keys_survive_the_next_scan(ctx):
+    """The pipelining pattern of bench.py's closed step with genomes beyond the LDS table: the key extraction of scan t is
+    queued, scan t + 1 is queued on the SAME scan context behind spsp_scan_output_wait and rewrites the super-k-mer buffer,
+    and only then is the extraction collected.  Everything the extraction reads of the caller's buffers it reads in the
+    work _begin queued (there is no host path behind _end any more), so the keys are those of scan t."""
+    import torch
+    k, m, s = 31, 11, 20.0
+    rng = np.random.default_rng(123)
+    sets = []
+    for r in range(2):
+        gs = [[synth.random_genome(rng, 300_000)], [synth.random_genome(rng, 40_000)], [synth.random_genome(rng, 200_000), synth.random_genome(rng, 150_000)]]
+        recs = [x for g in gs for x in g]
+        first = np.cumsum([0] + [len(g) for g in gs]).astype(np.uint32)
+        bases, off = synth.concat_records(recs)
+        texts = [b"".join(synth.to_fasta(x, "r%d" % j) for j, x in enumerate(g)) for g in gs]
+        sets.append((torch.from_numpy(np.concatenate([bases, np.zeros(64, np.uint8)])).cuda(), torch.from_numpy(off.view(np.int64)).cuda(), len(bases), len(recs), first, texts))
+    torch.cuda.synchronize()
+    p = sp.make_params(k, m, s)
+    reader = sp.Context(0)
+    try:
+        for un in (True, False):
+            d_b, d_o, nb, nr, first, texts = sets[0]
+            d_sk, n_sk = ctx.scan_device(p, d_b.data_ptr(), nb, d_o.data_ptr(), nr)
+            reader.wait_stream(ctx)
+            reader.sketch_keys_device_begin(p, d_b.data_ptr(), nb, d_o.data_ptr(), d_sk, n_sk, first, unordered=un)
+            ctx.scan_output_wait(reader)
+            d_b2, d_o2, nb2, nr2, _, _ = sets[1]
+            ctx.scan_device(p, d_b2.data_ptr(), nb2, d_o2.data_ptr(), nr2)        # rewrites the buffer the extraction read
+            got = reader.sketch_keys_device_end()
+            assert reader.sketch_keys_big_genomes() == 2
+            _check_keys(reader, got, _keys_want(texts, k, m, s), k, not un, un)
+    finally:
+        reader.close()
+
+
+def test_configs4_shape_record_set_keys_equal_the_oracle(ctx):
+    """BASELINE configs[4]'s shape (k63 m15 s100) at the size of one streamed segment: 60 records of 2 Mbp as ONE genome,
+    ~1.2 x 10^6 selected k-mers -- two hundred times the LDS table -- from the scan to the comparator's keys on the device,
+    equal to the oracle's sketch read back by the oracle's comparator (orc_sketch_keys), sorted form element by element."""
+    import torch
+    k, m, s = 63, 15, 100.0
+    rng = np.random.default_rng(5)
+    recs = [synth.random_genome(rng, 2_000_000) for _ in range(60)]
+    recs[7][:500_000] = recs[3][:500_000]                                # a repeated stretch: k-mers seen twice
+    bases, off = synth.concat_records(recs)
+    text = b"".join(synth.to_fasta(r, "r%d" % j) for j, r in enumerate(recs))
+    want = _keys_want([text], k, m, s)
+    assert len(want[0][2]) > 1_000_000
+    d_b = torch.from_numpy(np.concatenate([bases, np.zeros(64, np.uint8)])).cuda()
+    d_o = torch.from_numpy(off.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    p = sp.make_params(k, m, s)
+    d_sk, n_sk = ctx.scan_device(p, d_b.data_ptr(), len(bases), d_o.data_ptr(), len(recs))
+    for un in (False, True):
+        got = ctx.sketch_keys_device(p, d_b.data_ptr(), len(bases), d_o.data_ptr(), d_sk, n_sk, [0, len(recs)], unordered=un)
+        assert ctx.sketch_keys_big_genomes() == 1
+        _check_keys(ctx, got, want, k, not un, un)
