@@ -1126,33 +1126,76 @@ def scan_config5(ctx, dev, skip_oracle, peak, gbp=4.0):
     return out
 
 
-def compare_config3(ctx, dev, skip_oracle):
-    """BASELINE configs[2]: 1000 RefSeq-like sketches (~5 000 k-mers each, 50 families of 20 at mu 0.001/0.01/0.05,
-    sizes spread over 2-8 k keys), all-vs-all on one GPU, keys resident in HBM.  Genomes are shortened and sampled
-    at s=50 so that a sketch still holds ~L/s keys without generating 5 Gbp (SURVEY.md 8d allows direct synthesis;
-    these go through the real scan + sketch builder so that the oracle can read the same payloads)."""
-    n, k, m, s = 1000, 31, 11, 50.0
-    rng = np.random.default_rng(3)
-    fam = n // 20
-    t0 = time.time()
-    genomes = []
-    for f in range(fam):
-        L = int(rng.integers(100_000, 400_000))
-        anc = synth.random_genome(rng, L)
-        for j in range(n // fam):
-            genomes.append(synth.mutate(rng, anc, [0.001, 0.01, 0.05][j % 3]))
+def config3_true_shape(ctx, dev, n, with_oracle, seed=3, host_threads=None, unordered=False):
+    """BASELINE configs[2] at its TRUE shape (SURVEY.md 8d "C3"): n genomes of L ~ U[2, 8] Mbp in families of 20 at mu
+    0.001 / 0.01 / 0.05, generated on the device batch by batch (synth.device_family_batches), k=31 m=11 s=1000 -- sketched
+    by the HIP path: ONE spsp_scan_device per batch of 100 genomes and spsp_sketch_keys_device from its super-k-mer stream
+    to the comparator's keys, no file and no host code in between.  unordered: the form the pipelined step uses (an LDS
+    table per genome); there a fifth of the genomes (> 6.7 Mbp: more than 6144 k-mer places) take the table in HBM
+    (spsp_bigkeys.hip); the sorted form holds 8192 per genome, which this shape does not reach.  with_oracle: every
+    batch is also copied to the host and sketched by the oracle (Subsampler::parse_fasta_test restated) on `host_threads`
+    threads, one genome per task like the reference's OpenMP loop.  Returns the keys of all n sketches resident on the
+    device, their offsets, the oracle's payloads and the timings."""
+    import concurrent.futures as cf
+    k, m, s = 31, 11, 1000.0
     p = sp.make_params(k, m, s)
-    sketches, payloads = [], []
-    for g in genomes:
-        b, o = synth.concat_records([g])
-        pl, _ = sp.sketch_build(p, s, b, o, ctx.scan(p, b, o))
-        payloads.append(pl)
-        sketches.append(sp.sketch_parse(pl))
-    cnt = np.array([len(x) for x in sketches], dtype=np.int64)
-    d_min = torch.from_numpy(np.concatenate([x.minimizer for x in sketches]).view(np.int32)).to(dev)
-    d_lo = torch.from_numpy(np.concatenate([x.kmer_lo for x in sketches]).view(np.int64)).to(dev)
+    threads = host_threads or max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("BENCH_HOST_THREADS", "16"))))
+    mins, los, cnts, payloads = [], [], [], []
+    scan_ms = keys_ms = oracle_s = 0.0
+    big = bases_total = kmers = 0
+    if with_oracle:
+        from oracle import oracle_py as orc
+        orc.use_native()
+    for B in synth.device_family_batches(n, seed, dev):
+        nb, n_rec = B["n_bases"], len(B["rec_off"]) - 1
+        d_off = torch.from_numpy(B["rec_off"].view(np.int64)).to(dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        d_sk, n_sk = ctx.scan_device(p, B["bases"].data_ptr(), nb, d_off.data_ptr(), n_rec)
+        t1 = time.perf_counter()
+        d_mn, d_lo, _, koff = ctx.sketch_keys_device(p, B["bases"].data_ptr(), nb, d_off.data_ptr(), d_sk, n_sk, B["first_rec"], unordered=unordered)
+        t2 = time.perf_counter()
+        scan_ms += (t1 - t0) * 1e3
+        keys_ms += (t2 - t1) * 1e3
+        big += ctx.sketch_keys_big_genomes()
+        tot = int(koff[-1])
+        mins.append(device_bytes_as_tensor(d_mn, 4 * tot, dev).clone())
+        los.append(device_bytes_as_tensor(d_lo, 8 * tot, dev).clone())
+        cnts.append(np.diff(koff.astype(np.int64)))
+        bases_total += nb
+        kmers += int(sum(max(0, int(B["rec_off"][r + 1] - B["rec_off"][r]) - k + 1) for r in range(n_rec)))
+        if with_oracle:
+            host = B["bases"][:nb].cpu().numpy()
+            ro, fr = B["rec_off"], B["first_rec"]
+
+            def one(g):
+                text = b"".join(b">r%d\n" % r + host[int(ro[r]):int(ro[r + 1])].tobytes() + b"\n" for r in range(int(fr[g]), int(fr[g + 1])))
+                return orc.sketch_fasta(text, k, m, s)[0]
+            t0 = time.perf_counter()
+            with cf.ThreadPoolExecutor(threads) as ex:
+                payloads += list(ex.map(one, range(len(fr) - 1)))
+            oracle_s += time.perf_counter() - t0
+            del host
+        del B
+    cnt = np.concatenate(cnts)
     sk_off = np.zeros(n + 1, np.uint64)
     sk_off[1:] = np.cumsum(cnt)
+    return {"k": k, "m": m, "s": s, "d_min": torch.cat(mins).view(torch.int32), "d_lo": torch.cat(los).view(torch.int64), "sk_off": sk_off, "cnt": cnt,
+            "payloads": payloads if with_oracle else None, "big_genomes": big, "bases": bases_total, "kmers": kmers,
+            "scan_ms": scan_ms, "keys_ms": keys_ms, "oracle_sketch_s": oracle_s, "oracle_threads": threads}
+
+
+def compare_config3(ctx, dev, skip_oracle):
+    """BASELINE configs[2] at its true shape: 1000 RefSeq-like genomes, L ~ U[2, 8] Mbp, 50 families of 20 at mu
+    0.001 / 0.01 / 0.05, k=31 m=11 s=1000 (config3_true_shape: 5 Gbp generated on the device and sketched by the HIP path),
+    all-vs-all on one GPU, keys resident in HBM; every pair and every cardinality against the oracle, which sketches the
+    same genomes on the host threads and compares them on one."""
+    n = 1000
+    t0 = time.time()
+    T = config3_true_shape(ctx, dev, n, not skip_oracle, unordered=True)
+    ctx.compare_keys_unordered(True)
+    k, m, s = T["k"], T["m"], T["s"]
+    d_min, d_lo, sk_off, cnt, payloads = T["d_min"], T["d_lo"], T["sk_off"], T["cnt"], T["payloads"]
     d_inter = torch.zeros((n, n), dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
     setup_s = time.time() - t0
@@ -1174,8 +1217,14 @@ def compare_config3(ctx, dev, skip_oracle):
     total = int(cnt.sum())
     no_reuse = 8.0 * total * (n - 1) + 4.0 * pairs           # sum over pairs of 8 (n_i + n_j) + 4
     compulsory = 8.0 * total + 4.0 * pairs
-    out = {"workload": "BASELINE configs[2]: %d sketches, %d keys (mean %.0f, min %d, max %d), 50 families x 20, k=31 m=11; "
-                       "keys resident in HBM" % (n, total, cnt.mean(), cnt.min(), cnt.max()),
+    out = {"workload": "BASELINE configs[2] at its true shape: %d genomes of L ~ U[2, 8] Mbp (%.2f Gbp, 50 families x 20, mu 0.001/0.01/0.05) generated "
+                       "on the device, k=31 m=11 s=1000, sketched by the HIP path (scan + keys on the device, %d genomes beyond the per-genome "
+                       "LDS table through the table in HBM); %d keys (mean %.0f, min %d, max %d); keys resident in HBM"
+                       % (n, T["bases"] / 1e9, T["big_genomes"], total, cnt.mean(), cnt.min(), cnt.max()),
+           "sketching": {"what": "per batch of 100 genomes: ONE spsp_scan_device + ONE spsp_sketch_keys_device (SPSP_KEYS_UNORDERED, the form of the timed step), host wall ms summed over the 10 batches",
+                         "scan_ms": T["scan_ms"], "sketch_keys_ms": T["keys_ms"], "kmers": T["kmers"], "kmers_per_s": T["kmers"] / ((T["scan_ms"] + T["keys_ms"]) / 1e3),
+                         "genomes_through_the_table_in_hbm": T["big_genomes"],
+                         **({"oracle_sketch_s": T["oracle_sketch_s"], "oracle_threads": T["oracle_threads"]} if payloads is not None else {})},
            "pairs": pairs, "pipeline_ms": ms, "host_wall_ms_per_call": wall_ms,
            "sketch_pairs_per_s": pairs / (ms / 1e3) if ms > 0 else None,
            "kernel_ms": {"k_parts_scatter": t["scatter_ms"] / max(1, t["scatter_launches"]),
@@ -1190,6 +1239,7 @@ def compare_config3(ctx, dev, skip_oracle):
                                              "model": "8 sum(n_i) + 4 N(N-1)/2 bytes: every key read once, every cell written once"}},
            "setup_s": setup_s}
     out["roofline"].update(pmc_compare("r03_compare_pmc_hbm_traffic.json", total))
+    ctx.compare_keys_unordered(False)
     if not skip_oracle:
         from oracle import oracle_py as orc
         want, card, sec = orc.compare(payloads, timed=True)

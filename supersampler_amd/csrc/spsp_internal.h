@@ -69,6 +69,14 @@ struct ScanJob {
     uint64_t rows_per_wave = 0;
 };
 struct CompareJob;   // spsp_compare.hip
+// the key extraction queued by sketch_keys_begin_impl: what its last stages need when _end has to queue them (spsp_keys.hip)
+struct KeysJob {
+    bool has_hi = false, sorted = false;
+    uint32_t n_genomes = 0;
+    uint64_t bound = 0;          // k-mer places of all genomes together (the extent of the staging arrays)
+    uint32_t abundance = 1;
+    bool big_queued = false;     // the table kernels for genomes beyond the LDS forms were queued by _begin
+};
 }  // namespace spsp
 
 struct spsp_ctx {
@@ -106,6 +114,8 @@ struct spsp_ctx {
     bool keys_unordered = false;       // spsp_compare_keys_unordered: the comparisons of this context do not insist on sorted sketches
     uint32_t keys_genomes = 0;
     bool keys_sorted = false;          // the pending extraction promised sorted sketches (its big genomes are sorted in _end)
+    spsp::KeysJob keys_job;
+    bool keys_expect_big = false;      // the last extraction collected on this context met a genome beyond the LDS forms
     uint32_t keys_big_genomes = 0;     // genomes of the last collected extraction that went through the global-memory stages (spsp_bigkeys.hip)
     hipEvent_t keys_done = nullptr;
     uint32_t* h_keys = nullptr;        // pinned: genome record ranges in, key offsets + overflow report out

@@ -188,6 +188,33 @@ __device__ __forceinline__ uint64_t keys_mix(uint64_t x) {
     x ^= x >> 27; x *= 0x94d049bb133111ebULL;
     return x ^ (x >> 31);
 }
+// One super-k-mer's k-mer places as raw records (minimizer | orientation << 31, canonical k-mer) for the table in HBM of
+// spsp_bigkeys.hip: place0 + j = k-mer j, 0xffffffff where the super-k-mer has fewer than w.  Rolled base by base from
+// global memory: only the genomes that do not fit a workgroup's LDS come this way.
+__device__ __noinline__ void roll_places(const uint8_t* __restrict__ bases, bool packed, const uint64_t* __restrict__ rec_off, const spsp_superkmer e,
+                                         uint32_t k, uint32_t w, uint32_t place0, uint32_t* __restrict__ r_mn, uint64_t* __restrict__ r_lo,
+                                         uint64_t* __restrict__ r_hi) {
+    const uint64_t src = rec_off[e.rec] + e.start;
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(bases);
+    const u128d mask = k == 64 ? ~(u128d)0 : (((u128d)1 << (2 * k)) - 1);
+    u128d fwd = 0, rc = 0;
+    uint32_t made = 0;
+    for (uint32_t t = 0; t < e.len && made < w; ++t) {
+        const uint64_t b = src + t;
+        const uint32_t c = packed ? (words[b >> 4] >> (30u - 2u * (uint32_t)(b & 15u))) & 3u : ((uint32_t)bases[b] >> 1) & 3u;
+        fwd = ((fwd << 2) | c) & mask;
+        rc = (rc >> 2) | ((u128d)(c ^ 2u) << (2 * (k - 1)));
+        if (t + 1 < k) continue;
+        const u128d canon = fwd < rc ? fwd : rc;                   // (orientation as in k_keys_emit)
+        const u128d oriented = e.rev ? rc : fwd;
+        r_mn[place0 + made] = e.minimizer | (oriented != canon ? 0x80000000u : 0u);
+        r_lo[place0 + made] = (uint64_t)canon;
+        if (r_hi) r_hi[place0 + made] = (uint64_t)(canon >> 64);
+        ++made;
+    }
+    for (; made < w; ++made) r_mn[place0 + made] = 0xffffffffu;
+}
+
 template <bool HAS_HI>
 __global__ __launch_bounds__(kKeySortThreads) void k_keys_fused(const uint8_t* __restrict__ bases, bool packed, uint64_t n_bases_readable,
                                                                const uint64_t* __restrict__ rec_off,
@@ -238,9 +265,15 @@ __global__ __launch_bounds__(kKeySortThreads) void k_keys_fused(const uint8_t* _
     const bool too_big = n > FULL || q1 - q0 > SKM_MAX;
     if (t == 0) { raw_off[seg] = r0; raw_cnt[seg] = n; big[seg] = too_big ? 1u : 0u; s_count = 0; }
     if (n == 0) { if (t == 0) distinct[seg] = 0; return; }
-    // more k-mer places (or super-k-mers) than this workgroup's LDS holds: k_keys_big_roll and the global-memory table
-    // behind it (spsp_bigkeys.hip) take the genome; flags[0] is their gate, flags[1] counts such genomes for the report
-    if (too_big) { if (t == 0) { distinct[seg] = 0; atomicOr(&flags[0], 1u); atomicAdd(&flags[1], 1u); } return; }
+    // more k-mer places (or super-k-mers) than this workgroup's LDS holds: the table in HBM (spsp_bigkeys.hip) takes the
+    // genome.  Its raw records are written here, into the genome's slice of the context's staging arrays, so that those
+    // stages read nothing of the caller's -- they may be queued right behind this kernel or, the first time a context
+    // meets such a genome, from _end.  flags[0] is their gate, flags[1] counts such genomes for the report.
+    if (too_big) {
+        if (t == 0) { distinct[seg] = 0; atomicOr(&flags[0], 1u); atomicAdd(&flags[1], 1u); }
+        for (uint32_t q = q0 + t; q < q1; q += kKeySortThreads) roll_places(bases, packed, rec_off, sk[q], k, w, q * w, r_mn, r_lo, HAS_HI ? r_hi : nullptr);
+        return;
+    }
     for (uint32_t x = t; x < SLOTS; x += kKeySortThreads) slot[x] = 0;
     {
         const uint32_t* gw = reinterpret_cast<const uint32_t*>(bases);
@@ -385,44 +418,6 @@ __global__ __launch_bounds__(kKeySortThreads) void k_keys_fused(const uint8_t* _
     if (t == 0) distinct[seg] = base;
 }
 
-// The genomes k_keys_fused flagged: their k-mer places as raw records (minimizer | orientation << 31, canonical k-mer) in the
-// genome's slice of the staging arrays -- place q w + j = k-mer j of super-k-mer q, 0xffffffff where a super-k-mer has fewer
-// than w -- for the global-memory table of spsp_bigkeys.hip.  One lane per super-k-mer, launched over all of them; every
-// workgroup leaves at once when nothing was flagged (flags[0], the gate).
-__global__ __launch_bounds__(256) void k_keys_big_roll(const uint8_t* __restrict__ bases, bool packed, const uint64_t* __restrict__ rec_off,
-                                                      const spsp_superkmer* __restrict__ sk, uint32_t n_sk, uint32_t k, uint32_t w,
-                                                      const uint32_t* __restrict__ raw_off, const uint32_t* __restrict__ raw_cnt,
-                                                      const uint32_t* __restrict__ big, uint32_t n_genomes, const uint32_t* __restrict__ gate,
-                                                      uint32_t* __restrict__ r_mn, uint64_t* __restrict__ r_lo, uint64_t* __restrict__ r_hi) {
-    if (*gate == 0) return;
-    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= n_sk) return;
-    const uint32_t place0 = q * w;
-    uint32_t lo_g = 0, hi_g = n_genomes;                           // the last genome whose slice starts at or before this place
-    while (hi_g - lo_g > 1) { const uint32_t mid = (lo_g + hi_g) >> 1; if (raw_off[mid] <= place0) lo_g = mid; else hi_g = mid; }
-    if (!big[lo_g] || place0 - raw_off[lo_g] >= raw_cnt[lo_g]) return;
-    const spsp_superkmer e = sk[q];
-    const uint64_t src = rec_off[e.rec] + e.start;
-    const uint32_t* words = reinterpret_cast<const uint32_t*>(bases);
-    const u128d mask = k == 64 ? ~(u128d)0 : (((u128d)1 << (2 * k)) - 1);
-    u128d fwd = 0, rc = 0;
-    uint32_t made = 0;
-    for (uint32_t t = 0; t < e.len && made < w; ++t) {
-        const uint64_t b = src + t;
-        const uint32_t c = packed ? (words[b >> 4] >> (30u - 2u * (uint32_t)(b & 15u))) & 3u : ((uint32_t)bases[b] >> 1) & 3u;
-        fwd = ((fwd << 2) | c) & mask;
-        rc = (rc >> 2) | ((u128d)(c ^ 2u) << (2 * (k - 1)));
-        if (t + 1 < k) continue;
-        const u128d canon = fwd < rc ? fwd : rc;                   // (orientation as in k_keys_emit)
-        const u128d oriented = e.rev ? rc : fwd;
-        r_mn[place0 + made] = e.minimizer | (oriented != canon ? 0x80000000u : 0u);
-        r_lo[place0 + made] = (uint64_t)canon;
-        if (r_hi) r_hi[place0 + made] = (uint64_t)(canon >> 64);
-        ++made;
-    }
-    for (; made < w; ++made) r_mn[place0 + made] = 0xffffffffu;
-}
-
 // genomes back to back: a genome's distinct keys lie at the start of its slice of the staging arrays -- (r_*) for the
 // LDS forms, (b_*) for a genome the global-memory stages took
 __global__ __launch_bounds__(256) void k_keys_compact(const uint32_t* __restrict__ r_mn, const uint64_t* __restrict__ r_lo,
@@ -461,10 +456,40 @@ __global__ __launch_bounds__(256) void k_keys_compact(const uint32_t* __restrict
         host_out[g] = o0;
         host_out[n_genomes + 2 + g] = from_b ? 1u : 0u;
         if (g == n_genomes - 1) {
-            host_out[n_genomes] = o0 + n; host_out[n_genomes + 1] = flags[1];
+            host_out[n_genomes] = o0 + n;
+            // (zeroed by the host at _begin; a second run queued from _end finds the word reported and cleared: it stays)
+            if (flags[1]) host_out[n_genomes + 1] = flags[1];
             flags[0] = 0; flags[1] = 0;                         // for the next extraction on this context (every reader of this one has finished)
         }
     }
+}
+
+// [the table in HBM for the flagged genomes] -> [offsets, sorted form] -> compaction, on the context's stream.  with_big:
+// queue k_big_insert / k_big_emit (gate: a device word that is zero when no genome was flagged, or nullptr = run).
+static int keys_finish_queue(spsp_ctx* ctx, bool with_big, const uint32_t* d_gate) {
+    const KeysJob& J = ctx->keys_job;
+    const uint32_t ng = J.n_genomes;
+    uint32_t* d_first_rec = ctx->dc_meta.as<uint32_t>();
+    uint32_t* d_raw_off = d_first_rec + (ng + 2);
+    uint32_t* d_distinct = d_raw_off + (ng + 2);
+    uint32_t* d_out_off = d_distinct + (ng + 2);
+    uint32_t* d_raw_cnt = d_out_off + (ng + 2);
+    uint32_t* d_big = d_raw_cnt + (ng + 2);
+    uint32_t* d_flags = ctx->c_flags.as<uint32_t>() + 12;
+    uint32_t* h_out = ctx->h_keys + (ng + 1);
+    uint32_t* a_mn = ctx->a_mn.as<uint32_t>();
+    uint64_t *a_lo = ctx->a_lo.as<uint64_t>(), *a_hi = J.has_hi ? ctx->a_hi.as<uint64_t>() : (uint64_t*)nullptr;
+    uint32_t* b_mn = ctx->b_mn.as<uint32_t>();
+    uint64_t *b_lo = ctx->b_lo.as<uint64_t>(), *b_hi = J.has_hi ? ctx->b_hi.as<uint64_t>() : (uint64_t*)nullptr;
+    int rc;
+    if (with_big && J.bound &&
+        (rc = big_dedupe_launch(ctx, J.has_hi, a_mn, a_lo, a_hi, d_raw_off, d_raw_cnt, d_big, ng, J.bound, d_gate, J.abundance, b_mn, b_lo, b_hi, d_distinct))) return rc;
+    if (J.sorted && (rc = launch_scan_u32(ctx, d_distinct, d_out_off, ng, ctx->h_scalar + 7))) return rc;
+    hipLaunchKernelGGL(k_keys_compact, dim3(8, ng), dim3(256), 0, ctx->stream, a_mn, a_lo, a_hi, b_mn, b_lo, b_hi, d_raw_off, d_distinct, d_big,
+                       J.sorted ? (const uint32_t*)d_out_off : (const uint32_t*)nullptr, ctx->c_min.as<uint32_t>(), ctx->c_lo.as<uint64_t>(),
+                       J.has_hi ? ctx->c_hi.as<uint64_t>() : (uint64_t*)nullptr, ng, d_flags, h_out);
+    SPSP_HIP(hipGetLastError());
+    return SPSP_OK;
 }
 
 int sketch_keys_begin_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, bool packed, const uint64_t* d_rec_off,
@@ -492,7 +517,7 @@ int sketch_keys_begin_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d
         ctx->h_keys_cap = cap;
     }
     memcpy(ctx->h_keys, h_first_rec, (size_t)(n_genomes + 1) * 4);
-    uint32_t* h_out = ctx->h_keys + (n_genomes + 1);
+    ctx->h_keys[(n_genomes + 1) + (n_genomes + 1)] = 0;            // "genomes beyond the LDS forms": written by the compaction only when there are any
     // a_*: the LDS forms' staging (raw records in, a genome's distinct keys out, slice by slice); b_*: the output slices of
     // the genomes the global-memory stages take; c_*: the keys of all genomes back to back (what the comparison reads)
     if ((rc = ctx->a_cnt.reserve((size_t)(n + 1) * 4)) || (rc = ctx->a_off.reserve((size_t)(n + 2) * 4)) ||
@@ -525,10 +550,7 @@ int sketch_keys_begin_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d
     const uint32_t ab = p->k == p->m ? 0u : (p->abundance ? p->abundance : 1u);
     uint32_t* a_mn = ctx->a_mn.as<uint32_t>();
     uint64_t *a_lo = ctx->a_lo.as<uint64_t>(), *a_hi = has_hi ? ctx->a_hi.as<uint64_t>() : (uint64_t*)nullptr;
-    uint32_t* b_mn = ctx->b_mn.as<uint32_t>();
-    uint64_t *b_lo = ctx->b_lo.as<uint64_t>(), *b_hi = has_hi ? ctx->b_hi.as<uint64_t>() : (uint64_t*)nullptr;
-    uint32_t* c_mn = ctx->c_min.as<uint32_t>();
-    uint64_t *c_lo = ctx->c_lo.as<uint64_t>(), *c_hi = has_hi ? ctx->c_hi.as<uint64_t>() : (uint64_t*)nullptr;
+    ctx->keys_job = KeysJob{has_hi, !unordered, n_genomes, bound, ab, false};
     if (unordered) {
         const size_t lds_d = (has_hi ? (size_t)kDedupCapHi * 28 : (size_t)kDedupCapLo * 20) + kDedupSkmWords * 4;
         if (!ctx->attr_dedupe_set) {
@@ -540,16 +562,6 @@ int sketch_keys_begin_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d
                                        d_sk, n, d_first_rec, p->k, w, ab, a_mn, a_lo, a_hi, d_raw_off, d_distinct, d_raw_cnt, d_big, d_flags);
         else hipLaunchKernelGGL((k_keys_fused<false>), dim3(n_genomes), dim3(kKeySortThreads), lds_d, ctx->stream, d_bases, packed, n_bases_readable, d_rec_off,
                                 d_sk, n, d_first_rec, p->k, w, ab, a_mn, a_lo, a_hi, d_raw_off, d_distinct, d_raw_cnt, d_big, d_flags);
-        SPSP_HIP(hipGetLastError());
-        if (n) {
-            // genomes beyond the LDS table (none at the bench's 5 Mbp and s = 1000: three launches whose workgroups read the gate and leave)
-            hipLaunchKernelGGL(k_keys_big_roll, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_bases, packed, d_rec_off, d_sk, n, p->k, w,
-                               (const uint32_t*)d_raw_off, (const uint32_t*)d_raw_cnt, (const uint32_t*)d_big, n_genomes, (const uint32_t*)d_flags, a_mn, a_lo, a_hi);
-            SPSP_HIP(hipGetLastError());
-            if ((rc = big_dedupe_launch(ctx, has_hi, a_mn, a_lo, a_hi, d_raw_off, d_raw_cnt, d_big, n_genomes, bound, d_flags, ab, b_mn, b_lo, b_hi, d_distinct))) return rc;
-        }
-        hipLaunchKernelGGL(k_keys_compact, dim3(8, n_genomes), dim3(256), 0, ctx->stream, a_mn, a_lo, a_hi, b_mn, b_lo, b_hi, d_raw_off, d_distinct, d_big,
-                           (const uint32_t*)nullptr, c_mn, c_lo, c_hi, n_genomes, d_flags, h_out);
         SPSP_HIP(hipGetLastError());
     } else {
         if (n) {
@@ -574,14 +586,15 @@ int sketch_keys_begin_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d
         if (has_hi) hipLaunchKernelGGL(k_keys_sort<true>, dim3(n_genomes), dim3(kKeySortThreads), lds, ctx->stream, a_mn, a_lo, a_hi, d_raw_off, ab, d_distinct, d_raw_cnt, d_big, d_flags);
         else hipLaunchKernelGGL(k_keys_sort<false>, dim3(n_genomes), dim3(kKeySortThreads), lds, ctx->stream, a_mn, a_lo, (uint64_t*)nullptr, d_raw_off, ab, d_distinct, d_raw_cnt, d_big, d_flags);
         SPSP_HIP(hipGetLastError());
-        // a genome beyond the LDS sort: its raw records are where k_keys_emit left them -- the global-memory table makes its
-        // distinct keys (in no order: _end sorts them where the compaction puts them)
-        if (n && (rc = big_dedupe_launch(ctx, has_hi, a_mn, a_lo, a_hi, d_raw_off, d_raw_cnt, d_big, n_genomes, bound, d_flags, ab, b_mn, b_lo, b_hi, d_distinct))) return rc;
-        if ((rc = launch_scan_u32(ctx, d_distinct, d_out_off, n_genomes, ctx->h_scalar + 7))) return rc;
-        hipLaunchKernelGGL(k_keys_compact, dim3(8, n_genomes), dim3(256), 0, ctx->stream, a_mn, a_lo, a_hi, b_mn, b_lo, b_hi, d_raw_off, d_distinct, d_big,
-                           (const uint32_t*)d_out_off, c_mn, c_lo, c_hi, n_genomes, d_flags, h_out);
-        SPSP_HIP(hipGetLastError());
     }
+    // Behind the LDS kernel: the table in HBM for the genomes it flagged (their raw records lie in the staging arrays, in
+    // both forms), then the compaction.  A context whose last extraction met no such genome leaves the two table kernels
+    // out -- a key extraction per 0.1 ms step pays for every launch on its stream -- and runs them from _end in the call
+    // that does meet one; from then on they are queued here, behind a gate word that lets them leave at once.
+    static const char* force = getenv("SPSP_DEBUG_KEYS_BIG");      // test hook: "early" / "late" pins the choice
+    const bool early = force ? force[0] == 'e' : ctx->keys_expect_big;
+    if ((rc = keys_finish_queue(ctx, early, early ? d_flags : nullptr))) return rc;
+    ctx->keys_job.big_queued = early;
     if (!ctx->keys_done) SPSP_HIP(hipEventCreateWithFlags(&ctx->keys_done, hipEventDisableTiming));
     SPSP_HIP(hipEventRecord(ctx->keys_done, ctx->stream));
     ctx->keys_pending = true;
@@ -598,13 +611,20 @@ int sketch_keys_end_impl(spsp_ctx* ctx, void** d_mn, void** d_lo, void** d_hi, u
     SPSP_HIP(hipEventSynchronize(ctx->keys_done));
     const uint32_t n_genomes = ctx->keys_genomes;
     const uint32_t* h_out = ctx->h_keys + (n_genomes + 1);
-    for (uint32_t g = 0; g <= n_genomes; ++g) sk_off[g] = h_out[g];
     ctx->keys_big_genomes = h_out[n_genomes + 1];
+    if (ctx->keys_big_genomes && !ctx->keys_job.big_queued) {
+        // the first extraction of this context that meets a genome beyond the LDS forms: the table kernels were not queued.
+        // Everything they read is the context's own (raw records, segment tables): the caller's inputs are not touched.
+        int rc = keys_finish_queue(ctx, true, nullptr);
+        if (rc) return rc;
+        SPSP_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    ctx->keys_expect_big = ctx->keys_big_genomes != 0;
+    for (uint32_t g = 0; g <= n_genomes; ++g) sk_off[g] = h_out[g];
     *d_mn = ctx->c_min.p; *d_lo = ctx->c_lo.p; *d_hi = ctx->keys_has_hi ? ctx->c_hi.p : nullptr;
     if (ctx->keys_sorted && ctx->keys_big_genomes) {
-        // the sorted form promises sorted sketches: the keys of the genomes the global-memory stages took are distinct and
-        // in place, in no order.  Sizes are known here, so this is the one part of the job that is queued from _end -- it
-        // reads and writes context-owned buffers only (the caller's inputs were last read by the work queued in _begin).
+        // the sorted form promises sorted sketches: the keys of the genomes the table took are distinct and in place, in no
+        // order.  Sizes are known here, so the merge sort is queued from _end -- over context-owned buffers only.
         std::vector<std::pair<uint32_t, uint32_t>> segs;
         for (uint32_t g = 0; g < n_genomes; ++g)
             if (h_out[n_genomes + 2 + g]) segs.emplace_back(h_out[g], h_out[g + 1] - h_out[g]);

@@ -175,3 +175,46 @@ def direct_family_sketches(n, fam_size=20, k=31, m=11, seed=4, device="cpu", skm
     skm_off_np[1:] = np.cumsum(h_sk.cpu().numpy())
     return DirectSketches(k, m, (key_hi & 0xffffffff).to(torch.int32).contiguous(), lo.contiguous(), sk_off, universe, skm_off_np,
                           bucket, flank)
+
+
+def device_family_batches(n_genomes, seed, device, fam_size=20, len_range=(2_000_000, 8_000_000), mus=(0.001, 0.01, 0.05),
+                          genomes_per_batch=100):
+    """BASELINE configs[2]'s true shape (SURVEY.md 8d "C3": N genomes, L ~ U[2, 8] Mbp, families of 20, mu in
+    {0.001, 0.01, 0.05}), generated ON THE DEVICE batch by batch so that 5 Gbp never exist on the host: a family's ancestor
+    is uniform i.i.d. ACGT of a length drawn per family, member j is the ancestor under independent substitutions at
+    mus[j % len(mus)] (always to a different base); genome i has 1 + i % 3 records.  Yields per batch a dict with
+    `bases` (uint8 torch tensor on `device`: cleaned ASCII records back to back + 64 bytes of padding), `rec_off` (np.uint64,
+    records + 1), `first_rec` (np.uint32, genomes + 1: genome g = records [first_rec[g], first_rec[g + 1])), `lengths`
+    and `first_genome`.  torch is plumbing here (device memory + the random generator), as in bench.py."""
+    import torch
+    assert genomes_per_batch % fam_size == 0 and n_genomes % fam_size == 0
+    gen = torch.Generator(device=device)
+    gen.manual_seed(int(seed))
+    host_rng = np.random.default_rng(seed)
+    lut = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device=device)
+    for g0 in range(0, n_genomes, genomes_per_batch):
+        nb = min(genomes_per_batch, n_genomes - g0)
+        fams = nb // fam_size
+        lens = [int(host_rng.integers(len_range[0], len_range[1] + 1)) for _ in range(fams)]
+        total = sum(L * fam_size for L in lens)
+        bases = torch.empty(total + 64, dtype=torch.uint8, device=device)
+        bases[total:] = 65
+        rec_off, first_rec, lengths = [0], [0], []
+        at = 0
+        for f, L in enumerate(lens):
+            anc = torch.randint(0, 4, (L,), device=device, generator=gen, dtype=torch.int64)
+            for j in range(fam_size):
+                mu = mus[j % len(mus)]
+                hit = torch.rand(L, device=device, generator=gen) < mu
+                shift = torch.randint(1, 4, (L,), device=device, generator=gen, dtype=torch.int64)
+                bases[at:at + L] = lut[(anc + hit * shift) % 4]
+                i = g0 + f * fam_size + j
+                nr = 1 + i % 3
+                for r in range(nr):
+                    rec_off.append(at + L * (r + 1) // nr)
+                first_rec.append(len(rec_off) - 1)
+                lengths.append(L)
+                at += L
+            del anc
+        yield {"bases": bases, "n_bases": total, "rec_off": np.asarray(rec_off, dtype=np.uint64), "first_rec": np.asarray(first_rec, dtype=np.uint32),
+               "lengths": lengths, "first_genome": g0}

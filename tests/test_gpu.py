@@ -1274,3 +1274,104 @@ def test_configs4_shape_record_set_keys_equal_the_oracle(ctx):
         got = ctx.sketch_keys_device(p, d_b.data_ptr(), len(bases), d_o.data_ptr(), d_sk, n_sk, [0, len(recs)], unordered=un)
         assert ctx.sketch_keys_big_genomes() == 1
         _check_keys(ctx, got, want, k, not un, un)
+
+
+def test_config1_single_genome_sketch_and_self_compare(ctx, tmp_path):
+    """BASELINE configs[0]: ONE 4 641 652-bp genome (the E. coli K-12 length stand-in of SURVEY.md 8d "C1", seed 1, three
+    records), k31 m11 s1000 by default flags: `sub_sampler -i` writes the oracle's payload bytes and prints print_stat's
+    numbers (SubSampler.cpp:306-510, 633-665, 749-760); `comparator -f` on that ONE sketch takes the single-file route of
+    the merge -- every bucket goes through skip_bucket (Comparator.cpp:60-63) -- and prints the two 1 x 1 matrices
+    (:362-460); spsp_compare with n = 1, host and device forms."""
+    import torch
+    k, m, s = 31, 11, 1000
+    g = synth.random_genome(np.random.default_rng(1), 4_641_652)
+    text = synth.to_fasta(g, "ecoli_stand_in", n_records=3)
+    (tmp_path / "ecoli.fa").write_bytes(text)
+    r = subprocess.run([os.path.join(ROOT, "bin", "sub_sampler"), "-i", "ecoli.fa"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    want, st = orc.sketch_fasta(text, k, m, float(np.float32(s)))
+    got = gzip.open(tmp_path / "subsampled_ecoli.gz", "rb").read()
+    assert got == want
+    assert 3_000 < st["selected_kmer_number"] < 7_000
+    out = r.stdout
+    assert out.startswith(" I use k=31 m=11 s=1000\nMaximal super kmer are of length 51 or 21 kmers\n")
+    assert not (tmp_path / "subsampled_ecoli.txt").exists()            # -i writes no list of sketches (SubSampler.cpp:749-760)
+    at = 0
+    for line in ["I have seen %s kmers and I selected %s kmers" % (_fmt_commas(st["total_kmer_number"]), _fmt_commas(st["selected_kmer_number"])),
+                 "After removing duplicate kmers, I selected %s kmers" % _fmt_commas(st["seen_kmers_at_reconstruction"]),
+                 "I have seen %s superkmers and I selected %s superkmers" % (_fmt_commas(st["total_superkmer_number"]), _fmt_commas(st["selected_superkmer_number"])),
+                 "After reconstruction and filtering with abundance, I have selected %s superkmers" % _fmt_commas(st["seen_superkmers_at_reconstruction"]),
+                 "Minimizer number: %s Skmer/minimizer:  " % _fmt_commas(st["actual_minimizer_number"]),
+                 "Number of maximal skmer was:       %s" % _fmt_commas(st["count_maximal_skmer"]),
+                 "Actual number of maximal skmer is: %s" % _fmt_commas(st["seen_max_superkmers_at_reconstruction"])]:
+        nxt = out.find(line, at)
+        assert nxt >= 0, (line, out[at:at + 400])
+        at = nxt + len(line)
+    (tmp_path / "one.txt").write_text("subsampled_ecoli.gz\n")
+    r = subprocess.run([os.path.join(ROOT, "bin", "comparator"), "-f", "one.txt", "-o", "self"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.split("\n")[1] == "I found 1 documents"
+    inter, card, _, _ = orc.compare([want])
+    assert inter.shape == (1, 1) and int(card[0]) == len(orc.sketch_keys(want)[2]) > 3_000
+    for jac, fn in ((True, "self_jaccard.csv.gz"), (False, "self_containment.csv.gz")):
+        assert gzip.open(tmp_path / fn, "rb").read() == orc.csv(jac, ["subsampled_ecoli.gz"], inter, card, None, 6, 0.0)
+    # n = 1 through the C-ABI: host form, device form, and the device keys of the one genome
+    sk = sp.sketches_from_payloads([got])
+    i1, c1 = ctx.compare(sk)
+    assert i1.shape == (1, 1) and int(i1[0, 0]) == 0 and int(c1[0]) == int(card[0])
+    bases, off = sp.clean_fasta(text)
+    d_b = torch.from_numpy(np.concatenate([bases, np.zeros(64, np.uint8)])).cuda()
+    d_o = torch.from_numpy(off.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    p = sp.make_params(k, m, float(s))
+    d_sk, n_sk = ctx.scan_device(p, d_b.data_ptr(), len(bases), d_o.data_ptr(), len(off) - 1)
+    d_mn, d_lo, d_hi, koff = ctx.sketch_keys_device(p, d_b.data_ptr(), len(bases), d_o.data_ptr(), d_sk, n_sk, [0, len(off) - 1])
+    assert int(koff[1]) == int(card[0])
+    assert (ctx.to_host(d_mn, int(koff[1]), np.uint32) == sk[0].minimizer).all() and (ctx.to_host(d_lo, int(koff[1]), np.uint64) == sk[0].kmer_lo).all()
+    d_inter = torch.full((1, 1), 7, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    ctx.compare_device(k, d_mn, d_lo, None, koff, 1, 0, 1, d_inter.data_ptr())
+    torch.cuda.synchronize()
+    assert int(d_inter[0, 0].item()) == 7                                # a 1 x 1 problem has no cell (i, j > i): nothing is written
+
+
+def test_config3_true_shape_sketched_on_device_equals_oracle(ctx):
+    """BASELINE configs[2] at its TRUE shape, reduced count (bench.py's `compare` leg runs all 1000): 60 genomes of
+    L ~ U[2, 8] Mbp in 3 families of 20 at mu 0.001 / 0.01 / 0.05, generated on the device, k31 m11 s1000 -- ~100 minimizer
+    buckets shared by every genome, ~L / 1000 keys per sketch, a third of the genomes beyond the per-genome LDS table.
+    Sketched by the HIP path (one scan + one key extraction per batch, no file, no host path), all pairs and every
+    cardinality against the oracle's sketcher + comparator over the same bases."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    n = 60
+    dev = torch.device("cuda", 0)
+    want = card = None
+    for un in (False, True):
+        T = bench.config3_true_shape(ctx, dev, n, want is None, seed=3, unordered=un)
+        # unordered form: genomes above ~6.7 Mbp hold more than its 6144 k-mer places -> the table in HBM; the sorted form's 8192 are not reached
+        assert (T["big_genomes"] >= 5) if un else (T["big_genomes"] == 0)
+        assert 2_000 * n < int(T["sk_off"][-1]) < 8_000 * n
+        d_inter = torch.zeros((n, n), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        ctx.compare_keys_unordered(un)
+        ctx.compare_device(T["k"], T["d_min"].data_ptr(), T["d_lo"].data_ptr(), None, T["sk_off"], n, 0, 1, d_inter.data_ptr())
+        torch.cuda.synchronize()
+        ctx.compare_keys_unordered(False)
+        if want is None:
+            payloads = T["payloads"]
+            want, card, _, _ = orc.compare(payloads)
+        assert (np.triu(d_inter.cpu().numpy().astype(np.uint32), 1) == np.triu(want, 1)).all(), un
+        assert (card.astype(np.int64) == T["cnt"]).all(), un
+        assert int(np.count_nonzero(np.triu(want, 1))) >= 3 * 190        # every pair inside a family shares k-mers
+        # the same keys, genome by genome, as the oracle's comparator enumerates them from the oracle's sketch files
+        mn = T["d_min"].cpu().numpy().view(np.uint32)
+        lo = T["d_lo"].cpu().numpy().view(np.uint64)
+        for g in (0, 7, 23, 41, 59):
+            _, _, w_mn, w_lo, _ = orc.sketch_keys(payloads[g])
+            a, b = int(T["sk_off"][g]), int(T["sk_off"][g + 1])
+            x, y = mn[a:b], lo[a:b]
+            if un:
+                o = np.lexsort((y, x))
+                x, y = x[o], y[o]
+            assert (x == w_mn).all() and (y == w_lo).all(), (un, g)
