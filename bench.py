@@ -1109,6 +1109,26 @@ def scan_config5(ctx, dev, skip_oracle, peak, gbp=4.0):
                                                  "scaled_from_bases_per_launch": d["workload"]["bases_per_launch"]}
     except Exception:  # noqa: BLE001
         out["roofline"]["traffic"] = None
+    # From the scan to the comparator's keys: the segment as ONE sketch -- a metagenome file is one
+    # sketch -- through spsp_sketch_keys_device: ~4 x 10^7 selected k-mers, four orders of magnitude beyond a workgroup's LDS:
+    # the table in HBM of spsp_bigkeys.hip (and, in the sorted form, its merge sort).  Host wall clock around the call.
+    try:
+        one = np.array([0, n_rec], dtype=np.uint32)
+        res = {}
+        for name, un in (("unordered", True), ("sorted", False)):
+            ctx.sketch_keys_device(p, bases.data_ptr(), seg_n, off.data_ptr(), d_out, n_out, one, unordered=un)      # buffers, table
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            _, _, _, koff = ctx.sketch_keys_device(p, bases.data_ptr(), seg_n, off.data_ptr(), d_out, n_out, one, unordered=un)
+            res[name + "_ms"] = (time.perf_counter() - t0) * 1e3
+            res[name + "_keys"] = int(koff[1])
+        out["sketch_keys"] = {"what": "spsp_sketch_keys_device over the scan's output, all %d records as one sketch (handle_superkmer's counts, the emission / "
+                                      "reader round trip and canonize composed; SubSampler.cpp:243-302,458-620, Comparator.cpp:186-260)" % n_rec,
+                              "sketch_keys_ms": res["unordered_ms"], "sketch_keys_sorted_ms": res["sorted_ms"], "keys": res["unordered_keys"],
+                              "forms_agree_on_the_count": res["unordered_keys"] == res["sorted_keys"], "selected_kmer_occurrences": sel,
+                              "genomes_through_the_table_in_hbm": ctx.sketch_keys_big_genomes()}
+    except Exception as e:  # noqa: BLE001
+        out["sketch_keys"] = {"error": repr(e)}
     if not skip_oracle:
         from oracle import oracle_py as orc
         orc.use_native()
@@ -1123,6 +1143,18 @@ def scan_config5(ctx, dev, skip_oracle, peak, gbp=4.0):
                                          "(%d k-mers), %.2f s" % (R, km, sec)}
         out["parity_vs_oracle"] = {"records": R, "superkmers": int(len(want)),
                                    "equal": bool(len(mine) == len(want) and all((mine[f] == want[f]).all() for f in want.dtype.names))}
+        try:
+            # ... and their keys: the first R records as one sketch (1.2 x 10^5 selected k-mers: the table in HBM + the merge sort)
+            # against the oracle's comparator walk (orc_sketch_keys) over the oracle's sketch of the same records
+            text = b"".join(b">r%d\n" % r + hb[r * rec_len:(r + 1) * rec_len].tobytes() + b"\n" for r in range(R))
+            _, _, w_mn, w_lo, w_hi = orc.sketch_keys(orc.sketch_fasta(text, k, m, s)[0])
+            d_mn, d_lo, d_hi, koff = ctx.sketch_keys_device(p, bases.data_ptr(), seg_n, off.data_ptr(), d_out, n_out, np.array([0, R], dtype=np.uint32))
+            tot = int(koff[1])
+            out["parity_vs_oracle"]["sketch_keys"] = {"keys": tot, "equal": bool(tot == len(w_mn) and (ctx.to_host(d_mn, tot, np.uint32) == w_mn).all()
+                                                                                 and (ctx.to_host(d_lo, tot, np.uint64) == w_lo).all()
+                                                                                 and (ctx.to_host(d_hi, tot, np.uint64) == w_hi).all())}
+        except Exception as e:  # noqa: BLE001
+            out["parity_vs_oracle"]["sketch_keys"] = {"error": repr(e)}
     return out
 
 

@@ -10,7 +10,8 @@
 //                           FULL keys compared against the claiming record, the occurrences counted in the slot word
 //            k_big_emit     the claimer of every group whose count passes handle_superkmer's uint8 rule emits the key,
 //                           unless the other orientation's group does (same rule as k_keys_fused, spsp_keys.hip);
-//                           places inside the segment's output slice come from one wave-aggregated atomic per wave
+//                           places inside the segment's output slice come from ONE atomic per workgroup (its lanes' counts
+//                           are summed in LDS first)
 //   sort     k_bigsort_chunks / k_bigsort_merge   (callers that promise sorted sketches) bitonic sort of 2048-key chunks
 //                           in LDS, then merge passes over global memory, merge-path partitioned: one 2048-key output
 //                           tile per workgroup, both inputs staged in LDS, 8 keys per lane
@@ -102,6 +103,8 @@ __global__ __launch_bounds__(kBigThreads) void k_big_emit(const uint32_t* __rest
     if (gate && *gate == 0) return;
     const uint32_t lane = threadIdx.x & 63u;
     uint32_t s = 0xffffffffu, first = 0, cnt = 0, big = 0;
+    uint32_t emit_mask = 0;                                        // bit u: this lane's u-th place emits its key
+    uint32_t s_lo_seen = 0xffffffffu;                              // segment of this lane's first emitting place (segments only grow with u)
     auto usable = [&](unsigned long long wd) { return ((uint32_t)(wd >> 48) & 255u) >= abundance; };   // uint8 count (SubSampler.h:24)
 #pragma unroll 1
     for (uint32_t u = 0; u < kBigPer; ++u) {
@@ -125,6 +128,7 @@ __global__ __launch_bounds__(kBigThreads) void k_big_emit(const uint32_t* __rest
                 }
                 if ((uint32_t)cur == p + 1 && usable(cur)) {       // one lane per (key, orientation) group: its claimer
                     emit = true;
+                    if (s_lo_seen == 0xffffffffu) s_lo_seen = s;
                     if (mo >> 31) {                                // the forward-oriented group of the same canonical key emits if it is usable
                         const uint32_t sib = mo & 0x7fffffffu;
                         uint32_t h2 = big_home(s, sib, lo, hi, mask);
@@ -139,19 +143,59 @@ __global__ __launch_bounds__(kBigThreads) void k_big_emit(const uint32_t* __rest
                 }
             }
         }
-        // places in the segment's output slice: one atomic per wave and segment (a wave rarely straddles two)
+        if (emit) emit_mask |= 1u << u;
+    }
+    // Places in the segment's output slice.  A workgroup's places nearly always lie in ONE segment: then its lanes' counts
+    // are summed in LDS and the workgroup draws its room with one atomic (one per wave made k_big_emit wait on 600 000
+    // same-address atomics at 4 x 10^7 keys); a workgroup that straddles segments draws per wave and segment.
+    __shared__ uint32_t s_wave[kBigThreads / 64], s_base, s_ref;
+    const uint32_t p_first = blockIdx.x * kBigPer * kBigThreads;
+    if (threadIdx.x == 0) s_ref = big_segment(seg_first, n_seg, p_first < n_places ? p_first : n_places - 1);
+    __syncthreads();
+    const uint32_t ref = s_ref;
+    const bool one_segment = __syncthreads_and(emit_mask == 0 || (s_lo_seen == ref && s == ref)) != 0;
+    if (one_segment) {
+        const uint32_t mine = (uint32_t)__popc(emit_mask);
+        uint32_t x = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d); if (lane >= (uint32_t)d) x += y; }
+        if (lane == 63) s_wave[threadIdx.x >> 6] = x;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t tot = 0;
+            for (uint32_t wv = 0; wv < kBigThreads / 64; ++wv) tot += s_wave[wv];
+            s_base = tot ? atomicAdd(&distinct[ref], tot) : 0u;
+        }
+        __syncthreads();
+        uint32_t at = seg_first[ref] + s_base + x - mine;
+        for (uint32_t wv = 0; wv < (threadIdx.x >> 6); ++wv) at += s_wave[wv];
+        for (uint32_t u = 0; u < kBigPer; ++u) {
+            if (!((emit_mask >> u) & 1u)) continue;
+            const uint32_t p = (blockIdx.x * kBigPer + u) * kBigThreads + threadIdx.x;
+            o_mn[at] = raw_mn[p] & 0x7fffffffu; o_lo[at] = raw_lo[p];
+            if (HAS_HI) o_hi[at] = raw_hi[p];
+            ++at;
+        }
+        return;
+    }
+#pragma unroll 1
+    for (uint32_t u = 0; u < kBigPer; ++u) {
+        const uint32_t p = (blockIdx.x * kBigPer + u) * kBigThreads + threadIdx.x;
+        const bool emit = (emit_mask >> u) & 1u;
+        uint32_t sl_mine = 0, first_mine = 0;
+        if (emit) { sl_mine = big_segment(seg_first, n_seg, p); first_mine = seg_first[sl_mine]; }
         unsigned long long todo = __ballot(emit);
         while (todo) {
             const int leader = __ffsll((long long)todo) - 1;
-            const uint32_t sl = __shfl(s, leader);
-            const unsigned long long same = __ballot(emit && s == sl);
+            const uint32_t sl = __shfl(sl_mine, leader);
+            const unsigned long long same = __ballot(emit && sl_mine == sl);
             uint32_t base = 0;
             if ((int)lane == leader) base = atomicAdd(&distinct[sl], (uint32_t)__popcll(same));
             base = __shfl(base, leader);
-            if (emit && s == sl) {
-                const uint32_t at = first + base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-                o_mn[at] = mo & 0x7fffffffu; o_lo[at] = lo;
-                if (HAS_HI) o_hi[at] = hi;
+            if (emit && sl_mine == sl) {
+                const uint32_t at = first_mine + base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+                o_mn[at] = raw_mn[p] & 0x7fffffffu; o_lo[at] = raw_lo[p];
+                if (HAS_HI) o_hi[at] = raw_hi[p];
             }
             todo &= ~same;
         }

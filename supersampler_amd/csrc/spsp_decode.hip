@@ -322,7 +322,8 @@ int sketch_decode_device_impl(spsp_ctx* ctx, const uint8_t* const* payloads, con
                                            d_first32, d_raw_cnt, d_big, n, R, nullptr, 0u, ctx->b_mn.as<uint32_t>(), ctx->b_lo.as<uint64_t>(),
                                            has_hi ? ctx->b_hi.as<uint64_t>() : nullptr, d_distinct))) return fail(rc);
     if ((rc = launch_scan_u32(ctx, d_distinct, d_out_off, n, ctx->h_scalar + 7))) return fail(rc);
-    hipLaunchKernelGGL(k_decode_compact, dim3(8, n), dim3(256), 0, ctx->stream, ctx->dc_mn.as<uint32_t>(), ctx->dc_lo.as<uint64_t>(),
+    const uint32_t gx = (uint32_t)std::min<uint64_t>(2048, std::max<uint64_t>(8, R / n / 2048));   // (more workgroups per sketch when sketches are huge)
+    hipLaunchKernelGGL(k_decode_compact, dim3(gx, n), dim3(256), 0, ctx->stream, ctx->dc_mn.as<uint32_t>(), ctx->dc_lo.as<uint64_t>(),
                        has_hi ? ctx->dc_hi.as<uint64_t>() : (const uint64_t*)nullptr, ctx->b_mn.as<uint32_t>(), ctx->b_lo.as<uint64_t>(),
                        has_hi ? ctx->b_hi.as<uint64_t>() : (const uint64_t*)nullptr, d_raw_off, d_big, d_distinct, d_out_off, ctx->c_min.as<uint32_t>(),
                        ctx->c_lo.as<uint64_t>(), has_hi ? ctx->c_hi.as<uint64_t>() : (uint64_t*)nullptr);

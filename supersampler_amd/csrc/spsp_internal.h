@@ -71,7 +71,7 @@ struct ScanJob {
 struct CompareJob;   // spsp_compare.hip
 // the key extraction queued by sketch_keys_begin_impl: what its last stages need when _end has to queue them (spsp_keys.hip)
 struct KeysJob {
-    bool has_hi = false, sorted = false;
+    bool has_hi = false, flat = false;   // flat: raw records by one lane per super-k-mer + per-genome LDS sort (the sorted form's kernels)
     uint32_t n_genomes = 0;
     uint64_t bound = 0;          // k-mer places of all genomes together (the extent of the staging arrays)
     uint32_t abundance = 1;

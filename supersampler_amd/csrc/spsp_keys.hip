@@ -26,6 +26,7 @@
 // the same _begin call: one open-addressing table in HBM with the same (key, orientation) groups, counts and uint8 rule,
 // and -- for the sorted form -- a merge sort of its distinct keys where they finally lie.  The reference's index is
 // unbounded (SubSampler.h:62, SubSampler.cpp:274-300); so is this one, and nothing of it runs on the host.
+#include <algorithm>
 #include <cstring>
 #include <string>
 
@@ -484,9 +485,11 @@ static int keys_finish_queue(spsp_ctx* ctx, bool with_big, const uint32_t* d_gat
     int rc;
     if (with_big && J.bound &&
         (rc = big_dedupe_launch(ctx, J.has_hi, a_mn, a_lo, a_hi, d_raw_off, d_raw_cnt, d_big, ng, J.bound, d_gate, J.abundance, b_mn, b_lo, b_hi, d_distinct))) return rc;
-    if (J.sorted && (rc = launch_scan_u32(ctx, d_distinct, d_out_off, ng, ctx->h_scalar + 7))) return rc;
-    hipLaunchKernelGGL(k_keys_compact, dim3(8, ng), dim3(256), 0, ctx->stream, a_mn, a_lo, a_hi, b_mn, b_lo, b_hi, d_raw_off, d_distinct, d_big,
-                       J.sorted ? (const uint32_t*)d_out_off : (const uint32_t*)nullptr, ctx->c_min.as<uint32_t>(), ctx->c_lo.as<uint64_t>(),
+    if (J.flat && (rc = launch_scan_u32(ctx, d_distinct, d_out_off, ng, ctx->h_scalar + 7))) return rc;
+    // (8 workgroups of 256 copy a genome's few thousand keys; a call with few, huge genomes gets as many as its keys need)
+    const uint32_t gx = (uint32_t)std::min<uint64_t>(2048, std::max<uint64_t>(8, J.bound / ng / 2048));
+    hipLaunchKernelGGL(k_keys_compact, dim3(gx, ng), dim3(256), 0, ctx->stream, a_mn, a_lo, a_hi, b_mn, b_lo, b_hi, d_raw_off, d_distinct, d_big,
+                       J.flat ? (const uint32_t*)d_out_off : (const uint32_t*)nullptr, ctx->c_min.as<uint32_t>(), ctx->c_lo.as<uint64_t>(),
                        J.has_hi ? ctx->c_hi.as<uint64_t>() : (uint64_t*)nullptr, ng, d_flags, h_out);
     SPSP_HIP(hipGetLastError());
     return SPSP_OK;
@@ -540,7 +543,8 @@ int sketch_keys_begin_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d
     // bounds straight from the pinned staging block (no copy packet in front), and the gate words are cleared by the
     // compaction kernel that reports them (no fill packet either; cleared here after a call that did not get that far).
     // The sorted form keeps the copy: several of its kernels read the bounds.
-    if (!unordered) SPSP_HIP(hipMemcpyAsync(d_first_rec, ctx->h_keys, (size_t)(n_genomes + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    const bool flat_front = !unordered || bound > (uint64_t)n_genomes * 32768ull;   // (see below)
+    if (flat_front) SPSP_HIP(hipMemcpyAsync(d_first_rec, ctx->h_keys, (size_t)(n_genomes + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
     else d_first_rec = ctx->h_keys;
     if (!ctx->keys_flags_clear) SPSP_HIP(hipMemsetAsync(d_flags, 0, 8, ctx->stream));
     ctx->keys_flags_clear = false;
@@ -550,8 +554,12 @@ int sketch_keys_begin_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d
     const uint32_t ab = p->k == p->m ? 0u : (p->abundance ? p->abundance : 1u);
     uint32_t* a_mn = ctx->a_mn.as<uint32_t>();
     uint64_t *a_lo = ctx->a_lo.as<uint64_t>(), *a_hi = has_hi ? ctx->a_hi.as<uint64_t>() : (uint64_t*)nullptr;
-    ctx->keys_job = KeysJob{has_hi, !unordered, n_genomes, bound, ab, false};
-    if (unordered) {
+    // Unordered form with few, very large genomes (a metagenome record set as ONE sketch, BASELINE configs[4]): one workgroup
+    // per genome would roll millions of k-mers alone.  Such a call takes the sorted form's front end -- one lane per
+    // super-k-mer over the whole stream -- and leaves out the final sort only.
+    const bool flat = flat_front;
+    ctx->keys_job = KeysJob{has_hi, flat, n_genomes, bound, ab, false};
+    if (!flat) {
         const size_t lds_d = (has_hi ? (size_t)kDedupCapHi * 28 : (size_t)kDedupCapLo * 20) + kDedupSkmWords * 4;
         if (!ctx->attr_dedupe_set) {
             SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_keys_fused<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kDedupCapHi * 28 + kDedupSkmWords * 4)));
