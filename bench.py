@@ -71,6 +71,30 @@ def cpu_model():
     return "unknown"
 
 
+def env_report():
+    """Every BENCH_* / SPSP_* variable that is set goes into the line (`config.env`): a stale variable on the box must not
+    change the headline silently.  Variables that take work out of the timed region, replace the library or the transport,
+    or exist for analysis only make the line INVALID as a measurement (`valid`: false, with the reasons)."""
+    env = {k: v for k, v in sorted(os.environ.items()) if k.startswith(("BENCH_", "SPSP_"))}
+    why = []
+    for k, v in env.items():
+        if "_DEBUG_" in k or "_EXP_" in k:
+            why.append("%s is an analysis / test hook" % k)
+        elif k == "BENCH_DEVICE_KEYS" and v == "0":
+            why.append("BENCH_DEVICE_KEYS=0 leaves the key extraction out of the step")
+        elif k == "BENCH_SIM_WORLD" and v not in ("", "1"):
+            why.append("BENCH_SIM_WORLD simulates one rank's share, no exchange")
+        elif k == "BENCH_SHARE_GPU" and v == "1":
+            why.append("BENCH_SHARE_GPU=1 puts every rank on one device")
+        elif k == "BENCH_BACKEND" and v != "nccl":
+            why.append("BENCH_BACKEND=%s is not RCCL" % v)
+        elif k == "SPSP_LIB":
+            why.append("SPSP_LIB replaces the in-tree libspsp.so")
+        elif k == "BENCH_BATCHES" and v in ("0", "1"):
+            why.append("BENCH_BATCHES=%s lets consecutive steps read the same batch (Infinity Cache)" % v)
+    return env, why
+
+
 def main():
     # stdout carries exactly ONE JSON line: anything native libraries print there (RCCL's version banner,
     # for one) is sent to stderr by pointing fd 1 at fd 2 until the result is written
@@ -692,6 +716,7 @@ def main():
             exchange_check = "check failed: %r" % (e,)
 
     if rank == 0:
+        env_set, env_why = env_report()
         value = total_kmers_per_step * args.steps / elapsed
         ms_per_step = elapsed * 1e3 / args.steps
         dense_avg_ms = dense_ms / max(1, tm["dense_launches"])
@@ -712,7 +737,9 @@ def main():
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: %d synthetic %d bp genomes per GPU (10 families, mu 0.001/0.01), "
+            "valid": not env_why, **({"invalid_because": env_why} if env_why else {}),
+            "config": {"env": env_set,
+                       "workload": "BASELINE configs[1]: %d synthetic %d bp genomes per GPU (10 families, mu 0.001/0.01), "
                                    "k=31 m=11 s=1000, scan + all-vs-all; inputs resident in HBM; consecutive steps scan different batches "
                                    "(ring of %d x %d MB)" % (args.genomes, args.length, n_batches, d_bases.numel() // 1000000),
                        "batches": n_batches,

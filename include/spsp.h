@@ -80,6 +80,8 @@ typedef struct spsp_sketch_view {
 } spsp_sketch_view;
 
 /* ------------------------------------------------------------ lifecycle -- */
+/* how many gfx950 devices this process sees (devices 0 .. count - 1 are usable with spsp_create); 0 = none, see spsp_last_error */
+int spsp_device_count(void);
 int spsp_create(int device, void* hip_stream /* hipStream_t or NULL = own stream */, spsp_ctx** out);
 void spsp_destroy(spsp_ctx* ctx);
 const char* spsp_last_error(void);
@@ -235,7 +237,7 @@ int spsp_compare_device(spsp_ctx* ctx, uint32_t k, const void* d_minimizer, cons
 /* ----------------------------------- multi-GPU exchange ---- */
 /* The reference is single-process; its all-vs-all merge (Comparator.cpp:97-287) has no sharded form to mirror.
  * Key-partitioned split: equal (minimizer, k-mer) keys hash to the same rank, every rank counts its own hash
- * class for ALL pairs, and inter = the sum of the partial matrices (one all-reduce).  Each rank sends each of
+ * class for ALL pairs, and inter = the sum of the partial matrices (sparse: spsp_matrix_cells_device).  Each rank sends each of
  * its keys exactly once (all-to-all) -- O(own keys) per rank, against O(all keys) for an all-gather.
  *
  * Sender: scatter this rank's n sketches (concatenated key arrays as in spsp_compare_device) into `parts`
@@ -251,8 +253,10 @@ int spsp_partition_keys_device(spsp_ctx* ctx, uint32_t k, const void* d_minimize
                                uint32_t parts, uint32_t slot_cap, void* d_slots);
 /* Receiver: d_slots holds `parts` slots, slot s as sent by rank s (same n, slot_cap, k everywhere). Global
  * sketch id = s * n + local id; d_inter is the dense (parts*n)^2 uint32 partial matrix: cells (i, j > i)
- * are overwritten with this rank's share of |K_i ∩ K_j|, everything else is left untouched.  Returns after
- * one synchronisation of the context's stream (format / overflow / collision flags). */
+ * are overwritten with this rank's share of |K_i ∩ K_j|, everything else is left untouched.  The slot headers
+ * (geometry, keys per sketch) are read on the host first -- a malformed slot is SPSP_ERR_FORMAT, one that
+ * overflowed at the sender SPSP_ERR_OVERFLOW, before any kernel reads it -- then the records are unpacked into
+ * flat key arrays and go through the same partition-form comparison as spsp_compare_device, every row owned. */
 int spsp_compare_slots_device(spsp_ctx* ctx, uint32_t k, const void* d_slots, uint32_t parts, uint32_t n,
                               uint32_t slot_cap, void* d_inter);
 
@@ -398,7 +402,7 @@ int spsp_sketch_file(spsp_ctx* ctx, const spsp_params* p, double rate, const cha
  * the library: the n files are taken in list order, a few at a time; `threads` workers read (and gunzip) a batch's files
  * into one pinned buffer, the batch crosses PCIe in one copy and goes through ONE ingest, ONE scan and ONE gather on the
  * GPU (a GPU job per file is a chain of launches and host waits that costs ~0.35 ms however small the file), and the
- * workers then run the sketch builder, gzip and the write per file.  Up to three batches are in flight, each on a
+ * workers then run the sketch builder, gzip and the write per file.  Up to four batches (at most one per worker) are in flight, each on a
  * context (HIP stream) of its own, so reading, the GPU and the builders overlap inside ONE process.  With -a > 1 the
  * k-mer counting pass is per file: one GPU job per file, one context per worker.  `cb` (may be
  * NULL) is called with phase 0 when file `index` is taken off the queue (inside the queue's lock: the calls come in
@@ -436,6 +440,29 @@ int spsp_compare_files(spsp_ctx* ctx, const char* const* paths, uint32_t n, uint
  * (Comparator.cpp:56,69,364,414; all-versus-all runs also :503,509) -- for bin/comparator */
 int spsp_compare_files_chatty(spsp_ctx* ctx, const char* const* paths, uint32_t n, uint32_t n_query,
                               int precision, double min_threshold, const char* out_prefix, int all_versus_all);
+
+/* The comparator over several GPUs of one node (the reference's compare_sketches, Comparator.cpp:39-74, is
+ * one thread over one merge).  One context per entry of `devices` (the same device may be named more than once: contexts
+ * then share it), one host thread each.  The split is by KEY: every context decodes a block of the sketch files, deals
+ * its keys into one exchange slot per context (spsp_partition_keys_device: equal keys hash to the same slot), fetches
+ * the slots of its own hash class from all the others (peer copies over xGMI), compares ALL sketches' keys of that class
+ * (spsp_compare_slots_device: 1/n_dev of the dictionary and of the row sums, the same share for every context) and
+ * hands the non-zero cells of its partial matrix to the host (spsp_matrix_cells_device), where they add up to the pair
+ * matrix the two CSVs are printed from.  Same files out as spsp_compare_files, byte for byte.
+ * chatter: 0 silent, 1 / 2 the reference's stdout lines of an all-versus-all / a query run (spsp_compare_files_chatty);
+ * times (may be NULL): wall seconds per stage. */
+int spsp_compare_files_multi(const int* devices, uint32_t n_dev, const char* const* paths, uint32_t n, uint32_t n_query, int precision,
+                             double min_threshold, const char* out_prefix, int chatter, struct spsp_stage_times* times);
+
+/* A pair matrix in sparse form: the non-zero cells (i, j > i) of rows row_first <= i < row_limit of the dense n x n
+ * matrix d_inter as packed 64-bit words  i << 48 | j << 32 | count  (n <= 65535, the reference's bound: Comparator.h:26),
+ * in no particular order, in d_cells (room for `cap` words).  *n_cells = how many there are; SPSP_ERR_OVERFLOW when
+ * that is more than cap (nothing is lost: call again with that much room).  A partial matrix of the key-partitioned
+ * split is mostly zeros -- this is what crosses the fabric instead of n x n cells.  Waits for the context's stream. */
+int spsp_matrix_cells_device(spsp_ctx* ctx, const void* d_inter, uint32_t n, uint32_t row_first, uint32_t row_limit, void* d_cells,
+                             uint64_t cap, uint64_t* n_cells);
+/* d_inter[i][j] += count for every packed cell (the collecting side of the above) */
+int spsp_matrix_add_cells_device(spsp_ctx* ctx, void* d_inter, uint32_t n, const void* d_cells, uint64_t n_cells);
 
 #ifdef __cplusplus
 }

@@ -79,11 +79,11 @@ SUPERKMER_DTYPE = np.dtype([("rec", "<u4"), ("minimizer", "<u4"), ("start", "<u8
 
 # every symbol include/spsp.h declares (tests check the .so exports them all)
 ABI_SYMBOLS = [
-    "spsp_create", "spsp_destroy", "spsp_last_error", "spsp_version", "spsp_free", "spsp_copy_to_host",
+    "spsp_device_count", "spsp_create", "spsp_destroy", "spsp_last_error", "spsp_version", "spsp_free", "spsp_copy_to_host",
     "spsp_stream_create_cus", "spsp_stream_destroy", "spsp_set_cu_count", "spsp_pack_bases_device",
     "spsp_timing_enable", "spsp_timing_sample", "spsp_timing_read", "spsp_threshold_host", "spsp_scan", "spsp_scan_device", "spsp_scan_device_begin", "spsp_scan_device_end", "spsp_scan_tail_stream", "spsp_wait_dense", "spsp_wait_stream", "spsp_scan_hits_device", "spsp_count_superkmers_device", "spsp_compare",
     "spsp_compare_device", "spsp_slot_bytes", "spsp_partition_keys_device", "spsp_compare_slots_device", "spsp_compare_device_begin", "spsp_compare_slots_device_begin", "spsp_compare_end", "spsp_fasta_clean_host", "spsp_fasta_clean_device", "spsp_fasta_clean_packed_device", "spsp_sketch_text", "spsp_sketch_build_host", "spsp_sketch_parse_host", "spsp_sketch_decode_device", "spsp_sketch_keys_device", "spsp_sketch_keys_device_begin", "spsp_sketch_keys_device_end", "spsp_sketch_keys_big_genomes", "spsp_scan_output_wait", "spsp_compare_keys_unordered", "spsp_sketch_chain_host",
-    "spsp_csv_host", "spsp_sort_csv_host", "spsp_read_file_host", "spsp_write_gz_host", "spsp_sketch_file", "spsp_compare_files", "spsp_compare_files_chatty", "spsp_stage_times_read", "spsp_measure_hbm_device", "spsp_sketch_files", "spsp_sketch_files_release",
+    "spsp_csv_host", "spsp_sort_csv_host", "spsp_read_file_host", "spsp_write_gz_host", "spsp_sketch_file", "spsp_compare_files", "spsp_compare_files_chatty", "spsp_stage_times_read", "spsp_measure_hbm_device", "spsp_sketch_files", "spsp_sketch_files_release", "spsp_compare_files_multi", "spsp_matrix_cells_device", "spsp_matrix_add_cells_device",
 ]
 
 _lib = None
@@ -102,6 +102,7 @@ def lib():
         print("[supersampler_amd] SPSP_LIB is set: loaded %s instead of the in-tree libspsp.so" % LIB_PATH, file=sys.stderr, flush=True)
     u64, u32, vp, cp, dbl, i32 = C.c_uint64, C.c_uint32, C.c_void_p, C.c_char_p, C.c_double, C.c_int
     P = C.POINTER
+    L.spsp_device_count.restype = i32; L.spsp_device_count.argtypes = []
     L.spsp_create.restype = i32; L.spsp_create.argtypes = [i32, vp, P(vp)]
     L.spsp_destroy.restype = None; L.spsp_destroy.argtypes = [vp]
     L.spsp_last_error.restype = cp; L.spsp_last_error.argtypes = []
@@ -182,6 +183,10 @@ def lib():
     L.spsp_sketch_files.argtypes = [i32, P(Params), dbl, P(cp), P(cp), u32, u32, FILE_CALLBACK, vp, P(StageTimes)]
     L.spsp_sketch_files_release.restype = None; L.spsp_sketch_files_release.argtypes = [i32]
     L.spsp_measure_hbm_device.restype = i32; L.spsp_measure_hbm_device.argtypes = [vp, u64, u32, P(HbmRates)]
+    L.spsp_compare_files_multi.restype = i32
+    L.spsp_compare_files_multi.argtypes = [P(i32), u32, P(cp), u32, u32, i32, dbl, cp, i32, P(StageTimes)]
+    L.spsp_matrix_cells_device.restype = i32; L.spsp_matrix_cells_device.argtypes = [vp, vp, u32, u32, u32, vp, u64, P(u64)]
+    L.spsp_matrix_add_cells_device.restype = i32; L.spsp_matrix_add_cells_device.argtypes = [vp, vp, u32, vp, u64]
     _lib = L
     return L
 
@@ -342,6 +347,17 @@ def sketch_files(fasta_paths, out_paths, k=31, m=11, s=1000.0, abundance=1, thre
 def sketch_files_release(device=-1):
     """release the contexts and pinned buffers spsp_sketch_files keeps between calls"""
     lib().spsp_sketch_files_release(device)
+
+
+def compare_files_multi(devices, paths, out_prefix, n_query=None, precision=6, min_threshold=0.0):
+    """spsp_compare_files_multi: the comparator split by key over one context per entry of `devices` -> stage seconds"""
+    n = len(paths)
+    devs = (C.c_int * len(devices))(*devices)
+    arr = (C.c_char_p * n)(*[p.encode() for p in paths])
+    st = StageTimes()
+    _check(lib().spsp_compare_files_multi(devs, len(devices), arr, n, n if n_query is None else n_query, precision, float(min_threshold),
+                                          out_prefix.encode(), 0, C.byref(st)))
+    return {f: getattr(st, f) for f, _ in StageTimes._fields_}
 
 
 def stream_create_cus(device, first_cu, n_cu):
@@ -593,6 +609,15 @@ class Context:
     def compare_slots_device(self, k, d_slots, parts, n, slot_cap, d_inter):
         """Partial pair matrix of the hash class this rank received (one slot per source rank)."""
         _check(lib().spsp_compare_slots_device(self._h, k, d_slots, parts, n, slot_cap, d_inter))
+
+    def matrix_cells_device(self, d_inter, n, d_cells, cap, row_first=0, row_limit=None):
+        """non-zero cells (i < j) of a dense pair matrix on the device as packed words i << 48 | j << 32 | count -> how many"""
+        cnt = C.c_uint64()
+        _check(lib().spsp_matrix_cells_device(self._h, d_inter, n, row_first, n if row_limit is None else row_limit, d_cells, cap, C.byref(cnt)))
+        return cnt.value
+
+    def matrix_add_cells_device(self, d_inter, n, d_cells, n_cells):
+        _check(lib().spsp_matrix_add_cells_device(self._h, d_inter, n, d_cells, n_cells))
 
     def compare_files(self, paths, out_prefix, n_query=None, precision=6, min_threshold=0.0):
         n = len(paths)

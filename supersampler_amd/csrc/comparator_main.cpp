@@ -6,6 +6,8 @@
 #include <chrono>
 #include <iostream>
 #include <sstream>
+#include <algorithm>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -62,15 +64,28 @@ int main(int argc, char** argv) {
         cout << "I query " << n_query << " file(s) against the bank" << endl;
         read_names(inputfof, names);
     }
-    spsp_ctx* ctx = nullptr;
-    if (spsp_create(0, nullptr, &ctx) != SPSP_OK) { cout << "GPU unavailable: " << spsp_last_error() << endl; return 1; }
     vector<const char*> paths;
     for (auto& s : names) paths.push_back(s.c_str());
+    // Devices: every visible GPU when there is enough work to split (the comparison is dealt by key over one context per
+    // device, spsp_compare_files_multi), else the first.  SPSP_DEVICES="0,1,2,3" (or "0,0": two contexts on one device)
+    // names them explicitly.  The reference has no such notion (one thread, Comparator.cpp:39-74).
+    vector<int> devices;
+    if (const char* e = getenv("SPSP_DEVICES")) {
+        istringstream is(e);
+        string tok;
+        while (getline(is, tok, ',')) if (!tok.empty()) devices.push_back(atoi(tok.c_str()));
+    }
+    if (devices.empty()) {
+        const int visible = spsp_device_count();
+        if (visible <= 0) { cout << "GPU unavailable: " << spsp_last_error() << endl; return 1; }
+        const size_t per_device = 512;                        // sketches per device below which splitting does not pay
+        const int use = (int)std::max<size_t>(1, std::min<size_t>((size_t)visible, names.size() / per_device));
+        for (int d = 0; d < use; ++d) devices.push_back(d);
+    }
     // the progress lines of the reference (Comparator.cpp:56,69,364,414,503,509) are printed by the driver where the
     // reference prints them
-    const int rc = spsp_compare_files_chatty(ctx, paths.data(), (uint32_t)paths.size(), n_query, (int)p, min_threshold,
-                                             output_name.c_str(), query == "" ? 1 : 0);
-    spsp_destroy(ctx);
+    const int rc = spsp_compare_files_multi(devices.data(), (uint32_t)devices.size(), paths.data(), (uint32_t)paths.size(), n_query, (int)p,
+                                            min_threshold, output_name.c_str(), query == "" ? 1 : 2, nullptr);
     if (rc != SPSP_OK) { cout << "Comparison failed: " << spsp_last_error() << endl; return 1; }
     return 0;
 }

@@ -164,6 +164,19 @@ int spsp_create(int device, void* hip_stream, spsp_ctx** out) {
     return SPSP_OK;
 }
 
+int spsp_device_count(void) {
+    int count = 0;
+    const hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) { set_error("no HIP device available (%s)", e == hipSuccess ? "device count is 0" : hipGetErrorString(e)); return 0; }
+    int usable = 0;
+    for (int d = 0; d < count; ++d) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) ++usable; else break;
+    }
+    if (!usable) set_error("no gfx950 device among the %d visible", count);
+    return usable;
+}
+
 int spsp_stream_create_cus(int device, uint32_t first_cu, uint32_t n_cu, void** hip_stream) {
     if (!hip_stream) { set_error("NULL argument"); return SPSP_ERR_ARG; }
     *hip_stream = nullptr;
@@ -217,7 +230,7 @@ void spsp_destroy(spsp_ctx* c) {
     if (c->compare_done) (void)hipEventDestroy(c->compare_done);
     DevBuf* bufs[] = {&c->bases, &c->rec_off, &c->bitmap, &c->tile_count, &c->tile_off, &c->hits, &c->emit_count,
                       &c->scan_tmp, &c->d_scalar, &c->seg_a, &c->seg_b, &c->wave_hits, &c->wave_cnt, &c->packed, &c->unpacked, &c->st_count, &c->st_open, &c->filter, &c->bloom, &c->pairtab, &c->c_min, &c->c_lo, &c->c_hi, &c->c_table,
-                      &c->c_owner, &c->c_rowid, &c->c_row, &c->x_cnt, &c->x_off, &c->x_begin, &c->x_end, &c->x_tot, &c->dc_text, &c->dc_desc, &c->dc_mn, &c->dc_lo, &c->dc_hi, &c->dc_meta, &c->a_cnt, &c->a_off, &c->a_mn, &c->a_lo, &c->a_hi, &c->a_slot, &c->a_slot_of, &c->a_flags, &c->b_mn, &c->b_lo, &c->b_hi, &c->b_table, &c->b_tiles, &c->b_seg, &c->c_matrix, &c->c_inter, &c->c_flags, &c->c_slot_lo, &c->c_slot_hi, &c->c_slot_mn, &c->c_part_cnt, &c->c_recs, &c->c_where, &c->c_lref, &c->c_filter,
+                      &c->c_owner, &c->c_rowid, &c->c_row, &c->x_cnt, &c->x_off, &c->x_begin, &c->x_end, &c->x_tot, &c->dc_text, &c->dc_desc, &c->dc_mn, &c->dc_lo, &c->dc_hi, &c->dc_meta, &c->a_cnt, &c->a_off, &c->a_mn, &c->a_lo, &c->a_hi, &c->a_slot, &c->a_slot_of, &c->a_flags, &c->b_mn, &c->b_lo, &c->b_hi, &c->b_table, &c->b_tiles, &c->b_seg, &c->m_send, &c->m_recv, &c->m_cells, &c->m_mn, &c->m_lo, &c->m_hi, &c->c_matrix, &c->c_inter, &c->c_flags, &c->c_slot_lo, &c->c_slot_hi, &c->c_slot_mn, &c->c_part_cnt, &c->c_recs, &c->c_where, &c->c_lref, &c->c_filter,
                       &c->c_skoff, &c->i_text, &c->i_tiles, &c->i_entry, &c->i_outoff, &c->i_recbase, &c->i_lens, &c->i_dst,
                       &c->i_compact};
     for (DevBuf* b : bufs) b->release();

@@ -1425,15 +1425,8 @@ static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t*
 //     u32 cnt[n_sketches]          keys per local sketch in this slot (padded to an even count)
 //     record[slot_cap]             words x u64: kmer_lo, (kmer_hi if k > 32), minimizer | local sketch << 32
 // Records are grouped by sketch, sketches in order, keys of a sketch in their original (sorted) order.
-constexpr uint32_t kSlotMagic = 0x4c535053u;   // "SPSL"
-constexpr uint32_t kMaxParts = 64;
+// (kSlotMagic, kMaxParts, slot_rec_off / slot_words / slot_bytes: spsp_internal.h -- the receiver is spsp_multi.hip)
 constexpr int kPartThreads = 256;
-
-__host__ __device__ inline uint64_t slot_rec_off(uint32_t n) { return 16 + (uint64_t)((n + 1) & ~1u) * 4; }
-__host__ __device__ inline uint32_t slot_words(uint32_t k) { return k > 32 ? 3u : 2u; }
-__host__ __device__ inline uint64_t slot_bytes(uint32_t n, uint32_t cap, uint32_t k) {
-    return slot_rec_off(n) + (uint64_t)cap * slot_words(k) * 8;
-}
 
 __device__ __forceinline__ uint32_t part_of(uint64_t lo, uint32_t mn, uint64_t hi, bool has_hi, uint32_t parts) {
     uint64_t h = mix64(lo ^ 0xD6E8FEB86659FD93ULL);
@@ -1543,133 +1536,6 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(Keys K, const uin
     }
 }
 
-// --- receiver ---
-struct SlotView {
-    const uint8_t* base;
-    uint64_t slot_sz, rec_off;
-    uint32_t cap, n, words, parts;
-    uint64_t fp_mask;
-};
-__device__ __forceinline__ const uint64_t* slot_rec(const SlotView& V, uint32_t e) {
-    const uint32_t s = e / V.cap, idx = e - s * V.cap;
-    return reinterpret_cast<const uint64_t*>(V.base + (uint64_t)s * V.slot_sz + V.rec_off) + (uint64_t)idx * V.words;
-}
-__device__ __forceinline__ uint64_t rec_fingerprint(const uint64_t* r, uint32_t words, uint64_t seed, uint64_t fp_mask) {
-    uint64_t f = mix64(r[0] + seed);
-    f = mix64(f ^ ((r[words - 1] & 0xffffffffull) * 0x9E3779B97F4A7C15ULL));
-    if (words == 3) f = mix64(f + r[1]);
-    f &= fp_mask;
-    return f ? f : 1;
-}
-// receiver 1/3: per source slot, validate the header and turn the counts into entry ranges of the
-// GLOBAL sketch ids source * n + j (entry index space: source * slot_cap + position in the slot)
-__global__ __launch_bounds__(kPartThreads) void k_slot_index(SlotView V, uint64_t* __restrict__ sk_begin,
-                                                            uint64_t* __restrict__ sk_end, uint32_t* __restrict__ tot,
-                                                            uint32_t* __restrict__ flags) {
-    __shared__ uint32_t wave_sum[kPartThreads / 64];
-    __shared__ uint32_t s_carry;
-    const uint32_t s = blockIdx.x, t = threadIdx.x, lane = t & 63, wid = t >> 6;
-    const uint32_t* hdr = reinterpret_cast<const uint32_t*>(V.base + (uint64_t)s * V.slot_sz);
-    const bool good = hdr[0] == kSlotMagic && hdr[1] == V.n && hdr[3] == V.words;
-    const uint32_t total = good ? hdr[2] : 0u;
-    if (t == 0) {
-        s_carry = 0;
-        if (!good) atomicOr(&flags[3], 1u);
-        else if (total > V.cap) atomicOr(&flags[4], 1u);
-        tot[s] = total > V.cap ? V.cap : total;
-    }
-    __syncthreads();
-    for (uint32_t base = 0; base < V.n; base += kPartThreads) {
-        const uint32_t j = base + t;
-        const uint32_t v = (good && j < V.n) ? hdr[4 + j] : 0u;
-        uint32_t x = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t y = __shfl_up(x, d);
-            if (lane >= (uint32_t)d) x += y;
-        }
-        if (lane == 63) wave_sum[wid] = x;
-        __syncthreads();
-        uint32_t pre = s_carry, all = 0;
-        for (uint32_t w = 0; w < kPartThreads / 64; ++w) { if (w < wid) pre += wave_sum[w]; all += wave_sum[w]; }
-        if (j < V.n) {
-            // a run never reaches past the stored records, whatever the counts claim
-            const uint64_t b = (uint64_t)pre + x - v, e = b + v;
-            const uint64_t lim = total > V.cap ? V.cap : total;
-            sk_begin[(uint64_t)s * V.n + j] = (uint64_t)s * V.cap + (b < lim ? b : lim);
-            sk_end[(uint64_t)s * V.n + j] = (uint64_t)s * V.cap + (e < lim ? e : lim);
-        }
-        __syncthreads();
-        if (t == 0) s_carry += all;
-        __syncthreads();
-    }
-    if (t == 0 && good && s_carry != total) atomicOr(&flags[3], 1u);
-}
-
-// receiver 2/3 and 3/3: k_insert / k_fill over slot records (every sketch is an owned row here)
-__global__ void k_insert_slots(SlotView V, const uint32_t* __restrict__ tot, uint64_t seed, uint64_t* __restrict__ table,
-                               uint32_t log2cap, uint32_t* __restrict__ owner, SlotKeys SK, uint32_t passes, uint32_t pass) {
-    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= V.parts * V.cap) return;
-    if (e % V.cap >= tot[e / V.cap]) return;
-    const uint64_t* r = slot_rec(V, e);
-    if (passes > 1 && pass_of(r[0], (uint32_t)r[V.words - 1], V.words == 3 ? r[1] : 0, V.words == 3, passes) != pass) return;
-    const uint64_t fp = rec_fingerprint(r, V.words, seed, V.fp_mask);
-    const uint64_t mask = (1ull << log2cap) - 1;
-    uint64_t pos = home_slot(fp, log2cap);
-    for (uint64_t probes = 0; probes <= mask; ++probes) {    // bounded: a full table must not spin (k_fill_slots reports it)
-        const unsigned long long old = atomicCAS((unsigned long long*)&table[pos], 0ull, (unsigned long long)fp);
-        if (old == 0ull) {
-            owner[pos] = e;
-            SK.lo[pos] = r[0]; SK.mn[pos] = (uint32_t)r[V.words - 1];
-            if (V.words == 3) SK.hi[pos] = r[1];
-            break;
-        }
-        if (old == fp) break;
-        pos = (pos + 1) & mask;
-    }
-}
-__global__ void k_fill_slots(SlotView V, const uint32_t* __restrict__ tot, uint64_t seed, const uint64_t* __restrict__ table,
-                             uint32_t log2cap, const uint32_t* __restrict__ owner, const uint32_t* __restrict__ rowid,
-                             SlotKeys SK, uint32_t W, unsigned long long* __restrict__ A,
-                             uint32_t* __restrict__ row_of_entry, uint32_t* __restrict__ flags, uint32_t passes,
-                             uint32_t pass) {
-    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= V.parts * V.cap) return;
-    const uint32_t s = e / V.cap;
-    if (e - s * V.cap >= tot[s]) return;
-    const uint64_t* r = slot_rec(V, e);
-    if (passes > 1 && pass_of(r[0], (uint32_t)r[V.words - 1], V.words == 3 ? r[1] : 0, V.words == 3, passes) != pass) {
-        row_of_entry[e] = 0xffffffffu;
-        return;
-    }
-    row_of_entry[e] = 0xffffffffu;                            // until the row is found (see k_fill)
-    const uint32_t local = (uint32_t)(r[V.words - 1] >> 32);
-    if (local >= V.n) { atomicOr(&flags[3], 1u); return; }
-    const uint32_t g = s * V.n + local;                       // global sketch id = colour
-    const uint64_t fp = rec_fingerprint(r, V.words, seed, V.fp_mask);
-    const uint64_t mask = (1ull << log2cap) - 1;
-    uint64_t pos = home_slot(fp, log2cap);
-    for (uint64_t probes = 0;; ++probes) {
-        if (probes > mask) { atomicOr(&flags[5], 1u); return; }
-        const uint64_t v = table[pos];
-        if (v == 0) { atomicOr(&flags[5], 1u); return; }     // every record was inserted: only a full table gets here
-        if (v == fp) {
-            const bool same = SK.lo[pos] == r[0] && SK.mn[pos] == (uint32_t)r[V.words - 1] &&
-                              (V.words != 3 || SK.hi[pos] == r[1]);
-            if (same) {
-                const uint32_t row = rowid ? rowid[pos] : owner[pos];
-                atomicOr(&A[(uint64_t)row * W + (g >> 6)], 1ull << (g & 63));
-                row_of_entry[e] = row;
-            } else {
-                atomicOr(&flags[1], 1u);                      // two distinct keys, one fingerprint: rebuild
-            }
-            return;
-        }
-        pos = (pos + 1) & mask;
-    }
-}
-
 int partition_keys_impl(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min, const uint64_t* d_lo, const uint64_t* d_hi,
                         const uint64_t* h_sk_off, uint32_t n, uint32_t parts, uint32_t cap, uint8_t* d_slots) {
     if (n == 0 || n > 65535) { set_error("1..65535 sketches per rank"); return SPSP_ERR_ARG; }
@@ -1698,61 +1564,6 @@ int partition_keys_impl(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min, const 
                        d_slots, sz, cap, words);
     SPSP_HIP(hipGetLastError());
     return SPSP_OK;
-}
-
-// returns 0 with a job pending, < 0 on error
-int compare_slots_begin_impl(spsp_ctx* ctx, uint32_t k, const uint8_t* d_slots, uint32_t parts, uint32_t n, uint32_t cap,
-                             uint32_t* d_inter) {
-    if (ctx->compare_job) { set_error("a comparison is already pending on this context: call spsp_compare_end first"); return SPSP_ERR_ARG; }
-    if (n == 0 || parts == 0 || parts > kMaxParts) { set_error("bad slot geometry"); return SPSP_ERR_ARG; }
-    const uint64_t N = (uint64_t)parts * n;
-    if (N > 65535) { set_error("at most 65535 sketches (the reference's uint32 pair key, Comparator.h:26)"); return SPSP_ERR_ARG; }
-    const uint64_t E = (uint64_t)parts * cap;
-    if (cap == 0 || E > 0xfffffff0ull) { set_error("too many sketch k-mers for one call"); return SPSP_ERR_OVERFLOW; }
-    if (((uintptr_t)d_slots & 7u) != 0) { set_error("d_slots must be 8-byte aligned"); return SPSP_ERR_ARG; }
-    int rc = ctx->ev_begin(kEvCompare);
-    if (rc) return rc;
-    auto body = [&]() -> int {
-        int r2;
-        if ((r2 = ctx->x_begin.reserve((size_t)N * 8))) return r2;
-        if ((r2 = ctx->x_end.reserve((size_t)N * 8))) return r2;
-        if ((r2 = ctx->x_tot.reserve((size_t)parts * 4))) return r2;
-        if ((r2 = ctx->c_flags.reserve(64))) return r2;
-        SPSP_HIP(hipMemsetAsync(ctx->c_flags.p, 0, 64, ctx->stream));
-        uint32_t* flags = ctx->c_flags.as<uint32_t>();
-        const SlotView V{d_slots, slot_bytes(n, cap, k), slot_rec_off(n), cap, n, slot_words(k), parts, ~0ull};
-        hipLaunchKernelGGL(k_slot_index, dim3(parts), dim3(kPartThreads), 0, ctx->stream, V, ctx->x_begin.as<uint64_t>(),
-                           ctx->x_end.as<uint64_t>(), ctx->x_tot.as<uint32_t>(), flags);
-        SPSP_HIP(hipGetLastError());
-        const uint32_t* tot = ctx->x_tot.as<uint32_t>();
-        const dim3 grid((uint32_t)((E + 255) / 256));
-        CompareJob* J = new CompareJob;
-        J->P = ComparePlan{E, E, (uint32_t)N, (uint32_t)N, 0, 1, (uint32_t)N, ctx->x_begin.as<uint64_t>(), ctx->x_end.as<uint64_t>(), d_inter};
-        J->insert = [=](uint64_t seed, uint64_t fp_mask, uint32_t log2cap, uint32_t passes, uint32_t pass) -> int {
-            SlotView Vm = V; Vm.fp_mask = fp_mask;
-            hipLaunchKernelGGL(k_insert_slots, grid, dim3(256), 0, ctx->stream, Vm, tot, seed, ctx->c_table.as<uint64_t>(),
-                               log2cap, ctx->c_owner.as<uint32_t>(),
-                               SlotKeys{ctx->c_slot_lo.as<uint64_t>(), ctx->c_slot_hi.as<uint64_t>(), ctx->c_slot_mn.as<uint32_t>()},
-                               passes, pass);
-            SPSP_HIP(hipGetLastError());
-            return SPSP_OK;
-        };
-        J->fill = [=](uint64_t seed, uint64_t fp_mask, uint32_t log2cap, uint32_t W, bool direct_rows, uint32_t passes, uint32_t pass) -> int {
-            SlotView Vm = V; Vm.fp_mask = fp_mask;
-            hipLaunchKernelGGL(k_fill_slots, grid, dim3(256), 0, ctx->stream, Vm, tot, seed, ctx->c_table.as<uint64_t>(), log2cap,
-                               ctx->c_owner.as<uint32_t>(), direct_rows ? (const uint32_t*)nullptr : ctx->c_rowid.as<uint32_t>(),
-                               SlotKeys{ctx->c_slot_lo.as<uint64_t>(), ctx->c_slot_hi.as<uint64_t>(), ctx->c_slot_mn.as<uint32_t>()},
-                               W, ctx->c_matrix.as<unsigned long long>(), ctx->c_row.as<uint32_t>(), flags, passes, pass);
-            SPSP_HIP(hipGetLastError());
-            return SPSP_OK;
-        };
-        return compare_job_begin(ctx, J);
-    };
-    rc = body();
-    // the bracket closes behind the last queued kernel: here for speculative builds, in compare_job_end otherwise
-    const bool deferred = !rc && ctx->compare_job && !ctx->compare_job->speculative;
-    const int rc2 = deferred ? SPSP_OK : ctx->ev_end(kEvCompare);
-    return rc ? rc : rc2;
 }
 
 int compare_device_begin_impl(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min, const uint64_t* d_lo,

@@ -426,7 +426,13 @@ private:
                     while (got < f.text_len && (r = read(fd, dst + got, f.text_len - got)) > 0) got += (uint64_t)r;
                     close(fd);
                 }
-                if (got != f.text_len) { f.rc = SPSP_ERR_IO; f.err = std::string("short read of '") + in_[f.index] + "' (the file changed while it was read)"; memset(dst + got, '\n', f.text_len - got); }
+                if (got != f.text_len) {
+                    // the file contributes NOTHING: its whole region -- the forced '>' and what was read included -- becomes empty
+                    // lines, so that no header line of it starts a record that the file in front would be given (gpu() derives a
+                    // file's records from the next good file's first record)
+                    f.rc = SPSP_ERR_IO; f.err = std::string("short read of '") + in_[f.index] + "' (the file changed while it was read)";
+                    memset(s.slab + f.off, '\n', (size_t)(f.force_header ? 1 : 0) + f.text_len);
+                }
             }
             // the gap up to the next file's tile: newlines (empty lines: no bases, no record)
             const uint64_t end = f.off + (f.force_header ? 1 : 0) + f.text_len;

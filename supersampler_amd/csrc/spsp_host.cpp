@@ -853,7 +853,8 @@ int spsp_stage_times_read(spsp_ctx* ctx, spsp_stage_times* out, int reset) {
 // chatter: 0 = silent; 1 = the stdout lines of the reference's all-versus-all run (Comparator.cpp:56,69,364,414,
 // 503,509); 2 = those of its query run (:56,69,364,414)
 static int compare_files_impl(spsp_ctx* ctx, const char* const* paths, uint32_t n, uint32_t n_query, int precision,
-                              double min_threshold, const char* out_prefix, int chatter) {
+                              double min_threshold, const char* out_prefix, int chatter, spsp_ctx* const* more = nullptr, uint32_t n_more = 0) {
+    // more / n_more: all contexts of a multi-device call (more[0] == ctx): the comparison is then split by key over them
     if (!ctx || !paths || !out_prefix) { set_error("NULL argument"); return SPSP_ERR_ARG; }
     double t0 = now_s(), t1;
     const double t_start = t0;
@@ -966,8 +967,10 @@ static int compare_files_impl(spsp_ctx* ctx, const char* const* paths, uint32_t 
         t1 = now_s(); ctx->stages.load_s += t1 - t0; t0 = t1;
         uint32_t kk = 0, mm2 = 0;
         if (n) inter.assign((size_t)n * n, 0);
-        rc = spsp::compare_payloads_impl(ctx, datas.data(), lens.data(), n, extra_has.data(), extra_mn.data(), n_query, &kk, &mm2,
-                                         inter.data(), card.data());
+        if (n_more > 1) rc = spsp::compare_payloads_multi(more, n_more, datas.data(), lens.data(), n, extra_has.data(), extra_mn.data(), n_query, &kk, &mm2,
+                                                          inter.data(), card.data());
+        else rc = spsp::compare_payloads_impl(ctx, datas.data(), lens.data(), n, extra_has.data(), extra_mn.data(), n_query, &kk, &mm2,
+                                              inter.data(), card.data());
     }
     free_datas();
     t1 = now_s(); ctx->stages.compare_s += t1 - t0;
@@ -1001,6 +1004,24 @@ int spsp_compare_files(spsp_ctx* ctx, const char* const* paths, uint32_t n, uint
 int spsp_compare_files_chatty(spsp_ctx* ctx, const char* const* paths, uint32_t n, uint32_t n_query, int precision,
                               double min_threshold, const char* out_prefix, int all_versus_all) {
     return compare_files_impl(ctx, paths, n, n_query, precision, min_threshold, out_prefix, all_versus_all ? 1 : 2);
+}
+
+int spsp_compare_files_multi(const int* devices, uint32_t n_dev, const char* const* paths, uint32_t n, uint32_t n_query, int precision,
+                             double min_threshold, const char* out_prefix, int chatter, spsp_stage_times* times) {
+    if (!devices || n_dev == 0 || n_dev > 64 || !paths || !out_prefix) { set_error("1..64 devices, file list and output prefix"); return SPSP_ERR_ARG; }
+    std::vector<spsp_ctx*> ctxs;
+    int rc = SPSP_OK;
+    for (uint32_t d = 0; d < n_dev && !rc; ++d) {
+        spsp_ctx* c = nullptr;
+        rc = spsp_create(devices[d], nullptr, &c);
+        if (!rc) ctxs.push_back(c);
+    }
+    if (!rc) rc = compare_files_impl(ctxs[0], paths, n, n_query, precision, min_threshold, out_prefix, chatter < 0 ? 0 : (chatter > 2 ? 2 : chatter), ctxs.data(), (uint32_t)ctxs.size());
+    if (!rc && times) *times = ctxs[0]->stages;
+    const std::string err = rc ? spsp_last_error() : "";
+    for (spsp_ctx* c : ctxs) spsp_destroy(c);
+    if (rc) set_error("%s", err.c_str());
+    return rc;
 }
 
 }  // extern "C"

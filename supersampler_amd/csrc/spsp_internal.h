@@ -159,6 +159,7 @@ struct spsp_ctx {
     // genomes / sketches beyond the per-segment LDS forms (spsp_bigkeys.hip): output slices, the open-addressing table in HBM
     // (slot words carry the epoch of the call that claimed them: never cleared between calls), the sort's tile list
     spsp::DevBuf b_mn, b_lo, b_hi, b_table, b_tiles, b_seg;
+    spsp::DevBuf m_send, m_recv, m_cells, m_mn, m_lo, m_hi;   // key-partitioned split (spsp_multi.hip): slots out / in, sparse cells, unpacked keys
     uint32_t big_epoch = 0;
 };
 
@@ -227,6 +228,25 @@ int inflate_all_host(const uint8_t* in, size_t n, std::vector<uint8_t>& out);
 // host sketch builder over per-super-k-mer base pointers (spsp_host.cpp)
 // -a on the device (spsp_abund.hip): per k-mer occurrence of the gathered super-k-mers, bit 0 usable, bit 1 first of a dropped k-mer
 int abundance_flags_impl(spsp_ctx* ctx, const spsp_params* p, const spsp_superkmer* d_sk, uint64_t n_sk, uint8_t** h_flags, uint64_t* n_occ);
+// exchange slots of the key-partitioned split (wire format: spsp_compare.hip, sender; spsp_multi.hip, receiver)
+constexpr uint32_t kSlotMagic = 0x4c535053u;   // "SPSL"
+constexpr uint32_t kMaxParts = 64;
+__host__ __device__ inline uint64_t slot_rec_off(uint32_t n) { return 16 + (uint64_t)((n + 1) & ~1u) * 4; }
+__host__ __device__ inline uint32_t slot_words(uint32_t k) { return k > 32 ? 3u : 2u; }
+__host__ __device__ inline uint64_t slot_bytes(uint32_t n, uint32_t cap, uint32_t k) {
+    return slot_rec_off(n) + (uint64_t)cap * slot_words(k) * 8;
+}
+int partition_keys_impl(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min, const uint64_t* d_lo, const uint64_t* d_hi,
+                        const uint64_t* h_sk_off, uint32_t n, uint32_t parts, uint32_t cap, uint8_t* d_slots);
+int compare_slots_begin_impl(spsp_ctx* ctx, uint32_t k, const uint8_t* d_slots, uint32_t parts, uint32_t n, uint32_t cap,
+                             uint32_t* d_inter);
+// sparse form of a pair matrix (spsp_multi.hip): non-zero cells (i < j) as i << 48 | j << 32 | count
+int matrix_cells_impl(spsp_ctx* ctx, const uint32_t* d_inter, uint32_t n, uint32_t row_first, uint32_t row_limit, uint64_t* d_cells,
+                      uint64_t cap, uint64_t* n_cells);
+// decode + all-vs-all over several contexts (one per device, or several on one): the device half of spsp_compare_files_multi
+int compare_payloads_multi(spsp_ctx* const* ctxs, uint32_t n_ctx, const uint8_t* const* payloads, const uint64_t* lens, uint32_t n,
+                           const int* extra_has, const uint32_t* extra_mn, uint32_t n_query, uint32_t* k_out, uint32_t* m_out,
+                           uint32_t* inter, uint64_t* card);
 // spsp_bigkeys.hip: distinct keys of flagged segments through one table in HBM (queued, no host wait); segments sorted in place
 int big_dedupe_launch(spsp_ctx* ctx, bool has_hi, const uint32_t* raw_mn, const uint64_t* raw_lo, const uint64_t* raw_hi,
                       const uint32_t* d_seg_first, const uint32_t* d_seg_cnt, const uint32_t* d_seg_big, uint32_t n_seg, uint64_t n_places,

@@ -132,6 +132,10 @@ int main(int argc, char** argv) {
     run.verbose = verbose; run.k = k; run.m = m1; run.out_fof = nullptr;
     auto cb = [](void* user, uint32_t i, int phase, int rc, const spsp_sketch_stats* st, const char* err) {
         Run& r = *(Run*)user;
+        // the library serialises the phase-0 calls among themselves and the phase-1 calls among themselves; stdout is one
+        // stream: a file-name line must not land inside another file's print_stat block (critical(cout), SubSampler.cpp:782,791)
+        static std::mutex out_mutex;
+        std::lock_guard<std::mutex> lock(out_mutex);
         if (phase == 0) {
             if (r.out_fof) {                                  // :784-785 (file-of-files mode only)
                 cout << r.files[i] << endl;

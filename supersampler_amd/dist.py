@@ -278,7 +278,12 @@ class SlotExchange:
 
     begin(): spsp_partition_keys_device -> all-to-all of one fixed-size slot per peer (asynchronous with
              nccl, so the caller can queue other GPU work -- e.g. the next scan -- behind it);
-    end():   wait, spsp_compare_slots_device on the received slots, all-reduce of the partial matrices.
+    end():   wait, spsp_compare_slots_device on the received slots (the partition-form comparison over every sketch's
+             keys of this rank's hash class: 1 / world of the one-GPU work on every rank), then the partial matrices are
+             summed -- reduce="cells" (what a large matrix wants): every rank turns its partial matrix into its non-zero
+             cells (spsp_matrix_cells_device: 95 000 of 5 x 10^7 at BASELINE configs[3]), the cells are all-gathered and
+             every rank adds the others' into its own matrix; "all" / "scatter": all-reduce / reduce-scatter of the dense
+             matrices (small matrices inside a pipelined step: no host wait).
     Every rank must hold the same number of sketches `n_local`; global sketch id = rank * n_local + local id.
     """
 
@@ -347,17 +352,66 @@ class SlotExchange:
         if handle is not None:
             with self._on_stream():
                 handle.wait()
-        self.ctx.compare_slots_device_begin(self.k, self.recv.data_ptr(), self.world, self.n_local, self.slot_cap,
-                                            d_inter.data_ptr())
-
-    def end_collect(self, d_inter):
-        """second half of end(): wait for the partial matrix, all-reduce it"""
         from . import SpspError, ERR_OVERFLOW
+        self._overflow = False
         try:
-            self.ctx.compare_end()
-        except SpspError as e:
+            self.ctx.compare_slots_device_begin(self.k, self.recv.data_ptr(), self.world, self.n_local, self.slot_cap,
+                                                d_inter.data_ptr())
+        except SpspError as e:          # the receiver reads the slot headers first: a slot that overflowed at a sender is refused here
             if e.code != ERR_OVERFLOW:
                 raise
+            self._overflow = True
+
+    def _sum_cells(self, d_inter):
+        """reduce="cells": the partial matrices meet as packed non-zero cells (i << 48 | j << 32 | count), all-gathered;
+        every rank ends with the summed matrix.  Cell [0, 0] = number of ranks whose slots overflowed."""
+        from . import SpspError, ERR_OVERFLOW
+        n = d_inter.shape[0]
+        cnt = 0
+        if not self._overflow:
+            cap = getattr(self, "_cells_cap", max(1 << 16, 32 * n))
+            while True:
+                if getattr(self, "_cells", None) is None or self._cells.numel() < cap:
+                    self._cells = torch.zeros(cap, dtype=torch.int64, device=self.device)
+                try:
+                    cnt = self.ctx.matrix_cells_device(d_inter.data_ptr(), n, self._cells.data_ptr(), cap)
+                    break
+                except SpspError as e:
+                    if e.code != ERR_OVERFLOW:
+                        raise
+                    cap = 2 * cap
+            self._cells_cap = cap
+        staged = self.backend != "nccl" and d_inter.is_cuda             # gloo with GPU compute (tests): through the host
+        comm = torch.device("cpu") if staged else self.device
+        with self._on_stream():
+            mine = torch.tensor([cnt, 1 if self._overflow else 0], dtype=torch.int64, device=comm)
+            every = torch.zeros(2 * self.world, dtype=torch.int64, device=comm)
+            dist.all_gather_into_tensor(every, mine, group=self.group)
+            every = every.view(self.world, 2).cpu()
+            most = int(every[:, 0].max().item())
+            bad = int(every[:, 1].sum().item())
+            if most:
+                send = torch.zeros(most, dtype=torch.int64, device=comm)
+                if cnt:
+                    send[:cnt] = self._cells[:cnt].to(comm)
+                got = torch.zeros(self.world * most, dtype=torch.int64, device=comm)
+                dist.all_gather_into_tensor(got, send, group=self.group)
+                got = got.to(self.device).view(self.world, most)
+                torch.cuda.synchronize()
+                for r in range(self.world):
+                    c = int(every[r, 0].item())
+                    if r != self.rank and c:
+                        self.ctx.matrix_add_cells_device(d_inter.data_ptr(), n, got[r].data_ptr(), c)
+            if bad:
+                d_inter.view(-1)[0] = bad
+
+    def end_collect(self, d_inter):
+        """second half of end(): wait for the partial matrix, sum the partial matrices over the ranks"""
+        if not self._overflow:
+            self.ctx.compare_end()
+        if self.reduce == "cells":
+            return self._sum_cells(d_inter)
+        if self._overflow:
             d_inter.view(-1)[0] += 1
         if self.backend == "nccl" or not d_inter.is_cuda:
             with self._on_stream():

@@ -92,6 +92,16 @@ def main_slots(mode, rank, world, k, payloads, mine, counts, my_min, my_lo, per_
             d2.zero_()
             small.end(small.begin(d_min.data_ptr(), d_lo.data_ptr(), None, sk_off), d2)
         assert bool((d2.cpu() == merged).all())
+        # the partial matrices summed as sparse cells (what BASELINE configs[3] uses): every rank ends with the same matrix
+        cx = spd.SlotExchange(ctx, k, per_rank, int(sk_off[-1]), dev, reduce="cells")
+        d3 = torch.zeros_like(d_inter)
+        for _ in range(2):
+            cx.end(cx.begin(d_min.data_ptr(), d_lo.data_ptr(), None, sk_off), d3)
+        assert not cx.overflowed(d3) and bool((d3.cpu() == merged).all())
+        cx.slot_cap = 8
+        cx._alloc()
+        cx.end(cx.begin(d_min.data_ptr(), d_lo.data_ptr(), None, sk_off), d3)
+        assert cx.overflowed(d3)
         ctx.close()
     else:
         ex = spd.SlotExchange(None, k, per_rank, int(sk_off[-1]), torch.device("cpu"))
@@ -220,14 +230,14 @@ def main_nccl(rank, world):
     ok = rank != 0 or bool((full.cpu().numpy() == want).all())
     sk_off = np.zeros(per_rank + 1, dtype=np.uint64)
     sk_off[1:] = np.cumsum(counts)
-    for reduce in ("all", "scatter"):
+    for reduce in ("all", "scatter", "cells"):
         sx = spd.SlotExchange(ctx, k, per_rank, int(sk_off[-1]), dev, stream=stream, reduce=reduce)
         with torch.cuda.stream(stream):
             d2 = torch.zeros((n_total, n_total), dtype=torch.int32, device=dev)
         sx.end(sx.begin(d_min.data_ptr(), d_lo.data_ptr(), None, sk_off), d2)
         stream.synchronize()
         got = d2.cpu().numpy()
-        if reduce == "all":
+        if reduce in ("all", "cells"):
             got[0, 0] = 0                                              # the overflow tally lives in an unused cell
             ok = ok and bool((got == want).all())
         else:

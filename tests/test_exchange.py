@@ -11,6 +11,8 @@ import numpy as np
 import pytest
 
 import supersampler_amd as sp
+from oracle import oracle_py as orc
+from supersampler_amd import synth
 
 torch = pytest.importorskip("torch")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -704,3 +706,82 @@ def test_small_problem_form_respects_the_part_limit():
     for mean in ("1", "2"):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SPSP_DEBUG_SMALL_MEAN=mean), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0 and "ok" in r.stdout, (mean, r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_compare_files_over_several_contexts_equals_one_and_the_oracle(tmp_path):
+    """spsp_compare_files_multi: the comparator split by KEY over several contexts (one per device on a multi-GPU node; here
+    one, two, three and five contexts on device 0) writes the CSV bytes of the single-context driver and of the oracle's
+    comparator + printers (Comparator.cpp:39-74, 362-460): related and unrelated sketches, an empty sketch, a number of
+    files that no context count divides, query mode (rows of the first files only), k <= 32 and k > 32; bin/comparator
+    with SPSP_DEVICES="0,0" takes the same route."""
+    import gzip
+    import subprocess
+    for (k, m, s, n_files) in ((31, 11, 40.0, 23), (63, 15, 25.0, 11)):
+        rng = np.random.default_rng(900 + k)
+        anc = [synth.random_genome(rng, 60_000) for _ in range(3)]
+        paths, payloads = [], []
+        for i in range(n_files):
+            g = synth.mutate(rng, anc[i % 3], [0.0, 0.01, 0.03][(i // 3) % 3]) if i != 7 else synth.random_genome(rng, k - 2)   # file 7: no k-mer at all
+            pl = orc.sketch_fasta(synth.to_fasta(g, "g%d" % i, n_records=1 + i % 2), k, m, s)[0]
+            pth = tmp_path / ("k%d_s%02d.gz" % (k, i))
+            sp.write_gz(str(pth), pl)
+            paths.append(str(pth)); payloads.append(pl)
+        inter, card, _, _ = orc.compare(payloads)
+        want = {jac: orc.csv(jac, paths, inter, card, None, 6, 0.0) for jac in (True, False)}
+        with sp.Context(0) as ctx:
+            ctx.compare_files(paths, str(tmp_path / "one"))
+        for devs in ([0], [0, 0], [0, 0, 0], [0] * 5):
+            pre = str(tmp_path / ("multi%d_%d" % (k, len(devs))))
+            st = sp.compare_files_multi(devs, paths, pre)
+            assert st["compare_calls"] == 1
+            for jac, suf in ((True, "_jaccard.csv.gz"), (False, "_containment.csv.gz")):
+                got = gzip.open(pre + suf, "rb").read()
+                assert got == want[jac], (k, devs, suf)
+                assert got == gzip.open(str(tmp_path / "one") + suf, "rb").read()
+        # query mode: the first four files are the queries
+        qi, qc, _, _ = orc.compare(payloads, n_query=4)
+        pre = str(tmp_path / ("q%d" % k))
+        sp.compare_files_multi([0, 0, 0], paths, pre, n_query=4)
+        for jac, suf in ((True, "_jaccard.csv.gz"), (False, "_containment.csv.gz")):
+            assert gzip.open(pre + suf, "rb").read() == orc.csv(jac, paths, qi, qc, 4, 6, 0.0), (k, suf)
+    fof = tmp_path / "fof.txt"
+    fof.write_text("\n".join(paths) + "\n")
+    r = subprocess.run([os.path.join(ROOT, "bin", "comparator"), "-f", str(fof), "-o", "cli2"], cwd=tmp_path, capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, SPSP_DEVICES="0,0"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert gzip.open(tmp_path / "cli2_jaccard.csv.gz", "rb").read() == want[True]
+    assert r.stdout.split("\n")[1] == "I found %d documents" % n_files and "Comparisons done" in r.stdout
+
+
+def test_pair_matrix_cells_round_trip():
+    """spsp_matrix_cells_device / spsp_matrix_add_cells_device: the non-zero cells (i < j) of a dense matrix as packed words
+    and back; rows outside [row_first, row_limit) stay out; too little room is reported with the number needed; a cell that
+    names a sketch outside the matrix is refused."""
+    import torch
+    rng = np.random.default_rng(12)
+    n = 1500
+    dense = np.zeros((n, n), dtype=np.uint32)
+    ii, jj = rng.integers(0, n, 4000), rng.integers(0, n, 4000)
+    dense[ii, jj] = rng.integers(1, 1 << 20, 4000)
+    up = np.triu(dense, 1)
+    d = torch.from_numpy(dense.view(np.int32)).cuda()
+    d_cells = torch.zeros(8000, dtype=torch.int64, device="cuda")
+    with sp.Context(0) as ctx:
+        cnt = ctx.matrix_cells_device(d.data_ptr(), n, d_cells.data_ptr(), 8000)
+        assert cnt == int(np.count_nonzero(up))
+        cells = d_cells[:cnt].cpu().numpy().view(np.uint64)
+        back = np.zeros((n, n), dtype=np.uint32)
+        back[(cells >> np.uint64(48)).astype(np.int64), ((cells >> np.uint64(32)) & np.uint64(0xffff)).astype(np.int64)] = (cells & np.uint64(0xffffffff)).astype(np.uint32)
+        assert (back == up).all()
+        part = ctx.matrix_cells_device(d.data_ptr(), n, d_cells.data_ptr(), 8000, row_first=100, row_limit=700)
+        assert part == int(np.count_nonzero(up[100:700]))
+        with pytest.raises(sp.SpspError) as e:
+            ctx.matrix_cells_device(d.data_ptr(), n, d_cells.data_ptr(), 10)
+        assert e.value.code == sp.ERR_OVERFLOW and str(cnt) in str(e.value)
+        acc = torch.from_numpy(np.triu(dense, 1).view(np.int32).copy()).cuda()
+        ctx.matrix_cells_device(d.data_ptr(), n, d_cells.data_ptr(), 8000)
+        ctx.matrix_add_cells_device(acc.data_ptr(), n, d_cells.data_ptr(), cnt)
+        assert (acc.cpu().numpy().view(np.uint32) == 2 * up).all()
+        bad = torch.tensor([(5 << 48) | (2000 << 32) | 1], dtype=torch.int64, device="cuda")
+        with pytest.raises(sp.SpspError):
+            ctx.matrix_add_cells_device(acc.data_ptr(), n, bad.data_ptr(), 1)

@@ -29,6 +29,7 @@ int gather_superkmers_impl(spsp_ctx*, const uint8_t*, const uint64_t*, const sps
 int clean_device_impl(spsp_ctx*, const uint8_t*, uint64_t, uint8_t**, uint64_t*, uint64_t**, uint32_t*) { return SPSP_ERR_NO_DEVICE; }
 int scan_device_impl(spsp_ctx*, const spsp_params*, const uint8_t*, uint64_t, const uint64_t*, uint32_t, spsp_superkmer**, uint64_t*) { return SPSP_ERR_NO_DEVICE; }
 int compare_payloads_impl(spsp_ctx*, const uint8_t* const*, const uint64_t*, uint32_t, const int*, const uint32_t*, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint64_t*) { return SPSP_ERR_NO_DEVICE; }
+int compare_payloads_multi(spsp_ctx* const*, uint32_t, const uint8_t* const*, const uint64_t*, uint32_t, const int*, const uint32_t*, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint64_t*) { return SPSP_ERR_NO_DEVICE; }
 int check_params(const spsp_params* p) { return (p && p->m >= 1 && p->m <= 15 && p->k >= p->m && p->k <= 63) ? SPSP_OK : SPSP_ERR_ARG; }
 }  // namespace spsp
 extern "C" {
@@ -38,6 +39,8 @@ int spsp_scan(spsp_ctx*, const spsp_params*, const uint8_t*, const uint64_t*, ui
 int spsp_compare(spsp_ctx*, const spsp_sketch_view*, uint32_t, uint32_t, uint32_t*, uint64_t*) { return SPSP_ERR_NO_DEVICE; }
 int spsp_sketch_text(spsp_ctx*, const spsp_params*, double, const char*, uint64_t, uint8_t**, uint64_t*, spsp_sketch_stats*) { return SPSP_ERR_NO_DEVICE; }
 int spsp_copy_to_host(spsp_ctx*, void*, const void*, uint64_t) { return SPSP_ERR_NO_DEVICE; }
+int spsp_create(int, void*, spsp_ctx**) { return SPSP_ERR_NO_DEVICE; }
+void spsp_destroy(spsp_ctx*) {}
 }
 
 static std::string slurp(const std::string& p) {
