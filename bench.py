@@ -715,6 +715,14 @@ def main():
         except Exception as e:  # noqa: BLE001
             exchange_check = "check failed: %r" % (e,)
 
+    # BASELINE configs[3] over the ranks of this job (every rank takes part; rank 0 reports)
+    c4_dist = None
+    if use_dist and world > 1 and not args.no_extras:
+        try:
+            del d_batches[1:]
+            c4_dist = compare_config4_dist(ctx_full, dev, full_stream, rank, world, backend)
+        except Exception as e:  # noqa: BLE001
+            c4_dist = {"error": repr(e)}
     if rank == 0:
         env_set, env_why = env_report()
         value = total_kmers_per_step * args.steps / elapsed
@@ -898,6 +906,8 @@ def main():
                 out["scan_c5"] = scan_config5(ctx_full, dev, args.no_cpu_baseline, pk)
             except Exception as e:  # noqa: BLE001
                 out["scan_c5"] = {"error": repr(e)}
+        if c4_dist is not None:
+            out["compare_c4"] = c4_dist
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
@@ -1078,6 +1088,80 @@ def compare_config4(ctx, dev, skip_oracle, peak):
         out["parity_vs_oracle"] = {"sketches": sub, "pairs": sub * (sub - 1) // 2,
                                    "equal": bool((np.triu(got, 1) == np.triu(want, 1)).all() and (card == cnt[:sub]).all()),
                                    "nonzero_pairs": int(np.count_nonzero(np.triu(want, 1)))}
+    return out
+
+
+def compare_config4_dist(ctx, dev, stream, rank, world, backend):
+    """BASELINE configs[3] as it is stated: 10 000 sketches all-vs-all over the ranks of this job (what
+    Comparator::compare_sketches, Comparator.cpp:39-74, does on one thread).  Every rank synthesises the same 10 000 sketches
+    (the single-GPU leg's, seed 4) and keeps the block it would have sketched; the comparison is split BY KEY (spsp_multi.hip,
+    DESIGN.md 5): each rank deals its keys into one slot per rank (spsp_partition_keys_device), ONE RCCL all-to-all moves
+    them (each key crosses the fabric once), each rank compares every sketch's keys of its hash class with all rows owned
+    and emits the non-zero cells of its partial matrix straight from the row sums (spsp_compare_slots_cells_device), the
+    cells are all-gathered (95 000 per rank, 0.76 MB) and added up on every rank.  Timed with a barrier + device
+    synchronisation on both sides of every stage, MAX over ranks; checked against ONE device's comparison of all sketches
+    on rank 0.  BENCH_C4_SKETCHES overrides the count (rehearsals)."""
+    n = int(os.environ.get("BENCH_C4_SKETCHES", "10000"))
+    n -= n % (20 * world)
+    per = n // world
+    k, m = 31, 11
+    t0 = time.time()
+    D = synth.direct_family_sketches(n, fam_size=20, k=k, m=m, seed=4, device=dev, skm_range=(120, 360))
+    off = D.sk_off.astype(np.int64)
+    a, b = int(off[rank * per]), int(off[(rank + 1) * per])
+    my_mn, my_lo = D.minimizer[a:b].contiguous(), D.kmer_lo[a:b].contiguous()
+    my_off = (off[rank * per:(rank + 1) * per + 1] - a).astype(np.uint64)
+    ex = spd.SlotExchange(ctx, k, per, int(my_off[-1]), dev, stream=stream, reduce="cells")
+    d_inter = torch.zeros((n, n), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    setup_s = time.time() - t0
+
+    def fence():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(times=None):
+        fence(); t_a = time.perf_counter()
+        h = ex.begin(my_mn.data_ptr(), my_lo.data_ptr(), None, my_off)       # partition + all-to-all
+        ex.end_queue(h, d_inter)
+        fence(); t_b = time.perf_counter()
+        ex.end_collect(d_inter)                                                 # comparison -> cells -> all-gather -> sum
+        fence(); t_c = time.perf_counter()
+        if times is not None:
+            times.append((t_b - t_a, t_c - t_b))
+    for _ in range(2):
+        step()
+    reps, times = 5, []
+    for _ in range(reps):
+        step(times)
+    if ex.overflowed(d_inter):
+        return {"error": "exchange slots overflowed"}
+    loc = torch.tensor([sum(t[0] for t in times) / reps, sum(t[1] for t in times) / reps], dtype=torch.float64,
+                       device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(loc, op=dist.ReduceOp.MAX)
+    ex_ms, cmp_ms = float(loc[0].item()) * 1e3, float(loc[1].item()) * 1e3
+    pairs = n * (n - 1) // 2
+    total = int(off[-1])
+    out = None
+    if rank == 0:
+        # untimed: ONE device's comparison of all the sketches (what the gpu tests hold against the oracle at this shape)
+        d_ref = torch.zeros((n, n), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        ctx.compare_device(k, D.minimizer.data_ptr(), D.kmer_lo.data_ptr(), None, D.sk_off, n, 0, 1, d_ref.data_ptr())
+        torch.cuda.synchronize()
+        got = torch.triu(d_inter, 1)
+        same = bool(torch.equal(got, torch.triu(d_ref, 1)))
+        ms = ex_ms + cmp_ms
+        out = {"workload": "BASELINE configs[3]: %d sketches (500 families x 20, mu 0.001/0.01/0.05, the single-GPU leg's), %d keys, k=31 m=11, "
+                           "all-vs-all split by key over %d ranks (%d sketches and their keys per rank to begin with)" % (n, total, world, per),
+               "pairs": pairs, "ms": ms, "sketch_pairs_per_s": pairs / (ms / 1e3),
+               "stage_ms": {"partition_and_all_to_all": ex_ms, "compare_cells_all_gather_sum": cmp_ms},
+               "slot_bytes_per_peer": int(ex.slot_bytes), "keys_on_the_wire_per_rank_bytes": int(ex.slot_bytes) * (world - 1),
+               "nonzero_pairs": int(torch.count_nonzero(got).item()),
+               "exchange_check": ("sum of the ranks' partial matrices equals a one-device comparison of all %d sketches" % n) if same else "MISMATCH",
+               "timing": "barrier + device synchronisation around both stages, mean of %d, max over ranks" % reps, "setup_s": setup_s}
+    del d_inter
     return out
 
 

@@ -461,6 +461,16 @@ int spsp_compare_files_multi(const int* devices, uint32_t n_dev, const char* con
  * split is mostly zeros -- this is what crosses the fabric instead of n x n cells.  Waits for the context's stream. */
 int spsp_matrix_cells_device(spsp_ctx* ctx, const void* d_inter, uint32_t n, uint32_t row_first, uint32_t row_limit, void* d_cells,
                              uint64_t cap, uint64_t* n_cells);
+/* spsp_compare_device (every row i < n_query, all-vs-all: n_query = n) and spsp_compare_slots_device with the result
+ * returned in that sparse form.  Where the comparison's form allows it -- the partition form, all rows, one workgroup
+ * per row: every large problem -- the cells leave the row sums directly and the dense matrix is never written (d_scratch,
+ * n x n uint32, stays as it was); otherwise d_scratch receives the dense matrix and is sparsified.  SPSP_ERR_OVERFLOW
+ * with *n_cells = the room needed when there are more than cap.  Synchronous. */
+int spsp_compare_cells_device(spsp_ctx* ctx, uint32_t k, const void* d_minimizer, const void* d_kmer_lo, const void* d_kmer_hi,
+                              const uint64_t* h_sk_off, uint32_t n, uint32_t n_query, void* d_scratch, void* d_cells, uint64_t cap,
+                              uint64_t* n_cells);
+int spsp_compare_slots_cells_device(spsp_ctx* ctx, uint32_t k, const void* d_slots, uint32_t parts, uint32_t n, uint32_t slot_cap,
+                                    void* d_scratch, void* d_cells, uint64_t cap, uint64_t* n_cells);
 /* d_inter[i][j] += count for every packed cell (the collecting side of the above) */
 int spsp_matrix_add_cells_device(spsp_ctx* ctx, void* d_inter, uint32_t n, const void* d_cells, uint64_t n_cells);
 

@@ -83,7 +83,7 @@ ABI_SYMBOLS = [
     "spsp_stream_create_cus", "spsp_stream_destroy", "spsp_set_cu_count", "spsp_pack_bases_device",
     "spsp_timing_enable", "spsp_timing_sample", "spsp_timing_read", "spsp_threshold_host", "spsp_scan", "spsp_scan_device", "spsp_scan_device_begin", "spsp_scan_device_end", "spsp_scan_tail_stream", "spsp_wait_dense", "spsp_wait_stream", "spsp_scan_hits_device", "spsp_count_superkmers_device", "spsp_compare",
     "spsp_compare_device", "spsp_slot_bytes", "spsp_partition_keys_device", "spsp_compare_slots_device", "spsp_compare_device_begin", "spsp_compare_slots_device_begin", "spsp_compare_end", "spsp_fasta_clean_host", "spsp_fasta_clean_device", "spsp_fasta_clean_packed_device", "spsp_sketch_text", "spsp_sketch_build_host", "spsp_sketch_parse_host", "spsp_sketch_decode_device", "spsp_sketch_keys_device", "spsp_sketch_keys_device_begin", "spsp_sketch_keys_device_end", "spsp_sketch_keys_big_genomes", "spsp_scan_output_wait", "spsp_compare_keys_unordered", "spsp_sketch_chain_host",
-    "spsp_csv_host", "spsp_sort_csv_host", "spsp_read_file_host", "spsp_write_gz_host", "spsp_sketch_file", "spsp_compare_files", "spsp_compare_files_chatty", "spsp_stage_times_read", "spsp_measure_hbm_device", "spsp_sketch_files", "spsp_sketch_files_release", "spsp_compare_files_multi", "spsp_matrix_cells_device", "spsp_matrix_add_cells_device",
+    "spsp_csv_host", "spsp_sort_csv_host", "spsp_read_file_host", "spsp_write_gz_host", "spsp_sketch_file", "spsp_compare_files", "spsp_compare_files_chatty", "spsp_stage_times_read", "spsp_measure_hbm_device", "spsp_sketch_files", "spsp_sketch_files_release", "spsp_compare_files_multi", "spsp_matrix_cells_device", "spsp_matrix_add_cells_device", "spsp_compare_cells_device", "spsp_compare_slots_cells_device",
 ]
 
 _lib = None
@@ -186,6 +186,8 @@ def lib():
     L.spsp_compare_files_multi.restype = i32
     L.spsp_compare_files_multi.argtypes = [P(i32), u32, P(cp), u32, u32, i32, dbl, cp, i32, P(StageTimes)]
     L.spsp_matrix_cells_device.restype = i32; L.spsp_matrix_cells_device.argtypes = [vp, vp, u32, u32, u32, vp, u64, P(u64)]
+    L.spsp_compare_cells_device.restype = i32; L.spsp_compare_cells_device.argtypes = [vp, u32, vp, vp, vp, vp, u32, u32, vp, vp, u64, P(u64)]
+    L.spsp_compare_slots_cells_device.restype = i32; L.spsp_compare_slots_cells_device.argtypes = [vp, u32, vp, u32, u32, u32, vp, vp, u64, P(u64)]
     L.spsp_matrix_add_cells_device.restype = i32; L.spsp_matrix_add_cells_device.argtypes = [vp, vp, u32, vp, u64]
     _lib = L
     return L
@@ -614,6 +616,20 @@ class Context:
         """non-zero cells (i < j) of a dense pair matrix on the device as packed words i << 48 | j << 32 | count -> how many"""
         cnt = C.c_uint64()
         _check(lib().spsp_matrix_cells_device(self._h, d_inter, n, row_first, n if row_limit is None else row_limit, d_cells, cap, C.byref(cnt)))
+        return cnt.value
+
+    def compare_cells_device(self, k, d_min, d_lo, d_hi, sk_off, n, d_scratch, d_cells, cap, n_query=None):
+        """all-vs-all with the pair matrix returned as packed non-zero cells (i << 48 | j << 32 | count) -> how many"""
+        sk_off = np.ascontiguousarray(sk_off, dtype=np.uint64)
+        cnt = C.c_uint64()
+        _check(lib().spsp_compare_cells_device(self._h, k, d_min, d_lo, d_hi, sk_off.ctypes.data, n, n if n_query is None else n_query, d_scratch,
+                                               d_cells, cap, C.byref(cnt)))
+        return cnt.value
+
+    def compare_slots_cells_device(self, k, d_slots, parts, n, slot_cap, d_scratch, d_cells, cap):
+        """this rank's partial matrix of the key-partitioned split as packed non-zero cells -> how many"""
+        cnt = C.c_uint64()
+        _check(lib().spsp_compare_slots_cells_device(self._h, k, d_slots, parts, n, slot_cap, d_scratch, d_cells, cap, C.byref(cnt)))
         return cnt.value
 
     def matrix_add_cells_device(self, d_inter, n, d_cells, n_cells):

@@ -334,7 +334,9 @@ __global__ __launch_bounds__(kSparseThreads) void k_accumulate_sparse(const uint
                                                                      uint32_t cols, uint32_t copies_log2, uint32_t split,
                                                                      uint32_t* __restrict__ inter,
                                                                      const uint32_t* __restrict__ flags,
-                                                                     uint32_t* __restrict__ host_flags) {
+                                                                     uint32_t* __restrict__ host_flags,
+                                                                     unsigned long long* __restrict__ cells, unsigned long long cells_cap,
+                                                                     unsigned long long* __restrict__ cells_count) {
     extern __shared__ uint32_t s_cnt[];
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < kFlags) host_flags[threadIdx.x] = flags[threadIdx.x];
     // a part overflowed: its workgroup of k_parts_group left without writing list references, so the ones in place are
@@ -405,6 +407,25 @@ __global__ __launch_bounds__(kSparseThreads) void k_accumulate_sparse(const uint
         }
     }
     __syncthreads();
+    if (cells) {
+        // sparse result (the key-partitioned split: a rank's partial row is nearly all zeros): the row's non-zero cells
+        // leave as packed words i << 48 | j << 32 | count, one atomic per wave that has any -- the dense row is not written
+        const uint32_t lane = threadIdx.x & 63u;
+        for (uint32_t x = threadIdx.x; x < cols; x += kSparseThreads) {
+            const uint32_t col = col0 + x;
+            uint32_t v = 0;
+            if (col > i && col < n)
+                for (uint32_t k = 0; k < copies; ++k) v += s_cnt[(x << copies_log2) + k];
+            const unsigned long long hit = __ballot(v != 0);
+            if (!hit) continue;
+            const int leader = __ffsll((long long)hit) - 1;
+            unsigned long long at = 0;
+            if ((int)lane == leader) at = atomicAdd(cells_count, (unsigned long long)__popcll(hit));
+            at = __shfl(at, leader) + (unsigned long long)__popcll(hit & ((1ull << lane) - 1ull));
+            if (v && at < cells_cap) cells[at] = ((unsigned long long)i << 48) | ((unsigned long long)col << 32) | v;
+        }
+        return;
+    }
     for (uint32_t x = threadIdx.x; x < cols; x += kSparseThreads) {
         const uint32_t col = col0 + x;
         if (col > i && col < n) {
@@ -907,7 +928,7 @@ static int job_mark_done(spsp_ctx* ctx) {
     SPSP_HIP(hipEventRecord(ctx->compare_done, ctx->stream));
     return SPSP_OK;
 }
-static int launch_accumulate_sparse(spsp_ctx* ctx, const ComparePlan& P, uint32_t* flags) {
+static int launch_accumulate_sparse(spsp_ctx* ctx, const ComparePlan& P, uint32_t* flags, bool may_emit_cells = false) {
     uint32_t cols = 64;
     while (cols < P.n && cols < (uint32_t)kSparseCols) cols <<= 1;
     // a row's keys are walked by ONE workgroup unless the sketches are huge (few sketches of millions of keys):
@@ -925,7 +946,12 @@ static int launch_accumulate_sparse(spsp_ctx* ctx, const ComparePlan& P, uint32_
                        ((size_t)cols << copies_log2) * 4, ctx->stream,
                        P.list_ref ? P.list_ref : ctx->c_row.as<uint32_t>(), P.where, ctx->c_matrix.as<uint16_t>(), P.sk_begin, P.sk_end,
                        P.n, P.row_first, P.row_stride, P.row_limit, cols, copies_log2, split, P.d_inter, flags,
-                       reinterpret_cast<uint32_t*>(ctx->h_scalar + 8));
+                       reinterpret_cast<uint32_t*>(ctx->h_scalar + 8),
+                       // a caller that wants the result as sparse cells (compare_cells_run) gets them straight from the row sums
+                       // when ONE workgroup makes a row (no split) -- else the dense matrix is written and sparsified afterwards
+                       (may_emit_cells && ctx->cells_req.armed && split == 1) ? ctx->cells_req.cells : (unsigned long long*)nullptr,
+                       (unsigned long long)ctx->cells_req.cap, ctx->cells_req.count);
+    ctx->cells_req.direct = may_emit_cells && ctx->cells_req.armed && split == 1;
     SPSP_HIP(hipGetLastError());
     return SPSP_OK;
 }
@@ -933,6 +959,7 @@ static int job_queue_flags(spsp_ctx* ctx);
 // partition form: prepare -> scatter -> group -> row sums, queued in one go (small problems: prepare -> scatter -> group + count)
 static int job_parts(spsp_ctx* ctx, CompareJob& J) {
     uint32_t* flags = ctx->c_flags.as<uint32_t>();
+    ctx->cells_req.direct = false;                            // (set by the row sums of the general form when they emit cells)
     int rc;
     if ((rc = ctx->c_part_cnt.reserve((size_t)J.n_parts * 4))) return rc;
     if (!J.small && (rc = ctx->c_matrix.reserve((size_t)J.n_parts * 4 * kPartCap * sizeof(uint16_t)))) return rc;     // sketch lists
@@ -959,7 +986,8 @@ static int job_parts(spsp_ctx* ctx, CompareJob& J) {
     if ((rc = ctx->ev_begin(kEvAccumulate))) return rc;
     ComparePlan PP = J.P;
     PP.list_ref = ctx->c_lref.as<uint32_t>(); PP.where = ctx->c_where.as<uint32_t>();
-    if (!(skip & 4) && (rc = launch_accumulate_sparse(ctx, PP, flags))) return rc;
+    // (an attempt whose parts overflow leaves this kernel at its first line, before any cell is emitted: the retry emits them once)
+    if (!(skip & 4) && (rc = launch_accumulate_sparse(ctx, PP, flags, true))) return rc;
     if ((rc = ctx->ev_end(kEvAccumulate))) return rc;
     return job_mark_done(ctx);
 }
@@ -990,6 +1018,7 @@ static int job_sparse(spsp_ctx* ctx, CompareJob& J) {
 
 // dictionary build: table (and row ids unless the owner's entry index serves as the row)
 static int job_front(spsp_ctx* ctx, CompareJob& J) {
+    ctx->cells_req.direct = false;                            // a colour-matrix form: the dense matrix is written
     uint32_t* flags = ctx->c_flags.as<uint32_t>();
     int rc;
     // speculative: the matrix size is known now (one row per inserted key), so it is cleared by the same launch

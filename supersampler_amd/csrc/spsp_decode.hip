@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <thread>
 #include <vector>
@@ -352,8 +353,29 @@ int compare_payloads_impl(spsp_ctx* ctx, const uint8_t* const* payloads, const u
     memset(inter, 0, (size_t)n * n * 4);
     if (sk_off[n] == 0) return SPSP_OK;
     if ((rc = ctx->c_inter.reserve((size_t)n * n * 4))) return rc;
-    SPSP_HIP(hipMemsetAsync(ctx->c_inter.p, 0, (size_t)n * n * 4, ctx->stream));
     const uint32_t k = *k_out;
+    if (n >= 1024 && n <= 65535) {
+        // a large matrix is mostly zeros (sketches of different species share no k-mer) and 4 n^2 bytes would cross PCIe:
+        // the non-zero cells come back instead, straight from the row sums (spsp_multi.hip: compare_cells_run)
+        uint64_t cap = std::max<uint64_t>(1u << 16, (uint64_t)n * 32), n_cells = 0;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            if ((rc = ctx->m_cells.reserve((size_t)cap * 8))) return rc;
+            rc = compare_cells_run(ctx, [&]() { return compare_device_begin_impl(ctx, k, ctx->c_min.as<uint32_t>(), ctx->c_lo.as<uint64_t>(), k > 32 ? ctx->c_hi.as<uint64_t>() : nullptr,
+                                                                                  sk_off.data(), n, n_query, 0, 1, ctx->c_inter.as<uint32_t>()); },
+                                   n, n_query < n ? n_query : n, ctx->c_inter.as<uint32_t>(), ctx->m_cells.as<uint64_t>(), cap, &n_cells);
+            if (rc != SPSP_ERR_OVERFLOW) break;
+            cap = n_cells;
+        }
+        if (rc) return rc;
+        std::vector<uint64_t> cells((size_t)n_cells);
+        if (n_cells) {
+            SPSP_HIP(hipMemcpyAsync(cells.data(), ctx->m_cells.p, (size_t)n_cells * 8, hipMemcpyDeviceToHost, ctx->stream));
+            SPSP_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        for (uint64_t cw : cells) inter[(size_t)(cw >> 48) * n + (size_t)((cw >> 32) & 0xffffu)] = (uint32_t)cw;
+        return SPSP_OK;
+    }
+    SPSP_HIP(hipMemsetAsync(ctx->c_inter.p, 0, (size_t)n * n * 4, ctx->stream));
     if ((rc = compare_device_impl(ctx, k, ctx->c_min.as<uint32_t>(), ctx->c_lo.as<uint64_t>(), k > 32 ? ctx->c_hi.as<uint64_t>() : nullptr,
                                   sk_off.data(), n, n_query, 0, 1, ctx->c_inter.as<uint32_t>()))) return rc;
     SPSP_HIP(hipMemcpyAsync(inter, ctx->c_inter.p, (size_t)n * n * 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <functional>
 #include <string>
 #include <utility>
 #include <vector>
@@ -114,6 +115,8 @@ struct spsp_ctx {
     bool keys_unordered = false;       // spsp_compare_keys_unordered: the comparisons of this context do not insist on sorted sketches
     uint32_t keys_genomes = 0;
     bool keys_sorted = false;          // the pending extraction promised sorted sketches (its big genomes are sorted in _end)
+    // a comparison whose caller wants the pair matrix as sparse cells (spsp_multi.hip: compare_cells_run)
+    struct CellsReq { unsigned long long* cells = nullptr; unsigned long long cap = 0; unsigned long long* count = nullptr; bool armed = false, direct = false; } cells_req;
     spsp::KeysJob keys_job;
     bool keys_expect_big = false;      // the last extraction collected on this context met a genome beyond the LDS forms
     uint32_t keys_big_genomes = 0;     // genomes of the last collected extraction that went through the global-memory stages (spsp_bigkeys.hip)
@@ -242,6 +245,10 @@ int compare_slots_begin_impl(spsp_ctx* ctx, uint32_t k, const uint8_t* d_slots, 
                              uint32_t* d_inter);
 // sparse form of a pair matrix (spsp_multi.hip): non-zero cells (i < j) as i << 48 | j << 32 | count
 int matrix_cells_impl(spsp_ctx* ctx, const uint32_t* d_inter, uint32_t n, uint32_t row_first, uint32_t row_limit, uint64_t* d_cells,
+                      uint64_t cap, uint64_t* n_cells);
+// queue a comparison with begin() and return its pair matrix as sparse cells: straight from the row sums where the form allows
+// it (d_scratch then stays unwritten), else through the dense matrix in d_scratch (n x n uint32) and k_matrix_cells
+int compare_cells_run(spsp_ctx* ctx, const std::function<int()>& begin, uint32_t n, uint32_t row_limit, uint32_t* d_scratch, uint64_t* d_cells,
                       uint64_t cap, uint64_t* n_cells);
 // decode + all-vs-all over several contexts (one per device, or several on one): the device half of spsp_compare_files_multi
 int compare_payloads_multi(spsp_ctx* const* ctxs, uint32_t n_ctx, const uint8_t* const* payloads, const uint64_t* lens, uint32_t n,

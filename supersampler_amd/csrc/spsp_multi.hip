@@ -20,6 +20,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <thread>
 #include <vector>
@@ -96,6 +97,30 @@ int matrix_cells_impl(spsp_ctx* ctx, const uint32_t* d_inter, uint32_t n, uint32
     hipLaunchKernelGGL(k_matrix_cells, dim3((n + 1023) / 1024, row_limit - row_first), dim3(256), 0, ctx->stream, d_inter, n, row_first, row_limit,
                        reinterpret_cast<unsigned long long*>(d_cells), (unsigned long long)cap, d_count);
     SPSP_HIP(hipGetLastError());
+    SPSP_HIP(hipMemcpyAsync(ctx->h_scalar + 12, d_count, 8, hipMemcpyDeviceToHost, ctx->stream));
+    SPSP_HIP(hipStreamSynchronize(ctx->stream));
+    *n_cells = ctx->h_scalar[12];
+    if (*n_cells > cap) { set_error("the matrix has %llu non-zero cells, room was given for %llu", (unsigned long long)*n_cells, (unsigned long long)cap); return SPSP_ERR_OVERFLOW; }
+    return SPSP_OK;
+}
+
+int compare_cells_run(spsp_ctx* ctx, const std::function<int()>& begin, uint32_t n, uint32_t row_limit, uint32_t* d_scratch, uint64_t* d_cells,
+                      uint64_t cap, uint64_t* n_cells) {
+    if (n > 65535) { set_error("at most 65535 sketches (the packed cell holds two 16-bit sketch numbers; Comparator.h:26 has the same bound)"); return SPSP_ERR_ARG; }
+    *n_cells = 0;
+    int rc;
+    if ((rc = ctx->c_flags.reserve(64))) return rc;
+    unsigned long long* d_count = reinterpret_cast<unsigned long long*>(ctx->c_flags.as<uint32_t>() + 14);
+    SPSP_HIP(hipMemsetAsync(d_count, 0, 8, ctx->stream));
+    ctx->cells_req.cells = reinterpret_cast<unsigned long long*>(d_cells); ctx->cells_req.cap = cap; ctx->cells_req.count = d_count;
+    ctx->cells_req.armed = row_limit >= n;                         // (query mode: rows are limited by the sparsifier, through the dense matrix)
+    ctx->cells_req.direct = false;
+    rc = begin();
+    if (!rc) rc = compare_end_impl(ctx);
+    const bool direct = ctx->cells_req.direct;
+    ctx->cells_req = spsp_ctx::CellsReq{};
+    if (rc) return rc;
+    if (!direct) return matrix_cells_impl(ctx, d_scratch, n, 0, row_limit, d_cells, cap, n_cells);
     SPSP_HIP(hipMemcpyAsync(ctx->h_scalar + 12, d_count, 8, hipMemcpyDeviceToHost, ctx->stream));
     SPSP_HIP(hipStreamSynchronize(ctx->stream));
     *n_cells = ctx->h_scalar[12];
@@ -261,6 +286,8 @@ int compare_payloads_multi(spsp_ctx* const* ctxs, uint32_t n_ctx, const uint8_t*
         S.cap = need;
     }
     const uint64_t slot_sz = slot_bytes(S.per, S.cap, S.k);
+    std::vector<std::vector<uint64_t>> host_cells(n_ctx);
+    std::vector<uint64_t> n_cells(n_ctx, 0);
     rc = run_stage(n_ctx, S, [&](uint32_t d) -> int {
         spsp_ctx* c = ctxs[d];
         SPSP_HIP(hipSetDevice(c->device));
@@ -271,39 +298,34 @@ int compare_payloads_multi(spsp_ctx* const* ctxs, uint32_t n_ctx, const uint8_t*
             if (ctxs[s]->device == c->device) SPSP_HIP(hipMemcpyAsync(dst, src, slot_sz, hipMemcpyDeviceToDevice, c->stream));
             else SPSP_HIP(hipMemcpyPeerAsync(dst, c->device, src, ctxs[s]->device, slot_sz, c->stream));
         }
-        // D: every sketch's keys of this class, every row owned (query mode: the rows of the query sketches)
+        // D + E: every sketch's keys of this class, every row owned; the partial matrix is sparse: its non-zero cells leave
+        // the row sums as packed words (query mode: through the dense matrix, rows of the query sketches only)
         int r;
         const size_t cells_n = (size_t)NP * NP;
         if ((r = c->c_inter.reserve(cells_n * 4))) return r;
-        SPSP_HIP(hipMemsetAsync(c->c_inter.p, 0, cells_n * 4, c->stream));
-        if ((r = compare_slots_begin_impl(c, S.k, c->m_recv.as<uint8_t>(), n_ctx, S.per, S.cap, c->c_inter.as<uint32_t>()))) return r;
-        if ((r = compare_end_impl(c))) return r;
+        const uint32_t row_limit = (uint32_t)std::min<uint64_t>(NP, n_query);
+        uint64_t cap = std::max<uint64_t>(1u << 16, (uint64_t)NP * 32);
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            if ((r = c->m_cells.reserve((size_t)cap * 8))) return r;
+            r = compare_cells_run(c, [&]() { return compare_slots_begin_impl(c, S.k, c->m_recv.as<uint8_t>(), n_ctx, S.per, S.cap, c->c_inter.as<uint32_t>()); },
+                                  (uint32_t)NP, row_limit, c->c_inter.as<uint32_t>(), c->m_cells.as<uint64_t>(), cap, &n_cells[d]);
+            if (r != SPSP_ERR_OVERFLOW) break;
+            cap = n_cells[d];
+        }
+        if (r) return r;
+        host_cells[d].resize((size_t)n_cells[d]);
+        if (n_cells[d]) {
+            SPSP_HIP(hipMemcpyAsync(host_cells[d].data(), c->m_cells.p, (size_t)n_cells[d] * 8, hipMemcpyDeviceToHost, c->stream));
+            SPSP_HIP(hipStreamSynchronize(c->stream));
+        }
         return SPSP_OK;
     });
     if (rc) return rc;
-    // E: the partial matrices are sparse: their non-zero cells come to the host (one context after the other adds its own)
-    for (uint32_t d = 0; d < n_ctx; ++d) {
-        spsp_ctx* c = ctxs[d];
-        SPSP_HIP(hipSetDevice(c->device));
-        uint64_t cap = std::max<uint64_t>(1u << 16, (uint64_t)NP * 32), n_cells = 0;
-        const uint32_t row_limit = (uint32_t)std::min<uint64_t>(NP, n_query);
-        for (int attempt = 0; attempt < 2; ++attempt) {
-            if ((rc = c->m_cells.reserve((size_t)cap * 8))) return rc;
-            rc = matrix_cells_impl(c, c->c_inter.as<uint32_t>(), (uint32_t)NP, 0, row_limit, c->m_cells.as<uint64_t>(), cap, &n_cells);
-            if (rc != SPSP_ERR_OVERFLOW) break;
-            cap = n_cells;
-        }
-        if (rc) return rc;
-        std::vector<uint64_t> cells((size_t)n_cells);
-        if (n_cells) {
-            SPSP_HIP(hipMemcpyAsync(cells.data(), c->m_cells.p, (size_t)n_cells * 8, hipMemcpyDeviceToHost, c->stream));
-            SPSP_HIP(hipStreamSynchronize(c->stream));
-        }
-        for (uint64_t cw : cells) {
+    for (uint32_t d = 0; d < n_ctx; ++d)
+        for (uint64_t cw : host_cells[d]) {
             const uint32_t i = (uint32_t)(cw >> 48), j = (uint32_t)(cw >> 32) & 0xffffu;
             if (i < n && j < n) inter[(size_t)i * n + j] += (uint32_t)cw;      // (exchange numbers >= n are the padding of the last block: no keys, no cells)
         }
-    }
     return SPSP_OK;
 }
 
@@ -318,6 +340,25 @@ int spsp_matrix_cells_device(spsp_ctx* ctx, const void* d_inter, uint32_t n, uin
     if (!ctx || !d_inter || !n_cells || (cap && !d_cells)) { set_error("NULL argument"); return SPSP_ERR_ARG; }
     SPSP_HIP(hipSetDevice(ctx->device));
     return matrix_cells_impl(ctx, (const uint32_t*)d_inter, n, row_first, row_limit, (uint64_t*)d_cells, cap, n_cells);
+}
+
+int spsp_compare_slots_cells_device(spsp_ctx* ctx, uint32_t k, const void* d_slots, uint32_t parts, uint32_t n, uint32_t slot_cap, void* d_scratch,
+                                    void* d_cells, uint64_t cap, uint64_t* n_cells) {
+    if (!ctx || !d_slots || !d_scratch || !n_cells || (cap && !d_cells)) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    SPSP_HIP(hipSetDevice(ctx->device));
+    const uint64_t N = (uint64_t)parts * n;
+    if (N > 65535) { set_error("at most 65535 sketches"); return SPSP_ERR_ARG; }
+    return compare_cells_run(ctx, [&]() { return compare_slots_begin_impl(ctx, k, (const uint8_t*)d_slots, parts, n, slot_cap, (uint32_t*)d_scratch); }, (uint32_t)N, (uint32_t)N,
+                             (uint32_t*)d_scratch, (uint64_t*)d_cells, cap, n_cells);
+}
+
+int spsp_compare_cells_device(spsp_ctx* ctx, uint32_t k, const void* d_minimizer, const void* d_kmer_lo, const void* d_kmer_hi, const uint64_t* h_sk_off,
+                              uint32_t n, uint32_t n_query, void* d_scratch, void* d_cells, uint64_t cap, uint64_t* n_cells) {
+    if (!ctx || !h_sk_off || !d_scratch || !n_cells || (cap && !d_cells)) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    SPSP_HIP(hipSetDevice(ctx->device));
+    return compare_cells_run(ctx, [&]() { return compare_device_begin_impl(ctx, k, (const uint32_t*)d_minimizer, (const uint64_t*)d_kmer_lo, (const uint64_t*)d_kmer_hi,
+                                                                            h_sk_off, n, n_query, 0, 1, (uint32_t*)d_scratch); },
+                             n, n_query < n ? n_query : n, (uint32_t*)d_scratch, (uint64_t*)d_cells, cap, n_cells);
 }
 
 int spsp_matrix_add_cells_device(spsp_ctx* ctx, void* d_inter, uint32_t n, const void* d_cells, uint64_t n_cells) {

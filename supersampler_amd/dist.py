@@ -354,6 +354,9 @@ class SlotExchange:
                 handle.wait()
         from . import SpspError, ERR_OVERFLOW
         self._overflow = False
+        self._d_inter = d_inter
+        if self.reduce == "cells":      # the comparison and its sparse result are one synchronous call (spsp_compare_slots_cells_device): end_collect
+            return
         try:
             self.ctx.compare_slots_device_begin(self.k, self.recv.data_ptr(), self.world, self.n_local, self.slot_cap,
                                                 d_inter.data_ptr())
@@ -368,19 +371,27 @@ class SlotExchange:
         from . import SpspError, ERR_OVERFLOW
         n = d_inter.shape[0]
         cnt = 0
-        if not self._overflow:
-            cap = getattr(self, "_cells_cap", max(1 << 16, 32 * n))
-            while True:
-                if getattr(self, "_cells", None) is None or self._cells.numel() < cap:
-                    self._cells = torch.zeros(cap, dtype=torch.int64, device=self.device)
-                try:
-                    cnt = self.ctx.matrix_cells_device(d_inter.data_ptr(), n, self._cells.data_ptr(), cap)
-                    break
-                except SpspError as e:
-                    if e.code != ERR_OVERFLOW:
-                        raise
+        cap = getattr(self, "_cells_cap", max(1 << 16, 32 * n))
+        while True:
+            if getattr(self, "_cells", None) is None or self._cells.numel() < cap:
+                self._cells = torch.zeros(cap, dtype=torch.int64, device=self.device)
+            try:
+                # this rank's partial matrix: its non-zero cells straight from the row sums (d_inter is scratch during the call)
+                cnt = self.ctx.compare_slots_cells_device(self.k, self.recv.data_ptr(), self.world, self.n_local, self.slot_cap, d_inter.data_ptr(),
+                                                          self._cells.data_ptr(), cap)
+                break
+            except SpspError as e:
+                if e.code != ERR_OVERFLOW:
+                    raise
+                if "non-zero cells" in str(e):      # more cells than room: again with twice the room
                     cap = 2 * cap
-            self._cells_cap = cap
+                    continue
+                self._overflow = True               # a slot overflowed at its sender
+                break
+        self._cells_cap = cap
+        d_inter.zero_()
+        if cnt:
+            self.ctx.matrix_add_cells_device(d_inter.data_ptr(), n, self._cells.data_ptr(), cnt)
         staged = self.backend != "nccl" and d_inter.is_cuda             # gloo with GPU compute (tests): through the host
         comm = torch.device("cpu") if staged else self.device
         with self._on_stream():
@@ -407,10 +418,10 @@ class SlotExchange:
 
     def end_collect(self, d_inter):
         """second half of end(): wait for the partial matrix, sum the partial matrices over the ranks"""
-        if not self._overflow:
-            self.ctx.compare_end()
         if self.reduce == "cells":
             return self._sum_cells(d_inter)
+        if not self._overflow:
+            self.ctx.compare_end()
         if self._overflow:
             d_inter.view(-1)[0] += 1
         if self.backend == "nccl" or not d_inter.is_cuda:

@@ -67,7 +67,8 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     GPU: both ranks compute on cuda:0 and the collectives go through gloo (BENCH_BACKEND / BENCH_SHARE_GPU).  The
     whole N > 1 path of the file runs -- rank-sharded genomes, key all-gather, own rows, strips to rank 0, barrier,
     max over ranks, ONE JSON line from rank 0 -- and the line's untimed check says the collected matrix equals a
-    one-device comparison of all sketches."""
+    one-device comparison of all sketches; so does the multi-rank BASELINE configs[3] leg (`compare_c4`: the comparison
+    split by key, slots by all-to-all, partial matrices as sparse cells), here at 400 sketches."""
     import json
     env = dict(os.environ, BENCH_BACKEND="gloo", BENCH_SHARE_GPU="1", BENCH_PREWARM_STEPS="0", HSA_ENABLE_IPC_MODE_LEGACY="0",
                OMP_NUM_THREADS="1")
@@ -75,7 +76,8 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29631", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
-           "--genomes", "6", "--length", "300000", "--no-extras", "--no-cpu-baseline"]
+           "--genomes", "6", "--length", "300000", "--no-cpu-baseline"]
+    env["BENCH_C4_SKETCHES"] = "400"                         # the multi-rank configs[3] leg at a rehearsal's size
     p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
@@ -84,4 +86,7 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 4
     assert d["config"]["sketches_total"] == 12
     assert d["config"]["exchange_check"].startswith("collected strips equal"), d["config"]["exchange_check"]
-    assert "rehearsal" in d["config"] and d["value"] > 0
+    assert "rehearsal" in d["config"] and d["value"] > 0 and d["valid"] is False
+    c4 = d["compare_c4"]
+    assert c4["exchange_check"].startswith("sum of the ranks' partial matrices equals"), c4
+    assert c4["nonzero_pairs"] == 20 * 190 and c4["pairs"] == 400 * 399 // 2

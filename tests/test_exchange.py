@@ -785,3 +785,79 @@ def test_pair_matrix_cells_round_trip():
         bad = torch.tensor([(5 << 48) | (2000 << 32) | 1], dtype=torch.int64, device="cuda")
         with pytest.raises(sp.SpspError):
             ctx.matrix_add_cells_device(acc.data_ptr(), n, bad.data_ptr(), 1)
+
+
+def test_pair_matrix_as_cells_straight_from_the_row_sums(ctx, tmp_path):
+    """spsp_compare_cells_device / spsp_compare_slots_cells_device: the pair matrix as packed non-zero cells without a dense
+    matrix in between (the partition form's row sums emit them), equal to the dense spsp_compare_device result cell for
+    cell -- 2 048 configs[3]-shaped sketches all-vs-all, in query mode (through the dense matrix: rows limited), with too
+    little room (the count needed comes back), for a small problem (the LDS pair-counter form: dense, then sparsified) and
+    as the four partial matrices of a key-partitioned split; spsp_compare_files over 1 100 sketch files takes the same
+    route (n >= 1024) and writes the oracle's CSV bytes."""
+    import gzip
+    dev = torch.device("cuda", 0)
+    n = 2048
+    D = synth.direct_family_sketches(n, fam_size=16, seed=11, device=dev, skm_range=(20, 40))
+    dense = torch.zeros((n, n), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ctx.compare_device(31, D.minimizer.data_ptr(), D.kmer_lo.data_ptr(), None, D.sk_off, n, 0, 1, dense.data_ptr())
+    torch.cuda.synchronize()
+    want = np.triu(dense.cpu().numpy().view(np.uint32), 1)
+    assert np.count_nonzero(want) >= (n // 16) * 100
+
+    def unpack(cells, cnt, size):
+        c = cells[:cnt].cpu().numpy().view(np.uint64)
+        out = np.zeros((size, size), dtype=np.uint32)
+        ii, jj = (c >> np.uint64(48)).astype(np.int64), ((c >> np.uint64(32)) & np.uint64(0xffff)).astype(np.int64)
+        assert len(set(zip(ii.tolist(), jj.tolist()))) == cnt              # every cell once
+        out[ii, jj] = (c & np.uint64(0xffffffff)).astype(np.uint32)
+        return out
+    scratch = torch.full((n, n), 7, dtype=torch.int32, device=dev)
+    cells = torch.zeros(1 << 20, dtype=torch.int64, device=dev)
+    cnt = ctx.compare_cells_device(31, D.minimizer.data_ptr(), D.kmer_lo.data_ptr(), None, D.sk_off, n, scratch.data_ptr(), cells.data_ptr(), cells.numel())
+    assert cnt == np.count_nonzero(want) and (unpack(cells, cnt, n) == want).all()
+    assert int((scratch != 7).sum().item()) == 0                            # the dense matrix was never written
+    cnt_q = ctx.compare_cells_device(31, D.minimizer.data_ptr(), D.kmer_lo.data_ptr(), None, D.sk_off, n, scratch.data_ptr(), cells.data_ptr(), cells.numel(), n_query=100)
+    assert (unpack(cells, cnt_q, n)[:100] == want[:100]).all() and cnt_q == np.count_nonzero(want[:100])
+    with pytest.raises(sp.SpspError) as e:
+        ctx.compare_cells_device(31, D.minimizer.data_ptr(), D.kmer_lo.data_ptr(), None, D.sk_off, n, scratch.data_ptr(), cells.data_ptr(), 1000)
+    assert e.value.code == sp.ERR_OVERFLOW and str(cnt) in str(e.value)
+    # a small problem (<= 128 sketches: pair counters in LDS, dense result) comes back sparse all the same
+    off100 = D.sk_off[:101].copy()
+    c100 = ctx.compare_cells_device(31, D.minimizer.data_ptr(), D.kmer_lo.data_ptr(), None, off100, 100, scratch.data_ptr(), cells.data_ptr(), cells.numel())
+    assert (unpack(cells, c100, 100) == want[:100, :100]).all()
+    # key-partitioned: four ranks' partial matrices as cells add up to the whole
+    G, per = 4, n // 4
+    off = D.sk_off.astype(np.int64)
+    sends, cap = [], None
+    most = max(int(off[(r + 1) * per] - off[r * per]) for r in range(G))
+    cap = int(most / G * 1.3) + 1024
+    slot_sz = sp.slot_bytes(per, cap, 31)
+    for r in range(G):
+        a, b = int(off[r * per]), int(off[(r + 1) * per])
+        snd = torch.zeros(G * slot_sz, dtype=torch.uint8, device=dev)
+        bm, bl = D.minimizer[a:b].contiguous(), D.kmer_lo[a:b].contiguous()
+        ctx.partition_keys_device(31, bm.data_ptr(), bl.data_ptr(), None, (off[r * per:(r + 1) * per + 1] - a).astype(np.uint64), per, G, cap, snd.data_ptr())
+        torch.cuda.synchronize()
+        sends.append(snd)
+    total = torch.zeros((n, n), dtype=torch.int32, device=dev)
+    for r in range(G):
+        recv = torch.cat([sends[s][r * slot_sz:(r + 1) * slot_sz] for s in range(G)])
+        torch.cuda.synchronize()
+        c = ctx.compare_slots_cells_device(31, recv.data_ptr(), G, per, cap, scratch.data_ptr(), cells.data_ptr(), cells.numel())
+        assert 0 < c <= cnt
+        ctx.matrix_add_cells_device(total.data_ptr(), n, cells.data_ptr(), c)
+    torch.cuda.synchronize()
+    assert (np.triu(total.cpu().numpy().view(np.uint32), 1) == want).all()
+    # spsp_compare_files with n >= 1024: cells over PCIe instead of 4 n^2 bytes
+    m = 1100
+    paths, payloads = [], []
+    for i in range(m):
+        pl = D.payload(i)
+        pth = str(tmp_path / ("s%04d.gz" % i))
+        sp.write_gz(pth, pl, 1)
+        paths.append(pth); payloads.append(pl)
+    ctx.compare_files(paths, str(tmp_path / "big"))
+    inter, card, _, _ = orc.compare(payloads)
+    for jac, suf in ((True, "_jaccard.csv.gz"), (False, "_containment.csv.gz")):
+        assert gzip.open(str(tmp_path / "big") + suf, "rb").read() == orc.csv(jac, paths, inter, card, None, 6, 0.0), suf

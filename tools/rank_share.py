@@ -56,5 +56,59 @@ for form in ("block", "strided"):
         t["equal_to_full"] = bool((got[own] == full[own]).all() and (got[~own] == -1).all())
         t["share_of_full"] = round(t["pipeline_ms"] / t_full["pipeline_ms"], 3)
         out["%s_rank%d" % (form, r)] = t
+# ---- key-partitioned split
+import time  # noqa: E402
+mn_all, lo_all = D.minimizer, D.kmer_lo
+off = D.sk_off.astype(np.int64)
+blocks = []
+for sdr in range(G):
+    a, b = int(off[sdr * per]), int(off[(sdr + 1) * per])
+    blocks.append((mn_all[a:b].contiguous(), lo_all[a:b].contiguous(), (off[sdr * per:(sdr + 1) * per + 1] - a).astype(np.uint64)))
+most = max(int(x[2][-1]) for x in blocks)
+cap = int(most / G * 1.25) + 4096
+slot_sz = sp.slot_bytes(per, cap, 31)
+sends = [torch.zeros(G * slot_sz, dtype=torch.uint8, device=dev) for _ in range(G)]
+part_ms = []
+for sdr in range(G):
+    bm, bl, bo = blocks[sdr]
+    ctx.partition_keys_device(31, bm.data_ptr(), bl.data_ptr(), None, bo, per, G, cap, sends[sdr].data_ptr())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ctx.partition_keys_device(31, bm.data_ptr(), bl.data_ptr(), None, bo, per, G, cap, sends[sdr].data_ptr())
+    torch.cuda.synchronize()
+    part_ms.append((time.perf_counter() - t0) * 1e3 / reps)
+total = torch.zeros((n, n), dtype=torch.int32, device=dev)
+d_part = torch.zeros((n, n), dtype=torch.int32, device=dev)
+cells = torch.zeros(max(1 << 20, 64 * n), dtype=torch.int64, device=dev)
+keyed = {}
+for r in range(G):
+    recv = torch.cat([sends[sdr][r * slot_sz:(r + 1) * slot_sz] for sdr in range(G)])
+    torch.cuda.synchronize()
+    for _ in range(2):
+        cnt = ctx.compare_slots_cells_device(31, recv.data_ptr(), G, per, cap, d_part.data_ptr(), cells.data_ptr(), cells.numel())
+    ctx.timing_enable(True, sp.TIME_ALL)
+    ctx.timing_read()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        cnt = ctx.compare_slots_cells_device(31, recv.data_ptr(), G, per, cap, d_part.data_ptr(), cells.data_ptr(), cells.numel())
+    torch.cuda.synchronize()
+    cmp_ms = (time.perf_counter() - t0) * 1e3 / reps
+    cells_ms = 0.0                                  # (the cells leave the row sums: no pass of their own)
+    t = ctx.timing_read()
+    ctx.timing_enable(False)
+    ctx.matrix_add_cells_device(total.data_ptr(), n, cells.data_ptr(), cnt)
+    pk = lambda k: t[k + "_ms"] / max(1, t[k + "_launches"])  # noqa: E731
+    keyed["rank%d" % r] = {"partition_own_keys_ms": round(part_ms[r], 4), "compare_slots_cells_wall_ms": round(cmp_ms, 4),
+                           "compare_pipeline_ms": round(t["compare_ms"] / max(1, t["compare_calls"]), 4), "scatter_ms": round(pk("scatter"), 4),
+                           "group_ms": round(pk("group"), 4), "accumulate_ms": round(pk("accumulate"), 4), "cells": int(cnt),
+                           "share_of_full": round((part_ms[r] + cmp_ms + cells_ms) / t_full["pipeline_ms"], 3),
+                           "share_of_full_kernels_only": round((t["compare_ms"] / max(1, t["compare_calls"])) / t_full["pipeline_ms"], 3)}
+torch.cuda.synchronize()
+up = np.triu(np.ones((n, n), bool), 1)
+keyed["sum_of_partials_equals_full"] = bool((total.cpu().numpy()[up] == full[up]).all())
+keyed["slot_cap"], keyed["slot_bytes"] = cap, slot_sz
+keyed["largest_share"] = max(v["share_of_full"] for k2, v in keyed.items() if k2.startswith("rank"))
+out["key_partitioned"] = keyed
 print(json.dumps(out))
 ctx.close()
