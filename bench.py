@@ -1076,10 +1076,16 @@ def compare_config4(ctx, dev, skip_oracle, peak):
     nz = int(torch.count_nonzero(torch.triu(d_inter, 1)).item())
     out["parity_sampled_pairs"] = {"checked": checked, "mismatches": bad, "against": "numpy set intersections of the (minimizer, k-mer) keys",
                                    "nonzero_pairs": nz, "nonzero_pairs_expected": (n // 20) * 190}
+    pls = None
+    try:
+        out["compare_files"] = compare_files_config4(ctx, D, n, skip_oracle)
+        pls = out["compare_files"].pop("_payloads", None)
+    except Exception as e:  # noqa: BLE001
+        out["compare_files"] = {"error": repr(e)}
     if not skip_oracle:
         from oracle import oracle_py as orc
         sub = 1600
-        pls = [D.payload(i) for i in range(sub)]
+        pls = pls[:sub] if pls else [D.payload(i) for i in range(sub)]
         want, card, sec = orc.compare(pls, timed=True)
         got = d_inter[:sub, :sub].cpu().numpy().astype(np.uint32)
         out["cpu_baseline"] = {"sketch_pairs_per_s": (sub * (sub - 1) // 2) / sec if sec > 0 else None, "cores": 1, "kind": "port", "cpu_model": cpu_model(),
@@ -1089,6 +1095,53 @@ def compare_config4(ctx, dev, skip_oracle, peak):
                                    "equal": bool((np.triu(got, 1) == np.triu(want, 1)).all() and (card == cnt[:sub]).all()),
                                    "nonzero_pairs": int(np.count_nonzero(np.triu(want, 1)))}
     return out
+
+
+def compare_files_config4(ctx, D, n, skip_oracle):
+    """What the reference's only timer brackets (Comparator.cpp:499-509: compare_sketches + both CSV dumps) at BASELINE
+    configs[3]: the 10 000 sketches of the leg above written out as sketch files (tmpfs), then spsp_compare_files -- read +
+    gunzip on the host threads, decode + all-vs-all on the GPU (the pair matrix comes back as its non-zero cells, not as
+    400 MB), both 10^8-cell matrices formatted and gzipped (level 1, as the reference) -- with the seconds per stage; the
+    CSV bytes of a run over the first 1 600 files are held against the oracle's comparator + printers."""
+    import gzip
+    import shutil
+    import tempfile
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    tmp = tempfile.mkdtemp(prefix="spsp_c4_", dir=base)
+    try:
+        t0 = time.perf_counter()
+        pls = [D.payload(i) for i in range(n)]
+        paths = []
+        for i, pl in enumerate(pls):
+            pth = os.path.join(tmp, "s%05d.gz" % i)
+            sp.write_gz(pth, pl, 1)
+            paths.append(pth)
+        write_s = time.perf_counter() - t0
+        ctx.compare_files(paths[:64], os.path.join(tmp, "warm"))
+        ctx.stage_times(reset=True)
+        t0 = time.perf_counter()
+        ctx.compare_files(paths, os.path.join(tmp, "all"))
+        wall = time.perf_counter() - t0
+        st = ctx.stage_times(reset=True)
+        sizes = {name: os.path.getsize(os.path.join(tmp, "all_%s.csv.gz" % name)) for name in ("jaccard", "containment")}
+        out = {"workload": "the %d sketches as gzip sketch files on %s (%.1f MB) -> <o>_jaccard.csv.gz + <o>_containment.csv.gz (10^8 cells each)"
+                           % (n, base or "the temp dir", sum(os.path.getsize(x) for x in paths) / 1e6),
+               "wall_s": wall, "sketch_pairs_per_s": n * (n - 1) / 2 / wall,
+               "stage_s": {"read_gunzip": st["load_s"], "decode_compare_cells_to_host": st["compare_s"], "format_both_matrices": st["csv_s"],
+                           "gzip_and_write": st["csv_gzip_s"]},
+               "csv_gz_bytes": sizes, "files_written_s": write_s}
+        if not skip_oracle:
+            from oracle import oracle_py as orc
+            sub = 1600
+            ctx.compare_files(paths[:sub], os.path.join(tmp, "sub"))
+            inter, card, _, _ = orc.compare(pls[:sub])
+            out["csv_bytes_equal_the_oracle_on_%d_files" % sub] = bool(all(
+                gzip.open(os.path.join(tmp, "sub_%s.csv.gz" % name), "rb").read() == orc.csv(jac, paths[:sub], inter, card, None, 6, 0.0)
+                for jac, name in ((True, "jaccard"), (False, "containment"))))
+        out["_payloads"] = pls
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def compare_config4_dist(ctx, dev, stream, rank, world, backend):

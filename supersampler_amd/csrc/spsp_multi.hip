@@ -211,7 +211,8 @@ int run_stage(uint32_t n_ctx, MultiShared& S, F&& body) {
 
 int compare_payloads_multi(spsp_ctx* const* ctxs, uint32_t n_ctx, const uint8_t* const* payloads, const uint64_t* lens, uint32_t n,
                            const int* extra_has, const uint32_t* extra_mn, uint32_t n_query, uint32_t* k_out, uint32_t* m_out,
-                           uint32_t* inter, uint64_t* card) {
+                           uint32_t* inter, uint64_t* card, bool* mirrored) {
+    if (mirrored) *mirrored = false;
     if (n_ctx == 0 || n_ctx > kMaxParts) { set_error("1..%u contexts", kMaxParts); return SPSP_ERR_ARG; }
     if (n == 0) { *k_out = *m_out = 0; return SPSP_OK; }
     MultiShared S;
@@ -222,7 +223,7 @@ int compare_payloads_multi(spsp_ctx* const* ctxs, uint32_t n_ctx, const uint8_t*
     S.sk_off.assign(n_ctx, std::vector<uint64_t>((size_t)S.per + 1, 0));
     S.rc.assign(n_ctx, SPSP_OK); S.err.assign(n_ctx, std::string());
     std::vector<uint32_t> ks(n_ctx, 0), ms(n_ctx, 0);
-    memset(inter, 0, (size_t)n * n * 4);
+    // (inter is zero on entry)
     // peers: every context's device reads the others' slots
     for (uint32_t a = 0; a < n_ctx; ++a)
         for (uint32_t b = 0; b < n_ctx; ++b) {
@@ -324,8 +325,12 @@ int compare_payloads_multi(spsp_ctx* const* ctxs, uint32_t n_ctx, const uint8_t*
     for (uint32_t d = 0; d < n_ctx; ++d)
         for (uint64_t cw : host_cells[d]) {
             const uint32_t i = (uint32_t)(cw >> 48), j = (uint32_t)(cw >> 32) & 0xffffu;
-            if (i < n && j < n) inter[(size_t)i * n + j] += (uint32_t)cw;      // (exchange numbers >= n are the padding of the last block: no keys, no cells)
+            if (i < n && j < n) {                                              // (exchange numbers >= n are the padding of the last block: no keys, no cells)
+                inter[(size_t)i * n + j] += (uint32_t)cw;
+                if (mirrored) inter[(size_t)j * n + i] += (uint32_t)cw;        // (the printers then read rows only)
+            }
         }
+    if (mirrored) *mirrored = true;
     return SPSP_OK;
 }
 

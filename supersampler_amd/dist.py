@@ -375,6 +375,7 @@ class SlotExchange:
         while True:
             if getattr(self, "_cells", None) is None or self._cells.numel() < cap:
                 self._cells = torch.zeros(cap, dtype=torch.int64, device=self.device)
+                torch.cuda.synchronize()
             try:
                 # this rank's partial matrix: its non-zero cells straight from the row sums (d_inter is scratch during the call)
                 cnt = self.ctx.compare_slots_cells_device(self.k, self.recv.data_ptr(), self.world, self.n_local, self.slot_cap, d_inter.data_ptr(),
@@ -389,7 +390,11 @@ class SlotExchange:
                 self._overflow = True               # a slot overflowed at its sender
                 break
         self._cells_cap = cap
-        d_inter.zero_()
+        # (torch work on the context's stream, like the library calls around it: the caller's current stream may be another)
+        with self._on_stream():
+            d_inter.zero_()
+        if self.stream is None:
+            torch.cuda.synchronize()
         if cnt:
             self.ctx.matrix_add_cells_device(d_inter.data_ptr(), n, self._cells.data_ptr(), cnt)
         staged = self.backend != "nccl" and d_inter.is_cuda             # gloo with GPU compute (tests): through the host
