@@ -414,6 +414,12 @@ int spsp_sketch_file(spsp_ctx* ctx, const spsp_params* p, double rate, const cha
 typedef void (*spsp_file_callback)(void* user, uint32_t index, int phase, int rc, const spsp_sketch_stats* stats, const char* error);
 int spsp_sketch_files(int device, const spsp_params* p, double rate, const char* const* fasta_paths, const char* const* out_paths,
                       uint32_t n, uint32_t threads, spsp_file_callback cb, void* user, struct spsp_stage_times* times);
+/* The same over several GPUs of one node: the batches are dealt over the devices (slot j of the pipeline lives on
+ * devices[j mod n_dev]; up to four batches in flight per device), everything else as above -- sketching shards by genome,
+ * there is nothing to exchange.  A device may be named more than once. */
+int spsp_sketch_files_multi(const int* devices, uint32_t n_dev, const spsp_params* p, double rate, const char* const* fasta_paths,
+                            const char* const* out_paths, uint32_t n, uint32_t threads, spsp_file_callback cb, void* user,
+                            struct spsp_stage_times* times);
 /* spsp_sketch_files keeps its contexts, device buffers and pinned staging buffers for the next call on the same device
  * (setting them up costs more than sketching a hundred genomes).  This releases the idle ones (device < 0: of every
  * device); optional -- a process that simply exits never needs it. */

@@ -83,7 +83,7 @@ ABI_SYMBOLS = [
     "spsp_stream_create_cus", "spsp_stream_destroy", "spsp_set_cu_count", "spsp_pack_bases_device",
     "spsp_timing_enable", "spsp_timing_sample", "spsp_timing_read", "spsp_threshold_host", "spsp_scan", "spsp_scan_device", "spsp_scan_device_begin", "spsp_scan_device_end", "spsp_scan_tail_stream", "spsp_wait_dense", "spsp_wait_stream", "spsp_scan_hits_device", "spsp_count_superkmers_device", "spsp_compare",
     "spsp_compare_device", "spsp_slot_bytes", "spsp_partition_keys_device", "spsp_compare_slots_device", "spsp_compare_device_begin", "spsp_compare_slots_device_begin", "spsp_compare_end", "spsp_fasta_clean_host", "spsp_fasta_clean_device", "spsp_fasta_clean_packed_device", "spsp_sketch_text", "spsp_sketch_build_host", "spsp_sketch_parse_host", "spsp_sketch_decode_device", "spsp_sketch_keys_device", "spsp_sketch_keys_device_begin", "spsp_sketch_keys_device_end", "spsp_sketch_keys_big_genomes", "spsp_scan_output_wait", "spsp_compare_keys_unordered", "spsp_sketch_chain_host",
-    "spsp_csv_host", "spsp_sort_csv_host", "spsp_read_file_host", "spsp_write_gz_host", "spsp_sketch_file", "spsp_compare_files", "spsp_compare_files_chatty", "spsp_stage_times_read", "spsp_measure_hbm_device", "spsp_sketch_files", "spsp_sketch_files_release", "spsp_compare_files_multi", "spsp_matrix_cells_device", "spsp_matrix_add_cells_device", "spsp_compare_cells_device", "spsp_compare_slots_cells_device",
+    "spsp_csv_host", "spsp_sort_csv_host", "spsp_read_file_host", "spsp_write_gz_host", "spsp_sketch_file", "spsp_compare_files", "spsp_compare_files_chatty", "spsp_stage_times_read", "spsp_measure_hbm_device", "spsp_sketch_files", "spsp_sketch_files_multi", "spsp_sketch_files_release", "spsp_compare_files_multi", "spsp_matrix_cells_device", "spsp_matrix_add_cells_device", "spsp_compare_cells_device", "spsp_compare_slots_cells_device",
 ]
 
 _lib = None
@@ -181,6 +181,8 @@ def lib():
     L.spsp_stage_times_read.restype = i32; L.spsp_stage_times_read.argtypes = [vp, P(StageTimes), i32]
     L.spsp_sketch_files.restype = i32
     L.spsp_sketch_files.argtypes = [i32, P(Params), dbl, P(cp), P(cp), u32, u32, FILE_CALLBACK, vp, P(StageTimes)]
+    L.spsp_sketch_files_multi.restype = i32
+    L.spsp_sketch_files_multi.argtypes = [P(i32), u32, P(Params), dbl, P(cp), P(cp), u32, u32, FILE_CALLBACK, vp, P(StageTimes)]
     L.spsp_sketch_files_release.restype = None; L.spsp_sketch_files_release.argtypes = [i32]
     L.spsp_measure_hbm_device.restype = i32; L.spsp_measure_hbm_device.argtypes = [vp, u64, u32, P(HbmRates)]
     L.spsp_compare_files_multi.restype = i32
@@ -323,7 +325,7 @@ def write_gz(path, data, level=9):
     _check(lib().spsp_write_gz_host(path.encode(), data, len(data), level))
 
 
-def sketch_files(fasta_paths, out_paths, k=31, m=11, s=1000.0, abundance=1, threads=8, device=0, flags=SPSP_SCAN_DEFAULT):
+def sketch_files(fasta_paths, out_paths, k=31, m=11, s=1000.0, abundance=1, threads=8, device=0, flags=SPSP_SCAN_DEFAULT, devices=None):
     """many FASTA files -> many sketch files on `threads` workers, one context (HIP stream) each (spsp_sketch_files).
     Returns (per-file list of (rc, stats dict or None, error text or None), stage seconds summed over the workers)."""
     n = len(fasta_paths)
@@ -340,7 +342,11 @@ def sketch_files(fasta_paths, out_paths, k=31, m=11, s=1000.0, abundance=1, thre
             res[i] = (rc, {f: getattr(st.contents, f) for f, _ in SketchStats._fields_} if rc == 0 else None, err.decode() if err else None)
     cb = FILE_CALLBACK(on_file)
     times = StageTimes()
-    rc = lib().spsp_sketch_files(device, C.byref(p), float(s), ins, outs, n, threads, cb, None, C.byref(times))
+    if devices is not None:         # spsp_sketch_files_multi: the batches dealt over these devices
+        devs = (C.c_int * len(devices))(*devices)
+        rc = lib().spsp_sketch_files_multi(devs, len(devices), C.byref(p), float(s), ins, outs, n, threads, cb, None, C.byref(times))
+    else:
+        rc = lib().spsp_sketch_files(device, C.byref(p), float(s), ins, outs, n, threads, cb, None, C.byref(times))
     if rc != 0 and not any(r is not None and r[0] != 0 for r in res):
         _check(rc)
     return res, {f: getattr(times, f) for f, _ in StageTimes._fields_}, started

@@ -110,7 +110,7 @@ int spsp_sketch_file(spsp_ctx* ctx, const spsp_params* p, double rate, const cha
 
 // File-of-files loop, one context per worker and one GPU job per file (spsp_sketch_file): the form used with -a > 1 (the
 // abundance pass counts k-mers per file) and as the A/B partner of the batched pipeline below (SPSP_FILES_PER_WORKER=1).
-static int sketch_files_per_worker(int device, const spsp_params* p, double rate, const char* const* fasta_paths, const char* const* out_paths,
+static int sketch_files_per_worker(const std::vector<int>& devices, const spsp_params* p, double rate, const char* const* fasta_paths, const char* const* out_paths,
                       uint32_t n, uint32_t threads, spsp_file_callback cb, void* user, spsp_stage_times* times) {
     if (!p || (n && (!fasta_paths || !out_paths))) { set_error("NULL argument"); return SPSP_ERR_ARG; }
     int rc0 = spsp::check_params(p);
@@ -126,7 +126,7 @@ static int sketch_files_per_worker(int device, const spsp_params* p, double rate
     auto work = [&](uint32_t w) {
         spsp_ctx* ctx = nullptr;
         memset(&per[w], 0, sizeof per[w]);
-        if ((worker_rc[w] = spsp_create(device, nullptr, &ctx))) { worker_err[w] = spsp_last_error(); return; }
+        if ((worker_rc[w] = spsp_create(devices[w % devices.size()], nullptr, &ctx))) { worker_err[w] = spsp_last_error(); return; }   // workers dealt over the devices
         for (;;) {
             uint32_t i;
             {   // named critical section `fof` of the reference (:776-786): dequeue + the caller's "started" line, in list order
@@ -205,13 +205,14 @@ struct PipeSlot {
     uint8_t* compact = nullptr;
     uint32_t* coff = nullptr;
     bool busy = false;
+    int device = 0;              // the device its context lives on
 };
 
 class FilePipeline {
 public:
-    FilePipeline(int device, const spsp_params* p, double rate, const char* const* in, const char* const* out, uint32_t n, uint32_t threads,
+    FilePipeline(const std::vector<int>& devices, const spsp_params* p, double rate, const char* const* in, const char* const* out, uint32_t n, uint32_t threads,
                  spsp_file_callback cb, void* user)
-        : device_(device), p_(*p), rate_(rate), in_(in), out_(out), n_(n), threads_(threads), cb_(cb), user_(user) {}
+        : devices_(devices), p_(*p), rate_(rate), in_(in), out_(out), n_(n), threads_(threads), cb_(cb), user_(user) {}
 
     int run(spsp_stage_times* times) {
         // sizes decide how many files travel together: batches of ~1/12 of the job, between 8 and 32 MB of text (pinning
@@ -229,12 +230,16 @@ public:
         const double t_setup0 = now_s();
         // batches in flight: with one worker nothing overlaps the host's work anyway (and every slot costs a context, a
         // pinned slab and device buffers, which a short-lived process pays for in full)
-        const uint32_t n_slots = std::min<uint32_t>(std::min<uint32_t>(4, threads_), n_);
+        // (several devices: the batches are dealt over them, slot j on device j mod n -- up to four in flight per device)
+        const uint32_t n_slots = std::min<uint32_t>(std::min<uint32_t>(4 * (uint32_t)devices_.size(), threads_), n_);
         slots_.resize(n_slots);
-        for (auto& s : slots_) {
-            s = take_slot(device_);
+        for (size_t j = 0; j < slots_.size(); ++j) {
+            auto& s = slots_[j];
+            const int dev = devices_[j % devices_.size()];
+            s = take_slot(dev);
+            s->device = dev;
             if (!s->ctx) {
-                const int rc = spsp_create(device_, nullptr, &s->ctx);
+                const int rc = spsp_create(dev, nullptr, &s->ctx);
                 if (rc) { fatal_rc_ = rc; fatal_err_ = spsp_last_error(); break; }
             }
             s->ctx->stages = spsp_stage_times{};
@@ -259,7 +264,8 @@ public:
             }
             free(s->compact); free(s->coff); s->compact = nullptr; s->coff = nullptr;
             std::vector<PipeFile>().swap(s->files);
-            give_slot(device_, std::move(s));
+            const int dev = s->device;
+            give_slot(dev, std::move(s));
         }
         if (times) { times->read_s = read_s_; times->build_s = build_s_; times->gzip_s = gzip_s_; times->sketch_files = done_files_; }
         if (getenv("SPSP_DEBUG_PIPE_TIMES"))
@@ -395,7 +401,7 @@ private:
         }
         s.total = at;
         if (s.slab_cap < at + 64) {
-            (void)hipSetDevice(device_);
+            (void)hipSetDevice(s.device);
             if (s.slab) { (void)hipStreamSynchronize(s.ctx->stream); (void)hipHostFree(s.slab); s.slab = nullptr; s.slab_cap = 0; }
             const size_t cap = (size_t)std::max<uint64_t>(at + at / 8 + 64, budget_ + budget_ / 4);
             const double t_slab = now_s();
@@ -451,7 +457,7 @@ private:
         s.sk.clear(); s.rec_off.clear();
         auto run = [&]() -> int {
             if (s.total == 0) return SPSP_OK;
-            SPSP_HIP(hipSetDevice(device_));
+            SPSP_HIP(hipSetDevice(s.device));
             double t0 = now_s(), t1;
             int r;
             if ((r = ctx->i_text.reserve((size_t)s.total + 64))) return r;
@@ -568,7 +574,7 @@ private:
 
     void add_time(double& acc, double dt) { std::lock_guard<std::mutex> g(time_m_); acc += dt; }
 
-    int device_;
+    std::vector<int> devices_;
     spsp_params p_;
     double rate_;
     const char* const* in_;
@@ -594,9 +600,10 @@ private:
 
 void spsp_sketch_files_release(int device) { FilePipeline::release_idle(device); }
 
-int spsp_sketch_files(int device, const spsp_params* p, double rate, const char* const* fasta_paths, const char* const* out_paths,
-                      uint32_t n, uint32_t threads, spsp_file_callback cb, void* user, spsp_stage_times* times) {
-    if (!p || (n && (!fasta_paths || !out_paths))) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+int spsp_sketch_files_multi(const int* devices, uint32_t n_dev, const spsp_params* p, double rate, const char* const* fasta_paths, const char* const* out_paths,
+                            uint32_t n, uint32_t threads, spsp_file_callback cb, void* user, spsp_stage_times* times) {
+    if (!devices || n_dev == 0 || n_dev > 64 || !p || (n && (!fasta_paths || !out_paths))) { set_error("NULL argument (or not 1..64 devices)"); return SPSP_ERR_ARG; }
+    const std::vector<int> device(devices, devices + n_dev);
     const int rc0 = spsp::check_params(p);
     if (rc0) return rc0;
     if (threads == 0) threads = 1;
@@ -606,6 +613,11 @@ int spsp_sketch_files(int device, const spsp_params* p, double rate, const char*
     if (times) memset(times, 0, sizeof *times);
     FilePipeline pipe(device, p, rate, fasta_paths, out_paths, n, threads, cb, user);
     return pipe.run(times);
+}
+
+int spsp_sketch_files(int device, const spsp_params* p, double rate, const char* const* fasta_paths, const char* const* out_paths,
+                      uint32_t n, uint32_t threads, spsp_file_callback cb, void* user, spsp_stage_times* times) {
+    return spsp_sketch_files_multi(&device, 1, p, rate, fasta_paths, out_paths, n, threads, cb, user, times);
 }
 
 

@@ -4,6 +4,7 @@
 #include <getopt.h>
 #include <sys/stat.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -150,7 +151,20 @@ int main(int argc, char** argv) {
         vector<const char*> in, out;
         for (auto& f : run.files) in.push_back(f.c_str());
         for (auto& f : run.outs) out.push_back(f.c_str());
-        const int rc = spsp_sketch_files(0, &P, s, in.data(), out.data(), (uint32_t)in.size(), threads, cb, &run, nullptr);
+        // devices: SPSP_DEVICES="0,1,..." names them; else every visible GPU once there are enough files to deal (sketching
+        // shards by genome: spsp_sketch_files_multi deals the batches, nothing is exchanged)
+        vector<int> devices;
+        if (const char* e = getenv("SPSP_DEVICES")) {
+            istringstream is(e);
+            string tok;
+            while (getline(is, tok, ',')) if (!tok.empty()) devices.push_back(atoi(tok.c_str()));
+        }
+        if (devices.empty()) {
+            const int visible = spsp_device_count();
+            const int use = std::max(1, std::min(visible, (int)(in.size() / 16)));
+            for (int d = 0; d < use; ++d) devices.push_back(d);
+        }
+        const int rc = spsp_sketch_files_multi(devices.data(), (uint32_t)devices.size(), &P, s, in.data(), out.data(), (uint32_t)in.size(), threads, cb, &run, nullptr);
         if (rc == SPSP_ERR_NO_DEVICE || rc == SPSP_ERR_HIP) { cout << "GPU unavailable: " << spsp_last_error() << endl; run.gpu_ok = false; }
     };
 

@@ -1375,3 +1375,35 @@ def test_config3_true_shape_sketched_on_device_equals_oracle(ctx):
                 o = np.lexsort((y, x))
                 x, y = x[o], y[o]
             assert (x == w_mn).all() and (y == w_lo).all(), (un, g)
+
+
+def test_sketch_files_dealt_over_a_device_list(tmp_path):
+    """spsp_sketch_files_multi: the batches of the file pipeline dealt over several devices (here device 0 named twice and
+    three times: one pipeline slot per entry and round) write the oracle's payload bytes and report its statistics, with
+    -a 1 (batched pipeline) and -a 2 (one GPU job per file, workers dealt over the devices); bin/sub_sampler with
+    SPSP_DEVICES="0,0" takes the same route."""
+    k, m, s = 31, 11, 60.0
+    gs = synth.family_genomes(77, 10, 120_000, 2, [0.0, 0.01, 0.03])
+    ins, texts = [], []
+    for i, g in enumerate(gs):
+        t = synth.to_fasta(g, "g%d" % i, n_records=1 + i % 3)
+        if i == 4:
+            t = t + t.replace(b">g4", b">again")                 # every k-mer twice: -a 2 keeps them
+        pth = tmp_path / ("d%d.fa" % i)
+        pth.write_bytes(t)
+        ins.append(str(pth)); texts.append(t)
+    for ab in (1, 2):
+        want = [orc.sketch_fasta(t, k, m, s, ab) for t in texts]
+        for devs in ([0, 0], [0, 0, 0]):
+            outs = [str(tmp_path / ("o%d_%d_%d.gz" % (ab, len(devs), i))) for i in range(len(ins))]
+            res, _, _ = sp.sketch_files(ins, outs, k, m, s, abundance=ab, threads=4, devices=devs)
+            for i, (rc, st, err) in enumerate(res):
+                assert rc == 0 and sp.read_file(outs[i]) == want[i][0], (ab, devs, i, rc, err)
+                assert st["selected_kmer_number"] == want[i][1]["selected_kmer_number"]
+    (tmp_path / "fof.txt").write_text("\n".join(ins) + "\n")
+    r = subprocess.run([os.path.join(ROOT, "bin", "sub_sampler"), "-f", "fof.txt", "-k", str(k), "-m", str(m), "-s", str(int(s)), "-t", "3", "-p", "two_"],
+                       cwd=tmp_path, capture_output=True, text=True, timeout=600, env=dict(os.environ, SPSP_DEVICES="0,0"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    want = [orc.sketch_fasta(t, k, m, float(np.float32(s)))[0] for t in texts]
+    for i in range(len(ins)):
+        assert gzip.open(tmp_path / ("two_d%d.gz" % i), "rb").read() == want[i], i
