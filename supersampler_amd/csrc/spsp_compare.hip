@@ -336,13 +336,20 @@ __global__ __launch_bounds__(kSparseThreads) void k_accumulate_sparse(const uint
                                                                      const uint32_t* __restrict__ flags,
                                                                      uint32_t* __restrict__ host_flags,
                                                                      unsigned long long* __restrict__ cells, unsigned long long cells_cap,
-                                                                     unsigned long long* __restrict__ cells_count) {
+                                                                     unsigned long long* __restrict__ cells_count, uint32_t xcd_rows) {
     extern __shared__ uint32_t s_cnt[];
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < kFlags) host_flags[threadIdx.x] = flags[threadIdx.x];
     // a part overflowed: its workgroup of k_parts_group left without writing list references, so the ones in place are
     // whatever the buffer held before -- nothing may be followed from them (the host repeats the call with more parts)
     if (flags[6]) return;
-    const uint32_t i = row_first + blockIdx.y * row_stride, col0 = blockIdx.x * cols;
+    // Which row: workgroups go to the 8 XCDs round-robin by their flat number, so consecutive rows -- the members of a family,
+    // which hold the same keys and therefore fetch the SAME holder lists -- would run on eight different L2s.  With xcd_rows
+    // (= rows per XCD; grids of one column block and one slice only) XCD x takes the rows [x xcd_rows, (x + 1) xcd_rows) in
+    // order: a family's members run side by side behind one L2 and a list line comes from HBM once per family, not once per
+    // member (MI355X_MICROARCH.md: 4 MiB of L2 per XCD, not coherent across XCDs; a family's lists are ~0.25 MB).
+    uint32_t r = blockIdx.y;
+    if (xcd_rows) { r = (blockIdx.y & 7u) * xcd_rows + (blockIdx.y >> 3); if ((blockIdx.y >> 3) >= xcd_rows) return; }
+    const uint32_t i = row_first + r * row_stride, col0 = blockIdx.x * cols;
     if (i >= n || i >= row_limit) return;
     if (col0 + cols <= i + 1) return;                       // no column > i in this block
     uint64_t e0 = sk_begin[i], e1 = sk_end[i];
@@ -942,7 +949,12 @@ static int launch_accumulate_sparse(spsp_ctx* ctx, const ComparePlan& P, uint32_
     }
     uint32_t copies_log2 = 0;                                // as many copies of the counters as 64 KiB of LDS hold, up to 16
     while (copies_log2 < 4 && ((size_t)cols << (copies_log2 + 1)) * 4 <= (size_t)kSparseCols * 4) ++copies_log2;
-    hipLaunchKernelGGL(k_accumulate_sparse, dim3((P.n + cols - 1) / cols, P.n_own, split), dim3(kSparseThreads),
+    // rows of one family behind one L2 (see the kernel): when a row is ONE workgroup and there are rows enough to fill the chip
+    static const char* dbg_xcd = getenv("SPSP_DEBUG_ACC_XCD");     // "0": rows in launch order (A/B, profiles/r04_acc_xcd.md)
+    const uint32_t col_blocks = (P.n + cols - 1) / cols;
+    const bool by_xcd = col_blocks == 1 && split == 1 && P.n_own >= 512 && !(dbg_xcd && dbg_xcd[0] == '0');
+    const uint32_t xcd_rows = by_xcd ? (P.n_own + 7) / 8 : 0u;
+    hipLaunchKernelGGL(k_accumulate_sparse, dim3(col_blocks, by_xcd ? xcd_rows * 8 : P.n_own, split), dim3(kSparseThreads),
                        ((size_t)cols << copies_log2) * 4, ctx->stream,
                        P.list_ref ? P.list_ref : ctx->c_row.as<uint32_t>(), P.where, ctx->c_matrix.as<uint16_t>(), P.sk_begin, P.sk_end,
                        P.n, P.row_first, P.row_stride, P.row_limit, cols, copies_log2, split, P.d_inter, flags,
@@ -950,7 +962,7 @@ static int launch_accumulate_sparse(spsp_ctx* ctx, const ComparePlan& P, uint32_
                        // a caller that wants the result as sparse cells (compare_cells_run) gets them straight from the row sums
                        // when ONE workgroup makes a row (no split) -- else the dense matrix is written and sparsified afterwards
                        (may_emit_cells && ctx->cells_req.armed && split == 1) ? ctx->cells_req.cells : (unsigned long long*)nullptr,
-                       (unsigned long long)ctx->cells_req.cap, ctx->cells_req.count);
+                       (unsigned long long)ctx->cells_req.cap, ctx->cells_req.count, xcd_rows);
     ctx->cells_req.direct = may_emit_cells && ctx->cells_req.armed && split == 1;
     SPSP_HIP(hipGetLastError());
     return SPSP_OK;
