@@ -2,13 +2,13 @@
 # Run ON THE GPU BOX (via gpurun) from the repo root: refreshes gpurun_out/prof_<tag>/ with
 #   bench    bench line (plain run), kernel-trace summary of the same command, bench line under rocprof,
 #            FETCH_SIZE / WRITE_SIZE PMC passes (separate runs), the SQ counters of the dense kernel
-#   compare  the same for the comparator at BASELINE configs[2] scale (tests/tools/compare_bench.py 1000)
+#   compare  the same for the comparator at BASELINE configs[2], true shape (tools/c3_compare.py 1000)
 #   c4       ... at configs[3] scale on one GPU (tools/c4_compare.py 10000)
 #   c5       the configs[4]-shape scan (tools/c5_scan.py 4 4): kernel trace, FETCH/WRITE, SQ counters of k_dense_bloom
 #   fetchcal FETCH_SIZE / WRITE_SIZE per byte for known access shapes (tools/exp/exp_fetchcal)
 # usage: tools/refresh_profiles.sh <tag> [bench|compare|c4|c5|fetchcal|all]
 set -o pipefail
-tag=${1:-r03}
+tag=${1:-r04}
 what=${2:-all}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$R/gpurun_out/prof_$tag
@@ -50,11 +50,11 @@ rm -f $out/bench_FETCH_SIZE.csv $out/bench_WRITE_SIZE.csv
 echo "sq done"
 fi
 if [ "$what" = all ] || [ "$what" = compare ]; then
-cmd="python3 $R/tests/tools/compare_bench.py 1000 0"
+cmd="python3 $R/tools/c3_compare.py 1000 10"
 rm -rf /tmp/ktc && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ktc -o r -- $cmd > $out/compare_line_under_rocprof.txt 2>/dev/null || exit 1
 python3 $R/tools/prof_summary.py $(find /tmp/ktc -name "*kernel_trace.csv") $out/compare_kernel_summary.md > /dev/null
 pmc_pair cmp $cmd || exit 1
-python3 $R/tools/pmc_traffic.py $out/cmp_FETCH_SIZE.csv $out/cmp_WRITE_SIZE.csv $out/compare_pmc_hbm_traffic.json "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 tests/tools/compare_bench.py 1000 0" '{"sketches": 1000, "shape": "BASELINE configs[2]: 50 families x 20, ~5 400 keys per sketch, k=31 m=11"}' > /dev/null
+python3 $R/tools/pmc_traffic.py $out/cmp_FETCH_SIZE.csv $out/cmp_WRITE_SIZE.csv $out/compare_pmc_hbm_traffic.json "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 tools/c3_compare.py 1000 10" '{"sketches": 1000, "shape": "BASELINE configs[2] at its true shape: 1000 genomes of L ~ U[2, 8] Mbp, 50 families x 20, k=31 m=11 s=1000, sketched on the device"}' > /dev/null
 rm -f $out/cmp_FETCH_SIZE.csv $out/cmp_WRITE_SIZE.csv
 echo "compare done"
 fi
