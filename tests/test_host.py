@@ -211,6 +211,25 @@ def test_csv_large_matrix_threaded_rows_match_oracle():
         assert sp.csv(jac, names, inter, card, 10, 3, 0.05) == orc.csv(jac, names, inter, card, 10, 3, 0.05)
 
 
+def test_csv_sparse_matrix_long_zero_runs_match_oracle():
+    """a matrix of thousands of sketches is nearly all zeros: rows are written as runs of "0," copied from a constant
+    (4096 cells at a time), broken by the diagonal, a few non-zero partners and the threshold rule -- bytes equal the
+    oracle's cell-by-cell printer, also when a zero run is longer than the constant and for a row that is all zeros"""
+    rng = np.random.default_rng(8)
+    n = 4500
+    card = rng.integers(3000, 9000, size=n).astype(np.uint64)
+    inter = np.zeros((n, n), dtype=np.uint32)
+    ii, jj = rng.integers(0, n, 3000), rng.integers(0, n, 3000)
+    keep = ii < jj
+    inter[ii[keep], jj[keep]] = rng.integers(1, 3000, int(keep.sum()))
+    inter[7, :] = 0; inter[:, 7] = 0                   # sketch 7 shares nothing with anybody
+    inter[0, n - 1] = 1234                             # first row: one partner at the far end behind 4 498 zeros
+    names = ["g%d" % i for i in range(n)]
+    for jac in (True, False):
+        assert sp.csv(jac, names, inter, card, 12, 6, 0.0) == orc.csv(jac, names, inter, card, 12, 6, 0.0)
+    assert sp.csv(True, names, inter, card, n, 4, 0.2) == orc.csv(True, names, inter, card, n, 4, 0.2)
+
+
 def test_gz_io_roundtrip(tmp_path):
     data = os.urandom(1000) + b"ACGT" * 100000
     p = str(tmp_path / "x.gz")
