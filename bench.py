@@ -719,7 +719,6 @@ def main():
     c4_dist = None
     if use_dist and world > 1 and not args.no_extras:
         try:
-            del d_batches[1:]
             c4_dist = compare_config4_dist(ctx_full, dev, full_stream, rank, world, backend)
         except Exception as e:  # noqa: BLE001
             c4_dist = {"error": repr(e)}

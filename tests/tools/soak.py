@@ -209,10 +209,8 @@ def main():
             for unordered in (False, True):
                 try:
                     d_mn, d_lo, d_hi, koff = ctx.sketch_keys_device(pk, d_b.data_ptr(), len(gb), d_o.data_ptr(), d_sk, n_skm, first, unordered=unordered)
-                except sp.SpspError as e:
-                    if e.code != sp.ERR_OVERFLOW:
-                        raise
-                    continue                                      # a genome beyond the per-genome table: goes through files
+                except sp.SpspError:
+                    raise                                         # (no size is refused any more: genomes beyond the LDS forms take the table in HBM)
                 tot = int(koff[-1])
                 mn, lo = ctx.to_host(d_mn, tot, np.uint32), ctx.to_host(d_lo, tot, np.uint64)
                 hi = ctx.to_host(d_hi, tot, np.uint64) if k > 32 else np.zeros(tot, np.uint64)
@@ -281,6 +279,49 @@ def main():
                 pickle.dump({"payloads": payloads, "nq": nq, "k": k, "m": m}, open(os.path.join(ROOT, "gpurun_out", "soak_cmp.pkl"), "wb"))
                 sys.exit(1)
             n_cmp += 1
+            # the same problem as sparse cells straight from the row sums (or through the dense matrix: small problems, query rows),
+            # and -- now and then -- from sketch FILES over two or three contexts on this device (the key-partitioned split)
+            tot_keys = sum(len(x) for x in sketches)
+            if tot_keys:
+                dev = torch.device("cuda", 0)
+                use_hi = k > 32
+                d_mn = torch.from_numpy(np.concatenate([x.minimizer for x in sketches]).view(np.int32)).to(dev)
+                d_lo = torch.from_numpy(np.concatenate([x.kmer_lo for x in sketches]).view(np.int64)).to(dev)
+                d_hi = torch.from_numpy(np.concatenate([x.kmer_hi for x in sketches]).view(np.int64)).to(dev)
+                off = np.zeros(n + 1, np.uint64)
+                off[1:] = np.cumsum([len(x) for x in sketches])
+                scratch = torch.zeros((n, n), dtype=torch.int32, device=dev)
+                cells = torch.zeros(n * n + 16, dtype=torch.int64, device=dev)
+                torch.cuda.synchronize()
+                mark("cells after scan %d: n=%d nq=%d keys=%d" % (n_scan, n, nq, tot_keys))
+                cnt = ctx.compare_cells_device(k, d_mn.data_ptr(), d_lo.data_ptr(), d_hi.data_ptr() if use_hi else None, off, n, scratch.data_ptr(),
+                                               cells.data_ptr(), cells.numel(), n_query=nq)
+                cw = cells[:cnt].cpu().numpy().view(np.uint64)
+                back = np.zeros((n, n), np.uint32)
+                back[(cw >> np.uint64(48)).astype(np.int64), ((cw >> np.uint64(32)) & np.uint64(0xffff)).astype(np.int64)] = (cw & np.uint64(0xffffffff)).astype(np.uint32)
+                if not (back[:nq] == np.triu(want_inter, 1)[:nq]).all() or cnt != int(np.count_nonzero(np.triu(want_inter, 1)[:nq])):
+                    print("CELLS MISMATCH k=%d m=%d s=%g n=%d nq=%d" % (k, m, s, n, nq))
+                    sys.exit(1)
+            if n_cmp % 4 == 0:
+                import gzip
+                import shutil
+                import tempfile
+                tmp = tempfile.mkdtemp(prefix="soak_multi_")
+                try:
+                    paths = []
+                    for i, pl in enumerate(payloads):
+                        pth = os.path.join(tmp, "s%d.gz" % i)
+                        sp.write_gz(pth, pl, 1)
+                        paths.append(pth)
+                    devs = [0] * int(rng.integers(2, 4))
+                    mark("compare_files_multi after scan %d: n=%d nq=%d contexts=%d" % (n_scan, n, nq, len(devs)))
+                    sp.compare_files_multi(devs, paths, os.path.join(tmp, "m"), n_query=nq)
+                    for jac, suf in ((True, "_jaccard.csv.gz"), (False, "_containment.csv.gz")):
+                        if gzip.open(os.path.join(tmp, "m") + suf, "rb").read() != orc.csv(jac, paths, want_inter, want_card, nq, 6, 0.0):
+                            print("MULTI-CONTEXT CSV MISMATCH k=%d m=%d s=%g n=%d nq=%d contexts=%d" % (k, m, s, n, nq, len(devs)))
+                            sys.exit(1)
+                finally:
+                    shutil.rmtree(tmp, ignore_errors=True)
     sp.sketch_files_release()
     print("soak ok: %d scans, %d sketch payloads, %d comparisons, %d exchanges + CSV pairs, %d row-partitioned comparisons, %d key extractions, %d files through the pipeline in %.0f s"
           % (n_scan, n_sk, n_cmp, n_ex, n_rows, n_keys, n_files, time.time() - t0))
