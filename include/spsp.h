@@ -383,6 +383,13 @@ int spsp_csv_host(int jaccard, const char* const* names, uint32_t n, uint32_t n_
                   const uint32_t* inter, const uint64_t* card, int precision, double min_threshold,
                   char** text, uint64_t* len);
 
+/* The same two printers from the SPARSE form of the pair matrix: `cells` = its non-zero entries as packed words
+ * i << 48 | j << 32 | count (i < j < n <= 65535, every pair at most once, any order: what spsp_compare_cells_device
+ * returns).  A comparison of thousands of sketches has ~10 non-zero partners per row; a row is then written as runs of
+ * "0," between them and no n x n matrix is built or scanned.  Same bytes as spsp_csv_host on the dense matrix. */
+int spsp_csv_cells_host(int jaccard, const char* const* names, uint32_t n, uint32_t n_query, const uint64_t* cells, uint64_t n_cells,
+                        const uint64_t* card, int precision, double min_threshold, char** text, uint64_t* len);
+
 /* sortCSV (sort_csv.cpp:26-111): rows and columns of a symmetric all-vs-all Jaccard CSV (gunzipped text) put into
  * the order of the original file of files.  Inputs the reference mishandles (name missing from the fof or listed
  * twice, short or unparsable rows, diagonal != 1) are rejected with SPSP_ERR_FORMAT. */

@@ -353,8 +353,10 @@ int sketch_decode_device_impl(spsp_ctx* ctx, const uint8_t* const* payloads, con
 }
 
 int compare_payloads_impl(spsp_ctx* ctx, const uint8_t* const* payloads, const uint64_t* lens, uint32_t n, const int* extra_has,
-                          const uint32_t* extra_mn, uint32_t n_query, uint32_t* k_out, uint32_t* m_out, uint32_t* inter, uint64_t* card, bool* mirrored) {
+                          const uint32_t* extra_mn, uint32_t n_query, uint32_t* k_out, uint32_t* m_out, uint32_t* inter, uint64_t* card, bool* mirrored,
+                          std::vector<uint64_t>* cells_out) {
     if (mirrored) *mirrored = false;
+    if (cells_out) cells_out->clear();
     std::vector<uint64_t> sk_off((size_t)n + 1, 0);
     int rc = sketch_decode_device_impl(ctx, payloads, lens, n, extra_has, extra_mn, k_out, m_out, sk_off.data());
     if (rc || n == 0) return rc;
@@ -380,6 +382,7 @@ int compare_payloads_impl(spsp_ctx* ctx, const uint8_t* const* payloads, const u
             SPSP_HIP(hipMemcpyAsync(cells.data(), ctx->m_cells.p, (size_t)n_cells * 8, hipMemcpyDeviceToHost, ctx->stream));
             SPSP_HIP(hipStreamSynchronize(ctx->stream));
         }
+        if (cells_out) { cells_out->swap(cells); return SPSP_OK; }   // the caller prints from the cells: no matrix
         for (uint64_t cw : cells) {
             const size_t i = (size_t)(cw >> 48), j = (size_t)((cw >> 32) & 0xffffu);
             inter[i * n + j] = (uint32_t)cw;

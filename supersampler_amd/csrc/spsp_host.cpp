@@ -760,6 +760,101 @@ static int csv_impl(int jaccard, const char* const* names, uint32_t n, uint32_t 
     return SPSP_OK;
 }
 
+// The same bytes from the SPARSE form of the pair matrix (packed cells i << 48 | j << 32 | count, i < j, every pair at most
+// once): a comparison of thousands of sketches returns ~10 non-zero partners per row, and a row is then "0," runs between
+// them -- no n x n matrix is built or scanned (10^4 sketches: 2 x 400 MB of reads per matrix before).
+static int csv_cells_impl(int jaccard, const char* const* names, uint32_t n, uint32_t n_query, const std::vector<uint64_t>& cells,
+                          const uint64_t* card, int precision, double min_threshold, char** text, uint64_t* len) {
+    std::string head;
+    for (uint32_t i = 0; i < n; ++i) { head += names[i]; head += (i + 1 != n) ? ',' : '\n'; }
+    if (!jaccard) head += '\n';
+    const uint32_t rows = n < n_query ? n : n_query;
+    // partners of every printed row, by column
+    std::vector<uint32_t> deg((size_t)rows + 1, 0);
+    for (uint64_t c : cells) {
+        const uint32_t i = (uint32_t)(c >> 48), j = (uint32_t)(c >> 32) & 0xffffu;
+        if (i < rows) ++deg[i + 1];
+        if (j < rows) ++deg[j + 1];
+    }
+    for (uint32_t i = 0; i < rows; ++i) deg[i + 1] += deg[i];
+    std::vector<uint64_t> adj((size_t)deg[rows]);                  // partner << 32 | count
+    {
+        std::vector<uint32_t> at(deg.begin(), deg.end() - 1);
+        for (uint64_t c : cells) {
+            const uint32_t i = (uint32_t)(c >> 48), j = (uint32_t)(c >> 32) & 0xffffu;
+            if (i < rows) adj[at[i]++] = ((uint64_t)j << 32) | (uint32_t)c;
+            if (j < rows) adj[at[j]++] = ((uint64_t)i << 32) | (uint32_t)c;
+        }
+    }
+    static const std::string zero_run = []() { std::string z; z.reserve(8192); for (int i = 0; i < 4096; ++i) z += "0,"; return z; }();
+    auto format_rows = [&](uint32_t r0, uint32_t r1, std::string& out) {
+        char num[64];
+        out.reserve((size_t)(r1 - r0) * n * 2 + 4096);
+        for (uint32_t i = r0; i < r1; ++i) {
+            std::sort(adj.begin() + deg[i], adj.begin() + deg[i + 1]);
+            uint32_t col = 0;
+            auto zeros_to = [&](uint32_t upto) {                 // cells [col, upto) are "0,"
+                uint32_t z = upto - col;
+                while (z) { const uint32_t take = z < 4096 ? z : 4096; out.append(zero_run.data(), (size_t)take * 2); z -= take; }
+                col = upto;
+            };
+            bool diag_done = false;
+            auto diagonal = [&]() { zeros_to(i); out += "1,"; col = i + 1; diag_done = true; };
+            for (uint32_t e = deg[i]; e < deg[i + 1]; ++e) {
+                const uint32_t j = (uint32_t)(adj[e] >> 32), sc = (uint32_t)adj[e];
+                if (!diag_done && j > i) diagonal();
+                zeros_to(j);
+                const double score = jaccard ? (double)sc / (double)(card[i] + card[j] - sc) : (double)sc / (double)card[i];
+                if (score < min_threshold) out += '0';
+                else { const int l = snprintf(num, sizeof num, "%.*g", precision, score); out.append(num, l); }
+                out += ',';
+                col = j + 1;
+            }
+            if (!diag_done) diagonal();
+            zeros_to(n);
+            out.back() = '\n';
+        }
+    };
+    unsigned workers = std::thread::hardware_concurrency();
+    if (workers == 0) workers = 1;
+    if (workers > 16) workers = 16;
+    if (workers > rows) workers = rows ? rows : 1;
+    std::vector<std::string> parts(workers);
+    {
+        std::vector<std::thread> pool;
+        for (unsigned w = 0; w < workers; ++w) {
+            const uint32_t r0 = (uint32_t)((uint64_t)rows * w / workers), r1 = (uint32_t)((uint64_t)rows * (w + 1) / workers);
+            if (w + 1 == workers) format_rows(r0, r1, parts[w]);
+            else pool.emplace_back(format_rows, r0, r1, std::ref(parts[w]));
+        }
+        for (auto& th : pool) th.join();
+    }
+    size_t total = head.size();
+    for (auto& p2 : parts) total += p2.size();
+    *text = (char*)malloc(total + 1);
+    if (!*text) { set_error("out of host memory"); return SPSP_ERR_NOMEM; }
+    size_t at = 0;
+    memcpy(*text, head.data(), head.size()); at += head.size();
+    for (auto& p2 : parts) { memcpy(*text + at, p2.data(), p2.size()); at += p2.size(); }
+    (*text)[total] = 0;
+    *len = total;
+    return SPSP_OK;
+}
+
+int spsp_csv_cells_host(int jaccard, const char* const* names, uint32_t n, uint32_t n_query, const uint64_t* cells, uint64_t n_cells,
+                        const uint64_t* card, int precision, double min_threshold, char** text, uint64_t* len) {
+    if (!text || !len || (n && (!names || !card)) || (n_cells && !cells)) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    if (n > 65535) { set_error("at most 65535 sketches (a packed cell holds two 16-bit sketch numbers)"); return SPSP_ERR_ARG; }
+    std::vector<uint64_t> v(cells, cells + n_cells);
+    std::sort(v.begin(), v.end());
+    for (size_t e = 0; e < v.size(); ++e) {
+        const uint32_t i = (uint32_t)(v[e] >> 48), j = (uint32_t)(v[e] >> 32) & 0xffffu;
+        if (i >= j || j >= n) { set_error("cell %zu names the pair (%u, %u): not i < j < n", e, i, j); return SPSP_ERR_FORMAT; }
+        if (e && (v[e] >> 32) == (v[e - 1] >> 32)) { set_error("the pair (%u, %u) occurs twice: add partial cells up first (spsp_matrix_add_cells_device)", i, j); return SPSP_ERR_FORMAT; }
+    }
+    return csv_cells_impl(jaccard, names, n, n_query, v, card, precision, min_threshold, text, len);
+}
+
 int spsp_csv_host(int jaccard, const char* const* names, uint32_t n, uint32_t n_query, const uint32_t* inter,
                   const uint64_t* card, int precision, double min_threshold, char** text, uint64_t* len) {
     return csv_impl(jaccard, names, n, n_query, inter, card, precision, min_threshold, text, len, false);
@@ -928,7 +1023,9 @@ static int compare_files_impl(spsp_ctx* ctx, const char* const* paths, uint32_t 
     // the pair matrix: zero pages from calloc (400 MB at 10^4 sketches: touched only where a row is written or read)
     struct Matrix { uint32_t* p = nullptr; ~Matrix() { free(p); } uint32_t* data() { return p; }
                     int zero(size_t cells) { free(p); p = (uint32_t*)calloc(cells ? cells : 1, 4); return p ? SPSP_OK : SPSP_ERR_NOMEM; } } inter;
-    bool mirrored = false;                                    // both triangles filled (the cells path of a large comparison)
+    bool mirrored = false;                                    // both triangles filled
+    std::vector<uint64_t> cells;                              // ... or no matrix at all: a large comparison comes back as its non-zero cells
+    bool as_cells = false;
     std::vector<uint64_t> card(n, 0);
     if (!rc && host_decode) {
         // round-1 path: every sketch decoded and sorted by spsp_sketch_parse_host on the host threads, keys uploaded by spsp_compare
@@ -981,11 +1078,12 @@ static int compare_files_impl(spsp_ctx* ctx, const char* const* paths, uint32_t 
         if (chatter && n) { printf("kmers evaluated are of length: %u minimizer size is %u\n", k0, m0); fflush(stdout); }   // :56
         t1 = now_s(); ctx->stages.load_s += t1 - t0; t0 = t1;
         uint32_t kk = 0, mm2 = 0;
-        if ((rc = inter.zero((size_t)n * n))) set_error("out of host memory");
+        as_cells = n >= 1024 && n <= 65535;                    // (the printers then work from the cells: no n x n matrix on the host)
+        if (!as_cells && (rc = inter.zero((size_t)n * n))) set_error("out of host memory");
         else if (n_more > 1) rc = spsp::compare_payloads_multi(more, n_more, datas.data(), lens.data(), n, extra_has.data(), extra_mn.data(), n_query, &kk, &mm2,
-                                                               inter.data(), card.data(), &mirrored);
+                                                               inter.data(), card.data(), &mirrored, as_cells ? &cells : nullptr);
         else rc = spsp::compare_payloads_impl(ctx, datas.data(), lens.data(), n, extra_has.data(), extra_mn.data(), n_query, &kk, &mm2,
-                                              inter.data(), card.data(), &mirrored);
+                                              inter.data(), card.data(), &mirrored, as_cells ? &cells : nullptr);
     }
     free_datas();
     t1 = now_s(); ctx->stages.compare_s += t1 - t0;
@@ -1000,7 +1098,8 @@ static int compare_files_impl(spsp_ctx* ctx, const char* const* paths, uint32_t 
         char* text = nullptr; uint64_t len = 0;
         t0 = now_s();
         if (chatter) { printf(jac ? "Jackard index dump\n" : "Containement index dump \n"); fflush(stdout); }   // :364, :414
-        rc = csv_impl(jac, paths, n, n_query, inter.data(), card.data(), precision, min_threshold, &text, &len, mirrored);
+        rc = as_cells ? csv_cells_impl(jac, paths, n, n_query, cells, card.data(), precision, min_threshold, &text, &len)
+                      : csv_impl(jac, paths, n, n_query, inter.data(), card.data(), precision, min_threshold, &text, &len, mirrored);
         t1 = now_s(); ctx->stages.csv_s += t1 - t0;
         if (rc) break;
         const std::string out = std::string(out_prefix) + (jac ? "_jaccard.csv.gz" : "_containment.csv.gz");

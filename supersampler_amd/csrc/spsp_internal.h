@@ -212,7 +212,8 @@ int sketch_parse_structure_host(const uint8_t* payload, uint64_t len, ParsedSket
 // (inter: n x n, zero on entry; *mirrored = every written cell (i, j > i) was also stored at (j, i))
 int compare_payloads_impl(spsp_ctx* ctx, const uint8_t* const* payloads, const uint64_t* lens, uint32_t n, const int* extra_has,
                           const uint32_t* extra_mn, uint32_t n_query, uint32_t* k_out, uint32_t* m_out, uint32_t* inter, uint64_t* card,
-                          bool* mirrored = nullptr);
+                          bool* mirrored = nullptr, std::vector<uint64_t>* cells_out = nullptr);
+// (cells_out, for 1024 <= n <= 65535: the non-zero cells i << 48 | j << 32 | count, every pair once, INSTEAD of the matrix: inter may be null)
 int sketch_decode_device_impl(spsp_ctx* ctx, const uint8_t* const* payloads, const uint64_t* lens, uint32_t n,
                               const int* extra_has, const uint32_t* extra_mn, uint32_t* k_out, uint32_t* m_out, uint64_t* sk_off);
 // ingest (spsp_ingest.hip)
@@ -255,7 +256,7 @@ int compare_cells_run(spsp_ctx* ctx, const std::function<int()>& begin, uint32_t
 // decode + all-vs-all over several contexts (one per device, or several on one): the device half of spsp_compare_files_multi
 int compare_payloads_multi(spsp_ctx* const* ctxs, uint32_t n_ctx, const uint8_t* const* payloads, const uint64_t* lens, uint32_t n,
                            const int* extra_has, const uint32_t* extra_mn, uint32_t n_query, uint32_t* k_out, uint32_t* m_out,
-                           uint32_t* inter, uint64_t* card, bool* mirrored = nullptr);
+                           uint32_t* inter, uint64_t* card, bool* mirrored = nullptr, std::vector<uint64_t>* cells_out = nullptr);
 // spsp_bigkeys.hip: distinct keys of flagged segments through one table in HBM (queued, no host wait); segments sorted in place
 int big_dedupe_launch(spsp_ctx* ctx, bool has_hi, const uint32_t* raw_mn, const uint64_t* raw_lo, const uint64_t* raw_hi,
                       const uint32_t* d_seg_first, const uint32_t* d_seg_cnt, const uint32_t* d_seg_big, uint32_t n_seg, uint64_t n_places,

@@ -211,8 +211,9 @@ int run_stage(uint32_t n_ctx, MultiShared& S, F&& body) {
 
 int compare_payloads_multi(spsp_ctx* const* ctxs, uint32_t n_ctx, const uint8_t* const* payloads, const uint64_t* lens, uint32_t n,
                            const int* extra_has, const uint32_t* extra_mn, uint32_t n_query, uint32_t* k_out, uint32_t* m_out,
-                           uint32_t* inter, uint64_t* card, bool* mirrored) {
+                           uint32_t* inter, uint64_t* card, bool* mirrored, std::vector<uint64_t>* cells_out) {
     if (mirrored) *mirrored = false;
+    if (cells_out) cells_out->clear();
     if (n_ctx == 0 || n_ctx > kMaxParts) { set_error("1..%u contexts", kMaxParts); return SPSP_ERR_ARG; }
     if (n == 0) { *k_out = *m_out = 0; return SPSP_OK; }
     MultiShared S;
@@ -322,6 +323,21 @@ int compare_payloads_multi(spsp_ctx* const* ctxs, uint32_t n_ctx, const uint8_t*
         return SPSP_OK;
     });
     if (rc) return rc;
+    if (cells_out) {
+        // the caller prints from the cells: the contexts' partial cells of one pair are added up (sort by pair, sum the runs)
+        std::vector<uint64_t>& all = *cells_out;
+        for (uint32_t d = 0; d < n_ctx; ++d) all.insert(all.end(), host_cells[d].begin(), host_cells[d].end());
+        std::sort(all.begin(), all.end());
+        size_t w = 0;
+        for (size_t r = 0; r < all.size();) {
+            const uint64_t pair = all[r] >> 32;
+            uint64_t sum = 0;
+            for (; r < all.size() && (all[r] >> 32) == pair; ++r) sum += (uint32_t)all[r];
+            if ((uint32_t)(pair >> 16) < n && (uint32_t)(pair & 0xffffu) < n) all[w++] = (pair << 32) | (uint32_t)sum;
+        }
+        all.resize(w);
+        return SPSP_OK;
+    }
     for (uint32_t d = 0; d < n_ctx; ++d)
         for (uint64_t cw : host_cells[d]) {
             const uint32_t i = (uint32_t)(cw >> 48), j = (uint32_t)(cw >> 32) & 0xffffu;

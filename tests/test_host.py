@@ -228,6 +228,18 @@ def test_csv_sparse_matrix_long_zero_runs_match_oracle():
     for jac in (True, False):
         assert sp.csv(jac, names, inter, card, 12, 6, 0.0) == orc.csv(jac, names, inter, card, 12, 6, 0.0)
     assert sp.csv(True, names, inter, card, n, 4, 0.2) == orc.csv(True, names, inter, card, n, 4, 0.2)
+    # ... and from the sparse form of the same matrix (what a large comparison returns): no n x n matrix at all
+    ii, jj = np.nonzero(np.triu(inter, 1))
+    cells = (ii.astype(np.uint64) << np.uint64(48)) | (jj.astype(np.uint64) << np.uint64(32)) | inter[ii, jj].astype(np.uint64)
+    cells = cells[rng.permutation(len(cells))]
+    for jac in (True, False):
+        assert sp.csv_cells(jac, names, cells, card, 12, 6, 0.0) == orc.csv(jac, names, inter, card, 12, 6, 0.0)
+        assert sp.csv_cells(jac, names, cells, card, n, 4, 0.2) == orc.csv(jac, names, inter, card, n, 4, 0.2)
+    assert sp.csv_cells(True, names[:3], np.zeros(0, np.uint64), card[:3]) == orc.csv(True, names[:3], np.zeros((3, 3), np.uint32), card[:3])
+    with pytest.raises(sp.SpspError):
+        sp.csv_cells(True, names, np.concatenate([cells, cells[:1]]), card)                      # a pair twice
+    with pytest.raises(sp.SpspError):
+        sp.csv_cells(True, names[:10], np.array([(3 << 48) | (2 << 32) | 5], np.uint64), card[:10])   # not i < j
 
 
 def test_gz_io_roundtrip(tmp_path):

@@ -28,8 +28,8 @@ void set_error(const char* fmt, ...) {
 int gather_superkmers_impl(spsp_ctx*, const uint8_t*, const uint64_t*, const spsp_superkmer*, uint64_t, uint8_t**, uint32_t**) { return SPSP_ERR_NO_DEVICE; }
 int clean_device_impl(spsp_ctx*, const uint8_t*, uint64_t, uint8_t**, uint64_t*, uint64_t**, uint32_t*) { return SPSP_ERR_NO_DEVICE; }
 int scan_device_impl(spsp_ctx*, const spsp_params*, const uint8_t*, uint64_t, const uint64_t*, uint32_t, spsp_superkmer**, uint64_t*) { return SPSP_ERR_NO_DEVICE; }
-int compare_payloads_impl(spsp_ctx*, const uint8_t* const*, const uint64_t*, uint32_t, const int*, const uint32_t*, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint64_t*, bool*) { return SPSP_ERR_NO_DEVICE; }
-int compare_payloads_multi(spsp_ctx* const*, uint32_t, const uint8_t* const*, const uint64_t*, uint32_t, const int*, const uint32_t*, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint64_t*, bool*) { return SPSP_ERR_NO_DEVICE; }
+int compare_payloads_impl(spsp_ctx*, const uint8_t* const*, const uint64_t*, uint32_t, const int*, const uint32_t*, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint64_t*, bool*, std::vector<uint64_t>*) { return SPSP_ERR_NO_DEVICE; }
+int compare_payloads_multi(spsp_ctx* const*, uint32_t, const uint8_t* const*, const uint64_t*, uint32_t, const int*, const uint32_t*, uint32_t, uint32_t*, uint32_t*, uint32_t*, uint64_t*, bool*, std::vector<uint64_t>*) { return SPSP_ERR_NO_DEVICE; }
 int check_params(const spsp_params* p) { return (p && p->m >= 1 && p->m <= 15 && p->k >= p->m && p->k <= 63) ? SPSP_OK : SPSP_ERR_ARG; }
 }  // namespace spsp
 extern "C" {
