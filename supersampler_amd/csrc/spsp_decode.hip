@@ -182,6 +182,8 @@ __global__ __launch_bounds__(256) void k_decode_compact(const uint32_t* __restri
 int sketch_decode_device_impl(spsp_ctx* ctx, const uint8_t* const* payloads, const uint64_t* lens, uint32_t n,
                               const int* extra_has, const uint32_t* extra_mn, uint32_t* k_out, uint32_t* m_out, uint64_t* sk_off) {
     int rc = SPSP_OK;
+    static const bool dbg_times = getenv("SPSP_DEBUG_DECODE_TIMES") != nullptr;
+    double tm[6] = {now_s(), 0, 0, 0, 0, 0};
     std::vector<ParsedSketch> P(n);
     std::vector<int> rcs(n, SPSP_OK);
     std::vector<std::string> errs(n);
@@ -219,6 +221,7 @@ int sketch_decode_device_impl(spsp_ctx* ctx, const uint8_t* const* payloads, con
         work();
         for (auto& th : pool) th.join();
     }
+    tm[1] = now_s();
     for (uint32_t i = 0; i < n; ++i) if (rcs[i]) { free_hk(); set_error("%s", errs[i].c_str()); return rcs[i]; }
     for (uint32_t i = 1; i < n; ++i)
         if (P[i].k != P[0].k || P[i].m != P[0].m) { free_hk(); set_error("sketch %u was made with k=%u m=%u, expected k=%u m=%u", i, P[i].k, P[i].m, P[0].k, P[0].m); return SPSP_ERR_FORMAT; }
@@ -250,17 +253,40 @@ int sketch_decode_device_impl(spsp_ctx* ctx, const uint8_t* const* payloads, con
     const uint64_t R = raw_off[n];
     if (R > 0xfffffff0ull) { free_hk(); set_error("too many sketch k-mers for one call"); return SPSP_ERR_OVERFLOW; }
     // descriptors with absolute offsets
+    // (every sketch's descriptors have their place: written by a few threads -- 2.4 x 10^6 of them at 10 000 sketches --
+    // together with the sketch's text into the one buffer that crosses PCIe)
     std::vector<DecDesc> desc;
+    std::vector<uint8_t> text_all;
     {
-        size_t total = 0;
-        for (uint32_t i = 0; i < n; ++i) total += P[i].desc.size() + 1;
-        desc.reserve(total);
-        for (uint32_t i = 0; i < n; ++i) {
-            if (presorted[i]) continue;
-            for (DecDesc d : P[i].desc) { d.off += text_off[i]; d.out += (uint32_t)raw_off[i]; desc.push_back(d); }
-            if (extra_has && extra_has[i]) desc.push_back(DecDesc{text_off[i], extra_mn[i], 2u, (uint32_t)(raw_off[i] + P[i].n_keys), 0});
-        }
+        std::vector<size_t> d_at((size_t)n + 1, 0);
+        for (uint32_t i = 0; i < n; ++i) d_at[i + 1] = d_at[i] + (presorted[i] ? 0 : P[i].desc.size() + ((extra_has && extra_has[i]) ? 1 : 0));
+        desc.resize(d_at[n]);
+        const bool one_copy = n > 8 && text_off[n] > 0;
+        if (one_copy) text_all.resize((size_t)text_off[n]);
+        unsigned workers = std::thread::hardware_concurrency();
+        if (workers == 0) workers = 1;
+        if (workers > 16) workers = 16;
+        if (d_at[n] < (1u << 16)) workers = 1;
+        std::atomic<uint32_t> next(0);
+        auto work = [&]() {
+            for (;;) {
+                const uint32_t i0 = next.fetch_add(64);
+                if (i0 >= n) break;
+                for (uint32_t i = i0; i < std::min(n, i0 + 64); ++i) {
+                    if (presorted[i]) continue;
+                    size_t at = d_at[i];
+                    for (DecDesc d : P[i].desc) { d.off += text_off[i]; d.out += (uint32_t)raw_off[i]; desc[at++] = d; }
+                    if (extra_has && extra_has[i]) desc[at++] = DecDesc{text_off[i], extra_mn[i], 2u, (uint32_t)(raw_off[i] + P[i].n_keys), 0};
+                    if (one_copy && lens[i]) memcpy(text_all.data() + text_off[i], payloads[i], (size_t)lens[i]);
+                }
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned w = 1; w < workers; ++w) pool.emplace_back(work);
+        work();
+        for (auto& th : pool) th.join();
     }
+    tm[2] = now_s();
     auto fail = [&](int r) { free_hk(); return r; };
     if ((rc = ctx->dc_text.reserve((size_t)text_off[n] + 64))) return fail(rc);
     if ((rc = ctx->dc_desc.reserve(desc.size() * sizeof(DecDesc) + 64))) return fail(rc);
@@ -288,13 +314,7 @@ int sketch_decode_device_impl(spsp_ctx* ctx, const uint8_t* const* payloads, con
     uint8_t* d_presorted = reinterpret_cast<uint8_t*>(d_out_off + n + 1);
     hipError_t e = hipSuccess;
     // the payloads cross in ONE copy (10 000 sketch files: ten thousand pageable copies of 3 KB each were 0.1 s of a 0.16 s stage)
-    std::vector<uint8_t> text_all;
-    if (n > 8 && text_off[n]) {
-        text_all.resize((size_t)text_off[n]);
-        for (uint32_t i = 0; i < n; ++i)
-            if (!presorted[i] && lens[i]) memcpy(text_all.data() + text_off[i], payloads[i], (size_t)lens[i]);
-        e = hipMemcpyAsync(d_text, text_all.data(), text_all.size(), hipMemcpyHostToDevice, ctx->stream);
-    }
+    if (!text_all.empty()) e = hipMemcpyAsync(d_text, text_all.data(), text_all.size(), hipMemcpyHostToDevice, ctx->stream);
     for (uint32_t i = 0; i < n && e == hipSuccess; ++i) {
         if (!presorted[i]) { if (lens[i] && text_all.empty()) e = hipMemcpyAsync(d_text + text_off[i], payloads[i], (size_t)lens[i], hipMemcpyHostToDevice, ctx->stream); }
         else if (hk[i].n) {
@@ -310,6 +330,7 @@ int sketch_decode_device_impl(spsp_ctx* ctx, const uint8_t* const* payloads, con
     if (e == hipSuccess) e = hipMemcpyAsync(d_first32, first32.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_big, big.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
     if (e != hipSuccess) { free_hk(); return hip_fail(e, "sketch upload", __FILE__, __LINE__); }
+    tm[3] = now_s();
     if (!desc.empty()) {
         hipLaunchKernelGGL(k_decode_emit, dim3((uint32_t)((desc.size() + 255) / 256)), dim3(256), 0, ctx->stream, d_text,
                            ctx->dc_desc.as<DecDesc>(), (uint32_t)desc.size(), k, m, ctx->dc_mn.as<uint32_t>(), ctx->dc_lo.as<uint64_t>(),
@@ -342,6 +363,9 @@ int sketch_decode_device_impl(spsp_ctx* ctx, const uint8_t* const* payloads, con
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     free_hk();
     if (e != hipSuccess) return hip_fail(e, "sketch decode", __FILE__, __LINE__);
+    tm[4] = now_s();
+    if (dbg_times) fprintf(stderr, "[spsp decode] %u sketches: structure walk %.1f ms, descriptors %.1f ms, uploads queued %.1f ms, kernels + wait %.1f ms\n", n,
+                           (tm[1] - tm[0]) * 1e3, (tm[2] - tm[1]) * 1e3, (tm[3] - tm[2]) * 1e3, (tm[4] - tm[3]) * 1e3);
     for (uint32_t i = 0; i <= n; ++i) sk_off[i] = off32[i];
     if (any_big) {
         std::vector<std::pair<uint32_t, uint32_t>> segs;

@@ -763,8 +763,14 @@ static int csv_impl(int jaccard, const char* const* names, uint32_t n, uint32_t 
 // The same bytes from the SPARSE form of the pair matrix (packed cells i << 48 | j << 32 | count, i < j, every pair at most
 // once): a comparison of thousands of sketches returns ~10 non-zero partners per row, and a row is then "0," runs between
 // them -- no n x n matrix is built or scanned (10^4 sketches: 2 x 400 MB of reads per matrix before).
+static int deflate_member(const uint8_t* data, uint64_t len, int level, std::vector<uint8_t>& out);
+// gz_path != nullptr: nothing is returned as text; row blocks of ~8 MB are formatted AND deflated by the workers, one gzip
+// member each, and written in order (a valid gzip file that zstr / zlib / gunzip read back as one stream, like the members
+// of spsp_write_gz_host): the 200 MB of a 10^8-cell matrix never exist in one piece.  times[0] / times[1]: the workers'
+// formatting / deflate + write seconds, summed and divided by the worker count.
 static int csv_cells_impl(int jaccard, const char* const* names, uint32_t n, uint32_t n_query, const std::vector<uint64_t>& cells,
-                          const uint64_t* card, int precision, double min_threshold, char** text, uint64_t* len) {
+                          const uint64_t* card, int precision, double min_threshold, char** text, uint64_t* len,
+                          const char* gz_path = nullptr, int gz_level = 1, double* times = nullptr) {
     std::string head;
     for (uint32_t i = 0; i < n; ++i) { head += names[i]; head += (i + 1 != n) ? ',' : '\n'; }
     if (!jaccard) head += '\n';
@@ -819,6 +825,48 @@ static int csv_cells_impl(int jaccard, const char* const* names, uint32_t n, uin
     if (workers == 0) workers = 1;
     if (workers > 16) workers = 16;
     if (workers > rows) workers = rows ? rows : 1;
+    if (gz_path) {
+        const uint32_t rpb = std::max<uint32_t>(1, (uint32_t)((8ull << 20) / (2ull * (n ? n : 1))));   // rows per block: ~8 MB of text
+        const uint32_t n_blocks = rows ? (rows + rpb - 1) / rpb : 0;
+        std::vector<std::vector<uint8_t>> gz((size_t)n_blocks + 1);
+        std::vector<int> rcs((size_t)n_blocks + 1, SPSP_OK);
+        std::atomic<uint32_t> next(0);
+        std::vector<double> t_fmt(workers, 0.0), t_gz(workers, 0.0);
+        rcs[0] = deflate_member((const uint8_t*)head.data(), head.size(), gz_level, gz[0]);        // the header line(s): a member of their own
+        auto work = [&](unsigned w) {
+            std::string out;
+            for (;;) {
+                const uint32_t b = next.fetch_add(1);
+                if (b >= n_blocks) break;
+                out.clear();
+                const double t0 = now_s();
+                format_rows(b * rpb, std::min(rows, (b + 1) * rpb), out);
+                const double t1 = now_s();
+                rcs[b + 1] = deflate_member((const uint8_t*)out.data(), out.size(), gz_level, gz[b + 1]);
+                t_fmt[w] += t1 - t0; t_gz[w] += now_s() - t1;
+            }
+        };
+        if (workers > n_blocks) workers = n_blocks ? n_blocks : 1;
+        {
+            std::vector<std::thread> pool;
+            for (unsigned w = 1; w < workers; ++w) pool.emplace_back(work, w);
+            work(0);
+            for (auto& th : pool) th.join();
+        }
+        const double t2 = now_s();
+        for (int r : rcs) if (r) { set_error("deflate failed"); return r; }
+        FILE* f = fopen(gz_path, "wb");
+        if (!f) { set_error("cannot create '%s'", gz_path); return SPSP_ERR_IO; }
+        int rc = SPSP_OK;
+        for (auto& m : gz) if (!rc && fwrite(m.data(), 1, m.size(), f) != m.size()) { set_error("short write to '%s'", gz_path); rc = SPSP_ERR_IO; }
+        if (fclose(f) != 0 && !rc) { set_error("close failed for '%s'", gz_path); rc = SPSP_ERR_IO; }
+        if (times) {
+            double a = 0, b2 = 0;
+            for (unsigned w = 0; w < workers; ++w) { a += t_fmt[w]; b2 += t_gz[w]; }
+            times[0] = a / workers; times[1] = b2 / workers + (now_s() - t2);
+        }
+        return rc;
+    }
     std::vector<std::string> parts(workers);
     {
         std::vector<std::thread> pool;
@@ -1098,8 +1146,15 @@ static int compare_files_impl(spsp_ctx* ctx, const char* const* paths, uint32_t 
         char* text = nullptr; uint64_t len = 0;
         t0 = now_s();
         if (chatter) { printf(jac ? "Jackard index dump\n" : "Containement index dump \n"); fflush(stdout); }   // :364, :414
-        rc = as_cells ? csv_cells_impl(jac, paths, n, n_query, cells, card.data(), precision, min_threshold, &text, &len)
-                      : csv_impl(jac, paths, n, n_query, inter.data(), card.data(), precision, min_threshold, &text, &len, mirrored);
+        const std::string out_gz = std::string(out_prefix) + (jac ? "_jaccard.csv.gz" : "_containment.csv.gz");
+        if (as_cells) {
+            // rows formatted from the cells and deflated block by block on the workers, level 1 (Comparator.cpp:363,413)
+            double tt[2] = {0, 0};
+            rc = csv_cells_impl(jac, paths, n, n_query, cells, card.data(), precision, min_threshold, nullptr, nullptr, out_gz.c_str(), 1, tt);
+            ctx->stages.csv_s += tt[0]; ctx->stages.csv_gzip_s += tt[1];
+            continue;
+        }
+        rc = csv_impl(jac, paths, n, n_query, inter.data(), card.data(), precision, min_threshold, &text, &len, mirrored);
         t1 = now_s(); ctx->stages.csv_s += t1 - t0;
         if (rc) break;
         const std::string out = std::string(out_prefix) + (jac ? "_jaccard.csv.gz" : "_containment.csv.gz");
