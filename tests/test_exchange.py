@@ -738,6 +738,13 @@ def test_compare_files_over_several_contexts_equals_one_and_the_oracle(tmp_path)
                 got = gzip.open(pre + suf, "rb").read()
                 assert got == want[jac], (k, devs, suf)
                 assert got == gzip.open(str(tmp_path / "one") + suf, "rb").read()
+        # more contexts than files: two files and ONE file over three contexts (contexts without a sketch take part in the exchange all the same)
+        for few in (2, 1):
+            fi, fc, _, _ = orc.compare(payloads[:few])
+            pre = str(tmp_path / ("few%d_%d" % (k, few)))
+            sp.compare_files_multi([0, 0, 0], paths[:few], pre)
+            for jac, suf in ((True, "_jaccard.csv.gz"), (False, "_containment.csv.gz")):
+                assert gzip.open(pre + suf, "rb").read() == orc.csv(jac, paths[:few], fi, fc, None, 6, 0.0), (k, few, suf)
         # query mode: the first four files are the queries
         qi, qc, _, _ = orc.compare(payloads, n_query=4)
         pre = str(tmp_path / ("q%d" % k))
