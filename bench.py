@@ -717,7 +717,7 @@ def main():
 
     # BASELINE configs[3] over the ranks of this job (every rank takes part; rank 0 reports)
     c4_dist = None
-    if use_dist and world > 1 and not args.no_extras:
+    if use_dist and not args.no_extras:          # (BENCH_FORCE_DIST=1: also with ONE rank -- the RCCL calls of the leg on a one-GPU box)
         try:
             c4_dist = compare_config4_dist(ctx_full, dev, full_stream, rank, world, backend)
         except Exception as e:  # noqa: BLE001
