@@ -964,6 +964,8 @@ static int launch_accumulate_sparse(spsp_ctx* ctx, const ComparePlan& P, uint32_
                        (may_emit_cells && ctx->cells_req.armed && split == 1) ? ctx->cells_req.cells : (unsigned long long*)nullptr,
                        (unsigned long long)ctx->cells_req.cap, ctx->cells_req.count, xcd_rows);
     ctx->cells_req.direct = may_emit_cells && ctx->cells_req.armed && split == 1;
+    // the number of cells travels to pinned memory behind the kernel: whoever waits for the job (compare_end) has it, no round trip of its own
+    if (ctx->cells_req.direct) SPSP_HIP(hipMemcpyAsync(ctx->h_scalar + 12, ctx->cells_req.count, 8, hipMemcpyDeviceToHost, ctx->stream));
     SPSP_HIP(hipGetLastError());
     return SPSP_OK;
 }
@@ -1467,7 +1469,7 @@ static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t*
 //     record[slot_cap]             words x u64: kmer_lo, (kmer_hi if k > 32), minimizer | local sketch << 32
 // Records are grouped by sketch, sketches in order, keys of a sketch in their original (sorted) order.
 // (kSlotMagic, kMaxParts, slot_rec_off / slot_words / slot_bytes: spsp_internal.h -- the receiver is spsp_multi.hip)
-constexpr int kPartThreads = 256;
+constexpr int kPartThreads = 1024;
 
 __device__ __forceinline__ uint32_t part_of(uint64_t lo, uint32_t mn, uint64_t hi, bool has_hi, uint32_t parts) {
     uint64_t h = mix64(lo ^ 0xD6E8FEB86659FD93ULL);
@@ -1636,7 +1638,8 @@ int compare_slots_impl(spsp_ctx* ctx, uint32_t k, const uint8_t* d_slots, uint32
                        uint32_t* d_inter) {
     int rc = compare_slots_begin_impl(ctx, k, d_slots, parts, n, cap, d_inter);
     if (rc) return rc;
-    return compare_end_impl(ctx);
+    rc = compare_end_impl(ctx);
+    return rc ? rc : slots_bad_record(ctx);
 }
 
 int compare_device_impl(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min, const uint64_t* d_lo,
@@ -1699,7 +1702,8 @@ int spsp_compare_slots_device_begin(spsp_ctx* ctx, uint32_t k, const void* d_slo
 int spsp_compare_end(spsp_ctx* ctx) {
     if (!ctx) { set_error("NULL argument"); return SPSP_ERR_ARG; }
     SPSP_HIP(hipSetDevice(ctx->device));
-    return compare_end_impl(ctx);
+    const int rc = compare_end_impl(ctx);
+    return rc ? rc : slots_bad_record(ctx);                   // (a comparison of exchange slots: the unpack's record check)
 }
 
 int spsp_compare(spsp_ctx* ctx, const spsp_sketch_view* sk, uint32_t n, uint32_t n_query, uint32_t* inter,

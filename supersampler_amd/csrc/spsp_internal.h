@@ -162,6 +162,9 @@ struct spsp_ctx {
     // genomes / sketches beyond the per-segment LDS forms (spsp_bigkeys.hip): output slices, the open-addressing table in HBM
     // (slot words carry the epoch of the call that claimed them: never cleared between calls), the sort's tile list
     spsp::DevBuf b_mn, b_lo, b_hi, b_table, b_tiles, b_seg;
+    std::vector<uint64_t> m_h_skoff;                          // host arrays a queued slot unpack reads (spsp_multi.hip)
+    std::vector<uint32_t> m_h_tot, m_h_base;
+    bool m_slots_job = false;                                 // the pending comparison came from exchange slots: its record check is read behind compare_end
     spsp::DevBuf m_send, m_recv, m_cells, m_mn, m_lo, m_hi;   // key-partitioned split (spsp_multi.hip): slots out / in, sparse cells, unpacked keys
     uint32_t big_epoch = 0;
 };
@@ -246,6 +249,7 @@ int partition_keys_impl(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min, const 
                         const uint64_t* h_sk_off, uint32_t n, uint32_t parts, uint32_t cap, uint8_t* d_slots);
 int compare_slots_begin_impl(spsp_ctx* ctx, uint32_t k, const uint8_t* d_slots, uint32_t parts, uint32_t n, uint32_t cap,
                              uint32_t* d_inter);
+int slots_bad_record(spsp_ctx* ctx);
 // sparse form of a pair matrix (spsp_multi.hip): non-zero cells (i < j) as i << 48 | j << 32 | count
 int matrix_cells_impl(spsp_ctx* ctx, const uint32_t* d_inter, uint32_t n, uint32_t row_first, uint32_t row_limit, uint64_t* d_cells,
                       uint64_t cap, uint64_t* n_cells);

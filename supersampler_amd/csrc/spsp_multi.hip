@@ -104,6 +104,16 @@ int matrix_cells_impl(spsp_ctx* ctx, const uint32_t* d_inter, uint32_t n, uint32
     return SPSP_OK;
 }
 
+// after compare_end of a comparison queued by compare_slots_begin_impl: did k_slot_unpack meet a record that names a sketch its
+// position does not belong to?  (the records were compared all the same -- as keys of the sketch their POSITION belongs to;
+// the result of such a call is refused)
+int slots_bad_record(spsp_ctx* ctx) {
+    if (!ctx->m_slots_job) return SPSP_OK;
+    ctx->m_slots_job = false;
+    if ((uint32_t)ctx->h_scalar[13]) { set_error("an exchange slot is malformed (a record names a sketch its position does not belong to)"); return SPSP_ERR_FORMAT; }
+    return SPSP_OK;
+}
+
 int compare_cells_run(spsp_ctx* ctx, const std::function<int()>& begin, uint32_t n, uint32_t row_limit, uint32_t* d_scratch, uint64_t* d_cells,
                       uint64_t cap, uint64_t* n_cells) {
     if (n > 65535) { set_error("at most 65535 sketches (the packed cell holds two 16-bit sketch numbers; Comparator.h:26 has the same bound)"); return SPSP_ERR_ARG; }
@@ -117,13 +127,12 @@ int compare_cells_run(spsp_ctx* ctx, const std::function<int()>& begin, uint32_t
     ctx->cells_req.direct = false;
     rc = begin();
     if (!rc) rc = compare_end_impl(ctx);
+    if (!rc) rc = slots_bad_record(ctx);
     const bool direct = ctx->cells_req.direct;
     ctx->cells_req = spsp_ctx::CellsReq{};
     if (rc) return rc;
     if (!direct) return matrix_cells_impl(ctx, d_scratch, n, 0, row_limit, d_cells, cap, n_cells);
-    SPSP_HIP(hipMemcpyAsync(ctx->h_scalar + 12, d_count, 8, hipMemcpyDeviceToHost, ctx->stream));
-    SPSP_HIP(hipStreamSynchronize(ctx->stream));
-    *n_cells = ctx->h_scalar[12];
+    *n_cells = ctx->h_scalar[12];                                  // (copied to pinned memory behind the row sums: compare_end has waited for it)
     if (*n_cells > cap) { set_error("the matrix has %llu non-zero cells, room was given for %llu", (unsigned long long)*n_cells, (unsigned long long)cap); return SPSP_ERR_OVERFLOW; }
     return SPSP_OK;
 }
@@ -145,8 +154,10 @@ int compare_slots_begin_impl(spsp_ctx* ctx, uint32_t k, const uint8_t* d_slots, 
     std::vector<uint8_t> h((size_t)parts * hdr);
     SPSP_HIP(hipMemcpy2DAsync(h.data(), hdr, d_slots, slot_sz, hdr, parts, hipMemcpyDeviceToHost, ctx->stream));
     SPSP_HIP(hipStreamSynchronize(ctx->stream));
-    std::vector<uint64_t> sk_off((size_t)N + 1, 0);
-    std::vector<uint32_t> tot(parts), base(parts);
+    // (host arrays the queued copies read: kept in the context until its next call, so that nothing here has to wait for them)
+    std::vector<uint64_t>& sk_off = ctx->m_h_skoff;
+    std::vector<uint32_t>&tot = ctx->m_h_tot, &base = ctx->m_h_base;
+    sk_off.assign((size_t)N + 1, 0); tot.assign(parts, 0); base.assign(parts, 0);
     uint64_t at = 0;
     for (uint32_t s = 0; s < parts; ++s) {
         const uint32_t* w = reinterpret_cast<const uint32_t*>(h.data() + (size_t)s * hdr);
@@ -173,12 +184,12 @@ int compare_slots_begin_impl(spsp_ctx* ctx, uint32_t k, const uint8_t* d_slots, 
         hipLaunchKernelGGL(k_slot_unpack, dim3(gx, parts), dim3(256), 0, ctx->stream, d_slots, slot_sz, hdr, words, (const uint32_t*)d_tot, (const uint32_t*)(d_tot + parts), n,
                            (const uint64_t*)ctx->x_begin.p, d_bad, ctx->m_mn.as<uint32_t>(), ctx->m_lo.as<uint64_t>(), has_hi ? ctx->m_hi.as<uint64_t>() : (uint64_t*)nullptr);
         SPSP_HIP(hipGetLastError());
-        SPSP_HIP(hipMemcpyAsync(ctx->h_scalar + 12, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
-        SPSP_HIP(hipStreamSynchronize(ctx->stream));               // (tot / base / sk_off are read from host vectors)
-        if ((uint32_t)ctx->h_scalar[12]) { set_error("an exchange slot is malformed (a record names a sketch its position does not belong to)"); return SPSP_ERR_FORMAT; }
+        SPSP_HIP(hipMemcpyAsync(ctx->h_scalar + 13, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));   // read by slots_bad_record() once the job has been waited for
     }
-    return compare_device_begin_impl(ctx, k, ctx->m_mn.as<uint32_t>(), ctx->m_lo.as<uint64_t>(), has_hi ? ctx->m_hi.as<uint64_t>() : nullptr, sk_off.data(),
-                                     (uint32_t)N, (uint32_t)N, 0, 1, d_inter);
+    const int rc2 = compare_device_begin_impl(ctx, k, ctx->m_mn.as<uint32_t>(), ctx->m_lo.as<uint64_t>(), has_hi ? ctx->m_hi.as<uint64_t>() : nullptr, sk_off.data(),
+                                              (uint32_t)N, (uint32_t)N, 0, 1, d_inter);
+    ctx->m_slots_job = rc2 == SPSP_OK && at > 0;                   // (its record check is read behind compare_end: slots_bad_record)
+    return rc2;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
