@@ -325,11 +325,9 @@ constexpr int kFlags = 8;   // [0] unsorted input, [1] fingerprint collision, [2
 // group the same column is spread over `copies` banks.  A thread takes kAccU keys at a time: the list
 // references are one coalesced load and the lists' first words are issued together.
 constexpr int kSparseThreads = 1024, kAccU = 2, kAccW = 4, kAccR = 2;
-// HALF: 16-bit counters, two to a word (no row holds 65 536 keys): half the LDS.  THREADS: 1024 lanes for a row of thousands of keys,
-// 256 for short rows (a rank's share of the key-partitioned split: ~600 keys per row) -- a CU has wave slots for two workgroups
-// of 1024 but eight of 256, and a row spends its time waiting for two dependent random reads per key
-template <bool HALF, int THREADS>
-__global__ __launch_bounds__(THREADS) void k_accumulate_sparse(const uint32_t* __restrict__ list_of_entry,
+// HALF: 16-bit counters, two to a word (no row holds 65 536 keys): half the LDS per workgroup
+template <bool HALF>
+__global__ __launch_bounds__(kSparseThreads) void k_accumulate_sparse(const uint32_t* __restrict__ list_of_entry,
                                                                      const uint32_t* __restrict__ where,
                                                                      const uint16_t* __restrict__ ids,
                                                                      const uint64_t* __restrict__ sk_begin,
@@ -364,7 +362,7 @@ __global__ __launch_bounds__(THREADS) void k_accumulate_sparse(const uint32_t* _
         if (e0 >= e1) return;
     }
     const uint32_t copies = 1u << copies_log2, mine = threadIdx.x & (copies - 1);
-    for (uint32_t x = threadIdx.x; x < ((cols << copies_log2) >> (HALF ? 1 : 0)); x += THREADS) s_cnt[x] = 0;
+    for (uint32_t x = threadIdx.x; x < ((cols << copies_log2) >> (HALF ? 1 : 0)); x += kSparseThreads) s_cnt[x] = 0;
     __syncthreads();
     auto count = [&](uint32_t jj) {
         if (jj > i && jj - col0 < cols) {
@@ -376,17 +374,17 @@ __global__ __launch_bounds__(THREADS) void k_accumulate_sparse(const uint32_t* _
     auto counter = [&](uint32_t idx) { return HALF ? (s_cnt[idx >> 1] >> ((idx & 1u) << 4)) & 0xffffu : s_cnt[idx]; };
     // kAccR list references are fetched together (the partition form reaches them through `where`: two dependent
     // loads, the second scattered -- eight of each in flight per thread hide the extra hop), then the lists kAccU at a time
-    for (uint64_t e = e0 + threadIdx.x; e < e1; e += (uint64_t)kAccR * THREADS) {
+    for (uint64_t e = e0 + threadIdx.x; e < e1; e += (uint64_t)kAccR * kSparseThreads) {
         uint32_t refs[kAccR];
         if (where) {                                         // the reference sits where the key's record went
             uint32_t at[kAccR];
 #pragma unroll
-            for (int r = 0; r < kAccR; ++r) { const uint64_t eu = e + (uint64_t)r * THREADS; at[r] = eu < e1 ? where[eu] : kNoWhere; }
+            for (int r = 0; r < kAccR; ++r) { const uint64_t eu = e + (uint64_t)r * kSparseThreads; at[r] = eu < e1 ? where[eu] : kNoWhere; }
 #pragma unroll
             for (int r = 0; r < kAccR; ++r) refs[r] = at[r] != kNoWhere ? list_of_entry[at[r]] : kNoList;
         } else {
 #pragma unroll
-            for (int r = 0; r < kAccR; ++r) { const uint64_t eu = e + (uint64_t)r * THREADS; refs[r] = eu < e1 ? list_of_entry[eu] : kNoList; }
+            for (int r = 0; r < kAccR; ++r) { const uint64_t eu = e + (uint64_t)r * kSparseThreads; refs[r] = eu < e1 ? list_of_entry[eu] : kNoList; }
         }
 #pragma unroll
         for (int g = 0; g < kAccR; g += kAccU) {
@@ -429,7 +427,7 @@ __global__ __launch_bounds__(THREADS) void k_accumulate_sparse(const uint32_t* _
         // sparse result (the key-partitioned split: a rank's partial row is nearly all zeros): the row's non-zero cells
         // leave as packed words i << 48 | j << 32 | count, one atomic per wave that has any -- the dense row is not written
         const uint32_t lane = threadIdx.x & 63u;
-        for (uint32_t x = threadIdx.x; x < cols; x += THREADS) {
+        for (uint32_t x = threadIdx.x; x < cols; x += kSparseThreads) {
             const uint32_t col = col0 + x;
             uint32_t v = 0;
             if (col > i && col < n)
@@ -444,7 +442,7 @@ __global__ __launch_bounds__(THREADS) void k_accumulate_sparse(const uint32_t* _
         }
         return;
     }
-    for (uint32_t x = threadIdx.x; x < cols; x += THREADS) {
+    for (uint32_t x = threadIdx.x; x < cols; x += kSparseThreads) {
         const uint32_t col = col0 + x;
         if (col > i && col < n) {
             uint32_t v = 0;
@@ -971,11 +969,9 @@ static int launch_accumulate_sparse(spsp_ctx* ctx, const ComparePlan& P, uint32_
     static const char* dbg_half = getenv("SPSP_DEBUG_ACC_HALF");   // "0": 32-bit counters (A/B)
     const bool half = split == 1 && P.max_row > 0 && P.max_row <= 65535 && !(dbg_half && dbg_half[0] == '0');
     // (256-lane workgroups for short rows were measured for the key-partitioned ranks' ~600-key rows: 0.178 -> 0.192 ms -- a row's fixed
-    // cost is clearing and scanning its N counters, which takes four times as many rounds with a quarter of the lanes; not used)
-    const bool short_rows = false;
-    auto kern = half ? (short_rows ? &k_accumulate_sparse<true, 256> : &k_accumulate_sparse<true, kSparseThreads>)
-                     : (short_rows ? &k_accumulate_sparse<false, 256> : &k_accumulate_sparse<false, kSparseThreads>);
-    hipLaunchKernelGGL(kern, dim3(col_blocks, by_xcd ? xcd_rows * 8 : P.n_own, split), dim3(short_rows ? 256 : kSparseThreads),
+    // cost is clearing and scanning its N counters, which takes four times as many rounds with a quarter of the lanes; not kept)
+    auto kern = half ? &k_accumulate_sparse<true> : &k_accumulate_sparse<false>;
+    hipLaunchKernelGGL(kern, dim3(col_blocks, by_xcd ? xcd_rows * 8 : P.n_own, split), dim3(kSparseThreads),
                        ((size_t)cols << copies_log2) * (half ? 2 : 4), ctx->stream,
                        P.list_ref ? P.list_ref : ctx->c_row.as<uint32_t>(), P.where, ctx->c_matrix.as<uint16_t>(), P.sk_begin, P.sk_end,
                        P.n, P.row_first, P.row_stride, P.row_limit, cols, copies_log2, split, P.d_inter, flags,
