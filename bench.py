@@ -1129,11 +1129,24 @@ def compare_files_config4(ctx, D, n, skip_oracle):
                "stage_s": {"read_gunzip": st["load_s"], "decode_compare_cells_to_host": st["compare_s"], "format_both_matrices": st["csv_s"],
                            "gzip_and_write": st["csv_gzip_s"]},
                "csv_gz_bytes": sizes, "files_written_s": write_s}
+        # sortCSV (sort_csv.cpp:26-111) over the 10^8-cell Jaccard matrix: rows and columns back into another file-of-files order
+        try:
+            jac_text = sp.read_file(os.path.join(tmp, "all_jaccard.csv.gz"))
+            fof = ("\n".join(paths[i] for i in np.random.default_rng(9).permutation(n)) + "\n").encode()
+            t0 = time.perf_counter()
+            sorted_text = sp.sort_csv(jac_text, fof)
+            out["sort_csv"] = {"seconds": time.perf_counter() - t0, "csv_bytes": len(jac_text), "same_size_out": len(sorted_text) == len(jac_text)}
+            del jac_text, sorted_text
+        except Exception as e:  # noqa: BLE001
+            out["sort_csv"] = {"error": repr(e)}
         if not skip_oracle:
             from oracle import oracle_py as orc
             sub = 1600
             ctx.compare_files(paths[:sub], os.path.join(tmp, "sub"))
             inter, card, _, _ = orc.compare(pls[:sub])
+            sub_text = sp.read_file(os.path.join(tmp, "sub_jaccard.csv.gz"))
+            sub_fof = ("\n".join(paths[i] for i in np.random.default_rng(10).permutation(sub)) + "\n").encode()
+            out["sort_csv"]["equal_to_the_oracle_on_%d_files" % sub] = bool(sp.sort_csv(sub_text, sub_fof) == orc.sort_csv(sub_text, sub_fof))
             out["csv_bytes_equal_the_oracle_on_%d_files" % sub] = bool(all(
                 gzip.open(os.path.join(tmp, "sub_%s.csv.gz" % name), "rb").read() == orc.csv(jac, paths[:sub], inter, card, None, 6, 0.0)
                 for jac, name in ((True, "jaccard"), (False, "containment"))))

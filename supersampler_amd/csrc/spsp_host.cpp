@@ -662,37 +662,122 @@ int spsp_sort_csv_host(const char* csv, uint64_t csv_len, const char* fof, uint6
         if (order[c].first == order[c - 1].first) { set_error("column '%s' appears twice", head[order[c].second].c_str()); return SPSP_ERR_FORMAT; }
     std::vector<uint32_t> new_of(N);
     for (size_t r = 0; r < N; ++r) new_of[order[r].second] = (uint32_t)r;
-    std::vector<double> m(N * N, 0.0);
-    size_t row = 0;
-    for (size_t l = 1; l < lines.size(); ++l) {
-        if (lines[l].second < N) break;                 // sort_csv.cpp:80 (also what stops at a containment file's blank line)
-        if (row >= N) { set_error("more than %zu rows", N); return SPSP_ERR_FORMAT; }
-        const std::vector<std::string> v = tokens(lines[l].first, lines[l].second);
-        if (v.size() < N) { set_error("row %zu has %zu values, expected %zu", row, v.size(), N); return SPSP_ERR_FORMAT; }
-        for (size_t c = 0; c < N; ++c) {
-            char* endp = nullptr;
-            const double x = strtod(v[c].c_str(), &endp);
-            if (endp == v[c].c_str()) { set_error("row %zu, column %zu: not a number", row, c); return SPSP_ERR_FORMAT; }
-            m[(size_t)new_of[c] * N + new_of[row]] = x;   // the reference fills the transposed cell (sort_csv.cpp:83)
+    // Rows.  A matrix of thousands of sketches is nearly all "0" cells (10^8 cells at BASELINE configs[3], 95 000 pairs that
+    // share anything): the cells that are not literally "0" are kept as (output row, output column, value) -- the reference
+    // fills the TRANSPOSED cell (sort_csv.cpp:83) -- and a row is written as runs of "0," between them.  Lines are independent:
+    // parsed and printed by a few threads (the round-3 form built 10^8 std::strings and an N x N array of doubles: 8 s at
+    // N = 6 000 on one thread).
+    size_t n_rows = 0;                                   // consecutive lines that can hold a row (sort_csv.cpp:80 stops at the first that cannot)
+    while (1 + n_rows < lines.size() && lines[1 + n_rows].second >= N) ++n_rows;
+    const size_t parse_rows = n_rows < N ? n_rows : N;
+    struct Cell { uint32_t orow, ocol; double x; };
+    unsigned workers = std::thread::hardware_concurrency();
+    if (workers == 0) workers = 1;
+    if (workers > 16) workers = 16;
+    if (N * N < (1u << 20)) workers = 1;
+    if (workers > parse_rows) workers = parse_rows ? (unsigned)parse_rows : 1;
+    std::vector<std::vector<Cell>> found(workers);
+    std::vector<size_t> bad_row(workers, (size_t)-1);       // first row this worker could not parse
+    std::vector<std::string> bad_msg(workers);
+    auto parse = [&](unsigned w) {
+        char buf[64];
+        for (size_t r = w; r < parse_rows; r += workers) {
+            const char* p = lines[1 + r].first;
+            const size_t n = lines[1 + r].second;
+            size_t a = 0, c = 0;
+            bool failed = false;
+            auto cell = [&](size_t b) {                  // cell c = [a, b)
+                const size_t l = b - a;
+                if (l == 1 && p[a] == '0') return;       // the common case: 0 -> "0"
+                if (l == 0 || l >= sizeof buf) { failed = true; return; }
+                memcpy(buf, p + a, l); buf[l] = 0;
+                char* endp = nullptr;
+                const double x = strtod(buf, &endp);
+                if (endp == buf) { failed = true; return; }
+                found[w].push_back(Cell{new_of[c], new_of[r], x});
+            };
+            for (size_t i = 0; i < n && c < N && !failed; ++i)
+                if (p[i] == ',') { cell(i); if (failed) { char t[96]; snprintf(t, sizeof t, "row %zu, column %zu: not a number", r, c); bad_msg[w] = t; } a = i + 1; ++c; }
+            if (!failed && c < N) {                       // the last field ends at the first non-printable byte (split(), utils.cpp:609-629)
+                size_t e = a;
+                while (e < n && isprint((unsigned char)p[e])) ++e;
+                if (c + 1 < N) { char t[96]; snprintf(t, sizeof t, "row %zu has %zu values, expected %zu", r, c + 1, N); bad_msg[w] = t; failed = true; }
+                else { cell(e); if (failed) { char t[96]; snprintf(t, sizeof t, "row %zu, column %zu: not a number", r, c); bad_msg[w] = t; } ++c; }
+            }
+            if (failed) { bad_row[w] = r; return; }
         }
-        ++row;
+    };
+    {
+        std::vector<std::thread> pool;
+        for (unsigned w = 1; w < workers; ++w) pool.emplace_back(parse, w);
+        parse(0);
+        for (auto& th : pool) th.join();
     }
-    if (row != N) { set_error("%zu rows for %zu columns (a containment file, or a query-mode matrix?)", row, N); return SPSP_ERR_FORMAT; }
-    std::string out;
-    for (size_t r = 0; r < N; ++r) { out += head[order[r].second]; out += (r + 1 != N) ? ',' : '\n'; }
-    char num[40];
-    for (size_t i = 0; i < N; ++i) {
-        if (m[i * N + i] != 1) { set_error("diagonal entry %zu is not 1 (the reference stops here)", i); return SPSP_ERR_FORMAT; }
-        for (size_t j = 0; j < N; ++j) {
-            out.append(num, (size_t)snprintf(num, sizeof num, "%g", m[i * N + j]));
-            out += (j + 1 != N) ? ',' : '\n';
+    {
+        unsigned first = workers;
+        for (unsigned w = 0; w < workers; ++w) if (bad_row[w] != (size_t)-1 && (first == workers || bad_row[w] < bad_row[first])) first = w;
+        if (first != workers) { set_error("%s", bad_msg[first].c_str()); return SPSP_ERR_FORMAT; }
+    }
+    if (n_rows > N) { set_error("more than %zu rows", N); return SPSP_ERR_FORMAT; }
+    if (n_rows != N) { set_error("%zu rows for %zu columns (a containment file, or a query-mode matrix?)", n_rows, N); return SPSP_ERR_FORMAT; }
+    // cells by output row, then by column
+    std::vector<size_t> at(N + 1, 0);
+    for (auto& v : found) for (const Cell& c : v) ++at[c.orow + 1];
+    for (size_t i = 0; i < N; ++i) at[i + 1] += at[i];
+    std::vector<std::pair<uint32_t, double>> adj(at[N]);
+    {
+        std::vector<size_t> cur(at.begin(), at.end() - 1);
+        for (auto& v : found) for (const Cell& c : v) adj[cur[c.orow]++] = std::make_pair(c.ocol, c.x);
+    }
+    std::vector<std::vector<Cell>>().swap(found);
+    for (size_t i = 0; i < N; ++i) {                      // the diagonal must be 1 (the reference stops at the first that is not, sort_csv.cpp:100-104)
+        double d = 0;
+        for (size_t e = at[i]; e < at[i + 1]; ++e) if (adj[e].first == i) d = adj[e].second;
+        if (d != 1) { set_error("diagonal entry %zu is not 1 (the reference stops here)", i); return SPSP_ERR_FORMAT; }
+    }
+    std::string head_out;
+    for (size_t r = 0; r < N; ++r) { head_out += head[order[r].second]; head_out += (r + 1 != N) ? ',' : '\n'; }
+    static const std::string zero_run = []() { std::string z; z.reserve(8192); for (int i = 0; i < 4096; ++i) z += "0,"; return z; }();
+    std::vector<std::string> parts(workers);
+    auto print = [&](unsigned w) {
+        std::string& out = parts[w];
+        const size_t r0 = N * w / workers, r1 = N * (w + 1) / workers;
+        out.reserve((r1 - r0) * N * 2 + 4096);
+        char num[40];
+        for (size_t i = r0; i < r1; ++i) {
+            std::sort(adj.begin() + at[i], adj.begin() + at[i + 1], [](const std::pair<uint32_t, double>& x, const std::pair<uint32_t, double>& y) { return x.first < y.first; });
+            size_t col = 0;
+            auto zeros_to = [&](size_t upto) {
+                size_t z = upto - col;
+                while (z) { const size_t take = z < 4096 ? z : 4096; out.append(zero_run.data(), take * 2); z -= take; }
+                col = upto;
+            };
+            for (size_t e = at[i]; e < at[i + 1]; ++e) {
+                if (e + 1 < at[i + 1] && adj[e + 1].first == adj[e].first) continue;      // (a column given twice cannot happen: columns are a permutation)
+                zeros_to(adj[e].first);
+                out.append(num, (size_t)snprintf(num, sizeof num, "%g", adj[e].second));
+                out += ',';
+                col = adj[e].first + 1;
+            }
+            zeros_to(N);
+            out.back() = '\n';
         }
+    };
+    {
+        std::vector<std::thread> pool;
+        for (unsigned w = 1; w < workers; ++w) pool.emplace_back(print, w);
+        print(0);
+        for (auto& th : pool) th.join();
     }
-    char* buf = (char*)malloc(out.size() + 1);
+    size_t total = head_out.size();
+    for (auto& p2 : parts) total += p2.size();
+    char* buf = (char*)malloc(total + 1);
     if (!buf) { set_error("out of host memory"); return SPSP_ERR_NOMEM; }
-    memcpy(buf, out.data(), out.size());
-    buf[out.size()] = 0;
-    *text = buf; *len = out.size();
+    size_t pos = 0;
+    memcpy(buf, head_out.data(), head_out.size()); pos += head_out.size();
+    for (auto& p2 : parts) { memcpy(buf + pos, p2.data(), p2.size()); pos += p2.size(); }
+    buf[total] = 0;
+    *text = buf; *len = total;
     return SPSP_OK;
 }
 

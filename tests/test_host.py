@@ -315,6 +315,28 @@ def test_sort_csv_matches_oracle_and_restores_fof_order(n, precision):
         assert again == got
 
 
+def test_sort_csv_large_sparse_matrix_matches_oracle():
+    """sortCSV at the scale it is for (N3: the matrix of thousands of sketches, nearly all "0"): rows are parsed and printed by
+    several threads, cells that are not "0" kept sparsely, zero runs copied -- bytes equal the oracle's cell-by-cell sortCSV;
+    values that are not plain ("1e-05", "0.0", "-0") pass through strtod and %g as in the reference"""
+    rng = np.random.default_rng(21)
+    n = 1500
+    names = ["d/s%04d.gz" % i for i in range(n)]
+    card = rng.integers(3000, 9000, n).astype(np.uint64)
+    ii, jj = rng.integers(0, n, 8 * n), rng.integers(0, n, 8 * n)
+    keep = ii < jj
+    cells = np.unique((ii[keep].astype(np.uint64) << np.uint64(48)) | (jj[keep].astype(np.uint64) << np.uint64(32))) | np.uint64(41)
+    txt = sp.csv_cells(True, names, cells, card)
+    lines = txt.split(b"\n")
+    row = lines[3].split(b",")
+    row[7], row[9], row[11] = b"1e-05", b"0.0", b"-0"                     # (cells (2, 7), (2, 9), (2, 11) of an otherwise sparse row)
+    lines[3] = b",".join(row)
+    txt = b"\n".join(lines)
+    fof = ("\n".join(names[i] for i in rng.permutation(n)) + "\n").encode()
+    want = orc.sort_csv(txt, fof)
+    assert want is not None and sp.sort_csv(txt, fof) == want
+
+
 def test_sort_csv_rejects_what_the_reference_mishandles():
     rng = np.random.default_rng(5)
     names, shuffled, csv = _jaccard_csv(rng, 6)
