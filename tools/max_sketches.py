@@ -48,6 +48,25 @@ def main():
         assert (row[: i + 1] == 0).all()
     print("sampled cells wrong: %d" % bad)
     assert bad == 0
+    # the same comparison as sparse cells (four column blocks per row at this width: the cells leave every block's row sums)
+    cells = torch.zeros(1 << 25, dtype=torch.int64, device=dev)
+    scratch = torch.zeros_like(d_inter)                          # (the API asks for n x n; at this size the cells leave the row sums directly and it stays zero)
+    t0 = time.perf_counter()
+    cnt = ctx.compare_cells_device(31, d_mn.data_ptr(), d_lo.data_ptr(), None, sk_off, n, scratch.data_ptr(), cells.data_ptr(), cells.numel())
+    print("as cells: %d non-zero pairs in %.1f ms" % (cnt, (time.perf_counter() - t0) * 1e3))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    cnt2 = ctx.compare_cells_device(31, d_mn.data_ptr(), d_lo.data_ptr(), None, sk_off, n, scratch.data_ptr(), cells.data_ptr(), cells.numel())
+    print("as cells, again: %d non-zero pairs in %.1f ms" % (cnt2, (time.perf_counter() - t0) * 1e3))
+    nz = int(torch.count_nonzero(torch.triu(d_inter, 1)).item()) if n <= 20000 else None
+    cw = cells[:cnt]
+    ii, jj, cc = (cw >> 48) & 0xffff, (cw >> 32) & 0xffff, cw & 0xffffffff
+    assert bool((d_inter[ii, jj].to(torch.int64) == cc).all()) and bool((ii < jj).all())
+    sample_rows = rng.integers(0, n, size=20).tolist()
+    for i in sample_rows:
+        assert int((ii == i).sum().item()) == int(torch.count_nonzero(d_inter[i]).item())
+    print("scratch matrix written: %s" % bool(scratch.any().item()))
+    print("cells equal the dense matrix on every cell they name and on the non-zero counts of 20 sampled rows")
     try:
         ctx.compare_device(31, d_mn.data_ptr(), d_lo.data_ptr(), None, np.zeros(65538, np.uint64), 65536, 0, 1, d_inter.data_ptr())
         raise SystemExit("65536 sketches were accepted")
