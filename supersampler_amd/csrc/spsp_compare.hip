@@ -418,6 +418,11 @@ __global__ __launch_bounds__(kSparseThreads) void k_accumulate_sparse(const uint
             };
 #pragma unroll
             for (int q = 0; q < kAccW; ++q) if (q == 0 || len >= 8u * q) word(w[u][q], 8u * q);
+            // (long lists -- keys of one large family: every holder reads the whole list, h^2 x 2 bytes per key, and that traffic
+            // through the L2s is what such a key costs: 3.5 TB/s at 1 300 holders per key.  Tried and not kept: the waves taking a
+            // long list together, a lane per holder -- one list and its load latency at a time, 1.9x slower; every lane starting
+            // its walk at another word of its list, against meeting on the same counters -- 1.5x slower, they do not meet.
+            // Keys of that many holders get columns instead, see k_spill_pairs.)
             for (uint32_t q = kAccW; 8 * q <= len; ++q) word(L[q], 8 * q);
         }
         }
@@ -492,6 +497,7 @@ __global__ __launch_bounds__(256) void k_zero_rows(uint32_t n, uint32_t row_firs
 //   k_accumulate_sparse  as in the sketch-list form above: row sums by walking the lists
 // Parts have a fixed capacity; one that overflows (heavily duplicated keys) raises flags[6] and the host
 // falls back to the global-dictionary forms.
+constexpr uint32_t kColFlag = 0x80000000u;      // in place of a list offset: the key has a column of the bit matrix, not a list (k_spill_pairs)
 constexpr int kPartCap = 4096, kPartSlots = 7936, kGroupThreads = 1024;   // (record index + 1 fits the 13 low bits of a slot word)
 constexpr int kScatThreads = 1024, kScatPer = 4, kScatSub = kScatThreads * kScatPer;   // entries per sub-chunk
 constexpr int kMaxKeyParts = 32000;   // x ~2 900 records: 9 x 10^7 keys per comparison (BASELINE configs[3] has 5.2 x 10^7); x 16 Ki u16 of lists
@@ -637,7 +643,8 @@ __global__ __launch_bounds__(kScatThreads, 4) void k_parts_scatter(Keys K, const
 template <bool HAS_HI>
 __global__ __launch_bounds__(kGroupThreads) void k_parts_group(const uint64_t* __restrict__ recs, const uint32_t* __restrict__ part_cnt,
                                                               uint16_t* __restrict__ ids, uint32_t* __restrict__ list_of_slot,
-                                                              uint32_t* __restrict__ flags) {
+                                                              uint32_t* __restrict__ flags, uint32_t t_bits, uint32_t max_cols,
+                                                              unsigned long long* __restrict__ bits, uint32_t n_sk) {
     constexpr uint32_t W = HAS_HI ? 3 : 2;
     constexpr uint32_t R = kPartCap / kGroupThreads;      // records per thread
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_g[];
@@ -649,7 +656,7 @@ __global__ __launch_bounds__(kGroupThreads) void k_parts_group(const uint64_t* _
     const uint32_t p = blockIdx.x, t = threadIdx.x;
     const uint32_t n = part_cnt[p];
     if (t == 0) atomicAdd(&flags[7], n);                  // records in all parts: sizes the parts of a filtered call's next attempt
-    if (n > (uint32_t)kPartCap) { if (t == 0) atomicOr(&flags[6], 1u); return; }
+    if (n > (uint32_t)kPartCap) { if (t == 0) { atomicOr(&flags[6], 1u); atomicAdd(&flags[2], n); } return; }   // ([2]: records of all overflowed parts -- sizes the spill)
     for (uint32_t x = t; x < (uint32_t)kPartSlots; x += kGroupThreads) slot[x] = 0;
     if (t == 0) *cursor = 0;
     const uint64_t* base = recs + (uint64_t)p * kPartCap * W;
@@ -701,6 +708,12 @@ __global__ __launch_bounds__(kGroupThreads) void k_parts_group(const uint64_t* _
 #pragma unroll
     for (uint32_t u = 0; u < R; ++u) {
         if (!claimer[u] || cnt[u] < 2) continue;          // one thread per key held by >= 2 sketches
+        if (cnt[u] >= t_bits) {                           // spill attempts only (else t_bits = 0xffffffff): a column instead of a list, see k_spill_pairs
+            const uint32_t col = atomicAdd(&flags[9], 1u);
+            if (col >= max_cols) atomicOr(&flags[5], 1u);
+            slot[hs[u]] = kColFlag | (col < max_cols ? col : 0u);
+            continue;
+        }
         const uint32_t o = ids_base + atomicAdd(cursor, list_u16(cnt[u]));   // 8 u16 per 2..7 records: fits 4 x kPartCap
         ids[o] = (uint16_t)cnt[u];                        // a key is held at most once per sketch: <= 65535
         slot[hs[u]] = o;
@@ -713,8 +726,192 @@ __global__ __launch_bounds__(kGroupThreads) void k_parts_group(const uint64_t* _
         uint32_t* out = list_of_slot + (size_t)p * kPartCap + r;         // record order: coalesced
         if (cnt[u] < 2) { *out = kNoList; continue; }                    // held by one sketch: no pair to count
         const uint32_t o = slot[hs[u]];
+        if (o & kColFlag) {
+            const uint32_t col = o & ~kColFlag;
+            atomicOr(&bits[(uint64_t)(col >> 6) * n_sk + sk[u]], 1ull << (col & 63u));
+            *out = kNoList;
+            continue;
+        }
         ids[o + 1 + rank[u]] = (uint16_t)sk[u];
         *out = list_ref(o, cnt[u]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Spill: parts that overflow.  A part holds kPartCap records and is planned for 2 900; keys arrive with ALL their holders,
+// so a collection whose genomes come in families of a hundred or more (one species sequenced many times) makes parts
+// that do not fit -- whatever their number, since a key held by 5 000 sketches is 5 000 records of one part.  The records
+// of exactly those parts (every record of them: a key's holders must stay together) are grouped in a table in HBM instead:
+//   k_spill_insert   entry of an overflowed part -> slot of its key (claimed by entry number, full keys compared through
+//                    the claimer's entry), its rank among the key's holders
+//   k_spill_ranges   slot -> place of the key's holder list behind the parts' lists (workgroup prefix, one atomic per
+//                    workgroup), or -- a key held by t_bits sketches or more -- a COLUMN of the bit matrix below
+//   k_spill_fill     holder ids into the lists / bits into the columns; `where` of the entry -> its key's list reference
+// and the row sums run as for any other key.  Keys held by a large share of the sketches leave the lists altogether: one
+// such key costs a row-sum workgroup h LDS adds per holder (h^2 / 2 in all), while as one bit per sketch it costs every PAIR
+// of sketches one AND + popcount per 64 keys (k_spill_pairs: wavefront-wide popcounts, no MFMA -- BASELINE north_star).
+constexpr int kSpillThreads = 256;
+__device__ __forceinline__ uint32_t spill_home(uint64_t h, uint32_t log2cap) { return (uint32_t)(mix64(h ^ 0x8EBC6AF09C88C6E3ULL) >> (64 - log2cap)); }
+
+template <bool HAS_HI>
+__global__ __launch_bounds__(kSpillThreads) void k_spill_insert(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n, uint64_t S, uint64_t e_first,
+                                                               uint32_t row_first, uint32_t n_parts, const uint32_t* __restrict__ part_cnt,
+                                                               uint32_t* __restrict__ tbl, uint32_t log2cap, uint32_t* __restrict__ cnt,
+                                                               uint32_t* __restrict__ where, uint32_t* __restrict__ rank_of, uint32_t room,
+                                                               uint32_t* __restrict__ flags) {
+    if (flags[2] > room) return;                          // more records than this attempt has room for: the host repeats it with the count
+    const uint64_t e = e_first + (uint64_t)blockIdx.x * kSpillThreads + threadIdx.x;
+    if (e >= S) return;
+    const uint64_t lo = K.lo[e], hi = HAS_HI ? K.hi[e] : 0ull;
+    const uint32_t mn = K.mn[e];
+    const uint64_t h = key_hash(lo, mn, hi, HAS_HI);
+    if (part_cnt[(uint32_t)(((h >> 32) * n_parts) >> 32)] <= (uint32_t)kPartCap) return;
+    if (sketch_of(sk_off, n, e) < row_first) return;      // (the scatter deals nothing of the sketches in front of the first owned row)
+    const uint32_t mask = (1u << log2cap) - 1u;
+    uint32_t pos = spill_home(h, log2cap);
+    for (uint32_t probes = 0;; ++probes) {
+        uint32_t cur = tbl[pos];
+        if (cur == 0) cur = atomicCAS(&tbl[pos], 0u, (uint32_t)e + 1u);
+        if (cur == 0) break;                              // claimed
+        const uint64_t c = cur - 1u;
+        if (K.lo[c] == lo && K.mn[c] == mn && (!HAS_HI || K.hi[c] == hi)) break;
+        if (probes > mask) { atomicOr(&flags[5], 1u); where[e] = kNoWhere; return; }
+        pos = (pos + 1u) & mask;
+    }
+    rank_of[e] = atomicAdd(&cnt[pos], 1u);
+    where[e] = pos;                                       // (until k_spill_fill has run)
+}
+
+// flags[8] = u16 of lists handed out, flags[9] = columns handed out
+__global__ __launch_bounds__(kRowThreads) void k_spill_ranges(const uint32_t* __restrict__ cnt, uint64_t cap, uint32_t* __restrict__ off,
+                                                             uint16_t* __restrict__ ids, uint32_t ids_base, uint32_t ids_room,
+                                                             uint32_t* __restrict__ lref, uint32_t t_bits, uint32_t max_cols, uint32_t room,
+                                                             uint32_t* __restrict__ flags) {
+    if (flags[2] > room) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) flags[6] = 0;           // the overflowed parts are taken care of: the row sums may run
+    __shared__ uint32_t wave_sum[kRowThreads / 64], wave_cols[kRowThreads / 64];
+    __shared__ uint32_t s_base, s_cols;
+    const uint32_t t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const uint64_t base_slot = ((uint64_t)blockIdx.x * kRowThreads + t) * kRowSlots;   // 16 consecutive slots per lane
+    uint32_t c[kRowSlots];
+    uint32_t sum = 0, cols = 0;
+#pragma unroll
+    for (int u = 0; u < kRowSlots; ++u) {
+        const uint64_t sl = base_slot + u;
+        c[u] = sl < cap ? cnt[sl] : 0u;
+        if (c[u] >= t_bits) ++cols;
+        else if (c[u] >= 2) sum += list_u16(c[u]);       // (a key of one holder takes part in no pair: no list)
+    }
+    uint32_t x = sum, y = cols;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t x2 = __shfl_up(x, d), y2 = __shfl_up(y, d);
+        if (lane >= (uint32_t)d) { x += x2; y += y2; }
+    }
+    if (lane == 63) { wave_sum[wid] = x; wave_cols[wid] = y; }
+    __syncthreads();
+    uint32_t pre = 0, all = 0, pre_c = 0, all_c = 0;
+    for (uint32_t w = 0; w < kRowThreads / 64; ++w) {
+        if (w < wid) { pre += wave_sum[w]; pre_c += wave_cols[w]; }
+        all += wave_sum[w]; all_c += wave_cols[w];
+    }
+    if (t == 0) { s_base = all ? atomicAdd(&flags[8], all) : 0u; s_cols = all_c ? atomicAdd(&flags[9], all_c) : 0u; }
+    __syncthreads();
+    uint32_t at = s_base + pre + x - sum, col = s_cols + pre_c + y - cols;
+    if ((all && s_base + all > ids_room) || (all_c && s_cols + all_c > max_cols)) { if (t == 0) atomicOr(&flags[5], 1u); return; }   // (cannot happen: sized from the count)
+#pragma unroll
+    for (int u = 0; u < kRowSlots; ++u) {
+        if (c[u] < 2) continue;
+        const uint64_t sl = base_slot + u;
+        if (c[u] >= t_bits) { off[sl] = kColFlag | col; ++col; continue; }
+        off[sl] = at;
+        ids[ids_base + at] = (uint16_t)c[u];
+        lref[sl] = list_ref(ids_base + at, c[u]);
+        at += list_u16(c[u]);
+    }
+}
+
+template <bool HAS_HI>
+__global__ __launch_bounds__(kSpillThreads) void k_spill_fill(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n, uint64_t S, uint64_t e_first,
+                                                             uint32_t row_first, uint32_t n_parts, const uint32_t* __restrict__ part_cnt,
+                                                             const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
+                                                             uint16_t* __restrict__ ids, uint32_t ids_base, uint32_t lref_base,
+                                                             unsigned long long* __restrict__ bits, uint32_t* __restrict__ where,
+                                                             const uint32_t* __restrict__ rank_of, uint32_t room, const uint32_t* __restrict__ flags) {
+    if (flags[2] > room || flags[5]) return;
+    const uint64_t e = e_first + (uint64_t)blockIdx.x * kSpillThreads + threadIdx.x;
+    if (e >= S) return;
+    const uint64_t h = key_hash(K.lo[e], K.mn[e], HAS_HI ? K.hi[e] : 0ull, HAS_HI);
+    if (part_cnt[(uint32_t)(((h >> 32) * n_parts) >> 32)] <= (uint32_t)kPartCap) return;
+    const uint32_t j = sketch_of(sk_off, n, e);
+    if (j < row_first) return;
+    const uint32_t pos = where[e];
+    if (pos == kNoWhere) return;
+    const uint32_t c = cnt[pos];
+    if (c < 2) { where[e] = kNoWhere; return; }           // held by this sketch only
+    const uint32_t o = off[pos];
+    if (o & kColFlag) {                                   // one bit per holder: word (column / 64) of sketch j
+        const uint32_t col = o & ~kColFlag;
+        atomicOr(&bits[(uint64_t)(col >> 6) * n + j], 1ull << (col & 63u));
+        where[e] = kNoWhere;                              // (no list: the row sums pass it by)
+        return;
+    }
+    ids[ids_base + o + 1u + rank_of[e]] = (uint16_t)j;
+    where[e] = lref_base + pos;
+}
+
+// Pair counts of the keys that have a column: cell (i, j > i) += popcount(bits[.][i] & bits[.][j]) over the words in use.
+// A workgroup takes a 64 x 64 tile of pairs, a thread 4 x 4 of them (rows p * 16 + t / 16, columns q * 16 + t % 16: the
+// sixteen lanes of a row read consecutive LDS words and store consecutive cells); the two 64-sketch panels pass through
+// LDS kPairWords words at a time (a word of 64 consecutive sketches is one 512-byte line run).  v_and + v_bcnt
+// (popcount-accumulate): four VALU instructions per pair and 64 keys -- the kernel runs at the VALU issue rate (4.6 x 10^13
+// lane operations/s measured), so larger tiles buy nothing (128 x 128, 8 x 8 per thread: 15 % slower, fewer waves per SIMD).
+// Tile pairs are dealt to the XCDs in runs, so that the tiles of one row of tiles (same first panel) sit behind one L2.
+constexpr int kPairTile = 64, kPairWords = 16, kPairThreads = 256, kPairR = kPairTile / 16;
+__global__ __launch_bounds__(kPairThreads) void k_spill_pairs(const unsigned long long* __restrict__ bits, uint32_t n, uint32_t tiles,
+                                                             uint32_t row_first, uint32_t row_stride, uint32_t row_limit,
+                                                             uint32_t* __restrict__ inter, const uint32_t* __restrict__ flags) {
+    const uint32_t words = (flags[9] + 63u) >> 6;
+    if (words == 0 || flags[6] || flags[5]) return;
+    const uint32_t total = tiles * (tiles + 1) / 2, per_xcd = gridDim.x >> 3;          // (the grid is a multiple of 8)
+    uint32_t left = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (left >= total) return;
+    // tile pair (bi <= bj) from its flat number: row bi of the upper triangle holds tiles - bi pairs
+    uint32_t bi = 0;
+    while (left >= tiles - bi) { left -= tiles - bi; ++bi; }
+    const uint32_t bj = bi + left;
+    __shared__ unsigned long long a[kPairWords][kPairTile], b[kPairWords][kPairTile];
+    const uint32_t t = threadIdx.x, ti = t >> 4, tj = t & 15u;
+    uint32_t acc[kPairR][kPairR] = {};
+    for (uint32_t w0 = 0; w0 < words; w0 += kPairWords) {
+        for (uint32_t x = t; x < kPairWords * kPairTile; x += kPairThreads) {
+            const uint32_t w = w0 + x / kPairTile, c = x % kPairTile;
+            const uint32_t si = bi * kPairTile + c, sj = bj * kPairTile + c;
+            a[x / kPairTile][c] = (w < words && si < n) ? bits[(uint64_t)w * n + si] : 0ull;
+            b[x / kPairTile][c] = (w < words && sj < n) ? bits[(uint64_t)w * n + sj] : 0ull;
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (uint32_t w = 0; w < kPairWords; ++w) {
+            unsigned long long va[kPairR], vb[kPairR];
+#pragma unroll
+            for (int q = 0; q < kPairR; ++q) { va[q] = a[w][q * 16 + ti]; vb[q] = b[w][q * 16 + tj]; }
+#pragma unroll
+            for (int p = 0; p < kPairR; ++p)
+#pragma unroll
+                for (int q = 0; q < kPairR; ++q) acc[p][q] += (uint32_t)__popcll(va[p] & vb[q]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int p = 0; p < kPairR; ++p) {
+        const uint32_t i = bi * kPairTile + p * 16 + ti;
+        if (i >= n || !owned_row(i, row_first, row_stride, row_limit)) continue;
+#pragma unroll
+        for (int q = 0; q < kPairR; ++q) {
+            const uint32_t j = bj * kPairTile + q * 16 + tj;
+            if (j < n && j > i && acc[p][q]) inter[(uint64_t)i * n + j] += acc[p][q];   // (the row sums have stored the cell: same stream, earlier kernel)
+        }
     }
 }
 
@@ -912,6 +1109,9 @@ __global__ __launch_bounds__(kAccThreads) void k_accumulate(const uint32_t* __re
 // Like the scan it is split at its host synchronisation: compare_job_begin queues the
 // (speculative) pipeline and returns, compare_job_end waits, checks the flags and --
 // only after a fingerprint collision or for inputs too large to speculate -- queues more.
+// room = records the table and the lists are sized for; the key table has 2^log2cap slots; keys held by t_bits sketches or
+// more get a column of the bit matrix (0xffffffff: none do); lists / list references of spilled keys start at ids_base / lref_base
+struct SpillPlan { uint64_t room = 0; uint32_t log2cap = 0, t_bits = 0xffffffffu, max_cols = 0, ids_base = 0, ids_room = 0, lref_base = 0; };
 struct ComparePlan {
     uint64_t S_own;        // upper bound on the keys inserted (sizes the table and the speculative matrix)
     uint64_t S_entries;    // entry index space (sizes row_of_entry)
@@ -941,7 +1141,7 @@ struct CompareJob {
                                     // matrix are built class by class, so the matrix never exceeds its budget
     // partition form (flat entry point): see k_parts_scatter
     std::function<int(uint32_t n_parts, bool small, bool filtered, uint32_t fmask)> scatter_parts;
-    std::function<int(uint32_t n_parts)> group_parts;
+    std::function<int(uint32_t n_parts, const SpillPlan&)> group_parts;
     std::function<int(uint32_t n_parts)> group_small;     // small problems: grouping + counting in one kernel (k_parts_group_small)
     bool parts = false, small = false;
     uint32_t n_parts = 0, parts_attempt = 0, n_sub = 0;
@@ -951,6 +1151,9 @@ struct CompareJob {
     uint32_t filter_words = 0;
     uint64_t parts_entries = 0;     // records the parts are sized for
     bool bracket_closed = false;    // the kEvCompare bracket of the begin call has been closed already
+    // spill (partition form, unfiltered): the records of parts that overflow are grouped in a table in HBM (k_spill_insert)
+    SpillPlan spill;                // room = 0: not part of this attempt
+    std::function<int(uint32_t n_parts, const SpillPlan&, int phase)> spill_parts;   // phase 0: buffers cleared (in front of the scatter), 1: the kernels (behind the grouping)
 };
 // flags: [0] unsorted input, [1] fingerprint collision, [2] n_rows, [3] malformed slot, [4] slot overflow, [5] table full
 static uint64_t job_fp_mask(const CompareJob& J) {
@@ -1012,7 +1215,8 @@ static int job_parts(spsp_ctx* ctx, CompareJob& J) {
     ctx->cells_req.direct = false;                            // (set by the row sums of the general form when they emit cells)
     int rc;
     if ((rc = ctx->c_part_cnt.reserve((size_t)J.n_parts * 4))) return rc;
-    if (!J.small && (rc = ctx->c_matrix.reserve((size_t)J.n_parts * 4 * kPartCap * sizeof(uint16_t)))) return rc;     // sketch lists
+    if (!J.small && (rc = ctx->c_matrix.reserve(((size_t)J.n_parts * 4 * kPartCap + J.spill.ids_room) * sizeof(uint16_t)))) return rc;     // sketch lists
+    if (J.spill.room && (rc = ctx->c_lref.reserve(((size_t)J.spill.lref_base + ((size_t)1 << J.spill.log2cap)) * 4))) return rc;             // (before the scatter asks for less)
     if (J.filtered && (rc = ctx->c_filter.reserve((size_t)J.filter_words * 4))) return rc;
     const uint32_t filter_vec = J.filtered ? J.filter_words / 4 : 0u;
     const uint32_t most = std::max(std::max(std::max(J.n_parts, J.n_skoff), std::max(J.n_sub, J.small ? J.P.n * J.P.n : 0u)), filter_vec);
@@ -1027,17 +1231,26 @@ static int job_parts(spsp_ctx* ctx, CompareJob& J) {
     static const int skip = getenv("SPSP_DEBUG_SKIP_STAGES") ? atoi(getenv("SPSP_DEBUG_SKIP_STAGES")) : 0;
     if ((rc = ctx->ev_begin(kEvScatter))) return rc;
     if (J.filtered && (rc = J.build_filter(J.filter_words - 1))) return rc;
+    if (J.spill.room && !J.small && (rc = J.spill_parts(J.n_parts, J.spill, 0))) return rc;
     if (!(skip & 1) && (rc = J.scatter_parts(J.n_parts, J.small, J.filtered, J.filter_words - 1))) return rc;
     if ((rc = ctx->ev_end(kEvScatter))) return rc;
     if ((rc = ctx->ev_begin(kEvGroup))) return rc;
-    if (!(skip & 2) && (rc = J.small ? J.group_small(J.n_parts) : J.group_parts(J.n_parts))) return rc;
+    if (!(skip & 2) && (rc = J.small ? J.group_small(J.n_parts) : J.group_parts(J.n_parts, J.spill))) return rc;
+    if (J.spill.room && !J.small && (rc = J.spill_parts(J.n_parts, J.spill, 1))) return rc;
     if ((rc = ctx->ev_end(kEvGroup))) return rc;
     if (J.small) return job_queue_flags(ctx);             // (no later kernel forwards the flags)
     if ((rc = ctx->ev_begin(kEvAccumulate))) return rc;
     ComparePlan PP = J.P;
     PP.list_ref = ctx->c_lref.as<uint32_t>(); PP.where = ctx->c_where.as<uint32_t>();
     // (an attempt whose parts overflow leaves this kernel at its first line, before any cell is emitted: the retry emits them once)
-    if (!(skip & 4) && (rc = launch_accumulate_sparse(ctx, PP, flags, true))) return rc;
+    // (with a spill the keys that have columns add into the dense matrix behind the row sums: no cells straight from them)
+    if (!(skip & 4) && (rc = launch_accumulate_sparse(ctx, PP, flags, J.spill.room == 0))) return rc;
+    if (J.spill.room && J.spill.t_bits != 0xffffffffu) {
+        const uint32_t tiles = (J.P.n + kPairTile - 1) / kPairTile;
+        hipLaunchKernelGGL(k_spill_pairs, dim3((tiles * (tiles + 1) / 2 + 7) / 8 * 8), dim3(kPairThreads), 0, ctx->stream, ctx->c_bits.as<unsigned long long>(),
+                           J.P.n, tiles, J.P.row_first, J.P.row_stride, J.P.row_limit, J.P.d_inter, (const uint32_t*)flags);
+        SPSP_HIP(hipGetLastError());
+    }
     if ((rc = ctx->ev_end(kEvAccumulate))) return rc;
     return job_mark_done(ctx);
 }
@@ -1198,6 +1411,28 @@ static uint32_t parts_for(uint64_t entries, uint32_t attempt) {
     return (uint32_t)std::max<uint64_t>(1, (entries + mean - 1) / mean);
 }
 
+// Can the records of overflowed parts (`records` of them) be grouped beside n_parts parts?  The lists must stay inside
+// the 2^29 u16 a list reference can address and the list references inside a `where` word.
+static bool spill_plan(const CompareJob& J, uint64_t records, SpillPlan* sp) {
+    static const char* dbg_spill = getenv("SPSP_DEBUG_SPILL");          // "0": the forms of before (half-size parts, then the global dictionary)
+    if (dbg_spill && dbg_spill[0] == '0') return false;
+    if (!J.spill_parts || J.small || J.filtered || records == 0) return false;
+    SpillPlan P;
+    P.room = std::min<uint64_t>(records, J.P.S_entries);
+    P.log2cap = 10;
+    while ((1ull << P.log2cap) < 2 * P.room) ++P.log2cap;
+    const uint64_t ids_base = (uint64_t)J.n_parts * 4 * kPartCap, ids_room = 4 * P.room + 8, lref_base = (uint64_t)J.n_parts * kPartCap;
+    if (P.log2cap > 31 || ids_base + ids_room > (1ull << 29) || lref_base + (1ull << P.log2cap) >= 0xffffffffull) return false;
+    P.ids_base = (uint32_t)ids_base; P.ids_room = (uint32_t)ids_room; P.lref_base = (uint32_t)lref_base;
+    // a key held by h sketches costs the row sums h^2 / 2 LDS adds and the pair kernel N^2 / 128 word operations: columns from
+    // N / 24 holders on (measured rates); SPSP_DEBUG_SPILL_BITS=<holders> sets the threshold, 0 = lists only
+    static const char* dbg_bits = getenv("SPSP_DEBUG_SPILL_BITS");
+    P.t_bits = dbg_bits ? (atoi(dbg_bits) > 0 ? (uint32_t)std::max(2, atoi(dbg_bits)) : 0xffffffffu) : std::max(64u, J.P.n / 24u);
+    P.max_cols = P.t_bits == 0xffffffffu ? 0u : (uint32_t)(J.P.S_entries / P.t_bits + 1);   // (any part may hold such keys, overflowed or not)
+    *sp = P;
+    return true;
+}
+
 // takes ownership of `job`; on success it is pending on the context until compare_job_end
 static int compare_job_begin(spsp_ctx* ctx, CompareJob* job) {
     std::unique_ptr<CompareJob> J(job);
@@ -1238,6 +1473,9 @@ static int compare_job_begin(spsp_ctx* ctx, CompareJob* job) {
         }
         J->n_parts = J->small ? parts_small(P.S_entries) : parts_for(J->parts_entries, 0);
         if ((rc = ctx->c_row.reserve((size_t)P.S_entries * 4))) return rc;
+        // the context's last comparison spilled: this one is queued with room for as much again (a collection is compared
+        // batch after batch of the same kind); a guess that turns out too small costs one more attempt, nothing else
+        if (ctx->spill_expect && !spill_plan(*J, ctx->spill_expect + ctx->spill_expect / 4 + 4096, &J->spill)) J->spill = SpillPlan{};
         if ((rc = job_parts(ctx, *J))) return rc;
     } else if ((rc = job_begin_dictionary(ctx, J.get()))) return rc;
     ctx->compare_job = J.release();
@@ -1253,8 +1491,15 @@ int compare_job_end(spsp_ctx* ctx) {
         uint32_t h_flags[kFlags];
         if ((rc = job_wait_flags(ctx, h_flags))) return rc;
         if (J->filtered && h_flags[7]) ctx->filter_ratio = (double)h_flags[7] / (double)J->P.S_own;
-        if (!h_flags[6]) return SPSP_OK;
-        // a part overflowed (many sketches share their keys): once more with parts half the size, then the
+        if (!h_flags[6]) {
+            if (!J->filtered && !J->small) ctx->spill_expect = h_flags[2];
+            static const bool trace = getenv("SPSP_DEBUG_SPILL_TRACE") != nullptr;     // test hook: which way the comparison went
+            if (trace && J->spill.room) fprintf(stderr, "spsp spill: %u records of overflowed parts grouped in HBM (room %llu, %u parts, columns from %u holders)\n",
+                                                h_flags[2], (unsigned long long)J->spill.room, J->n_parts, J->spill.t_bits);
+            return SPSP_OK;
+        }
+        // a part overflowed (many sketches share their keys): the same parts once more with the records of the
+        // overflowed ones grouped in HBM (spill); where that does not apply, parts half the size, then the
         // global-dictionary forms, which have no such limit
         J->bracket_closed = true;
         if (J->filtered && h_flags[7] > J->parts_entries) {   // more keys passed the filter than the parts were sized for: now the count is known
@@ -1272,6 +1517,11 @@ int compare_job_end(spsp_ctx* ctx) {
             if ((rc = job_parts(ctx, *J))) return rc;
             continue;
         }
+        if (!J->small && h_flags[2] > J->spill.room && spill_plan(*J, h_flags[2], &J->spill)) {   // (the count is exact: the same parts overflow again)
+            if ((rc = job_parts(ctx, *J))) return rc;
+            continue;
+        }
+        J->spill = SpillPlan{};
         if (J->parts_attempt == 0 && parts_for(J->parts_entries, 1) <= (uint32_t)kMaxKeyParts) {
             J->parts_attempt = 1;
             J->n_parts = parts_for(J->parts_entries, 1);
@@ -1456,23 +1706,59 @@ static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t*
         SPSP_HIP(hipGetLastError());
         return SPSP_OK;
     };
-    J->group_parts = [=](uint32_t n_parts) -> int {
+    J->group_parts = [=](uint32_t n_parts, const SpillPlan& sp) -> int {
         const size_t lds = (size_t)kPartCap * (8 + (has_hi ? 8 : 0) + 4) + (size_t)kPartSlots * 4 + 16;
+        // (a spill attempt: keys of many holders get columns here too -- a part they do not overflow would otherwise list them)
+        const uint32_t t_bits = sp.room ? sp.t_bits : 0xffffffffu, max_cols = sp.room ? sp.max_cols : 0u;
+        unsigned long long* bits = (sp.room && sp.max_cols) ? ctx->c_bits.as<unsigned long long>() : (unsigned long long*)nullptr;
         if (has_hi) {
             if (!ctx->attr_group_hi_set) {
                 SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_parts_group<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 ctx->attr_group_hi_set = true;
             }
             hipLaunchKernelGGL(k_parts_group<true>, dim3(n_parts), dim3(kGroupThreads), lds, ctx->stream, ctx->c_recs.as<uint64_t>(),
-                               ctx->c_part_cnt.as<uint32_t>(), ctx->c_matrix.as<uint16_t>(), ctx->c_lref.as<uint32_t>(), flags);
+                               ctx->c_part_cnt.as<uint32_t>(), ctx->c_matrix.as<uint16_t>(), ctx->c_lref.as<uint32_t>(), flags, t_bits, max_cols, bits, n);
         } else {
             if (!ctx->attr_group_set) {
                 SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_parts_group<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 ctx->attr_group_set = true;
             }
             hipLaunchKernelGGL(k_parts_group<false>, dim3(n_parts), dim3(kGroupThreads), lds, ctx->stream, ctx->c_recs.as<uint64_t>(),
-                               ctx->c_part_cnt.as<uint32_t>(), ctx->c_matrix.as<uint16_t>(), ctx->c_lref.as<uint32_t>(), flags);
+                               ctx->c_part_cnt.as<uint32_t>(), ctx->c_matrix.as<uint16_t>(), ctx->c_lref.as<uint32_t>(), flags, t_bits, max_cols, bits, n);
         }
+        SPSP_HIP(hipGetLastError());
+        return SPSP_OK;
+    };
+    J->spill_parts = [=](uint32_t n_parts, const SpillPlan& sp, int phase) -> int {
+        const uint64_t slots = 1ull << sp.log2cap;
+        int r2;
+        if (phase == 0) {
+            if ((r2 = ctx->c_table.reserve((size_t)slots * 4)) || (r2 = ctx->c_owner.reserve((size_t)slots * 4)) || (r2 = ctx->c_rowid.reserve((size_t)slots * 4))) return r2;
+            SPSP_HIP(hipMemsetAsync(ctx->c_table.p, 0, (size_t)slots * 4, ctx->stream));
+            SPSP_HIP(hipMemsetAsync(ctx->c_owner.p, 0, (size_t)slots * 4, ctx->stream));
+            if (sp.max_cols) {
+                const size_t bytes = (size_t)((sp.max_cols + 63) / 64) * n * 8;
+                if ((r2 = ctx->c_bits.reserve(bytes))) return r2;
+                SPSP_HIP(hipMemsetAsync(ctx->c_bits.p, 0, bytes, ctx->stream));
+            }
+            return SPSP_OK;
+        }
+        const dim3 grid((uint32_t)((S - e_own + kSpillThreads - 1) / kSpillThreads));
+        uint32_t *tbl = ctx->c_table.as<uint32_t>(), *cnt = ctx->c_owner.as<uint32_t>(), *off = ctx->c_rowid.as<uint32_t>();
+        uint32_t *where = ctx->c_where.as<uint32_t>(), *rank_of = ctx->c_row.as<uint32_t>();
+        const uint32_t* part_cnt = ctx->c_part_cnt.as<uint32_t>();
+        const uint32_t room = (uint32_t)sp.room;
+        if (has_hi) hipLaunchKernelGGL(k_spill_insert<true>, grid, dim3(kSpillThreads), 0, ctx->stream, K, sk, n, S, e_own, row_first, n_parts, part_cnt, tbl, sp.log2cap, cnt, where, rank_of, room, flags);
+        else hipLaunchKernelGGL(k_spill_insert<false>, grid, dim3(kSpillThreads), 0, ctx->stream, K, sk, n, S, e_own, row_first, n_parts, part_cnt, tbl, sp.log2cap, cnt, where, rank_of, room, flags);
+        SPSP_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_spill_ranges, dim3((uint32_t)((slots + (uint64_t)kRowThreads * kRowSlots - 1) / ((uint64_t)kRowThreads * kRowSlots))), dim3(kRowThreads), 0, ctx->stream,
+                           (const uint32_t*)cnt, slots, off, ctx->c_matrix.as<uint16_t>(), sp.ids_base, sp.ids_room, ctx->c_lref.as<uint32_t>() + sp.lref_base, sp.t_bits, sp.max_cols, room, flags);
+        SPSP_HIP(hipGetLastError());
+        unsigned long long* bits = sp.max_cols ? ctx->c_bits.as<unsigned long long>() : (unsigned long long*)nullptr;
+        if (has_hi) hipLaunchKernelGGL(k_spill_fill<true>, grid, dim3(kSpillThreads), 0, ctx->stream, K, sk, n, S, e_own, row_first, n_parts, part_cnt, (const uint32_t*)cnt, (const uint32_t*)off,
+                                       ctx->c_matrix.as<uint16_t>(), sp.ids_base, sp.lref_base, bits, where, (const uint32_t*)rank_of, room, (const uint32_t*)flags);
+        else hipLaunchKernelGGL(k_spill_fill<false>, grid, dim3(kSpillThreads), 0, ctx->stream, K, sk, n, S, e_own, row_first, n_parts, part_cnt, (const uint32_t*)cnt, (const uint32_t*)off,
+                                ctx->c_matrix.as<uint16_t>(), sp.ids_base, sp.lref_base, bits, where, (const uint32_t*)rank_of, room, (const uint32_t*)flags);
         SPSP_HIP(hipGetLastError());
         return SPSP_OK;
     };

@@ -1407,3 +1407,76 @@ def test_sketch_files_dealt_over_a_device_list(tmp_path):
     want = [orc.sketch_fasta(t, k, m, float(np.float32(s)))[0] for t in texts]
     for i in range(len(ins)):
         assert gzip.open(tmp_path / ("two_d%d.gz" % i), "rb").read() == want[i], i
+
+
+_ONE_SPECIES = r"""
+import numpy as np, sys, os
+sys.path.insert(0, %r)
+import supersampler_amd as sp
+import torch
+use_hi = bool(int(sys.argv[1])); n = int(sys.argv[2])
+rng = np.random.default_rng(n + use_hi)
+U = 2600                                            # ancestral keys: held by 90 %% / 50 %% / 10 %% / 1 %% of the sketches
+share = np.repeat([0.9, 0.5, 0.1, 0.01], U // 4)
+B = rng.random((n, U)) < share[None, :]
+B[n // 3] = False                                   # an empty sketch
+B[n // 2] = B[n // 2 - 1]                           # two identical ones
+anc = np.stack([rng.integers(0, 2**22, U), rng.integers(0, 2**62, U), rng.integers(0, 2**62, U) if use_hi else np.zeros(U, np.int64)], 1)
+sketches, sizes = [], []
+for i in range(n):
+    own = np.stack([rng.integers(0, 2**22, 150), rng.integers(0, 2**62, 150), rng.integers(0, 2**62, 150) if use_hi else np.zeros(150, np.int64)], 1)
+    keys = np.concatenate([anc[B[i]], own]) if B[i].any() else anc[:0]
+    order = np.lexsort((keys[:, 1], keys[:, 2], keys[:, 0]))          # by (minimizer, kmer_hi, kmer_lo)
+    keys = keys[order]
+    sizes.append(len(keys))
+    sketches.append(sp.Sketch(63 if use_hi else 31, 11, keys[:, 0].astype(np.uint32), keys[:, 1].astype(np.uint64), keys[:, 2].astype(np.uint64)))
+want = np.triu(B.astype(np.int64) @ B.astype(np.int64).T, 1)
+ctx = sp.Context(0)
+for rep in range(2):                                # (the second call is queued with the spill from the start)
+    inter, card = ctx.compare(sketches)
+    assert [int(c) for c in card] == sizes
+    assert (np.triu(inter.astype(np.int64), 1) == want).all(), rep
+# a collection that does not overflow, then the species again
+small = sketches[: n // 8]
+inter, _ = ctx.compare(small)
+assert (np.triu(inter.astype(np.int64), 1) == want[: n // 8, : n // 8]).all()
+inter, _ = ctx.compare(sketches)
+assert (np.triu(inter.astype(np.int64), 1) == want).all()
+# query mode (rows of the first sketches only) and the result as sparse cells
+q = 37
+inter, _ = ctx.compare(sketches, n_query=q)
+assert (np.triu(inter.astype(np.int64), 1)[:q] == want[:q]).all()
+dev = torch.device("cuda", 0)
+mn = torch.from_numpy(np.concatenate([s.minimizer for s in sketches]).astype(np.int32)).to(dev)
+lo = torch.from_numpy(np.concatenate([s.kmer_lo for s in sketches]).view(np.int64)).to(dev)
+hi = torch.from_numpy(np.concatenate([s.kmer_hi for s in sketches]).view(np.int64)).to(dev) if use_hi else None
+sk_off = np.zeros(n + 1, np.uint64); sk_off[1:] = np.cumsum(sizes)
+scratch = torch.zeros((n, n), dtype=torch.int32, device=dev)
+cells = torch.zeros(n * n, dtype=torch.int64, device=dev)
+cnt = ctx.compare_cells_device(63 if use_hi else 31, mn.data_ptr(), lo.data_ptr(), hi.data_ptr() if use_hi else None, sk_off, n, scratch.data_ptr(), cells.data_ptr(), cells.numel())
+c = cells[:cnt].cpu().numpy()
+got = np.zeros((n, n), np.int64)
+got[(c >> 48) & 0xffff, (c >> 32) & 0xffff] = c & 0xffffffff
+assert cnt == np.count_nonzero(want) and (got == want).all()
+# rows dealt i %% 3 (a rank of a row-partitioned comparison)
+d_inter = torch.zeros((n, n), dtype=torch.int32, device=dev)
+ctx.compare_device(63 if use_hi else 31, mn.data_ptr(), lo.data_ptr(), hi.data_ptr() if use_hi else None, sk_off, n, 1, 3, d_inter.data_ptr())
+got = d_inter.cpu().numpy().astype(np.int64)
+assert (got[1::3] == want[1::3]).all() and not got[0::3].any() and not got[2::3].any()
+print("ok")
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_hi,n,env", [(0, 400, {}), (1, 300, {}), (0, 400, {"SPSP_DEBUG_SPILL_BITS": "0"}), (0, 300, {"SPSP_DEBUG_SPILL_BITS": "2"}),
+                                          (1, 260, {"SPSP_DEBUG_SPILL": "0"}), (0, 330, {"SPSP_DEBUG_FILTER": "0"})])
+def test_compare_one_species_collection_spills_overflowed_parts(use_hi, n, env):
+    """Hundreds of sketches that share most of their keys (one species sequenced many times): a key arrives in its part
+    with all its holders, parts overflow whatever their number, and their records are grouped in HBM instead (k_spill_*):
+    holder lists for the keys of few sketches, columns of the bit matrix + popcounts for the keys of many
+    (SPSP_DEBUG_SPILL_BITS: lists only / columns only; SPSP_DEBUG_SPILL=0: the global dictionary of before).  Every pair
+    against B B^T of the incidence matrix, all-vs-all, query mode, as cells and for a rank's rows; k <= 32 and k > 32."""
+    r = subprocess.run([sys.executable, "-c", _ONE_SPECIES % ROOT, str(use_hi), str(n)], env=dict(os.environ, SPSP_DEBUG_SPILL_TRACE="1", **env),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+    assert ("spsp spill:" in r.stderr) == (env.get("SPSP_DEBUG_SPILL") != "0"), r.stderr[-2000:]
