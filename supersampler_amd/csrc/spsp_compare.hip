@@ -338,7 +338,7 @@ __global__ __launch_bounds__(kSparseThreads) void k_accumulate_sparse(const uint
                                                                      const uint32_t* __restrict__ flags,
                                                                      uint32_t* __restrict__ host_flags,
                                                                      unsigned long long* __restrict__ cells, unsigned long long cells_cap,
-                                                                     unsigned long long* __restrict__ cells_count, uint32_t xcd_rows) {
+                                                                     unsigned long long* __restrict__ cells_count, uint32_t xcd_rows, bool add) {
     extern __shared__ uint32_t s_cnt[];
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < kFlags) host_flags[threadIdx.x] = flags[threadIdx.x];
     // a part overflowed: its workgroup of k_parts_group left without writing list references, so the ones in place are
@@ -472,6 +472,7 @@ __global__ __launch_bounds__(kSparseThreads) void k_accumulate_sparse(const uint
             uint32_t v = 0;
             for (uint32_t k = 0; k < copies; ++k) v += counter((x << copies_log2) + k);
             if (split > 1) { if (v) atomicAdd(&inter[(uint64_t)i * n + col], v); }
+            else if (add) { if (v) inter[(uint64_t)i * n + col] += v; }     // (a later key class of a very large input: the cell is this workgroup's alone)
             else inter[(uint64_t)i * n + col] = v;
         }
     }
@@ -503,6 +504,8 @@ constexpr int kScatThreads = 1024, kScatPer = 4, kScatSub = kScatThreads * kScat
 constexpr int kMaxKeyParts = 32000;   // x ~2 900 records: 9 x 10^7 keys per comparison (BASELINE configs[3] has 5.2 x 10^7); x 16 Ki u16 of lists
                                       // each stays inside the 2^29 u16 a list reference can address
 
+// key class of a pass (bits the part and the slot of a key depend on least)
+__device__ __forceinline__ uint32_t key_class(uint64_t h, uint32_t classes) { return (uint32_t)((((h >> 8) & 0xffffffull) * classes) >> 24); }
 __device__ __forceinline__ uint64_t key_hash(uint64_t lo, uint32_t mn, uint64_t hi, bool has_hi) {
     uint64_t h = mix64(lo ^ 0xA0761D6478BD642FULL);
     h = mix64(h + (uint64_t)mn * 0xE7037ED1A0B428DBULL);
@@ -557,7 +560,8 @@ __global__ __launch_bounds__(kScatThreads, 4) void k_parts_scatter(Keys K, const
                                                                uint32_t cap, uint32_t* __restrict__ part_cnt, uint64_t* __restrict__ recs,
                                                                uint32_t* __restrict__ where, uint32_t* __restrict__ flags, bool check_order,
                                                                const uint32_t* __restrict__ filter, uint32_t fmask, uint64_t e_first,
-                                                               uint32_t row_first, uint32_t row_stride, uint32_t row_limit) {
+                                                               uint32_t row_first, uint32_t row_stride, uint32_t row_limit,
+                                                               uint32_t classes, uint32_t cls) {
     constexpr uint32_t W = HAS_HI ? 3 : 2;
     extern __shared__ uint32_t hist[];                   // [n_parts]
     const uint32_t t = threadIdx.x, lane = t & 63;
@@ -599,6 +603,10 @@ __global__ __launch_bounds__(kScatThreads, 4) void k_parts_scatter(Keys K, const
         const uint64_t e = base + (uint64_t)u * kScatThreads + t;
         hsh[u] = key_hash(lo[u], mn[u], hi[u], HAS_HI);
         keep[u] = e < S && sk_of[u] >= row_first;        // (sketches in front of the first owned row are never counted by an owned row)
+        if (classes > 1 && keep[u] && key_class(hsh[u], classes) != cls) {   // very large inputs: one class of keys per pass (compare_job_begin)
+            keep[u] = false;
+            where[e] = kNoWhere;                         // (the row sums of this pass read every entry of their row)
+        }
         if (filter && keep[u] && !owned_row(sk_of[u], row_first, row_stride, row_limit)) {
             const uint32_t bits = filter_bits(hsh[u]);
             keep[u] = (filter[(uint32_t)hsh[u] & fmask] & bits) == bits;
@@ -758,13 +766,14 @@ __global__ __launch_bounds__(kSpillThreads) void k_spill_insert(Keys K, const ui
                                                                uint32_t row_first, uint32_t n_parts, const uint32_t* __restrict__ part_cnt,
                                                                uint32_t* __restrict__ tbl, uint32_t log2cap, uint32_t* __restrict__ cnt,
                                                                uint32_t* __restrict__ where, uint32_t* __restrict__ rank_of, uint32_t room,
-                                                               uint32_t* __restrict__ flags) {
+                                                               uint32_t* __restrict__ flags, uint32_t classes, uint32_t cls) {
     if (flags[2] > room) return;                          // more records than this attempt has room for: the host repeats it with the count
     const uint64_t e = e_first + (uint64_t)blockIdx.x * kSpillThreads + threadIdx.x;
     if (e >= S) return;
     const uint64_t lo = K.lo[e], hi = HAS_HI ? K.hi[e] : 0ull;
     const uint32_t mn = K.mn[e];
     const uint64_t h = key_hash(lo, mn, hi, HAS_HI);
+    if (classes > 1 && key_class(h, classes) != cls) return;
     if (part_cnt[(uint32_t)(((h >> 32) * n_parts) >> 32)] <= (uint32_t)kPartCap) return;
     if (sketch_of(sk_off, n, e) < row_first) return;      // (the scatter deals nothing of the sketches in front of the first owned row)
     const uint32_t mask = (1u << log2cap) - 1u;
@@ -837,11 +846,13 @@ __global__ __launch_bounds__(kSpillThreads) void k_spill_fill(Keys K, const uint
                                                              const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
                                                              uint16_t* __restrict__ ids, uint32_t ids_base, uint32_t lref_base,
                                                              unsigned long long* __restrict__ bits, uint32_t* __restrict__ where,
-                                                             const uint32_t* __restrict__ rank_of, uint32_t room, const uint32_t* __restrict__ flags) {
+                                                             const uint32_t* __restrict__ rank_of, uint32_t room, const uint32_t* __restrict__ flags,
+                                                             uint32_t classes, uint32_t cls) {
     if (flags[2] > room || flags[5]) return;
     const uint64_t e = e_first + (uint64_t)blockIdx.x * kSpillThreads + threadIdx.x;
     if (e >= S) return;
     const uint64_t h = key_hash(K.lo[e], K.mn[e], HAS_HI ? K.hi[e] : 0ull, HAS_HI);
+    if (classes > 1 && key_class(h, classes) != cls) return;
     if (part_cnt[(uint32_t)(((h >> 32) * n_parts) >> 32)] <= (uint32_t)kPartCap) return;
     const uint32_t j = sketch_of(sk_off, n, e);
     if (j < row_first) return;
@@ -1140,7 +1151,7 @@ struct CompareJob {
     uint32_t passes = 1, pass = 0;  // large builds: the keys are split into classes and the dictionary + colour
                                     // matrix are built class by class, so the matrix never exceeds its budget
     // partition form (flat entry point): see k_parts_scatter
-    std::function<int(uint32_t n_parts, bool small, bool filtered, uint32_t fmask)> scatter_parts;
+    std::function<int(uint32_t n_parts, bool small, bool filtered, uint32_t fmask, uint32_t classes, uint32_t cls)> scatter_parts;
     std::function<int(uint32_t n_parts, const SpillPlan&)> group_parts;
     std::function<int(uint32_t n_parts)> group_small;     // small problems: grouping + counting in one kernel (k_parts_group_small)
     bool parts = false, small = false;
@@ -1151,9 +1162,13 @@ struct CompareJob {
     uint32_t filter_words = 0;
     uint64_t parts_entries = 0;     // records the parts are sized for
     bool bracket_closed = false;    // the kEvCompare bracket of the begin call has been closed already
+    // very large inputs (more keys than kMaxKeyParts parts hold): the keys go through the partition form one hash class at a
+    // time, the first class's row sums store the cells, the later ones add
+    uint32_t classes = 1, cls = 0;
+    uint64_t S_behind = 0;          // keys of the first owned row and later sketches: what the scatter deals
     // spill (partition form, unfiltered): the records of parts that overflow are grouped in a table in HBM (k_spill_insert)
     SpillPlan spill;                // room = 0: not part of this attempt
-    std::function<int(uint32_t n_parts, const SpillPlan&, int phase)> spill_parts;   // phase 0: buffers cleared (in front of the scatter), 1: the kernels (behind the grouping)
+    std::function<int(uint32_t n_parts, const SpillPlan&, int phase, uint32_t classes, uint32_t cls)> spill_parts;   // phase 0: buffers cleared (in front of the scatter), 1: the kernels (behind the grouping)
 };
 // flags: [0] unsorted input, [1] fingerprint collision, [2] n_rows, [3] malformed slot, [4] slot overflow, [5] table full
 static uint64_t job_fp_mask(const CompareJob& J) {
@@ -1167,14 +1182,14 @@ static int job_mark_done(spsp_ctx* ctx) {
     SPSP_HIP(hipEventRecord(ctx->compare_done, ctx->stream));
     return SPSP_OK;
 }
-static int launch_accumulate_sparse(spsp_ctx* ctx, const ComparePlan& P, uint32_t* flags, bool may_emit_cells = false) {
+static int launch_accumulate_sparse(spsp_ctx* ctx, const ComparePlan& P, uint32_t* flags, bool may_emit_cells = false, bool add = false) {
     uint32_t cols = 64;
     while (cols < P.n && cols < (uint32_t)kSparseCols) cols <<= 1;
     // a row's keys are walked by ONE workgroup unless the sketches are huge (few sketches of millions of keys):
     // then slices of the row add into cells cleared first
     const uint64_t per_row = P.n_own ? P.S_own / P.n_own : 0;
     const uint32_t split = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, per_row / 65536), 64);
-    if (split > 1) {
+    if (split > 1 && !add) {
         hipLaunchKernelGGL(k_zero_rows, dim3(std::max(1u, std::min((P.n + 255) / 256, 64u)), P.n_own), dim3(256), 0, ctx->stream,
                            P.n, P.row_first, P.row_stride, P.row_limit, P.d_inter);
         SPSP_HIP(hipGetLastError());
@@ -1201,7 +1216,7 @@ static int launch_accumulate_sparse(spsp_ctx* ctx, const ComparePlan& P, uint32_
                        // a caller that wants the result as sparse cells (compare_cells_run) gets them straight from the row sums
                        // when ONE workgroup makes a row (no split) -- else the dense matrix is written and sparsified afterwards
                        (may_emit_cells && ctx->cells_req.armed && split == 1) ? ctx->cells_req.cells : (unsigned long long*)nullptr,
-                       (unsigned long long)ctx->cells_req.cap, ctx->cells_req.count, xcd_rows);
+                       (unsigned long long)ctx->cells_req.cap, ctx->cells_req.count, xcd_rows, add);
     ctx->cells_req.direct = may_emit_cells && ctx->cells_req.armed && split == 1;
     // the number of cells travels to pinned memory behind the kernel: whoever waits for the job (compare_end) has it, no round trip of its own
     if (ctx->cells_req.direct) SPSP_HIP(hipMemcpyAsync(ctx->h_scalar + 12, ctx->cells_req.count, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -1231,12 +1246,12 @@ static int job_parts(spsp_ctx* ctx, CompareJob& J) {
     static const int skip = getenv("SPSP_DEBUG_SKIP_STAGES") ? atoi(getenv("SPSP_DEBUG_SKIP_STAGES")) : 0;
     if ((rc = ctx->ev_begin(kEvScatter))) return rc;
     if (J.filtered && (rc = J.build_filter(J.filter_words - 1))) return rc;
-    if (J.spill.room && !J.small && (rc = J.spill_parts(J.n_parts, J.spill, 0))) return rc;
-    if (!(skip & 1) && (rc = J.scatter_parts(J.n_parts, J.small, J.filtered, J.filter_words - 1))) return rc;
+    if (J.spill.room && !J.small && (rc = J.spill_parts(J.n_parts, J.spill, 0, J.classes, J.cls))) return rc;
+    if (!(skip & 1) && (rc = J.scatter_parts(J.n_parts, J.small, J.filtered, J.filter_words - 1, J.classes, J.cls))) return rc;
     if ((rc = ctx->ev_end(kEvScatter))) return rc;
     if ((rc = ctx->ev_begin(kEvGroup))) return rc;
     if (!(skip & 2) && (rc = J.small ? J.group_small(J.n_parts) : J.group_parts(J.n_parts, J.spill))) return rc;
-    if (J.spill.room && !J.small && (rc = J.spill_parts(J.n_parts, J.spill, 1))) return rc;
+    if (J.spill.room && !J.small && (rc = J.spill_parts(J.n_parts, J.spill, 1, J.classes, J.cls))) return rc;
     if ((rc = ctx->ev_end(kEvGroup))) return rc;
     if (J.small) return job_queue_flags(ctx);             // (no later kernel forwards the flags)
     if ((rc = ctx->ev_begin(kEvAccumulate))) return rc;
@@ -1244,7 +1259,8 @@ static int job_parts(spsp_ctx* ctx, CompareJob& J) {
     PP.list_ref = ctx->c_lref.as<uint32_t>(); PP.where = ctx->c_where.as<uint32_t>();
     // (an attempt whose parts overflow leaves this kernel at its first line, before any cell is emitted: the retry emits them once)
     // (with a spill the keys that have columns add into the dense matrix behind the row sums: no cells straight from them)
-    if (!(skip & 4) && (rc = launch_accumulate_sparse(ctx, PP, flags, J.spill.room == 0))) return rc;
+    //  -- nor with key classes: a pair's count comes in several parts)
+    if (!(skip & 4) && (rc = launch_accumulate_sparse(ctx, PP, flags, J.spill.room == 0 && J.classes == 1, J.cls > 0))) return rc;
     if (J.spill.room && J.spill.t_bits != 0xffffffffu) {
         const uint32_t tiles = (J.P.n + kPairTile - 1) / kPairTile;
         hipLaunchKernelGGL(k_spill_pairs, dim3((tiles * (tiles + 1) / 2 + 7) / 8 * 8), dim3(kPairThreads), 0, ctx->stream, ctx->c_bits.as<unsigned long long>(),
@@ -1413,9 +1429,12 @@ static uint32_t parts_for(uint64_t entries, uint32_t attempt) {
 
 // Can the records of overflowed parts (`records` of them) be grouped beside n_parts parts?  The lists must stay inside
 // the 2^29 u16 a list reference can address and the list references inside a `where` word.
-static bool spill_plan(const CompareJob& J, uint64_t records, SpillPlan* sp) {
+static bool spill_enabled() {
     static const char* dbg_spill = getenv("SPSP_DEBUG_SPILL");          // "0": the forms of before (half-size parts, then the global dictionary)
-    if (dbg_spill && dbg_spill[0] == '0') return false;
+    return !(dbg_spill && dbg_spill[0] == '0');
+}
+static bool spill_plan(const CompareJob& J, uint64_t records, SpillPlan* sp) {
+    if (!spill_enabled()) return false;
     if (!J.spill_parts || J.small || J.filtered || records == 0) return false;
     SpillPlan P;
     P.room = std::min<uint64_t>(records, J.P.S_entries);
@@ -1441,8 +1460,13 @@ static int compare_job_begin(spsp_ctx* ctx, CompareJob* job) {
     // Partition form unless a test hook asks for one of the global-dictionary forms (SPSP_DEBUG_PARTS=0 by name)
     static const bool hooks = getenv("SPSP_DEBUG_MATRIX_BUDGET") || getenv("SPSP_DEBUG_SPARSE") || getenv("SPSP_DEBUG_FP_BITS");
     static const char* dbg_parts = getenv("SPSP_DEBUG_PARTS");
-    J->parts = J->scatter_parts && (dbg_parts ? atoi(dbg_parts) != 0 : !hooks) &&
-               parts_for(P.S_entries, 0) <= (uint32_t)kMaxKeyParts;
+    // More keys than kMaxKeyParts parts hold (9 x 10^7: tens of thousands of sketches): one hash class of the keys per pass
+    // through the same parts (SPSP_DEBUG_KEY_CLASSES=<n> forces n classes on small inputs)
+    static const char* dbg_classes = getenv("SPSP_DEBUG_KEY_CLASSES");
+    // (with several classes, half the parts a single one may take: the lists of a spill fit behind them, spill_plan)
+    J->classes = dbg_classes ? (uint32_t)std::max(1, atoi(dbg_classes))
+                             : parts_for(P.S_entries, 0) <= (uint32_t)kMaxKeyParts ? 1u : (uint32_t)((parts_for(P.S_entries, 0) + kMaxKeyParts / 2 - 1) / (kMaxKeyParts / 2));
+    J->parts = J->scatter_parts && (dbg_parts ? atoi(dbg_parts) != 0 : !hooks) && J->classes <= 256;
     if (J->parts) {
         J->speculative = true;                      // queued in one go, checked once
         // small problems (bench.py's 100 sketches): one kernel groups and counts.  Every row must be owned (the parts
@@ -1453,6 +1477,7 @@ static int compare_job_begin(spsp_ctx* ctx, CompareJob* job) {
         // would otherwise ask for 41 000)
         J->small = J->group_small && !small_off && !dbg_mean_set() && P.n <= (uint32_t)kSmallN && P.n_own == P.n && P.row_first == 0 && P.row_stride == 1 &&
                    P.row_limit >= P.n && parts_small(P.S_entries) <= (uint32_t)kMaxKeyParts;
+        if (ctx->spill_expect) J->small = false;     // (the context's last comparison overflowed its parts: straight to the form that spills)
         // row-partitioned call that owns at most 3/4 of the keys: the other sketches' keys go through a filter first
         // (k_parts_filter) and the parts are sized for what got through last time (the count comes back with the flags;
         // an attempt that overflows is repeated with the exact count).  SPSP_DEBUG_FILTER=0/1 forces the choice.
@@ -1470,6 +1495,12 @@ static int compare_job_begin(spsp_ctx* ctx, CompareJob* job) {
             J->filter_words = words;
             const double ratio = std::min(std::max(ctx->filter_ratio, 1.0), (double)S_behind / (double)P.S_own);
             J->parts_entries = std::min<uint64_t>(S_behind, (uint64_t)((double)P.S_own * ratio * 1.08) + 2900);
+        }
+        J->S_behind = S_behind;
+        if (J->classes > 1) {
+            J->small = false; J->filtered = false;
+            J->parts_entries = S_behind / J->classes + S_behind / J->classes / 32 + 65536;
+            if (parts_for(J->parts_entries, 0) > (uint32_t)kMaxKeyParts) { set_error("internal: a key class needs %u parts", parts_for(J->parts_entries, 0)); return SPSP_ERR_ARG; }
         }
         J->n_parts = J->small ? parts_small(P.S_entries) : parts_for(J->parts_entries, 0);
         if ((rc = ctx->c_row.reserve((size_t)P.S_entries * 4))) return rc;
@@ -1496,6 +1527,12 @@ int compare_job_end(spsp_ctx* ctx) {
             static const bool trace = getenv("SPSP_DEBUG_SPILL_TRACE") != nullptr;     // test hook: which way the comparison went
             if (trace && J->spill.room) fprintf(stderr, "spsp spill: %u records of overflowed parts grouped in HBM (room %llu, %u parts, columns from %u holders)\n",
                                                 h_flags[2], (unsigned long long)J->spill.room, J->n_parts, J->spill.t_bits);
+            if (J->cls + 1 < J->classes) {              // the next class of keys through the same parts; its row sums add
+                ++J->cls;
+                J->bracket_closed = true;
+                if ((rc = job_parts(ctx, *J))) return rc;
+                continue;
+            }
             return SPSP_OK;
         }
         // a part overflowed (many sketches share their keys): the same parts once more with the records of the
@@ -1522,6 +1559,15 @@ int compare_job_end(spsp_ctx* ctx) {
             continue;
         }
         J->spill = SpillPlan{};
+        // no room for the spilled keys' lists behind this many parts (list references address 2^29 u16): twice the classes,
+        // so half the parts -- everything starts over, a key's class changes
+        if (!J->filtered && spill_enabled() && J->spill_parts && J->n_parts > 4096 && J->classes <= 128 && h_flags[2] > 0) {
+            J->classes *= 2; J->cls = 0;
+            J->parts_entries = J->S_behind / J->classes + J->S_behind / J->classes / 32 + 65536;
+            J->n_parts = parts_for(J->parts_entries, 0);
+            if ((rc = job_parts(ctx, *J))) return rc;
+            continue;
+        }
         if (J->parts_attempt == 0 && parts_for(J->parts_entries, 1) <= (uint32_t)kMaxKeyParts) {
             J->parts_attempt = 1;
             J->n_parts = parts_for(J->parts_entries, 1);
@@ -1678,7 +1724,7 @@ static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t*
     };
     // (nothing of the sketches in front of the first owned row is dealt: the grid starts at that row's chunk)
     const uint64_t e_own = h_sk_off[row_first] / (4u * kScatThreads) * (4u * kScatThreads);
-    J->scatter_parts = [=](uint32_t n_parts, bool small, bool filtered, uint32_t fmask) -> int {
+    J->scatter_parts = [=](uint32_t n_parts, bool small, bool filtered, uint32_t fmask, uint32_t classes, uint32_t cls) -> int {
         const uint32_t cap = small ? (uint32_t)kSmallCap : (uint32_t)kPartCap;
         int r2 = ctx->c_recs.reserve((size_t)n_parts * cap * (has_hi ? 24 : 16));
         if (r2) return r2;
@@ -1699,7 +1745,7 @@ static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t*
         }
 #define SPSP_SCATTER(HI, E) hipLaunchKernelGGL((k_parts_scatter<HI, E>), grid, dim3(kScatThreads), lds, ctx->stream, K, sk, n, sub_sk, S, \
                                                n_parts, cap, ctx->c_part_cnt.as<uint32_t>(), ctx->c_recs.as<uint64_t>(), where, flags, !ctx->keys_unordered, \
-                                               filter, fmask, e_first, row_first, row_stride, row_limit)
+                                               filter, fmask, e_first, row_first, row_stride, row_limit, classes, cls)
         if (has_hi) SPSP_SCATTER(true, 4);
         else SPSP_SCATTER(false, 4);
 #undef SPSP_SCATTER
@@ -1729,7 +1775,7 @@ static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t*
         SPSP_HIP(hipGetLastError());
         return SPSP_OK;
     };
-    J->spill_parts = [=](uint32_t n_parts, const SpillPlan& sp, int phase) -> int {
+    J->spill_parts = [=](uint32_t n_parts, const SpillPlan& sp, int phase, uint32_t classes, uint32_t cls) -> int {
         const uint64_t slots = 1ull << sp.log2cap;
         int r2;
         if (phase == 0) {
@@ -1748,17 +1794,17 @@ static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t*
         uint32_t *where = ctx->c_where.as<uint32_t>(), *rank_of = ctx->c_row.as<uint32_t>();
         const uint32_t* part_cnt = ctx->c_part_cnt.as<uint32_t>();
         const uint32_t room = (uint32_t)sp.room;
-        if (has_hi) hipLaunchKernelGGL(k_spill_insert<true>, grid, dim3(kSpillThreads), 0, ctx->stream, K, sk, n, S, e_own, row_first, n_parts, part_cnt, tbl, sp.log2cap, cnt, where, rank_of, room, flags);
-        else hipLaunchKernelGGL(k_spill_insert<false>, grid, dim3(kSpillThreads), 0, ctx->stream, K, sk, n, S, e_own, row_first, n_parts, part_cnt, tbl, sp.log2cap, cnt, where, rank_of, room, flags);
+        if (has_hi) hipLaunchKernelGGL(k_spill_insert<true>, grid, dim3(kSpillThreads), 0, ctx->stream, K, sk, n, S, e_own, row_first, n_parts, part_cnt, tbl, sp.log2cap, cnt, where, rank_of, room, flags, classes, cls);
+        else hipLaunchKernelGGL(k_spill_insert<false>, grid, dim3(kSpillThreads), 0, ctx->stream, K, sk, n, S, e_own, row_first, n_parts, part_cnt, tbl, sp.log2cap, cnt, where, rank_of, room, flags, classes, cls);
         SPSP_HIP(hipGetLastError());
         hipLaunchKernelGGL(k_spill_ranges, dim3((uint32_t)((slots + (uint64_t)kRowThreads * kRowSlots - 1) / ((uint64_t)kRowThreads * kRowSlots))), dim3(kRowThreads), 0, ctx->stream,
                            (const uint32_t*)cnt, slots, off, ctx->c_matrix.as<uint16_t>(), sp.ids_base, sp.ids_room, ctx->c_lref.as<uint32_t>() + sp.lref_base, sp.t_bits, sp.max_cols, room, flags);
         SPSP_HIP(hipGetLastError());
         unsigned long long* bits = sp.max_cols ? ctx->c_bits.as<unsigned long long>() : (unsigned long long*)nullptr;
         if (has_hi) hipLaunchKernelGGL(k_spill_fill<true>, grid, dim3(kSpillThreads), 0, ctx->stream, K, sk, n, S, e_own, row_first, n_parts, part_cnt, (const uint32_t*)cnt, (const uint32_t*)off,
-                                       ctx->c_matrix.as<uint16_t>(), sp.ids_base, sp.lref_base, bits, where, (const uint32_t*)rank_of, room, (const uint32_t*)flags);
+                                       ctx->c_matrix.as<uint16_t>(), sp.ids_base, sp.lref_base, bits, where, (const uint32_t*)rank_of, room, (const uint32_t*)flags, classes, cls);
         else hipLaunchKernelGGL(k_spill_fill<false>, grid, dim3(kSpillThreads), 0, ctx->stream, K, sk, n, S, e_own, row_first, n_parts, part_cnt, (const uint32_t*)cnt, (const uint32_t*)off,
-                                ctx->c_matrix.as<uint16_t>(), sp.ids_base, sp.lref_base, bits, where, (const uint32_t*)rank_of, room, (const uint32_t*)flags);
+                                ctx->c_matrix.as<uint16_t>(), sp.ids_base, sp.lref_base, bits, where, (const uint32_t*)rank_of, room, (const uint32_t*)flags, classes, cls);
         SPSP_HIP(hipGetLastError());
         return SPSP_OK;
     };

@@ -433,9 +433,10 @@ def test_comparison_forms_agree_on_random_inputs():
         "print('digest', digest.hexdigest())\n") % (ROOT, os.path.join(ROOT, "tests"))
     digests = []
     # {} = the partition form (LDS dictionary per key class), the others force the global-dictionary forms
-    # SPSP_DEBUG_SMALL=0: the general partition form also for <= 128 sketches
+    # SPSP_DEBUG_SMALL=0: the general partition form also for <= 128 sketches; SPSP_DEBUG_KEY_CLASSES: the keys in that many
+    # hash classes, one pass through the parts each (what inputs beyond 9 x 10^7 keys get), also with many tiny parts
     for env in ({}, {"SPSP_DEBUG_SPARSE": "1"}, {"SPSP_DEBUG_MATRIX_BUDGET": "9000"}, {"SPSP_DEBUG_SPARSE": "0"}, {"SPSP_DEBUG_PARTS": "0"},
-                {"SPSP_DEBUG_SMALL": "0"}):
+                {"SPSP_DEBUG_SMALL": "0"}, {"SPSP_DEBUG_KEY_CLASSES": "3"}, {"SPSP_DEBUG_KEY_CLASSES": "2", "SPSP_DEBUG_PART_MEAN": "40"}):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0 and "digest" in r.stdout, (env, r.stdout[-2000:], r.stderr[-3000:])
         digests.append(r.stdout.strip().split()[-1])
@@ -452,8 +453,10 @@ def test_many_sketches_global_dictionary():
 
 
 def test_partition_form_overflow_falls_back(ctx):
-    """600 sketches holding the SAME 4 000 keys (+ a few private ones): every key class receives its keys 600 at a
-    time, the fixed-capacity parts overflow on both attempts and the global-dictionary form takes over."""
+    """600 sketches holding the SAME 4 000 keys (+ a few private ones): every part receives its keys 600 at a
+    time, the fixed-capacity parts overflow and their records are grouped in HBM (spill; before round 4 the
+    global-dictionary form took over -- tests/test_gpu.py::test_compare_one_species_collection_spills_overflowed_parts
+    runs that way too, SPSP_DEBUG_SPILL=0)."""
     rng = np.random.default_rng(77)
     n = 600
     shared = np.unique(rng.integers(1, 2**62, size=4000, dtype=np.int64)).astype(np.uint64)

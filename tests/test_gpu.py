@@ -1469,7 +1469,8 @@ print("ok")
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("use_hi,n,env", [(0, 400, {}), (1, 300, {}), (0, 400, {"SPSP_DEBUG_SPILL_BITS": "0"}), (0, 300, {"SPSP_DEBUG_SPILL_BITS": "2"}),
-                                          (1, 260, {"SPSP_DEBUG_SPILL": "0"}), (0, 330, {"SPSP_DEBUG_FILTER": "0"})])
+                                          (1, 260, {"SPSP_DEBUG_SPILL": "0"}), (0, 330, {"SPSP_DEBUG_FILTER": "0"}),
+                                          (0, 440, {"SPSP_DEBUG_KEY_CLASSES": "2"})])
 def test_compare_one_species_collection_spills_overflowed_parts(use_hi, n, env):
     """Hundreds of sketches that share most of their keys (one species sequenced many times): a key arrives in its part
     with all its holders, parts overflow whatever their number, and their records are grouped in HBM instead (k_spill_*):
