@@ -132,8 +132,13 @@ struct spsp_ctx {
     spsp::DevBuf wave_hits, wave_cnt;    // per-wave hit lists of the table variants of the dense pass
     spsp::DevBuf packed, unpacked;       // SPSP_SCAN_PACKED_INPUT: spsp_pack_bases_device's output; ASCII copy for the variants that need one
     spsp::DevBuf st_count, st_open;      // print_stat counting pass (spsp_stats.hip)
-    uint64_t hits_cap = 0, out_cap = 0;  // entries the sparse-stage buffers are sized for (grow on overflow)
+    uint64_t hits_cap = 0, out_cap = 0;  // entries the sparse-stage buffers of the call in flight are sized for (grow on overflow)
+    // what the last overflow taught: hits / super-k-mers per base at that threshold (scan_begin_impl sizes the next call by it)
+    bool learn_valid = false;
+    uint64_t learn_threshold = 0;
+    double learn_hits_per_base = 0, learn_out_per_base = 0;
     uint64_t list_cap = 0;               // hits one wave's list holds (grows on overflow)
+    uint64_t list_cap_threshold = 0;     // ... learnt at this threshold (another threshold starts from its own expectation)
     // LDS pre-filter table cache (keyed by m, threshold)
     spsp::DevBuf filter;
     uint32_t filter_m = 0;

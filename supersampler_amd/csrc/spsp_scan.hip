@@ -1213,9 +1213,11 @@ __device__ __forceinline__ Rescan rescan_hits(const HitView& V, uint32_t hb, uin
 }
 
 // cluster = hits hb .. hb + cnt - 1 of V
+// `cut`: the last of the cnt hits is the FIRST hit of the next piece of a cluster cut in two (head_kind): this piece ends
+// with the iteration in which that hit enters and takes over -- the super-k-mer it closes is this piece's last.
 template <bool WRITE>
 __device__ uint32_t run_cluster(const HitView& V, uint32_t hb, uint32_t cnt, uint64_t r0, uint64_t n, uint32_t k,
-                                uint32_t m, uint32_t rec, spsp_superkmer* __restrict__ out, uint32_t room) {
+                                uint32_t m, uint32_t rec, spsp_superkmer* __restrict__ out, uint32_t room, bool cut) {
     const uint64_t km = k - m, w = km + 1;
     auto q = [&](uint32_t i) -> uint64_t { return V.at(hb + i).pos - r0; };
     uint32_t nem = 0;
@@ -1275,6 +1277,7 @@ __device__ uint32_t run_cluster(const HitView& V, uint32_t hb, uint32_t cnt, uin
             emit(last_position, i + k - last_position, old_min, old_rev);
             last_position = i + 1; old_min = minimizer; old_rev = rev;
         }
+        if (cut && enters && nh + 1 == cnt) { closed = true; break; }   // the next piece starts from exactly this state
         // skip iterations in which nothing can happen: the next event is the
         // next hit entering or the tracked minimizer leaving the window.
         uint64_t ni = position_min;
@@ -1284,6 +1287,31 @@ __device__ uint32_t run_cluster(const HitView& V, uint32_t hb, uint32_t cnt, uin
     }
     if (!closed) emit(last_position, n - last_position, old_min, old_rev);  // :441-454 tail
     return nem;
+}
+
+// Where a replay may start.  1: the first hit of a cluster (no usable hit of its record within w positions in front of
+// it).  2: a hit whose hash is strictly below every hit of the w positions in front of it, beyond the record's first
+// window -- when it enters, the reference's state machine (SubSampler.cpp:374-388) takes it as the new minimizer whatever
+// it was tracking (the tracked m-mer is one of those w, its hash is larger, so is its canonical value: XXH64 of 8 bytes
+// is a bijection), closes the running super-k-mer and goes on from a state that depends on this hit alone: the same state
+// a cluster starts from (run_cluster, q0 > km).  So a cluster can be cut in front of every such hit, the piece in front of
+// it replayed up to and including that iteration (`cut`), the piece behind it like a cluster of its own: identical output.
+// A strict window minimum comes along every ~w positions at the latest when every m-mer is selected (s = 1: one
+// cluster per RECORD, replayed by one lane -- 7 s per 10^8 bases before this).
+__device__ __forceinline__ uint32_t head_kind(const HitView& V, uint32_t x, uint64_t w, uint64_t km, const uint64_t* __restrict__ rec_off) {
+    const Hit me = V.at(x);
+    if (!(me.flags & 2u)) return 0u;
+    bool any = false;
+    for (uint32_t g = x; g-- > 0;) {
+        const Hit o = V.at(g);
+        if (me.pos - o.pos > w) break;
+        if ((o.flags & 2u) && o.rec == me.rec) {
+            if (o.hash <= me.hash) return 0u;
+            any = true;
+        }
+    }
+    if (!any) return 1u;
+    return me.pos - rec_off[me.rec] > km ? 2u : 0u;
 }
 
 // One lane per hit; cluster heads replay their cluster.  The count pass (WRITE = false) leaves, besides the
@@ -1298,7 +1326,7 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(const Hit* __restri
                                                              uint32_t m, uint32_t* __restrict__ emit_count,
                                                              uint32_t* __restrict__ wave_sum, uint32_t* __restrict__ chunk_sum,
                                                              uint32_t n_chunks, uint64_t* __restrict__ total_host,
-                                                             spsp_superkmer* __restrict__ out, uint32_t out_cap) {
+                                                             spsp_superkmer* __restrict__ out, uint32_t out_cap, uint32_t n_super) {
     __shared__ __attribute__((aligned(16))) Hit s_hit[kResolveThreads + kResolveBefore + kResolveAfter];
     const uint32_t h = blockIdx.x * kResolveThreads + threadIdx.x, lane = threadIdx.x & 63, gw = h >> 6;
     uint32_t n_hits = *n_hits_dev;
@@ -1316,26 +1344,25 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(const Hit* __restri
         for (uint32_t i = threadIdx.x; i < 2 * (V.hi - V.lo); i += kResolveThreads) dst[i] = src[i];
     }
     __syncthreads();
-    const uint64_t w = k - m + 1;
+    const uint64_t w = k - m + 1, km = k - m;
+    // where replays start among the staged hits (a piece that runs past them asks hit by hit)
+    __shared__ uint8_t s_kind[kResolveThreads + kResolveBefore + kResolveAfter];
+    for (uint32_t x = V.lo + threadIdx.x; x < V.hi; x += kResolveThreads) s_kind[x - V.lo] = (uint8_t)head_kind(V, x, w, km, rec_off);
+    __syncthreads();
     Hit me{};
-    bool head = false;
+    bool head = false, cut = false;
     uint32_t cnt = 0;
     if (h < n_hits) {
         me = V.at(h);
-        head = (me.flags & 2u) != 0;
-        if (head) {
-            for (uint32_t g = h; g-- > 0;) {
-                const Hit o = V.at(g);
-                if (me.pos - o.pos > w) break;
-                if ((o.flags & 2u) && o.rec == me.rec) { head = false; break; }
-            }
-        }
+        head = s_kind[h - V.lo] != 0;
         if (head) {
             cnt = 1;
             Hit a = me;
             while (h + cnt < n_hits) {
-                const Hit b = V.at(h + cnt);
+                const uint32_t x = h + cnt;
+                const Hit b = V.at(x);
                 if (!(b.flags & 2u) || b.rec != me.rec || b.pos - a.pos > w) break;
+                if (x < V.hi ? s_kind[x - V.lo] != 0 : head_kind(V, x, w, km, rec_off) != 0) { cut = true; ++cnt; break; }   // (the piece sees the hit that ends it)
                 a = b;
                 ++cnt;
             }
@@ -1344,7 +1371,7 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(const Hit* __restri
     uint64_t r0 = 0, r1 = 0;
     if (head) { r0 = rec_off[me.rec]; r1 = rec_off[me.rec + 1]; }
     if (!WRITE) {
-        const uint32_t c = head ? run_cluster<false>(V, h, cnt, r0, r1 - r0, k, m, me.rec, nullptr, 0u) : 0u;
+        const uint32_t c = head ? run_cluster<false>(V, h, cnt, r0, r1 - r0, k, m, me.rec, nullptr, 0u, cut) : 0u;
         if (h < hits_cap) emit_count[h] = c;
         uint32_t t = c;
 #pragma unroll
@@ -1363,22 +1390,40 @@ __global__ __launch_bounds__(kResolveThreads) void k_resolve(const Hit* __restri
         const uint32_t y = __shfl_up(x, d);
         if (lane >= (uint32_t)d) x += y;
     }
-    const uint32_t wi = gw & 63u, ci = gw >> 6;
+    // (n_super != 0: a third level, sums of 64 chunks made by k_super_sums between the passes -- with two levels a wave of an
+    // input that is all hits summed 10^5 chunk sums, quadratic in the hits; few hits: two levels and no launch in between)
+    const uint32_t wi = gw & 63u, ci = gw >> 6, si = ci >> 6;
+    const uint32_t* super_sum = chunk_sum + n_chunks;
     uint32_t v = lane < wi ? wave_sum[(gw & ~63u) + lane] : 0u;
-    for (uint32_t j = lane; j < ci; j += 64) v += chunk_sum[j];
+    if (n_super) {
+        if ((ci & ~63u) + lane < ci) v += chunk_sum[(ci & ~63u) + lane];
+        for (uint32_t j = lane; j < si; j += 64) v += super_sum[j];
+    } else {
+        for (uint32_t j = lane; j < ci; j += 64) v += chunk_sum[j];
+    }
 #pragma unroll
     for (int d = 32; d; d >>= 1) v += __shfl_xor(v, d);
     if (gw == 0) {   // number of super-k-mers, for the host
         uint32_t tv = 0;
-        for (uint32_t j = lane; j < n_chunks; j += 64) tv += chunk_sum[j];
+        if (n_super) { for (uint32_t j = lane; j < n_super; j += 64) tv += super_sum[j]; }
+        else for (uint32_t j = lane; j < n_chunks; j += 64) tv += chunk_sum[j];
 #pragma unroll
         for (int d = 32; d; d >>= 1) tv += __shfl_xor(tv, d);
         if (lane == 0) *total_host = tv;
     }
     if (head) {
         const uint32_t at = v + x - c;
-        run_cluster<true>(V, h, cnt, r0, r1 - r0, k, m, me.rec, out + at, at < out_cap ? out_cap - at : 0u);
+        run_cluster<true>(V, h, cnt, r0, r1 - r0, k, m, me.rec, out + at, at < out_cap ? out_cap - at : 0u, cut);
     }
+}
+
+// super_sum[j] = chunk sums 64 j .. 64 j + 63 (one wave each), written behind the chunk sums
+__global__ __launch_bounds__(64) void k_super_sums(uint32_t* __restrict__ chunk_sum, uint32_t n_chunks) {
+    const uint32_t c = blockIdx.x * 64u + threadIdx.x;
+    uint32_t v = c < n_chunks ? chunk_sum[c] : 0u;
+#pragma unroll
+    for (int d = 32; d; d >>= 1) v += __shfl_xor(v, d);
+    if (threadIdx.x == 0) chunk_sum[n_chunks + blockIdx.x] = v;
 }
 
 int launch_scan_u32(spsp_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, uint64_t n, uint64_t* total_host) {
@@ -1493,7 +1538,7 @@ static int plan_lists(spsp_ctx* ctx, const spsp_params* p, int variant, uint64_t
     uint64_t cap = (uint64_t)(expect * 1.5) + 48;
     static const char* dbg_hits = getenv("SPSP_DEBUG_HITS_CAP");      // test hook: tiny lists, so the overflow paths run
     if (dbg_hits && ctx->list_cap == 0) cap = (uint64_t)atoll(dbg_hits) / 8 + 1;
-    if (ctx->list_cap > cap) cap = ctx->list_cap;                     // grown by an earlier overflow: keep
+    if (ctx->list_cap > cap && ctx->list_cap_threshold == p->threshold) cap = ctx->list_cap;   // grown by an earlier overflow at this threshold: keep
     const uint64_t most = P->rows_per_wave * kRowPosPair63;           // a wave cannot find more hits than it has positions
     if (cap > most) cap = most;
     if (cap > 0xfffffff0ull) { set_error("input too large for one call"); return SPSP_ERR_OVERFLOW; }
@@ -1672,9 +1717,10 @@ static int scan_enqueue(spsp_ctx* ctx) {
     if ((rc = ctx->scan_tmp.reserve((size_t)out_cap * sizeof(spsp_superkmer)))) return rc;
     const uint32_t rblocks = (hits_cap + kResolveThreads - 1) / kResolveThreads;
     const uint32_t n_waves = rblocks * (kResolveThreads / 64), n_chunks = (n_waves + 63) / 64;
-    if ((rc = ctx->seg_b.reserve((size_t)(n_chunks + n_waves) * 4))) return rc;
+    const uint32_t n_super = n_chunks > 2048 ? (n_chunks + 63) / 64 : 0u;   // sums of 64 chunks behind the chunk sums: from 8 x 10^6 hits on
+    if ((rc = ctx->seg_b.reserve((size_t)(n_chunks + n_super + n_waves) * 4))) return rc;
     uint32_t* chunk_sum = ctx->seg_b.as<uint32_t>();
-    uint32_t* wave_sum = chunk_sum + n_chunks;
+    uint32_t* wave_sum = chunk_sum + n_chunks + n_super;
     if ((rc = ctx->d_scalar.reserve(64))) return rc;
     uint32_t* d_sc = ctx->d_scalar.as<uint32_t>();
     if (J.redo_from == 0) {
@@ -1706,12 +1752,13 @@ static int scan_enqueue(spsp_ctx* ctx) {
         SPSP_HIP(hipGetLastError());
         hipLaunchKernelGGL(k_resolve<false>, dim3(rblocks), dim3(kResolveThreads), 0, sparse, ctx->hits.as<Hit>(), d_sc + 0,
                            hits_cap, J.d_rec_off, p->k, p->m, ctx->emit_count.as<uint32_t>(), wave_sum, chunk_sum, n_chunks,
-                           (uint64_t*)nullptr, (spsp_superkmer*)nullptr, 0u);
+                           (uint64_t*)nullptr, (spsp_superkmer*)nullptr, 0u, n_super);
         SPSP_HIP(hipGetLastError());
+        if (n_super) { hipLaunchKernelGGL(k_super_sums, dim3(n_super), dim3(64), 0, sparse, chunk_sum, n_chunks); SPSP_HIP(hipGetLastError()); }
     }
     hipLaunchKernelGGL(k_resolve<true>, dim3(rblocks), dim3(kResolveThreads), 0, sparse, ctx->hits.as<Hit>(), d_sc + 0,
                        hits_cap, J.d_rec_off, p->k, p->m, ctx->emit_count.as<uint32_t>(), wave_sum, chunk_sum, n_chunks,
-                       ctx->h_scalar + 1, ctx->scan_tmp.as<spsp_superkmer>(), out_cap);
+                       ctx->h_scalar + 1, ctx->scan_tmp.as<spsp_superkmer>(), out_cap, n_super);
     SPSP_HIP(hipGetLastError());
     // what scan_end waits on: this job's last kernel, not the whole stream (a caller may already have queued
     // the next batch's work behind it)
@@ -1736,15 +1783,24 @@ int scan_begin_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases,
     if (J.n_tiles > 0x7fffffffull) { J.pending = false; set_error("input too large for one call"); return SPSP_ERR_OVERFLOW; }
     const double frac = (double)p->threshold / 18446744073709551616.0;
     uint64_t want_hits = (uint64_t)((double)n_bases * frac * 1.25) + 4096;
+    // Capacities are per call (the resolve grids are as large as the capacity): what an overflow of an earlier call taught
+    // -- hits and super-k-mers per base at this threshold -- is kept as a RATE, not as a size.  (Kept as sizes, one call that
+    // selects every m-mer of 500 Mbp left every later call of the context with grids of 4 x 10^6 workgroups: 65 ms each.)
+    uint64_t want_out = 0;
+    if (ctx->learn_threshold == p->threshold && ctx->learn_valid) {
+        want_hits = std::max(want_hits, (uint64_t)((double)n_bases * ctx->learn_hits_per_base * 1.125) + 4096);
+        want_out = (uint64_t)((double)n_bases * ctx->learn_out_per_base * 1.125) + 4096;
+    }
     if (want_hits > n_bases) want_hits = n_bases;
-    if (ctx->hits_cap < want_hits) ctx->hits_cap = want_hits;
-    if (ctx->out_cap < ctx->hits_cap) ctx->out_cap = ctx->hits_cap;
+    ctx->hits_cap = want_hits;
+    ctx->out_cap = std::max(want_hits, want_out);
     // test hooks: start from deliberately small buffers so the overflow/retry paths run
     static const char* dbg_hits = getenv("SPSP_DEBUG_HITS_CAP");
     static const char* dbg_out = getenv("SPSP_DEBUG_OUT_CAP");
     if (dbg_hits) ctx->hits_cap = (uint64_t)atoll(dbg_hits);
     if (dbg_out) ctx->out_cap = (uint64_t)atoll(dbg_out);
     if (dbg_hits) ctx->list_cap = 0;
+    if (ctx->list_cap_threshold != p->threshold) ctx->list_cap = 0;
     J.redo_from = 0;
     J.use_bitmap = false;
     if ((rc = ctx->ev_begin(kEvScan))) { J.pending = false; return rc; }
@@ -1773,7 +1829,7 @@ int scan_end_impl(spsp_ctx* ctx, spsp_superkmer** d_out, uint64_t* n_out) {
             const uint64_t want = fullest + fullest / 8 + 16;
             const uint64_t budget = dbg_budget ? (uint64_t)atoll(dbg_budget) : std::max<uint64_t>(256ull << 20, 8 * J.n_bases);
             if (want * J.n_lists * sizeof(Hit) > budget) J.use_bitmap = true;
-            else ctx->list_cap = want;
+            else { ctx->list_cap = want; ctx->list_cap_threshold = J.p.threshold; }
             if (n_hits > J.hits_cap) ctx->hits_cap = n_hits + n_hits / 8 + 1024;   // (clamped counts: a lower bound)
             if (ctx->out_cap < ctx->hits_cap && !dbg_out) ctx->out_cap = ctx->hits_cap;
             J.redo_from = 0;
@@ -1787,6 +1843,11 @@ int scan_end_impl(spsp_ctx* ctx, spsp_superkmer** d_out, uint64_t* n_out) {
         } else {
             *d_out = n_em ? ctx->scan_tmp.as<spsp_superkmer>() : nullptr;
             *n_out = n_em;
+            if (attempt > 0) {                     // an overflow happened: the next call at this threshold starts with room
+                ctx->learn_threshold = J.p.threshold; ctx->learn_valid = true;
+                ctx->learn_hits_per_base = (double)n_hits / (double)J.n_bases;
+                ctx->learn_out_per_base = (double)n_em / (double)J.n_bases;
+            }
             return SPSP_OK;
         }
         if (attempt == 4) break;

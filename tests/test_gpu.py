@@ -137,6 +137,29 @@ def test_scan_dense_selection_many_hits(ctx):
         _assert_stream_equal(got, want)
 
 
+def test_scan_every_mmer_selected_over_megabases(ctx):
+    """s = 1 (no sub-sampling): every m-mer is a hit, a record is ONE cluster of millions of hits -- replayed in pieces
+    cut in front of every strict window minimum (head_kind), offsets over three levels of sums (> 8 x 10^6 hits need 40 Mbp:
+    test_scan_40_mbp_stream_equals_oracle's shape at s = 1 below).  Random records, a repeat-rich one (equal m-mers inside one
+    window: no strict minimum, long pieces) and a homopolymer run, k - m + 1 = 21 and 49."""
+    rng = np.random.default_rng(2718)
+    unit = synth.random_genome(rng, 37)
+    gen = [synth.random_genome(rng, 1_500_000), np.tile(unit, 3000), synth.random_genome(rng, 700_001),
+           np.concatenate([synth.random_genome(rng, 5000), np.frombuffer(b"G" * 3000, np.uint8), synth.random_genome(rng, 5000)])]
+    bases, offs = synth.concat_records(gen)
+    for k, m, s in [(31, 11, 1.0), (63, 15, 1.0)]:
+        p = sp.make_params(k, m, s)
+        got = ctx.scan(p, bases, offs)
+        want = _oracle_stream(k, m, p.threshold, bases, offs)
+        assert len(want) > 80_000
+        _assert_stream_equal(got, want)
+    # 10^7 hits: the third level of the write pass's offsets
+    g = synth.random_genome(rng, 10_000_000)
+    bases, offs = synth.concat_records([g, g[:1_000_000]])
+    p = sp.make_params(21, 11, 1.0)
+    _assert_stream_equal(ctx.scan(p, bases, offs), _oracle_stream(21, 11, p.threshold, bases, offs))
+
+
 def test_scan_40_mbp_stream_equals_oracle(ctx):
     """40 Mbp in 23 records: 2 441 tiles, i.e. several scan segments, tens of thousands of waves in the expand pass and
     (at s = 5) more than 64 chunk sums in the write pass -- the full stream against the oracle, not just invariants."""
