@@ -165,12 +165,15 @@ struct Builder {
         return -1;
     }
 
-    // emission half of parse_fasta_test (SubSampler.cpp:458-504)
-    void emit(double rate, std::string& out) {
+    // emission half of parse_fasta_test (SubSampler.cpp:458-504): the header line ...
+    static void emit_header(uint32_t k, uint32_t m, uint64_t selected_kmers, double rate, std::string& out) {
         char hdr[128];
         const int hl = snprintf(hdr, sizeof hdr, "%llu %llu %llu %f\n", (unsigned long long)(k - 1 + (k - m + 1)),
-                                (unsigned long long)m, (unsigned long long)st.selected_kmer_number, rate);
+                                (unsigned long long)m, (unsigned long long)selected_kmers, rate);
         out.append(hdr, hl);
+    }
+    // ... and the buckets this builder holds (one, when sketch_build_core builds bucket by bucket)
+    void emit(std::string& out) {
         // std::map<uint32_t,...> order over buckets, insertion order inside one (ankerl dense map)
         std::stable_sort(order.begin(), order.end(),
                          [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) { return a.first < b.first; });
@@ -312,18 +315,24 @@ int sketch_build_core(const spsp_params* p, double rate, const uint64_t* rec_off
         set_error("NULL argument");
         return SPSP_ERR_ARG;
     }
-    Builder b;
-    b.k = p->k; b.m = p->m; b.abundance = p->abundance;
-    b.kmask = (((u128)1) << (2 * p->k)) - 1;
-    b.mmask = (1u << (2 * p->m)) - 1;
-    memset(&b.st, 0, sizeof b.st);
-    b.index.init(1024);
+    // The k-mers of a bucket (one minimizer) meet no k-mer of another: the index is keyed by (minimizer, k-mer), the walk
+    // of reconstruct_superkmer stays inside its bucket, buckets are written in minimizer order.  So the super-k-mers are
+    // grouped by minimizer (stream order kept inside a group) and every bucket is built and written on its own -- an index
+    // that fits a core's cache instead of one over all k-mers of a genome (a 1 Gbp record at -s 100: 10^7 k-mers, 10 us
+    // per super-k-mer in one table, 5.0 s), and on several threads when there is enough to do.
+    spsp_sketch_stats st;
+    memset(&st, 0, sizeof st);
     uint64_t nb = 0, pos_end = 0, occ = 0;                // occ: k-mer occurrences so far (numbering of kmer_flags)
     uint32_t cur_rec = 0xffffffffu;
     for (uint32_t r = 0; r < n_rec; ++r) {
         const uint64_t len = rec_off[r + 1] - rec_off[r];
-        if (len >= p->k) b.st.read_kmer += len - p->k + 1;
+        if (len >= p->k) st.read_kmer += len - p->k + 1;
     }
+    std::vector<std::pair<uint32_t, uint32_t>> by_mn;     // (minimizer, super-k-mer)
+    std::vector<uint64_t> occ_of;                         // first k-mer occurrence of every super-k-mer (kmer_flags)
+    if (n_sk > 0xfffffff0ull) { set_error("too many super-k-mers for one sketch"); return SPSP_ERR_OVERFLOW; }
+    by_mn.reserve((size_t)n_sk);
+    if (kmer_flags) occ_of.reserve((size_t)n_sk);
     for (uint64_t i = 0; i < n_sk; ++i) {
         const spsp_superkmer& e = sk[i];
         if (e.rec >= n_rec || e.len < p->k || e.start + e.len > rec_off[e.rec + 1] - rec_off[e.rec]) {
@@ -342,19 +351,73 @@ int sketch_build_core(const spsp_params* p, double rate, const uint64_t* rec_off
             } else nb += e.start + e.len - (pos_end + 1);
             pos_end = e.start + e.len - 1;
         }
-        const uint8_t* src = compact ? compact + compact_off[i] : bases + rec_off[e.rec] + e.start;
-        b.add_superkmer(src, e.len, e.minimizer, e.rev != 0, kmer_flags ? kmer_flags + occ : nullptr);
+        by_mn.emplace_back(e.minimizer, (uint32_t)i);
+        if (kmer_flags) occ_of.push_back(occ);
+        st.selected_kmer_number += e.len - p->k + 1;
         occ += e.len - p->k + 1;
     }
     nb -= p->m - 1;  // SubSampler.cpp:458
-    b.st.nb_mmer_selected = nb;
+    st.nb_mmer_selected = nb;
+    std::stable_sort(by_mn.begin(), by_mn.end(), [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) { return a.first < b.first; });
+    struct Bucket { size_t first, last; std::string text; spsp_sketch_stats st; };
+    std::vector<Bucket> buckets;
+    for (size_t a = 0; a < by_mn.size();) {
+        size_t z = a;
+        while (z < by_mn.size() && by_mn[z].first == by_mn[a].first) ++z;
+        buckets.push_back(Bucket{a, z, std::string(), spsp_sketch_stats{}});
+        a = z;
+    }
+    std::vector<uint32_t> todo(buckets.size());           // largest first: the threads finish together
+    for (uint32_t i = 0; i < todo.size(); ++i) todo[i] = i;
+    std::sort(todo.begin(), todo.end(), [&](uint32_t a, uint32_t b) { return buckets[a].last - buckets[a].first > buckets[b].last - buckets[b].first; });
+    std::atomic<uint32_t> next{0};
+    auto work = [&]() {
+        for (;;) {
+            const uint32_t t = next.fetch_add(1);
+            if (t >= todo.size()) return;
+            Bucket& B = buckets[todo[t]];
+            Builder b;
+            b.k = p->k; b.m = p->m; b.abundance = p->abundance;
+            b.kmask = (((u128)1) << (2 * p->k)) - 1;
+            b.mmask = (1u << (2 * p->m)) - 1;
+            memset(&b.st, 0, sizeof b.st);
+            b.index.init(1024);
+            for (size_t x = B.first; x < B.last; ++x) {
+                const uint32_t i = by_mn[x].second;
+                const spsp_superkmer& e = sk[i];
+                const uint8_t* src = compact ? compact + compact_off[i] : bases + rec_off[e.rec] + e.start;
+                b.add_superkmer(src, e.len, e.minimizer, e.rev != 0, kmer_flags ? kmer_flags + occ_of[i] : nullptr);
+            }
+            b.emit(B.text);                               // (nothing when every k-mer of the bucket was dropped without a trace: the bucket does not exist)
+            B.st = b.st;
+        }
+    };
+    // (the file pipeline builds the sketches of different files on its own worker threads: threads of its own only for a
+    // sketch that is large by itself)
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned n_thr = n_sk >= 20000 ? std::min<unsigned>(std::min<unsigned>(8u, hw), (unsigned)std::max<size_t>(1, buckets.size())) : 1u;
+    if (n_thr <= 1) work();
+    else {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < n_thr; ++t) pool.emplace_back(work);
+        for (auto& th : pool) th.join();
+    }
     std::string out;
-    b.emit(rate, out);
+    Builder::emit_header(p->k, p->m, st.selected_kmer_number, rate, out);
+    for (const Bucket& B : buckets) {
+        out += B.text;
+        st.selected_superkmer_number += B.st.selected_superkmer_number;
+        st.count_maximal_skmer += B.st.count_maximal_skmer;
+        st.actual_minimizer_number += B.st.actual_minimizer_number;
+        st.seen_kmers_at_reconstruction += B.st.seen_kmers_at_reconstruction;
+        st.seen_superkmers_at_reconstruction += B.st.seen_superkmers_at_reconstruction;
+        st.seen_max_superkmers_at_reconstruction += B.st.seen_max_superkmers_at_reconstruction;
+    }
     *payload = (uint8_t*)malloc(out.size() + 1);
     if (!*payload) { set_error("out of host memory"); return SPSP_ERR_NOMEM; }
     memcpy(*payload, out.data(), out.size());
     *payload_len = out.size();
-    if (stats) *stats = b.st;
+    if (stats) *stats = st;
     return SPSP_OK;
 }
 
