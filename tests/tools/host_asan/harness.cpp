@@ -49,6 +49,29 @@ static std::string slurp(const std::string& p) {
 }
 
 // ThreadSanitizer mode: the host functions that spread work over threads (CSV rows, gzip members, file reads)
+// the sketch builder on a stream large enough for its threads (buckets built side by side): the oracle's bytes
+static int large_build(const std::string& dir) {
+    const std::string bb = slurp(dir + "/build_bases.bin"), bo = slurp(dir + "/build_off.bin"), bs = slurp(dir + "/build_sk.bin");
+    if (bs.empty()) return 0;
+    std::vector<uint64_t> off(bo.size() / 8);
+    memcpy(off.data(), bo.data(), off.size() * 8);
+    std::vector<spsp_superkmer> sk(bs.size() / sizeof(spsp_superkmer));
+    memcpy(sk.data(), bs.data(), sk.size() * sizeof(spsp_superkmer));
+    for (uint32_t ab = 1; ab <= 2; ++ab) {
+        const std::string want = slurp(dir + "/build_payload_a" + std::to_string(ab) + ".bin");
+        spsp_params P{21, 9, spsp_threshold_host(21, 9, 4.0), ab, 0};
+        uint8_t* payload = nullptr; uint64_t plen = 0; spsp_sketch_stats st;
+        if (spsp_sketch_build_host(&P, 4.0, (const uint8_t*)bb.data(), off.data(), (uint32_t)off.size() - 1, sk.data(), sk.size(), &payload, &plen, &st) != SPSP_OK) {
+            fprintf(stderr, "large sketch build failed: %s\n", spsp_last_error()); return 9;
+        }
+        const bool same = plen == want.size() && memcmp(payload, want.data(), plen) == 0;
+        free(payload);
+        if (!same) { fprintf(stderr, "large sketch build: payload differs from the oracle's (abundance %u)\n", ab); return 9; }
+    }
+    printf("large sketch build (%zu super-k-mers, threads): the oracle's bytes\n", sk.size());
+    return 0;
+}
+
 static int threads_mode(const std::string& dir) {
     const uint32_t n = 900;
     std::mt19937_64 rng(7);
@@ -74,7 +97,8 @@ static int threads_mode(const std::string& dir) {
     uint8_t* back = nullptr; uint64_t blen = 0;
     if (spsp_read_file_host(path.c_str(), &back, &blen) != SPSP_OK || blen != big.size() || memcmp(back, big.data(), blen) != 0) return 7;
     free(back);
-    printf("host thread-sanitizer harness: threaded CSV, parallel gzip members, read-back OK\n");
+    if (int r = large_build(dir)) return r;
+    printf("host thread-sanitizer harness: threaded CSV, parallel gzip members, read-back, threaded sketch build OK\n");
     return 0;
 }
 
@@ -153,6 +177,7 @@ int main(int argc, char** argv) {
             } else ++rejected;
         }
     }
+    if (int r = large_build(dir)) return r;
     printf("host sanitizer harness: %llu calls accepted, %llu rejected, no crash\n", (unsigned long long)ok, (unsigned long long)rejected);
     return 0;
 }

@@ -256,6 +256,32 @@ def main():
                 n_files += nf
             finally:
                 shutil.rmtree(tmp, ignore_errors=True)
+        if n_scan % 30 == 7:     # a collection of one species: hundreds of sketches sharing most keys -> parts overflow, spill, bit columns
+            n = int(rng.integers(130, 460))
+            use_hi = bool(rng.integers(0, 2))
+            U = int(rng.integers(400, 3600))
+            share = rng.choice([0.95, 0.6, 0.3, 0.08, 0.01], size=U)
+            B = rng.random((n, U)) < share[None, :]
+            if rng.random() < 0.5:
+                B[int(rng.integers(0, n))] = False
+            anc = np.stack([rng.integers(0, 2**22, U), rng.integers(0, 2**62, U), rng.integers(0, 2**62, U) if use_hi else np.zeros(U, np.int64)], 1)
+            own_n = int(rng.integers(0, 200))
+            sks, sizes = [], []
+            for i in range(n):
+                own = np.stack([rng.integers(0, 2**22, own_n), rng.integers(0, 2**62, own_n), rng.integers(0, 2**62, own_n) if use_hi else np.zeros(own_n, np.int64)], 1)
+                keys = np.concatenate([anc[B[i]], own]) if B[i].any() else anc[:0]
+                keys = keys[np.lexsort((keys[:, 1], keys[:, 2], keys[:, 0]))]
+                sizes.append(len(keys))
+                sks.append(sp.Sketch(63 if use_hi else 31, 11, keys[:, 0].astype(np.uint32), keys[:, 1].astype(np.uint64), keys[:, 2].astype(np.uint64)))
+            nq = n if rng.random() < 0.7 else int(rng.integers(1, n + 1))
+            want_sp = np.triu(B.astype(np.int64) @ B.astype(np.int64).T, 1)
+            mark("one-species compare after scan %d: n=%d nq=%d use_hi=%d U=%d keys=%d" % (n_scan, n, nq, use_hi, U, sum(sizes)))
+            inter, card = ctx.compare(sks, n_query=nq)
+            if not ((np.triu(inter.astype(np.int64), 1)[:nq] == want_sp[:nq]).all() and [int(c) for c in card] == sizes):
+                print("ONE-SPECIES COMPARE MISMATCH n=%d nq=%d use_hi=%d U=%d" % (n, nq, use_hi, U))
+                np.save(os.path.join(ROOT, "gpurun_out", "soak_species_B.npy"), B)
+                sys.exit(1)
+            n_cmp += 1
         if n_scan % 8 == 0:      # a comparison problem from sketches of related genomes
             n = int(rng.integers(2, 40))
             anc = synth.random_genome(rng, int(rng.integers(2000, 30_000)))

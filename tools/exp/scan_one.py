@@ -15,7 +15,7 @@ dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev)
 g.manual_seed(5)
 bases = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)[torch.randint(0, 4, (total,), generator=g, device=dev)]
-R = 5_000_000
+R = int(os.environ.get("SCAN_ONE_RECORD", "5000000"))
 n_rec = total // R
 off = torch.arange(0, n_rec + 1, dtype=torch.int64, device=dev) * R
 ctx = sp.Context(0)
