@@ -404,4 +404,4 @@ def test_host_parsers_under_address_and_ub_sanitizers():
     cannot run on the GPU side of this pool, so the host side is where they run)."""
     r = subprocess.run([os.path.join(ROOT, "tests", "tools", "host_asan", "run.sh"), "2500"], env=dict(os.environ, SPSP_ROOT=ROOT),
                        capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and "no crash" in r.stdout and "read-back OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+    assert r.returncode == 0 and "no crash" in r.stdout and "threaded sketch build OK" in r.stdout and r.stdout.count("the oracle's bytes") == 2, (r.stdout[-1500:], r.stderr[-3000:])
