@@ -428,8 +428,25 @@ private:
                 const int fd = open(in_[f.index], O_RDONLY);
                 uint64_t got = 0;
                 if (fd >= 0) {
-                    ssize_t r;
-                    while (got < f.text_len && (r = read(fd, dst + got, f.text_len - got)) > 0) got += (uint64_t)r;
+                    // a large file (a whole eukaryote genome) is read in slices on a few threads of its own: one thread copies
+                    // the page cache at ~20 GB/s, which was a fifth of the whole call for a 4 GB file
+                    const uint64_t slice = 256ull << 20;
+                    const unsigned parts = (unsigned)std::min<uint64_t>(8, f.text_len / slice);
+                    auto take = [&](uint64_t from, uint64_t to) -> uint64_t {
+                        uint64_t at = from;
+                        ssize_t r;
+                        while (at < to && (r = pread(fd, dst + at, to - at, (off_t)at)) > 0) at += (uint64_t)r;
+                        return at - from;
+                    };
+                    if (parts >= 2) {
+                        std::vector<uint64_t> part_got(parts, 0);
+                        std::vector<std::thread> pool;
+                        const uint64_t per = (f.text_len + parts - 1) / parts;
+                        for (unsigned t = 1; t < parts; ++t) pool.emplace_back([&, t]() { part_got[t] = take(per * t, std::min<uint64_t>(f.text_len, per * (t + 1))); });
+                        part_got[0] = take(0, std::min<uint64_t>(f.text_len, per));
+                        for (auto& th : pool) th.join();
+                        for (uint64_t g : part_got) got += g;
+                    } else got = take(0, f.text_len);
                     close(fd);
                 }
                 if (got != f.text_len) {
