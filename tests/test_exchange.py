@@ -871,3 +871,42 @@ def test_pair_matrix_as_cells_straight_from_the_row_sums(ctx, tmp_path):
     inter, card, _, _ = orc.compare(payloads)
     for jac, suf in ((True, "_jaccard.csv.gz"), (False, "_containment.csv.gz")):
         assert gzip.open(str(tmp_path / "big") + suf, "rb").read() == orc.csv(jac, paths, inter, card, None, 6, 0.0), suf
+
+
+@pytest.mark.gpu
+def test_compare_files_of_one_species_over_contexts_equal_the_oracle(tmp_path):
+    """320 sketch FILES of one species (one ancestor, 0-1 % substitutions): every part of the comparison overflows, so the
+    file-level drivers go through the spill and the bit columns -- with one context (cells through the dense matrix) and
+    split by key over three (each context spills its own hash class; partial cells added on the host).  CSV bytes against
+    the oracle's comparator + printers, all-vs-all and with 9 query files."""
+    import gzip
+    import subprocess
+    rng = np.random.default_rng(4242)
+    anc = synth.random_genome(rng, 120_000)
+    k, m, s = 31, 11, 30.0
+    paths, payloads = [], []
+    for i in range(320):
+        g = synth.mutate(rng, anc, [0.0, 0.001, 0.003, 0.01][i % 4])
+        pl = orc.sketch_fasta(synth.to_fasta(g, "g%d" % i), k, m, s)[0]
+        pth = tmp_path / ("sp_%03d.gz" % i)
+        sp.write_gz(str(pth), pl, 1)
+        paths.append(str(pth)); payloads.append(pl)
+    code = ("import sys\nsys.path.insert(0, %r)\nimport supersampler_amd as sp\n"
+            "paths = [l.strip() for l in open(sys.argv[1])]\n"
+            "with sp.Context(0) as ctx:\n    ctx.compare_files(paths, sys.argv[2] + '_one')\n    ctx.compare_files(paths, sys.argv[2] + '_oneq', n_query=9)\n"
+            "sp.compare_files_multi([0, 0, 0], paths, sys.argv[2] + '_multi')\nsp.compare_files_multi([0, 0], paths, sys.argv[2] + '_multiq', n_query=9)\nprint('ok')\n") % ROOT
+    fof = tmp_path / "fof.txt"
+    fof.write_text("\n".join(paths) + "\n")
+    r = subprocess.run([sys.executable, "-c", code, str(fof), str(tmp_path / "out")], env=dict(os.environ, SPSP_DEBUG_SPILL_TRACE="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+    assert r.stderr.count("spsp spill:") >= 4, r.stderr[-3000:]          # the one-context call and every context of the split
+    inter, card, _, _ = orc.compare(payloads)
+    qi, qc, _, _ = orc.compare(payloads, n_query=9)
+    assert int((inter > 0).sum()) == 320 * 319 // 2
+    for jac, suf in ((True, "_jaccard.csv.gz"), (False, "_containment.csv.gz")):
+        want = orc.csv(jac, paths, inter, card, None, 6, 0.0)
+        assert gzip.open(str(tmp_path / "out") + "_one" + suf, "rb").read() == want
+        assert gzip.open(str(tmp_path / "out") + "_multi" + suf, "rb").read() == want
+        want_q = orc.csv(jac, paths, qi, qc, 9, 6, 0.0)
+        assert gzip.open(str(tmp_path / "out") + "_oneq" + suf, "rb").read() == want_q
+        assert gzip.open(str(tmp_path / "out") + "_multiq" + suf, "rb").read() == want_q
