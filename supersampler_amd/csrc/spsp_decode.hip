@@ -396,7 +396,7 @@ int compare_payloads_impl(spsp_ctx* ctx, const uint8_t* const* payloads, const u
             if ((rc = ctx->m_cells.reserve((size_t)cap * 8))) return rc;
             rc = compare_cells_run(ctx, [&]() { return compare_device_begin_impl(ctx, k, ctx->c_min.as<uint32_t>(), ctx->c_lo.as<uint64_t>(), k > 32 ? ctx->c_hi.as<uint64_t>() : nullptr,
                                                                                   sk_off.data(), n, n_query, 0, 1, ctx->c_inter.as<uint32_t>()); },
-                                   n, n_query < n ? n_query : n, ctx->c_inter.as<uint32_t>(), ctx->m_cells.as<uint64_t>(), cap, &n_cells);
+                                   n, n_query < n ? n_query : n, ctx->c_inter.as<uint32_t>(), ctx->m_cells.as<uint64_t>(), cap, &n_cells, &ctx->m_cells);
             if (rc != SPSP_ERR_OVERFLOW) break;
             cap = n_cells;
         }

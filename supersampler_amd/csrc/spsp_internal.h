@@ -262,7 +262,7 @@ int matrix_cells_impl(spsp_ctx* ctx, const uint32_t* d_inter, uint32_t n, uint32
 // queue a comparison with begin() and return its pair matrix as sparse cells: straight from the row sums where the form allows
 // it (d_scratch then stays unwritten), else through the dense matrix in d_scratch (n x n uint32) and k_matrix_cells
 int compare_cells_run(spsp_ctx* ctx, const std::function<int()>& begin, uint32_t n, uint32_t row_limit, uint32_t* d_scratch, uint64_t* d_cells,
-                      uint64_t cap, uint64_t* n_cells);
+                      uint64_t cap, uint64_t* n_cells, DevBuf* grow = nullptr);
 // decode + all-vs-all over several contexts (one per device, or several on one): the device half of spsp_compare_files_multi
 int compare_payloads_multi(spsp_ctx* const* ctxs, uint32_t n_ctx, const uint8_t* const* payloads, const uint64_t* lens, uint32_t n,
                            const int* extra_has, const uint32_t* extra_mn, uint32_t n_query, uint32_t* k_out, uint32_t* m_out,
