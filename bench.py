@@ -1075,6 +1075,13 @@ def compare_config4(ctx, dev, skip_oracle, peak):
     nz = int(torch.count_nonzero(torch.triu(d_inter, 1)).item())
     out["parity_sampled_pairs"] = {"checked": checked, "mismatches": bad, "against": "numpy set intersections of the (minimizer, k-mer) keys",
                                    "nonzero_pairs": nz, "nonzero_pairs_expected": (n // 20) * 190}
+    # the same size under other collection shapes: families of 200 / 2 000 / all 10 000 genomes of one species (parts overflow ->
+    # spill to HBM, bit columns + popcounts) -- sampled pairs against torch set algebra on the keys
+    try:
+        out["collection_shapes"] = compare_config4_shapes(ctx, dev, n, d_inter)
+    except Exception as e:  # noqa: BLE001
+        out["collection_shapes"] = {"error": repr(e)}
+    call()                                                # (d_inter holds configs[3]'s matrix again: the oracle check below reads it)
     pls = None
     try:
         out["compare_files"] = compare_files_config4(ctx, D, n, skip_oracle)
@@ -1094,6 +1101,40 @@ def compare_config4(ctx, dev, skip_oracle, peak):
                                    "equal": bool((np.triu(got, 1) == np.triu(want, 1)).all() and (card == cnt[:sub]).all()),
                                    "nonzero_pairs": int(np.count_nonzero(np.triu(want, 1)))}
     return out
+
+
+def compare_config4_shapes(ctx, dev, n, d_inter):
+    """configs[3]'s size, other collection structures (tools/exp/c4_shapes.py): wall ms per spsp_compare_device call in steady
+    state and 40 sampled pairs per shape (inside families and across) against set algebra on the keys."""
+    res = {}
+    rng = np.random.default_rng(5)
+    for F in (200, 2000, n):
+        D = synth.direct_family_sketches(n, fam_size=F, seed=4, device=dev, skm_range=(120, 360))
+        torch.cuda.synchronize()
+        call = lambda: ctx.compare_device(31, D.minimizer.data_ptr(), D.kmer_lo.data_ptr(), None, D.sk_off, n, 0, 1, d_inter.data_ptr())  # noqa: E731
+        for _ in range(2):
+            call()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            call()
+        ms = (time.perf_counter() - t0) * 1e3 / 3
+        key = torch.stack([D.minimizer.to(torch.int64), D.kmer_lo.view(torch.int64)], 1)
+        off = D.sk_off.astype(np.int64)
+        pairs = [(int(a), int(b)) for a, b in zip(rng.integers(0, n, 20), rng.integers(0, n, 20))]
+        pairs += [(int(a), min(n - 1, int(a) // F * F + int(rng.integers(0, F)))) for a in rng.integers(0, n, 20)]
+        wrong = checked = 0
+        for a, b in pairs:
+            if a == b:
+                continue
+            i, j = min(a, b), max(a, b)
+            ka, kb = key[off[i]:off[i + 1]], key[off[j]:off[j + 1]]
+            want = ka.shape[0] + kb.shape[0] - torch.cat([ka, kb]).unique(dim=0).shape[0]
+            wrong += int(d_inter[i, j].item()) != want
+            checked += 1
+        res["families_of_%d" % F] = {"keys": int(D.sk_off[-1]), "wall_ms_per_call": ms, "sketch_pairs_per_s": n * (n - 1) / 2 / (ms / 1e3),
+                                     "nonzero_pairs": int(torch.count_nonzero(torch.triu(d_inter, 1)).item()), "sampled_pairs": checked, "sampled_pairs_wrong": wrong}
+        del D, key
+    return res
 
 
 def compare_files_config4(ctx, D, n, skip_oracle):

@@ -41,6 +41,16 @@ with sp.Context(0) as ctx:
         print("compare_files: %.3f s" % (time.perf_counter() - t0), {k: round(v, 4) for k, v in ctx.stage_times().items() if v}, flush=True)
 for jac, suf in ((True, "_jaccard.csv.gz"), (False, "_containment.csv.gz")):
     ok &= gzip.open(os.path.join(tmp, "one") + suf, "rb").read() == want[jac]
+# sortCSV over the dense Jaccard matrix: rows and columns into a shuffled file order, against the oracle's
+jac_text = gzip.open(os.path.join(tmp, "one") + "_jaccard.csv.gz", "rb").read()
+order = rng.permutation(n)
+fof = ("\n".join(paths[i] for i in order) + "\n").encode()
+t0 = time.perf_counter()
+got_sorted = sp.sort_csv(jac_text, fof)
+t1 = time.perf_counter()
+want_sorted = orc.sort_csv(jac_text, fof)
+print("sort_csv: %.3f s for %d MB (oracle %.1f s), equal: %s" % (t1 - t0, len(jac_text) >> 20, time.perf_counter() - t1, got_sorted == want_sorted), flush=True)
+ok &= got_sorted == want_sorted
 for rep in range(2):
     t0 = time.perf_counter()
     sp.compare_files_multi([0, 0, 0], paths, os.path.join(tmp, "multi"))
