@@ -643,14 +643,22 @@ class Context:
         """all-vs-all with the pair matrix returned as packed non-zero cells (i << 48 | j << 32 | count) -> how many"""
         sk_off = np.ascontiguousarray(sk_off, dtype=np.uint64)
         cnt = C.c_uint64()
-        _check(lib().spsp_compare_cells_device(self._h, k, d_min, d_lo, d_hi, sk_off.ctypes.data, n, n if n_query is None else n_query, d_scratch,
-                                               d_cells, cap, C.byref(cnt)))
+        try:
+            _check(lib().spsp_compare_cells_device(self._h, k, d_min, d_lo, d_hi, sk_off.ctypes.data, n, n if n_query is None else n_query, d_scratch,
+                                                   d_cells, cap, C.byref(cnt)))
+        except SpspError as e:
+            e.cells_needed = cnt.value
+            raise
         return cnt.value
 
     def compare_slots_cells_device(self, k, d_slots, parts, n, slot_cap, d_scratch, d_cells, cap):
         """this rank's partial matrix of the key-partitioned split as packed non-zero cells -> how many"""
         cnt = C.c_uint64()
-        _check(lib().spsp_compare_slots_cells_device(self._h, k, d_slots, parts, n, slot_cap, d_scratch, d_cells, cap, C.byref(cnt)))
+        try:
+            _check(lib().spsp_compare_slots_cells_device(self._h, k, d_slots, parts, n, slot_cap, d_scratch, d_cells, cap, C.byref(cnt)))
+        except SpspError as e:
+            e.cells_needed = cnt.value          # ERR_OVERFLOW from too little room: how much there must be (spsp.h)
+            raise
         return cnt.value
 
     def matrix_add_cells_device(self, d_inter, n, d_cells, n_cells):

@@ -384,8 +384,8 @@ class SlotExchange:
             except SpspError as e:
                 if e.code != ERR_OVERFLOW:
                     raise
-                if "non-zero cells" in str(e):      # more cells than room: again with twice the room
-                    cap = 2 * cap
+                if "non-zero cells" in str(e):      # more cells than room: again with the room it asks for (a dense partial matrix
+                    cap = max(2 * cap, int(getattr(e, "cells_needed", 0)) + 1024)   # -- one species -- would double eight times)
                     continue
                 self._overflow = True               # a slot overflowed at its sender
                 break

@@ -831,7 +831,7 @@ def test_pair_matrix_as_cells_straight_from_the_row_sums(ctx, tmp_path):
     assert (unpack(cells, cnt_q, n)[:100] == want[:100]).all() and cnt_q == np.count_nonzero(want[:100])
     with pytest.raises(sp.SpspError) as e:
         ctx.compare_cells_device(31, D.minimizer.data_ptr(), D.kmer_lo.data_ptr(), None, D.sk_off, n, scratch.data_ptr(), cells.data_ptr(), 1000)
-    assert e.value.code == sp.ERR_OVERFLOW and str(cnt) in str(e.value)
+    assert e.value.code == sp.ERR_OVERFLOW and str(cnt) in str(e.value) and e.value.cells_needed == cnt
     # a small problem (<= 128 sketches: pair counters in LDS, dense result) comes back sparse all the same
     off100 = D.sk_off[:101].copy()
     c100 = ctx.compare_cells_device(31, D.minimizer.data_ptr(), D.kmer_lo.data_ptr(), None, off100, 100, scratch.data_ptr(), cells.data_ptr(), cells.numel())
