@@ -338,7 +338,8 @@ __global__ __launch_bounds__(kSparseThreads) void k_accumulate_sparse(const uint
                                                                      const uint32_t* __restrict__ flags,
                                                                      uint32_t* __restrict__ host_flags,
                                                                      unsigned long long* __restrict__ cells, unsigned long long cells_cap,
-                                                                     unsigned long long* __restrict__ cells_count, uint32_t xcd_rows, bool add) {
+                                                                     unsigned long long* __restrict__ cells_count, uint32_t xcd_rows, bool add,
+                                                                     const uint32_t* __restrict__ row_order) {
     extern __shared__ uint32_t s_cnt[];
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < kFlags) host_flags[threadIdx.x] = flags[threadIdx.x];
     // a part overflowed: its workgroup of k_parts_group left without writing list references, so the ones in place are
@@ -351,7 +352,11 @@ __global__ __launch_bounds__(kSparseThreads) void k_accumulate_sparse(const uint
     // member (MI355X_MICROARCH.md: 4 MiB of L2 per XCD, not coherent across XCDs; a family's lists are ~0.25 MB).
     uint32_t r = blockIdx.y;
     if (xcd_rows) { r = (blockIdx.y & 7u) * xcd_rows + (blockIdx.y >> 3); if ((blockIdx.y >> 3) >= xcd_rows) return; }
-    const uint32_t i = row_first + r * row_stride, col0 = blockIdx.x * cols;
+    if (row_order && r >= n) return;
+    // (row_order: every row owned; flags[10] / flags[11] = sketches with a sketch of the same signature close in front of them in the
+    // new order / in the input's: the new order is taken when the input keeps fewer than half as many together)
+    const bool reorder = row_order && 2u * flags[11] < flags[10];
+    const uint32_t i = reorder ? row_order[r] : row_first + r * row_stride, col0 = blockIdx.x * cols;
     if (i >= n || i >= row_limit) return;
     if (col0 + cols <= i + 1) return;                       // no column > i in this block
     uint64_t e0 = sk_begin[i], e1 = sk_end[i];
@@ -511,6 +516,87 @@ __device__ __forceinline__ uint64_t key_hash(uint64_t lo, uint32_t mn, uint64_t 
     h = mix64(h + (uint64_t)mn * 0xE7037ED1A0B428DBULL);
     if (has_hi) h = mix64(h ^ hi);
     return h;
+}
+
+// Rows of similar sketches side by side, whatever order the sketches came in.  The row sums deal the rows to the XCDs in
+// runs so that the rows of a family -- which fetch the same holder lists -- sit behind one L2; that presumes families come
+// in runs.  sig[j] = the smallest key hash of sketch j (a min-hash: two sketches share it with the probability of their
+// Jaccard index).  A key's part is the top of its hash, so a sketch's smallest hash lies in the first part it has a key in:
+// the records of the first few parts hold it for every sketch (64 parts: ~19 keys of each).
+constexpr uint32_t kSigParts = 64;
+template <bool HAS_HI>
+__global__ __launch_bounds__(1024) void k_row_signature(const uint64_t* __restrict__ recs, const uint32_t* __restrict__ part_cnt, uint32_t cap,
+                                                       unsigned long long* __restrict__ sig) {
+    constexpr uint32_t W = HAS_HI ? 3 : 2;
+    const uint32_t p = blockIdx.x, n = min(part_cnt[p], cap);
+    const uint64_t* base = recs + (uint64_t)p * cap * W;
+    for (uint32_t r = threadIdx.x; r < n; r += 1024) {
+        const uint64_t lo = base[(uint64_t)r * W], w1 = base[(uint64_t)r * W + 1], hi = HAS_HI ? base[(uint64_t)r * W + 2] : 0ull;
+        atomicMin(&sig[(uint32_t)(w1 >> 32)], (unsigned long long)key_hash(lo, (uint32_t)w1, hi, HAS_HI));
+    }
+}
+// The order: sketches dealt into 8 192 buckets by the top of their signature (a counting sort in ONE workgroup: equal
+// signatures land in the same bucket, a bucket holds one or two sketches on average, n <= 16 Ki).  stats[0] += sketches that
+// have a sketch of the same signature among the 32 in front of them in this order, stats[1] += the same count in INPUT order:
+// the row sums take the new order only when the input keeps fewer than half as many together -- sketches that come family by
+// family are already in a better order than one min-hash can make.
+constexpr uint32_t kOrderBuckets = 8192, kOrderWindow = 16, kOrderMost = 16384;
+__global__ __launch_bounds__(1024) void k_row_order(const unsigned long long* __restrict__ sig, uint32_t n, uint32_t* __restrict__ order, uint32_t* __restrict__ stats) {
+    extern __shared__ uint32_t lds_o[];
+    uint32_t* hist = lds_o;                       // [kOrderBuckets]
+    uint32_t* tag = lds_o + kOrderBuckets;        // [n]: the signatures, mixed once more (a smallest hash has no high bits), 32 bits of them
+    __shared__ uint32_t wave_sum[16];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wid = t >> 6;
+    for (uint32_t b = t; b < kOrderBuckets; b += 1024) hist[b] = 0;
+    __syncthreads();
+    for (uint32_t i = t; i < n; i += 1024) {
+        const uint32_t g = (uint32_t)(mix64(sig[i]) >> 32);
+        tag[i] = g;
+        atomicAdd(&hist[g >> 19], 1u);
+    }
+    __syncthreads();
+    uint32_t near_new = 0, near_in = 0;
+    for (uint32_t p = t; p < n; p += 1024) {      // input order: a sketch of the same signature among the kOrderWindow in front?
+        const uint32_t a = tag[p];
+        bool f = false;
+        for (uint32_t w = 1; w <= kOrderWindow && w <= p; ++w) f |= tag[p - w] == a;
+        near_in += f ? 1u : 0u;
+    }
+    // exclusive prefix over the buckets, 8 per thread
+    uint32_t c[8], sum = 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { c[u] = hist[t * 8 + u]; sum += c[u]; }
+    uint32_t x = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d); if (lane >= (uint32_t)d) x += y; }
+    if (lane == 63) wave_sum[wid] = x;
+    __syncthreads();
+    uint32_t pre = 0;
+    for (uint32_t w = 0; w < wid; ++w) pre += wave_sum[w];
+    uint32_t at = pre + x - sum;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { hist[t * 8 + u] = at; at += c[u]; }
+    __syncthreads();
+    uint32_t mine[kOrderMost / 1024], where_[kOrderMost / 1024];
+#pragma unroll
+    for (uint32_t u = 0; u < kOrderMost / 1024; ++u) {
+        const uint32_t i = t + u * 1024;
+        mine[u] = 0; where_[u] = 0;
+        if (i < n) { mine[u] = tag[i]; where_[u] = atomicAdd(&hist[mine[u] >> 19], 1u); order[where_[u]] = i; }
+    }
+    __syncthreads();                              // every tag has been read: the array now holds them in the new order
+#pragma unroll
+    for (uint32_t u = 0; u < kOrderMost / 1024; ++u) if (t + u * 1024 < n) tag[where_[u]] = mine[u];
+    __syncthreads();
+    for (uint32_t p = t; p < n; p += 1024) {
+        const uint32_t a = tag[p];
+        bool f = false;
+        for (uint32_t w = 1; w <= kOrderWindow && w <= p; ++w) f |= tag[p - w] == a;
+        near_new += f ? 1u : 0u;
+    }
+#pragma unroll
+    for (int d = 32; d; d >>= 1) { near_new += __shfl_xor(near_new, d); near_in += __shfl_xor(near_in, d); }
+    if (lane == 0) { if (near_new) atomicAdd(&stats[0], near_new); if (near_in) atomicAdd(&stats[1], near_in); }
 }
 
 // sub_sk[c] = sketch holding entry c * kScatSub (worked out by the host, which has the offsets anyway)
@@ -1132,6 +1218,7 @@ struct ComparePlan {
     const uint32_t* list_ref = nullptr;  // list reference per entry -- or per record slot, with `where` = slot of every entry
     const uint32_t* where = nullptr;
     uint64_t max_row = 0;                // keys of the longest sketch (0 = unknown): bounds every pair count
+    const uint32_t* row_order = nullptr; // rows in the order of their sketches' min-hash (k_row_order), or null
 };
 struct CompareJob {
     ComparePlan P;
@@ -1164,6 +1251,8 @@ struct CompareJob {
     bool bracket_closed = false;    // the kEvCompare bracket of the begin call has been closed already
     // very large inputs (more keys than kMaxKeyParts parts hold): the keys go through the partition form one hash class at a
     // time, the first class's row sums store the cells, the later ones add
+    bool has_hi = false;            // k > 32: records carry a second key word
+    bool ordered = false;           // this attempt makes a row order (k_row_order)
     uint32_t classes = 1, cls = 0;
     uint64_t S_behind = 0;          // keys of the first owned row and later sketches: what the scatter deals
     // spill (partition form, unfiltered): the records of parts that overflow are grouped in a table in HBM (k_spill_insert)
@@ -1216,7 +1305,7 @@ static int launch_accumulate_sparse(spsp_ctx* ctx, const ComparePlan& P, uint32_
                        // a caller that wants the result as sparse cells (compare_cells_run) gets them straight from the row sums
                        // when ONE workgroup makes a row (no split) -- else the dense matrix is written and sparsified afterwards
                        (may_emit_cells && ctx->cells_req.armed && split == 1) ? ctx->cells_req.cells : (unsigned long long*)nullptr,
-                       (unsigned long long)ctx->cells_req.cap, ctx->cells_req.count, xcd_rows, add);
+                       (unsigned long long)ctx->cells_req.cap, ctx->cells_req.count, xcd_rows, add, by_xcd ? P.row_order : (const uint32_t*)nullptr);
     ctx->cells_req.direct = may_emit_cells && ctx->cells_req.armed && split == 1;
     // the number of cells travels to pinned memory behind the kernel: whoever waits for the job (compare_end) has it, no round trip of its own
     if (ctx->cells_req.direct) SPSP_HIP(hipMemcpyAsync(ctx->h_scalar + 12, ctx->cells_req.count, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -1247,7 +1336,32 @@ static int job_parts(spsp_ctx* ctx, CompareJob& J) {
     if ((rc = ctx->ev_begin(kEvScatter))) return rc;
     if (J.filtered && (rc = J.build_filter(J.filter_words - 1))) return rc;
     if (J.spill.room && !J.small && (rc = J.spill_parts(J.n_parts, J.spill, 0, J.classes, J.cls))) return rc;
+    // rows of similar sketches side by side for the row sums (their holder lists meet in one L2), whatever order the sketches
+    // came in: the scatter leaves every sketch's smallest key hash, k_row_order ranks them (SPSP_DEBUG_ROW_ORDER=0: launch order)
+    static const char* dbg_order = getenv("SPSP_DEBUG_ROW_ORDER");
+    const bool all_rows = J.P.row_first == 0 && J.P.row_stride == 1 && J.P.row_limit >= J.P.n && J.P.n_own == J.P.n;
+    bool ordered = !J.small && all_rows && J.P.n >= 512 && J.P.n <= (uint32_t)kSparseCols && !(dbg_order && dbg_order[0] == '0');
+    // (a context whose last comparison came in a good order of its own -- k_row_order's verdict, read back with the job -- skips
+    // the making of the order for the next fifteen: collections are compared batch after batch of the same kind)
+    if (ordered && ctx->order_quiet > 0 && !(dbg_order && dbg_order[0] == '2')) { --ctx->order_quiet; ordered = false; }
+    J.ordered = ordered;
+    if (ordered && ((rc = ctx->c_sig.reserve((size_t)J.P.n * 8)) || (rc = ctx->c_order.reserve((size_t)J.P.n * 4)))) return rc;
     if (!(skip & 1) && (rc = J.scatter_parts(J.n_parts, J.small, J.filtered, J.filter_words - 1, J.classes, J.cls))) return rc;
+    if (ordered) {
+        const hipStream_t side = ctx->stream;          // (on a stream of their own beside the grouping kernel these three short launches cost the same 0.06 ms: measured)
+        SPSP_HIP(hipMemsetAsync(ctx->c_sig.p, 0xff, (size_t)J.P.n * 8, side));
+        unsigned long long* sig = ctx->c_sig.as<unsigned long long>();
+        const uint32_t sp = std::min<uint32_t>(J.n_parts, kSigParts);
+        if (J.has_hi) hipLaunchKernelGGL(k_row_signature<true>, dim3(sp), dim3(1024), 0, side, ctx->c_recs.as<uint64_t>(), ctx->c_part_cnt.as<uint32_t>(), (uint32_t)kPartCap, sig);
+        else hipLaunchKernelGGL(k_row_signature<false>, dim3(sp), dim3(1024), 0, side, ctx->c_recs.as<uint64_t>(), ctx->c_part_cnt.as<uint32_t>(), (uint32_t)kPartCap, sig);
+        static_assert(kOrderMost == kSparseCols, "the order is made for comparisons of one column block");
+        if (!ctx->attr_order_set) {
+            SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_row_order), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((kOrderBuckets + kOrderMost) * 4)));
+            ctx->attr_order_set = true;
+        }
+        hipLaunchKernelGGL(k_row_order, dim3(1), dim3(1024), (size_t)(kOrderBuckets + J.P.n) * 4, side, (const unsigned long long*)sig, J.P.n, ctx->c_order.as<uint32_t>(), flags + 10);
+        SPSP_HIP(hipGetLastError());
+    }
     if ((rc = ctx->ev_end(kEvScatter))) return rc;
     if ((rc = ctx->ev_begin(kEvGroup))) return rc;
     if (!(skip & 2) && (rc = J.small ? J.group_small(J.n_parts) : J.group_parts(J.n_parts, J.spill))) return rc;
@@ -1257,6 +1371,10 @@ static int job_parts(spsp_ctx* ctx, CompareJob& J) {
     if ((rc = ctx->ev_begin(kEvAccumulate))) return rc;
     ComparePlan PP = J.P;
     PP.list_ref = ctx->c_lref.as<uint32_t>(); PP.where = ctx->c_where.as<uint32_t>();
+    if (ordered) {
+        PP.row_order = ctx->c_order.as<uint32_t>();
+        SPSP_HIP(hipMemcpyAsync(ctx->h_scalar + 14, flags + 10, 8, hipMemcpyDeviceToHost, ctx->stream));   // the verdict, for compare_job_end
+    }
     // (an attempt whose parts overflow leaves this kernel at its first line, before any cell is emitted: the retry emits them once)
     // (with a spill the keys that have columns add into the dense matrix behind the row sums: no cells straight from them)
     //  -- nor with key classes: a pair's count comes in several parts)
@@ -1524,6 +1642,10 @@ int compare_job_end(spsp_ctx* ctx) {
         if (J->filtered && h_flags[7]) ctx->filter_ratio = (double)h_flags[7] / (double)J->P.S_own;
         if (!h_flags[6]) {
             if (!J->filtered && !J->small) ctx->spill_expect = h_flags[2];
+            if (J->ordered) {
+                const uint32_t near_new = (uint32_t)ctx->h_scalar[14], near_in = (uint32_t)(ctx->h_scalar[14] >> 32);
+                ctx->order_quiet = 2 * near_in >= near_new ? 15 : 0;
+            }
             static const bool trace = getenv("SPSP_DEBUG_SPILL_TRACE") != nullptr;     // test hook: which way the comparison went
             if (trace && J->spill.room) fprintf(stderr, "spsp spill: %u records of overflowed parts grouped in HBM (room %llu, %u parts, columns from %u holders)\n",
                                                 h_flags[2], (unsigned long long)J->spill.room, J->n_parts, J->spill.t_bits);
@@ -1711,6 +1833,7 @@ static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t*
         return SPSP_OK;
     };
     const bool has_hi = K.hi != nullptr;
+    J->has_hi = has_hi;
     const uint32_t* sub_sk = reinterpret_cast<const uint32_t*>(sk + n + 1);
     J->n_sub = (uint32_t)((S + kScatSub - 1) / kScatSub);
     J->build_filter = [=](uint32_t fmask) -> int {

@@ -910,3 +910,34 @@ def test_compare_files_of_one_species_over_contexts_equal_the_oracle(tmp_path):
         want_q = orc.csv(jac, paths, qi, qc, 9, 6, 0.0)
         assert gzip.open(str(tmp_path / "out") + "_oneq" + suf, "rb").read() == want_q
         assert gzip.open(str(tmp_path / "out") + "_multiq" + suf, "rb").read() == want_q
+
+
+@pytest.mark.gpu
+def test_rows_ordered_by_min_hash_give_the_same_matrix(ctx):
+    """1 500 sketches in families of 20, once family by family and once in a random order: the row sums of the shuffled
+    collection run in the order of the sketches' min-hash signatures (k_row_signature / k_row_order: a family's rows side by
+    side behind one L2) -- scheduling only, so every cell must equal the cell of the same two sketches in the first matrix.
+    Several calls per context (a context that saw a well-ordered input skips the ordering for a while)."""
+    n, F = 1500, 20
+    dev = torch.device("cuda", 0)
+    D = synth.direct_family_sketches(n, fam_size=F, seed=11, device=dev, skm_range=(40, 90))
+    rng = np.random.default_rng(3)
+    perm = rng.permutation(n)
+    off0 = D.sk_off.astype(np.int64)
+    cnt = np.diff(off0)[perm]
+    new_off = np.zeros(n + 1, np.int64)
+    new_off[1:] = np.cumsum(cnt)
+    src = torch.from_numpy(np.repeat(off0[:-1][perm] - new_off[:-1], cnt)).to(dev) + torch.arange(int(new_off[-1]), device=dev)
+    mn_b, lo_b = D.minimizer[src].contiguous(), D.kmer_lo[src].contiguous()
+    a = torch.zeros((n, n), dtype=torch.int32, device=dev)
+    b = torch.zeros((n, n), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    for rep in range(3):
+        ctx.compare_device(31, D.minimizer.data_ptr(), D.kmer_lo.data_ptr(), None, D.sk_off, n, 0, 1, a.data_ptr())
+        ctx.compare_device(31, mn_b.data_ptr(), lo_b.data_ptr(), None, new_off.astype(np.uint64), n, 0, 1, b.data_ptr())
+        A = np.triu(a.cpu().numpy(), 1)
+        A = A + A.T                                       # the pair count of two sketches, whichever comes first
+        B = np.triu(b.cpu().numpy(), 1)
+        want = np.triu(A[np.ix_(perm, perm)], 1)
+        assert (B == want).all(), rep
+    assert np.count_nonzero(A) >= n * (F - 1) * 0.9

@@ -28,6 +28,20 @@ d_inter = torch.zeros((n, n), dtype=torch.int32, device=dev)
 rng = np.random.default_rng(1)
 for F in fams:
     D = synth.direct_family_sketches(n, fam_size=F, seed=4, device=dev, skm_range=(120, 360), mus=(0.001, 0.01, 0.05))
+    if os.environ.get("SHAPES_SHUFFLE", "0") == "1":            # the sketches in a random order (families no longer side by side)
+        perm = rng.permutation(n)
+        off0 = D.sk_off.astype(np.int64)
+        cnt = np.diff(off0)[perm]
+        new_off = np.zeros(n + 1, np.int64)
+        new_off[1:] = np.cumsum(cnt)
+        src = torch.from_numpy(np.repeat(off0[:-1][perm] - new_off[:-1], cnt)).to(dev) + torch.arange(int(new_off[-1]), device=dev)
+        D.minimizer = D.minimizer[src].contiguous()
+        D.kmer_lo = D.kmer_lo[src].contiguous()
+        D.sk_off = new_off.astype(np.uint64)
+        fam_of = (perm // F)
+        del src
+    else:
+        fam_of = np.arange(n) // F
     torch.cuda.synchronize()
     d_hi = ((D.kmer_lo.view(torch.int64) * 0x9E3779B97F4A7C15) >> 3) & 0x0fffffffffffffff if use_hi else None
     call = lambda: ctx.compare_device(63 if use_hi else 31, D.minimizer.data_ptr(), D.kmer_lo.data_ptr(), d_hi.data_ptr() if use_hi else None, D.sk_off, n, 0, 1,  # noqa: E731
@@ -55,7 +69,9 @@ for F in fams:
     off = D.sk_off.astype(np.int64)
     wrong = 0
     pairs = [(int(a), int(b)) for a, b in zip(rng.integers(0, n, 30), rng.integers(0, n, 30))]
-    pairs += [(int(a), min(n - 1, int(a) // F * F + int(rng.integers(0, F)))) for a in rng.integers(0, n, 30)]
+    for a in rng.integers(0, n, 30):                             # pairs inside a family
+        mates = np.nonzero(fam_of == fam_of[int(a)])[0]
+        pairs.append((int(a), int(mates[int(rng.integers(0, len(mates)))])))
     for a, b in pairs:
         if a == b:
             continue
