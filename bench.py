@@ -1108,8 +1108,19 @@ def compare_config4_shapes(ctx, dev, n, d_inter):
     state and 40 sampled pairs per shape (inside families and across) against set algebra on the keys."""
     res = {}
     rng = np.random.default_rng(5)
-    for F in (200, 2000, n):
+    for F, shuffled in ((20, True), (200, False), (2000, False), (n, False)):
         D = synth.direct_family_sketches(n, fam_size=F, seed=4, device=dev, skm_range=(120, 360))
+        fam_of = np.arange(n) // F
+        if shuffled:                                       # configs[3]'s own sketches in a random order (files are not listed family by family)
+            perm = rng.permutation(n)
+            off0 = D.sk_off.astype(np.int64)
+            cnt = np.diff(off0)[perm]
+            new_off = np.zeros(n + 1, np.int64)
+            new_off[1:] = np.cumsum(cnt)
+            src = torch.from_numpy(np.repeat(off0[:-1][perm] - new_off[:-1], cnt)).to(dev) + torch.arange(int(new_off[-1]), device=dev)
+            D.minimizer, D.kmer_lo, D.sk_off = D.minimizer[src].contiguous(), D.kmer_lo[src].contiguous(), new_off.astype(np.uint64)
+            fam_of = perm // F
+            del src
         torch.cuda.synchronize()
         call = lambda: ctx.compare_device(31, D.minimizer.data_ptr(), D.kmer_lo.data_ptr(), None, D.sk_off, n, 0, 1, d_inter.data_ptr())  # noqa: E731
         for _ in range(2):
@@ -1121,7 +1132,9 @@ def compare_config4_shapes(ctx, dev, n, d_inter):
         key = torch.stack([D.minimizer.to(torch.int64), D.kmer_lo.view(torch.int64)], 1)
         off = D.sk_off.astype(np.int64)
         pairs = [(int(a), int(b)) for a, b in zip(rng.integers(0, n, 20), rng.integers(0, n, 20))]
-        pairs += [(int(a), min(n - 1, int(a) // F * F + int(rng.integers(0, F)))) for a in rng.integers(0, n, 20)]
+        for a in rng.integers(0, n, 20):                   # pairs inside a family
+            mates = np.nonzero(fam_of == fam_of[int(a)])[0]
+            pairs.append((int(a), int(mates[int(rng.integers(0, len(mates)))])))
         wrong = checked = 0
         for a, b in pairs:
             if a == b:
@@ -1131,7 +1144,7 @@ def compare_config4_shapes(ctx, dev, n, d_inter):
             want = ka.shape[0] + kb.shape[0] - torch.cat([ka, kb]).unique(dim=0).shape[0]
             wrong += int(d_inter[i, j].item()) != want
             checked += 1
-        res["families_of_%d" % F] = {"keys": int(D.sk_off[-1]), "wall_ms_per_call": ms, "sketch_pairs_per_s": n * (n - 1) / 2 / (ms / 1e3),
+        res["families_of_%d%s" % (F, "_in_random_order" if shuffled else "")] = {"keys": int(D.sk_off[-1]), "wall_ms_per_call": ms, "sketch_pairs_per_s": n * (n - 1) / 2 / (ms / 1e3),
                                      "nonzero_pairs": int(torch.count_nonzero(torch.triu(d_inter, 1)).item()), "sampled_pairs": checked, "sampled_pairs_wrong": wrong}
         del D, key
     return res

@@ -1337,7 +1337,8 @@ static int job_parts(spsp_ctx* ctx, CompareJob& J) {
     if (J.filtered && (rc = J.build_filter(J.filter_words - 1))) return rc;
     if (J.spill.room && !J.small && (rc = J.spill_parts(J.n_parts, J.spill, 0, J.classes, J.cls))) return rc;
     // rows of similar sketches side by side for the row sums (their holder lists meet in one L2), whatever order the sketches
-    // came in: the scatter leaves every sketch's smallest key hash, k_row_order ranks them (SPSP_DEBUG_ROW_ORDER=0: launch order)
+    // came in: every sketch's smallest key hash from the records of the first parts (k_row_signature), the order they give
+    // (k_row_order).  SPSP_DEBUG_ROW_ORDER=0: launch order, 2: an order for every comparison
     static const char* dbg_order = getenv("SPSP_DEBUG_ROW_ORDER");
     const bool all_rows = J.P.row_first == 0 && J.P.row_stride == 1 && J.P.row_limit >= J.P.n && J.P.n_own == J.P.n;
     bool ordered = !J.small && all_rows && J.P.n >= 512 && J.P.n <= (uint32_t)kSparseCols && !(dbg_order && dbg_order[0] == '0');
@@ -1348,7 +1349,7 @@ static int job_parts(spsp_ctx* ctx, CompareJob& J) {
     if (ordered && ((rc = ctx->c_sig.reserve((size_t)J.P.n * 8)) || (rc = ctx->c_order.reserve((size_t)J.P.n * 4)))) return rc;
     if (!(skip & 1) && (rc = J.scatter_parts(J.n_parts, J.small, J.filtered, J.filter_words - 1, J.classes, J.cls))) return rc;
     if (ordered) {
-        const hipStream_t side = ctx->stream;          // (on a stream of their own beside the grouping kernel these three short launches cost the same 0.06 ms: measured)
+        const hipStream_t side = ctx->stream;          // (on a stream of their own, beside the grouping kernel, these three short launches cost the same 0.06 ms: measured)
         SPSP_HIP(hipMemsetAsync(ctx->c_sig.p, 0xff, (size_t)J.P.n * 8, side));
         unsigned long long* sig = ctx->c_sig.as<unsigned long long>();
         const uint32_t sp = std::min<uint32_t>(J.n_parts, kSigParts);
