@@ -339,7 +339,7 @@ __global__ __launch_bounds__(kSparseThreads) void k_accumulate_sparse(const uint
                                                                      uint32_t* __restrict__ host_flags,
                                                                      unsigned long long* __restrict__ cells, unsigned long long cells_cap,
                                                                      unsigned long long* __restrict__ cells_count, uint32_t xcd_rows, bool add,
-                                                                     const uint32_t* __restrict__ row_order) {
+                                                                     const uint32_t* __restrict__ row_order, uint32_t long_limit) {
     extern __shared__ uint32_t s_cnt[];
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < kFlags) host_flags[threadIdx.x] = flags[threadIdx.x];
     // a part overflowed: its workgroup of k_parts_group left without writing list references, so the ones in place are
@@ -358,8 +358,9 @@ __global__ __launch_bounds__(kSparseThreads) void k_accumulate_sparse(const uint
     const bool reorder = row_order && 2u * flags[11] < flags[10];
     const uint32_t i = reorder ? row_order[r] : row_first + r * row_stride, col0 = blockIdx.x * cols;
     if (i >= n || i >= row_limit) return;
-    if (col0 + cols <= i + 1) return;                       // no column > i in this block
+    if (col0 + cols <= i + 1 || i + 1 >= n) return;         // no column > i in this block / at all
     uint64_t e0 = sk_begin[i], e1 = sk_end[i];
+    if (long_limit && e1 - e0 > long_limit) return;         // a row far longer than the others: summed in slices by a launch of its own
     if (split > 1) {
         const uint64_t per = (e1 - e0 + split - 1) / split;
         e0 += per * blockIdx.z;
@@ -530,9 +531,26 @@ __global__ __launch_bounds__(1024) void k_row_signature(const uint64_t* __restri
     constexpr uint32_t W = HAS_HI ? 3 : 2;
     const uint32_t p = blockIdx.x, n = min(part_cnt[p], cap);
     const uint64_t* base = recs + (uint64_t)p * cap * W;
-    for (uint32_t r = threadIdx.x; r < n; r += 1024) {
-        const uint64_t lo = base[(uint64_t)r * W], w1 = base[(uint64_t)r * W + 1], hi = HAS_HI ? base[(uint64_t)r * W + 2] : 0ull;
-        atomicMin(&sig[(uint32_t)(w1 >> 32)], (unsigned long long)key_hash(lo, (uint32_t)w1, hi, HAS_HI));
+    for (uint32_t r0 = 0; r0 < n; r0 += 1024) {          // (every lane makes every round: the waves vote)
+        const uint32_t r = r0 + threadIdx.x;
+        const bool valid = r < n;
+        uint32_t sk = 0;
+        unsigned long long h = ~0ull;
+        if (valid) {
+            const uint64_t lo = base[(uint64_t)r * W], w1 = base[(uint64_t)r * W + 1], hi = HAS_HI ? base[(uint64_t)r * W + 2] : 0ull;
+            sk = (uint32_t)(w1 >> 32);
+            h = (unsigned long long)key_hash(lo, (uint32_t)w1, hi, HAS_HI);
+        }
+        // records reach a part in runs of one sketch: a wave of one sketch sends ONE atomic (a sketch of 3 x 10^6 keys among
+        // 10 000 small ones had 11 000 records here, all on one address: 0.12 ms)
+        const unsigned long long live = __ballot(valid);
+        if (!live) continue;
+        const uint32_t sk0 = __shfl(sk, __ffsll((long long)live) - 1);
+        if (__all(!valid || sk == sk0)) {
+#pragma unroll
+            for (int d = 32; d; d >>= 1) { const unsigned long long o = __shfl_xor(h, d); h = o < h ? o : h; }
+            if ((threadIdx.x & 63u) == 0) atomicMin(&sig[sk0], h);
+        } else if (valid) atomicMin(&sig[sk], h);
     }
 }
 // The order: sketches dealt into 8 192 buckets by the top of their signature (a counting sort in ONE workgroup: equal
@@ -1277,7 +1295,18 @@ static int launch_accumulate_sparse(spsp_ctx* ctx, const ComparePlan& P, uint32_
     // a row's keys are walked by ONE workgroup unless the sketches are huge (few sketches of millions of keys):
     // then slices of the row add into cells cleared first
     const uint64_t per_row = P.n_own ? P.S_own / P.n_own : 0;
-    const uint32_t split = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, per_row / 65536), 64);
+    uint32_t split = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, per_row / 65536), 64);
+    // ... or a FEW rows are (one eukaryote among ten thousand bacteria): those rows get launches of their own, in slices, and
+    // the launch of all rows passes them by -- one workgroup walking 3 x 10^6 keys was 5 ms of tail behind a 0.9 ms kernel, and
+    // its length had switched the 16-bit counters off for every row (a counter is bounded by the SHORTER sketch of its pair)
+    constexpr uint64_t kLongRow = 65535;
+    std::vector<uint32_t> long_rows;
+    if (split == 1 && P.max_row > kLongRow && ctx->h_skoff) {
+        for (uint32_t i = P.row_first; i < std::min(P.row_limit, P.n) && long_rows.size() <= 64; i += P.row_stride)
+            if (ctx->h_skoff[i + 1] - ctx->h_skoff[i] > kLongRow) long_rows.push_back(i);
+        if (long_rows.size() > 64) { long_rows.clear(); split = 2; }        // many: every row in slices (the form for huge sketches)
+    }
+    const uint32_t long_limit = long_rows.empty() ? 0u : (uint32_t)kLongRow;
     if (split > 1 && !add) {
         hipLaunchKernelGGL(k_zero_rows, dim3(std::max(1u, std::min((P.n + 255) / 256, 64u)), P.n_own), dim3(256), 0, ctx->stream,
                            P.n, P.row_first, P.row_stride, P.row_limit, P.d_inter);
@@ -1293,23 +1322,37 @@ static int launch_accumulate_sparse(spsp_ctx* ctx, const ComparePlan& P, uint32_
     // 16-bit counters when no row can make one overflow: half the LDS per workgroup -> twice the rows in flight per CU (the
     // kernel waits on two dependent random reads per key: more rows in flight is more of them in flight)
     static const char* dbg_half = getenv("SPSP_DEBUG_ACC_HALF");   // "0": 32-bit counters (A/B)
-    const bool half = split == 1 && P.max_row > 0 && P.max_row <= 65535 && !(dbg_half && dbg_half[0] == '0');
+    const bool half = split == 1 && P.max_row > 0 && (P.max_row <= kLongRow || long_limit) && !(dbg_half && dbg_half[0] == '0');
     // (256-lane workgroups for short rows were measured for the key-partitioned ranks' ~600-key rows: 0.178 -> 0.192 ms -- a row's fixed
     // cost is clearing and scanning its N counters, which takes four times as many rounds with a quarter of the lanes; not kept)
     auto kern = half ? &k_accumulate_sparse<true> : &k_accumulate_sparse<false>;
+    // a caller that wants the result as sparse cells (compare_cells_run) gets them straight from the row sums
+    // when ONE workgroup makes a row (no split, no long rows) -- else the dense matrix is written and sparsified afterwards
+    const bool direct = may_emit_cells && ctx->cells_req.armed && split == 1 && long_rows.empty();
     hipLaunchKernelGGL(kern, dim3(col_blocks, by_xcd ? xcd_rows * 8 : P.n_own, split), dim3(kSparseThreads),
                        ((size_t)cols << copies_log2) * (half ? 2 : 4), ctx->stream,
                        P.list_ref ? P.list_ref : ctx->c_row.as<uint32_t>(), P.where, ctx->c_matrix.as<uint16_t>(), P.sk_begin, P.sk_end,
                        P.n, P.row_first, P.row_stride, P.row_limit, cols, copies_log2, split, P.d_inter, flags,
                        reinterpret_cast<uint32_t*>(ctx->h_scalar + 8),
-                       // a caller that wants the result as sparse cells (compare_cells_run) gets them straight from the row sums
-                       // when ONE workgroup makes a row (no split) -- else the dense matrix is written and sparsified afterwards
-                       (may_emit_cells && ctx->cells_req.armed && split == 1) ? ctx->cells_req.cells : (unsigned long long*)nullptr,
-                       (unsigned long long)ctx->cells_req.cap, ctx->cells_req.count, xcd_rows, add, by_xcd ? P.row_order : (const uint32_t*)nullptr);
-    ctx->cells_req.direct = may_emit_cells && ctx->cells_req.armed && split == 1;
-    // the number of cells travels to pinned memory behind the kernel: whoever waits for the job (compare_end) has it, no round trip of its own
-    if (ctx->cells_req.direct) SPSP_HIP(hipMemcpyAsync(ctx->h_scalar + 12, ctx->cells_req.count, 8, hipMemcpyDeviceToHost, ctx->stream));
+                       direct ? ctx->cells_req.cells : (unsigned long long*)nullptr,
+                       (unsigned long long)ctx->cells_req.cap, ctx->cells_req.count, xcd_rows, add, by_xcd ? P.row_order : (const uint32_t*)nullptr, long_limit);
     SPSP_HIP(hipGetLastError());
+    for (uint32_t i : long_rows) {
+        const uint64_t keys = ctx->h_skoff[i + 1] - ctx->h_skoff[i];
+        const uint32_t slices = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(2, keys / 32768), 256);
+        if (!add) {
+            hipLaunchKernelGGL(k_zero_rows, dim3(std::max(1u, std::min((P.n + 255) / 256, 64u)), 1), dim3(256), 0, ctx->stream, P.n, i, 1u, i + 1, P.d_inter);
+            SPSP_HIP(hipGetLastError());
+        }
+        hipLaunchKernelGGL(k_accumulate_sparse<false>, dim3(col_blocks, 1, slices), dim3(kSparseThreads), ((size_t)cols << copies_log2) * 4, ctx->stream,
+                           P.list_ref ? P.list_ref : ctx->c_row.as<uint32_t>(), P.where, ctx->c_matrix.as<uint16_t>(), P.sk_begin, P.sk_end,
+                           P.n, i, 1u, i + 1, cols, copies_log2, slices, P.d_inter, flags, reinterpret_cast<uint32_t*>(ctx->h_scalar + 8),
+                           (unsigned long long*)nullptr, 0ull, (unsigned long long*)nullptr, 0u, add, (const uint32_t*)nullptr, 0u);
+        SPSP_HIP(hipGetLastError());
+    }
+    ctx->cells_req.direct = direct;
+    // the number of cells travels to pinned memory behind the kernel: whoever waits for the job (compare_end) has it, no round trip of its own
+    if (direct) SPSP_HIP(hipMemcpyAsync(ctx->h_scalar + 12, ctx->cells_req.count, 8, hipMemcpyDeviceToHost, ctx->stream));
     return SPSP_OK;
 }
 static int job_queue_flags(spsp_ctx* ctx);

@@ -941,3 +941,55 @@ def test_rows_ordered_by_min_hash_give_the_same_matrix(ctx):
         want = np.triu(A[np.ix_(perm, perm)], 1)
         assert (B == want).all(), rep
     assert np.count_nonzero(A) >= n * (F - 1) * 0.9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("where", ["first", "middle", "last"])
+def test_one_sketch_far_longer_than_the_others(ctx, where):
+    """600 sketches of a few hundred keys and ONE of 90 000 (a eukaryote among bacteria): the long row is summed in slices by a
+    launch of its own, the launch of all rows passes it by and keeps its 16-bit counters (k_accumulate_sparse, long_limit).
+    Every cell against numpy set algebra; dense and as cells."""
+    import torch
+    rng = np.random.default_rng(17)
+    n = 601
+    uni_mn = rng.integers(0, 2**22, 4000).astype(np.uint32)
+    uni_lo = rng.integers(0, 2**62, 4000).astype(np.uint64)
+    pos = {"first": 0, "middle": 300, "last": n - 1}[where]
+    sets = []
+    for i in range(n):
+        if i == pos:
+            pick = rng.random(4000) < 0.3
+            extra = 90_000
+        else:
+            pick = rng.random(4000) < rng.choice([0.02, 0.1])
+            extra = int(rng.integers(0, 50))
+        mn = np.concatenate([uni_mn[pick], rng.integers(0, 2**22, extra).astype(np.uint32)])
+        lo = np.concatenate([uni_lo[pick], rng.integers(2**62, 2**63, extra).astype(np.uint64)])     # (private keys: another range)
+        order = np.lexsort((lo, mn))
+        sets.append((mn[order], lo[order]))
+    off = np.zeros(n + 1, np.uint64)
+    off[1:] = np.cumsum([len(s[0]) for s in sets])
+    dev = torch.device("cuda", 0)
+    d_mn = torch.from_numpy(np.concatenate([s[0] for s in sets]).view(np.int32)).to(dev)
+    d_lo = torch.from_numpy(np.concatenate([s[1] for s in sets]).view(np.int64)).to(dev)
+    d_inter = torch.full((n, n), -1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    ctx.compare_device(31, d_mn.data_ptr(), d_lo.data_ptr(), None, off, n, 0, 1, d_inter.data_ptr())
+    got = d_inter.cpu().numpy()
+    in_uni = np.zeros((n, 4000), bool)                     # shared keys come from the universe only
+    key_id = {(int(a), int(b)): j for j, (a, b) in enumerate(zip(uni_mn, uni_lo))}
+    for i, (mn, lo) in enumerate(sets):
+        for a, b in zip(mn.tolist(), lo.tolist()):
+            j = key_id.get((a, b))
+            if j is not None:
+                in_uni[i, j] = True
+    want = np.triu(in_uni.astype(np.int64) @ in_uni.astype(np.int64).T, 1)
+    assert (np.triu(got, 1) == want).all()
+    assert (got[np.tril_indices(n)] == -1).all()           # the diagonal and the lower triangle stay the caller's
+    cells = torch.zeros(n * n, dtype=torch.int64, device=dev)
+    scratch = torch.zeros((n, n), dtype=torch.int32, device=dev)
+    cnt = ctx.compare_cells_device(31, d_mn.data_ptr(), d_lo.data_ptr(), None, off, n, scratch.data_ptr(), cells.data_ptr(), cells.numel())
+    c = cells[:cnt].cpu().numpy()
+    back = np.zeros((n, n), np.int64)
+    back[(c >> 48) & 0xffff, (c >> 32) & 0xffff] = c & 0xffffffff
+    assert cnt == np.count_nonzero(want) and (back == want).all()
