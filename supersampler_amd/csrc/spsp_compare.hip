@@ -380,7 +380,9 @@ __global__ __launch_bounds__(kSparseThreads) void k_accumulate_sparse(const uint
     auto counter = [&](uint32_t idx) { return HALF ? (s_cnt[idx >> 1] >> ((idx & 1u) << 4)) & 0xffffu : s_cnt[idx]; };
     // kAccR list references are fetched together (the partition form reaches them through `where`: two dependent
     // loads, the second scattered -- eight of each in flight per thread hide the extra hop), then the lists kAccU at a time
-    for (uint64_t e = e0 + threadIdx.x; e < e1; e += (uint64_t)kAccR * kSparseThreads) {
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint64_t eb = e0; eb < e1; eb += (uint64_t)kAccR * kSparseThreads) {     // (every lane makes every round: the waves pool their long lists, below)
+        const uint64_t e = eb + threadIdx.x;
         uint32_t refs[kAccR];
         if (where) {                                         // the reference sits where the key's record went
             uint32_t at[kAccR];
@@ -397,39 +399,72 @@ __global__ __launch_bounds__(kSparseThreads) void k_accumulate_sparse(const uint
         uint32_t ref[kAccU];
 #pragma unroll
         for (int u = 0; u < kAccU; ++u) ref[u] = refs[g + u];
-        // the first kAccW 16-byte words of each list (length + 31 ids) are requested together; longer lists loop
+        // the first kAccW 16-byte words of each SHORT list (length + 31 ids) are requested together; of a longer list only the first
         uint4 w[kAccU][kAccW];
 #pragma unroll
         for (int u = 0; u < kAccU; ++u) {
             const uint4* L = reinterpret_cast<const uint4*>(ids) + (ref[u] & kRefOffMask);
-            const uint32_t len = ref[u] >> kRefOffBits;
+            const uint32_t lenf = ref[u] >> kRefOffBits;     // (63 = "63 or more")
 #pragma unroll
             for (int q = 0; q < kAccW; ++q)
-                w[u][q] = (ref[u] != kNoList && (q == 0 || len >= 8u * q)) ? L[q] : make_uint4(0, 0, 0, 0);   // (len 63 = "63 or more")
+                w[u][q] = (ref[u] != kNoList && (q == 0 || (lenf >= 8u * q && lenf < 8u * kAccW))) ? L[q] : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int u = 0; u < kAccU; ++u) {
-            if (ref[u] == kNoList) continue;
-            const uint4* L = reinterpret_cast<const uint4*>(ids) + (ref[u] & kRefOffMask);
-            uint32_t len = ref[u] >> kRefOffBits;
-            if (len == kRefLenMax) len = w[u][0].x & 0xffffu;
+            const bool has = ref[u] != kNoList;
+            uint32_t len = 0;
+            if (has) { len = ref[u] >> kRefOffBits; if (len == kRefLenMax) len = w[u][0].x & 0xffffu; }
             // list element t (element 0 is the length, ids are 1..len) = half-word t & 7 of word t >> 3
-            auto word = [&](const uint4& v, uint32_t first) {
+            auto word = [&](const uint4& v, uint32_t first, uint32_t ln) {
                 const uint32_t d[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (uint32_t h = 0; h < 8; ++h) {
                     const uint32_t t = first + h;
-                    if (t >= 1 && t <= len) count((d[h >> 1] >> (16 * (h & 1))) & 0xffffu);
+                    if (t >= 1 && t <= ln) count((d[h >> 1] >> (16 * (h & 1))) & 0xffffu);
                 }
             };
+            const bool is_long = has && len >= 8u * kAccW;
+            if (has) {
+                word(w[u][0], 0u, len);
+                if (!is_long) {
 #pragma unroll
-            for (int q = 0; q < kAccW; ++q) if (q == 0 || len >= 8u * q) word(w[u][q], 8u * q);
-            // (long lists -- keys of one large family: every holder reads the whole list, h^2 x 2 bytes per key, and that traffic
-            // through the L2s is what such a key costs: 3.5 TB/s at 1 300 holders per key.  Tried and not kept: the waves taking a
-            // long list together, a lane per holder -- one list and its load latency at a time, 1.9x slower; every lane starting
-            // its walk at another word of its list, against meeting on the same counters -- 1.5x slower, they do not meet.
-            // Keys of that many holders get columns instead, see k_spill_pairs.)
-            for (uint32_t q = kAccW; 8 * q <= len; ++q) word(L[q], 8 * q);
+                    for (int q = 1; q < kAccW; ++q) if (len >= 8u * q) word(w[u][q], 8u * q, len);
+                }
+            }
+            // LONG lists (keys of a large family) are read by the wave TOGETHER.  Lane by lane -- every lane walking its own list,
+            // 16 bytes at a time -- a wave's load touches 64 different lines for 1 KiB of use, the lines of 2 048 lanes do not fit the
+            // CU's vector cache, and every 16 bytes cost a 128-byte line from the L2 again: 19 GB of lists were 150 GB of L2 traffic at
+            // 317 holders per key.  The words 1.. of the wave's long lists form ONE sequence (a prefix sum over the lanes); lane l of
+            // round r takes word 64 r + l of it -- whole lines, every lane busy, two rounds in flight -- and finds the list it belongs
+            // to by a binary search over the lanes' prefix (shuffles).
+            if (__any(is_long)) {
+                const uint32_t nwp = is_long ? (len >> 3) : 0u;
+                uint32_t incl = nwp;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if (lane >= (uint32_t)d) incl += y; }
+                const uint32_t excl = incl - nwp, total = __shfl(incl, 63);
+                auto locate = [&](uint32_t gw, uint32_t& r_, uint32_t& ln_, uint32_t& wi_) {
+                    uint32_t lo = 0;
+#pragma unroll
+                    for (uint32_t step = 32; step; step >>= 1) {
+                        const uint32_t cand = lo + step;
+                        const uint32_t pc = __shfl(excl, cand & 63u);
+                        if (cand < 64u && pc <= gw) lo = cand;
+                    }
+                    r_ = __shfl(ref[u], lo); ln_ = __shfl(len, lo);
+                    wi_ = gw - __shfl(excl, lo) + 1u;
+                };
+                for (uint32_t g0 = 0; g0 < total; g0 += 128u) {
+                    uint32_t rA, lnA, wA, rB, lnB, wB;
+                    const uint32_t gA = g0 + lane, gB = g0 + 64u + lane;
+                    locate(gA < total ? gA : 0u, rA, lnA, wA);
+                    locate(gB < total ? gB : 0u, rB, lnB, wB);
+                    const uint4 vA = gA < total ? (reinterpret_cast<const uint4*>(ids) + (rA & kRefOffMask))[wA] : make_uint4(0, 0, 0, 0);
+                    const uint4 vB = gB < total ? (reinterpret_cast<const uint4*>(ids) + (rB & kRefOffMask))[wB] : make_uint4(0, 0, 0, 0);
+                    if (gA < total) word(vA, 8u * wA, lnA);
+                    if (gB < total) word(vB, 8u * wB, lnB);
+                }
+            }
         }
         }
     }
