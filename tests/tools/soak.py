@@ -257,7 +257,7 @@ def main():
             finally:
                 shutil.rmtree(tmp, ignore_errors=True)
         if n_scan % 30 == 7:     # a collection of one species: hundreds of sketches sharing most keys -> parts overflow, spill, bit columns
-            n = int(rng.integers(130, 460))
+            n = int(rng.integers(130, 760))                     # (from 512 rows on: rows dealt to the XCDs in runs, in min-hash order)
             use_hi = bool(rng.integers(0, 2))
             U = int(rng.integers(400, 3600))
             share = rng.choice([0.95, 0.6, 0.3, 0.08, 0.01], size=U)
