@@ -301,7 +301,9 @@ typedef struct spsp_sketch_stats {
 /* handle_superkmer + the emission half of parse_fasta_test
  * (SubSampler.cpp:243-302, 458-504, 512-620; strCompressor utils.cpp:48-68):
  * super-k-mer stream -> uncompressed sketch payload. `rate` is the -s value
- * after stof (SubSampler.cpp:699), printed into the header. */
+ * after stof (SubSampler.cpp:699), printed into the header.  Buckets (minimizers) are
+ * built one by one -- they never meet -- and, from 20 000 super-k-mers on, on up to
+ * 8 (16 from 400 000 on) host threads of the call's own: same bytes out. */
 int spsp_sketch_build_host(const spsp_params* p, double rate, const uint8_t* bases,
                            const uint64_t* rec_off, uint32_t n_rec, const spsp_superkmer* sk,
                            uint64_t n_sk, uint8_t** payload, uint64_t* payload_len,
