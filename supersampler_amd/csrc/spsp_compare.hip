@@ -339,7 +339,8 @@ __global__ __launch_bounds__(kSparseThreads) void k_accumulate_sparse(const uint
                                                                      uint32_t* __restrict__ host_flags,
                                                                      unsigned long long* __restrict__ cells, unsigned long long cells_cap,
                                                                      unsigned long long* __restrict__ cells_count, uint32_t xcd_rows, bool add,
-                                                                     const uint32_t* __restrict__ row_order, uint32_t long_limit) {
+                                                                     const uint32_t* __restrict__ row_order, uint32_t long_limit,
+                                                                     const uint32_t* __restrict__ multi, uint32_t multi_slots) {
     extern __shared__ uint32_t s_cnt[];
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < kFlags) host_flags[threadIdx.x] = flags[threadIdx.x];
     // a part overflowed: its workgroup of k_parts_group left without writing list references, so the ones in place are
@@ -381,6 +382,7 @@ __global__ __launch_bounds__(kSparseThreads) void k_accumulate_sparse(const uint
     // kAccR list references are fetched together (the partition form reaches them through `where`: two dependent
     // loads, the second scattered -- eight of each in flight per thread hide the extra hop), then the lists kAccU at a time
     const uint32_t lane = threadIdx.x & 63u;
+    const bool use_multi = multi && 5u * flags[12] < 2u * flags[13];     // (records with a list / records, in a sample of the parts: k_parts_group)
     for (uint64_t eb = e0; eb < e1; eb += (uint64_t)kAccR * kSparseThreads) {     // (every lane makes every round: the waves pool their long lists, below)
         const uint64_t e = eb + threadIdx.x;
         uint32_t refs[kAccR];
@@ -389,7 +391,12 @@ __global__ __launch_bounds__(kSparseThreads) void k_accumulate_sparse(const uint
 #pragma unroll
             for (int r = 0; r < kAccR; ++r) { const uint64_t eu = e + (uint64_t)r * kSparseThreads; at[r] = eu < e1 ? where[eu] : kNoWhere; }
 #pragma unroll
-            for (int r = 0; r < kAccR; ++r) refs[r] = at[r] != kNoWhere ? list_of_entry[at[r]] : kNoList;
+            for (int r = 0; r < kAccR; ++r) {
+                // (multi: a bit per record slot of the parts -- has the key a list? -- in front of the list reference's miss)
+                bool fetch = at[r] != kNoWhere;
+                if (fetch && use_multi && at[r] < multi_slots) fetch = (multi[at[r] >> 5] >> (at[r] & 31u)) & 1u;
+                refs[r] = fetch ? list_of_entry[at[r]] : kNoList;
+            }
         } else {
 #pragma unroll
             for (int r = 0; r < kAccR; ++r) { const uint64_t eu = e + (uint64_t)r * kSparseThreads; refs[r] = eu < e1 ? list_of_entry[eu] : kNoList; }
@@ -791,7 +798,8 @@ template <bool HAS_HI>
 __global__ __launch_bounds__(kGroupThreads) void k_parts_group(const uint64_t* __restrict__ recs, const uint32_t* __restrict__ part_cnt,
                                                               uint16_t* __restrict__ ids, uint32_t* __restrict__ list_of_slot,
                                                               uint32_t* __restrict__ flags, uint32_t t_bits, uint32_t max_cols,
-                                                              unsigned long long* __restrict__ bits, uint32_t n_sk) {
+                                                              unsigned long long* __restrict__ bits, uint32_t n_sk,
+                                                              unsigned long long* __restrict__ multi) {
     constexpr uint32_t W = HAS_HI ? 3 : 2;
     constexpr uint32_t R = kPartCap / kGroupThreads;      // records per thread
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_g[];
@@ -805,7 +813,7 @@ __global__ __launch_bounds__(kGroupThreads) void k_parts_group(const uint64_t* _
     if (t == 0) atomicAdd(&flags[7], n);                  // records in all parts: sizes the parts of a filtered call's next attempt
     if (n > (uint32_t)kPartCap) { if (t == 0) { atomicOr(&flags[6], 1u); atomicAdd(&flags[2], n); } return; }   // ([2]: records of all overflowed parts -- sizes the spill)
     for (uint32_t x = t; x < (uint32_t)kPartSlots; x += kGroupThreads) slot[x] = 0;
-    if (t == 0) *cursor = 0;
+    if (t == 0) { cursor[0] = 0; cursor[1] = 0; }
     const uint64_t* base = recs + (uint64_t)p * kPartCap * W;
     uint64_t lo[R], hi[R];
     uint32_t mn[R], sk[R], hs[R], rank[R];
@@ -850,7 +858,26 @@ __global__ __launch_bounds__(kGroupThreads) void k_parts_group(const uint64_t* _
         cnt[u] = w >> 13;
         claimer[u] = r < n && (w & 0x1fffu) == r + 1;
     }
-    __syncthreads();
+    // multi: one bit per record slot -- does the record's key have a list?  The row sums look here (8.7 MB at configs[3]: it
+    // stays in the L2s) before they fetch a list reference (70 MB, a line from HBM each): a key held by one sketch costs them
+    // no miss.  A wave's 64 consecutive slots are one 8-byte store.
+    // (flags[12] / flags[13] = records that have a list / records, of every 64th part: the row sums use the bits only when fewer than 2 in 5 do -- with more, the extra
+    // dependent read costs more than the misses it saves: 0.84 -> 0.99 ms at configs[3], 0.84 -> 0.32 for unrelated sketches)
+    if (multi) {                                          // (not made when the context's last comparison had no use for it: job_parts)
+        uint32_t listed = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < R; ++u) {
+            const uint32_t r = u * kGroupThreads + t;
+            const unsigned long long m = __ballot(r < n && cnt[u] >= 2 && cnt[u] < t_bits);
+            if ((t & 63u) == 0) { multi[((uint64_t)p * kPartCap + r) >> 6] = m; listed += (uint32_t)__popcll(m); }
+        }
+        if ((p & 63u) == 0) {                             // (a sample: one part in 64 -- an atomic per workgroup on one word was 0.15 ms)
+            if ((t & 63u) == 0 && listed) atomicAdd(cursor + 1, listed);      // (the word behind the list cursor: summed per workgroup)
+            __syncthreads();
+            if (t == 0) { atomicAdd(&flags[12], cursor[1]); atomicAdd(&flags[13], n); }
+        }
+    }
+    __syncthreads();                                      // (every count has been read: the slots are reused for the list places)
     const uint32_t ids_base = p * (4u * kPartCap);
 #pragma unroll
     for (uint32_t u = 0; u < R; ++u) {
@@ -1272,6 +1299,8 @@ struct ComparePlan {
     const uint32_t* where = nullptr;
     uint64_t max_row = 0;                // keys of the longest sketch (0 = unknown): bounds every pair count
     const uint32_t* row_order = nullptr; // rows in the order of their sketches' min-hash (k_row_order), or null
+    const uint32_t* multi = nullptr;     // partition form: one bit per record slot -- has the record's key a list? (k_parts_group)
+    uint32_t multi_slots = 0;
 };
 struct CompareJob {
     ComparePlan P;
@@ -1292,7 +1321,7 @@ struct CompareJob {
                                     // matrix are built class by class, so the matrix never exceeds its budget
     // partition form (flat entry point): see k_parts_scatter
     std::function<int(uint32_t n_parts, bool small, bool filtered, uint32_t fmask, uint32_t classes, uint32_t cls)> scatter_parts;
-    std::function<int(uint32_t n_parts, const SpillPlan&)> group_parts;
+    std::function<int(uint32_t n_parts, const SpillPlan&, bool want_multi)> group_parts;
     std::function<int(uint32_t n_parts)> group_small;     // small problems: grouping + counting in one kernel (k_parts_group_small)
     bool parts = false, small = false;
     uint32_t n_parts = 0, parts_attempt = 0, n_sub = 0;
@@ -1306,6 +1335,7 @@ struct CompareJob {
     // time, the first class's row sums store the cells, the later ones add
     bool has_hi = false;            // k > 32: records carry a second key word
     bool ordered = false;           // this attempt makes a row order (k_row_order)
+    bool want_multi = false;        // this attempt makes the has-a-list bits (k_parts_group) and reads back what share of the records have one
     uint32_t classes = 1, cls = 0;
     uint64_t S_behind = 0;          // keys of the first owned row and later sketches: what the scatter deals
     // spill (partition form, unfiltered): the records of parts that overflow are grouped in a table in HBM (k_spill_insert)
@@ -1370,7 +1400,7 @@ static int launch_accumulate_sparse(spsp_ctx* ctx, const ComparePlan& P, uint32_
                        P.n, P.row_first, P.row_stride, P.row_limit, cols, copies_log2, split, P.d_inter, flags,
                        reinterpret_cast<uint32_t*>(ctx->h_scalar + 8),
                        direct ? ctx->cells_req.cells : (unsigned long long*)nullptr,
-                       (unsigned long long)ctx->cells_req.cap, ctx->cells_req.count, xcd_rows, add, by_xcd ? P.row_order : (const uint32_t*)nullptr, long_limit);
+                       (unsigned long long)ctx->cells_req.cap, ctx->cells_req.count, xcd_rows, add, by_xcd ? P.row_order : (const uint32_t*)nullptr, long_limit, P.multi, P.multi_slots);
     SPSP_HIP(hipGetLastError());
     for (uint32_t i : long_rows) {
         const uint64_t keys = ctx->h_skoff[i + 1] - ctx->h_skoff[i];
@@ -1382,7 +1412,7 @@ static int launch_accumulate_sparse(spsp_ctx* ctx, const ComparePlan& P, uint32_
         hipLaunchKernelGGL(k_accumulate_sparse<false>, dim3(col_blocks, 1, slices), dim3(kSparseThreads), ((size_t)cols << copies_log2) * 4, ctx->stream,
                            P.list_ref ? P.list_ref : ctx->c_row.as<uint32_t>(), P.where, ctx->c_matrix.as<uint16_t>(), P.sk_begin, P.sk_end,
                            P.n, i, 1u, i + 1, cols, copies_log2, slices, P.d_inter, flags, reinterpret_cast<uint32_t*>(ctx->h_scalar + 8),
-                           (unsigned long long*)nullptr, 0ull, (unsigned long long*)nullptr, 0u, add, (const uint32_t*)nullptr, 0u);
+                           (unsigned long long*)nullptr, 0ull, (unsigned long long*)nullptr, 0u, add, (const uint32_t*)nullptr, 0u, P.multi, P.multi_slots);
         SPSP_HIP(hipGetLastError());
     }
     ctx->cells_req.direct = direct;
@@ -1443,17 +1473,21 @@ static int job_parts(spsp_ctx* ctx, CompareJob& J) {
     }
     if ((rc = ctx->ev_end(kEvScatter))) return rc;
     if ((rc = ctx->ev_begin(kEvGroup))) return rc;
-    if (!(skip & 2) && (rc = J.small ? J.group_small(J.n_parts) : J.group_parts(J.n_parts, J.spill))) return rc;
+    // the has-a-list bits pay when most keys are held by one sketch only (unrelated genomes: row sums 0.84 -> 0.32 ms); a context
+    // whose last comparison had lists for two records in five or more leaves them out for its next fifteen (they cost the grouping
+    // kernel 0.03 ms and, used, the row sums 0.15 ms at configs[3])
+    J.want_multi = !J.small;
+    if (J.want_multi && ctx->multi_quiet > 0) { --ctx->multi_quiet; J.want_multi = false; }
+    if (!(skip & 2) && (rc = J.small ? J.group_small(J.n_parts) : J.group_parts(J.n_parts, J.spill, J.want_multi))) return rc;
     if (J.spill.room && !J.small && (rc = J.spill_parts(J.n_parts, J.spill, 1, J.classes, J.cls))) return rc;
     if ((rc = ctx->ev_end(kEvGroup))) return rc;
     if (J.small) return job_queue_flags(ctx);             // (no later kernel forwards the flags)
     if ((rc = ctx->ev_begin(kEvAccumulate))) return rc;
     ComparePlan PP = J.P;
     PP.list_ref = ctx->c_lref.as<uint32_t>(); PP.where = ctx->c_where.as<uint32_t>();
-    if (ordered) {
-        PP.row_order = ctx->c_order.as<uint32_t>();
-        SPSP_HIP(hipMemcpyAsync(ctx->h_scalar + 14, flags + 10, 8, hipMemcpyDeviceToHost, ctx->stream));   // the verdict, for compare_job_end
-    }
+    if (J.want_multi) { PP.multi = ctx->c_multi.as<uint32_t>(); PP.multi_slots = J.n_parts * (uint32_t)kPartCap; }
+    if (ordered) PP.row_order = ctx->c_order.as<uint32_t>();
+    if (ordered || J.want_multi) SPSP_HIP(hipMemcpyAsync(ctx->h_scalar + 14, flags + 10, 16, hipMemcpyDeviceToHost, ctx->stream));   // the verdicts, for compare_job_end
     // (an attempt whose parts overflow leaves this kernel at its first line, before any cell is emitted: the retry emits them once)
     // (with a spill the keys that have columns add into the dense matrix behind the row sums: no cells straight from them)
     //  -- nor with key classes: a pair's count comes in several parts)
@@ -1725,6 +1759,10 @@ int compare_job_end(spsp_ctx* ctx) {
                 const uint32_t near_new = (uint32_t)ctx->h_scalar[14], near_in = (uint32_t)(ctx->h_scalar[14] >> 32);
                 ctx->order_quiet = 2 * near_in >= near_new ? 15 : 0;
             }
+            if (J->want_multi) {
+                const uint64_t listed = (uint32_t)ctx->h_scalar[15], sampled = (uint32_t)(ctx->h_scalar[15] >> 32);
+                ctx->multi_quiet = (sampled && 5 * listed >= 2 * sampled) ? 15 : 0;
+            }
             static const bool trace = getenv("SPSP_DEBUG_SPILL_TRACE") != nullptr;     // test hook: which way the comparison went
             if (trace && J->spill.room) fprintf(stderr, "spsp spill: %u records of overflowed parts grouped in HBM (room %llu, %u parts, columns from %u holders)\n",
                                                 h_flags[2], (unsigned long long)J->spill.room, J->n_parts, J->spill.t_bits);
@@ -1954,25 +1992,27 @@ static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t*
         SPSP_HIP(hipGetLastError());
         return SPSP_OK;
     };
-    J->group_parts = [=](uint32_t n_parts, const SpillPlan& sp) -> int {
+    J->group_parts = [=](uint32_t n_parts, const SpillPlan& sp, bool want_multi) -> int {
         const size_t lds = (size_t)kPartCap * (8 + (has_hi ? 8 : 0) + 4) + (size_t)kPartSlots * 4 + 16;
         // (a spill attempt: keys of many holders get columns here too -- a part they do not overflow would otherwise list them)
         const uint32_t t_bits = sp.room ? sp.t_bits : 0xffffffffu, max_cols = sp.room ? sp.max_cols : 0u;
         unsigned long long* bits = (sp.room && sp.max_cols) ? ctx->c_bits.as<unsigned long long>() : (unsigned long long*)nullptr;
+        if (want_multi) { const int rm = ctx->c_multi.reserve((size_t)n_parts * kPartCap / 8 + 64); if (rm) return rm; }
+        unsigned long long* multi = want_multi ? ctx->c_multi.as<unsigned long long>() : (unsigned long long*)nullptr;
         if (has_hi) {
             if (!ctx->attr_group_hi_set) {
                 SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_parts_group<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 ctx->attr_group_hi_set = true;
             }
             hipLaunchKernelGGL(k_parts_group<true>, dim3(n_parts), dim3(kGroupThreads), lds, ctx->stream, ctx->c_recs.as<uint64_t>(),
-                               ctx->c_part_cnt.as<uint32_t>(), ctx->c_matrix.as<uint16_t>(), ctx->c_lref.as<uint32_t>(), flags, t_bits, max_cols, bits, n);
+                               ctx->c_part_cnt.as<uint32_t>(), ctx->c_matrix.as<uint16_t>(), ctx->c_lref.as<uint32_t>(), flags, t_bits, max_cols, bits, n, multi);
         } else {
             if (!ctx->attr_group_set) {
                 SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_parts_group<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 ctx->attr_group_set = true;
             }
             hipLaunchKernelGGL(k_parts_group<false>, dim3(n_parts), dim3(kGroupThreads), lds, ctx->stream, ctx->c_recs.as<uint64_t>(),
-                               ctx->c_part_cnt.as<uint32_t>(), ctx->c_matrix.as<uint16_t>(), ctx->c_lref.as<uint32_t>(), flags, t_bits, max_cols, bits, n);
+                               ctx->c_part_cnt.as<uint32_t>(), ctx->c_matrix.as<uint16_t>(), ctx->c_lref.as<uint32_t>(), flags, t_bits, max_cols, bits, n, multi);
         }
         SPSP_HIP(hipGetLastError());
         return SPSP_OK;

@@ -107,6 +107,7 @@ struct spsp_ctx {
     hipEvent_t tail_event = nullptr;   // spsp_wait_stream: marks the current end of this context's stream
     hipEvent_t scan_done = nullptr;    // behind the last kernel of the queued scan: what spsp_scan_device_end waits on
     hipEvent_t compare_done = nullptr; // likewise for the queued comparison
+    uint32_t multi_quiet = 0;          // comparisons that leave out the has-a-list bits (the last one had lists for most records)
     uint32_t order_quiet = 0;          // comparisons that skip the making of a row order (the last one came in a good order of its own)
     bool attr_pair_set = false, attr_single_set = false, attr_bloom_set = false, attr_small_set = false, attr_group_set = false, attr_group_hi_set = false, attr_scatter_set = false, attr_sort_set = false, attr_order_set = false;   // dynamic-LDS attributes set on this context's device
     spsp::ScanJob scan_job;
@@ -159,7 +160,7 @@ struct spsp_ctx {
     // ingest workspace (GPU-side getLineFasta + clean_dna)
     spsp::DevBuf i_text, i_tiles, i_entry, i_outoff, i_recbase, i_lens, i_dst, i_compact;
     // compare workspace
-    spsp::DevBuf c_min, c_lo, c_hi, c_table, c_owner, c_rowid, c_row, c_matrix, c_inter, c_flags, c_skoff, c_slot_lo, c_slot_hi, c_slot_mn, c_part_cnt, c_recs, c_where, c_lref, c_filter, c_bits, c_sig, c_order;
+    spsp::DevBuf c_min, c_lo, c_hi, c_table, c_owner, c_rowid, c_row, c_matrix, c_inter, c_flags, c_skoff, c_slot_lo, c_slot_hi, c_slot_mn, c_part_cnt, c_recs, c_where, c_lref, c_filter, c_bits, c_sig, c_order, c_multi;
     uint64_t spill_expect = 0;     // records the last unfiltered partition-form comparison had in overflowed parts (0: none) -- see spill_plan
     uint32_t filter_skipped = 0;
     double filter_ratio = 1.0;   // records dealt into parts per owned key in the last filtered comparison (sizes the next one's parts)
