@@ -316,8 +316,12 @@ __global__ void k_fill_sparse(Keys K, const uint64_t* __restrict__ sk_off, uint3
 }
 
 constexpr int kSparseCols = 16384;
-constexpr int kFlags = 8;   // [0] unsorted input, [1] fingerprint collision, [2] n_rows, [3] malformed slot, [4] slot overflow,
-                            // [5] table full, [6] a key part overflowed its capacity (partition form), [7] records dealt into parts
+constexpr int kFlags = 8;   // [0] unsorted input, [1] fingerprint collision, [2] n_rows (dictionary forms) / records of overflowed parts (partition
+                            // form: sizes the spill), [3] malformed slot, [4] slot overflow, [5] table full, [6] a key part overflowed its
+                            // capacity (partition form), [7] records dealt into parts -- these eight travel to the host with every job.
+                            // Device-side words behind them (16 in all, cleared by k_parts_prepare): [8] u16 of spilled lists handed out,
+                            // [9] bit columns handed out, [10] / [11] k_row_order's verdict, [12] / [13] records with a list / records in a
+                            // sample of the parts (k_parts_group), [14..15] the cell count of a comparison returned as cells
 // grid.y = owned row (sketch row_first + y * row_stride), grid.x = block of `cols` columns, grid.z = slice of the
 // row's keys (split > 1: the slices add into cells zeroed by k_zero_rows).  Counters live in dynamic LDS,
 // `copies` of each, interleaved (counter c of copy k at c * copies + k): the lists of one row's keys name the
