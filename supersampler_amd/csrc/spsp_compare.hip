@@ -482,38 +482,54 @@ __global__ __launch_bounds__(kSparseThreads) void k_accumulate_sparse(const uint
     __syncthreads();
     if (cells) {
         // sparse result (the key-partitioned split: a rank's partial row is nearly all zeros): the row's non-zero cells
-        // leave as packed words i << 48 | j << 32 | count -- the dense row is not written.  ONE atomic per workgroup that
-        // has any (all of them hit the same counter: one per wave and column step cost 11 ns each, 75 ms at 65 535 sketches
-        // of unrelated genomes against 5 ms for the dense form): the waves count first, the counters stay in registers.
+        // leave as packed words i << 48 | j << 32 | count -- the dense row is not written.  One atomic per WAVE that has any
+        // (not per wave and column step: all of them hit the same counter, 11 ns each when millions queue up -- 75 ms at
+        // 65 535 sketches of unrelated genomes against 5 ms for the dense form), and with several column blocks per row ONE
+        // per workgroup: the waves count first, the counters stay in registers.
         constexpr int kSteps = kSparseCols / kSparseThreads;
         __shared__ uint32_t s_wave[kSparseThreads / 64];
         __shared__ unsigned long long s_base;
         const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-        uint32_t vv[kSteps], wave_total = 0;
-#pragma unroll
-        for (int s = 0; s < kSteps; ++s) {
-            const uint32_t x = threadIdx.x + (uint32_t)s * kSparseThreads, col = col0 + x;
+        auto value = [&](int st) -> uint32_t {
+            const uint32_t x = threadIdx.x + (uint32_t)st * kSparseThreads, col = col0 + x;
             uint32_t v = 0;
             if (x < cols && col > i && col < n)
                 for (uint32_t k = 0; k < copies; ++k) v += counter((x << copies_log2) + k);
-            vv[s] = v;
-            wave_total += (uint32_t)__popcll(__ballot(v != 0));
-        }
-        if (lane == 0) s_wave[wave] = wave_total;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t total = 0;
-            for (uint32_t w = 0; w < kSparseThreads / 64; ++w) { const uint32_t c = s_wave[w]; s_wave[w] = total; total += c; }
-            s_base = total ? atomicAdd(cells_count, (unsigned long long)total) : 0ull;
-        }
-        __syncthreads();
-        unsigned long long at = s_base + s_wave[wave];
+            return v;
+        };
+        // the wave counts first (which of its column steps have any cell: most have none), then writes those steps only
+        uint32_t wave_total = 0, steps = 0;
 #pragma unroll
-        for (int s = 0; s < kSteps; ++s) {
-            const unsigned long long hit = __ballot(vv[s] != 0);
+        for (int st = 0; st < kSteps; ++st) {
+            const unsigned long long hit = __ballot(value(st) != 0);
+            if (hit) { wave_total += (uint32_t)__popcll(hit); steps |= 1u << st; }
+        }
+        unsigned long long at;
+        if (gridDim.x == 1) {
+            // one column block per row (up to 16 Ki sketches): at most 16 waves x rows atomics and no barrier -- the two barriers of
+            // the workgroup form were 0.03 ms of the 0.18 ms a key-partitioned rank's 10 000 short rows take
+            unsigned long long base = 0;
+            if (lane == 0 && wave_total) base = atomicAdd(cells_count, (unsigned long long)wave_total);
+            at = __shfl(base, 0);
+        } else {
+            if (lane == 0) s_wave[wave] = wave_total;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint32_t total = 0;
+                for (uint32_t w = 0; w < kSparseThreads / 64; ++w) { const uint32_t c = s_wave[w]; s_wave[w] = total; total += c; }
+                s_base = total ? atomicAdd(cells_count, (unsigned long long)total) : 0ull;
+            }
+            __syncthreads();
+            at = s_base + s_wave[wave];
+        }
+        while (steps) {                                  // (wave-uniform: the mask came from ballots)
+            const int st = __ffs((int)steps) - 1;
+            steps &= steps - 1;
+            const uint32_t v = value(st);
+            const unsigned long long hit = __ballot(v != 0);
             const unsigned long long mine_at = at + (unsigned long long)__popcll(hit & ((1ull << lane) - 1ull));
-            if (vv[s] && mine_at < cells_cap)
-                cells[mine_at] = ((unsigned long long)i << 48) | ((unsigned long long)(col0 + threadIdx.x + (uint32_t)s * kSparseThreads) << 32) | vv[s];
+            if (v && mine_at < cells_cap)
+                cells[mine_at] = ((unsigned long long)i << 48) | ((unsigned long long)(col0 + threadIdx.x + (uint32_t)st * kSparseThreads) << 32) | v;
             at += (unsigned long long)__popcll(hit);
         }
         return;
