@@ -1469,9 +1469,9 @@ static int job_parts(spsp_ctx* ctx, CompareJob& J) {
     // (k_row_order).  SPSP_DEBUG_ROW_ORDER=0: launch order, 2: an order for every comparison
     static const char* dbg_order = getenv("SPSP_DEBUG_ROW_ORDER");
     const bool all_rows = J.P.row_first == 0 && J.P.row_stride == 1 && J.P.row_limit >= J.P.n && J.P.n_own == J.P.n;
-    bool ordered = !J.small && all_rows && J.P.n >= 512 && J.P.n <= (uint32_t)kSparseCols && !(dbg_order && dbg_order[0] == '0');
+    bool ordered = !J.small && all_rows && J.P.n >= (dbg_order && dbg_order[0] == '2' ? 512u : 2048u) && J.P.n <= (uint32_t)kSparseCols && !(dbg_order && dbg_order[0] == '0');
     // (a context whose last comparison came in a good order of its own -- k_row_order's verdict, read back with the job -- skips
-    // the making of the order for the next fifteen: collections are compared batch after batch of the same kind)
+    // the making of the order for the next 63: collections are compared batch after batch of the same kind)
     if (ordered && ctx->order_quiet > 0 && !(dbg_order && dbg_order[0] == '2')) { --ctx->order_quiet; ordered = false; }
     J.ordered = ordered;
     if (ordered && ((rc = ctx->c_sig.reserve((size_t)J.P.n * 8)) || (rc = ctx->c_order.reserve((size_t)J.P.n * 4)))) return rc;
@@ -1494,7 +1494,7 @@ static int job_parts(spsp_ctx* ctx, CompareJob& J) {
     if ((rc = ctx->ev_end(kEvScatter))) return rc;
     if ((rc = ctx->ev_begin(kEvGroup))) return rc;
     // the has-a-list bits pay when most keys are held by one sketch only (unrelated genomes: row sums 0.84 -> 0.32 ms); a context
-    // whose last comparison had lists for two records in five or more leaves them out for its next fifteen (they cost the grouping
+    // whose last comparison had lists for two records in five or more leaves them out for its next 63 (they cost the grouping
     // kernel 0.03 ms and, used, the row sums 0.15 ms at configs[3])
     J.want_multi = !J.small;
     if (J.want_multi && ctx->multi_quiet > 0) { --ctx->multi_quiet; J.want_multi = false; }
@@ -1777,11 +1777,11 @@ int compare_job_end(spsp_ctx* ctx) {
             if (!J->filtered && !J->small) ctx->spill_expect = h_flags[2];
             if (J->ordered) {
                 const uint32_t near_new = (uint32_t)ctx->h_scalar[14], near_in = (uint32_t)(ctx->h_scalar[14] >> 32);
-                ctx->order_quiet = 2 * near_in >= near_new ? 15 : 0;
+                ctx->order_quiet = 2 * near_in >= near_new ? 63 : 0;
             }
             if (J->want_multi) {
                 const uint64_t listed = (uint32_t)ctx->h_scalar[15], sampled = (uint32_t)(ctx->h_scalar[15] >> 32);
-                ctx->multi_quiet = (sampled && 5 * listed >= 2 * sampled) ? 15 : 0;
+                ctx->multi_quiet = (sampled && 5 * listed >= 2 * sampled) ? 63 : 0;
             }
             static const bool trace = getenv("SPSP_DEBUG_SPILL_TRACE") != nullptr;     // test hook: which way the comparison went
             if (trace && J->spill.room) fprintf(stderr, "spsp spill: %u records of overflowed parts grouped in HBM (room %llu, %u parts, columns from %u holders)\n",

@@ -918,7 +918,7 @@ def test_rows_ordered_by_min_hash_give_the_same_matrix(ctx):
     collection run in the order of the sketches' min-hash signatures (k_row_signature / k_row_order: a family's rows side by
     side behind one L2) -- scheduling only, so every cell must equal the cell of the same two sketches in the first matrix.
     Several calls per context (a context that saw a well-ordered input skips the ordering for a while)."""
-    n, F = 1500, 20
+    n, F = 2600, 20
     dev = torch.device("cuda", 0)
     D = synth.direct_family_sketches(n, fam_size=F, seed=11, device=dev, skm_range=(40, 90))
     rng = np.random.default_rng(3)
