@@ -947,12 +947,21 @@ __global__ __launch_bounds__(kGroupThreads) void k_parts_group(const uint64_t* _
 constexpr int kSpillThreads = 256;
 __device__ __forceinline__ uint32_t spill_home(uint64_t h, uint32_t log2cap) { return (uint32_t)(mix64(h ^ 0x8EBC6AF09C88C6E3ULL) >> (64 - log2cap)); }
 
+// sketch of entry e: from the sketch of its 4096-entry sub-chunk (the table the scatter uses), a few steps on (a binary search
+// over the offsets -- 14 dependent reads per entry -- was most of these kernels' time)
+__device__ __forceinline__ uint32_t spill_sketch(const uint64_t* __restrict__ sk_off, uint32_t n, const uint32_t* __restrict__ sub_sk, uint64_t e) {
+    uint32_t j = sub_sk[e / kScatSub];
+    while (j + 1 < n && sk_off[j + 1] <= e) ++j;
+    return j;
+}
+
 template <bool HAS_HI>
 __global__ __launch_bounds__(kSpillThreads) void k_spill_insert(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n, uint64_t S, uint64_t e_first,
                                                                uint32_t row_first, uint32_t n_parts, const uint32_t* __restrict__ part_cnt,
                                                                uint32_t* __restrict__ tbl, uint32_t log2cap, uint32_t* __restrict__ cnt,
                                                                uint32_t* __restrict__ where, uint32_t* __restrict__ rank_of, uint32_t room,
-                                                               uint32_t* __restrict__ flags, uint32_t classes, uint32_t cls) {
+                                                               uint32_t* __restrict__ flags, uint32_t classes, uint32_t cls,
+                                                               const uint32_t* __restrict__ sub_sk) {
     if (flags[2] > room) return;                          // more records than this attempt has room for: the host repeats it with the count
     const uint64_t e = e_first + (uint64_t)blockIdx.x * kSpillThreads + threadIdx.x;
     if (e >= S) return;
@@ -961,7 +970,7 @@ __global__ __launch_bounds__(kSpillThreads) void k_spill_insert(Keys K, const ui
     const uint64_t h = key_hash(lo, mn, hi, HAS_HI);
     if (classes > 1 && key_class(h, classes) != cls) return;
     if (part_cnt[(uint32_t)(((h >> 32) * n_parts) >> 32)] <= (uint32_t)kPartCap) return;
-    if (sketch_of(sk_off, n, e) < row_first) return;      // (the scatter deals nothing of the sketches in front of the first owned row)
+    if (row_first && spill_sketch(sk_off, n, sub_sk, e) < row_first) return;   // (the scatter deals nothing of the sketches in front of the first owned row)
     const uint32_t mask = (1u << log2cap) - 1u;
     uint32_t pos = spill_home(h, log2cap);
     for (uint32_t probes = 0;; ++probes) {
@@ -1033,14 +1042,14 @@ __global__ __launch_bounds__(kSpillThreads) void k_spill_fill(Keys K, const uint
                                                              uint16_t* __restrict__ ids, uint32_t ids_base, uint32_t lref_base,
                                                              unsigned long long* __restrict__ bits, uint32_t* __restrict__ where,
                                                              const uint32_t* __restrict__ rank_of, uint32_t room, const uint32_t* __restrict__ flags,
-                                                             uint32_t classes, uint32_t cls) {
+                                                             uint32_t classes, uint32_t cls, const uint32_t* __restrict__ sub_sk) {
     if (flags[2] > room || flags[5]) return;
     const uint64_t e = e_first + (uint64_t)blockIdx.x * kSpillThreads + threadIdx.x;
     if (e >= S) return;
     const uint64_t h = key_hash(K.lo[e], K.mn[e], HAS_HI ? K.hi[e] : 0ull, HAS_HI);
     if (classes > 1 && key_class(h, classes) != cls) return;
     if (part_cnt[(uint32_t)(((h >> 32) * n_parts) >> 32)] <= (uint32_t)kPartCap) return;
-    const uint32_t j = sketch_of(sk_off, n, e);
+    const uint32_t j = spill_sketch(sk_off, n, sub_sk, e);
     if (j < row_first) return;
     const uint32_t pos = where[e];
     if (pos == kNoWhere) return;
@@ -2056,17 +2065,17 @@ static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t*
         uint32_t *where = ctx->c_where.as<uint32_t>(), *rank_of = ctx->c_row.as<uint32_t>();
         const uint32_t* part_cnt = ctx->c_part_cnt.as<uint32_t>();
         const uint32_t room = (uint32_t)sp.room;
-        if (has_hi) hipLaunchKernelGGL(k_spill_insert<true>, grid, dim3(kSpillThreads), 0, ctx->stream, K, sk, n, S, e_own, row_first, n_parts, part_cnt, tbl, sp.log2cap, cnt, where, rank_of, room, flags, classes, cls);
-        else hipLaunchKernelGGL(k_spill_insert<false>, grid, dim3(kSpillThreads), 0, ctx->stream, K, sk, n, S, e_own, row_first, n_parts, part_cnt, tbl, sp.log2cap, cnt, where, rank_of, room, flags, classes, cls);
+        if (has_hi) hipLaunchKernelGGL(k_spill_insert<true>, grid, dim3(kSpillThreads), 0, ctx->stream, K, sk, n, S, e_own, row_first, n_parts, part_cnt, tbl, sp.log2cap, cnt, where, rank_of, room, flags, classes, cls, sub_sk);
+        else hipLaunchKernelGGL(k_spill_insert<false>, grid, dim3(kSpillThreads), 0, ctx->stream, K, sk, n, S, e_own, row_first, n_parts, part_cnt, tbl, sp.log2cap, cnt, where, rank_of, room, flags, classes, cls, sub_sk);
         SPSP_HIP(hipGetLastError());
         hipLaunchKernelGGL(k_spill_ranges, dim3((uint32_t)((slots + (uint64_t)kRowThreads * kRowSlots - 1) / ((uint64_t)kRowThreads * kRowSlots))), dim3(kRowThreads), 0, ctx->stream,
                            (const uint32_t*)cnt, slots, off, ctx->c_matrix.as<uint16_t>(), sp.ids_base, sp.ids_room, ctx->c_lref.as<uint32_t>() + sp.lref_base, sp.t_bits, sp.max_cols, room, flags);
         SPSP_HIP(hipGetLastError());
         unsigned long long* bits = sp.max_cols ? ctx->c_bits.as<unsigned long long>() : (unsigned long long*)nullptr;
         if (has_hi) hipLaunchKernelGGL(k_spill_fill<true>, grid, dim3(kSpillThreads), 0, ctx->stream, K, sk, n, S, e_own, row_first, n_parts, part_cnt, (const uint32_t*)cnt, (const uint32_t*)off,
-                                       ctx->c_matrix.as<uint16_t>(), sp.ids_base, sp.lref_base, bits, where, (const uint32_t*)rank_of, room, (const uint32_t*)flags, classes, cls);
+                                       ctx->c_matrix.as<uint16_t>(), sp.ids_base, sp.lref_base, bits, where, (const uint32_t*)rank_of, room, (const uint32_t*)flags, classes, cls, sub_sk);
         else hipLaunchKernelGGL(k_spill_fill<false>, grid, dim3(kSpillThreads), 0, ctx->stream, K, sk, n, S, e_own, row_first, n_parts, part_cnt, (const uint32_t*)cnt, (const uint32_t*)off,
-                                ctx->c_matrix.as<uint16_t>(), sp.ids_base, sp.lref_base, bits, where, (const uint32_t*)rank_of, room, (const uint32_t*)flags, classes, cls);
+                                ctx->c_matrix.as<uint16_t>(), sp.ids_base, sp.lref_base, bits, where, (const uint32_t*)rank_of, room, (const uint32_t*)flags, classes, cls, sub_sk);
         SPSP_HIP(hipGetLastError());
         return SPSP_OK;
     };
