@@ -982,7 +982,8 @@ __global__ __launch_bounds__(kSpillThreads) void k_spill_insert(Keys K, const ui
         if (probes > mask) { atomicOr(&flags[5], 1u); where[e] = kNoWhere; return; }
         pos = (pos + 1u) & mask;
     }
-    rank_of[e] = atomicAdd(&cnt[pos], 1u);
+    atomicAdd(&cnt[pos], 1u);                             // (result unused: the keys that nearly every sketch holds put thousands of these on one word, and
+                                                          // a returning atomic waits for its turn; a list key draws its place in k_spill_fill instead)
     where[e] = pos;                                       // (until k_spill_fill has run)
 }
 
@@ -1025,8 +1026,8 @@ __global__ __launch_bounds__(kRowThreads) void k_spill_ranges(const uint32_t* __
     if ((all && s_base + all > ids_room) || (all_c && s_cols + all_c > max_cols)) { if (t == 0) atomicOr(&flags[5], 1u); return; }   // (cannot happen: sized from the count)
 #pragma unroll
     for (int u = 0; u < kRowSlots; ++u) {
-        if (c[u] < 2) continue;
         const uint64_t sl = base_slot + u;
+        if (c[u] < 2) { if (c[u] == 1) off[sl] = kNoWhere; continue; }          // (held by one sketch: k_spill_fill reads this, the counts count down under it)
         if (c[u] >= t_bits) { off[sl] = kColFlag | col; ++col; continue; }
         off[sl] = at;
         ids[ids_base + at] = (uint16_t)c[u];
@@ -1038,7 +1039,7 @@ __global__ __launch_bounds__(kRowThreads) void k_spill_ranges(const uint32_t* __
 template <bool HAS_HI>
 __global__ __launch_bounds__(kSpillThreads) void k_spill_fill(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n, uint64_t S, uint64_t e_first,
                                                              uint32_t row_first, uint32_t n_parts, const uint32_t* __restrict__ part_cnt,
-                                                             const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
+                                                             uint32_t* __restrict__ cnt, const uint32_t* __restrict__ off,
                                                              uint16_t* __restrict__ ids, uint32_t ids_base, uint32_t lref_base,
                                                              unsigned long long* __restrict__ bits, uint32_t* __restrict__ where,
                                                              const uint32_t* __restrict__ rank_of, uint32_t room, const uint32_t* __restrict__ flags,
@@ -1053,16 +1054,15 @@ __global__ __launch_bounds__(kSpillThreads) void k_spill_fill(Keys K, const uint
     if (j < row_first) return;
     const uint32_t pos = where[e];
     if (pos == kNoWhere) return;
-    const uint32_t c = cnt[pos];
-    if (c < 2) { where[e] = kNoWhere; return; }           // held by this sketch only
     const uint32_t o = off[pos];
+    if (o == kNoWhere) { where[e] = kNoWhere; return; }   // held by this sketch only
     if (o & kColFlag) {                                   // one bit per holder: word (column / 64) of sketch j
         const uint32_t col = o & ~kColFlag;
         atomicOr(&bits[(uint64_t)(col >> 6) * n + j], 1ull << (col & 63u));
         where[e] = kNoWhere;                              // (no list: the row sums pass it by)
         return;
     }
-    ids[ids_base + o + 1u + rank_of[e]] = (uint16_t)j;
+    ids[ids_base + o + atomicSub(&cnt[pos], 1u)] = (uint16_t)j;     // the count runs down c .. 1: the places behind the length word
     where[e] = lref_base + pos;
 }
 
@@ -2072,9 +2072,9 @@ static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t*
                            (const uint32_t*)cnt, slots, off, ctx->c_matrix.as<uint16_t>(), sp.ids_base, sp.ids_room, ctx->c_lref.as<uint32_t>() + sp.lref_base, sp.t_bits, sp.max_cols, room, flags);
         SPSP_HIP(hipGetLastError());
         unsigned long long* bits = sp.max_cols ? ctx->c_bits.as<unsigned long long>() : (unsigned long long*)nullptr;
-        if (has_hi) hipLaunchKernelGGL(k_spill_fill<true>, grid, dim3(kSpillThreads), 0, ctx->stream, K, sk, n, S, e_own, row_first, n_parts, part_cnt, (const uint32_t*)cnt, (const uint32_t*)off,
+        if (has_hi) hipLaunchKernelGGL(k_spill_fill<true>, grid, dim3(kSpillThreads), 0, ctx->stream, K, sk, n, S, e_own, row_first, n_parts, part_cnt, cnt, (const uint32_t*)off,
                                        ctx->c_matrix.as<uint16_t>(), sp.ids_base, sp.lref_base, bits, where, (const uint32_t*)rank_of, room, (const uint32_t*)flags, classes, cls, sub_sk);
-        else hipLaunchKernelGGL(k_spill_fill<false>, grid, dim3(kSpillThreads), 0, ctx->stream, K, sk, n, S, e_own, row_first, n_parts, part_cnt, (const uint32_t*)cnt, (const uint32_t*)off,
+        else hipLaunchKernelGGL(k_spill_fill<false>, grid, dim3(kSpillThreads), 0, ctx->stream, K, sk, n, S, e_own, row_first, n_parts, part_cnt, cnt, (const uint32_t*)off,
                                 ctx->c_matrix.as<uint16_t>(), sp.ids_base, sp.lref_base, bits, where, (const uint32_t*)rank_of, room, (const uint32_t*)flags, classes, cls, sub_sk);
         SPSP_HIP(hipGetLastError());
         return SPSP_OK;
