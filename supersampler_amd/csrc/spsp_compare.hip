@@ -1478,6 +1478,12 @@ static int job_parts(spsp_ctx* ctx, CompareJob& J) {
     // (k_row_order).  SPSP_DEBUG_ROW_ORDER=0: launch order, 2: an order for every comparison
     static const char* dbg_order = getenv("SPSP_DEBUG_ROW_ORDER");
     const bool all_rows = J.P.row_first == 0 && J.P.row_stride == 1 && J.P.row_limit >= J.P.n && J.P.n_own == J.P.n;
+    // (what a context learnt holds for the collection it learnt it on: another one -- other offsets -- is looked at afresh)
+    if (ctx->h_skoff) {
+        const uint64_t fp = (uint64_t)J.P.n * 0x9E3779B97F4A7C15ULL ^ J.P.S_entries * 0xC2B2AE3D27D4EB4FULL ^ ctx->h_skoff[1] * 0x165667B19E3779F9ULL ^
+                            ctx->h_skoff[J.P.n / 2] * 0x27D4EB2F165667C5ULL ^ ctx->h_skoff[J.P.n - J.P.n / 3] * 0x85EBCA77C2B2AE63ULL;
+        if (fp != ctx->learnt_on) { ctx->learnt_on = fp; ctx->order_quiet = 0; ctx->multi_quiet = 0; }
+    }
     bool ordered = !J.small && all_rows && J.P.n >= (dbg_order && dbg_order[0] == '2' ? 512u : 2048u) && J.P.n <= (uint32_t)kSparseCols && !(dbg_order && dbg_order[0] == '0');
     // (a context whose last comparison came in a good order of its own -- k_row_order's verdict, read back with the job -- skips
     // the making of the order for the next 63: collections are compared batch after batch of the same kind)
