@@ -874,6 +874,32 @@ def test_pair_matrix_as_cells_straight_from_the_row_sums(ctx, tmp_path):
 
 
 @pytest.mark.gpu
+def test_compare_files_of_one_species_dense_matrix_as_cells(tmp_path):
+    """1 100 sketch files of one species: from 1 024 files on the drivers take the pair matrix as CELLS -- here every cell is
+    non-zero (6 x 10^5 of them: the first guess of the cell buffer is too small, the spill's result goes through the dense
+    matrix and is sparsified again into a larger one) and every CSV row is dense (row blocks sized for threads, not for rows of
+    "0,").  CSV bytes of one context and of two against the oracle's comparator + printers."""
+    import gzip
+    rng = np.random.default_rng(99)
+    anc = synth.random_genome(rng, 40_000)
+    paths, payloads = [], []
+    for i in range(1100):
+        pl = orc.sketch_fasta(synth.to_fasta(synth.mutate(rng, anc, [0.0, 0.001, 0.004][i % 3]), "g%d" % i), 31, 11, 40.0)[0]
+        pth = tmp_path / ("d_%04d.gz" % i)
+        sp.write_gz(str(pth), pl, 1)
+        paths.append(str(pth)); payloads.append(pl)
+    inter, card, _, _ = orc.compare(payloads)
+    assert int((np.triu(inter, 1) > 0).sum()) == 1100 * 1099 // 2
+    with sp.Context(0) as ctx:
+        ctx.compare_files(paths, str(tmp_path / "one"))
+    sp.compare_files_multi([0, 0], paths, str(tmp_path / "two"))
+    for jac, suf in ((True, "_jaccard.csv.gz"), (False, "_containment.csv.gz")):
+        want = orc.csv(jac, paths, inter, card, None, 6, 0.0)
+        assert gzip.open(str(tmp_path / "one") + suf, "rb").read() == want
+        assert gzip.open(str(tmp_path / "two") + suf, "rb").read() == want
+
+
+@pytest.mark.gpu
 def test_compare_files_of_one_species_over_contexts_equal_the_oracle(tmp_path):
     """320 sketch FILES of one species (one ancestor, 0-1 % substitutions): every part of the comparison overflows, so the
     file-level drivers go through the spill and the bit columns -- with one context (cells through the dense matrix) and
