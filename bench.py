@@ -42,6 +42,40 @@ import time
 # whatever is queued behind it), which cost the multi-GPU step ~0.1 ms in rehearsal. Must be set before HIP starts.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
+
+def launch_ranks_if_needed():
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment (the driver's plain command): this
+    process starts the N ranks itself -- `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` as
+    a CHILD process, before anything here has touched the GPU (nothing but the standard library is imported yet; never
+    an exec) -- forwards rank 0's one JSON line and leaves with the children's status."""
+    if "WORLD_SIZE" in os.environ:
+        return
+    n = 1
+    for i, a in enumerate(sys.argv[1:]):
+        if a == "--gpus" and i + 2 < len(sys.argv):
+            n = int(sys.argv[i + 2])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    if n <= 1:
+        return
+    import socket
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s:                          # a free port of this host (two benches side by side must not meet)
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] --gpus %d without WORLD_SIZE: starting the ranks as child processes: %s" % (n, " ".join(cmd[1:])),
+          file=sys.stderr, flush=True)
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)  # the children write to this process's stdout / stderr
+
+
+if __name__ == "__main__":
+    launch_ranks_if_needed()
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402  device memory, streams, torch.distributed -- plumbing (imported before libspsp, see package docstring)
 import torch.distributed as dist
@@ -116,9 +150,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
-                             % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: run `python bench.py --gpus N` (it starts its ranks itself) or launch "
+                         "N ranks with torch.distributed.run" % (args.gpus, world))
     # BENCH_SHARE_GPU=1 + BENCH_BACKEND=gloo (rehearsal on a one-GPU box): every rank computes on cuda:0 and the collectives
     # go through gloo -- the N > 1 code path of this file end to end, without RCCL's transport; the timing means nothing
     backend = os.environ.get("BENCH_BACKEND", "nccl")

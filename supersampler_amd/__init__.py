@@ -372,6 +372,11 @@ def sketch_files_release(device=-1):
     lib().spsp_sketch_files_release(device)
 
 
+def device_count():
+    """spsp_device_count: gfx950 devices visible to this process (initialises HIP)"""
+    return int(lib().spsp_device_count())
+
+
 def compare_files_multi(devices, paths, out_prefix, n_query=None, precision=6, min_threshold=0.0):
     """spsp_compare_files_multi: the comparator split by key over one context per entry of `devices` -> stage seconds"""
     n = len(paths)

@@ -78,7 +78,10 @@ int main(int argc, char** argv) {
     if (devices.empty()) {
         const int visible = spsp_device_count();
         if (visible <= 0) { cout << "GPU unavailable: " << spsp_last_error() << endl; return 1; }
-        const size_t per_device = 512;                        // sketches per device below which splitting does not pay
+        // sketches per device below which splitting does not pay (one partition + one exchange + a host join per device against
+        // a comparison of a few hundred microseconds); SPSP_PER_DEVICE=<n> overrides the 512 (a guess until measured on a node)
+        size_t per_device = 512;
+        if (const char* e = getenv("SPSP_PER_DEVICE")) { const long v = atol(e); if (v > 0) per_device = (size_t)v; }
         const int use = (int)std::max<size_t>(1, std::min<size_t>((size_t)visible, names.size() / per_device));
         for (int d = 0; d < use; ++d) devices.push_back(d);
     }

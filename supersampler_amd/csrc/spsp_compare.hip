@@ -1937,7 +1937,7 @@ static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t*
     int rc;
     // staging copy of the offsets (one job may be pending per context, and the previous one has been collected)
     if ((rc = stage_sk_off(ctx, h_sk_off, n))) return rc;
-    if ((rc = ctx->c_flags.reserve(64))) return rc;
+    if ((rc = ctx->c_flags.reserve(128))) return rc;
     Keys K{d_min, d_lo, (k > 32) ? d_hi : nullptr, ~0ull};
     const uint64_t* sk = ctx->c_skoff.as<uint64_t>();
     uint32_t* flags = ctx->c_flags.as<uint32_t>();

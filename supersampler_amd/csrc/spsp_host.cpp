@@ -1334,6 +1334,11 @@ int spsp_compare_files_multi(const int* devices, uint32_t n_dev, const char* con
     if (!devices || n_dev == 0 || n_dev > 64 || !paths || !out_prefix) { set_error("1..64 devices, file list and output prefix"); return SPSP_ERR_ARG; }
     std::vector<spsp_ctx*> ctxs;
     int rc = SPSP_OK;
+    if (getenv("SPSP_DEBUG_MULTI_TRACE")) {                   // which devices a CLI run chose (tests/test_multi_device.py)
+        std::string devs;
+        for (uint32_t d = 0; d < n_dev; ++d) devs += (d ? "," : "") + std::to_string(devices[d]);
+        fprintf(stderr, "spsp multi: %u contexts on devices %s, %u sketches\n", n_dev, devs.c_str(), n);
+    }
     for (uint32_t d = 0; d < n_dev && !rc; ++d) {
         spsp_ctx* c = nullptr;
         rc = spsp_create(devices[d], nullptr, &c);

@@ -476,7 +476,7 @@ static int keys_finish_queue(spsp_ctx* ctx, bool with_big, const uint32_t* d_gat
     uint32_t* d_out_off = d_distinct + (ng + 2);
     uint32_t* d_raw_cnt = d_out_off + (ng + 2);
     uint32_t* d_big = d_raw_cnt + (ng + 2);
-    uint32_t* d_flags = ctx->c_flags.as<uint32_t>() + 12;
+    uint32_t* d_flags = ctx->c_flags.as<uint32_t>() + 16;
     uint32_t* h_out = ctx->h_keys + (ng + 1);
     uint32_t* a_mn = ctx->a_mn.as<uint32_t>();
     uint64_t *a_lo = ctx->a_lo.as<uint64_t>(), *a_hi = J.has_hi ? ctx->a_hi.as<uint64_t>() : (uint64_t*)nullptr;
@@ -537,8 +537,8 @@ int sketch_keys_begin_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d
     uint32_t* d_out_off = d_distinct + (n_genomes + 2);
     uint32_t* d_raw_cnt = d_out_off + (n_genomes + 2);
     uint32_t* d_big = d_raw_cnt + (n_genomes + 2);
-    if ((rc = ctx->c_flags.reserve(64))) return rc;
-    uint32_t* d_flags = ctx->c_flags.as<uint32_t>() + 12;          // two words of the comparison's flag block that it does not use
+    if ((rc = ctx->c_flags.reserve(128))) return rc;
+    uint32_t* d_flags = ctx->c_flags.as<uint32_t>() + 16;          // two words of its own behind the comparison's sixteen (which k_parts_prepare clears and k_parts_group counts in)
     // The unordered form runs on a stream that carries a key extraction per step: its workgroups read their two record
     // bounds straight from the pinned staging block (no copy packet in front), and the gate words are cleared by the
     // compaction kernel that reports them (no fill packet either; cleared here after a call that did not get that far).

@@ -161,7 +161,9 @@ int main(int argc, char** argv) {
         }
         if (devices.empty()) {
             const int visible = spsp_device_count();
-            const int use = std::max(1, std::min(visible, (int)(in.size() / 16)));
+            long per_device = 16;                               // files per device from which dealing pays; SPSP_PER_DEVICE=<n> overrides
+            if (const char* e = getenv("SPSP_PER_DEVICE")) { const long v = atol(e); if (v > 0) per_device = v; }
+            const int use = std::max(1, std::min(visible, (int)((long)in.size() / per_device)));
             for (int d = 0; d < use; ++d) devices.push_back(d);
         }
         const int rc = spsp_sketch_files_multi(devices.data(), (uint32_t)devices.size(), &P, s, in.data(), out.data(), (uint32_t)in.size(), threads, cb, &run, nullptr);

@@ -63,7 +63,7 @@ def test_two_ranks_rccl_both_exchange_forms():
 
 @pytest.mark.gpu
 def test_bench_two_ranks_rehearsal_on_one_gpu():
-    """bench.py as the driver launches it for N = 2 (torch.distributed.run, one process per rank), rehearsed on ONE
+    """bench.py as the driver launches it for N = 2 (`python bench.py --gpus 2`: one process per rank), rehearsed on ONE
     GPU: both ranks compute on cuda:0 and the collectives go through gloo (BENCH_BACKEND / BENCH_SHARE_GPU).  The
     whole N > 1 path of the file runs -- rank-sharded genomes, key all-gather, own rows, strips to rank 0, barrier,
     max over ranks, ONE JSON line from rank 0 -- and the line's untimed check says the collected matrix equals a
@@ -74,8 +74,9 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
                OMP_NUM_THREADS="1")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29631", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+    # the PLAIN command of the driver (`python bench.py --gpus N ...`, no WORLD_SIZE): bench.py starts its two ranks itself,
+    # as child processes through torch.distributed.run, before it touches the GPU
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
            "--genomes", "6", "--length", "300000", "--no-cpu-baseline"]
     env["BENCH_C4_SKETCHES"] = "400"                         # the multi-rank configs[3] leg at a rehearsal's size
     p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
@@ -90,3 +91,45 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     c4 = d["compare_c4"]
     assert c4["exchange_check"].startswith("sum of the ranks' partial matrices equals"), c4
     assert c4["nonzero_pairs"] == 20 * 190 and c4["pairs"] == 400 * 399 // 2
+
+
+def test_bench_starts_its_own_ranks_when_called_plainly(monkeypatch):
+    """`python bench.py --gpus N` without WORLD_SIZE (the driver's command): N ranks as a CHILD process through
+    torch.distributed.run on 127.0.0.1, same arguments, the child's status returned; with WORLD_SIZE set, or N = 1, nothing
+    is started (CPU: the launcher only -- the GPU tier runs it for real in test_bench_two_ranks_rehearsal_on_one_gpu)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = []
+
+    class Done:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        seen.append((cmd, env))
+        return Done()
+
+    monkeypatch.setattr(bench.subprocess, "run", fake_run)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    with pytest.raises(SystemExit) as e:
+        bench.launch_ranks_if_needed()
+    assert e.value.code == 7 and len(seen) == 1
+    cmd, env = seen[0]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus=2"])
+    with pytest.raises(SystemExit):
+        bench.launch_ranks_if_needed()
+    assert seen[-1][0][seen[-1][0].index("--nproc-per-node") + 1] == "2"
+    n = len(seen)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "3"])
+    bench.launch_ranks_if_needed()                              # one GPU: this process is the bench
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4"])
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    bench.launch_ranks_if_needed()                              # already a rank
+    assert len(seen) == n

@@ -1275,6 +1275,42 @@ def test_sketch_keys_survive_the_next_scan(ctx):
         reader.close()
 
 
+def test_key_extraction_keeps_its_gate_words_across_a_large_comparison():
+    """the key extraction's two device words (big-genome gate and count) were words 12 / 13 of the comparison's
+    flag block, where k_parts_group leaves its list statistics after any comparison beyond the small form -- the next
+    extraction on the same context then reported them as `big genomes` and ran the table kernels ungated.  They are words of
+    the extraction's own now: extraction -> comparison of 2 000 sketches -> extraction on ONE context, big_genomes == 0
+    both times and the same keys."""
+    import torch
+    dev = torch.device("cuda", 0)
+    k, m, s = 31, 11, 200.0
+    rng = np.random.default_rng(9)
+    gs = [synth.random_genome(rng, 150_000) for _ in range(6)]
+    bases, off = synth.concat_records(gs)
+    texts = [synth.to_fasta(g, "g%d" % i) for i, g in enumerate(gs)]
+    want = _keys_want(texts, k, m, s)
+    d_b = torch.from_numpy(np.concatenate([bases, np.zeros(64, np.uint8)])).cuda()
+    d_o = torch.from_numpy(off.view(np.int64)).cuda()
+    n = 2000
+    D = synth.direct_family_sketches(n, fam_size=20, seed=5, device=dev, skm_range=(20, 40))
+    dense = torch.zeros((n, n), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    p = sp.make_params(k, m, s)
+    c = sp.Context(0)
+    try:
+        for rnd in range(2):
+            for un in (True, False):
+                d_sk, n_sk = c.scan_device(p, d_b.data_ptr(), len(bases), d_o.data_ptr(), len(gs))
+                got = c.sketch_keys_device(p, d_b.data_ptr(), len(bases), d_o.data_ptr(), d_sk, n_sk, list(range(len(gs) + 1)), unordered=un)
+                assert c.sketch_keys_big_genomes() == 0, (rnd, un)
+                _check_keys(c, got, want, k, not un, (rnd, un))
+            c.compare_device(31, D.minimizer.data_ptr(), D.kmer_lo.data_ptr(), None, D.sk_off, n, 0, 1, dense.data_ptr())
+            torch.cuda.synchronize()
+            assert int((dense != 0).sum().item()) >= (n // 20) * 100
+    finally:
+        c.close()
+
+
 def test_configs4_shape_record_set_keys_equal_the_oracle(ctx):
     """BASELINE configs[4]'s shape (k63 m15 s100) at the size of one streamed segment: 60 records of 2 Mbp as ONE genome,
     ~1.2 x 10^6 selected k-mers -- two hundred times the LDS table -- from the scan to the comparator's keys on the device,
