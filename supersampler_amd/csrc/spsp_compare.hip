@@ -31,6 +31,10 @@
 #include "spsp_internal.h"
 #include "spsp_device.h"
 
+#ifndef SPSP_EXP
+#define SPSP_EXP 0          // timing experiments (tools/exp/build_variant.sh): kernels with parts of their work left out; 0 in the product
+#endif
+
 namespace spsp {
 
 struct Keys {
@@ -375,7 +379,18 @@ __global__ __launch_bounds__(kSparseThreads) void k_accumulate_sparse(const uint
     const uint32_t copies = 1u << copies_log2, mine = threadIdx.x & (copies - 1);
     for (uint32_t x = threadIdx.x; x < ((cols << copies_log2) >> (HALF ? 1 : 0)); x += kSparseThreads) s_cnt[x] = 0;
     __syncthreads();
+#if SPSP_EXP & 8
+    uint32_t exp_chk = 0;
+#endif
     auto count = [&](uint32_t jj) {
+#if SPSP_EXP & 8
+        exp_chk += jj;                                        // (timing experiment: the lists are read, nothing is added in LDS)
+        return;
+#endif
+#if SPSP_EXP & 64
+        if (jj > i && jj - col0 < cols) { atomicAdd(&s_cnt[(threadIdx.x * 33u + jj) & 4095u], 1u); }   // (timing experiment: adds without same-address conflicts)
+        return;
+#endif
         if (jj > i && jj - col0 < cols) {
             const uint32_t idx = ((jj - col0) << copies_log2) + mine;
             if (HALF) atomicAdd(&s_cnt[idx >> 1], 1u << ((idx & 1u) << 4));    // (a half never carries: a counter is at most the row's key count)
@@ -386,7 +401,7 @@ __global__ __launch_bounds__(kSparseThreads) void k_accumulate_sparse(const uint
     // kAccR list references are fetched together (the partition form reaches them through `where`: two dependent
     // loads, the second scattered -- eight of each in flight per thread hide the extra hop), then the lists kAccU at a time
     const uint32_t lane = threadIdx.x & 63u;
-    const bool use_multi = multi && 5u * flags[12] < 2u * flags[13];     // (records with a list / records, in a sample of the parts: k_parts_group)
+    const bool use_multi = multi && (multi_slots >> 31 ? true : 5u * flags[12] < 2u * flags[13]);   // (top bit of multi_slots: the host insists, SPSP_DEBUG_MULTI=1)     // (records with a list / records, in a sample of the parts: k_parts_group)
     for (uint64_t eb = e0; eb < e1; eb += (uint64_t)kAccR * kSparseThreads) {     // (every lane makes every round: the waves pool their long lists, below)
         const uint64_t e = eb + threadIdx.x;
         uint32_t refs[kAccR];
@@ -398,8 +413,15 @@ __global__ __launch_bounds__(kSparseThreads) void k_accumulate_sparse(const uint
             for (int r = 0; r < kAccR; ++r) {
                 // (multi: a bit per record slot of the parts -- has the key a list? -- in front of the list reference's miss)
                 bool fetch = at[r] != kNoWhere;
-                if (fetch && use_multi && at[r] < multi_slots) fetch = (multi[at[r] >> 5] >> (at[r] & 31u)) & 1u;
+                if (fetch && use_multi && at[r] < (multi_slots & 0x7fffffffu)) fetch = (multi[at[r] >> 5] >> (at[r] & 31u)) & 1u;
+#if SPSP_EXP & 32
+                refs[r] = fetch && at[r] == 0xfffffff1u ? list_of_entry[at[r]] : kNoList;   // (timing experiment: no reference read)
+#else
                 refs[r] = fetch ? list_of_entry[at[r]] : kNoList;
+#endif
+#if SPSP_EXP & 16
+                if (refs[r] != 0xfffffff2u) refs[r] = kNoList;                              // (timing experiment: no list read)
+#endif
             }
         } else {
 #pragma unroll
@@ -479,6 +501,9 @@ __global__ __launch_bounds__(kSparseThreads) void k_accumulate_sparse(const uint
         }
         }
     }
+#if SPSP_EXP & 8
+    if (exp_chk == 0x12345u) s_cnt[1] = exp_chk;
+#endif
     __syncthreads();
     if (cells) {
         // sparse result (the key-partitioned split: a rank's partial row is nearly all zeros): the row's non-zero cells
@@ -806,6 +831,126 @@ __global__ __launch_bounds__(kScatThreads, 4) void k_parts_scatter(Keys K, const
         uint64_t* r = recs + ((uint64_t)part * cap + at) * W;
         if (HAS_HI) { r[0] = lo[u]; r[1] = (uint64_t)mn[u] | ((uint64_t)j << 32); r[2] = hi[u]; }
         else *reinterpret_cast<ulonglong2*>(r) = make_ulonglong2(lo[u], (uint64_t)mn[u] | ((uint64_t)j << 32));   // one 16-byte store
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Tiles: the scatter over (block of sketches) x (range of every sketch) instead of over 4096 consecutive entries (round 5).
+// With consecutive entries a workgroup deals ~one sketch, so the holders of one key -- the members of a family -- are dealt
+// by as many workgroups, at different times: every record is a 16-byte store of its own into the tail of its part and every
+// record's list reference sits in a line of its own (one miss per key in the row sums).  A TILE is range s of T -- the
+// entries [s len / T, (s + 1) len / T) -- of each of tile_sk consecutive sketches, ~4 000 entries in all.  Sketches of a family
+// hold mostly the same keys in the same (sorted) order, so a key sits at nearly the same relative place in each of them: its
+// holders inside the block are dealt in the same round by ONE workgroup, take consecutive ranks in the key's part (nothing
+// else of the round goes to that part, as a rule: 4096 records over thousands of parts) and leave as one run; their list
+// references share lines that the family's rows -- side by side behind one L2 (xcd_rows) -- fetch once.  Ranges by PLACE,
+// not by key: splitter keys (every sketch's lower bound of the pivot sketch's quantiles, found by binary or galloping
+// search) were built first and cost 0.11 ms at configs[3] -- 14 random lines per search whatever the search -- for the same
+// row-sum time: a holder that lands in the neighbouring range only splits its key's run in two.  Scheduling only: same
+// records, same parts, same `where` semantics, every entry in exactly one tile whatever the keys are.
+constexpr uint32_t kTileSkMax = 64;                    // sketches per block: a power of two up to this (stage_sk_off)
+// tile_info[tile] = block | s << 32 | T << 48: the tile is range s of the T ranges of block `block` (made by the host, which
+// has the offsets: stage_sk_off)
+template <bool HAS_HI>
+__global__ __launch_bounds__(kScatThreads, 4) void k_parts_scatter_tiles(Keys K, const uint64_t* __restrict__ sk_off, uint32_t n,
+                                                                     const uint64_t* __restrict__ tile_info, uint32_t tile_sk,
+                                                                     uint32_t n_parts, uint32_t cap,
+                                                                     uint32_t* __restrict__ part_cnt, uint64_t* __restrict__ recs,
+                                                                     uint32_t* __restrict__ where, uint32_t* __restrict__ flags, bool check_order,
+                                                                     uint32_t row_first, uint32_t classes, uint32_t cls) {
+    constexpr int E = 4;
+    constexpr uint32_t W = HAS_HI ? 3 : 2;
+    extern __shared__ uint32_t hist[];                   // [n_parts]
+    __shared__ uint32_t s_a[kTileSkMax], s_pre[kTileSkMax + 1];
+    const uint32_t t = threadIdx.x, lane = t & 63u, tile = blockIdx.x;
+    const uint64_t info = tile_info[tile];
+    const uint32_t b = (uint32_t)info;
+    if (t < 64) {
+        const uint32_t j = b * tile_sk + t;
+        uint32_t a = 0, z = 0;
+        if (t < tile_sk && j < n) {                       // range s of T: the same share of every sketch
+            const uint64_t j0 = sk_off[j], len = sk_off[j + 1] - j0, s_ = (info >> 32) & 0xffffu, T_ = info >> 48;
+            a = (uint32_t)(j0 + s_ * len / T_); z = (uint32_t)(j0 + (s_ + 1) * len / T_);
+        }
+        uint32_t incl = z - a;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(incl, d); if (lane >= (uint32_t)d) incl += y; }
+        s_a[t] = a; s_pre[t] = incl - (z - a);
+        if (t == 63) s_pre[64] = incl;
+    }
+    __syncthreads();
+    const uint32_t total = s_pre[64];
+    for (uint32_t x0 = 0; x0 < total; x0 += (uint32_t)E * kScatThreads) {     // (one round, as a rule: tiles are made for 0.9 of a round)
+        for (uint32_t p = t; p < n_parts; p += kScatThreads) hist[p] = 0;
+        uint64_t lo[E], hi[E], ent[E];
+        uint32_t mn[E], sk_of[E], pr[E];
+        bool first_of_run[E];
+#pragma unroll
+        for (int u = 0; u < E; ++u) {
+            const uint32_t x = x0 + (uint32_t)u * kScatThreads + t;
+            lo[u] = 0; mn[u] = 0; hi[u] = 0; ent[u] = ~0ull; sk_of[u] = 0; first_of_run[u] = false;
+            if (x < total) {
+                uint32_t q = 0;                           // the sketch of the block whose run holds place x: largest q with s_pre[q] <= x
+#pragma unroll
+                for (uint32_t step = 32; step; step >>= 1) if (s_pre[q + step] <= x) q += step;
+                const uint64_t e = (uint64_t)s_a[q] + (x - s_pre[q]);
+                ent[u] = e; sk_of[u] = b * tile_sk + q; first_of_run[u] = x == s_pre[q];
+                lo[u] = K.lo[e]; mn[u] = K.mn[e]; if (HAS_HI) hi[u] = K.hi[e];
+            }
+        }
+        uint64_t hsh[E];
+        bool keep[E];
+#pragma unroll
+        for (int u = 0; u < E; ++u) {
+            // the key in front of e: the neighbouring lane's, except for the first lane of a wave and the first entry of a run
+            uint64_t plo = __shfl_up(lo[u], 1), phi = HAS_HI ? __shfl_up(hi[u], 1) : 0ull;
+            uint32_t pmn = __shfl_up(mn[u], 1);
+            const uint64_t e = ent[u];
+            const bool valid = e != ~0ull;
+            if (check_order && valid && e > sk_off[sk_of[u]]) {   // strictly increasing inside a sketch (spsp_compare_keys_unordered: the caller vouches for distinct keys instead)
+                if (lane == 0 || first_of_run[u]) { plo = K.lo[e - 1]; pmn = K.mn[e - 1]; if (HAS_HI) phi = K.hi[e - 1]; }
+                const bool less = pmn != mn[u] ? pmn < mn[u] : (HAS_HI && phi != hi[u]) ? phi < hi[u] : plo < lo[u];
+                if (!less) atomicOr(&flags[0], 1u);
+            }
+            hsh[u] = key_hash(lo[u], mn[u], hi[u], HAS_HI);
+            keep[u] = valid && sk_of[u] >= row_first;     // (sketches in front of the first owned row are never counted by an owned row)
+            if (classes > 1 && keep[u] && key_class(hsh[u], classes) != cls) { keep[u] = false; where[e] = kNoWhere; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < E; ++u) {
+            pr[u] = 0xffffffffu;
+            if (keep[u]) {
+                const uint32_t part = (uint32_t)(((hsh[u] >> 32) * n_parts) >> 32);
+                pr[u] = part | (atomicAdd(&hist[part], 1u) << 15);
+            }
+        }
+        __syncthreads();
+        for (uint32_t p = t; p < n_parts; p += kScatThreads) {
+            const uint32_t c = hist[p];
+#if SPSP_EXP & 1
+            if (c) hist[p] = (blockIdx.x * 29u) % (cap / 2);     // (timing experiment: no reservation -- results are wrong)
+#else
+            if (c) hist[p] = atomicAdd(&part_cnt[p], c);
+#endif
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < E; ++u) {
+            if (!keep[u]) continue;
+            const uint32_t part = pr[u] & 0x7fffu, at = hist[part] + (pr[u] >> 15);
+#if !(SPSP_EXP & 4)
+            where[ent[u]] = at < cap ? part * cap + at : kNoWhere;
+#endif
+            if (at >= cap) continue;
+#if SPSP_EXP & 2
+            continue;
+#endif
+            uint64_t* r = recs + ((uint64_t)part * cap + at) * W;
+            if (HAS_HI) { r[0] = lo[u]; r[1] = (uint64_t)mn[u] | ((uint64_t)sk_of[u] << 32); r[2] = hi[u]; }
+            else *reinterpret_cast<ulonglong2*>(r) = make_ulonglong2(lo[u], (uint64_t)mn[u] | ((uint64_t)sk_of[u] << 32));
+        }
+        __syncthreads();                                  // (the next round clears the counters these stores read)
     }
 }
 
@@ -1512,7 +1657,10 @@ static int job_parts(spsp_ctx* ctx, CompareJob& J) {
     // whose last comparison had lists for two records in five or more leaves them out for its next 63 (they cost the grouping
     // kernel 0.03 ms and, used, the row sums 0.15 ms at configs[3])
     J.want_multi = !J.small;
-    if (J.want_multi && ctx->multi_quiet > 0) { --ctx->multi_quiet; J.want_multi = false; }
+    static const char* dbg_multi = getenv("SPSP_DEBUG_MULTI");       // "0": never made, "1": always made and always used (A/B)
+    if (dbg_multi && dbg_multi[0] == '0') J.want_multi = false;
+    else if (dbg_multi && dbg_multi[0] == '1') {}
+    else if (J.want_multi && ctx->multi_quiet > 0) { --ctx->multi_quiet; J.want_multi = false; }
     if (!(skip & 2) && (rc = J.small ? J.group_small(J.n_parts) : J.group_parts(J.n_parts, J.spill, J.want_multi))) return rc;
     if (J.spill.room && !J.small && (rc = J.spill_parts(J.n_parts, J.spill, 1, J.classes, J.cls))) return rc;
     if ((rc = ctx->ev_end(kEvGroup))) return rc;
@@ -1520,7 +1668,7 @@ static int job_parts(spsp_ctx* ctx, CompareJob& J) {
     if ((rc = ctx->ev_begin(kEvAccumulate))) return rc;
     ComparePlan PP = J.P;
     PP.list_ref = ctx->c_lref.as<uint32_t>(); PP.where = ctx->c_where.as<uint32_t>();
-    if (J.want_multi) { PP.multi = ctx->c_multi.as<uint32_t>(); PP.multi_slots = J.n_parts * (uint32_t)kPartCap; }
+    if (J.want_multi) { PP.multi = ctx->c_multi.as<uint32_t>(); PP.multi_slots = J.n_parts * (uint32_t)kPartCap | ((dbg_multi && dbg_multi[0] == '1') ? 0x80000000u : 0u); }
     if (ordered) PP.row_order = ctx->c_order.as<uint32_t>();
     if (ordered || J.want_multi) SPSP_HIP(hipMemcpyAsync(ctx->h_scalar + 14, flags + 10, 16, hipMemcpyDeviceToHost, ctx->stream));   // the verdicts, for compare_job_end
     // (an attempt whose parts overflow leaves this kernel at its first line, before any cell is emitted: the retry emits them once)
@@ -1888,11 +2036,30 @@ void compare_job_drop(spsp_ctx* ctx) {
 }
 
 // pinned copy of the caller's offsets: the queued H2D copy must not read memory the caller may free
-static int stage_sk_off(spsp_ctx* ctx, const uint64_t* h_sk_off, uint32_t n) {
+// tiles (k_parts_scatter_tiles): behind the sub-chunk table (8-byte aligned), tile_info[tile] = block | s << 32 | T << 48 -- the
+// tile is range s of the T ranges of its block of tile_sk sketches; a block gets one range per kTileTarget entries (none when
+// it is empty or lies in front of the first owned row).  SPSP_DEBUG_TILES=0: no tiles (the scatter over consecutive entries);
+// =<n>: n entries per tile; SPSP_DEBUG_TILE_SK=<8|16|32|64>: sketches per block
+constexpr uint32_t kTileTarget = 4032, kTileSk = 32, kTileMinSketches = 2 * kTileSk;
+static int stage_sk_off(spsp_ctx* ctx, const uint64_t* h_sk_off, uint32_t n, uint32_t row_first, uint32_t* n_tiles_out, uint32_t* tile_sk_out) {
     // n + 1 offsets, then (partition form) one u32 per sub-chunk of kScatSub entries: the sketch holding its first entry
     const uint64_t S = h_sk_off[n];
     const size_t n_sub = (size_t)((S + kScatSub - 1) / kScatSub);
-    const size_t need = (size_t)(n + 1) + (n_sub + 1) / 2;
+    static const char* dbg_tiles = getenv("SPSP_DEBUG_TILES");
+    static const char* dbg_sk = getenv("SPSP_DEBUG_TILE_SK");
+    const uint32_t target = dbg_tiles && atoi(dbg_tiles) >= 32 ? (uint32_t)atoi(dbg_tiles) : kTileTarget;
+    uint32_t tile_sk = kTileSk;
+    if (dbg_sk && (atoi(dbg_sk) == 8 || atoi(dbg_sk) == 16 || atoi(dbg_sk) == 32 || atoi(dbg_sk) == 64)) tile_sk = (uint32_t)atoi(dbg_sk);
+    const bool tiles = !(dbg_tiles && atoi(dbg_tiles) == 0) && n >= kTileMinSketches;
+    const uint32_t n_blocks = tiles ? (n + tile_sk - 1) / tile_sk : 0u;
+    uint64_t n_tiles = 0;
+    for (uint32_t b = 0; b < n_blocks; ++b) {
+        const uint32_t j0 = b * tile_sk, j1 = std::min(n, j0 + tile_sk);
+        const uint64_t E = h_sk_off[j1] - h_sk_off[j0];
+        if (j1 > row_first && E) n_tiles += std::min<uint64_t>((E + target - 1) / target, 0xffffu);
+    }
+    const size_t sub_words = (n_sub + 1) / 2;              // u64 words of the sub-chunk table
+    const size_t need = (size_t)(n + 1) + sub_words + (size_t)n_tiles;
     if (ctx->h_skoff_cap < need) {
         if (ctx->h_skoff) { SPSP_HIP(hipStreamSynchronize(ctx->stream)); (void)hipHostFree(ctx->h_skoff); ctx->h_skoff = nullptr; ctx->h_skoff_cap = 0; }
         size_t cap = 1024;
@@ -1908,6 +2075,17 @@ static int stage_sk_off(spsp_ctx* ctx, const uint64_t* h_sk_off, uint32_t n) {
         while (j + 1 < n && h_sk_off[j + 1] <= e) ++j;
         sub[c] = j;
     }
+    if (n_sub & 1) sub[n_sub] = 0;
+    uint64_t* info = ctx->h_skoff + n + 1 + sub_words;
+    uint64_t t = 0;
+    for (uint32_t b = 0; b < n_blocks; ++b) {
+        const uint32_t j0 = b * tile_sk, j1 = std::min(n, j0 + tile_sk);
+        const uint64_t E = h_sk_off[j1] - h_sk_off[j0];
+        if (!(j1 > row_first && E)) continue;
+        const uint64_t T = std::min<uint64_t>((E + target - 1) / target, 0xffffu);
+        for (uint64_t s = 0; s < T; ++s) info[t++] = (uint64_t)b | (s << 32) | (T << 48);
+    }
+    *n_tiles_out = (uint32_t)n_tiles; *tile_sk_out = tile_sk;
     return ctx->c_skoff.reserve(need * 8);
 }
 
@@ -1936,7 +2114,8 @@ static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t*
     }
     int rc;
     // staging copy of the offsets (one job may be pending per context, and the previous one has been collected)
-    if ((rc = stage_sk_off(ctx, h_sk_off, n))) return rc;
+    uint32_t n_tiles = 0, tile_sk = 0;
+    if ((rc = stage_sk_off(ctx, h_sk_off, n, row_first, &n_tiles, &tile_sk))) return rc;
     if ((rc = ctx->c_flags.reserve(128))) return rc;
     Keys K{d_min, d_lo, (k > 32) ? d_hi : nullptr, ~0ull};
     const uint64_t* sk = ctx->c_skoff.as<uint64_t>();
@@ -1987,7 +2166,10 @@ static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t*
     const bool has_hi = K.hi != nullptr;
     J->has_hi = has_hi;
     const uint32_t* sub_sk = reinterpret_cast<const uint32_t*>(sk + n + 1);
-    J->n_sub = (uint32_t)((S + kScatSub - 1) / kScatSub);
+    const uint32_t n_sub_real = (uint32_t)((S + kScatSub - 1) / kScatSub);
+    const uint32_t sub_words = (n_sub_real + 1) / 2;
+    J->n_sub = 2 * (sub_words + n_tiles);                        // u32 words behind the offsets that k_parts_prepare brings over: sub-chunk sketches, then the tile table
+    const uint64_t* tile_info = sk + n + 1 + sub_words;
     J->build_filter = [=](uint32_t fmask) -> int {
         uint64_t max_own = 0;
         for (uint32_t i = row_first; i < row_limit; i += row_stride) max_own = std::max(max_own, ctx->h_skoff[i + 1] - ctx->h_skoff[i]);
@@ -2008,6 +2190,22 @@ static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t*
         uint32_t* where = small ? nullptr : ctx->c_where.as<uint32_t>();
         static_assert(kMaxKeyParts < (1 << 15), "k_parts_scatter keeps the part in 15 bits of its (part, rank) word");
         if (n_parts > (uint32_t)kMaxKeyParts) { set_error("internal: %u key parts exceed the scatter's limit of %d", n_parts, kMaxKeyParts); return SPSP_ERR_ARG; }
+        // tiles: the general partition form (a filtered call's scatter starts at its first owned row's chunk and drops most of
+        // what it reads; the small form keeps no `where` and its 100 sketches are one block anyway)
+        if (!small && !filtered && n_tiles) {
+            const size_t lds_t = (size_t)n_parts * 4;
+            if (lds_t > 48 * 1024 && !ctx->attr_scatter_tiles_set) {
+                SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_parts_scatter_tiles<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxKeyParts * 4));
+                SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_parts_scatter_tiles<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxKeyParts * 4));
+                ctx->attr_scatter_tiles_set = true;
+            }
+            if (has_hi) hipLaunchKernelGGL(k_parts_scatter_tiles<true>, dim3(n_tiles), dim3(kScatThreads), lds_t, ctx->stream, K, sk, n, tile_info, tile_sk, n_parts,
+                                           cap, ctx->c_part_cnt.as<uint32_t>(), ctx->c_recs.as<uint64_t>(), where, flags, !ctx->keys_unordered, row_first, classes, cls);
+            else hipLaunchKernelGGL(k_parts_scatter_tiles<false>, dim3(n_tiles), dim3(kScatThreads), lds_t, ctx->stream, K, sk, n, tile_info, tile_sk, n_parts,
+                                    cap, ctx->c_part_cnt.as<uint32_t>(), ctx->c_recs.as<uint64_t>(), where, flags, !ctx->keys_unordered, row_first, classes, cls);
+            SPSP_HIP(hipGetLastError());
+            return SPSP_OK;
+        }
         const uint32_t per_wg = 4u * kScatThreads;
         const uint64_t e_first = e_own;
         const dim3 grid((uint32_t)((S - e_first + per_wg - 1) / per_wg));

@@ -110,7 +110,7 @@ struct spsp_ctx {
     uint64_t learnt_on = 0;            // offsets' fingerprint of the collection order_quiet / multi_quiet were learnt on
     uint32_t multi_quiet = 0;          // comparisons that leave out the has-a-list bits (the last one had lists for most records)
     uint32_t order_quiet = 0;          // comparisons that skip the making of a row order (the last one came in a good order of its own)
-    bool attr_pair_set = false, attr_single_set = false, attr_bloom_set = false, attr_small_set = false, attr_group_set = false, attr_group_hi_set = false, attr_scatter_set = false, attr_sort_set = false, attr_order_set = false;   // dynamic-LDS attributes set on this context's device
+    bool attr_pair_set = false, attr_single_set = false, attr_bloom_set = false, attr_small_set = false, attr_group_set = false, attr_group_hi_set = false, attr_scatter_set = false, attr_scatter_tiles_set = false, attr_sort_set = false, attr_order_set = false;   // dynamic-LDS attributes set on this context's device
     spsp::ScanJob scan_job;
     spsp::CompareJob* compare_job = nullptr;
     // spsp_sketch_keys_device_begin / _end (spsp_keys.hip)

@@ -436,7 +436,12 @@ def test_comparison_forms_agree_on_random_inputs():
     # SPSP_DEBUG_SMALL=0: the general partition form also for <= 128 sketches; SPSP_DEBUG_KEY_CLASSES: the keys in that many
     # hash classes, one pass through the parts each (what inputs beyond 9 x 10^7 keys get), also with many tiny parts
     for env in ({}, {"SPSP_DEBUG_SPARSE": "1"}, {"SPSP_DEBUG_MATRIX_BUDGET": "9000"}, {"SPSP_DEBUG_SPARSE": "0"}, {"SPSP_DEBUG_PARTS": "0"},
-                {"SPSP_DEBUG_SMALL": "0"}, {"SPSP_DEBUG_KEY_CLASSES": "3"}, {"SPSP_DEBUG_KEY_CLASSES": "2", "SPSP_DEBUG_PART_MEAN": "40"}):
+                {"SPSP_DEBUG_SMALL": "0"}, {"SPSP_DEBUG_KEY_CLASSES": "3"}, {"SPSP_DEBUG_KEY_CLASSES": "2", "SPSP_DEBUG_PART_MEAN": "40"},
+                # SPSP_DEBUG_TILES: the scatter over tiles (32 sketches x the same share of each) switched off / with tiles of ~40
+                # entries / of ~9 000 (three rounds per tile) in blocks of 8 and 64 sketches
+                {"SPSP_DEBUG_TILES": "0", "SPSP_DEBUG_SMALL": "0"}, {"SPSP_DEBUG_TILES": "40", "SPSP_DEBUG_SMALL": "0"},
+                {"SPSP_DEBUG_TILES": "9000", "SPSP_DEBUG_SMALL": "0", "SPSP_DEBUG_TILE_SK": "64"},
+                {"SPSP_DEBUG_TILES": "40", "SPSP_DEBUG_KEY_CLASSES": "3", "SPSP_DEBUG_PART_MEAN": "40", "SPSP_DEBUG_TILE_SK": "8"}):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0 and "digest" in r.stdout, (env, r.stdout[-2000:], r.stderr[-3000:])
         digests.append(r.stdout.strip().split()[-1])
@@ -1019,3 +1024,48 @@ def test_one_sketch_far_longer_than_the_others(ctx, where):
     back = np.zeros((n, n), np.int64)
     back[(c >> 48) & 0xffff, (c >> 32) & 0xffff] = c & 0xffffffff
     assert cnt == np.count_nonzero(want) and (back == want).all()
+
+
+@pytest.mark.parametrize("use_hi", [False, True])
+def test_scatter_tiles_of_any_shape_give_the_same_matrix(ctx, use_hi):
+    """k_parts_scatter_tiles (the scatter over tiles of 32 sketches x the same share of each): scheduling only, so any
+    collection gives the matrix of set algebra -- a block whose longest sketch shares nothing with the other 31, blocks with
+    empty sketches, a ragged last block, a block of identical sketches, sketches of one key; all-vs-all and in query mode;
+    and a sketch that is not sorted is refused whichever tile its keys fall into."""
+    rng = np.random.default_rng(31 + use_hi)
+    uni = [(int(rng.integers(100, 2**20)), int(rng.integers(0, 2**62)) if use_hi else 0, int(rng.integers(0, 2**62))) for _ in range(6000)]
+    sets = []
+    low = {(1, 0, int(x)) for x in rng.integers(0, 2**62, 6000)}                       # minimizer 1: below every universe key
+    high = {(2**22 - 1, 0, int(x)) for x in rng.integers(0, 2**62, 6000)}              # above every universe key
+    for i in range(32 * 5 + 9):
+        blk, q = divmod(i, 32)
+        pick = lambda p: {uni[j] for j in np.nonzero(rng.random(len(uni)) < p)[0]}
+        if blk == 0: st = low if q == 5 else pick(0.65)                                  # longest sketch below the others
+        elif blk == 1: st = high if q == 0 else pick(0.6)                                # ... above the others
+        elif blk == 2: st = set() if q % 3 else pick(0.2)                                # mostly empty
+        elif blk == 3: st = set(sets[32]) if q else pick(0.5)                            # (q = 0 sets the block's own sketch, the others copy sketch 32)
+        elif blk == 4: st = {uni[int(rng.integers(0, len(uni)))]}                        # one key each
+        else: st = pick(0.1)
+        sets.append(st)
+    n = len(sets)
+    sk = []
+    for st in sets:
+        keys = sorted(st)
+        sk.append(sp.Sketch(63 if use_hi else 31, 11, np.array([x[0] for x in keys], np.uint32), np.array([x[2] for x in keys], np.uint64),
+                            np.array([x[1] for x in keys], np.uint64)))
+    idx = {key: c for c, key in enumerate(sorted(set().union(*sets)))}
+    inc = np.zeros((n, len(idx)), np.int64)
+    for i, st in enumerate(sets):
+        inc[i, [idx[x] for x in st]] = 1
+    want = np.triu(inc @ inc.T, 1).astype(np.uint32)
+    inter, card = ctx.compare(sk)
+    assert (inter == want).all() and [int(c) for c in card] == [len(st) for st in sets]
+    inter_q, _ = ctx.compare(sk, n_query=40)
+    assert (inter_q[:40] == want[:40]).all()
+    # a sketch that is not sorted is refused
+    bad = sk[70]
+    bad.kmer_lo[[10, 400]] = bad.kmer_lo[[400, 10]]
+    bad.minimizer[[10, 400]] = bad.minimizer[[400, 10]]
+    bad.kmer_hi[[10, 400]] = bad.kmer_hi[[400, 10]]
+    with pytest.raises(sp.SpspError):
+        ctx.compare(sk)
