@@ -175,8 +175,9 @@ int spsp_scan_device(spsp_ctx* ctx, const spsp_params* p, const void* d_bases, u
  * device into the packed form -- 16 bases per little-endian 32-bit word, first base in bits 31:30, A=0 C=1 T=2 G=3, the
  * last word zero-filled and 256 readable bytes behind it -- in a buffer the context owns (valid until its next pack call).
  * A scan whose spsp_params.flags carry SPSP_SCAN_PACKED_INPUT takes that buffer as d_bases (n_bases stays the number of
- * BASES; record offsets are base offsets as ever).  The pair-table dense pass reads it directly: a quarter of the
- * traffic, no packing arithmetic; the other variants unpack it into an ASCII copy first.  Same stream out. */
+ * BASES; record offsets are base offsets as ever).  The pair-table and the blocked-Bloom dense passes (m >= 9 at coarse
+ * sampling; m = 13 / 15 at fine sampling: BASELINE configs[1] and configs[4]) read it directly: a quarter of the traffic, no
+ * packing arithmetic; the other variants unpack it into an ASCII copy first.  Same stream out. */
 int spsp_pack_bases_device(spsp_ctx* ctx, const void* d_bases, uint64_t n_bases, void** d_packed);
 
 /* The same call split at its host synchronisation, for callers that pipeline several streams (one context

@@ -16,7 +16,7 @@
 //                           in LDS, then merge passes over global memory, merge-path partitioned: one 2048-key output
 //                           tile per workgroup, both inputs staged in LDS, 8 keys per lane
 //
-// The table is never cleared between calls: a slot word carries the epoch (a 16-bit call counter) of the call that
+// The table is never cleared between calls: a slot word carries the epoch (an 8-bit call counter) of the call that
 // claimed it, and a slot of another epoch is free.  The dedupe kernels are launched over ALL raw places of a call and
 // find their segment by a search on the segment starts; a gate word (set by the LDS form when it meets a segment it
 // cannot hold) lets every workgroup leave at once in the common case that nothing is flagged.
@@ -37,12 +37,14 @@ __device__ __forceinline__ uint64_t big_mix(uint64_t x) {
     x ^= x >> 27; x *= 0x94d049bb133111ebULL;
     return x ^ (x >> 31);
 }
-__device__ __forceinline__ uint32_t big_home(uint32_t seg, uint32_t mo, uint64_t lo, uint64_t hi, uint32_t mask) {
+// 64 hash bits of (segment, key): the home slot comes from bits 16.., the 8-bit fingerprint kept in the slot word from the top
+__device__ __forceinline__ uint64_t big_hash(uint32_t seg, uint32_t mo, uint64_t lo, uint64_t hi) {
     uint64_t h = big_mix(lo ^ 0x9E3779B97F4A7C15ULL);
     h = big_mix(h + (uint64_t)mo * 0xD6E8FEB86659FD93ULL + (uint64_t)seg * 0xA0761D6478BD642FULL);
-    h = big_mix(h ^ hi);
-    return (uint32_t)(h >> 16) & mask;
+    return big_mix(h ^ hi);
 }
+__device__ __forceinline__ uint32_t big_home(uint64_t h, uint32_t mask) { return (uint32_t)(h >> 16) & mask; }
+__device__ __forceinline__ uint32_t big_fp(uint64_t h) { return (uint32_t)(h >> 56); }
 
 // segment of raw place p: the last s with seg_first[s] <= p (segments with no place share their start with the next one)
 __device__ __forceinline__ uint32_t big_segment(const uint32_t* __restrict__ seg_first, uint32_t n_seg, uint32_t p) {
@@ -51,8 +53,12 @@ __device__ __forceinline__ uint32_t big_segment(const uint32_t* __restrict__ seg
     return lo;
 }
 
-// slot word: [63:48] occurrences (wraps at 2^16; the uint8 rule reads it mod 256), [47:32] epoch, [31:0] claiming record + 1
-__device__ __forceinline__ uint32_t slot_epoch(unsigned long long wd) { return (uint32_t)(wd >> 32) & 0xffffu; }
+// slot word: [63:48] occurrences (wraps at 2^16; the uint8 rule reads it mod 256), [47:40] epoch, [39:32] fingerprint of the
+// claimer's key, [31:0] claiming record + 1.  The fingerprint only SKIPS comparisons (a probe that meets another key's slot --
+// three in ten at the table's load -- read that key's record, three random lines, to learn that it differs: a third of both
+// kernels' time at 4 x 10^7 keys); equal fingerprints are followed by the full comparison as before, so nothing is decided by it.
+__device__ __forceinline__ uint32_t slot_epoch(unsigned long long wd) { return (uint32_t)(wd >> 40) & 0xffu; }
+__device__ __forceinline__ uint32_t slot_fp(unsigned long long wd) { return (uint32_t)(wd >> 32) & 0xffu; }
 
 template <bool HAS_HI>
 __global__ __launch_bounds__(kBigThreads) void k_big_insert(const uint32_t* __restrict__ raw_mn, const uint64_t* __restrict__ raw_lo,
@@ -74,22 +80,27 @@ __global__ __launch_bounds__(kBigThreads) void k_big_insert(const uint32_t* __re
         const uint32_t mo = raw_mn[p];
         if (mo == 0xffffffffu) continue;                           // a place without a k-mer
         const uint64_t lo = raw_lo[p], hi = HAS_HI ? raw_hi[p] : 0ull;
-        const unsigned long long mine = ((unsigned long long)epoch << 32) | (unsigned long long)(p + 1);
-        uint32_t h = big_home(s, mo, lo, hi, mask);
+        // (a claim carries its own occurrence: one atomic per distinct key instead of a CAS and an add on the same line --
+        // a metagenome's keys are nearly all distinct, and the table's atomics are what this kernel's time is)
+        const uint64_t hh = big_hash(s, mo, lo, hi);
+        const uint32_t fp = big_fp(hh);
+        const unsigned long long mine = (1ull << 48) | ((unsigned long long)epoch << 40) | ((unsigned long long)fp << 32) | (unsigned long long)(p + 1);
+        uint32_t h = big_home(hh, mask);
         unsigned long long cur = slot[h];
+        bool claimed = false;
         for (;;) {                                                 // ends: at least twice as many slots as records
             if (slot_epoch(cur) != epoch) {                        // free (an older call's word, or never used)
                 const unsigned long long prev = atomicCAS(&slot[h], cur, mine);
-                if (prev == cur) break;                            // claimed
+                if (prev == cur) { claimed = true; break; }
                 cur = prev;                                        // somebody was faster (or the plain load was stale): look at what is there
                 continue;
             }
             const uint32_t c = (uint32_t)cur - 1;                  // the claimer's key was written by the kernel before this one
-            if (c - first < cnt && raw_lo[c] == lo && raw_mn[c] == mo && (!HAS_HI || raw_hi[c] == hi)) break;
+            if (slot_fp(cur) == fp && c - first < cnt && raw_lo[c] == lo && raw_mn[c] == mo && (!HAS_HI || raw_hi[c] == hi)) break;
             h = (h + 1) & mask;
             cur = slot[h];
         }
-        atomicAdd(&slot[h], 1ull << 48);
+        if (!claimed) atomicAdd(&slot[h], 1ull << 48);
     }
 }
 
@@ -118,12 +129,15 @@ __global__ __launch_bounds__(kBigThreads) void k_big_emit(const uint32_t* __rest
             }
             if (big && p - first < cnt && (mo = raw_mn[p]) != 0xffffffffu) {
                 lo = raw_lo[p]; hi = HAS_HI ? raw_hi[p] : 0ull;
-                uint32_t h = big_home(s, mo, lo, hi, mask);
+                const uint64_t hh = big_hash(s, mo, lo, hi);
+                const uint32_t fp = big_fp(hh);
+                uint32_t h = big_home(hh, mask);
                 unsigned long long cur;
                 for (;;) {                                         // this record's group: k_big_insert left it on this chain
                     cur = slot[h];
                     const uint32_t c = (uint32_t)cur - 1;
-                    if (c - first < cnt && raw_lo[c] == lo && raw_mn[c] == mo && (!HAS_HI || raw_hi[c] == hi)) break;
+                    if (c == p) break;                             // its own claim
+                    if (slot_epoch(cur) == epoch && slot_fp(cur) == fp && c - first < cnt && raw_lo[c] == lo && raw_mn[c] == mo && (!HAS_HI || raw_hi[c] == hi)) break;
                     h = (h + 1) & mask;
                 }
                 if ((uint32_t)cur == p + 1 && usable(cur)) {       // one lane per (key, orientation) group: its claimer
@@ -131,12 +145,14 @@ __global__ __launch_bounds__(kBigThreads) void k_big_emit(const uint32_t* __rest
                     if (s_lo_seen == 0xffffffffu) s_lo_seen = s;
                     if (mo >> 31) {                                // the forward-oriented group of the same canonical key emits if it is usable
                         const uint32_t sib = mo & 0x7fffffffu;
-                        uint32_t h2 = big_home(s, sib, lo, hi, mask);
+                        const uint64_t hs = big_hash(s, sib, lo, hi);
+                        const uint32_t fps = big_fp(hs);
+                        uint32_t h2 = big_home(hs, mask);
                         for (;;) {
                             const unsigned long long c2 = slot[h2];
                             if (slot_epoch(c2) != epoch) break;    // no such group
                             const uint32_t c = (uint32_t)c2 - 1;
-                            if (c - first < cnt && raw_lo[c] == lo && raw_mn[c] == sib && (!HAS_HI || raw_hi[c] == hi)) { if (usable(c2)) emit = false; break; }
+                            if (slot_fp(c2) == fps && c - first < cnt && raw_lo[c] == lo && raw_mn[c] == sib && (!HAS_HI || raw_hi[c] == hi)) { if (usable(c2)) emit = false; break; }
                             h2 = (h2 + 1) & mask;
                         }
                     }
@@ -148,33 +164,40 @@ __global__ __launch_bounds__(kBigThreads) void k_big_emit(const uint32_t* __rest
     // Places in the segment's output slice.  A workgroup's places nearly always lie in ONE segment: then its lanes' counts
     // are summed in LDS and the workgroup draws its room with one atomic (one per wave made k_big_emit wait on 600 000
     // same-address atomics at 4 x 10^7 keys); a workgroup that straddles segments draws per wave and segment.
-    __shared__ uint32_t s_wave[kBigThreads / 64], s_base, s_ref;
+    __shared__ uint32_t s_base, s_ref;
     const uint32_t p_first = blockIdx.x * kBigPer * kBigThreads;
     if (threadIdx.x == 0) s_ref = big_segment(seg_first, n_seg, p_first < n_places ? p_first : n_places - 1);
     __syncthreads();
     const uint32_t ref = s_ref;
     const bool one_segment = __syncthreads_and(emit_mask == 0 || (s_lo_seen == ref && s == ref)) != 0;
     if (one_segment) {
-        const uint32_t mine = (uint32_t)__popc(emit_mask);
-        uint32_t x = mine;
+        // output places in PLACE order (round u, then lane): the stores of one round are consecutive across a wave's lanes.
+        // (Lane-major places -- every lane's up to eight keys side by side -- made each store instruction touch 64 different
+        // lines: 2.5 of this kernel's 2.8 ms at 4 x 10^7 keys.)
+        __shared__ uint32_t s_cnt[kBigPer][kBigThreads / 64];
+        const uint32_t wv = threadIdx.x >> 6;
+        unsigned long long votes[kBigPer];
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d); if (lane >= (uint32_t)d) x += y; }
-        if (lane == 63) s_wave[threadIdx.x >> 6] = x;
+        for (uint32_t u = 0; u < kBigPer; ++u) {
+            votes[u] = __ballot((emit_mask >> u) & 1u);
+            if (lane == 0) s_cnt[u][wv] = (uint32_t)__popcll(votes[u]);
+        }
         __syncthreads();
         if (threadIdx.x == 0) {
             uint32_t tot = 0;
-            for (uint32_t wv = 0; wv < kBigThreads / 64; ++wv) tot += s_wave[wv];
+            for (uint32_t u = 0; u < kBigPer; ++u)
+                for (uint32_t w2 = 0; w2 < kBigThreads / 64; ++w2) { const uint32_t c = s_cnt[u][w2]; s_cnt[u][w2] = tot; tot += c; }
             s_base = tot ? atomicAdd(&distinct[ref], tot) : 0u;
         }
         __syncthreads();
-        uint32_t at = seg_first[ref] + s_base + x - mine;
-        for (uint32_t wv = 0; wv < (threadIdx.x >> 6); ++wv) at += s_wave[wv];
+        const uint32_t base = seg_first[ref] + s_base;
+#pragma unroll
         for (uint32_t u = 0; u < kBigPer; ++u) {
             if (!((emit_mask >> u) & 1u)) continue;
             const uint32_t p = (blockIdx.x * kBigPer + u) * kBigThreads + threadIdx.x;
+            const uint32_t at = base + s_cnt[u][wv] + (uint32_t)__popcll(votes[u] & ((1ull << lane) - 1ull));
             o_mn[at] = raw_mn[p] & 0x7fffffffu; o_lo[at] = raw_lo[p];
             if (HAS_HI) o_hi[at] = raw_hi[p];
-            ++at;
         }
         return;
     }
@@ -309,7 +332,7 @@ int big_dedupe_launch(spsp_ctx* ctx, bool has_hi, const uint32_t* raw_mn, const 
         if ((rc = ctx->b_table.reserve((size_t)slots * 8))) return rc;
         ctx->big_epoch = 0;                                        // fresh memory: no word of it means anything
     }
-    if (ctx->big_epoch == 0 || ctx->big_epoch == 0xffffu) {        // first use, or the 16-bit epoch wraps: every word becomes "free"
+    if (ctx->big_epoch == 0 || ctx->big_epoch == 0xffu) {          // first use, or the 8-bit epoch wraps: every word becomes "free"
         SPSP_HIP(hipMemsetAsync(ctx->b_table.p, 0, ctx->b_table.cap, ctx->stream));
         ctx->big_epoch = 0;
     }

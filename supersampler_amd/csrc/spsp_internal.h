@@ -161,7 +161,7 @@ struct spsp_ctx {
     // ingest workspace (GPU-side getLineFasta + clean_dna)
     spsp::DevBuf i_text, i_tiles, i_entry, i_outoff, i_recbase, i_lens, i_dst, i_compact;
     // compare workspace
-    spsp::DevBuf c_min, c_lo, c_hi, c_table, c_owner, c_rowid, c_row, c_matrix, c_inter, c_flags, c_skoff, c_slot_lo, c_slot_hi, c_slot_mn, c_part_cnt, c_recs, c_where, c_lref, c_filter, c_bits, c_sig, c_order, c_multi;
+    spsp::DevBuf c_min, c_lo, c_hi, c_table, c_owner, c_rowid, c_row, c_matrix, c_inter, c_flags, c_skoff, c_slot_lo, c_slot_hi, c_slot_mn, c_part_cnt, c_recs, c_where, c_lref, c_filter, c_bits, c_sig, c_order, c_multi, scan_blocks;
     uint64_t spill_expect = 0;     // records the last unfiltered partition-form comparison had in overflowed parts (0: none) -- see spill_plan
     uint32_t filter_skipped = 0;
     double filter_ratio = 1.0;   // records dealt into parts per owned key in the last filtered comparison (sizes the next one's parts)

@@ -192,6 +192,78 @@ __device__ __forceinline__ uint64_t keys_mix(uint64_t x) {
 // One super-k-mer's k-mer places as raw records (minimizer | orientation << 31, canonical k-mer) for the table in HBM of
 // spsp_bigkeys.hip: place0 + j = k-mer j, 0xffffffff where the super-k-mer has fewer than w.  Rolled base by base from
 // global memory: only the genomes that do not fit a workgroup's LDS come this way.
+// The same records, one lane per k-mer PLACE (round 5): a workgroup takes 1024 consecutive places, finds the super-k-mer of
+// the first one (64 probes per search step), stages the place offsets of the <= 1024 super-k-mers that can own them in LDS
+// and every lane cuts its k-mer out of the bases by a shift -- coalesced stores, no serial roll.  (One lane per super-k-mer
+// wrote its ~50 places one after the other, every store of a wave to 64 different lines: 2.7 ms for 4 x 10^7 places of a
+// metagenome segment, BASELINE configs[4].)
+constexpr uint32_t kPlaceThreads = 256, kPlacePer = 4, kPlaceTile = kPlaceThreads * kPlacePer;
+__global__ __launch_bounds__(kPlaceThreads) void k_keys_emit_places(const uint8_t* __restrict__ bases, bool packed, const uint64_t* __restrict__ rec_off,
+                                                                   const spsp_superkmer* __restrict__ sk, const uint32_t* __restrict__ raw_first,
+                                                                   const uint32_t* __restrict__ cnt, uint32_t n_sk, uint32_t k,
+                                                                   uint32_t* __restrict__ r_mn, uint64_t* __restrict__ r_lo, uint64_t* __restrict__ r_hi) {
+    __shared__ uint32_t s_first[kPlaceTile + 1];
+    __shared__ uint32_t s_i0;
+    const uint32_t t = threadIdx.x, lane = t & 63u;
+    const uint32_t total = raw_first[n_sk - 1] + cnt[n_sk - 1];
+    const uint32_t P0 = blockIdx.x * kPlaceTile;
+    if (P0 >= total) return;
+    if (t < 64) {                                                  // the last super-k-mer whose first place is <= P0
+        uint32_t lo = 0, hi = n_sk;                                // answer in [lo, hi): raw_first[lo] <= P0 (raw_first[0] = 0)
+        while (hi - lo > 1) {
+            const uint32_t span = hi - lo - 1, step = (span + 63) / 64;       // probes lo + step, lo + 2 step, ...
+            const uint32_t at = lo + (lane + 1) * step;
+            const bool le = at < hi && raw_first[at] <= P0;
+            const uint32_t nle = (uint32_t)__popcll(__ballot(le));           // probes 1 .. nle are <= P0 (monotone)
+            const uint32_t new_lo = lo + nle * step, next = new_lo + step;
+            hi = next < hi ? next : hi;
+            lo = new_lo;
+        }
+        if (lane == 0) s_i0 = lo;
+    }
+    __syncthreads();
+    const uint32_t i0 = s_i0;
+    for (uint32_t x = t; x <= kPlaceTile; x += kPlaceThreads) s_first[x] = i0 + x < n_sk ? raw_first[i0 + x] : 0xffffffffu;
+    __syncthreads();
+    const uint32_t* words = reinterpret_cast<const uint32_t*>(bases);
+    const u128d mask = k == 64 ? ~(u128d)0 : (((u128d)1 << (2 * k)) - 1);
+#pragma unroll 1
+    for (uint32_t u = 0; u < kPlacePer; ++u) {
+        const uint32_t o = P0 + u * kPlaceThreads + t;
+        if (o >= total) break;
+        uint32_t x = 0;                                            // the last staged super-k-mer whose first place is <= o (one without places
+#pragma unroll                                                     // shares its offset with the next one: the last of equals owns the place)
+        for (uint32_t step = kPlaceTile / 2; step; step >>= 1) if (s_first[x + step] <= o) x += step;
+        uint32_t i = i0 + x, first = s_first[x];
+        spsp_superkmer e = sk[i];
+        if (o - first >= (e.len >= k ? e.len - k + 1 : 0u)) {      // (more than 1024 super-k-mers without a place in front of this one: never from
+            uint32_t lo = i, hi = n_sk;                            // the scan, which emits no super-k-mer below k bases -- searched, not assumed)
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (raw_first[mid] <= o) lo = mid; else hi = mid; }
+            i = lo; first = raw_first[i]; e = sk[i];
+        }
+        const uint64_t q = rec_off[e.rec] + e.start + (o - first);          // first base of this place's k-mer
+        u128d fwd;
+        if (packed) {
+            const uint32_t* W = words + (q >> 4);
+            const uint32_t sh = 2u * (uint32_t)(q & 15u);
+            const u128d top = ((u128d)W[0] << 96) | ((u128d)W[1] << 64) | ((u128d)W[2] << 32) | (u128d)W[3];
+            const u128d win = sh ? (top << sh) | ((u128d)W[4] >> (32u - sh)) : top;      // 64 bases from q on (256 readable bytes follow the last word)
+            fwd = win >> (128u - 2u * k);
+        } else {
+            fwd = 0;
+            for (uint32_t b = 0; b < k; ++b) fwd = (fwd << 2) | (((uint32_t)bases[q + b] >> 1) & 3u);
+        }
+        const u128d top_aligned = fwd << (128u - 2u * k);
+        const u128d rcw = ((u128d)rc_window64((uint64_t)top_aligned) << 64) | (u128d)rc_window64((uint64_t)(top_aligned >> 64));
+        const u128d rc = rcw & mask;
+        const u128d canon = fwd < rc ? fwd : rc;
+        const u128d oriented = e.rev ? rc : fwd;
+        r_mn[o] = e.minimizer | (oriented != canon ? 0x80000000u : 0u);
+        r_lo[o] = (uint64_t)canon;
+        if (r_hi) r_hi[o] = (uint64_t)(canon >> 64);
+    }
+}
+
 __device__ __noinline__ void roll_places(const uint8_t* __restrict__ bases, bool packed, const uint64_t* __restrict__ rec_off, const spsp_superkmer e,
                                          uint32_t k, uint32_t w, uint32_t place0, uint32_t* __restrict__ r_mn, uint64_t* __restrict__ r_lo,
                                          uint64_t* __restrict__ r_hi) {
@@ -578,8 +650,14 @@ int sketch_keys_begin_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d
         }
         if ((rc = launch_scan_u32(ctx, ctx->a_cnt.as<uint32_t>(), ctx->a_off.as<uint32_t>(), n, ctx->h_scalar + 7))) return rc;
         if (n) {
-            hipLaunchKernelGGL(k_keys_emit, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_bases, packed, d_rec_off, d_sk, ctx->a_off.as<uint32_t>(), n, p->k,
-                               a_mn, a_lo, a_hi);
+            // one lane per place from a few places per super-k-mer on (SPSP_DEBUG_KEYS_EMIT=sk: one lane per super-k-mer always)
+            static const char* dbg_emit = getenv("SPSP_DEBUG_KEYS_EMIT");
+            if (dbg_emit && dbg_emit[0] == 's')
+                hipLaunchKernelGGL(k_keys_emit, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, d_bases, packed, d_rec_off, d_sk, ctx->a_off.as<uint32_t>(), n, p->k,
+                                   a_mn, a_lo, a_hi);
+            else
+                hipLaunchKernelGGL(k_keys_emit_places, dim3((uint32_t)((bound + kPlaceTile - 1) / kPlaceTile)), dim3(kPlaceThreads), 0, ctx->stream, d_bases, packed,
+                                   d_rec_off, d_sk, ctx->a_off.as<uint32_t>(), ctx->a_cnt.as<uint32_t>(), n, p->k, a_mn, a_lo, a_hi);
             SPSP_HIP(hipGetLastError());
         }
         hipLaunchKernelGGL(k_keys_ranges, dim3((n_genomes + 1 + 255) / 256), dim3(256), 0, ctx->stream, d_sk, n, ctx->a_off.as<uint32_t>(), d_first_rec,

@@ -619,6 +619,9 @@ __global__ __launch_bounds__(64 * kPairWaves) void k_dense_single(const uint8_t*
             drain(64);
         }
     };
+    const bool halo_lane = lane >= kRowChunks;
+    uint32_t rel = lane * kChunk;
+    const uint32_t rel_step = (uint32_t)row_bytes;
     const uint64_t full_rows = n >= 64 * kChunk ? (n - 64 * kChunk) / kRowPosPair63 + 1 : 0;
     const uint64_t n_fast_all = first < full_rows ? full_rows - first : 0;
     const uint64_t n_fast = n_fast_all < n_my ? n_fast_all : n_my;
@@ -627,9 +630,6 @@ __global__ __launch_bounds__(64 * kPairWaves) void k_dense_single(const uint8_t*
     uint4 raw0 = make_uint4(0, 0, 0, 0), raw1 = raw0;
     if (i < n_fast) raw0 = load_row16(ptr);
     if (i + 1 < n_fast) raw1 = load_row16(ptr + row_bytes);
-    const bool halo_lane = lane >= kRowChunks;
-    uint32_t rel = lane * kChunk;
-    const uint32_t rel_step = (uint32_t)row_bytes;
     auto body = [&](uint4& raw, uint64_t r, const uint8_t* at, uint32_t rl) {
         const uint32_t hi = pack16(raw);
         raw = load_row16(r + 2 < n_fast ? at + 2 * row_bytes : at);
@@ -959,7 +959,9 @@ __device__ __forceinline__ uint32_t bloom_lookup16(const uint32_t* __restrict__ 
 
 constexpr int kBloomBytes = 131072;
 
-template <int M>
+// PACKED: 2-bit input as k_dense_pair<., true> reads it (one dword per lane and row, the ingest's k_clean_write<PACK> makes it):
+// a quarter of the stream and no pack16 in a kernel that is bound by its instruction issue
+template <int M, bool PACKED>
 __global__ __launch_bounds__(64 * kPairWaves) void k_dense_bloom(const uint8_t* __restrict__ bases, uint64_t n, uint64_t thr,
                                                                 const uint32_t* __restrict__ bloom, uint64_t n_rows, WaveLists L) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds1[];
@@ -1032,6 +1034,46 @@ __global__ __launch_bounds__(64 * kPairWaves) void k_dense_bloom(const uint8_t* 
             drain(64);
         }
     };
+    const bool halo_lane = lane >= kRowChunks;
+    uint32_t rel = lane * kChunk;
+    const uint32_t rel_step = (uint32_t)row_bytes;
+    if (PACKED) {
+        const uint32_t* b32 = reinterpret_cast<const uint32_t*>(bases);
+        const uint64_t n_dw = (n + kChunk - 1) / kChunk;                        // dwords that hold bases (the tail of the last one is 0)
+        const uint64_t full_p = n_dw >= 64 ? (n_dw - 64) / kRowChunks + 1 : 0;  // rows whose 64 dwords (halo included) exist
+        const uint64_t nf_all = first < full_p ? full_p - first : 0;
+        const uint64_t nf = nf_all < n_my ? nf_all : n_my;
+        const uint32_t* p = b32 + first * kRowChunks + lane;
+        constexpr uint32_t rs = kRowChunks;                                     // dwords per row
+        uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+        if (0 < nf) r0 = __builtin_nontemporal_load(p);
+        if (1 < nf) r1 = __builtin_nontemporal_load(p + rs);
+        if (2 < nf) r2 = __builtin_nontemporal_load(p + 2 * rs);
+        if (3 < nf) r3 = __builtin_nontemporal_load(p + 3 * rs);
+        uint64_t i = 0;
+        auto row = [&](uint32_t& r, uint64_t ahead, uint32_t rl) {             // (unconditional refill: past its last row a wave re-reads its current one)
+            const uint32_t hi = r; r = __builtin_nontemporal_load(i + ahead < nf ? p + ahead * rs : p);
+            const uint32_t nxt = next_lane(hi);
+            const uint32_t c = bloom_lookup16<M>(tab, hi, nxt);
+            handle(halo_lane ? 0u : c, rl, hi, nxt);
+        };
+        for (; i + 3 < nf; i += 4, p += 4 * rs, rel += 4 * rel_step) {
+            row(r0, 4, rel);
+            row(r1, 5, rel + rel_step);
+            row(r2, 6, rel + 2 * rel_step);
+            row(r3, 7, rel + 3 * rel_step);
+        }
+        for (; i < n_my; ++i, rel += rel_step) {        // up to three rows left, and the rows at the end of the buffer
+            const uint64_t at = (first + i) * kRowChunks + lane;
+            const uint32_t hi = at < n_dw ? b32[at] : 0u;
+            const uint32_t nxt = next_lane(hi);
+            const uint32_t c = bloom_lookup16<M>(tab, hi, nxt);
+            handle(halo_lane ? 0u : c, rel, hi, nxt);
+        }
+        drain(1);
+        if (lane == 0) L.cnt[gw] = out_n;
+        return;
+    }
     const uint64_t full_rows = n >= 64 * kChunk ? (n - 64 * kChunk) / kRowPosPair63 + 1 : 0;
     const uint64_t n_fast_all = first < full_rows ? full_rows - first : 0;
     const uint64_t n_fast = n_fast_all < n_my ? n_fast_all : n_my;
@@ -1040,9 +1082,6 @@ __global__ __launch_bounds__(64 * kPairWaves) void k_dense_bloom(const uint8_t* 
     uint4 raw0 = make_uint4(0, 0, 0, 0), raw1 = raw0;
     if (i < n_fast) raw0 = load_row16(ptr);
     if (i + 1 < n_fast) raw1 = load_row16(ptr + row_bytes);
-    const bool halo_lane = lane >= kRowChunks;
-    uint32_t rel = lane * kChunk;
-    const uint32_t rel_step = (uint32_t)row_bytes;
     auto body = [&](uint4& raw, uint64_t r, const uint8_t* at, uint32_t rl) {
         const uint32_t hi = pack16(raw);
         raw = load_row16(r + 2 < n_fast ? at + 2 * row_bytes : at);
@@ -1426,7 +1465,55 @@ __global__ __launch_bounds__(64) void k_super_sums(uint32_t* __restrict__ chunk_
     if (threadIdx.x == 0) chunk_sum[n_chunks + blockIdx.x] = v;
 }
 
+// Long inputs (the super-k-mers of a metagenome segment: 8 x 10^5 counts) in blocks: one workgroup's rounds over all of them
+// were 0.75 ms of a 7 ms key extraction.  Block sums -> their scan (the single-workgroup kernel, which also publishes the
+// total) -> every block scanned from its offset.
+constexpr uint32_t kScanBlock = 8192;
+__global__ __launch_bounds__(1024) void k_scan_block_sums(const uint32_t* __restrict__ in, uint64_t n, uint32_t* __restrict__ sums) {
+    __shared__ uint32_t wave_sum[16];
+    const uint64_t base = (uint64_t)blockIdx.x * kScanBlock + (uint64_t)threadIdx.x * 8;
+    uint32_t sum = 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sum += base + u < n ? in[base + u] : 0u;
+#pragma unroll
+    for (int d = 32; d; d >>= 1) sum += __shfl_xor(sum, d);
+    if ((threadIdx.x & 63u) == 0) wave_sum[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t all = 0; for (uint32_t w = 0; w < 16; ++w) all += wave_sum[w]; sums[blockIdx.x] = all; }
+}
+__global__ __launch_bounds__(1024) void k_scan_blocks(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint64_t n,
+                                                     const uint32_t* __restrict__ block_off) {
+    __shared__ uint32_t wave_sum[16];
+    const uint32_t t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const uint64_t i0 = (uint64_t)blockIdx.x * kScanBlock + (uint64_t)t * 8;
+    uint32_t v[8], sum = 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { v[u] = i0 + u < n ? in[i0 + u] : 0u; sum += v[u]; }
+    uint32_t x = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t y = __shfl_up(x, d); if (lane >= (uint32_t)d) x += y; }
+    if (lane == 63) wave_sum[wid] = x;
+    __syncthreads();
+    uint32_t pre = 0;
+    for (uint32_t w = 0; w < wid; ++w) pre += wave_sum[w];
+    uint32_t run = block_off[blockIdx.x] + pre + x - sum;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { if (i0 + u < n) out[i0 + u] = run; run += v[u]; }
+}
 int launch_scan_u32(spsp_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, uint64_t n, uint64_t* total_host) {
+    if (n > 4 * (uint64_t)kScanBlock) {
+        const uint32_t blocks = (uint32_t)((n + kScanBlock - 1) / kScanBlock);
+        int rc = ctx->scan_blocks.reserve((size_t)(2 * blocks + 2) * 4);
+        if (rc) return rc;
+        uint32_t* sums = ctx->scan_blocks.as<uint32_t>();
+        uint32_t* offs = sums + blocks;                                  // [blocks + 1]: the scan's own total lands in offs[blocks]
+        hipLaunchKernelGGL(k_scan_block_sums, dim3(blocks), dim3(1024), 0, ctx->stream, d_in, n, sums);
+        hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t*)sums, offs, (uint64_t)blocks, (const uint32_t*)nullptr,
+                           total_host, d_out + n);                       // out[n] = total, as the one-kernel form leaves it
+        hipLaunchKernelGGL(k_scan_blocks, dim3(blocks), dim3(1024), 0, ctx->stream, d_in, d_out, n, (const uint32_t*)offs);
+        SPSP_HIP(hipGetLastError());
+        return SPSP_OK;
+    }
     hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, ctx->stream, d_in, d_out, n, (const uint32_t*)nullptr,
                        total_host, (uint32_t*)nullptr);
     SPSP_HIP(hipGetLastError());
@@ -1445,7 +1532,7 @@ int check_params(const spsp_params* p) {
 // P(hash <= T) times the m-mers (both strands) that share one table bit.
 enum { kDenseDirect = 0, kDenseSingle = 1, kDensePair = 2, kDenseBloom = 3 };
 static int pick_dense(const spsp_params* p);
-bool scan_reads_packed(const spsp_params* p) { return pick_dense(p) == kDensePair; }
+bool scan_reads_packed(const spsp_params* p) { const int v = pick_dense(p); return v == kDensePair || v == kDenseBloom; }
 static int pick_dense(const spsp_params* p) {
     const bool bloom_ok = p->m == 13 || p->m == 15;
     if (p->flags & SPSP_SCAN_DIRECT_HASH) return kDenseDirect;
@@ -1546,11 +1633,11 @@ static int plan_lists(spsp_ctx* ctx, const spsp_params* p, int variant, uint64_t
     return SPSP_OK;
 }
 
-// SPSP_SCAN_PACKED_INPUT: only the pair-table pass reads 2-bit input; every other variant (and the bitmap fallback) gets
-// an ASCII copy made on the device.  Returns the buffer and flags the pass should use.
+// SPSP_SCAN_PACKED_INPUT: the pair-table pass and the blocked-Bloom pass read 2-bit input; the other variants (and the bitmap
+// fallback) get an ASCII copy made on the device.  Returns the buffer and flags the pass should use.
 static int unpack_if_needed(spsp_ctx* ctx, spsp_params* p, const uint8_t** d_bases, uint64_t n_bases, bool use_bitmap) {
     if (!(p->flags & SPSP_SCAN_PACKED_INPUT)) return SPSP_OK;
-    if (!use_bitmap && pick_dense(p) == kDensePair) return SPSP_OK;
+    if (!use_bitmap && (pick_dense(p) == kDensePair || pick_dense(p) == kDenseBloom)) return SPSP_OK;
     int rc = ctx->unpacked.reserve((size_t)n_bases + 64);
     if (rc) return rc;
     hipLaunchKernelGGL(k_unpack_bases, dim3((uint32_t)std::min<uint64_t>((n_bases / kChunk + 256) / 256, (uint64_t)ctx->n_cu * 32)), dim3(256), 0,
@@ -1578,8 +1665,8 @@ static int launch_dense(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_ba
     int rc;
     const int variant = use_bitmap ? kDenseDirect : pick_dense(p);
     *lists = variant != kDenseDirect;
-    const bool packed_in = (p->flags & SPSP_SCAN_PACKED_INPUT) != 0;      // (only the pair-table pass gets here with it: unpack_if_needed)
-    if (packed_in && variant != kDensePair) { set_error("internal: packed input reached the %d dense variant", variant); return SPSP_ERR_ARG; }
+    const bool packed_in = (p->flags & SPSP_SCAN_PACKED_INPUT) != 0;      // (only the pair-table and Bloom passes get here with it: unpack_if_needed)
+    if (packed_in && variant != kDensePair && variant != kDenseBloom) { set_error("internal: packed input reached the %d dense variant", variant); return SPSP_ERR_ARG; }
     if ((rc = ctx->d_scalar.reserve(64))) return rc;
     if (*lists) {
         if ((rc = plan_lists(ctx, p, variant, n_bases, LP))) return rc;
@@ -1621,14 +1708,17 @@ static int launch_dense(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_ba
         } else if (variant == kDenseBloom) {
             const size_t lds = (size_t)kBloomBytes + (size_t)kPairWaves * kQueueCap1 * 8;
             if (!ctx->attr_bloom_set) {
-                SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_bloom<15>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_bloom<13>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_bloom<15, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_bloom<13, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_bloom<15, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                SPSP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dense_bloom<13, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 ctx->attr_bloom_set = true;
             }
-            if (p->m == 15) hipExtLaunchKernelGGL(k_dense_bloom<15>, dim3(LP->grid), dim3(64 * kPairWaves), lds, ctx->stream, ev_start, ev_stop, 0, d_bases, n_bases,
-                                               p->threshold, ctx->bloom.as<uint32_t>(), LP->n_rows, L);
-            else hipExtLaunchKernelGGL(k_dense_bloom<13>, dim3(LP->grid), dim3(64 * kPairWaves), lds, ctx->stream, ev_start, ev_stop, 0, d_bases, n_bases,
-                                    p->threshold, ctx->bloom.as<uint32_t>(), LP->n_rows, L);
+#define SPSP_BLOOM(MV, PK) hipExtLaunchKernelGGL((k_dense_bloom<MV, PK>), dim3(LP->grid), dim3(64 * kPairWaves), lds, ctx->stream, ev_start, ev_stop, 0, d_bases, n_bases, \
+                                                 p->threshold, ctx->bloom.as<uint32_t>(), LP->n_rows, L)
+            if (packed_in) { if (p->m == 15) SPSP_BLOOM(15, true); else SPSP_BLOOM(13, true); }
+            else { if (p->m == 15) SPSP_BLOOM(15, false); else SPSP_BLOOM(13, false); }
+#undef SPSP_BLOOM
         } else {
             const size_t lds = (size_t)kKey10Bytes + (size_t)kPairWaves * kQueueCap1 * 8;
             if (!ctx->attr_single_set) {

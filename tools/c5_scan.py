@@ -3,6 +3,7 @@
 segments generated on the GPU (seeded; nothing is stored).  Every segment is one spsp_scan_device call; the
 super-k-mer streams are checked for their invariants (ordered, disjoint per record, inside records) and the number
 of selected k-mers against the expectation n/s.  Prints one JSON document.
+C5_PACKED=1: the segments as 2-bit words (spsp_pack_bases_device; SPSP_SCAN_PACKED_INPUT), what the FASTA ingest hands the scan.
 usage (GPU box): python tools/c5_scan.py [total_gbp=50] [segment_gbp=5]"""
 import json
 import os
@@ -32,7 +33,8 @@ def main():
     off = torch.arange(0, n_rec + 1, dtype=torch.int64, device=dev) * rec_len
     ctx = sp.Context(0)
     k, m, s = 63, 15, 100.0
-    p = sp.make_params(k, m, s)
+    packed = os.environ.get("C5_PACKED") == "1"
+    p = sp.make_params(k, m, s, flags=sp.SPSP_SCAN_PACKED_INPUT if packed else 0)
     ctx.timing_enable(True, sp.TIME_DENSE | sp.TIME_SCAN)
     segs = []
     tot_kmers = tot_sel = tot_sk = 0
@@ -43,11 +45,13 @@ def main():
             b = min(seg_n, a + step)
             bases[a:b] = lut[torch.randint(0, 4, (b - a,), device=dev, generator=g, dtype=torch.int64)]
         torch.cuda.synchronize()
+        src = ctx.pack_bases_device(bases.data_ptr(), seg_n) if packed else bases.data_ptr()
+        torch.cuda.synchronize()
         if si == 0:
-            ctx.scan_device(p, bases.data_ptr(), seg_n, off.data_ptr(), n_rec)      # warm-up: tables, buffers
+            ctx.scan_device(p, src, seg_n, off.data_ptr(), n_rec)      # warm-up: tables, buffers
             ctx.timing_read()
         t0 = time.perf_counter()
-        d_out, n_out = ctx.scan_device(p, bases.data_ptr(), seg_n, off.data_ptr(), n_rec)
+        d_out, n_out = ctx.scan_device(p, src, seg_n, off.data_ptr(), n_rec)
         wall = time.perf_counter() - t0
         t = ctx.timing_read()
         sk = ctx.to_host(d_out, n_out, sp.SUPERKMER_DTYPE)
@@ -63,7 +67,7 @@ def main():
         dense_ms += t["dense_ms"]; scan_ms += t["scan_ms"]; wall_s += wall
         print("segment %d/%d: %.1f Gbp scan %.2f ms (dense %.2f ms), %d super-k-mers, %d selected k-mers"
               % (si + 1, n_seg, seg_n / 1e9, t["scan_ms"], t["dense_ms"], n_out, sel), file=sys.stderr, flush=True)
-    doc = {"workload": "BASELINE configs[4]: %.0f Gbp as %d segments of %d records x 10^6 bp, k=63 m=15 s=100, generated on the GPU (seed 5)"
+    doc = {"input": "2-bit packed" if packed else "ASCII", "workload": "BASELINE configs[4]: %.0f Gbp as %d segments of %d records x 10^6 bp, k=63 m=15 s=100, generated on the GPU (seed 5)"
                        % (n_seg * seg_n / 1e9, n_seg, n_rec),
            "kmers": tot_kmers, "scan_pipeline_ms_total": scan_ms, "dense_kernel_ms_total": dense_ms, "host_wall_s_scan_calls": wall_s,
            "kmers_per_s_scan_pipeline": tot_kmers / (scan_ms / 1e3), "kmers_per_s_host_wall": tot_kmers / wall_s,
