@@ -105,13 +105,31 @@ def cpu_model():
     return "unknown"
 
 
+# Knobs of the step's schedule and of analysis runs (tools/exp/*.sh): read through xenv(), which returns the
+# default unless the run was started with --experiment -- a line made with --experiment is never a valid measurement
+EXPERIMENT_KNOBS = ("BENCH_PIPELINE", "BENCH_SCHEDULE", "BENCH_SMALL_CUS", "BENCH_DENSE_FIRST_CU", "BENCH_DENSE_STREAMS", "BENCH_SCAN_BUFFERS", "BENCH_SLOTS", "BENCH_SMALL_STREAMS", "BENCH_BATCHES", "BENCH_SIM_WORLD", "BENCH_ROWS", "BENCH_EXCHANGE", "BENCH_SLOT_REDUCE", "BENCH_DEVICE_KEYS", "BENCH_DEBUG_SKIP_COMPARE", "BENCH_KEYS_STREAM", "BENCH_KEYS_CUS", "BENCH_KEYS_STREAMS", "BENCH_DEBUG_NOISE_KERNELS", "BENCH_COLLECT_DEPTH", "BENCH_STAGE_TIMING", "BENCH_TIMING_EVERY")
+XENV = {"on": False, "ignored": []}
+
+
+def xenv(name, default=None):
+    if XENV["on"]:
+        return os.environ.get(name, default)
+    if name in os.environ and name not in XENV["ignored"]:
+        XENV["ignored"].append(name)
+    return default
+
+
 def env_report():
     """Every BENCH_* / SPSP_* variable that is set goes into the line (`config.env`): a stale variable on the box must not
     change the headline silently.  Variables that take work out of the timed region, replace the library or the transport,
     or exist for analysis only make the line INVALID as a measurement (`valid`: false, with the reasons)."""
     env = {k: v for k, v in sorted(os.environ.items()) if k.startswith(("BENCH_", "SPSP_"))}
     why = []
+    if XENV["on"]:
+        why.append("--experiment: the schedule / analysis knobs are honoured")
     for k, v in env.items():
+        if k in XENV["ignored"]:
+            continue                                          # set, but this run was not started with --experiment: not read
         if "_DEBUG_" in k or "_EXP_" in k:
             why.append("%s is an analysis / test hook" % k)
         elif k == "BENCH_DEVICE_KEYS" and v == "0":
@@ -144,7 +162,11 @@ def main():
     ap.add_argument("--mode", choices=["default", "direct", "filter", "pair"], default="default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the `compare` (config 3) and `end_to_end` objects")
+    ap.add_argument("--experiment", action="store_true",
+                    help="honour the schedule / analysis knobs (EXPERIMENT_KNOBS below); without it they are ignored, so that the "
+                         "headline path is the code as written with its defaults, whatever the environment holds")
     args = ap.parse_args()
+    XENV.update(on=args.experiment, ignored=[])
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -185,22 +207,22 @@ def main():
     # workgroup per CU and leaves the other half of every CU to it.  The host queues step t+1 before it collects
     # step t (scan_end / compare_end wait on per-job events, not on the streams).
     # BENCH_PIPELINE=0 runs the two halves back to back on one stream, one step at a time.
-    pipelined = os.environ.get("BENCH_PIPELINE", "1") != "0"
+    pipelined = xenv("BENCH_PIPELINE", "1") != "0"
     # BENCH_SCHEDULE: "single" = as above (0.158-0.163 ms); "streams" = every slot's scan on a stream of its own, its dense
     # pass behind the previous slot's by an event (0.167 ms); "tail" = scans on one stream, their sparse stages on
     # spsp_scan_tail_stream streams (0.18 ms)
     # "partition" = the chip is split (spsp_stream_create_cus): every dense pass runs on a stream that owns all but
     # BENCH_SMALL_CUS compute units, the sparse stages of every scan and every comparison on streams that own the rest
     # -- the dense passes run back to back and nothing that shares a CU with them slows them down
-    schedule = os.environ.get("BENCH_SCHEDULE", "partition")
+    schedule = xenv("BENCH_SCHEDULE", "partition")
     tail_streams = schedule in ("tail", "partition")
     # CUs of the small streams: a rank's share of the comparison grows with the world size (every rank streams the other
     # ranks' keys through its filter), so its streams get more of the chip -- measured with BENCH_SIM_WORLD (rank 0's
     # share, the largest; tools/sim_world_sweep.sh, ms per step at 64 / 96 / 128 CUs, rows in blocks): W = 2: 0.115 /
     # 0.124 / 0.144, W = 4: 0.142 / 0.124 / 0.147, W = 8: 0.185 / 0.149 / 0.148 (round 2, strided rows, every key
     # dealt on every rank: W = 4: 0.156 / 0.135 / 0.150, W = 8: 0.267 / 0.197 / 0.167)
-    sim_w = max(world, int(os.environ.get("BENCH_SIM_WORLD", "1")))
-    small_cus = int(os.environ.get("BENCH_SMALL_CUS", "64" if sim_w <= 2 else "96"))
+    sim_w = max(world, int(xenv("BENCH_SIM_WORLD", "1")))
+    small_cus = int(xenv("BENCH_SMALL_CUS", "64" if sim_w <= 2 else "96"))
     ctx_full, full_stream = ctx, stream                   # whole-device context: setup and the extras
     if schedule == "partition" and pipelined:
         try:                                              # (a runtime without CU masks: fall back to the unpartitioned schedule)
@@ -211,7 +233,7 @@ def main():
     if schedule == "partition" and pipelined:
         n_dev_cus = torch.cuda.get_device_properties(dev).multi_processor_count
         # BENCH_DENSE_FIRST_CU (experiment): the dense stream may start below the small streams' upper end, i.e. share CUs
-        dense_first = int(os.environ.get("BENCH_DENSE_FIRST_CU", str(small_cus)))
+        dense_first = int(xenv("BENCH_DENSE_FIRST_CU", str(small_cus)))
         dense_cus = n_dev_cus - dense_first
         masked = [sp.stream_create_cus(local_rank, dense_first, dense_cus)]
         stream = torch.cuda.ExternalStream(masked[0], device=dev)
@@ -223,13 +245,13 @@ def main():
         pass
 
     slots = []
-    dense_streams = int(os.environ.get("BENCH_DENSE_STREAMS", "1")) if (schedule == "partition" and pipelined) else 1
-    scan_buffers = int(os.environ.get("BENCH_SCAN_BUFFERS", "1")) if pipelined else 1
+    dense_streams = int(xenv("BENCH_DENSE_STREAMS", "1")) if (schedule == "partition" and pipelined) else 1
+    scan_buffers = int(xenv("BENCH_SCAN_BUFFERS", "1")) if pipelined else 1
     dense_extra = []
     # (four steps in flight: the closed step has more host work per visit -- two more queueing calls -- and the scans'
     # sparse stages finish later beside the key extraction: 0.134 / 0.127 / 0.124 ms per step with 2 / 3 / 4 slots)
     # (the multi-GPU step, which still compares the setup's keys, keeps the two slots it was tuned with)
-    for i in range(int(os.environ.get("BENCH_SLOTS", "2" if use_dist else "4")) if pipelined else 1):
+    for i in range(int(xenv("BENCH_SLOTS", "2" if use_dist else "4")) if pipelined else 1):
         sl = Slot()
         if pipelined:
             sl.stream_a = stream if (i == 0 or schedule != "streams") else torch.cuda.Stream(device=dev)
@@ -243,7 +265,7 @@ def main():
             sl.scan = ctx if i == 0 else sp.Context(local_rank, sl.stream_a.cuda_stream)
             if schedule == "partition":
                 sl.scan.set_cu_count(dense_cus, 2)
-                mode = os.environ.get("BENCH_SMALL_STREAMS", "shared")
+                mode = xenv("BENCH_SMALL_STREAMS", "shared")
                 if i == 0 or mode == "own":
                     # one stream for every slot's sparse stages and one for every comparison by default: every CU-masked
                     # stream is a hardware queue of its own, and a handful of them already delay each other's packets
@@ -301,7 +323,7 @@ def main():
     # that no step can be served by what the previous one left in the 256 MiB Infinity Cache (FETCH_SIZE counts its hits
     # as if they were HBM reads).  Batch b > 0 = batch 0 under a fixed permutation of the alphabet (A->C->G->T->A applied b
     # times): other k-mers, other minimizers, other hits -- the same records, family structure and base composition.
-    n_batches = max(1, int(os.environ.get("BENCH_BATCHES", "3")))
+    n_batches = max(1, int(xenv("BENCH_BATCHES", "3")))
     d_batches = [d_bases]
     for b in range(1, n_batches):
         lut = torch.arange(256, dtype=torch.uint8, device=dev)
@@ -329,19 +351,19 @@ def main():
     d_my_min = torch.from_numpy(my_min.view(np.int32)).to(dev)
     d_my_lo = torch.from_numpy(my_lo.view(np.int64)).to(dev)
     n_total = args.genomes * world
-    sim_world = int(os.environ.get("BENCH_SIM_WORLD", "1")) if not use_dist else 1
+    sim_world = int(xenv("BENCH_SIM_WORLD", "1")) if not use_dist else 1
     my_sk_off = np.zeros(args.genomes + 1, dtype=np.uint64)
     my_sk_off[1:] = np.cumsum(my_n)
     # rows of the pair matrix a rank owns after the all-gather: the BLOCK of the sketches it scanned (default: its
     # dictionary holds its own keys + what passes the filter) or every world-th row (BENCH_ROWS=strided)
-    row_form = os.environ.get("BENCH_ROWS", "block")
+    row_form = xenv("BENCH_ROWS", "block")
     # multi-GPU exchange: north_star's form (RCCL all-gather of the packed keys + row ownership) by default;
     # BENCH_EXCHANGE=slots selects the key-partitioned all-to-all + partial-matrix reduction (DESIGN.md 5 prices both)
-    exchange_kind = os.environ.get("BENCH_EXCHANGE", "gather") if use_dist else "none"
+    exchange_kind = xenv("BENCH_EXCHANGE", "gather") if use_dist else "none"
     if exchange_kind == "slots":      # key-partitioned: all-to-all of own keys + all-reduce of partial matrices
         for sl in slots:
             sl.exchange = spd.SlotExchange(sl.cmp, K, args.genomes, int(my_sk_off[-1]), dev, stream=sl.stream_b,
-                                           reduce=os.environ.get("BENCH_SLOT_REDUCE", "scatter"))
+                                           reduce=xenv("BENCH_SLOT_REDUCE", "scatter"))
         sk_off = np.zeros(n_total + 1, dtype=np.uint64)
         sk_off[-1] = slots[0].exchange.max_keys * world           # log line only
     elif exchange_kind == "gather":   # all-gather of every rank's keys; a rank owns the rows of the sketches it scanned
@@ -391,26 +413,26 @@ def main():
     # super-k-mer stream of an earlier step's scan (spsp_sketch_keys_device: what the comparator would read from the sketch
     # files of those genomes) -- no setup-time sketches inside the timed region.  BENCH_DEVICE_KEYS=0: the round-2 step
     # (keys of the setup's sketches, the same every step).
-    device_keys = (exchange_kind == "none" and sim_world == 1 and pipelined and os.environ.get("BENCH_DEVICE_KEYS", "1") != "0"
-                   and os.environ.get("BENCH_DEBUG_SKIP_COMPARE") != "1")
+    device_keys = (exchange_kind == "none" and sim_world == 1 and pipelined and xenv("BENCH_DEVICE_KEYS", "1") != "0"
+                   and xenv("BENCH_DEBUG_SKIP_COMPARE") != "1")
     if device_keys:
         # a third stream on the small CUs for the key extraction, two key contexts per slot (one's arrays are read by the
         # comparison in flight while the other's are being rewritten)
-        keys_stream = os.environ.get("BENCH_KEYS_STREAM", "own")  # "own" | "cmp" (the comparisons' stream) | "dense" (behind every dense pass)
+        keys_stream = xenv("BENCH_KEYS_STREAM", "own")  # "own" | "cmp" (the comparisons' stream) | "dense" (behind every dense pass)
         if keys_stream == "cmp":
             stream_k = slots[0].stream_b
         elif keys_stream == "dense":
             stream_k = stream
         elif schedule == "partition":
             # BENCH_KEYS_CUS="first,count" (experiment): the key extraction on a part of the small CUs only
-            k_first, k_cnt = (int(x) for x in os.environ.get("BENCH_KEYS_CUS", "0,%d" % small_cus).split(","))
+            k_first, k_cnt = (int(x) for x in xenv("BENCH_KEYS_CUS", "0,%d" % small_cus).split(","))
             masked.append(sp.stream_create_cus(local_rank, k_first, k_cnt))
             stream_k = torch.cuda.ExternalStream(masked[-1], device=dev)
         else:
             stream_k = torch.cuda.Stream(device=dev)
         # BENCH_KEYS_STREAMS=2 (experiment): the key extractions of consecutive steps on two streams over the same CUs
         streams_k = [stream_k]
-        if int(os.environ.get("BENCH_KEYS_STREAMS", "1")) > 1 and schedule == "partition" and keys_stream == "own":
+        if int(xenv("BENCH_KEYS_STREAMS", "1")) > 1 and schedule == "partition" and keys_stream == "own":
             masked.append(sp.stream_create_cus(local_rank, k_first, k_cnt))
             streams_k.append(torch.cuda.ExternalStream(masked[-1], device=dev))
         for si, sl in enumerate(slots):
@@ -427,7 +449,7 @@ def main():
 
     # analysis only (the line it prints is not a valid measurement): the step without its comparison, to see what the
     # comparison's kernels cost the dense pass they run beside
-    skip_compare = os.environ.get("BENCH_DEBUG_SKIP_COMPARE") == "1" and exchange_kind == "none"
+    skip_compare = xenv("BENCH_DEBUG_SKIP_COMPARE") == "1" and exchange_kind == "none"
 
     def on_b(sl):
         # torch ops and RCCL order themselves against torch's CURRENT stream: stream B of the slot.  Entering a stream
@@ -438,7 +460,7 @@ def main():
 
     # BENCH_DEBUG_NOISE_KERNELS=n (analysis only): n empty launches per step on a stream of the small CUs -- what kernel
     # boundaries beside a dense pass cost it, whatever the kernels do
-    noise_n = int(os.environ.get("BENCH_DEBUG_NOISE_KERNELS", "0"))
+    noise_n = int(xenv("BENCH_DEBUG_NOISE_KERNELS", "0"))
     if noise_n and schedule == "partition" and pipelined:
         masked.append(sp.stream_create_cus(local_rank, 0, small_cus))
         noise_stream = torch.cuda.ExternalStream(masked[-1], device=dev)
@@ -565,7 +587,7 @@ def main():
         import collections
         # a step is collected when `collect_depth` younger ones have been queued (default: when its slot comes round again).
         # BENCH_COLLECT_DEPTH < slots: earlier -- fewer chains left for the drain at the end of a short run, less slack for the host
-        collect_depth = min(len(slots), int(os.environ.get("BENCH_COLLECT_DEPTH", str(len(slots)))))
+        collect_depth = min(len(slots), int(xenv("BENCH_COLLECT_DEPTH", str(len(slots)))))
         pending = collections.deque()                     # steps queued and not yet collected, oldest first
         prev = None
         for i in range(n):
@@ -605,13 +627,13 @@ def main():
     run_steps(args.warmup)
     # the roofline needs the dense kernel's duration from HIP events in the timed region; the other brackets
     # (whole pipelines, accumulate kernel) are extra packets on the streams and are only recorded on request
-    kinds = sp.TIME_ALL if os.environ.get("BENCH_STAGE_TIMING", "0") == "1" or not pipelined else sp.TIME_DENSE
-    if os.environ.get("BENCH_STAGE_TIMING") == "off":     # experiment: what the event packets themselves cost
+    kinds = sp.TIME_ALL if xenv("BENCH_STAGE_TIMING", "0") == "1" or not pipelined else sp.TIME_DENSE
+    if xenv("BENCH_STAGE_TIMING") == "off":     # experiment: what the event packets themselves cost
         kinds = 0
     # every 8th dense pass is bracketed: two event packets per launch cost the pipelined step 8.6 us of 123 (measured,
     # BENCH_STAGE_TIMING=off); BENCH_TIMING_EVERY=1 brackets them all
     # (short runs -- the driver's --steps 20 -- bracket every 4th, so that a handful of launches is behind `roofline.achieved`)
-    timing_every = int(os.environ.get("BENCH_TIMING_EVERY", "8" if args.steps >= 64 else "4")) if pipelined and kinds == sp.TIME_DENSE else 1
+    timing_every = int(xenv("BENCH_TIMING_EVERY", "8" if args.steps >= 64 else "4")) if pipelined and kinds == sp.TIME_DENSE else 1
     for c in all_ctx:
         c.timing_enable(True, kinds)
         c.timing_sample(timing_every)
@@ -778,7 +800,7 @@ def main():
             "dtype": "u64",
             "data": "synthetic",
             "valid": not env_why, **({"invalid_because": env_why} if env_why else {}),
-            "config": {"env": env_set,
+            "config": {"env": env_set, **({"env_ignored_without_--experiment": sorted(XENV["ignored"])} if XENV["ignored"] else {}),
                        "workload": "BASELINE configs[1]: %d synthetic %d bp genomes per GPU (10 families, mu 0.001/0.01), "
                                    "k=31 m=11 s=1000, scan + all-vs-all; inputs resident in HBM; consecutive steps scan different batches "
                                    "(ring of %d x %d MB)" % (args.genomes, args.length, n_batches, d_bases.numel() // 1000000),
@@ -1372,6 +1394,27 @@ def scan_config5(ctx, dev, skip_oracle, peak, gbp=4.0):
                                                  "scaled_from_bases_per_launch": d["workload"]["bases_per_launch"]}
     except Exception:  # noqa: BLE001
         out["roofline"]["traffic"] = None
+    # the same segment as 2-bit words (what the FASTA ingest hands the scan: k_clean_write<PACK>): k_dense_bloom<15, true> reads
+    # them directly since round 5 -- no ASCII copy made on the device in front of the pass
+    try:
+        pp = sp.make_params(k, m, s, flags=sp.SPSP_SCAN_PACKED_INPUT)
+        d_pk = ctx.pack_bases_device(bases.data_ptr(), seg_n)
+        torch.cuda.synchronize()
+        ctx.scan_device(pp, d_pk, seg_n, off.data_ptr(), n_rec)
+        ctx.timing_enable(True, sp.TIME_DENSE | sp.TIME_SCAN)
+        ctx.timing_read()
+        for _ in range(reps):
+            d_out_p, n_out_p = ctx.scan_device(pp, d_pk, seg_n, off.data_ptr(), n_rec)
+        tp = ctx.timing_read()
+        ctx.timing_enable(False)
+        skp = ctx.to_host(d_out_p, n_out_p, sp.SUPERKMER_DTYPE)
+        dms, sms = tp["dense_ms"] / max(1, tp["dense_launches"]), tp["scan_ms"] / max(1, tp["scan_calls"])
+        out["packed_2bit"] = {"dense_kernel_ms": dms, "scan_pipeline_ms": sms, "kmers_per_s": kmers / (sms / 1e3),
+                              "byte_model": "0.25 B per m-mer position", "achieved_GBps": seg_n / 4 / 1e9 / (dms / 1e3),
+                              "same_stream_as_ascii": bool(n_out_p == n_out and all((skp[f] == sk[f]).all() for f in sk.dtype.names))}
+        d_out, n_out = ctx.scan_device(p, bases.data_ptr(), seg_n, off.data_ptr(), n_rec)      # (the key extraction below reads the ASCII scan's output)
+    except Exception as e:  # noqa: BLE001
+        out["packed_2bit"] = {"error": repr(e)}
     # From the scan to the comparator's keys: the segment as ONE sketch -- a metagenome file is one
     # sketch -- through spsp_sketch_keys_device: ~4 x 10^7 selected k-mers, four orders of magnitude beyond a workgroup's LDS:
     # the table in HBM of spsp_bigkeys.hip (and, in the sorted form, its merge sort).  Host wall clock around the call.
@@ -1392,6 +1435,13 @@ def scan_config5(ctx, dev, skip_oracle, peak, gbp=4.0):
                               "genomes_through_the_table_in_hbm": ctx.sketch_keys_big_genomes()}
     except Exception as e:  # noqa: BLE001
         out["sketch_keys"] = {"error": repr(e)}
+    # FILE -> SKETCH at this shape: the segment as ONE FASTA file on tmpfs through the file pipeline
+    # (spsp_sketch_files: read, ingest to 2-bit words, scan, gather, the host's sketch build -- handle_superkmer + emission,
+    # SubSampler.cpp:243-302, 458-620 -- gzip, write), stage seconds from the library
+    try:
+        out["sketch_file"] = sketch_file_config5(ctx, bases, n_rec, rec_len, k, m, s, skip_oracle)
+    except Exception as e:  # noqa: BLE001
+        out["sketch_file"] = {"error": repr(e)}
     if not skip_oracle:
         from oracle import oracle_py as orc
         orc.use_native()
@@ -1419,6 +1469,52 @@ def scan_config5(ctx, dev, skip_oracle, peak, gbp=4.0):
         except Exception as e:  # noqa: BLE001
             out["parity_vs_oracle"]["sketch_keys"] = {"error": repr(e)}
     return out
+
+
+def sketch_file_config5(ctx, bases, n_rec, rec_len, k, m, s, skip_oracle):
+    """one FASTA file of n_rec records x rec_len bp (the configs[4] segment) -> one sketch file; payload bytes against the
+    oracle's on a file of the first 100 records"""
+    import shutil
+    import tempfile
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    tmp = tempfile.mkdtemp(prefix="spsp_c5_", dir=base)
+    cores = max(1, min(len(os.sched_getaffinity(0)), int(os.environ.get("BENCH_HOST_THREADS", "16"))))
+    try:
+        def write(path, recs):
+            with open(path, "wb") as f:
+                for a in range(0, recs, 250):                # 250 Mbp of the segment at a time through the host
+                    hb = bases[a * rec_len:min(recs, a + 250) * rec_len].cpu().numpy()
+                    for r in range(len(hb) // rec_len):
+                        f.write(b">r%d\n" % (a + r))
+                        f.write(hb[r * rec_len:(r + 1) * rec_len].tobytes())
+                        f.write(b"\n")
+            return os.path.getsize(path)
+        big, small = os.path.join(tmp, "segment.fa"), os.path.join(tmp, "prefix.fa")
+        size = write(big, n_rec)
+        R = min(100, n_rec)
+        write(small, R)
+        kmers = n_rec * (rec_len - k + 1)
+        sp.sketch_files([small], [os.path.join(tmp, "prefix.gz")], k, m, s, threads=cores)          # buffers, tables, page cache of the small file
+        res = {}
+        for label, T in (("threads_%d" % cores, cores), ("threads_1", 1)):
+            t0 = time.perf_counter()
+            r, st, _ = sp.sketch_files([big], [os.path.join(tmp, "segment.gz")], k, m, s, threads=T)
+            wall = time.perf_counter() - t0
+            assert r[0][0] == 0, r[0]
+            res[label] = {"wall_s": wall, "kmers_per_s": kmers / wall, "fasta_GB_per_s": size / wall / 1e9,
+                          "stage_s_summed_over_workers": {key: st[key] for key in ("read_s", "ingest_s", "scan_s", "gather_s", "build_s", "gzip_s")},
+                          "selected_kmers": r[0][1]["selected_kmer_number"], "sketch_bytes": os.path.getsize(os.path.join(tmp, "segment.gz"))}
+        out = {"workload": "the segment as ONE FASTA file on %s: %d records x %d bp (%.2f GB), k=%d m=%d s=%g -> one sketch file (spsp_sketch_files, the "
+                           "library behind bin/sub_sampler)" % (base or "the temp dir", n_rec, rec_len, size / 1e9, k, m, s),
+               "kmers": kmers, "host_threads_available": cores, **res}
+        if not skip_oracle:
+            from oracle import oracle_py as orc
+            orc.use_native()
+            want = orc.sketch_fasta(open(small, "rb").read(), k, m, s)[0]
+            out["parity_vs_oracle"] = {"records": R, "payload_bytes": len(want), "equal": sp.read_file(os.path.join(tmp, "prefix.gz")) == want}
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def config3_true_shape(ctx, dev, n, with_oracle, seed=3, host_threads=None, unordered=False):

@@ -392,6 +392,12 @@ int spsp_csv_host(int jaccard, const char* const* names, uint32_t n, uint32_t n_
  * "0," between them and no n x n matrix is built or scanned.  Same bytes as spsp_csv_host on the dense matrix. */
 int spsp_csv_cells_host(int jaccard, const char* const* names, uint32_t n, uint32_t n_query, const uint64_t* cells, uint64_t n_cells,
                         const uint64_t* card, int precision, double min_threshold, char** text, uint64_t* len);
+/* The same matrix written straight to `gz_path` as the reference writes it (gzip, Comparator.cpp:363,413), without the text
+ * ever existing: row blocks become gzip members on the host threads, a run of "0," cells is two literals and a few deflate
+ * matches of distance 2, and the member's CRC-32 takes the run in 16 table steps (spsp_compare_files writes its two
+ * 10^8-cell matrices this way).  gunzip gives exactly the bytes spsp_csv_cells_host returns. */
+int spsp_csv_cells_gz_host(int jaccard, const char* const* names, uint32_t n, uint32_t n_query, const uint64_t* cells, uint64_t n_cells,
+                           const uint64_t* card, int precision, double min_threshold, const char* gz_path);
 
 /* sortCSV (sort_csv.cpp:26-111): rows and columns of a symmetric all-vs-all Jaccard CSV (gunzipped text) put into
  * the order of the original file of files.  Inputs the reference mishandles (name missing from the fof or listed

@@ -83,7 +83,7 @@ ABI_SYMBOLS = [
     "spsp_stream_create_cus", "spsp_stream_destroy", "spsp_set_cu_count", "spsp_pack_bases_device",
     "spsp_timing_enable", "spsp_timing_sample", "spsp_timing_read", "spsp_threshold_host", "spsp_scan", "spsp_scan_device", "spsp_scan_device_begin", "spsp_scan_device_end", "spsp_scan_tail_stream", "spsp_wait_dense", "spsp_wait_stream", "spsp_scan_hits_device", "spsp_count_superkmers_device", "spsp_compare",
     "spsp_compare_device", "spsp_slot_bytes", "spsp_partition_keys_device", "spsp_compare_slots_device", "spsp_compare_device_begin", "spsp_compare_slots_device_begin", "spsp_compare_end", "spsp_fasta_clean_host", "spsp_fasta_clean_device", "spsp_fasta_clean_packed_device", "spsp_sketch_text", "spsp_sketch_build_host", "spsp_sketch_parse_host", "spsp_sketch_decode_device", "spsp_sketch_keys_device", "spsp_sketch_keys_device_begin", "spsp_sketch_keys_device_end", "spsp_sketch_keys_big_genomes", "spsp_scan_output_wait", "spsp_compare_keys_unordered", "spsp_sketch_chain_host",
-    "spsp_csv_host", "spsp_csv_cells_host", "spsp_sort_csv_host", "spsp_read_file_host", "spsp_write_gz_host", "spsp_sketch_file", "spsp_compare_files", "spsp_compare_files_chatty", "spsp_stage_times_read", "spsp_measure_hbm_device", "spsp_sketch_files", "spsp_sketch_files_multi", "spsp_sketch_files_release", "spsp_compare_files_multi", "spsp_matrix_cells_device", "spsp_matrix_add_cells_device", "spsp_compare_cells_device", "spsp_compare_slots_cells_device",
+    "spsp_csv_host", "spsp_csv_cells_host", "spsp_csv_cells_gz_host", "spsp_sort_csv_host", "spsp_read_file_host", "spsp_write_gz_host", "spsp_sketch_file", "spsp_compare_files", "spsp_compare_files_chatty", "spsp_stage_times_read", "spsp_measure_hbm_device", "spsp_sketch_files", "spsp_sketch_files_multi", "spsp_sketch_files_release", "spsp_compare_files_multi", "spsp_matrix_cells_device", "spsp_matrix_add_cells_device", "spsp_compare_cells_device", "spsp_compare_slots_cells_device",
 ]
 
 _lib = None
@@ -158,6 +158,8 @@ def lib():
     L.spsp_csv_host.argtypes = [i32, P(cp), u32, u32, vp, vp, i32, dbl, P(vp), P(u64)]
     L.spsp_csv_cells_host.restype = i32
     L.spsp_csv_cells_host.argtypes = [i32, P(cp), u32, u32, vp, u64, vp, i32, dbl, P(vp), P(u64)]
+    L.spsp_csv_cells_gz_host.restype = i32
+    L.spsp_csv_cells_gz_host.argtypes = [i32, P(cp), u32, u32, vp, u64, vp, i32, dbl, cp]
     L.spsp_sort_csv_host.restype = i32
     L.spsp_sort_csv_host.argtypes = [cp, u64, cp, u64, P(vp), P(u64)]
     L.spsp_read_file_host.restype = i32; L.spsp_read_file_host.argtypes = [cp, P(vp), P(u64)]
@@ -302,6 +304,17 @@ def csv_cells(jaccard, names, cells, card, n_query=None, precision=6, min_thresh
     _check(lib().spsp_csv_cells_host(1 if jaccard else 0, arr, n, nq, cells.ctypes.data, len(cells), card.ctypes.data, precision,
                                      float(min_threshold), C.byref(out), C.byref(ln)))
     return _take(out, ln.value)
+
+
+def csv_cells_gz(jaccard, names, cells, card, gz_path, n_query=None, precision=6, min_threshold=0.0):
+    """spsp_csv_cells_gz_host: the same matrix straight into a .csv.gz (gzip members made without the text in between)"""
+    n = len(names)
+    nq = n if n_query is None else n_query
+    cells = np.ascontiguousarray(cells, dtype=np.uint64)
+    card = np.ascontiguousarray(card, dtype=np.uint64)
+    arr = (C.c_char_p * n)(*[s.encode() for s in names])
+    _check(lib().spsp_csv_cells_gz_host(1 if jaccard else 0, arr, n, nq, cells.ctypes.data, len(cells), card.ctypes.data, precision,
+                                        float(min_threshold), gz_path.encode()))
 
 
 def sketches_from_payloads(payloads):

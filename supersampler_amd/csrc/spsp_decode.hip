@@ -21,6 +21,7 @@
 #include <atomic>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -78,6 +79,93 @@ __global__ __launch_bounds__(256) void k_decode_emit(const uint8_t* __restrict__
         if (r_hi) r_hi[o] = fwd ? hi : rh;
         ++made;
     }
+}
+
+// The structure of every payload -- header, bucket boundaries, line ends: sketch_parse_structure_host's walk -- on the device,
+// one lane per sketch (round 5).  At 10 000 sketch files the host walk (2.4 x 10^6 descriptors made, copied and uploaded:
+// 58 MB) was 60 of the 66 ms in front of a 6 ms decode; the text crosses PCIe anyway, a lane reads its 3 KB payload from its
+// CU's vector cache and blobs are stepped over unread.  COUNT pass: descriptors and raw keys per sketch (the host needs
+// the totals to size the arrays) and a flag for anything the sketcher does not write -- such a sketch is decoded on the host
+// as before, and it is the host path that words the error for a malformed one.  WRITE pass: the same walk writes DecDesc.
+// Every read is bounded by the sketch's length and every descriptor names bytes inside it (the conditions are the host
+// parser's, line for line).
+struct DecCount { uint32_t n_desc, n_keys, flags, pad; };
+template <bool WRITE>
+__global__ __launch_bounds__(64) void k_decode_parse(const uint8_t* __restrict__ text, const uint64_t* __restrict__ text_off, const uint64_t* __restrict__ lens,
+                                                    uint32_t n, uint32_t k, uint32_t m, const uint32_t* __restrict__ extra, DecCount* __restrict__ counts,
+                                                    const uint64_t* __restrict__ desc_off, const uint64_t* __restrict__ raw_off,
+                                                    const uint8_t* __restrict__ skip, DecDesc* __restrict__ desc) {
+    const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    if (WRITE && skip[i]) return;                                  // decoded on the host: no descriptors
+    const uint8_t* p = text + text_off[i];
+    const uint64_t len = lens[i], t0 = text_off[i];
+    uint32_t n_desc = 0, flags = 0;
+    uint64_t keys = 0;
+    const uint64_t d0 = WRITE ? desc_off[i] : 0ull, r0 = WRITE ? raw_off[i] : 0ull;
+    auto push = [&](uint64_t off, uint32_t mn, uint32_t info, uint64_t count) {
+        if (count == 0) return;
+        if (keys + count > 0xfffffff0ull) { flags |= 1u; return; }
+        if (WRITE) desc[d0 + n_desc] = DecDesc{t0 + off, mn, info, (uint32_t)(r0 + keys), 0};
+        ++n_desc; keys += count;
+    };
+    // header: "<2k - m> <m> ..." -- anything but two plain decimal numbers that give this call's k and m goes to the host path
+    uint64_t pos = 0;
+    while (pos < len && p[pos] != '\n') ++pos;
+    bool ok = pos < len;
+    if (ok) {
+        uint64_t q = 0, skm = 0, mm = 0;
+        uint32_t digits = 0;
+        while (q < pos && p[q] >= '0' && p[q] <= '9' && digits < 6) { skm = skm * 10 + (p[q] - '0'); ++q; ++digits; }
+        ok = digits > 0 && digits < 6 && q < pos && p[q] == ' ';
+        while (q < pos && p[q] == ' ') ++q;
+        digits = 0;
+        while (q < pos && p[q] >= '0' && p[q] <= '9' && digits < 6) { mm = mm * 10 + (p[q] - '0'); ++q; ++digits; }
+        ok = ok && digits > 0 && digits < 6 && (q == pos || p[q] == ' ');
+        ok = ok && mm == m && skm == 2ull * k - m;                 // (the sketcher's header: k - 1 + k - m + 1, SubSampler.cpp:459)
+    }
+    if (!ok) flags |= 1u;
+    else {
+        const uint32_t half = k - m;
+        if (half > 0 && (2 * half) % 4 != 0) flags |= 1u;          // k - m odd: a blob byte straddles two super-k-mers -- host decoder
+        pos += 1;
+        while (pos + m <= len) {
+            uint32_t mn = 0;
+            for (uint32_t j = 0; j < m; ++j) mn = (mn << 2) | (((uint32_t)p[pos + j] >> 1) & 3u);
+            pos += m;
+            if (pos + 4 > len) break;
+            const uint32_t nbytes = (uint32_t)p[pos] | ((uint32_t)p[pos + 1] << 8) | ((uint32_t)p[pos + 2] << 16) | ((uint32_t)p[pos + 3] << 24);
+            pos += 4;
+            if (pos + nbytes > len) { flags |= 1u; break; }        // (the host path reports it)
+            uint64_t seq_len = 0;
+            if (nbytes) { if (p[pos] != 0) flags |= 1u; seq_len = (uint64_t)(nbytes - 1) * 4; }
+            if (half > 0) { for (uint64_t x = 0; (x + 1) * 2 * half <= seq_len; ++x) push(pos + 1 + x * (half / 2), mn, 0u, k - m + 1); }
+            else if (seq_len == 0) push(pos, mn, 2u, 1);
+            pos += nbytes;
+            for (;;) {                                             // "prefix\nsuffix\n" until an empty pair
+                if (pos >= len) break;
+                uint64_t e1 = pos;
+                while (e1 < len && p[e1] != '\n') ++e1;
+                const bool has1 = e1 < len;
+                const uint64_t s1 = pos, l1 = e1 - pos;
+                pos = has1 ? e1 + 1 : len;
+                uint64_t e2 = pos;
+                while (e2 < len && p[e2] != '\n') ++e2;
+                const bool has2 = pos < len && e2 < len;
+                const uint64_t s2 = pos, l2 = pos < len ? e2 - pos : 0;
+                pos = pos < len ? (has2 ? e2 + 1 : len) : len;
+                if (l1 == 0 && l2 == 0) break;
+                if (!has1 || l1 > 255 || l2 > 255 || s2 != s1 + l1 + 1) { flags |= 1u; continue; }
+                const uint64_t total = l1 + m + l2;
+                push(s1, mn, 1u | ((uint32_t)l1 << 2) | ((uint32_t)l2 << 10), total >= k ? total - k + 1 : 0);
+            }
+        }
+    }
+    if (extra && extra[i] != 0xffffffffu && !(flags & 1u)) {       // the phantom key of the comparator's first-read rule, behind the sketch's own
+        if (WRITE) desc[d0 + n_desc] = DecDesc{t0, extra[i], 2u, (uint32_t)(r0 + keys), 0};
+        ++n_desc; keys += 1;
+    }
+    if (!WRITE) counts[i] = DecCount{n_desc, (uint32_t)keys, flags, 0};
 }
 
 // sort + unique of one sketch's raw keys [raw_off[s], raw_off[s] + raw_cnt[s]) in LDS; sketches with presorted[s]
@@ -195,7 +283,109 @@ int sketch_decode_device_impl(spsp_ctx* ctx, const uint8_t* const* payloads, con
     std::vector<uint8_t> presorted(n, 0);
     std::vector<uint32_t> big(n, 0);
     auto free_hk = [&]() { for (auto& h : hk) { free(h.mn); free(h.lo); free(h.hi); } };
-    {
+    // Many sketches: the structure walk runs on the DEVICE (k_decode_parse) -- the payloads go up first, the walk's counts come
+    // back (one host wait), flagged sketches take the host decoder, and the descriptors are written where they are used.
+    // SPSP_DEBUG_DECODE_WALK=host / device pins the choice (tests run both on the same files).
+    static const char* dbg_walk = getenv("SPSP_DEBUG_DECODE_WALK");
+    const bool dev_walk = dbg_walk ? dbg_walk[0] == 'd' : n >= 256;
+    std::vector<DecCount> counts;
+    std::vector<uint64_t> text_off_dev;
+    uint64_t n_desc_dev = 0;
+    if (dev_walk && n) {
+        // k and m: the first sketch's header, by the host parser's rules (every other header is held against them by the walk)
+        {
+            const uint8_t* nl = (payloads[0] && lens[0]) ? (const uint8_t*)memchr(payloads[0], '\n', lens[0]) : nullptr;
+            ParsedSketch H;
+            if (!nl) { set_error("sketch has no header line"); return SPSP_ERR_FORMAT; }
+            if ((rc = sketch_parse_structure_host(payloads[0], (uint64_t)(nl - payloads[0]) + 1, &H))) return rc;   // (the header line alone)
+            for (uint32_t i = 0; i < n; ++i) { P[i].k = H.k; P[i].m = H.m; }
+        }
+        const uint32_t k = P[0].k, m = P[0].m;
+        text_off_dev.assign((size_t)n + 1, 0);
+        for (uint32_t i = 0; i < n; ++i) text_off_dev[i + 1] = text_off_dev[i] + ((lens[i] + 15) & ~15ull);
+        const uint64_t T = text_off_dev[n];
+        if ((rc = ctx->dc_text.reserve((size_t)T + 64)) || (rc = ctx->dc_walk.reserve((size_t)n * (8 + 8 + 4 + 16 + 8 + 8 + 1) + 256))) return rc;
+        // one pinned-size staging buffer for everything that goes up: texts back to back, then lens
+        // (malloc, not a vector: 30 MB of zeroed pages first touched by ONE thread were 10 ms; the gaps between sketches are never read)
+        struct Free { void operator()(uint8_t* q) const { free(q); } };
+        std::unique_ptr<uint8_t, Free> text_buf((uint8_t*)malloc((size_t)T + 64));
+        if (!text_buf) { set_error("out of host memory"); return SPSP_ERR_NOMEM; }
+        struct { uint8_t* p; uint8_t* data() const { return p; } } text_all{text_buf.get()};
+        {
+            unsigned workers = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+            if (T < (1u << 20)) workers = 1;
+            std::atomic<uint32_t> next(0);
+            auto work = [&]() {
+                for (;;) {
+                    const uint32_t i0 = next.fetch_add(64);
+                    if (i0 >= n) break;
+                    for (uint32_t i = i0; i < std::min(n, i0 + 64); ++i) if (lens[i]) memcpy(text_all.data() + text_off_dev[i], payloads[i], (size_t)lens[i]);
+                }
+            };
+            std::vector<std::thread> pool;
+            for (unsigned w = 1; w < workers; ++w) pool.emplace_back(work);
+            work();
+            for (auto& th : pool) th.join();
+        }
+        const double tw0 = now_s();
+        uint64_t* d_toff = ctx->dc_walk.as<uint64_t>();
+        uint64_t* d_lens = d_toff + n;
+        uint64_t* d_doff = d_lens + n;
+        uint64_t* d_roff = d_doff + n;
+        DecCount* d_counts = reinterpret_cast<DecCount*>(d_roff + n);
+        uint32_t* d_extra = reinterpret_cast<uint32_t*>(d_counts + n);
+        std::vector<uint32_t> extra((size_t)n, 0xffffffffu);
+        bool any_extra = false;
+        if (extra_has) for (uint32_t i = 0; i < n; ++i) if (extra_has[i]) { extra[i] = extra_mn[i]; any_extra = true; }
+        hipError_t e = T ? hipMemcpyAsync(ctx->dc_text.p, text_all.data(), (size_t)T, hipMemcpyHostToDevice, ctx->stream) : hipSuccess;
+        if (e == hipSuccess) e = hipMemcpyAsync(d_toff, text_off_dev.data(), (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_lens, lens, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess && any_extra) e = hipMemcpyAsync(d_extra, extra.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) return hip_fail(e, "sketch upload", __FILE__, __LINE__);
+        hipLaunchKernelGGL(k_decode_parse<false>, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, ctx->dc_text.as<uint8_t>(), (const uint64_t*)d_toff, (const uint64_t*)d_lens, n, k, m,
+                           any_extra ? (const uint32_t*)d_extra : (const uint32_t*)nullptr, d_counts, (const uint64_t*)nullptr, (const uint64_t*)nullptr,
+                           (const uint8_t*)nullptr, (DecDesc*)nullptr);
+        counts.resize(n);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(counts.data(), d_counts, (size_t)n * sizeof(DecCount), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) return hip_fail(e, "sketch structure walk", __FILE__, __LINE__);
+        tm[1] = now_s();
+        if (dbg_times) fprintf(stderr, "[spsp decode] device walk: texts assembled %.1f ms, upload + count pass + wait %.1f ms\n", (tw0 - tm[0]) * 1e3, (tm[1] - tw0) * 1e3);
+        // flagged sketches: the host decoder (and the host's wording of what is wrong with a malformed one)
+        std::vector<uint32_t> odd;
+        for (uint32_t i = 0; i < n; ++i) if (counts[i].flags & 1u) odd.push_back(i);
+        {
+            unsigned workers = std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+            if (workers > odd.size()) workers = odd.empty() ? 1 : (unsigned)odd.size();
+            std::atomic<uint32_t> next(0);
+            auto work = [&]() {
+                for (;;) {
+                    const uint32_t x = next.fetch_add(1);
+                    if (x >= odd.size()) break;
+                    const uint32_t i = odd[x];
+                    ParsedSketch Q;
+                    rcs[i] = sketch_parse_structure_host(payloads[i], lens[i], &Q);          // (its k and m, for the mismatch message below)
+                    if (rcs[i]) { errs[i] = spsp_last_error(); continue; }
+                    P[i].k = Q.k; P[i].m = Q.m;
+                    uint32_t kk, mm2;
+                    rcs[i] = spsp_sketch_parse_host(payloads[i], lens[i], &kk, &mm2, &hk[i].mn, &hk[i].lo, &hk[i].hi, &hk[i].n);
+                    if (rcs[i]) { errs[i] = spsp_last_error(); continue; }
+                    presorted[i] = 1;
+                }
+            };
+            std::vector<std::thread> pool;
+            for (unsigned w = 1; w < workers; ++w) pool.emplace_back(work);
+            work();
+            for (auto& th : pool) th.join();
+        }
+        for (uint32_t i = 0; i < n; ++i) {
+            if (presorted[i] || rcs[i]) continue;
+            P[i].n_keys = counts[i].n_keys - ((extra_has && extra_has[i]) ? 1u : 0u);
+            const uint32_t cap_i = k > 32 ? kSortCapHi : kSortCapLo;
+            big[i] = counts[i].n_keys > cap_i ? 1u : 0u;
+        }
+    } else {
         unsigned workers = std::thread::hardware_concurrency();
         if (workers == 0) workers = 1;
         if (workers > 16) workers = 16;
@@ -221,7 +411,7 @@ int sketch_decode_device_impl(spsp_ctx* ctx, const uint8_t* const* payloads, con
         work();
         for (auto& th : pool) th.join();
     }
-    tm[1] = now_s();
+    if (!(dev_walk && n)) tm[1] = now_s();
     for (uint32_t i = 0; i < n; ++i) if (rcs[i]) { free_hk(); set_error("%s", errs[i].c_str()); return rcs[i]; }
     for (uint32_t i = 1; i < n; ++i)
         if (P[i].k != P[0].k || P[i].m != P[0].m) { free_hk(); set_error("sketch %u was made with k=%u m=%u, expected k=%u m=%u", i, P[i].k, P[i].m, P[0].k, P[0].m); return SPSP_ERR_FORMAT; }
@@ -257,7 +447,32 @@ int sketch_decode_device_impl(spsp_ctx* ctx, const uint8_t* const* payloads, con
     // together with the sketch's text into the one buffer that crosses PCIe)
     std::vector<DecDesc> desc;
     std::vector<uint8_t> text_all;
-    {
+    if (dev_walk) {
+        // the descriptors are written on the device: where each sketch's start, and where its raw keys go
+        std::vector<uint64_t> doff((size_t)n, 0);
+        for (uint32_t i = 0; i < n; ++i) { doff[i] = n_desc_dev; if (!presorted[i]) n_desc_dev += counts[i].n_desc; }
+        if ((rc = ctx->dc_desc.reserve((size_t)n_desc_dev * sizeof(DecDesc) + 64))) { free_hk(); return rc; }
+        uint64_t* d_toff = ctx->dc_walk.as<uint64_t>();
+        uint64_t* d_lens = d_toff + n;
+        uint64_t* d_doff = d_lens + n;
+        uint64_t* d_roff = d_doff + n;
+        DecCount* d_counts = reinterpret_cast<DecCount*>(d_roff + n);
+        uint32_t* d_extra = reinterpret_cast<uint32_t*>(d_counts + n);
+        uint8_t* d_skip = reinterpret_cast<uint8_t*>(d_extra + n);
+        bool any_extra = false;
+        if (extra_has) for (uint32_t i = 0; i < n; ++i) any_extra |= extra_has[i] != 0;
+        hipError_t e = hipMemcpyAsync(d_doff, doff.data(), (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_roff, raw_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_skip, presorted.data(), (size_t)n, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);          // (doff is a local: the copies have read it)
+        if (e != hipSuccess) { free_hk(); return hip_fail(e, "sketch upload", __FILE__, __LINE__); }
+        if (n_desc_dev) {
+            hipLaunchKernelGGL(k_decode_parse<true>, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, ctx->dc_text.as<uint8_t>(), (const uint64_t*)d_toff, (const uint64_t*)d_lens, n, k, m,
+                               any_extra ? (const uint32_t*)d_extra : (const uint32_t*)nullptr, (DecCount*)nullptr, (const uint64_t*)d_doff, (const uint64_t*)d_roff,
+                               (const uint8_t*)d_skip, ctx->dc_desc.as<DecDesc>());
+            SPSP_HIP(hipGetLastError());
+        }
+    } else {
         std::vector<size_t> d_at((size_t)n + 1, 0);
         for (uint32_t i = 0; i < n; ++i) d_at[i + 1] = d_at[i] + (presorted[i] ? 0 : P[i].desc.size() + ((extra_has && extra_has[i]) ? 1 : 0));
         desc.resize(d_at[n]);
@@ -288,8 +503,8 @@ int sketch_decode_device_impl(spsp_ctx* ctx, const uint8_t* const* payloads, con
     }
     tm[2] = now_s();
     auto fail = [&](int r) { free_hk(); return r; };
-    if ((rc = ctx->dc_text.reserve((size_t)text_off[n] + 64))) return fail(rc);
-    if ((rc = ctx->dc_desc.reserve(desc.size() * sizeof(DecDesc) + 64))) return fail(rc);
+    if (!dev_walk && (rc = ctx->dc_text.reserve((size_t)text_off[n] + 64))) return fail(rc);
+    if (!dev_walk && (rc = ctx->dc_desc.reserve(desc.size() * sizeof(DecDesc) + 64))) return fail(rc);
     if ((rc = ctx->dc_mn.reserve((size_t)R * 4 + 64))) return fail(rc);
     if ((rc = ctx->dc_lo.reserve((size_t)R * 8 + 64))) return fail(rc);
     if (has_hi && (rc = ctx->dc_hi.reserve((size_t)R * 8 + 64))) return fail(rc);
@@ -316,7 +531,7 @@ int sketch_decode_device_impl(spsp_ctx* ctx, const uint8_t* const* payloads, con
     // the payloads cross in ONE copy (10 000 sketch files: ten thousand pageable copies of 3 KB each were 0.1 s of a 0.16 s stage)
     if (!text_all.empty()) e = hipMemcpyAsync(d_text, text_all.data(), text_all.size(), hipMemcpyHostToDevice, ctx->stream);
     for (uint32_t i = 0; i < n && e == hipSuccess; ++i) {
-        if (!presorted[i]) { if (lens[i] && text_all.empty()) e = hipMemcpyAsync(d_text + text_off[i], payloads[i], (size_t)lens[i], hipMemcpyHostToDevice, ctx->stream); }
+        if (!presorted[i]) { if (!dev_walk && lens[i] && text_all.empty()) e = hipMemcpyAsync(d_text + text_off[i], payloads[i], (size_t)lens[i], hipMemcpyHostToDevice, ctx->stream); }
         else if (hk[i].n) {
             e = hipMemcpyAsync(ctx->dc_mn.as<uint32_t>() + raw_off[i], hk[i].mn, hk[i].n * 4, hipMemcpyHostToDevice, ctx->stream);
             if (e == hipSuccess) e = hipMemcpyAsync(ctx->dc_lo.as<uint64_t>() + raw_off[i], hk[i].lo, hk[i].n * 8, hipMemcpyHostToDevice, ctx->stream);
@@ -331,9 +546,11 @@ int sketch_decode_device_impl(spsp_ctx* ctx, const uint8_t* const* payloads, con
     if (e == hipSuccess) e = hipMemcpyAsync(d_big, big.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
     if (e != hipSuccess) { free_hk(); return hip_fail(e, "sketch upload", __FILE__, __LINE__); }
     tm[3] = now_s();
-    if (!desc.empty()) {
-        hipLaunchKernelGGL(k_decode_emit, dim3((uint32_t)((desc.size() + 255) / 256)), dim3(256), 0, ctx->stream, d_text,
-                           ctx->dc_desc.as<DecDesc>(), (uint32_t)desc.size(), k, m, ctx->dc_mn.as<uint32_t>(), ctx->dc_lo.as<uint64_t>(),
+    const uint64_t n_desc_all = dev_walk ? n_desc_dev : (uint64_t)desc.size();
+    if (n_desc_all > 0xfffffff0ull) return fail((set_error("too many stored super-k-mers for one call"), SPSP_ERR_OVERFLOW));
+    if (n_desc_all) {
+        hipLaunchKernelGGL(k_decode_emit, dim3((uint32_t)((n_desc_all + 255) / 256)), dim3(256), 0, ctx->stream, d_text,
+                           ctx->dc_desc.as<DecDesc>(), (uint32_t)n_desc_all, k, m, ctx->dc_mn.as<uint32_t>(), ctx->dc_lo.as<uint64_t>(),
                            has_hi ? ctx->dc_hi.as<uint64_t>() : (uint64_t*)nullptr);
     }
     const size_t lds = has_hi ? (size_t)kSortCapHi * 20 : (size_t)kSortCapLo * 12;

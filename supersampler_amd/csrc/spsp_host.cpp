@@ -322,6 +322,8 @@ int sketch_build_core(const spsp_params* p, double rate, const uint64_t* rec_off
     // per super-k-mer in one table, 5.0 s), and on several threads when there is enough to do.
     spsp_sketch_stats st;
     memset(&st, 0, sizeof st);
+    static const bool dbg_times = getenv("SPSP_DEBUG_BUILD_TIMES") != nullptr;   // analysis: where the builder's time goes (stderr)
+    const double bt0 = dbg_times ? now_s() : 0.0;
     uint64_t nb = 0, pos_end = 0, occ = 0;                // occ: k-mer occurrences so far (numbering of kmer_flags)
     uint32_t cur_rec = 0xffffffffu;
     for (uint32_t r = 0; r < n_rec; ++r) {
@@ -358,7 +360,21 @@ int sketch_build_core(const spsp_params* p, double rate, const uint64_t* rec_off
     }
     nb -= p->m - 1;  // SubSampler.cpp:458
     st.nb_mmer_selected = nb;
-    std::stable_sort(by_mn.begin(), by_mn.end(), [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) { return a.first < b.first; });
+    // grouped by minimizer, stream order kept inside a group: two stable counting passes over 16 bits each (a comparison sort of
+    // the 8 x 10^5 super-k-mers of a 4 Gbp metagenome segment was 0.1 s on one thread in front of the threaded part)
+    if (by_mn.size() > 4096) {
+        std::vector<std::pair<uint32_t, uint32_t>> tmp(by_mn.size());
+        std::vector<uint32_t> cnt(65537);
+        for (int pass = 0; pass < 2; ++pass) {
+            const int sh = 16 * pass;
+            std::fill(cnt.begin(), cnt.end(), 0u);
+            for (const auto& e : by_mn) ++cnt[((e.first >> sh) & 0xffffu) + 1];
+            for (size_t i = 1; i < cnt.size(); ++i) cnt[i] += cnt[i - 1];
+            for (const auto& e : by_mn) tmp[cnt[(e.first >> sh) & 0xffffu]++] = e;
+            by_mn.swap(tmp);
+        }
+    } else
+        std::stable_sort(by_mn.begin(), by_mn.end(), [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) { return a.first < b.first; });
     struct Bucket { size_t first, last; std::string text; spsp_sketch_stats st; };
     std::vector<Bucket> buckets;
     for (size_t a = 0; a < by_mn.size();) {
@@ -367,6 +383,7 @@ int sketch_build_core(const spsp_params* p, double rate, const uint64_t* rec_off
         buckets.push_back(Bucket{a, z, std::string(), spsp_sketch_stats{}});
         a = z;
     }
+    const double bt1 = dbg_times ? now_s() : 0.0;
     std::vector<uint32_t> todo(buckets.size());           // largest first: the threads finish together
     for (uint32_t i = 0; i < todo.size(); ++i) todo[i] = i;
     std::sort(todo.begin(), todo.end(), [&](uint32_t a, uint32_t b) { return buckets[a].last - buckets[a].first > buckets[b].last - buckets[b].first; });
@@ -402,6 +419,7 @@ int sketch_build_core(const spsp_params* p, double rate, const uint64_t* rec_off
         for (unsigned t = 0; t < n_thr; ++t) pool.emplace_back(work);
         for (auto& th : pool) th.join();
     }
+    const double bt2 = dbg_times ? now_s() : 0.0;
     std::string out;
     Builder::emit_header(p->k, p->m, st.selected_kmer_number, rate, out);
     for (const Bucket& B : buckets) {
@@ -418,6 +436,8 @@ int sketch_build_core(const spsp_params* p, double rate, const uint64_t* rec_off
     memcpy(*payload, out.data(), out.size());
     *payload_len = out.size();
     if (stats) *stats = st;
+    if (dbg_times) fprintf(stderr, "[spsp build] %llu super-k-mers, %zu buckets, %u threads: group by minimizer %.1f ms, buckets %.1f ms, join %.1f ms\n",
+                           (unsigned long long)n_sk, buckets.size(), n_thr, (bt1 - bt0) * 1e3, (bt2 - bt1) * 1e3, (now_s() - bt2) * 1e3);
     return SPSP_OK;
 }
 
@@ -908,6 +928,96 @@ static int csv_impl(int jaccard, const char* const* names, uint32_t n, uint32_t 
     return SPSP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Rows of a sparse pair matrix straight into a gzip member (round 5).  A row of a 10^4-sketch matrix is ~12 runs of "0,"
+// between ~10 numbers; formatted as text and handed to zlib it is 20 KB through deflate's match finder and crc32 -- 42 ms of
+// thread time per 10^8-cell matrix.  Here the row never exists as text: a run of z cells is the two literals "0," and
+// ceil((2z - 2) / 258) matches of distance 2 in ONE fixed-Huffman deflate block (RFC 1951 3.2.6), and the member's CRC-32
+// takes the run as 16 table steps -- crc(A || B) = crc(A) * x^(8 |B|) + crc(B) over GF(2), with the operators x^(16 * 2^t)
+// (2^t cells) as byte tables and crc("0," x 2^t) precomputed.  gunzip gives the bytes the text path writes (the tests read
+// every member back through zlib, which checks CRC-32 and ISIZE).
+namespace {
+struct ZeroRunCrc {
+    uint32_t tab[17][4][256];                 // tab[t]: multiplication of a (reflected) CRC value by x^(16 * 2^t), byte-wise
+    uint32_t crc[17];                         // crc32 of "0," x 2^t
+    static uint32_t times(const uint32_t* mat, uint32_t vec) { uint32_t s = 0; for (int i = 0; vec; vec >>= 1, ++i) if (vec & 1u) s ^= mat[i]; return s; }
+    ZeroRunCrc() {
+        uint32_t a[32], b[32];
+        a[0] = 0xedb88320u;                    // the operator of ONE zero bit (zlib crc32_combine): the polynomial, then the shifts
+        for (int n = 1; n < 32; ++n) a[n] = 1u << (n - 1);
+        auto square = [](uint32_t* dst, const uint32_t* src) { for (int n = 0; n < 32; ++n) dst[n] = times(src, src[n]); };
+        square(b, a); square(a, b); square(b, a); square(a, b);   // 2, 4, 8, 16 bits: a = two zero bytes = one cell
+        const char cell[2] = {'0', ','};
+        for (int t = 0; t <= 16; ++t) {
+            for (int by = 0; by < 4; ++by)
+                for (uint32_t v = 0; v < 256; ++v) tab[t][by][v] = times(a, v << (8 * by));
+            if (t == 0) crc[0] = (uint32_t)crc32(0L, (const Bytef*)cell, 2);
+            else crc[t] = mul(t - 1, crc[t - 1]) ^ crc[t - 1];   // 2^t cells = 2^(t-1) cells followed by 2^(t-1) cells
+            square(b, a); memcpy(a, b, sizeof a);
+        }
+    }
+    uint32_t mul(int t, uint32_t c) const { return tab[t][0][c & 255u] ^ tab[t][1][(c >> 8) & 255u] ^ tab[t][2][(c >> 16) & 255u] ^ tab[t][3][c >> 24]; }
+    uint32_t append(uint32_t c, uint32_t cells) const {            // crc of (what c covers) followed by `cells` x "0,"
+        for (int t = 0; cells; cells >>= 1, ++t) if (cells & 1u) c = mul(t, c) ^ crc[t];
+        return c;
+    }
+};
+static const ZeroRunCrc& zero_run_crc() { static const ZeroRunCrc z; return z; }
+
+struct StringSink {
+    std::string* out;
+    void bytes(const char* p, size_t n) { out->append(p, n); }
+    void zeros(uint32_t cells) {
+        static const std::string run = []() { std::string z; z.reserve(8192); for (int i = 0; i < 4096; ++i) z += "0,"; return z; }();
+        while (cells) { const uint32_t take = cells < 4096 ? cells : 4096; out->append(run.data(), (size_t)take * 2); cells -= take; }
+    }
+};
+struct GzSink {                                // one gzip member: header, ONE fixed-Huffman block, CRC-32, ISIZE
+    std::vector<uint8_t>* out;
+    uint64_t acc = 0; int nbits = 0;
+    uint32_t crc = 0; uint64_t isize = 0;
+    static uint32_t rev(uint32_t v, int n) { uint32_t r = 0; for (int i = 0; i < n; ++i) r |= ((v >> i) & 1u) << (n - 1 - i); return r; }
+    void put(uint32_t v, int n) {               // n bits, least significant first
+        acc |= (uint64_t)v << nbits; nbits += n;
+        while (nbits >= 8) { out->push_back((uint8_t)acc); acc >>= 8; nbits -= 8; }
+    }
+    void begin() {
+        static const uint8_t hdr[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3};
+        out->insert(out->end(), hdr, hdr + 10);
+        put(1, 1); put(1, 2);                   // BFINAL = 1, BTYPE = 01
+    }
+    void literal(uint8_t b) { if (b < 144) put(rev(0x30u + b, 8), 8); else put(rev(0x190u + (b - 144u), 9), 9); }
+    void match2(uint32_t len) {                 // `len` bytes (3 .. 258) copied from distance 2
+        static const uint16_t base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+        static const uint8_t extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+        int c = 28;
+        while (base[c] > len) --c;              // (258 has a code of its own; 227 .. 257 are code 284 + extra bits)
+        const uint32_t sym = 257u + (uint32_t)c;
+        if (sym < 280) put(rev(sym - 256u, 7), 7); else put(rev(0xc0u + (sym - 280u), 8), 8);
+        if (extra[c]) put(len - base[c], extra[c]);
+        put(rev(1u, 5), 5);                     // distance code 1 = distance 2, no extra bits
+    }
+    void bytes(const char* p, size_t n) {
+        for (size_t i = 0; i < n; ++i) literal((uint8_t)p[i]);
+        crc = (uint32_t)crc32(crc, (const Bytef*)p, (uInt)n); isize += n;
+    }
+    void zeros(uint32_t cells) {
+        if (!cells) return;
+        literal('0'); literal(',');
+        uint64_t rem = 2ull * cells - 2;
+        while (rem >= 258) { match2(258); rem -= 258; }
+        if (rem >= 4) match2((uint32_t)rem); else if (rem == 2) { literal('0'); literal(','); }
+        crc = zero_run_crc().append(crc, cells); isize += 2ull * cells;
+    }
+    void end() {
+        put(0, 7);                              // end of block (symbol 256: seven zero bits)
+        if (nbits) put(0, 8 - nbits);
+        for (int i = 0; i < 4; ++i) out->push_back((uint8_t)(crc >> (8 * i)));
+        for (int i = 0; i < 4; ++i) out->push_back((uint8_t)((uint32_t)isize >> (8 * i)));
+    }
+};
+}  // namespace
+
 // The same bytes from the SPARSE form of the pair matrix (packed cells i << 48 | j << 32 | count, i < j, every pair at most
 // once): a comparison of thousands of sketches returns ~10 non-zero partners per row, and a row is then "0," runs between
 // them -- no n x n matrix is built or scanned (10^4 sketches: 2 x 400 MB of reads per matrix before).
@@ -940,33 +1050,37 @@ static int csv_cells_impl(int jaccard, const char* const* names, uint32_t n, uin
             if (j < rows) adj[at[j]++] = ((uint64_t)i << 32) | (uint32_t)c;
         }
     }
-    static const std::string zero_run = []() { std::string z; z.reserve(8192); for (int i = 0; i < 4096; ++i) z += "0,"; return z; }();
-    auto format_rows = [&](uint32_t r0, uint32_t r1, std::string& out) {
+    // rows [r0, r1) into a sink: text (StringSink) or a gzip member made directly (GzSink).  A cell is its text and ',' -- '\n'
+    // for the row's last cell; a run of zeros that reaches the end of the row is one cell shorter and ends in "0\n"
+    auto format_rows = [&](uint32_t r0, uint32_t r1, auto& sink) {
         char num[64];
-        out.reserve((size_t)(r1 - r0) * n * 2 + 4096);
         for (uint32_t i = r0; i < r1; ++i) {
             std::sort(adj.begin() + deg[i], adj.begin() + deg[i + 1]);
             uint32_t col = 0;
             auto zeros_to = [&](uint32_t upto) {                 // cells [col, upto) are "0,"
-                uint32_t z = upto - col;
-                while (z) { const uint32_t take = z < 4096 ? z : 4096; out.append(zero_run.data(), (size_t)take * 2); z -= take; }
+                if (upto > col) {
+                    if (upto == n) { sink.zeros(upto - col - 1); sink.bytes("0\n", 2); }
+                    else sink.zeros(upto - col);
+                }
                 col = upto;
             };
+            auto cell = [&](const char* p, size_t l, uint32_t at) {   // the cell of column `at`
+                sink.bytes(p, l);
+                sink.bytes(at + 1 == n ? "\n" : ",", 1);
+                col = at + 1;
+            };
             bool diag_done = false;
-            auto diagonal = [&]() { zeros_to(i); out += "1,"; col = i + 1; diag_done = true; };
+            auto diagonal = [&]() { zeros_to(i); cell("1", 1, i); diag_done = true; };
             for (uint32_t e = deg[i]; e < deg[i + 1]; ++e) {
                 const uint32_t j = (uint32_t)(adj[e] >> 32), sc = (uint32_t)adj[e];
                 if (!diag_done && j > i) diagonal();
                 zeros_to(j);
                 const double score = jaccard ? (double)sc / (double)(card[i] + card[j] - sc) : (double)sc / (double)card[i];
-                if (score < min_threshold) out += '0';
-                else { const int l = snprintf(num, sizeof num, "%.*g", precision, score); out.append(num, l); }
-                out += ',';
-                col = j + 1;
+                if (score < min_threshold) cell("0", 1, j);
+                else { const int l = snprintf(num, sizeof num, "%.*g", precision, score); cell(num, (size_t)l, j); }
             }
             if (!diag_done) diagonal();
             zeros_to(n);
-            out.back() = '\n';
         }
     };
     unsigned workers = std::thread::hardware_concurrency();
@@ -985,16 +1099,15 @@ static int csv_cells_impl(int jaccard, const char* const* names, uint32_t n, uin
         std::vector<double> t_fmt(workers, 0.0), t_gz(workers, 0.0);
         rcs[0] = deflate_member((const uint8_t*)head.data(), head.size(), gz_level, gz[0]);        // the header line(s): a member of their own
         auto work = [&](unsigned w) {
-            std::string out;
             for (;;) {
                 const uint32_t b = next.fetch_add(1);
                 if (b >= n_blocks) break;
-                out.clear();
                 const double t0 = now_s();
-                format_rows(b * rpb, std::min(rows, (b + 1) * rpb), out);
-                const double t1 = now_s();
-                rcs[b + 1] = deflate_member((const uint8_t*)out.data(), out.size(), gz_level, gz[b + 1]);
-                t_fmt[w] += t1 - t0; t_gz[w] += now_s() - t1;
+                GzSink sink{&gz[b + 1]};                          // formatted and deflated in one go: the rows never exist as text
+                sink.begin();
+                format_rows(b * rpb, std::min(rows, (b + 1) * rpb), sink);
+                sink.end();
+                t_fmt[w] += now_s() - t0;
             }
         };
         if (workers > n_blocks) workers = n_blocks ? n_blocks : 1;
@@ -1023,8 +1136,13 @@ static int csv_cells_impl(int jaccard, const char* const* names, uint32_t n, uin
         std::vector<std::thread> pool;
         for (unsigned w = 0; w < workers; ++w) {
             const uint32_t r0 = (uint32_t)((uint64_t)rows * w / workers), r1 = (uint32_t)((uint64_t)rows * (w + 1) / workers);
-            if (w + 1 == workers) format_rows(r0, r1, parts[w]);
-            else pool.emplace_back(format_rows, r0, r1, std::ref(parts[w]));
+            auto job = [&format_rows, &parts, n](uint32_t a, uint32_t z, unsigned which) {
+                parts[which].reserve((size_t)(z - a) * n * 2 + 4096);
+                StringSink sink{&parts[which]};
+                format_rows(a, z, sink);
+            };
+            if (w + 1 == workers) job(r0, r1, w);
+            else pool.emplace_back(job, r0, r1, w);
         }
         for (auto& th : pool) th.join();
     }
@@ -1052,6 +1170,20 @@ int spsp_csv_cells_host(int jaccard, const char* const* names, uint32_t n, uint3
         if (e && (v[e] >> 32) == (v[e - 1] >> 32)) { set_error("the pair (%u, %u) occurs twice: add partial cells up first (spsp_matrix_add_cells_device)", i, j); return SPSP_ERR_FORMAT; }
     }
     return csv_cells_impl(jaccard, names, n, n_query, v, card, precision, min_threshold, text, len);
+}
+
+int spsp_csv_cells_gz_host(int jaccard, const char* const* names, uint32_t n, uint32_t n_query, const uint64_t* cells, uint64_t n_cells,
+                           const uint64_t* card, int precision, double min_threshold, const char* gz_path) {
+    if (!gz_path || (n && (!names || !card)) || (n_cells && !cells)) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    if (n > 65535) { set_error("at most 65535 sketches (a packed cell holds two 16-bit sketch numbers)"); return SPSP_ERR_ARG; }
+    std::vector<uint64_t> v(cells, cells + n_cells);
+    std::sort(v.begin(), v.end());
+    for (size_t e = 0; e < v.size(); ++e) {
+        const uint32_t i = (uint32_t)(v[e] >> 48), j = (uint32_t)(v[e] >> 32) & 0xffffu;
+        if (i >= j || j >= n) { set_error("cell %zu names the pair (%u, %u): not i < j < n", e, i, j); return SPSP_ERR_FORMAT; }
+        if (e && (v[e] >> 32) == (v[e - 1] >> 32)) { set_error("the pair (%u, %u) occurs twice: add partial cells up first (spsp_matrix_add_cells_device)", i, j); return SPSP_ERR_FORMAT; }
+    }
+    return csv_cells_impl(jaccard, names, n, n_query, v, card, precision, min_threshold, nullptr, nullptr, gz_path, 1, nullptr);
 }
 
 int spsp_csv_host(int jaccard, const char* const* names, uint32_t n, uint32_t n_query, const uint32_t* inter,

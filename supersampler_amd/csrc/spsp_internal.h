@@ -166,7 +166,7 @@ struct spsp_ctx {
     uint32_t filter_skipped = 0;
     double filter_ratio = 1.0;   // records dealt into parts per owned key in the last filtered comparison (sizes the next one's parts)
     spsp::DevBuf x_cnt, x_off, x_begin, x_end, x_tot;   // key-partitioned exchange (spsp_compare.hip)
-    spsp::DevBuf dc_text, dc_desc, dc_mn, dc_lo, dc_hi, dc_meta;   // bulk sketch decode (spsp_decode.hip)
+    spsp::DevBuf dc_text, dc_desc, dc_mn, dc_lo, dc_hi, dc_meta, dc_walk;   // bulk sketch decode (spsp_decode.hip)
     spsp::DevBuf a_cnt, a_off, a_mn, a_lo, a_hi, a_slot, a_slot_of, a_flags;   // -a abundance pass (spsp_abund.hip)
     // genomes / sketches beyond the per-segment LDS forms (spsp_bigkeys.hip): output slices, the open-addressing table in HBM
     // (slot words carry the epoch of the call that claimed them: never cleared between calls), the sort's tile list

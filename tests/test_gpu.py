@@ -828,6 +828,58 @@ def test_gpu_sketch_decode_matches_oracle_keys(ctx):
             assert int(sk_off[5] - sk_off[4]) > 8192               # the large sketch went through the table in HBM and the merge sort
 
 
+_DECODE_WALKS = r"""
+import sys, hashlib
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+import supersampler_amd as sp
+from oracle import oracle_py as orc
+from supersampler_amd import synth
+import test_gpu
+ctx = sp.Context(0)
+test_gpu.test_gpu_sketch_decode_matches_oracle_keys(ctx)            # the oracle's keys, sketch by sketch, through this walk
+rng = np.random.default_rng(99)
+k, m, s = 31, 11, 12
+good = [orc.sketch_fasta(synth.to_fasta(synth.random_genome(rng, int(L)), "g%%d" %% i), k, m, s)[0] for i, L in enumerate(rng.integers(2000, 30000, 40))]
+def mutants(pl):
+    nl = pl.index(b"\n")
+    yield "truncated", pl[: len(pl) * 2 // 3]
+    yield "no header", pl.replace(b"\n", b" ")
+    yield "header words", b"x" + pl
+    yield "other m", pl[:nl].replace(b" 11 ", b" 13 ") + pl[nl:]
+    b = bytearray(pl); b[nl + 1 + m : nl + 1 + m + 4] = (2**31).to_bytes(4, "little"); yield "blob past the end", bytes(b)
+    b = bytearray(pl); b[nl + 1 + m + 4] = 2; yield "partial blob byte", bytes(b)
+    yield "long line", pl[:-2] + b"A" * 300 + b"\n" + b"C" * 5 + b"\n\n\n"
+    yield "no last newline", pl[:-1]
+    yield "only header", pl[: nl + 1]
+    yield "empty", b""
+digest = hashlib.sha256()
+for name, bad in mutants(good[3]):
+    batch = list(good); batch[7] = bad
+    try:
+        kk, mm, d_mn, d_lo, d_hi, off = ctx.sketch_decode_device(batch)
+        tot = int(off[-1])
+        digest.update(name.encode() + off.tobytes() + ctx.to_host(d_mn, tot, np.uint32).tobytes() + ctx.to_host(d_lo, tot, np.uint64).tobytes())
+    except sp.SpspError as e:
+        digest.update(name.encode() + b"error %%d " %% e.code + str(e).encode())
+print("digest", digest.hexdigest())
+"""
+
+
+def test_sketch_decode_structure_walk_on_the_device_equals_the_host_walk():
+    """k_decode_parse (the payload structure walk on the device, what collections of >= 256 sketch files take) against
+    sketch_parse_structure_host: the oracle's keys for every shape of test_gpu_sketch_decode_matches_oracle_keys through BOTH
+    walks, and ten malformed payloads (truncated, no header, another m, a blob that runs past the end, a partial blob byte, a
+    300-base line, ...) in a batch of 40: the two walks return the same keys or the same error, text included."""
+    out = []
+    for walk in ("host", "device"):
+        r = subprocess.run([sys.executable, "-c", _DECODE_WALKS % (ROOT, os.path.join(ROOT, "tests"))], env=dict(os.environ, SPSP_DEBUG_DECODE_WALK=walk),
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "digest" in r.stdout, (walk, r.stdout[-2000:], r.stderr[-3000:])
+        out.append(r.stdout.strip().split()[-1])
+    assert out[0] == out[1]
+
+
 def test_cu_partitioned_streams_and_sampled_timing():
     """spsp_stream_create_cus / spsp_set_cu_count (bench.py's step schedule): a scan whose dense pass runs on a stream
     that owns 192 CUs (two workgroups each) with its sparse stages on a 64-CU stream, next to a comparison on

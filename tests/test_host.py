@@ -242,6 +242,53 @@ def test_csv_sparse_matrix_long_zero_runs_match_oracle():
         sp.csv_cells(True, names[:10], np.array([(3 << 48) | (2 << 32) | 5], np.uint64), card[:10])   # not i < j
 
 
+def test_csv_cells_straight_into_gzip_members(tmp_path):
+    """spsp_csv_cells_gz_host (what spsp_compare_files writes its matrices with): rows go into gzip members without ever being
+    text -- zero runs as deflate matches of distance 2 in a fixed-Huffman block, their CRC-32 by GF(2) operators.  Python's
+    gzip (zlib: every member's CRC-32 and ISIZE are checked on the way) must read back exactly the text path's bytes: zero
+    runs of every length class (1, 2, 3, 129, 130, 131, 4 097, 65 534 cells; runs that end the row and runs that do not),
+    a last column that is a number / the diagonal / a zero, numbers with bytes >= 144 nowhere but names, query mode,
+    the threshold rule, 1 x 1 and 2 x 2 matrices, and the containment header's blank line."""
+    import gzip
+    rng = np.random.default_rng(80)
+
+    def check(n, pairs, nq=None, thr=0.0, prec=6, tag=""):
+        card = rng.integers(3000, 9000, size=n).astype(np.uint64)
+        cells = np.array([(i << 48) | (j << 32) | c for (i, j, c) in pairs], dtype=np.uint64)
+        names = ["génome_%d.fa" % i for i in range(n)]            # (a byte >= 144 in every name: the 9-bit literals)
+        for jac in (True, False):
+            want = sp.csv_cells(jac, names, cells, card, nq, prec, thr)
+            pth = str(tmp_path / ("m%s_%d_%d.csv.gz" % (tag, n, jac)))
+            sp.csv_cells_gz(jac, names, cells, card, pth, nq, prec, thr)
+            assert gzip.open(pth, "rb").read() == want, (tag, n, jac)
+            assert sp.read_file(pth) == want                        # ... and through the library's own reader (zstr's member loop)
+
+    check(1, [], tag="one")
+    check(2, [(0, 1, 7)], tag="two")
+    check(2, [], tag="two0")
+    for n in (3, 4, 5, 131, 132, 133, 260, 4099):
+        check(n, [(0, n - 1, 5), (1, 2, 9)] if n > 3 else [(0, 2, 5)], tag="ends")
+        check(n, [(0, 1, 5)], tag="head")
+        check(n, [], tag="empty")
+    n = 70000 // 2                                                  # rows of 35 000 cells: runs of up to 34 999
+    check(n, [(0, 17, 3), (5, n - 2, 8), (n - 2, n - 1, 4)], nq=6, tag="long")
+    check(65535, [(0, 65534, 11), (1, 30000, 2)], nq=2, tag="max")
+    # a random sparse matrix with the threshold rule and query rows
+    n = 3000
+    ii, jj = rng.integers(0, n, 5000), rng.integers(0, n, 5000)
+    keep = ii < jj
+    seen = set()
+    pairs = []
+    for i, j in zip(ii[keep].tolist(), jj[keep].tolist()):
+        if (i, j) not in seen:
+            seen.add((i, j)); pairs.append((i, j, int(rng.integers(1, 3000))))
+    check(n, pairs, tag="rand")
+    check(n, pairs, nq=40, thr=0.2, prec=4, tag="randq")
+    # a dense block (one species): every cell a number
+    n = 60
+    check(n, [(i, j, 100 + i + j) for i in range(n) for j in range(i + 1, n)], tag="dense")
+
+
 def test_gz_io_roundtrip(tmp_path):
     data = os.urandom(1000) + b"ACGT" * 100000
     p = str(tmp_path / "x.gz")

@@ -1,5 +1,5 @@
 set -e
-run() { name=$1; shift; env "$@" BENCH_FORCE_DIST=1 python bench.py --steps 400 --no-extras --no-cpu-baseline $EXTRA > gpurun_out/dv_$name.json 2> gpurun_out/dv_$name.err; python - <<P
+run() { name=$1; shift; env "$@" BENCH_FORCE_DIST=1 python bench.py --experiment --steps 400 --no-extras --no-cpu-baseline $EXTRA > gpurun_out/dv_$name.json 2> gpurun_out/dv_$name.err; python - <<P
 import json
 d=json.loads(open("gpurun_out/dv_$name.json").read().strip().splitlines()[-1]); print("$name", round(d["ms_per_step"],4), d["host_ms_per_step"], d["config"]["exchange_check"][:20])
 P
