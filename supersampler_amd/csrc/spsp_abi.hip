@@ -4,6 +4,10 @@
 #include <cstring>
 #include <vector>
 
+#include <mutex>
+#include <utility>
+#include <vector>
+
 #include "spsp_internal.h"
 
 namespace spsp {
@@ -24,12 +28,38 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
     return (e == hipErrorOutOfMemory) ? SPSP_ERR_NOMEM : SPSP_ERR_HIP;
 }
 
+// A buffer that is outgrown is not freed on the spot: hipFree waits for the whole device and works off whatever the runtime
+// has deferred -- 19 ms measured for ONE free in front of a 40 ms decode of 10 000 sketch files -- and buffers grow
+// geometrically, so the outgrown ones add up to less than what is in use.  They are kept in a list and freed when a context
+// is destroyed, or when the list passes 16 GiB.
+namespace {
+struct Retired { std::mutex mu; std::vector<std::pair<void*, size_t>> list; size_t bytes = 0; };
+Retired& retired() { static Retired r; return r; }
+void retire(void* p, size_t bytes) {
+    Retired& r = retired();
+    std::vector<std::pair<void*, size_t>> now;
+    {
+        std::lock_guard<std::mutex> g(r.mu);
+        r.list.emplace_back(p, bytes);
+        r.bytes += bytes;
+        if (r.bytes > (16ull << 30)) { now.swap(r.list); r.bytes = 0; }
+    }
+    for (auto& q : now) (void)hipFree(q.first);
+}
+}  // namespace
+void devbuf_flush_retired() {
+    Retired& r = retired();
+    std::vector<std::pair<void*, size_t>> now;
+    { std::lock_guard<std::mutex> g(r.mu); now.swap(r.list); r.bytes = 0; }
+    for (auto& q : now) (void)hipFree(q.first);
+}
+
 int DevBuf::reserve(size_t bytes) {
     if (bytes <= cap && p) return SPSP_OK;
     static const bool dbg = getenv("SPSP_DEBUG_ALLOC_TIMES") != nullptr;   // analysis: what growing a buffer costs (stderr)
     const double t0 = dbg ? now_s() : 0.0;
     const size_t had = cap;
-    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    if (p) { retire(p, cap); p = nullptr; cap = 0; }
     const double t1 = dbg ? now_s() : 0.0;
     size_t want = bytes + bytes / 4 + 256;  // headroom so batch loops settle quickly
     hipError_t e = hipMalloc(&p, want);
@@ -235,10 +265,11 @@ void spsp_destroy(spsp_ctx* c) {
     if (c->compare_done) (void)hipEventDestroy(c->compare_done);
     DevBuf* bufs[] = {&c->bases, &c->rec_off, &c->bitmap, &c->tile_count, &c->tile_off, &c->hits, &c->emit_count,
                       &c->scan_tmp, &c->d_scalar, &c->seg_a, &c->seg_b, &c->wave_hits, &c->wave_cnt, &c->packed, &c->unpacked, &c->st_count, &c->st_open, &c->filter, &c->bloom, &c->pairtab, &c->c_min, &c->c_lo, &c->c_hi, &c->c_table,
-                      &c->c_owner, &c->c_rowid, &c->c_row, &c->x_cnt, &c->x_off, &c->x_begin, &c->x_end, &c->x_tot, &c->dc_text, &c->dc_desc, &c->dc_mn, &c->dc_lo, &c->dc_hi, &c->dc_meta, &c->dc_walk, &c->a_cnt, &c->a_off, &c->a_mn, &c->a_lo, &c->a_hi, &c->a_slot, &c->a_slot_of, &c->a_flags, &c->b_mn, &c->b_lo, &c->b_hi, &c->b_table, &c->b_tiles, &c->b_seg, &c->m_send, &c->m_recv, &c->m_cells, &c->m_mn, &c->m_lo, &c->m_hi, &c->c_matrix, &c->c_inter, &c->c_flags, &c->c_slot_lo, &c->c_slot_hi, &c->c_slot_mn, &c->c_part_cnt, &c->c_recs, &c->c_where, &c->c_lref, &c->c_filter, &c->c_bits, &c->c_sig, &c->c_order, &c->c_multi, &c->scan_blocks,
+                      &c->c_owner, &c->c_rowid, &c->c_row, &c->x_cnt, &c->x_off, &c->x_begin, &c->x_end, &c->x_tot, &c->dc_text, &c->dc_desc, &c->dc_mn, &c->dc_lo, &c->dc_hi, &c->dc_meta, &c->dc_walk, &c->a_cnt, &c->a_off, &c->a_mn, &c->a_lo, &c->a_hi, &c->a_slot, &c->a_slot_of, &c->a_flags, &c->a_seg, &c->b_mn, &c->b_lo, &c->b_hi, &c->b_table, &c->b_tiles, &c->b_seg, &c->m_send, &c->m_recv, &c->m_cells, &c->m_mn, &c->m_lo, &c->m_hi, &c->c_matrix, &c->c_inter, &c->c_flags, &c->c_slot_lo, &c->c_slot_hi, &c->c_slot_mn, &c->c_part_cnt, &c->c_recs, &c->c_where, &c->c_lref, &c->c_filter, &c->c_bits, &c->c_sig, &c->c_order, &c->c_multi, &c->scan_blocks,
                       &c->c_skoff, &c->i_text, &c->i_tiles, &c->i_entry, &c->i_outoff, &c->i_recbase, &c->i_lens, &c->i_dst,
                       &c->i_compact};
     for (DevBuf* b : bufs) b->release();
+    devbuf_flush_retired();
     for (int kind = 0; kind < kEvKinds; ++kind) {
         for (auto* v : {&c->evlog[kind].used, &c->evlog[kind].spare})
             for (auto& ev : *v) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }

@@ -61,20 +61,35 @@ __device__ __forceinline__ uint64_t abund_hash(uint32_t mn, uint64_t lo, uint64_
     return abund_mix(h ^ hi);
 }
 
+// seg_sk (n_seg + 1 super-k-mer numbers; nullptr = one segment): the super-k-mers of a BATCH of files, counted file by file in ONE
+// pass -- the reference's map is per file (one Subsampler per file, SubSampler.cpp:787), so a k-mer of another file is
+// another key: the segment is hashed with the key and a claimer outside the occurrence's own segment never matches
+// (round 5: -a > 1 through the batched file pipeline, one GPU job per batch instead of one per file)
+__global__ void k_abund_segments(const uint32_t* __restrict__ seg_sk, uint32_t n_seg, const uint32_t* __restrict__ occ_off, uint32_t* __restrict__ seg_occ) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s <= n_seg) seg_occ[s] = occ_off[seg_sk[s]];
+}
 __global__ __launch_bounds__(256) void k_abund_insert(const uint32_t* __restrict__ k_mn, const uint64_t* __restrict__ k_lo,
                                                      const uint64_t* __restrict__ k_hi, uint32_t n_occ, uint32_t* __restrict__ slot,
-                                                     uint32_t* __restrict__ count, uint32_t cap_mask, uint32_t* __restrict__ slot_of) {
+                                                     uint32_t* __restrict__ count, uint32_t cap_mask, uint32_t* __restrict__ slot_of,
+                                                     const uint32_t* __restrict__ seg_occ, uint32_t n_seg) {
     const uint32_t o = blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= n_occ) return;
     const uint32_t mn = k_mn[o];
     const uint64_t lo = k_lo[o], hi = k_hi[o];
-    uint32_t h = (uint32_t)abund_hash(mn, lo, hi) & cap_mask;
+    uint32_t seg = 0, first = 0, last = n_occ;
+    if (seg_occ) {                                        // the last segment whose first occurrence is <= o
+        uint32_t a = 0, z = n_seg;
+        while (z - a > 1) { const uint32_t mid = (a + z) >> 1; if (seg_occ[mid] <= o) a = mid; else z = mid; }
+        seg = a; first = seg_occ[a]; last = seg_occ[a + 1];
+    }
+    uint32_t h = (uint32_t)abund_hash(mn + seg * 0x9E3779B1u, lo, hi) & cap_mask;
     for (;;) {                                            // ends: the table has at least twice as many slots as keys
         uint32_t cur = slot[h];
         if (cur == 0) cur = atomicCAS(&slot[h], 0u, o + 1);
         if (cur == 0) break;                              // claimed
         const uint32_t c = cur - 1;                       // the claimer's key was written by the kernel before this one
-        if (k_lo[c] == lo && k_mn[c] == mn && k_hi[c] == hi) break;
+        if (c >= first && c < last && k_lo[c] == lo && k_mn[c] == mn && k_hi[c] == hi) break;
         h = (h + 1) & cap_mask;
     }
     atomicAdd(&count[h], 1u);
@@ -93,7 +108,8 @@ __global__ __launch_bounds__(256) void k_abund_flags(uint32_t n_occ, const uint3
 // Flags for every k-mer occurrence of the gathered super-k-mers (the buffers gather_superkmers_impl left on the
 // device: ctx->i_compact / ctx->i_dst): malloc'd, one byte per occurrence, numbered super-k-mer by super-k-mer.
 // SPSP_ERR_OVERFLOW when the occurrences do not fit 31 bits: the caller then lets the host count.
-int abundance_flags_impl(spsp_ctx* ctx, const spsp_params* p, const spsp_superkmer* d_sk, uint64_t n_sk, uint8_t** h_flags, uint64_t* n_occ_out) {
+int abundance_flags_impl(spsp_ctx* ctx, const spsp_params* p, const spsp_superkmer* d_sk, uint64_t n_sk, uint8_t** h_flags, uint64_t* n_occ_out,
+                         const uint32_t* h_seg_sk, uint32_t n_seg) {
     *h_flags = nullptr; *n_occ_out = 0;
     if (n_sk == 0) { *h_flags = (uint8_t*)malloc(1); return *h_flags ? SPSP_OK : SPSP_ERR_NOMEM; }
     // a super-k-mer holds at most k - m + 1 <= 63 k-mers: below this many of them the 32-bit prefix sums cannot wrap
@@ -124,8 +140,18 @@ int abundance_flags_impl(spsp_ctx* ctx, const spsp_params* p, const spsp_superkm
     hipLaunchKernelGGL(k_abund_emit, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->i_compact.as<uint8_t>(), ctx->i_dst.as<uint32_t>(),
                        d_sk, ctx->a_off.as<uint32_t>(), n, p->k, ctx->a_mn.as<uint32_t>(), ctx->a_lo.as<uint64_t>(), ctx->a_hi.as<uint64_t>());
     const uint32_t blocks = (uint32_t)((n_occ + 255) / 256);
+    uint32_t* d_seg_occ = nullptr;
+    if (h_seg_sk && n_seg > 1) {
+        if ((rc = ctx->a_seg.reserve((size_t)(n_seg + 1) * 8 + 64))) { free(out); return rc; }
+        uint32_t* d_seg_sk = ctx->a_seg.as<uint32_t>();
+        d_seg_occ = d_seg_sk + (n_seg + 1);
+        e = hipMemcpyAsync(d_seg_sk, h_seg_sk, (size_t)(n_seg + 1) * 4, hipMemcpyHostToDevice, ctx->stream);     // (the caller's array outlives the wait below)
+        if (e != hipSuccess) { free(out); return hip_fail(e, "abundance segments", __FILE__, __LINE__); }
+        hipLaunchKernelGGL(k_abund_segments, dim3((n_seg + 256) / 256), dim3(256), 0, ctx->stream, (const uint32_t*)d_seg_sk, n_seg, (const uint32_t*)ctx->a_off.as<uint32_t>(), d_seg_occ);
+    }
     hipLaunchKernelGGL(k_abund_insert, dim3(blocks), dim3(256), 0, ctx->stream, ctx->a_mn.as<uint32_t>(), ctx->a_lo.as<uint64_t>(),
-                       ctx->a_hi.as<uint64_t>(), (uint32_t)n_occ, slot, count, (uint32_t)(cap - 1), ctx->a_slot_of.as<uint32_t>());
+                       ctx->a_hi.as<uint64_t>(), (uint32_t)n_occ, slot, count, (uint32_t)(cap - 1), ctx->a_slot_of.as<uint32_t>(),
+                       (const uint32_t*)d_seg_occ, n_seg);
     hipLaunchKernelGGL(k_abund_flags, dim3(blocks), dim3(256), 0, ctx->stream, (uint32_t)n_occ, ctx->a_slot_of.as<uint32_t>(), slot, count,
                        p->abundance, ctx->a_flags.as<uint8_t>());
     e = hipGetLastError();

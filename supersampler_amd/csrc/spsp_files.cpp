@@ -186,6 +186,7 @@ struct PipeFile {
     uint64_t text_len = 0, off = 0;      // place in the slab (off is a multiple of kSlabAlign)
     uint32_t first_rec = 0, n_rec = 0;
     uint64_t sk0 = 0, sk1 = 0;           // its super-k-mers in the batch's stream
+    uint64_t occ0 = 0;                   // -a > 1: its first k-mer occurrence in the batch's numbering
     uint64_t total_superkmers = 0;       // SPSP_SCAN_STATS
     bool done = false;                   // sketched and written already (one-job-per-file fallback of an over-large batch)
     spsp_sketch_stats st{};
@@ -204,6 +205,7 @@ struct PipeSlot {
     std::vector<spsp_superkmer> sk;
     uint8_t* compact = nullptr;
     uint32_t* coff = nullptr;
+    uint8_t* kflags = nullptr;           // -a > 1: the device abundance pass's verdict per k-mer occurrence of the batch (file by file)
     bool busy = false;
     int device = 0;              // the device its context lives on
 };
@@ -262,7 +264,7 @@ public:
                 const spsp_stage_times& t = s->ctx->stages;
                 times->ingest_s += t.ingest_s; times->scan_s += t.scan_s; times->gather_s += t.gather_s;
             }
-            free(s->compact); free(s->coff); s->compact = nullptr; s->coff = nullptr;
+            free(s->compact); free(s->coff); free(s->kflags); s->compact = nullptr; s->coff = nullptr; s->kflags = nullptr;
             std::vector<PipeFile>().swap(s->files);
             const int dev = s->device;
             give_slot(dev, std::move(s));
@@ -470,7 +472,7 @@ private:
     void gpu(PipeSlot& s) {
         int rc = SPSP_OK;
         spsp_ctx* ctx = s.ctx;
-        free(s.compact); free(s.coff); s.compact = nullptr; s.coff = nullptr;
+        free(s.compact); free(s.coff); free(s.kflags); s.compact = nullptr; s.coff = nullptr; s.kflags = nullptr;
         s.sk.clear(); s.rec_off.clear();
         auto run = [&]() -> int {
             if (s.total == 0) return SPSP_OK;
@@ -516,6 +518,23 @@ private:
                 f.sk1 = at;
             }
             t1 = now_s(); ctx->stages.gather_s += t1 - t0; t0 = t1;
+            if (p_.abundance > 1 && n_sk) {
+                // -a > 1: every k-mer occurrence of the batch counted in ONE device pass, file by file (the reference's index is per
+                // file: one Subsampler per file, SubSampler.cpp:787) -- a GPU job per file was ~0.35 ms of launches and waits each
+                std::vector<uint32_t> seg;
+                uint64_t occ = 0;
+                size_t q = 0;
+                for (auto& f : s.files) {
+                    if (f.rc) continue;
+                    for (; q < f.sk0; ++q) occ += s.sk[q].len >= p_.k ? s.sk[q].len - p_.k + 1 : 0;
+                    f.occ0 = occ;
+                    seg.push_back(seg.empty() ? 0u : (uint32_t)f.sk0);
+                }
+                seg.push_back((uint32_t)n_sk);
+                uint64_t n_occ = 0;
+                if ((r = spsp::abundance_flags_impl(ctx, &p_, d_sk, n_sk, &s.kflags, &n_occ, seg.data(), (uint32_t)seg.size() - 1))) return r;
+                t1 = now_s(); ctx->stages.scan_s += t1 - t0; t0 = t1;
+            }
             if (p_.flags & SPSP_SCAN_STATS) {
                 // print_stat's count of ALL super-k-mers (SubSampler.cpp:429-430,451-452) is a per-file figure: the counting
                 // pass runs over each file's records, addressed from the file's first base
@@ -560,7 +579,7 @@ private:
             for (auto& e : mine) e.rec -= f.first_rec;
             static const uint64_t no_rec[1] = {0};
             f.rc = spsp::sketch_build_core(&p_, rate_, f.n_rec ? s.rec_off.data() + f.first_rec : no_rec, f.n_rec, mine.data(), mine.size(), nullptr, s.compact,
-                                           s.coff ? s.coff + f.sk0 : nullptr, &payload, &plen, &f.st, nullptr);
+                                           s.coff ? s.coff + f.sk0 : nullptr, &payload, &plen, &f.st, s.kflags ? s.kflags + f.occ0 : nullptr);
             if (f.rc) f.err = spsp_last_error();
             if (!f.rc && (p_.flags & SPSP_SCAN_STATS)) { f.st.total_superkmer_number = f.total_superkmers; f.st.total_kmer_number = f.st.read_kmer; }
             double t1 = now_s();
@@ -625,7 +644,8 @@ int spsp_sketch_files_multi(const int* devices, uint32_t n_dev, const spsp_param
     if (rc0) return rc0;
     if (threads == 0) threads = 1;
     static const bool per_worker = getenv("SPSP_FILES_PER_WORKER") != nullptr;   // A/B switch: one GPU job per file
-    if (per_worker || p->abundance > 1 || n == 0)          // (-a > 1: the abundance pass counts k-mers per file on the device)
+    static const bool abund_per_file = getenv("SPSP_DEBUG_ABUND_PER_FILE") != nullptr;   // A/B: -a > 1 as one GPU job per file (the form until round 5)
+    if (per_worker || (p->abundance > 1 && abund_per_file) || n == 0)
         return sketch_files_per_worker(device, p, rate, fasta_paths, out_paths, n, threads, cb, user, times);
     if (times) memset(times, 0, sizeof *times);
     FilePipeline pipe(device, p, rate, fasta_paths, out_paths, n, threads, cb, user);

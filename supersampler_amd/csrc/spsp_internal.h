@@ -167,7 +167,7 @@ struct spsp_ctx {
     double filter_ratio = 1.0;   // records dealt into parts per owned key in the last filtered comparison (sizes the next one's parts)
     spsp::DevBuf x_cnt, x_off, x_begin, x_end, x_tot;   // key-partitioned exchange (spsp_compare.hip)
     spsp::DevBuf dc_text, dc_desc, dc_mn, dc_lo, dc_hi, dc_meta, dc_walk;   // bulk sketch decode (spsp_decode.hip)
-    spsp::DevBuf a_cnt, a_off, a_mn, a_lo, a_hi, a_slot, a_slot_of, a_flags;   // -a abundance pass (spsp_abund.hip)
+    spsp::DevBuf a_cnt, a_off, a_mn, a_lo, a_hi, a_slot, a_slot_of, a_flags, a_seg;   // -a abundance pass (spsp_abund.hip)
     // genomes / sketches beyond the per-segment LDS forms (spsp_bigkeys.hip): output slices, the open-addressing table in HBM
     // (slot words carry the epoch of the call that claimed them: never cleared between calls), the sort's tile list
     spsp::DevBuf b_mn, b_lo, b_hi, b_table, b_tiles, b_seg;
@@ -245,7 +245,8 @@ int launch_scan_u32(spsp_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, uint64
 int inflate_all_host(const uint8_t* in, size_t n, std::vector<uint8_t>& out);
 // host sketch builder over per-super-k-mer base pointers (spsp_host.cpp)
 // -a on the device (spsp_abund.hip): per k-mer occurrence of the gathered super-k-mers, bit 0 usable, bit 1 first of a dropped k-mer
-int abundance_flags_impl(spsp_ctx* ctx, const spsp_params* p, const spsp_superkmer* d_sk, uint64_t n_sk, uint8_t** h_flags, uint64_t* n_occ);
+int abundance_flags_impl(spsp_ctx* ctx, const spsp_params* p, const spsp_superkmer* d_sk, uint64_t n_sk, uint8_t** h_flags, uint64_t* n_occ_out,
+                         const uint32_t* h_seg_sk = nullptr, uint32_t n_seg = 0);
 // exchange slots of the key-partitioned split (wire format: spsp_compare.hip, sender; spsp_multi.hip, receiver)
 constexpr uint32_t kSlotMagic = 0x4c535053u;   // "SPSL"
 constexpr uint32_t kMaxParts = 64;

@@ -1082,13 +1082,63 @@ def test_sketch_files_pipeline_equals_oracle(tmp_path):
     res, _, started = sp.sketch_files(bad, outs, k, m, s, threads=2)
     assert [r[0] == 0 for r in res] == [True, True, False, True, True] and "missing.fa" in res[2][2]
     assert sp.read_file(outs[4]) == want[3][0]
-    # -a 2: k-mers are counted per file on the device -> one GPU job per file
+    # -a 2: k-mers are counted per file on the device (since round 5 in one pass per batch: test_abundance_through_the_batched_pipeline)
     dup = texts[0] + texts[0].replace(b">g0", b">again")
     open(str(tmp_path / "dup.fa"), "wb").write(dup)
     outs = [str(tmp_path / "dup.gz"), str(tmp_path / "single.gz")]
     res, _, _ = sp.sketch_files([str(tmp_path / "dup.fa"), ins[0]], outs, k, m, s, abundance=2, threads=2)
     assert all(r[0] == 0 for r in res)
     assert sp.read_file(outs[0]) == orc.sketch_fasta(dup, k, m, s, 2)[0] and sp.read_file(outs[1]) == orc.sketch_fasta(texts[0], k, m, s, 2)[0]
+
+
+@pytest.mark.parametrize("k,m,s,ab", [(31, 11, 40.0, 2), (63, 15, 15.0, 3), (31, 11, 40.0, 1)])
+def test_abundance_through_the_batched_pipeline(tmp_path, k, m, s, ab):
+    """-a > 1 in spsp_sketch_files: the k-mer occurrences of a whole batch of files are counted in ONE device pass with the
+    file as part of the key (the reference's index is per file: one Subsampler per file, SubSampler.cpp:787; its count is a
+    uint8, :283-300, and a k-mer is used only from `count >= abundance` on, :587,608).  100 files: every file holds segments
+    seen once, twice and three times (some on the other strand), a unit repeated 257 times (the count wraps to 1), and
+    shares its whole sequence with its neighbour file -- k-mers of ANOTHER file must not count.  Payload bytes and statistics
+    equal the oracle's, with 1, 4 and 16 workers, and the one-job-per-file form (SPSP_DEBUG_ABUND_PER_FILE) writes the same."""
+    rng = np.random.default_rng(500 + k + ab)
+    comp = {65: 84, 67: 71, 71: 67, 84: 65}
+    base = [synth.random_genome(rng, 30_000) for _ in range(50)]
+    texts = []
+    for i in range(100):
+        g = base[i // 2]                                              # files 2j and 2j + 1 hold the same genome ...
+        once, twice = g[:10_000], g[10_000:20_000]
+        rc_twice = np.array([comp[c] for c in twice[::-1].tolist()], dtype=np.uint8)
+        thrice = g[20_000:30_000]
+        unit = synth.random_genome(rng, k + 5)
+        recs = [once, twice, rc_twice if i % 2 else twice, thrice, thrice, thrice, np.tile(unit, 257)]
+        if i % 2:
+            recs = recs[::-1]                                         # ... in another record order
+        texts.append(b"".join(synth.to_fasta(r, "f%d_r%d" % (i, j)) for j, r in enumerate(recs)))
+    ins = []
+    for i, t in enumerate(texts):
+        pth = str(tmp_path / ("a%03d.fa" % i))
+        open(pth, "wb").write(t)
+        ins.append(pth)
+    want = [orc.sketch_fasta(t, k, m, s, ab) for t in texts]
+    assert want[0][0] != orc.sketch_fasta(texts[0], k, m, s, 1)[0] or ab == 1
+    fields = ("selected_kmer_number", "selected_superkmer_number", "seen_kmers_at_reconstruction", "actual_minimizer_number", "read_kmer",
+              "count_maximal_skmer", "nb_mmer_selected")
+    for threads in (1, 4, 16):
+        outs = [str(tmp_path / ("o%d_%03d.gz" % (threads, i))) for i in range(len(ins))]
+        res, times, _ = sp.sketch_files(ins, outs, k, m, s, abundance=ab, threads=threads)
+        for i, (rc, st, err) in enumerate(res):
+            assert rc == 0 and err is None, (threads, i, rc, err)
+            assert sp.read_file(outs[i]) == want[i][0], (threads, i)
+            for f in fields:
+                assert st[f] == want[i][1][f], (threads, i, f, st[f], want[i][1][f])
+    if ab > 1:
+        code = ("import sys\nsys.path.insert(0, %r)\nimport supersampler_amd as sp\n"
+                "ins = [l.strip() for l in open(sys.argv[1])]\nouts = [x + '.perfile.gz' for x in ins]\n"
+                "res, _, _ = sp.sketch_files(ins, outs, %d, %d, %r, abundance=%d, threads=4)\nassert all(r[0] == 0 for r in res)\nprint('ok')\n") % (ROOT, k, m, s, ab)
+        (tmp_path / "fof.txt").write_text("\n".join(ins[:12]) + "\n")
+        r = subprocess.run([sys.executable, "-c", code, str(tmp_path / "fof.txt")], env=dict(os.environ, SPSP_DEBUG_ABUND_PER_FILE="1"), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+        for i in range(12):
+            assert sp.read_file(ins[i] + ".perfile.gz") == want[i][0], i
 
 
 @pytest.mark.parametrize("k,m,s,ab", [(31, 11, 20.0, 1), (31, 11, 1000.0, 1), (63, 15, 10.0, 1), (21, 11, 3.0, 2), (33, 13, 4.0, 3), (11, 11, 4.0, 3)])
