@@ -986,7 +986,7 @@ def device_bytes_as_tensor(ptr, nbytes, dev):
     return torch.as_tensor(_Arr(), device=dev)
 
 
-def sq_counters(kernel, kernel_ms, n_cu, default_file="r04_pmc_sq_bench.json"):
+def sq_counters(kernel, kernel_ms, n_cu, default_file="r05_pmc_sq_bench.json"):
     """VALU-issue fraction of a kernel (SURVEY.md 8d asks for it next to the HBM fraction: the scan is ALU-bound in
     practice).  SQ counters cannot be read from inside this process; they come from the committed rocprofv3 --pmc passes
     of the matching command (profiles/, with provenance).  A wave64 VALU instruction holds its SIMD's issue port for 4
@@ -1015,7 +1015,7 @@ def pmc_traffic(args, kernel):
     same command, gfx950 correction applied).  Counters cannot be read from inside this process: the figure comes from
     the committed profile of the matching workload, with its provenance; null when there is none."""
     try:
-        name = os.environ.get("BENCH_PMC_FILE", "r04_pmc_hbm_traffic.json")
+        name = os.environ.get("BENCH_PMC_FILE", "r05_pmc_hbm_traffic.json")
         path = os.path.join(ROOT, "profiles", name)
         d = json.load(open(path))
         w = d["workload"]
@@ -1111,7 +1111,7 @@ def compare_config4(ctx, dev, skip_oracle, peak):
                         "compulsory_model": {"bytes": compulsory, "achieved": compulsory / ms / 1e6, "frac": compulsory / ms / 1e6 / HBM_PEAK_GBS,
                                              "model": "8 sum(n_i) + 4 N(N-1)/2 bytes: every key read once, every cell written once"}},
            "setup_s": setup_s}
-    out["roofline"].update(pmc_compare("r04_c4_pmc_hbm_traffic.json", total))
+    out["roofline"].update(pmc_compare("r05_c4_pmc_hbm_traffic.json", total))
     # sampled pairs against numpy set intersections (whole matrix)
     rng = np.random.default_rng(0)
     mn_all, lo_all = D.minimizer, D.kmer_lo
@@ -1385,12 +1385,12 @@ def scan_config5(ctx, dev, skip_oracle, peak, gbp=4.0):
                         "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                         "frac_of_measured_read": gbs / peak["read_GBps"] if peak.get("read_GBps") else None,
                         "algorithmic_bytes_per_launch": seg_n, "byte_model": "1 B per m-mer position (cleaned ASCII)"}}
-    out["roofline"].update(sq_counters("k_dense_bloom", dense_ms, 0, "r04_pmc_sq_c5.json"))
+    out["roofline"].update(sq_counters("k_dense_bloom", dense_ms, 0, "r05_pmc_sq_c5.json"))
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r04_c5_pmc_hbm_traffic.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r05_c5_pmc_hbm_traffic.json")))
         kn = [x for x in d["kernels"] if x.startswith("k_dense_bloom")][0]
         out["roofline"]["traffic"] = d["kernels"][kn]["hbm_bytes_per_launch_corrected"] * (seg_n / d["workload"]["bases_per_launch"])
-        out["roofline"]["traffic_provenance"] = {"file": "profiles/r04_c5_pmc_hbm_traffic.json", "commit": d.get("commit"),
+        out["roofline"]["traffic_provenance"] = {"file": "profiles/r05_c5_pmc_hbm_traffic.json", "commit": d.get("commit"),
                                                  "scaled_from_bases_per_launch": d["workload"]["bases_per_launch"]}
     except Exception:  # noqa: BLE001
         out["roofline"]["traffic"] = None
@@ -1629,7 +1629,7 @@ def compare_config3(ctx, dev, skip_oracle):
                                              "frac": compulsory / ms / 1e6 / HBM_PEAK_GBS if ms > 0 else None,
                                              "model": "8 sum(n_i) + 4 N(N-1)/2 bytes: every key read once, every cell written once"}},
            "setup_s": setup_s}
-    out["roofline"].update(pmc_compare("r04_compare_pmc_hbm_traffic.json", total))
+    out["roofline"].update(pmc_compare("r05_compare_pmc_hbm_traffic.json", total))
     ctx.compare_keys_unordered(False)
     if not skip_oracle:
         from oracle import oracle_py as orc
@@ -1643,7 +1643,7 @@ def compare_config3(ctx, dev, skip_oracle):
     return out
 
 
-def pmc_compare(name="r04_compare_pmc_hbm_traffic.json", n_keys=None):
+def pmc_compare(name="r05_compare_pmc_hbm_traffic.json", n_keys=None):
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", name)))
         tr = {kname: v["hbm_bytes_per_launch_corrected"] for kname, v in d["kernels"].items() if kname.startswith(("k_parts", "k_accumulate"))}

@@ -187,6 +187,9 @@ struct PipeFile {
     uint32_t first_rec = 0, n_rec = 0;
     uint64_t sk0 = 0, sk1 = 0;           // its super-k-mers in the batch's stream
     uint64_t occ0 = 0;                   // -a > 1: its first k-mer occurrence in the batch's numbering
+    std::string body;                    // device builder: everything behind the header line
+    bool built = false;
+    uint64_t dev_stats[4] = {0, 0, 0, 0};
     uint64_t total_superkmers = 0;       // SPSP_SCAN_STATS
     bool done = false;                   // sketched and written already (one-job-per-file fallback of an over-large batch)
     spsp_sketch_stats st{};
@@ -507,7 +510,12 @@ private:
             if (prev) prev->n_rec = n_rec - prev->first_rec;
             s.sk.resize((size_t)n_sk);
             if (n_sk) SPSP_HIP(hipMemcpyAsync(s.sk.data(), d_sk, (size_t)n_sk * sizeof(spsp_superkmer), hipMemcpyDeviceToHost, ctx->stream));
-            if ((r = spsp::gather_superkmers_impl(ctx, d_bases, d_off, d_sk, n_sk, &s.compact, &s.coff, packed))) return r;   // synchronises the stream
+            SPSP_HIP(hipStreamSynchronize(ctx->stream));                      // (the stream's copy above: the files' ranges and the choice below come from it)
+            uint64_t places = 0;
+            for (const spsp_superkmer& e : s.sk) places += e.len >= p_.k ? e.len - p_.k + 1 : 0;
+            const bool dev_build = spsp::build_on_device(places) && n_sk <= 0xfffffff0ull;
+            bool built = false;
+            if (!dev_build && (r = spsp::gather_superkmers_impl(ctx, d_bases, d_off, d_sk, n_sk, &s.compact, &s.coff, packed))) return r;   // synchronises the stream
             // the stream is in genome order: a file's super-k-mers are those of its records
             size_t at = 0;
             for (auto& f : s.files) {
@@ -518,7 +526,32 @@ private:
                 f.sk1 = at;
             }
             t1 = now_s(); ctx->stages.gather_s += t1 - t0; t0 = t1;
-            if (p_.abundance > 1 && n_sk) {
+            if (dev_build) {
+                // the sketch builder on the device, for the whole batch (spsp_build.hip): file j's super-k-mers are [sk0, sk1)
+                std::vector<uint32_t> fsk;
+                std::vector<size_t> who;
+                for (size_t j = 0; j < s.files.size(); ++j) {
+                    if (s.files[j].rc) continue;
+                    fsk.push_back((uint32_t)s.files[j].sk0);
+                    who.push_back(j);
+                }
+                fsk.push_back((uint32_t)n_sk);
+                if (!who.empty()) fsk[0] = 0;
+                std::vector<std::string> bodies;
+                std::vector<uint64_t> fst;
+                r = who.empty() ? SPSP_OK : spsp::sketch_build_device_impl(ctx, &p_, d_bases, packed, d_off, d_sk, n_sk, fsk.data(), (uint32_t)who.size(), &bodies, &fst);
+                if (r == SPSP_OK) {
+                    for (size_t x = 0; x < who.size(); ++x) {
+                        PipeFile& f = s.files[who[x]];
+                        f.body.swap(bodies[x]); f.built = true;
+                        for (int q = 0; q < 4; ++q) f.dev_stats[q] = fst[4 * x + q];
+                    }
+                    built = true;
+                } else if (r != SPSP_ERR_OVERFLOW) return r;
+                else if ((r = spsp::gather_superkmers_impl(ctx, d_bases, d_off, d_sk, n_sk, &s.compact, &s.coff, packed))) return r;   // too many places: the host builder
+                t1 = now_s(); add_time(build_s_, t1 - t0); t0 = t1;
+            }
+            if (!built && p_.abundance > 1 && n_sk) {
                 // -a > 1: every k-mer occurrence of the batch counted in ONE device pass, file by file (the reference's index is per
                 // file: one Subsampler per file, SubSampler.cpp:787) -- a GPU job per file was ~0.35 ms of launches and waits each
                 std::vector<uint32_t> seg;
@@ -578,6 +611,21 @@ private:
             std::vector<spsp_superkmer> mine(s.sk.begin() + (ptrdiff_t)f.sk0, s.sk.begin() + (ptrdiff_t)f.sk1);
             for (auto& e : mine) e.rec -= f.first_rec;
             static const uint64_t no_rec[1] = {0};
+            if (f.built) {
+                // built on the device: the counters of the stream and the header line are the host's
+                f.rc = spsp::sketch_stream_stats(&p_, f.n_rec ? s.rec_off.data() + f.first_rec : no_rec, f.n_rec, mine.data(), mine.size(), &f.st);
+                if (!f.rc) {
+                    f.st.actual_minimizer_number = f.dev_stats[0]; f.st.seen_kmers_at_reconstruction = f.dev_stats[1];
+                    f.st.seen_superkmers_at_reconstruction = f.dev_stats[2]; f.st.seen_max_superkmers_at_reconstruction = f.dev_stats[3];
+                    std::string head;
+                    spsp::sketch_header_line(p_.k, p_.m, f.st.selected_kmer_number, rate_, head);
+                    plen = head.size() + f.body.size();
+                    payload = (uint8_t*)malloc((size_t)plen + 1);
+                    if (!payload) { spsp::set_error("out of host memory"); f.rc = SPSP_ERR_NOMEM; }
+                    else { memcpy(payload, head.data(), head.size()); memcpy(payload + head.size(), f.body.data(), f.body.size()); }
+                    std::string().swap(f.body);
+                }
+            } else
             f.rc = spsp::sketch_build_core(&p_, rate_, f.n_rec ? s.rec_off.data() + f.first_rec : no_rec, f.n_rec, mine.data(), mine.size(), nullptr, s.compact,
                                            s.coff ? s.coff + f.sk0 : nullptr, &payload, &plen, &f.st, s.kflags ? s.kflags + f.occ0 : nullptr);
             if (f.rc) f.err = spsp_last_error();

@@ -441,6 +441,45 @@ int sketch_build_core(const spsp_params* p, double rate, const uint64_t* rec_off
     return SPSP_OK;
 }
 
+// What the device builder (spsp_build.hip) leaves to the host: the counters that are a pure function of the scan's stream
+// (the same lines as in sketch_build_core above) and the header line.
+int sketch_stream_stats(const spsp_params* p, const uint64_t* rec_off, uint32_t n_rec, const spsp_superkmer* sk, uint64_t n_sk, spsp_sketch_stats* st_out) {
+    spsp_sketch_stats st;
+    memset(&st, 0, sizeof st);
+    uint64_t nb = 0, pos_end = 0;
+    uint32_t cur_rec = 0xffffffffu;
+    for (uint32_t r = 0; r < n_rec; ++r) {
+        const uint64_t len = rec_off[r + 1] - rec_off[r];
+        if (len >= p->k) st.read_kmer += len - p->k + 1;
+    }
+    for (uint64_t i = 0; i < n_sk; ++i) {
+        const spsp_superkmer& e = sk[i];
+        if (e.rec >= n_rec || e.len < p->k || e.start + e.len > rec_off[e.rec + 1] - rec_off[e.rec]) {
+            set_error("super-k-mer %llu is outside its record", (unsigned long long)i);
+            return SPSP_ERR_ARG;
+        }
+        if (e.rec != cur_rec) { cur_rec = e.rec; pos_end = 0; }
+        const uint64_t rlen = rec_off[e.rec + 1] - rec_off[e.rec];
+        if (e.start + e.len == rlen) nb -= p->m - 1;
+        else {
+            if (e.start + p->m - 2 > pos_end) {
+                if (pos_end > 0) nb -= p->m - 1;
+                nb += e.len;
+                nb -= p->k - p->m;
+            } else nb += e.start + e.len - (pos_end + 1);
+            pos_end = e.start + e.len - 1;
+        }
+        st.selected_kmer_number += e.len - p->k + 1;
+        st.selected_superkmer_number++;
+        if (e.len == 2 * p->k - p->m) st.count_maximal_skmer++;
+    }
+    nb -= p->m - 1;
+    st.nb_mmer_selected = nb;
+    *st_out = st;
+    return SPSP_OK;
+}
+void sketch_header_line(uint32_t k, uint32_t m, uint64_t selected_kmers, double rate, std::string& out) { Builder::emit_header(k, m, selected_kmers, rate, out); }
+
 // structure of one payload for the GPU decoder (spsp_decode.hip): header (Comparator.cpp:23-37) and, per bucket,
 // [m ASCII][u32 n][blob][lines]["\n\n"] (:186-260).  Every offset it hands to the device is checked against `len` here.
 int sketch_parse_structure_host(const uint8_t* payload, uint64_t len, ParsedSketch* P) {

@@ -20,6 +20,9 @@
 #include <cstdlib>
 #include <vector>
 
+#include <cstring>
+#include <string>
+
 #include "spsp_internal.h"
 #include "spsp_device.h"
 
@@ -466,6 +469,17 @@ int gather_superkmers_impl(spsp_ctx* ctx, const uint8_t* d_bases, const uint64_t
     return SPSP_OK;
 }
 
+// Where the sketch is built.  The device builder (spsp_build.hip) is a chain of ~25 launches and four host waits, ~2.5 ms
+// whatever the size, then ~1.2 ns per k-mer place; the host builder costs ~110 ns per place and thread and runs file by file
+// on the pipeline's workers.  A batch of bacterial genomes at -s 1000 (4 x 10^4 places) is faster on the host threads, a
+// metagenome file (4 x 10^7 places: 0.23 s of host builder against 0.05 s) on the device: from 5 x 10^5 places on.
+// SPSP_BUILD=device / host pins the choice (the tests run both).
+bool build_on_device(uint64_t places) {
+    static const char* e = getenv("SPSP_BUILD");
+    if (e && e[0] == 'h') return false;
+    if (e && e[0] == 'd') return true;
+    return places >= 500000;
+}
 bool ingest_packs(const spsp_params* p) {
     static const bool ascii = getenv("SPSP_INGEST_ASCII") != nullptr;
     return !ascii && !(p->flags & SPSP_SCAN_PACKED_INPUT) && scan_reads_packed(p);
@@ -524,6 +538,44 @@ int spsp_sketch_text(spsp_ctx* ctx, const spsp_params* p, double rate, const cha
     std::vector<spsp_superkmer> sk((size_t)n_sk);
     SPSP_HIP(hipMemcpyAsync(rec_off.data(), d_off, rec_off.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (n_sk) SPSP_HIP(hipMemcpyAsync(sk.data(), d_sk, (size_t)n_sk * sizeof(spsp_superkmer), hipMemcpyDeviceToHost, ctx->stream));
+    // the sketch builder on the device (spsp_build.hip; SPSP_BUILD=host: the host builder over the gathered super-k-mers, as until
+    // round 5): only the finished payload comes back
+    uint64_t places = 0;
+    if (n_sk) {
+        SPSP_HIP(hipStreamSynchronize(ctx->stream));                   // (the stream's copy queued above)
+        for (const spsp_superkmer& e : sk) places += e.len >= p->k ? e.len - p->k + 1 : 0;
+    }
+    if (build_on_device(places)) {
+        const uint32_t fsk[2] = {0u, (uint32_t)n_sk};
+        std::vector<std::string> bodies;
+        std::vector<uint64_t> fst;
+        rc = n_sk <= 0xfffffff0ull ? sketch_build_device_impl(ctx, p, d_bases, packed, d_off, d_sk, n_sk, fsk, 1, &bodies, &fst) : SPSP_ERR_OVERFLOW;
+        if (rc != SPSP_ERR_OVERFLOW) {
+            if (rc) return rc;
+            SPSP_HIP(hipStreamSynchronize(ctx->stream));               // (the copies of the stream and the offsets queued above)
+            spsp_sketch_stats st;
+            if ((rc = sketch_stream_stats(p, rec_off.data(), n_rec, sk.data(), n_sk, &st))) return rc;
+            st.actual_minimizer_number = fst[0]; st.seen_kmers_at_reconstruction = fst[1];
+            st.seen_superkmers_at_reconstruction = fst[2]; st.seen_max_superkmers_at_reconstruction = fst[3];
+            std::string head;
+            sketch_header_line(p->k, p->m, st.selected_kmer_number, rate, head);
+            *payload = (uint8_t*)malloc(head.size() + bodies[0].size() + 1);
+            if (!*payload) { set_error("out of host memory"); return SPSP_ERR_NOMEM; }
+            memcpy(*payload, head.data(), head.size());
+            memcpy(*payload + head.size(), bodies[0].data(), bodies[0].size());
+            *payload_len = head.size() + bodies[0].size();
+            if (stats) *stats = st;
+            ctx->stages.build_s += now_s() - t0;
+            if (stats && (p->flags & SPSP_SCAN_STATS)) {
+                t0 = now_s();
+                rc = count_superkmers_impl(ctx, p, d_bases, n_bases, d_off, n_rec, &stats->total_superkmer_number, packed, 0);
+                stats->total_kmer_number = stats->read_kmer;
+                ctx->stages.scan_s += now_s() - t0;
+            }
+            return rc;
+        }
+        rc = SPSP_OK;                                                  // beyond the device builder's numbering: the host builder below
+    }
     uint8_t* compact = nullptr; uint32_t* coff = nullptr;
     if ((rc = gather_superkmers_impl(ctx, d_bases, d_off, d_sk, n_sk, &compact, &coff, packed))) return rc;   // synchronises the stream
     // -a > 1: the k-mers are counted here, over the gathered super-k-mers still on the device, and the host builder

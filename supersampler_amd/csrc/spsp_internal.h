@@ -166,6 +166,7 @@ struct spsp_ctx {
     uint32_t filter_skipped = 0;
     double filter_ratio = 1.0;   // records dealt into parts per owned key in the last filtered comparison (sizes the next one's parts)
     spsp::DevBuf x_cnt, x_off, x_begin, x_end, x_tot;   // key-partitioned exchange (spsp_compare.hip)
+    spsp::DevBuf bl_hist, bl_keys, bl_vals, bl_meta, bl_lo, bl_hi, bl_pmin, bl_pb, bl_slot, bl_first, bl_codes, bl_text, bl_outs, bl_out;   // sketch builder on the device (spsp_build.hip)
     spsp::DevBuf dc_text, dc_desc, dc_mn, dc_lo, dc_hi, dc_meta, dc_walk;   // bulk sketch decode (spsp_decode.hip)
     spsp::DevBuf a_cnt, a_off, a_mn, a_lo, a_hi, a_slot, a_slot_of, a_flags, a_seg;   // -a abundance pass (spsp_abund.hip)
     // genomes / sketches beyond the per-segment LDS forms (spsp_bigkeys.hip): output slices, the open-addressing table in HBM
@@ -235,12 +236,19 @@ int clean_device_impl(spsp_ctx* ctx, const uint8_t* d_text, uint64_t n_text, uin
                       uint64_t** d_rec_off, uint32_t* n_rec, bool pack = false);
 // does the dense pass chosen for these parameters read 2-bit input directly? (spsp_scan.hip)
 bool scan_reads_packed(const spsp_params* p);
+bool build_on_device(uint64_t places);    // the sketch builder on the device from 5 x 10^5 k-mer places on (SPSP_BUILD=device / host pins it)
 // should the whole-file drivers let the ingest write 2-bit words for these parameters? (spsp_ingest.hip)
 bool ingest_packs(const spsp_params* p);
 int gather_superkmers_impl(spsp_ctx* ctx, const uint8_t* d_bases, const uint64_t* d_rec_off, const spsp_superkmer* d_sk,
                            uint64_t n_sk, uint8_t** h_compact, uint32_t** h_off, bool packed = false);
 // out[i] = sum(in[0..i)), out[n] = total (also stored to *total_host, pinned)
 int launch_scan_u32(spsp_ctx* ctx, const uint32_t* d_in, uint32_t* d_out, uint64_t n, uint64_t* total_host);
+int sketch_stream_stats(const spsp_params* p, const uint64_t* rec_off, uint32_t n_rec, const spsp_superkmer* sk, uint64_t n_sk, spsp_sketch_stats* st);
+void sketch_header_line(uint32_t k, uint32_t m, uint64_t selected_kmers, double rate, std::string& out);
+// the sketch builder on the device (spsp_build.hip): the bodies of n_files sketches from the scan's stream; file_stats: per file
+// actual_minimizer_number, seen_kmers_at_reconstruction, seen_superkmers_at_reconstruction, seen_max_superkmers_at_reconstruction
+int sketch_build_device_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, bool packed, const uint64_t* d_rec_off, const spsp_superkmer* d_sk,
+                             uint64_t n_sk, const uint32_t* h_file_sk, uint32_t n_files, std::vector<std::string>* bodies, std::vector<uint64_t>* file_stats);
 // zstr-style inflate of a whole buffer: gzip / zlib members, or the bytes as they are (spsp_host.cpp)
 int inflate_all_host(const uint8_t* in, size_t n, std::vector<uint8_t>& out);
 // host sketch builder over per-super-k-mer base pointers (spsp_host.cpp)

@@ -616,6 +616,61 @@ def test_abundance_filter_on_device_equals_oracle(ctx, k, m, s, ab):
         assert 0 < wst["seen_superkmers_at_reconstruction"] and len(want) < len(orc.sketch_fasta(text, k, m, s, 1)[0])
 
 
+_BUILDER = r"""
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np
+import supersampler_amd as sp
+from oracle import oracle_py as orc
+from supersampler_amd import synth
+import test_gpu
+ctx = sp.Context(0)
+fields = ("selected_kmer_number", "selected_superkmer_number", "count_maximal_skmer", "seen_kmers_at_reconstruction", "seen_superkmers_at_reconstruction",
+          "seen_max_superkmers_at_reconstruction", "actual_minimizer_number", "read_kmer", "nb_mmer_selected")
+comp = bytes.maketrans(b"ACGT", b"TGCA")
+n_cases = 0
+for (k, m, s, ab) in [(31, 11, 20.0, 1), (31, 11, 3.0, 2), (63, 15, 10.0, 1), (63, 15, 4.0, 3), (21, 11, 1.0, 1), (15, 15, 3.0, 1), (15, 15, 2.0, 2), (33, 13, 50.0, 1), (13, 9, 2.0, 1)]:
+    rng = np.random.default_rng(31 * k + ab)
+    a, b, c = (synth.random_genome(rng, n).tobytes() for n in (40_000, 20_000, 8_000))
+    unit = synth.random_genome(rng, k + 7).tobytes()
+    texts = [
+        b">one\n" + a + b"\n",                                                                        # plain
+        b"".join(b">r%%d\n%%s\n" %% (i, r) for i, r in enumerate([a + b, b[::-1].translate(comp) + c, c + a[:10_000] + c, unit * 257 + unit[:50], unit[::-1].translate(comp) * 256])),
+        b">hp\n" + b"A" * 3000 + c[:500] + b"T" * 3000 + b"\n>again\n" + b"A" * 3000 + b"\n",         # homopolymers: one k-mer thousands of times
+        b">short\n" + a[: k - 1] + b"\n>exact\n" + a[:k] + b"\n>plus1\n" + a[: k + 1] + b"\n",        # no k-mer / one / two
+        b">inv\n" + c + c[::-1].translate(comp) + c + b"\n",                                            # an inverted repeat: both strands of every k-mer
+        b">empty\n",
+    ]
+    for i, text in enumerate(texts):
+        got, gst = ctx.sketch_text(text, k, m, s, abundance=ab)
+        want, wst = orc.sketch_fasta(text, k, m, s, ab)
+        assert got == want, (k, m, s, ab, i, len(got), len(want))
+        for f in fields:
+            assert gst[f] == wst[f], (k, m, s, ab, i, f, gst[f], wst[f])
+        n_cases += 1
+print("ok", n_cases)
+"""
+
+
+def test_sketch_builder_on_the_device_equals_the_oracle(tmp_path):
+    """spsp_build.hip (SPSP_BUILD=device: handle_superkmer's index, the greedy emission walk and strCompressor on the GPU;
+    SubSampler.cpp:243-302, 458-620, utils.cpp:48-68) against the oracle's payload BYTES and every counter of print_stat,
+    on the shapes that exercise the walk's order rules: plain genomes, a segment on both strands, a k-mer seen twice and
+    three times (-a 1 / 2 / 3), a unit repeated 257 and 256 times (the uint8 count wraps to 1 / 0), homopolymers (one k-mer
+    thousands of times, ties of the minimizer inside a k-mer), records of k - 1 / k / k + 1 bases, an inverted repeat, an
+    empty file; k <= 32 and k > 32, k == m, -s 1 (every k-mer selected: buckets of thousands of k-mers).  Then the batched
+    file pipeline's own tests with the device builder pinned, and the same payloads with SPSP_BUILD=host."""
+    for build in ("device", "host"):
+        r = subprocess.run([sys.executable, "-c", _BUILDER % (ROOT, os.path.join(ROOT, "tests"))], env=dict(os.environ, SPSP_BUILD=build), capture_output=True, text=True, timeout=1200)
+        assert r.returncode == 0 and "ok 54" in r.stdout, (build, r.stdout[-2000:], r.stderr[-3000:])
+    code = ("import sys, pathlib, tempfile\nsys.path.insert(0, %r); sys.path.insert(0, %r)\nimport test_gpu\n"
+            "d = pathlib.Path(tempfile.mkdtemp(dir=sys.argv[1]))\ntest_gpu.test_sketch_files_pipeline_equals_oracle(d)\n"
+            "for (k, m, s, ab) in [(31, 11, 40.0, 2), (63, 15, 15.0, 3)]:\n"
+            "    d = pathlib.Path(tempfile.mkdtemp(dir=sys.argv[1]))\n    test_gpu.test_abundance_through_the_batched_pipeline(d, k, m, s, ab)\nprint('ok')\n") % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code, str(tmp_path)], env=dict(os.environ, SPSP_BUILD="device"), capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
 def test_scan_buffer_overflow_retries():
     """the sparse stages are launched with capacity-sized buffers; a call that overflows them
     re-runs with room (hits: from the dense pass, super-k-mers: the write pass only)."""

@@ -74,7 +74,7 @@ python3 $R/tools/prof_summary.py $(find /tmp/kt5 -name "*kernel_trace.csv") $out
 pmc_pair c5 $cmd || exit 1
 python3 $R/tools/pmc_traffic.py $out/c5_FETCH_SIZE.csv $out/c5_WRITE_SIZE.csv $out/c5_pmc_hbm_traffic.json "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE (separate passes) -- python3 tools/c5_scan.py 4 4" '{"bases_per_launch": 4000000000, "k": 63, "m": 15, "s": 100.0}' > /dev/null
 sq_sets c5 $cmd || exit 1
-python3 $R/tools/pmc_sq.py --json $out/pmc_sq_c5.json --command "rocprofv3 --pmc <4 SQ counters per pass> -- python3 tools/c5_scan.py 4 4" "k_dense_bloom<15>" $(find /tmp/pmc_c5_sq_* -name "*counter_collection.csv") > $out/pmc_sq_k_dense_bloom.txt
+python3 $R/tools/pmc_sq.py --json $out/pmc_sq_c5.json --command "rocprofv3 --pmc <4 SQ counters per pass> -- python3 tools/c5_scan.py 4 4" "k_dense_bloom<15" $(find /tmp/pmc_c5_sq_* -name "*counter_collection.csv") > $out/pmc_sq_k_dense_bloom.txt
 rm -f $out/c5_FETCH_SIZE.csv $out/c5_WRITE_SIZE.csv
 echo "c5 done"
 fi
