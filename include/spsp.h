@@ -352,6 +352,11 @@ int spsp_sketch_keys_device_begin(spsp_ctx* ctx, const spsp_params* p, const voi
 /* on != 0: the device-form comparisons queued on this context from now on accept sketches whose keys are distinct but
  * unsorted (the caller vouches for "distinct": duplicates inside a sketch would be counted twice) */
 int spsp_compare_keys_unordered(spsp_ctx* ctx, int on);
+/* A context remembers what its last comparisons looked like (the input came in a good row order, most records had lists,
+ * parts spilled, the filter's pass rate) and queues the next one accordingly -- scheduling only, results never depend on it.
+ * This forgets all of it: for timing or profiling comparisons of different collections on one context.
+ * SPSP_DEBUG_SPILL_TRACE=1 prints the form every comparison took on stderr. */
+int spsp_compare_forget(spsp_ctx* ctx);
 int spsp_sketch_keys_device_end(spsp_ctx* ctx, void** d_minimizer, void** d_kmer_lo, void** d_kmer_hi, uint64_t* sk_off);
 /* how many genomes of the extraction last collected on this context were beyond the per-genome LDS forms and went
  * through the table in HBM (a diagnostic for tests and benchmarks) */

@@ -82,7 +82,7 @@ ABI_SYMBOLS = [
     "spsp_device_count", "spsp_create", "spsp_destroy", "spsp_last_error", "spsp_version", "spsp_free", "spsp_copy_to_host",
     "spsp_stream_create_cus", "spsp_stream_destroy", "spsp_set_cu_count", "spsp_pack_bases_device",
     "spsp_timing_enable", "spsp_timing_sample", "spsp_timing_read", "spsp_threshold_host", "spsp_scan", "spsp_scan_device", "spsp_scan_device_begin", "spsp_scan_device_end", "spsp_scan_tail_stream", "spsp_wait_dense", "spsp_wait_stream", "spsp_scan_hits_device", "spsp_count_superkmers_device", "spsp_compare",
-    "spsp_compare_device", "spsp_slot_bytes", "spsp_partition_keys_device", "spsp_compare_slots_device", "spsp_compare_device_begin", "spsp_compare_slots_device_begin", "spsp_compare_end", "spsp_fasta_clean_host", "spsp_fasta_clean_device", "spsp_fasta_clean_packed_device", "spsp_sketch_text", "spsp_sketch_build_host", "spsp_sketch_parse_host", "spsp_sketch_decode_device", "spsp_sketch_keys_device", "spsp_sketch_keys_device_begin", "spsp_sketch_keys_device_end", "spsp_sketch_keys_big_genomes", "spsp_scan_output_wait", "spsp_compare_keys_unordered", "spsp_sketch_chain_host",
+    "spsp_compare_device", "spsp_slot_bytes", "spsp_partition_keys_device", "spsp_compare_slots_device", "spsp_compare_device_begin", "spsp_compare_slots_device_begin", "spsp_compare_end", "spsp_fasta_clean_host", "spsp_fasta_clean_device", "spsp_fasta_clean_packed_device", "spsp_sketch_text", "spsp_sketch_build_host", "spsp_sketch_parse_host", "spsp_sketch_decode_device", "spsp_sketch_keys_device", "spsp_sketch_keys_device_begin", "spsp_sketch_keys_device_end", "spsp_sketch_keys_big_genomes", "spsp_scan_output_wait", "spsp_compare_keys_unordered", "spsp_compare_forget", "spsp_sketch_chain_host",
     "spsp_csv_host", "spsp_csv_cells_host", "spsp_csv_cells_gz_host", "spsp_sort_csv_host", "spsp_read_file_host", "spsp_write_gz_host", "spsp_sketch_file", "spsp_compare_files", "spsp_compare_files_chatty", "spsp_stage_times_read", "spsp_measure_hbm_device", "spsp_sketch_files", "spsp_sketch_files_multi", "spsp_sketch_files_release", "spsp_compare_files_multi", "spsp_matrix_cells_device", "spsp_matrix_add_cells_device", "spsp_compare_cells_device", "spsp_compare_slots_cells_device",
 ]
 
@@ -173,6 +173,7 @@ def lib():
     L.spsp_sketch_keys_device_begin.restype = i32
     L.spsp_sketch_keys_device_begin.argtypes = [vp, P(Params), vp, u64, vp, vp, u64, vp, u32, u32]
     L.spsp_compare_keys_unordered.restype = i32; L.spsp_compare_keys_unordered.argtypes = [vp, i32]
+    L.spsp_compare_forget.restype = i32; L.spsp_compare_forget.argtypes = [vp]
     L.spsp_sketch_keys_device_end.restype = i32
     L.spsp_sketch_keys_device_end.argtypes = [vp, P(vp), P(vp), P(vp), vp]
     L.spsp_sketch_keys_big_genomes.restype = u32; L.spsp_sketch_keys_big_genomes.argtypes = [vp]
@@ -575,6 +576,10 @@ class Context:
     def scan_output_wait(self, reader):
         """this context's next scan writes its output only behind `reader`'s latest sketch_keys_device_begin"""
         _check(lib().spsp_scan_output_wait(self._h, reader._h))
+
+    def compare_forget(self):
+        """forget what earlier comparisons taught this context about its inputs (scheduling only: spsp_compare_forget)"""
+        _check(lib().spsp_compare_forget(self._h))
 
     def compare_keys_unordered(self, on=True):
         """device-form comparisons of this context accept sketches whose keys are distinct but unsorted"""

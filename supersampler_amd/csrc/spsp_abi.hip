@@ -394,6 +394,15 @@ int spsp_wait_stream(spsp_ctx* waiter, spsp_ctx* other) {
     return SPSP_OK;
 }
 
+// what a context has learnt from earlier comparisons (a good row order of the input's own, lists for most records, parts that
+// spilled, the filter's pass rate) only changes WHICH kernels the next comparison queues, never its result; a caller that
+// times or profiles comparisons of different collections on one context can start from a clean slate
+int spsp_compare_forget(spsp_ctx* ctx) {
+    if (!ctx) { set_error("NULL argument"); return SPSP_ERR_ARG; }
+    ctx->learnt_on = 0; ctx->order_quiet = 0; ctx->multi_quiet = 0; ctx->spill_expect = 0; ctx->filter_ratio = 1.0;
+    return SPSP_OK;
+}
+
 int spsp_compare_keys_unordered(spsp_ctx* ctx, int on) {
     if (!ctx) { set_error("NULL argument"); return SPSP_ERR_ARG; }
     ctx->keys_unordered = on != 0;

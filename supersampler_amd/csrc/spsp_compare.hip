@@ -1627,7 +1627,7 @@ static int job_parts(spsp_ctx* ctx, CompareJob& J) {
     if (ctx->h_skoff) {
         const uint64_t fp = (uint64_t)J.P.n * 0x9E3779B97F4A7C15ULL ^ J.P.S_entries * 0xC2B2AE3D27D4EB4FULL ^ ctx->h_skoff[1] * 0x165667B19E3779F9ULL ^
                             ctx->h_skoff[J.P.n / 2] * 0x27D4EB2F165667C5ULL ^ ctx->h_skoff[J.P.n - J.P.n / 3] * 0x85EBCA77C2B2AE63ULL;
-        if (fp != ctx->learnt_on) { ctx->learnt_on = fp; ctx->order_quiet = 0; ctx->multi_quiet = 0; }
+        if (fp != ctx->learnt_on) { ctx->learnt_on = fp; ctx->order_quiet = 0; ctx->multi_quiet = 0; }   // (spsp_compare_forget resets all of it)
     }
     bool ordered = !J.small && all_rows && J.P.n >= (dbg_order && dbg_order[0] == '2' ? 512u : 2048u) && J.P.n <= (uint32_t)kSparseCols && !(dbg_order && dbg_order[0] == '0');
     // (a context whose last comparison came in a good order of its own -- k_row_order's verdict, read back with the job -- skips
@@ -1947,6 +1947,9 @@ int compare_job_end(spsp_ctx* ctx) {
                 ctx->multi_quiet = (sampled && 5 * listed >= 2 * sampled) ? 63 : 0;
             }
             static const bool trace = getenv("SPSP_DEBUG_SPILL_TRACE") != nullptr;     // test hook: which way the comparison went
+            if (trace) fprintf(stderr, "spsp compare: %u sketches, %s form, %u parts, classes %u, row order %s, has-a-list bits %s, spill %s\n", J->P.n,
+                               J->small ? "small" : (J->filtered ? "filtered" : "partition"), J->n_parts, J->classes, J->ordered ? "made" : "as given",
+                               J->want_multi ? "made" : "left out", J->spill.room ? "yes" : "no");
             if (trace && J->spill.room) fprintf(stderr, "spsp spill: %u records of overflowed parts grouped in HBM (room %llu, %u parts, columns from %u holders)\n",
                                                 h_flags[2], (unsigned long long)J->spill.room, J->n_parts, J->spill.t_bits);
             if (J->cls + 1 < J->classes) {              // the next class of keys through the same parts; its row sums add

@@ -1293,13 +1293,13 @@ int spsp_write_gz_host(const char* path, const uint8_t* data, uint64_t len, int 
     // One gzip member per 16 MiB of payload.  Small outputs (every sketch) are a single member, exactly what
     // zstr::ofstream writes; large CSVs are compressed member by member on a few threads -- a valid gzip file
     // that zstr / zlib / gunzip read back as one stream (zstr.hpp:198-203 restarts the inflator per member).
-    // (beyond 16 MiB the members shrink to 4 MiB at the least, so that a 60 MB sketch -- one 4 Gbp record set at -s 100 --
-    // keeps 15 threads busy instead of 4: 0.43 -> 0.12 s)
+    // (beyond 16 MiB the members shrink to 1 MiB at the least, so that the 28 MB sketch of a 4 Gbp record set at -s 100 keeps
+    // every worker busy: 0.43 s with 16 MiB members, 0.11 s with 4 MiB -- seven members on sixteen threads)
     unsigned workers = std::thread::hardware_concurrency();
     if (workers == 0) workers = 1;
     if (workers > 16) workers = 16;
     uint64_t chunk = 16ull << 20;
-    if (len > chunk) chunk = std::max<uint64_t>(4ull << 20, std::min<uint64_t>(chunk, ((len + workers - 1) / workers + 0xfffffull) & ~0xfffffull));
+    if (len > chunk) chunk = std::max<uint64_t>(1ull << 20, std::min<uint64_t>(chunk, ((len + workers - 1) / workers + 0xfffffull) & ~0xfffffull));
     const uint64_t n_chunks = len ? (len + chunk - 1) / chunk : 1;
     if (workers > n_chunks) workers = (unsigned)n_chunks;
     int rc = SPSP_OK;

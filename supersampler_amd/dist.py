@@ -283,7 +283,9 @@ class SlotExchange:
              summed -- reduce="cells" (what a large matrix wants): every rank turns its partial matrix into its non-zero
              cells (spsp_matrix_cells_device: 95 000 of 5 x 10^7 at BASELINE configs[3]), the cells are all-gathered and
              every rank adds the others' into its own matrix; "all" / "scatter": all-reduce / reduce-scatter of the dense
-             matrices (small matrices inside a pipelined step: no host wait).
+             matrices (small matrices inside a pipelined step; the receiver's spsp_compare_slots_device_begin reads the slot
+             headers back before it queues anything -- one host wait per step, since round 4: the flat comparison wants the
+             sketch offsets on the host).
     Every rank must hold the same number of sketches `n_local`; global sketch id = rank * n_local + local id.
     """
 
