@@ -425,7 +425,9 @@ int spsp_sketch_file(spsp_ctx* ctx, const spsp_params* p, double rate, const cha
  * GPU (a GPU job per file is a chain of launches and host waits that costs ~0.35 ms however small the file), and the
  * workers then run the sketch builder, gzip and the write per file.  Up to four batches (at most one per worker) are in flight, each on a
  * context (HIP stream) of its own, so reading, the GPU and the builders overlap inside ONE process.  With -a > 1 the
- * k-mer counting pass is per file: one GPU job per file, one context per worker.  `cb` (may be
+ * k-mer occurrences of the whole batch are counted in one device pass, file by file (the file is part of the key).  A batch
+ * with 5 x 10^5 selected k-mer occurrences or more (one metagenome file) has its sketches BUILT on the device as well
+ * (handle_superkmer + the emission walk, spsp_build.hip; SPSP_BUILD=device / host pins the choice).  `cb` (may be
  * NULL) is called with phase 0 when file `index` is taken off the queue (inside the queue's lock: the calls come in
  * list order, like the reference's critical(fof) section that prints the name and appends to the output list; with ONE
  * worker right before the file's own phase-1 call, the way the reference's single thread alternates names and reports) and
