@@ -1495,6 +1495,7 @@ def sketch_file_config5(ctx, bases, n_rec, rec_len, k, m, s, skip_oracle):
         write(small, R)
         kmers = n_rec * (rec_len - k + 1)
         sp.sketch_files([small], [os.path.join(tmp, "prefix.gz")], k, m, s, threads=cores)          # buffers, tables, page cache of the small file
+        sp.sketch_files([big], [os.path.join(tmp, "segment.gz")], k, m, s, threads=cores)            # the slot's pinned slab and device buffers at this size (0.2-0.4 s once per process)
         res = {}
         for label, T in (("threads_%d" % cores, cores), ("threads_1", 1)):
             t0 = time.perf_counter()
