@@ -266,7 +266,7 @@ __host__ __device__ inline uint64_t slot_bytes(uint32_t n, uint32_t cap, uint32_
 int partition_keys_impl(spsp_ctx* ctx, uint32_t k, const uint32_t* d_min, const uint64_t* d_lo, const uint64_t* d_hi,
                         const uint64_t* h_sk_off, uint32_t n, uint32_t parts, uint32_t cap, uint8_t* d_slots);
 int compare_slots_begin_impl(spsp_ctx* ctx, uint32_t k, const uint8_t* d_slots, uint32_t parts, uint32_t n, uint32_t cap,
-                             uint32_t* d_inter);
+                             uint32_t* d_inter, const uint8_t* h_headers = nullptr);
 int slots_bad_record(spsp_ctx* ctx);
 // sparse form of a pair matrix (spsp_multi.hip): non-zero cells (i < j) as i << 48 | j << 32 | count
 int matrix_cells_impl(spsp_ctx* ctx, const uint32_t* d_inter, uint32_t n, uint32_t row_first, uint32_t row_limit, uint64_t* d_cells,

@@ -150,8 +150,11 @@ int compare_cells_run(spsp_ctx* ctx, const std::function<int()>& begin, uint32_t
 // ---------------------------------------------------------------------------------------------------------------
 // Receiver of the key-partitioned split.  The slot headers (magic, geometry, keys per sketch) go to the host first: the
 // flat form needs the sketch offsets there, and a malformed or overflowed slot is refused before any kernel reads it.
+// h_headers (optional): the `parts` slot headers (slot_rec_off(n) bytes each, back to back) in HOST memory already -- the
+// senders of a one-process split read them back behind their partition, in the wait they make anyway (compare_payloads_multi),
+// so the receiver queues its unpack without a read-back and a wait of its own
 int compare_slots_begin_impl(spsp_ctx* ctx, uint32_t k, const uint8_t* d_slots, uint32_t parts, uint32_t n, uint32_t cap,
-                             uint32_t* d_inter) {
+                             uint32_t* d_inter, const uint8_t* h_headers) {
     if (ctx->compare_job) { set_error("a comparison is already pending on this context: call spsp_compare_end first"); return SPSP_ERR_ARG; }
     if (n == 0 || parts == 0 || parts > kMaxParts) { set_error("bad slot geometry"); return SPSP_ERR_ARG; }
     const uint64_t N = (uint64_t)parts * n;
@@ -161,9 +164,13 @@ int compare_slots_begin_impl(spsp_ctx* ctx, uint32_t k, const uint8_t* d_slots, 
     if (((uintptr_t)d_slots & 7u) != 0) { set_error("d_slots must be 8-byte aligned"); return SPSP_ERR_ARG; }
     const uint64_t slot_sz = slot_bytes(n, cap, k), hdr = slot_rec_off(n);
     const uint32_t words = slot_words(k);
-    std::vector<uint8_t> h((size_t)parts * hdr);
-    SPSP_HIP(hipMemcpy2DAsync(h.data(), hdr, d_slots, slot_sz, hdr, parts, hipMemcpyDeviceToHost, ctx->stream));
-    SPSP_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<uint8_t> h;
+    if (h_headers) h.assign(h_headers, h_headers + (size_t)parts * hdr);
+    else {
+        h.resize((size_t)parts * hdr);
+        SPSP_HIP(hipMemcpy2DAsync(h.data(), hdr, d_slots, slot_sz, hdr, parts, hipMemcpyDeviceToHost, ctx->stream));
+        SPSP_HIP(hipStreamSynchronize(ctx->stream));
+    }
     // (host arrays the queued copies read: kept in the context until its next call, so that nothing here has to wait for them)
     std::vector<uint64_t>& sk_off = ctx->m_h_skoff;
     std::vector<uint32_t>&tot = ctx->m_h_tot, &base = ctx->m_h_base;
@@ -289,6 +296,7 @@ int compare_payloads_multi(spsp_ctx* const* ctxs, uint32_t n_ctx, const uint8_t*
     const bool has_hi = S.k > 32;
     // B + C + D, repeated with exact room when a slot turns out fuller than the hash's mean share suggested
     S.cap = (uint32_t)std::min<uint64_t>(0x7ffffff0ull, most / n_ctx + most / (4 * n_ctx) + 4096);
+    std::vector<std::vector<uint8_t>> hdrs(n_ctx);                 // [sender]: its n_ctx slot headers
     for (int attempt = 0;; ++attempt) {
         const uint64_t slot_sz = slot_bytes(S.per, S.cap, S.k);
         std::vector<uint32_t> fullest(n_ctx, 0);
@@ -299,11 +307,13 @@ int compare_payloads_multi(spsp_ctx* const* ctxs, uint32_t n_ctx, const uint8_t*
             if ((r = c->m_send.reserve((size_t)slot_sz * n_ctx + 64)) || (r = c->m_recv.reserve((size_t)slot_sz * n_ctx + 64))) return r;
             if ((r = partition_keys_impl(c, S.k, c->c_min.as<uint32_t>(), c->c_lo.as<uint64_t>(), has_hi ? c->c_hi.as<uint64_t>() : nullptr, S.sk_off[d].data(), S.per,
                                          n_ctx, S.cap, c->m_send.as<uint8_t>()))) return r;
-            // how full did the slots get? (header word 2 = keys that wanted in)
-            std::vector<uint32_t> w((size_t)n_ctx * 4);
-            SPSP_HIP(hipMemcpy2DAsync(w.data(), 16, c->m_send.p, slot_sz, 16, n_ctx, hipMemcpyDeviceToHost, c->stream));
+            // how full did the slots get? (header word 2 = keys that wanted in) -- the WHOLE headers come back in this wait: the
+            // receivers take them from here (hdrs[sender][destination]) instead of reading them back once more
+            const uint64_t hdr = slot_rec_off(S.per);
+            hdrs[d].resize((size_t)n_ctx * hdr);
+            SPSP_HIP(hipMemcpy2DAsync(hdrs[d].data(), hdr, c->m_send.p, slot_sz, hdr, n_ctx, hipMemcpyDeviceToHost, c->stream));
             SPSP_HIP(hipStreamSynchronize(c->stream));
-            for (uint32_t p = 0; p < n_ctx; ++p) fullest[d] = std::max(fullest[d], w[(size_t)p * 4 + 2]);
+            for (uint32_t p = 0; p < n_ctx; ++p) fullest[d] = std::max(fullest[d], reinterpret_cast<const uint32_t*>(hdrs[d].data() + (size_t)p * hdr)[2]);
             return SPSP_OK;
         });
         if (rc) return rc;
@@ -334,7 +344,11 @@ int compare_payloads_multi(spsp_ctx* const* ctxs, uint32_t n_ctx, const uint8_t*
         uint64_t cap = std::max<uint64_t>(1u << 16, (uint64_t)NP * 32);
         for (int attempt = 0; attempt < 2; ++attempt) {
             if ((r = c->m_cells.reserve((size_t)cap * 8))) return r;
-            r = compare_cells_run(c, [&]() { return compare_slots_begin_impl(c, S.k, c->m_recv.as<uint8_t>(), n_ctx, S.per, S.cap, c->c_inter.as<uint32_t>()); },
+            // the headers of slot d of every sender, in sender order: what m_recv holds
+            const uint64_t hdr = slot_rec_off(S.per);
+            std::vector<uint8_t> mine((size_t)n_ctx * hdr);
+            for (uint32_t s = 0; s < n_ctx; ++s) memcpy(mine.data() + (size_t)s * hdr, hdrs[s].data() + (size_t)d * hdr, (size_t)hdr);
+            r = compare_cells_run(c, [&]() { return compare_slots_begin_impl(c, S.k, c->m_recv.as<uint8_t>(), n_ctx, S.per, S.cap, c->c_inter.as<uint32_t>(), mine.data()); },
                                   (uint32_t)NP, row_limit, c->c_inter.as<uint32_t>(), c->m_cells.as<uint64_t>(), cap, &n_cells[d], &c->m_cells);
             if (r != SPSP_ERR_OVERFLOW) break;
             cap = n_cells[d];
