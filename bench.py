@@ -66,6 +66,7 @@ def launch_ranks_if_needed():
             port = str(s.getsockname()[1])
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     env.setdefault("OMP_NUM_THREADS", "1")
+    env.setdefault("GLOO_SOCKET_IFNAME", "lo")              # (one node: a gloo rehearsal must not wait for the host's name to resolve)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
            "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
     print("[bench] --gpus %d without WORLD_SIZE: starting the ranks as child processes: %s" % (n, " ".join(cmd[1:])),

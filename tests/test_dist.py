@@ -14,6 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _launch(mode, port, world=2, rows="block"):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world),
                HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1", SPSP_TEST_ROWS=rows)
+    env.setdefault("GLOO_SOCKET_IFNAME", "lo")      # (gloo otherwise looks the host's name up: tens of seconds on a box whose name does not resolve)
     procs = []
     for r in range(world):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
@@ -72,6 +73,7 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     import json
     env = dict(os.environ, BENCH_BACKEND="gloo", BENCH_SHARE_GPU="1", BENCH_PREWARM_STEPS="0", HSA_ENABLE_IPC_MODE_LEGACY="0",
                OMP_NUM_THREADS="1")
+    env.setdefault("GLOO_SOCKET_IFNAME", "lo")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     # the PLAIN command of the driver (`python bench.py --gpus N ...`, no WORLD_SIZE): bench.py starts its two ranks itself,
