@@ -307,11 +307,27 @@ int sketch_decode_device_impl(spsp_ctx* ctx, const uint8_t* const* payloads, con
         if ((rc = ctx->dc_text.reserve((size_t)T + 64)) || (rc = ctx->dc_walk.reserve((size_t)n * (8 + 8 + 4 + 16 + 8 + 8 + 1) + 256))) return rc;
         // one pinned-size staging buffer for everything that goes up: texts back to back, then lens
         // (malloc, not a vector: 30 MB of zeroed pages first touched by ONE thread were 10 ms; the gaps between sketches are never read)
-        struct Free { void operator()(uint8_t* q) const { free(q); } };
-        std::unique_ptr<uint8_t, Free> text_buf((uint8_t*)malloc((size_t)T + 64));
-        if (!text_buf) { set_error("out of host memory"); return SPSP_ERR_NOMEM; }
-        struct { uint8_t* p; uint8_t* data() const { return p; } } text_all{text_buf.get()};
+        // ... unless the caller's payloads already lie exactly so (spsp_compare_files reads its files into one block): then
+        // they go up from where they are
+        const uint8_t* laid_out = nullptr;
+        uint64_t laid_end = 0;
         {
+            static const bool allow = getenv("SPSP_DEBUG_DECODE_GATHER") == nullptr;
+            bool ok = allow;
+            for (uint32_t i = 0; i < n && ok; ++i) {
+                if (!lens[i]) continue;
+                if (!laid_out) laid_out = payloads[i] - text_off_dev[i];
+                ok = payloads[i] == laid_out + text_off_dev[i];
+                laid_end = text_off_dev[i] + lens[i];
+            }
+            if (!ok) laid_out = nullptr;
+        }
+        struct Free { void operator()(uint8_t* q) const { free(q); } };
+        std::unique_ptr<uint8_t, Free> text_buf(laid_out ? nullptr : (uint8_t*)malloc((size_t)T + 64));
+        if (!laid_out && !text_buf) { set_error("out of host memory"); return SPSP_ERR_NOMEM; }
+        struct { const uint8_t* p; const uint8_t* data() const { return p; } } text_all{laid_out ? laid_out : text_buf.get()};
+        const uint64_t T_up = laid_out ? laid_end : T;          // (never past the caller's last byte)
+        if (!laid_out) {
             unsigned workers = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
             if (T < (1u << 20)) workers = 1;
             std::atomic<uint32_t> next(0);
@@ -319,7 +335,7 @@ int sketch_decode_device_impl(spsp_ctx* ctx, const uint8_t* const* payloads, con
                 for (;;) {
                     const uint32_t i0 = next.fetch_add(64);
                     if (i0 >= n) break;
-                    for (uint32_t i = i0; i < std::min(n, i0 + 64); ++i) if (lens[i]) memcpy(text_all.data() + text_off_dev[i], payloads[i], (size_t)lens[i]);
+                    for (uint32_t i = i0; i < std::min(n, i0 + 64); ++i) if (lens[i]) memcpy(text_buf.get() + text_off_dev[i], payloads[i], (size_t)lens[i]);
                 }
             };
             std::vector<std::thread> pool;
@@ -337,7 +353,7 @@ int sketch_decode_device_impl(spsp_ctx* ctx, const uint8_t* const* payloads, con
         std::vector<uint32_t> extra((size_t)n, 0xffffffffu);
         bool any_extra = false;
         if (extra_has) for (uint32_t i = 0; i < n; ++i) if (extra_has[i]) { extra[i] = extra_mn[i]; any_extra = true; }
-        hipError_t e = T ? hipMemcpyAsync(ctx->dc_text.p, text_all.data(), (size_t)T, hipMemcpyHostToDevice, ctx->stream) : hipSuccess;
+        hipError_t e = T_up ? hipMemcpyAsync(ctx->dc_text.p, text_all.data(), (size_t)T_up, hipMemcpyHostToDevice, ctx->stream) : hipSuccess;
         if (e == hipSuccess) e = hipMemcpyAsync(d_toff, text_off_dev.data(), (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(d_lens, lens, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess && any_extra) e = hipMemcpyAsync(d_extra, extra.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);
@@ -449,9 +465,11 @@ int sketch_decode_device_impl(spsp_ctx* ctx, const uint8_t* const* payloads, con
     std::vector<uint8_t> text_all;
     if (dev_walk) {
         // the descriptors are written on the device: where each sketch's start, and where its raw keys go
+        const double td0 = now_s();
         std::vector<uint64_t> doff((size_t)n, 0);
         for (uint32_t i = 0; i < n; ++i) { doff[i] = n_desc_dev; if (!presorted[i]) n_desc_dev += counts[i].n_desc; }
         if ((rc = ctx->dc_desc.reserve((size_t)n_desc_dev * sizeof(DecDesc) + 64))) { free_hk(); return rc; }
+        const double td1 = now_s();
         uint64_t* d_toff = ctx->dc_walk.as<uint64_t>();
         uint64_t* d_lens = d_toff + n;
         uint64_t* d_doff = d_lens + n;
@@ -472,6 +490,8 @@ int sketch_decode_device_impl(spsp_ctx* ctx, const uint8_t* const* payloads, con
                                (const uint8_t*)d_skip, ctx->dc_desc.as<DecDesc>());
             SPSP_HIP(hipGetLastError());
         }
+        if (dbg_times) fprintf(stderr, "[spsp decode] device walk, second pass: since the count pass %.2f ms, offsets + reserve %.2f ms, copies + wait + launch %.2f ms\n",
+                               (td0 - tm[1]) * 1e3, (td1 - td0) * 1e3, (now_s() - td1) * 1e3);
     } else {
         std::vector<size_t> d_at((size_t)n + 1, 0);
         for (uint32_t i = 0; i < n; ++i) d_at[i + 1] = d_at[i] + (presorted[i] ? 0 : P[i].desc.size() + ((extra_has && extra_has[i]) ? 1 : 0));

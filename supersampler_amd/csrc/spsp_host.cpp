@@ -4,6 +4,7 @@
 // they work on 2-bit integers throughout instead of the reference's
 // std::string substr/find chains, but produce the same bytes.
 #include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -12,6 +13,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <deque>
+#include <cerrno>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -263,14 +265,24 @@ int inflate_all(const uint8_t* in, size_t n, std::vector<uint8_t>& out) {
     const bool packed = n >= 2 && ((in[0] == 0x1F && in[1] == 0x8B) ||
                                    (in[0] == 0x78 && (in[1] == 0x01 || in[1] == 0x9C || in[1] == 0xDA)));
     if (!packed) { out.assign(in, in + n); return SPSP_OK; }
+    // One inflator per THREAD, reset per member (10 000 sketch files of 3 KB: inflateInit2's 40 KB of state and a zeroed 1 MiB
+    // bounce buffer per file were most of the 48 us a file cost its thread), and the output grows in place: the member's ISIZE
+    // trailer says how much is coming (a hint only: sizes are taken from what inflate delivers)
+    struct Inflator { z_stream zs; bool live = false; ~Inflator() { if (live) inflateEnd(&zs); } };
+    static thread_local Inflator I;
     out.clear();
-    out.reserve(n * 4);
-    std::vector<uint8_t> chunk(1 << 20);
-    size_t at = 0;
-    while (at < n) {  // concatenated members: a fresh inflator per member, as zstr does (:198-203)
-        z_stream zs;
-        memset(&zs, 0, sizeof zs);
-        if (inflateInit2(&zs, 15 + 32) != Z_OK) { set_error("inflateInit2 failed"); return SPSP_ERR_IO; }
+    size_t hint = n * 4 + 64;
+    if (n >= 18 && in[0] == 0x1F) { uint32_t isize; memcpy(&isize, in + n - 4, 4); if (isize >= n && isize < (1u << 30)) hint = (size_t)isize + 64; }
+    out.resize(hint);
+    size_t have = 0, at = 0;
+    while (at < n) {  // concatenated members: the inflator starts afresh per member, as zstr does (:198-203)
+        if (!I.live) {
+            memset(&I.zs, 0, sizeof I.zs);
+            if (inflateInit2(&I.zs, 15 + 32) != Z_OK) { set_error("inflateInit2 failed"); return SPSP_ERR_IO; }
+            I.live = true;
+        } else if (inflateReset2(&I.zs, 15 + 32) != Z_OK) { set_error("inflateReset2 failed"); return SPSP_ERR_IO; }
+        z_stream& zs = I.zs;
+        zs.avail_in = 0;
         int ret = Z_OK;
         bool truncated = false;
         while (ret != Z_STREAM_END) {
@@ -281,20 +293,21 @@ int inflate_all(const uint8_t* in, size_t n, std::vector<uint8_t>& out) {
                 zs.avail_in = (uInt)take;
                 at += take;
             }
-            zs.next_out = chunk.data();
-            zs.avail_out = (uInt)chunk.size();
+            if (have == out.size()) out.resize(out.size() * 2 + 4096);
+            const size_t room = std::min<size_t>(out.size() - have, (size_t)1 << 30);
+            zs.next_out = out.data() + have;
+            zs.avail_out = (uInt)room;
             ret = inflate(&zs, Z_NO_FLUSH);
             if (ret != Z_OK && ret != Z_STREAM_END && ret != Z_BUF_ERROR) {
-                inflateEnd(&zs);
                 set_error("inflate failed (%d)", ret);
                 return SPSP_ERR_IO;
             }
-            out.insert(out.end(), chunk.data(), chunk.data() + (chunk.size() - zs.avail_out));
+            have += room - zs.avail_out;
         }
         at -= zs.avail_in;  // bytes not consumed belong to the next member
-        inflateEnd(&zs);
         if (truncated) break;
     }
+    out.resize(have);
     return SPSP_OK;
 }
 
@@ -1230,20 +1243,45 @@ int spsp_csv_host(int jaccard, const char* const* names, uint32_t n, uint32_t n_
     return csv_impl(jaccard, names, n, n_query, inter, card, precision, min_threshold, text, len, false);
 }
 
+// Three system calls for a small file (open, one read that comes back short, close): where system calls are the cost -- 10^4
+// sketch files of 3 KB, on hosts that serialise them -- fopen + fstat + two freads + fclose were twice that.
 static int slurp(const char* path, uint8_t** raw, uint64_t* n) {
-    FILE* f = fopen(path, "rb");
-    if (!f) { set_error("cannot open '%s'", path); return SPSP_ERR_IO; }
-    struct stat st;
-    size_t cap = (fstat(fileno(f), &st) == 0 && st.st_size > 0) ? (size_t)st.st_size + 1 : (1u << 20);
-    uint8_t* buf = (uint8_t*)malloc(cap + 64);
+    const int fd = open(path, O_RDONLY | O_CLOEXEC);
+    if (fd < 0) { set_error("cannot open '%s'", path); return SPSP_ERR_IO; }
+    // the first 64 KiB land in a buffer the thread keeps (a fresh 64 KiB block per file had malloc trimming the heap per file)
+    struct Scratch { uint8_t* p = (uint8_t*)malloc((1u << 16) + 64); ~Scratch() { free(p); } };
+    static thread_local Scratch scratch;
+    size_t cap = 1u << 16;
+    uint8_t* buf = scratch.p;
+    bool own = false;
     size_t got = 0;
+    bool regular_known = false, regular = false;
     while (buf) {
-        const size_t r = fread(buf + got, 1, cap - got, f);
-        got += r;
+        const ssize_t r = read(fd, buf + got, cap - got);
+        if (r < 0) { if (errno == EINTR) continue; if (own) free(buf); close(fd); set_error("cannot read '%s'", path); return SPSP_ERR_IO; }
         if (r == 0) break;
-        if (got == cap) { cap *= 2; uint8_t* nb = (uint8_t*)realloc(buf, cap + 64); if (!nb) { free(buf); buf = nullptr; } else buf = nb; }
+        got += (size_t)r;
+        if (got < cap) {
+            // a short read ends a REGULAR file (pipes and ttys may come back short at any time)
+            if (!regular_known) { struct stat st; regular = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && (size_t)st.st_size == got; regular_known = true; if (regular) break; }
+            continue;
+        }
+        if (!regular_known) {   // a big file: size the buffer once instead of doubling through it
+            struct stat st;
+            regular_known = true;
+            if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && (size_t)st.st_size > cap) cap = (size_t)st.st_size + 1; else cap *= 2;
+        } else cap *= 2;
+        uint8_t* nb = own ? (uint8_t*)realloc(buf, cap + 64) : (uint8_t*)malloc(cap + 64);
+        if (nb && !own) memcpy(nb, buf, got);
+        if (!nb) { if (own) free(buf); buf = nullptr; } else buf = nb;
+        own = true;
     }
-    fclose(f);
+    close(fd);
+    if (buf && !own) {   // small file: an exact-size copy out of the scratch
+        uint8_t* nb = (uint8_t*)malloc(got + 64);
+        if (nb) memcpy(nb, buf, got);
+        buf = nb;
+    }
     if (!buf) { set_error("out of host memory"); return SPSP_ERR_NOMEM; }
     *raw = buf; *n = got;
     return SPSP_OK;
@@ -1270,9 +1308,17 @@ int spsp_read_file_host(const char* path, uint8_t** data, uint64_t* len) {
 
 // zstr::ofstream(filename, expbuffer, level) -> gzip container (zstr.hpp:78-82)
 static int deflate_member(const uint8_t* data, uint64_t len, int level, std::vector<uint8_t>& out) {
-    z_stream zs;
-    memset(&zs, 0, sizeof zs);
-    if (deflateInit2(&zs, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return SPSP_ERR_IO;
+    // one deflator per thread and level, reset per member (deflateInit2 is 268 KB of allocation per call: per sketch, in the
+    // file pipeline)
+    struct Deflator { z_stream zs; int level = -100; ~Deflator() { if (level != -100) deflateEnd(&zs); } };
+    static thread_local Deflator D;
+    if (D.level != level) {
+        if (D.level != -100) { deflateEnd(&D.zs); D.level = -100; }
+        memset(&D.zs, 0, sizeof D.zs);
+        if (deflateInit2(&D.zs, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return SPSP_ERR_IO;
+        D.level = level;
+    } else if (deflateReset(&D.zs) != Z_OK) return SPSP_ERR_IO;
+    z_stream& zs = D.zs;
     out.resize(deflateBound(&zs, (uLong)len) + 64);
     zs.next_in = const_cast<Bytef*>(data);
     zs.avail_in = (uInt)len;
@@ -1280,7 +1326,6 @@ static int deflate_member(const uint8_t* data, uint64_t len, int level, std::vec
     zs.avail_out = (uInt)out.size();
     const int ret = deflate(&zs, Z_FINISH);
     const size_t have = out.size() - zs.avail_out;
-    deflateEnd(&zs);
     if (ret != Z_STREAM_END) return SPSP_ERR_IO;
     out.resize(have);
     return SPSP_OK;
@@ -1288,8 +1333,18 @@ static int deflate_member(const uint8_t* data, uint64_t len, int level, std::vec
 
 int spsp_write_gz_host(const char* path, const uint8_t* data, uint64_t len, int level) {
     if (!path || (len && !data)) { set_error("NULL argument"); return SPSP_ERR_ARG; }
-    FILE* f = fopen(path, "wb");
-    if (!f) { set_error("cannot create '%s'", path); return SPSP_ERR_IO; }
+    // plain descriptors, not stdio: fopen/fclose take a process-wide lock (the list of open FILEs), and the file pipeline
+    // writes one sketch per task on every host thread
+    const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC | O_CLOEXEC, 0666);
+    if (fd < 0) { set_error("cannot create '%s'", path); return SPSP_ERR_IO; }
+    auto write_all = [&](const uint8_t* p, size_t n) {
+        while (n) {
+            const ssize_t w = write(fd, p, n);
+            if (w < 0) { if (errno == EINTR) continue; return false; }
+            p += w; n -= (size_t)w;
+        }
+        return true;
+    };
     // One gzip member per 16 MiB of payload.  Small outputs (every sketch) are a single member, exactly what
     // zstr::ofstream writes; large CSVs are compressed member by member on a few threads -- a valid gzip file
     // that zstr / zlib / gunzip read back as one stream (zstr.hpp:198-203 restarts the inflator per member).
@@ -1318,10 +1373,10 @@ int spsp_write_gz_host(const char* path, const uint8_t* data, uint64_t len, int 
         for (auto& th : pool) th.join();
         for (unsigned b = 0; b < batch && !rc; ++b) {
             if (rcs[b]) { set_error("deflate failed"); rc = rcs[b]; break; }
-            if (fwrite(outs[b].data(), 1, outs[b].size(), f) != outs[b].size()) { set_error("short write to '%s'", path); rc = SPSP_ERR_IO; }
+            if (!write_all(outs[b].data(), outs[b].size())) { set_error("short write to '%s'", path); rc = SPSP_ERR_IO; }
         }
     }
-    if (fclose(f) != 0 && !rc) { set_error("close failed for '%s'", path); rc = SPSP_ERR_IO; }
+    if (close(fd) != 0 && !rc) { set_error("close failed for '%s'", path); rc = SPSP_ERR_IO; }
     return rc;
 }
 
@@ -1346,30 +1401,111 @@ static int compare_files_impl(spsp_ctx* ctx, const char* const* paths, uint32_t 
     std::vector<uint64_t> lens(n, 0);
     std::vector<int> rcs(n, SPSP_OK);
     std::vector<std::string> errs(n);
-    auto free_datas = [&]() { for (auto*& d : datas) { free(d); d = nullptr; } };
-    // One file at a time per worker: no N open streams (Comparator.cpp:45-50); read + gunzip is independent work,
-    // spread over a few host threads.  Decoding (strDecompressor, inject_minimizer, the k-mer walks, sort, unique)
-    // happens for all sketches at once on the GPU (spsp_decode.hip).
+    // Many sketches land in ONE block, each at the 16-byte-rounded end of the one before: the decoder sends exactly that
+    // layout to the device, and when it finds the payloads already laid out so it uploads them where they lie
+    // (spsp_decode.hip: 10^4 mallocs and a 40 MB gather gone).  datas[i] then points INTO the block (own[i] == 0).
+    uint8_t* block = nullptr;
+    std::vector<uint8_t> own(n, 1);
+    auto free_datas = [&]() { for (uint32_t i = 0; i < n; ++i) { if (own[i]) free(datas[i]); datas[i] = nullptr; } block = nullptr; };   // (the block stays with the context)
     unsigned workers = std::thread::hardware_concurrency();
     if (workers == 0) workers = 1;
     if (workers > 16) workers = 16;
     if (workers > n) workers = n ? n : 1;
-    {
+    auto on_threads = [&](const std::function<void(uint32_t)>& one) {
         std::atomic<uint32_t> next(0);
-        auto work = [&]() {
-            for (;;) {
-                const uint32_t i = next.fetch_add(1);
-                if (i >= n) break;
-                rcs[i] = spsp_read_file_host(paths[i], &datas[i], &lens[i]);
-                if (rcs[i]) errs[i] = spsp_last_error();
-            }
-        };
+        auto work = [&]() { for (;;) { const uint32_t i = next.fetch_add(1); if (i >= n) break; one(i); } };
         std::vector<std::thread> pool;
         for (unsigned w = 1; w < workers; ++w) pool.emplace_back(work);
         work();
         for (auto& th : pool) th.join();
+    };
+    // One file at a time per worker: no N open streams (Comparator.cpp:45-50); read + gunzip is independent work,
+    // spread over a few host threads.  Decoding (strDecompressor, inject_minimizer, the k-mer walks, sort, unique)
+    // happens for all sketches at once on the GPU (spsp_decode.hip).
+    static const bool one_block = getenv("SPSP_DEBUG_READ_BLOCK") == nullptr || getenv("SPSP_DEBUG_READ_BLOCK")[0] != '0';
+    if (n >= 256 && one_block) {
+        // pass 1: the bytes of every file as they are on disk; a gzip file of ONE member says in its trailer how long it gets
+        std::vector<uint64_t> raw_len(n, 0), want(n, 0);
+        std::vector<uint8_t> gz(n, 0);
+        on_threads([&](uint32_t i) {
+            rcs[i] = slurp(paths[i], &datas[i], &raw_len[i]);
+            if (rcs[i]) { errs[i] = spsp_last_error(); return; }
+            const uint8_t* r = datas[i];
+            const uint64_t len = raw_len[i];
+            if (len >= 18 && r[0] == 0x1F && r[1] == 0x8B) { uint32_t isize; memcpy(&isize, r + len - 4, 4); gz[i] = 1; want[i] = isize; }
+            else if (len >= 2 && r[0] == 0x78 && (r[1] == 0x01 || r[1] == 0x9C || r[1] == 0xDA)) {   // a zlib wrapper: no length up front
+                std::vector<uint8_t> plain;
+                uint8_t* q = nullptr;
+                rcs[i] = inflate_all(r, len, plain);
+                if (!rcs[i] && !(q = (uint8_t*)malloc(plain.size() + 64))) { set_error("out of host memory"); rcs[i] = SPSP_ERR_NOMEM; }
+                if (rcs[i]) { errs[i] = spsp_last_error(); return; }
+                if (!plain.empty()) memcpy(q, plain.data(), plain.size());
+                free(datas[i]); datas[i] = q; raw_len[i] = want[i] = plain.size();
+            } else want[i] = len;
+        });
+        std::vector<uint64_t> at((size_t)n + 1, 0);
+        for (uint32_t i = 0; i < n; ++i) at[i + 1] = at[i] + ((want[i] + 15) & ~15ull);
+        bool fits = at[n] < (64ull << 30);                       // (a forged trailer must not size a buffer)
+        for (uint32_t i = 0; i < n && fits; ++i) if (gz[i] && want[i] > 1032ull * raw_len[i] + 64) fits = false;   // deflate never expands more
+        if (fits) {
+            const size_t need = (size_t)at[n] + 64;
+            if (ctx->h_read_block_cap < need) {
+                free(ctx->h_read_block);
+                const size_t cap = (need + need / 4 + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
+                ctx->h_read_block = (uint8_t*)aligned_alloc(2u << 20, cap);
+                ctx->h_read_block_cap = ctx->h_read_block ? cap : 0;
+                if (ctx->h_read_block) (void)madvise(ctx->h_read_block, cap, MADV_HUGEPAGE);   // (a hint: 4 KiB pages if the host says no)
+            }
+            block = ctx->h_read_block;
+        }
+        const double t_pass1 = now_s();
+        // pass 2: every payload to its place
+        on_threads([&](uint32_t i) {
+            if (rcs[i]) return;
+            uint8_t* raw = datas[i];
+            if (block && !gz[i]) { if (want[i]) memcpy(block + at[i], raw, (size_t)want[i]); free(raw); datas[i] = block + at[i]; own[i] = 0; lens[i] = want[i]; return; }
+            if (!gz[i]) { lens[i] = want[i]; return; }
+            if (block) {
+                // straight into the block when the file is one member of the promised length
+                struct Inflator { z_stream zs; bool live = false; ~Inflator() { if (live) inflateEnd(&zs); } };
+                static thread_local Inflator I;
+                bool ok = true;
+                if (!I.live) { memset(&I.zs, 0, sizeof I.zs); ok = inflateInit2(&I.zs, 15 + 16) == Z_OK; I.live = ok; }
+                else ok = inflateReset2(&I.zs, 15 + 16) == Z_OK;
+                if (ok && raw_len[i] < (1ull << 31) && want[i] < (1ull << 31)) {
+                    uint8_t spill[8];
+                    I.zs.next_in = raw; I.zs.avail_in = (uInt)raw_len[i];
+                    I.zs.next_out = want[i] ? block + at[i] : spill; I.zs.avail_out = (uInt)want[i];
+                    int ret = inflate(&I.zs, Z_FINISH);
+                    if (ret == Z_BUF_ERROR && I.zs.avail_out == 0) {   // the output is full: the trailer is still to be read
+                        I.zs.next_out = spill; I.zs.avail_out = 0;
+                        ret = inflate(&I.zs, Z_FINISH);
+                    }
+                    if (ret == Z_STREAM_END && I.zs.avail_in == 0 && I.zs.total_out == want[i]) {
+                        free(raw); datas[i] = block + at[i]; own[i] = 0; lens[i] = want[i];
+                        return;
+                    }
+                }
+            }
+            // several members, a trailer that does not tell the truth, a damaged file: the general reader (and its error text)
+            std::vector<uint8_t> plain;
+            uint8_t* q = nullptr;
+            rcs[i] = inflate_all(raw, raw_len[i], plain);
+            if (!rcs[i] && !(q = (uint8_t*)malloc(plain.size() + 64))) { set_error("out of host memory"); rcs[i] = SPSP_ERR_NOMEM; }
+            if (rcs[i]) { errs[i] = spsp_last_error(); return; }
+            if (!plain.empty()) memcpy(q, plain.data(), plain.size());
+            free(raw); datas[i] = q; lens[i] = plain.size();
+        });
+        if (getenv("SPSP_DEBUG_DECODE_TIMES")) fprintf(stderr, "[load] files read %.4f s, payloads to their places %.4f s\n", t_pass1 - t0, now_s() - t_pass1);
+    } else {
+        on_threads([&](uint32_t i) {
+            rcs[i] = spsp_read_file_host(paths[i], &datas[i], &lens[i]);
+            if (rcs[i]) errs[i] = spsp_last_error();
+        });
     }
     int rc = SPSP_OK;
+    static const bool load_times = getenv("SPSP_DEBUG_DECODE_TIMES") != nullptr;
+    if (load_times) fprintf(stderr, "[load] read + gunzip of %u files on %u threads %.4f s\n", n, workers, now_s() - t0);
     for (uint32_t i = 0; i < n && !rc; ++i)
         if (rcs[i]) { set_error("%s", errs[i].c_str()); rc = rcs[i]; }
     // k and m of the first header (every sketch is checked against them by the decoder)
@@ -1393,6 +1529,7 @@ static int compare_files_impl(spsp_ctx* ctx, const char* const* paths, uint32_t 
             if (!rc && has) { extra_has[i] = 1; extra_mn[i] = mn; }
         }
     }
+    if (load_times) fprintf(stderr, "[load] ... with the first-read chain %.4f s\n", now_s() - t0);
     // the pair matrix: zero pages from calloc (400 MB at 10^4 sketches: touched only where a row is written or read)
     struct Matrix { uint32_t* p = nullptr; ~Matrix() { free(p); } uint32_t* data() { return p; }
                     int zero(size_t cells) { free(p); p = (uint32_t*)calloc(cells ? cells : 1, 4); return p ? SPSP_OK : SPSP_ERR_NOMEM; } } inter;

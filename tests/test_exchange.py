@@ -905,6 +905,58 @@ def test_compare_files_of_one_species_dense_matrix_as_cells(tmp_path):
 
 
 @pytest.mark.gpu
+def test_compare_files_read_into_one_block_whatever_the_container(tmp_path):
+    """spsp_compare_files from 256 files on reads every payload into ONE block (each at the 16-byte-rounded end of the one
+    before) and the decoder uploads them from where they lie.  300 sketch files in every container the reader knows -- gzip
+    of one member, gzip of two members (the trailer's length is then not the payload's: that file takes the general reader
+    and the decoder gathers), a zlib wrapper, plain text, an empty sketch (header only) -- as ONE kind each and mixed, in one
+    context and over two, against the oracle's CSV bytes; a truncated gzip file is the reader's error, not a wrong matrix."""
+    import gzip
+    import zlib
+    rng = np.random.default_rng(123)
+    anc = [synth.random_genome(rng, 30_000) for _ in range(6)]
+    payloads = []
+    for i in range(300):
+        g = synth.mutate(rng, anc[i % 6], 0.002 * (i % 4))
+        payloads.append(orc.sketch_fasta(synth.to_fasta(g, "g%d" % i), 31, 11, 60.0)[0])
+    payloads[17] = payloads[17][:payloads[17].index(b"\n") + 1]           # a sketch with no bucket at all
+    inter, card, _, _ = orc.compare(payloads)
+
+    def container(kind, pl):
+        if kind == 0:
+            return gzip.compress(pl, 1)
+        if kind == 1:
+            cut = len(pl) // 3
+            return gzip.compress(pl[:cut], 6) + gzip.compress(pl[cut:], 1)
+        if kind == 2:
+            return zlib.compress(pl, 6)
+        return pl
+    for tag, kinds in (("gz", [0] * 300), ("plain", [3] * 300), ("mixed", [int(x) for x in rng.integers(0, 4, 300)]), ("two", [1] * 300)):
+        paths = []
+        for i, pl in enumerate(payloads):
+            pth = str(tmp_path / ("%s_%03d" % (tag, i)))
+            open(pth, "wb").write(container(kinds[i], pl))
+            paths.append(pth)
+        with sp.Context(0) as ctx:
+            ctx.compare_files(paths, str(tmp_path / (tag + "_one")))
+            ctx.compare_files(paths, str(tmp_path / (tag + "_q")), n_query=7)
+        sp.compare_files_multi([0, 0], paths, str(tmp_path / (tag + "_multi")))
+        for jac, suf in ((True, "_jaccard.csv.gz"), (False, "_containment.csv.gz")):
+            want = orc.csv(jac, paths, inter, card, None, 6, 0.0)
+            assert gzip.open(str(tmp_path / (tag + "_one")) + suf, "rb").read() == want, (tag, suf)
+            assert gzip.open(str(tmp_path / (tag + "_multi")) + suf, "rb").read() == want, (tag, suf)
+            assert gzip.open(str(tmp_path / (tag + "_q")) + suf, "rb").read() == orc.csv(jac, paths, inter, card, 7, 6, 0.0), (tag, suf)
+    # damaged files: the general reader's verdict
+    bad = list(paths)
+    blob = gzip.compress(payloads[5], 1)
+    open(bad[5], "wb").write(blob[:-8] + bytes([blob[-8] ^ 0xff]) + blob[-7:])      # the trailer's CRC-32 does not match the data
+    with sp.Context(0) as ctx:
+        with pytest.raises(sp.SpspError):
+            ctx.compare_files(bad, str(tmp_path / "bad"))
+        ctx.compare_files(paths[:5] + paths[6:], str(tmp_path / "after"))      # ... and the context works on
+
+
+@pytest.mark.gpu
 def test_compare_files_of_one_species_over_contexts_equal_the_oracle(tmp_path):
     """320 sketch FILES of one species (one ancestor, 0-1 % substitutions): every part of the comparison overflows, so the
     file-level drivers go through the spill and the bit columns -- with one context (cells through the dense matrix) and

@@ -307,6 +307,16 @@ def test_gz_io_roundtrip(tmp_path):
     b = str(tmp_path / "big.gz")
     sp.write_gz(b, big, 1)
     assert gzip.open(b, "rb").read() == big and sp.read_file(b) == big
+    import zlib
+    z = str(tmp_path / "wrapped.z")
+    open(z, "wb").write(zlib.compress(data, 6))     # zstr autodetect: a zlib wrapper inflates too
+    assert sp.read_file(z) == data
+    # the per-thread inflator is reset per member and per file: a tiny file after a big one, many members of ragged sizes
+    assert sp.read_file(r) == b"hello world"
+    parts = [os.urandom(n) for n in (0, 1, 4095, 4096, 4097, 70000, 3)]
+    mz = str(tmp_path / "ragged.gz")
+    open(mz, "wb").write(b"".join(gzip.compress(x, 1) for x in parts))
+    assert sp.read_file(mz) == b"".join(parts)
     e = str(tmp_path / "empty")
     open(e, "wb").close()
     assert sp.read_file(e) == b""
