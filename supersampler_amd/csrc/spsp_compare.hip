@@ -334,8 +334,14 @@ constexpr int kFlags = 8;   // [0] unsorted input, [1] fingerprint collision, [2
 // references are one coalesced load and the lists' first words are issued together.
 constexpr int kSparseThreads = 1024, kAccU = 2, kAccW = 4, kAccR = 2;
 // HALF: 16-bit counters, two to a word (no row holds 65 536 keys): half the LDS per workgroup
-template <bool HALF>
-__global__ __launch_bounds__(kSparseThreads) void k_accumulate_sparse(const uint32_t* __restrict__ list_of_entry,
+// TOUCH (cells out, HALF, one column block, no split): the workgroup STAYS and takes row after row (rows_y of them in all:
+// what grid.y would have been), and a row costs what it touches -- the counters are cleared once, whoever makes a counter
+// non-zero notes it in a list, the row's cells are the list's columns and only they are cleared again.  Without it a row
+// costs a clear and a scan of all N counters whatever it holds: a key-partitioned rank's 10 000 rows of ~600 keys were 0.20 ms
+// of that and of workgroup starts.  A row that touches more than kTouchCap counters (a family of thousands) is scanned as before.
+constexpr uint32_t kTouchCap = 1024;
+template <bool HALF, bool TOUCH, int T>
+__global__ __launch_bounds__(T) void k_accumulate_sparse(const uint32_t* __restrict__ list_of_entry,
                                                                      const uint32_t* __restrict__ where,
                                                                      const uint16_t* __restrict__ ids,
                                                                      const uint64_t* __restrict__ sk_begin,
@@ -348,8 +354,11 @@ __global__ __launch_bounds__(kSparseThreads) void k_accumulate_sparse(const uint
                                                                      unsigned long long* __restrict__ cells, unsigned long long cells_cap,
                                                                      unsigned long long* __restrict__ cells_count, uint32_t xcd_rows, bool add,
                                                                      const uint32_t* __restrict__ row_order, uint32_t long_limit,
-                                                                     const uint32_t* __restrict__ multi, uint32_t multi_slots) {
+                                                                     const uint32_t* __restrict__ multi, uint32_t multi_slots, uint32_t rows_y) {
+    static_assert(!TOUCH || HALF, "the touched-counter form packs 16-bit counters");
     extern __shared__ uint32_t s_cnt[];
+    __shared__ uint32_t s_list[TOUCH ? kTouchCap : 1];
+    __shared__ uint32_t s_nt;
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x < kFlags) host_flags[threadIdx.x] = flags[threadIdx.x];
     // a part overflowed: its workgroup of k_parts_group left without writing list references, so the ones in place are
     // whatever the buffer held before -- nothing may be followed from them (the host repeats the call with more parts)
@@ -359,29 +368,42 @@ __global__ __launch_bounds__(kSparseThreads) void k_accumulate_sparse(const uint
     // (= rows per XCD; grids of one column block and one slice only) XCD x takes the rows [x xcd_rows, (x + 1) xcd_rows) in
     // order: a family's members run side by side behind one L2 and a list line comes from HBM once per family, not once per
     // member (MI355X_MICROARCH.md: 4 MiB of L2 per XCD, not coherent across XCDs; a family's lists are ~0.25 MB).
-    uint32_t r = blockIdx.y;
-    if (xcd_rows) { r = (blockIdx.y & 7u) * xcd_rows + (blockIdx.y >> 3); if ((blockIdx.y >> 3) >= xcd_rows) return; }
-    if (row_order && r >= n) return;
+    const uint32_t copies = 1u << copies_log2, mine = threadIdx.x & (copies - 1);
+    if (TOUCH) {
+        for (uint32_t x = threadIdx.x; x < ((cols << copies_log2) >> 1); x += T) s_cnt[x] = 0;
+        if (threadIdx.x == 0) s_nt = 0;
+        __syncthreads();
+    }
+    if (TOUCH) { split = 1; add = false; long_limit = 0; }                     // (what the host guarantees for this form: the code for the rest folds away)
+    uint32_t by = blockIdx.y;
+    // (rows in fixed strides: drawing them from a per-XCD ticket counter was measured for the long rows of an all-vs-all call --
+    // where this form loses anyway, see the host side -- and for a rank's short ones, 0.161 -> 0.171 ms: not kept)
+    do {                                                                       // (TOUCH: row after row; else once -- not a loop to the compiler)
+    uint32_t r = by;
+    if (xcd_rows) { r = (by & 7u) * xcd_rows + (by >> 3); if ((by >> 3) >= xcd_rows) continue; }
+    if (row_order && r >= n) continue;
     // (row_order: every row owned; flags[10] / flags[11] = sketches with a sketch of the same signature close in front of them in the
     // new order / in the input's: the new order is taken when the input keeps fewer than half as many together)
     const bool reorder = row_order && 2u * flags[11] < flags[10];
-    const uint32_t i = reorder ? row_order[r] : row_first + r * row_stride, col0 = blockIdx.x * cols;
-    if (i >= n || i >= row_limit) return;
-    if (col0 + cols <= i + 1 || i + 1 >= n) return;         // no column > i in this block / at all
+    const uint32_t i = reorder ? row_order[r] : row_first + r * row_stride, col0 = TOUCH ? 0u : blockIdx.x * cols;
+    if (i >= n || i >= row_limit) continue;
+    if (col0 + cols <= i + 1 || i + 1 >= n) continue;       // no column > i in this block / at all
     uint64_t e0 = sk_begin[i], e1 = sk_end[i];
-    if (long_limit && e1 - e0 > long_limit) return;         // a row far longer than the others: summed in slices by a launch of its own
+    if (long_limit && e1 - e0 > long_limit) continue;       // a row far longer than the others: summed in slices by a launch of its own
     if (split > 1) {
         const uint64_t per = (e1 - e0 + split - 1) / split;
         e0 += per * blockIdx.z;
         if (e0 + per < e1) e1 = e0 + per;
-        if (e0 >= e1) return;
+        if (e0 >= e1) continue;
     }
-    const uint32_t copies = 1u << copies_log2, mine = threadIdx.x & (copies - 1);
-    for (uint32_t x = threadIdx.x; x < ((cols << copies_log2) >> (HALF ? 1 : 0)); x += kSparseThreads) s_cnt[x] = 0;
-    __syncthreads();
+    if (!TOUCH) {
+        for (uint32_t x = threadIdx.x; x < ((cols << copies_log2) >> (HALF ? 1 : 0)); x += T) s_cnt[x] = 0;
+        __syncthreads();
+    }
 #if SPSP_EXP & 8
     uint32_t exp_chk = 0;
 #endif
+    const uint32_t lane = threadIdx.x & 63u;
     auto count = [&](uint32_t jj) {
 #if SPSP_EXP & 8
         exp_chk += jj;                                        // (timing experiment: the lists are read, nothing is added in LDS)
@@ -393,22 +415,33 @@ __global__ __launch_bounds__(kSparseThreads) void k_accumulate_sparse(const uint
 #endif
         if (jj > i && jj - col0 < cols) {
             const uint32_t idx = ((jj - col0) << copies_log2) + mine;
-            if (HALF) atomicAdd(&s_cnt[idx >> 1], 1u << ((idx & 1u) << 4));    // (a half never carries: a counter is at most the row's key count)
+            if (TOUCH) {
+                const uint32_t sh = (idx & 1u) << 4;
+                const uint32_t old = atomicAdd(&s_cnt[idx >> 1], 1u << sh);
+                if (((old >> sh) & 0xffffu) == 0) {            // this counter's first: the lanes that have one now note them together
+                    const unsigned long long firsts = __ballot(1);
+                    const int leader = __ffsll((long long)firsts) - 1;
+                    uint32_t base = 0;
+                    if ((int)lane == leader) base = atomicAdd(&s_nt, (uint32_t)__popcll(firsts));
+                    base = __shfl(base, leader);
+                    const uint32_t at_l = base + (uint32_t)__popcll(firsts & ((1ull << lane) - 1ull));
+                    if (at_l < kTouchCap) s_list[at_l] = idx;
+                }
+            } else if (HALF) atomicAdd(&s_cnt[idx >> 1], 1u << ((idx & 1u) << 4));    // (a half never carries: a counter is at most the row's key count)
             else atomicAdd(&s_cnt[idx], 1u);
         }
     };
     auto counter = [&](uint32_t idx) { return HALF ? (s_cnt[idx >> 1] >> ((idx & 1u) << 4)) & 0xffffu : s_cnt[idx]; };
     // kAccR list references are fetched together (the partition form reaches them through `where`: two dependent
     // loads, the second scattered -- eight of each in flight per thread hide the extra hop), then the lists kAccU at a time
-    const uint32_t lane = threadIdx.x & 63u;
     const bool use_multi = multi && (multi_slots >> 31 ? true : 5u * flags[12] < 2u * flags[13]);   // (top bit of multi_slots: the host insists, SPSP_DEBUG_MULTI=1)     // (records with a list / records, in a sample of the parts: k_parts_group)
-    for (uint64_t eb = e0; eb < e1; eb += (uint64_t)kAccR * kSparseThreads) {     // (every lane makes every round: the waves pool their long lists, below)
+    for (uint64_t eb = e0; eb < e1; eb += (uint64_t)kAccR * T) {     // (every lane makes every round: the waves pool their long lists, below)
         const uint64_t e = eb + threadIdx.x;
         uint32_t refs[kAccR];
         if (where) {                                         // the reference sits where the key's record went
             uint32_t at[kAccR];
 #pragma unroll
-            for (int r = 0; r < kAccR; ++r) { const uint64_t eu = e + (uint64_t)r * kSparseThreads; at[r] = eu < e1 ? where[eu] : kNoWhere; }
+            for (int r = 0; r < kAccR; ++r) { const uint64_t eu = e + (uint64_t)r * T; at[r] = eu < e1 ? where[eu] : kNoWhere; }
 #pragma unroll
             for (int r = 0; r < kAccR; ++r) {
                 // (multi: a bit per record slot of the parts -- has the key a list? -- in front of the list reference's miss)
@@ -425,7 +458,7 @@ __global__ __launch_bounds__(kSparseThreads) void k_accumulate_sparse(const uint
             }
         } else {
 #pragma unroll
-            for (int r = 0; r < kAccR; ++r) { const uint64_t eu = e + (uint64_t)r * kSparseThreads; refs[r] = eu < e1 ? list_of_entry[eu] : kNoList; }
+            for (int r = 0; r < kAccR; ++r) { const uint64_t eu = e + (uint64_t)r * T; refs[r] = eu < e1 ? list_of_entry[eu] : kNoList; }
         }
 #pragma unroll
         for (int g = 0; g < kAccR; g += kAccU) {
@@ -505,29 +538,90 @@ __global__ __launch_bounds__(kSparseThreads) void k_accumulate_sparse(const uint
     if (exp_chk == 0x12345u) s_cnt[1] = exp_chk;
 #endif
     __syncthreads();
+    if (TOUCH) {
+        const uint32_t nt = s_nt;
+        if (nt <= kTouchCap) {
+            // the row's cells: the columns in the list (a column with several copies of its counter is in the list once per copy
+            // that counted: the lowest such copy speaks for it)
+            const uint32_t rounds = (nt + 63u) >> 6;
+            for (uint32_t q = threadIdx.x >> 6; q < rounds; q += T / 64) {
+                const uint32_t t = (q << 6) + lane;
+                uint32_t v = 0, x = 0;
+                if (t < nt) {
+                    const uint32_t idx = s_list[t];
+                    x = idx >> copies_log2;
+                    bool speaks = true;
+                    for (uint32_t k = 0; k < copies; ++k) {
+                        const uint32_t c = counter((x << copies_log2) + k);
+                        if (c && k < (idx & (copies - 1u))) speaks = false;
+                        v += c;
+                    }
+                    if (!speaks) v = 0;
+                }
+                const unsigned long long hit = __ballot(v != 0);
+                if (hit) {
+                    unsigned long long base = 0;
+                    if (lane == 0) base = atomicAdd(cells_count, (unsigned long long)__popcll(hit));
+                    base = __shfl(base, 0);
+                    const unsigned long long mine_at = base + (unsigned long long)__popcll(hit & ((1ull << lane) - 1ull));
+                    if (v && mine_at < cells_cap) cells[mine_at] = ((unsigned long long)i << 48) | ((unsigned long long)(col0 + x) << 32) | v;
+                }
+            }
+            __syncthreads();
+            for (uint32_t t = threadIdx.x; t < nt; t += T) s_cnt[s_list[t] >> 1] = 0;     // (both halves: the other is zero or in the list too)
+            if (threadIdx.x == 0) s_nt = 0;
+            __syncthreads();
+            continue;
+        }
+    }
+    if (TOUCH) {
+        // a row that touched more counters than the list holds (a family of thousands): every counter looked at, every counter cleared
+#pragma unroll 1
+        for (uint32_t x0 = 0; x0 < cols; x0 += T) {
+            const uint32_t x = x0 + threadIdx.x;
+            uint32_t v = 0;
+            if (x < cols && x > i && x < n)
+                for (uint32_t k = 0; k < copies; ++k) v += counter((x << copies_log2) + k);
+            const unsigned long long hit = __ballot(v != 0);
+            if (hit) {
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(cells_count, (unsigned long long)__popcll(hit));
+                base = __shfl(base, 0);
+                const unsigned long long mine_at = base + (unsigned long long)__popcll(hit & ((1ull << lane) - 1ull));
+                if (v && mine_at < cells_cap) cells[mine_at] = ((unsigned long long)i << 48) | ((unsigned long long)x << 32) | v;
+            }
+        }
+        __syncthreads();
+        for (uint32_t x = threadIdx.x; x < ((cols << copies_log2) >> 1); x += T) s_cnt[x] = 0;
+        if (threadIdx.x == 0) s_nt = 0;
+        __syncthreads();
+        continue;
+    }
     if (cells) {
         // sparse result (the key-partitioned split: a rank's partial row is nearly all zeros): the row's non-zero cells
         // leave as packed words i << 48 | j << 32 | count -- the dense row is not written.  One atomic per WAVE that has any
         // (not per wave and column step: all of them hit the same counter, 11 ns each when millions queue up -- 75 ms at
         // 65 535 sketches of unrelated genomes against 5 ms for the dense form), and with several column blocks per row ONE
         // per workgroup: the waves count first, the counters stay in registers.
-        constexpr int kSteps = kSparseCols / kSparseThreads;
-        __shared__ uint32_t s_wave[kSparseThreads / 64];
+        constexpr int kSteps = kSparseCols / T;
+        __shared__ uint32_t s_wave[T / 64];
         __shared__ unsigned long long s_base;
-        const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+        const uint32_t wave = threadIdx.x >> 6;
         auto value = [&](int st) -> uint32_t {
-            const uint32_t x = threadIdx.x + (uint32_t)st * kSparseThreads, col = col0 + x;
+            const uint32_t x = threadIdx.x + (uint32_t)st * T, col = col0 + x;
             uint32_t v = 0;
             if (x < cols && col > i && col < n)
                 for (uint32_t k = 0; k < copies; ++k) v += counter((x << copies_log2) + k);
             return v;
         };
         // the wave counts first (which of its column steps have any cell: most have none), then writes those steps only
-        uint32_t wave_total = 0, steps = 0;
+        static_assert(kSteps <= 64, "one bit per column step");
+        uint32_t wave_total = 0;
+        unsigned long long steps = 0;
 #pragma unroll
         for (int st = 0; st < kSteps; ++st) {
             const unsigned long long hit = __ballot(value(st) != 0);
-            if (hit) { wave_total += (uint32_t)__popcll(hit); steps |= 1u << st; }
+            if (hit) { wave_total += (uint32_t)__popcll(hit); steps |= 1ull << st; }
         }
         unsigned long long at;
         if (gridDim.x == 1) {
@@ -541,25 +635,25 @@ __global__ __launch_bounds__(kSparseThreads) void k_accumulate_sparse(const uint
             __syncthreads();
             if (threadIdx.x == 0) {
                 uint32_t total = 0;
-                for (uint32_t w = 0; w < kSparseThreads / 64; ++w) { const uint32_t c = s_wave[w]; s_wave[w] = total; total += c; }
+                for (uint32_t w = 0; w < T / 64; ++w) { const uint32_t c = s_wave[w]; s_wave[w] = total; total += c; }
                 s_base = total ? atomicAdd(cells_count, (unsigned long long)total) : 0ull;
             }
             __syncthreads();
             at = s_base + s_wave[wave];
         }
         while (steps) {                                  // (wave-uniform: the mask came from ballots)
-            const int st = __ffs((int)steps) - 1;
+            const int st = __ffsll((long long)steps) - 1;
             steps &= steps - 1;
             const uint32_t v = value(st);
             const unsigned long long hit = __ballot(v != 0);
             const unsigned long long mine_at = at + (unsigned long long)__popcll(hit & ((1ull << lane) - 1ull));
             if (v && mine_at < cells_cap)
-                cells[mine_at] = ((unsigned long long)i << 48) | ((unsigned long long)(col0 + threadIdx.x + (uint32_t)st * kSparseThreads) << 32) | v;
+                cells[mine_at] = ((unsigned long long)i << 48) | ((unsigned long long)(col0 + threadIdx.x + (uint32_t)st * T) << 32) | v;
             at += (unsigned long long)__popcll(hit);
         }
-        return;
+        continue;
     }
-    for (uint32_t x = threadIdx.x; x < cols; x += kSparseThreads) {
+    for (uint32_t x = threadIdx.x; x < cols; x += T) {
         const uint32_t col = col0 + x;
         if (col > i && col < n) {
             uint32_t v = 0;
@@ -569,6 +663,7 @@ __global__ __launch_bounds__(kSparseThreads) void k_accumulate_sparse(const uint
             else inter[(uint64_t)i * n + col] = v;
         }
     }
+    } while (TOUCH && (by += gridDim.y) < rows_y);
 }
 // cells (i, j > i) of the owned rows = 0 (only needed when the row sums are split over several workgroups)
 __global__ __launch_bounds__(256) void k_zero_rows(uint32_t n, uint32_t row_first, uint32_t row_stride, uint32_t row_limit,
@@ -1564,17 +1659,39 @@ static int launch_accumulate_sparse(spsp_ctx* ctx, const ComparePlan& P, uint32_
     const bool half = split == 1 && P.max_row > 0 && (P.max_row <= kLongRow || long_limit) && !(dbg_half && dbg_half[0] == '0');
     // (256-lane workgroups for short rows were measured for the key-partitioned ranks' ~600-key rows: 0.178 -> 0.192 ms -- a row's fixed
     // cost is clearing and scanning its N counters, which takes four times as many rounds with a quarter of the lanes; not kept)
-    auto kern = half ? &k_accumulate_sparse<true> : &k_accumulate_sparse<false>;
+    auto kern = half ? &k_accumulate_sparse<true, false, kSparseThreads> : &k_accumulate_sparse<false, false, kSparseThreads>;
     // a caller that wants the result as sparse cells (compare_cells_run) gets them straight from the row sums
     // when ONE workgroup makes a row (no split, no long rows) -- else the dense matrix is written and sparsified afterwards
     const bool direct = may_emit_cells && ctx->cells_req.armed && split == 1 && long_rows.empty();
-    hipLaunchKernelGGL(kern, dim3(col_blocks, by_xcd ? xcd_rows * 8 : P.n_own, split), dim3(kSparseThreads),
-                       ((size_t)cols << copies_log2) * (half ? 2 : 4), ctx->stream,
+    // ... and, when the rows are SHORT (a key-partitioned rank's: ~600 keys of each of 10 000 sketches), by workgroups of 256 lanes
+    // that stay and take row after row, a row costing what it touches (TOUCH, see the kernel): 0.204 -> 0.161 ms for such a rank.
+    // Long rows keep a workgroup each: noting first touches takes LDS adds that RETURN, ~20 per key, and a 4 800-key row's clear
+    // and scan are little beside its keys (configs[3] all-vs-all as cells: 0.775 ms against 0.95 with 1 024 lanes staying, 1.14 with 256)
+    static const char* dbg_touch = getenv("SPSP_DEBUG_ACC_TOUCH");   // "0": never; "s" / "l": always, 256 / 1 024 lanes (A/B, tests)
+    const bool touch_forced = dbg_touch && (dbg_touch[0] == 's' || dbg_touch[0] == 'l');
+    const bool touch = direct && half && col_blocks == 1 && !(dbg_touch && dbg_touch[0] == '0') && (per_row <= 2048 || touch_forced);
+    const uint32_t rows_y = by_xcd ? xcd_rows * 8 : P.n_own;
+    uint32_t grid_y = rows_y, threads = kSparseThreads;
+    size_t lds = ((size_t)cols << copies_log2) * (half ? 2 : 4);
+    if (touch) {
+        // counters for the N columns there are, not for the next power of two (one column block): more workgroups to a CU
+        cols = (P.n + 63u) & ~63u;
+        copies_log2 = 0;
+        while (copies_log2 < 4 && ((size_t)cols << (copies_log2 + 1)) * 2 <= 32u * 1024u) ++copies_log2;
+        lds = ((size_t)cols << copies_log2) * 2;
+        const bool small_wg = !(dbg_touch && dbg_touch[0] == 'l');
+        threads = small_wg ? 256 : kSparseThreads;
+        const uint32_t per_cu = small_wg ? (uint32_t)std::min<size_t>(8, (160u * 1024u) / (lds + kTouchCap * 4 + 512)) : 2u;
+        grid_y = std::min(rows_y, std::max(8u, (uint32_t)ctx->n_cu * std::max(1u, per_cu)) & ~7u);
+        if (grid_y < 8 || (grid_y & 7u)) grid_y = rows_y;                                        // (fewer than eight rows: one workgroup each)
+        kern = small_wg ? &k_accumulate_sparse<true, true, 256> : &k_accumulate_sparse<true, true, kSparseThreads>;
+    }
+    hipLaunchKernelGGL(kern, dim3(col_blocks, grid_y, split), dim3(threads), lds, ctx->stream,
                        P.list_ref ? P.list_ref : ctx->c_row.as<uint32_t>(), P.where, ctx->c_matrix.as<uint16_t>(), P.sk_begin, P.sk_end,
                        P.n, P.row_first, P.row_stride, P.row_limit, cols, copies_log2, split, P.d_inter, flags,
                        reinterpret_cast<uint32_t*>(ctx->h_scalar + 8),
                        direct ? ctx->cells_req.cells : (unsigned long long*)nullptr,
-                       (unsigned long long)ctx->cells_req.cap, ctx->cells_req.count, xcd_rows, add, by_xcd ? P.row_order : (const uint32_t*)nullptr, long_limit, P.multi, P.multi_slots);
+                       (unsigned long long)ctx->cells_req.cap, ctx->cells_req.count, xcd_rows, add, by_xcd ? P.row_order : (const uint32_t*)nullptr, long_limit, P.multi, P.multi_slots, rows_y);
     SPSP_HIP(hipGetLastError());
     for (uint32_t i : long_rows) {
         const uint64_t keys = ctx->h_skoff[i + 1] - ctx->h_skoff[i];
@@ -1583,10 +1700,10 @@ static int launch_accumulate_sparse(spsp_ctx* ctx, const ComparePlan& P, uint32_
             hipLaunchKernelGGL(k_zero_rows, dim3(std::max(1u, std::min((P.n + 255) / 256, 64u)), 1), dim3(256), 0, ctx->stream, P.n, i, 1u, i + 1, P.d_inter);
             SPSP_HIP(hipGetLastError());
         }
-        hipLaunchKernelGGL(k_accumulate_sparse<false>, dim3(col_blocks, 1, slices), dim3(kSparseThreads), ((size_t)cols << copies_log2) * 4, ctx->stream,
+        hipLaunchKernelGGL((k_accumulate_sparse<false, false, kSparseThreads>), dim3(col_blocks, 1, slices), dim3(kSparseThreads), ((size_t)cols << copies_log2) * 4, ctx->stream,
                            P.list_ref ? P.list_ref : ctx->c_row.as<uint32_t>(), P.where, ctx->c_matrix.as<uint16_t>(), P.sk_begin, P.sk_end,
                            P.n, i, 1u, i + 1, cols, copies_log2, slices, P.d_inter, flags, reinterpret_cast<uint32_t*>(ctx->h_scalar + 8),
-                           (unsigned long long*)nullptr, 0ull, (unsigned long long*)nullptr, 0u, add, (const uint32_t*)nullptr, 0u, P.multi, P.multi_slots);
+                           (unsigned long long*)nullptr, 0ull, (unsigned long long*)nullptr, 0u, add, (const uint32_t*)nullptr, 0u, P.multi, P.multi_slots, 1u);
         SPSP_HIP(hipGetLastError());
     }
     ctx->cells_req.direct = direct;
@@ -2119,7 +2236,7 @@ static int compare_device_begin_inner(spsp_ctx* ctx, uint32_t k, const uint32_t*
     // staging copy of the offsets (one job may be pending per context, and the previous one has been collected)
     uint32_t n_tiles = 0, tile_sk = 0;
     if ((rc = stage_sk_off(ctx, h_sk_off, n, row_first, &n_tiles, &tile_sk))) return rc;
-    if ((rc = ctx->c_flags.reserve(128))) return rc;
+    if ((rc = ctx->c_flags.reserve(256))) return rc;
     Keys K{d_min, d_lo, (k > 32) ? d_hi : nullptr, ~0ull};
     const uint64_t* sk = ctx->c_skoff.as<uint64_t>();
     uint32_t* flags = ctx->c_flags.as<uint32_t>();

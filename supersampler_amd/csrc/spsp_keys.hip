@@ -609,7 +609,7 @@ int sketch_keys_begin_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d
     uint32_t* d_out_off = d_distinct + (n_genomes + 2);
     uint32_t* d_raw_cnt = d_out_off + (n_genomes + 2);
     uint32_t* d_big = d_raw_cnt + (n_genomes + 2);
-    if ((rc = ctx->c_flags.reserve(128))) return rc;
+    if ((rc = ctx->c_flags.reserve(256))) return rc;
     uint32_t* d_flags = ctx->c_flags.as<uint32_t>() + 16;          // two words of its own behind the comparison's sixteen (which k_parts_prepare clears and k_parts_group counts in)
     // The unordered form runs on a stream that carries a key extraction per step: its workgroups read their two record
     // bounds straight from the pinned staging block (no copy packet in front), and the gate words are cleared by the

@@ -91,7 +91,7 @@ int matrix_cells_impl(spsp_ctx* ctx, const uint32_t* d_inter, uint32_t n, uint32
     if (n < 2 || row_first >= row_limit) return SPSP_OK;
     if (row_limit > n) row_limit = n;
     int rc;
-    if ((rc = ctx->c_flags.reserve(128))) return rc;
+    if ((rc = ctx->c_flags.reserve(256))) return rc;
     unsigned long long* d_count = reinterpret_cast<unsigned long long*>(ctx->c_flags.as<uint32_t>() + 14);   // two words of the flag block nobody else uses
     SPSP_HIP(hipMemsetAsync(d_count, 0, 8, ctx->stream));
     hipLaunchKernelGGL(k_matrix_cells, dim3((n + 1023) / 1024, row_limit - row_first), dim3(256), 0, ctx->stream, d_inter, n, row_first, row_limit,
@@ -121,7 +121,7 @@ int compare_cells_run(spsp_ctx* ctx, const std::function<int()>& begin, uint32_t
     if (n > 65535) { set_error("at most 65535 sketches (the packed cell holds two 16-bit sketch numbers; Comparator.h:26 has the same bound)"); return SPSP_ERR_ARG; }
     *n_cells = 0;
     int rc;
-    if ((rc = ctx->c_flags.reserve(128))) return rc;
+    if ((rc = ctx->c_flags.reserve(256))) return rc;
     unsigned long long* d_count = reinterpret_cast<unsigned long long*>(ctx->c_flags.as<uint32_t>() + 14);
     SPSP_HIP(hipMemsetAsync(d_count, 0, 8, ctx->stream));
     ctx->cells_req.cells = reinterpret_cast<unsigned long long*>(d_cells); ctx->cells_req.cap = cap; ctx->cells_req.count = d_count;
@@ -460,7 +460,7 @@ int spsp_matrix_add_cells_device(spsp_ctx* ctx, void* d_inter, uint32_t n, const
     if (n_cells == 0) return SPSP_OK;
     SPSP_HIP(hipSetDevice(ctx->device));
     int rc;
-    if ((rc = ctx->c_flags.reserve(128))) return rc;
+    if ((rc = ctx->c_flags.reserve(256))) return rc;
     uint32_t* d_bad = ctx->c_flags.as<uint32_t>() + 14;
     SPSP_HIP(hipMemsetAsync(d_bad, 0, 4, ctx->stream));
     hipLaunchKernelGGL(k_matrix_add_cells, dim3((uint32_t)std::min<uint64_t>(4096, (n_cells + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t*)d_inter, n,
