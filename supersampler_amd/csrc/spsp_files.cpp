@@ -235,10 +235,15 @@ public:
         static const char* dbg_budget = getenv("SPSP_DEBUG_PIPE_BUDGET_MB");   // tuning knob
         if (dbg_budget) budget_ = (uint64_t)std::max(1, atoi(dbg_budget)) << 20;
         const double t_setup0 = now_s();
+        t_begin_ = t_setup0;
         // batches in flight: with one worker nothing overlaps the host's work anyway (and every slot costs a context, a
         // pinned slab and device buffers, which a short-lived process pays for in full)
-        // (several devices: the batches are dealt over them, slot j on device j mod n -- up to four in flight per device)
-        const uint32_t n_slots = std::min<uint32_t>(std::min<uint32_t>(4 * (uint32_t)devices_.size(), threads_), n_);
+        // (several devices: the batches are dealt over them, slot j on device j mod n -- up to six in flight per device)
+        static const char* dbg_slots = getenv("SPSP_DEBUG_PIPE_SLOTS");         // tuning knob: batches in flight per device
+        // (six: 100 x 5 Mbp on 16 threads, median of 7 calls 17.4 ms with four, 13.2 with six, 15.4 with eight -- a slot is a batch being read,
+        // one on the GPU or one being built; with four the workers ran out of reads while batches sat in their GPU stage)
+        const uint32_t per_dev = dbg_slots ? (uint32_t)std::max(1, atoi(dbg_slots)) : 6u;
+        const uint32_t n_slots = std::min<uint32_t>(std::min<uint32_t>(per_dev * (uint32_t)devices_.size(), threads_), n_);
         slots_.resize(n_slots);
         for (size_t j = 0; j < slots_.size(); ++j) {
             auto& s = slots_[j];
@@ -278,6 +283,11 @@ public:
         if (getenv("SPSP_DEBUG_PIPE_TIMES"))
             fprintf(stderr, "[spsp pipeline] contexts %.1f ms, pinned slabs %.1f ms, teardown follows; budget %llu MB, %u slots\n", setup_s_ * 1e3, slab_s_ * 1e3,
                     (unsigned long long)(budget_ >> 20), (unsigned)slots_.size());
+        if (trace_on_) {
+            std::sort(trace_.begin(), trace_.end(), [](const TraceEv& a, const TraceEv& b) { return a.t0 < b.t0; });
+            for (const TraceEv& e : trace_) fprintf(stderr, "[pipe] slot %d %c %8.3f .. %8.3f ms (%.3f)\n", e.slot, e.stage, e.t0, e.t1, e.t1 - e.t0);
+            fprintf(stderr, "[pipe] call %.3f ms\n", (now_s() - t_begin_) * 1e3);
+        }
         if (fatal_rc_) { set_error("%s", fatal_err_.c_str()); return fatal_rc_; }
         if (failed_) { set_error("%u of %u files could not be sketched (see the callback's reports)", failed_, n_); return SPSP_ERR_IO; }
         return SPSP_OK;
@@ -395,11 +405,13 @@ private:
             close(fd);
         }
         add_time(read_s_, now_s() - t0);
+        trace(s, 'p', t0);
         if (s.left.fetch_sub(1) == 1) layout(s);
     }
 
     // between stages 1 and 2 (one thread): every good file gets a tile-aligned place in the slab
     void layout(PipeSlot& s) {
+        const double t_lay = now_s();
         uint64_t at = 0;
         for (auto& f : s.files) {
             if (f.rc) continue;
@@ -429,6 +441,7 @@ private:
             if (s.ctx->i_text.reserve((size_t)s.total + 64) == SPSP_OK) s.d_text = s.ctx->i_text.as<uint8_t>();
         }
         s.left.store((int)s.files.size());
+        trace(s, 'l', t_lay);
         for (size_t j = 0; j < s.files.size(); ++j) push([this, &s, j]() { fill(s, j); });
     }
     // bytes [from, to) of the slab to their place on the device (queued on the slot's stream; the GPU stage's kernels follow them)
@@ -503,11 +516,13 @@ private:
             }
         }
         add_time(read_s_, now_s() - t0);
+        trace(s, 'f', t0);
         if (s.left.fetch_sub(1) == 1) push([this, &s]() { gpu(s); });
     }
 
     // stage 3, per batch: one copy, one ingest, one scan, one gather
     void gpu(PipeSlot& s) {
+        const double t_gpu = now_s();
         int rc = SPSP_OK;
         spsp_ctx* ctx = s.ctx;
         free(s.compact); free(s.coff); free(s.kflags); s.compact = nullptr; s.coff = nullptr; s.kflags = nullptr;
@@ -530,12 +545,12 @@ private:
             SPSP_HIP(hipMemcpyAsync(rec_base.data(), ctx->i_recbase.p, (size_t)n_tiles * 4, hipMemcpyDeviceToHost, ctx->stream));
             s.rec_off.resize((size_t)n_rec + 1);
             SPSP_HIP(hipMemcpyAsync(s.rec_off.data(), d_off, s.rec_off.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-            t1 = now_s(); ctx->stages.ingest_s += t1 - t0; t0 = t1;
+            t1 = now_s(); ctx->stages.ingest_s += t1 - t0; trace(s, 'i', t0); t0 = t1;
             spsp_superkmer* d_sk = nullptr; uint64_t n_sk = 0;
             spsp_params ps = p_;
             if (packed) ps.flags |= SPSP_SCAN_PACKED_INPUT;
             if ((r = spsp::scan_device_impl(ctx, &ps, d_bases, n_bases, d_off, n_rec, &d_sk, &n_sk))) return r;   // (its host wait also completes the copies above)
-            t1 = now_s(); ctx->stages.scan_s += t1 - t0; t0 = t1;
+            t1 = now_s(); ctx->stages.scan_s += t1 - t0; trace(s, 's', t0); t0 = t1;
             PipeFile* prev = nullptr;
             for (auto& f : s.files) {
                 if (f.rc) continue;
@@ -561,7 +576,7 @@ private:
                 while (at < s.sk.size() && s.sk[at].rec < f.first_rec + f.n_rec) ++at;
                 f.sk1 = at;
             }
-            t1 = now_s(); ctx->stages.gather_s += t1 - t0; t0 = t1;
+            t1 = now_s(); ctx->stages.gather_s += t1 - t0; trace(s, 'G', t0); t0 = t1;
             if (dev_build) {
                 // the sketch builder on the device, for the whole batch (spsp_build.hip): file j's super-k-mers are [sk0, sk1)
                 std::vector<uint32_t> fsk;
@@ -635,12 +650,14 @@ private:
         }
         if (rc) { const std::string e = spsp_last_error(); for (auto& f : s.files) if (!f.rc) { f.rc = rc; f.err = e; } }
         s.left.store((int)s.files.size());
+        trace(s, 'g', t_gpu);
         for (size_t j = 0; j < s.files.size(); ++j) push([this, &s, j]() { finish(s, j); });
     }
 
     // stage 4, per file: handle_superkmer + emission (SubSampler.cpp:243-302, 458-504), gzip -9, write, report
     void finish(PipeSlot& s, size_t j) {
         PipeFile& f = s.files[j];
+        const double t_fin = now_s();
         uint8_t* payload = nullptr; uint64_t plen = 0;
         if (!f.rc && !f.done) {
             double t0 = now_s();
@@ -684,6 +701,7 @@ private:
             if (cb_ && threads_ == 1) cb_(user_, f.index, 0, SPSP_OK, nullptr, nullptr);
             if (cb_) cb_(user_, f.index, 1, f.rc, &f.st, f.rc ? f.err.c_str() : nullptr);
         }
+        trace(s, 'w', t_fin);
         if (s.left.fetch_sub(1) == 1) {
             std::lock_guard<std::mutex> g(m_);
             --batches_in_flight_;
@@ -693,6 +711,18 @@ private:
     }
 
     void add_time(double& acc, double dt) { std::lock_guard<std::mutex> g(time_m_); acc += dt; }
+    // SPSP_DEBUG_PIPE_TRACE: every task's begin and end (ms since the call began), by slot and stage, printed when the call ends
+    struct TraceEv { int slot; char stage; double t0, t1; };
+    void trace(const PipeSlot& s, char stage, double t0) {
+        if (!trace_on_) return;
+        int slot = -1;
+        for (size_t j = 0; j < slots_.size(); ++j) if (slots_[j].get() == &s) slot = (int)j;
+        std::lock_guard<std::mutex> g(time_m_);
+        trace_.push_back(TraceEv{slot, stage, (t0 - t_begin_) * 1e3, (now_s() - t_begin_) * 1e3});
+    }
+    bool trace_on_ = getenv("SPSP_DEBUG_PIPE_TRACE") != nullptr;
+    double t_begin_ = 0;
+    std::vector<TraceEv> trace_;
 
     std::vector<int> devices_;
     spsp_params p_;
