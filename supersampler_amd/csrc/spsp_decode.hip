@@ -174,7 +174,7 @@ template <bool HAS_HI>
 __global__ __launch_bounds__(kSortThreads) void k_decode_sort(uint32_t* __restrict__ r_mn, uint64_t* __restrict__ r_lo,
                                                              uint64_t* __restrict__ r_hi, const uint64_t* __restrict__ raw_off,
                                                              const uint32_t* __restrict__ raw_cnt, const uint8_t* __restrict__ presorted,
-                                                             const uint32_t* __restrict__ big, uint32_t* __restrict__ distinct) {
+                                                             const uint32_t* __restrict__ big, uint32_t* __restrict__ distinct, uint32_t force_network) {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_s[];
     constexpr uint32_t CAP = HAS_HI ? kSortCapHi : kSortCapLo;
     uint64_t* s_lo = reinterpret_cast<uint64_t*>(lds_s);
@@ -194,6 +194,61 @@ __global__ __launch_bounds__(kSortThreads) void k_decode_sort(uint32_t* __restri
         else { s_mn[i] = 0xffffffffu; s_lo[i] = ~0ull; if (HAS_HI) s_hi[i] = ~0ull; }
     }
     __syncthreads();
+    // A sketch as the sketcher writes it has its buckets in ascending minimizer order (the reference walks a std::map,
+    // SubSampler.cpp:458-504): the raw keys are sorted by minimizer already and only a bucket's k-mers -- tens of them -- are
+    // out of order.  Then every key finds its place by COUNTING the smaller keys of its bucket (no exchange network, two
+    // barriers): 4.4 -> ~0.5 ms for the 10 000 sketches of configs[3].  A payload whose minimizers do not ascend, or with a
+    // bucket of more than kBucketMax keys (a low-complexity genome), takes the bitonic network below.
+    constexpr uint32_t kBucketMax = 256, PERK = CAP / kSortThreads;
+    __shared__ uint32_t s_slow;
+    if (t == 0) s_slow = force_network;
+    __syncthreads();
+    if (!force_network) {
+        // a lane takes PERK CONSECUTIVE keys: mostly one bucket, whose bounds come from two binary searches over the (ascending)
+        // minimizers -- walking to the bucket's ends key by key was a chain of ~100 dependent LDS reads per key and slower
+        // than the network it replaces
+        uint32_t my_rank[PERK];
+        uint64_t my_lo[PERK], my_hi[PERK];
+        bool slow = false;
+        uint32_t b0 = 0, b1 = 0, b_mn = 0;
+        bool have = false;
+#pragma unroll
+        for (uint32_t u = 0; u < PERK; ++u) {
+            const uint32_t i = t * PERK + u;
+            my_rank[u] = 0xffffffffu;
+            if (i >= n) continue;
+            const uint32_t mn = s_mn[i];
+            if (i && s_mn[i - 1] > mn) slow = true;
+            if (!have || mn != b_mn) {
+                uint32_t lo_ = 0, hi_ = n;
+                while (lo_ < hi_) { const uint32_t mid = (lo_ + hi_) >> 1; if (s_mn[mid] < mn) lo_ = mid + 1; else hi_ = mid; }
+                b0 = lo_; hi_ = n;
+                while (lo_ < hi_) { const uint32_t mid = (lo_ + hi_) >> 1; if (s_mn[mid] <= mn) lo_ = mid + 1; else hi_ = mid; }
+                b1 = lo_; b_mn = mn; have = true;
+            }
+            // (minimizers that do not ascend make the searches meaningless: the bounds are clamped around i so that the loop below
+            // stays short and in range -- that sketch takes the network anyway)
+            if (b0 > i || b1 <= i || b1 - b0 > kBucketMax) { slow = true; continue; }
+            const uint64_t lo = s_lo[i], hi = HAS_HI ? s_hi[i] : 0ull;
+            uint32_t smaller = 0;
+            for (uint32_t j = b0; j < b1; ++j) {
+                const uint64_t lj = s_lo[j], hj = HAS_HI ? s_hi[j] : 0ull;
+                const bool less = HAS_HI ? (hj < hi || (hj == hi && (lj < lo || (lj == lo && j < i)))) : (lj < lo || (lj == lo && j < i));
+                smaller += less ? 1u : 0u;
+            }
+            my_rank[u] = b0 + smaller; my_lo[u] = lo; my_hi[u] = hi;
+        }
+        if (slow) s_slow = 1;
+        __syncthreads();
+        const bool any_slow = s_slow != 0;
+        if (!any_slow) {
+#pragma unroll
+            for (uint32_t u = 0; u < PERK; ++u)
+                if (my_rank[u] != 0xffffffffu) { s_lo[my_rank[u]] = my_lo[u]; if (HAS_HI) s_hi[my_rank[u]] = my_hi[u]; }
+        }
+        __syncthreads();
+    }
+    if (s_slow) {
     auto greater = [&](uint32_t a, uint32_t b) {
         if (s_mn[a] != s_mn[b]) return s_mn[a] > s_mn[b];
         if (HAS_HI && s_hi[a] != s_hi[b]) return s_hi[a] > s_hi[b];
@@ -202,7 +257,7 @@ __global__ __launch_bounds__(kSortThreads) void k_decode_sort(uint32_t* __restri
     for (uint32_t size = 2; size <= n2; size <<= 1) {
         for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
             for (uint32_t idx = t; idx < (n2 >> 1); idx += kSortThreads) {
-                const uint32_t i = ((idx / stride) * (stride << 1)) + (idx % stride), j = i + stride;
+                const uint32_t i = ((idx & ~(stride - 1u)) << 1) | (idx & (stride - 1u)), j = i + stride;   // (stride is a power of two)
                 const bool asc = (i & size) == 0;
                 if (greater(i, j) == asc) {
                     const uint32_t tm = s_mn[i]; s_mn[i] = s_mn[j]; s_mn[j] = tm;
@@ -212,6 +267,7 @@ __global__ __launch_bounds__(kSortThreads) void k_decode_sort(uint32_t* __restri
             }
             __syncthreads();
         }
+    }
     }
     // unique: first of every run of equal keys, ranks by a workgroup prefix sum (CAP / kSortThreads consecutive elements per lane)
     constexpr uint32_t PER = CAP / kSortThreads;
@@ -579,10 +635,12 @@ int sketch_decode_device_impl(spsp_ctx* ctx, const uint8_t* const* payloads, con
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_sort<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kSortCapLo * 12));
         ctx->attr_sort_set = true;
     }
+    static const char* dbg_sort = getenv("SPSP_DEBUG_DECODE_SORT");     // "network": every sketch through the bitonic network (A/B, tests)
+    const uint32_t force_network = dbg_sort && dbg_sort[0] == 'n' ? 1u : 0u;
     if (has_hi) hipLaunchKernelGGL(k_decode_sort<true>, dim3(n), dim3(kSortThreads), lds, ctx->stream, ctx->dc_mn.as<uint32_t>(), ctx->dc_lo.as<uint64_t>(),
-                                   ctx->dc_hi.as<uint64_t>(), d_raw_off, d_raw_cnt, d_presorted, d_big, d_distinct);
+                                   ctx->dc_hi.as<uint64_t>(), d_raw_off, d_raw_cnt, d_presorted, d_big, d_distinct, force_network);
     else hipLaunchKernelGGL(k_decode_sort<false>, dim3(n), dim3(kSortThreads), lds, ctx->stream, ctx->dc_mn.as<uint32_t>(), ctx->dc_lo.as<uint64_t>(),
-                            (uint64_t*)nullptr, d_raw_off, d_raw_cnt, d_presorted, d_big, d_distinct);
+                            (uint64_t*)nullptr, d_raw_off, d_raw_cnt, d_presorted, d_big, d_distinct, force_network);
     // the sketches beyond the LDS sort: distinct keys through the table in HBM (no count rule here: the reader takes every
     // k-mer a sketch holds; no orientation bit: k_decode_emit writes canonical keys), sorted once they lie in place
     if (any_big && (rc = big_dedupe_launch(ctx, has_hi, ctx->dc_mn.as<uint32_t>(), ctx->dc_lo.as<uint64_t>(), has_hi ? ctx->dc_hi.as<uint64_t>() : nullptr,

@@ -883,6 +883,46 @@ def test_gpu_sketch_decode_matches_oracle_keys(ctx):
             assert int(sk_off[5] - sk_off[4]) > 8192               # the large sketch went through the table in HBM and the merge sort
 
 
+def _decode_sort_cases(ctx):
+    """sketches whose buckets are small (tens of k-mers: every key finds its place by counting inside its bucket), a sketch
+    with buckets of thousands of k-mers (a mutated tandem repeat at -s 2: that workgroup takes the bitonic network) and an
+    empty one, k <= 32 and k > 32: the decoder's keys = the oracle's, sketch by sketch"""
+    rng = np.random.default_rng(707)
+    unit = synth.random_genome(rng, 57)
+    rep = synth.mutate(rng, np.tile(unit, 700), 0.01)
+    out = []
+    for (k, m, s) in [(31, 11, 2.0), (63, 15, 3.0)]:
+        gs = [synth.random_genome(rng, 30_000), rep, np.concatenate([synth.random_genome(rng, 5_000), rep[:9_000]]), synth.random_genome(rng, 12_000)]
+        payloads = [orc.sketch_fasta(synth.to_fasta(g, "g%d" % i), k, m, s)[0] for i, g in enumerate(gs)] + [orc.sketch_fasta(b">e\n", k, m, s)[0]]
+        kk, mm, d_mn, d_lo, d_hi, sk_off = ctx.sketch_decode_device(payloads)
+        total = int(sk_off[-1])
+        mn, lo = ctx.to_host(d_mn, total, np.uint32), ctx.to_host(d_lo, total, np.uint64)
+        hi = ctx.to_host(d_hi, total, np.uint64) if k > 32 else np.zeros(total, np.uint64)
+        biggest = []
+        for i, pl in enumerate(payloads):
+            _, _, w_mn, w_lo, w_hi = orc.sketch_keys(pl)
+            a, b = int(sk_off[i]), int(sk_off[i + 1])
+            assert b - a == len(w_mn) and (mn[a:b] == w_mn).all() and (lo[a:b] == w_lo).all() and (hi[a:b] == w_hi).all(), (k, i)
+            biggest.append(int(np.bincount(np.unique(w_mn, return_inverse=True)[1]).max()) if len(w_mn) else 0)
+        out.append(biggest)
+        assert biggest[1] > 256 and biggest[0] <= 256 and biggest[3] <= 256, biggest   # (both sorts ran, whatever the order the workgroups came in)
+    return out
+
+
+@pytest.mark.gpu
+def test_decode_sort_by_bucket_and_by_network_give_the_oracle_keys(ctx):
+    """k_decode_sort: counting inside the buckets (payloads as the sketcher writes them: minimizers ascend) and the bitonic
+    network (buckets of more than 256 k-mers; every sketch with SPSP_DEBUG_DECODE_SORT=network, in a process of its own)."""
+    import subprocess
+    import sys
+    _decode_sort_cases(ctx)
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\nimport supersampler_amd as sp, test_gpu\n"
+            "ctx = sp.Context(0)\ntest_gpu._decode_sort_cases(ctx)\ntest_gpu.test_gpu_sketch_decode_matches_oracle_keys(ctx)\nprint('ok')\n") % (ROOT, os.path.join(ROOT, "tests"))
+    env = dict(os.environ, SPSP_DEBUG_DECODE_SORT="network")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
 _DECODE_WALKS = r"""
 import sys, hashlib
 sys.path.insert(0, %r); sys.path.insert(0, %r)
