@@ -242,7 +242,10 @@ public:
         static const char* dbg_slots = getenv("SPSP_DEBUG_PIPE_SLOTS");         // tuning knob: batches in flight per device
         // (six: 100 x 5 Mbp on 16 threads, median of 7 calls 17.4 ms with four, 13.2 with six, 15.4 with eight -- a slot is a batch being read,
         // one on the GPU or one being built; with four the workers ran out of reads while batches sat in their GPU stage)
-        const uint32_t per_dev = dbg_slots ? (uint32_t)std::max(1, atoi(dbg_slots)) : 6u;
+        // ... for a long job.  A slot is also a context, a pinned slab and a set of device buffers that a short-lived process pays
+        // for in full: `sub_sampler` on 100 files, a fresh process each, 0.28-0.29 s with four against 0.30-0.34 with six -- so six from
+        // 32 batches on)
+        const uint32_t per_dev = dbg_slots ? (uint32_t)std::max(1, atoi(dbg_slots)) : (total / budget_ >= 32 ? 6u : 4u);
         const uint32_t n_slots = std::min<uint32_t>(std::min<uint32_t>(per_dev * (uint32_t)devices_.size(), threads_), n_);
         slots_.resize(n_slots);
         for (size_t j = 0; j < slots_.size(); ++j) {
@@ -620,17 +623,22 @@ private:
                 t1 = now_s(); ctx->stages.scan_s += t1 - t0; t0 = t1;
             }
             if (p_.flags & SPSP_SCAN_STATS) {
-                // print_stat's count of ALL super-k-mers (SubSampler.cpp:429-430,451-452) is a per-file figure: the counting
-                // pass runs over each file's records, addressed from the file's first base
-                std::vector<uint64_t> rel;
-                for (auto& f : s.files) {
-                    if (f.rc || f.n_rec == 0) continue;
-                    const uint64_t b0 = s.rec_off[f.first_rec];
-                    rel.resize((size_t)f.n_rec + 1);
-                    for (uint32_t q = 0; q <= f.n_rec; ++q) rel[q] = s.rec_off[f.first_rec + q] - b0;
-                    if ((r = ctx->seg_a.reserve(rel.size() * 8))) return r;
-                    SPSP_HIP(hipMemcpyAsync(ctx->seg_a.p, rel.data(), rel.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-                    if ((r = spsp::count_superkmers_impl(ctx, &p_, d_bases, rel[f.n_rec], ctx->seg_a.as<uint64_t>(), f.n_rec, &f.total_superkmers, packed, b0))) return r;
+                // print_stat's count of ALL super-k-mers (SubSampler.cpp:429-430,451-452) is a per-file figure.  One counting pass
+                // over the batch's records, a total per file (a launch per 5 Mbp file filled a third of the chip: 7 ms each, the
+                // largest part of a batch of six in a `sub_sampler` process); the count of a record does not depend on what lies
+                // in front of it (spsp_stats.hip: every record starts from a fresh rescan)
+                std::vector<uint32_t> frec;
+                std::vector<size_t> who;
+                for (size_t j = 0; j < s.files.size(); ++j) {
+                    if (s.files[j].rc || s.files[j].n_rec == 0) continue;
+                    frec.push_back(s.files[j].first_rec);
+                    who.push_back(j);
+                }
+                if (!who.empty()) {
+                    frec[0] = 0;                                        // (records in front of the first good file: there are none)
+                    std::vector<uint64_t> tot(who.size(), 0);
+                    if ((r = spsp::count_superkmers_impl(ctx, &p_, d_bases, n_bases, d_off, n_rec, tot.data(), packed, 0, frec.data(), (uint32_t)frec.size()))) return r;
+                    for (size_t x = 0; x < who.size(); ++x) s.files[who[x]].total_superkmers = tot[x];
                 }
                 ctx->stages.scan_s += now_s() - t0;
             }

@@ -136,7 +136,7 @@ struct spsp_ctx {
     spsp::DevBuf bases, rec_off, bitmap, tile_count, tile_off, hits, emit_count, scan_tmp, d_scalar, seg_a, seg_b;
     spsp::DevBuf wave_hits, wave_cnt;    // per-wave hit lists of the table variants of the dense pass
     spsp::DevBuf packed, unpacked;       // SPSP_SCAN_PACKED_INPUT: spsp_pack_bases_device's output; ASCII copy for the variants that need one
-    spsp::DevBuf st_count, st_open;      // print_stat counting pass (spsp_stats.hip)
+    spsp::DevBuf st_count, st_open, st_total;      // print_stat counting pass (spsp_stats.hip)
     uint64_t hits_cap = 0, out_cap = 0;  // entries the sparse-stage buffers of the call in flight are sized for (grow on overflow)
     // what the last overflow taught: hits / super-k-mers per base at that threshold (scan_begin_impl sizes the next call by it)
     bool learn_valid = false;
@@ -205,7 +205,7 @@ int pack_bases_impl(spsp_ctx* ctx, const uint8_t* d_bases, uint64_t n_bases, uin
 // every super-k-mer of the input, selected or not (spsp_stats.hip)
 // packed: d_bases holds 2-bit words (16 bases per dword); base0: first base of rec_off[0]'s record in d_bases, added to every offset
 int count_superkmers_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, uint64_t n_bases, const uint64_t* d_rec_off,
-                          uint32_t n_rec, uint64_t* total, bool packed = false, uint64_t base0 = 0);
+                          uint32_t n_rec, uint64_t* total, bool packed = false, uint64_t base0 = 0, const uint32_t* h_file_rec = nullptr, uint32_t n_files = 1);
 // bulk sketch decode (spsp_decode.hip): one stored super-k-mer of a sketch payload, as the host's structure walk finds it
 struct DecDesc {
     uint64_t off;    // byte offset in the payload (later: in the concatenated payload buffer): blob bytes (kind 0) / prefix line (kind 1)

@@ -11,6 +11,8 @@
 // over a chunk of iterations from a fresh rescan a little in front of the chunk: once it has met such an event
 // before its chunk starts, everything it counts is exact.  Chunks that meet none (period-w repeats,
 // homopolymers) are counted again in a second pass, serially from the last exact point.
+#include <vector>
+
 #include "spsp_internal.h"
 #include "spsp_device.h"
 
@@ -100,15 +102,26 @@ struct StatMachine {
     }
 };
 
+// the file of record r: the last f with file_rec[f] <= r
+__device__ __forceinline__ uint32_t stat_file_of(const uint32_t* __restrict__ file_rec, uint32_t n_files, uint32_t r) {
+    uint32_t a = 0, z = n_files;
+    while (z - a > 1) { const uint32_t mid = (a + z) >> 1; if (file_rec[mid] <= r) a = mid; else z = mid; }
+    return a;
+}
+
 // chunk c covers the global k-mer iterations [c * kStatChunk, (c + 1) * kStatChunk) of the concatenated records:
 // iteration g of record r = its k-mer g - rec_off[r] (only iterations i with i + k < len run the loop; the tail
 // super-k-mer of every record with >= 1 k-mer is one more, added by whoever handles its k-mer 0)
 __global__ __launch_bounds__(kStatThreads) void k_stat_count(const uint8_t* __restrict__ bases, bool packed, uint64_t base0, const uint64_t* __restrict__ rec_off,
                                                             uint32_t n_rec, uint32_t k, uint32_t m, uint64_t n_chunks,
                                                             uint32_t lookback, uint32_t* __restrict__ chunk_count,
-                                                            uint8_t* __restrict__ chunk_open, unsigned long long* __restrict__ total) {
+                                                            uint8_t* __restrict__ chunk_open, unsigned long long* __restrict__ total,
+                                                            const uint32_t* __restrict__ file_rec, uint32_t n_files) {
+    // file_rec (optional): first record of each of n_files files -- the records of SEVERAL files in one launch, total[f] per file
+    // (the file pipeline's batch: a launch per 5 Mbp file filled a third of the chip and was 7 ms of a 9 ms batch)
     const uint64_t c = (uint64_t)blockIdx.x * kStatThreads + threadIdx.x;
     unsigned long long mine = 0;
+    uint32_t my_file = 0;
     if (c < n_chunks) {
         const uint64_t g0 = c * kStatChunk, g1 = g0 + kStatChunk;
         uint32_t r = 0, hi = n_rec;                          // record holding position g0
@@ -134,16 +147,22 @@ __global__ __launch_bounds__(kStatThreads) void k_stat_count(const uint8_t* __re
                 for (uint64_t i = a; i < b; ++i) cnt += M.step(i, &reset);
             }
             if (first && a > 0) { first_count = cnt; first_open = open; }   // only a chunk's first piece can start inexact
+            if (file_rec) {
+                const uint32_t f = stat_file_of(file_rec, n_files, r);
+                if (f != my_file) { if (mine) atomicAdd(&total[my_file], mine); mine = 0; my_file = f; }
+            }
             mine += cnt;
             first = false;
         }
         chunk_count[c] = first_count;
         chunk_open[c] = first_open ? 1 : 0;
     }
-    // one atomic per wave
+    // one atomic per wave (several files: per wave when its lanes ended in the same file -- nearly always)
+    const uint32_t f0 = __shfl(my_file, 0);
+    if (file_rec && __any(my_file != f0)) { if (mine) atomicAdd(&total[my_file], mine); return; }
 #pragma unroll
     for (int d = 32; d; d >>= 1) mine += __shfl_xor(mine, d);
-    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(total, mine);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&total[file_rec ? f0 : 0u], mine);
 }
 
 // second pass: every RUN of consecutive open chunks (inside one record) is replayed by one lane from the exact
@@ -151,7 +170,8 @@ __global__ __launch_bounds__(kStatThreads) void k_stat_count(const uint8_t* __re
 __global__ __launch_bounds__(kStatThreads) void k_stat_fix(const uint8_t* __restrict__ bases, bool packed, uint64_t base0, const uint64_t* __restrict__ rec_off,
                                                           uint32_t n_rec, uint32_t k, uint32_t m, uint64_t n_chunks,
                                                           uint32_t lookback, const uint32_t* __restrict__ chunk_count,
-                                                          const uint8_t* __restrict__ chunk_open, unsigned long long* __restrict__ total) {
+                                                          const uint8_t* __restrict__ chunk_open, unsigned long long* __restrict__ total,
+                                                          const uint32_t* __restrict__ file_rec, uint32_t n_files) {
     const uint64_t c = (uint64_t)blockIdx.x * kStatThreads + threadIdx.x;
     if (c >= n_chunks || !chunk_open[c]) return;
     const uint64_t g0 = c * kStatChunk;
@@ -176,34 +196,42 @@ __global__ __launch_bounds__(kStatThreads) void k_stat_fix(const uint8_t* __rest
         for (uint64_t i = ca; i < cb; ++i) cnt += M.step(i, &reset);
         delta += (long long)cnt - (long long)chunk_count[cc];
     }
-    if (delta) atomicAdd(total, (unsigned long long)delta);
+    if (delta) atomicAdd(&total[file_rec ? stat_file_of(file_rec, n_files, r) : 0u], (unsigned long long)delta);
 }
 
+// h_file_rec / n_files (optional): the records are those of n_files files, file f starting with record h_file_rec[f]: total[f]
+// per file from ONE pair of launches (else n_files = 1 and `total` is one number)
 int count_superkmers_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, uint64_t n_bases, const uint64_t* d_rec_off,
-                          uint32_t n_rec, uint64_t* total, bool packed, uint64_t base0) {
-    *total = 0;
+                          uint32_t n_rec, uint64_t* total, bool packed, uint64_t base0, const uint32_t* h_file_rec, uint32_t n_files) {
+    if (!h_file_rec) n_files = 1;
+    for (uint32_t f = 0; f < n_files; ++f) total[f] = 0;
     int rc = check_params(p);
     if (rc) return rc;
-    if (n_rec == 0 || n_bases < p->k) return SPSP_OK;
+    if (n_rec == 0 || n_bases < p->k || n_files == 0) return SPSP_OK;
+    if (n_files > 1024) { set_error("too many files for one statistics pass"); return SPSP_ERR_ARG; }
     const uint64_t n_chunks = (n_bases + kStatChunk - 1) / kStatChunk;
     if (n_chunks > 0x7fffffffull * kStatThreads) { set_error("input too large for one call"); return SPSP_ERR_OVERFLOW; }
     if ((rc = ctx->st_count.reserve((size_t)n_chunks * 4))) return rc;
     if ((rc = ctx->st_open.reserve((size_t)n_chunks + 8))) return rc;
-    if ((rc = ctx->d_scalar.reserve(64))) return rc;
-    unsigned long long* d_total = reinterpret_cast<unsigned long long*>(ctx->d_scalar.as<uint8_t>() + 32);
-    SPSP_HIP(hipMemsetAsync(d_total, 0, 8, ctx->stream));
+    if ((rc = ctx->st_total.reserve((size_t)n_files * 12 + 64))) return rc;
+    unsigned long long* d_total = ctx->st_total.as<unsigned long long>();
+    uint32_t* d_file_rec = reinterpret_cast<uint32_t*>(d_total + n_files);
+    SPSP_HIP(hipMemsetAsync(d_total, 0, (size_t)n_files * 8, ctx->stream));
+    if (h_file_rec) SPSP_HIP(hipMemcpyAsync(d_file_rec, h_file_rec, (size_t)n_files * 4, hipMemcpyHostToDevice, ctx->stream));
+    const uint32_t* file_rec = h_file_rec ? d_file_rec : nullptr;
     const uint32_t w = p->k - p->m + 1;
     const uint32_t lookback = 8 * w < 64 ? 64 : 8 * w;
     const uint32_t blocks = (uint32_t)((n_chunks + kStatThreads - 1) / kStatThreads);
     hipLaunchKernelGGL(k_stat_count, dim3(blocks), dim3(kStatThreads), 0, ctx->stream, d_bases, packed, base0, d_rec_off, n_rec, p->k, p->m, n_chunks,
-                       lookback, ctx->st_count.as<uint32_t>(), ctx->st_open.as<uint8_t>(), d_total);
+                       lookback, ctx->st_count.as<uint32_t>(), ctx->st_open.as<uint8_t>(), d_total, file_rec, n_files);
     SPSP_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_stat_fix, dim3(blocks), dim3(kStatThreads), 0, ctx->stream, d_bases, packed, base0, d_rec_off, n_rec, p->k, p->m, n_chunks,
-                       lookback, ctx->st_count.as<uint32_t>(), ctx->st_open.as<uint8_t>(), d_total);
+                       lookback, ctx->st_count.as<uint32_t>(), ctx->st_open.as<uint8_t>(), d_total, file_rec, n_files);
     SPSP_HIP(hipGetLastError());
-    SPSP_HIP(hipMemcpyAsync(ctx->h_scalar + 3, d_total, 8, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<unsigned long long> back(n_files);
+    SPSP_HIP(hipMemcpyAsync(back.data(), d_total, (size_t)n_files * 8, hipMemcpyDeviceToHost, ctx->stream));
     SPSP_HIP(hipStreamSynchronize(ctx->stream));
-    *total = ctx->h_scalar[3];
+    for (uint32_t f = 0; f < n_files; ++f) total[f] = back[f];
     return SPSP_OK;
 }
 
