@@ -265,7 +265,7 @@ void spsp_destroy(spsp_ctx* c) {
     if (c->scan_done) (void)hipEventDestroy(c->scan_done);
     if (c->compare_done) (void)hipEventDestroy(c->compare_done);
     DevBuf* bufs[] = {&c->bases, &c->rec_off, &c->bitmap, &c->tile_count, &c->tile_off, &c->hits, &c->emit_count,
-                      &c->scan_tmp, &c->d_scalar, &c->seg_a, &c->seg_b, &c->wave_hits, &c->wave_cnt, &c->packed, &c->unpacked, &c->st_count, &c->st_open, &c->st_total, &c->filter, &c->bloom, &c->pairtab, &c->c_min, &c->c_lo, &c->c_hi, &c->c_table,
+                      &c->scan_tmp, &c->d_scalar, &c->seg_a, &c->seg_b, &c->wave_hits, &c->wave_cnt, &c->packed, &c->unpacked, &c->st_count, &c->st_open, &c->st_total, &c->st_over, &c->filter, &c->bloom, &c->pairtab, &c->c_min, &c->c_lo, &c->c_hi, &c->c_table,
                       &c->c_owner, &c->c_rowid, &c->c_row, &c->x_cnt, &c->x_off, &c->x_begin, &c->x_end, &c->x_tot, &c->dc_text, &c->dc_desc, &c->dc_mn, &c->dc_lo, &c->dc_hi, &c->dc_meta, &c->dc_walk, &c->bl_hist, &c->bl_keys, &c->bl_vals, &c->bl_meta, &c->bl_lo, &c->bl_hi, &c->bl_pmin, &c->bl_pb, &c->bl_slot, &c->bl_first, &c->bl_codes, &c->bl_text, &c->bl_outs, &c->bl_out, &c->a_cnt, &c->a_off, &c->a_mn, &c->a_lo, &c->a_hi, &c->a_slot, &c->a_slot_of, &c->a_flags, &c->a_seg, &c->b_mn, &c->b_lo, &c->b_hi, &c->b_table, &c->b_tiles, &c->b_seg, &c->m_send, &c->m_recv, &c->m_cells, &c->m_mn, &c->m_lo, &c->m_hi, &c->c_matrix, &c->c_inter, &c->c_flags, &c->c_slot_lo, &c->c_slot_hi, &c->c_slot_mn, &c->c_part_cnt, &c->c_recs, &c->c_where, &c->c_lref, &c->c_filter, &c->c_bits, &c->c_sig, &c->c_order, &c->c_multi, &c->scan_blocks,
                       &c->c_skoff, &c->i_text, &c->i_tiles, &c->i_entry, &c->i_outoff, &c->i_recbase, &c->i_lens, &c->i_dst,
                       &c->i_compact};

@@ -641,6 +641,7 @@ private:
                     for (size_t x = 0; x < who.size(); ++x) s.files[who[x]].total_superkmers = tot[x];
                 }
                 ctx->stages.scan_s += now_s() - t0;
+                trace(s, 'S', t0);
             }
             return SPSP_OK;
         };

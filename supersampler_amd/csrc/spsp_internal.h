@@ -136,7 +136,7 @@ struct spsp_ctx {
     spsp::DevBuf bases, rec_off, bitmap, tile_count, tile_off, hits, emit_count, scan_tmp, d_scalar, seg_a, seg_b;
     spsp::DevBuf wave_hits, wave_cnt;    // per-wave hit lists of the table variants of the dense pass
     spsp::DevBuf packed, unpacked;       // SPSP_SCAN_PACKED_INPUT: spsp_pack_bases_device's output; ASCII copy for the variants that need one
-    spsp::DevBuf st_count, st_open, st_total;      // print_stat counting pass (spsp_stats.hip)
+    spsp::DevBuf st_count, st_open, st_total, st_over;      // print_stat counting pass (spsp_stats.hip)
     uint64_t hits_cap = 0, out_cap = 0;  // entries the sparse-stage buffers of the call in flight are sized for (grow on overflow)
     // what the last overflow taught: hits / super-k-mers per base at that threshold (scan_begin_impl sizes the next call by it)
     bool learn_valid = false;

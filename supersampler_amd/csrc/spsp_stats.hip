@@ -199,6 +199,205 @@ __global__ __launch_bounds__(kStatThreads) void k_stat_fix(const uint8_t* __rest
     if (delta) atomicAdd(&total[file_rec ? stat_file_of(file_rec, n_files, r) : 0u], (unsigned long long)delta);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same count by SEGMENTS (round 5).  One lane replaying the machine position by position hashes every m-mer again at every
+// rescan, and with 64 lanes at different places of their chunks some lane of the wave is rescanning at nearly every step:
+// a 30 Mbp batch took 8 ms whatever the chunk size (the largest part of a `sub_sampler` process's GPU stage).  What the count
+// needs, taken apart:
+//   * (canon, strand, hash) of every m-mer -- once, in parallel, into LDS;
+//   * the iterations where the entering m-mer beats the window's minimum ("resets") -- data only: the tracked hash is the
+//     true minimum of the window at all times (the believed position never lies behind the minimum's rightmost place), so
+//     reset <=> hash[e] < min(hash[window]), a sliding minimum over k - m + 1 LDS words;  a reset always cuts (its m-mer
+//     differs from the one before: the hash is smaller) and leaves a state that does not depend on what came before;
+//   * between two resets the only cuts are the rescans (`dump`), at the iterations where the believed position leaves the
+//     window: i = position_min, then position_min = i + 1 + (what regular_minimizer_pos finds in k-mer i + 1) -- a chain
+//     of rescans, each 'k - m + 1 LDS reads', no stepping in between.
+// A tile is kSegIter iterations (plus a halo the chains may run into); a lane owns the resets and record starts of its
+// iterations.  A chain that leaves the halo (a long repeat: no reset for thousands of positions) is handed to k_seg_tail,
+// which walks it with the literal machine.  Same totals as k_stat_count / k_stat_fix (SPSP_DEBUG_STATS=chunks keeps them).
+constexpr int kSegIter = 2048, kSegHalo = 1024, kSegThreads = 256;
+constexpr int kSegSpan = kSegIter + kSegHalo + 64;              // m-mers held: a window of the last halo iteration ends inside
+constexpr uint32_t kSegOverCap = 1u << 20;                     // chains handed on per call (beyond: the chunk kernels do the call)
+
+// regular_minimizer_pos over LDS (see StatMachine::rescan): k-mer at tile place ks
+__device__ __forceinline__ uint32_t seg_rescan(const uint64_t* __restrict__ s_h, const uint32_t* __restrict__ s_c, uint32_t ks, uint32_t km) {
+    uint32_t c0 = s_c[ks + km];
+    uint32_t mini = c0 & 0x7fffffffu;
+    bool is_rev = (c0 >> 31) != 0;
+    uint32_t pos = is_rev ? 0u : km;
+    uint64_t hash_mini = s_h[ks + km];
+    for (uint32_t i = 1; i <= km; ++i) {
+        const uint32_t off = km - i;
+        const uint32_t c = s_c[ks + off];
+        const uint64_t h = s_h[ks + off];
+        const uint32_t canon = c & 0x7fffffffu;
+        const bool local_rev = (c >> 31) != 0;
+        if (hash_mini > h) { pos = off; mini = canon; is_rev = local_rev; hash_mini = h; }
+        else if (canon == mini && local_rev == is_rev) {
+            if (is_rev && pos > i) pos = i;
+            if (!is_rev && pos > off) pos = off;
+        }
+    }
+    return pos;
+}
+
+__global__ __launch_bounds__(kSegThreads) void k_seg_count(const uint8_t* __restrict__ bases, bool packed, uint64_t n_bases, const uint64_t* __restrict__ rec_off,
+                                                          uint32_t n_rec, uint32_t k, uint32_t m, unsigned long long* __restrict__ total,
+                                                          const uint32_t* __restrict__ file_rec, uint32_t n_files,
+                                                          unsigned long long* __restrict__ over, uint32_t* __restrict__ over_n) {
+    __shared__ uint64_t s_h[kSegSpan];
+    __shared__ uint32_t s_c[kSegSpan];                          // canon | strand << 31
+    __shared__ uint32_t s_d[kSegSpan];                          // iterations from this place to the end of its record's loop (0: not an iteration) | record start << 31
+    __shared__ unsigned long long s_flag[(kSegIter + kSegHalo) / 64];
+    const uint32_t t = threadIdx.x, lane = t & 63u, km = k - m, mask = (1u << (2 * m)) - 1u;
+    const uint64_t T0 = (uint64_t)blockIdx.x * kSegIter;
+    // ---- every m-mer of the span once: a lane takes consecutive places (one search for its record, the m-mer rolls)
+    {
+        constexpr uint32_t PER = (kSegSpan + kSegThreads - 1) / kSegThreads;
+        const uint32_t p0 = t * PER, p1 = p0 + PER < (uint32_t)kSegSpan ? p0 + PER : (uint32_t)kSegSpan;
+        uint64_t g = T0 + p0;
+        uint32_t r = 0;
+        if (p0 < p1 && g < n_bases) {
+            uint32_t hi = n_rec;
+            while (hi - r > 1) { const uint32_t mid = (r + hi) >> 1; if (rec_off[mid] <= g) r = mid; else hi = mid; }
+        }
+        uint64_t r0 = rec_off[r], r1 = rec_off[r + 1];
+        StatMachine B;                                          // (for its base reader only)
+        B.bind(bases, packed, 0);
+        uint32_t f = 0, filled = 0;                             // the m-mer ending at the last base read; bases of it that are of this record
+        for (uint32_t p = p0; p < p1; ++p, ++g) {
+            uint64_t h = ~0ull; uint32_t c = 0, d = 0;
+            if (g < n_bases) {
+                while (g >= r1 && r + 1 < n_rec) { ++r; r0 = r1; r1 = rec_off[r + 1]; filled = 0; }
+                const uint64_t len = r1 - r0;
+                if (g + m <= r1) {                              // an m-mer of the record starts here
+                    if (filled == 0) { for (uint32_t j = 0; j < m; ++j) f = ((f << 2) | B.code(g + j)) & mask; filled = 1; }
+                    else f = ((f << 2) | B.code(g + m - 1)) & mask;
+                    const uint32_t rc = rc_mmer32(f, m), canon = f < rc ? f : rc;
+                    c = canon | (canon != f ? 0x80000000u : 0u);
+                    h = xxh64_u64(canon);
+                } else filled = 0;
+                if (len >= k) {
+                    const uint64_t n_iter = len - k, i = g - r0;
+                    if (i < n_iter) d = (uint32_t)(n_iter - i < 0x7fffffffull ? n_iter - i : 0x7fffffffull);
+                    if (i == 0) d |= 0x80000000u;
+                }
+            }
+            s_h[p] = h; s_c[p] = c; s_d[p] = d;
+        }
+    }
+    __syncthreads();
+    // ---- resets: the entering m-mer (place p + km + 1) beats the window [p, p + km]
+    for (uint32_t q = 0; q < (uint32_t)(kSegIter + kSegHalo); q += kSegThreads) {
+        const uint32_t p = q + t;
+        bool reset = false;
+        if ((s_d[p] & 0x7fffffffu) != 0) {
+            uint64_t mn = s_h[p];
+            for (uint32_t j = 1; j <= km; ++j) { const uint64_t h = s_h[p + j]; mn = h < mn ? h : mn; }
+            reset = s_h[p + km + 1] < mn;
+        }
+        const unsigned long long b = __ballot(reset);
+        if (lane == 0) s_flag[p >> 6] = b;
+    }
+    __syncthreads();
+    // ---- the chains
+    unsigned long long mine = 0;
+    uint32_t my_file = 0xffffffffu;
+    constexpr uint32_t LIMIT = kSegIter + kSegHalo;
+    auto next_reset = [&](uint32_t from, uint32_t end) -> uint32_t {     // first reset in [from, end), or end; end <= LIMIT
+        uint32_t p = from;
+        while (p < end) {
+            unsigned long long w = s_flag[p >> 6] >> (p & 63u);
+            if (w) { const uint32_t x = p + (uint32_t)__ffsll((long long)w) - 1u; return x < end ? x : end; }
+            p = (p | 63u) + 1u;
+        }
+        return end;
+    };
+    for (uint32_t q = 0; q < (uint32_t)kSegIter; q += kSegThreads) {
+        const uint32_t p = q + t;
+        const uint32_t d = s_d[p];
+        const bool is_start = (d >> 31) != 0, is_reset = (s_flag[p >> 6] >> (p & 63u)) & 1ull;
+        if (!is_start && !is_reset) continue;
+        const uint32_t left = d & 0x7fffffffu;                  // iterations p .. p + left - 1 exist
+        uint32_t cnt = 0;
+#pragma unroll 1
+        for (int kind = 0; kind < 2; ++kind) {                  // 0: the record's start (state of a rescan of k-mer 0), 1: a reset at p
+            if (kind == 0 ? !is_start : !is_reset) continue;
+            cnt += 1;                                           // the record's tail super-k-mer / the reset's cut
+            uint32_t P = kind == 0 ? p + seg_rescan(s_h, s_c, p, km) : p + km + 1;
+            const uint32_t from = kind == 0 ? p : p + 1;
+            const uint64_t end64 = (uint64_t)p + left;
+            const uint32_t end = end64 < LIMIT ? (uint32_t)end64 : LIMIT;
+            uint32_t R = from < end ? next_reset(from, end) : end;
+            bool unknown = R == end && end64 > LIMIT;           // no reset up to the halo's end: where the chain stops is not known here
+            uint32_t add = 0;
+            while (!unknown && P < R) {
+                P = P + 1 + seg_rescan(s_h, s_c, P + 1, km);
+                ++add;
+            }
+            if (unknown) {
+                const uint32_t at = atomicAdd(over_n, 1u);
+                if (at < kSegOverCap) over[at] = ((T0 + p) << 1) | (unsigned long long)kind;
+                add = 0;                                        // (k_seg_tail counts the whole chain)
+            }
+            cnt += add;
+        }
+        if (file_rec) {
+            // the record of place p: the search again (only lanes with an event come here)
+            uint32_t r = 0, hi = n_rec;
+            const uint64_t g = T0 + p;
+            while (hi - r > 1) { const uint32_t mid = (r + hi) >> 1; if (rec_off[mid] <= g) r = mid; else hi = mid; }
+            const uint32_t fl = stat_file_of(file_rec, n_files, r);
+            if (fl != my_file) { if (mine) atomicAdd(&total[my_file], mine); mine = 0; my_file = fl; }
+        }
+        mine += cnt;
+    }
+    // one atomic per wave (several files: when the lanes that counted anything counted for the same file -- nearly always; an
+    // atomic per lane on the handful of totals was 12 of this kernel's 20 ms)
+    uint32_t f_wave = 0;
+    if (file_rec) {
+        const unsigned long long have = __ballot(mine != 0);
+        if (!have) return;
+        f_wave = __shfl(my_file, __ffsll((long long)have) - 1);
+        if (__any(mine != 0 && my_file != f_wave)) { if (mine) atomicAdd(&total[my_file], mine); return; }
+    }
+#pragma unroll
+    for (int dd = 32; dd; dd >>= 1) mine += __shfl_xor(mine, dd);
+    if (lane == 0 && mine) atomicAdd(&total[f_wave], mine);
+}
+
+// chains that left their tile's halo: the literal machine from the chain's first state to the next reset (or the record's end)
+__global__ __launch_bounds__(64) void k_seg_tail(const uint8_t* __restrict__ bases, bool packed, const uint64_t* __restrict__ rec_off, uint32_t n_rec,
+                                                uint32_t k, uint32_t m, unsigned long long* __restrict__ total, const uint32_t* __restrict__ file_rec,
+                                                uint32_t n_files, const unsigned long long* __restrict__ over, const uint32_t* __restrict__ over_n) {
+    const uint32_t x = blockIdx.x * 64 + threadIdx.x;
+    const uint32_t n = *over_n < kSegOverCap ? *over_n : kSegOverCap;
+    if (x >= n) return;
+    const unsigned long long e = over[x];
+    const uint64_t g = e >> 1;
+    const bool at_reset = (e & 1ull) != 0;
+    uint32_t r = 0, hi = n_rec;
+    while (hi - r > 1) { const uint32_t mid = (r + hi) >> 1; if (rec_off[mid] <= g) r = mid; else hi = mid; }
+    const uint64_t r0 = rec_off[r], len = rec_off[r + 1] - r0, n_iter = len - k;
+    StatMachine M;
+    M.bind(bases, packed, r0); M.len = len; M.k = k; M.m = m; M.mask = (1u << (2 * m)) - 1u;
+    uint64_t i = g - r0;
+    bool reset = false;
+    if (at_reset) {
+        M.start(i + 1);                                       // (sets the rolling m-mer registers to k-mer i + 1's last m-mer ...)
+        const uint32_t canon = M.min_seq < M.min_rc ? M.min_seq : M.min_rc;
+        M.minimizer = canon; M.old_minimizer = canon; M.hash_min = xxh64_u64(canon); M.position_min = i + k - m + 1;   // ... which is the reset's m-mer
+        ++i;
+    } else M.start(0);
+    unsigned long long cnt = 0;
+    for (; i < n_iter; ++i) {
+        const uint32_t c = M.step(i, &reset);
+        if (reset) break;                                     // (its cut belongs to the reset's own chain)
+        cnt += c;
+    }
+    if (cnt) atomicAdd(&total[file_rec ? stat_file_of(file_rec, n_files, r) : 0u], cnt);
+}
+
 // h_file_rec / n_files (optional): the records are those of n_files files, file f starting with record h_file_rec[f]: total[f]
 // per file from ONE pair of launches (else n_files = 1 and `total` is one number)
 int count_superkmers_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, uint64_t n_bases, const uint64_t* d_rec_off,
@@ -219,6 +418,30 @@ int count_superkmers_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_
     SPSP_HIP(hipMemsetAsync(d_total, 0, (size_t)n_files * 8, ctx->stream));
     if (h_file_rec) SPSP_HIP(hipMemcpyAsync(d_file_rec, h_file_rec, (size_t)n_files * 4, hipMemcpyHostToDevice, ctx->stream));
     const uint32_t* file_rec = h_file_rec ? d_file_rec : nullptr;
+    static const char* dbg_stats = getenv("SPSP_DEBUG_STATS");      // "chunks": the chunk kernels for every call (A/B, tests)
+    const uint64_t n_tiles = (n_bases + kSegIter - 1) / kSegIter;
+    if (!(dbg_stats && dbg_stats[0] == 'c') && base0 == 0 && n_tiles < 0x7fffffffull) {
+        if ((rc = ctx->st_over.reserve((size_t)kSegOverCap * 8 + 64))) return rc;
+        unsigned long long* d_over = ctx->st_over.as<unsigned long long>() + 1;
+        uint32_t* d_over_n = ctx->st_over.as<uint32_t>();
+        SPSP_HIP(hipMemsetAsync(d_over_n, 0, 8, ctx->stream));
+        hipLaunchKernelGGL(k_seg_count, dim3((uint32_t)n_tiles), dim3(kSegThreads), 0, ctx->stream, d_bases, packed, n_bases, d_rec_off, n_rec, p->k, p->m,
+                           d_total, file_rec, n_files, d_over, d_over_n);
+        SPSP_HIP(hipGetLastError());
+        // the chains that left their tile (long repeats): as many lanes as there can be -- the kernel reads the count
+        hipLaunchKernelGGL(k_seg_tail, dim3(kSegOverCap / 64 / 64), dim3(64), 0, ctx->stream, d_bases, packed, d_rec_off, n_rec, p->k, p->m, d_total, file_rec, n_files,
+                           (const unsigned long long*)d_over, (const uint32_t*)d_over_n);
+        SPSP_HIP(hipGetLastError());
+        std::vector<unsigned long long> back(n_files);
+        SPSP_HIP(hipMemcpyAsync(back.data(), d_total, (size_t)n_files * 8, hipMemcpyDeviceToHost, ctx->stream));
+        SPSP_HIP(hipMemcpyAsync(ctx->h_scalar + 3, d_over_n, 4, hipMemcpyDeviceToHost, ctx->stream));
+        SPSP_HIP(hipStreamSynchronize(ctx->stream));
+        if ((uint32_t)ctx->h_scalar[3] <= kSegOverCap / 64) {    // (every chain handed on had its lane)
+            for (uint32_t f = 0; f < n_files; ++f) total[f] = back[f];
+            return SPSP_OK;
+        }
+        SPSP_HIP(hipMemsetAsync(d_total, 0, (size_t)n_files * 8, ctx->stream));   // more long chains than lanes: the chunk kernels, from zero
+    }
     const uint32_t w = p->k - p->m + 1;
     const uint32_t lookback = 8 * w < 64 ? 64 : 8 * w;
     const uint32_t blocks = (uint32_t)((n_chunks + kStatThreads - 1) / kStatThreads);
