@@ -418,7 +418,7 @@ int count_superkmers_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_
     SPSP_HIP(hipMemsetAsync(d_total, 0, (size_t)n_files * 8, ctx->stream));
     if (h_file_rec) SPSP_HIP(hipMemcpyAsync(d_file_rec, h_file_rec, (size_t)n_files * 4, hipMemcpyHostToDevice, ctx->stream));
     const uint32_t* file_rec = h_file_rec ? d_file_rec : nullptr;
-    static const char* dbg_stats = getenv("SPSP_DEBUG_STATS");      // "chunks": the chunk kernels for every call (A/B, tests)
+    static const char* dbg_stats = getenv("SPSP_DEBUG_STATS");      // "chunks": the chunk kernels for every call (A/B, tests); "tiny": see below
     const uint64_t n_tiles = (n_bases + kSegIter - 1) / kSegIter;
     if (!(dbg_stats && dbg_stats[0] == 'c') && base0 == 0 && n_tiles < 0x7fffffffull) {
         if ((rc = ctx->st_over.reserve((size_t)kSegOverCap * 8 + 64))) return rc;
@@ -436,7 +436,8 @@ int count_superkmers_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_
         SPSP_HIP(hipMemcpyAsync(back.data(), d_total, (size_t)n_files * 8, hipMemcpyDeviceToHost, ctx->stream));
         SPSP_HIP(hipMemcpyAsync(ctx->h_scalar + 3, d_over_n, 4, hipMemcpyDeviceToHost, ctx->stream));
         SPSP_HIP(hipStreamSynchronize(ctx->stream));
-        if ((uint32_t)ctx->h_scalar[3] <= kSegOverCap / 64) {    // (every chain handed on had its lane)
+        const uint32_t tail_lanes = dbg_stats && dbg_stats[0] == 't' ? 1u : kSegOverCap / 64;   // ("tiny": the hand-over to the chunk kernels, for tests)
+        if ((uint32_t)ctx->h_scalar[3] <= tail_lanes) {          // (every chain handed on had its lane)
             for (uint32_t f = 0; f < n_files; ++f) total[f] = back[f];
             return SPSP_OK;
         }

@@ -382,6 +382,19 @@ def test_count_all_superkmers_matches_oracle(ctx):
     assert ctx.count_superkmers_device(p, d_b2.data_ptr(), len(b2), d_o2.data_ptr(), 1) == st["total_superkmer_number"]
 
 
+@pytest.mark.gpu
+def test_count_all_superkmers_chunk_replay_form_matches_oracle():
+    """the statistics pass's first form (one lane replays a chunk of 512 iterations; SPSP_DEBUG_STATS=chunks, and the
+    fallback of the segment form when thousands of chains leave their tiles) on the same records, in a process of its own"""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\nimport supersampler_amd as sp, test_gpu\n"
+            "ctx = sp.Context(0)\ntest_gpu.test_count_all_superkmers_matches_oracle(ctx)\nprint('ok')\n") % (ROOT, os.path.join(ROOT, "tests"))
+    for form in ("chunks", "tiny"):          # tiny: the segment form hands a call over when more than ONE chain leaves its tile
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, SPSP_DEBUG_STATS=form), timeout=600)
+        assert r.returncode == 0 and "ok" in r.stdout, (form, r.stderr[-2000:])
+
+
 def test_cli_default_verbose_stdout_matches_reference_lines(tmp_path):
     """-v 1 (the default): print_stat's lines (SubSampler.cpp:633-665) with the numbers of the oracle, in the
     reference's wording and order, and the comparator's progress lines (Comparator.cpp:56,69,364,414,494,498,503,509)."""
