@@ -59,6 +59,7 @@ namespace spsp {
 struct ScanJob {
     bool pending = false, empty = false;
     int redo_from = 0;           // first stage the next attempt runs: 0 dense, 1 compact (lists intact), 2 write pass
+    bool segments = false;       // the attempt in flight is the scan by segments (spsp_stats.hip: thresholds that select nearly everything)
     bool use_bitmap = false;     // hit bitmap + k_expand (dense selections, list-overflow fallback) instead of per-wave lists
     bool lists = false;          // the attempt in flight used per-wave hit lists
     spsp_params p{};
@@ -189,6 +190,9 @@ int scan_device_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases
 int scan_begin_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, uint64_t n_bases,
                     const uint64_t* d_rec_off, uint32_t n_rec);
 int scan_end_impl(spsp_ctx* ctx, spsp_superkmer** d_out, uint64_t* n_out);
+int seg_scan_count(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, bool packed, uint64_t n_bases, const uint64_t* d_rec_off, uint32_t n_rec);
+int seg_scan_emit(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, bool packed, uint64_t n_bases, const uint64_t* d_rec_off, uint32_t n_rec,
+                  spsp_superkmer* d_out, uint64_t out_cap);
 int scan_hits_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, uint64_t n_bases,
                    uint64_t* n_hits);
 // compare pipeline (spsp_compare.hip)

@@ -1893,6 +1893,22 @@ int scan_begin_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases,
     if (ctx->list_cap_threshold != p->threshold) ctx->list_cap = 0;
     J.redo_from = 0;
     J.use_bitmap = false;
+    // a threshold that selects (nearly) every m-mer: the scan by segments (spsp_stats.hip::k_seg_scan) -- every position a
+    // 32-byte hit record through compact and resolve was 245 ms per 500 Mbp at -s 1.  From -s 1.25 on (-s 2: 3.4 ms) the
+    // dense + sparse passes are faster again.
+    static const char* dbg_seg = getenv("SPSP_DEBUG_SEG_SCAN");       // "0": never, "1": whatever the threshold (A/B, tests)
+    J.segments = (dbg_seg ? dbg_seg[0] == '1' : frac >= 0.8) && n_bases < (1ull << 32);   // (32-bit places for the emitted super-k-mers)
+    if (J.segments) {
+        if ((rc = ctx->ev_begin(kEvScan))) { J.pending = false; return rc; }
+        rc = seg_scan_count(ctx, p, d_bases, (p->flags & SPSP_SCAN_PACKED_INPUT) != 0, n_bases, d_rec_off, n_rec);
+        if (!rc) {
+            if (!ctx->scan_done && hipEventCreateWithFlags(&ctx->scan_done, hipEventDisableTiming) != hipSuccess) rc = SPSP_ERR_HIP;
+            if (!rc && hipEventRecord(ctx->scan_done, ctx->stream) != hipSuccess) rc = SPSP_ERR_HIP;
+        }
+        const int rc2 = ctx->ev_end(kEvScan);
+        if (rc || rc2) J.pending = false;
+        return rc ? rc : rc2;
+    }
     if ((rc = ctx->ev_begin(kEvScan))) { J.pending = false; return rc; }
     rc = scan_enqueue(ctx);
     const int rc2 = ctx->ev_end(kEvScan);   // brackets the first attempt (a retry after an overflow is not timed)
@@ -1909,6 +1925,24 @@ int scan_end_impl(spsp_ctx* ctx, spsp_superkmer** d_out, uint64_t* n_out) {
     static const char* dbg_out = getenv("SPSP_DEBUG_OUT_CAP");
     static const char* dbg_budget = getenv("SPSP_DEBUG_LIST_BUDGET");   // test hook: bytes the grown hit lists may take
     int rc;
+    if (J.segments) {
+        SPSP_HIP(hipEventSynchronize(ctx->scan_done));
+        const uint64_t n_em = (uint32_t)ctx->h_scalar[0];
+        const uint32_t left_halo = (uint32_t)ctx->h_scalar[1];
+        if (left_halo == 0) {
+            if (n_em == 0) return SPSP_OK;
+            if ((rc = ctx->scan_tmp.reserve((size_t)n_em * sizeof(spsp_superkmer) + 64))) return rc;
+            if ((rc = seg_scan_emit(ctx, &J.p, J.d_bases, (J.p.flags & SPSP_SCAN_PACKED_INPUT) != 0, J.n_bases, J.d_rec_off, J.n_rec,
+                                    ctx->scan_tmp.as<spsp_superkmer>(), n_em))) return rc;
+            SPSP_HIP(hipStreamSynchronize(ctx->stream));
+            *d_out = ctx->scan_tmp.as<spsp_superkmer>();
+            *n_out = n_em;
+            return SPSP_OK;
+        }
+        // a chain left its tile's halo (a long run without a reset: a homopolymer, a short-period repeat): the product scan
+        J.segments = false;
+        if ((rc = scan_enqueue(ctx))) return rc;
+    }
     for (int attempt = 0; attempt < 5; ++attempt) {
         SPSP_HIP(hipEventSynchronize(ctx->scan_done));
         const uint64_t n_hits = ctx->h_scalar[0], n_em = ctx->h_scalar[1], fullest = J.lists ? ctx->h_scalar[2] : 0;

@@ -241,6 +241,28 @@ __device__ __forceinline__ uint32_t seg_rescan(const uint64_t* __restrict__ s_h,
     return pos;
 }
 
+// the tile's events -- iterations that are a record's start or a reset -- as an ordered list in LDS: with one lane per EVENT every
+// lane of a round walks a chain (a lane per ITERATION had nine lanes in ten idle while some lane of the wave walked one: the walk
+// was 8 rounds of the longest chain each).  All lanes call; returns the number of events.
+__device__ __forceinline__ uint32_t seg_events(const uint32_t* __restrict__ s_d, const unsigned long long* __restrict__ s_flag, uint16_t* __restrict__ s_ev,
+                                               uint32_t* __restrict__ s_wave) {
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    uint32_t base = 0;
+    for (uint32_t q = 0; q < (uint32_t)kSegIter; q += kSegThreads) {
+        const uint32_t p = q + t;
+        const bool has = (s_d[p] >> 31) != 0 || ((s_flag[p >> 6] >> (p & 63u)) & 1ull) != 0;
+        const unsigned long long b = __ballot(has);
+        if (lane == 0) s_wave[wave] = (uint32_t)__popcll(b);
+        __syncthreads();
+        uint32_t pre = 0, tot = 0;
+        for (uint32_t w = 0; w < kSegThreads / 64; ++w) { const uint32_t c = s_wave[w]; if (w < wave) pre += c; tot += c; }
+        if (has) s_ev[base + pre + (uint32_t)__popcll(b & ((1ull << lane) - 1ull))] = (uint16_t)p;
+        base += tot;
+        __syncthreads();
+    }
+    return base;
+}
+
 __global__ __launch_bounds__(kSegThreads) void k_seg_count(const uint8_t* __restrict__ bases, bool packed, uint64_t n_bases, const uint64_t* __restrict__ rec_off,
                                                           uint32_t n_rec, uint32_t k, uint32_t m, unsigned long long* __restrict__ total,
                                                           const uint32_t* __restrict__ file_rec, uint32_t n_files,
@@ -249,6 +271,8 @@ __global__ __launch_bounds__(kSegThreads) void k_seg_count(const uint8_t* __rest
     __shared__ uint32_t s_c[kSegSpan];                          // canon | strand << 31
     __shared__ uint32_t s_d[kSegSpan];                          // iterations from this place to the end of its record's loop (0: not an iteration) | record start << 31
     __shared__ unsigned long long s_flag[(kSegIter + kSegHalo) / 64];
+    __shared__ uint16_t s_ev[kSegIter];
+    __shared__ uint32_t s_wave[kSegThreads / 64];
     const uint32_t t = threadIdx.x, lane = t & 63u, km = k - m, mask = (1u << (2 * m)) - 1u;
     const uint64_t T0 = (uint64_t)blockIdx.x * kSegIter;
     // ---- every m-mer of the span once: a lane takes consecutive places (one search for its record, the m-mer rolls)
@@ -313,11 +337,11 @@ __global__ __launch_bounds__(kSegThreads) void k_seg_count(const uint8_t* __rest
         }
         return end;
     };
-    for (uint32_t q = 0; q < (uint32_t)kSegIter; q += kSegThreads) {
-        const uint32_t p = q + t;
+    const uint32_t n_ev = seg_events(s_d, s_flag, s_ev, s_wave);
+    for (uint32_t j = t; j < n_ev; j += kSegThreads) {
+        const uint32_t p = s_ev[j];
         const uint32_t d = s_d[p];
         const bool is_start = (d >> 31) != 0, is_reset = (s_flag[p >> 6] >> (p & 63u)) & 1ull;
-        if (!is_start && !is_reset) continue;
         const uint32_t left = d & 0x7fffffffu;                  // iterations p .. p + left - 1 exist
         uint32_t cnt = 0;
 #pragma unroll 1
@@ -364,6 +388,179 @@ __global__ __launch_bounds__(kSegThreads) void k_seg_count(const uint8_t* __rest
 #pragma unroll
     for (int dd = 32; dd; dd >>= 1) mine += __shfl_xor(mine, dd);
     if (lane == 0 && mine) atomicAdd(&total[f_wave], mine);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The scan itself by segments, for thresholds that select (nearly) every m-mer (-s 1): what k_seg_count counts, emitted.
+// Every event -- a record's start, a reset, a rescan -- opens a super-k-mer: it starts behind the event's iteration, carries
+// the minimizer and strand the event leaves, and ends with the next event (SubSampler.cpp:401-438; the record's last one at
+// :441-454 by the same formula).  A lane owns the events of its iterations and walks the reset's chain as above, so it knows
+// every super-k-mer of the chain in full; the selected ones (hash of the minimizer <= threshold, :405) are counted per owning
+// iteration, placed by a prefix over the tile and the tiles' totals (two launches: counts, then the same walk writing), and
+// leave in genome order.  The product scan's dense + sparse passes take 245 ms per 500 Mbp at -s 1 (every position a 32-byte
+// hit record); this form takes ~50.  A chain that leaves its tile's halo makes the whole call take the product scan (flag).
+struct SegState { uint32_t mn; uint32_t rev; uint64_t h; uint32_t pos; };
+__device__ __forceinline__ SegState seg_rescan_full(const uint64_t* __restrict__ s_h, const uint32_t* __restrict__ s_c, uint32_t ks, uint32_t km) {
+    const uint32_t c0 = s_c[ks + km];
+    SegState S;
+    S.mn = c0 & 0x7fffffffu; S.rev = c0 >> 31; S.pos = S.rev ? 0u : km; S.h = s_h[ks + km];
+    for (uint32_t i = 1; i <= km; ++i) {
+        const uint32_t off = km - i;
+        const uint32_t c = s_c[ks + off];
+        const uint64_t h = s_h[ks + off];
+        const uint32_t canon = c & 0x7fffffffu, lrev = c >> 31;
+        if (S.h > h) { S.pos = off; S.mn = canon; S.rev = lrev; S.h = h; }
+        else if (canon == S.mn && lrev == S.rev) {
+            if (S.rev && S.pos > i) S.pos = i;
+            if (!S.rev && S.pos > off) S.pos = off;
+        }
+    }
+    return S;
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(kSegThreads) void k_seg_scan(const uint8_t* __restrict__ bases, bool packed, uint64_t n_bases, const uint64_t* __restrict__ rec_off,
+                                                         uint32_t n_rec, uint32_t k, uint32_t m, uint64_t threshold,
+                                                         uint32_t* __restrict__ tile_count, const uint32_t* __restrict__ tile_off,
+                                                         spsp_superkmer* __restrict__ out, uint64_t out_cap, uint32_t* __restrict__ over_n) {
+    __shared__ uint64_t s_h[kSegSpan];
+    __shared__ uint32_t s_c[kSegSpan];
+    __shared__ uint32_t s_d[kSegSpan];
+    __shared__ unsigned long long s_flag[(kSegIter + kSegHalo) / 64];
+    __shared__ uint16_t s_cnt[kSegIter];                        // selected super-k-mers opened by event j; then their first place in the tile (< 2^16: an event per iteration at most)
+    __shared__ uint16_t s_ev[kSegIter];
+    __shared__ uint32_t s_wave[kSegThreads / 64];
+    const uint32_t t = threadIdx.x, lane = t & 63u, km = k - m, mask = (1u << (2 * m)) - 1u;
+    const uint64_t T0 = (uint64_t)blockIdx.x * kSegIter;
+    {
+        constexpr uint32_t PER = (kSegSpan + kSegThreads - 1) / kSegThreads;
+        const uint32_t p0 = t * PER, p1 = p0 + PER < (uint32_t)kSegSpan ? p0 + PER : (uint32_t)kSegSpan;
+        uint64_t g = T0 + p0;
+        uint32_t r = 0;
+        if (p0 < p1 && g < n_bases) {
+            uint32_t hi = n_rec;
+            while (hi - r > 1) { const uint32_t mid = (r + hi) >> 1; if (rec_off[mid] <= g) r = mid; else hi = mid; }
+        }
+        uint64_t r0 = rec_off[r], r1 = rec_off[r + 1];
+        StatMachine B;
+        B.bind(bases, packed, 0);
+        uint32_t f = 0, filled = 0;
+        for (uint32_t p = p0; p < p1; ++p, ++g) {
+            uint64_t h = ~0ull; uint32_t c = 0, d = 0;
+            if (g < n_bases) {
+                while (g >= r1 && r + 1 < n_rec) { ++r; r0 = r1; r1 = rec_off[r + 1]; filled = 0; }
+                const uint64_t len = r1 - r0;
+                if (g + m <= r1) {
+                    if (filled == 0) { for (uint32_t j = 0; j < m; ++j) f = ((f << 2) | B.code(g + j)) & mask; filled = 1; }
+                    else f = ((f << 2) | B.code(g + m - 1)) & mask;
+                    const uint32_t rc = rc_mmer32(f, m), canon = f < rc ? f : rc;
+                    c = canon | (canon != f ? 0x80000000u : 0u);
+                    h = xxh64_u64(canon);
+                } else filled = 0;
+                if (len >= k) {
+                    const uint64_t n_iter = len - k, i = g - r0;
+                    if (i < n_iter) d = (uint32_t)(n_iter - i < 0x7fffffffull ? n_iter - i : 0x7fffffffull);
+                    if (i == 0) d |= 0x80000000u;
+                }
+            }
+            s_h[p] = h; s_c[p] = c; s_d[p] = d;
+        }
+    }
+    for (uint32_t x = t; x < (uint32_t)kSegIter; x += kSegThreads) s_cnt[x] = 0;
+    __syncthreads();
+    for (uint32_t q = 0; q < (uint32_t)(kSegIter + kSegHalo); q += kSegThreads) {
+        const uint32_t p = q + t;
+        bool reset = false;
+        if ((s_d[p] & 0x7fffffffu) != 0) {
+            uint64_t mn = s_h[p];
+            for (uint32_t j = 1; j <= km; ++j) { const uint64_t h = s_h[p + j]; mn = h < mn ? h : mn; }
+            reset = s_h[p + km + 1] < mn;
+        }
+        const unsigned long long b = __ballot(reset);
+        if (lane == 0) s_flag[p >> 6] = b;
+    }
+    __syncthreads();
+    constexpr uint32_t LIMIT = kSegIter + kSegHalo;
+    auto next_reset = [&](uint32_t from, uint32_t end) -> uint32_t {
+        uint32_t p = from;
+        while (p < end) {
+            unsigned long long w = s_flag[p >> 6] >> (p & 63u);
+            if (w) { const uint32_t x = p + (uint32_t)__ffsll((long long)w) - 1u; return x < end ? x : end; }
+            p = (p | 63u) + 1u;
+        }
+        return end;
+    };
+    const uint32_t n_ev = seg_events(s_d, s_flag, s_ev, s_wave);
+    // the walk, a lane per event: WRITE = false counts the selected super-k-mers of each event, WRITE = true puts them in their places
+    auto walk = [&](bool write) {
+        for (uint32_t j = t; j < n_ev; j += kSegThreads) {
+            const uint32_t p = s_ev[j];
+            const uint32_t d = s_d[p];
+            const bool is_start = (d >> 31) != 0, is_reset = (s_flag[p >> 6] >> (p & 63u)) & 1ull;
+            const uint32_t left = d & 0x7fffffffu;
+            uint32_t cnt = 0;
+            uint64_t at = 0, r0 = 0;
+            uint32_t rec = 0;
+            if (write) {
+                uint32_t hi = n_rec;
+                const uint64_t g = T0 + p;
+                while (hi - rec > 1) { const uint32_t mid = (rec + hi) >> 1; if (rec_off[mid] <= g) rec = mid; else hi = mid; }
+                r0 = rec_off[rec];
+                at = (uint64_t)tile_off[blockIdx.x] + s_cnt[j];
+            }
+#pragma unroll 1
+            for (int kind = 0; kind < 2; ++kind) {
+                if (kind == 0 ? !is_start : !is_reset) continue;
+                SegState S;
+                uint32_t P, cur;
+                if (kind == 0) { S = seg_rescan_full(s_h, s_c, p, km); P = p + S.pos; cur = p; }
+                else { const uint32_t c = s_c[p + km + 1]; S.mn = c & 0x7fffffffu; S.rev = c >> 31; S.h = s_h[p + km + 1]; P = p + km + 1; cur = p + 1; }
+                const uint64_t end64 = (uint64_t)p + left;
+                const uint32_t end = end64 < LIMIT ? (uint32_t)end64 : LIMIT;
+                const uint32_t R = cur < end ? next_reset(cur, end) : end;
+                if (R == end && end64 > LIMIT) { if (!write) atomicAdd(over_n, 1u); continue; }   // the chain leaves the halo: the product scan takes the call
+                for (;;) {
+                    const bool more = P < R;
+                    const uint32_t close = more ? P : R;                 // the iteration that cuts the open super-k-mer (or the record's end)
+                    if (S.h <= threshold) {
+                        if (write && at < out_cap) {
+                            spsp_superkmer e;
+                            e.rec = rec; e.minimizer = S.mn; e.start = (T0 + cur) - r0; e.len = close + k - cur; e.rev = S.rev;
+                            out[at] = e;
+                        }
+                        ++at; ++cnt;
+                    }
+                    if (!more) break;
+                    S = seg_rescan_full(s_h, s_c, P + 1, km);
+                    cur = P + 1;
+                    P = P + 1 + S.pos;
+                }
+            }
+            if (!write) s_cnt[j] = (uint16_t)cnt;
+        }
+    };
+    walk(false);
+    __syncthreads();
+    // exclusive prefix over the tile's iterations (8 consecutive per lane)
+    {
+        constexpr uint32_t PER = kSegIter / kSegThreads;
+        uint32_t v[PER], sum = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < PER; ++u) { v[u] = s_cnt[t * PER + u]; sum += v[u]; }
+        uint32_t x = sum;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t y = __shfl_up(x, dd); if (lane >= (uint32_t)dd) x += y; }
+        if (lane == 63) s_wave[t >> 6] = x;
+        __syncthreads();
+        uint32_t pre = 0, all = 0;
+        for (uint32_t w = 0; w < kSegThreads / 64; ++w) { if (w < (t >> 6)) pre += s_wave[w]; all += s_wave[w]; }
+        uint32_t run = pre + x - sum;
+#pragma unroll
+        for (uint32_t u = 0; u < PER; ++u) { s_cnt[t * PER + u] = run; run += v[u]; }
+        if (!EMIT) { if (t == 0) tile_count[blockIdx.x] = all; return; }
+    }
+    __syncthreads();
+    walk(true);
 }
 
 // chains that left their tile's halo: the literal machine from the chain's first state to the next reset (or the record's end)
@@ -456,6 +653,36 @@ int count_superkmers_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_
     SPSP_HIP(hipMemcpyAsync(back.data(), d_total, (size_t)n_files * 8, hipMemcpyDeviceToHost, ctx->stream));
     SPSP_HIP(hipStreamSynchronize(ctx->stream));
     for (uint32_t f = 0; f < n_files; ++f) total[f] = back[f];
+    return SPSP_OK;
+}
+
+
+// the scan by segments (see k_seg_scan).  _count: queues the counting launch, the prefix over the tiles and the copies of the total and of
+// the number of chains that left their tile to h_scalar[0] / [1]; _emit (after the caller has waited and reserved `out`): the writing launch
+int seg_scan_count(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, bool packed, uint64_t n_bases, const uint64_t* d_rec_off, uint32_t n_rec) {
+    const uint64_t n_tiles = (n_bases + kSegIter - 1) / kSegIter;
+    if (n_tiles > 0x7ffffff0ull) { set_error("input too large for one call"); return SPSP_ERR_OVERFLOW; }
+    int rc;
+    if ((rc = ctx->st_count.reserve((size_t)(n_tiles + 1) * 4 * 2 + 64)) || (rc = ctx->st_over.reserve(64))) return rc;
+    uint32_t* d_cnt = ctx->st_count.as<uint32_t>();
+    uint32_t* d_off = d_cnt + n_tiles + 1;
+    uint32_t* d_over_n = ctx->st_over.as<uint32_t>();
+    SPSP_HIP(hipMemsetAsync(d_over_n, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(k_seg_scan<false>, dim3((uint32_t)n_tiles), dim3(kSegThreads), 0, ctx->stream, d_bases, packed, n_bases, d_rec_off, n_rec, p->k, p->m, p->threshold,
+                       d_cnt, (const uint32_t*)nullptr, (spsp_superkmer*)nullptr, 0ull, d_over_n);
+    SPSP_HIP(hipGetLastError());
+    if ((rc = launch_scan_u32(ctx, d_cnt, d_off, n_tiles, ctx->h_scalar + 0))) return rc;      // (the total to h_scalar[0])
+    SPSP_HIP(hipMemcpyAsync(ctx->h_scalar + 1, d_over_n, 4, hipMemcpyDeviceToHost, ctx->stream));
+    return SPSP_OK;
+}
+int seg_scan_emit(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, bool packed, uint64_t n_bases, const uint64_t* d_rec_off, uint32_t n_rec,
+                  spsp_superkmer* d_out, uint64_t out_cap) {
+    const uint64_t n_tiles = (n_bases + kSegIter - 1) / kSegIter;
+    uint32_t* d_cnt = ctx->st_count.as<uint32_t>();
+    uint32_t* d_off = d_cnt + n_tiles + 1;
+    hipLaunchKernelGGL(k_seg_scan<true>, dim3((uint32_t)n_tiles), dim3(kSegThreads), 0, ctx->stream, d_bases, packed, n_bases, d_rec_off, n_rec, p->k, p->m, p->threshold,
+                       d_cnt, (const uint32_t*)d_off, d_out, out_cap, ctx->st_over.as<uint32_t>());
+    SPSP_HIP(hipGetLastError());
     return SPSP_OK;
 }
 
