@@ -123,6 +123,22 @@ def test_scan_randomised_configs(ctx):
             raise AssertionError("config it=%d k=%d m=%d s=%g mode=%d n=%d: %s" % (it, k, m, s, mode, len(bases), e))
 
 
+def test_scan_by_segments_and_by_hits_agree_with_the_oracle():
+    """the scan by segments (spsp_stats.hip::k_seg_scan: what a threshold that selects nearly every m-mer takes, -s 1) pinned
+    for EVERY threshold (SPSP_DEBUG_SEG_SCAN=1: random configurations, the repeat library, low complexity -- chains that
+    leave their tile hand the call to the product scan) and switched off (=0: -s 1 through the dense + sparse passes, as
+    until round 5); each in a process of its own (the switch is read once)."""
+    import subprocess
+    import sys
+    for val, names in (("1", ("test_scan_randomised_configs", "test_scan_repeat_rich_genome", "test_scan_edge_inputs")),
+                       ("0", ("test_scan_every_mmer_selected_over_megabases",))):
+        code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\nimport supersampler_amd as sp, test_gpu\nctx = sp.Context(0)\n" % (ROOT, os.path.join(ROOT, "tests"))
+                + "".join("test_gpu.%s(ctx)\n" % n for n in names)
+                + "for mode in test_gpu.MODES: test_gpu.test_scan_select_all_and_low_complexity(ctx, mode)\nprint('ok')\n")
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, SPSP_DEBUG_SEG_SCAN=val), timeout=900)
+        assert r.returncode == 0 and "ok" in r.stdout, (val, r.stderr[-2000:])
+
+
 def test_scan_dense_selection_many_hits(ctx):
     """a dense selection over 3 Mbp: several hundred thousand hits and super-k-mers, so the write pass of the
     sparse stage sums more than 64 chunk totals and several 16-Ki-position tiles carry thousands of hits each"""
