@@ -1295,19 +1295,6 @@ int spsp_read_file_host(const char* path, uint8_t** data, uint64_t* len) {
     const bool packed = n >= 2 && ((raw[0] == 0x1F && raw[1] == 0x8B) ||
                                    (raw[0] == 0x78 && (raw[1] == 0x01 || raw[1] == 0x9C || raw[1] == 0xDA)));
     if (!packed) { *data = raw; *len = n; return SPSP_OK; }   // plain text passes through (zstr autodetect)
-    if (n >= 18 && raw[0] == 0x1F) {
-        // one member whose trailer tells the length: the one-go decoder (spsp_inflate.cpp); anything else is zlib's
-        static const bool fast_ok = getenv("SPSP_DEBUG_INFLATE") == nullptr || getenv("SPSP_DEBUG_INFLATE")[0] != 'z';
-        uint32_t isize; memcpy(&isize, raw + n - 4, 4);
-        if (fast_ok && (uint64_t)isize <= 1032ull * n + 64) {
-            uint8_t* q = (uint8_t*)malloc((size_t)isize + 64);
-            if (q && spsp::fast_gunzip_member(raw, (size_t)n, q, isize) == 0) { free(raw); *data = q; *len = isize; return SPSP_OK; }
-            free(q);
-            if (getenv("SPSP_DEBUG_INFLATE") && getenv("SPSP_DEBUG_INFLATE")[0] == 's') {      // "strict" (tests): no second opinion
-                free(raw); set_error("the one-go gunzip refused '%s'", path); return SPSP_ERR_IO;
-            }
-        }
-    }
     std::vector<uint8_t> plain;
     rc = inflate_all(raw, n, plain);
     free(raw);
@@ -1478,13 +1465,8 @@ static int compare_files_impl(spsp_ctx* ctx, const char* const* paths, uint32_t 
             uint8_t* raw = datas[i];
             if (block && !gz[i]) { if (want[i]) memcpy(block + at[i], raw, (size_t)want[i]); free(raw); datas[i] = block + at[i]; own[i] = 0; lens[i] = want[i]; return; }
             if (!gz[i]) { lens[i] = want[i]; return; }
-            static const bool fast_ok = getenv("SPSP_DEBUG_INFLATE") == nullptr || getenv("SPSP_DEBUG_INFLATE")[0] != 'z';   // "zlib": A/B, tests
-            if (block && fast_ok && spsp::fast_gunzip_member(raw, (size_t)raw_len[i], block + at[i], (size_t)want[i]) == 0) {
-                free(raw); datas[i] = block + at[i]; own[i] = 0; lens[i] = want[i];
-                return;
-            }
             if (block) {
-                // (zlib's inflate: what the one-go decoder did not take) straight into the block when the file is one member of the promised length
+                // straight into the block when the file is one member of the promised length
                 struct Inflator { z_stream zs; bool live = false; ~Inflator() { if (live) inflateEnd(&zs); } };
                 static thread_local Inflator I;
                 bool ok = true;

@@ -190,8 +190,6 @@ int scan_device_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases
 int scan_begin_impl(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, uint64_t n_bases,
                     const uint64_t* d_rec_off, uint32_t n_rec);
 int scan_end_impl(spsp_ctx* ctx, spsp_superkmer** d_out, uint64_t* n_out);
-// spsp_inflate.cpp: one gzip member of known payload length, in one go; 0 = done and CRC-checked, -1 = let zlib look at it (`in` readable to in + n + 8)
-int fast_gunzip_member(const uint8_t* in, size_t n, uint8_t* out, size_t out_len);
 int seg_scan_count(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, bool packed, uint64_t n_bases, const uint64_t* d_rec_off, uint32_t n_rec);
 int seg_scan_emit(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, bool packed, uint64_t n_bases, const uint64_t* d_rec_off, uint32_t n_rec,
                   spsp_superkmer* d_out, uint64_t out_cap);
