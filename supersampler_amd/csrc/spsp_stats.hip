@@ -30,6 +30,7 @@ struct StatMachine {
     // state
     uint64_t hash_min, position_min;
     uint32_t minimizer, old_minimizer, min_seq, min_rc;
+    uint32_t last_rev;    // strand of the minimizer the last rescan found
 
     __device__ __forceinline__ uint32_t code(uint64_t at) const {
         if (pk) { const uint64_t q = base + at; return (pk[q >> 4] >> (30u - 2u * (uint32_t)(q & 15u))) & 3u; }
@@ -65,7 +66,7 @@ struct StatMachine {
                 if (!is_rev && pos > off) pos = off;                     // :158-164
             }
         }
-        minimizer = mini; hash_min = hash_mini; *position = pos;
+        minimizer = mini; hash_min = hash_mini; *position = pos; last_rev = is_rev ? 1u : 0u;
     }
     // state in front of iteration i0 as a rescan of k-mer i0 leaves it (exact for i0 = 0: SubSampler.cpp:359-365)
     __device__ void start(uint64_t i0) {
@@ -217,7 +218,8 @@ __global__ __launch_bounds__(kStatThreads) void k_stat_fix(const uint8_t* __rest
 // which walks it with the literal machine.  Same totals as k_stat_count / k_stat_fix (SPSP_DEBUG_STATS=chunks keeps them).
 constexpr int kSegIter = 2048, kSegHalo = 1024, kSegThreads = 256;
 constexpr int kSegSpan = kSegIter + kSegHalo + 64;              // m-mers held: a window of the last halo iteration ends inside
-constexpr uint32_t kSegOverCap = 1u << 20;                     // chains handed on per call (beyond: the chunk kernels do the call)
+constexpr uint32_t kSegOverCap = 1u << 20;
+constexpr uint32_t kSegSlowMax = 16384;                    // iterations a lane walks alone behind its tile's halo (k_seg_scan) before the call is handed on                     // chains handed on per call (beyond: the chunk kernels do the call)
 
 // regular_minimizer_pos over LDS (see StatMachine::rescan): k-mer at tile place ks
 __device__ __forceinline__ uint32_t seg_rescan(const uint64_t* __restrict__ s_h, const uint32_t* __restrict__ s_c, uint32_t ks, uint32_t km) {
@@ -427,7 +429,7 @@ __global__ __launch_bounds__(kSegThreads) void k_seg_scan(const uint8_t* __restr
     __shared__ uint32_t s_c[kSegSpan];
     __shared__ uint32_t s_d[kSegSpan];
     __shared__ unsigned long long s_flag[(kSegIter + kSegHalo) / 64];
-    __shared__ uint16_t s_cnt[kSegIter];                        // selected super-k-mers opened by event j; then their first place in the tile (< 2^16: an event per iteration at most)
+    __shared__ uint32_t s_cnt[kSegIter];                        // selected super-k-mers opened by event j; then their first place in the tile
     __shared__ uint16_t s_ev[kSegIter];
     __shared__ uint32_t s_wave[kSegThreads / 64];
     const uint32_t t = threadIdx.x, lane = t & 63u, km = k - m, mask = (1u << (2 * m)) - 1u;
@@ -501,6 +503,7 @@ __global__ __launch_bounds__(kSegThreads) void k_seg_scan(const uint8_t* __restr
             uint32_t cnt = 0;
             uint64_t at = 0, r0 = 0;
             uint32_t rec = 0;
+            bool write_lookup_done = write;                        // (the record of place p: the writing pass looks it up for every event, the counting pass for chains that leave the halo)
             if (write) {
                 uint32_t hi = n_rec;
                 const uint64_t g = T0 + p;
@@ -518,25 +521,75 @@ __global__ __launch_bounds__(kSegThreads) void k_seg_scan(const uint8_t* __restr
                 const uint64_t end64 = (uint64_t)p + left;
                 const uint32_t end = end64 < LIMIT ? (uint32_t)end64 : LIMIT;
                 const uint32_t R = cur < end ? next_reset(cur, end) : end;
-                if (R == end && end64 > LIMIT) { if (!write) atomicAdd(over_n, 1u); continue; }   // the chain leaves the halo: the product scan takes the call
-                for (;;) {
-                    const bool more = P < R;
-                    const uint32_t close = more ? P : R;                 // the iteration that cuts the open super-k-mer (or the record's end)
-                    if (S.h <= threshold) {
-                        if (write && at < out_cap) {
-                            spsp_superkmer e;
-                            e.rec = rec; e.minimizer = S.mn; e.start = (T0 + cur) - r0; e.len = close + k - cur; e.rev = S.rev;
-                            out[at] = e;
-                        }
-                        ++at; ++cnt;
+                // the chain leaves the halo (no reset for 1 024 iterations and more: a homopolymer, a short-period repeat): its rescans
+                // inside the halo as below, then this lane goes on alone, iteration by iteration over the bases themselves
+                const bool unknown = R == end && end64 > LIMIT;
+                const uint32_t stop = unknown ? LIMIT : R;
+                if (unknown && !write_lookup_done) {
+                    uint32_t hi = n_rec;
+                    const uint64_t g = T0 + p;
+                    rec = 0;
+                    while (hi - rec > 1) { const uint32_t mid = (rec + hi) >> 1; if (rec_off[mid] <= g) rec = mid; else hi = mid; }
+                    r0 = rec_off[rec];
+                    write_lookup_done = true;
+                }
+                auto emit = [&](uint64_t start_rel, uint64_t len, uint32_t mn, uint32_t rev, uint64_t h) {
+                    if (h > threshold) return;
+                    if (write && at < out_cap) {
+                        spsp_superkmer e;
+                        e.rec = rec; e.minimizer = mn; e.start = start_rel; e.len = (uint32_t)len; e.rev = rev;
+                        out[at] = e;
                     }
+                    ++at; ++cnt;
+                };
+                for (;;) {
+                    const bool more = P < stop;
+                    if (!more && unknown) break;                         // (the open super-k-mer goes on behind the halo)
+                    const uint32_t close = more ? P : R;                 // the iteration that cuts the open super-k-mer (or the record's end)
+                    emit((T0 + cur) - r0, (uint64_t)close + k - cur, S.mn, S.rev, S.h);
                     if (!more) break;
                     S = seg_rescan_full(s_h, s_c, P + 1, km);
                     cur = P + 1;
                     P = P + 1 + S.pos;
                 }
+                if (unknown) {
+                    const uint64_t rec_len = rec_off[rec + 1] - r0, n_iter = rec_len - k;
+                    StatMachine M;
+                    M.bind(bases, packed, r0); M.len = rec_len; M.k = k; M.m = m; M.mask = mask;
+                    uint64_t i = (T0 + LIMIT) - r0;                      // the first iteration behind the halo
+                    uint64_t open = (T0 + cur) - r0;
+                    {
+                        uint32_t f = 0;
+                        for (uint32_t jj = 0; jj < m; ++jj) f = (f << 2) | M.code(i + km + jj);       // the m-mer that ends with base i + k - 1
+                        M.min_seq = f; M.min_rc = rc_mmer32(f, m);
+                    }
+                    M.minimizer = S.mn; M.hash_min = S.h; M.position_min = (T0 + P) - r0; M.old_minimizer = S.mn;
+                    uint32_t rev = S.rev;
+                    bool ended = false;
+                    for (uint32_t steps = 0; steps < kSegSlowMax; ++steps, ++i) {
+                        if (i >= n_iter) { emit(open, rec_len - open, M.minimizer, rev, M.hash_min); ended = true; break; }   // the record's last super-k-mer
+                        const uint32_t b = M.code(i + k);
+                        M.min_seq = ((M.min_seq << 2) | b) & mask;
+                        M.min_rc = (M.min_rc >> 2) | ((b ^ 2u) << (2 * m - 2));
+                        const uint32_t canon = M.min_seq < M.min_rc ? M.min_seq : M.min_rc;
+                        if (xxh64_u64(canon) < M.hash_min) {               // a reset: it cuts, and is its own tile's event from here on
+                            emit(open, i + k - open, M.minimizer, rev, M.hash_min);
+                            ended = true;
+                            break;
+                        }
+                        if (i >= M.position_min) {
+                            emit(open, i + k - open, M.minimizer, rev, M.hash_min);
+                            uint64_t pos;
+                            M.rescan(i + 1, &pos);
+                            M.position_min = pos + i + 1;
+                            rev = M.last_rev;
+                            open = i + 1;
+                        }
+                    }
+                    if (!ended && !write) atomicAdd(over_n, 1u);           // longer than that: the product scan takes the call
+                }
             }
-            if (!write) s_cnt[j] = (uint16_t)cnt;
+            if (!write) s_cnt[j] = cnt;
         }
     };
     walk(false);

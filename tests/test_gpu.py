@@ -123,6 +123,25 @@ def test_scan_randomised_configs(ctx):
             raise AssertionError("config it=%d k=%d m=%d s=%g mode=%d n=%d: %s" % (it, k, m, s, mode, len(bases), e))
 
 
+def test_scan_select_all_through_long_runs_without_a_reset(ctx):
+    """-s 1 by segments (k_seg_scan) where a chain of rescans leaves its tile's halo -- 1 024 iterations without an m-mer that
+    beats the window's minimum: the owning lane goes on alone over the bases.  Runs that end with a reset (random sequence
+    behind a homopolymer), with the record (a homopolymer record, a short-period tandem repeat), inside the halo (500), and one
+    longer than the lane walks (40 kb: the call goes to the dense + sparse passes); records that start inside such a run."""
+    rng = np.random.default_rng(909)
+    A = lambda c, n: np.full(n, ord(c), np.uint8)   # noqa: E731
+    recs = [np.concatenate([synth.random_genome(rng, 5000), A("G", 3000), synth.random_genome(rng, 5000)]),
+            A("A", 5000), np.tile(np.frombuffer(b"ACGGT", np.uint8), 2000),
+            np.concatenate([A("T", 500), synth.random_genome(rng, 3000), A("C", 1500), A("A", 1500)]),
+            synth.random_genome(rng, 30_000)]
+    long_run = recs + [np.concatenate([synth.random_genome(rng, 2000), A("C", 40_000), synth.random_genome(rng, 2000)])]
+    for group in (recs, long_run):
+        bases, offs = synth.concat_records(group)
+        for (k, m) in [(31, 11), (63, 15), (21, 11), (15, 15)]:
+            p = sp.make_params(k, m, 1.0)
+            _assert_stream_equal(ctx.scan(p, bases, offs), _oracle_stream(k, m, p.threshold, bases, offs))
+
+
 def test_scan_by_segments_and_by_hits_agree_with_the_oracle():
     """the scan by segments (spsp_stats.hip::k_seg_scan: what a threshold that selects nearly every m-mer takes, -s 1) pinned
     for EVERY threshold (SPSP_DEBUG_SEG_SCAN=1: random configurations, the repeat library, low complexity -- chains that
