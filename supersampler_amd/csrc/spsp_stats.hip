@@ -11,6 +11,7 @@
 // over a chunk of iterations from a fresh rescan a little in front of the chunk: once it has met such an event
 // before its chunk starts, everything it counts is exact.  Chunks that meet none (period-w repeats,
 // homopolymers) are counted again in a second pass, serially from the last exact point.
+#include <algorithm>
 #include <vector>
 
 #include "spsp_internal.h"
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(kStatThreads) void k_stat_fix(const uint8_t* __rest
 constexpr int kSegIter = 2048, kSegHalo = 1024, kSegThreads = 256;
 constexpr int kSegSpan = kSegIter + kSegHalo + 64;              // m-mers held: a window of the last halo iteration ends inside
 constexpr uint32_t kSegOverCap = 1u << 20;
-constexpr uint32_t kSegSlowMax = 16384;                    // iterations a lane walks alone behind its tile's halo (k_seg_scan) before the call is handed on                     // chains handed on per call (beyond: the chunk kernels do the call)
+constexpr uint32_t kSegSlowMax = 16384;                    // iterations ONE lane walks alone behind its tile's halo (k_seg_scan) at the most; all of a call's together: slow_budget                     // chains handed on per call (beyond: the chunk kernels do the call)
 
 // regular_minimizer_pos over LDS (see StatMachine::rescan): k-mer at tile place ks
 __device__ __forceinline__ uint32_t seg_rescan(const uint64_t* __restrict__ s_h, const uint32_t* __restrict__ s_c, uint32_t ks, uint32_t km) {
@@ -424,7 +425,7 @@ template <bool EMIT>
 __global__ __launch_bounds__(kSegThreads) void k_seg_scan(const uint8_t* __restrict__ bases, bool packed, uint64_t n_bases, const uint64_t* __restrict__ rec_off,
                                                          uint32_t n_rec, uint32_t k, uint32_t m, uint64_t threshold,
                                                          uint32_t* __restrict__ tile_count, const uint32_t* __restrict__ tile_off,
-                                                         spsp_superkmer* __restrict__ out, uint64_t out_cap, uint32_t* __restrict__ over_n) {
+                                                         spsp_superkmer* __restrict__ out, uint64_t out_cap, uint32_t* __restrict__ over_n, uint32_t slow_budget) {
     __shared__ uint64_t s_h[kSegSpan];
     __shared__ uint32_t s_c[kSegSpan];
     __shared__ uint32_t s_d[kSegSpan];
@@ -567,6 +568,9 @@ __global__ __launch_bounds__(kSegThreads) void k_seg_scan(const uint8_t* __restr
                     uint32_t rev = S.rev;
                     bool ended = false;
                     for (uint32_t steps = 0; steps < kSegSlowMax; ++steps, ++i) {
+                        // (what all such lanes of the call may walk together is bounded: ~3 us per iteration and pass, against 0.5 ns per
+                        // base for the dense + sparse passes -- counted by the counting launch, which decides for the call)
+                        if (!EMIT && (steps & 255u) == 0 && atomicAdd(over_n + 1, 256u) + 256u > slow_budget) break;
                         if (i >= n_iter) { emit(open, rec_len - open, M.minimizer, rev, M.hash_min); ended = true; break; }   // the record's last super-k-mer
                         const uint32_t b = M.code(i + k);
                         M.min_seq = ((M.min_seq << 2) | b) & mask;
@@ -721,8 +725,12 @@ int seg_scan_count(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, 
     uint32_t* d_off = d_cnt + n_tiles + 1;
     uint32_t* d_over_n = ctx->st_over.as<uint32_t>();
     SPSP_HIP(hipMemsetAsync(d_over_n, 0, 8, ctx->stream));
+    // iterations the lanes may walk alone behind their tiles' halos, all chains of the call together: as many as cost what the dense +
+    // sparse passes cost the call before they meet the run themselves (~10 us per iteration over the three walks against 0.5 ns per base;
+    // they are no faster on such a run: 100 Mbp with a homopolymer of 2 000 / 8 000 / 16 000 bases: 16 / 116 / 267 ms here, 60 / 145 / 241 there)
+    const uint32_t slow_budget = (uint32_t)std::min<uint64_t>(1u << 20, 512 + n_bases / 20000);
     hipLaunchKernelGGL(k_seg_scan<false>, dim3((uint32_t)n_tiles), dim3(kSegThreads), 0, ctx->stream, d_bases, packed, n_bases, d_rec_off, n_rec, p->k, p->m, p->threshold,
-                       d_cnt, (const uint32_t*)nullptr, (spsp_superkmer*)nullptr, 0ull, d_over_n);
+                       d_cnt, (const uint32_t*)nullptr, (spsp_superkmer*)nullptr, 0ull, d_over_n, slow_budget);
     SPSP_HIP(hipGetLastError());
     if ((rc = launch_scan_u32(ctx, d_cnt, d_off, n_tiles, ctx->h_scalar + 0))) return rc;      // (the total to h_scalar[0])
     SPSP_HIP(hipMemcpyAsync(ctx->h_scalar + 1, d_over_n, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -734,7 +742,7 @@ int seg_scan_emit(spsp_ctx* ctx, const spsp_params* p, const uint8_t* d_bases, b
     uint32_t* d_cnt = ctx->st_count.as<uint32_t>();
     uint32_t* d_off = d_cnt + n_tiles + 1;
     hipLaunchKernelGGL(k_seg_scan<true>, dim3((uint32_t)n_tiles), dim3(kSegThreads), 0, ctx->stream, d_bases, packed, n_bases, d_rec_off, n_rec, p->k, p->m, p->threshold,
-                       d_cnt, (const uint32_t*)d_off, d_out, out_cap, ctx->st_over.as<uint32_t>());
+                       d_cnt, (const uint32_t*)d_off, d_out, out_cap, ctx->st_over.as<uint32_t>(), 0u);
     SPSP_HIP(hipGetLastError());
     return SPSP_OK;
 }
