@@ -421,6 +421,38 @@ __device__ __forceinline__ SegState seg_rescan_full(const uint64_t* __restrict__
     return S;
 }
 
+// the same over a ring of the last 64 m-mers (index = m-mer place & 63): the lane that walks a chain behind its tile's halo
+__device__ __forceinline__ SegState seg_rescan_ring(const uint64_t* __restrict__ r_h, const uint32_t* __restrict__ r_c, uint64_t ks, uint32_t km) {
+    const uint32_t c0 = r_c[(ks + km) & 63u];
+    SegState S;
+    S.mn = c0 & 0x7fffffffu; S.rev = c0 >> 31; S.pos = S.rev ? 0u : km; S.h = r_h[(ks + km) & 63u];
+    // eight m-mers' words are requested together, then judged in order: the lane is alone in its wave here, and a rescan of one
+    // dependent LDS read after the other was most of an iteration's time
+    for (uint32_t i0 = 1; i0 <= km; i0 += 8) {
+        uint64_t hh[8];
+        uint32_t cc[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) {
+            const uint32_t i = i0 + u, idx = (uint32_t)((ks + km - (i <= km ? i : km)) & 63u);
+            hh[u] = r_h[idx]; cc[u] = r_c[idx];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) {
+            const uint32_t i = i0 + u;
+            if (i > km) break;
+            const uint32_t off = km - i;
+            const uint32_t canon = cc[u] & 0x7fffffffu, lrev = cc[u] >> 31;
+            if (S.h > hh[u]) { S.pos = off; S.mn = canon; S.rev = lrev; S.h = hh[u]; }
+            else if (canon == S.mn && lrev == S.rev) {
+                if (S.rev && S.pos > i) S.pos = i;
+                if (!S.rev && S.pos > off) S.pos = off;
+            }
+        }
+    }
+    return S;
+}
+constexpr uint32_t kSegRings = 2;                            // lanes of a workgroup that may walk behind the halo with a ring in LDS at a time
+
 template <bool EMIT>
 __global__ __launch_bounds__(kSegThreads) void k_seg_scan(const uint8_t* __restrict__ bases, bool packed, uint64_t n_bases, const uint64_t* __restrict__ rec_off,
                                                          uint32_t n_rec, uint32_t k, uint32_t m, uint64_t threshold,
@@ -431,6 +463,9 @@ __global__ __launch_bounds__(kSegThreads) void k_seg_scan(const uint8_t* __restr
     __shared__ uint32_t s_d[kSegSpan];
     __shared__ unsigned long long s_flag[(kSegIter + kSegHalo) / 64];
     __shared__ uint32_t s_cnt[kSegIter];                        // selected super-k-mers opened by event j; then their first place in the tile
+    __shared__ uint64_t s_ring_h[kSegRings][64];
+    __shared__ uint32_t s_ring_c[kSegRings][64];
+    __shared__ uint32_t s_ring_used[kSegRings];
     __shared__ uint16_t s_ev[kSegIter];
     __shared__ uint32_t s_wave[kSegThreads / 64];
     const uint32_t t = threadIdx.x, lane = t & 63u, km = k - m, mask = (1u << (2 * m)) - 1u;
@@ -470,6 +505,7 @@ __global__ __launch_bounds__(kSegThreads) void k_seg_scan(const uint8_t* __restr
         }
     }
     for (uint32_t x = t; x < (uint32_t)kSegIter; x += kSegThreads) s_cnt[x] = 0;
+    if (t < kSegRings) s_ring_used[t] = 0;
     __syncthreads();
     for (uint32_t q = 0; q < (uint32_t)(kSegIter + kSegHalo); q += kSegThreads) {
         const uint32_t p = q + t;
@@ -565,31 +601,63 @@ __global__ __launch_bounds__(kSegThreads) void k_seg_scan(const uint8_t* __restr
                         M.min_seq = f; M.min_rc = rc_mmer32(f, m);
                     }
                     M.minimizer = S.mn; M.hash_min = S.h; M.position_min = (T0 + P) - r0; M.old_minimizer = S.mn;
-                    uint32_t rev = S.rev;
+                    uint32_t rev = S.rev, ahead = 0;
                     bool ended = false;
+                    // a ring of the window's m-mers in LDS when one is free: an iteration is then ONE hash (the entering m-mer) and a rescan
+                    // k - m + 1 LDS reads, instead of k - m + 2 hashes.  (Measured: 116 -> 61 ms for 7 000 iterations in three walks -- ~2.6 us an
+                    // iteration and walk still: a lane alone in its wave pays four cycles an instruction like a full wave, and the ~500 instructions
+                    // of an iteration with a rescan are what is left.  The rescan by the WAVE -- a lane per m-mer of the window, the tie rules as
+                    // reductions -- is the form that would take it to ~0.3 us)
+                    int ring = -1;
+                    for (uint32_t q = 0; q < kSegRings && ring < 0; ++q) if (atomicCAS(&s_ring_used[q], 0u, 1u) == 0u) ring = (int)q;
+                    if (ring >= 0) {
+                        uint64_t* r_h = s_ring_h[ring];
+                        uint32_t* r_c = s_ring_c[ring];
+                        uint32_t f = 0;
+                        for (uint32_t jj = 0; jj + 1 < m; ++jj) f = (f << 2) | M.code(i + jj);
+                        for (uint64_t e = i; e <= i + km; ++e) {                 // the m-mers of k-mer i
+                            f = ((f << 2) | M.code(e + m - 1)) & mask;
+                            const uint32_t rc = rc_mmer32(f, m), canon = f < rc ? f : rc;
+                            r_h[e & 63u] = xxh64_u64(canon); r_c[e & 63u] = canon | (canon != f ? 0x80000000u : 0u);
+                        }
+                    }
                     for (uint32_t steps = 0; steps < kSegSlowMax; ++steps, ++i) {
                         // (what all such lanes of the call may walk together is bounded: ~3 us per iteration and pass, against 0.5 ns per
                         // base for the dense + sparse passes -- counted by the counting launch, which decides for the call)
                         if (!EMIT && (steps & 255u) == 0 && atomicAdd(over_n + 1, 256u) + 256u > slow_budget) break;
                         if (i >= n_iter) { emit(open, rec_len - open, M.minimizer, rev, M.hash_min); ended = true; break; }   // the record's last super-k-mer
-                        const uint32_t b = M.code(i + k);
+                        // the bases eight at a time (eight independent loads): one dependent global load per iteration was most of the 3 us
+                        if ((steps & 7u) == 0) {
+                            ahead = 0;
+#pragma unroll
+                            for (uint32_t jj = 0; jj < 8; ++jj) { const uint64_t q = i + k + jj; ahead |= (q < rec_len ? M.code(q) : 0u) << (2 * jj); }
+                        }
+                        const uint32_t b = (ahead >> (2 * (steps & 7u))) & 3u;
                         M.min_seq = ((M.min_seq << 2) | b) & mask;
                         M.min_rc = (M.min_rc >> 2) | ((b ^ 2u) << (2 * m - 2));
                         const uint32_t canon = M.min_seq < M.min_rc ? M.min_seq : M.min_rc;
-                        if (xxh64_u64(canon) < M.hash_min) {               // a reset: it cuts, and is its own tile's event from here on
+                        const uint64_t h_in = xxh64_u64(canon);
+                        if (ring >= 0) { const uint64_t e = i + km + 1; s_ring_h[ring][e & 63u] = h_in; s_ring_c[ring][e & 63u] = canon | (canon != M.min_seq ? 0x80000000u : 0u); }
+                        if (h_in < M.hash_min) {                            // a reset: it cuts, and is its own tile's event from here on
                             emit(open, i + k - open, M.minimizer, rev, M.hash_min);
                             ended = true;
                             break;
                         }
                         if (i >= M.position_min) {
                             emit(open, i + k - open, M.minimizer, rev, M.hash_min);
-                            uint64_t pos;
-                            M.rescan(i + 1, &pos);
-                            M.position_min = pos + i + 1;
-                            rev = M.last_rev;
+                            if (ring >= 0) {
+                                const SegState N = seg_rescan_ring(s_ring_h[ring], s_ring_c[ring], i + 1, km);
+                                M.minimizer = N.mn; M.hash_min = N.h; M.position_min = N.pos + i + 1; rev = N.rev;
+                            } else {
+                                uint64_t pos;
+                                M.rescan(i + 1, &pos);
+                                M.position_min = pos + i + 1;
+                                rev = M.last_rev;
+                            }
                             open = i + 1;
                         }
                     }
+                    if (ring >= 0) s_ring_used[ring] = 0;
                     if (!ended && !write) atomicAdd(over_n, 1u);           // longer than that: the product scan takes the call
                 }
             }
