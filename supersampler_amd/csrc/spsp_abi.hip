@@ -256,7 +256,7 @@ void spsp_destroy(spsp_ctx* c) {
     if (c->tail_stream) (void)hipStreamSynchronize(c->tail_stream);
     compare_job_drop(c);
     if (c->h_skoff) (void)hipHostFree(c->h_skoff);
-    free(c->h_read_block);
+    for (auto& g : c->h_read_regions) free(g.p);
     if (c->h_text) (void)hipHostFree(c->h_text);
     if (c->h_keys) (void)hipHostFree(c->h_keys);
     if (c->keys_done) (void)hipEventDestroy(c->keys_done);

@@ -363,26 +363,24 @@ int sketch_decode_device_impl(spsp_ctx* ctx, const uint8_t* const* payloads, con
         if ((rc = ctx->dc_text.reserve((size_t)T + 64)) || (rc = ctx->dc_walk.reserve((size_t)n * (8 + 8 + 4 + 16 + 8 + 8 + 1) + 256))) return rc;
         // one pinned-size staging buffer for everything that goes up: texts back to back, then lens
         // (malloc, not a vector: 30 MB of zeroed pages first touched by ONE thread were 10 ms; the gaps between sketches are never read)
-        // ... unless the caller's payloads already lie exactly so (spsp_compare_files reads its files into one block): then
-        // they go up from where they are
-        const uint8_t* laid_out = nullptr;
-        uint64_t laid_end = 0;
+        // ... unless the caller's payloads already lie so, in a few pieces (spsp_compare_files reads its files into a region per reader
+        // thread, each payload at the 16-byte-rounded end of the one before): then every piece goes up from where it is
+        struct Run { const uint8_t* host; uint64_t dev, bytes; };
+        std::vector<Run> runs;
         {
             static const bool allow = getenv("SPSP_DEBUG_DECODE_GATHER") == nullptr;
             bool ok = allow;
             for (uint32_t i = 0; i < n && ok; ++i) {
                 if (!lens[i]) continue;
-                if (!laid_out) laid_out = payloads[i] - text_off_dev[i];
-                ok = payloads[i] == laid_out + text_off_dev[i];
-                laid_end = text_off_dev[i] + lens[i];
+                if (!runs.empty() && payloads[i] == runs.back().host + (text_off_dev[i] - runs.back().dev)) runs.back().bytes = text_off_dev[i] + lens[i] - runs.back().dev;
+                else { runs.push_back(Run{payloads[i], text_off_dev[i], lens[i]}); ok = runs.size() <= 64; }
             }
-            if (!ok) laid_out = nullptr;
+            if (!ok) runs.clear();
         }
+        const bool laid_out = !runs.empty();
         struct Free { void operator()(uint8_t* q) const { free(q); } };
         std::unique_ptr<uint8_t, Free> text_buf(laid_out ? nullptr : (uint8_t*)malloc((size_t)T + 64));
         if (!laid_out && !text_buf) { set_error("out of host memory"); return SPSP_ERR_NOMEM; }
-        struct { const uint8_t* p; const uint8_t* data() const { return p; } } text_all{laid_out ? laid_out : text_buf.get()};
-        const uint64_t T_up = laid_out ? laid_end : T;          // (never past the caller's last byte)
         if (!laid_out) {
             unsigned workers = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
             if (T < (1u << 20)) workers = 1;
@@ -398,6 +396,7 @@ int sketch_decode_device_impl(spsp_ctx* ctx, const uint8_t* const* payloads, con
             for (unsigned w = 1; w < workers; ++w) pool.emplace_back(work);
             work();
             for (auto& th : pool) th.join();
+            runs.push_back(Run{text_buf.get(), 0, T});
         }
         const double tw0 = now_s();
         uint64_t* d_toff = ctx->dc_walk.as<uint64_t>();
@@ -409,7 +408,9 @@ int sketch_decode_device_impl(spsp_ctx* ctx, const uint8_t* const* payloads, con
         std::vector<uint32_t> extra((size_t)n, 0xffffffffu);
         bool any_extra = false;
         if (extra_has) for (uint32_t i = 0; i < n; ++i) if (extra_has[i]) { extra[i] = extra_mn[i]; any_extra = true; }
-        hipError_t e = T_up ? hipMemcpyAsync(ctx->dc_text.p, text_all.data(), (size_t)T_up, hipMemcpyHostToDevice, ctx->stream) : hipSuccess;
+        hipError_t e = hipSuccess;
+        for (const Run& r : runs)
+            if (e == hipSuccess && r.bytes) e = hipMemcpyAsync(ctx->dc_text.as<uint8_t>() + r.dev, r.host, (size_t)r.bytes, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(d_toff, text_off_dev.data(), (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(d_lens, lens, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess && any_extra) e = hipMemcpyAsync(d_extra, extra.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream);

@@ -1414,12 +1414,15 @@ static int compare_files_impl(spsp_ctx* ctx, const char* const* paths, uint32_t 
     std::vector<uint64_t> lens(n, 0);
     std::vector<int> rcs(n, SPSP_OK);
     std::vector<std::string> errs(n);
-    // Many sketches land in ONE block, each at the 16-byte-rounded end of the one before: the decoder sends exactly that
-    // layout to the device, and when it finds the payloads already laid out so it uploads them where they lie
-    // (spsp_decode.hip: 10^4 mallocs and a 40 MB gather gone).  datas[i] then points INTO the block (own[i] == 0).
-    uint8_t* block = nullptr;
+    // Many sketch files: every reader thread takes a RANGE of the files and lays their payloads down back to back (each at the
+    // 16-byte-rounded end of the one before) in a region of its own that the context keeps; the decoder finds payloads that lie
+    // as it would lay them out and uploads them from where they are, a copy per region (spsp_decode.hip).  One pass: open / read /
+    // close do not scale with threads on the hosts measured (10 000 files: 13 ms from one thread and from sixteen,
+    // tools/exp/open_scaling.sh), the inflating does -- so a file is inflated by the thread that read it while the others wait for
+    // the kernel (two passes, all reads then all inflates into one block by the trailers' lengths, were 13 + 12 ms).
+    // datas[i] then points INTO a region (own[i] == 0).
     std::vector<uint8_t> own(n, 1);
-    auto free_datas = [&]() { for (uint32_t i = 0; i < n; ++i) { if (own[i]) free(datas[i]); datas[i] = nullptr; } block = nullptr; };   // (the block stays with the context)
+    auto free_datas = [&]() { for (uint32_t i = 0; i < n; ++i) { if (own[i]) free(datas[i]); datas[i] = nullptr; } };   // (the regions stay with the context)
     unsigned workers = std::thread::hardware_concurrency();
     if (workers == 0) workers = 1;
     if (workers > 16) workers = 16;
@@ -1432,84 +1435,78 @@ static int compare_files_impl(spsp_ctx* ctx, const char* const* paths, uint32_t 
         work();
         for (auto& th : pool) th.join();
     };
-    // One file at a time per worker: no N open streams (Comparator.cpp:45-50); read + gunzip is independent work,
-    // spread over a few host threads.  Decoding (strDecompressor, inject_minimizer, the k-mer walks, sort, unique)
-    // happens for all sketches at once on the GPU (spsp_decode.hip).
-    static const bool one_block = getenv("SPSP_DEBUG_READ_BLOCK") == nullptr || getenv("SPSP_DEBUG_READ_BLOCK")[0] != '0';
-    if (n >= 256 && one_block) {
-        // pass 1: the bytes of every file as they are on disk; a gzip file of ONE member says in its trailer how long it gets
-        std::vector<uint64_t> raw_len(n, 0), want(n, 0);
-        std::vector<uint8_t> gz(n, 0);
-        on_threads([&](uint32_t i) {
-            rcs[i] = slurp(paths[i], &datas[i], &raw_len[i]);
-            if (rcs[i]) { errs[i] = spsp_last_error(); return; }
-            const uint8_t* r = datas[i];
-            const uint64_t len = raw_len[i];
-            if (len >= 18 && r[0] == 0x1F && r[1] == 0x8B) { uint32_t isize; memcpy(&isize, r + len - 4, 4); gz[i] = 1; want[i] = isize; }
-            else if (len >= 2 && r[0] == 0x78 && (r[1] == 0x01 || r[1] == 0x9C || r[1] == 0xDA)) {   // a zlib wrapper: no length up front
-                std::vector<uint8_t> plain;
-                uint8_t* q = nullptr;
-                rcs[i] = inflate_all(r, len, plain);
-                if (!rcs[i] && !(q = (uint8_t*)malloc(plain.size() + 64))) { set_error("out of host memory"); rcs[i] = SPSP_ERR_NOMEM; }
-                if (rcs[i]) { errs[i] = spsp_last_error(); return; }
-                if (!plain.empty()) memcpy(q, plain.data(), plain.size());
-                free(datas[i]); datas[i] = q; raw_len[i] = want[i] = plain.size();
-            } else want[i] = len;
-        });
-        std::vector<uint64_t> at((size_t)n + 1, 0);
-        for (uint32_t i = 0; i < n; ++i) at[i + 1] = at[i] + ((want[i] + 15) & ~15ull);
-        bool fits = at[n] < (64ull << 30);                       // (a forged trailer must not size a buffer)
-        for (uint32_t i = 0; i < n && fits; ++i) if (gz[i] && want[i] > 1032ull * raw_len[i] + 64) fits = false;   // deflate never expands more
-        if (fits) {
-            const size_t need = (size_t)at[n] + 64;
-            if (ctx->h_read_block_cap < need) {
-                free(ctx->h_read_block);
-                const size_t cap = (need + need / 4 + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
-                ctx->h_read_block = (uint8_t*)aligned_alloc(2u << 20, cap);
-                ctx->h_read_block_cap = ctx->h_read_block ? cap : 0;
-                if (ctx->h_read_block) (void)madvise(ctx->h_read_block, cap, MADV_HUGEPAGE);   // (a hint: 4 KiB pages if the host says no)
-            }
-            block = ctx->h_read_block;
-        }
-        const double t_pass1 = now_s();
-        // pass 2: every payload to its place
-        on_threads([&](uint32_t i) {
-            if (rcs[i]) return;
-            uint8_t* raw = datas[i];
-            if (block && !gz[i]) { if (want[i]) memcpy(block + at[i], raw, (size_t)want[i]); free(raw); datas[i] = block + at[i]; own[i] = 0; lens[i] = want[i]; return; }
-            if (!gz[i]) { lens[i] = want[i]; return; }
-            if (block) {
-                // straight into the block when the file is one member of the promised length
-                struct Inflator { z_stream zs; bool live = false; ~Inflator() { if (live) inflateEnd(&zs); } };
-                static thread_local Inflator I;
-                bool ok = true;
-                if (!I.live) { memset(&I.zs, 0, sizeof I.zs); ok = inflateInit2(&I.zs, 15 + 16) == Z_OK; I.live = ok; }
-                else ok = inflateReset2(&I.zs, 15 + 16) == Z_OK;
-                if (ok && raw_len[i] < (1ull << 31) && want[i] < (1ull << 31)) {
-                    uint8_t spill[8];
-                    I.zs.next_in = raw; I.zs.avail_in = (uInt)raw_len[i];
-                    I.zs.next_out = want[i] ? block + at[i] : spill; I.zs.avail_out = (uInt)want[i];
-                    int ret = inflate(&I.zs, Z_FINISH);
-                    if (ret == Z_BUF_ERROR && I.zs.avail_out == 0) {   // the output is full: the trailer is still to be read
-                        I.zs.next_out = spill; I.zs.avail_out = 0;
-                        ret = inflate(&I.zs, Z_FINISH);
+    // One file at a time per worker: no N open streams (Comparator.cpp:45-50).  Decoding (strDecompressor, inject_minimizer, the
+    // k-mer walks, sort, unique) happens for all sketches at once on the GPU (spsp_decode.hip).
+    static const bool regions_on = getenv("SPSP_DEBUG_READ_BLOCK") == nullptr || getenv("SPSP_DEBUG_READ_BLOCK")[0] != '0';
+    if (n >= 256 && regions_on) {
+        if (ctx->h_read_regions.size() < workers) ctx->h_read_regions.resize(workers);
+        std::vector<uint64_t> at(n, 0);                          // the payload's place in its thread's region
+        auto range = [&](unsigned w) {
+            spsp_ctx::ReadRegion& G = ctx->h_read_regions[w];
+            size_t used = 0;
+            auto room = [&](size_t more) -> bool {              // (grows by half: the places are offsets until the range is done)
+                if (used + more + 64 <= G.cap) return true;
+                size_t cap = std::max<size_t>(G.cap + G.cap / 2, used + more + 64);
+                cap = (cap + 0xfffffu) & ~(size_t)0xfffffu;
+                uint8_t* q = (uint8_t*)realloc(G.p, cap);
+                if (!q) return false;
+                G.p = q; G.cap = cap;
+                return true;
+            };
+            struct Inflator { z_stream zs; bool live = false; ~Inflator() { if (live) inflateEnd(&zs); } };
+            static thread_local Inflator I;
+            std::vector<uint8_t> plain;
+            const uint32_t i0 = (uint32_t)((uint64_t)n * w / workers), i1 = (uint32_t)((uint64_t)n * (w + 1) / workers);
+            for (uint32_t i = i0; i < i1; ++i) {
+                uint8_t* raw = nullptr; uint64_t raw_len = 0;
+                rcs[i] = slurp(paths[i], &raw, &raw_len);
+                if (rcs[i]) { errs[i] = spsp_last_error(); continue; }
+                const bool gz = raw_len >= 18 && raw[0] == 0x1F && raw[1] == 0x8B;
+                const bool zl = !gz && raw_len >= 2 && raw[0] == 0x78 && (raw[1] == 0x01 || raw[1] == 0x9C || raw[1] == 0xDA);
+                bool placed = false;
+                if (gz) {
+                    // one member whose trailer tells the length (a forged one must not size a buffer: deflate never expands 1032-fold):
+                    // inflated straight to its place
+                    uint32_t isize; memcpy(&isize, raw + raw_len - 4, 4);
+                    bool ok = (uint64_t)isize <= 1032ull * raw_len + 64 && raw_len < (1ull << 31) && room(isize);
+                    if (ok) {
+                        if (!I.live) { memset(&I.zs, 0, sizeof I.zs); ok = inflateInit2(&I.zs, 15 + 16) == Z_OK; I.live = ok; }
+                        else ok = inflateReset2(&I.zs, 15 + 16) == Z_OK;
                     }
-                    if (ret == Z_STREAM_END && I.zs.avail_in == 0 && I.zs.total_out == want[i]) {
-                        free(raw); datas[i] = block + at[i]; own[i] = 0; lens[i] = want[i];
-                        return;
+                    if (ok) {
+                        uint8_t spill[8];
+                        I.zs.next_in = raw; I.zs.avail_in = (uInt)raw_len;
+                        I.zs.next_out = isize ? G.p + used : spill; I.zs.avail_out = isize;
+                        int ret = inflate(&I.zs, Z_FINISH);
+                        if (ret == Z_BUF_ERROR && I.zs.avail_out == 0) {   // the output is full: the trailer is still to be read
+                            I.zs.next_out = spill; I.zs.avail_out = 0;
+                            ret = inflate(&I.zs, Z_FINISH);
+                        }
+                        if (ret == Z_STREAM_END && I.zs.avail_in == 0 && I.zs.total_out == isize) { at[i] = used; lens[i] = isize; placed = true; }
                     }
                 }
+                if (!placed) {
+                    // several members, a trailer that does not tell the truth, a zlib wrapper, a damaged file (the general reader and
+                    // its error text), or plain text: appended all the same
+                    const uint8_t* src = raw; uint64_t len = raw_len;
+                    if (gz || zl) {
+                        rcs[i] = inflate_all(raw, raw_len, plain);
+                        if (rcs[i]) { errs[i] = spsp_last_error(); free(raw); continue; }
+                        src = plain.data(); len = plain.size();
+                    }
+                    if (!room((size_t)len)) { set_error("out of host memory"); rcs[i] = SPSP_ERR_NOMEM; errs[i] = spsp_last_error(); free(raw); continue; }
+                    if (len) memcpy(G.p + used, src, (size_t)len);
+                    at[i] = used; lens[i] = len;
+                }
+                free(raw);
+                used = (size_t)((used + lens[i] + 15) & ~(uint64_t)15);
             }
-            // several members, a trailer that does not tell the truth, a damaged file: the general reader (and its error text)
-            std::vector<uint8_t> plain;
-            uint8_t* q = nullptr;
-            rcs[i] = inflate_all(raw, raw_len[i], plain);
-            if (!rcs[i] && !(q = (uint8_t*)malloc(plain.size() + 64))) { set_error("out of host memory"); rcs[i] = SPSP_ERR_NOMEM; }
-            if (rcs[i]) { errs[i] = spsp_last_error(); return; }
-            if (!plain.empty()) memcpy(q, plain.data(), plain.size());
-            free(raw); datas[i] = q; lens[i] = plain.size();
-        });
-        if (getenv("SPSP_DEBUG_DECODE_TIMES")) fprintf(stderr, "[load] files read %.4f s, payloads to their places %.4f s\n", t_pass1 - t0, now_s() - t_pass1);
+            for (uint32_t i = i0; i < i1; ++i) if (!rcs[i]) { datas[i] = G.p + at[i]; own[i] = 0; }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned w = 1; w < workers; ++w) pool.emplace_back(range, w);
+        range(0);
+        for (auto& th : pool) th.join();
     } else {
         on_threads([&](uint32_t i) {
             rcs[i] = spsp_read_file_host(paths[i], &datas[i], &lens[i]);

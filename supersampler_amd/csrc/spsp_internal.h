@@ -131,8 +131,8 @@ struct spsp_ctx {
     size_t h_text_cap = 0;
     uint64_t* h_skoff = nullptr;       // pinned staging for the sketch offsets of a queued comparison
     size_t h_skoff_cap = 0;
-    uint8_t* h_read_block = nullptr;   // spsp_compare_files: the payloads of all files, back to back (kept: 10^4 page faults and a 40 MB
-    size_t h_read_block_cap = 0;       // munmap per call otherwise); 2 MiB-aligned, huge pages asked for
+    struct ReadRegion { uint8_t* p = nullptr; size_t cap = 0; };
+    std::vector<ReadRegion> h_read_regions;   // spsp_compare_files: one per reader thread, the payloads of its files back to back (kept: page faults and munmaps per call otherwise)
     // scan workspace
     spsp::DevBuf bases, rec_off, bitmap, tile_count, tile_off, hits, emit_count, scan_tmp, d_scalar, seg_a, seg_b;
     spsp::DevBuf wave_hits, wave_cnt;    // per-wave hit lists of the table variants of the dense pass
