@@ -1040,17 +1040,34 @@ struct GzSink {                                // one gzip member: header, ONE f
     uint64_t acc = 0; int nbits = 0;
     uint32_t crc = 0; uint64_t isize = 0;
     static uint32_t rev(uint32_t v, int n) { uint32_t r = 0; for (int i = 0; i < n; ++i) r |= ((v >> i) & 1u) << (n - 1 - i); return r; }
-    void put(uint32_t v, int n) {               // n bits, least significant first
+    // the bit patterns of the fixed code, made once: a literal's (8 or 9 bits), and the match of 258 bytes at distance 2 (13 bits)
+    struct Codes {
+        uint16_t lit[256]; uint8_t lit_len[256]; uint32_t m258; int m258_len;
+        Codes() {
+            for (uint32_t b = 0; b < 256; ++b) { if (b < 144) { lit[b] = (uint16_t)rev(0x30u + b, 8); lit_len[b] = 8; } else { lit[b] = (uint16_t)rev(0x190u + (b - 144u), 9); lit_len[b] = 9; } }
+            m258 = rev(0xc0u + 5u, 8) | (rev(1u, 5) << 8); m258_len = 13;      // symbol 285 (no extra bits), distance code 1
+        }
+    };
+    static const Codes& codes() { static const Codes c; return c; }
+    void put(uint32_t v, int n) {               // n bits, least significant first (n <= 32, at most 7 bits pending: 39 fit)
         acc |= (uint64_t)v << nbits; nbits += n;
-        while (nbits >= 8) { out->push_back((uint8_t)acc); acc >>= 8; nbits -= 8; }
+        if (nbits >= 32) {                      // four bytes at a time
+            const size_t at = out->size();
+            out->resize(at + 4);
+            const uint32_t w = (uint32_t)acc;
+            memcpy(out->data() + at, &w, 4);
+            acc >>= 32; nbits -= 32;
+        }
     }
+    void flush_bytes() { while (nbits >= 8) { out->push_back((uint8_t)acc); acc >>= 8; nbits -= 8; } }
     void begin() {
         static const uint8_t hdr[10] = {0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3};
         out->insert(out->end(), hdr, hdr + 10);
         put(1, 1); put(1, 2);                   // BFINAL = 1, BTYPE = 01
     }
-    void literal(uint8_t b) { if (b < 144) put(rev(0x30u + b, 8), 8); else put(rev(0x190u + (b - 144u), 9), 9); }
+    void literal(uint8_t b) { const Codes& C = codes(); put(C.lit[b], C.lit_len[b]); }
     void match2(uint32_t len) {                 // `len` bytes (3 .. 258) copied from distance 2
+        if (len == 258) { const Codes& C = codes(); put(C.m258, C.m258_len); return; }
         static const uint16_t base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
         static const uint8_t extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
         int c = 28;
@@ -1074,7 +1091,8 @@ struct GzSink {                                // one gzip member: header, ONE f
     }
     void end() {
         put(0, 7);                              // end of block (symbol 256: seven zero bits)
-        if (nbits) put(0, 8 - nbits);
+        flush_bytes();
+        if (nbits) { put(0, 8 - nbits); flush_bytes(); }
         for (int i = 0; i < 4; ++i) out->push_back((uint8_t)(crc >> (8 * i)));
         for (int i = 0; i < 4; ++i) out->push_back((uint8_t)((uint32_t)isize >> (8 * i)));
     }
