@@ -174,22 +174,33 @@ template <bool HAS_HI>
 __global__ __launch_bounds__(kSortThreads) void k_decode_sort(uint32_t* __restrict__ r_mn, uint64_t* __restrict__ r_lo,
                                                              uint64_t* __restrict__ r_hi, const uint64_t* __restrict__ raw_off,
                                                              const uint32_t* __restrict__ raw_cnt, const uint8_t* __restrict__ presorted,
-                                                             const uint32_t* __restrict__ big, uint32_t* __restrict__ distinct, uint32_t force_network) {
+                                                             const uint32_t* __restrict__ big, uint32_t* __restrict__ distinct, uint32_t force_network,
+                                                             uint32_t cap_rt, uint32_t second) {
+    // cap_rt: keys the LDS arrays of THIS launch hold.  The first launch is sized for the largest sketch as it is (counting inside
+    // buckets needs no padding: 4 800 keys are 58 KB, two workgroups a CU, where the network's power of two was 96 KB and one);
+    // a sketch that needs the network and whose power of two does not fit marks itself (kNeedsNetwork) and is sorted by the
+    // second launch, which has the full arrays and passes every other sketch by.
+    constexpr uint32_t kNeedsNetwork = 0xffffffffu;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_s[];
     constexpr uint32_t CAP = HAS_HI ? kSortCapHi : kSortCapLo;
     uint64_t* s_lo = reinterpret_cast<uint64_t*>(lds_s);
-    uint64_t* s_hi = s_lo + CAP;                                   // (HAS_HI only)
-    uint32_t* s_mn = reinterpret_cast<uint32_t*>(s_hi + (HAS_HI ? CAP : 0));
+    uint64_t* s_hi = s_lo + cap_rt;                                // (HAS_HI only)
+    uint32_t* s_mn = reinterpret_cast<uint32_t*>(s_hi + (HAS_HI ? cap_rt : 0));
     __shared__ uint32_t wave_sum[kSortThreads / 64];
     const uint32_t s = blockIdx.x, t = threadIdx.x, lane = t & 63, wid = t >> 6;
     const uint32_t n = raw_cnt[s];
     const uint64_t r0 = raw_off[s];
-    if (presorted[s]) { if (t == 0) distinct[s] = n; return; }
-    if (big[s]) { if (t == 0) distinct[s] = 0; return; }           // beyond this workgroup's LDS: k_big_insert / k_big_emit count it
-    if (n == 0) { if (t == 0) distinct[s] = 0; return; }
+    if (second) { if (distinct[s] != kNeedsNetwork) return; force_network = 1; }
+    else {
+        if (presorted[s]) { if (t == 0) distinct[s] = n; return; }
+        if (big[s]) { if (t == 0) distinct[s] = 0; return; }       // beyond this workgroup's LDS: k_big_insert / k_big_emit count it
+        if (n == 0) { if (t == 0) distinct[s] = 0; return; }
+    }
     uint32_t n2 = 1;
     while (n2 < n) n2 <<= 1;
-    for (uint32_t i = t; i < n2; i += kSortThreads) {
+    if (force_network && n2 > cap_rt) { if (t == 0) distinct[s] = kNeedsNetwork; return; }    // (the first launch with the network pinned: test hook)
+    const uint32_t fill = n2 <= cap_rt ? n2 : n;                   // (the padding only where the network could run)
+    for (uint32_t i = t; i < fill; i += kSortThreads) {
         if (i < n) { s_mn[i] = r_mn[r0 + i]; s_lo[i] = r_lo[r0 + i]; if (HAS_HI) s_hi[i] = r_hi[r0 + i]; }
         else { s_mn[i] = 0xffffffffu; s_lo[i] = ~0ull; if (HAS_HI) s_hi[i] = ~0ull; }
     }
@@ -204,27 +215,27 @@ __global__ __launch_bounds__(kSortThreads) void k_decode_sort(uint32_t* __restri
     if (t == 0) s_slow = force_network;
     __syncthreads();
     if (!force_network) {
-        // a lane takes PERK CONSECUTIVE keys: mostly one bucket, whose bounds come from two binary searches over the (ascending)
-        // minimizers -- walking to the bucket's ends key by key was a chain of ~100 dependent LDS reads per key and slower
-        // than the network it replaces
+        // lane t takes keys t, t + 1024, ...: the lanes of a wave hold 64 NEIGHBOURING keys -- mostly one or two buckets, so they loop
+        // over the same bounds and read the same LDS words (a lane with eight consecutive keys made every wave wait for its longest
+        // bucket eight times over: the pass was bound by its compare loop, 53 us a workgroup whatever ran beside it).  A key's bucket
+        // bounds are two binary searches over the (ascending) minimizers.
         uint32_t my_rank[PERK];
         uint64_t my_lo[PERK], my_hi[PERK];
         bool slow = false;
-        uint32_t b0 = 0, b1 = 0, b_mn = 0;
-        bool have = false;
 #pragma unroll
         for (uint32_t u = 0; u < PERK; ++u) {
-            const uint32_t i = t * PERK + u;
+            const uint32_t i = t + u * kSortThreads;
             my_rank[u] = 0xffffffffu;
             if (i >= n) continue;
             const uint32_t mn = s_mn[i];
             if (i && s_mn[i - 1] > mn) slow = true;
-            if (!have || mn != b_mn) {
+            uint32_t b0, b1;
+            {
                 uint32_t lo_ = 0, hi_ = n;
                 while (lo_ < hi_) { const uint32_t mid = (lo_ + hi_) >> 1; if (s_mn[mid] < mn) lo_ = mid + 1; else hi_ = mid; }
                 b0 = lo_; hi_ = n;
                 while (lo_ < hi_) { const uint32_t mid = (lo_ + hi_) >> 1; if (s_mn[mid] <= mn) lo_ = mid + 1; else hi_ = mid; }
-                b1 = lo_; b_mn = mn; have = true;
+                b1 = lo_;
             }
             // (minimizers that do not ascend make the searches meaningless: the bounds are clamped around i so that the loop below
             // stays short and in range -- that sketch takes the network anyway)
@@ -248,6 +259,7 @@ __global__ __launch_bounds__(kSortThreads) void k_decode_sort(uint32_t* __restri
         }
         __syncthreads();
     }
+    if (s_slow && n2 > cap_rt) { if (t == 0) distinct[s] = kNeedsNetwork; return; }          // (the second launch's)
     if (s_slow) {
     auto greater = [&](uint32_t a, uint32_t b) {
         if (s_mn[a] != s_mn[b]) return s_mn[a] > s_mn[b];
@@ -630,7 +642,6 @@ int sketch_decode_device_impl(spsp_ctx* ctx, const uint8_t* const* payloads, con
                            ctx->dc_desc.as<DecDesc>(), (uint32_t)n_desc_all, k, m, ctx->dc_mn.as<uint32_t>(), ctx->dc_lo.as<uint64_t>(),
                            has_hi ? ctx->dc_hi.as<uint64_t>() : (uint64_t*)nullptr);
     }
-    const size_t lds = has_hi ? (size_t)kSortCapHi * 20 : (size_t)kSortCapLo * 12;
     if (!ctx->attr_sort_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_sort<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kSortCapHi * 20));
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_decode_sort<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kSortCapLo * 12));
@@ -638,10 +649,21 @@ int sketch_decode_device_impl(spsp_ctx* ctx, const uint8_t* const* payloads, con
     }
     static const char* dbg_sort = getenv("SPSP_DEBUG_DECODE_SORT");     // "network": every sketch through the bitonic network (A/B, tests)
     const uint32_t force_network = dbg_sort && dbg_sort[0] == 'n' ? 1u : 0u;
-    if (has_hi) hipLaunchKernelGGL(k_decode_sort<true>, dim3(n), dim3(kSortThreads), lds, ctx->stream, ctx->dc_mn.as<uint32_t>(), ctx->dc_lo.as<uint64_t>(),
-                                   ctx->dc_hi.as<uint64_t>(), d_raw_off, d_raw_cnt, d_presorted, d_big, d_distinct, force_network);
-    else hipLaunchKernelGGL(k_decode_sort<false>, dim3(n), dim3(kSortThreads), lds, ctx->stream, ctx->dc_mn.as<uint32_t>(), ctx->dc_lo.as<uint64_t>(),
-                            (uint64_t*)nullptr, d_raw_off, d_raw_cnt, d_presorted, d_big, d_distinct, force_network);
+    // the first launch's arrays hold the largest sketch it sorts, as it is (see the kernel); the second has them in full
+    const uint32_t cap_full = has_hi ? kSortCapHi : kSortCapLo;
+    uint32_t cap1 = 64;
+    for (uint32_t i = 0; i < n; ++i) if (!presorted[i] && !big[i] && raw_cnt[i] > cap1) cap1 = raw_cnt[i];
+    cap1 = std::min(cap_full, (cap1 + 63u) & ~63u);
+    if (force_network) cap1 = cap_full;
+    const size_t per_key = has_hi ? 20 : 12;
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1 && cap1 == cap_full) break;                  // (nothing could have been left for it)
+        const uint32_t cap_rt = pass == 0 ? cap1 : cap_full;
+        if (has_hi) hipLaunchKernelGGL(k_decode_sort<true>, dim3(n), dim3(kSortThreads), (size_t)cap_rt * per_key, ctx->stream, ctx->dc_mn.as<uint32_t>(), ctx->dc_lo.as<uint64_t>(),
+                                       ctx->dc_hi.as<uint64_t>(), d_raw_off, d_raw_cnt, d_presorted, d_big, d_distinct, force_network, cap_rt, (uint32_t)pass);
+        else hipLaunchKernelGGL(k_decode_sort<false>, dim3(n), dim3(kSortThreads), (size_t)cap_rt * per_key, ctx->stream, ctx->dc_mn.as<uint32_t>(), ctx->dc_lo.as<uint64_t>(),
+                                (uint64_t*)nullptr, d_raw_off, d_raw_cnt, d_presorted, d_big, d_distinct, force_network, cap_rt, (uint32_t)pass);
+    }
     // the sketches beyond the LDS sort: distinct keys through the table in HBM (no count rule here: the reader takes every
     // k-mer a sketch holds; no orientation bit: k_decode_emit writes canonical keys), sorted once they lie in place
     if (any_big && (rc = big_dedupe_launch(ctx, has_hi, ctx->dc_mn.as<uint32_t>(), ctx->dc_lo.as<uint64_t>(), has_hi ? ctx->dc_hi.as<uint64_t>() : nullptr,
