@@ -906,8 +906,8 @@ def test_compare_files_of_one_species_dense_matrix_as_cells(tmp_path):
 
 @pytest.mark.gpu
 def test_compare_files_read_into_one_block_whatever_the_container(tmp_path):
-    """spsp_compare_files from 256 files on reads every payload into ONE block (each at the 16-byte-rounded end of the one
-    before) and the decoder uploads them from where they lie.  300 sketch files in every container the reader knows -- gzip
+    """spsp_compare_files from 256 files on lays the payloads of every reader thread's range of files down back to back in a region
+    of its own (each at the 16-byte-rounded end of the one before) and the decoder uploads them from where they lie, a copy per region.  300 sketch files in every container the reader knows -- gzip
     of one member, gzip of two members (the trailer's length is then not the payload's: that file takes the general reader
     and the decoder gathers), a zlib wrapper, plain text, an empty sketch (header only) -- as ONE kind each and mixed, in one
     context and over two, against the oracle's CSV bytes; a truncated gzip file is the reader's error, not a wrong matrix."""
