@@ -217,7 +217,7 @@ __global__ __launch_bounds__(kStatThreads) void k_stat_fix(const uint8_t* __rest
 // A tile is kSegIter iterations (plus a halo the chains may run into); a lane owns the resets and record starts of its
 // iterations.  A chain that leaves the halo (a long repeat: no reset for thousands of positions) is handed to k_seg_tail,
 // which walks it with the literal machine.  Same totals as k_stat_count / k_stat_fix (SPSP_DEBUG_STATS=chunks keeps them).
-constexpr int kSegIter = 2048, kSegHalo = 1024, kSegThreads = 256;
+constexpr int kSegIter = 2048, kSegHalo = 1024, kSegThreads = 512;
 constexpr int kSegSpan = kSegIter + kSegHalo + 64;              // m-mers held: a window of the last halo iteration ends inside
 constexpr uint32_t kSegOverCap = 1u << 20;
 constexpr uint32_t kSegSlowMax = 16384;                    // iterations ONE lane walks alone behind its tile's halo (k_seg_scan) at the most; all of a call's together: slow_budget                     // chains handed on per call (beyond: the chunk kernels do the call)
